@@ -1,0 +1,126 @@
+/*
+ * snake_hip.h — C ABI of the MI355X (gfx950) implementation of Snake-SLAM's
+ * per-frame feature pipeline and local bundle adjustment.
+ *
+ * Every entry point replaces one seam of the reference (darglein/Snake-SLAM);
+ * the seam is cited as `path:line` relative to the reference checkout.  The
+ * reference has no FFI layer: its seams are C++ member calls into the (absent)
+ * saiga submodule, so a C++ adaptor on the Snake side converts std::vector /
+ * Eigen to the plain pointers used here (see INTEGRATION.md and
+ * snake_slam_amd/cpp/snake_hip.hpp).
+ *
+ * Conventions
+ *  - all functions return an snk_status (0 = ok); nothing aborts or throws;
+ *  - "host" entry points take host pointers, are synchronous, and copy through
+ *    buffers owned by the handle (the reference's call shape);
+ *  - "_dev" entry points take device pointers, enqueue on the handle's stream and
+ *    return without synchronising (batched throughput path; inputs resident in HBM);
+ *  - a handle is used by one thread at a time; different handles are independent
+ *    (reference threading: FeatureDetection || Preprocess || Tracking || LBA);
+ *  - a descriptor is 256 bits = 4 x uint64_t, little-endian bit order: bit b of the
+ *    descriptor is bit (b & 63) of word (b >> 6).
+ */
+#ifndef SNAKE_HIP_H
+#define SNAKE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNK_API __attribute__((visibility("default")))
+
+typedef enum snk_status
+{
+    SNK_OK                = 0,
+    SNK_ERR_INVALID_ARG   = 1,
+    SNK_ERR_NO_DEVICE     = 2, /* no HIP device / HIP runtime failure at create */
+    SNK_ERR_HIP           = 3, /* a HIP call failed; see snk_last_error() */
+    SNK_ERR_CAPACITY      = 4, /* caller-provided capacity too small */
+    SNK_ERR_NOT_CONFIGURED = 5
+} snk_status;
+
+/* "infinite" Hamming distance: the Snake side initialises its running minima with 256
+ * (Snake/Tracking/SnakeORBMatcher.cpp:121,280,462) and an absent neighbour is reported so. */
+#define SNK_DIST_INF 256
+
+SNK_API const char* snk_last_error(void);  /* thread-local text of the last failure */
+SNK_API const char* snk_version(void);
+SNK_API int snk_device_count(void);        /* number of visible HIP devices (0 = none) */
+
+/* ------------------------------------------------------------------------------------------
+ * Descriptor matching
+ * ------------------------------------------------------------------------------------------ */
+
+/* A rectified / undistorted keypoint as the matchers consume it.  Mirrors the fields of
+ * Saiga::KeyPoint<double> that Snake reads: .point, .angle (degrees, float), .octave
+ * (Snake/Preprocess/Preprocess.cpp:129-130,214-215; Snake/Map/Features.cpp:24,44). */
+typedef struct snk_kp64
+{
+    double x, y;
+    float angle;
+    int32_t octave;
+} snk_kp64;
+
+/* kNN-2 result for one query descriptor: {idx1, dist1, idx2, dist2}; idx = -1 / dist =
+ * SNK_DIST_INF when the train set has fewer than 1 / 2 entries. */
+typedef struct snk_knn2
+{
+    int32_t idx1, dist1, idx2, dist2;
+} snk_knn2;
+
+typedef struct snk_matcher snk_matcher;
+
+/* device: HIP device ordinal.  stream: a hipStream_t to enqueue on, or NULL for a stream
+ * owned by the handle. */
+SNK_API int snk_matcher_create(int device, void* stream, snk_matcher** out);
+SNK_API int snk_matcher_destroy(snk_matcher* m);
+SNK_API int snk_matcher_sync(snk_matcher* m); /* hipStreamSynchronize on the handle's stream */
+
+/* Replaces Saiga::BruteForceMatcher<DescriptorORB>::matchKnn2 / matchKnn2_omp —
+ * call site Snake/Tracking/TrackingCoarse.cpp:350-351 (also LoopClosing/LoopORBMatcher.cpp:103-105,
+ * Tracking/Initialization/MonoInitializer.cpp:589-592).  For every query the two nearest train
+ * descriptors by Hamming distance, ties resolved towards the lower train index. */
+SNK_API int snk_bf_knn2(snk_matcher* m, const uint64_t (*query)[4], int nq, const uint64_t (*train)[4], int nt,
+                        snk_knn2* out /* nq */);
+
+/* Replaces BruteForceMatcher::filterMatches(threshold, ratio) + the public `matches` vector —
+ * Snake/Tracking/TrackingCoarse.cpp:352,373-387.  Keeps (query, idx1) when dist1 <= threshold and
+ * dist1 <= ratio * dist2 (float compare), in ascending query order.  pairs has room for nq entries. */
+SNK_API int snk_bf_filter(snk_matcher* m, const snk_knn2* knn, int nq, int threshold, float ratio,
+                          int32_t (*pairs)[2], int* n_pairs);
+
+/* Batched, device-resident forms.  Layout: batch b owns rows [b*cap, b*cap + n[b]) of each array;
+ * counts live on the device (they are produced there by the extractor).  n_pairs_dev[b] receives
+ * the number of pairs of batch b. */
+SNK_API int snk_bf_knn2_batch_dev(snk_matcher* m, const uint64_t* query_dev, const int32_t* nq_dev, int nq_cap,
+                                  const uint64_t* train_dev, const int32_t* nt_dev, int nt_cap, int batch,
+                                  snk_knn2* out_dev);
+SNK_API int snk_bf_filter_batch_dev(snk_matcher* m, const snk_knn2* knn_dev, const int32_t* nq_dev, int nq_cap,
+                                    int batch, int threshold, float ratio, int32_t* pairs_dev /* [batch][nq_cap][2] */,
+                                    int32_t* n_pairs_dev);
+
+/* Replaces Snake::Preprocess::StereoMatching(Frame&) — Snake/Preprocess/Preprocess.cpp:122-242
+ * (declared Snake/Preprocess/Preprocess.h:33).  left / right are the RECTIFIED keypoints
+ * (rect_left.Forward / rect_right.Forward already applied, Preprocess.cpp:140-150); left is in
+ * feature-grid order, right in extractor order (Preprocess.cpp:41-49).  level_scale[o] =
+ * scalePyramid.Scale(o) (float), n_levels entries.  bf = rect_left.bf.  relaxed =
+ * settings.fd_relaxed_stereo.  right_points / depth are in/out (pre-filled with -1000 by
+ * Frame::allocateTmp, Snake/Map/Frame.cpp:25-26); only matched entries are overwritten.
+ * *n_matches receives the return value of StereoMatching. */
+SNK_API int snk_stereo_match(snk_matcher* m, const snk_kp64* left, const uint64_t (*desc_left)[4], int nl,
+                             const snk_kp64* right, const uint64_t (*desc_right)[4], int nr, double bf,
+                             const float* level_scale, int n_levels, int relaxed, float* right_points, float* depth,
+                             int* n_matches);
+
+SNK_API int snk_stereo_match_batch_dev(snk_matcher* m, const snk_kp64* left_dev, const uint64_t* desc_left_dev,
+                                       const int32_t* nl_dev, int nl_cap, const snk_kp64* right_dev,
+                                       const uint64_t* desc_right_dev, const int32_t* nr_dev, int nr_cap, int batch,
+                                       double bf, const float* level_scale_host, int n_levels, int relaxed,
+                                       float* right_points_dev, float* depth_dev, int32_t* n_matches_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNAKE_HIP_H */

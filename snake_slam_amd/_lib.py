@@ -1,0 +1,73 @@
+"""ctypes binding of ``libsnake_hip.so`` (the C ABI declared in ``include/snake_hip.h``).
+
+There is no CPU fallback: if the library is missing or does not load, importing the product
+API raises.  Tests and the bench call the kernels only through this binding.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "lib" / "libsnake_hip.so"
+
+
+class SnakeHipError(RuntimeError):
+    pass
+
+
+class Knn2(C.Structure):
+    _fields_ = [("idx1", C.c_int32), ("dist1", C.c_int32), ("idx2", C.c_int32), ("dist2", C.c_int32)]
+
+
+class Kp64(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("angle", C.c_float), ("octave", C.c_int32)]
+
+
+_lib = None
+
+vp = C.c_void_p
+i32 = C.c_int
+f32 = C.c_float
+f64 = C.c_double
+
+# name -> (restype, argtypes).  Kept in one table so tests can check it against the header.
+SIGNATURES = {
+    "snk_last_error": (C.c_char_p, []),
+    "snk_version": (C.c_char_p, []),
+    "snk_device_count": (i32, []),
+    "snk_matcher_create": (i32, [i32, vp, C.POINTER(vp)]),
+    "snk_matcher_destroy": (i32, [vp]),
+    "snk_matcher_sync": (i32, [vp]),
+    "snk_bf_knn2": (i32, [vp, vp, i32, vp, i32, vp]),
+    "snk_bf_filter": (i32, [vp, vp, i32, i32, f32, vp, C.POINTER(i32)]),
+    "snk_bf_knn2_batch_dev": (i32, [vp, vp, vp, i32, vp, vp, i32, i32, vp]),
+    "snk_bf_filter_batch_dev": (i32, [vp, vp, vp, i32, i32, i32, f32, vp, vp]),
+    "snk_stereo_match": (i32, [vp, vp, vp, i32, vp, vp, i32, f64, vp, i32, i32, vp, vp, C.POINTER(i32)]),
+    "snk_stereo_match_batch_dev": (i32, [vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, f64, vp, i32, i32, vp, vp, vp]),
+}
+
+
+def load() -> C.CDLL:
+    """Load the C-ABI library; raise loudly when it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise SnakeHipError(
+            f"{LIB_PATH} not found: build it with `python -m snake_slam_amd.build` "
+            "(or __graft_entry__.build()).  There is no CPU fallback."
+        )
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().snk_last_error().decode(errors="replace")
+        raise SnakeHipError(f"{what} failed with status {rc}: {msg}")

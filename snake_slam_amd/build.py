@@ -1,0 +1,72 @@
+"""In-tree build of the gfx950 C-ABI library (hipcc cross-compiles without a GPU).
+
+`build_library()` compiles every ``csrc/*.hip`` to an object and links
+``snake_slam_amd/lib/libsnake_hip.so``; objects are rebuilt only when a source or header is
+newer.  No CUDA / multi-backend switches: the only target is gfx950.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+CSRC = PKG / "csrc"
+LIBDIR = PKG / "lib"
+LIB = LIBDIR / "libsnake_hip.so"
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -ffp-contract=off: float results must be bit-identical between the kernels and the CPU oracle,
+# so no silent FMA contraction anywhere (explicit fma() only where the algorithm says so).
+HIP_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
+    "-fno-fast-math", "-Wall", "-Wno-unused-function", f"-I{ROOT / 'include'}", f"-I{CSRC}",
+]
+
+
+def _newer(target: Path, deps) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(map(str, cmd)) + "\n" + r.stdout + r.stderr)
+        raise RuntimeError(f"build step failed: {cmd[0]} ... {cmd[-1]}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> Path:
+    srcs = sorted(CSRC.glob("*.hip"))
+    hdrs = sorted(CSRC.glob("*.hpp")) + sorted((ROOT / "include").glob("*.h"))
+    objdir = CSRC / "build"
+    objdir.mkdir(exist_ok=True)
+    LIBDIR.mkdir(exist_ok=True)
+    jobs = []
+    objs = []
+    for s in srcs:
+        o = objdir / (s.stem + ".o")
+        objs.append(o)
+        if force or _newer(o, [s] + hdrs):
+            jobs.append([HIPCC, *HIP_FLAGS, "-c", str(s), "-o", str(o)])
+    if jobs:
+        if verbose:
+            print(f"[build] compiling {len(jobs)} HIP source(s) for gfx950", flush=True)
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(_run, jobs))
+    if force or jobs or _newer(LIB, objs):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(LIB)])
+        if verbose:
+            print(f"[build] linked {LIB}", flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv, verbose=True)

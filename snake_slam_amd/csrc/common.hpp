@@ -1,0 +1,91 @@
+// Shared host-side plumbing for the C-ABI library: error reporting, handle base, grow-only
+// device scratch.  gfx950 only; no CUDA paths.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "snake_hip.h"
+
+namespace snk
+{
+void set_error(const char* fmt, ...);
+
+#define SNK_HIP_CHECK(expr)                                                                      \
+    do                                                                                           \
+    {                                                                                            \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+        {                                                                                        \
+            ::snk::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return SNK_ERR_HIP;                                                                  \
+        }                                                                                        \
+    } while (0)
+
+#define SNK_REQUIRE(cond, msg)                        \
+    do                                                \
+    {                                                 \
+        if (!(cond))                                  \
+        {                                             \
+            ::snk::set_error("invalid argument: %s", msg); \
+            return SNK_ERR_INVALID_ARG;               \
+        }                                             \
+    } while (0)
+
+#define SNK_LAUNCH_CHECK()                                                                          \
+    do                                                                                              \
+    {                                                                                               \
+        hipError_t _e = hipGetLastError();                                                          \
+        if (_e != hipSuccess)                                                                       \
+        {                                                                                           \
+            ::snk::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return SNK_ERR_HIP;                                                                     \
+        }                                                                                           \
+    } while (0)
+
+// Grow-only device buffer.
+struct DevBuf
+{
+    void* p      = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t n)
+    {
+        if (n <= bytes) return SNK_OK;
+        if (p) (void)hipFree(p);
+        p     = nullptr;
+        bytes = 0;
+        size_t want = n + n / 4 + 256;
+        SNK_HIP_CHECK(hipMalloc(&p, want));
+        bytes = want;
+        return SNK_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p     = nullptr;
+        bytes = 0;
+    }
+    template <typename T>
+    T* as() const
+    {
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+struct HandleBase
+{
+    int device          = 0;
+    hipStream_t stream  = nullptr;
+    bool own_stream     = false;
+    int init(int dev, void* user_stream);
+    void fini();
+};
+
+inline int ceil_div(int a, int b)
+{
+    return (a + b - 1) / b;
+}
+}  // namespace snk

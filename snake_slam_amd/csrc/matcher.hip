@@ -1,0 +1,478 @@
+// 256-bit Hamming matchers for gfx950: brute-force kNN-2 (+ ratio filter) and the epipolar
+// row-band stereo matcher of Snake::Preprocess.
+//
+// Mapping to the hardware: one 64-lane wavefront owns QW query descriptors (held in registers,
+// wave-uniform) and its lanes stride over the train set with coalesced 32-byte-per-lane loads
+// (served by L1/L2: a 1000-descriptor train set is 32 KB).  Each lane keeps the two smallest
+// packed keys (distance << 20 | index) per query; the wavefront then merges them with a
+// 6-step xor-shuffle network.  Packing the index below the distance makes the reduction a plain
+// unsigned min, and reproduces the sequential scan's "strict <, first index wins" tie-break
+// exactly (the two lexicographically smallest (dist, idx) pairs).
+#include "common.hpp"
+
+namespace snk
+{
+namespace
+{
+using u32 = unsigned int;
+using u64 = unsigned long long;
+
+constexpr u32 BF_IDX_BITS = 20;
+constexpr u32 BF_IDX_MASK = (1u << BF_IDX_BITS) - 1u;
+constexpr u32 BF_INF_KEY  = ((u32)SNK_DIST_INF << BF_IDX_BITS) | BF_IDX_MASK;
+
+__device__ __forceinline__ int hamming256(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1)
+{
+    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+           __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// keep the two smallest of {k1 <= k2} U {o1 <= o2}
+template <typename K>
+__device__ __forceinline__ void merge2(K& k1, K& k2, K o1, K o2)
+{
+    K lo = k1 < o1 ? k1 : o1;
+    K hi = k1 < o1 ? o1 : k1;
+    K m  = k2 < o2 ? k2 : o2;
+    k2   = hi < m ? hi : m;
+    k1   = lo;
+}
+
+template <typename K>
+__device__ __forceinline__ void insert2(K& k1, K& k2, K key)
+{
+    K hi = k1 < key ? key : k1;
+    k1   = k1 < key ? k1 : key;
+    k2   = k2 < hi ? k2 : hi;
+}
+
+template <int QW>
+__global__ __launch_bounds__(256) void bf_knn2_kernel(const uint4* __restrict__ query, const int* __restrict__ nq_dev,
+                                                      int nq_cap, int nq_host, const uint4* __restrict__ train,
+                                                      const int* __restrict__ nt_dev, int nt_cap, int nt_host,
+                                                      snk_knn2* __restrict__ out)
+{
+    const int b    = blockIdx.y;
+    int nq         = nq_dev ? nq_dev[b] : nq_host;
+    int nt         = nt_dev ? nt_dev[b] : nt_host;
+    nq             = nq < nq_cap ? nq : nq_cap;
+    nt             = nt < nt_cap ? nt : nt_cap;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int q0   = (blockIdx.x * 4 + wave) * QW;
+    if (q0 >= nq) return;
+
+    const uint4* qb = query + (size_t)b * nq_cap * 2;
+    const uint4* tb = train + (size_t)b * nt_cap * 2;
+
+    uint4 qa[QW], qc[QW];
+    u32 k1[QW], k2[QW];
+#pragma unroll
+    for (int k = 0; k < QW; ++k)
+    {
+        int qi = q0 + k < nq ? q0 + k : nq - 1;
+        qa[k]  = qb[(size_t)qi * 2];
+        qc[k]  = qb[(size_t)qi * 2 + 1];
+        k1[k]  = BF_INF_KEY;
+        k2[k]  = BF_INF_KEY;
+    }
+
+    for (int j = lane; j < nt; j += 64)
+    {
+        const uint4 ta = tb[(size_t)j * 2];
+        const uint4 tc = tb[(size_t)j * 2 + 1];
+#pragma unroll
+        for (int k = 0; k < QW; ++k)
+        {
+            u32 d   = (u32)hamming256(qa[k], qc[k], ta, tc);
+            u32 key = (d << BF_IDX_BITS) | (u32)j;
+            insert2(k1[k], k2[k], key);
+        }
+    }
+
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+    {
+#pragma unroll
+        for (int k = 0; k < QW; ++k)
+        {
+            u32 o1 = __shfl_xor(k1[k], off);
+            u32 o2 = __shfl_xor(k2[k], off);
+            merge2(k1[k], k2[k], o1, o2);
+        }
+    }
+
+    if (lane == 0)
+    {
+#pragma unroll
+        for (int k = 0; k < QW; ++k)
+        {
+            if (q0 + k < nq)
+            {
+                snk_knn2 r;
+                r.dist1 = (int)(k1[k] >> BF_IDX_BITS);
+                r.idx1  = (k1[k] & BF_IDX_MASK) == BF_IDX_MASK ? -1 : (int)(k1[k] & BF_IDX_MASK);
+                r.dist2 = (int)(k2[k] >> BF_IDX_BITS);
+                r.idx2  = (k2[k] & BF_IDX_MASK) == BF_IDX_MASK ? -1 : (int)(k2[k] & BF_IDX_MASK);
+                out[(size_t)b * nq_cap + q0 + k] = r;
+            }
+        }
+    }
+}
+
+// Order-preserving compaction of the accepted (query, train) pairs; one workgroup per batch entry.
+__global__ __launch_bounds__(256) void bf_filter_kernel(const snk_knn2* __restrict__ knn, const int* __restrict__ nq_dev,
+                                                        int nq_cap, int nq_host, int threshold, float ratio,
+                                                        int2* __restrict__ pairs, int* __restrict__ n_pairs)
+{
+    __shared__ int wave_cnt[4];
+    __shared__ int base_s;
+    const int b    = blockIdx.x;
+    int nq         = nq_dev ? nq_dev[b] : nq_host;
+    nq             = nq < nq_cap ? nq : nq_cap;
+    const int tid  = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int start = 0; start < nq; start += 256)
+    {
+        const int i = start + tid;
+        bool keep   = false;
+        snk_knn2 k  = {};
+        if (i < nq)
+        {
+            k    = knn[(size_t)b * nq_cap + i];
+            keep = k.idx1 >= 0 && k.dist1 <= threshold && (float)k.dist1 <= ratio * (float)k.dist2;
+        }
+        const u64 mask   = __ballot(keep);
+        const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = __popcll(mask);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (keep) pairs[(size_t)b * nq_cap + off + prefix] = make_int2(i, k.idx1);
+        __syncthreads();
+        if (tid == 0) base_s += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    if (tid == 0) n_pairs[b] = base_s;
+}
+
+struct LevelScales
+{
+    float s[32];
+    int n;
+};
+
+__device__ __forceinline__ int iround_d(double x)
+{
+    return (int)floor(x + 0.5);
+}
+
+constexpr u64 ST_INF_KEY = (250ull << 40) | 0xFFFFFFFFFFull;
+
+// Snake::Preprocess::StereoMatching (reference Snake/Preprocess/Preprocess.cpp:161-240) with one
+// wavefront per left keypoint.  The reference walks row buckets y-r..y+r in ascending row, each in
+// index order, with strict '<'; that scan picks the lexicographic minimum of (dist, row, idx), so
+// the lanes evaluate the gates for every right keypoint and min-reduce that packed key instead of
+// building row buckets.
+__global__ __launch_bounds__(256) void stereo_kernel(const snk_kp64* __restrict__ left, const uint4* __restrict__ dl,
+                                                     const int* __restrict__ nl_dev, int nl_cap, int nl_host,
+                                                     const snk_kp64* __restrict__ right, const uint4* __restrict__ dr,
+                                                     const int* __restrict__ nr_dev, int nr_cap, int nr_host, double bf,
+                                                     LevelScales ls, int relaxed, float* __restrict__ right_points,
+                                                     float* __restrict__ depth, int* __restrict__ n_matches)
+{
+    const int b    = blockIdx.y;
+    int nl         = nl_dev ? nl_dev[b] : nl_host;
+    int nr         = nr_dev ? nr_dev[b] : nr_host;
+    nl             = nl < nl_cap ? nl : nl_cap;
+    nr             = nr < nr_cap ? nr : nr_cap;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int i    = blockIdx.x * 4 + wave;
+    if (i >= nl || nr <= 0) return;
+
+    const snk_kp64* lb = left + (size_t)b * nl_cap;
+    const snk_kp64* rb = right + (size_t)b * nr_cap;
+    const uint4* dlb   = dl + (size_t)b * nl_cap * 2;
+    const uint4* drb   = dr + (size_t)b * nr_cap * 2;
+
+    const snk_kp64 kp = lb[i];
+    const uint4 qa    = dlb[(size_t)i * 2];
+    const uint4 qc    = dlb[(size_t)i * 2 + 1];
+    const int y       = iround_d(kp.y);
+    int oct           = kp.octave;
+    oct               = oct < 0 ? 0 : (oct >= ls.n ? ls.n - 1 : oct);
+    const float r     = ceilf(2.0f * ls.s[oct]);
+    const int ri      = (int)r;
+    const float min_disp = 0.0f;
+    const float max_disp = (float)(bf * 0.5);
+
+    u64 k1 = ST_INF_KEY, k2 = ST_INF_KEY;
+    for (int j = lane; j < nr; j += 64)
+    {
+        const snk_kp64 kr = rb[j];
+        const int yj      = iround_d(kr.y);
+        const int rel     = yj - (y - ri);
+        if (rel < 0 || rel > 2 * ri) continue;
+        const double disparity = kp.x - kr.x;
+        if (disparity < (double)min_disp || disparity > (double)max_disp) continue;
+        int doct = kp.octave - kr.octave;
+        doct     = doct < 0 ? -doct : doct;
+        if (doct > 1) continue;
+        const uint4 ta = drb[(size_t)j * 2];
+        const uint4 tc = drb[(size_t)j * 2 + 1];
+        const int dist = hamming256(qa, qc, ta, tc);
+        if (dist >= 250) continue;
+        const u64 key = ((u64)dist << 40) | ((u64)rel << 24) | (u64)j;
+        insert2(k1, k2, key);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+    {
+        u64 o1 = __shfl_xor(k1, off);
+        u64 o2 = __shfl_xor(k2, off);
+        merge2(k1, k2, o1, o2);
+    }
+    if (lane != 0) return;
+
+    const int best_dist        = (int)(k1 >> 40);
+    const int second_best_dist = (int)(k2 >> 40);
+    if (best_dist > (relaxed ? 75 : 40)) return;
+    if ((double)best_dist > (relaxed ? 0.9 : 0.7) * (double)second_best_dist) return;
+    const int best_id  = (int)(k1 & 0xFFFFFFull);
+    const snk_kp64 kb  = rb[best_id];
+    const float angle1 = kp.angle;
+    const float angle2 = kb.angle;
+    const float rot    = fminf(fabsf(angle1 - angle2), fminf(fabsf((angle1 + 365.0f) - angle2), fabsf(angle1 - (angle2 + 365.0f))));
+    if (rot > (relaxed ? 25.0f : 5.0f)) return;
+
+    double right_point = kb.x;
+    double disparity   = kp.x - right_point;
+    if (disparity <= 0.001)
+    {
+        disparity   = 0.001;
+        right_point = kp.x - disparity;
+    }
+    right_points[(size_t)b * nl_cap + i] = (float)right_point;
+    depth[(size_t)b * nl_cap + i]        = (float)(bf / disparity);
+    atomicAdd(&n_matches[b], 1);
+}
+}  // namespace
+}  // namespace snk
+
+using namespace snk;
+
+struct snk_matcher : HandleBase
+{
+    DevBuf q, t, out, aux, aux2, cnt;
+};
+
+extern "C" {
+
+int snk_matcher_create(int device, void* stream, snk_matcher** out)
+{
+    SNK_REQUIRE(out != nullptr, "out is NULL");
+    *out           = nullptr;
+    snk_matcher* m = new snk_matcher();
+    int rc         = m->init(device, stream);
+    if (rc != SNK_OK)
+    {
+        delete m;
+        return rc;
+    }
+    *out = m;
+    return SNK_OK;
+}
+
+int snk_matcher_destroy(snk_matcher* m)
+{
+    if (!m) return SNK_OK;
+    (void)hipSetDevice(m->device);
+    m->q.release();
+    m->t.release();
+    m->out.release();
+    m->aux.release();
+    m->aux2.release();
+    m->cnt.release();
+    m->fini();
+    delete m;
+    return SNK_OK;
+}
+
+int snk_matcher_sync(snk_matcher* m)
+{
+    SNK_REQUIRE(m != nullptr, "matcher is NULL");
+    SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return SNK_OK;
+}
+
+static int launch_knn2(snk_matcher* m, const uint64_t* q, const int32_t* nq_dev, int nq_cap, int nq_host,
+                       const uint64_t* t, const int32_t* nt_dev, int nt_cap, int nt_host, int batch, snk_knn2* out)
+{
+    if (batch <= 0 || nq_cap <= 0) return SNK_OK;
+    // 4 queries per wavefront once there is enough work to fill 256 CUs, else 1 (latency).
+    const bool wide = (long long)batch * nq_cap >= 16384;
+    const int qw    = wide ? 4 : 1;
+    dim3 grid(ceil_div(nq_cap, 4 * qw), batch);
+    if (wide)
+        hipLaunchKernelGGL(bf_knn2_kernel<4>, grid, dim3(256), 0, m->stream, (const uint4*)q, nq_dev, nq_cap, nq_host,
+                           (const uint4*)t, nt_dev, nt_cap, nt_host, out);
+    else
+        hipLaunchKernelGGL(bf_knn2_kernel<1>, grid, dim3(256), 0, m->stream, (const uint4*)q, nq_dev, nq_cap, nq_host,
+                           (const uint4*)t, nt_dev, nt_cap, nt_host, out);
+    SNK_LAUNCH_CHECK();
+    return SNK_OK;
+}
+
+int snk_bf_knn2(snk_matcher* m, const uint64_t (*query)[4], int nq, const uint64_t (*train)[4], int nt, snk_knn2* out)
+{
+    SNK_REQUIRE(m != nullptr, "matcher is NULL");
+    SNK_REQUIRE(nq >= 0 && nt >= 0, "negative count");
+    SNK_REQUIRE(nt < (int)BF_IDX_MASK, "train set too large (max 2^20-2)");
+    if (nq == 0) return SNK_OK;
+    SNK_REQUIRE(query != nullptr && out != nullptr, "NULL buffer");
+    SNK_REQUIRE(nt == 0 || train != nullptr, "NULL train buffer");
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    int rc;
+    if ((rc = m->q.reserve((size_t)nq * 32)) != SNK_OK) return rc;
+    if ((rc = m->t.reserve((size_t)(nt > 0 ? nt : 1) * 32)) != SNK_OK) return rc;
+    if ((rc = m->out.reserve((size_t)nq * sizeof(snk_knn2))) != SNK_OK) return rc;
+    SNK_HIP_CHECK(hipMemcpyAsync(m->q.p, query, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
+    if (nt > 0) SNK_HIP_CHECK(hipMemcpyAsync(m->t.p, train, (size_t)nt * 32, hipMemcpyHostToDevice, m->stream));
+    rc = launch_knn2(m, m->q.as<uint64_t>(), nullptr, nq, nq, m->t.as<uint64_t>(), nullptr, nt > 0 ? nt : 1, nt, 1,
+                     m->out.as<snk_knn2>());
+    if (rc != SNK_OK) return rc;
+    SNK_HIP_CHECK(hipMemcpyAsync(out, m->out.p, (size_t)nq * sizeof(snk_knn2), hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return SNK_OK;
+}
+
+int snk_bf_knn2_batch_dev(snk_matcher* m, const uint64_t* query_dev, const int32_t* nq_dev, int nq_cap,
+                          const uint64_t* train_dev, const int32_t* nt_dev, int nt_cap, int batch, snk_knn2* out_dev)
+{
+    SNK_REQUIRE(m != nullptr, "matcher is NULL");
+    SNK_REQUIRE(batch >= 0 && nq_cap >= 0 && nt_cap >= 1, "bad sizes");
+    SNK_REQUIRE(nt_cap < (int)BF_IDX_MASK, "train capacity too large (max 2^20-2)");
+    SNK_REQUIRE(query_dev && train_dev && out_dev && nq_dev && nt_dev, "NULL device buffer");
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    return launch_knn2(m, query_dev, nq_dev, nq_cap, 0, train_dev, nt_dev, nt_cap, 0, batch, out_dev);
+}
+
+int snk_bf_filter(snk_matcher* m, const snk_knn2* knn, int nq, int threshold, float ratio, int32_t (*pairs)[2],
+                  int* n_pairs)
+{
+    SNK_REQUIRE(m != nullptr, "matcher is NULL");
+    SNK_REQUIRE(nq >= 0, "negative count");
+    SNK_REQUIRE(n_pairs != nullptr, "n_pairs is NULL");
+    *n_pairs = 0;
+    if (nq == 0) return SNK_OK;
+    SNK_REQUIRE(knn != nullptr && pairs != nullptr, "NULL buffer");
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    int rc;
+    if ((rc = m->out.reserve((size_t)nq * sizeof(snk_knn2))) != SNK_OK) return rc;
+    if ((rc = m->aux.reserve((size_t)nq * 8)) != SNK_OK) return rc;
+    if ((rc = m->cnt.reserve(64)) != SNK_OK) return rc;
+    SNK_HIP_CHECK(hipMemcpyAsync(m->out.p, knn, (size_t)nq * sizeof(snk_knn2), hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(bf_filter_kernel, dim3(1), dim3(256), 0, m->stream, m->out.as<snk_knn2>(), (const int*)nullptr,
+                       nq, nq, threshold, ratio, m->aux.as<int2>(), m->cnt.as<int>());
+    SNK_LAUNCH_CHECK();
+    int n = 0;
+    SNK_HIP_CHECK(hipMemcpyAsync(&n, m->cnt.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (n > 0) SNK_HIP_CHECK(hipMemcpy(pairs, m->aux.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    *n_pairs = n;
+    return SNK_OK;
+}
+
+int snk_bf_filter_batch_dev(snk_matcher* m, const snk_knn2* knn_dev, const int32_t* nq_dev, int nq_cap, int batch,
+                            int threshold, float ratio, int32_t* pairs_dev, int32_t* n_pairs_dev)
+{
+    SNK_REQUIRE(m != nullptr, "matcher is NULL");
+    SNK_REQUIRE(batch >= 0 && nq_cap >= 0, "bad sizes");
+    SNK_REQUIRE(knn_dev && nq_dev && pairs_dev && n_pairs_dev, "NULL device buffer");
+    if (batch == 0) return SNK_OK;
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    hipLaunchKernelGGL(bf_filter_kernel, dim3(batch), dim3(256), 0, m->stream, knn_dev, nq_dev, nq_cap, 0, threshold,
+                       ratio, (int2*)pairs_dev, n_pairs_dev);
+    SNK_LAUNCH_CHECK();
+    return SNK_OK;
+}
+
+static int make_scales(const float* level_scale, int n_levels, LevelScales* ls)
+{
+    SNK_REQUIRE(level_scale != nullptr && n_levels >= 1 && n_levels <= 32, "level_scale / n_levels (1..32)");
+    for (int i = 0; i < 32; ++i) ls->s[i] = i < n_levels ? level_scale[i] : level_scale[n_levels - 1];
+    ls->n = n_levels;
+    return SNK_OK;
+}
+
+int snk_stereo_match(snk_matcher* m, const snk_kp64* left, const uint64_t (*desc_left)[4], int nl,
+                     const snk_kp64* right, const uint64_t (*desc_right)[4], int nr, double bf, const float* level_scale,
+                     int n_levels, int relaxed, float* right_points, float* depth, int* n_matches)
+{
+    SNK_REQUIRE(m != nullptr, "matcher is NULL");
+    SNK_REQUIRE(nl >= 0 && nr >= 0, "negative count");
+    SNK_REQUIRE(n_matches != nullptr, "n_matches is NULL");
+    SNK_REQUIRE(nr < (1 << 24), "right set too large");
+    *n_matches = 0;
+    LevelScales ls;
+    int rc = make_scales(level_scale, n_levels, &ls);
+    if (rc != SNK_OK) return rc;
+    if (nl == 0 || nr == 0) return SNK_OK;
+    SNK_REQUIRE(left && desc_left && right && desc_right && right_points && depth, "NULL buffer");
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    const size_t kl = (size_t)nl * sizeof(snk_kp64), kr = (size_t)nr * sizeof(snk_kp64);
+    // aux: left kps | right kps ; q/t: descriptors ; aux2: right_points | depth ; cnt: n_matches
+    if ((rc = m->aux.reserve(kl + kr)) != SNK_OK) return rc;
+    if ((rc = m->q.reserve((size_t)nl * 32)) != SNK_OK) return rc;
+    if ((rc = m->t.reserve((size_t)nr * 32)) != SNK_OK) return rc;
+    if ((rc = m->aux2.reserve((size_t)nl * 8)) != SNK_OK) return rc;
+    if ((rc = m->cnt.reserve(64)) != SNK_OK) return rc;
+    char* ab   = m->aux.as<char>();
+    float* rp  = m->aux2.as<float>();
+    float* dp  = rp + nl;
+    SNK_HIP_CHECK(hipMemcpyAsync(ab, left, kl, hipMemcpyHostToDevice, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(ab + kl, right, kr, hipMemcpyHostToDevice, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(m->q.p, desc_left, (size_t)nl * 32, hipMemcpyHostToDevice, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(m->t.p, desc_right, (size_t)nr * 32, hipMemcpyHostToDevice, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(rp, right_points, (size_t)nl * 4, hipMemcpyHostToDevice, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(dp, depth, (size_t)nl * 4, hipMemcpyHostToDevice, m->stream));
+    SNK_HIP_CHECK(hipMemsetAsync(m->cnt.p, 0, sizeof(int), m->stream));
+    hipLaunchKernelGGL(stereo_kernel, dim3(ceil_div(nl, 4), 1), dim3(256), 0, m->stream, (const snk_kp64*)ab,
+                       m->q.as<uint4>(), (const int*)nullptr, nl, nl, (const snk_kp64*)(ab + kl), m->t.as<uint4>(),
+                       (const int*)nullptr, nr, nr, bf, ls, relaxed, rp, dp, m->cnt.as<int>());
+    SNK_LAUNCH_CHECK();
+    SNK_HIP_CHECK(hipMemcpyAsync(right_points, rp, (size_t)nl * 4, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(depth, dp, (size_t)nl * 4, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(n_matches, m->cnt.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return SNK_OK;
+}
+
+int snk_stereo_match_batch_dev(snk_matcher* m, const snk_kp64* left_dev, const uint64_t* desc_left_dev,
+                               const int32_t* nl_dev, int nl_cap, const snk_kp64* right_dev,
+                               const uint64_t* desc_right_dev, const int32_t* nr_dev, int nr_cap, int batch, double bf,
+                               const float* level_scale_host, int n_levels, int relaxed, float* right_points_dev,
+                               float* depth_dev, int32_t* n_matches_dev)
+{
+    SNK_REQUIRE(m != nullptr, "matcher is NULL");
+    SNK_REQUIRE(batch >= 0 && nl_cap >= 0 && nr_cap >= 1 && nr_cap < (1 << 24), "bad sizes");
+    SNK_REQUIRE(left_dev && desc_left_dev && nl_dev && right_dev && desc_right_dev && nr_dev && right_points_dev &&
+                    depth_dev && n_matches_dev,
+                "NULL device buffer");
+    LevelScales ls;
+    int rc = make_scales(level_scale_host, n_levels, &ls);
+    if (rc != SNK_OK) return rc;
+    if (batch == 0 || nl_cap == 0) return SNK_OK;
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    SNK_HIP_CHECK(hipMemsetAsync(n_matches_dev, 0, (size_t)batch * sizeof(int), m->stream));
+    hipLaunchKernelGGL(stereo_kernel, dim3(ceil_div(nl_cap, 4), batch), dim3(256), 0, m->stream, left_dev,
+                       (const uint4*)desc_left_dev, nl_dev, nl_cap, 0, right_dev, (const uint4*)desc_right_dev, nr_dev,
+                       nr_cap, 0, bf, ls, relaxed, right_points_dev, depth_dev, n_matches_dev);
+    SNK_LAUNCH_CHECK();
+    return SNK_OK;
+}
+}

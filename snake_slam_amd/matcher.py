@@ -1,0 +1,141 @@
+"""Host-side mirror of the reference's matcher interfaces over the C ABI.
+
+* ``BruteForceMatcher`` mirrors ``Saiga::BruteForceMatcher<DescriptorORB>`` as Snake uses it
+  (reference Snake/Tracking/TrackingCoarse.cpp:350-352,373-387): ``matchKnn2`` /
+  ``matchKnn2_omp`` then ``filterMatches(threshold, ratio)`` and the public ``matches``.
+* ``StereoMatcher.StereoMatching`` mirrors ``Snake::Preprocess::StereoMatching``
+  (reference Snake/Preprocess/Preprocess.cpp:122-242).
+
+Everything runs in the HIP library; numpy only carries host buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+KP64_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("angle", "<f4"), ("octave", "<i4")])
+KNN2_DTYPE = np.dtype([("idx1", "<i4"), ("dist1", "<i4"), ("idx2", "<i4"), ("dist2", "<i4")])
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data) if a is not None and a.size else C.c_void_p(0)
+
+
+def _as_desc(d) -> np.ndarray:
+    d = np.ascontiguousarray(d)
+    if d.dtype == np.uint8:
+        if d.ndim != 2 or d.shape[1] != 32:
+            raise ValueError("uint8 descriptors must be [N, 32]")
+        d = d.view("<u8")
+    if d.dtype != np.uint64 or d.ndim != 2 or d.shape[1] != 4:
+        raise ValueError("descriptors must be [N, 4] uint64 (or [N, 32] uint8)")
+    return d
+
+
+class _Handle:
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.snk_matcher_create(device, C.c_void_p(stream or 0), C.byref(h)), "snk_matcher_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.snk_matcher_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _lib.check(self._lib.snk_matcher_sync(self._h), "snk_matcher_sync")
+
+
+class BruteForceMatcher(_Handle):
+    """matchKnn2 + filterMatches with the reference's call shape."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        super().__init__(device, stream)
+        self.knn = np.zeros(0, KNN2_DTYPE)
+        self.matches = np.zeros((0, 2), np.int32)
+
+    def matchKnn2(self, desc1, desc2) -> None:
+        q, t = _as_desc(desc1), _as_desc(desc2)
+        out = np.zeros(q.shape[0], KNN2_DTYPE)
+        _lib.check(self._lib.snk_bf_knn2(self._h, _ptr(q), q.shape[0], _ptr(t), t.shape[0], _ptr(out)), "snk_bf_knn2")
+        self.knn = out
+
+    def matchKnn2_omp(self, desc1, desc2, threads: int = 1) -> None:  # thread count is meaningless on the GPU
+        self.matchKnn2(desc1, desc2)
+
+    def filterMatches(self, threshold: int, ratio: float) -> int:
+        nq = self.knn.shape[0]
+        pairs = np.zeros((max(nq, 1), 2), np.int32)
+        n = C.c_int(0)
+        _lib.check(
+            self._lib.snk_bf_filter(self._h, _ptr(self.knn), nq, int(threshold), float(ratio), _ptr(pairs), C.byref(n)),
+            "snk_bf_filter",
+        )
+        self.matches = pairs[: n.value].copy()
+        return n.value
+
+    # ---- device-resident batched forms (torch tensors on the handle's device) ----
+    def knn2_batch_dev(self, query, nq, train, nt, out):
+        """query [B, capq, 4] int64/uint64 cuda tensor, nq [B] int32; train likewise; out [B, capq, 4] int32."""
+        B, capq = query.shape[0], query.shape[1]
+        _lib.check(
+            self._lib.snk_bf_knn2_batch_dev(self._h, query.data_ptr(), nq.data_ptr(), capq, train.data_ptr(),
+                                            nt.data_ptr(), train.shape[1], B, out.data_ptr()),
+            "snk_bf_knn2_batch_dev",
+        )
+
+    def filter_batch_dev(self, knn, nq, threshold, ratio, pairs, n_pairs):
+        B, capq = knn.shape[0], knn.shape[1]
+        _lib.check(
+            self._lib.snk_bf_filter_batch_dev(self._h, knn.data_ptr(), nq.data_ptr(), capq, B, int(threshold),
+                                              float(ratio), pairs.data_ptr(), n_pairs.data_ptr()),
+            "snk_bf_filter_batch_dev",
+        )
+
+
+class StereoMatcher(_Handle):
+    def StereoMatching(self, left_kps, desc_left, right_kps, desc_right, bf: float, level_scale,
+                       relaxed: bool = True, right_points=None, depth=None):
+        """Returns (num_matches, right_points, depth).  left_kps/right_kps: KP64_DTYPE arrays of
+        RECTIFIED keypoints.  right_points/depth default to the -1000 fill of Frame::allocateTmp."""
+        lk = np.ascontiguousarray(left_kps, dtype=KP64_DTYPE)
+        rk = np.ascontiguousarray(right_kps, dtype=KP64_DTYPE)
+        dl, dr = _as_desc(desc_left), _as_desc(desc_right)
+        nl, nr = lk.shape[0], rk.shape[0]
+        if dl.shape[0] != nl or dr.shape[0] != nr:
+            raise ValueError("keypoint / descriptor count mismatch")
+        rp = np.full(nl, -1000.0, np.float32) if right_points is None else np.ascontiguousarray(right_points, np.float32)
+        dp = np.full(nl, -1000.0, np.float32) if depth is None else np.ascontiguousarray(depth, np.float32)
+        ls = np.ascontiguousarray(level_scale, np.float32)
+        n = C.c_int(0)
+        _lib.check(
+            self._lib.snk_stereo_match(self._h, _ptr(lk), _ptr(dl), nl, _ptr(rk), _ptr(dr), nr, float(bf), _ptr(ls),
+                                       ls.shape[0], int(bool(relaxed)), _ptr(rp), _ptr(dp), C.byref(n)),
+            "snk_stereo_match",
+        )
+        return n.value, rp, dp
+
+    def match_batch_dev(self, left, desc_left, nl, right, desc_right, nr, bf, level_scale, relaxed, right_points,
+                        depth, n_matches):
+        """Device tensors: left [B, capl, 24 bytes] (uint8 view of snk_kp64), desc [B, cap, 4] int64, counts int32."""
+        ls = np.ascontiguousarray(level_scale, np.float32)
+        B = desc_left.shape[0]
+        _lib.check(
+            self._lib.snk_stereo_match_batch_dev(self._h, left.data_ptr(), desc_left.data_ptr(), nl.data_ptr(),
+                                                 desc_left.shape[1], right.data_ptr(), desc_right.data_ptr(),
+                                                 nr.data_ptr(), desc_right.shape[1], B, float(bf), _ptr(ls),
+                                                 ls.shape[0], int(bool(relaxed)), right_points.data_ptr(),
+                                                 depth.data_ptr(), n_matches.data_ptr()),
+            "snk_stereo_match_batch_dev",
+        )

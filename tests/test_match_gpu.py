@@ -1,0 +1,171 @@
+"""GPU: HIP matchers vs the CPU oracle through the C ABI — bit-exact (integer work)."""
+import numpy as np
+import pytest
+
+from helpers import SEED, knn_to_array, make_stereo_case, rand_desc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bf():
+    from snake_slam_amd.matcher import BruteForceMatcher
+
+    m = BruteForceMatcher(0)
+    yield m
+    m.close()
+
+
+@pytest.fixture(scope="module")
+def st():
+    from snake_slam_amd.matcher import StereoMatcher
+
+    m = StereoMatcher(0)
+    yield m
+    m.close()
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (5, 0), (7, 1), (3, 2), (64, 64), (65, 63), (1000, 1000), (2000, 2000), (1500, 777)])
+def test_bf_knn2_parity(bf, orc, nq, nt):
+    rng = np.random.default_rng(SEED + nq * 7 + nt)
+    q, t = rand_desc(rng, nq), rand_desc(rng, nt)
+    if nt > 8:  # ties: duplicates, and a query identical to two train rows
+        t[nt // 2] = t[0]
+        t[nt - 1] = t[3]
+        q[0] = t[0]
+        q[nq - 1] = t[3]
+    bf.matchKnn2(q, t)
+    want = orc.bf_knn2(q, t)
+    assert np.array_equal(knn_to_array(bf.knn), knn_to_array(want))
+    for th, ratio in [(60, 0.8), (120, 0.9), (60, 0.75), (256, 1.0)]:
+        n = bf.filterMatches(th, ratio)
+        wp = orc.bf_filter(want, th, ratio)
+        assert n == wp.shape[0]
+        assert np.array_equal(bf.matches, wp)
+
+
+def test_bf_knn2_low_entropy_ties(bf, orc):
+    """Descriptors drawn from 3 distinct values: almost everything ties; first index must win."""
+    rng = np.random.default_rng(5)
+    base = rand_desc(rng, 3)
+    q = base[rng.integers(0, 3, 300)]
+    t = base[rng.integers(0, 3, 500)]
+    bf.matchKnn2(q, t)
+    assert np.array_equal(knn_to_array(bf.knn), knn_to_array(orc.bf_knn2(q, t)))
+    assert bf.filterMatches(60, 0.8) == orc.bf_filter(orc.bf_knn2(q, t), 60, 0.8).shape[0]
+
+
+def test_bf_extremes(bf, orc):
+    z = np.zeros((2, 4), np.uint64)
+    o = np.full((2, 4), np.uint64(0xFFFFFFFFFFFFFFFF))
+    bf.matchKnn2(z, o)
+    got = knn_to_array(bf.knn)
+    assert got.tolist() == [[0, 256, 1, 256], [0, 256, 1, 256]]
+    assert np.array_equal(got, knn_to_array(orc.bf_knn2(z, o)))
+
+
+def test_bf_batch_dev_parity(bf, orc):
+    import torch
+
+    rng = np.random.default_rng(SEED)
+    B, capq, capt = 24, 1000, 1000  # B*capq >= 16384 -> exercises the 4-queries-per-wave kernel
+    nq = rng.integers(0, capq + 1, B).astype(np.int32)
+    nt = rng.integers(0, capt + 1, B).astype(np.int32)
+    nq[0], nt[0] = capq, capt
+    nq[1], nt[1] = 0, 5
+    nq[2], nt[2] = 9, 0
+    q = rand_desc(rng, B * capq).reshape(B, capq, 4)
+    t = rand_desc(rng, B * capt).reshape(B, capt, 4)
+    dev = torch.device("cuda:0")
+    qd = torch.from_numpy(q.view(np.int64)).to(dev)
+    td = torch.from_numpy(t.view(np.int64)).to(dev)
+    nqd = torch.from_numpy(nq).to(dev)
+    ntd = torch.from_numpy(nt).to(dev)
+    out = torch.full((B, capq, 4), -7, dtype=torch.int32, device=dev)
+    pairs = torch.full((B, capq, 2), -7, dtype=torch.int32, device=dev)
+    npairs = torch.zeros(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    bf.knn2_batch_dev(qd, nqd, td, ntd, out)
+    bf.filter_batch_dev(out, nqd, 60, 0.8, pairs, npairs)
+    bf.sync()
+    out_h, pairs_h, np_h = out.cpu().numpy(), pairs.cpu().numpy(), npairs.cpu().numpy()
+    for b in range(B):
+        want = orc.bf_knn2(q[b, : nq[b]], t[b, : nt[b]])
+        assert np.array_equal(out_h[b, : nq[b]], knn_to_array(want)), f"batch {b}"
+        assert (out_h[b, nq[b]:] == -7).all()
+        wp = orc.bf_filter(want, 60, 0.8)
+        assert np_h[b] == wp.shape[0]
+        assert np.array_equal(pairs_h[b, : np_h[b]], wp)
+
+
+@pytest.mark.parametrize("nl,nr,relaxed", [(1000, 1000, True), (1000, 1000, False), (257, 63, True), (5, 2000, True), (300, 1, True)])
+def test_stereo_parity(st, orc, nl, nr, relaxed):
+    rng = np.random.default_rng(SEED + nl + nr)
+    left, dl, right, dr, bfv, ls = make_stereo_case(rng, nl, nr)
+    n, rp, dp = st.StereoMatching(left, dl, right, dr, bfv, ls, relaxed)
+    n2, rp2, dp2 = orc.stereo_match(left, dl, right, dr, bfv, ls, relaxed)
+    assert n == n2
+    assert np.array_equal(rp, rp2) and np.array_equal(dp, dp2)
+    if nl >= 257 and nr >= 63:
+        assert n > 0
+
+
+def test_stereo_empty(st):
+    from oracle.oracle import KP64
+
+    ls = np.ones(4, np.float32)
+    e = np.zeros(0, KP64)
+    d = np.zeros((0, 4), np.uint64)
+    n, rp, dp = st.StereoMatching(e, d, e, d, 47.9, ls)
+    assert n == 0 and rp.size == 0
+
+
+def test_stereo_batch_dev_parity(st, orc):
+    import torch
+
+    rng = np.random.default_rng(SEED + 99)
+    B, capl, capr = 6, 700, 650
+    dev = torch.device("cuda:0")
+    from oracle.oracle import KP64
+
+    L = np.zeros((B, capl), KP64)
+    R = np.zeros((B, capr), KP64)
+    DL = np.zeros((B, capl, 4), np.uint64)
+    DR = np.zeros((B, capr, 4), np.uint64)
+    nl = np.array([700, 0, 123, 699, 64, 1], np.int32)
+    nr = np.array([650, 10, 0, 1, 650, 333], np.int32)
+    cases = []
+    for b in range(B):
+        if nl[b] and nr[b]:
+            l, dl, r, dr, bfv, ls = make_stereo_case(rng, int(nl[b]), int(nr[b]))
+            L[b, : nl[b]], DL[b, : nl[b]], R[b, : nr[b]], DR[b, : nr[b]] = l, dl, r, dr
+        cases.append(b)
+    ls = (np.float32(1.2) ** np.arange(4)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    Ld, Rd = t(L.view(np.uint8).reshape(B, capl, 24)), t(R.view(np.uint8).reshape(B, capr, 24))
+    DLd, DRd = t(DL.view(np.int64)), t(DR.view(np.int64))
+    nld, nrd = t(nl), t(nr)
+    rp = torch.full((B, capl), -1000.0, dtype=torch.float32, device=dev)
+    dp = torch.full((B, capl), -1000.0, dtype=torch.float32, device=dev)
+    nm = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    st.match_batch_dev(Ld, DLd, nld, Rd, DRd, nrd, 47.9, ls, True, rp, dp, nm)
+    st.sync()
+    rp_h, dp_h, nm_h = rp.cpu().numpy(), dp.cpu().numpy(), nm.cpu().numpy()
+    for b in range(B):
+        n2, rp2, dp2 = orc.stereo_match(L[b, : nl[b]], DL[b, : nl[b]], R[b, : nr[b]], DR[b, : nr[b]], 47.9, ls, True)
+        assert nm_h[b] == n2, f"batch {b}"
+        assert np.array_equal(rp_h[b, : nl[b]], rp2) and np.array_equal(dp_h[b, : nl[b]], dp2)
+        assert (rp_h[b, nl[b]:] == -1000).all()
+
+
+def test_invalid_args_return_status(bf):
+    from snake_slam_amd import _lib
+    import ctypes as C
+
+    lib = _lib.load()
+    rc = lib.snk_bf_knn2(None, None, 1, None, 1, None)
+    assert rc == 1
+    assert b"NULL" in lib.snk_last_error() or b"invalid" in lib.snk_last_error()
+    h = C.c_void_p()
+    assert lib.snk_matcher_create(9999, None, C.byref(h)) != 0
