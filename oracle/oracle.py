@@ -76,3 +76,126 @@ def stereo_match(left, dl, right, dr, bf, level_scale, relaxed=True, right_point
     n = lib().orc_stereo_match(_p(left), _p(dl), C.c_int(nl), _p(right), _p(dr), C.c_int(right.shape[0]),
                                C.c_double(bf), _p(ls), C.c_int(int(relaxed)), _p(rp), _p(dp))
     return n, rp, dp
+
+
+# ------------------------------------------------------------------ ORB ------------------------
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("n_levels", C.c_int32),
+                ("ini_th", C.c_int32), ("min_th", C.c_int32)]
+
+
+class OrbLayout(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("scale", C.c_float * 16), ("w", C.c_int32 * 16), ("h", C.c_int32 * 16),
+                ("nfeat", C.c_int32 * 16)]
+
+
+KEYPOINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4")])
+CAND = np.dtype([("x", "<u2"), ("y", "<u2"), ("score", "<u2"), ("cell", "<u2")])
+
+
+def orb_params(nfeatures=1000, scale_factor=1.2, n_levels=4, ini_th=20, min_th=7) -> OrbParams:
+    return OrbParams(nfeatures, scale_factor, n_levels, ini_th, min_th)
+
+
+def orb_layout(p: OrbParams, w: int, h: int) -> OrbLayout:
+    L = OrbLayout()
+    rc = lib().orc_orb_layout(C.byref(p), w, h, C.byref(L))
+    if rc != 0:
+        raise ValueError("bad ORB parameters")
+    return L
+
+
+def resize(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize(_p(src), src.shape[1], src.shape[0], src.shape[1], _p(dst), dw, dh, dw)
+    return dst
+
+
+def pyramid(p: OrbParams, img: np.ndarray):
+    L = orb_layout(p, img.shape[1], img.shape[0])
+    levels = [np.ascontiguousarray(img, np.uint8)]
+    for l in range(1, L.n_levels):
+        levels.append(resize(levels[-1], L.w[l], L.h[l]))
+    return levels, L
+
+
+def fast_score(img: np.ndarray, x: int, y: int) -> int:
+    lib().orc_fast_score.restype = C.c_int
+    return lib().orc_fast_score(_p(img), img.shape[1], x, y)
+
+
+def candidates(img: np.ndarray, ini_th=20, min_th=7, cap=8192) -> np.ndarray:
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros(cap, CAND)
+    lib().orc_orb_candidates.restype = C.c_int
+    n = lib().orc_orb_candidates(_p(img), img.shape[1], img.shape[0], img.shape[1], ini_th, min_th, _p(out), cap)
+    return out[:n].copy()
+
+
+def distribute(cands: np.ndarray, w: int, h: int, N: int) -> np.ndarray:
+    cands = np.ascontiguousarray(cands, CAND)
+    out = np.zeros(N + 8, np.int32)
+    lib().orc_orb_distribute.restype = C.c_int
+    n = lib().orc_orb_distribute(_p(cands), cands.shape[0], w, h, N, _p(out))
+    return out[:n].copy()
+
+
+def point_key(x: int, y: int, W: int, H: int) -> int:
+    lib().orc_point_key.restype = C.c_uint64
+    return lib().orc_point_key(x, y, W, H)
+
+
+def ic_moments(img: np.ndarray, x: int, y: int):
+    m10, m01 = C.c_int(), C.c_int()
+    lib().orc_ic_moments(_p(img), img.shape[1], x, y, C.byref(m10), C.byref(m01))
+    return m10.value, m01.value
+
+
+def fast_atan2(y: float, x: float) -> np.float32:
+    lib().orc_fast_atan2.restype = C.c_float
+    return np.float32(lib().orc_fast_atan2(C.c_float(y), C.c_float(x)))
+
+
+def sincos_deg(deg: float):
+    s, c = C.c_float(), C.c_float()
+    lib().orc_sincos_deg(C.c_float(deg), C.byref(s), C.byref(c))
+    return np.float32(s.value), np.float32(c.value)
+
+
+def blur_at(img: np.ndarray, x: int, y: int) -> int:
+    lib().orc_blur_at.restype = C.c_int
+    return lib().orc_blur_at(_p(img), img.shape[1], img.shape[0], img.shape[1], x, y)
+
+
+def blur_image(img: np.ndarray) -> np.ndarray:
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros_like(img)
+    lib().orc_blur_image(_p(img), img.shape[1], img.shape[0], img.shape[1], _p(out), img.shape[1])
+    return out
+
+
+def descriptor(img: np.ndarray, x: int, y: int, angle: float) -> np.ndarray:
+    out = np.zeros(4, np.uint64)
+    lib().orc_descriptor(_p(img), img.shape[1], img.shape[0], img.shape[1], x, y, C.c_float(angle), _p(out))
+    return out
+
+
+def brief_pattern() -> np.ndarray:
+    arr = (C.c_int8 * 1024).in_dll(lib(), "orc_brief_pattern")
+    return np.frombuffer(arr, np.int8).copy()
+
+
+def orb_detect(p: OrbParams, img: np.ndarray, level_cap: int = 0, threads: int = 1):
+    if img.dtype != np.uint8 or img.strides[1] != 1:
+        img = np.ascontiguousarray(img, np.uint8)  # row pitch (strides[0]) may exceed the width
+    cap = p.nfeatures + 4 * p.n_levels + 8
+    kps = np.zeros(cap, KEYPOINT)
+    desc = np.zeros((cap, 4), np.uint64)
+    lib().orc_orb_detect.restype = C.c_int
+    n = lib().orc_orb_detect(C.byref(p), _p(img), img.shape[1], img.shape[0], img.strides[0], _p(kps), _p(desc), cap,
+                             level_cap, threads)
+    if n < 0:
+        raise RuntimeError(f"orc_orb_detect failed: {n}")
+    return kps[:n].copy(), desc[:n].copy()

@@ -32,6 +32,64 @@ int orc_stereo_match(const orc_kp64* left, const uint64_t (*dl)[4], int nl, cons
                      const uint64_t (*dr)[4], int nr, double bf, const float* level_scale, int relaxed,
                      float* right_points, float* depth);
 
+/* ---- orb_oracle.c ---- */
+#define ORC_MAX_LEVELS 16
+#define ORC_LEVEL_CAP 8192
+
+typedef struct orc_orb_params
+{
+    int32_t nfeatures;
+    float scale_factor;
+    int32_t n_levels;
+    int32_t ini_th;
+    int32_t min_th;
+} orc_orb_params;
+
+typedef struct orc_keypoint
+{
+    float x, y, size, angle, response;
+    int32_t octave;
+} orc_keypoint;
+
+typedef struct orc_orb_layout_t
+{
+    int32_t n_levels;
+    float scale[ORC_MAX_LEVELS];
+    int32_t w[ORC_MAX_LEVELS], h[ORC_MAX_LEVELS], nfeat[ORC_MAX_LEVELS];
+} orc_orb_layout_t;
+
+typedef struct orc_cell_grid_t
+{
+    int32_t n_cols, n_rows, w_cell, h_cell;
+} orc_cell_grid_t;
+
+typedef struct orc_cand
+{
+    uint16_t x, y, score, cell;
+} orc_cand;
+
+extern const int8_t orc_brief_pattern[1024];
+int orc_orb_layout(const orc_orb_params* p, int w, int h, orc_orb_layout_t* L);
+void orc_resize_coords(int src, int dst, int32_t* ofs, int32_t* w1);
+void orc_resize(const uint8_t* src, int sw, int sh, int spitch, uint8_t* dst, int dw, int dh, int dpitch);
+int orc_fast_score(const uint8_t* img, int pitch, int x, int y);
+void orc_cell_grid(int w, int h, orc_cell_grid_t* g);
+int orc_orb_candidates(const uint8_t* img, int w, int h, int pitch, int ini_th, int min_th, orc_cand* out, int cap);
+uint64_t orc_point_key(int x, int y, int W, int H);
+int orc_orb_distribute(const orc_cand* pts, int n, int w, int h, int N, int* out_idx);
+void orc_umax(int* umax);
+void orc_ic_moments(const uint8_t* img, int pitch, int x, int y, int* m10, int* m01);
+float orc_fast_atan2(float y, float x);
+void orc_sincos_deg(float deg, float* s_out, float* c_out);
+int orc_blur_at(const uint8_t* img, int w, int h, int pitch, int x, int y);
+void orc_blur_image(const uint8_t* img, int w, int h, int pitch, uint8_t* dst, int dpitch);
+void orc_descriptor_blurred(const uint8_t* blurred, int pitch, int x, int y, float angle_deg, uint64_t out[4]);
+void orc_descriptor(const uint8_t* img, int w, int h, int pitch, int x, int y, float angle_deg, uint64_t out[4]);
+int orc_orb_pyramid(const orc_orb_params* p, const uint8_t* img, int w, int h, int pitch, uint8_t** levels,
+                    orc_orb_layout_t* L);
+int orc_orb_detect(const orc_orb_params* p, const uint8_t* img, int w, int h, int pitch, orc_keypoint* kps,
+                   uint64_t (*desc)[4], int capacity, int level_cap, int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void bf_knn2_kernel(const uint4* __restrict__ 
         for (int k = 0; k < QW; ++k)
         {
             u32 d   = (u32)hamming256(qa[k], qc[k], ta, tc);
-            u32 key = (d << BF_IDX_BITS) | (u32)j;
+            // d == 256 is "infinite" on the Snake side (strict '<' against an initial 256), never a neighbour
+            u32 key = d < (u32)SNK_DIST_INF ? ((d << BF_IDX_BITS) | (u32)j) : BF_INF_KEY;
             insert2(k1[k], k2[k], key);
         }
     }

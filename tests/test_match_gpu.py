@@ -60,7 +60,7 @@ def test_bf_extremes(bf, orc):
     o = np.full((2, 4), np.uint64(0xFFFFFFFFFFFFFFFF))
     bf.matchKnn2(z, o)
     got = knn_to_array(bf.knn)
-    assert got.tolist() == [[0, 256, 1, 256], [0, 256, 1, 256]]
+    assert got.tolist() == [[-1, 256, -1, 256], [-1, 256, -1, 256]]  # 256 is 'infinite': never a neighbour
     assert np.array_equal(got, knn_to_array(orc.bf_knn2(z, o)))
 
 
