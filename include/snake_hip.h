@@ -23,6 +23,7 @@
 #ifndef SNAKE_HIP_H
 #define SNAKE_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -64,7 +65,8 @@ typedef struct snk_kp64
 } snk_kp64;
 
 /* kNN-2 result for one query descriptor: {idx1, dist1, idx2, dist2}; idx = -1 / dist =
- * SNK_DIST_INF when the train set has fewer than 1 / 2 entries. */
+ * SNK_DIST_INF when the train set has fewer than 1 / 2 entries.  A train descriptor at distance
+ * 256 (all bits differ) is never reported: 256 is "infinite" on the Snake side. */
 typedef struct snk_knn2
 {
     int32_t idx1, dist1, idx2, dist2;
@@ -119,6 +121,72 @@ SNK_API int snk_stereo_match_batch_dev(snk_matcher* m, const snk_kp64* left_dev,
                                        const uint64_t* desc_right_dev, const int32_t* nr_dev, int nr_cap, int batch,
                                        double bf, const float* level_scale_host, int n_levels, int relaxed,
                                        float* right_points_dev, float* depth_dev, int32_t* n_matches_dev);
+
+/* ------------------------------------------------------------------------------------------
+ * ORB extractor
+ * ------------------------------------------------------------------------------------------ */
+
+/* Constructor arguments of Saiga::ORBExtractor / ORBExtractorGPU as Snake passes them
+ * (Snake/Preprocess/FeatureDetector.cpp:31-33,40-41: fd_features, fd_scale_factor, fd_levels,
+ * fd_iniThFAST, fd_minThFAST; the CPU extractor's thread count has no meaning here).
+ * level_cap bounds the FAST candidates considered per pyramid level (0 = 8192; a power of two
+ * in [256, 8192]); see DESIGN.md "candidate budget". */
+typedef struct snk_orb_params
+{
+    int32_t nfeatures;
+    float scale_factor;
+    int32_t n_levels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+    int32_t level_cap;
+} snk_orb_params;
+
+/* Saiga::KeyPoint<float> fields (Snake reads .point, .octave, .angle; FeatureDetector.cpp:129-132). */
+typedef struct snk_keypoint
+{
+    float x, y;     /* level-0 pixel coordinates */
+    float size;     /* 31 * scale(octave) */
+    float angle;    /* degrees, [0, 360] */
+    float response; /* FAST corner score */
+    int32_t octave;
+} snk_keypoint;
+
+typedef struct snk_orb snk_orb;
+
+SNK_API int snk_orb_create(const snk_orb_params* params, int device, void* stream, snk_orb** out);
+SNK_API int snk_orb_destroy(snk_orb* o);
+SNK_API int snk_orb_sync(snk_orb* o);
+
+/* Size the device buffers for width x height images and up to max_batch images per call.
+ * snk_orb_detect (re)configures itself on the first image / a size change. */
+SNK_API int snk_orb_configure(snk_orb* o, int width, int height, int max_batch);
+/* Upper bound of keypoints per image for the configured size (output capacity to provide). */
+SNK_API int snk_orb_max_keypoints(const snk_orb* o, int* out);
+
+/* Replaces ORBExtractor::Detect / ORBExtractorGPU::Detect(ImageView<uchar>, vector<KeyPoint<float>>&,
+ * vector<DescriptorORB>&) — Snake/Preprocess/FeatureDetector.cpp:119,124,149,154.  One synchronous
+ * call per image; keypoints and descriptors are index-aligned (FeatureDetector.cpp:169). */
+SNK_API int snk_orb_detect(snk_orb* o, const uint8_t* img, int width, int height, int pitch_bytes, snk_keypoint* kps,
+                           uint64_t (*desc)[4], int capacity, int* n_out);
+
+/* Batched, device-resident form: image b starts at images_dev + b*image_stride (row pitch
+ * pitch_bytes); outputs kps_dev[b*out_cap ...], desc_dev[(b*out_cap + i)*4 ...], n_dev[b]. */
+SNK_API int snk_orb_detect_batch_dev(snk_orb* o, const uint8_t* images_dev, int pitch_bytes, size_t image_stride,
+                                     int batch, snk_keypoint* kps_dev, uint64_t* desc_dev, int32_t* n_dev,
+                                     int out_cap);
+
+/* Intermediate results of the last call (tests / debugging). */
+enum
+{
+    SNK_ORB_DEBUG_PYRAMID         = 1, /* u8 rows of the level (level >= 1), `pitch` bytes each */
+    SNK_ORB_DEBUG_CELL_COUNTS     = 2, /* u16 per FAST cell */
+    SNK_ORB_DEBUG_CELL_CANDIDATES = 3, /* u32[64] per cell: score<<12 | (63-dy)<<6 | (63-dx), strongest first */
+    SNK_ORB_DEBUG_SELECTED        = 4, /* u32 per slot: x | y<<16 (level pixels) */
+    SNK_ORB_DEBUG_SELECTED_COUNT  = 5, /* int */
+    SNK_ORB_DEBUG_LEVEL_INFO      = 6  /* int[8]: w, h, pitch, ncols, nrows, wcell, hcell, nfeat */
+};
+SNK_API int snk_orb_debug_fetch(snk_orb* o, int what, int image, int level, void* out, size_t cap_bytes,
+                                size_t* n_bytes);
 
 #ifdef __cplusplus
 }

@@ -259,10 +259,11 @@ static int cand_cmp_strength(const void* a, const void* b)
     return 0;
 }
 
-/* [DEFINED] bounded candidate list of a level.  If the level has more than `cap` candidates,
- * every cell keeps only its k strongest (score desc, then y, then x), with k the largest value
- * for which the total fits in cap.  Order of the result: cell-major, raster inside the cell
- * (strength-filtered).  Returns the number stored. */
+/* [DEFINED] candidate budget of a level: every cell keeps its k strongest candidates (score desc,
+ * then y, then x), with k the largest value <= ORC_CELL_SLOTS (64) for which the level total
+ * sum(min(n_cell, k)) fits in `cap`.  (No effect unless a cell holds more than 64 candidates or
+ * the level more than `cap`.)  Order of the result: cell-major, raster inside the cell; nothing
+ * downstream depends on that order.  Returns the number stored. */
 int orc_orb_candidates(const uint8_t* img, int w, int h, int pitch, int ini_th, int min_th, orc_cand* out, int cap)
 {
     orc_cell_grid_t g;
@@ -271,14 +272,16 @@ int orc_orb_candidates(const uint8_t* img, int w, int h, int pitch, int ini_th, 
     if (ncell <= 0) return 0;
     int* cc   = (int*)calloc((size_t)ncell, sizeof(int));
     int total = level_candidates_raw(img, w, h, pitch, ini_th, min_th, out, cc, cap);
-    if (total <= cap)
+    int over  = 0;
+    for (int c = 0; c < ncell; ++c) over |= cc[c] > ORC_CELL_SLOTS;
+    if (total <= cap && !over)
     {
         free(cc);
         return total;
     }
     orc_cand* all = (orc_cand*)malloc(sizeof(orc_cand) * (size_t)total);
     level_candidates_raw(img, w, h, pitch, ini_th, min_th, all, cc, total);
-    int k = 1024;
+    int k = ORC_CELL_SLOTS;
     for (;;)
     {
         long s = 0;
@@ -626,20 +629,19 @@ void orc_ic_moments(const uint8_t* img, int pitch, int x, int y, int* m10, int* 
  * float operation order (no FMA) so the kernel can reproduce it bit for bit. */
 float orc_fast_atan2(float y, float x)
 {
-    const float p1 = 0.9997878412794807f * (float)(180.0 / 3.14159265358979323846);
-    const float p3 = -0.3258083974640975f * (float)(180.0 / 3.14159265358979323846);
-    const float p5 = 0.1555786518463281f * (float)(180.0 / 3.14159265358979323846);
-    const float p7 = -0.04432655554792128f * (float)(180.0 / 3.14159265358979323846);
+    /* 0.9997878412794807f, -0.3258083974640975f, 0.1555786518463281f, -0.04432655554792128f, each
+     * times (float)(180/pi), written as exact float literals */
+    const float p1 = 0x1.ca44dep+5f, p3 = -0x1.2aaddcp+4f, p5 = 0x1.1d3f7ep+3f, p7 = -0x1.4515b2p+1f;
     float ax = fabsf(x), ay = fabsf(y), a, c, c2;
     if (ax >= ay)
     {
-        c  = ay / (ax + 2.2204460492503131e-16f);
+        c  = ay / (ax + 0x1p-52f);
         c2 = c * c;
         a  = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
     }
     else
     {
-        c  = ax / (ay + 2.2204460492503131e-16f);
+        c  = ax / (ay + 0x1p-52f);
         c2 = c * c;
         a  = 90.0f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
     }

@@ -35,6 +35,7 @@ int orc_stereo_match(const orc_kp64* left, const uint64_t (*dl)[4], int nl, cons
 /* ---- orb_oracle.c ---- */
 #define ORC_MAX_LEVELS 16
 #define ORC_LEVEL_CAP 8192
+#define ORC_CELL_SLOTS 64
 
 typedef struct orc_orb_params
 {

@@ -45,6 +45,14 @@ SIGNATURES = {
     "snk_bf_filter_batch_dev": (i32, [vp, vp, vp, i32, i32, i32, f32, vp, vp]),
     "snk_stereo_match": (i32, [vp, vp, vp, i32, vp, vp, i32, f64, vp, i32, i32, vp, vp, C.POINTER(i32)]),
     "snk_stereo_match_batch_dev": (i32, [vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, f64, vp, i32, i32, vp, vp, vp]),
+    "snk_orb_create": (i32, [vp, i32, vp, C.POINTER(vp)]),
+    "snk_orb_destroy": (i32, [vp]),
+    "snk_orb_sync": (i32, [vp]),
+    "snk_orb_configure": (i32, [vp, i32, i32, i32]),
+    "snk_orb_max_keypoints": (i32, [vp, C.POINTER(i32)]),
+    "snk_orb_detect": (i32, [vp, vp, i32, i32, i32, vp, vp, i32, C.POINTER(i32)]),
+    "snk_orb_detect_batch_dev": (i32, [vp, vp, i32, C.c_size_t, i32, vp, vp, vp, i32]),
+    "snk_orb_debug_fetch": (i32, [vp, i32, i32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
 }
 
 

@@ -1,0 +1,1175 @@
+// ORB extractor for gfx950 — replaces Saiga::ORBExtractor / ORBExtractorGPU::Detect
+// (reference call sites Snake/Preprocess/FeatureDetector.cpp:31-41,119,124,149,154).
+//
+// Semantics: "snk-orb v1"  — the published ORB-SLAM2 extractor with every
+// unspecified step fixed in integer / explicitly ordered float arithmetic.  The whole library is
+// built with -ffp-contract=off, so the few float expressions below round exactly like their
+// scalar restatement.
+//
+// Pipeline (all kernels batched over B images, blockIdx.y/z = image):
+//   resize_kernel      level l-1 -> level l, 11-bit fixed-point bilinear       (L-1 launches)
+//   fast_kernel        one workgroup per ~30x30 FAST cell: image tile -> LDS, FAST-9/16 score,
+//                      in-cell 3x3 NMS, ini/min threshold fallback, candidates ranked by strength
+//   distribute_kernel  one workgroup per (image, level): quadtree distribution on sorted
+//                      subdivision keys (bitonic sort in LDS + histogram of common-prefix lengths)
+//   describe_kernel    one wavefront per keypoint: 43x43 patch -> LDS, integer IC moments,
+//                      polynomial atan2, separable 7x7 blur in LDS, 256 steered BRIEF tests,
+//                      4 ballots assemble the 256-bit descriptor
+#include "common.hpp"
+
+namespace snk
+{
+namespace
+{
+using u8  = unsigned char;
+using u16 = unsigned short;
+using u32 = unsigned int;
+using u64 = unsigned long long;
+
+constexpr int MAX_LEVELS     = 16;
+constexpr int EDGE_THRESHOLD = 19;
+constexpr int MIN_BORDER     = 16;
+constexpr int CELL_W         = 30;
+constexpr int CELL_SLOTS     = 64;   // strongest candidates kept per cell
+constexpr int MAX_CELL       = 59;   // cells are at most 59 px wide by construction
+constexpr int KEY_DIGITS     = 16;
+constexpr int DEFAULT_LEVEL_CAP = 8192;
+
+__constant__ signed char c_pattern[1024] = {
+#include "brief_pattern_31.inc"
+};
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+struct LevelInfo
+{
+    int w, h, pitch;
+    long long img_stride;  // bytes between consecutive images of this level
+    u8* base;              // level buffer (levels >= 1); level 0 comes from the caller
+    int ncols, nrows, wcell, hcell;
+    int cell_off;          // first cell of this level in the per-image cell arrays
+    int nfeat;             // features wanted on this level
+    int slot_off, slot_cap;  // per-image slots for the selected keypoints of this level
+    int nroots;
+    float scale;
+    const int* xofs;  // resize tables (device): source column / weight per destination column
+    const int* xw1;
+    const int* yofs;
+    const int* yw1;
+};
+
+struct Layout
+{
+    int n_levels;
+    int total_cells;
+    int total_slots;
+    int level_cap;
+    LevelInfo lv[MAX_LEVELS];
+};
+
+// ------------------------------------------------------------------------------------------------
+// pyramid
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resize_kernel(const u8* __restrict__ src, int spitch, long long sstride, int sw,
+                                                     int sh, u8* __restrict__ dst, int dpitch, long long dstride, int dw,
+                                                     int dh, const int* __restrict__ xofs, const int* __restrict__ xw1,
+                                                     const int* __restrict__ yofs, const int* __restrict__ yw1)
+{
+    const int b  = blockIdx.z;
+    const int y  = blockIdx.y;
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x4 >= dw) return;
+    const u8* s  = src + (long long)b * sstride;
+    const int sy = yofs[y], wy1 = yw1[y], wy0 = 2048 - wy1;
+    const int sy1 = sy + 1 < sh ? sy + 1 : sh - 1;
+    const u8* r0  = s + (long long)sy * spitch;
+    const u8* r1  = s + (long long)sy1 * spitch;
+    u32 packed    = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+        const int x = x4 + k;
+        if (x < dw)
+        {
+            const int sx = xofs[x], wx1 = xw1[x], wx0 = 2048 - wx1;
+            const int sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
+            const int v   = ((int)r0[sx] * wx0 + (int)r0[sx1] * wx1) * wy0 + ((int)r1[sx] * wx0 + (int)r1[sx1] * wx1) * wy1;
+            packed |= (u32)((v + (1 << 21)) >> 22) << (8 * k);
+        }
+    }
+    u8* d = dst + (long long)b * dstride + (long long)y * dpitch + x4;
+    if (x4 + 3 < dw)
+        *reinterpret_cast<u32*>(d) = packed;  // dpitch is a multiple of 64 and x4 of 4: aligned
+    else
+        for (int k = 0; k < 4 && x4 + k < dw; ++k) d[k] = (u8)(packed >> (8 * k));
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST-9/16 score: S = max over the 16 arcs of 9 of min(ring - c), and of min(c - ring).
+// corner(t) <=> S > t.  Sliding-window minima by doubling (2,4,8,+1).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int fast_score16(const int (&d)[16])
+{
+    int a2[16], a4[16], b2[16], b4[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+    {
+        a2[i] = min(d[i], d[(i + 1) & 15]);
+        b2[i] = max(d[i], d[(i + 1) & 15]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+    {
+        a4[i] = min(a2[i], a2[(i + 2) & 15]);
+        b4[i] = max(b2[i], b2[(i + 2) & 15]);
+    }
+    int bright = -1000, dark = 1000;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+    {
+        const int a9 = min(min(a4[i], a4[(i + 4) & 15]), d[(i + 8) & 15]);
+        const int b9 = max(max(b4[i], b4[(i + 4) & 15]), d[(i + 8) & 15]);
+        bright       = max(bright, a9);
+        dark         = min(dark, b9);
+    }
+    return max(bright, -dark);
+}
+
+constexpr int TILE_PITCH = 72;  // >= MAX_CELL + 6, multiple of 4
+constexpr int S_PITCH    = 64;  // >= MAX_CELL + 2
+
+__global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restrict__ img0, int pitch0, long long stride0,
+                                                   int ini_th, int min_th, u32* __restrict__ cand,
+                                                   u16* __restrict__ cell_cnt)
+{
+    __shared__ u8 tile[(MAX_CELL + 6) * TILE_PITCH];
+    __shared__ u8 S[(MAX_CELL + 2) * S_PITCH];
+    __shared__ u32 list[((MAX_CELL + 1) / 2) * ((MAX_CELL + 1) / 2)];  // NMS survivors (<= 30*30)
+    __shared__ int n_list, n_ini;
+
+    const int b   = blockIdx.y;
+    const int cid = blockIdx.x;
+    int l         = 0;
+    while (l + 1 < L.n_levels && cid >= L.lv[l + 1].cell_off) ++l;
+    const LevelInfo& lv = L.lv[l];
+    const int c   = cid - lv.cell_off;
+    const int ci  = c / lv.ncols, cj = c - ci * lv.ncols;
+    const int x0  = EDGE_THRESHOLD + cj * lv.wcell;
+    const int y0  = EDGE_THRESHOLD + ci * lv.hcell;
+    const int x1  = min(x0 + lv.wcell, lv.w - EDGE_THRESHOLD);
+    const int y1  = min(y0 + lv.hcell, lv.h - EDGE_THRESHOLD);
+    const int cw = x1 - x0, ch = y1 - y0;
+    const int tid = threadIdx.x;
+    const long long cell_index = (long long)b * L.total_cells + cid;
+    if (cw <= 0 || ch <= 0)
+    {
+        if (tid == 0) cell_cnt[cell_index] = 0;
+        return;
+    }
+    const u8* src   = l == 0 ? img0 + (long long)b * stride0 : lv.base + (long long)b * lv.img_stride;
+    const int pitch = l == 0 ? pitch0 : lv.pitch;
+
+    if (tid == 0)
+    {
+        n_list = 0;
+        n_ini  = 0;
+    }
+    // image tile with the 3-pixel ring halo (always inside the image: cells start at x,y >= 19)
+    const int tw = cw + 6, th = ch + 6;
+    for (int i = tid; i < tw * th; i += 256)
+    {
+        const int ty = i / tw, tx = i - ty * tw;
+        tile[ty * TILE_PITCH + tx] = src[(long long)(y0 - 3 + ty) * pitch + (x0 - 3 + tx)];
+    }
+    // score map with a zero ring (pixels outside the cell never suppress: OpenCV FAST on the sub-image)
+    for (int i = tid; i < (ch + 2) * S_PITCH; i += 256) S[i] = 0;
+    __syncthreads();
+
+    for (int i = tid; i < cw * ch; i += 256)
+    {
+        const int py = i / cw, px = i - py * cw;
+        const u8* t  = &tile[(py + 3) * TILE_PITCH + px + 3];
+        const int v  = t[0];
+        // quick reject: every 9-arc holds one pixel of each opposite pair
+        const int d0 = t[3 * TILE_PITCH] - v, d8 = t[-3 * TILE_PITCH] - v, d4 = t[3] - v, d12 = t[-3] - v;
+        const int ub_b = min(max(d0, d8), max(d4, d12));
+        const int ub_d = min(max(-d0, -d8), max(-d4, -d12));
+        int s = 0;
+        if (ub_b > min_th || ub_d > min_th)
+        {
+            int d[16];
+            d[0]  = d0;
+            d[1]  = t[3 * TILE_PITCH + 1] - v;
+            d[2]  = t[2 * TILE_PITCH + 2] - v;
+            d[3]  = t[1 * TILE_PITCH + 3] - v;
+            d[4]  = d4;
+            d[5]  = t[-1 * TILE_PITCH + 3] - v;
+            d[6]  = t[-2 * TILE_PITCH + 2] - v;
+            d[7]  = t[-3 * TILE_PITCH + 1] - v;
+            d[8]  = d8;
+            d[9]  = t[-3 * TILE_PITCH - 1] - v;
+            d[10] = t[-2 * TILE_PITCH - 2] - v;
+            d[11] = t[-1 * TILE_PITCH - 3] - v;
+            d[12] = d12;
+            d[13] = t[1 * TILE_PITCH - 3] - v;
+            d[14] = t[2 * TILE_PITCH - 2] - v;
+            d[15] = t[3 * TILE_PITCH - 1] - v;
+            s     = fast_score16(d);
+            s     = s < 0 ? 0 : s;
+        }
+        S[(py + 1) * S_PITCH + px + 1] = (u8)s;  // s <= 255
+    }
+    __syncthreads();
+
+    // 3x3 non-max suppression (strict) among scores above min_th; count those above ini_th
+    for (int i = tid; i < cw * ch; i += 256)
+    {
+        const int py = i / cw, px = i - py * cw;
+        const u8* s  = &S[(py + 1) * S_PITCH + px + 1];
+        const int v  = s[0];
+        if (v <= min_th) continue;
+        if (v > s[-1] && v > s[1] && v > s[-S_PITCH - 1] && v > s[-S_PITCH] && v > s[-S_PITCH + 1] && v > s[S_PITCH - 1] &&
+            v > s[S_PITCH] && v > s[S_PITCH + 1])
+        {
+            // strength key: higher score first, then smaller y, then smaller x
+            const u32 key = ((u32)v << 12) | ((u32)(63 - py) << 6) | (u32)(63 - px);
+            list[atomicAdd(&n_list, 1)] = key;
+            if (v > ini_th) atomicAdd(&n_ini, 1);
+        }
+    }
+    __syncthreads();
+    const int nl   = n_list;
+    const bool ini = n_ini > 0;
+    const u32 thr  = ((u32)(ini ? ini_th : min_th) << 12) | 0xFFFu;  // key > thr  <=>  score > threshold
+    const int n    = ini ? n_ini : nl;
+    // rank the survivors of the effective threshold by strength; keep the CELL_SLOTS strongest
+    u32* out = cand + cell_index * CELL_SLOTS;
+    for (int i = tid; i < nl; i += 256)
+    {
+        const u32 k = list[i];
+        if (k <= thr) continue;
+        int r = 0;
+        for (int j = 0; j < nl; ++j) r += list[j] > k ? 1 : 0;
+        if (r < CELL_SLOTS) out[r] = k;
+    }
+    if (tid == 0) cell_cnt[cell_index] = (u16)(n > 65535 ? 65535 : n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// quadtree distribution
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 point_key(int x, int y, int W, int H, int nroots)
+{
+    const int root = (int)(((long long)x * nroots) / W);
+    int x0 = (int)(((long long)root * W + nroots - 1) / nroots), x1 = (int)(((long long)(root + 1) * W + nroots - 1) / nroots);
+    int y0 = 0, y1 = H;
+    u64 key = (u64)root;
+#pragma unroll
+    for (int d = 0; d < KEY_DIGITS; ++d)
+    {
+        const int mx = x0 + (x1 - x0 + 1) / 2, my = y0 + (y1 - y0 + 1) / 2;
+        const int cx = x >= mx, cy = y >= my;
+        x0 = cx ? mx : x0;
+        x1 = cx ? x1 : mx;
+        y0 = cy ? my : y0;
+        y1 = cy ? y1 : my;
+        key = (key << 2) | (u64)(cx + 2 * cy);
+    }
+    return key;  // 8 + 32 bits
+}
+
+// in-LDS bitonic sort of n_pow2 u64 keys (ascending), all threads of the block participate
+__device__ void bitonic_sort(u64* a, int n_pow2, int tid, int nthreads)
+{
+    for (int k = 2; k <= n_pow2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1)
+        {
+            for (int t = tid; t < (n_pow2 >> 1); t += nthreads)
+            {
+                const int i   = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int ixj = i | j;
+                const bool up = (i & k) == 0;
+                const u64 x = a[i], y = a[ixj];
+                if ((x > y) == up)
+                {
+                    a[i]   = y;
+                    a[ixj] = x;
+                }
+            }
+            __syncthreads();
+        }
+}
+
+// block-wide inclusive scan of one int per thread (512 threads = 8 waves)
+constexpr int DIST_THREADS = 512;
+__device__ int block_scan_incl(int v, int tid, int* wave_tot /* >= 8 */)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    int x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+    {
+        const int y = __shfl_up(x, off);
+        if (lane >= off) x += y;
+    }
+    if (lane == 63) wave_tot[wave] = x;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wave_tot[w];
+    __syncthreads();
+    return x + base;
+}
+
+// Dynamic LDS carve (cap = level_cap, a power of two):
+//   keys  u64[cap]      sort keys: subdivision key << 13 | candidate slot
+//   nodes u64[cap/2]    careful-phase node list
+//   px,py u16[cap]      candidate coordinates (level pixels)
+//   sc    u8[cap]       scores
+//   lcp   i8[cap + 1]   common-prefix length with the predecessor (-1 = different root)
+//   fd    u8[cap]       final node depth of every sorted point
+__global__ __launch_bounds__(DIST_THREADS) void distribute_kernel(Layout L, const u32* __restrict__ cand,
+                                                                  const u16* __restrict__ cell_cnt,
+                                                                  u32* __restrict__ sel /* [B][total_slots] x|y<<16 */,
+                                                                  u8* __restrict__ sel_score, int* __restrict__ sel_cnt,
+                                                                  int* __restrict__ cand_total /* debug: [B][levels] */)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int cap = L.level_cap;
+    u64* keys     = reinterpret_cast<u64*>(smem);
+    u64* nodes    = keys + cap;
+    u16* px       = reinterpret_cast<u16*>(nodes + cap / 2);
+    u16* py       = px + cap;
+    u8* sc        = reinterpret_cast<u8*>(py + cap);
+    signed char* lcp = reinterpret_cast<signed char*>(sc + cap);
+    u8* fd        = reinterpret_cast<u8*>(lcp + cap + 16);
+    __shared__ int wave_tot[8];
+    __shared__ int hist_lcp[20], hist_m[20];
+    __shared__ int s_n, s_k, s_D, s_careful, s_size, s_nnodes, s_finish, s_jstar, s_out;
+
+    const int tid = threadIdx.x;
+    const int l   = blockIdx.x;
+    const int b   = blockIdx.y;
+    const LevelInfo& lv = L.lv[l];
+    const int ncell = lv.ncols * lv.nrows;
+    const int N     = lv.nfeat;
+    const u16* cc   = cell_cnt + (long long)b * L.total_cells + lv.cell_off;
+    const u32* cd   = cand + ((long long)b * L.total_cells + lv.cell_off) * CELL_SLOTS;
+    int* out_cnt    = sel_cnt + b * MAX_LEVELS + l;
+
+    // ---- 1. per-cell budget k: largest k <= CELL_SLOTS with sum(min(cnt, k)) <= cap -------------
+    if (tid == 0) s_k = CELL_SLOTS;
+    __syncthreads();
+    for (;;)
+    {
+        const int k = s_k;
+        int part    = 0;
+        for (int c = tid; c < ncell; c += DIST_THREADS) part += min((int)cc[c], k);
+        const int incl = block_scan_incl(part, tid, wave_tot);
+        if (tid == DIST_THREADS - 1) s_n = incl;
+        __syncthreads();
+        if (s_n <= cap || k == 0) break;
+        if (tid == 0) s_k = k - 1;
+        __syncthreads();
+    }
+    const int kcell = s_k;
+    const int n     = s_n;
+    if (tid == 0 && cand_total) cand_total[b * MAX_LEVELS + l] = n;
+    if (n == 0 || N <= 0)
+    {
+        if (tid == 0) *out_cnt = 0;
+        return;
+    }
+    int n_pow2 = 1;
+    while (n_pow2 < n) n_pow2 <<= 1;
+
+    // ---- 2. gather candidates (cell slots are strength-ordered: the first k are the k strongest) --
+    {
+        // cells are walked in chunks of DIST_THREADS with a running offset
+        int base = 0;
+        for (int c0 = 0; c0 < ncell; c0 += DIST_THREADS)
+        {
+            const int c   = c0 + tid;
+            const int cnt = c < ncell ? min((int)cc[c], kcell) : 0;
+            const int incl = block_scan_incl(cnt, tid, wave_tot);
+            const int off  = base + incl - cnt;
+            if (cnt > 0)
+            {
+                const int ci = c / lv.ncols, cj = c - ci * lv.ncols;
+                const int x0 = EDGE_THRESHOLD + cj * lv.wcell, y0 = EDGE_THRESHOLD + ci * lv.hcell;
+                for (int i = 0; i < cnt; ++i)
+                {
+                    const u32 k = cd[(long long)c * CELL_SLOTS + i];
+                    px[off + i] = (u16)(x0 + 63 - (int)(k & 63u));
+                    py[off + i] = (u16)(y0 + 63 - (int)((k >> 6) & 63u));
+                    sc[off + i] = (u8)(k >> 12);
+                }
+            }
+            if (tid == DIST_THREADS - 1) s_out = incl;
+            __syncthreads();
+            base += s_out;
+            __syncthreads();
+        }
+    }
+    const int W = lv.w - 2 * MIN_BORDER, H = lv.h - 2 * MIN_BORDER;
+    for (int i = tid; i < n_pow2; i += DIST_THREADS)
+        keys[i] = i < n ? ((point_key(px[i] - MIN_BORDER, py[i] - MIN_BORDER, W, H, lv.nroots) << 13) | (u64)i) : ~0ull;
+    __syncthreads();
+
+    // ---- 3. sort by subdivision key -------------------------------------------------------------
+    bitonic_sort(keys, n_pow2, tid, DIST_THREADS);
+
+    // ---- 4. common-prefix lengths and the per-depth node statistics ------------------------------
+    if (tid < 20)
+    {
+        hist_lcp[tid] = 0;
+        hist_m[tid]   = 0;
+    }
+    for (int i = tid; i <= n; i += DIST_THREADS)
+    {
+        int v = -1;
+        if (i > 0 && i < n)
+        {
+            const u64 diff = (keys[i] >> 13) ^ (keys[i - 1] >> 13);  // 40-bit keys, never equal
+            if ((diff >> 32) == 0)
+            {
+                const int hb = 63 - __clzll(diff);  // highest differing bit, 0..31
+                v            = 15 - (hb >> 1);      // equal leading digits, 0..15
+            }
+        }
+        lcp[i] = (signed char)v;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += DIST_THREADS)
+    {
+        if (i > 0) atomicAdd(&hist_lcp[lcp[i] + 1], 1);
+        const int m = max((int)lcp[i], (int)lcp[i + 1]);  // lcp[0] = lcp[n] = -1
+        atomicAdd(&hist_m[m + 1], 1);
+    }
+    __syncthreads();
+
+    // ---- 5. replay ORB-SLAM2's split passes on the statistics (one thread, <= 16 steps) -----------
+    if (tid == 0)
+    {
+        // heads_d = 1 + #{i>=1 : lcp(i) < d};  singles_d = #{i : max(lcp(i), lcp(i+1)) < d}
+        int cum_l = 0, cum_m = 0;
+        int size_prev = 1 + hist_lcp[0];  // d = 0: roots that hold points
+        cum_l = hist_lcp[0];
+        cum_m = hist_m[0];
+        int D = KEY_DIGITS, careful = 0, size_D = 0;
+        bool done = false;
+        for (int d = 1; d <= KEY_DIGITS && !done; ++d)
+        {
+            cum_l += hist_lcp[d];  // lcp value d-1
+            cum_m += hist_m[d];
+            const int size  = 1 + cum_l;
+            const int multi = size - cum_m;
+            if (size >= N || size == size_prev)
+            {
+                D = d; careful = 0; size_D = size; done = true;
+            }
+            else if (size + 3 * multi > N)
+            {
+                D = d; careful = 1; size_D = size; done = true;
+            }
+            size_prev = size;
+            if (!done && d == KEY_DIGITS) { D = KEY_DIGITS; careful = 0; size_D = size; }
+        }
+        s_D       = D;
+        s_careful = careful;
+        s_size    = size_D;
+        s_finish  = 0;
+    }
+    __syncthreads();
+    const int D = s_D;
+    for (int i = tid; i < n; i += DIST_THREADS) fd[i] = (u8)D;
+    __syncthreads();
+
+    // ---- 6. careful phase: split the fullest nodes first until N nodes exist ----------------------
+    if (s_careful)
+    {
+        // round r works on nodes of depth dd = D + r whose points have fd == dd ("active")
+        for (int dd = D; dd < KEY_DIGITS; ++dd)
+        {
+            if (tid == 0) s_nnodes = 0;
+            __syncthreads();
+            // a node head at depth dd: lcp(i) < dd; active nodes of this round have fd == dd and, for
+            // rounds after the first, were created by a split in the previous round (fd was raised to dd)
+            for (int i = tid; i < n; i += DIST_THREADS)
+            {
+                if (fd[i] != dd || (int)lcp[i] >= dd) continue;
+                int e = i + 1, delta = 0;
+                while (e < n && (int)lcp[e] >= dd)
+                {
+                    delta += (int)lcp[e] == dd ? 1 : 0;
+                    ++e;
+                }
+                const int cnt = e - i;
+                if (cnt > 1)
+                {
+                    // order: count descending, then position (= key prefix) ascending
+                    const u64 nk = ((u64)(0xFFFF - cnt) << 32) | ((u64)i << 16) | (u64)delta;
+                    nodes[atomicAdd(&s_nnodes, 1)] = nk;
+                }
+            }
+            __syncthreads();
+            const int m = s_nnodes;
+            if (m == 0) break;
+            int m_pow2 = 1;
+            while (m_pow2 < m) m_pow2 <<= 1;
+            for (int i = m + tid; i < m_pow2; i += DIST_THREADS) nodes[i] = ~0ull;
+            __syncthreads();
+            bitonic_sort(nodes, m_pow2, tid, DIST_THREADS);
+            // running node count after splitting the first j+1 nodes; j* = first j reaching N
+            if (tid == 0) s_jstar = m;  // "none"
+            __syncthreads();
+            int base = s_size;
+            for (int j0 = 0; j0 < m; j0 += DIST_THREADS)
+            {
+                const int j     = j0 + tid;
+                const int delta = j < m ? (int)(nodes[j] & 0xFFFFu) : 0;
+                const int incl  = block_scan_incl(delta, tid, wave_tot);
+                if (j < m && base + incl >= N) atomicMin(&s_jstar, j);
+                if (tid == DIST_THREADS - 1) s_out = incl;
+                __syncthreads();
+                base += s_out;
+                __syncthreads();
+            }
+            const int jstar = s_jstar;
+            const int last  = jstar < m ? jstar : m - 1;  // nodes 0..last are split
+            // size after this round
+            if (tid == 0)
+            {
+                int add = 0;
+                for (int j = 0; j <= last; ++j) add += (int)(nodes[j] & 0xFFFFu);
+                s_finish = (s_size + add >= N || add == 0) ? 1 : 0;
+                s_size += add;
+            }
+            for (int j = tid; j <= last; j += DIST_THREADS)
+            {
+                const int i = (int)((nodes[j] >> 16) & 0xFFFFu);
+                int e       = i;
+                do
+                {
+                    fd[e] = (u8)(dd + 1);
+                    ++e;
+                } while (e < n && (int)lcp[e] >= dd);
+            }
+            __syncthreads();
+            if (s_finish) break;
+        }
+    }
+    __syncthreads();
+
+    // ---- 7. one keypoint per final node: highest score, then smallest y, then smallest x ----------
+    {
+        u32* out    = sel + (long long)b * L.total_slots + lv.slot_off;
+        u8* out_sc  = sel_score + (long long)b * L.total_slots + lv.slot_off;
+        int base = 0;
+        for (int i0 = 0; i0 < n; i0 += DIST_THREADS)
+        {
+            const int i    = i0 + tid;
+            const bool head = i < n && (int)lcp[i] < (int)fd[i];
+            const int incl  = block_scan_incl(head ? 1 : 0, tid, wave_tot);
+            if (head)
+            {
+                const int depth = fd[i];
+                int best = (int)(keys[i] & 0x1FFFu);
+                int e    = i + 1;
+                while (e < n && (int)lcp[e] >= depth)
+                {
+                    const int c = (int)(keys[e] & 0x1FFFu);
+                    if (sc[c] > sc[best] || (sc[c] == sc[best] && (py[c] < py[best] || (py[c] == py[best] && px[c] < px[best]))))
+                        best = c;
+                    ++e;
+                }
+                const int pos = base + incl - 1;
+                if (pos < lv.slot_cap)
+                {
+                    out[pos]    = (u32)px[best] | ((u32)py[best] << 16);
+                    out_sc[pos] = sc[best];
+                }
+            }
+            if (tid == DIST_THREADS - 1) s_out = incl;
+            __syncthreads();
+            base += s_out;
+            __syncthreads();
+        }
+        if (tid == 0) *out_cnt = base < lv.slot_cap ? base : lv.slot_cap;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// orientation + descriptor
+// ------------------------------------------------------------------------------------------------
+// cv::fastAtan2's polynomial with a fixed operation order (degrees in [0, 360]).
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float p1 = 0x1.ca44dep+5f, p3 = -0x1.2aaddcp+4f, p5 = 0x1.1d3f7ep+3f, p7 = -0x1.4515b2p+1f;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay)
+    {
+        c  = ay / (ax + 0x1p-52f);
+        c2 = c * c;
+        a  = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    else
+    {
+        c  = ax / (ay + 0x1p-52f);
+        c2 = c * c;
+        a  = 90.0f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.0f - a;
+    if (y < 0) a = 360.0f - a;
+    return a;
+}
+
+// sine / cosine of degrees: exact octant reduction + Taylor polynomials on [0, 45] degrees.
+__device__ __forceinline__ void sincos_deg(float deg, float& s_out, float& c_out)
+{
+    int q   = 0;
+    float r = deg;
+    if (r >= 360.0f) r -= 360.0f;
+    if (r >= 270.0f) { r -= 270.0f; q = 3; }
+    else if (r >= 180.0f) { r -= 180.0f; q = 2; }
+    else if (r >= 90.0f) { r -= 90.0f; q = 1; }
+    bool swap = false;
+    if (r > 45.0f) { r = 90.0f - r; swap = true; }
+    const float x  = r * 0.017453292519943295f;
+    const float x2 = x * x;
+    float s = x + x * x2 * (-1.6666667e-1f + x2 * (8.3333333e-3f + x2 * (-1.9841270e-4f + x2 * 2.7557319e-6f)));
+    float c = 1.0f + x2 * (-0.5f + x2 * (4.1666667e-2f + x2 * (-1.3888889e-3f + x2 * 2.4801587e-5f)));
+    if (swap) { const float t = s; s = c; c = t; }
+    switch (q)
+    {
+        case 0: s_out = s; c_out = c; break;
+        case 1: s_out = c; c_out = -s; break;
+        case 2: s_out = -s; c_out = -c; break;
+        default: s_out = -c; c_out = s; break;
+    }
+}
+
+constexpr int RAW_R   = 21;  // 15 (pattern, rotated <= 18) + 3 (blur)
+constexpr int RAW_W   = 2 * RAW_R + 1;  // 43
+constexpr int RAW_P   = 44;
+constexpr int BL_R    = 18;
+constexpr int BL_W    = 2 * BL_R + 1;  // 37
+constexpr int BL_P    = 40;
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
+}
+
+struct DescWaveLds
+{
+    u8 raw[RAW_W * RAW_P];
+    u16 hb[RAW_W * BL_P];  // horizontal pass: rows -21..21, cols -18..18
+    u8 bl[BL_W * BL_P];
+};
+
+__global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __restrict__ img0, int pitch0,
+                                                       long long stride0, const u32* __restrict__ sel,
+                                                       const u8* __restrict__ sel_score, const int* __restrict__ sel_cnt,
+                                                       snk_keypoint* __restrict__ kps, u64* __restrict__ desc,
+                                                       int* __restrict__ n_out, int out_cap)
+{
+    __shared__ DescWaveLds lds[4];
+    __shared__ signed char pat[1024];
+    const int tid  = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int l    = blockIdx.y;
+    const int b    = blockIdx.z;
+    const int slot = blockIdx.x * 4 + wave;
+    for (int i = tid; i < 1024; i += 256) pat[i] = c_pattern[i];
+
+    const int* cnts = sel_cnt + b * MAX_LEVELS;
+    int offset = 0, total = 0;
+    for (int k = 0; k < L.n_levels; ++k)
+    {
+        const int c = cnts[k];
+        offset += k < l ? c : 0;
+        total += c;
+    }
+    if (blockIdx.x == 0 && l == 0 && tid == 0) n_out[b] = total < out_cap ? total : out_cap;
+    __syncthreads();
+    const LevelInfo& lv = L.lv[l];
+    if (slot >= cnts[l]) return;  // whole wavefront
+    const int oi = offset + slot;
+    if (oi >= out_cap) return;
+
+    const u32 xy    = sel[(long long)b * L.total_slots + lv.slot_off + slot];
+    const int score = sel_score[(long long)b * L.total_slots + lv.slot_off + slot];
+    const int kx = (int)(xy & 0xFFFFu), ky = (int)(xy >> 16);
+    const u8* src   = l == 0 ? img0 + (long long)b * stride0 : lv.base + (long long)b * lv.img_stride;
+    const int pitch = l == 0 ? pitch0 : lv.pitch;
+    DescWaveLds& w  = lds[wave];
+
+    // raw 43x43 patch, reflect-101 outside the level image (at most 2 px: keypoints sit >= 19 px inside)
+    for (int i = lane; i < RAW_W * RAW_W; i += 64)
+    {
+        const int ry = i / RAW_W, rx = i - ry * RAW_W;
+        const int sy = reflect101(ky - RAW_R + ry, lv.h), sx = reflect101(kx - RAW_R + rx, lv.w);
+        w.raw[ry * RAW_P + rx] = src[(long long)sy * pitch + sx];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+
+    // intensity-centroid moments over the radius-15 disc (integers)
+    int m10 = 0, m01 = 0;
+    for (int i = lane; i < 31 * 31; i += 64)
+    {
+        const int vy = i / 31 - 15, ux = i % 31 - 15;
+        const int av = vy < 0 ? -vy : vy, au = ux < 0 ? -ux : ux;
+        if (au <= c_umax[av])
+        {
+            const int p = w.raw[(vy + RAW_R) * RAW_P + ux + RAW_R];
+            m10 += ux * p;
+            m01 += vy * p;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+    {
+        m10 += __shfl_xor(m10, off);
+        m01 += __shfl_xor(m01, off);
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    float sn, cs;
+    sincos_deg(angle, sn, cs);
+
+    // separable 7x7 Gaussian {18,33,49,56,49,33,18}/256: exact 16-bit rows, one rounding
+    for (int i = lane; i < RAW_W * BL_W; i += 64)
+    {
+        const int ry = i / BL_W, bx = i - ry * BL_W;  // bx: blurred column 0..36 <-> raw column bx + 3
+        const u8* r  = &w.raw[ry * RAW_P + bx];
+        w.hb[ry * BL_P + bx] = (u16)(18 * (r[0] + r[6]) + 33 * (r[1] + r[5]) + 49 * (r[2] + r[4]) + 56 * r[3]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    for (int i = lane; i < BL_W * BL_W; i += 64)
+    {
+        const int by = i / BL_W, bx = i - by * BL_W;
+        const u16* h = &w.hb[by * BL_P + bx];
+        const int acc = 18 * (h[0] + h[6 * BL_P]) + 33 * (h[BL_P] + h[5 * BL_P]) + 49 * (h[2 * BL_P] + h[4 * BL_P]) + 56 * h[3 * BL_P];
+        w.bl[by * BL_P + bx] = (u8)((acc + (1 << 15)) >> 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+
+    // 256 steered tests; lane computes bits lane, lane+64, lane+128, lane+192 -> 4 ballots
+    u64 word[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+        const int bit = k * 64 + lane;
+        int t[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+        {
+            const float pxf = (float)pat[4 * bit + 2 * e], pyf = (float)pat[4 * bit + 2 * e + 1];
+            const int ry    = __float2int_rn(pxf * sn + pyf * cs);
+            const int rx    = __float2int_rn(pxf * cs - pyf * sn);
+            t[e]            = w.bl[(ry + BL_R) * BL_P + rx + BL_R];
+        }
+        word[k] = __ballot(t[0] < t[1]);
+    }
+    if (lane == 0)
+    {
+        snk_keypoint kp;
+        kp.x        = (float)kx * lv.scale;
+        kp.y        = (float)ky * lv.scale;
+        kp.size     = 31.0f * lv.scale;
+        kp.angle    = angle;
+        kp.response = (float)(score - 1);
+        kp.octave   = l;
+        kps[(long long)b * out_cap + oi] = kp;
+        u64* d = desc + ((long long)b * out_cap + oi) * 4;
+        d[0] = word[0];
+        d[1] = word[1];
+        d[2] = word[2];
+        d[3] = word[3];
+    }
+}
+}  // namespace
+}  // namespace snk
+
+using namespace snk;
+
+struct snk_orb : HandleBase
+{
+    snk_orb_params params{};
+    int width = 0, height = 0, max_batch = 0;
+    bool configured = false;
+    Layout lay{};
+    DevBuf pyr[MAX_LEVELS];  // levels >= 1
+    DevBuf tables;           // resize tables
+    DevBuf img0;             // level-0 staging for the host API
+    DevBuf cand, cell_cnt, sel, sel_score, sel_cnt, cand_total;
+    DevBuf out_kps, out_desc, out_n;  // host-API staging
+    int pitch0_host = 0;
+    size_t dist_lds = 0;
+};
+
+static int compute_layout(snk_orb* o, int w, int h)
+{
+    const snk_orb_params& p = o->params;
+    Layout& L               = o->lay;
+    memset(&L, 0, sizeof(L));
+    L.n_levels  = p.n_levels;
+    L.level_cap = p.level_cap > 0 ? p.level_cap : DEFAULT_LEVEL_CAP;
+    float scale[MAX_LEVELS];
+    scale[0] = 1.0f;
+    for (int l = 1; l < p.n_levels; ++l) scale[l] = scale[l - 1] * p.scale_factor;
+    // ORB-SLAM2 constructor arithmetic (float)
+    const float factor = 1.0f / p.scale_factor;
+    float n_desired    = (float)p.nfeatures * (1.0f - factor) / (1.0f - (float)pow((double)factor, (double)p.n_levels));
+    int sum            = 0;
+    int cell_off = 0, slot_off = 0;
+    for (int l = 0; l < p.n_levels; ++l)
+    {
+        LevelInfo& lv = L.lv[l];
+        const float inv = 1.0f / scale[l];
+        lv.w     = (int)lrintf((float)w * inv);
+        lv.h     = (int)lrintf((float)h * inv);
+        lv.scale = scale[l];
+        if (l < p.n_levels - 1)
+        {
+            lv.nfeat = (int)lrintf(n_desired);
+            sum += lv.nfeat;
+            n_desired *= factor;
+        }
+        else
+            lv.nfeat = p.nfeatures - sum > 0 ? p.nfeatures - sum : 0;
+        const int width = lv.w - 2 * MIN_BORDER, height = lv.h - 2 * MIN_BORDER;
+        lv.ncols = width > 0 ? width / CELL_W : 0;
+        lv.nrows = height > 0 ? height / CELL_W : 0;
+        if (lv.ncols < 1 || lv.nrows < 1 || lv.w < 2 * EDGE_THRESHOLD + 1 || lv.h < 2 * EDGE_THRESHOLD + 1)
+        {
+            lv.ncols = lv.nrows = 0;
+            lv.wcell = lv.hcell = 1;
+        }
+        else
+        {
+            lv.wcell = (width + lv.ncols - 1) / lv.ncols;
+            lv.hcell = (height + lv.nrows - 1) / lv.nrows;
+        }
+        lv.cell_off = cell_off;
+        cell_off += lv.ncols * lv.nrows;
+        int nroots = height > 0 ? (2 * width + height) / (2 * height) : 1;
+        nroots     = nroots < 1 ? 1 : (nroots > 255 ? 255 : nroots);
+        lv.nroots  = nroots;
+        lv.slot_off = slot_off;
+        lv.slot_cap = lv.nfeat + 3 > 4 * nroots ? lv.nfeat + 3 : 4 * nroots;
+        slot_off += lv.slot_cap;
+        lv.pitch      = (lv.w + 63) & ~63;
+        lv.img_stride = (long long)lv.pitch * lv.h;
+    }
+    L.total_cells = cell_off;
+    L.total_slots = slot_off;
+    return SNK_OK;
+}
+
+static void resize_tables(int src, int dst, int* ofs, int* w1)
+{
+    const double scale = (double)src / (double)dst;
+    for (int d = 0; d < dst; ++d)
+    {
+        double f = ((double)d + 0.5) * scale - 0.5;
+        int s    = (int)floor(f);
+        f -= (double)s;
+        if (s < 0)
+        {
+            s = 0;
+            f = 0.0;
+        }
+        if (s >= src - 1)
+        {
+            s = src - 1;
+            f = 0.0;
+        }
+        ofs[d] = s;
+        w1[d]  = (int)lrint(f * 2048.0);
+    }
+}
+
+extern "C" {
+
+int snk_orb_create(const snk_orb_params* params, int device, void* stream, snk_orb** out)
+{
+    SNK_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    SNK_REQUIRE(params != nullptr, "params is NULL");
+    SNK_REQUIRE(params->n_levels >= 1 && params->n_levels <= MAX_LEVELS, "n_levels must be 1..16");
+    SNK_REQUIRE(params->scale_factor > 1.0f, "scale_factor must be > 1");
+    SNK_REQUIRE(params->nfeatures >= 1 && params->nfeatures <= 100000, "nfeatures must be 1..100000");
+    SNK_REQUIRE(params->ini_th_fast >= 1 && params->ini_th_fast <= 254 && params->min_th_fast >= 1 &&
+                    params->min_th_fast <= 254,
+                "FAST thresholds must be 1..254");
+    if (params->level_cap != 0)
+    {
+        const int c = params->level_cap;
+        SNK_REQUIRE(c >= 256 && c <= 8192 && (c & (c - 1)) == 0, "level_cap must be a power of two in [256, 8192] (or 0)");
+    }
+    snk_orb* o = new snk_orb();
+    o->params  = *params;
+    int rc     = o->init(device, stream);
+    if (rc != SNK_OK)
+    {
+        delete o;
+        return rc;
+    }
+    *out = o;
+    return SNK_OK;
+}
+
+int snk_orb_destroy(snk_orb* o)
+{
+    if (!o) return SNK_OK;
+    (void)hipSetDevice(o->device);
+    for (auto& b : o->pyr) b.release();
+    o->tables.release();
+    o->img0.release();
+    o->cand.release();
+    o->cell_cnt.release();
+    o->sel.release();
+    o->sel_score.release();
+    o->sel_cnt.release();
+    o->cand_total.release();
+    o->out_kps.release();
+    o->out_desc.release();
+    o->out_n.release();
+    o->fini();
+    delete o;
+    return SNK_OK;
+}
+
+int snk_orb_sync(snk_orb* o)
+{
+    SNK_REQUIRE(o != nullptr, "orb is NULL");
+    SNK_HIP_CHECK(hipStreamSynchronize(o->stream));
+    return SNK_OK;
+}
+
+int snk_orb_configure(snk_orb* o, int width, int height, int max_batch)
+{
+    SNK_REQUIRE(o != nullptr, "orb is NULL");
+    SNK_REQUIRE(width >= 1 && height >= 1 && width <= 16384 && height <= 16384, "image size must be 1..16384");
+    SNK_REQUIRE(max_batch >= 1 && max_batch <= 65535, "max_batch must be 1..65535");
+    SNK_HIP_CHECK(hipSetDevice(o->device));
+    if (o->configured && o->width == width && o->height == height && o->max_batch >= max_batch) return SNK_OK;
+    SNK_HIP_CHECK(hipStreamSynchronize(o->stream));
+    int rc = compute_layout(o, width, height);
+    if (rc != SNK_OK) return rc;
+    Layout& L = o->lay;
+    // resize tables
+    size_t tab_ints = 0;
+    for (int l = 1; l < L.n_levels; ++l) tab_ints += 2 * (size_t)(L.lv[l].w + L.lv[l].h);
+    if ((rc = o->tables.reserve((tab_ints + 4) * sizeof(int))) != SNK_OK) return rc;
+    {
+        int* host = (int*)malloc((tab_ints + 4) * sizeof(int));
+        size_t at = 0;
+        for (int l = 1; l < L.n_levels; ++l)
+        {
+            LevelInfo& lv = L.lv[l];
+            int* dev      = o->tables.as<int>();
+            lv.xofs = dev + at;
+            lv.xw1  = dev + at + lv.w;
+            resize_tables(L.lv[l - 1].w, lv.w, host + at, host + at + lv.w);
+            at += 2 * (size_t)lv.w;
+            lv.yofs = dev + at;
+            lv.yw1  = dev + at + lv.h;
+            resize_tables(L.lv[l - 1].h, lv.h, host + at, host + at + lv.h);
+            at += 2 * (size_t)lv.h;
+        }
+        hipError_t e = hipMemcpy(o->tables.p, host, tab_ints * sizeof(int), hipMemcpyHostToDevice);
+        free(host);
+        SNK_HIP_CHECK(e);
+    }
+    for (int l = 1; l < L.n_levels; ++l)
+    {
+        if ((rc = o->pyr[l].reserve((size_t)L.lv[l].img_stride * max_batch + 64)) != SNK_OK) return rc;
+        L.lv[l].base = o->pyr[l].as<u8>();
+    }
+    const size_t cells = (size_t)(L.total_cells > 0 ? L.total_cells : 1) * max_batch;
+    const size_t slots = (size_t)(L.total_slots > 0 ? L.total_slots : 1) * max_batch;
+    if ((rc = o->cand.reserve(cells * CELL_SLOTS * sizeof(u32))) != SNK_OK) return rc;
+    if ((rc = o->cell_cnt.reserve(cells * sizeof(u16))) != SNK_OK) return rc;
+    if ((rc = o->sel.reserve(slots * sizeof(u32))) != SNK_OK) return rc;
+    if ((rc = o->sel_score.reserve(slots)) != SNK_OK) return rc;
+    if ((rc = o->sel_cnt.reserve((size_t)max_batch * MAX_LEVELS * sizeof(int))) != SNK_OK) return rc;
+    if ((rc = o->cand_total.reserve((size_t)max_batch * MAX_LEVELS * sizeof(int))) != SNK_OK) return rc;
+    // distribute kernel dynamic LDS
+    const size_t cap = (size_t)L.level_cap;
+    o->dist_lds      = cap * 8 + cap / 2 * 8 + cap * 2 * 2 + cap + (cap + 16) + cap;
+    SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(distribute_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->dist_lds));
+    o->width      = width;
+    o->height     = height;
+    o->max_batch  = max_batch;
+    o->configured = true;
+    return SNK_OK;
+}
+
+int snk_orb_max_keypoints(const snk_orb* o, int* out)
+{
+    SNK_REQUIRE(o != nullptr && out != nullptr, "NULL argument");
+    if (!o->configured)
+    {
+        set_error("snk_orb_configure has not been called");
+        return SNK_ERR_NOT_CONFIGURED;
+    }
+    *out = o->lay.total_slots;
+    return SNK_OK;
+}
+
+static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long image_stride, int batch,
+                        snk_keypoint* kps_dev, uint64_t* desc_dev, int32_t* n_dev, int out_cap)
+{
+    const Layout& L = o->lay;
+    // pyramid chain
+    for (int l = 1; l < L.n_levels; ++l)
+    {
+        const LevelInfo& d = L.lv[l];
+        const LevelInfo& s = L.lv[l - 1];
+        const u8* src      = l == 1 ? images_dev : s.base;
+        const int spitch   = l == 1 ? pitch : s.pitch;
+        const long long ss = l == 1 ? image_stride : s.img_stride;
+        dim3 grid(ceil_div(ceil_div(d.w, 4), 256), d.h, batch);
+        hipLaunchKernelGGL(resize_kernel, grid, dim3(256), 0, o->stream, src, spitch, ss, s.w, s.h, d.base, d.pitch,
+                           d.img_stride, d.w, d.h, d.xofs, d.xw1, d.yofs, d.yw1);
+        SNK_LAUNCH_CHECK();
+    }
+    if (L.total_cells > 0)
+    {
+        hipLaunchKernelGGL(fast_kernel, dim3(L.total_cells, batch), dim3(256), 0, o->stream, L, images_dev, pitch,
+                           image_stride, o->params.ini_th_fast, o->params.min_th_fast, o->cand.as<u32>(),
+                           o->cell_cnt.as<u16>());
+        SNK_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(distribute_kernel, dim3(L.n_levels, batch), dim3(DIST_THREADS), o->dist_lds, o->stream, L,
+                       o->cand.as<u32>(), o->cell_cnt.as<u16>(), o->sel.as<u32>(), o->sel_score.as<u8>(),
+                       o->sel_cnt.as<int>(), o->cand_total.as<int>());
+    SNK_LAUNCH_CHECK();
+    int max_slot = 1;
+    for (int l = 0; l < L.n_levels; ++l) max_slot = L.lv[l].slot_cap > max_slot ? L.lv[l].slot_cap : max_slot;
+    hipLaunchKernelGGL(describe_kernel, dim3(ceil_div(max_slot, 4), L.n_levels, batch), dim3(256), 0, o->stream, L,
+                       images_dev, pitch, image_stride, o->sel.as<u32>(), o->sel_score.as<u8>(), o->sel_cnt.as<int>(),
+                       kps_dev, (u64*)desc_dev, n_dev, out_cap);
+    SNK_LAUNCH_CHECK();
+    return SNK_OK;
+}
+
+int snk_orb_detect_batch_dev(snk_orb* o, const uint8_t* images_dev, int pitch, size_t image_stride, int batch,
+                             snk_keypoint* kps_dev, uint64_t* desc_dev, int32_t* n_dev, int out_cap)
+{
+    SNK_REQUIRE(o != nullptr, "orb is NULL");
+    if (!o->configured)
+    {
+        set_error("snk_orb_configure has not been called");
+        return SNK_ERR_NOT_CONFIGURED;
+    }
+    SNK_REQUIRE(batch >= 0 && batch <= o->max_batch, "batch exceeds the configured max_batch");
+    SNK_REQUIRE(images_dev && kps_dev && desc_dev && n_dev, "NULL device buffer");
+    SNK_REQUIRE(pitch >= o->width, "pitch smaller than the image width");
+    SNK_REQUIRE(out_cap >= 1, "out_cap must be >= 1");
+    if (batch == 0) return SNK_OK;
+    SNK_HIP_CHECK(hipSetDevice(o->device));
+    return run_pipeline(o, images_dev, pitch, (long long)image_stride, batch, kps_dev, desc_dev, n_dev, out_cap);
+}
+
+int snk_orb_detect(snk_orb* o, const uint8_t* img, int w, int h, int pitch, snk_keypoint* kps, uint64_t (*desc)[4],
+                   int capacity, int* n_out)
+{
+    SNK_REQUIRE(o != nullptr, "orb is NULL");
+    SNK_REQUIRE(n_out != nullptr, "n_out is NULL");
+    *n_out = 0;
+    SNK_REQUIRE(img != nullptr && w >= 1 && h >= 1 && pitch >= w, "bad image");
+    SNK_REQUIRE(capacity >= 0 && (capacity == 0 || (kps && desc)), "bad output buffers");
+    int rc;
+    if (!o->configured || o->width != w || o->height != h)
+        if ((rc = snk_orb_configure(o, w, h, o->max_batch > 0 ? o->max_batch : 1)) != SNK_OK) return rc;
+    SNK_HIP_CHECK(hipSetDevice(o->device));
+    const int dpitch = (w + 63) & ~63;
+    const int cap    = o->lay.total_slots > 0 ? o->lay.total_slots : 1;
+    if ((rc = o->img0.reserve((size_t)dpitch * h + 64)) != SNK_OK) return rc;
+    if ((rc = o->out_kps.reserve((size_t)cap * sizeof(snk_keypoint))) != SNK_OK) return rc;
+    if ((rc = o->out_desc.reserve((size_t)cap * 32)) != SNK_OK) return rc;
+    if ((rc = o->out_n.reserve(64)) != SNK_OK) return rc;
+    SNK_HIP_CHECK(hipMemcpy2DAsync(o->img0.p, dpitch, img, pitch, w, h, hipMemcpyHostToDevice, o->stream));
+    rc = run_pipeline(o, o->img0.as<u8>(), dpitch, (long long)dpitch * h, 1, o->out_kps.as<snk_keypoint>(),
+                      o->out_desc.as<uint64_t>(), o->out_n.as<int32_t>(), cap);
+    if (rc != SNK_OK) return rc;
+    int n = 0;
+    SNK_HIP_CHECK(hipMemcpyAsync(&n, o->out_n.p, sizeof(int), hipMemcpyDeviceToHost, o->stream));
+    SNK_HIP_CHECK(hipStreamSynchronize(o->stream));
+    if (n > capacity)
+    {
+        set_error("capacity %d too small for %d keypoints (see snk_orb_max_keypoints)", capacity, n);
+        *n_out = n;
+        return SNK_ERR_CAPACITY;
+    }
+    if (n > 0)
+    {
+        SNK_HIP_CHECK(hipMemcpy(kps, o->out_kps.p, (size_t)n * sizeof(snk_keypoint), hipMemcpyDeviceToHost));
+        SNK_HIP_CHECK(hipMemcpy(desc, o->out_desc.p, (size_t)n * 32, hipMemcpyDeviceToHost));
+    }
+    *n_out = n;
+    return SNK_OK;
+}
+
+int snk_orb_debug_fetch(snk_orb* o, int what, int image, int level, void* out, size_t cap_bytes, size_t* n_bytes)
+{
+    SNK_REQUIRE(o != nullptr && n_bytes != nullptr, "NULL argument");
+    *n_bytes = 0;
+    if (!o->configured)
+    {
+        set_error("snk_orb_configure has not been called");
+        return SNK_ERR_NOT_CONFIGURED;
+    }
+    const Layout& L = o->lay;
+    SNK_REQUIRE(level >= 0 && level < L.n_levels && image >= 0 && image < o->max_batch, "bad image / level");
+    SNK_HIP_CHECK(hipSetDevice(o->device));
+    SNK_HIP_CHECK(hipStreamSynchronize(o->stream));
+    const LevelInfo& lv = L.lv[level];
+    const void* src     = nullptr;
+    size_t bytes        = 0;
+    switch (what)
+    {
+        case SNK_ORB_DEBUG_PYRAMID:  // level >= 1: h rows of `pitch` bytes
+            SNK_REQUIRE(level >= 1, "level 0 is the caller's image");
+            src   = lv.base + (long long)image * lv.img_stride;
+            bytes = (size_t)lv.img_stride;
+            break;
+        case SNK_ORB_DEBUG_CELL_COUNTS:
+            src   = o->cell_cnt.as<u16>() + (long long)image * L.total_cells + lv.cell_off;
+            bytes = (size_t)lv.ncols * lv.nrows * sizeof(u16);
+            break;
+        case SNK_ORB_DEBUG_CELL_CANDIDATES:
+            src   = o->cand.as<u32>() + ((long long)image * L.total_cells + lv.cell_off) * CELL_SLOTS;
+            bytes = (size_t)lv.ncols * lv.nrows * CELL_SLOTS * sizeof(u32);
+            break;
+        case SNK_ORB_DEBUG_SELECTED:
+            src   = o->sel.as<u32>() + (long long)image * L.total_slots + lv.slot_off;
+            bytes = (size_t)lv.slot_cap * sizeof(u32);
+            break;
+        case SNK_ORB_DEBUG_SELECTED_COUNT:
+            src   = o->sel_cnt.as<int>() + image * MAX_LEVELS + level;
+            bytes = sizeof(int);
+            break;
+        case SNK_ORB_DEBUG_LEVEL_INFO:
+        {
+            int info[8] = {lv.w, lv.h, lv.pitch, lv.ncols, lv.nrows, lv.wcell, lv.hcell, lv.nfeat};
+            SNK_REQUIRE(cap_bytes >= sizeof(info), "buffer too small");
+            memcpy(out, info, sizeof(info));
+            *n_bytes = sizeof(info);
+            return SNK_OK;
+        }
+        default: SNK_REQUIRE(false, "unknown debug selector");
+    }
+    SNK_REQUIRE(out != nullptr && cap_bytes >= bytes, "buffer too small");
+    if (bytes) SNK_HIP_CHECK(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
+    *n_bytes = bytes;
+    return SNK_OK;
+}
+}

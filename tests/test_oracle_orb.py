@@ -141,7 +141,7 @@ def test_candidate_cap_truncation_is_per_cell_topk(orc):
     cells = {}
     for c in full:
         cells.setdefault(int(c["cell"]), []).append(c)
-    k = max(kk for kk in range(0, 400) if sum(min(len(v), kk) for v in cells.values()) <= cap)
+    k = max(kk for kk in range(0, 65) if sum(min(len(v), kk) for v in cells.values()) <= cap)
     want = []
     for cell in sorted(cells):
         v = cells[cell]

@@ -1,0 +1,145 @@
+"""GPU: HIP ORB extractor vs the CPU oracle through the C ABI — bit-exact keypoints and
+descriptors (integer pipeline + explicitly ordered float), with stage-by-stage checks so a
+mismatch points at the kernel that caused it."""
+import numpy as np
+import pytest
+
+from helpers import SEED
+
+pytestmark = pytest.mark.gpu
+
+
+def stage_check(ext, orc, img, p):
+    """Compare pyramid, per-cell candidates and per-level selections with the oracle."""
+    from snake_slam_amd import orb as O
+
+    levels, L = orc.pyramid(p, img)
+    for l in range(L.n_levels):
+        info = ext.debug_fetch(O.DEBUG_LEVEL_INFO, 0, l, np.int32)
+        w, h, pitch, ncols, nrows, wcell, hcell, nfeat = [int(v) for v in info]
+        assert (w, h, nfeat) == (L.w[l], L.h[l], L.nfeat[l]), f"level {l} geometry"
+        if l >= 1:
+            pyr = ext.debug_fetch(O.DEBUG_PYRAMID, 0, l, np.uint8).reshape(h, pitch)[:, :w]
+            assert np.array_equal(pyr, levels[l]), f"pyramid level {l} differs"
+        cand = orc.candidates(levels[l], p.ini_th, p.min_th, 8192)       # after the level budget
+        cand_cells = orc.candidates(levels[l], p.ini_th, p.min_th, 60000)  # only the 64-per-cell rule
+        want = {}
+        for c in cand_cells:
+            want.setdefault(int(c["cell"]), set()).add((int(c["x"]), int(c["y"]), int(c["score"])))
+        cnt = ext.debug_fetch(O.DEBUG_CELL_COUNTS, 0, l, np.uint16)
+        cc = ext.debug_fetch(O.DEBUG_CELL_CANDIDATES, 0, l, np.uint32).reshape(-1, 64)
+        for cell in range(ncols * nrows):
+            ci, cj = divmod(cell, ncols)
+            x0, y0 = 19 + cj * wcell, 19 + ci * hcell
+            got = set()
+            for k in cc[cell, : min(int(cnt[cell]), 64)]:
+                k = int(k)
+                got.add((x0 + 63 - (k & 63), y0 + 63 - ((k >> 6) & 63), k >> 12))
+            assert got == want.get(cell, set()), f"level {l} cell {cell}: candidates differ"
+        sel = orc.distribute(cand, w, h, L.nfeat[l])
+        n_sel = int(ext.debug_fetch(O.DEBUG_SELECTED_COUNT, 0, l, np.int32)[0])
+        got_sel = ext.debug_fetch(O.DEBUG_SELECTED, 0, l, np.uint32)[:n_sel]
+        want_sel = [(int(cand[i]["x"]) | (int(cand[i]["y"]) << 16)) for i in sel]
+        assert [int(v) for v in got_sel] == want_sel, f"level {l}: selection differs"
+
+
+def check_image(orc, img, nfeatures=1000, n_levels=4, scale=1.2, ini=20, mn=7, stages=True):
+    from snake_slam_amd.orb import ORBExtractor
+
+    ext = ORBExtractor(nfeatures, scale, n_levels, ini, mn)
+    try:
+        kps, desc = ext.Detect(img)
+        p = orc.orb_params(nfeatures, scale, n_levels, ini, mn)
+        if stages:
+            stage_check(ext, orc, np.ascontiguousarray(img), p)
+        wk, wd = orc.orb_detect(p, img)
+        assert len(kps) == len(wk)
+        for f in ("octave", "x", "y", "size", "response", "angle"):
+            assert np.array_equal(kps[f], wk[f]), f"keypoint field {f} differs"
+        assert np.array_equal(desc, wd), "descriptors differ"
+        return len(kps)
+    finally:
+        ext.close()
+
+
+def test_euroc_frame_parity(orc):
+    from snake_slam_amd import synth
+
+    left, right = synth.stereo_frame(0)
+    assert check_image(orc, left) >= 1000
+    assert check_image(orc, right) >= 1000
+
+
+def test_kitti_shape_parity(orc):
+    from snake_slam_amd import synth
+
+    left, _ = synth.stereo_frame(1, 1241, 376, n_rects=600)
+    assert check_image(orc, left, 2000, 7) >= 1500
+
+
+@pytest.mark.parametrize("shape", [(480, 752), (376, 1241), (200, 120), (97, 131), (70, 75), (40, 45)])
+def test_noise_images_hit_the_candidate_budget(orc, shape):
+    """Uniform noise: hundreds of corners per cell -> exercises the 64-per-cell cap, the level
+    budget reduction and heavy score ties."""
+    rng = np.random.default_rng(SEED + shape[0])
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    check_image(orc, img, 1000, 4)
+
+
+def test_low_contrast_uses_min_threshold(orc):
+    rng = np.random.default_rng(9)
+    img = (100 + rng.integers(0, 3, (300, 400))).astype(np.uint8)
+    for _ in range(60):
+        y, x = int(rng.integers(20, 260)), int(rng.integers(20, 360))
+        img[y:y + int(rng.integers(6, 30)), x:x + int(rng.integers(6, 30))] += np.uint8(rng.integers(9, 19))
+    n = check_image(orc, img, 500, 3)
+    assert n > 20
+
+
+def test_flat_and_tiny_images(orc):
+    assert check_image(orc, np.full((480, 752), 128, np.uint8)) == 0
+    assert check_image(orc, np.zeros((40, 45), np.uint8), 100, 4) == 0
+
+
+def test_pitch_and_params_variants(orc):
+    from snake_slam_amd import synth
+
+    left, _ = synth.stereo_frame(2, 640, 400, n_rects=300)
+    padded = np.zeros((400, 700), np.uint8)
+    padded[:, :640] = left
+    check_image(orc, padded[:, :640], 1400, 3, 1.2, 20, 3)      # reference configs/saiga.ini
+    check_image(orc, left, 300, 8, 1.3, 30, 10, stages=False)
+    check_image(orc, left, 50, 1, 1.2, 20, 7)
+
+
+def test_batch_dev_matches_single(orc):
+    import torch
+    from snake_slam_amd import synth
+    from snake_slam_amd.orb import ORBExtractor, KEYPOINT_DTYPE
+
+    B = 5
+    imgs = [synth.stereo_frame(i)[i % 2] for i in range(B)]
+    imgs[3] = np.full((480, 752), 7, np.uint8)  # an empty frame inside the batch
+    pitch = 768
+    host = np.zeros((B, 480, pitch), np.uint8)
+    for i, im in enumerate(imgs):
+        host[i, :, :752] = im
+    ext = ORBExtractor(1000, 1.2, 4, 20, 7)
+    cap = ext.configure(752, 480, B)
+    dev = torch.device("cuda:0")
+    d_img = torch.from_numpy(host).to(dev)
+    d_kps = torch.zeros((B, cap, 24), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((B, cap, 4), dtype=torch.int64, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ext.detect_batch_dev(d_img, d_kps, d_desc, d_n)
+    ext.sync()
+    n = d_n.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(KEYPOINT_DTYPE).reshape(B, cap)
+    desc = d_desc.cpu().numpy().view(np.uint64)
+    p = orc.orb_params()
+    for i in range(B):
+        wk, wd = orc.orb_detect(p, imgs[i])
+        assert n[i] == len(wk), f"image {i}"
+        assert np.array_equal(kps[i, : n[i]], wk.astype(KEYPOINT_DTYPE)) and np.array_equal(desc[i, : n[i]], wd)
+    ext.close()
