@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path on MI355X.
+
+Metric (BASELINE.json): frames/s of ORB extract + match at 752x480.  One "step" = one pass of
+the per-frame feature pipeline over a batch of B synthetic EuRoC-shaped STEREO frames resident
+in HBM: ORB extraction of the left and right image (2B images: pyramid, FAST cells, quadtree
+distribution, angle + blur + BRIEF), undistort/rectify, the Preprocess stereo row-band matcher,
+and the brute-force kNN-2 Hamming matcher + ratio filter between the two descriptor sets.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0.  `value` is whole-job frames/s (all ranks; weak scaling: every
+GPU processes its own batch, no data-path collective; one RCCL all_gather of a per-rank result
+block after the timed region).  `roofline` is for the dominant kernel (the FAST cell kernel),
+timed with HIP events recorded on the launch stream inside the timed region.  `cpu_baseline` is
+the CPU oracle (a restatement of the reference path — NOT the reference binary, which cannot be
+built here) timed on this box's host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+W, H = 752, 480
+ORB = dict(nfeatures=1000, scale_factor=1.2, n_levels=4, ini_th_fast=20, min_th_fast=7)  # reference configs/euroc.ini:32-36
+BF_SYNTH = 47.9 * 2.5  # bf such that the synthetic disparities (2..60 px) fall inside [0, bf/2]
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+N_DISTINCT = 8         # distinct synthetic stereo pairs, tiled to fill the batch
+
+
+def pyramid_pixels():
+    s, tot = 1.0, 0
+    f = np.float32(1.0)
+    for _ in range(ORB["n_levels"]):
+        inv = np.float32(1.0) / f
+        tot += int(np.rint(np.float32(W) * inv)) * int(np.rint(np.float32(H) * inv))
+        f = np.float32(f * np.float32(ORB["scale_factor"]))
+    return tot
+
+
+def cpu_baseline(frames, seconds_budget=12.0):
+    """Oracle pipeline on host cores with the reference's thread configuration: extractor 2
+    threads (fd_threads), matchers 4 threads (num_tracking_threads)."""
+    from oracle import oracle as orc
+
+    orc.build()
+    p = orc.orb_params(ORB["nfeatures"], ORB["scale_factor"], ORB["n_levels"], ORB["ini_th_fast"], ORB["min_th_fast"])
+    ls = (np.float32(ORB["scale_factor"]) ** np.arange(ORB["n_levels"])).astype(np.float32)
+    rect = orc.rectification((1.0, 1.0, 0.0, 0.0))
+    done, t0 = 0, time.perf_counter()
+    while True:
+        left, right = frames[done % len(frames)]
+        kl, dl = orc.orb_detect(p, left, threads=2)
+        kr, dr = orc.orb_detect(p, right, threads=2)
+        rl, _ = orc.rectify(rect, kl)
+        rr, _ = orc.rectify(rect, kr)
+        orc.stereo_match(rl, dl, rr, dr, BF_SYNTH, ls, True)
+        knn = orc.bf_knn2(dl, dr, threads=4)
+        orc.bf_filter(knn, 60, 0.8)
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= seconds_budget or done >= 400:
+            break
+    return {"value": round(done / el, 3), "unit": "frames/s", "cores": 4, "kind": "port",
+            "sample": f"{done} stereo frames 752x480 (extract L+R with 2 threads, rectify, stereo match, "
+                      f"BF kNN-2 with 4 threads + filter) in {el:.1f} s; CPU restatement of the reference path, not the reference binary"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="stereo frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from snake_slam_amd import synth
+    from snake_slam_amd.matcher import BruteForceMatcher, Preprocess, Rectification
+    from snake_slam_amd.orb import ORBExtractor
+
+    B = args.batch
+    # ---- synthetic frames (seeded; a few distinct pairs tiled over the batch), resident in HBM ----
+    frames = [synth.stereo_frame(rank * N_DISTINCT + i, W, H) for i in range(N_DISTINCT)]
+    pitch = 768
+    host = np.zeros((2 * B, H, pitch), np.uint8)  # [0,B): left images, [B,2B): right images
+    for b in range(B):
+        l, r = frames[b % N_DISTINCT]
+        host[b, :, :W] = l
+        host[B + b, :, :W] = r
+    images = torch.from_numpy(host).to(dev)
+    del host
+
+    stream = torch.cuda.Stream(device=dev)
+    sh = stream.cuda_stream
+    ext = ORBExtractor(**ORB, device=local, stream=sh)
+    cap = ext.configure(W, H, 2 * B)
+    pre = Preprocess(local, sh)
+    bf = BruteForceMatcher(local, sh)
+    rect = Rectification.make((1.0, 1.0, 0.0, 0.0))  # synthetic pairs are already rectified
+    level_scale = (np.float32(ORB["scale_factor"]) ** np.arange(ORB["n_levels"])).astype(np.float32)
+
+    kps = torch.zeros((2 * B, cap, 24), dtype=torch.uint8, device=dev)
+    desc = torch.zeros((2 * B, cap, 4), dtype=torch.int64, device=dev)
+    nkp = torch.zeros(2 * B, dtype=torch.int32, device=dev)
+    kp64 = torch.zeros((2 * B, cap, 24), dtype=torch.uint8, device=dev)
+    right_points = torch.full((B, cap), -1000.0, dtype=torch.float32, device=dev)
+    depth = torch.full((B, cap), -1000.0, dtype=torch.float32, device=dev)
+    n_stereo = torch.zeros(B, dtype=torch.int32, device=dev)
+    knn = torch.zeros((B, cap, 4), dtype=torch.int32, device=dev)
+    pairs = torch.zeros((B, cap, 2), dtype=torch.int32, device=dev)
+    n_pairs = torch.zeros(B, dtype=torch.int32, device=dev)
+
+    def step():
+        ext.detect_batch_dev(images, kps, desc, nkp)
+        pre.rectify_batch_dev(rect, kps, nkp, kp64)
+        pre.match_batch_dev(kp64[:B], desc[:B], nkp[:B], kp64[B:], desc[B:], nkp[B:], BF_SYNTH, level_scale, True,
+                            right_points, depth, n_stereo)
+        bf.knn2_batch_dev(desc[:B], nkp[:B], desc[B:], nkp[B:], knn)
+        bf.filter_batch_dev(knn, nkp[:B], 60, 0.8, pairs, n_pairs)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            right_points.fill_(-1000.0)
+            depth.fill_(-1000.0)
+            step()
+        torch.cuda.synchronize()
+        ext.set_profiling(not args.no_stage_events)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+    stage_ms, n_calls = ext.stage_times() if not args.no_stage_events else ([0, 0, 0, 0], 0)
+    ext.set_profiling(False)
+
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+
+    # ---- result gather: one fixed-size block per rank (RCCL all_gather over xGMI) ----
+    block = torch.tensor([float(B * args.steps), float(nkp.sum().item()), float(n_stereo.sum().item()),
+                          float(n_pairs.sum().item()), t1 - t0, 0.0, 0.0, 0.0], dtype=torch.float64, device=dev)
+    if world > 1:
+        blocks = [torch.zeros_like(block) for _ in range(world)]
+        dist.all_gather(blocks, block)
+    else:
+        blocks = [block]
+
+    if rank == 0:
+        total_frames = sum(float(b[0].item()) for b in blocks)
+        value = total_frames / elapsed
+        P = pyramid_pixels()
+        out = {
+            "metric": "frames/s ORB extract+match @752x480",
+            "value": round(value, 2),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": f"synthetic: seeded 752x480 stereo pairs (gradient + 400 rectangles + noise), {N_DISTINCT} distinct pairs tiled over the batch, resident in HBM",
+            "config": {"workload": "EuRoC stereo 752x480: ORB extract (L+R, 1000 feat, 4 levels) + stereo row-band match + BF kNN-2 Hamming match",
+                       "frames_per_gpu_per_step": B, "images_per_frame": 2, "orb": ORB,
+                       "parallelism": f"{world} x independent batches (one per GPU), RCCL all_gather of results only"},
+            "keypoints_per_image": round(float(blocks[0][1].item()) / (2 * B), 1),
+            "stereo_matches_per_frame": round(float(blocks[0][2].item()) / B, 1),
+            "bf_pairs_per_frame": round(float(blocks[0][3].item()) / B, 1),
+        }
+        if n_calls > 0:
+            fast_ms = stage_ms[1] / n_calls
+            alg_bytes = P * 2 * B  # read every pyramid pixel once (the FAST+score pass of A_orb)
+            achieved = alg_bytes / (fast_ms * 1e-3) / 1e9
+            traffic = None
+            tj = ROOT / "profiles" / "fast_kernel_traffic.json"
+            if tj.exists():
+                try:
+                    t = json.loads(tj.read_text())
+                    if t.get("images_per_launch") == 2 * B:
+                        traffic = t.get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "hbm", "kernel": "fast_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                               "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(fast_ms, 4)}
+            out["stage_ms_per_step"] = {k: round(v / n_calls, 4) for k, v in zip(["pyramid", "fast", "distribute", "describe"], stage_ms)}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(frames)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

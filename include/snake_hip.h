@@ -175,6 +175,13 @@ SNK_API int snk_orb_detect_batch_dev(snk_orb* o, const uint8_t* images_dev, int 
                                      int batch, snk_keypoint* kps_dev, uint64_t* desc_dev, int32_t* n_dev,
                                      int out_cap);
 
+/* Optional per-stage timing with HIP events recorded on the handle's stream around the four
+ * kernel stages of every detect call (pyramid, FAST cells, distribution, descriptors).
+ * snk_orb_stage_times synchronises, returns the summed milliseconds per stage over the calls since
+ * the last query (ms[4]) and their number, and resets the accumulation. */
+SNK_API int snk_orb_set_profiling(snk_orb* o, int enable);
+SNK_API int snk_orb_stage_times(snk_orb* o, float* ms, int* n_calls);
+
 /* Intermediate results of the last call (tests / debugging). */
 enum
 {
@@ -187,6 +194,31 @@ enum
 };
 SNK_API int snk_orb_debug_fetch(snk_orb* o, int what, int image, int level, void* out, size_t cap_bytes,
                                 size_t* n_bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * Preprocess: undistort / rectify keypoints
+ * ------------------------------------------------------------------------------------------ */
+
+/* The fields of Saiga::Rectification that Snake uses (rect_left / rect_right,
+ * Snake/System/SnakeGlobal.h:107-108; filled by Snake/Preprocess/StereoTransforms.cpp:58-68).
+ * D_src is the rational radial-tangential model in the order k1 k2 k3 k4 k5 k6 p1 p2. */
+typedef struct snk_rectification
+{
+    double K_src[4]; /* fx fy cx cy */
+    double D_src[8];
+    double R[9];     /* row-major 3x3 */
+    double K_dst[4]; /* fx fy cx cy */
+    double bf;
+} snk_rectification;
+
+/* Replaces the per-keypoint body of Snake::Preprocess::undistortKeypoints
+ * (Snake/Preprocess/Preprocess.cpp:55-77) and Rectification::Forward as applied in
+ * StereoMatching (Preprocess.cpp:140-150): out[i] = rectified pixel position with angle / octave
+ * copied, normalized[i] = the point stored in frame.normalized_points (may be NULL). */
+SNK_API int snk_rectify(snk_matcher* m, const snk_rectification* rect, const snk_keypoint* kps, int n, snk_kp64* out,
+                        double (*normalized)[2]);
+SNK_API int snk_rectify_batch_dev(snk_matcher* m, const snk_rectification* rect, const snk_keypoint* kps_dev,
+                                  const int32_t* n_dev, int cap, int batch, snk_kp64* out_dev, double* normalized_dev);
 
 #ifdef __cplusplus
 }

@@ -199,3 +199,27 @@ def orb_detect(p: OrbParams, img: np.ndarray, level_cap: int = 0, threads: int =
     if n < 0:
         raise RuntimeError(f"orc_orb_detect failed: {n}")
     return kps[:n].copy(), desc[:n].copy()
+
+
+# ------------------------------------------------------------------ Preprocess -----------------
+class Rectification(C.Structure):
+    _fields_ = [("K_src", C.c_double * 4), ("D_src", C.c_double * 8), ("R", C.c_double * 9), ("K_dst", C.c_double * 4),
+                ("bf", C.c_double)]
+
+
+def rectification(K_src, D_src=None, R=None, K_dst=None, bf=0.0) -> Rectification:
+    r = Rectification()
+    r.K_src[:] = list(K_src)
+    r.D_src[:] = list(D_src) if D_src is not None else [0.0] * 8
+    r.R[:] = list(np.asarray(R, np.float64).reshape(9)) if R is not None else [1, 0, 0, 0, 1, 0, 0, 0, 1]
+    r.K_dst[:] = list(K_dst) if K_dst is not None else list(K_src)
+    r.bf = bf
+    return r
+
+
+def rectify(rect: Rectification, kps):
+    k = np.ascontiguousarray(kps, KEYPOINT)
+    out = np.zeros(k.shape[0], KP64)
+    norm = np.zeros((k.shape[0], 2), np.float64)
+    lib().orc_rectify(C.byref(rect), _p(k), C.c_int(k.shape[0]), _p(out), _p(norm))
+    return out, norm

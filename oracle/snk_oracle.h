@@ -91,6 +91,18 @@ int orc_orb_pyramid(const orc_orb_params* p, const uint8_t* img, int w, int h, i
 int orc_orb_detect(const orc_orb_params* p, const uint8_t* img, int w, int h, int pitch, orc_keypoint* kps,
                    uint64_t (*desc)[4], int capacity, int level_cap, int threads);
 
+/* ---- preprocess_oracle.c ---- */
+typedef struct orc_rectification
+{
+    double K_src[4]; /* fx fy cx cy */
+    double D_src[8]; /* k1 k2 k3 k4 k5 k6 p1 p2 */
+    double R[9];     /* row-major */
+    double K_dst[4];
+    double bf;
+} orc_rectification;
+void orc_undistort_gn(const double* D, double px, double py, double* ox, double* oy);
+void orc_rectify(const orc_rectification* R, const orc_keypoint* kps, int n, orc_kp64* out, double (*normalized)[2]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,8 @@ SIGNATURES = {
     "snk_bf_filter_batch_dev": (i32, [vp, vp, vp, i32, i32, i32, f32, vp, vp]),
     "snk_stereo_match": (i32, [vp, vp, vp, i32, vp, vp, i32, f64, vp, i32, i32, vp, vp, C.POINTER(i32)]),
     "snk_stereo_match_batch_dev": (i32, [vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, f64, vp, i32, i32, vp, vp, vp]),
+    "snk_rectify": (i32, [vp, vp, vp, i32, vp, vp]),
+    "snk_rectify_batch_dev": (i32, [vp, vp, vp, vp, i32, i32, vp, vp]),
     "snk_orb_create": (i32, [vp, i32, vp, C.POINTER(vp)]),
     "snk_orb_destroy": (i32, [vp]),
     "snk_orb_sync": (i32, [vp]),
@@ -52,6 +54,8 @@ SIGNATURES = {
     "snk_orb_max_keypoints": (i32, [vp, C.POINTER(i32)]),
     "snk_orb_detect": (i32, [vp, vp, i32, i32, i32, vp, vp, i32, C.POINTER(i32)]),
     "snk_orb_detect_batch_dev": (i32, [vp, vp, i32, C.c_size_t, i32, vp, vp, vp, i32]),
+    "snk_orb_set_profiling": (i32, [vp, i32]),
+    "snk_orb_stage_times": (i32, [vp, vp, C.POINTER(i32)]),
     "snk_orb_debug_fetch": (i32, [vp, i32, i32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
 }
 
@@ -66,6 +70,13 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: build it with `python -m snake_slam_amd.build` "
             "(or __graft_entry__.build()).  There is no CPU fallback."
         )
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64 (SONAME libamdhip64.so.7).
+    # Importing torch first makes the loader resolve this library's DT_NEEDED to that same copy
+    # instead of mapping /opt/rocm's next to it (two runtimes in one process fight over the GPU).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
@@ -73,6 +84,16 @@ def load() -> C.CDLL:
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def hip_runtimes_mapped() -> list[str]:
+    """Distinct libamdhip64 files mapped into this process (should be exactly one)."""
+    out = set()
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                out.add(line.split()[-1])
+    return sorted(out)
 
 
 def check(rc: int, what: str = "") -> None:

@@ -266,10 +266,7 @@ __global__ __launch_bounds__(256) void stereo_kernel(const snk_kp64* __restrict_
 
 using namespace snk;
 
-struct snk_matcher : HandleBase
-{
-    DevBuf q, t, out, aux, aux2, cnt;
-};
+#include "matcher_handle.hpp"
 
 extern "C" {
 

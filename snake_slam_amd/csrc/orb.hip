@@ -17,6 +17,9 @@
 //                      4 ballots assemble the 256-bit descriptor
 #include "common.hpp"
 
+#include <array>
+#include <vector>
+
 namespace snk
 {
 namespace
@@ -809,6 +812,10 @@ struct snk_orb : HandleBase
     DevBuf out_kps, out_desc, out_n;  // host-API staging
     int pitch0_host = 0;
     size_t dist_lds = 0;
+    // optional per-stage timing with HIP events on the handle's stream (bench.py roofline leg)
+    bool profiling = false;
+    std::vector<std::array<hipEvent_t, 5>> ev_sets;  // resize | fast | distribute | describe boundaries
+    size_t ev_used = 0;
 };
 
 static int compute_layout(snk_orb* o, int w, int h)
@@ -939,6 +946,8 @@ int snk_orb_destroy(snk_orb* o)
     o->out_kps.release();
     o->out_desc.release();
     o->out_n.release();
+    for (auto& e : o->ev_sets)
+        for (auto& x : e) (void)hipEventDestroy(x);
     o->fini();
     delete o;
     return SNK_OK;
@@ -1027,6 +1036,18 @@ static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long i
                         snk_keypoint* kps_dev, uint64_t* desc_dev, int32_t* n_dev, int out_cap)
 {
     const Layout& L = o->lay;
+    std::array<hipEvent_t, 5>* ev = nullptr;
+    if (o->profiling)
+    {
+        if (o->ev_used == o->ev_sets.size())
+        {
+            std::array<hipEvent_t, 5> e{};
+            for (auto& x : e) SNK_HIP_CHECK(hipEventCreate(&x));
+            o->ev_sets.push_back(e);
+        }
+        ev = &o->ev_sets[o->ev_used++];
+        SNK_HIP_CHECK(hipEventRecord((*ev)[0], o->stream));
+    }
     // pyramid chain
     for (int l = 1; l < L.n_levels; ++l)
     {
@@ -1040,6 +1061,7 @@ static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long i
                            d.img_stride, d.w, d.h, d.xofs, d.xw1, d.yofs, d.yw1);
         SNK_LAUNCH_CHECK();
     }
+    if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[1], o->stream));
     if (L.total_cells > 0)
     {
         hipLaunchKernelGGL(fast_kernel, dim3(L.total_cells, batch), dim3(256), 0, o->stream, L, images_dev, pitch,
@@ -1047,16 +1069,19 @@ static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long i
                            o->cell_cnt.as<u16>());
         SNK_LAUNCH_CHECK();
     }
+    if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[2], o->stream));
     hipLaunchKernelGGL(distribute_kernel, dim3(L.n_levels, batch), dim3(DIST_THREADS), o->dist_lds, o->stream, L,
                        o->cand.as<u32>(), o->cell_cnt.as<u16>(), o->sel.as<u32>(), o->sel_score.as<u8>(),
                        o->sel_cnt.as<int>(), o->cand_total.as<int>());
     SNK_LAUNCH_CHECK();
+    if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[3], o->stream));
     int max_slot = 1;
     for (int l = 0; l < L.n_levels; ++l) max_slot = L.lv[l].slot_cap > max_slot ? L.lv[l].slot_cap : max_slot;
     hipLaunchKernelGGL(describe_kernel, dim3(ceil_div(max_slot, 4), L.n_levels, batch), dim3(256), 0, o->stream, L,
                        images_dev, pitch, image_stride, o->sel.as<u32>(), o->sel_score.as<u8>(), o->sel_cnt.as<int>(),
                        kps_dev, (u64*)desc_dev, n_dev, out_cap);
     SNK_LAUNCH_CHECK();
+    if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[4], o->stream));
     return SNK_OK;
 }
 
@@ -1115,6 +1140,34 @@ int snk_orb_detect(snk_orb* o, const uint8_t* img, int w, int h, int pitch, snk_
         SNK_HIP_CHECK(hipMemcpy(desc, o->out_desc.p, (size_t)n * 32, hipMemcpyDeviceToHost));
     }
     *n_out = n;
+    return SNK_OK;
+}
+
+int snk_orb_set_profiling(snk_orb* o, int enable)
+{
+    SNK_REQUIRE(o != nullptr, "orb is NULL");
+    SNK_HIP_CHECK(hipSetDevice(o->device));
+    SNK_HIP_CHECK(hipStreamSynchronize(o->stream));
+    o->profiling = enable != 0;
+    o->ev_used   = 0;
+    return SNK_OK;
+}
+
+int snk_orb_stage_times(snk_orb* o, float* ms /* 4: resize, fast, distribute, describe */, int* n_calls)
+{
+    SNK_REQUIRE(o != nullptr && ms != nullptr && n_calls != nullptr, "NULL argument");
+    SNK_HIP_CHECK(hipSetDevice(o->device));
+    SNK_HIP_CHECK(hipStreamSynchronize(o->stream));
+    for (int k = 0; k < 4; ++k) ms[k] = 0.0f;
+    for (size_t i = 0; i < o->ev_used; ++i)
+        for (int k = 0; k < 4; ++k)
+        {
+            float t = 0.0f;
+            SNK_HIP_CHECK(hipEventElapsedTime(&t, o->ev_sets[i][k], o->ev_sets[i][k + 1]));
+            ms[k] += t;
+        }
+    *n_calls   = (int)o->ev_used;
+    o->ev_used = 0;
     return SNK_OK;
 }
 

@@ -1,0 +1,132 @@
+// Snake::Preprocess::undistortKeypoints / Rectification::Forward on the device
+// (reference Snake/Preprocess/Preprocess.cpp:55-77,140-150): per keypoint, fp64,
+// unproject (K_src) -> Gauss-Newton undistort -> rotate (R) -> divide -> project (K_dst).
+// One thread per keypoint; the arithmetic is a fixed sequence of IEEE fp64 operations
+// (library built with -ffp-contract=off) so it matches the scalar restatement bit for bit.
+#include "matcher_handle.hpp"
+
+namespace snk
+{
+namespace
+{
+struct RectDev
+{
+    double K_src[4], D[8], R[9], K_dst[4];
+};
+
+__device__ __forceinline__ void distort(const double* D, double x, double y, double& xd, double& yd, double (&J)[4])
+{
+    const double k1 = D[0], k2 = D[1], k3 = D[2], k4 = D[3], k5 = D[4], k6 = D[5], p1 = D[6], p2 = D[7];
+    const double x2 = x * x, y2 = y * y, xy = x * y;
+    const double r2 = x2 + y2, r4 = r2 * r2, r6 = r4 * r2;
+    const double num = 1.0 + k1 * r2 + k2 * r4 + k3 * r6;
+    const double den = 1.0 + k4 * r2 + k5 * r4 + k6 * r6;
+    const double rad = num / den;
+    xd = x * rad + 2.0 * p1 * xy + p2 * (r2 + 2.0 * x2);
+    yd = y * rad + p1 * (r2 + 2.0 * y2) + 2.0 * p2 * xy;
+    const double dnum = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r4;
+    const double dden = k4 + 2.0 * k5 * r2 + 3.0 * k6 * r4;
+    const double drad = (dnum * den - num * dden) / (den * den);
+    J[0] = rad + x * drad * 2.0 * x + 2.0 * p1 * y + p2 * (2.0 * x + 4.0 * x);
+    J[1] = x * drad * 2.0 * y + 2.0 * p1 * x + p2 * 2.0 * y;
+    J[2] = y * drad * 2.0 * x + p1 * 2.0 * x + 2.0 * p2 * y;
+    J[3] = rad + y * drad * 2.0 * y + p1 * (2.0 * y + 4.0 * y) + 2.0 * p2 * x;
+}
+
+__global__ __launch_bounds__(256) void rectify_kernel(RectDev rc, const snk_keypoint* __restrict__ kps,
+                                                      const int* __restrict__ n_dev, int cap, int n_host,
+                                                      snk_kp64* __restrict__ out, double2* __restrict__ normalized)
+{
+    const int b = blockIdx.y;
+    int n       = n_dev ? n_dev[b] : n_host;
+    n           = n < cap ? n : cap;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const snk_keypoint kp = kps[(size_t)b * cap + i];
+    const double px = ((double)kp.x - rc.K_src[2]) / rc.K_src[0];
+    const double py = ((double)kp.y - rc.K_src[3]) / rc.K_src[1];
+    double x = px, y = py;
+#pragma unroll 1
+    for (int it = 0; it < 5; ++it)
+    {
+        double xd, yd, J[4];
+        distort(rc.D, x, y, xd, yd, J);
+        const double rx = xd - px, ry = yd - py;
+        const double det = J[0] * J[3] - J[1] * J[2];
+        const double dx  = (J[3] * rx - J[1] * ry) / det;
+        const double dy  = (J[0] * ry - J[2] * rx) / det;
+        x = x - dx;
+        y = y - dy;
+    }
+    const double rx = rc.R[0] * x + rc.R[1] * y + rc.R[2];
+    const double ry = rc.R[3] * x + rc.R[4] * y + rc.R[5];
+    const double rz = rc.R[6] * x + rc.R[7] * y + rc.R[8];
+    const double nx = rx / rz, ny = ry / rz;
+    if (normalized) normalized[(size_t)b * cap + i] = make_double2(nx, ny);
+    snk_kp64 o;
+    o.x      = rc.K_dst[0] * nx + rc.K_dst[2];
+    o.y      = rc.K_dst[1] * ny + rc.K_dst[3];
+    o.angle  = kp.angle;
+    o.octave = kp.octave;
+    out[(size_t)b * cap + i] = o;
+}
+
+int to_dev(const snk_rectification* r, RectDev* d)
+{
+    SNK_REQUIRE(r != nullptr, "rectification is NULL");
+    SNK_REQUIRE(r->K_src[0] != 0.0 && r->K_src[1] != 0.0, "K_src focal length is zero");
+    memcpy(d->K_src, r->K_src, sizeof(d->K_src));
+    memcpy(d->D, r->D_src, sizeof(d->D));
+    memcpy(d->R, r->R, sizeof(d->R));
+    memcpy(d->K_dst, r->K_dst, sizeof(d->K_dst));
+    return SNK_OK;
+}
+}  // namespace
+}  // namespace snk
+
+using namespace snk;
+
+extern "C" {
+
+int snk_rectify_batch_dev(snk_matcher* m, const snk_rectification* rect, const snk_keypoint* kps_dev,
+                          const int32_t* n_dev, int cap, int batch, snk_kp64* out_dev, double* normalized_dev)
+{
+    SNK_REQUIRE(m != nullptr, "matcher is NULL");
+    SNK_REQUIRE(batch >= 0 && cap >= 0, "bad sizes");
+    SNK_REQUIRE(kps_dev && n_dev && out_dev, "NULL device buffer");
+    RectDev rc;
+    int st = to_dev(rect, &rc);
+    if (st != SNK_OK) return st;
+    if (batch == 0 || cap == 0) return SNK_OK;
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    hipLaunchKernelGGL(rectify_kernel, dim3(ceil_div(cap, 256), batch), dim3(256), 0, m->stream, rc, kps_dev, n_dev, cap,
+                       0, out_dev, (double2*)normalized_dev);
+    SNK_LAUNCH_CHECK();
+    return SNK_OK;
+}
+
+int snk_rectify(snk_matcher* m, const snk_rectification* rect, const snk_keypoint* kps, int n, snk_kp64* out,
+                double (*normalized)[2])
+{
+    SNK_REQUIRE(m != nullptr, "matcher is NULL");
+    SNK_REQUIRE(n >= 0, "negative count");
+    RectDev rc;
+    int st = to_dev(rect, &rc);
+    if (st != SNK_OK) return st;
+    if (n == 0) return SNK_OK;
+    SNK_REQUIRE(kps && out, "NULL buffer");
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    const size_t kin = (size_t)n * sizeof(snk_keypoint), kout = (size_t)n * sizeof(snk_kp64), nb = (size_t)n * 16;
+    if ((st = m->aux.reserve(kin + kout)) != SNK_OK) return st;
+    if ((st = m->aux2.reserve(nb)) != SNK_OK) return st;
+    char* ab = m->aux.as<char>();
+    SNK_HIP_CHECK(hipMemcpyAsync(ab, kps, kin, hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(rectify_kernel, dim3(ceil_div(n, 256), 1), dim3(256), 0, m->stream, rc, (const snk_keypoint*)ab,
+                       (const int*)nullptr, n, n, (snk_kp64*)(ab + kin), normalized ? m->aux2.as<double2>() : nullptr);
+    SNK_LAUNCH_CHECK();
+    SNK_HIP_CHECK(hipMemcpyAsync(out, ab + kin, kout, hipMemcpyDeviceToHost, m->stream));
+    if (normalized) SNK_HIP_CHECK(hipMemcpyAsync(normalized, m->aux2.p, nb, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return SNK_OK;
+}
+}

@@ -139,3 +139,45 @@ class StereoMatcher(_Handle):
                                                  depth.data_ptr(), n_matches.data_ptr()),
             "snk_stereo_match_batch_dev",
         )
+
+
+class Rectification(C.Structure):
+    """Mirror of the Saiga::Rectification fields Snake uses (reference Snake/System/SnakeGlobal.h:107-108)."""
+    _fields_ = [("K_src", C.c_double * 4), ("D_src", C.c_double * 8), ("R", C.c_double * 9), ("K_dst", C.c_double * 4),
+                ("bf", C.c_double)]
+
+    @classmethod
+    def make(cls, K_src, D_src=None, R=None, K_dst=None, bf=0.0):
+        r = cls()
+        r.K_src[:] = list(K_src)
+        r.D_src[:] = list(D_src) if D_src is not None else [0.0] * 8
+        r.R[:] = list(np.asarray(R, np.float64).reshape(9)) if R is not None else [1, 0, 0, 0, 1, 0, 0, 0, 1]
+        r.K_dst[:] = list(K_dst) if K_dst is not None else list(K_src)
+        r.bf = bf
+        return r
+
+
+class Preprocess(StereoMatcher):
+    """undistortKeypoints / Rectification::Forward + StereoMatching on one handle (the reference's
+    "Preprocess" thread, Snake/Preprocess/Preprocess.cpp:35-53)."""
+
+    def rectify(self, rect: Rectification, kps, want_normalized: bool = True):
+        from .orb import KEYPOINT_DTYPE
+
+        k = np.ascontiguousarray(kps, dtype=KEYPOINT_DTYPE)
+        out = np.zeros(k.shape[0], KP64_DTYPE)
+        norm = np.zeros((k.shape[0], 2), np.float64) if want_normalized else None
+        _lib.check(
+            self._lib.snk_rectify(self._h, C.byref(rect), _ptr(k), k.shape[0], _ptr(out),
+                                  _ptr(norm) if norm is not None else C.c_void_p(0)),
+            "snk_rectify",
+        )
+        return out, norm
+
+    def rectify_batch_dev(self, rect: Rectification, kps, n, out, normalized=None):
+        B, cap = kps.shape[0], kps.shape[1]
+        _lib.check(
+            self._lib.snk_rectify_batch_dev(self._h, C.byref(rect), kps.data_ptr(), n.data_ptr(), cap, B, out.data_ptr(),
+                                            normalized.data_ptr() if normalized is not None else 0),
+            "snk_rectify_batch_dev",
+        )

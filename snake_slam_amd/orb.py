@@ -84,6 +84,16 @@ class ORBExtractor:
             "snk_orb_detect_batch_dev",
         )
 
+    def set_profiling(self, enable: bool) -> None:
+        _lib.check(self._lib.snk_orb_set_profiling(self._h, int(enable)), "snk_orb_set_profiling")
+
+    def stage_times(self):
+        """(ms per stage [resize, fast, distribute, describe] summed over calls, number of calls)."""
+        ms = (C.c_float * 4)()
+        n = C.c_int(0)
+        _lib.check(self._lib.snk_orb_stage_times(self._h, ms, C.byref(n)), "snk_orb_stage_times")
+        return list(ms), n.value
+
     def debug_fetch(self, what: int, image: int, level: int, dtype, max_bytes: int = 1 << 24) -> np.ndarray:
         buf = np.zeros(max_bytes, np.uint8)
         nb = C.c_size_t(0)

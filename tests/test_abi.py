@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     from snake_slam_amd import _lib
 
     assert _lib.LIB_PATH.exists(), "libsnake_hip.so missing: run __graft_entry__.build()"
-    lib = ctypes.CDLL(str(_lib.LIB_PATH))
+    lib = _lib.load()
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, f"declared in snake_hip.h but not exported: {missing}"
 
@@ -52,3 +52,11 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         assert "no CPU fallback" in str(e) or "not found" in str(e)
     else:
         raise AssertionError("loading a missing library must raise")
+
+
+def test_single_hip_runtime_in_process():
+    """torch bundles its own libamdhip64; the loader must not map a second copy next to it."""
+    from snake_slam_amd import _lib
+
+    _lib.load()
+    assert len(_lib.hip_runtimes_mapped()) == 1, _lib.hip_runtimes_mapped()
