@@ -1,0 +1,510 @@
+/*
+ * TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+ *
+ * CPU restatement ("oracle") of the local-bundle-adjustment solve the reference performs through
+ * Saiga::BARecRel::create / initAndSolve / solve (call sites
+ * Snake/Optimizer/LocalBundleAdjustment.cpp:357-365,403-407; options :47-64) and of
+ * Scene::residual2 / residual3 used by the chi-square outlier pass (:372-395, :423-457).
+ *
+ * PARITY UNPINNED.  The solver lives in the absent, unpinned submodule darglein/saiga.  What the
+ * reference fixes is restated as is: the observation model of MakeLocalScene (:246-293: pixel
+ * point, depth>0 => stereo, weight, constant images/points skipped when both constant :286),
+ * Levenberg-Marquardt with maxIterations, an iterative (PCG) solve of the explicit Schur
+ * complement with maxIterativeIterations / iterativeTolerance, Huber thresholds huberMono /
+ * huberStereo.  Everything else is [DEFINED] here ("snk-ba v1"):
+ *   residual  r = weight * (projection - observation); stereo adds u_r = u - bf/z against
+ *             (u_obs - bf/depth); observations with z <= 0 contribute nothing;
+ *   robust    Huber on s = |r|^2: rho = s (s <= d^2) else 2 d sqrt(s) - d^2; IRLS scale sqrt(rho');
+ *   pose      T <- exp(delta) * T, delta = (translation, rotation), SE3 exponential;
+ *   damping   H + lambda * clamp(diag(H), 1e-6, 1e32), lambda0 = 1e-4, on success lambda /= 3 and
+ *             v = 2, on failure lambda *= v, v *= 2 and the step is reverted;
+ *   PCG       block-Jacobi (6x6) preconditioner, x0 = 0, stop when |r| <= tol * |rhs| or after
+ *             max_pcg iterations; exactly max_iterations LM iterations are run.
+ * Double precision throughout.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "snk_oracle.h"
+
+/* ---------- small linear algebra ---------- */
+static void quat_to_R(const double* q, double* R)
+{
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
+    R[3] = 2 * (x * y + z * w);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+    R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
+}
+
+static void quat_mul(const double* a, const double* b, double* o) /* o = a * b, (x,y,z,w) */
+{
+    const double ax = a[0], ay = a[1], az = a[2], aw = a[3], bx = b[0], by = b[1], bz = b[2], bw = b[3];
+    o[0] = aw * bx + ax * bw + ay * bz - az * by;
+    o[1] = aw * by - ax * bz + ay * bw + az * bx;
+    o[2] = aw * bz + ax * by - ay * bx + az * bw;
+    o[3] = aw * bw - ax * bx - ay * by - az * bz;
+}
+
+/* pose <- exp(delta) * pose; delta = (vx,vy,vz, wx,wy,wz) */
+void orc_se3_update(const double* pose, const double* d, double* out)
+{
+    const double wx = d[3], wy = d[4], wz = d[5];
+    const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
+    double A, B, Cc; /* sin(th)/th, (1-cos)/th^2, (th-sin)/th^3 */
+    double qd[4];
+    if (th < 1e-8)
+    {
+        A = 1.0 - th2 / 6.0;
+        B = 0.5 - th2 / 24.0;
+        Cc = 1.0 / 6.0 - th2 / 120.0;
+        const double h = 0.5 - th2 / 48.0; /* sin(th/2)/th */
+        qd[0] = h * wx; qd[1] = h * wy; qd[2] = h * wz; qd[3] = 1.0 - th2 / 8.0;
+    }
+    else
+    {
+        const double s = sin(th), c = cos(th);
+        A  = s / th;
+        B  = (1.0 - c) / th2;
+        Cc = (th - s) / (th2 * th);
+        const double sh = sin(0.5 * th) / th;
+        qd[0] = sh * wx; qd[1] = sh * wy; qd[2] = sh * wz; qd[3] = cos(0.5 * th);
+    }
+    (void)A;
+    /* V * v with V = I + B [w]x + Cc [w]x^2 */
+    const double vx = d[0], vy = d[1], vz = d[2];
+    const double cx = wy * vz - wz * vy, cy = wz * vx - wx * vz, cz = wx * vy - wy * vx;       /* w x v */
+    const double ccx = wy * cz - wz * cy, ccy = wz * cx - wx * cz, ccz = wx * cy - wy * cx;    /* w x (w x v) */
+    const double tdx = vx + B * cx + Cc * ccx, tdy = vy + B * cy + Cc * ccy, tdz = vz + B * cz + Cc * ccz;
+    double Rd[9];
+    quat_to_R(qd, Rd);
+    const double tx = pose[4], ty = pose[5], tz = pose[6];
+    double q[4];
+    quat_mul(qd, pose, q);
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    out[0] = q[0] / n; out[1] = q[1] / n; out[2] = q[2] / n; out[3] = q[3] / n;
+    out[4] = Rd[0] * tx + Rd[1] * ty + Rd[2] * tz + tdx;
+    out[5] = Rd[3] * tx + Rd[4] * ty + Rd[5] * tz + tdy;
+    out[6] = Rd[6] * tx + Rd[7] * ty + Rd[8] * tz + tdz;
+}
+
+/* Observation: residual r (dim 2 or 3), Jc (dim x 6), Jp (dim x 3), all multiplied by `scale`
+ * outside.  Returns dim, or 0 when the point is not in front of the camera. */
+static int obs_linearize(const double* pose, const double* pt, const double* K, double bf, double u, double v,
+                         double depth, double w, double* r, double* Jc, double* Jp)
+{
+    double R[9];
+    quat_to_R(pose, R);
+    const double X = R[0] * pt[0] + R[1] * pt[1] + R[2] * pt[2] + pose[4];
+    const double Y = R[3] * pt[0] + R[4] * pt[1] + R[5] * pt[2] + pose[5];
+    const double Z = R[6] * pt[0] + R[7] * pt[1] + R[8] * pt[2] + pose[6];
+    if (Z <= 0.0) return 0;
+    const double iz = 1.0 / Z, iz2 = iz * iz;
+    const double fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+    const int dim = depth > 0.0 ? 3 : 2;
+    r[0] = w * (fx * X * iz + cx - u);
+    r[1] = w * (fy * Y * iz + cy - v);
+    /* d(proj)/d(Pc) rows */
+    double P[9];
+    P[0] = fx * iz; P[1] = 0.0;     P[2] = -fx * X * iz2;
+    P[3] = 0.0;     P[4] = fy * iz; P[5] = -fy * Y * iz2;
+    if (dim == 3)
+    {
+        r[2] = w * ((fx * X * iz + cx - bf * iz) - (u - bf / depth));
+        P[6] = fx * iz; P[7] = 0.0; P[8] = -fx * X * iz2 + bf * iz2;
+    }
+    for (int k = 0; k < dim; ++k)
+    {
+        const double a = w * P[3 * k], b = w * P[3 * k + 1], c = w * P[3 * k + 2];
+        /* d Pc / d(translation) = I ; d Pc / d(rotation) = -[Pc]x */
+        Jc[6 * k + 0] = a;
+        Jc[6 * k + 1] = b;
+        Jc[6 * k + 2] = c;
+        Jc[6 * k + 3] = -b * Z + c * Y;  /* (a,b,c) . (-[Pc]x col 0) = (0, -Z... ) */
+        Jc[6 * k + 4] = a * Z - c * X;
+        Jc[6 * k + 5] = -a * Y + b * X;
+        /* d Pc / d(point) = R */
+        Jp[3 * k + 0] = a * R[0] + b * R[3] + c * R[6];
+        Jp[3 * k + 1] = a * R[1] + b * R[4] + c * R[7];
+        Jp[3 * k + 2] = a * R[2] + b * R[5] + c * R[8];
+    }
+    return dim;
+}
+
+static double huber_rho(double s, double d, double* sqrt_w)
+{
+    const double d2 = d * d;
+    if (s <= d2)
+    {
+        *sqrt_w = 1.0;
+        return s;
+    }
+    const double rt = sqrt(s);
+    *sqrt_w = sqrt(d / rt);
+    return 2.0 * d * rt - d2;
+}
+
+/* squared norm of the weighted residual of every observation (Scene::residual2/3 of the chi-square
+ * pass); 0 for skipped observations (both constant, outlier flag set, or z <= 0). */
+void orc_ba_chi2(const orc_ba_problem* P, double* chi2)
+{
+    for (int o = 0; o < P->n_obs; ++o)
+    {
+        chi2[o] = 0.0;
+        const int i = P->obs_img[o], p = P->obs_pt[o];
+        if (i < 0 || p < 0) continue;
+        if (P->obs_outlier && P->obs_outlier[o]) continue;
+        if (P->img_const[i] && P->pt_const[p]) continue;
+        double r[3], Jc[18], Jp[9];
+        int dim = obs_linearize(P->pose[i], P->pt[p], P->K, P->bf, P->obs_uv[o][0], P->obs_uv[o][1], P->obs_depth[o],
+                                P->obs_weight[o], r, Jc, Jp);
+        double s = 0;
+        for (int k = 0; k < dim; ++k) s += r[k] * r[k];
+        chi2[o] = s;
+    }
+}
+
+static double total_cost(const orc_ba_problem* P, const orc_ba_options* O, double (*pose)[7], double (*pt)[3])
+{
+    double c = 0.0;
+    for (int o = 0; o < P->n_obs; ++o)
+    {
+        const int i = P->obs_img[o], p = P->obs_pt[o];
+        if (i < 0 || p < 0) continue;
+        if (P->obs_outlier && P->obs_outlier[o]) continue;
+        if (P->img_const[i] && P->pt_const[p]) continue;
+        double r[3], Jc[18], Jp[9], sw;
+        int dim = obs_linearize(pose[i], pt[p], P->K, P->bf, P->obs_uv[o][0], P->obs_uv[o][1], P->obs_depth[o],
+                                P->obs_weight[o], r, Jc, Jp);
+        if (!dim) continue;
+        double s = 0;
+        for (int k = 0; k < dim; ++k) s += r[k] * r[k];
+        c += huber_rho(s, dim == 3 ? O->huber_stereo : O->huber_mono, &sw);
+    }
+    return c;
+}
+
+static int inv3_sym(const double* V /* 3x3 */, double* Vi)
+{
+    const double a = V[0], b = V[1], c = V[2], d = V[4], e = V[5], f = V[8];
+    const double A = d * f - e * e, B = c * e - b * f, C = b * e - c * d;
+    const double det = a * A + b * B + c * C;
+    if (det == 0.0) return -1;
+    const double id = 1.0 / det;
+    Vi[0] = A * id; Vi[1] = B * id; Vi[2] = C * id;
+    Vi[3] = Vi[1];  Vi[4] = (a * f - c * c) * id; Vi[5] = (b * c - a * e) * id;
+    Vi[6] = Vi[2];  Vi[7] = Vi[5]; Vi[8] = (a * d - b * b) * id;
+    return 0;
+}
+
+/* Cholesky solve of a dense SPD n x n system in place (n <= 6 here) */
+static int chol_inv6(const double* A, double* Ai)
+{
+    double L[36];
+    memset(L, 0, sizeof(L));
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j <= i; ++j)
+        {
+            double s = A[i * 6 + j];
+            for (int k = 0; k < j; ++k) s -= L[i * 6 + k] * L[j * 6 + k];
+            if (i == j)
+            {
+                if (s <= 0.0) return -1;
+                L[i * 6 + i] = sqrt(s);
+            }
+            else
+                L[i * 6 + j] = s / L[j * 6 + j];
+        }
+    for (int c = 0; c < 6; ++c)
+    {
+        double y[6], x[6];
+        for (int i = 0; i < 6; ++i)
+        {
+            double s = i == c ? 1.0 : 0.0;
+            for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k];
+            y[i] = s / L[i * 6 + i];
+        }
+        for (int i = 5; i >= 0; --i)
+        {
+            double s = y[i];
+            for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * x[k];
+            x[i] = s / L[i * 6 + i];
+        }
+        for (int i = 0; i < 6; ++i) Ai[i * 6 + c] = x[i];
+    }
+    return 0;
+}
+
+static double clampd(double v)
+{
+    return v < 1e-6 ? 1e-6 : (v > 1e32 ? 1e32 : v);
+}
+
+/* Runs `iterations` LM iterations in place on P->pose / P->pt.  Returns 0, fills costs. */
+int orc_ba_solve(orc_ba_problem* P, const orc_ba_options* O, int iterations, double* cost_initial, double* cost_final,
+                 int* pcg_iterations_total)
+{
+    const int ni = P->n_img, np = P->n_pt, no = P->n_obs;
+    int* cam_idx = (int*)malloc(sizeof(int) * (size_t)(ni > 0 ? ni : 1));
+    int nfc      = 0;
+    for (int i = 0; i < ni; ++i) cam_idx[i] = P->img_const[i] ? -1 : nfc++;
+    const int n6 = 6 * nfc;
+    double* U  = (double*)calloc((size_t)nfc * 36 + 1, sizeof(double));
+    double* bc = (double*)calloc((size_t)n6 + 1, sizeof(double));
+    double* V  = (double*)calloc((size_t)np * 9 + 1, sizeof(double));
+    double* Vi = (double*)calloc((size_t)np * 9 + 1, sizeof(double));
+    double* bp = (double*)calloc((size_t)np * 3 + 1, sizeof(double));
+    double* Wm = (double*)calloc((size_t)no * 18 + 1, sizeof(double));
+    uint8_t* used = (uint8_t*)calloc((size_t)no + 1, 1);
+    double* S   = (double*)calloc((size_t)n6 * n6 + 1, sizeof(double));
+    double* rhs = (double*)calloc((size_t)n6 + 1, sizeof(double));
+    double* Minv = (double*)calloc((size_t)nfc * 36 + 1, sizeof(double));
+    double* x = (double*)calloc((size_t)n6 + 1, sizeof(double));
+    double* rr = (double*)calloc((size_t)n6 + 1, sizeof(double));
+    double* zz = (double*)calloc((size_t)n6 + 1, sizeof(double));
+    double* pp = (double*)calloc((size_t)n6 + 1, sizeof(double));
+    double* Ap = (double*)calloc((size_t)n6 + 1, sizeof(double));
+    double(*pose_new)[7] = (double(*)[7])malloc(sizeof(double) * 7 * (size_t)(ni > 0 ? ni : 1));
+    double(*pt_new)[3]   = (double(*)[3])malloc(sizeof(double) * 3 * (size_t)(np > 0 ? np : 1));
+    double* dpt = (double*)calloc((size_t)np * 3 + 1, sizeof(double));
+
+    double lambda = O->lambda_init > 0 ? O->lambda_init : 1e-4, vfac = 2.0;
+    double cost = total_cost(P, O, P->pose, P->pt);
+    *cost_initial = cost;
+    int pcg_total = 0;
+
+    for (int it = 0; it < iterations; ++it)
+    {
+        memset(U, 0, sizeof(double) * (size_t)nfc * 36);
+        memset(bc, 0, sizeof(double) * (size_t)n6);
+        memset(V, 0, sizeof(double) * (size_t)np * 9);
+        memset(bp, 0, sizeof(double) * (size_t)np * 3);
+        memset(used, 0, (size_t)no);
+        /* 1. linearise */
+        for (int o = 0; o < no; ++o)
+        {
+            const int i = P->obs_img[o], p = P->obs_pt[o];
+            if (i < 0 || p < 0) continue;
+            if (P->obs_outlier && P->obs_outlier[o]) continue;
+            if (P->img_const[i] && P->pt_const[p]) continue;
+            double r[3], Jc[18], Jp[9], sw;
+            int dim = obs_linearize(P->pose[i], P->pt[p], P->K, P->bf, P->obs_uv[o][0], P->obs_uv[o][1],
+                                    P->obs_depth[o], P->obs_weight[o], r, Jc, Jp);
+            if (!dim) continue;
+            double s = 0;
+            for (int k = 0; k < dim; ++k) s += r[k] * r[k];
+            huber_rho(s, dim == 3 ? O->huber_stereo : O->huber_mono, &sw);
+            for (int k = 0; k < dim; ++k)
+            {
+                r[k] *= sw;
+                for (int a = 0; a < 6; ++a) Jc[6 * k + a] *= sw;
+                for (int a = 0; a < 3; ++a) Jp[3 * k + a] *= sw;
+            }
+            const int c = cam_idx[i];
+            const int pfree = !P->pt_const[p];
+            if (c >= 0)
+                for (int a = 0; a < 6; ++a)
+                {
+                    for (int b = 0; b < 6; ++b)
+                    {
+                        double s2 = 0;
+                        for (int k = 0; k < dim; ++k) s2 += Jc[6 * k + a] * Jc[6 * k + b];
+                        U[c * 36 + a * 6 + b] += s2;
+                    }
+                    double g = 0;
+                    for (int k = 0; k < dim; ++k) g += Jc[6 * k + a] * r[k];
+                    bc[c * 6 + a] -= g;
+                }
+            if (pfree)
+                for (int a = 0; a < 3; ++a)
+                {
+                    for (int b = 0; b < 3; ++b)
+                    {
+                        double s2 = 0;
+                        for (int k = 0; k < dim; ++k) s2 += Jp[3 * k + a] * Jp[3 * k + b];
+                        V[p * 9 + a * 3 + b] += s2;
+                    }
+                    double g = 0;
+                    for (int k = 0; k < dim; ++k) g += Jp[3 * k + a] * r[k];
+                    bp[p * 3 + a] -= g;
+                }
+            if (c >= 0 && pfree)
+            {
+                used[o] = 1;
+                for (int a = 0; a < 6; ++a)
+                    for (int b = 0; b < 3; ++b)
+                    {
+                        double s2 = 0;
+                        for (int k = 0; k < dim; ++k) s2 += Jc[6 * k + a] * Jp[3 * k + b];
+                        Wm[o * 18 + a * 3 + b] = s2;
+                    }
+            }
+        }
+        /* 2. damping */
+        for (int c = 0; c < nfc; ++c)
+            for (int a = 0; a < 6; ++a) U[c * 36 + a * 7] += lambda * clampd(U[c * 36 + a * 7]);
+        for (int p = 0; p < np; ++p)
+        {
+            if (P->pt_const[p]) continue;
+            for (int a = 0; a < 3; ++a) V[p * 9 + a * 4] += lambda * clampd(V[p * 9 + a * 4]);
+            if (inv3_sym(V + p * 9, Vi + p * 9) != 0) memset(Vi + p * 9, 0, 72);
+        }
+        /* 3. Schur complement S = U - W V^-1 W^T, rhs = bc - W V^-1 bp */
+        memset(S, 0, sizeof(double) * (size_t)n6 * n6);
+        for (int c = 0; c < nfc; ++c)
+            for (int a = 0; a < 6; ++a)
+            {
+                for (int b = 0; b < 6; ++b) S[(size_t)(c * 6 + a) * n6 + c * 6 + b] = U[c * 36 + a * 6 + b];
+                rhs[c * 6 + a] = bc[c * 6 + a];
+            }
+        /* per point: the observations that couple it to free cameras */
+        {
+            int* start = (int*)calloc((size_t)np + 2, sizeof(int));
+            int* items = (int*)malloc(sizeof(int) * (size_t)(no + 1));
+            for (int o = 0; o < no; ++o)
+                if (used[o]) start[P->obs_pt[o] + 1]++;
+            for (int p = 0; p < np; ++p) start[p + 1] += start[p];
+            int* fill = (int*)malloc(sizeof(int) * (size_t)(np + 1));
+            memcpy(fill, start, sizeof(int) * (size_t)(np + 1));
+            for (int o = 0; o < no; ++o)
+                if (used[o]) items[fill[P->obs_pt[o]]++] = o;
+            for (int p = 0; p < np; ++p)
+            {
+                const double* vi = Vi + p * 9;
+                for (int a1 = start[p]; a1 < start[p + 1]; ++a1)
+                {
+                    const int o1 = items[a1], c1 = cam_idx[P->obs_img[o1]];
+                    double Y[18]; /* W1 * Vi (6x3) */
+                    for (int a = 0; a < 6; ++a)
+                        for (int b = 0; b < 3; ++b)
+                            Y[a * 3 + b] = Wm[o1 * 18 + a * 3] * vi[b] + Wm[o1 * 18 + a * 3 + 1] * vi[3 + b] +
+                                           Wm[o1 * 18 + a * 3 + 2] * vi[6 + b];
+                    for (int a = 0; a < 6; ++a)
+                        rhs[c1 * 6 + a] -= Y[a * 3] * bp[p * 3] + Y[a * 3 + 1] * bp[p * 3 + 1] + Y[a * 3 + 2] * bp[p * 3 + 2];
+                    for (int a2 = start[p]; a2 < start[p + 1]; ++a2)
+                    {
+                        const int o2 = items[a2], c2 = cam_idx[P->obs_img[o2]];
+                        for (int a = 0; a < 6; ++a)
+                            for (int b = 0; b < 6; ++b)
+                                S[(size_t)(c1 * 6 + a) * n6 + c2 * 6 + b] -=
+                                    Y[a * 3] * Wm[o2 * 18 + b * 3] + Y[a * 3 + 1] * Wm[o2 * 18 + b * 3 + 1] +
+                                    Y[a * 3 + 2] * Wm[o2 * 18 + b * 3 + 2];
+                    }
+                }
+            }
+            /* 4. PCG with block-Jacobi preconditioner */
+            for (int c = 0; c < nfc; ++c)
+            {
+                double blk[36];
+                for (int a = 0; a < 6; ++a)
+                    for (int b = 0; b < 6; ++b) blk[a * 6 + b] = S[(size_t)(c * 6 + a) * n6 + c * 6 + b];
+                if (chol_inv6(blk, Minv + c * 36) != 0)
+                {
+                    memset(Minv + c * 36, 0, 288);
+                    for (int a = 0; a < 6; ++a) Minv[c * 36 + a * 7] = 1.0 / clampd(blk[a * 7]);
+                }
+            }
+            double bnorm2 = 0;
+            for (int k = 0; k < n6; ++k)
+            {
+                x[k]  = 0.0;
+                rr[k] = rhs[k];
+                bnorm2 += rhs[k] * rhs[k];
+            }
+            double rz = 0;
+            for (int c = 0; c < nfc; ++c)
+                for (int a = 0; a < 6; ++a)
+                {
+                    double s2 = 0;
+                    for (int b = 0; b < 6; ++b) s2 += Minv[c * 36 + a * 6 + b] * rr[c * 6 + b];
+                    zz[c * 6 + a] = s2;
+                    pp[c * 6 + a] = s2;
+                    rz += rr[c * 6 + a] * s2;
+                }
+            const double stop2 = O->pcg_tol * O->pcg_tol * bnorm2;
+            for (int k = 0; k < O->max_pcg_iterations && n6 > 0; ++k)
+            {
+                double rn2 = 0;
+                for (int q = 0; q < n6; ++q) rn2 += rr[q] * rr[q];
+                if (rn2 <= stop2) break;
+                double pAp = 0;
+                for (int q = 0; q < n6; ++q)
+                {
+                    double s2 = 0;
+                    for (int t = 0; t < n6; ++t) s2 += S[(size_t)q * n6 + t] * pp[t];
+                    Ap[q] = s2;
+                    pAp += pp[q] * s2;
+                }
+                if (pAp <= 0.0) break;
+                const double alpha = rz / pAp;
+                for (int q = 0; q < n6; ++q)
+                {
+                    x[q] += alpha * pp[q];
+                    rr[q] -= alpha * Ap[q];
+                }
+                double rz_new = 0;
+                for (int c = 0; c < nfc; ++c)
+                    for (int a = 0; a < 6; ++a)
+                    {
+                        double s2 = 0;
+                        for (int b = 0; b < 6; ++b) s2 += Minv[c * 36 + a * 6 + b] * rr[c * 6 + b];
+                        zz[c * 6 + a] = s2;
+                        rz_new += rr[c * 6 + a] * s2;
+                    }
+                const double beta = rz_new / rz;
+                rz = rz_new;
+                for (int q = 0; q < n6; ++q) pp[q] = zz[q] + beta * pp[q];
+                pcg_total++;
+            }
+            /* 5. back-substitution: dp = Vi (bp - sum W^T dc) */
+            for (int p = 0; p < np; ++p)
+            {
+                double g[3] = {bp[p * 3], bp[p * 3 + 1], bp[p * 3 + 2]};
+                if (P->pt_const[p])
+                {
+                    dpt[p * 3] = dpt[p * 3 + 1] = dpt[p * 3 + 2] = 0.0;
+                    continue;
+                }
+                for (int a1 = start[p]; a1 < start[p + 1]; ++a1)
+                {
+                    const int o1 = items[a1], c1 = cam_idx[P->obs_img[o1]];
+                    for (int b = 0; b < 3; ++b)
+                        for (int a = 0; a < 6; ++a) g[b] -= Wm[o1 * 18 + a * 3 + b] * x[c1 * 6 + a];
+                }
+                const double* vi = Vi + p * 9;
+                for (int a = 0; a < 3; ++a) dpt[p * 3 + a] = vi[a * 3] * g[0] + vi[a * 3 + 1] * g[1] + vi[a * 3 + 2] * g[2];
+            }
+            free(start);
+            free(items);
+            free(fill);
+        }
+        /* 6. trial update, accept / reject */
+        for (int i = 0; i < ni; ++i)
+        {
+            if (cam_idx[i] < 0) memcpy(pose_new[i], P->pose[i], 56);
+            else orc_se3_update(P->pose[i], x + cam_idx[i] * 6, pose_new[i]);
+        }
+        for (int p = 0; p < np; ++p)
+            for (int a = 0; a < 3; ++a) pt_new[p][a] = P->pt[p][a] + dpt[p * 3 + a];
+        const double cost_new = total_cost(P, O, pose_new, pt_new);
+        if (cost_new < cost)
+        {
+            memcpy(P->pose, pose_new, sizeof(double) * 7 * (size_t)ni);
+            memcpy(P->pt, pt_new, sizeof(double) * 3 * (size_t)np);
+            cost   = cost_new;
+            lambda = lambda * (1.0 / 3.0);
+            vfac   = 2.0;
+        }
+        else
+        {
+            lambda *= vfac;
+            vfac *= 2.0;
+        }
+    }
+    *cost_final = cost;
+    if (pcg_iterations_total) *pcg_iterations_total = pcg_total;
+    free(cam_idx); free(U); free(bc); free(V); free(Vi); free(bp); free(Wm); free(used); free(S); free(rhs); free(Minv);
+    free(x); free(rr); free(zz); free(pp); free(Ap); free(pose_new); free(pt_new); free(dpt);
+    return 0;
+}

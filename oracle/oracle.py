@@ -223,3 +223,64 @@ def rectify(rect: Rectification, kps):
     norm = np.zeros((k.shape[0], 2), np.float64)
     lib().orc_rectify(C.byref(rect), _p(k), C.c_int(k.shape[0]), _p(out), _p(norm))
     return out, norm
+
+
+# ------------------------------------------------------------------ BA -------------------------
+class BaOptions(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("max_pcg_iterations", C.c_int32), ("pcg_tol", C.c_double),
+                ("huber_mono", C.c_double), ("huber_stereo", C.c_double), ("lambda_init", C.c_double)]
+
+
+class BaProblem(C.Structure):
+    _fields_ = [("n_img", C.c_int32), ("n_pt", C.c_int32), ("n_obs", C.c_int32), ("pose", C.c_void_p),
+                ("img_const", C.c_void_p), ("pt", C.c_void_p), ("pt_const", C.c_void_p), ("obs_img", C.c_void_p),
+                ("obs_pt", C.c_void_p), ("obs_uv", C.c_void_p), ("obs_depth", C.c_void_p), ("obs_weight", C.c_void_p),
+                ("obs_outlier", C.c_void_p), ("K", C.c_double * 4), ("bf", C.c_double)]
+
+
+def ba_options(max_iterations=3, max_pcg_iterations=30, pcg_tol=1e-10, huber_mono=2.1, huber_stereo=2.3, lambda_init=0.0):
+    """Defaults = reference Snake/Optimizer/LocalBundleAdjustment.cpp:47-64 and SnakeGlobal.h:145-150."""
+    return BaOptions(max_iterations, max_pcg_iterations, pcg_tol, huber_mono, huber_stereo, lambda_init)
+
+
+def _ba_pack(scene, outlier=None):
+    """scene: dict with pose[n,7], img_const[n], pt[m,3], pt_const[m], obs_img, obs_pt, obs_uv[k,2], obs_depth,
+    obs_weight, K[4], bf.  Returns (BaProblem, keepalive arrays)."""
+    a = {
+        "pose": np.array(scene["pose"], np.float64, order="C"),
+        "img_const": np.ascontiguousarray(scene["img_const"], np.uint8),
+        "pt": np.array(scene["pt"], np.float64, order="C"),
+        "pt_const": np.ascontiguousarray(scene["pt_const"], np.uint8),
+        "obs_img": np.ascontiguousarray(scene["obs_img"], np.int32),
+        "obs_pt": np.ascontiguousarray(scene["obs_pt"], np.int32),
+        "obs_uv": np.ascontiguousarray(scene["obs_uv"], np.float64),
+        "obs_depth": np.ascontiguousarray(scene["obs_depth"], np.float64),
+        "obs_weight": np.ascontiguousarray(scene["obs_weight"], np.float64),
+    }
+    if outlier is not None:
+        a["obs_outlier"] = np.ascontiguousarray(outlier, np.uint8)
+    P = BaProblem()
+    P.n_img, P.n_pt, P.n_obs = a["pose"].shape[0], a["pt"].shape[0], a["obs_img"].shape[0]
+    for k in ("pose", "img_const", "pt", "pt_const", "obs_img", "obs_pt", "obs_uv", "obs_depth", "obs_weight"):
+        setattr(P, k, a[k].ctypes.data if a[k].size else 0)
+    P.obs_outlier = a["obs_outlier"].ctypes.data if outlier is not None else 0
+    P.K[:] = list(scene["K"])
+    P.bf = float(scene["bf"])
+    return P, a
+
+
+def ba_chi2(scene, outlier=None) -> np.ndarray:
+    P, a = _ba_pack(scene, outlier)
+    out = np.zeros(P.n_obs, np.float64)
+    lib().orc_ba_chi2(C.byref(P), _p(out))
+    return out
+
+
+def ba_solve(scene, options: BaOptions = None, iterations=None, outlier=None):
+    """Returns (pose, pt, cost_initial, cost_final, pcg_iterations)."""
+    options = options or ba_options()
+    P, a = _ba_pack(scene, outlier)
+    ci, cf, it = C.c_double(), C.c_double(), C.c_int()
+    lib().orc_ba_solve(C.byref(P), C.byref(options), C.c_int(options.max_iterations if iterations is None else iterations),
+                       C.byref(ci), C.byref(cf), C.byref(it))
+    return a["pose"], a["pt"], ci.value, cf.value, it.value

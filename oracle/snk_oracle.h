@@ -103,6 +103,38 @@ typedef struct orc_rectification
 void orc_undistort_gn(const double* D, double px, double py, double* ox, double* oy);
 void orc_rectify(const orc_rectification* R, const orc_keypoint* kps, int n, orc_kp64* out, double (*normalized)[2]);
 
+/* ---- ba_oracle.c ---- */
+typedef struct orc_ba_options
+{
+    int32_t max_iterations;     /* LM iterations (reference: 3) */
+    int32_t max_pcg_iterations; /* reference: 30 */
+    double pcg_tol;             /* reference: 1e-10 */
+    double huber_mono, huber_stereo;
+    double lambda_init; /* 0 -> 1e-4 */
+} orc_ba_options;
+
+typedef struct orc_ba_problem
+{
+    int32_t n_img, n_pt, n_obs;
+    double (*pose)[7]; /* qx qy qz qw tx ty tz, world -> camera; updated in place */
+    const uint8_t* img_const;
+    double (*pt)[3]; /* updated in place */
+    const uint8_t* pt_const;
+    const int32_t* obs_img;
+    const int32_t* obs_pt;
+    const double (*obs_uv)[2];
+    const double* obs_depth; /* > 0 => stereo observation */
+    const double* obs_weight;
+    const uint8_t* obs_outlier; /* may be NULL */
+    double K[4];                /* fx fy cx cy */
+    double bf;
+} orc_ba_problem;
+
+void orc_se3_update(const double* pose, const double* d, double* out);
+void orc_ba_chi2(const orc_ba_problem* P, double* chi2);
+int orc_ba_solve(orc_ba_problem* P, const orc_ba_options* O, int iterations, double* cost_initial, double* cost_final,
+                 int* pcg_iterations_total);
+
 #ifdef __cplusplus
 }
 #endif

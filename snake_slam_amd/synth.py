@@ -52,3 +52,78 @@ def stereo_frame(index: int = 0, width: int = 752, height: int = 480, n_rects: i
 def random_descriptors(n: int, seed: int = SEED):
     rng = np.random.default_rng(seed)
     return rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+
+
+def _quat_from_R(R):
+    w = np.sqrt(max(0.0, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+    x = (R[2, 1] - R[1, 2]) / (4 * w)
+    y = (R[0, 2] - R[2, 0]) / (4 * w)
+    z = (R[1, 0] - R[0, 1]) / (4 * w)
+    return np.array([x, y, z, w])
+
+
+def _rot(axis, ang):
+    axis = axis / np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+
+
+def ba_scene(n_kf: int = 20, n_pt: int = 2000, obs_per_pt: int = 8, seed: int = SEED, pixel_noise: float = 0.5,
+             perturb: bool = True, stereo_frac: float = 0.5, n_fixed: int = 1, outlier_frac: float = 0.0):
+    """The synthetic local-BA problem of SURVEY.md §8(d): cameras on an arc looking at a box of
+    points, every point seen by `obs_per_pt` consecutive cameras (round-robin windows), EuRoC-like
+    intrinsics, half of the observations stereo, weights 1/1.44^octave, noisy pixels, perturbed
+    initial poses / points, first camera(s) constant.  Returns (scene, ground_truth)."""
+    rng = np.random.default_rng(seed)
+    K = (458.654, 457.296, 367.215, 248.375)
+    bf = 47.9
+    poses_R, poses_t = [], []
+    for i in range(n_kf):
+        a = (i / max(1, n_kf - 1) - 0.5) * 0.9  # arc angle
+        c = np.array([10.0 * np.sin(a), 0.15 * np.sin(3 * a), 10.0 * (1 - np.cos(a)) - 1.0])  # camera centre
+        Rwc = _rot(np.array([0.0, 1.0, 0.0]), -a * 0.8)  # camera-to-world: look roughly at the box
+        Rcw = Rwc.T
+        poses_R.append(Rcw)
+        poses_t.append(-Rcw @ c)
+    pts = np.stack([rng.uniform(-4, 4, n_pt), rng.uniform(-2, 2, n_pt), rng.uniform(5, 9, n_pt)], axis=1)
+    obs_img, obs_pt, obs_uv, obs_depth, obs_w = [], [], [], [], []
+    for p in range(n_pt):
+        first = p % n_kf
+        for k in range(min(obs_per_pt, n_kf)):
+            i = (first + k) % n_kf
+            pc = poses_R[i] @ pts[p] + poses_t[i]
+            if pc[2] <= 0.5:
+                continue
+            u = K[0] * pc[0] / pc[2] + K[2]
+            v = K[1] * pc[1] / pc[2] + K[3]
+            octave = int(rng.integers(0, 4))
+            stereo = rng.random() < stereo_frac
+            nu, nv, nd = rng.normal(0, pixel_noise, 3) if pixel_noise > 0 else (0.0, 0.0, 0.0)
+            if outlier_frac > 0 and rng.random() < outlier_frac:
+                nu += rng.uniform(15, 40) * rng.choice([-1, 1])
+            obs_img.append(i)
+            obs_pt.append(p)
+            obs_uv.append((u + nu, v + nv))
+            # depth consistent with a noisy right-image coordinate u_r = u - bf/z
+            if stereo:
+                ur = (u - bf / pc[2]) + nd
+                disp = max((u + nu) - ur, 1e-3)
+                obs_depth.append(bf / disp)
+            else:
+                obs_depth.append(-1.0)
+            obs_w.append(1.0 / 1.44**octave)
+    gt_pose = np.array([np.concatenate([_quat_from_R(R), t]) for R, t in zip(poses_R, poses_t)])
+    pose0, pt0 = gt_pose.copy(), pts.copy()
+    if perturb:
+        for i in range(n_fixed, n_kf):
+            dR = _rot(rng.normal(size=3), np.radians(0.5) * rng.uniform(0.5, 1.0))
+            R = dR @ poses_R[i]
+            t = dR @ poses_t[i] + rng.normal(0, 0.02 / np.sqrt(3), 3)
+            pose0[i] = np.concatenate([_quat_from_R(R), t])
+        pt0 = pts + rng.normal(0, 0.05 / np.sqrt(3), pts.shape)
+    img_const = np.zeros(n_kf, np.uint8)
+    img_const[:n_fixed] = 1
+    scene = dict(pose=pose0, img_const=img_const, pt=pt0, pt_const=np.zeros(n_pt, np.uint8),
+                 obs_img=np.array(obs_img, np.int32), obs_pt=np.array(obs_pt, np.int32), obs_uv=np.array(obs_uv, np.float64),
+                 obs_depth=np.array(obs_depth, np.float64), obs_weight=np.array(obs_w, np.float64), K=K, bf=bf)
+    return scene, dict(pose=gt_pose, pt=pts)
