@@ -220,6 +220,76 @@ SNK_API int snk_rectify(snk_matcher* m, const snk_rectification* rect, const snk
 SNK_API int snk_rectify_batch_dev(snk_matcher* m, const snk_rectification* rect, const snk_keypoint* kps_dev,
                                   const int32_t* n_dev, int cap, int batch, snk_kp64* out_dev, double* normalized_dev);
 
+/* ------------------------------------------------------------------------------------------
+ * Local bundle adjustment
+ * ------------------------------------------------------------------------------------------ */
+
+/* The members of Saiga::OptimizationOptions / BAOptions that Snake sets
+ * (Snake/Optimizer/LocalBundleAdjustment.cpp:47-64): maxIterations = 3, maxIterativeIterations = 30,
+ * iterativeTolerance = 1e-10, solverType = Iterative with buildExplizitSchur, huberMono / huberStereo
+ * = reprojectionErrorThreshold{Mono,Stereo} * lbaErrorFactor (Snake/System/SnakeGlobal.h:145-150).
+ * lambda_init: initial LM damping (0 = 1e-4). */
+typedef struct snk_ba_options
+{
+    int32_t max_iterations;
+    int32_t max_pcg_iterations;
+    double pcg_tol;
+    double huber_mono, huber_stereo;
+    double lambda_init;
+} snk_ba_options;
+
+/* One Saiga::Scene as MakeLocalScene fills it (LocalBundleAdjustment.cpp:187-293), flattened:
+ * images[i] = {se3 (world -> camera; quaternion x y z w, translation), constant};
+ * worldPoints[j] = {p, constant}; one entry per StereoImagePoint = {image, wp, point (pixels),
+ * depth (> 0 => stereo observation; u_r = u - bf/depth), weight}; intrinsics[0] = K; scene.bf. */
+typedef struct snk_ba_problem
+{
+    int32_t n_img, n_pt, n_obs;
+    double (*pose)[7];
+    const uint8_t* img_const;
+    double (*pt)[3];
+    const uint8_t* pt_const;
+    const int32_t* obs_img;
+    const int32_t* obs_pt;
+    const double (*obs_uv)[2];
+    const double* obs_depth;
+    const double* obs_weight;
+    double K[4]; /* fx fy cx cy */
+    double bf;
+} snk_ba_problem;
+
+typedef struct snk_ba snk_ba;
+
+SNK_API int snk_ba_create(const snk_ba_options* options, int device, void* stream, snk_ba** out);
+SNK_API int snk_ba_destroy(snk_ba* h);
+SNK_API int snk_ba_sync(snk_ba* h);
+
+/* Replaces BARecRel::create(scene) — LocalBundleAdjustment.cpp:359: analyse the structure, copy
+ * the problem to the device.  set_problems loads `count` independent windows that are solved side
+ * by side (one launch sequence for all).  The arrays are copied; they need not stay alive. */
+SNK_API int snk_ba_set_problem(snk_ba* h, const snk_ba_problem* problem);
+SNK_API int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count);
+
+/* Observations flagged here are ignored by solve / residuals, like StereoImagePoint::outlier
+ * (LocalBundleAdjustment.cpp:382,391).  obs_outlier has n_obs entries in caller order; NULL clears. */
+SNK_API int snk_ba_set_outliers(snk_ba* h, int problem, const uint8_t* obs_outlier);
+
+/* Replaces BARecRel::initAndSolve() / solve() — LocalBundleAdjustment.cpp:365,407: `iterations`
+ * LM iterations on every loaded problem (state stays on the device; fetch it with
+ * snk_ba_get_state).  cost_initial / cost_final (one per problem, may be NULL) mirror
+ * OptimizationResults::cost_initial / cost_final (LocalBundleAdjustment.cpp:412). */
+SNK_API int snk_ba_solve(snk_ba* h, int iterations, double* cost_initial, double* cost_final);
+SNK_API int snk_ba_solve_async(snk_ba* h, int iterations); /* enqueue only */
+SNK_API int snk_ba_reset(snk_ba* h);                       /* restore the poses / points given to set_problems */
+
+/* Optimised scene.images[i].se3 / scene.worldPoints[j].p (LocalBundleAdjustment.cpp:485-498). */
+SNK_API int snk_ba_get_state(snk_ba* h, int problem, double (*pose)[7], double (*pt)[3], int* pcg_iterations);
+
+/* Replaces the per-observation Scene::residual3 / residual2 squared norms of the chi-square outlier
+ * passes (LocalBundleAdjustment.cpp:372-395, 423-457): chi2_per_obs[o] = |weighted residual|^2 at the
+ * current state (0 for skipped observations), n_obs entries in caller order. */
+SNK_API int snk_ba_residuals(snk_ba* h, int problem, double* chi2_per_obs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,17 @@ SIGNATURES = {
     "snk_orb_set_profiling": (i32, [vp, i32]),
     "snk_orb_stage_times": (i32, [vp, vp, C.POINTER(i32)]),
     "snk_orb_debug_fetch": (i32, [vp, i32, i32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "snk_ba_create": (i32, [vp, i32, vp, C.POINTER(vp)]),
+    "snk_ba_destroy": (i32, [vp]),
+    "snk_ba_sync": (i32, [vp]),
+    "snk_ba_set_problem": (i32, [vp, vp]),
+    "snk_ba_set_problems": (i32, [vp, vp, i32]),
+    "snk_ba_set_outliers": (i32, [vp, i32, vp]),
+    "snk_ba_solve": (i32, [vp, i32, vp, vp]),
+    "snk_ba_solve_async": (i32, [vp, i32]),
+    "snk_ba_reset": (i32, [vp]),
+    "snk_ba_get_state": (i32, [vp, i32, vp, vp, C.POINTER(i32)]),
+    "snk_ba_residuals": (i32, [vp, i32, vp]),
 }
 
 

@@ -1,0 +1,1144 @@
+// Local bundle adjustment for gfx950 — replaces Saiga::BARecRel::create / initAndSolve / solve and
+// Scene::residual2/3 as Snake uses them (reference Snake/Optimizer/LocalBundleAdjustment.cpp:
+// options :47-64, scene :187-293, solve :353-413, chi-square passes :372-395,:423-457).
+//
+// Semantics: "snk-ba v1" (DESIGN.md §BA): Levenberg-Marquardt, Huber IRLS, explicit Schur
+// complement on the points, block-Jacobi PCG on the reduced camera system, all fp64.
+//
+// Mapping to the hardware.  A local window is small (<= 36 free cameras, a few thousand points,
+// ~10^4 observations), so the design goals are (1) no host round trip inside the LM loop — every
+// decision (accept / reject, lambda) is taken on the device, the host only enqueues a fixed
+// kernel sequence per iteration; (2) bit-reproducible sums — every reduction has a fixed order:
+// observations are stored sorted by point, per-camera and per-block sums walk precomputed index
+// lists, no floating-point atomics; (3) many windows per launch (blockIdx.y = problem) so that
+// disjoint keyframe windows / sequences fill the 256 CUs.
+//
+//   point_pass<0> thread per point : residuals + Jacobians of its observations, V, b_p, W, damping,
+//                                    V^-1, Y = W V^-1, Y b_p, robust cost of the point
+//   cam_pass      workgroup per free camera : U, b_c, rhs = b_c - sum Y b_p (fixed-order tree sums)
+//   schur_pass    36 threads per camera-pair block : S = U - sum Y W^T over the co-observations
+//   pcg_solve     one workgroup per problem : block-Jacobi PCG, vectors in LDS, S streamed from L2
+//   update_pass   thread per point / camera : back-substitution, trial points and poses (SE3 exp)
+//   point_pass<1> thread per point : robust cost at the trial state
+//   accept_pass   one workgroup per problem : fixed-order cost sums, accept / reject, lambda schedule
+#include "common.hpp"
+
+#include <algorithm>
+#include <vector>
+
+namespace snk
+{
+namespace
+{
+struct Prob
+{
+    int ni, np, no;     // images, points, valid observations (sorted by point)
+    int nfc, n6;        // free cameras, 6 * nfc
+    int img_off, pt_off, obs_off, cam_off;
+    int ptstart_off, camstart_off, citem_off, blkstart_off, ent_off;
+    int vec_off;        // n6-vectors (rhs, x)
+    long long s_off;    // S (n6 * n6 doubles)
+    int orig_off;       // first caller-order observation of this problem
+    int pad;
+    double K[4];
+    double bf;
+};
+
+struct Opt
+{
+    int max_pcg;
+    double pcg_tol, huber_mono, huber_stereo, lambda_init;
+};
+
+struct State  // per problem, device resident
+{
+    double cost, cost_new, lambda, vfac, cost_initial;
+    int accepted, iter, pcg_iters, pad;
+};
+
+struct Arrays
+{
+    const Prob* prob;
+    State* state;
+    double* pose;  // [img][7]
+    double* pose_new;
+    double* pt;  // [pt][3]
+    double* pt_new;
+    const unsigned char* pt_const;
+    const int* cam_idx;  // [img] free-camera index or -1
+    const int* pt_start;
+    // observations sorted by point
+    const int* o_img;
+    const int* o_cam;               // free-camera index of the observation's image, or -1
+    const unsigned char* o_ptfree;  // 1 when the observation's point is an unknown
+    const double2* o_uv;
+    const double* o_depth;
+    const double* o_weight;
+    const int* o_orig;             // caller-order index (global over problems)
+    const unsigned char* outlier;  // caller order
+    double* o_Jc;  // [obs][18] scaled pose Jacobian
+    double* o_r;   // [obs][4]  scaled residual, [3] = dim (0: inactive in this iteration)
+    double* o_W;   // [obs][18]
+    double* o_Y;   // [obs][18]
+    double* o_yb;  // [obs][6]
+    double* Vinv;  // [pt][6]
+    double* bp;    // [pt][3]
+    double* cost_pt;
+    double* cost_pt_new;
+    double* U;  // [cam][36] damped
+    const int* cam_start;
+    const int* cam_items;
+    const int* blk_start;
+    const int2* blk_ent;
+    double* S;
+    double* rhs;
+    double* x;
+    double* chi2;  // caller order
+};
+
+__device__ __forceinline__ void quat_to_R(const double* q, double* R)
+{
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
+    R[3] = 2 * (x * y + z * w);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+    R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
+}
+
+// residual (dim 2|3) and Jacobians; returns dim or 0 (not in front of the camera)
+template <bool JAC>
+__device__ __forceinline__ int obs_linearize(const double* pose, const double* R, const double* pt, const double* K, double bf,
+                                             double u, double v, double depth, double w, double* r, double* Jc, double* Jp)
+{
+    const double X = R[0] * pt[0] + R[1] * pt[1] + R[2] * pt[2] + pose[4];
+    const double Y = R[3] * pt[0] + R[4] * pt[1] + R[5] * pt[2] + pose[5];
+    const double Z = R[6] * pt[0] + R[7] * pt[1] + R[8] * pt[2] + pose[6];
+    if (Z <= 0.0) return 0;
+    const double iz = 1.0 / Z, iz2 = iz * iz;
+    const double fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+    const int dim = depth > 0.0 ? 3 : 2;
+    r[0] = w * (fx * X * iz + cx - u);
+    r[1] = w * (fy * Y * iz + cy - v);
+    r[2] = dim == 3 ? w * ((fx * X * iz + cx - bf * iz) - (u - bf / depth)) : 0.0;
+    if (JAC)
+    {
+        double P[9];
+        P[0] = fx * iz; P[1] = 0.0;     P[2] = -fx * X * iz2;
+        P[3] = 0.0;     P[4] = fy * iz; P[5] = -fy * Y * iz2;
+        P[6] = fx * iz; P[7] = 0.0;     P[8] = -fx * X * iz2 + bf * iz2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+        {
+            const double m = k < dim ? w : 0.0;
+            const double a = m * P[3 * k], b = m * P[3 * k + 1], c = m * P[3 * k + 2];
+            Jc[6 * k + 0] = a;
+            Jc[6 * k + 1] = b;
+            Jc[6 * k + 2] = c;
+            Jc[6 * k + 3] = -b * Z + c * Y;
+            Jc[6 * k + 4] = a * Z - c * X;
+            Jc[6 * k + 5] = -a * Y + b * X;
+            Jp[3 * k + 0] = a * R[0] + b * R[3] + c * R[6];
+            Jp[3 * k + 1] = a * R[1] + b * R[4] + c * R[7];
+            Jp[3 * k + 2] = a * R[2] + b * R[5] + c * R[8];
+        }
+    }
+    return dim;
+}
+
+__device__ __forceinline__ double huber_rho(double s, double d, double& sqrt_w)
+{
+    const double d2 = d * d;
+    if (s <= d2)
+    {
+        sqrt_w = 1.0;
+        return s;
+    }
+    const double rt = sqrt(s);
+    sqrt_w = sqrt(d / rt);
+    return 2.0 * d * rt - d2;
+}
+
+__device__ __forceinline__ double clampd(double v)
+{
+    return v < 1e-6 ? 1e-6 : (v > 1e32 ? 1e32 : v);
+}
+
+// MODE 0: linearise at the current state; MODE 1: robust cost at the trial state;
+// MODE 2: chi-square (squared weighted residual norm) per caller observation at the current state
+template <int MODE>
+__global__ __launch_bounds__(128) void point_pass(Arrays A, Opt O)
+{
+    const int pb  = blockIdx.y;
+    const Prob pr = A.prob[pb];
+    const int p   = blockIdx.x * 128 + threadIdx.x;
+    if (p >= pr.np) return;
+    const int gp        = pr.pt_off + p;
+    const double* poses = (MODE == 1 ? A.pose_new : A.pose) + (size_t)pr.img_off * 7;
+    const double* ptp   = (MODE == 1 ? A.pt_new : A.pt) + (size_t)gp * 3;
+    const double pt[3]  = {ptp[0], ptp[1], ptp[2]};
+    const bool pfree    = !A.pt_const[gp];
+    const int s0 = A.pt_start[pr.ptstart_off + p], s1 = A.pt_start[pr.ptstart_off + p + 1];
+    double V[6] = {0, 0, 0, 0, 0, 0}, bp[3] = {0, 0, 0};
+    double cost = 0.0;
+
+    for (int s = s0; s < s1; ++s)
+    {
+        const int go = pr.obs_off + s;
+        const int oo = A.o_orig[go];
+        if (MODE == 0) A.o_r[(size_t)go * 4 + 3] = 0.0;
+        if (A.outlier[oo])
+        {
+            if (MODE == 2) A.chi2[oo] = 0.0;
+            continue;
+        }
+        const double* pose = poses + (size_t)A.o_img[go] * 7;
+        double R[9];
+        quat_to_R(pose, R);
+        double r[3], Jc[18], Jp[9];
+        const double2 uv = A.o_uv[go];
+        const int dim = obs_linearize<MODE == 0>(pose, R, pt, pr.K, pr.bf, uv.x, uv.y, A.o_depth[go], A.o_weight[go], r, Jc, Jp);
+        const double sq = dim ? r[0] * r[0] + r[1] * r[1] + r[2] * r[2] : 0.0;
+        if (MODE == 2)
+        {
+            A.chi2[oo] = sq;
+            continue;
+        }
+        if (!dim) continue;
+        double sw;
+        cost += huber_rho(sq, dim == 3 ? O.huber_stereo : O.huber_mono, sw);
+        if (MODE == 0)
+        {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) r[k] *= sw;
+#pragma unroll
+            for (int k = 0; k < 18; ++k) Jc[k] *= sw;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Jp[k] *= sw;
+            const int c = A.o_cam[go];
+            double* rr  = A.o_r + (size_t)go * 4;
+            rr[0] = r[0];
+            rr[1] = r[1];
+            rr[2] = r[2];
+            rr[3] = (double)dim;
+            if (c >= 0)
+            {
+                double* jc = A.o_Jc + (size_t)go * 18;
+#pragma unroll
+                for (int k = 0; k < 18; ++k) jc[k] = Jc[k];
+            }
+            if (pfree)
+            {
+                // V (upper: 00 01 02 11 12 22), b_p = -Jp^T r
+                V[0] += Jp[0] * Jp[0] + Jp[3] * Jp[3] + Jp[6] * Jp[6];
+                V[1] += Jp[0] * Jp[1] + Jp[3] * Jp[4] + Jp[6] * Jp[7];
+                V[2] += Jp[0] * Jp[2] + Jp[3] * Jp[5] + Jp[6] * Jp[8];
+                V[3] += Jp[1] * Jp[1] + Jp[4] * Jp[4] + Jp[7] * Jp[7];
+                V[4] += Jp[1] * Jp[2] + Jp[4] * Jp[5] + Jp[7] * Jp[8];
+                V[5] += Jp[2] * Jp[2] + Jp[5] * Jp[5] + Jp[8] * Jp[8];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) bp[a] -= Jp[a] * r[0] + Jp[3 + a] * r[1] + Jp[6 + a] * r[2];
+                if (c >= 0)
+                {
+                    double* Wp = A.o_W + (size_t)go * 18;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a)
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) Wp[a * 3 + b] = Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b] + Jc[12 + a] * Jp[6 + b];
+                }
+            }
+        }
+    }
+    if (MODE == 2) return;
+    if (MODE == 1)
+    {
+        A.cost_pt_new[gp] = cost;
+        return;
+    }
+    A.cost_pt[gp] = cost;
+    if (!pfree) return;
+    const double lambda = A.state[pb].lambda;
+    V[0] += lambda * clampd(V[0]);
+    V[3] += lambda * clampd(V[3]);
+    V[5] += lambda * clampd(V[5]);
+    double Vi[6];
+    {
+        const double a = V[0], b = V[1], c = V[2], d = V[3], e = V[4], f = V[5];
+        const double Aa = d * f - e * e, Bb = c * e - b * f, Cc = b * e - c * d;
+        const double det = a * Aa + b * Bb + c * Cc;
+        const double id  = det == 0.0 ? 0.0 : 1.0 / det;
+        Vi[0] = Aa * id;
+        Vi[1] = Bb * id;
+        Vi[2] = Cc * id;
+        Vi[3] = (a * f - c * c) * id;
+        Vi[4] = (b * c - a * e) * id;
+        Vi[5] = (a * d - b * b) * id;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) A.Vinv[(size_t)gp * 6 + k] = Vi[k];
+    A.bp[(size_t)gp * 3 + 0] = bp[0];
+    A.bp[(size_t)gp * 3 + 1] = bp[1];
+    A.bp[(size_t)gp * 3 + 2] = bp[2];
+    // Y = W V^-1 and Y b_p for every active coupling observation of this point
+    for (int s = s0; s < s1; ++s)
+    {
+        const int go = pr.obs_off + s;
+        if (A.o_cam[go] < 0 || A.o_r[(size_t)go * 4 + 3] == 0.0) continue;
+        const double* Wp = A.o_W + (size_t)go * 18;
+        double* Yp       = A.o_Y + (size_t)go * 18;
+        double* yb       = A.o_yb + (size_t)go * 6;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+        {
+            const double w0 = Wp[a * 3], w1 = Wp[a * 3 + 1], w2 = Wp[a * 3 + 2];
+            const double y0 = w0 * Vi[0] + w1 * Vi[1] + w2 * Vi[2];
+            const double y1 = w0 * Vi[1] + w1 * Vi[3] + w2 * Vi[4];
+            const double y2 = w0 * Vi[2] + w1 * Vi[4] + w2 * Vi[5];
+            Yp[a * 3]     = y0;
+            Yp[a * 3 + 1] = y1;
+            Yp[a * 3 + 2] = y2;
+            yb[a]         = y0 * bp[0] + y1 * bp[1] + y2 * bp[2];
+        }
+    }
+}
+
+// fixed-order sum of one double per thread over the workgroup (power-of-two size)
+template <int THREADS>
+__device__ __forceinline__ double block_sum(double v, double* red, int tid)
+{
+    red[tid] = v;
+    __syncthreads();
+#pragma unroll
+    for (int off = THREADS / 2; off > 0; off >>= 1)
+    {
+        if (tid < off) red[tid] += red[tid + off];
+        __syncthreads();
+    }
+    const double t = red[0];
+    __syncthreads();
+    return t;
+}
+
+constexpr int CAM_THREADS = 256;
+__global__ __launch_bounds__(CAM_THREADS) void cam_pass(Arrays A)
+{
+    __shared__ double red[CAM_THREADS];
+    const int pb  = blockIdx.y;
+    const Prob pr = A.prob[pb];
+    const int c   = blockIdx.x;
+    if (c >= pr.nfc) return;
+    const int tid = threadIdx.x;
+    const int s0 = A.cam_start[pr.camstart_off + c], s1 = A.cam_start[pr.camstart_off + c + 1];
+    double acc[33];  // 21 (U upper) | 6 (b_c) | 6 (sum Y b_p)
+#pragma unroll
+    for (int k = 0; k < 33; ++k) acc[k] = 0.0;
+    for (int s = s0 + tid; s < s1; s += CAM_THREADS)
+    {
+        const int go     = pr.obs_off + A.cam_items[pr.citem_off + s];
+        const double* rr = A.o_r + (size_t)go * 4;
+        if (rr[3] == 0.0) continue;
+        const double* jc = A.o_Jc + (size_t)go * 18;
+        double J[18];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) J[k] = jc[k];
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b) acc[q++] += J[a] * J[b] + J[6 + a] * J[6 + b] + J[12 + a] * J[12 + b];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) acc[21 + a] -= J[a] * rr[0] + J[6 + a] * rr[1] + J[12 + a] * rr[2];
+        if (A.o_ptfree[go])
+        {
+            const double* yb = A.o_yb + (size_t)go * 6;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[27 + a] += yb[a];
+        }
+    }
+    double tot[33];
+#pragma unroll 1
+    for (int k = 0; k < 33; ++k) tot[k] = block_sum<CAM_THREADS>(acc[k], red, tid);
+    if (tid == 0)
+    {
+        const double lambda = A.state[pb].lambda;
+        double* U = A.U + (size_t)(pr.cam_off + c) * 36;
+        int q = 0;
+        for (int a = 0; a < 6; ++a)
+            for (int b = a; b < 6; ++b)
+            {
+                double v = tot[q++];
+                if (a == b) v += lambda * clampd(v);
+                U[a * 6 + b] = v;
+                U[b * 6 + a] = v;
+            }
+        for (int a = 0; a < 6; ++a) A.rhs[pr.vec_off + c * 6 + a] = tot[21 + a] - tot[27 + a];
+    }
+}
+
+// S block (c1, c2) = [c1 == c2] U - sum over co-observations of Y(c1) W(c2)^T ; 36 threads per block
+__global__ __launch_bounds__(252) void schur_pass(Arrays A)
+{
+    const int pb  = blockIdx.y;
+    const Prob pr = A.prob[pb];
+    const int blk = blockIdx.x * 7 + threadIdx.x / 36;
+    const int e   = threadIdx.x % 36;
+    if (blk >= pr.nfc * pr.nfc) return;
+    const int c1 = blk / pr.nfc, c2 = blk - c1 * pr.nfc;
+    const int r = e / 6, c = e - r * 6;
+    double acc = c1 == c2 ? A.U[(size_t)(pr.cam_off + c1) * 36 + e] : 0.0;
+    const int e0 = A.blk_start[pr.blkstart_off + blk], e1 = A.blk_start[pr.blkstart_off + blk + 1];
+    double sub = 0.0;
+    for (int k = e0; k < e1; ++k)
+    {
+        const int2 en = A.blk_ent[pr.ent_off + k];
+        const int g1 = pr.obs_off + en.x, g2 = pr.obs_off + en.y;
+        if (A.o_r[(size_t)g1 * 4 + 3] == 0.0 || A.o_r[(size_t)g2 * 4 + 3] == 0.0) continue;
+        const double* Y = A.o_Y + (size_t)g1 * 18 + r * 3;
+        const double* W = A.o_W + (size_t)g2 * 18 + c * 3;
+        sub += Y[0] * W[0] + Y[1] * W[1] + Y[2] * W[2];
+    }
+    A.S[pr.s_off + (size_t)(c1 * 6 + r) * pr.n6 + c2 * 6 + c] = acc - sub;
+}
+
+// 6x6 SPD inverse by Cholesky (one thread); falls back to the clamped diagonal
+__device__ void inv6_spd(const double* Ain, int lda, double* Ai)
+{
+    double L[36];
+    bool ok = true;
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j <= i; ++j)
+        {
+            double s = Ain[i * lda + j];
+            for (int k = 0; k < j; ++k) s -= L[i * 6 + k] * L[j * 6 + k];
+            if (i == j)
+            {
+                if (s <= 0.0)
+                {
+                    ok = false;
+                    s  = 1.0;
+                }
+                L[i * 6 + i] = sqrt(s);
+            }
+            else
+                L[i * 6 + j] = s / L[j * 6 + j];
+        }
+    if (!ok)
+    {
+        for (int k = 0; k < 36; ++k) Ai[k] = 0.0;
+        for (int a = 0; a < 6; ++a) Ai[a * 7] = 1.0 / clampd(Ain[a * lda + a]);
+        return;
+    }
+    for (int c = 0; c < 6; ++c)
+    {
+        double y[6], x[6];
+        for (int i = 0; i < 6; ++i)
+        {
+            double s = i == c ? 1.0 : 0.0;
+            for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k];
+            y[i] = s / L[i * 6 + i];
+        }
+        for (int i = 5; i >= 0; --i)
+        {
+            double s = y[i];
+            for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * x[k];
+            x[i] = s / L[i * 6 + i];
+        }
+        for (int i = 0; i < 6; ++i) Ai[i * 6 + c] = x[i];
+    }
+}
+
+constexpr int PCG_THREADS = 256;
+// dynamic LDS: r, z, p, Ap (n6 each) | Minv (nfc*36)
+__global__ __launch_bounds__(PCG_THREADS) void pcg_solve(Arrays A, Opt O)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ double red[PCG_THREADS];
+    const int pb  = blockIdx.x;
+    const Prob pr = A.prob[pb];
+    const int n6 = pr.n6, nfc = pr.nfc;
+    const int tid = threadIdx.x;
+    double* r  = reinterpret_cast<double*>(smem_raw);
+    double* z  = r + n6;
+    double* p  = z + n6;
+    double* Ap = p + n6;
+    double* Mi = Ap + n6;
+    const double* S   = A.S + pr.s_off;
+    const double* rhs = A.rhs + pr.vec_off;
+    double* x         = A.x + pr.vec_off;
+    if (n6 == 0) return;
+
+    for (int c = tid; c < nfc; c += PCG_THREADS) inv6_spd(S + (size_t)(c * 6) * n6 + c * 6, n6, Mi + c * 36);
+    double part = 0.0;
+    for (int q = tid; q < n6; q += PCG_THREADS)
+    {
+        const double v = rhs[q];
+        r[q] = v;
+        x[q] = 0.0;
+        part += v * v;
+    }
+    const double bnorm2 = block_sum<PCG_THREADS>(part, red, tid);
+    // z = Minv r ; p = z
+    part = 0.0;
+    for (int q = tid; q < n6; q += PCG_THREADS)
+    {
+        const int c = q / 6, a = q - c * 6;
+        double s = 0.0;
+        for (int b = 0; b < 6; ++b) s += Mi[c * 36 + a * 6 + b] * r[c * 6 + b];
+        z[q] = s;
+        p[q] = s;
+        part += r[q] * s;
+    }
+    double rz = block_sum<PCG_THREADS>(part, red, tid);
+    const double stop2 = O.pcg_tol * O.pcg_tol * bnorm2;
+    int iters = 0;
+    for (int k = 0; k < O.max_pcg; ++k)
+    {
+        part = 0.0;
+        for (int q = tid; q < n6; q += PCG_THREADS) part += r[q] * r[q];
+        const double rn2 = block_sum<PCG_THREADS>(part, red, tid);
+        if (rn2 <= stop2) break;
+        part = 0.0;
+        for (int q = tid; q < n6; q += PCG_THREADS)
+        {
+            // row q of S == column q (symmetric): coalesced across q
+            double s = 0.0;
+            for (int t = 0; t < n6; ++t) s += S[(size_t)t * n6 + q] * p[t];
+            Ap[q] = s;
+            part += p[q] * s;
+        }
+        const double pAp = block_sum<PCG_THREADS>(part, red, tid);
+        if (pAp <= 0.0) break;
+        const double alpha = rz / pAp;
+        for (int q = tid; q < n6; q += PCG_THREADS)
+        {
+            x[q] += alpha * p[q];
+            r[q] -= alpha * Ap[q];
+        }
+        __syncthreads();
+        part = 0.0;
+        for (int q = tid; q < n6; q += PCG_THREADS)
+        {
+            const int c = q / 6, a = q - c * 6;
+            double s = 0.0;
+            for (int b = 0; b < 6; ++b) s += Mi[c * 36 + a * 6 + b] * r[c * 6 + b];
+            z[q] = s;
+            part += r[q] * s;
+        }
+        const double rz_new = block_sum<PCG_THREADS>(part, red, tid);
+        const double beta   = rz_new / rz;
+        rz                  = rz_new;
+        for (int q = tid; q < n6; q += PCG_THREADS) p[q] = z[q] + beta * p[q];
+        __syncthreads();
+        ++iters;
+    }
+    if (tid == 0) A.state[pb].pcg_iters += iters;
+}
+
+// pose <- exp(delta) * pose
+__device__ void se3_update(const double* pose, const double* d, double* out)
+{
+    const double wx = d[3], wy = d[4], wz = d[5];
+    const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
+    double B, Cc, qd[4];
+    if (th < 1e-8)
+    {
+        B  = 0.5 - th2 / 24.0;
+        Cc = 1.0 / 6.0 - th2 / 120.0;
+        const double h = 0.5 - th2 / 48.0;
+        qd[0] = h * wx; qd[1] = h * wy; qd[2] = h * wz; qd[3] = 1.0 - th2 / 8.0;
+    }
+    else
+    {
+        const double s = sin(th), c = cos(th);
+        B  = (1.0 - c) / th2;
+        Cc = (th - s) / (th2 * th);
+        const double sh = sin(0.5 * th) / th;
+        qd[0] = sh * wx; qd[1] = sh * wy; qd[2] = sh * wz; qd[3] = cos(0.5 * th);
+    }
+    const double vx = d[0], vy = d[1], vz = d[2];
+    const double cx = wy * vz - wz * vy, cy = wz * vx - wx * vz, cz = wx * vy - wy * vx;
+    const double ccx = wy * cz - wz * cy, ccy = wz * cx - wx * cz, ccz = wx * cy - wy * cx;
+    const double tdx = vx + B * cx + Cc * ccx, tdy = vy + B * cy + Cc * ccy, tdz = vz + B * cz + Cc * ccz;
+    double Rd[9];
+    quat_to_R(qd, Rd);
+    const double tx = pose[4], ty = pose[5], tz = pose[6];
+    const double ax = qd[0], ay = qd[1], az = qd[2], aw = qd[3], bx = pose[0], by = pose[1], bz = pose[2], bw = pose[3];
+    double q[4];
+    q[0] = aw * bx + ax * bw + ay * bz - az * by;
+    q[1] = aw * by - ax * bz + ay * bw + az * bx;
+    q[2] = aw * bz + ax * by - ay * bx + az * bw;
+    q[3] = aw * bw - ax * bx - ay * by - az * bz;
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    out[0] = q[0] / n; out[1] = q[1] / n; out[2] = q[2] / n; out[3] = q[3] / n;
+    out[4] = Rd[0] * tx + Rd[1] * ty + Rd[2] * tz + tdx;
+    out[5] = Rd[3] * tx + Rd[4] * ty + Rd[5] * tz + tdy;
+    out[6] = Rd[6] * tx + Rd[7] * ty + Rd[8] * tz + tdz;
+}
+
+// threads [0, np): back-substitution dp = V^-1 (b_p - sum W^T dc); threads [np, np + ni): trial poses
+__global__ __launch_bounds__(128) void update_pass(Arrays A)
+{
+    const int pb  = blockIdx.y;
+    const Prob pr = A.prob[pb];
+    const int t   = blockIdx.x * 128 + threadIdx.x;
+    const double* x = A.x + pr.vec_off;
+    if (t < pr.np)
+    {
+        const int gp = pr.pt_off + t;
+        double* out  = A.pt_new + (size_t)gp * 3;
+        const double* cur = A.pt + (size_t)gp * 3;
+        if (A.pt_const[gp])
+        {
+            out[0] = cur[0];
+            out[1] = cur[1];
+            out[2] = cur[2];
+            return;
+        }
+        double g[3] = {A.bp[(size_t)gp * 3], A.bp[(size_t)gp * 3 + 1], A.bp[(size_t)gp * 3 + 2]};
+        const int s0 = A.pt_start[pr.ptstart_off + t], s1 = A.pt_start[pr.ptstart_off + t + 1];
+        for (int s = s0; s < s1; ++s)
+        {
+            const int go = pr.obs_off + s;
+            const int c  = A.o_cam[go];
+            if (c < 0 || A.o_r[(size_t)go * 4 + 3] == 0.0) continue;
+            const double* Wp = A.o_W + (size_t)go * 18;
+            const double* xc = x + c * 6;
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int a = 0; a < 6; ++a) g[b] -= Wp[a * 3 + b] * xc[a];
+        }
+        const double* Vi = A.Vinv + (size_t)gp * 6;
+        out[0] = cur[0] + (Vi[0] * g[0] + Vi[1] * g[1] + Vi[2] * g[2]);
+        out[1] = cur[1] + (Vi[1] * g[0] + Vi[3] * g[1] + Vi[4] * g[2]);
+        out[2] = cur[2] + (Vi[2] * g[0] + Vi[4] * g[1] + Vi[5] * g[2]);
+    }
+    else if (t < pr.np + pr.ni)
+    {
+        const int i  = t - pr.np;
+        const int gi = pr.img_off + i;
+        const int c  = A.cam_idx[gi];
+        const double* cur = A.pose + (size_t)gi * 7;
+        double* out       = A.pose_new + (size_t)gi * 7;
+        if (c < 0)
+            for (int k = 0; k < 7; ++k) out[k] = cur[k];
+        else
+            se3_update(cur, x + c * 6, out);
+    }
+}
+
+constexpr int ACC_THREADS = 256;
+__global__ __launch_bounds__(ACC_THREADS) void accept_pass(Arrays A)
+{
+    __shared__ double red[ACC_THREADS];
+    __shared__ int s_acc;
+    const int pb  = blockIdx.x;
+    const Prob pr = A.prob[pb];
+    const int tid = threadIdx.x;
+    // fixed-order sums: contiguous chunk per thread, then the tree
+    const int chunk = (pr.np + ACC_THREADS - 1) / ACC_THREADS;
+    double c0 = 0.0, c1 = 0.0;
+    for (int k = 0; k < chunk; ++k)
+    {
+        const int p = tid * chunk + k;
+        if (p < pr.np)
+        {
+            c0 += A.cost_pt[pr.pt_off + p];
+            c1 += A.cost_pt_new[pr.pt_off + p];
+        }
+    }
+    const double cost     = block_sum<ACC_THREADS>(c0, red, tid);
+    const double cost_new = block_sum<ACC_THREADS>(c1, red, tid);
+    State& st = A.state[pb];
+    if (tid == 0)
+    {
+        if (st.iter == 0) st.cost_initial = cost;
+        const int acc = cost_new < cost ? 1 : 0;
+        st.cost_new   = cost_new;
+        st.accepted   = acc;
+        if (acc)
+        {
+            st.cost   = cost_new;
+            st.lambda = st.lambda * (1.0 / 3.0);
+            st.vfac   = 2.0;
+        }
+        else
+        {
+            st.cost = cost;
+            st.lambda *= st.vfac;
+            st.vfac *= 2.0;
+        }
+        st.iter += 1;
+        s_acc = acc;
+    }
+    __syncthreads();
+    if (!s_acc) return;
+    for (int k = tid; k < pr.np * 3; k += ACC_THREADS) A.pt[(size_t)pr.pt_off * 3 + k] = A.pt_new[(size_t)pr.pt_off * 3 + k];
+    for (int k = tid; k < pr.ni * 7; k += ACC_THREADS) A.pose[(size_t)pr.img_off * 7 + k] = A.pose_new[(size_t)pr.img_off * 7 + k];
+}
+
+__global__ void begin_solve(State* st, int n, double lambda_init)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    st[i].lambda    = lambda_init;
+    st[i].vfac      = 2.0;
+    st[i].iter      = 0;
+    st[i].pcg_iters = 0;
+    st[i].accepted  = 0;
+}
+}  // namespace
+}  // namespace snk
+
+using namespace snk;
+
+struct snk_ba : HandleBase
+{
+    snk_ba_options opt{};
+    int count = 0;
+    std::vector<Prob> probs;
+    int tot_img = 0, tot_pt = 0, tot_obs = 0, tot_cam = 0, tot_orig = 0, tot_vec = 0;
+    long long tot_s = 0;
+    int max_np = 0, max_nfc = 0, max_n6 = 0, max_ni = 0;
+    DevBuf d_prob, d_state, d_pose, d_pose_new, d_pose0, d_pt, d_pt_new, d_pt0, d_ptc, d_camidx, d_ptstart, d_oimg, d_ocam,
+        d_optfree, d_ouv, d_odepth, d_oweight, d_oorig, d_outlier, d_Jc, d_r, d_W, d_Y, d_yb, d_Vinv, d_bp, d_cost,
+        d_cost_new, d_U, d_camstart, d_camitems, d_blkstart, d_blkent, d_S, d_rhs, d_x, d_chi2;
+    Arrays arr{};
+    std::vector<int> orig_off, orig_n;
+};
+
+namespace
+{
+Opt make_opt(const snk_ba_options& o)
+{
+    Opt d;
+    d.max_pcg      = o.max_pcg_iterations;
+    d.pcg_tol      = o.pcg_tol;
+    d.huber_mono   = o.huber_mono;
+    d.huber_stereo = o.huber_stereo;
+    d.lambda_init  = o.lambda_init > 0.0 ? o.lambda_init : 1e-4;
+    return d;
+}
+
+template <typename T>
+int upload(DevBuf& b, const std::vector<T>& v, hipStream_t s)
+{
+    int rc = b.reserve(std::max<size_t>(v.size(), 1) * sizeof(T));
+    if (rc != SNK_OK) return rc;
+    if (!v.empty()) SNK_HIP_CHECK(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    return SNK_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int snk_ba_create(const snk_ba_options* options, int device, void* stream, snk_ba** out)
+{
+    SNK_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    SNK_REQUIRE(options != nullptr, "options is NULL");
+    SNK_REQUIRE(options->max_iterations >= 0 && options->max_pcg_iterations >= 0, "negative iteration count");
+    SNK_REQUIRE(options->huber_mono > 0.0 && options->huber_stereo > 0.0, "Huber thresholds must be > 0");
+    snk_ba* h = new snk_ba();
+    h->opt    = *options;
+    int rc    = h->init(device, stream);
+    if (rc != SNK_OK)
+    {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return SNK_OK;
+}
+
+int snk_ba_destroy(snk_ba* h)
+{
+    if (!h) return SNK_OK;
+    (void)hipSetDevice(h->device);
+    DevBuf* all[] = {&h->d_prob, &h->d_state, &h->d_pose, &h->d_pose_new, &h->d_pose0, &h->d_pt, &h->d_pt_new, &h->d_pt0,
+                     &h->d_ptc, &h->d_camidx, &h->d_ptstart, &h->d_oimg, &h->d_ocam, &h->d_optfree, &h->d_ouv, &h->d_odepth,
+                     &h->d_oweight, &h->d_oorig, &h->d_outlier, &h->d_Jc, &h->d_r, &h->d_W, &h->d_Y, &h->d_yb, &h->d_Vinv,
+                     &h->d_bp, &h->d_cost, &h->d_cost_new, &h->d_U, &h->d_camstart, &h->d_camitems, &h->d_blkstart,
+                     &h->d_blkent, &h->d_S, &h->d_rhs, &h->d_x, &h->d_chi2};
+    for (DevBuf* b : all) b->release();
+    h->fini();
+    delete h;
+    return SNK_OK;
+}
+
+int snk_ba_sync(snk_ba* h)
+{
+    SNK_REQUIRE(h != nullptr, "ba is NULL");
+    SNK_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return SNK_OK;
+}
+
+int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
+{
+    SNK_REQUIRE(h != nullptr, "ba is NULL");
+    SNK_REQUIRE(count >= 1 && count <= 65535 && problems != nullptr, "count must be 1..65535");
+    SNK_HIP_CHECK(hipSetDevice(h->device));
+    SNK_HIP_CHECK(hipStreamSynchronize(h->stream));
+
+    std::vector<Prob> probs((size_t)count);
+    std::vector<double> pose, pt, ouv2, odepth, oweight;
+    std::vector<unsigned char> ptc, optfree;
+    std::vector<int> camidx, ptstart, oimg, ocam, oorig, camstart, camitems, blkstart;
+    std::vector<int2> blkent;
+    h->orig_off.assign((size_t)count, 0);
+    h->orig_n.assign((size_t)count, 0);
+    int img_off = 0, pt_off = 0, obs_off = 0, cam_off = 0, orig_off = 0, vec_off = 0;
+    long long s_off = 0;
+    int max_np = 0, max_nfc = 0, max_n6 = 0, max_ni = 0;
+
+    for (int b = 0; b < count; ++b)
+    {
+        const snk_ba_problem& P = problems[b];
+        SNK_REQUIRE(P.n_img >= 0 && P.n_pt >= 0 && P.n_obs >= 0, "negative problem size");
+        SNK_REQUIRE(P.n_img == 0 || (P.pose && P.img_const), "NULL pose arrays");
+        SNK_REQUIRE(P.n_pt == 0 || (P.pt && P.pt_const), "NULL point arrays");
+        SNK_REQUIRE(P.n_obs == 0 || (P.obs_img && P.obs_pt && P.obs_uv && P.obs_depth && P.obs_weight), "NULL observation arrays");
+        Prob& pr = probs[(size_t)b];
+        memset(&pr, 0, sizeof(pr));
+        pr.ni = P.n_img;
+        pr.np = P.n_pt;
+        for (int k = 0; k < 4; ++k) pr.K[k] = P.K[k];
+        pr.bf       = P.bf;
+        pr.img_off  = img_off;
+        pr.pt_off   = pt_off;
+        pr.obs_off  = obs_off;
+        pr.cam_off  = cam_off;
+        pr.orig_off = orig_off;
+        pr.vec_off  = vec_off;
+        pr.s_off    = s_off;
+        h->orig_off[(size_t)b] = orig_off;
+        h->orig_n[(size_t)b]   = P.n_obs;
+        // values
+        for (int i = 0; i < P.n_img; ++i)
+            for (int k = 0; k < 7; ++k) pose.push_back(P.pose[i][k]);
+        for (int p = 0; p < P.n_pt; ++p)
+        {
+            for (int k = 0; k < 3; ++k) pt.push_back(P.pt[p][k]);
+            ptc.push_back(P.pt_const[p] ? 1 : 0);
+        }
+        // free cameras
+        int nfc = 0;
+        std::vector<int> cidx((size_t)P.n_img);
+        for (int i = 0; i < P.n_img; ++i) cidx[(size_t)i] = P.img_const[i] ? -1 : nfc++;
+        camidx.insert(camidx.end(), cidx.begin(), cidx.end());
+        pr.nfc = nfc;
+        pr.n6  = 6 * nfc;
+        // valid observations, counting sort by point (stable: caller order inside a point)
+        std::vector<int> pstart((size_t)P.n_pt + 1, 0);
+        std::vector<char> valid((size_t)P.n_obs, 0);
+        for (int o = 0; o < P.n_obs; ++o)
+        {
+            const int i = P.obs_img[o], p = P.obs_pt[o];
+            if (i < 0 || i >= P.n_img || p < 0 || p >= P.n_pt) continue;
+            if (P.img_const[i] && P.pt_const[p]) continue;  // reference LocalBundleAdjustment.cpp:286
+            valid[(size_t)o] = 1;
+            pstart[(size_t)p + 1]++;
+        }
+        for (int p = 0; p < P.n_pt; ++p) pstart[(size_t)p + 1] += pstart[(size_t)p];
+        const int no = pstart[(size_t)P.n_pt];
+        pr.no        = no;
+        std::vector<int> order((size_t)no);
+        {
+            std::vector<int> fill(pstart.begin(), pstart.end() - 1);
+            for (int o = 0; o < P.n_obs; ++o)
+                if (valid[(size_t)o]) order[(size_t)fill[(size_t)P.obs_pt[o]]++] = o;
+        }
+        pr.ptstart_off = (int)ptstart.size();
+        ptstart.insert(ptstart.end(), pstart.begin(), pstart.end());
+        std::vector<int> s_cam((size_t)no);
+        for (int s = 0; s < no; ++s)
+        {
+            const int o = order[(size_t)s];
+            const int i = P.obs_img[o], p = P.obs_pt[o];
+            oimg.push_back(i);
+            ocam.push_back(cidx[(size_t)i]);
+            s_cam[(size_t)s] = cidx[(size_t)i];
+            optfree.push_back(P.pt_const[p] ? 0 : 1);
+            ouv2.push_back(P.obs_uv[o][0]);
+            ouv2.push_back(P.obs_uv[o][1]);
+            odepth.push_back(P.obs_depth[o]);
+            oweight.push_back(P.obs_weight[o]);
+            oorig.push_back(orig_off + o);
+        }
+        // camera lists
+        pr.camstart_off = (int)camstart.size();
+        pr.citem_off    = (int)camitems.size();
+        {
+            std::vector<int> cs((size_t)nfc + 1, 0);
+            for (int s = 0; s < no; ++s)
+                if (s_cam[(size_t)s] >= 0) cs[(size_t)s_cam[(size_t)s] + 1]++;
+            for (int c = 0; c < nfc; ++c) cs[(size_t)c + 1] += cs[(size_t)c];
+            std::vector<int> items((size_t)cs[(size_t)nfc]);
+            std::vector<int> fill(cs.begin(), cs.end() - 1);
+            for (int s = 0; s < no; ++s)
+                if (s_cam[(size_t)s] >= 0) items[(size_t)fill[(size_t)s_cam[(size_t)s]]++] = s;
+            camstart.insert(camstart.end(), cs.begin(), cs.end());
+            camitems.insert(camitems.end(), items.begin(), items.end());
+        }
+        // camera-pair blocks: co-observations of every ordered pair (dense block grid, empty blocks allowed)
+        pr.blkstart_off = (int)blkstart.size();
+        pr.ent_off      = (int)blkent.size();
+        {
+            const size_t nb = (size_t)nfc * nfc;
+            std::vector<int> bs(nb + 1, 0);
+            for (int p = 0; p < P.n_pt; ++p)
+            {
+                if (P.pt_const[p]) continue;
+                for (int a = pstart[(size_t)p]; a < pstart[(size_t)p + 1]; ++a)
+                {
+                    if (s_cam[(size_t)a] < 0) continue;
+                    for (int c = pstart[(size_t)p]; c < pstart[(size_t)p + 1]; ++c)
+                        if (s_cam[(size_t)c] >= 0) bs[(size_t)s_cam[(size_t)a] * nfc + s_cam[(size_t)c] + 1]++;
+                }
+            }
+            for (size_t k = 0; k < nb; ++k) bs[k + 1] += bs[k];
+            std::vector<int2> ent((size_t)bs[nb]);
+            std::vector<int> fill(bs.begin(), bs.end() - 1);
+            for (int p = 0; p < P.n_pt; ++p)
+            {
+                if (P.pt_const[p]) continue;
+                for (int a = pstart[(size_t)p]; a < pstart[(size_t)p + 1]; ++a)
+                {
+                    if (s_cam[(size_t)a] < 0) continue;
+                    for (int c = pstart[(size_t)p]; c < pstart[(size_t)p + 1]; ++c)
+                        if (s_cam[(size_t)c] >= 0)
+                        {
+                            int2 e;
+                            e.x = a;
+                            e.y = c;
+                            ent[(size_t)fill[(size_t)s_cam[(size_t)a] * nfc + s_cam[(size_t)c]]++] = e;
+                        }
+                }
+            }
+            blkstart.insert(blkstart.end(), bs.begin(), bs.end());
+            blkent.insert(blkent.end(), ent.begin(), ent.end());
+        }
+        img_off += P.n_img;
+        pt_off += P.n_pt;
+        obs_off += no;
+        cam_off += nfc;
+        orig_off += P.n_obs;
+        vec_off += pr.n6;
+        s_off += (long long)pr.n6 * pr.n6;
+        max_np  = std::max(max_np, P.n_pt);
+        max_ni  = std::max(max_ni, P.n_img);
+        max_nfc = std::max(max_nfc, nfc);
+        max_n6  = std::max(max_n6, pr.n6);
+    }
+    const size_t pcg_lds = (size_t)max_n6 * 4 * 8 + (size_t)max_nfc * 36 * 8;
+    if (pcg_lds > 150 * 1024)
+    {
+        set_error("reduced camera system too large for the in-LDS PCG (%d free cameras)", max_nfc);
+        return SNK_ERR_CAPACITY;
+    }
+    h->probs = probs;
+    h->count = count;
+    h->tot_img = img_off; h->tot_pt = pt_off; h->tot_obs = obs_off; h->tot_cam = cam_off; h->tot_orig = orig_off;
+    h->tot_vec = vec_off; h->tot_s = s_off;
+    h->max_np = max_np; h->max_nfc = max_nfc; h->max_n6 = max_n6; h->max_ni = max_ni;
+
+    int rc;
+    hipStream_t st = h->stream;
+#define UP(buf, vec) if ((rc = upload(h->buf, vec, st)) != SNK_OK) return rc
+    UP(d_prob, probs);
+    UP(d_pose, pose);
+    UP(d_pose0, pose);
+    UP(d_pt, pt);
+    UP(d_pt0, pt);
+    UP(d_ptc, ptc);
+    UP(d_camidx, camidx);
+    UP(d_ptstart, ptstart);
+    UP(d_oimg, oimg);
+    UP(d_ocam, ocam);
+    UP(d_optfree, optfree);
+    UP(d_ouv, ouv2);
+    UP(d_odepth, odepth);
+    UP(d_oweight, oweight);
+    UP(d_oorig, oorig);
+    UP(d_camstart, camstart);
+    UP(d_camitems, camitems);
+    UP(d_blkstart, blkstart);
+    UP(d_blkent, blkent);
+#undef UP
+    const size_t nobs = (size_t)std::max(obs_off, 1), npt = (size_t)std::max(pt_off, 1);
+#define RS(buf, bytes) if ((rc = h->buf.reserve(bytes)) != SNK_OK) return rc
+    RS(d_state, (size_t)count * sizeof(State));
+    RS(d_pose_new, (size_t)std::max(img_off, 1) * 7 * 8);
+    RS(d_pt_new, npt * 3 * 8);
+    RS(d_outlier, (size_t)std::max(orig_off, 1));
+    RS(d_chi2, (size_t)std::max(orig_off, 1) * 8);
+    RS(d_Jc, nobs * 18 * 8);
+    RS(d_r, nobs * 4 * 8);
+    RS(d_W, nobs * 18 * 8);
+    RS(d_Y, nobs * 18 * 8);
+    RS(d_yb, nobs * 6 * 8);
+    RS(d_Vinv, npt * 6 * 8);
+    RS(d_bp, npt * 3 * 8);
+    RS(d_cost, npt * 8);
+    RS(d_cost_new, npt * 8);
+    RS(d_U, (size_t)std::max(cam_off, 1) * 36 * 8);
+    RS(d_S, (size_t)std::max<long long>(s_off, 1) * 8);
+    RS(d_rhs, (size_t)std::max(vec_off, 1) * 8);
+    RS(d_x, (size_t)std::max(vec_off, 1) * 8);
+#undef RS
+    SNK_HIP_CHECK(hipMemsetAsync(h->d_outlier.p, 0, (size_t)std::max(orig_off, 1), st));
+    SNK_HIP_CHECK(hipMemsetAsync(h->d_state.p, 0, (size_t)count * sizeof(State), st));
+    SNK_HIP_CHECK(hipMemsetAsync(h->d_r.p, 0, nobs * 4 * 8, st));
+    SNK_HIP_CHECK(hipMemsetAsync(h->d_x.p, 0, (size_t)std::max(vec_off, 1) * 8, st));
+    SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pcg_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)std::max<size_t>(pcg_lds, 64)));
+
+    Arrays& A   = h->arr;
+    A.prob      = h->d_prob.as<Prob>();
+    A.state     = h->d_state.as<State>();
+    A.pose      = h->d_pose.as<double>();
+    A.pose_new  = h->d_pose_new.as<double>();
+    A.pt        = h->d_pt.as<double>();
+    A.pt_new    = h->d_pt_new.as<double>();
+    A.pt_const  = h->d_ptc.as<unsigned char>();
+    A.cam_idx   = h->d_camidx.as<int>();
+    A.pt_start  = h->d_ptstart.as<int>();
+    A.o_img     = h->d_oimg.as<int>();
+    A.o_cam     = h->d_ocam.as<int>();
+    A.o_ptfree  = h->d_optfree.as<unsigned char>();
+    A.o_uv      = h->d_ouv.as<double2>();
+    A.o_depth   = h->d_odepth.as<double>();
+    A.o_weight  = h->d_oweight.as<double>();
+    A.o_orig    = h->d_oorig.as<int>();
+    A.outlier   = h->d_outlier.as<unsigned char>();
+    A.o_Jc      = h->d_Jc.as<double>();
+    A.o_r       = h->d_r.as<double>();
+    A.o_W       = h->d_W.as<double>();
+    A.o_Y       = h->d_Y.as<double>();
+    A.o_yb      = h->d_yb.as<double>();
+    A.Vinv      = h->d_Vinv.as<double>();
+    A.bp        = h->d_bp.as<double>();
+    A.cost_pt   = h->d_cost.as<double>();
+    A.cost_pt_new = h->d_cost_new.as<double>();
+    A.U         = h->d_U.as<double>();
+    A.cam_start = h->d_camstart.as<int>();
+    A.cam_items = h->d_camitems.as<int>();
+    A.blk_start = h->d_blkstart.as<int>();
+    A.blk_ent   = h->d_blkent.as<int2>();
+    A.S         = h->d_S.as<double>();
+    A.rhs       = h->d_rhs.as<double>();
+    A.x         = h->d_x.as<double>();
+    A.chi2      = h->d_chi2.as<double>();
+    SNK_HIP_CHECK(hipStreamSynchronize(st));
+    return SNK_OK;
+}
+
+int snk_ba_set_problem(snk_ba* h, const snk_ba_problem* problem)
+{
+    return snk_ba_set_problems(h, problem, 1);
+}
+
+int snk_ba_set_outliers(snk_ba* h, int problem, const uint8_t* obs_outlier)
+{
+    SNK_REQUIRE(h != nullptr && h->count > 0, "no problem set");
+    SNK_REQUIRE(problem >= 0 && problem < h->count, "problem index out of range");
+    SNK_HIP_CHECK(hipSetDevice(h->device));
+    unsigned char* dst = h->d_outlier.as<unsigned char>() + h->orig_off[(size_t)problem];
+    const size_t n     = (size_t)h->orig_n[(size_t)problem];
+    if (n == 0) return SNK_OK;
+    if (obs_outlier)
+        SNK_HIP_CHECK(hipMemcpyAsync(dst, obs_outlier, n, hipMemcpyHostToDevice, h->stream));
+    else
+        SNK_HIP_CHECK(hipMemsetAsync(dst, 0, n, h->stream));
+    SNK_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return SNK_OK;
+}
+
+int snk_ba_reset(snk_ba* h)
+{
+    SNK_REQUIRE(h != nullptr && h->count > 0, "no problem set");
+    SNK_HIP_CHECK(hipSetDevice(h->device));
+    SNK_HIP_CHECK(hipMemcpyAsync(h->d_pose.p, h->d_pose0.p, (size_t)h->tot_img * 7 * 8, hipMemcpyDeviceToDevice, h->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(h->d_pt.p, h->d_pt0.p, (size_t)h->tot_pt * 3 * 8, hipMemcpyDeviceToDevice, h->stream));
+    return SNK_OK;
+}
+
+int snk_ba_solve_async(snk_ba* h, int iterations)
+{
+    SNK_REQUIRE(h != nullptr && h->count > 0, "no problem set");
+    SNK_REQUIRE(iterations >= 0, "negative iteration count");
+    SNK_HIP_CHECK(hipSetDevice(h->device));
+    const Opt O     = make_opt(h->opt);
+    const Arrays& A = h->arr;
+    hipStream_t st  = h->stream;
+    const int B     = h->count;
+    hipLaunchKernelGGL(begin_solve, dim3(ceil_div(B, 64)), dim3(64), 0, st, h->d_state.as<State>(), B, O.lambda_init);
+    SNK_LAUNCH_CHECK();
+    const dim3 gpt(std::max(1, ceil_div(h->max_np, 128)), B);
+    const size_t pcg_lds = (size_t)h->max_n6 * 4 * 8 + (size_t)h->max_nfc * 36 * 8;
+    for (int it = 0; it < iterations; ++it)
+    {
+        hipLaunchKernelGGL(point_pass<0>, gpt, dim3(128), 0, st, A, O);
+        if (h->max_nfc > 0)
+        {
+            hipLaunchKernelGGL(cam_pass, dim3(h->max_nfc, B), dim3(CAM_THREADS), 0, st, A);
+            hipLaunchKernelGGL(schur_pass, dim3(ceil_div(h->max_nfc * h->max_nfc, 7), B), dim3(252), 0, st, A);
+            hipLaunchKernelGGL(pcg_solve, dim3(B), dim3(PCG_THREADS), pcg_lds, st, A, O);
+        }
+        hipLaunchKernelGGL(update_pass, dim3(std::max(1, ceil_div(h->max_np + h->max_ni, 128)), B), dim3(128), 0, st, A);
+        hipLaunchKernelGGL(point_pass<1>, gpt, dim3(128), 0, st, A, O);
+        hipLaunchKernelGGL(accept_pass, dim3(B), dim3(ACC_THREADS), 0, st, A);
+        SNK_LAUNCH_CHECK();
+    }
+    return SNK_OK;
+}
+
+int snk_ba_solve(snk_ba* h, int iterations, double* cost_initial, double* cost_final)
+{
+    int rc = snk_ba_solve_async(h, iterations);
+    if (rc != SNK_OK) return rc;
+    std::vector<State> st((size_t)h->count);
+    SNK_HIP_CHECK(hipMemcpyAsync(st.data(), h->d_state.p, st.size() * sizeof(State), hipMemcpyDeviceToHost, h->stream));
+    SNK_HIP_CHECK(hipStreamSynchronize(h->stream));
+    for (int b = 0; b < h->count; ++b)
+    {
+        if (cost_initial) cost_initial[b] = st[(size_t)b].cost_initial;
+        if (cost_final) cost_final[b] = st[(size_t)b].cost;
+    }
+    return SNK_OK;
+}
+
+int snk_ba_get_state(snk_ba* h, int problem, double (*pose)[7], double (*pt)[3], int* pcg_iterations)
+{
+    SNK_REQUIRE(h != nullptr && h->count > 0, "no problem set");
+    SNK_REQUIRE(problem >= 0 && problem < h->count, "problem index out of range");
+    SNK_HIP_CHECK(hipSetDevice(h->device));
+    const Prob& pr = h->probs[(size_t)problem];
+    if (pose && pr.ni)
+        SNK_HIP_CHECK(hipMemcpyAsync(pose, h->d_pose.as<double>() + (size_t)pr.img_off * 7, (size_t)pr.ni * 56,
+                                     hipMemcpyDeviceToHost, h->stream));
+    if (pt && pr.np)
+        SNK_HIP_CHECK(hipMemcpyAsync(pt, h->d_pt.as<double>() + (size_t)pr.pt_off * 3, (size_t)pr.np * 24,
+                                     hipMemcpyDeviceToHost, h->stream));
+    State st{};
+    SNK_HIP_CHECK(hipMemcpyAsync(&st, h->d_state.as<State>() + problem, sizeof(State), hipMemcpyDeviceToHost, h->stream));
+    SNK_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (pcg_iterations) *pcg_iterations = st.pcg_iters;
+    return SNK_OK;
+}
+
+int snk_ba_residuals(snk_ba* h, int problem, double* chi2_per_obs)
+{
+    SNK_REQUIRE(h != nullptr && h->count > 0, "no problem set");
+    SNK_REQUIRE(problem >= 0 && problem < h->count && chi2_per_obs != nullptr, "bad arguments");
+    SNK_HIP_CHECK(hipSetDevice(h->device));
+    const Opt O = make_opt(h->opt);
+    SNK_HIP_CHECK(hipMemsetAsync(h->d_chi2.p, 0, (size_t)std::max(h->tot_orig, 1) * 8, h->stream));
+    hipLaunchKernelGGL(point_pass<2>, dim3(std::max(1, ceil_div(h->max_np, 128)), h->count), dim3(128), 0, h->stream, h->arr, O);
+    SNK_LAUNCH_CHECK();
+    const size_t n = (size_t)h->orig_n[(size_t)problem];
+    if (n)
+        SNK_HIP_CHECK(hipMemcpyAsync(chi2_per_obs, h->d_chi2.as<double>() + h->orig_off[(size_t)problem], n * 8,
+                                     hipMemcpyDeviceToHost, h->stream));
+    SNK_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return SNK_OK;
+}
+}
