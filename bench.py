@@ -76,12 +76,30 @@ def cpu_baseline(frames, seconds_budget=12.0):
                       f"BF kNN-2 with 4 threads + filter) in {el:.1f} s; CPU restatement of the reference path, not the reference binary"}
 
 
+def cpu_baseline_ba(seconds_budget=5.0):
+    """Oracle LBA solve (1 thread, like the reference's numThreads = 1, LocalBundleAdjustment.cpp:56)."""
+    from oracle import oracle as orc
+    from snake_slam_amd import synth
+
+    sc, _ = synth.ba_scene()
+    done, t0 = 0, time.perf_counter()
+    while True:
+        orc.ba_solve(sc, orc.ba_options())
+        done += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget:
+            break
+    return {"value": round(done * 3 / el, 2), "unit": "LM iterations/s", "cores": 1, "kind": "port",
+            "sample": f"{done} solves of the 20x2000x8 window (3 LM iterations each) in {el:.1f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="stereo frames per GPU per step")
+    ap.add_argument("--ba-windows", type=int, default=256, help="independent local-BA windows per GPU per step (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events")
     args = ap.parse_args()
@@ -173,6 +191,52 @@ def main():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
 
+    # ---- second half of the metric: local-BA LM iterations/s (20 KF x 2000 pts x 8 obs/pt) ----
+    ba_out = None
+    if args.ba_windows > 0:
+        from snake_slam_amd.ba import BARec, lba_options
+
+        NW, LM_IT = args.ba_windows, 3
+        distinct = [synth.ba_scene(seed=synth.SEED + 1000 * rank + k)[0] for k in range(4)]
+        ba = BARec(lba_options(), device=local, stream=sh)
+        ba.create([distinct[k % 4] for k in range(NW)])
+        with torch.cuda.stream(stream):
+            for _ in range(max(1, args.warmup)):
+                ba.reset()
+                ba.solve_async(LM_IT)
+            torch.cuda.synchronize()
+            barrier()
+            tb0 = time.perf_counter()
+            for _ in range(args.steps):
+                ba.reset()
+                ba.solve_async(LM_IT)
+            torch.cuda.synchronize()
+            barrier()
+            tb1 = time.perf_counter()
+        ci, cf = ba.solve(0)
+        # single-window latency (one problem per launch sequence)
+        ba1 = BARec(lba_options(), device=local, stream=sh)
+        ba1.create(distinct[0])
+        with torch.cuda.stream(stream):
+            ba1.solve_async(LM_IT)
+            torch.cuda.synchronize()
+            tl0 = time.perf_counter()
+            for _ in range(10):
+                ba1.reset()
+                ba1.solve_async(LM_IT)
+            torch.cuda.synchronize()
+            tl1 = time.perf_counter()
+        tba = torch.tensor([tb1 - tb0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tba, op=dist.ReduceOp.MAX)
+        ba_out = {"metric": "local-BA LM iterations/s (20 KF x 2000 pts x 8 obs/pt, 3 LM its, PCG<=30)",
+                  "value": round(world * NW * LM_IT * args.steps / float(tba.item()), 1), "unit": "LM iterations/s",
+                  "windows_per_gpu_per_step": NW, "ms_per_step": round(float(tba.item()) / args.steps * 1e3, 4),
+                  "single_window_ms_per_solve": round((tl1 - tl0) / 10 * 1e3, 4),
+                  "cost_initial": round(float(ci[0]), 3), "cost_final": round(float(cf[0]), 3), "dtype": "f64"}
+        ba.close()
+        ba1.close()
+
     # ---- result gather: one fixed-size block per rank (RCCL all_gather over xGMI) ----
     block = torch.tensor([float(B * args.steps), float(nkp.sum().item()), float(n_stereo.sum().item()),
                           float(n_pairs.sum().item()), t1 - t0, 0.0, 0.0, 0.0], dtype=torch.float64, device=dev)
@@ -223,8 +287,12 @@ def main():
                                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(fast_ms, 4)}
             out["stage_ms_per_step"] = {k: round(v / n_calls, 4) for k, v in zip(["pyramid", "fast", "distribute", "describe"], stage_ms)}
+        if ba_out is not None:
+            out["ba"] = ba_out
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames)
+            if ba_out is not None:
+                out["cpu_baseline"]["ba"] = cpu_baseline_ba()
         print(json.dumps(out), flush=True)
 
     if world > 1:

@@ -153,7 +153,7 @@ void orc_ba_chi2(const orc_ba_problem* P, double* chi2)
     {
         chi2[o] = 0.0;
         const int i = P->obs_img[o], p = P->obs_pt[o];
-        if (i < 0 || p < 0) continue;
+        if (i < 0 || p < 0 || i >= P->n_img || p >= P->n_pt) continue;
         if (P->obs_outlier && P->obs_outlier[o]) continue;
         if (P->img_const[i] && P->pt_const[p]) continue;
         double r[3], Jc[18], Jp[9];
@@ -171,7 +171,7 @@ static double total_cost(const orc_ba_problem* P, const orc_ba_options* O, doubl
     for (int o = 0; o < P->n_obs; ++o)
     {
         const int i = P->obs_img[o], p = P->obs_pt[o];
-        if (i < 0 || p < 0) continue;
+        if (i < 0 || p < 0 || i >= P->n_img || p >= P->n_pt) continue;
         if (P->obs_outlier && P->obs_outlier[o]) continue;
         if (P->img_const[i] && P->pt_const[p]) continue;
         double r[3], Jc[18], Jp[9], sw;
@@ -285,7 +285,7 @@ int orc_ba_solve(orc_ba_problem* P, const orc_ba_options* O, int iterations, dou
         for (int o = 0; o < no; ++o)
         {
             const int i = P->obs_img[o], p = P->obs_pt[o];
-            if (i < 0 || p < 0) continue;
+            if (i < 0 || p < 0 || i >= P->n_img || p >= P->n_pt) continue;
             if (P->obs_outlier && P->obs_outlier[o]) continue;
             if (P->img_const[i] && P->pt_const[p]) continue;
             double r[3], Jc[18], Jp[9], sw;
