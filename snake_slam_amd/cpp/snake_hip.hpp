@@ -1,0 +1,222 @@
+// snake_hip.hpp — header-only C++17 adaptor over the C ABI (include/snake_hip.h) with the call
+// shapes of the saiga classes Snake-SLAM uses on this path, so the Snake side changes types, not
+// call sites.  Error style: the reference aborts through SAIGA_ASSERT /
+// SAIGA_EXIT_ERROR (e.g. Snake/Preprocess/FeatureDetector.cpp:35); here every non-zero status
+// becomes a std::runtime_error carrying snk_last_error().
+#pragma once
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "snake_hip.h"
+
+namespace snake_hip
+{
+using DescriptorORB = std::array<uint64_t, 4>;  // Saiga::DescriptorORB (256 bit, trivially copyable)
+using KeyPointF     = snk_keypoint;             // Saiga::KeyPoint<float>: point, size, angle, response, octave
+
+inline void check(int rc, const char* what)
+{
+    if (rc != SNK_OK) throw std::runtime_error(std::string(what) + ": " + snk_last_error());
+}
+
+// Saiga::ORBExtractor / ORBExtractorGPU — Snake/Preprocess/FeatureDetector.cpp:31-41,119,124
+class ORBExtractor
+{
+   public:
+    ORBExtractor(int nfeatures, float scale_factor, int levels, int iniThFAST, int minThFAST, int /*threads*/ = 0,
+                 int device = 0)
+    {
+        snk_orb_params p{nfeatures, scale_factor, levels, iniThFAST, minThFAST, 0};
+        check(snk_orb_create(&p, device, nullptr, &h_), "snk_orb_create");
+    }
+    ~ORBExtractor() { snk_orb_destroy(h_); }
+    ORBExtractor(const ORBExtractor&)            = delete;
+    ORBExtractor& operator=(const ORBExtractor&) = delete;
+
+    // Detect(ImageView<uchar>, vector<KeyPoint<float>>&, vector<DescriptorORB>&)
+    void Detect(const uint8_t* data, int width, int height, int pitch_bytes, std::vector<KeyPointF>& keypoints,
+                std::vector<DescriptorORB>& descriptors)
+    {
+        check(snk_orb_configure(h_, width, height, 1), "snk_orb_configure");
+        int cap = 0;
+        check(snk_orb_max_keypoints(h_, &cap), "snk_orb_max_keypoints");
+        keypoints.resize((size_t)cap);
+        descriptors.resize((size_t)cap);
+        int n = 0;
+        check(snk_orb_detect(h_, data, width, height, pitch_bytes, keypoints.data(),
+                             reinterpret_cast<uint64_t(*)[4]>(descriptors.data()), cap, &n),
+              "snk_orb_detect");
+        keypoints.resize((size_t)n);
+        descriptors.resize((size_t)n);
+    }
+
+   private:
+    snk_orb* h_ = nullptr;
+};
+
+// Saiga::BruteForceMatcher<DescriptorORB> — Snake/Tracking/TrackingCoarse.cpp:350-352,373-387
+class BruteForceMatcher
+{
+   public:
+    explicit BruteForceMatcher(int device = 0) { check(snk_matcher_create(device, nullptr, &h_), "snk_matcher_create"); }
+    ~BruteForceMatcher() { snk_matcher_destroy(h_); }
+    BruteForceMatcher(const BruteForceMatcher&)            = delete;
+    BruteForceMatcher& operator=(const BruteForceMatcher&) = delete;
+
+    void matchKnn2(const std::vector<DescriptorORB>& d1, const std::vector<DescriptorORB>& d2)
+    {
+        knn_.resize(d1.size());
+        check(snk_bf_knn2(h_, reinterpret_cast<const uint64_t(*)[4]>(d1.data()), (int)d1.size(),
+                          reinterpret_cast<const uint64_t(*)[4]>(d2.data()), (int)d2.size(), knn_.data()),
+              "snk_bf_knn2");
+    }
+    void matchKnn2_omp(const std::vector<DescriptorORB>& d1, const std::vector<DescriptorORB>& d2, int /*threads*/)
+    {
+        matchKnn2(d1, d2);
+    }
+    int filterMatches(int threshold, float ratio)
+    {
+        std::vector<std::array<int32_t, 2>> pairs(knn_.size() + 1);
+        int n = 0;
+        check(snk_bf_filter(h_, knn_.data(), (int)knn_.size(), threshold, ratio, reinterpret_cast<int32_t(*)[2]>(pairs.data()),
+                            &n),
+              "snk_bf_filter");
+        matches.resize((size_t)n);
+        for (int i = 0; i < n; ++i) matches[(size_t)i] = {pairs[(size_t)i][0], pairs[(size_t)i][1]};
+        return n;
+    }
+    std::vector<std::pair<int, int>> matches;  // (index into d1, index into d2)
+    const std::vector<snk_knn2>& knn() const { return knn_; }
+
+   private:
+    snk_matcher* h_ = nullptr;
+    std::vector<snk_knn2> knn_;
+};
+
+// Snake::Preprocess::undistortKeypoints + StereoMatching — Snake/Preprocess/Preprocess.cpp:55-77,122-242
+class Preprocess
+{
+   public:
+    explicit Preprocess(int device = 0) { check(snk_matcher_create(device, nullptr, &h_), "snk_matcher_create"); }
+    ~Preprocess() { snk_matcher_destroy(h_); }
+    Preprocess(const Preprocess&)            = delete;
+    Preprocess& operator=(const Preprocess&) = delete;
+
+    // rect.Forward for every keypoint (angle / octave copied); normalized may be null
+    void Rectify(const snk_rectification& rect, const std::vector<KeyPointF>& kps, std::vector<snk_kp64>& out,
+                 std::vector<std::array<double, 2>>* normalized = nullptr)
+    {
+        out.resize(kps.size());
+        if (normalized) normalized->resize(kps.size());
+        check(snk_rectify(h_, &rect, kps.data(), (int)kps.size(), out.data(),
+                          normalized ? reinterpret_cast<double(*)[2]>(normalized->data()) : nullptr),
+              "snk_rectify");
+    }
+
+    // returns the number of stereo matches; right_points / depth keep their -1000 fill where unmatched
+    int StereoMatching(const std::vector<snk_kp64>& left_rectified, const std::vector<DescriptorORB>& desc_left,
+                       const std::vector<snk_kp64>& right_rectified, const std::vector<DescriptorORB>& desc_right, double bf,
+                       const std::vector<float>& level_scale, bool relaxed, std::vector<float>& right_points,
+                       std::vector<float>& depth)
+    {
+        right_points.resize(left_rectified.size(), -1000.0f);
+        depth.resize(left_rectified.size(), -1000.0f);
+        int n = 0;
+        check(snk_stereo_match(h_, left_rectified.data(), reinterpret_cast<const uint64_t(*)[4]>(desc_left.data()),
+                               (int)left_rectified.size(), right_rectified.data(),
+                               reinterpret_cast<const uint64_t(*)[4]>(desc_right.data()), (int)right_rectified.size(), bf,
+                               level_scale.data(), (int)level_scale.size(), relaxed ? 1 : 0, right_points.data(),
+                               depth.data(), &n),
+              "snk_stereo_match");
+        return n;
+    }
+
+   private:
+    snk_matcher* h_ = nullptr;
+};
+
+// The part of Saiga::Scene that MakeLocalScene fills (LocalBundleAdjustment.cpp:187-293), flattened.
+struct Scene
+{
+    std::vector<std::array<double, 7>> poses;  // images[i].se3: qx qy qz qw tx ty tz
+    std::vector<uint8_t> image_constant;
+    std::vector<std::array<double, 3>> points;  // worldPoints[j].p
+    std::vector<uint8_t> point_constant;
+    std::vector<int32_t> obs_image, obs_point;      // StereoImagePoint owner image, .wp
+    std::vector<std::array<double, 2>> obs_pixel;   // .point
+    std::vector<double> obs_depth, obs_weight;      // .depth (> 0 => stereo), .weight
+    std::vector<uint8_t> obs_outlier;               // .outlier
+    double K[4] = {1, 1, 0, 0};                     // intrinsics[0]
+    double bf   = 0;
+};
+
+struct OptimizationResults
+{
+    double cost_initial = 0, cost_final = 0;
+};
+
+// Saiga::BARecRel as Snake drives it — Snake/Optimizer/LocalBundleAdjustment.cpp:357-365,403-407
+class BARec
+{
+   public:
+    snk_ba_options optimizationOptions{3, 30, 1e-10, 2.1, 2.3, 0.0};  // LocalBundleAdjustment.cpp:47-64
+
+    explicit BARec(int device = 0) : device_(device) {}
+    ~BARec() { snk_ba_destroy(h_); }
+    BARec(const BARec&)            = delete;
+    BARec& operator=(const BARec&) = delete;
+
+    void create(Scene& scene)
+    {
+        scene_ = &scene;
+        if (h_) snk_ba_destroy(h_);
+        h_ = nullptr;
+        check(snk_ba_create(&optimizationOptions, device_, nullptr, &h_), "snk_ba_create");
+        snk_ba_problem p{};
+        p.n_img      = (int)scene.poses.size();
+        p.n_pt       = (int)scene.points.size();
+        p.n_obs      = (int)scene.obs_image.size();
+        p.pose       = reinterpret_cast<double(*)[7]>(scene.poses.data());
+        p.img_const  = scene.image_constant.data();
+        p.pt         = reinterpret_cast<double(*)[3]>(scene.points.data());
+        p.pt_const   = scene.point_constant.data();
+        p.obs_img    = scene.obs_image.data();
+        p.obs_pt     = scene.obs_point.data();
+        p.obs_uv     = reinterpret_cast<const double(*)[2]>(scene.obs_pixel.data());
+        p.obs_depth  = scene.obs_depth.data();
+        p.obs_weight = scene.obs_weight.data();
+        for (int k = 0; k < 4; ++k) p.K[k] = scene.K[k];
+        p.bf = scene.bf;
+        check(snk_ba_set_problem(h_, &p), "snk_ba_set_problem");
+    }
+    OptimizationResults initAndSolve() { return solve(); }
+    OptimizationResults solve()
+    {
+        if (!scene_->obs_outlier.empty()) check(snk_ba_set_outliers(h_, 0, scene_->obs_outlier.data()), "snk_ba_set_outliers");
+        OptimizationResults r;
+        check(snk_ba_solve(h_, optimizationOptions.max_iterations, &r.cost_initial, &r.cost_final), "snk_ba_solve");
+        // the reference mutates the scene in place
+        check(snk_ba_get_state(h_, 0, reinterpret_cast<double(*)[7]>(scene_->poses.data()),
+                               reinterpret_cast<double(*)[3]>(scene_->points.data()), nullptr),
+              "snk_ba_get_state");
+        return r;
+    }
+    // squared norms of Scene::residual3 / residual2 for every observation
+    std::vector<double> residualsSquared()
+    {
+        std::vector<double> chi2(scene_->obs_image.size() + 1);
+        check(snk_ba_residuals(h_, 0, chi2.data()), "snk_ba_residuals");
+        chi2.resize(scene_->obs_image.size());
+        return chi2;
+    }
+
+   private:
+    int device_;
+    snk_ba* h_    = nullptr;
+    Scene* scene_ = nullptr;
+};
+}  // namespace snake_hip
