@@ -105,20 +105,15 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from snake_slam_amd import parallel
+
+    _, _, local = parallel.env_rank_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    rank, world = parallel.init_distributed(dev)  # "nccl" = RCCL over xGMI; used for barrier + result gather only
 
     from snake_slam_amd import synth
     from snake_slam_amd.matcher import BruteForceMatcher, Preprocess, Rectification
@@ -164,9 +159,7 @@ def main():
         bf.knn2_batch_dev(desc[:B], nkp[:B], desc[B:], nkp[B:], knn)
         bf.filter_batch_dev(knn, nkp[:B], 60, 0.8, pairs, n_pairs)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    barrier = parallel.barrier
 
     with torch.cuda.stream(stream):
         for _ in range(args.warmup):
@@ -186,10 +179,7 @@ def main():
     stage_ms, n_calls = ext.stage_times() if not args.no_stage_events else ([0, 0, 0, 0], 0)
     ext.set_profiling(False)
 
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
+    elapsed = parallel.max_over_ranks(t1 - t0, dev)
 
     # ---- second half of the metric: local-BA LM iterations/s (20 KF x 2000 pts x 8 obs/pt) ----
     ba_out = None
@@ -226,9 +216,7 @@ def main():
                 ba1.solve_async(LM_IT)
             torch.cuda.synchronize()
             tl1 = time.perf_counter()
-        tba = torch.tensor([tb1 - tb0], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(tba, op=dist.ReduceOp.MAX)
+        tba = torch.tensor([parallel.max_over_ranks(tb1 - tb0, dev)], dtype=torch.float64)
         ba_out = {"metric": "local-BA LM iterations/s (20 KF x 2000 pts x 8 obs/pt, 3 LM its, PCG<=30)",
                   "value": round(world * NW * LM_IT * args.steps / float(tba.item()), 1), "unit": "LM iterations/s",
                   "windows_per_gpu_per_step": NW, "ms_per_step": round(float(tba.item()) / args.steps * 1e3, 4),
@@ -240,11 +228,7 @@ def main():
     # ---- result gather: one fixed-size block per rank (RCCL all_gather over xGMI) ----
     block = torch.tensor([float(B * args.steps), float(nkp.sum().item()), float(n_stereo.sum().item()),
                           float(n_pairs.sum().item()), t1 - t0, 0.0, 0.0, 0.0], dtype=torch.float64, device=dev)
-    if world > 1:
-        blocks = [torch.zeros_like(block) for _ in range(world)]
-        dist.all_gather(blocks, block)
-    else:
-        blocks = [block]
+    blocks = parallel.gather_result_blocks(block)
 
     if rank == 0:
         total_frames = sum(float(b[0].item()) for b in blocks)
@@ -295,9 +279,7 @@ def main():
                 out["cpu_baseline"]["ba"] = cpu_baseline_ba()
         print(json.dumps(out), flush=True)
 
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    parallel.shutdown()
 
 
 if __name__ == "__main__":

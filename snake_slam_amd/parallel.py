@@ -1,0 +1,73 @@
+"""Multi-GPU plumbing of the hot path: one process per GPU, no data-path collective.
+
+The path shards over independent units (frames of a batch, sequences, disjoint BA windows —
+SURVEY.md §8e); the only communication is a result gather after the work is done.  Backend
+"nccl" is RCCL on ROCm (xGMI); "gloo" is used by the CPU tests.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+RESULT_BLOCK = 8  # doubles per rank: units, keypoints, stereo matches, bf pairs, seconds, 3 spare
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_distributed(device: torch.device | None = None, backend: str | None = None) -> tuple[int, int]:
+    """Initialise torch.distributed from the torchrun environment (no-op for world size 1)."""
+    rank, world, _ = env_rank_world()
+    if world <= 1:
+        return 0, 1
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend is None:
+        backend = "nccl" if (device is not None and device.type == "cuda") else "gloo"
+    kw = {"device_id": device} if backend == "nccl" and device is not None else {}
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world
+
+
+def is_distributed() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def barrier() -> None:
+    if is_distributed():
+        dist.barrier()
+
+
+def shard_range(n_items: int, rank: int, world: int) -> range:
+    """Contiguous, balanced split of n_items independent units (strong scaling: the frames of a
+    sequence list / the windows of a BA batch).  The first n_items % world ranks get one more."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return range(lo, lo + base + (1 if rank < rem else 0))
+
+
+def max_over_ranks(value: float, device: torch.device) -> float:
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    if is_distributed():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_result_blocks(block: torch.Tensor) -> list[torch.Tensor]:
+    """One fixed-size block per rank -> list of all ranks' blocks on every rank (all_gather)."""
+    assert block.numel() == RESULT_BLOCK and block.dtype == torch.float64
+    if not is_distributed():
+        return [block]
+    out = [torch.zeros_like(block) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, block)
+    return out
+
+
+def shutdown() -> None:
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()

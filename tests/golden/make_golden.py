@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures in this directory from the CPU oracle (oracle/).
+
+The reference (darglein/Snake-SLAM) ships no golden vectors for this path and its arithmetic lives
+in the absent saiga submodule, so these fixtures pin THIS repository's
+definition ("snk-orb v1", "snk-ba v1", matcher rules): they freeze the oracle so that neither
+it nor the kernels can drift silently.  Inputs are seeded; run from the repo root:
+
+    python tests/golden/make_golden.py
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+from helpers import SEED, make_stereo_case, rand_desc  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+from snake_slam_amd import synth  # noqa: E402
+
+OUT = Path(__file__).resolve().parent
+
+
+def main():
+    orc.build()
+    rng = np.random.default_rng(SEED)
+    # --- matchers ---
+    q, t = rand_desc(rng, 40), rand_desc(rng, 50)
+    t[7] = t[3]
+    q[0] = t[3]
+    knn = orc.bf_knn2(q, t)
+    pairs = orc.bf_filter(knn, 120, 0.9)
+    left, dl, right, dr, bf, ls = make_stereo_case(rng, 120, 110)
+    n, rp, dp = orc.stereo_match(left, dl, right, dr, bf, ls, True)
+    np.savez_compressed(OUT / "match_small.npz", q=q, t=t, knn=np.stack([knn[f] for f in ("idx1", "dist1", "idx2", "dist2")], 1),
+                        pairs=pairs, filter_args=np.array([120, 0.9]), left=left, dl=dl, right=right, dr=dr, bf=bf, ls=ls,
+                        n=n, rp=rp, dp=dp)
+    # --- ORB ---
+    img, _ = synth.stereo_frame(3, 160, 120, n_rects=40)
+    p = orc.orb_params(200, 1.2, 3, 20, 7)
+    kps, desc = orc.orb_detect(p, img)
+    np.savez_compressed(OUT / "orb_small.npz", img=img, params=np.array([200, 1.2, 3, 20, 7]), kps=kps, desc=desc)
+    # --- rectify ---
+    K = (458.654, 457.296, 367.215, 248.375)
+    D = (-0.28340811, 0.07395907, 0.0, 0.0, 0.0, 0.0, 0.00019359, 1.76187114e-05)
+    a = 0.01
+    R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    Kd = (435.2, 435.2, 367.4, 252.2)
+    k = np.zeros(64, orc.KEYPOINT)
+    k["x"] = rng.uniform(0, 752, 64).astype(np.float32)
+    k["y"] = rng.uniform(0, 480, 64).astype(np.float32)
+    k["angle"] = rng.uniform(0, 360, 64).astype(np.float32)
+    k["octave"] = rng.integers(0, 4, 64)
+    out, norm = orc.rectify(orc.rectification(K, D, R, Kd), k)
+    np.savez_compressed(OUT / "rectify_small.npz", K=K, D=D, R=R, Kd=Kd, kps=k, out=out, norm=norm)
+    # --- BA ---
+    sc, _ = synth.ba_scene(n_kf=6, n_pt=60, obs_per_pt=4, seed=77)
+    pose, pt, c0, c1, it = orc.ba_solve(sc, orc.ba_options())
+    chi = orc.ba_chi2(sc)
+    np.savez_compressed(OUT / "ba_small.npz", **{f"in_{k}": np.asarray(v) for k, v in sc.items()}, pose=pose, pt=pt,
+                        cost=np.array([c0, c1]), chi2=chi)
+    for f in sorted(OUT.glob("*.npz")):
+        print(f.name, f.stat().st_size, "bytes")
+
+
+if __name__ == "__main__":
+    main()
