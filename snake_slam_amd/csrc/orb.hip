@@ -8,12 +8,15 @@
 //
 // Pipeline (all kernels batched over B images, blockIdx.y/z = image):
 //   resize_kernel      level l-1 -> level l, 11-bit fixed-point bilinear       (L-1 launches)
-//   fast_kernel        one workgroup per ~30x30 FAST cell: image tile -> LDS, FAST-9/16 score,
-//                      in-cell 3x3 NMS, ini/min threshold fallback, candidates ranked by strength
+//   blur_kernel        7x7 Gaussian of every level (64x16 tiles, v_alignbyte + v_dot4_u32_u8)
+//   fast_kernel        one workgroup per ~30x30 FAST cell: image tile -> LDS (aligned dwords), quick
+//                      opposite-pair bound on every pixel, compaction, exact FAST-9/16 score of the
+//                      survivors in packed 16-bit lanes, in-cell 3x3 NMS, ini/min threshold fallback,
+//                      candidates ranked by strength
 //   distribute_kernel  one workgroup per (image, level): quadtree distribution on sorted
 //                      subdivision keys (bitonic sort in LDS + histogram of common-prefix lengths)
-//   describe_kernel    one wavefront per keypoint: 43x43 patch -> LDS, integer IC moments,
-//                      polynomial atan2, separable 7x7 blur in LDS, 256 steered BRIEF tests,
+//   describe_kernel    one wavefront per keypoint: integer IC moments from the raw level,
+//                      polynomial atan2, 256 steered BRIEF tests gathered from the blurred level,
 //                      4 ballots assemble the 256-bit descriptor
 #include "common.hpp"
 
@@ -48,6 +51,8 @@ struct LevelInfo
     int w, h, pitch;
     long long img_stride;  // bytes between consecutive images of this level
     u8* base;              // level buffer (levels >= 1); level 0 comes from the caller
+    u8* blur;              // blurred level (all levels), same pitch / stride as the level buffers
+    int tile_off, tiles_x; // blur tiles of this level in the per-image tile numbering
     int ncols, nrows, wcell, hcell;
     int cell_off;          // first cell of this level in the per-image cell arrays
     int nfeat;             // features wanted on this level
@@ -65,6 +70,7 @@ struct Layout
     int n_levels;
     int total_cells;
     int total_slots;
+    int total_tiles;
     int level_cap;
     LevelInfo lv[MAX_LEVELS];
 };
@@ -107,47 +113,98 @@ __global__ __launch_bounds__(256) void resize_kernel(const u8* __restrict__ src,
 }
 
 // ------------------------------------------------------------------------------------------------
-// FAST-9/16 score: S = max over the 16 arcs of 9 of min(ring - c), and of min(c - ring).
-// corner(t) <=> S > t.  Sliding-window minima by doubling (2,4,8,+1).
+// tile loader: tile[r][d] (dwords, row pitch PITCH_DW) = image bytes (ys + r, xs + 4d .. xs + 4d + 3),
+// xs a multiple of 4; coordinates outside the image are reflect-101'd.  A dword that lies inside the
+// image row is fetched with one aligned 32-bit load when the image base / pitch are 4-aligned.
+// Thread -> (row, dword) by shift/mask (no integer division).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int fast_score16(const int (&d)[16])
+__device__ __forceinline__ int reflect101(int i, int n)
 {
-    int a2[16], a4[16], b2[16], b4[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-    {
-        a2[i] = min(d[i], d[(i + 1) & 15]);
-        b2[i] = max(d[i], d[(i + 1) & 15]);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-    {
-        a4[i] = min(a2[i], a2[(i + 2) & 15]);
-        b4[i] = max(b2[i], b2[(i + 2) & 15]);
-    }
-    int bright = -1000, dark = 1000;
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-    {
-        const int a9 = min(min(a4[i], a4[(i + 4) & 15]), d[(i + 8) & 15]);
-        const int b9 = max(max(b4[i], b4[(i + 4) & 15]), d[(i + 8) & 15]);
-        bright       = max(bright, a9);
-        dark         = min(dark, b9);
-    }
-    return max(bright, -dark);
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
 }
 
-constexpr int TILE_PITCH = 72;  // >= MAX_CELL + 6, multiple of 4
-constexpr int S_PITCH    = 64;  // >= MAX_CELL + 2
+template <int PITCH_DW>
+__device__ __forceinline__ void load_tile(u32* tile, const u8* __restrict__ src, int pitch, int w, int h, int xs, int ys,
+                                          int ndw, int nrows, bool aligned, int tid, int nthreads)
+{
+    const int lc = ndw <= 16 ? 4 : 5;
+    for (int i = tid; i < (nrows << lc); i += nthreads)
+    {
+        const int r = i >> lc, d = i & ((1 << lc) - 1);
+        if (d >= ndw) continue;
+        const int y  = reflect101(ys + r, h);
+        const int x  = xs + 4 * d;
+        const u8* rp = src + (long long)y * pitch;
+        u32 v;
+        if (aligned && x >= 0 && x + 3 < w)
+            v = *reinterpret_cast<const u32*>(rp + x);
+        else
+            v = (u32)rp[reflect101(x, w)] | ((u32)rp[reflect101(x + 1, w)] << 8) | ((u32)rp[reflect101(x + 2, w)] << 16) |
+                ((u32)rp[reflect101(x + 3, w)] << 24);
+        tile[r * PITCH_DW + d] = v;
+    }
+}
 
+// ------------------------------------------------------------------------------------------------
+// FAST-9/16 score: S = max over the 16 arcs of 9 of min(ring - c), and of min(c - ring).
+// corner(t) <=> S > t.  Sliding-window minima by doubling (2,4,8,+1), two pixels per lane in packed
+// 16-bit lanes (v_pk_min_i16 / v_pk_max_i16).
+// ------------------------------------------------------------------------------------------------
+typedef short short2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ short2_t pk_min(short2_t a, short2_t b)
+{
+    return __builtin_elementwise_min(a, b);
+}
+__device__ __forceinline__ short2_t pk_max(short2_t a, short2_t b)
+{
+    return __builtin_elementwise_max(a, b);
+}
+
+__device__ __forceinline__ short2_t fast_score16_pk(const short2_t (&d)[16])
+{
+    short2_t a2[16], a4[16], b2[16], b4[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+    {
+        a2[i] = pk_min(d[i], d[(i + 1) & 15]);
+        b2[i] = pk_max(d[i], d[(i + 1) & 15]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+    {
+        a4[i] = pk_min(a2[i], a2[(i + 2) & 15]);
+        b4[i] = pk_max(b2[i], b2[(i + 2) & 15]);
+    }
+    short2_t bright = {-1000, -1000}, dark = {1000, 1000};
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+    {
+        const short2_t a9 = pk_min(pk_min(a4[i], a4[(i + 4) & 15]), d[(i + 8) & 15]);
+        const short2_t b9 = pk_max(pk_max(b4[i], b4[(i + 4) & 15]), d[(i + 8) & 15]);
+        bright            = pk_max(bright, a9);
+        dark              = pk_min(dark, b9);
+    }
+    return pk_max(bright, -dark);
+}
+
+constexpr int FT_PITCH_DW = 20;  // 80-byte tile rows: (MAX_CELL + 6) pixels + 3 bytes alignment slack
+constexpr int FT_PITCH    = FT_PITCH_DW * 4;
+constexpr int S_PITCH     = 64;  // >= MAX_CELL + 2
+
+// One workgroup per FAST cell.  Phase A runs the cheap opposite-pair bound on every pixel and
+// compacts the ~10 % that can still be corners; phase B evaluates the exact score only for those,
+// densely, two per lane; NMS and the threshold fallback then walk the compacted list.
 __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restrict__ img0, int pitch0, long long stride0,
-                                                   int ini_th, int min_th, u32* __restrict__ cand,
+                                                   int aligned0, int ini_th, int min_th, u32* __restrict__ cand,
                                                    u16* __restrict__ cell_cnt)
 {
-    __shared__ u8 tile[(MAX_CELL + 6) * TILE_PITCH];
+    __shared__ u32 tile_dw[(MAX_CELL + 6) * FT_PITCH_DW];
     __shared__ u8 S[(MAX_CELL + 2) * S_PITCH];
+    __shared__ u16 surv[MAX_CELL * MAX_CELL];                          // pixels passing the quick test
     __shared__ u32 list[((MAX_CELL + 1) / 2) * ((MAX_CELL + 1) / 2)];  // NMS survivors (<= 30*30)
-    __shared__ int n_list, n_ini;
+    __shared__ int n_surv, n_list, n_ini;
 
     const int b   = blockIdx.y;
     const int cid = blockIdx.x;
@@ -168,65 +225,64 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
         if (tid == 0) cell_cnt[cell_index] = 0;
         return;
     }
-    const u8* src   = l == 0 ? img0 + (long long)b * stride0 : lv.base + (long long)b * lv.img_stride;
-    const int pitch = l == 0 ? pitch0 : lv.pitch;
+    const u8* src      = l == 0 ? img0 + (long long)b * stride0 : lv.base + (long long)b * lv.img_stride;
+    const int pitch    = l == 0 ? pitch0 : lv.pitch;
+    const bool aligned = l == 0 ? aligned0 != 0 : true;
 
     if (tid == 0)
     {
+        n_surv = 0;
         n_list = 0;
         n_ini  = 0;
     }
     // image tile with the 3-pixel ring halo (always inside the image: cells start at x,y >= 19)
-    const int tw = cw + 6, th = ch + 6;
-    for (int i = tid; i < tw * th; i += 256)
-    {
-        const int ty = i / tw, tx = i - ty * tw;
-        tile[ty * TILE_PITCH + tx] = src[(long long)(y0 - 3 + ty) * pitch + (x0 - 3 + tx)];
-    }
-    // score map with a zero ring (pixels outside the cell never suppress: OpenCV FAST on the sub-image)
-    for (int i = tid; i < (ch + 2) * S_PITCH; i += 256) S[i] = 0;
+    const int xs  = (x0 - 3) & ~3;
+    const int sh  = (x0 - 3) - xs;  // tile byte column of cell pixel px is px + 3 + sh
+    const int ndw = (sh + cw + 6 + 3) >> 2;
+    load_tile<FT_PITCH_DW>(tile_dw, src, pitch, lv.w, lv.h, xs, y0 - 3, ndw, ch + 6, aligned, tid, 256);
+    for (int i = tid; i < (ch + 2) * (S_PITCH / 4); i += 256) reinterpret_cast<u32*>(S)[i] = 0;
     __syncthreads();
+    const u8* tile = reinterpret_cast<const u8*>(tile_dw);
 
-    for (int i = tid; i < cw * ch; i += 256)
-    {
-        const int py = i / cw, px = i - py * cw;
-        const u8* t  = &tile[(py + 3) * TILE_PITCH + px + 3];
-        const int v  = t[0];
-        // quick reject: every 9-arc holds one pixel of each opposite pair
-        const int d0 = t[3 * TILE_PITCH] - v, d8 = t[-3 * TILE_PITCH] - v, d4 = t[3] - v, d12 = t[-3] - v;
-        const int ub_b = min(max(d0, d8), max(d4, d12));
-        const int ub_d = min(max(-d0, -d8), max(-d4, -d12));
-        int s = 0;
-        if (ub_b > min_th || ub_d > min_th)
+    // phase A: every 9-arc holds one pixel of each opposite pair -> S <= min_i max(d_i, d_{i+8})
+    for (int py = tid >> 5; py < ch; py += 8)
+        for (int px = tid & 31; px < cw; px += 32)
         {
-            int d[16];
-            d[0]  = d0;
-            d[1]  = t[3 * TILE_PITCH + 1] - v;
-            d[2]  = t[2 * TILE_PITCH + 2] - v;
-            d[3]  = t[1 * TILE_PITCH + 3] - v;
-            d[4]  = d4;
-            d[5]  = t[-1 * TILE_PITCH + 3] - v;
-            d[6]  = t[-2 * TILE_PITCH + 2] - v;
-            d[7]  = t[-3 * TILE_PITCH + 1] - v;
-            d[8]  = d8;
-            d[9]  = t[-3 * TILE_PITCH - 1] - v;
-            d[10] = t[-2 * TILE_PITCH - 2] - v;
-            d[11] = t[-1 * TILE_PITCH - 3] - v;
-            d[12] = d12;
-            d[13] = t[1 * TILE_PITCH - 3] - v;
-            d[14] = t[2 * TILE_PITCH - 2] - v;
-            d[15] = t[3 * TILE_PITCH - 1] - v;
-            s     = fast_score16(d);
-            s     = s < 0 ? 0 : s;
+            const u8* t  = tile + (py + 3) * FT_PITCH + px + 3 + sh;
+            const int v  = t[0];
+            const int d0 = t[3 * FT_PITCH] - v, d8 = t[-3 * FT_PITCH] - v, d4 = t[3] - v, d12 = t[-3] - v;
+            const int ub_b = min(max(d0, d8), max(d4, d12));
+            const int ub_d = min(max(-d0, -d8), max(-d4, -d12));
+            if (ub_b > min_th || ub_d > min_th) surv[atomicAdd(&n_surv, 1)] = (u16)((py << 6) | px);
         }
-        S[(py + 1) * S_PITCH + px + 1] = (u8)s;  // s <= 255
+    __syncthreads();
+
+    // phase B: exact score of the survivors, two per lane
+    const int ns = n_surv;
+    for (int j = tid * 2; j < ns; j += 512)
+    {
+        const int e0 = surv[j], e1 = surv[j + 1 < ns ? j + 1 : j];
+        const int px0 = e0 & 63, py0 = e0 >> 6, px1 = e1 & 63, py1 = e1 >> 6;
+        const u8* t0 = tile + (py0 + 3) * FT_PITCH + px0 + 3 + sh;
+        const u8* t1 = tile + (py1 + 3) * FT_PITCH + px1 + 3 + sh;
+        const short v0 = t0[0], v1 = t1[0];
+        short2_t d[16];
+#define RING(i, dx, dy) d[i] = short2_t{(short)(t0[(dy)*FT_PITCH + (dx)] - v0), (short)(t1[(dy)*FT_PITCH + (dx)] - v1)};
+        RING(0, 0, 3) RING(1, 1, 3) RING(2, 2, 2) RING(3, 3, 1) RING(4, 3, 0) RING(5, 3, -1) RING(6, 2, -2) RING(7, 1, -3)
+        RING(8, 0, -3) RING(9, -1, -3) RING(10, -2, -2) RING(11, -3, -1) RING(12, -3, 0) RING(13, -3, 1) RING(14, -2, 2)
+        RING(15, -1, 3)
+#undef RING
+        const short2_t s = fast_score16_pk(d);
+        S[(py0 + 1) * S_PITCH + px0 + 1] = (u8)(s.x < 0 ? 0 : s.x);
+        if (j + 1 < ns) S[(py1 + 1) * S_PITCH + px1 + 1] = (u8)(s.y < 0 ? 0 : s.y);
     }
     __syncthreads();
 
-    // 3x3 non-max suppression (strict) among scores above min_th; count those above ini_th
-    for (int i = tid; i < cw * ch; i += 256)
+    // 3x3 non-max suppression (strict) among scores above min_th (all of them are survivors)
+    for (int j = tid; j < ns; j += 256)
     {
-        const int py = i / cw, px = i - py * cw;
+        const int e  = surv[j];
+        const int px = e & 63, py = e >> 6;
         const u8* s  = &S[(py + 1) * S_PITCH + px + 1];
         const int v  = s[0];
         if (v <= min_th) continue;
@@ -255,6 +311,78 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
         if (r < CELL_SLOTS) out[r] = k;
     }
     if (tid == 0) cell_cnt[cell_index] = (u16)(n > 65535 ? 65535 : n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 7x7 Gaussian {18,33,49,56,49,33,18}/256 over whole levels (what the descriptors sample).
+// One workgroup = 64x16 output tile: 22x80-byte input tile in LDS (aligned dword loads, reflect-101
+// at the image border), horizontal pass with v_alignbyte + v_dot4_u32_u8 (exact 16-bit rows),
+// vertical pass with one rounding, 4 pixels per lane and one dword store.
+// ------------------------------------------------------------------------------------------------
+constexpr int BT_W = 64, BT_H = 16;
+constexpr int BT_PITCH_DW = 20;
+
+__global__ __launch_bounds__(256) void blur_kernel(Layout L, const u8* __restrict__ img0, int pitch0, long long stride0,
+                                                   int aligned0)
+{
+    __shared__ u32 tile_dw[(BT_H + 6) * BT_PITCH_DW];
+    __shared__ u32 hb[(BT_H + 6) * 32];  // 64 u16 per row
+    const int b   = blockIdx.y;
+    const int tl  = blockIdx.x;
+    int l         = 0;
+    while (l + 1 < L.n_levels && tl >= L.lv[l + 1].tile_off) ++l;
+    const LevelInfo& lv = L.lv[l];
+    const int t   = tl - lv.tile_off;
+    const int ty  = t / lv.tiles_x, tx = t - ty * lv.tiles_x;
+    const int x0 = tx * BT_W, y0 = ty * BT_H;
+    const int tid = threadIdx.x;
+    const u8* src      = l == 0 ? img0 + (long long)b * stride0 : lv.base + (long long)b * lv.img_stride;
+    const int pitch    = l == 0 ? pitch0 : lv.pitch;
+    const bool aligned = l == 0 ? aligned0 != 0 : true;
+    load_tile<BT_PITCH_DW>(tile_dw, src, pitch, lv.w, lv.h, x0 - 4, y0 - 3, BT_PITCH_DW, BT_H + 6, aligned, tid, 256);
+    __syncthreads();
+    const u32 W0123 = 18u | (33u << 8) | (49u << 16) | (56u << 24);
+    const u32 W456  = 49u | (33u << 8) | (18u << 16);
+    for (int i = tid; i < (BT_H + 6) * 16; i += 256)
+    {
+        const int r = i >> 4, g = i & 15;
+        const u32 d0 = tile_dw[r * BT_PITCH_DW + g], d1 = tile_dw[r * BT_PITCH_DW + g + 1], d2 = tile_dw[r * BT_PITCH_DW + g + 2];
+        // output column 4g + j reads tile bytes 4g + 1 + j .. 4g + 7 + j
+        const u32 a = __builtin_amdgcn_alignbyte(d1, d0, 1), bq = __builtin_amdgcn_alignbyte(d2, d1, 1), cq = d2 >> 8;
+        u32 o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+            const u32 q  = j == 0 ? a : __builtin_amdgcn_alignbyte(bq, a, j);
+            const u32 rq = j == 0 ? bq : __builtin_amdgcn_alignbyte(cq, bq, j);
+            o[j]         = __builtin_amdgcn_udot4(q, W0123, __builtin_amdgcn_udot4(rq, W456, 0u, false), false);
+        }
+        hb[r * 32 + 2 * g]     = o[0] | (o[1] << 16);
+        hb[r * 32 + 2 * g + 1] = o[2] | (o[3] << 16);
+    }
+    __syncthreads();
+    {
+        const int r = tid >> 4, g = tid & 15;
+        const int y = y0 + r, x = x0 + 4 * g;
+        if (y < lv.h && x < lv.w)
+        {
+            const int wk[7] = {18, 33, 49, 56, 49, 33, 18};
+            u32 acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+            {
+                const u32 lo = hb[(r + k) * 32 + 2 * g], hi = hb[(r + k) * 32 + 2 * g + 1];
+                acc[0] += (u32)wk[k] * (lo & 0xFFFFu);
+                acc[1] += (u32)wk[k] * (lo >> 16);
+                acc[2] += (u32)wk[k] * (hi & 0xFFFFu);
+                acc[3] += (u32)wk[k] * (hi >> 16);
+            }
+            const u32 packed = ((acc[0] + 32768u) >> 16) | (((acc[1] + 32768u) >> 16) << 8) | (((acc[2] + 32768u) >> 16) << 16) |
+                               (((acc[3] + 32768u) >> 16) << 24);
+            u8* dst = lv.blur + (long long)b * lv.img_stride + (long long)y * lv.pitch + x;
+            *reinterpret_cast<u32*>(dst) = packed;  // pitch is a multiple of 64: columns up to the pitch exist
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -651,33 +779,14 @@ __device__ __forceinline__ void sincos_deg(float deg, float& s_out, float& c_out
     }
 }
 
-constexpr int RAW_R   = 21;  // 15 (pattern, rotated <= 18) + 3 (blur)
-constexpr int RAW_W   = 2 * RAW_R + 1;  // 43
-constexpr int RAW_P   = 44;
-constexpr int BL_R    = 18;
-constexpr int BL_W    = 2 * BL_R + 1;  // 37
-constexpr int BL_P    = 40;
-
-__device__ __forceinline__ int reflect101(int i, int n)
-{
-    i = i < 0 ? -i : i;
-    return i >= n ? 2 * n - 2 - i : i;
-}
-
-struct DescWaveLds
-{
-    u8 raw[RAW_W * RAW_P];
-    u16 hb[RAW_W * BL_P];  // horizontal pass: rows -21..21, cols -18..18
-    u8 bl[BL_W * BL_P];
-};
-
+// One wavefront per keypoint.  Moments come from the raw level (31x31 disc, lane = column),
+// the 256 steered tests gather from the blurred level; 4 ballots assemble the descriptor.
 __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __restrict__ img0, int pitch0,
                                                        long long stride0, const u32* __restrict__ sel,
                                                        const u8* __restrict__ sel_score, const int* __restrict__ sel_cnt,
                                                        snk_keypoint* __restrict__ kps, u64* __restrict__ desc,
                                                        int* __restrict__ n_out, int out_cap)
 {
-    __shared__ DescWaveLds lds[4];
     __shared__ signed char pat[1024];
     const int tid  = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -706,29 +815,24 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
     const int kx = (int)(xy & 0xFFFFu), ky = (int)(xy >> 16);
     const u8* src   = l == 0 ? img0 + (long long)b * stride0 : lv.base + (long long)b * lv.img_stride;
     const int pitch = l == 0 ? pitch0 : lv.pitch;
-    DescWaveLds& w  = lds[wave];
+    const u8* bsrc  = lv.blur + (long long)b * lv.img_stride;
 
-    // raw 43x43 patch, reflect-101 outside the level image (at most 2 px: keypoints sit >= 19 px inside)
-    for (int i = lane; i < RAW_W * RAW_W; i += 64)
-    {
-        const int ry = i / RAW_W, rx = i - ry * RAW_W;
-        const int sy = reflect101(ky - RAW_R + ry, lv.h), sx = reflect101(kx - RAW_R + rx, lv.w);
-        w.raw[ry * RAW_P + rx] = src[(long long)sy * pitch + sx];
-    }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-
-    // intensity-centroid moments over the radius-15 disc (integers)
+    // intensity-centroid moments over the radius-15 disc (integers); lane & 31 = column, lane >> 5 = row parity
     int m10 = 0, m01 = 0;
-    for (int i = lane; i < 31 * 31; i += 64)
     {
-        const int vy = i / 31 - 15, ux = i % 31 - 15;
-        const int av = vy < 0 ? -vy : vy, au = ux < 0 ? -ux : ux;
-        if (au <= c_umax[av])
+        const int ux = (lane & 31) - 15;
+        const int au = ux < 0 ? -ux : ux;
+#pragma unroll 4
+        for (int k = 0; k < 16; ++k)
         {
-            const int p = w.raw[(vy + RAW_R) * RAW_P + ux + RAW_R];
-            m10 += ux * p;
-            m01 += vy * p;
+            const int vy = 2 * k + (lane >> 5) - 15;
+            const int av = vy < 0 ? -vy : vy;
+            if (vy <= 15 && ux <= 15 && au <= c_umax[av])
+            {
+                const int p = src[(long long)(ky + vy) * pitch + kx + ux];
+                m10 += ux * p;
+                m01 += vy * p;
+            }
         }
     }
 #pragma unroll
@@ -741,27 +845,9 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
     float sn, cs;
     sincos_deg(angle, sn, cs);
 
-    // separable 7x7 Gaussian {18,33,49,56,49,33,18}/256: exact 16-bit rows, one rounding
-    for (int i = lane; i < RAW_W * BL_W; i += 64)
-    {
-        const int ry = i / BL_W, bx = i - ry * BL_W;  // bx: blurred column 0..36 <-> raw column bx + 3
-        const u8* r  = &w.raw[ry * RAW_P + bx];
-        w.hb[ry * BL_P + bx] = (u16)(18 * (r[0] + r[6]) + 33 * (r[1] + r[5]) + 49 * (r[2] + r[4]) + 56 * r[3]);
-    }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    for (int i = lane; i < BL_W * BL_W; i += 64)
-    {
-        const int by = i / BL_W, bx = i - by * BL_W;
-        const u16* h = &w.hb[by * BL_P + bx];
-        const int acc = 18 * (h[0] + h[6 * BL_P]) + 33 * (h[BL_P] + h[5 * BL_P]) + 49 * (h[2 * BL_P] + h[4 * BL_P]) + 56 * h[3 * BL_P];
-        w.bl[by * BL_P + bx] = (u8)((acc + (1 << 15)) >> 16);
-    }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-
-    // 256 steered tests; lane computes bits lane, lane+64, lane+128, lane+192 -> 4 ballots
+    // 256 steered tests on the blurred level; lane computes bits lane, lane+64, lane+128, lane+192
     u64 word[4];
+    const u8* bc = bsrc + (long long)ky * lv.pitch + kx;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
     {
@@ -773,7 +859,7 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
             const float pxf = (float)pat[4 * bit + 2 * e], pyf = (float)pat[4 * bit + 2 * e + 1];
             const int ry    = __float2int_rn(pxf * sn + pyf * cs);
             const int rx    = __float2int_rn(pxf * cs - pyf * sn);
-            t[e]            = w.bl[(ry + BL_R) * BL_P + rx + BL_R];
+            t[e]            = bc[ry * lv.pitch + rx];
         }
         word[k] = __ballot(t[0] < t[1]);
     }
@@ -805,7 +891,8 @@ struct snk_orb : HandleBase
     int width = 0, height = 0, max_batch = 0;
     bool configured = false;
     Layout lay{};
-    DevBuf pyr[MAX_LEVELS];  // levels >= 1
+    DevBuf pyr[MAX_LEVELS];   // levels >= 1
+    DevBuf blur[MAX_LEVELS];  // blurred levels (all)
     DevBuf tables;           // resize tables
     DevBuf img0;             // level-0 staging for the host API
     DevBuf cand, cell_cnt, sel, sel_score, sel_cnt, cand_total;
@@ -814,7 +901,7 @@ struct snk_orb : HandleBase
     size_t dist_lds = 0;
     // optional per-stage timing with HIP events on the handle's stream (bench.py roofline leg)
     bool profiling = false;
-    std::vector<std::array<hipEvent_t, 5>> ev_sets;  // resize | fast | distribute | describe boundaries
+    std::vector<std::array<hipEvent_t, 6>> ev_sets;  // pyramid | blur | fast | distribute | describe boundaries
     size_t ev_used = 0;
 };
 
@@ -832,7 +919,7 @@ static int compute_layout(snk_orb* o, int w, int h)
     const float factor = 1.0f / p.scale_factor;
     float n_desired    = (float)p.nfeatures * (1.0f - factor) / (1.0f - (float)pow((double)factor, (double)p.n_levels));
     int sum            = 0;
-    int cell_off = 0, slot_off = 0;
+    int cell_off = 0, slot_off = 0, tile_off = 0;
     for (int l = 0; l < p.n_levels; ++l)
     {
         LevelInfo& lv = L.lv[l];
@@ -871,9 +958,13 @@ static int compute_layout(snk_orb* o, int w, int h)
         slot_off += lv.slot_cap;
         lv.pitch      = (lv.w + 63) & ~63;
         lv.img_stride = (long long)lv.pitch * lv.h;
+        lv.tiles_x    = ceil_div(lv.w, BT_W);
+        lv.tile_off   = tile_off;
+        tile_off += lv.tiles_x * ceil_div(lv.h, BT_H);
     }
     L.total_cells = cell_off;
     L.total_slots = slot_off;
+    L.total_tiles = tile_off;
     return SNK_OK;
 }
 
@@ -935,6 +1026,7 @@ int snk_orb_destroy(snk_orb* o)
     if (!o) return SNK_OK;
     (void)hipSetDevice(o->device);
     for (auto& b : o->pyr) b.release();
+    for (auto& b : o->blur) b.release();
     o->tables.release();
     o->img0.release();
     o->cand.release();
@@ -1000,6 +1092,11 @@ int snk_orb_configure(snk_orb* o, int width, int height, int max_batch)
         if ((rc = o->pyr[l].reserve((size_t)L.lv[l].img_stride * max_batch + 64)) != SNK_OK) return rc;
         L.lv[l].base = o->pyr[l].as<u8>();
     }
+    for (int l = 0; l < L.n_levels; ++l)
+    {
+        if ((rc = o->blur[l].reserve((size_t)L.lv[l].img_stride * max_batch + 64)) != SNK_OK) return rc;
+        L.lv[l].blur = o->blur[l].as<u8>();
+    }
     const size_t cells = (size_t)(L.total_cells > 0 ? L.total_cells : 1) * max_batch;
     const size_t slots = (size_t)(L.total_slots > 0 ? L.total_slots : 1) * max_batch;
     if ((rc = o->cand.reserve(cells * CELL_SLOTS * sizeof(u32))) != SNK_OK) return rc;
@@ -1036,12 +1133,12 @@ static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long i
                         snk_keypoint* kps_dev, uint64_t* desc_dev, int32_t* n_dev, int out_cap)
 {
     const Layout& L = o->lay;
-    std::array<hipEvent_t, 5>* ev = nullptr;
+    std::array<hipEvent_t, 6>* ev = nullptr;
     if (o->profiling)
     {
         if (o->ev_used == o->ev_sets.size())
         {
-            std::array<hipEvent_t, 5> e{};
+            std::array<hipEvent_t, 6> e{};
             for (auto& x : e) SNK_HIP_CHECK(hipEventCreate(&x));
             o->ev_sets.push_back(e);
         }
@@ -1061,27 +1158,32 @@ static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long i
                            d.img_stride, d.w, d.h, d.xofs, d.xw1, d.yofs, d.yw1);
         SNK_LAUNCH_CHECK();
     }
+    const int aligned0 = (reinterpret_cast<uintptr_t>(images_dev) % 4 == 0 && pitch % 4 == 0 && image_stride % 4 == 0) ? 1 : 0;
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[1], o->stream));
+    hipLaunchKernelGGL(blur_kernel, dim3(L.total_tiles, batch), dim3(256), 0, o->stream, L, images_dev, pitch, image_stride,
+                       aligned0);
+    SNK_LAUNCH_CHECK();
+    if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[2], o->stream));
     if (L.total_cells > 0)
     {
         hipLaunchKernelGGL(fast_kernel, dim3(L.total_cells, batch), dim3(256), 0, o->stream, L, images_dev, pitch,
-                           image_stride, o->params.ini_th_fast, o->params.min_th_fast, o->cand.as<u32>(),
+                           image_stride, aligned0, o->params.ini_th_fast, o->params.min_th_fast, o->cand.as<u32>(),
                            o->cell_cnt.as<u16>());
         SNK_LAUNCH_CHECK();
     }
-    if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[2], o->stream));
+    if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[3], o->stream));
     hipLaunchKernelGGL(distribute_kernel, dim3(L.n_levels, batch), dim3(DIST_THREADS), o->dist_lds, o->stream, L,
                        o->cand.as<u32>(), o->cell_cnt.as<u16>(), o->sel.as<u32>(), o->sel_score.as<u8>(),
                        o->sel_cnt.as<int>(), o->cand_total.as<int>());
     SNK_LAUNCH_CHECK();
-    if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[3], o->stream));
+    if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[4], o->stream));
     int max_slot = 1;
     for (int l = 0; l < L.n_levels; ++l) max_slot = L.lv[l].slot_cap > max_slot ? L.lv[l].slot_cap : max_slot;
     hipLaunchKernelGGL(describe_kernel, dim3(ceil_div(max_slot, 4), L.n_levels, batch), dim3(256), 0, o->stream, L,
                        images_dev, pitch, image_stride, o->sel.as<u32>(), o->sel_score.as<u8>(), o->sel_cnt.as<int>(),
                        kps_dev, (u64*)desc_dev, n_dev, out_cap);
     SNK_LAUNCH_CHECK();
-    if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[4], o->stream));
+    if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[5], o->stream));
     return SNK_OK;
 }
 
@@ -1153,14 +1255,14 @@ int snk_orb_set_profiling(snk_orb* o, int enable)
     return SNK_OK;
 }
 
-int snk_orb_stage_times(snk_orb* o, float* ms /* 4: resize, fast, distribute, describe */, int* n_calls)
+int snk_orb_stage_times(snk_orb* o, float* ms /* 5: pyramid, blur, fast, distribute, describe */, int* n_calls)
 {
     SNK_REQUIRE(o != nullptr && ms != nullptr && n_calls != nullptr, "NULL argument");
     SNK_HIP_CHECK(hipSetDevice(o->device));
     SNK_HIP_CHECK(hipStreamSynchronize(o->stream));
-    for (int k = 0; k < 4; ++k) ms[k] = 0.0f;
+    for (int k = 0; k < 5; ++k) ms[k] = 0.0f;
     for (size_t i = 0; i < o->ev_used; ++i)
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 5; ++k)
         {
             float t = 0.0f;
             SNK_HIP_CHECK(hipEventElapsedTime(&t, o->ev_sets[i][k], o->ev_sets[i][k + 1]));

@@ -88,8 +88,8 @@ class ORBExtractor:
         _lib.check(self._lib.snk_orb_set_profiling(self._h, int(enable)), "snk_orb_set_profiling")
 
     def stage_times(self):
-        """(ms per stage [resize, fast, distribute, describe] summed over calls, number of calls)."""
-        ms = (C.c_float * 4)()
+        """(ms per stage [pyramid, blur, fast, distribute, describe] summed over calls, number of calls)."""
+        ms = (C.c_float * 5)()
         n = C.c_int(0)
         _lib.check(self._lib.snk_orb_stage_times(self._h, ms, C.byref(n)), "snk_orb_stage_times")
         return list(ms), n.value
