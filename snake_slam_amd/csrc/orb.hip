@@ -128,7 +128,7 @@ template <int PITCH_DW>
 __device__ __forceinline__ void load_tile(u32* tile, const u8* __restrict__ src, int pitch, int w, int h, int xs, int ys,
                                           int ndw, int nrows, bool aligned, int tid, int nthreads)
 {
-    const int lc = ndw <= 16 ? 4 : 5;
+    const int lc = ndw <= 16 ? 4 : (ndw <= 32 ? 5 : 6);
     for (int i = tid; i < (nrows << lc); i += nthreads)
     {
         const int r = i >> lc, d = i & ((1 << lc) - 1);
@@ -144,6 +144,56 @@ __device__ __forceinline__ void load_tile(u32* tile, const u8* __restrict__ src,
                 ((u32)rp[reflect101(x + 3, w)] << 24);
         tile[r * PITCH_DW + d] = v;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pyramid, tiled: one workgroup produces a 64x16 tile of level l from an LDS copy of the source
+// rectangle it needs (aligned dword loads), 4 output pixels per lane, one dword store.
+// ------------------------------------------------------------------------------------------------
+constexpr int RT_W = 64, RT_H = 16;
+constexpr int RT_PITCH_DW = 36;  // up to 144 source bytes per row
+constexpr int RT_ROWS     = 40;
+
+__global__ __launch_bounds__(256) void resize_tiled_kernel(const u8* __restrict__ src, int spitch, long long sstride, int sw,
+                                                           int sh, int aligned, u8* __restrict__ dst, int dpitch,
+                                                           long long dstride, int dw, int dh, const int* __restrict__ xofs,
+                                                           const int* __restrict__ xw1, const int* __restrict__ yofs,
+                                                           const int* __restrict__ yw1)
+{
+    __shared__ u32 tile_dw[RT_ROWS * RT_PITCH_DW];
+    const int b  = blockIdx.z;
+    const int x0 = blockIdx.x * RT_W, y0 = blockIdx.y * RT_H;
+    const int tid = threadIdx.x;
+    const int xl = min(x0 + RT_W - 1, dw - 1), yl = min(y0 + RT_H - 1, dh - 1);
+    const int sx_lo = xofs[x0], sx_hi = min(xofs[xl] + 1, sw - 1);
+    const int sy_lo = yofs[y0], sy_hi = min(yofs[yl] + 1, sh - 1);
+    const int xs    = sx_lo & ~3;
+    const int ndw   = ((sx_hi - xs) >> 2) + 1;
+    const int nrows = sy_hi - sy_lo + 1;
+    load_tile<RT_PITCH_DW>(tile_dw, src + (long long)b * sstride, spitch, sw, sh, xs, sy_lo, ndw, nrows, aligned != 0, tid, 256);
+    __syncthreads();
+    const u8* tile = reinterpret_cast<const u8*>(tile_dw);
+    const int y = y0 + (tid >> 4), x4 = x0 + 4 * (tid & 15);
+    if (y >= dh || x4 >= dw) return;
+    const int sy = yofs[y], wy1 = yw1[y], wy0 = 2048 - wy1;
+    const int sy1 = sy + 1 < sh ? sy + 1 : sh - 1;
+    const u8* r0  = tile + (sy - sy_lo) * (RT_PITCH_DW * 4) - xs;
+    const u8* r1  = tile + (sy1 - sy_lo) * (RT_PITCH_DW * 4) - xs;
+    u32 packed    = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+        const int x = x4 + k;
+        if (x < dw)
+        {
+            const int sx = xofs[x], wx1 = xw1[x], wx0 = 2048 - wx1;
+            const int sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
+            const int v   = ((int)r0[sx] * wx0 + (int)r0[sx1] * wx1) * wy0 + ((int)r1[sx] * wx0 + (int)r1[sx1] * wx1) * wy1;
+            packed |= (u32)((v + (1 << 21)) >> 22) << (8 * k);
+        }
+    }
+    u8* d = dst + (long long)b * dstride + (long long)y * dpitch + x4;
+    *reinterpret_cast<u32*>(d) = packed;  // dpitch is a multiple of 64: the padding columns exist
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -457,14 +507,16 @@ __device__ int block_scan_incl(int v, int tid, int* wave_tot /* >= 8 */)
 //   sc    u8[cap]       scores
 //   lcp   i8[cap + 1]   common-prefix length with the predecessor (-1 = different root)
 //   fd    u8[cap]       final node depth of every sorted point
-__global__ __launch_bounds__(DIST_THREADS) void distribute_kernel(Layout L, const u32* __restrict__ cand,
-                                                                  const u16* __restrict__ cell_cnt,
-                                                                  u32* __restrict__ sel /* [B][total_slots] x|y<<16 */,
-                                                                  u8* __restrict__ sel_score, int* __restrict__ sel_cnt,
-                                                                  int* __restrict__ cand_total /* debug: [B][levels] */)
+// Returns false (nothing written) when the level holds more candidates than this launch's LDS
+// carve (lds_cap) can sort; the caller then queues the (image, level) for the large-LDS launch.
+__device__ bool distribute_body(const Layout& L, int b, int l, int lds_cap, const u32* __restrict__ cand,
+                                const u16* __restrict__ cell_cnt, u32* __restrict__ sel /* [B][total_slots] x|y<<16 */,
+                                u8* __restrict__ sel_score, int* __restrict__ sel_cnt,
+                                int* __restrict__ cand_total /* debug: [B][levels] */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int cap = L.level_cap;
+    const int cap     = lds_cap;      // LDS carve of this launch
+    const int sem_cap = L.level_cap;  // candidate budget of the definition
     u64* keys     = reinterpret_cast<u64*>(smem);
     u64* nodes    = keys + cap;
     u16* px       = reinterpret_cast<u16*>(nodes + cap / 2);
@@ -477,8 +529,6 @@ __global__ __launch_bounds__(DIST_THREADS) void distribute_kernel(Layout L, cons
     __shared__ int s_n, s_k, s_D, s_careful, s_size, s_nnodes, s_finish, s_jstar, s_out;
 
     const int tid = threadIdx.x;
-    const int l   = blockIdx.x;
-    const int b   = blockIdx.y;
     const LevelInfo& lv = L.lv[l];
     const int ncell = lv.ncols * lv.nrows;
     const int N     = lv.nfeat;
@@ -497,17 +547,18 @@ __global__ __launch_bounds__(DIST_THREADS) void distribute_kernel(Layout L, cons
         const int incl = block_scan_incl(part, tid, wave_tot);
         if (tid == DIST_THREADS - 1) s_n = incl;
         __syncthreads();
-        if (s_n <= cap || k == 0) break;
+        if (s_n <= sem_cap || k == 0) break;
         if (tid == 0) s_k = k - 1;
         __syncthreads();
     }
     const int kcell = s_k;
     const int n     = s_n;
+    if (n > cap) return false;
     if (tid == 0 && cand_total) cand_total[b * MAX_LEVELS + l] = n;
     if (n == 0 || N <= 0)
     {
         if (tid == 0) *out_cnt = 0;
-        return;
+        return true;
     }
     int n_pow2 = 1;
     while (n_pow2 < n) n_pow2 <<= 1;
@@ -726,6 +777,34 @@ __global__ __launch_bounds__(DIST_THREADS) void distribute_kernel(Layout L, cons
         }
         if (tid == 0) *out_cnt = base < lv.slot_cap ? base : lv.slot_cap;
     }
+    return true;
+}
+
+// small-LDS launch over every (level, image); levels that do not fit are queued
+__global__ __launch_bounds__(DIST_THREADS) void distribute_kernel(Layout L, int lds_cap, const u32* __restrict__ cand,
+                                                                  const u16* __restrict__ cell_cnt, u32* __restrict__ sel,
+                                                                  u8* __restrict__ sel_score, int* __restrict__ sel_cnt,
+                                                                  int* __restrict__ cand_total, int* __restrict__ queue)
+{
+    const int l = blockIdx.x, b = blockIdx.y;
+    if (!distribute_body(L, b, l, lds_cap, cand, cell_cnt, sel, sel_score, sel_cnt, cand_total) && threadIdx.x == 0)
+        queue[1 + atomicAdd(&queue[0], 1)] = b * MAX_LEVELS + l;
+}
+
+// full-budget launch: a fixed set of workgroups drains the queue (normally empty)
+__global__ __launch_bounds__(DIST_THREADS) void distribute_large_kernel(Layout L, const u32* __restrict__ cand,
+                                                                        const u16* __restrict__ cell_cnt,
+                                                                        u32* __restrict__ sel, u8* __restrict__ sel_score,
+                                                                        int* __restrict__ sel_cnt, int* __restrict__ cand_total,
+                                                                        const int* __restrict__ queue)
+{
+    const int count = queue[0];
+    for (int i = blockIdx.x; i < count; i += gridDim.x)
+    {
+        const int item = queue[1 + i];
+        distribute_body(L, item / MAX_LEVELS, item % MAX_LEVELS, L.level_cap, cand, cell_cnt, sel, sel_score, sel_cnt, cand_total);
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -782,7 +861,7 @@ __device__ __forceinline__ void sincos_deg(float deg, float& s_out, float& c_out
 // One wavefront per keypoint.  Moments come from the raw level (31x31 disc, lane = column),
 // the 256 steered tests gather from the blurred level; 4 ballots assemble the descriptor.
 __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __restrict__ img0, int pitch0,
-                                                       long long stride0, const u32* __restrict__ sel,
+                                                       long long stride0, int aligned0, const u32* __restrict__ sel,
                                                        const u8* __restrict__ sel_score, const int* __restrict__ sel_cnt,
                                                        snk_keypoint* __restrict__ kps, u64* __restrict__ desc,
                                                        int* __restrict__ n_out, int out_cap)
@@ -816,10 +895,40 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
     const u8* src   = l == 0 ? img0 + (long long)b * stride0 : lv.base + (long long)b * lv.img_stride;
     const int pitch = l == 0 ? pitch0 : lv.pitch;
     const u8* bsrc  = lv.blur + (long long)b * lv.img_stride;
+    const bool aligned = l == 0 ? aligned0 != 0 : true;
 
-    // intensity-centroid moments over the radius-15 disc (integers); lane & 31 = column, lane >> 5 = row parity
+    // intensity-centroid moments over the radius-15 disc (integers)
     int m10 = 0, m01 = 0;
+    if (aligned)
     {
+        // 31 rows x 9 aligned dwords cover columns kx-15 .. kx+15 (byte offset sh2 inside the first dword)
+        const int xa  = (kx - 15) & ~3;
+        const int sh2 = (kx - 15) - xa;
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+        {
+            const int item = lane + 64 * k;
+            if (item < 31 * 9)
+            {
+                const int row = item / 9, d = item - row * 9;
+                const int vy  = row - 15;
+                const int lim = c_umax[vy < 0 ? -vy : vy];
+                const u32 dwv = *reinterpret_cast<const u32*>(src + (long long)(ky + vy) * pitch + xa + 4 * d);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                {
+                    const int ux = 4 * d + j - sh2 - 15;
+                    const int au = ux < 0 ? -ux : ux;
+                    const int p  = au <= lim ? (int)((dwv >> (8 * j)) & 0xFFu) : 0;
+                    m10 += ux * p;
+                    m01 += vy * p;
+                }
+            }
+        }
+    }
+    else
+    {
+        // byte path: lane & 31 = column, lane >> 5 = row parity
         const int ux = (lane & 31) - 15;
         const int au = ux < 0 ? -ux : ux;
 #pragma unroll 4
@@ -895,10 +1004,11 @@ struct snk_orb : HandleBase
     DevBuf blur[MAX_LEVELS];  // blurred levels (all)
     DevBuf tables;           // resize tables
     DevBuf img0;             // level-0 staging for the host API
-    DevBuf cand, cell_cnt, sel, sel_score, sel_cnt, cand_total;
+    DevBuf cand, cell_cnt, sel, sel_score, sel_cnt, cand_total, dist_queue;
     DevBuf out_kps, out_desc, out_n;  // host-API staging
     int pitch0_host = 0;
-    size_t dist_lds = 0;
+    size_t dist_lds = 0, dist_lds_small = 0;
+    int dist_small_cap = 0;
     // optional per-stage timing with HIP events on the handle's stream (bench.py roofline leg)
     bool profiling = false;
     std::vector<std::array<hipEvent_t, 6>> ev_sets;  // pyramid | blur | fast | distribute | describe boundaries
@@ -1035,6 +1145,7 @@ int snk_orb_destroy(snk_orb* o)
     o->sel_score.release();
     o->sel_cnt.release();
     o->cand_total.release();
+    o->dist_queue.release();
     o->out_kps.release();
     o->out_desc.release();
     o->out_n.release();
@@ -1106,9 +1217,14 @@ int snk_orb_configure(snk_orb* o, int width, int height, int max_batch)
     if ((rc = o->sel_cnt.reserve((size_t)max_batch * MAX_LEVELS * sizeof(int))) != SNK_OK) return rc;
     if ((rc = o->cand_total.reserve((size_t)max_batch * MAX_LEVELS * sizeof(int))) != SNK_OK) return rc;
     // distribute kernel dynamic LDS
-    const size_t cap = (size_t)L.level_cap;
-    o->dist_lds      = cap * 8 + cap / 2 * 8 + cap * 2 * 2 + cap + (cap + 16) + cap;
+    auto dist_lds_bytes = [](size_t cap) { return cap * 8 + cap / 2 * 8 + cap * 2 * 2 + cap + (cap + 16) + cap; };
+    o->dist_small_cap = L.level_cap < 2048 ? L.level_cap : 2048;
+    o->dist_lds       = dist_lds_bytes((size_t)L.level_cap);
+    o->dist_lds_small = dist_lds_bytes((size_t)o->dist_small_cap);
+    if ((rc = o->dist_queue.reserve(((size_t)max_batch * MAX_LEVELS + 1) * sizeof(int))) != SNK_OK) return rc;
     SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(distribute_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->dist_lds_small));
+    SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(distribute_large_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->dist_lds));
     o->width      = width;
     o->height     = height;
@@ -1153,9 +1269,22 @@ static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long i
         const u8* src      = l == 1 ? images_dev : s.base;
         const int spitch   = l == 1 ? pitch : s.pitch;
         const long long ss = l == 1 ? image_stride : s.img_stride;
-        dim3 grid(ceil_div(ceil_div(d.w, 4), 256), d.h, batch);
-        hipLaunchKernelGGL(resize_kernel, grid, dim3(256), 0, o->stream, src, spitch, ss, s.w, s.h, d.base, d.pitch,
-                           d.img_stride, d.w, d.h, d.xofs, d.xw1, d.yofs, d.yw1);
+        // source rectangle of a 64x16 tile: (64, 16) * scale + 2 (+3 bytes of alignment slack)
+        const double sfx = (double)s.w / d.w, sfy = (double)s.h / d.h;
+        const bool tiled = RT_W * sfx + 8 <= RT_PITCH_DW * 4 && RT_H * sfy + 3 <= RT_ROWS;
+        if (tiled)
+        {
+            const int al = l == 1 ? (reinterpret_cast<uintptr_t>(images_dev) % 4 == 0 && pitch % 4 == 0 && image_stride % 4 == 0) : 1;
+            dim3 grid(ceil_div(d.w, RT_W), ceil_div(d.h, RT_H), batch);
+            hipLaunchKernelGGL(resize_tiled_kernel, grid, dim3(256), 0, o->stream, src, spitch, ss, s.w, s.h, al, d.base,
+                               d.pitch, d.img_stride, d.w, d.h, d.xofs, d.xw1, d.yofs, d.yw1);
+        }
+        else
+        {
+            dim3 grid(ceil_div(ceil_div(d.w, 4), 256), d.h, batch);
+            hipLaunchKernelGGL(resize_kernel, grid, dim3(256), 0, o->stream, src, spitch, ss, s.w, s.h, d.base, d.pitch,
+                               d.img_stride, d.w, d.h, d.xofs, d.xw1, d.yofs, d.yw1);
+        }
         SNK_LAUNCH_CHECK();
     }
     const int aligned0 = (reinterpret_cast<uintptr_t>(images_dev) % 4 == 0 && pitch % 4 == 0 && image_stride % 4 == 0) ? 1 : 0;
@@ -1172,15 +1301,24 @@ static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long i
         SNK_LAUNCH_CHECK();
     }
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[3], o->stream));
-    hipLaunchKernelGGL(distribute_kernel, dim3(L.n_levels, batch), dim3(DIST_THREADS), o->dist_lds, o->stream, L,
-                       o->cand.as<u32>(), o->cell_cnt.as<u16>(), o->sel.as<u32>(), o->sel_score.as<u8>(),
-                       o->sel_cnt.as<int>(), o->cand_total.as<int>());
+    SNK_HIP_CHECK(hipMemsetAsync(o->dist_queue.p, 0, sizeof(int), o->stream));
+    hipLaunchKernelGGL(distribute_kernel, dim3(L.n_levels, batch), dim3(DIST_THREADS), o->dist_lds_small, o->stream, L,
+                       o->dist_small_cap, o->cand.as<u32>(), o->cell_cnt.as<u16>(), o->sel.as<u32>(), o->sel_score.as<u8>(),
+                       o->sel_cnt.as<int>(), o->cand_total.as<int>(), o->dist_queue.as<int>());
     SNK_LAUNCH_CHECK();
+    if (o->dist_small_cap < L.level_cap)
+    {
+        const int workers = L.n_levels * batch < 256 ? L.n_levels * batch : 256;
+        hipLaunchKernelGGL(distribute_large_kernel, dim3(workers), dim3(DIST_THREADS), o->dist_lds, o->stream, L,
+                           o->cand.as<u32>(), o->cell_cnt.as<u16>(), o->sel.as<u32>(), o->sel_score.as<u8>(),
+                           o->sel_cnt.as<int>(), o->cand_total.as<int>(), o->dist_queue.as<int>());
+        SNK_LAUNCH_CHECK();
+    }
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[4], o->stream));
     int max_slot = 1;
     for (int l = 0; l < L.n_levels; ++l) max_slot = L.lv[l].slot_cap > max_slot ? L.lv[l].slot_cap : max_slot;
     hipLaunchKernelGGL(describe_kernel, dim3(ceil_div(max_slot, 4), L.n_levels, batch), dim3(256), 0, o->stream, L,
-                       images_dev, pitch, image_stride, o->sel.as<u32>(), o->sel_score.as<u8>(), o->sel_cnt.as<int>(),
+                       images_dev, pitch, image_stride, aligned0, o->sel.as<u32>(), o->sel_score.as<u8>(), o->sel_cnt.as<int>(),
                        kps_dev, (u64*)desc_dev, n_dev, out_cap);
     SNK_LAUNCH_CHECK();
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[5], o->stream));

@@ -143,3 +143,38 @@ def test_batch_dev_matches_single(orc):
         assert n[i] == len(wk), f"image {i}"
         assert np.array_equal(kps[i, : n[i]], wk.astype(KEYPOINT_DTYPE)) and np.array_equal(desc[i, : n[i]], wd)
     ext.close()
+
+
+def test_unaligned_device_images_take_the_byte_path(orc):
+    """Odd base address and odd pitch: the aligned dword loaders must fall back to byte loads."""
+    import torch
+    from snake_slam_amd import synth
+    from snake_slam_amd.orb import ORBExtractor, KEYPOINT_DTYPE
+
+    B, H, W, P = 2, 240, 320, 323
+    imgs = [synth.stereo_frame(10 + i, W, H, n_rects=120)[0] for i in range(B)]
+    host = np.zeros((B, H, P), np.uint8)
+    for i, im in enumerate(imgs):
+        host[i, :, :W] = im
+    dev = torch.device("cuda:0")
+    flat = torch.zeros(B * H * P + 16, dtype=torch.uint8, device=dev)
+    view = flat[1:1 + B * H * P].view(B, H, P)
+    view.copy_(torch.from_numpy(host))
+    assert view.data_ptr() % 4 != 0
+    ext = ORBExtractor(500, 1.2, 4, 20, 7)
+    cap = ext.configure(W, H, B)
+    d_kps = torch.zeros((B, cap, 24), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((B, cap, 4), dtype=torch.int64, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ext.detect_batch_dev(view, d_kps, d_desc, d_n)
+    ext.sync()
+    n = d_n.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(KEYPOINT_DTYPE).reshape(B, cap)
+    desc = d_desc.cpu().numpy().view(np.uint64)
+    p = orc.orb_params(500, 1.2, 4, 20, 7)
+    for i in range(B):
+        wk, wd = orc.orb_detect(p, imgs[i])
+        assert n[i] == len(wk) and len(wk) > 100
+        assert np.array_equal(kps[i, : n[i]], wk.astype(KEYPOINT_DTYPE)) and np.array_equal(desc[i, : n[i]], wd)
+    ext.close()
