@@ -37,7 +37,6 @@ constexpr int EDGE_THRESHOLD = 19;
 constexpr int MIN_BORDER     = 16;
 constexpr int CELL_W         = 30;
 constexpr int CELL_SLOTS     = 64;   // strongest candidates kept per cell
-constexpr int MAX_CELL       = 59;   // cells are at most 59 px wide by construction
 constexpr int KEY_DIGITS     = 16;
 constexpr int DEFAULT_LEVEL_CAP = 8192;
 
@@ -72,6 +71,8 @@ struct Layout
     int total_slots;
     int total_tiles;
     int level_cap;
+    // per-wavefront LDS slice of fast_kernel (bytes; sized from the largest cell of the layout)
+    int f_tile_pitch_dw, f_s_pitch, f_off_s, f_off_surv, f_off_list, f_off_cnt, f_lds_wave;
     LevelInfo lv[MAX_LEVELS];
 };
 
@@ -124,25 +125,50 @@ __device__ __forceinline__ int reflect101(int i, int n)
     return i >= n ? 2 * n - 2 - i : i;
 }
 
-template <int PITCH_DW>
-__device__ __forceinline__ void load_tile(u32* tile, const u8* __restrict__ src, int pitch, int w, int h, int xs, int ys,
-                                          int ndw, int nrows, bool aligned, int tid, int nthreads)
+// The loads of a batch are all issued before the first LDS store, so a wavefront keeps BATCH
+// memory requests in flight instead of paying one full memory latency per dword.
+template <int BATCH>
+__device__ __forceinline__ void load_tile(u32* tile, int pitch_dw, const u8* __restrict__ src, int pitch, int w, int h, int xs,
+                                          int ys, int ndw, int nrows, bool aligned, int tid, int nthreads)
 {
-    const int lc = ndw <= 16 ? 4 : (ndw <= 32 ? 5 : 6);
-    for (int i = tid; i < (nrows << lc); i += nthreads)
+    const int lc    = ndw <= 8 ? 3 : (ndw <= 16 ? 4 : (ndw <= 32 ? 5 : 6));
+    const int total = nrows << lc;
+    for (int i0 = tid; i0 < total; i0 += nthreads * BATCH)
     {
-        const int r = i >> lc, d = i & ((1 << lc) - 1);
-        if (d >= ndw) continue;
-        const int y  = reflect101(ys + r, h);
-        const int x  = xs + 4 * d;
-        const u8* rp = src + (long long)y * pitch;
-        u32 v;
-        if (aligned && x >= 0 && x + 3 < w)
-            v = *reinterpret_cast<const u32*>(rp + x);
-        else
-            v = (u32)rp[reflect101(x, w)] | ((u32)rp[reflect101(x + 1, w)] << 8) | ((u32)rp[reflect101(x + 2, w)] << 16) |
-                ((u32)rp[reflect101(x + 3, w)] << 24);
-        tile[r * PITCH_DW + d] = v;
+        u32 v[BATCH];
+        int dst[BATCH];  // LDS dword index, -1: nothing to store, -2: border / unaligned (slow path)
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k)
+        {
+            const int i = i0 + k * nthreads;
+            const int r = i >> lc, d = i & ((1 << lc) - 1);
+            dst[k] = -1;
+            v[k]   = 0;
+            if (i < total && d < ndw)
+            {
+                const int x = xs + 4 * d;
+                dst[k]      = r * pitch_dw + d;
+                if (aligned && x >= 0 && x + 3 < w)
+                    v[k] = *reinterpret_cast<const u32*>(src + (long long)reflect101(ys + r, h) * pitch + x);
+                else
+                    dst[k] = -2 - dst[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k)
+        {
+            if (dst[k] <= -2)
+            {
+                const int i = i0 + k * nthreads;
+                const int r = i >> lc, d = i & ((1 << lc) - 1);
+                const int x = xs + 4 * d;
+                const u8* rp = src + (long long)reflect101(ys + r, h) * pitch;
+                v[k] = (u32)rp[reflect101(x, w)] | ((u32)rp[reflect101(x + 1, w)] << 8) | ((u32)rp[reflect101(x + 2, w)] << 16) |
+                       ((u32)rp[reflect101(x + 3, w)] << 24);
+                dst[k] = -2 - dst[k];
+            }
+            if (dst[k] >= 0) tile[dst[k]] = v[k];
+        }
     }
 }
 
@@ -170,7 +196,7 @@ __global__ __launch_bounds__(256) void resize_tiled_kernel(const u8* __restrict_
     const int xs    = sx_lo & ~3;
     const int ndw   = ((sx_hi - xs) >> 2) + 1;
     const int nrows = sy_hi - sy_lo + 1;
-    load_tile<RT_PITCH_DW>(tile_dw, src + (long long)b * sstride, spitch, sw, sh, xs, sy_lo, ndw, nrows, aligned != 0, tid, 256);
+    load_tile<8>(tile_dw, RT_PITCH_DW, src + (long long)b * sstride, spitch, sw, sh, xs, sy_lo, ndw, nrows, aligned != 0, tid, 256);
     __syncthreads();
     const u8* tile = reinterpret_cast<const u8*>(tile_dw);
     const int y = y0 + (tid >> 4), x4 = x0 + 4 * (tid & 15);
@@ -239,26 +265,30 @@ __device__ __forceinline__ short2_t fast_score16_pk(const short2_t (&d)[16])
     return pk_max(bright, -dark);
 }
 
-constexpr int FT_PITCH_DW = 20;  // 80-byte tile rows: (MAX_CELL + 6) pixels + 3 bytes alignment slack
-constexpr int FT_PITCH    = FT_PITCH_DW * 4;
-constexpr int S_PITCH     = 64;  // >= MAX_CELL + 2
-
-// One workgroup per FAST cell.  Phase A runs the cheap opposite-pair bound on every pixel and
-// compacts the ~10 % that can still be corners; phase B evaluates the exact score only for those,
-// densely, two per lane; NMS and the threshold fallback then walk the compacted list.
+// One WAVEFRONT per FAST cell (4 cells per workgroup, no workgroup barriers: the phases of a cell
+// only communicate through that wavefront's own LDS slice, which the LDS serves in program order).
+// Phase A runs the cheap opposite-pair bound on every pixel and compacts the ~10 % that can still
+// be corners; phase B evaluates the exact score only for those, densely, two per lane; NMS and the
+// threshold fallback then walk the compacted list.  LDS slice per wavefront (sizes from the layout):
+// image tile | score map with zero ring | quick-test survivors | NMS survivors | 3 counters.
 __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restrict__ img0, int pitch0, long long stride0,
                                                    int aligned0, int ini_th, int min_th, u32* __restrict__ cand,
-                                                   u16* __restrict__ cell_cnt)
+                                                   u16* __restrict__ cell_cnt, int dbg_stop)
 {
-    __shared__ u32 tile_dw[(MAX_CELL + 6) * FT_PITCH_DW];
-    __shared__ u8 S[(MAX_CELL + 2) * S_PITCH];
-    __shared__ u16 surv[MAX_CELL * MAX_CELL];                          // pixels passing the quick test
-    __shared__ u32 list[((MAX_CELL + 1) / 2) * ((MAX_CELL + 1) / 2)];  // NMS survivors (<= 30*30)
-    __shared__ int n_surv, n_list, n_ini;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b    = blockIdx.y;
+    const int cid  = blockIdx.x * 4 + wave;
+    if (cid >= L.total_cells) return;  // whole wavefront
+    unsigned char* slice = fsm + wave * L.f_lds_wave;
+    u32* tile_dw      = reinterpret_cast<u32*>(slice);
+    u8* S             = slice + L.f_off_s;
+    u16* surv         = reinterpret_cast<u16*>(slice + L.f_off_surv);
+    u32* list         = reinterpret_cast<u32*>(slice + L.f_off_list);
+    volatile int* cnt = reinterpret_cast<volatile int*>(slice + L.f_off_cnt);  // n_surv, n_list, n_ini
+    const int TPD = L.f_tile_pitch_dw, TP = TPD * 4, SP = L.f_s_pitch;
 
-    const int b   = blockIdx.y;
-    const int cid = blockIdx.x;
-    int l         = 0;
+    int l = 0;
     while (l + 1 < L.n_levels && cid >= L.lv[l + 1].cell_off) ++l;
     const LevelInfo& lv = L.lv[l];
     const int c   = cid - lv.cell_off;
@@ -268,91 +298,89 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
     const int x1  = min(x0 + lv.wcell, lv.w - EDGE_THRESHOLD);
     const int y1  = min(y0 + lv.hcell, lv.h - EDGE_THRESHOLD);
     const int cw = x1 - x0, ch = y1 - y0;
-    const int tid = threadIdx.x;
     const long long cell_index = (long long)b * L.total_cells + cid;
     if (cw <= 0 || ch <= 0)
     {
-        if (tid == 0) cell_cnt[cell_index] = 0;
+        if (lane == 0) cell_cnt[cell_index] = 0;
         return;
     }
     const u8* src      = l == 0 ? img0 + (long long)b * stride0 : lv.base + (long long)b * lv.img_stride;
     const int pitch    = l == 0 ? pitch0 : lv.pitch;
     const bool aligned = l == 0 ? aligned0 != 0 : true;
 
-    if (tid == 0)
-    {
-        n_surv = 0;
-        n_list = 0;
-        n_ini  = 0;
-    }
+    if (lane < 3) cnt[lane] = 0;
     // image tile with the 3-pixel ring halo (always inside the image: cells start at x,y >= 19)
     const int xs  = (x0 - 3) & ~3;
     const int sh  = (x0 - 3) - xs;  // tile byte column of cell pixel px is px + 3 + sh
     const int ndw = (sh + cw + 6 + 3) >> 2;
-    load_tile<FT_PITCH_DW>(tile_dw, src, pitch, lv.w, lv.h, xs, y0 - 3, ndw, ch + 6, aligned, tid, 256);
-    for (int i = tid; i < (ch + 2) * (S_PITCH / 4); i += 256) reinterpret_cast<u32*>(S)[i] = 0;
-    __syncthreads();
+    load_tile<8>(tile_dw, TPD, src, pitch, lv.w, lv.h, xs, y0 - 3, ndw, ch + 6, aligned, lane, 64);
+    for (int i = lane; i < (ch + 2) * (SP >> 2); i += 64) reinterpret_cast<u32*>(S)[i] = 0;
+    __builtin_amdgcn_wave_barrier();
     const u8* tile = reinterpret_cast<const u8*>(tile_dw);
+    if (dbg_stop == 1) { if (lane == 0) cell_cnt[cell_index] = (u16)(tile[lane] > 254 ? 1 : 0) * 0; return; }
 
     // phase A: every 9-arc holds one pixel of each opposite pair -> S <= min_i max(d_i, d_{i+8})
-    for (int py = tid >> 5; py < ch; py += 8)
-        for (int px = tid & 31; px < cw; px += 32)
+    for (int py = lane >> 5; py < ch; py += 2)
+        for (int px = lane & 31; px < cw; px += 32)
         {
-            const u8* t  = tile + (py + 3) * FT_PITCH + px + 3 + sh;
+            const u8* t  = tile + (py + 3) * TP + px + 3 + sh;
             const int v  = t[0];
-            const int d0 = t[3 * FT_PITCH] - v, d8 = t[-3 * FT_PITCH] - v, d4 = t[3] - v, d12 = t[-3] - v;
+            const int d0 = t[3 * TP] - v, d8 = t[-3 * TP] - v, d4 = t[3] - v, d12 = t[-3] - v;
             const int ub_b = min(max(d0, d8), max(d4, d12));
             const int ub_d = min(max(-d0, -d8), max(-d4, -d12));
-            if (ub_b > min_th || ub_d > min_th) surv[atomicAdd(&n_surv, 1)] = (u16)((py << 6) | px);
+            if (ub_b > min_th || ub_d > min_th) surv[atomicAdd(const_cast<int*>(&cnt[0]), 1)] = (u16)((py << 6) | px);
         }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
 
     // phase B: exact score of the survivors, two per lane
-    const int ns = n_surv;
-    for (int j = tid * 2; j < ns; j += 512)
+    const int ns = cnt[0];
+    if (dbg_stop == 2) { if (lane == 0) cell_cnt[cell_index] = (u16)(ns > 60000 ? 1 : 0); return; }
+    for (int j = lane * 2; j < ns; j += 128)
     {
         const int e0 = surv[j], e1 = surv[j + 1 < ns ? j + 1 : j];
         const int px0 = e0 & 63, py0 = e0 >> 6, px1 = e1 & 63, py1 = e1 >> 6;
-        const u8* t0 = tile + (py0 + 3) * FT_PITCH + px0 + 3 + sh;
-        const u8* t1 = tile + (py1 + 3) * FT_PITCH + px1 + 3 + sh;
+        const u8* t0 = tile + (py0 + 3) * TP + px0 + 3 + sh;
+        const u8* t1 = tile + (py1 + 3) * TP + px1 + 3 + sh;
         const short v0 = t0[0], v1 = t1[0];
         short2_t d[16];
-#define RING(i, dx, dy) d[i] = short2_t{(short)(t0[(dy)*FT_PITCH + (dx)] - v0), (short)(t1[(dy)*FT_PITCH + (dx)] - v1)};
+#define RING(i, dx, dy) d[i] = short2_t{(short)(t0[(dy)*TP + (dx)] - v0), (short)(t1[(dy)*TP + (dx)] - v1)};
         RING(0, 0, 3) RING(1, 1, 3) RING(2, 2, 2) RING(3, 3, 1) RING(4, 3, 0) RING(5, 3, -1) RING(6, 2, -2) RING(7, 1, -3)
         RING(8, 0, -3) RING(9, -1, -3) RING(10, -2, -2) RING(11, -3, -1) RING(12, -3, 0) RING(13, -3, 1) RING(14, -2, 2)
         RING(15, -1, 3)
 #undef RING
         const short2_t s = fast_score16_pk(d);
-        S[(py0 + 1) * S_PITCH + px0 + 1] = (u8)(s.x < 0 ? 0 : s.x);
-        if (j + 1 < ns) S[(py1 + 1) * S_PITCH + px1 + 1] = (u8)(s.y < 0 ? 0 : s.y);
+        S[(py0 + 1) * SP + px0 + 1] = (u8)(s.x < 0 ? 0 : s.x);
+        if (j + 1 < ns) S[(py1 + 1) * SP + px1 + 1] = (u8)(s.y < 0 ? 0 : s.y);
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
 
+    if (dbg_stop == 3) { if (lane == 0) cell_cnt[cell_index] = (u16)(S[SP + 1] > 254 ? 1 : 0) * 0; return; }
     // 3x3 non-max suppression (strict) among scores above min_th (all of them are survivors)
-    for (int j = tid; j < ns; j += 256)
+    for (int j = lane; j < ns; j += 64)
     {
         const int e  = surv[j];
         const int px = e & 63, py = e >> 6;
-        const u8* s  = &S[(py + 1) * S_PITCH + px + 1];
+        const u8* s  = &S[(py + 1) * SP + px + 1];
         const int v  = s[0];
         if (v <= min_th) continue;
-        if (v > s[-1] && v > s[1] && v > s[-S_PITCH - 1] && v > s[-S_PITCH] && v > s[-S_PITCH + 1] && v > s[S_PITCH - 1] &&
-            v > s[S_PITCH] && v > s[S_PITCH + 1])
+        if (v > s[-1] && v > s[1] && v > s[-SP - 1] && v > s[-SP] && v > s[-SP + 1] && v > s[SP - 1] && v > s[SP] &&
+            v > s[SP + 1])
         {
             // strength key: higher score first, then smaller y, then smaller x
             const u32 key = ((u32)v << 12) | ((u32)(63 - py) << 6) | (u32)(63 - px);
-            list[atomicAdd(&n_list, 1)] = key;
-            if (v > ini_th) atomicAdd(&n_ini, 1);
+            list[atomicAdd(const_cast<int*>(&cnt[1]), 1)] = key;
+            if (v > ini_th) atomicAdd(const_cast<int*>(&cnt[2]), 1);
         }
     }
-    __syncthreads();
-    const int nl   = n_list;
-    const bool ini = n_ini > 0;
+    __builtin_amdgcn_wave_barrier();
+    const int nl   = cnt[1];
+    const int nini = cnt[2];
+    const bool ini = nini > 0;
     const u32 thr  = ((u32)(ini ? ini_th : min_th) << 12) | 0xFFFu;  // key > thr  <=>  score > threshold
-    const int n    = ini ? n_ini : nl;
+    const int n    = ini ? nini : nl;
     // rank the survivors of the effective threshold by strength; keep the CELL_SLOTS strongest
     u32* out = cand + cell_index * CELL_SLOTS;
-    for (int i = tid; i < nl; i += 256)
+    for (int i = lane; i < nl; i += 64)
     {
         const u32 k = list[i];
         if (k <= thr) continue;
@@ -360,7 +388,7 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
         for (int j = 0; j < nl; ++j) r += list[j] > k ? 1 : 0;
         if (r < CELL_SLOTS) out[r] = k;
     }
-    if (tid == 0) cell_cnt[cell_index] = (u16)(n > 65535 ? 65535 : n);
+    if (lane == 0) cell_cnt[cell_index] = (u16)(n > 65535 ? 65535 : n);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -371,29 +399,33 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
 // ------------------------------------------------------------------------------------------------
 constexpr int BT_W = 64, BT_H = 16;
 constexpr int BT_PITCH_DW = 20;
+constexpr int BT_WAVE_DW  = (BT_H + 6) * BT_PITCH_DW + (BT_H + 6) * 32;  // tile | 16-bit rows
 
+// One WAVEFRONT per 64x16 output tile (4 tiles per workgroup, no workgroup barriers).
 __global__ __launch_bounds__(256) void blur_kernel(Layout L, const u8* __restrict__ img0, int pitch0, long long stride0,
                                                    int aligned0)
 {
-    __shared__ u32 tile_dw[(BT_H + 6) * BT_PITCH_DW];
-    __shared__ u32 hb[(BT_H + 6) * 32];  // 64 u16 per row
-    const int b   = blockIdx.y;
-    const int tl  = blockIdx.x;
-    int l         = 0;
+    __shared__ u32 lds[4 * BT_WAVE_DW];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b    = blockIdx.y;
+    const int tl   = blockIdx.x * 4 + wave;
+    if (tl >= L.total_tiles) return;  // whole wavefront
+    u32* tile_dw = lds + wave * BT_WAVE_DW;
+    u32* hb      = tile_dw + (BT_H + 6) * BT_PITCH_DW;  // 64 u16 per row
+    int l = 0;
     while (l + 1 < L.n_levels && tl >= L.lv[l + 1].tile_off) ++l;
     const LevelInfo& lv = L.lv[l];
     const int t   = tl - lv.tile_off;
     const int ty  = t / lv.tiles_x, tx = t - ty * lv.tiles_x;
     const int x0 = tx * BT_W, y0 = ty * BT_H;
-    const int tid = threadIdx.x;
     const u8* src      = l == 0 ? img0 + (long long)b * stride0 : lv.base + (long long)b * lv.img_stride;
     const int pitch    = l == 0 ? pitch0 : lv.pitch;
     const bool aligned = l == 0 ? aligned0 != 0 : true;
-    load_tile<BT_PITCH_DW>(tile_dw, src, pitch, lv.w, lv.h, x0 - 4, y0 - 3, BT_PITCH_DW, BT_H + 6, aligned, tid, 256);
-    __syncthreads();
+    load_tile<6>(tile_dw, BT_PITCH_DW, src, pitch, lv.w, lv.h, x0 - 4, y0 - 3, BT_PITCH_DW, BT_H + 6, aligned, lane, 64);
+    __builtin_amdgcn_wave_barrier();
     const u32 W0123 = 18u | (33u << 8) | (49u << 16) | (56u << 24);
     const u32 W456  = 49u | (33u << 8) | (18u << 16);
-    for (int i = tid; i < (BT_H + 6) * 16; i += 256)
+    for (int i = lane; i < (BT_H + 6) * 16; i += 64)
     {
         const int r = i >> 4, g = i & 15;
         const u32 d0 = tile_dw[r * BT_PITCH_DW + g], d1 = tile_dw[r * BT_PITCH_DW + g + 1], d2 = tile_dw[r * BT_PITCH_DW + g + 2];
@@ -410,9 +442,12 @@ __global__ __launch_bounds__(256) void blur_kernel(Layout L, const u8* __restric
         hb[r * 32 + 2 * g]     = o[0] | (o[1] << 16);
         hb[r * 32 + 2 * g + 1] = o[2] | (o[3] << 16);
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
     {
-        const int r = tid >> 4, g = tid & 15;
+        const int i = lane + 64 * it;
+        const int r = i >> 4, g = i & 15;
         const int y = y0 + r, x = x0 + 4 * g;
         if (y < lv.h && x < lv.w)
         {
@@ -1075,6 +1110,27 @@ static int compute_layout(snk_orb* o, int w, int h)
     L.total_cells = cell_off;
     L.total_slots = slot_off;
     L.total_tiles = tile_off;
+    {
+        int mw = 1, mh = 1;
+        for (int l = 0; l < p.n_levels; ++l)
+            if (L.lv[l].ncols > 0)
+            {
+                mw = L.lv[l].wcell > mw ? L.lv[l].wcell : mw;
+                mh = L.lv[l].hcell > mh ? L.lv[l].hcell : mh;
+            }
+        auto up16 = [](int v) { return (v + 15) & ~15; };
+        L.f_tile_pitch_dw = (mw + 6 + 3 + 3) / 4;
+        L.f_s_pitch       = (mw + 2 + 3) & ~3;
+        const int tile_b  = up16((mh + 6) * L.f_tile_pitch_dw * 4);
+        const int s_b     = up16((mh + 2) * L.f_s_pitch);
+        const int surv_b  = up16(mw * mh * 2);
+        const int list_b  = up16(((mw + 1) / 2) * ((mh + 1) / 2) * 4);
+        L.f_off_s    = tile_b;
+        L.f_off_surv = L.f_off_s + s_b;
+        L.f_off_list = L.f_off_surv + surv_b;
+        L.f_off_cnt  = L.f_off_list + list_b;
+        L.f_lds_wave = L.f_off_cnt + 16;
+    }
     return SNK_OK;
 }
 
@@ -1224,6 +1280,8 @@ int snk_orb_configure(snk_orb* o, int width, int height, int max_batch)
     if ((rc = o->dist_queue.reserve(((size_t)max_batch * MAX_LEVELS + 1) * sizeof(int))) != SNK_OK) return rc;
     SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(distribute_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->dist_lds_small));
+    SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      4 * L.f_lds_wave));
     SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(distribute_large_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->dist_lds));
     o->width      = width;
@@ -1289,15 +1347,16 @@ static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long i
     }
     const int aligned0 = (reinterpret_cast<uintptr_t>(images_dev) % 4 == 0 && pitch % 4 == 0 && image_stride % 4 == 0) ? 1 : 0;
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[1], o->stream));
-    hipLaunchKernelGGL(blur_kernel, dim3(L.total_tiles, batch), dim3(256), 0, o->stream, L, images_dev, pitch, image_stride,
-                       aligned0);
+    hipLaunchKernelGGL(blur_kernel, dim3(ceil_div(L.total_tiles, 4), batch), dim3(256), 0, o->stream, L, images_dev, pitch,
+                       image_stride, aligned0);
     SNK_LAUNCH_CHECK();
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[2], o->stream));
     if (L.total_cells > 0)
     {
-        hipLaunchKernelGGL(fast_kernel, dim3(L.total_cells, batch), dim3(256), 0, o->stream, L, images_dev, pitch,
+        hipLaunchKernelGGL(fast_kernel, dim3(ceil_div(L.total_cells, 4), batch), dim3(256), (size_t)4 * L.f_lds_wave, o->stream, L,
+                           images_dev, pitch,
                            image_stride, aligned0, o->params.ini_th_fast, o->params.min_th_fast, o->cand.as<u32>(),
-                           o->cell_cnt.as<u16>());
+                           o->cell_cnt.as<u16>(), getenv("SNK_DBG_FAST_STOP") ? atoi(getenv("SNK_DBG_FAST_STOP")) : 0);
         SNK_LAUNCH_CHECK();
     }
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[3], o->stream));
