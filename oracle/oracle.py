@@ -284,3 +284,105 @@ def ba_solve(scene, options: BaOptions = None, iterations=None, outlier=None):
     lib().orc_ba_solve(C.byref(P), C.byref(options), C.c_int(options.max_iterations if iterations is None else iterations),
                        C.byref(ci), C.byref(cf), C.byref(it))
     return a["pose"], a["pt"], ci.value, cf.value, it.value
+
+
+# ------------------------------------------------------------------ tracking matchers ----------
+class GridBounds(C.Structure):
+    _fields_ = [("min_x", C.c_double), ("min_y", C.c_double), ("max_x", C.c_double), ("max_y", C.c_double)]
+
+
+class FrameView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("cols", C.c_int32), ("rows", C.c_int32), ("kps", C.c_void_p), ("desc", C.c_void_p),
+                ("right_points", C.c_void_p), ("taken", C.c_void_p), ("cell_start", C.c_void_p), ("bounds", GridBounds)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double)]
+
+
+LM_COARSE = np.dtype([("pos", "<f8", 3), ("normal", "<f8", 3), ("desc", "<u8", 4), ("octave", "<i4"), ("angle", "<f4")])
+LM_FINE = np.dtype([("pos", "<f8", 3), ("normal", "<f8", 3), ("desc", "<u8", 4), ("reference_depth", "<f4"),
+                    ("reference_scale_level", "<i4"), ("valid", "u1"), ("pad", "u1", 7)])
+
+
+def det_log(x):
+    lib().orc_det_log.restype = C.c_double
+    return lib().orc_det_log(C.c_double(x))
+
+
+def det_exp(x):
+    lib().orc_det_exp.restype = C.c_double
+    return lib().orc_det_exp(C.c_double(x))
+
+
+def grid_dims(bounds):
+    b = GridBounds(*bounds)
+    c, r = C.c_int(), C.c_int()
+    lib().orc_grid_dims(C.byref(b), C.byref(c), C.byref(r))
+    return c.value, r.value
+
+
+def feature_grid(kps, bounds):
+    """Returns (perm [n] new index of old feature, cell_start [cols*rows+1], cols, rows)."""
+    kps = np.ascontiguousarray(kps, KP64)
+    cols, rows = grid_dims(bounds)
+    perm = np.zeros(max(len(kps), 1), np.int32)
+    cs = np.zeros(cols * rows + 1, np.int32)
+    b = GridBounds(*bounds)
+    lib().orc_feature_grid(_p(kps), C.c_int(len(kps)), C.byref(b), _p(perm), _p(cs))
+    return perm[: len(kps)], cs, cols, rows
+
+
+def make_frame_view(frame):
+    """frame: dict kps (KP64, grid order), desc, right_points, taken, cell_start, bounds (4), cols, rows."""
+    a = {"kps": np.ascontiguousarray(frame["kps"], KP64), "desc": np.ascontiguousarray(frame["desc"], np.uint64),
+         "right_points": np.ascontiguousarray(frame["right_points"], np.float32),
+         "taken": np.ascontiguousarray(frame["taken"], np.uint8), "cell_start": np.ascontiguousarray(frame["cell_start"], np.int32)}
+    v = FrameView()
+    v.n, v.cols, v.rows = len(a["kps"]), frame["cols"], frame["rows"]
+    for k in a:
+        setattr(v, k, a[k].ctypes.data if a[k].size else 0)
+    v.bounds = GridBounds(*frame["bounds"])
+    return v, a
+
+
+def match_coarse(frame, cam, pose, pts, th, feature_error, direction, level_scale):
+    v, keep = make_frame_view(frame)
+    pts = np.ascontiguousarray(pts, LM_COARSE)
+    ls = np.ascontiguousarray(level_scale, np.float32)
+    pose = np.ascontiguousarray(pose, np.float64)
+    out = np.zeros(max(len(pts), 1), np.int32)
+    c = Camera(*cam)
+    lib().orc_match_coarse.restype = C.c_int
+    n = lib().orc_match_coarse(C.byref(v), C.byref(c), _p(pose), _p(pts), C.c_int(len(pts)), C.c_float(th), C.c_int(feature_error),
+                               C.c_int(direction), _p(ls), C.c_int(len(ls)), _p(out))
+    return n, out[: len(pts)]
+
+
+def match_fine(frame, cam, pose, pts, th, ratio, level_scale):
+    """Returns (n, match_idx, visible, valid_out)."""
+    v, keep = make_frame_view(frame)
+    pts = np.array(pts, LM_FINE, order="C")
+    ls = np.ascontiguousarray(level_scale, np.float32)
+    pose = np.ascontiguousarray(pose, np.float64)
+    out = np.zeros(max(len(pts), 1), np.int32)
+    vis = np.zeros(max(len(pts), 1), np.uint8)
+    c = Camera(*cam)
+    lib().orc_match_fine.restype = C.c_int
+    n = lib().orc_match_fine(C.byref(v), C.byref(c), _p(pose), _p(pts), C.c_int(len(pts)), C.c_float(th), C.c_float(ratio),
+                             _p(ls), C.c_int(len(ls)), _p(out), _p(vis))
+    return n, out[: len(pts)], vis[: len(pts)], pts["valid"].copy()
+
+
+def match_keyframe(frame, cam, pose, pos, desc, skip, th, feature_error):
+    v, keep = make_frame_view(frame)
+    pos = np.ascontiguousarray(pos, np.float64).reshape(-1, 3)
+    desc = np.ascontiguousarray(desc, np.uint64).reshape(-1, 4)
+    skip = np.ascontiguousarray(skip, np.uint8)
+    pose = np.ascontiguousarray(pose, np.float64)
+    out = np.zeros(max(len(pos), 1), np.int32)
+    c = Camera(*cam)
+    lib().orc_match_keyframe.restype = C.c_int
+    n = lib().orc_match_keyframe(C.byref(v), C.byref(c), _p(pose), _p(pos), _p(desc), _p(skip), C.c_int(len(pos)), C.c_float(th),
+                                 C.c_int(feature_error), _p(out))
+    return n, out[: len(pos)]

@@ -135,6 +135,58 @@ void orc_ba_chi2(const orc_ba_problem* P, double* chi2);
 int orc_ba_solve(orc_ba_problem* P, const orc_ba_options* O, int iterations, double* cost_initial, double* cost_final,
                  int* pcg_iterations_total);
 
+/* ---- track_oracle.c ---- */
+typedef struct orc_grid_bounds
+{
+    double min_x, min_y, max_x, max_y;
+} orc_grid_bounds;
+
+typedef struct orc_frame_view
+{
+    int32_t n;
+    int32_t cols, rows;
+    const orc_kp64* kps;        /* undistorted keypoints, grid order */
+    const uint64_t (*desc)[4];
+    const float* right_points;
+    const uint8_t* taken;       /* mvpMapPoints[i] != nullptr */
+    const int32_t* cell_start;  /* cols*rows + 1, x-major cells */
+    orc_grid_bounds bounds;
+} orc_frame_view;
+
+typedef struct orc_camera
+{
+    double fx, fy, cx, cy, bf;
+} orc_camera;
+
+typedef struct orc_lm_coarse
+{
+    double pos[3], normal[3];
+    uint64_t desc[4];
+    int32_t octave;
+    float angle;
+} orc_lm_coarse;
+
+typedef struct orc_lm_fine
+{
+    double pos[3], normal[3];
+    uint64_t desc[4];
+    float reference_depth;
+    int32_t reference_scale_level;
+    uint8_t valid;
+    uint8_t pad[7];
+} orc_lm_fine;
+
+double orc_det_log(double x);
+double orc_det_exp(double y);
+void orc_grid_dims(const orc_grid_bounds* b, int* cols, int* rows);
+void orc_feature_grid(const orc_kp64* kps, int n, const orc_grid_bounds* b, int32_t* perm, int32_t* cell_start);
+int orc_match_coarse(const orc_frame_view* f, const orc_camera* cam, const double* pose, const orc_lm_coarse* pts, int m,
+                     float th, int feature_error, int direction, const float* level_scale, int n_levels, int32_t* match_idx);
+int orc_match_fine(const orc_frame_view* f, const orc_camera* cam, const double* pose, orc_lm_fine* pts, int m, float th,
+                   float ratio, const float* level_scale, int n_levels, int32_t* match_idx, uint8_t* visible);
+int orc_match_keyframe(const orc_frame_view* f, const orc_camera* cam, const double* pose, const double (*pos)[3],
+                       const uint64_t (*desc)[4], const uint8_t* skip, int m, float th, int feature_error, int32_t* match_idx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,91 @@
+"""CPU: pin the feature-grid / projection-matcher oracle (PARITY UNPINNED for the saiga helpers)."""
+import numpy as np
+
+import track_helpers as T
+from helpers import SEED
+
+
+def test_det_log_exp_accuracy(orc):
+    rng = np.random.default_rng(1)
+    for x in list(rng.uniform(1e-6, 1e6, 200)) + [1.0, 1.2, 0.5, 2.0]:
+        assert abs(orc.det_log(x) - np.log(x)) <= 4e-16 * max(1.0, abs(np.log(x)))
+    for y in list(rng.uniform(-20, 20, 200)) + [0.0, 1.0]:
+        assert abs(orc.det_exp(y) / np.exp(y) - 1) <= 4e-15
+    assert orc.det_log(1.0) == 0.0 and orc.det_exp(0.0) == 1.0
+
+
+def test_feature_grid_definition(orc):
+    rng = np.random.default_rng(2)
+    n = 500
+    kps = np.zeros(n, orc.KP64)
+    kps["x"] = rng.uniform(T.BOUNDS[0] - 5, T.BOUNDS[2] + 5, n)  # some outside -> clamped
+    kps["y"] = rng.uniform(T.BOUNDS[1] - 5, T.BOUNDS[3] + 5, n)
+    perm, cs, cols, rows = orc.feature_grid(kps, T.BOUNDS)
+    assert cols == int(np.ceil((T.BOUNDS[2] - T.BOUNDS[0]) / 20)) and rows == int(np.ceil((T.BOUNDS[3] - T.BOUNDS[1]) / 20))
+    assert sorted(perm.tolist()) == list(range(n)) and cs[0] == 0 and cs[-1] == n
+    cx = np.clip(np.floor((kps["x"] - T.BOUNDS[0]) / 20), 0, cols - 1).astype(int)
+    cy = np.clip(np.floor((kps["y"] - T.BOUNDS[1]) / 20), 0, rows - 1).astype(int)
+    cell = cx * rows + cy
+    order = np.argsort(cell, kind="stable")  # x-major cells, original order inside a cell
+    want = np.zeros(n, int)
+    want[order] = np.arange(n)
+    assert np.array_equal(perm, want)
+    assert np.array_equal(np.diff(cs), np.bincount(cell, minlength=cols * rows))
+
+
+def test_coarse_matches_brute_force(orc):
+    for seed, direction, th in [(1, 0, 15.0), (2, 1, 10.0), (3, 2, 15.0), (4, 0, 30.0)]:
+        rng = np.random.default_rng(SEED + seed)
+        frame, cam, pose, ls, world, _ = T.make_tracking_case(orc, rng, n_clutter=300, m_pts=200)
+        pts = T.lm_coarse(orc, world)
+        n, idx = orc.match_coarse(frame, cam, pose, pts, th, 75, direction, ls)
+        n2, idx2 = T.brute_coarse(frame, cam, pose, pts, th, 75, direction, ls)
+        assert n == n2 and np.array_equal(idx, idx2)
+        assert n > 20
+        got = idx[idx >= 0]
+        assert len(set(got.tolist())) == len(got) and (frame["taken"][got] == 0).all()
+
+
+def test_fine_and_keyframe_invariants(orc):
+    rng = np.random.default_rng(SEED + 9)
+    frame, cam, pose, ls, world, _ = T.make_tracking_case(orc, rng, n_clutter=400, m_pts=300)
+    pts = T.lm_fine(orc, rng, world, pose, ls)
+    n, idx, vis, valid = orc.match_fine(frame, cam, pose, pts, 5.0, 0.8, ls)
+    assert n == (idx >= 0).sum() and n > 30
+    got = idx[idx >= 0]
+    assert len(set(got.tolist())) == len(got) and (frame["taken"][got] == 0).all()
+    assert (valid <= pts["valid"]).all() and valid.sum() < pts["valid"].sum()  # culls only clear flags
+    assert (vis <= valid).all() and (idx[valid == 0] == -1).all()
+    # th == 1.0 takes the "no factor" branch and shrinks the windows
+    n1, _, _, _ = orc.match_fine(frame, cam, pose, pts, 1.0, 0.8, ls)
+    assert n1 <= n
+    # keyframe matcher: sequential exclusivity
+    skip = (rng.random(len(world["pos"])) < 0.1).astype(np.uint8)
+    nk, ik = orc.match_keyframe(frame, cam, pose, world["pos"], world["desc"], skip, 15.0, 100)
+    gk = ik[ik >= 0]
+    assert nk == len(gk) and len(set(gk.tolist())) == len(gk) and (ik[skip == 1] == -1).all() and nk > 30
+
+
+def test_keyframe_matcher_is_sequential_greedy(orc):
+    """Two points project to the same place; the first takes the best feature, the second the next best."""
+    from oracle.oracle import KP64
+
+    kps = np.zeros(2, KP64)
+    kps["x"], kps["y"] = [100.0, 103.0], [100.0, 100.0]
+    desc = np.zeros((2, 4), np.uint64)
+    desc[1, 0] = 0b111
+    perm, cs, cols, rows = orc.feature_grid(kps, T.BOUNDS)
+    assert perm.tolist() == [0, 1]
+    frame = dict(kps=kps, desc=desc, right_points=np.full(2, -1, np.float32), taken=np.zeros(2, np.uint8), cell_start=cs,
+                 bounds=T.BOUNDS, cols=cols, rows=rows)
+    cam = (100.0, 100.0, 100.0, 100.0, 10.0)
+    pose = np.array([0, 0, 0, 1.0, 0, 0, 0])
+    pos = np.array([[0.0, 0.0, 1.0], [0.0, 0.0, 1.0]])  # both project to (100, 100)
+    pd = np.zeros((2, 4), np.uint64)
+    n, idx = orc.match_keyframe(frame, cam, pose, pos, pd, np.zeros(2, np.uint8), 10.0, 50)
+    assert n == 2 and idx.tolist() == [0, 1]
+    # the parallel matchers instead drop the second claimant
+    pts = np.zeros(2, orc.LM_COARSE)
+    pts["pos"], pts["normal"] = pos, [[0, 0, -1.0], [0, 0, -1.0]]
+    nc, ic = orc.match_coarse(frame, cam, pose, pts, 10.0, 50, 0, np.ones(4, np.float32))
+    assert nc == 1 and ic.tolist() == [0, -1]
