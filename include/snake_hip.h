@@ -221,6 +221,90 @@ SNK_API int snk_rectify_batch_dev(snk_matcher* m, const snk_rectification* rect,
                                   const int32_t* n_dev, int cap, int batch, snk_kp64* out_dev, double* normalized_dev);
 
 /* ------------------------------------------------------------------------------------------
+ * Feature grid and projection-guided tracking matchers
+ * ------------------------------------------------------------------------------------------ */
+
+/* Saiga::FeatureGridBounds2<double, 20> as Snake uses it (featureGridBounds,
+ * Snake/System/SnakeGlobal.h:115): the extent of the undistorted image; 20-px cells. */
+typedef struct snk_grid_bounds
+{
+    double min_x, min_y, max_x, max_y;
+} snk_grid_bounds;
+
+/* Replaces frame.grid.create(featureGridBounds, undistorted_keypoints) —
+ * Snake/Preprocess/Preprocess.cpp:246: perm[i] = new index of feature i (the caller scatters its
+ * arrays as at :254-260); cell_start[cols*rows + 1] = first feature of every cell, cells ordered
+ * x-major (id = cx*rows + cy, the order Features::GetFeaturesInArea walks them,
+ * Snake/Map/Features.cpp:17-21). */
+SNK_API int snk_feature_grid(snk_matcher* m, const snk_kp64* undistorted, int n, const snk_grid_bounds* bounds,
+                             int32_t* perm, int32_t* cell_start, int* cols, int* rows);
+
+/* The per-frame data the tracking matchers read (Snake/Map/Features.h:18-41, Frame.h:44-46), in
+ * feature-grid order.  taken[i] != 0 <=> frame.mvpMapPoints[i] != nullptr. */
+typedef struct snk_frame_view
+{
+    int32_t n;
+    int32_t cols, rows;
+    const snk_kp64* kps; /* undistorted_keypoints */
+    const uint64_t (*desc)[4];
+    const float* right_points;
+    const uint8_t* taken;
+    const int32_t* cell_start;
+    snk_grid_bounds bounds;
+} snk_frame_view;
+
+/* K (fx fy cx cy) and stereo_cam.bf (Snake/System/SnakeGlobal.h:103-104). */
+typedef struct snk_camera
+{
+    double fx, fy, cx, cy, bf;
+} snk_camera;
+
+/* CoarseTrackingPoint / FineTrackingPoint without the MapPoint* (Snake/Map/LocalMap.h:17-55). */
+typedef struct snk_lm_coarse
+{
+    double pos[3], normal[3];
+    uint64_t desc[4];
+    int32_t octave;
+    float angle;
+} snk_lm_coarse;
+
+typedef struct snk_lm_fine
+{
+    double pos[3], normal[3];
+    uint64_t desc[4];
+    float reference_depth;
+    int32_t reference_scale_level;
+    uint8_t valid; /* in/out: cleared by the frustum / distance / viewing-angle culls */
+    uint8_t pad[7];
+} snk_lm_fine;
+
+/* Replaces SnakeORBMatcher::SearchByProjectionFrameFrame2 — Snake/Tracking/SnakeORBMatcher.cpp:191-354
+ * (call site Snake/Tracking/TrackingCoarse.cpp:234).  pose = CurrentFrame.Pose() (qx qy qz qw tx ty tz).
+ * direction: 0 none, 1 bForward, 2 bBackward (:210-212).  match_idx[i] = feature matched to
+ * local-map point i or -1 (the adaptor sets mvpMapPoints[match_idx[i]] = lm.points[i].mp);
+ * *n_matches = the function's return value. */
+SNK_API int snk_match_project_coarse(snk_matcher* m, const snk_frame_view* frame, const snk_camera* cam,
+                                     const double pose[7], const snk_lm_coarse* pts, int n_pts, float th, int feature_error,
+                                     int direction, const float* level_scale, int n_levels, int32_t* match_idx,
+                                     int* n_matches);
+
+/* Replaces SnakeORBMatcher::SearchByProjection2 — Snake/Tracking/SnakeORBMatcher.cpp:365-526 (call
+ * site Snake/Tracking/TrackingFine.cpp:149).  pts[i].valid is updated like lmp.valid; visible[i] = 1
+ * where the reference calls lmp.mp->IncreaseVisible() (:431). */
+SNK_API int snk_match_project_fine(snk_matcher* m, const snk_frame_view* frame, const snk_camera* cam, const double pose[7],
+                                   snk_lm_fine* pts, int n_pts, float th, float ratio, const float* level_scale, int n_levels,
+                                   int32_t* match_idx, uint8_t* visible, int* n_matches);
+
+/* Replaces SnakeORBMatcher::SearchByProjectionFrameToKeyframe — Snake/Tracking/SnakeORBMatcher.cpp:71-188.
+ * positions / descriptors: mp->getPosition() / mp->GetDescriptor() of kf.GetMapPointMatches();
+ * skip[i] != 0 where the keyframe has no point or the frame already holds it (:102-103).
+ * Greedy and sequential like the reference: a feature given to point i is unavailable to i+1. */
+SNK_API int snk_match_project_keyframe(snk_matcher* m, const snk_frame_view* frame, const snk_camera* cam,
+                                       const double pose[7], const double (*positions)[3],
+                                       const uint64_t (*descriptors)[4], const uint8_t* skip, int n_pts, float th,
+                                       int feature_error, int32_t* match_idx, int* n_matches);
+
+/* ------------------------------------------------------------------------------------------
  * Local bundle adjustment
  * ------------------------------------------------------------------------------------------ */
 

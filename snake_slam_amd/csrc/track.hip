@@ -1,0 +1,661 @@
+// Feature grid and projection-guided matchers for gfx950 — replaces
+//   Preprocess::computeFeatureGrid / FeatureGrid2::create         (reference Snake/Preprocess/Preprocess.cpp:244-266)
+//   Features::GetFeaturesInArea*                                  (reference Snake/Map/Features.cpp:13-76)
+//   SnakeORBMatcher::SearchByProjectionFrameFrame2 (coarse)       (reference Snake/Tracking/SnakeORBMatcher.cpp:191-354)
+//   SnakeORBMatcher::SearchByProjection2 (fine)                   (reference Snake/Tracking/SnakeORBMatcher.cpp:365-526)
+//   SnakeORBMatcher::SearchByProjectionFrameToKeyframe            (reference Snake/Tracking/SnakeORBMatcher.cpp:71-188)
+//
+// Mapping to the hardware.  The grid orders features x-major by 20-px cell, so the candidates of a
+// search window are, per cell column, ONE contiguous index range — no per-point candidate vectors:
+// one wavefront per local-map point projects the point (all lanes redundantly, fp64), walks the
+// <= (2r/20 + 1) cell columns of its window, the lanes stride over each range, evaluate the gates +
+// the 256-bit Hamming distance and keep the two smallest packed keys dist << 20 | index (the
+// reference's "strict <, first candidate wins" order is ascending feature index), and a 6-step
+// xor-shuffle network merges them.  The reference's serial first-claimant-wins pass becomes an
+// integer atomicMin of the local-map index per claimed feature (order independent, deterministic).
+// The keyframe matcher is greedy-sequential by definition (a feature taken by point i is gone for
+// point i+1), so one wavefront walks the points in order with the taken mask in LDS.
+#include "matcher_handle.hpp"
+
+namespace snk
+{
+namespace
+{
+using u8  = unsigned char;
+using u32 = unsigned int;
+using u64 = unsigned long long;
+
+constexpr u32 PJ_IDX_BITS = 20;
+constexpr u32 PJ_IDX_MASK = (1u << PJ_IDX_BITS) - 1u;
+constexpr u32 PJ_INF_KEY  = (256u << PJ_IDX_BITS) | PJ_IDX_MASK;
+
+struct FrameDev
+{
+    int n, cols, rows;
+    const snk_kp64* kps;
+    const uint4* desc;
+    const float* right_points;
+    const u8* taken;
+    const int* cell_start;
+    double min_x, min_y, max_x, max_y;
+};
+
+struct CamDev
+{
+    double fx, fy, cx, cy, bf;
+    double R[9], t[3], campos[3];
+};
+
+struct ScalesDev
+{
+    float s[32];
+    int n;
+    double log_f, s_last;
+};
+
+__device__ __forceinline__ double det_log(double x)
+{
+    int e;
+    double m = frexp(x, &e);
+    if (m < 0.70710678118654752440)
+    {
+        m *= 2.0;
+        e -= 1;
+    }
+    const double z = (m - 1.0) / (m + 1.0), z2 = z * z;
+    double s = 1.0 / 21.0;
+#pragma unroll 1
+    for (int k = 19; k >= 1; k -= 2) s = s * z2 + 1.0 / (double)k;
+    return 2.0 * z * s + (double)e * 0.69314718055994530942;
+}
+
+__device__ __forceinline__ double det_exp(double y)
+{
+    const double k = floor(y * 1.44269504088896340736 + 0.5);
+    const double f = y - k * 0.69314718055994530942;
+    double s = 1.0;
+#pragma unroll 1
+    for (int n = 16; n >= 1; --n) s = 1.0 + s * f / (double)n;
+    return ldexp(s, (int)k);
+}
+
+__device__ __forceinline__ int cell_coord(double p, double lo, int n)
+{
+    const int c = (int)floor((p - lo) / 20.0);
+    return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
+
+__device__ __forceinline__ int hamming256(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1)
+{
+    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+           __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+__device__ __forceinline__ void split_desc(const uint64_t* d, uint4& a, uint4& c)
+{
+    a = make_uint4((u32)d[0], (u32)(d[0] >> 32), (u32)d[1], (u32)(d[1] >> 32));
+    c = make_uint4((u32)d[2], (u32)(d[2] >> 32), (u32)d[3], (u32)(d[3] >> 32));
+}
+
+__device__ __forceinline__ void insert2(u32& k1, u32& k2, u32 key)
+{
+    const u32 hi = k1 < key ? key : k1;
+    k1           = k1 < key ? k1 : key;
+    k2           = k2 < hi ? k2 : hi;
+}
+__device__ __forceinline__ void merge2(u32& k1, u32& k2, u32 o1, u32 o2)
+{
+    const u32 lo = k1 < o1 ? k1 : o1, hi = k1 < o1 ? o1 : k1, m = k2 < o2 ? k2 : o2;
+    k2 = hi < m ? hi : m;
+    k1 = lo;
+}
+
+// Candidate scan of one search window by one wavefront.  MODE 0: radius only; 1: octave window;
+// 2: predicted scale.  `taken` may point to LDS (keyframe matcher) or global memory.
+template <int MODE>
+__device__ __forceinline__ void scan_window(const FrameDev& F, const u8* taken, double ipx, double ipy, double z, double bf,
+                                            double r, double r2, int min_oct, int max_oct, double pred, const uint4& qa,
+                                            const uint4& qc, int lane, u32& k1, u32& k2)
+{
+    const int cx0 = cell_coord(ipx - r, F.min_x, F.cols), cx1 = cell_coord(ipx + r, F.min_x, F.cols);
+    const int cy0 = cell_coord(ipy - r, F.min_y, F.rows), cy1 = cell_coord(ipy + r, F.min_y, F.rows);
+    const double disp = ipx - bf / z;
+    for (int cx = cx0; cx <= cx1; ++cx)
+    {
+        const int lo = F.cell_start[cx * F.rows + cy0], hi = F.cell_start[cx * F.rows + cy1 + 1];
+        for (int pid = lo + lane; pid < hi; pid += 64)
+        {
+            const snk_kp64 kp = F.kps[pid];
+            if (MODE == 1 && (kp.octave < min_oct || kp.octave > max_oct)) continue;
+            if (MODE == 2 && fabs(pred - (double)kp.octave) > 1.0) continue;
+            const double dx = kp.x - ipx, dy = kp.y - ipy;
+            if (!(dx * dx + dy * dy < r2)) continue;
+            if (taken[pid]) continue;
+            const float rp = F.right_points[pid];
+            if (rp > 0)
+            {
+                double er = fabs(disp - (double)rp);
+                if (MODE == 0) er = (double)(float)er;  // `const float er` in SearchByProjectionFrameToKeyframe
+                if (er > r * 0.5) continue;
+            }
+            const uint4 ta = F.desc[(size_t)pid * 2], tc = F.desc[(size_t)pid * 2 + 1];
+            const u32 d    = (u32)hamming256(qa, qc, ta, tc);
+            if (d < 256u) insert2(k1, k2, (d << PJ_IDX_BITS) | (u32)pid);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+    {
+        const u32 o1 = __shfl_xor(k1, off), o2 = __shfl_xor(k2, off);
+        merge2(k1, k2, o1, o2);
+    }
+}
+
+// coarse: best[i] = feature index or -1, bins[i] = rotation bin
+__global__ __launch_bounds__(256) void coarse_kernel(FrameDev F, CamDev C, ScalesDev S, const snk_lm_coarse* __restrict__ pts,
+                                                     int m, float th, int feature_error, int direction,
+                                                     int* __restrict__ best, int* __restrict__ bins)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= m) return;
+    const snk_lm_coarse lmp = pts[i];
+    int result = -1, bin = 0;
+    const double pcx = C.R[0] * lmp.pos[0] + C.R[1] * lmp.pos[1] + C.R[2] * lmp.pos[2] + C.t[0];
+    const double pcy = C.R[3] * lmp.pos[0] + C.R[4] * lmp.pos[1] + C.R[5] * lmp.pos[2] + C.t[1];
+    const double z   = C.R[6] * lmp.pos[0] + C.R[7] * lmp.pos[1] + C.R[8] * lmp.pos[2] + C.t[2];
+    const double ipx = C.fx * pcx / z + C.cx, ipy = C.fy * pcy / z + C.cy;
+    bool ok = z > 0 && ipx >= F.min_x && ipx < F.max_x && ipy >= F.min_y && ipy < F.max_y;
+    if (ok)
+    {
+        const double POx = C.campos[0] - lmp.pos[0], POy = C.campos[1] - lmp.pos[1], POz = C.campos[2] - lmp.pos[2];
+        const double dist    = sqrt(POx * POx + POy * POy + POz * POz);
+        const double viewCos = (POx * lmp.normal[0] + POy * lmp.normal[1] + POz * lmp.normal[2]) / dist;
+        ok = !(viewCos < 0.5);
+    }
+    if (ok)
+    {
+        int lvl = lmp.octave;
+        lvl     = lvl < 0 ? 0 : (lvl >= S.n ? S.n - 1 : lvl);
+        float r = th;
+        r *= S.s[lvl];
+        int mn, mx;
+        if (direction == 1) { mn = lmp.octave - 1; mx = 100; }
+        else if (direction == 2) { mn = 0; mx = lmp.octave; }
+        else { mn = lmp.octave - 1; mx = lmp.octave + 1; }
+        uint4 qa, qc;
+        split_desc(lmp.desc, qa, qc);
+        u32 k1 = PJ_INF_KEY, k2 = PJ_INF_KEY;
+        scan_window<1>(F, F.taken, ipx, ipy, z, C.bf, (double)r, (double)r * (double)r, mn, mx, 0.0, qa, qc, lane, k1, k2);
+        const int bd = (int)(k1 >> PJ_IDX_BITS);
+        if (bd <= feature_error && k1 != PJ_INF_KEY)
+        {
+            result    = (int)(k1 & PJ_IDX_MASK);
+            float rot = lmp.angle - F.kps[result].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            bin = (int)roundf(rot * (1.0f / 30));
+            if (bin == 30) bin = 0;
+        }
+    }
+    if (lane == 0)
+    {
+        best[i] = result;
+        bins[i] = bin;
+    }
+}
+
+__global__ __launch_bounds__(256) void fine_kernel(FrameDev F, CamDev C, ScalesDev S, snk_lm_fine* __restrict__ pts, int m,
+                                                   float th, float ratio, int* __restrict__ best, u8* __restrict__ visible)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= m) return;
+    const snk_lm_fine lmp = pts[i];
+    int result = -1;
+    u8 vis = 0, valid = lmp.valid;
+    if (valid)
+    {
+        const double pcx = C.R[0] * lmp.pos[0] + C.R[1] * lmp.pos[1] + C.R[2] * lmp.pos[2] + C.t[0];
+        const double pcy = C.R[3] * lmp.pos[0] + C.R[4] * lmp.pos[1] + C.R[5] * lmp.pos[2] + C.t[1];
+        const double z   = C.R[6] * lmp.pos[0] + C.R[7] * lmp.pos[1] + C.R[8] * lmp.pos[2] + C.t[2];
+        const double ipx = C.fx * pcx / z + C.cx, ipy = C.fy * pcy / z + C.cy;
+        if (z < 0 || !(ipx >= F.min_x && ipx < F.max_x && ipy >= F.min_y && ipy < F.max_y))
+            valid = 0;
+        else
+        {
+            const double POx = C.campos[0] - lmp.pos[0], POy = C.campos[1] - lmp.pos[1], POz = C.campos[2] - lmp.pos[2];
+            const double dist = sqrt(POx * POx + POy * POy + POz * POz);
+            int rl            = lmp.reference_scale_level;
+            rl                = rl < 0 ? 0 : (rl >= S.n ? S.n - 1 : rl);
+            const double sref = (double)S.s[rl];
+            const double max_dist = 1.2 * (double)lmp.reference_depth * sref;
+            const double min_dist = 0.8 * (double)lmp.reference_depth * sref / S.s_last;
+            const double viewCos  = (POx * lmp.normal[0] + POy * lmp.normal[1] + POz * lmp.normal[2]) / dist;
+            if (dist < min_dist || dist > max_dist || viewCos < 0.5)
+                valid = 0;
+            else
+            {
+                vis = 1;
+                const float vcf = (float)viewCos;
+                float r         = (double)vcf > 0.998 ? 2.5f : 4.0f;
+                if (th != 1.0f) r *= th;
+                double prediction = (double)lmp.reference_scale_level + det_log((double)lmp.reference_depth / dist) / S.log_f;
+                if (prediction < 0.0) prediction = 0.0;
+                if (prediction > (double)(S.n - 1)) prediction = (double)(S.n - 1);
+                r = (float)((double)r * det_exp(prediction * S.log_f));
+                uint4 qa, qc;
+                split_desc(lmp.desc, qa, qc);
+                u32 k1 = PJ_INF_KEY, k2 = PJ_INF_KEY;
+                scan_window<2>(F, F.taken, ipx, ipy, z, C.bf, (double)r, (double)r * (double)r, 0, 0, prediction, qa, qc, lane, k1,
+                               k2);
+                const int bd = (int)(k1 >> PJ_IDX_BITS);
+                if (k1 != PJ_INF_KEY && bd <= 100)
+                {
+                    const int bi  = (int)(k1 & PJ_IDX_MASK);
+                    const int bd2 = (int)(k2 >> PJ_IDX_BITS);
+                    const int l1  = F.kps[bi].octave;
+                    const int l2  = k2 != PJ_INF_KEY ? F.kps[k2 & PJ_IDX_MASK].octave : -1;
+                    if (!(l1 == l2 && (float)bd > ratio * (float)bd2)) result = bi;
+                }
+            }
+        }
+    }
+    if (lane == 0)
+    {
+        best[i]      = result;
+        visible[i]   = vis;
+        pts[i].valid = valid;
+    }
+}
+
+// first claimant (lowest local-map index) of every feature wins; coarse additionally applies the
+// rotation-histogram filter.  One workgroup.
+__global__ __launch_bounds__(256) void resolve_kernel(const int* __restrict__ best, const int* __restrict__ bins, int m,
+                                                      const u8* __restrict__ taken, int* __restrict__ claim, int n_feat,
+                                                      int with_rotation, int* __restrict__ match_idx, int* __restrict__ n_out)
+{
+    __shared__ int hist[30];
+    __shared__ int keep[3];
+    __shared__ int count;
+    const int tid = threadIdx.x;
+    if (tid < 30) hist[tid] = 0;
+    if (tid == 0) count = 0;
+    for (int f = tid; f < n_feat; f += 256) claim[f] = 0x7FFFFFFF;
+    __syncthreads();
+    for (int i = tid; i < m; i += 256)
+    {
+        const int b = best[i];
+        if (b >= 0 && !taken[b]) atomicMin(&claim[b], i);
+    }
+    __syncthreads();
+    for (int i = tid; i < m; i += 256)
+    {
+        const int b   = best[i];
+        const bool win = b >= 0 && !taken[b] && claim[b] == i;
+        match_idx[i]   = win ? b : -1;
+        if (win && with_rotation) atomicAdd(&hist[bins[i]], 1);
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        if (with_rotation)
+        {
+            int max1 = 0, max2 = 0, max3 = 0;  // ComputeThreeMaxima, SnakeORBMatcher.cpp:27-68
+            for (int k = 0; k < 30; k++)
+            {
+                const int s = hist[k];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = k; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = k; }
+                else if (s > max3) { max3 = s; ind3 = k; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        }
+        keep[0] = ind1;
+        keep[1] = ind2;
+        keep[2] = ind3;
+    }
+    __syncthreads();
+    int local = 0;
+    for (int i = tid; i < m; i += 256)
+    {
+        int v = match_idx[i];
+        if (v >= 0 && with_rotation)
+        {
+            const int b = bins[i];
+            if (b != keep[0] && b != keep[1] && b != keep[2])
+            {
+                v            = -1;
+                match_idx[i] = -1;
+            }
+        }
+        local += v >= 0 ? 1 : 0;
+    }
+    atomicAdd(&count, local);
+    __syncthreads();
+    if (tid == 0) *n_out = count;
+}
+
+// greedy sequential keyframe matcher: one wavefront, taken mask in LDS
+constexpr int KF_MAX_FEATURES = 49152;
+__global__ __launch_bounds__(64) void keyframe_kernel(FrameDev F, CamDev C, const double* __restrict__ pos,
+                                                      const uint4* __restrict__ desc, const u8* __restrict__ skip, int m,
+                                                      float th, int feature_error, int* __restrict__ match_idx,
+                                                      int* __restrict__ n_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char taken2[];
+    const int lane = threadIdx.x;
+    for (int f = lane; f < F.n; f += 64) taken2[f] = F.taken[f];
+    __builtin_amdgcn_wave_barrier();
+    int matches = 0;
+    const double r = (double)th, r2 = (double)(th * th);
+    for (int i = 0; i < m; ++i)
+    {
+        int result = -1;
+        if (!skip[i])
+        {
+            const double* p  = pos + (size_t)i * 3;
+            const double pcx = C.R[0] * p[0] + C.R[1] * p[1] + C.R[2] * p[2] + C.t[0];
+            const double pcy = C.R[3] * p[0] + C.R[4] * p[1] + C.R[5] * p[2] + C.t[1];
+            const double z   = C.R[6] * p[0] + C.R[7] * p[1] + C.R[8] * p[2] + C.t[2];
+            const double ipx = C.fx * pcx / z + C.cx, ipy = C.fy * pcy / z + C.cy;
+            if (z > 0 && ipx >= F.min_x && ipx < F.max_x && ipy >= F.min_y && ipy < F.max_y)
+            {
+                const uint4 qa = desc[(size_t)i * 2], qc = desc[(size_t)i * 2 + 1];
+                u32 k1 = PJ_INF_KEY, k2 = PJ_INF_KEY;
+                scan_window<0>(F, taken2, ipx, ipy, z, C.bf, r, r2, 0, 0, 0.0, qa, qc, lane, k1, k2);
+                if (k1 != PJ_INF_KEY && (int)(k1 >> PJ_IDX_BITS) <= feature_error) result = (int)(k1 & PJ_IDX_MASK);
+            }
+        }
+        if (result >= 0)
+        {
+            if (lane == 0) taken2[result] = 1;
+            matches++;
+        }
+        if (lane == 0) match_idx[i] = result;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) *n_out = matches;
+}
+
+// ---- feature grid: sort (cell << 16 | index) in LDS, derive the permutation and the cell ranges ----
+__global__ __launch_bounds__(256) void grid_kernel(const snk_kp64* __restrict__ kps, int n, double min_x, double min_y, int cols,
+                                                   int rows, int n_pow2, int* __restrict__ perm, int* __restrict__ cell_start)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+    u32* keys     = reinterpret_cast<u32*>(gsm);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n_pow2; i += 256)
+    {
+        u32 k = 0xFFFFFFFFu;
+        if (i < n)
+        {
+            const snk_kp64 kp = kps[i];
+            const int cell    = cell_coord(kp.x, min_x, cols) * rows + cell_coord(kp.y, min_y, rows);
+            k                 = ((u32)cell << 16) | (u32)i;
+        }
+        keys[i] = k;
+    }
+    __syncthreads();
+    for (int k = 2; k <= n_pow2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1)
+        {
+            for (int t = tid; t < (n_pow2 >> 1); t += 256)
+            {
+                const int i   = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int ixj = i | j;
+                const bool up = (i & k) == 0;
+                const u32 x = keys[i], y = keys[ixj];
+                if ((x > y) == up)
+                {
+                    keys[i]   = y;
+                    keys[ixj] = x;
+                }
+            }
+            __syncthreads();
+        }
+    const int ncell = cols * rows;
+    for (int p = tid; p < n; p += 256)
+    {
+        const u32 k   = keys[p];
+        perm[k & 0xFFFFu] = p;
+        const int c   = (int)(k >> 16);
+        const int cp  = p == 0 ? -1 : (int)(keys[p - 1] >> 16);
+        for (int q = cp + 1; q <= c; ++q) cell_start[q] = p;  // first feature of cell c (and of the empty cells before it)
+    }
+    const int last = n == 0 ? -1 : (int)(keys[n - 1] >> 16);
+    for (int q = last + 1 + tid; q <= ncell; q += 256) cell_start[q] = n;
+}
+
+int make_cam(const snk_camera* cam, const double* pose, CamDev* c)
+{
+    SNK_REQUIRE(cam != nullptr && pose != nullptr, "camera / pose is NULL");
+    c->fx = cam->fx; c->fy = cam->fy; c->cx = cam->cx; c->cy = cam->cy; c->bf = cam->bf;
+    const double x = pose[0], y = pose[1], z = pose[2], w = pose[3];
+    double* R = c->R;
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
+    R[3] = 2 * (x * y + z * w);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+    R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
+    c->t[0] = pose[4]; c->t[1] = pose[5]; c->t[2] = pose[6];
+    c->campos[0] = -(R[0] * c->t[0] + R[3] * c->t[1] + R[6] * c->t[2]);
+    c->campos[1] = -(R[1] * c->t[0] + R[4] * c->t[1] + R[7] * c->t[2]);
+    c->campos[2] = -(R[2] * c->t[0] + R[5] * c->t[1] + R[8] * c->t[2]);
+    return SNK_OK;
+}
+
+// series evaluated on the host exactly like det_log (same operation order, no FMA)
+double host_det_log(double x)
+{
+    int e;
+    double m = frexp(x, &e);
+    if (m < 0.70710678118654752440)
+    {
+        m *= 2.0;
+        e -= 1;
+    }
+    const double z = (m - 1.0) / (m + 1.0), z2 = z * z;
+    double s = 1.0 / 21.0;
+    for (int k = 19; k >= 1; k -= 2) s = s * z2 + 1.0 / (double)k;
+    return 2.0 * z * s + (double)e * 0.69314718055994530942;
+}
+
+int make_scales(const float* level_scale, int n_levels, ScalesDev* s)
+{
+    SNK_REQUIRE(level_scale != nullptr && n_levels >= 1 && n_levels <= 32, "level_scale / n_levels (1..32)");
+    for (int i = 0; i < 32; ++i) s->s[i] = i < n_levels ? level_scale[i] : level_scale[n_levels - 1];
+    s->n      = n_levels;
+    s->log_f  = host_det_log(n_levels > 1 ? (double)level_scale[1] / (double)level_scale[0] : 1.2);
+    s->s_last = (double)level_scale[n_levels - 1];
+    return SNK_OK;
+}
+
+void grid_dims(const snk_grid_bounds* b, int* cols, int* rows)
+{
+    int c = (int)ceil((b->max_x - b->min_x) / 20.0), r = (int)ceil((b->max_y - b->min_y) / 20.0);
+    *cols = c < 1 ? 1 : c;
+    *rows = r < 1 ? 1 : r;
+}
+
+// upload a host frame view into the handle's scratch; returns the device view
+int upload_frame(snk_matcher* m, const snk_frame_view* f, FrameDev* F)
+{
+    SNK_REQUIRE(f != nullptr, "frame view is NULL");
+    SNK_REQUIRE(f->n >= 0 && f->n < (int)PJ_IDX_MASK && f->cols >= 1 && f->rows >= 1, "bad frame view sizes");
+    SNK_REQUIRE(f->n == 0 || (f->kps && f->desc && f->right_points && f->taken), "NULL frame arrays");
+    SNK_REQUIRE(f->cell_start != nullptr, "cell_start is NULL");
+    const size_t n = (size_t)f->n, nc = (size_t)f->cols * f->rows + 1;
+    const size_t o_desc = (n * sizeof(snk_kp64) + 15) & ~(size_t)15, o_rp = o_desc + n * 32, o_tk = o_rp + n * 4,
+                 o_cs = (o_tk + n + 15) & ~(size_t)15, total = o_cs + nc * 4;
+    int rc = m->aux.reserve(total + 16);
+    if (rc != SNK_OK) return rc;
+    char* d = m->aux.as<char>();
+    if (n)
+    {
+        SNK_HIP_CHECK(hipMemcpyAsync(d, f->kps, n * sizeof(snk_kp64), hipMemcpyHostToDevice, m->stream));
+        SNK_HIP_CHECK(hipMemcpyAsync(d + o_desc, f->desc, n * 32, hipMemcpyHostToDevice, m->stream));
+        SNK_HIP_CHECK(hipMemcpyAsync(d + o_rp, f->right_points, n * 4, hipMemcpyHostToDevice, m->stream));
+        SNK_HIP_CHECK(hipMemcpyAsync(d + o_tk, f->taken, n, hipMemcpyHostToDevice, m->stream));
+    }
+    SNK_HIP_CHECK(hipMemcpyAsync(d + o_cs, f->cell_start, nc * 4, hipMemcpyHostToDevice, m->stream));
+    F->n = f->n; F->cols = f->cols; F->rows = f->rows;
+    F->kps          = reinterpret_cast<const snk_kp64*>(d);
+    F->desc         = reinterpret_cast<const uint4*>(d + o_desc);
+    F->right_points = reinterpret_cast<const float*>(d + o_rp);
+    F->taken        = reinterpret_cast<const u8*>(d + o_tk);
+    F->cell_start   = reinterpret_cast<const int*>(d + o_cs);
+    F->min_x = f->bounds.min_x; F->min_y = f->bounds.min_y; F->max_x = f->bounds.max_x; F->max_y = f->bounds.max_y;
+    return SNK_OK;
+}
+}  // namespace
+}  // namespace snk
+
+using namespace snk;
+
+extern "C" {
+
+int snk_feature_grid(snk_matcher* m, const snk_kp64* undistorted, int n, const snk_grid_bounds* bounds, int32_t* perm,
+                     int32_t* cell_start, int* cols_out, int* rows_out)
+{
+    SNK_REQUIRE(m != nullptr && bounds != nullptr && cell_start != nullptr, "NULL argument");
+    SNK_REQUIRE(n >= 0 && n <= 16384, "feature count must be 0..16384");
+    SNK_REQUIRE(n == 0 || (undistorted && perm), "NULL buffer");
+    int cols, rows;
+    grid_dims(bounds, &cols, &rows);
+    SNK_REQUIRE((long long)cols * rows < 65535, "grid too large");
+    if (cols_out) *cols_out = cols;
+    if (rows_out) *rows_out = rows;
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    const size_t nc = (size_t)cols * rows + 1;
+    int rc;
+    if ((rc = m->aux.reserve((size_t)(n > 0 ? n : 1) * sizeof(snk_kp64))) != SNK_OK) return rc;
+    if ((rc = m->aux2.reserve((size_t)(n > 0 ? n : 1) * 4 + nc * 4)) != SNK_OK) return rc;
+    int n_pow2 = 1;
+    while (n_pow2 < n) n_pow2 <<= 1;
+    if (n_pow2 < 2) n_pow2 = 2;
+    int* d_perm = m->aux2.as<int>();
+    int* d_cs   = d_perm + (n > 0 ? n : 1);
+    if (n) SNK_HIP_CHECK(hipMemcpyAsync(m->aux.p, undistorted, (size_t)n * sizeof(snk_kp64), hipMemcpyHostToDevice, m->stream));
+    SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      16384 * 4));
+    hipLaunchKernelGGL(grid_kernel, dim3(1), dim3(256), (size_t)n_pow2 * 4, m->stream, m->aux.as<snk_kp64>(), n, bounds->min_x,
+                       bounds->min_y, cols, rows, n_pow2, d_perm, d_cs);
+    SNK_LAUNCH_CHECK();
+    if (n) SNK_HIP_CHECK(hipMemcpyAsync(perm, d_perm, (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(cell_start, d_cs, nc * 4, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return SNK_OK;
+}
+
+int snk_match_project_coarse(snk_matcher* m, const snk_frame_view* frame, const snk_camera* cam, const double pose[7],
+                             const snk_lm_coarse* pts, int n_pts, float th, int feature_error, int direction,
+                             const float* level_scale, int n_levels, int32_t* match_idx, int* n_matches)
+{
+    SNK_REQUIRE(m != nullptr && n_matches != nullptr, "NULL argument");
+    *n_matches = 0;
+    SNK_REQUIRE(n_pts >= 0 && (n_pts == 0 || (pts && match_idx)), "bad point arrays");
+    SNK_REQUIRE(direction >= 0 && direction <= 2, "direction must be 0 (none), 1 (forward) or 2 (backward)");
+    CamDev C;
+    ScalesDev S;
+    FrameDev F;
+    int rc;
+    if ((rc = make_cam(cam, pose, &C)) != SNK_OK) return rc;
+    if ((rc = make_scales(level_scale, n_levels, &S)) != SNK_OK) return rc;
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    if ((rc = upload_frame(m, frame, &F)) != SNK_OK) return rc;
+    if (n_pts == 0) return SNK_OK;
+    const size_t np = (size_t)n_pts;
+    // q: points | out: best, bins, match | t: claim | cnt: count
+    if ((rc = m->q.reserve(np * sizeof(snk_lm_coarse))) != SNK_OK) return rc;
+    if ((rc = m->out.reserve(np * 12)) != SNK_OK) return rc;
+    if ((rc = m->t.reserve((size_t)(F.n > 0 ? F.n : 1) * 4)) != SNK_OK) return rc;
+    if ((rc = m->cnt.reserve(64)) != SNK_OK) return rc;
+    int* d_best = m->out.as<int>();
+    int* d_bins = d_best + np;
+    int* d_match = d_bins + np;
+    SNK_HIP_CHECK(hipMemcpyAsync(m->q.p, pts, np * sizeof(snk_lm_coarse), hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(coarse_kernel, dim3(ceil_div(n_pts, 4)), dim3(256), 0, m->stream, F, C, S, m->q.as<snk_lm_coarse>(), n_pts,
+                       th, feature_error, direction, d_best, d_bins);
+    hipLaunchKernelGGL(resolve_kernel, dim3(1), dim3(256), 0, m->stream, d_best, d_bins, n_pts, F.taken, m->t.as<int>(), F.n, 1,
+                       d_match, m->cnt.as<int>());
+    SNK_LAUNCH_CHECK();
+    SNK_HIP_CHECK(hipMemcpyAsync(match_idx, d_match, np * 4, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(n_matches, m->cnt.p, 4, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return SNK_OK;
+}
+
+int snk_match_project_fine(snk_matcher* m, const snk_frame_view* frame, const snk_camera* cam, const double pose[7],
+                           snk_lm_fine* pts, int n_pts, float th, float ratio, const float* level_scale, int n_levels,
+                           int32_t* match_idx, uint8_t* visible, int* n_matches)
+{
+    SNK_REQUIRE(m != nullptr && n_matches != nullptr, "NULL argument");
+    *n_matches = 0;
+    SNK_REQUIRE(n_pts >= 0 && (n_pts == 0 || (pts && match_idx && visible)), "bad point arrays");
+    CamDev C;
+    ScalesDev S;
+    FrameDev F;
+    int rc;
+    if ((rc = make_cam(cam, pose, &C)) != SNK_OK) return rc;
+    if ((rc = make_scales(level_scale, n_levels, &S)) != SNK_OK) return rc;
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    if ((rc = upload_frame(m, frame, &F)) != SNK_OK) return rc;
+    if (n_pts == 0) return SNK_OK;
+    const size_t np = (size_t)n_pts;
+    if ((rc = m->q.reserve(np * sizeof(snk_lm_fine))) != SNK_OK) return rc;
+    if ((rc = m->out.reserve(np * 12 + np)) != SNK_OK) return rc;
+    if ((rc = m->t.reserve((size_t)(F.n > 0 ? F.n : 1) * 4)) != SNK_OK) return rc;
+    if ((rc = m->cnt.reserve(64)) != SNK_OK) return rc;
+    int* d_best  = m->out.as<int>();
+    int* d_match = d_best + np;
+    u8* d_vis    = reinterpret_cast<u8*>(d_match + np);
+    SNK_HIP_CHECK(hipMemcpyAsync(m->q.p, pts, np * sizeof(snk_lm_fine), hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(fine_kernel, dim3(ceil_div(n_pts, 4)), dim3(256), 0, m->stream, F, C, S, m->q.as<snk_lm_fine>(), n_pts, th,
+                       ratio, d_best, d_vis);
+    hipLaunchKernelGGL(resolve_kernel, dim3(1), dim3(256), 0, m->stream, d_best, (const int*)nullptr, n_pts, F.taken,
+                       m->t.as<int>(), F.n, 0, d_match, m->cnt.as<int>());
+    SNK_LAUNCH_CHECK();
+    SNK_HIP_CHECK(hipMemcpyAsync(match_idx, d_match, np * 4, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(visible, d_vis, np, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(pts, m->q.p, np * sizeof(snk_lm_fine), hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(n_matches, m->cnt.p, 4, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return SNK_OK;
+}
+
+int snk_match_project_keyframe(snk_matcher* m, const snk_frame_view* frame, const snk_camera* cam, const double pose[7],
+                               const double (*positions)[3], const uint64_t (*descriptors)[4], const uint8_t* skip, int n_pts,
+                               float th, int feature_error, int32_t* match_idx, int* n_matches)
+{
+    SNK_REQUIRE(m != nullptr && n_matches != nullptr, "NULL argument");
+    *n_matches = 0;
+    SNK_REQUIRE(n_pts >= 0 && (n_pts == 0 || (positions && descriptors && skip && match_idx)), "bad point arrays");
+    CamDev C;
+    FrameDev F;
+    int rc;
+    if ((rc = make_cam(cam, pose, &C)) != SNK_OK) return rc;
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    if ((rc = upload_frame(m, frame, &F)) != SNK_OK) return rc;
+    SNK_REQUIRE(F.n <= KF_MAX_FEATURES, "too many features for the keyframe matcher");
+    if (n_pts == 0) return SNK_OK;
+    const size_t np = (size_t)n_pts;
+    const size_t o_desc = np * 24, o_skip = o_desc + np * 32, total = o_skip + np;
+    if ((rc = m->q.reserve(total)) != SNK_OK) return rc;
+    if ((rc = m->out.reserve(np * 4)) != SNK_OK) return rc;
+    if ((rc = m->cnt.reserve(64)) != SNK_OK) return rc;
+    char* d = m->q.as<char>();
+    SNK_HIP_CHECK(hipMemcpyAsync(d, positions, np * 24, hipMemcpyHostToDevice, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(d + o_desc, descriptors, np * 32, hipMemcpyHostToDevice, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(d + o_skip, skip, np, hipMemcpyHostToDevice, m->stream));
+    SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(keyframe_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, KF_MAX_FEATURES));
+    hipLaunchKernelGGL(keyframe_kernel, dim3(1), dim3(64), (size_t)((F.n + 15) & ~15) + 16, m->stream, F, C,
+                       reinterpret_cast<const double*>(d), reinterpret_cast<const uint4*>(d + o_desc),
+                       reinterpret_cast<const u8*>(d + o_skip), n_pts, th, feature_error, m->out.as<int>(), m->cnt.as<int>());
+    SNK_LAUNCH_CHECK();
+    SNK_HIP_CHECK(hipMemcpyAsync(match_idx, m->out.p, np * 4, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(n_matches, m->cnt.p, 4, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return SNK_OK;
+}
+}

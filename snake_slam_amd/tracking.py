@@ -1,0 +1,102 @@
+"""Host-side mirror of the tracking matcher interface over the C ABI.
+
+``SnakeORBMatcher`` mirrors ``Snake::SnakeORBMatcher`` (reference Snake/Tracking/SnakeORBMatcher.h:21-30)
+with the frame passed as a view (the SoA fields of Snake/Map/Features.h + the taken mask) and
+``FeatureGrid.create`` mirrors ``frame.grid.create`` (reference Snake/Preprocess/Preprocess.cpp:246).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .matcher import KP64_DTYPE, _Handle, _ptr
+
+LM_COARSE_DTYPE = np.dtype([("pos", "<f8", 3), ("normal", "<f8", 3), ("desc", "<u8", 4), ("octave", "<i4"), ("angle", "<f4")])
+LM_FINE_DTYPE = np.dtype([("pos", "<f8", 3), ("normal", "<f8", 3), ("desc", "<u8", 4), ("reference_depth", "<f4"),
+                          ("reference_scale_level", "<i4"), ("valid", "u1"), ("pad", "u1", 7)])
+
+
+class GridBounds(C.Structure):
+    _fields_ = [("min_x", C.c_double), ("min_y", C.c_double), ("max_x", C.c_double), ("max_y", C.c_double)]
+
+
+class FrameView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("cols", C.c_int32), ("rows", C.c_int32), ("kps", C.c_void_p), ("desc", C.c_void_p),
+                ("right_points", C.c_void_p), ("taken", C.c_void_p), ("cell_start", C.c_void_p), ("bounds", GridBounds)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double)]
+
+
+def _view(frame):
+    a = {"kps": np.ascontiguousarray(frame["kps"], KP64_DTYPE), "desc": np.ascontiguousarray(frame["desc"], np.uint64),
+         "right_points": np.ascontiguousarray(frame["right_points"], np.float32),
+         "taken": np.ascontiguousarray(frame["taken"], np.uint8), "cell_start": np.ascontiguousarray(frame["cell_start"], np.int32)}
+    v = FrameView()
+    v.n, v.cols, v.rows = len(a["kps"]), int(frame["cols"]), int(frame["rows"])
+    for k, arr in a.items():
+        setattr(v, k, arr.ctypes.data if arr.size else 0)
+    v.bounds = GridBounds(*frame["bounds"])
+    return v, a
+
+
+class FeatureGrid(_Handle):
+    def create(self, bounds, undistorted_keypoints):
+        """Returns (perm, cell_start, cols, rows); perm[i] = new index of feature i."""
+        k = np.ascontiguousarray(undistorted_keypoints, KP64_DTYPE)
+        b = GridBounds(*bounds)
+        cols, rows = C.c_int(), C.c_int()
+        nc = (int(np.ceil((b.max_x - b.min_x) / 20.0)) or 1) * (int(np.ceil((b.max_y - b.min_y) / 20.0)) or 1)
+        perm = np.zeros(max(len(k), 1), np.int32)
+        cs = np.zeros(nc + 1, np.int32)
+        _lib.check(self._lib.snk_feature_grid(self._h, _ptr(k), len(k), C.byref(b), _ptr(perm), _ptr(cs), C.byref(cols),
+                                              C.byref(rows)), "snk_feature_grid")
+        return perm[: len(k)], cs, cols.value, rows.value
+
+
+class SnakeORBMatcher(_Handle):
+    def SearchByProjectionFrameFrame2(self, frame, cam, pose, lm_points, th, feature_error, direction, level_scale):
+        """Coarse tracking match.  Returns (matches, match_idx[m])."""
+        v, keep = _view(frame)
+        pts = np.ascontiguousarray(lm_points, LM_COARSE_DTYPE)
+        ls = np.ascontiguousarray(level_scale, np.float32)
+        pose = np.ascontiguousarray(pose, np.float64)
+        out = np.full(max(len(pts), 1), -1, np.int32)
+        n = C.c_int(0)
+        c = Camera(*cam)
+        _lib.check(self._lib.snk_match_project_coarse(self._h, C.byref(v), C.byref(c), _ptr(pose), _ptr(pts), len(pts), float(th),
+                                                      int(feature_error), int(direction), _ptr(ls), len(ls), _ptr(out),
+                                                      C.byref(n)), "snk_match_project_coarse")
+        return n.value, out[: len(pts)]
+
+    def SearchByProjection2(self, frame, cam, pose, lm_points, th, ratio, level_scale):
+        """Fine tracking match.  Returns (matches, match_idx[m], visible[m], valid[m])."""
+        v, keep = _view(frame)
+        pts = np.array(lm_points, LM_FINE_DTYPE, order="C")
+        ls = np.ascontiguousarray(level_scale, np.float32)
+        pose = np.ascontiguousarray(pose, np.float64)
+        out = np.full(max(len(pts), 1), -1, np.int32)
+        vis = np.zeros(max(len(pts), 1), np.uint8)
+        n = C.c_int(0)
+        c = Camera(*cam)
+        _lib.check(self._lib.snk_match_project_fine(self._h, C.byref(v), C.byref(c), _ptr(pose), _ptr(pts), len(pts), float(th),
+                                                    float(ratio), _ptr(ls), len(ls), _ptr(out), _ptr(vis), C.byref(n)),
+                   "snk_match_project_fine")
+        return n.value, out[: len(pts)], vis[: len(pts)], pts["valid"].copy()
+
+    def SearchByProjectionFrameToKeyframe(self, frame, cam, pose, positions, descriptors, skip, th, feature_error):
+        v, keep = _view(frame)
+        pos = np.ascontiguousarray(positions, np.float64).reshape(-1, 3)
+        desc = np.ascontiguousarray(descriptors, np.uint64).reshape(-1, 4)
+        sk = np.ascontiguousarray(skip, np.uint8)
+        pose = np.ascontiguousarray(pose, np.float64)
+        out = np.full(max(len(pos), 1), -1, np.int32)
+        n = C.c_int(0)
+        c = Camera(*cam)
+        _lib.check(self._lib.snk_match_project_keyframe(self._h, C.byref(v), C.byref(c), _ptr(pose), _ptr(pos), _ptr(desc),
+                                                        _ptr(sk), len(pos), float(th), int(feature_error), _ptr(out), C.byref(n)),
+                   "snk_match_project_keyframe")
+        return n.value, out[: len(pos)]

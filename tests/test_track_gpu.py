@@ -1,0 +1,80 @@
+"""GPU: feature grid and projection matchers vs the oracle through the C ABI — bit-exact indices."""
+import numpy as np
+import pytest
+
+import track_helpers as T
+from helpers import SEED
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def matcher():
+    from snake_slam_amd.tracking import SnakeORBMatcher
+
+    m = SnakeORBMatcher(0)
+    yield m
+    m.close()
+
+
+def test_feature_grid_parity(orc):
+    from snake_slam_amd.tracking import FeatureGrid
+
+    g = FeatureGrid(0)
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 2, 777, 1500, 4097):
+        kps = np.zeros(n, orc.KP64)
+        kps["x"] = rng.uniform(T.BOUNDS[0] - 5, T.BOUNDS[2] + 5, n)
+        kps["y"] = rng.uniform(T.BOUNDS[1] - 5, T.BOUNDS[3] + 5, n)
+        if n > 10:
+            kps["x"][5:9] = kps["x"][4]  # several features in one cell
+            kps["y"][5:9] = kps["y"][4]
+        perm, cs, cols, rows = g.create(T.BOUNDS, kps)
+        wperm, wcs, wcols, wrows = orc.feature_grid(kps, T.BOUNDS)
+        assert (cols, rows) == (wcols, wrows)
+        assert np.array_equal(perm, wperm) and np.array_equal(cs, wcs)
+    g.close()
+
+
+@pytest.mark.parametrize("seed,direction,th,fe", [(1, 0, 15.0, 75), (2, 1, 10.0, 75), (3, 2, 15.0, 75), (4, 0, 30.0, 100), (5, 0, 10.0, 50)])
+def test_coarse_parity(orc, matcher, seed, direction, th, fe):
+    rng = np.random.default_rng(SEED + seed)
+    frame, cam, pose, ls, world, _ = T.make_tracking_case(orc, rng, n_clutter=900, m_pts=1200)
+    pts = T.lm_coarse(orc, world)
+    n, idx = matcher.SearchByProjectionFrameFrame2(frame, cam, pose, pts, th, fe, direction, ls)
+    wn, widx = orc.match_coarse(frame, cam, pose, pts, th, fe, direction, ls)
+    assert n == wn and np.array_equal(idx, widx)
+    assert n > 50
+
+
+@pytest.mark.parametrize("seed,th,ratio", [(11, 5.0, 0.8), (12, 4.0, 0.8), (13, 1.0, 0.9), (14, 5.0, 0.6)])
+def test_fine_parity(orc, matcher, seed, th, ratio):
+    rng = np.random.default_rng(SEED + seed)
+    frame, cam, pose, ls, world, _ = T.make_tracking_case(orc, rng, n_clutter=1000, m_pts=3000)
+    pts = T.lm_fine(orc, rng, world, pose, ls)
+    n, idx, vis, valid = matcher.SearchByProjection2(frame, cam, pose, pts, th, ratio, ls)
+    wn, widx, wvis, wvalid = orc.match_fine(frame, cam, pose, pts, th, ratio, ls)
+    assert n == wn and np.array_equal(idx, widx)
+    assert np.array_equal(vis, wvis) and np.array_equal(valid, wvalid)
+    assert n > 100
+
+
+def test_keyframe_parity(orc, matcher):
+    for seed in (21, 22):
+        rng = np.random.default_rng(SEED + seed)
+        frame, cam, pose, ls, world, _ = T.make_tracking_case(orc, rng, n_clutter=500, m_pts=800)
+        skip = (rng.random(len(world["pos"])) < 0.1).astype(np.uint8)
+        n, idx = matcher.SearchByProjectionFrameToKeyframe(frame, cam, pose, world["pos"], world["desc"], skip, 15.0, 100)
+        wn, widx = orc.match_keyframe(frame, cam, pose, world["pos"], world["desc"], skip, 15.0, 100)
+        assert n == wn and np.array_equal(idx, widx) and n > 50
+
+
+def test_empty_inputs(orc, matcher):
+    rng = np.random.default_rng(1)
+    frame, cam, pose, ls, world, _ = T.make_tracking_case(orc, rng, n_clutter=50, m_pts=20)
+    n, idx = matcher.SearchByProjectionFrameFrame2(frame, cam, pose, np.zeros(0, orc.LM_COARSE), 15.0, 75, 0, ls)
+    assert n == 0 and len(idx) == 0
+    empty = dict(frame, kps=frame["kps"][:0], desc=frame["desc"][:0], right_points=frame["right_points"][:0],
+                 taken=frame["taken"][:0], cell_start=np.zeros_like(frame["cell_start"]))
+    n, idx = matcher.SearchByProjectionFrameFrame2(empty, cam, pose, T.lm_coarse(orc, world), 15.0, 75, 0, ls)
+    assert n == 0 and (idx == -1).all()
