@@ -3,8 +3,8 @@
 
 Metric (BASELINE.json): frames/s of ORB extract + match at 752x480.  One "step" = one pass of
 the per-frame feature pipeline over a batch of B synthetic EuRoC-shaped STEREO frames resident
-in HBM: ORB extraction of the left and right image (2B images: pyramid, FAST cells, quadtree
-distribution, angle + blur + BRIEF), undistort/rectify, the Preprocess stereo row-band matcher,
+in HBM: ORB extraction of the left and right image (2B images: pyramid, blur, FAST cells, quadtree
+distribution, angle + BRIEF), undistort/rectify, feature grid, the Preprocess stereo row-band matcher,
 and the brute-force kNN-2 Hamming matcher + ratio filter between the two descriptor sets.
 
   python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
@@ -118,6 +118,7 @@ def main():
     from snake_slam_amd import synth
     from snake_slam_amd.matcher import BruteForceMatcher, Preprocess, Rectification
     from snake_slam_amd.orb import ORBExtractor
+    from snake_slam_amd.tracking import FeatureGrid
 
     B = args.batch
     # ---- synthetic frames (seeded; a few distinct pairs tiled over the batch), resident in HBM ----
@@ -137,6 +138,9 @@ def main():
     cap = ext.configure(W, H, 2 * B)
     pre = Preprocess(local, sh)
     bf = BruteForceMatcher(local, sh)
+    grid = FeatureGrid(local, sh)
+    GRID_BOUNDS = (0.0, 0.0, float(W), float(H))  # featureGridBounds of an undistorted 752x480 image
+    n_cells = int(np.ceil(W / 20.0)) * int(np.ceil(H / 20.0))
     rect = Rectification.make((1.0, 1.0, 0.0, 0.0))  # synthetic pairs are already rectified
     level_scale = (np.float32(ORB["scale_factor"]) ** np.arange(ORB["n_levels"])).astype(np.float32)
 
@@ -144,6 +148,10 @@ def main():
     desc = torch.zeros((2 * B, cap, 4), dtype=torch.int64, device=dev)
     nkp = torch.zeros(2 * B, dtype=torch.int32, device=dev)
     kp64 = torch.zeros((2 * B, cap, 24), dtype=torch.uint8, device=dev)
+    kp64_g = torch.zeros((B, cap, 24), dtype=torch.uint8, device=dev)  # left keypoints / descriptors in feature-grid order
+    desc_g = torch.zeros((B, cap, 4), dtype=torch.int64, device=dev)
+    perm = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+    cell_start = torch.zeros((B, n_cells + 1), dtype=torch.int32, device=dev)
     right_points = torch.full((B, cap), -1000.0, dtype=torch.float32, device=dev)
     depth = torch.full((B, cap), -1000.0, dtype=torch.float32, device=dev)
     n_stereo = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -153,10 +161,11 @@ def main():
 
     def step():
         ext.detect_batch_dev(images, kps, desc, nkp)
-        pre.rectify_batch_dev(rect, kps, nkp, kp64)
-        pre.match_batch_dev(kp64[:B], desc[:B], nkp[:B], kp64[B:], desc[B:], nkp[B:], BF_SYNTH, level_scale, True,
-                            right_points, depth, n_stereo)
-        bf.knn2_batch_dev(desc[:B], nkp[:B], desc[B:], nkp[B:], knn)
+        pre.rectify_batch_dev(rect, kps, nkp, kp64)                                   # undistortKeypoints / rect.Forward
+        grid.create_batch_dev(GRID_BOUNDS, kp64[:B], desc[:B], nkp[:B], kp64_g, desc_g, perm, cell_start)  # computeFeatureGrid
+        pre.match_batch_dev(kp64_g, desc_g, nkp[:B], kp64[B:], desc[B:], nkp[B:], BF_SYNTH, level_scale, True,
+                            right_points, depth, n_stereo)                            # StereoMatching
+        bf.knn2_batch_dev(desc_g, nkp[:B], desc[B:], nkp[B:], knn)                    # matchKnn2 + filterMatches
         bf.filter_batch_dev(knn, nkp[:B], 60, 0.8, pairs, n_pairs)
 
     barrier = parallel.barrier

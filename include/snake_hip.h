@@ -239,6 +239,14 @@ typedef struct snk_grid_bounds
 SNK_API int snk_feature_grid(snk_matcher* m, const snk_kp64* undistorted, int n, const snk_grid_bounds* bounds,
                              int32_t* perm, int32_t* cell_start, int* cols, int* rows);
 
+/* Batched, device-resident Preprocess::computeFeatureGrid (Preprocess.cpp:244-266): builds the grid
+ * of every image and scatters its rectified keypoints and descriptors into grid order
+ * (kps_out / desc_out); perm_dev [batch][cap], cell_start_dev [batch][cols*rows + 1]. */
+SNK_API int snk_feature_grid_batch_dev(snk_matcher* m, const snk_grid_bounds* bounds, const snk_kp64* kps_dev,
+                                       const uint64_t* desc_dev, const int32_t* n_dev, int cap, int batch,
+                                       snk_kp64* kps_out_dev, uint64_t* desc_out_dev, int32_t* perm_dev,
+                                       int32_t* cell_start_dev);
+
 /* The per-frame data the tracking matchers read (Snake/Map/Features.h:18-41, Frame.h:44-46), in
  * feature-grid order.  taken[i] != 0 <=> frame.mvpMapPoints[i] != nullptr. */
 typedef struct snk_frame_view

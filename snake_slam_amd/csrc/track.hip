@@ -380,12 +380,24 @@ __global__ __launch_bounds__(64) void keyframe_kernel(FrameDev F, CamDev C, cons
 }
 
 // ---- feature grid: sort (cell << 16 | index) in LDS, derive the permutation and the cell ranges ----
-__global__ __launch_bounds__(256) void grid_kernel(const snk_kp64* __restrict__ kps, int n, double min_x, double min_y, int cols,
-                                                   int rows, int n_pow2, int* __restrict__ perm, int* __restrict__ cell_start)
+// one workgroup per image; n_dev == nullptr: single image with n_host features
+__global__ __launch_bounds__(256) void grid_kernel(const snk_kp64* __restrict__ kps, const int* __restrict__ n_dev, int n_host,
+                                                   int cap, double min_x, double min_y, int cols, int rows,
+                                                   int* __restrict__ perm, int* __restrict__ order, int* __restrict__ cell_start)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     u32* keys     = reinterpret_cast<u32*>(gsm);
     const int tid = threadIdx.x;
+    const int b   = blockIdx.x;
+    int n         = n_dev ? n_dev[b] : n_host;
+    n             = n < cap ? n : cap;
+    int n_pow2    = 2;
+    while (n_pow2 < n) n_pow2 <<= 1;
+    kps += (size_t)b * cap;
+    perm += (size_t)b * cap;
+    if (order) order += (size_t)b * cap;
+    const int ncell = cols * rows;
+    cell_start += (size_t)b * (ncell + 1);
     for (int i = tid; i < n_pow2; i += 256)
     {
         u32 k = 0xFFFFFFFFu;
@@ -415,17 +427,34 @@ __global__ __launch_bounds__(256) void grid_kernel(const snk_kp64* __restrict__ 
             }
             __syncthreads();
         }
-    const int ncell = cols * rows;
     for (int p = tid; p < n; p += 256)
     {
-        const u32 k   = keys[p];
+        const u32 k       = keys[p];
         perm[k & 0xFFFFu] = p;
-        const int c   = (int)(k >> 16);
-        const int cp  = p == 0 ? -1 : (int)(keys[p - 1] >> 16);
+        if (order) order[p] = (int)(k & 0xFFFFu);
+        const int c  = (int)(k >> 16);
+        const int cp = p == 0 ? -1 : (int)(keys[p - 1] >> 16);
         for (int q = cp + 1; q <= c; ++q) cell_start[q] = p;  // first feature of cell c (and of the empty cells before it)
     }
     const int last = n == 0 ? -1 : (int)(keys[n - 1] >> 16);
     for (int q = last + 1 + tid; q <= ncell; q += 256) cell_start[q] = n;
+}
+
+// out[p] = in[order[p]] for the rectified keypoints and the descriptors (Preprocess.cpp:254-260)
+__global__ __launch_bounds__(256) void reorder_kernel(const int* __restrict__ order, const int* __restrict__ n_dev, int cap,
+                                                      const snk_kp64* __restrict__ kin, const uint4* __restrict__ din,
+                                                      snk_kp64* __restrict__ kout, uint4* __restrict__ dout)
+{
+    const int b = blockIdx.y;
+    int n       = n_dev[b];
+    n           = n < cap ? n : cap;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const size_t base = (size_t)b * cap;
+    const int src     = order[base + p];
+    kout[base + p]           = kin[base + src];
+    dout[(base + p) * 2]     = din[(base + src) * 2];
+    dout[(base + p) * 2 + 1] = din[(base + src) * 2 + 1];
 }
 
 int make_cam(const snk_camera* cam, const double* pose, CamDev* c)
@@ -538,12 +567,38 @@ int snk_feature_grid(snk_matcher* m, const snk_kp64* undistorted, int n, const s
     if (n) SNK_HIP_CHECK(hipMemcpyAsync(m->aux.p, undistorted, (size_t)n * sizeof(snk_kp64), hipMemcpyHostToDevice, m->stream));
     SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       16384 * 4));
-    hipLaunchKernelGGL(grid_kernel, dim3(1), dim3(256), (size_t)n_pow2 * 4, m->stream, m->aux.as<snk_kp64>(), n, bounds->min_x,
-                       bounds->min_y, cols, rows, n_pow2, d_perm, d_cs);
+    hipLaunchKernelGGL(grid_kernel, dim3(1), dim3(256), (size_t)n_pow2 * 4, m->stream, m->aux.as<snk_kp64>(), (const int*)nullptr,
+                       n, n > 0 ? n : 1, bounds->min_x, bounds->min_y, cols, rows, d_perm, (int*)nullptr, d_cs);
     SNK_LAUNCH_CHECK();
     if (n) SNK_HIP_CHECK(hipMemcpyAsync(perm, d_perm, (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
     SNK_HIP_CHECK(hipMemcpyAsync(cell_start, d_cs, nc * 4, hipMemcpyDeviceToHost, m->stream));
     SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return SNK_OK;
+}
+
+int snk_feature_grid_batch_dev(snk_matcher* m, const snk_grid_bounds* bounds, const snk_kp64* kps_dev,
+                               const uint64_t* desc_dev, const int32_t* n_dev, int cap, int batch, snk_kp64* kps_out_dev,
+                               uint64_t* desc_out_dev, int32_t* perm_dev, int32_t* cell_start_dev)
+{
+    SNK_REQUIRE(m != nullptr && bounds != nullptr, "NULL argument");
+    SNK_REQUIRE(batch >= 0 && cap >= 1 && cap <= 16384, "cap must be 1..16384");
+    SNK_REQUIRE(kps_dev && desc_dev && n_dev && kps_out_dev && desc_out_dev && perm_dev && cell_start_dev, "NULL device buffer");
+    int cols, rows;
+    grid_dims(bounds, &cols, &rows);
+    SNK_REQUIRE((long long)cols * rows < 65535, "grid too large");
+    if (batch == 0) return SNK_OK;
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    int rc;
+    if ((rc = m->aux2.reserve((size_t)batch * cap * 4)) != SNK_OK) return rc;
+    int cap_pow2 = 2;
+    while (cap_pow2 < cap) cap_pow2 <<= 1;
+    SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      16384 * 4));
+    hipLaunchKernelGGL(grid_kernel, dim3(batch), dim3(256), (size_t)cap_pow2 * 4, m->stream, kps_dev, n_dev, 0, cap, bounds->min_x,
+                       bounds->min_y, cols, rows, perm_dev, m->aux2.as<int>(), cell_start_dev);
+    hipLaunchKernelGGL(reorder_kernel, dim3(ceil_div(cap, 256), batch), dim3(256), 0, m->stream, m->aux2.as<int>(), n_dev, cap,
+                       kps_dev, reinterpret_cast<const uint4*>(desc_dev), kps_out_dev, reinterpret_cast<uint4*>(desc_out_dev));
+    SNK_LAUNCH_CHECK();
     return SNK_OK;
 }
 

@@ -57,6 +57,15 @@ class FeatureGrid(_Handle):
         return perm[: len(k)], cs, cols.value, rows.value
 
 
+    def create_batch_dev(self, bounds, kps, desc, n, kps_out, desc_out, perm, cell_start):
+        """Device tensors: kps [B, cap, 24] uint8 (snk_kp64), desc [B, cap, 4] int64, n [B] int32;
+        outputs in grid order + perm [B, cap] int32 + cell_start [B, cols*rows+1] int32."""
+        b = GridBounds(*bounds)
+        _lib.check(self._lib.snk_feature_grid_batch_dev(self._h, C.byref(b), kps.data_ptr(), desc.data_ptr(), n.data_ptr(),
+                                                        desc.shape[1], desc.shape[0], kps_out.data_ptr(), desc_out.data_ptr(),
+                                                        perm.data_ptr(), cell_start.data_ptr()), "snk_feature_grid_batch_dev")
+
+
 class SnakeORBMatcher(_Handle):
     def SearchByProjectionFrameFrame2(self, frame, cam, pose, lm_points, th, feature_error, direction, level_scale):
         """Coarse tracking match.  Returns (matches, match_idx[m])."""

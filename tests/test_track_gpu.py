@@ -78,3 +78,39 @@ def test_empty_inputs(orc, matcher):
                  taken=frame["taken"][:0], cell_start=np.zeros_like(frame["cell_start"]))
     n, idx = matcher.SearchByProjectionFrameFrame2(empty, cam, pose, T.lm_coarse(orc, world), 15.0, 75, 0, ls)
     assert n == 0 and (idx == -1).all()
+
+
+def test_feature_grid_batch_dev(orc):
+    import torch
+    from snake_slam_amd.tracking import FeatureGrid
+
+    rng = np.random.default_rng(8)
+    B, cap = 4, 1100
+    ns = np.array([1100, 0, 513, 64], np.int32)
+    K = np.zeros((B, cap), orc.KP64)
+    D = rng.integers(0, 2**64, size=(B, cap, 4), dtype=np.uint64)
+    for b in range(B):
+        K["x"][b, : ns[b]] = rng.uniform(T.BOUNDS[0], T.BOUNDS[2], ns[b])
+        K["y"][b, : ns[b]] = rng.uniform(T.BOUNDS[1], T.BOUNDS[3], ns[b])
+        K["octave"][b, : ns[b]] = rng.integers(0, 4, ns[b])
+    cols, rows = orc.grid_dims(T.BOUNDS)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(a).to(dev)
+    dk, dd, dn = t(K.view(np.uint8).reshape(B, cap, 24)), t(D.view(np.int64)), t(ns)
+    ok, od = torch.zeros_like(dk), torch.zeros_like(dd)
+    perm = torch.full((B, cap), -1, dtype=torch.int32, device=dev)
+    cs = torch.full((B, cols * rows + 1), -1, dtype=torch.int32, device=dev)
+    g = FeatureGrid(0)
+    torch.cuda.synchronize()
+    g.create_batch_dev(T.BOUNDS, dk, dd, dn, ok, od, perm, cs)
+    g.sync()
+    okh = ok.cpu().numpy().view(orc.KP64).reshape(B, cap)
+    odh = od.cpu().numpy().view(np.uint64)
+    for b in range(B):
+        n = int(ns[b])
+        wperm, wcs, _, _ = orc.feature_grid(K[b, :n], T.BOUNDS)
+        assert np.array_equal(perm[b, :n].cpu().numpy(), wperm) and np.array_equal(cs[b].cpu().numpy(), wcs)
+        wk, wd = np.zeros(n, orc.KP64), np.zeros((n, 4), np.uint64)
+        wk[wperm], wd[wperm] = K[b, :n], D[b, :n]
+        assert np.array_equal(okh[b, :n], wk) and np.array_equal(odh[b, :n], wd)
+    g.close()
