@@ -4,7 +4,9 @@
 // SAIGA_EXIT_ERROR (e.g. Snake/Preprocess/FeatureDetector.cpp:35); here every non-zero status
 // becomes a std::runtime_error carrying snk_last_error().
 #pragma once
+#include <algorithm>
 #include <array>
+#include <cmath>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -132,6 +134,107 @@ class Preprocess
                                level_scale.data(), (int)level_scale.size(), relaxed ? 1 : 0, right_points.data(),
                                depth.data(), &n),
               "snk_stereo_match");
+        return n;
+    }
+
+   private:
+    snk_matcher* h_ = nullptr;
+};
+
+// Frame data the tracking matchers read, grid-ordered (Snake/Map/Features.h:18-41, Frame.h:44-46).
+struct FrameView
+{
+    std::vector<snk_kp64> undistorted_keypoints;
+    std::vector<DescriptorORB> descriptors;
+    std::vector<float> right_points;
+    std::vector<uint8_t> taken;  // mvpMapPoints[i] != nullptr
+    std::vector<int32_t> cell_start;
+    int cols = 0, rows = 0;
+    snk_grid_bounds bounds{};
+
+    snk_frame_view view() const
+    {
+        snk_frame_view v{};
+        v.n            = (int)undistorted_keypoints.size();
+        v.cols         = cols;
+        v.rows         = rows;
+        v.kps          = undistorted_keypoints.data();
+        v.desc         = reinterpret_cast<const uint64_t(*)[4]>(descriptors.data());
+        v.right_points = right_points.data();
+        v.taken        = taken.data();
+        v.cell_start   = cell_start.data();
+        v.bounds       = bounds;
+        return v;
+    }
+};
+
+// frame.grid.create(featureGridBounds, undistorted_keypoints) + the three SnakeORBMatcher searches
+// (Snake/Preprocess/Preprocess.cpp:246; Snake/Tracking/SnakeORBMatcher.h:21-30)
+class SnakeORBMatcher
+{
+   public:
+    explicit SnakeORBMatcher(int device = 0) { check(snk_matcher_create(device, nullptr, &h_), "snk_matcher_create"); }
+    ~SnakeORBMatcher() { snk_matcher_destroy(h_); }
+    SnakeORBMatcher(const SnakeORBMatcher&)            = delete;
+    SnakeORBMatcher& operator=(const SnakeORBMatcher&) = delete;
+
+    // returns the permutation (new index of every feature); fills frame.cell_start / cols / rows
+    std::vector<int32_t> CreateGrid(FrameView& frame, const snk_grid_bounds& bounds)
+    {
+        frame.bounds = bounds;
+        const int n  = (int)frame.undistorted_keypoints.size();
+        std::vector<int32_t> perm((size_t)n + 1);
+        const int cols = std::max(1, (int)std::ceil((bounds.max_x - bounds.min_x) / 20.0));
+        const int rows = std::max(1, (int)std::ceil((bounds.max_y - bounds.min_y) / 20.0));
+        frame.cell_start.assign((size_t)cols * rows + 1, 0);
+        check(snk_feature_grid(h_, frame.undistorted_keypoints.data(), n, &bounds, perm.data(), frame.cell_start.data(),
+                               &frame.cols, &frame.rows),
+              "snk_feature_grid");
+        perm.resize((size_t)n);
+        return perm;
+    }
+    // match[i] = feature index for local-map point i or -1; the caller sets mvpMapPoints[match[i]] = lm.points[i].mp
+    int SearchByProjectionFrameFrame2(const FrameView& frame, const snk_camera& K, const double pose[7],
+                                      const std::vector<snk_lm_coarse>& lm, float th, int featureError, int direction,
+                                      const std::vector<float>& level_scale, std::vector<int32_t>& match)
+    {
+        const snk_frame_view v = frame.view();
+        match.assign(lm.size() + 1, -1);
+        int n = 0;
+        check(snk_match_project_coarse(h_, &v, &K, pose, lm.data(), (int)lm.size(), th, featureError, direction,
+                                       level_scale.data(), (int)level_scale.size(), match.data(), &n),
+              "snk_match_project_coarse");
+        match.resize(lm.size());
+        return n;
+    }
+    int SearchByProjection2(const FrameView& frame, const snk_camera& K, const double pose[7], std::vector<snk_lm_fine>& lm,
+                            float th, float ratio, const std::vector<float>& level_scale, std::vector<int32_t>& match,
+                            std::vector<uint8_t>& visible)
+    {
+        const snk_frame_view v = frame.view();
+        match.assign(lm.size() + 1, -1);
+        visible.assign(lm.size() + 1, 0);
+        int n = 0;
+        check(snk_match_project_fine(h_, &v, &K, pose, lm.data(), (int)lm.size(), th, ratio, level_scale.data(),
+                                     (int)level_scale.size(), match.data(), visible.data(), &n),
+              "snk_match_project_fine");
+        match.resize(lm.size());
+        visible.resize(lm.size());
+        return n;
+    }
+    int SearchByProjectionFrameToKeyframe(const FrameView& frame, const snk_camera& K, const double pose[7],
+                                          const std::vector<std::array<double, 3>>& positions,
+                                          const std::vector<DescriptorORB>& descriptors, const std::vector<uint8_t>& skip, float th,
+                                          int featureError, std::vector<int32_t>& match)
+    {
+        const snk_frame_view v = frame.view();
+        match.assign(positions.size() + 1, -1);
+        int n = 0;
+        check(snk_match_project_keyframe(h_, &v, &K, pose, reinterpret_cast<const double(*)[3]>(positions.data()),
+                                         reinterpret_cast<const uint64_t(*)[4]>(descriptors.data()), skip.data(),
+                                         (int)positions.size(), th, featureError, match.data(), &n),
+              "snk_match_project_keyframe");
+        match.resize(positions.size());
         return n;
     }
 

@@ -14,6 +14,11 @@ int main(int argc, char**) {
         snake_hip::BruteForceMatcher m; m.matchKnn2_omp(d, d, 4); m.filterMatches(60, 0.8f);
         snake_hip::Preprocess pp; std::vector<snk_kp64> r; snk_rectification rect{}; pp.Rectify(rect, k, r);
         std::vector<float> rp, dp; pp.StereoMatching(r, d, r, d, 47.9, {1.f, 1.2f}, true, rp, dp);
+        snake_hip::FrameView fv; snake_hip::SnakeORBMatcher om; snk_grid_bounds gb{0, 0, 752, 480}; om.CreateGrid(fv, gb);
+        snk_camera cam{}; double pose[7] = {0, 0, 0, 1, 0, 0, 0}; std::vector<int32_t> match; std::vector<uint8_t> vis;
+        std::vector<snk_lm_coarse> lc; om.SearchByProjectionFrameFrame2(fv, cam, pose, lc, 15.f, 75, 0, {1.f, 1.2f}, match);
+        std::vector<snk_lm_fine> lf; om.SearchByProjection2(fv, cam, pose, lf, 5.f, 0.8f, {1.f, 1.2f}, match, vis);
+        om.SearchByProjectionFrameToKeyframe(fv, cam, pose, {}, {}, {}, 15.f, 100, match);
         snake_hip::Scene sc; snake_hip::BARec ba; ba.create(sc); ba.initAndSolve(); ba.residualsSquared();
     }
     return snk_device_count() >= 0 ? 0 : 1;
