@@ -320,12 +320,12 @@ __device__ __forceinline__ double block_sum(double v, double* red, int tid)
 constexpr int CAM_THREADS = 256;
 __global__ __launch_bounds__(CAM_THREADS) void cam_pass(Arrays A)
 {
-    __shared__ double red[CAM_THREADS];
+    __shared__ double part[4][33];
     const int pb  = blockIdx.y;
     const Prob pr = A.prob[pb];
     const int c   = blockIdx.x;
     if (c >= pr.nfc) return;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int s0 = A.cam_start[pr.camstart_off + c], s1 = A.cam_start[pr.camstart_off + c + 1];
     double acc[33];  // 21 (U upper) | 6 (b_c) | 6 (sum Y b_p)
 #pragma unroll
@@ -353,11 +353,23 @@ __global__ __launch_bounds__(CAM_THREADS) void cam_pass(Arrays A)
             for (int a = 0; a < 6; ++a) acc[27 + a] += yb[a];
         }
     }
-    double tot[33];
-#pragma unroll 1
-    for (int k = 0; k < 33; ++k) tot[k] = block_sum<CAM_THREADS>(acc[k], red, tid);
+    // fixed-order reduction: xor butterfly inside each wavefront, then the 4 wavefronts in order
+#pragma unroll
+    for (int k = 0; k < 33; ++k)
+    {
+        double v = acc[k];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        acc[k] = v;
+    }
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < 33; ++k) part[wave][k] = acc[k];
+    __syncthreads();
     if (tid == 0)
     {
+        double tot[33];
+        for (int k = 0; k < 33; ++k) tot[k] = ((part[0][k] + part[1][k]) + part[2][k]) + part[3][k];
         const double lambda = A.state[pb].lambda;
         double* U = A.U + (size_t)(pr.cam_off + c) * 36;
         int q = 0;
@@ -373,29 +385,58 @@ __global__ __launch_bounds__(CAM_THREADS) void cam_pass(Arrays A)
     }
 }
 
-// S block (c1, c2) = [c1 == c2] U - sum over co-observations of Y(c1) W(c2)^T ; 36 threads per block
-__global__ __launch_bounds__(252) void schur_pass(Arrays A)
+// S block (c1, c2) = [c1 == c2] U - sum over co-observations of Y(c1) W(c2)^T.  One wavefront per
+// block: lanes stride over the block's co-observation list, each accumulating a full 6x6 product in
+// registers (36 + 36 operands from two contiguous 144-byte rows), then a fixed xor-butterfly sum.
+__global__ __launch_bounds__(256) void schur_pass(Arrays A)
 {
-    const int pb  = blockIdx.y;
-    const Prob pr = A.prob[pb];
-    const int blk = blockIdx.x * 7 + threadIdx.x / 36;
-    const int e   = threadIdx.x % 36;
+    const int pb   = blockIdx.y;
+    const Prob pr  = A.prob[pb];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int blk  = blockIdx.x * 4 + wave;
     if (blk >= pr.nfc * pr.nfc) return;
     const int c1 = blk / pr.nfc, c2 = blk - c1 * pr.nfc;
-    const int r = e / 6, c = e - r * 6;
-    double acc = c1 == c2 ? A.U[(size_t)(pr.cam_off + c1) * 36 + e] : 0.0;
     const int e0 = A.blk_start[pr.blkstart_off + blk], e1 = A.blk_start[pr.blkstart_off + blk + 1];
-    double sub = 0.0;
-    for (int k = e0; k < e1; ++k)
+    double acc[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+    for (int k = e0 + lane; k < e1; k += 64)
     {
         const int2 en = A.blk_ent[pr.ent_off + k];
         const int g1 = pr.obs_off + en.x, g2 = pr.obs_off + en.y;
         if (A.o_r[(size_t)g1 * 4 + 3] == 0.0 || A.o_r[(size_t)g2 * 4 + 3] == 0.0) continue;
-        const double* Y = A.o_Y + (size_t)g1 * 18 + r * 3;
-        const double* W = A.o_W + (size_t)g2 * 18 + c * 3;
-        sub += Y[0] * W[0] + Y[1] * W[1] + Y[2] * W[2];
+        const double2* Yp = reinterpret_cast<const double2*>(A.o_Y + (size_t)g1 * 18);
+        const double2* Wp = reinterpret_cast<const double2*>(A.o_W + (size_t)g2 * 18);
+        double y[18], w[18];
+#pragma unroll
+        for (int q = 0; q < 9; ++q)
+        {
+            const double2 a = Yp[q], b = Wp[q];
+            y[2 * q] = a.x; y[2 * q + 1] = a.y;
+            w[2 * q] = b.x; w[2 * q + 1] = b.y;
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) acc[r * 6 + c] += y[r * 3] * w[c * 3] + y[r * 3 + 1] * w[c * 3 + 1] + y[r * 3 + 2] * w[c * 3 + 2];
     }
-    A.S[pr.s_off + (size_t)(c1 * 6 + r) * pr.n6 + c2 * 6 + c] = acc - sub;
+#pragma unroll
+    for (int k = 0; k < 36; ++k)
+    {
+        double v = acc[k];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        acc[k] = v;
+    }
+    if (lane == 0)
+    {
+        double* S       = A.S + pr.s_off + (size_t)(c1 * 6) * pr.n6 + c2 * 6;
+        const double* U = A.U + (size_t)(pr.cam_off + c1) * 36;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) S[(size_t)r * pr.n6 + c] = (c1 == c2 ? U[r * 6 + c] : 0.0) - acc[r * 6 + c];
+    }
 }
 
 // 6x6 SPD inverse by Cholesky (one thread); falls back to the clamped diagonal
@@ -446,8 +487,8 @@ __device__ void inv6_spd(const double* Ain, int lda, double* Ai)
 }
 
 constexpr int PCG_THREADS = 256;
-// dynamic LDS: r, z, p, Ap (n6 each) | Minv (nfc*36)
-__global__ __launch_bounds__(PCG_THREADS) void pcg_solve(Arrays A, Opt O)
+// dynamic LDS: r, z, p, Ap (n6 each) | partial sums (4 * n6) | Minv (nfc*36) | S (n6*n6, when s_in_lds)
+__global__ __launch_bounds__(PCG_THREADS) void pcg_solve(Arrays A, Opt O, int s_in_lds)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ double red[PCG_THREADS];
@@ -459,13 +500,17 @@ __global__ __launch_bounds__(PCG_THREADS) void pcg_solve(Arrays A, Opt O)
     double* z  = r + n6;
     double* p  = z + n6;
     double* Ap = p + n6;
-    double* Mi = Ap + n6;
-    const double* S   = A.S + pr.s_off;
+    double* ps = Ap + n6;       // [4][n6] partial sums of the split matvec
+    double* Mi = ps + 4 * n6;
+    double* Sl = Mi + nfc * 36;
+    const double* Sg  = A.S + pr.s_off;
     const double* rhs = A.rhs + pr.vec_off;
     double* x         = A.x + pr.vec_off;
     if (n6 == 0) return;
-
-    for (int c = tid; c < nfc; c += PCG_THREADS) inv6_spd(S + (size_t)(c * 6) * n6 + c * 6, n6, Mi + c * 36);
+    if (s_in_lds)
+        for (int i = tid; i < n6 * n6; i += PCG_THREADS) Sl[i] = Sg[i];
+    const double* S = s_in_lds ? Sl : Sg;
+    for (int c = tid; c < nfc; c += PCG_THREADS) inv6_spd(Sg + (size_t)(c * 6) * n6 + c * 6, n6, Mi + c * 36);
     double part = 0.0;
     for (int q = tid; q < n6; q += PCG_THREADS)
     {
@@ -475,7 +520,6 @@ __global__ __launch_bounds__(PCG_THREADS) void pcg_solve(Arrays A, Opt O)
         part += v * v;
     }
     const double bnorm2 = block_sum<PCG_THREADS>(part, red, tid);
-    // z = Minv r ; p = z
     part = 0.0;
     for (int q = tid; q < n6; q += PCG_THREADS)
     {
@@ -488,6 +532,10 @@ __global__ __launch_bounds__(PCG_THREADS) void pcg_solve(Arrays A, Opt O)
     }
     double rz = block_sum<PCG_THREADS>(part, red, tid);
     const double stop2 = O.pcg_tol * O.pcg_tol * bnorm2;
+    // matvec split: `parts` threads share a row, each a contiguous column chunk (fixed combine order)
+    int parts = PCG_THREADS / n6;
+    parts     = parts < 1 ? 1 : (parts > 4 ? 4 : parts);
+    const int chunk = (n6 + parts - 1) / parts;
     int iters = 0;
     for (int k = 0; k < O.max_pcg; ++k)
     {
@@ -495,12 +543,20 @@ __global__ __launch_bounds__(PCG_THREADS) void pcg_solve(Arrays A, Opt O)
         for (int q = tid; q < n6; q += PCG_THREADS) part += r[q] * r[q];
         const double rn2 = block_sum<PCG_THREADS>(part, red, tid);
         if (rn2 <= stop2) break;
+        for (int t = tid; t < n6 * parts; t += PCG_THREADS)
+        {
+            const int pi = t / n6, q = t - pi * n6;
+            const int t0 = pi * chunk, t1 = min(t0 + chunk, n6);
+            double s = 0.0;
+            for (int u = t0; u < t1; ++u) s += S[(size_t)u * n6 + q] * p[u];  // column q == row q (symmetric)
+            ps[pi * n6 + q] = s;
+        }
+        __syncthreads();
         part = 0.0;
         for (int q = tid; q < n6; q += PCG_THREADS)
         {
-            // row q of S == column q (symmetric): coalesced across q
-            double s = 0.0;
-            for (int t = 0; t < n6; ++t) s += S[(size_t)t * n6 + q] * p[t];
+            double s = ps[q];
+            for (int pi = 1; pi < parts; ++pi) s += ps[pi * n6 + q];
             Ap[q] = s;
             part += p[q] * s;
         }
@@ -928,7 +984,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         max_nfc = std::max(max_nfc, nfc);
         max_n6  = std::max(max_n6, pr.n6);
     }
-    const size_t pcg_lds = (size_t)max_n6 * 4 * 8 + (size_t)max_nfc * 36 * 8;
+    const size_t pcg_lds = (size_t)max_n6 * 8 * 8 + (size_t)max_nfc * 36 * 8;
     if (pcg_lds > 150 * 1024)
     {
         set_error("reduced camera system too large for the in-LDS PCG (%d free cameras)", max_nfc);
@@ -989,7 +1045,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     SNK_HIP_CHECK(hipMemsetAsync(h->d_r.p, 0, nobs * 4 * 8, st));
     SNK_HIP_CHECK(hipMemsetAsync(h->d_x.p, 0, (size_t)std::max(vec_off, 1) * 8, st));
     SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pcg_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)std::max<size_t>(pcg_lds, 64)));
+                                      (int)std::min<size_t>(pcg_lds + (size_t)max_n6 * max_n6 * 8, 158 * 1024)));
 
     Arrays& A   = h->arr;
     A.prob      = h->d_prob.as<Prob>();
@@ -1073,15 +1129,18 @@ int snk_ba_solve_async(snk_ba* h, int iterations)
     hipLaunchKernelGGL(begin_solve, dim3(ceil_div(B, 64)), dim3(64), 0, st, h->d_state.as<State>(), B, O.lambda_init);
     SNK_LAUNCH_CHECK();
     const dim3 gpt(std::max(1, ceil_div(h->max_np, 128)), B);
-    const size_t pcg_lds = (size_t)h->max_n6 * 4 * 8 + (size_t)h->max_nfc * 36 * 8;
+    size_t pcg_lds        = (size_t)h->max_n6 * 8 * 8 + (size_t)h->max_nfc * 36 * 8;
+    const size_t s_bytes  = (size_t)h->max_n6 * h->max_n6 * 8;
+    const int s_in_lds    = pcg_lds + s_bytes <= 158 * 1024 ? 1 : 0;
+    if (s_in_lds) pcg_lds += s_bytes;
     for (int it = 0; it < iterations; ++it)
     {
         hipLaunchKernelGGL(point_pass<0>, gpt, dim3(128), 0, st, A, O);
         if (h->max_nfc > 0)
         {
             hipLaunchKernelGGL(cam_pass, dim3(h->max_nfc, B), dim3(CAM_THREADS), 0, st, A);
-            hipLaunchKernelGGL(schur_pass, dim3(ceil_div(h->max_nfc * h->max_nfc, 7), B), dim3(252), 0, st, A);
-            hipLaunchKernelGGL(pcg_solve, dim3(B), dim3(PCG_THREADS), pcg_lds, st, A, O);
+            hipLaunchKernelGGL(schur_pass, dim3(ceil_div(h->max_nfc * h->max_nfc, 4), B), dim3(256), 0, st, A);
+            hipLaunchKernelGGL(pcg_solve, dim3(B), dim3(PCG_THREADS), pcg_lds, st, A, O, s_in_lds);
         }
         hipLaunchKernelGGL(update_pass, dim3(std::max(1, ceil_div(h->max_np + h->max_ni, 128)), B), dim3(128), 0, st, A);
         hipLaunchKernelGGL(point_pass<1>, gpt, dim3(128), 0, st, A, O);
