@@ -396,6 +396,7 @@ __global__ __launch_bounds__(256) void schur_pass(Arrays A)
     const int blk  = blockIdx.x * 4 + wave;
     if (blk >= pr.nfc * pr.nfc) return;
     const int c1 = blk / pr.nfc, c2 = blk - c1 * pr.nfc;
+    if (c2 < c1) return;  // S is symmetric: the lower blocks are written as transposes of the upper ones
     const int e0 = A.blk_start[pr.blkstart_off + blk], e1 = A.blk_start[pr.blkstart_off + blk + 1];
     double acc[36];
 #pragma unroll
@@ -431,11 +432,32 @@ __global__ __launch_bounds__(256) void schur_pass(Arrays A)
     if (lane == 0)
     {
         double* S       = A.S + pr.s_off + (size_t)(c1 * 6) * pr.n6 + c2 * 6;
+        double* St      = A.S + pr.s_off + (size_t)(c2 * 6) * pr.n6 + c1 * 6;
         const double* U = A.U + (size_t)(pr.cam_off + c1) * 36;
+        if (c1 == c2)
+        {
+            // symmetrise the diagonal block (Y W^T of one camera is symmetric up to rounding)
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
+            for (int r = 0; r < 6; ++r)
 #pragma unroll
-            for (int c = 0; c < 6; ++c) S[(size_t)r * pr.n6 + c] = (c1 == c2 ? U[r * 6 + c] : 0.0) - acc[r * 6 + c];
+                for (int c = r; c < 6; ++c)
+                {
+                    const double v = U[r * 6 + c] - 0.5 * (acc[r * 6 + c] + acc[c * 6 + r]);
+                    S[(size_t)r * pr.n6 + c] = v;
+                    S[(size_t)c * pr.n6 + r] = v;
+                }
+        }
+        else
+        {
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+                {
+                    S[(size_t)r * pr.n6 + c]  = -acc[r * 6 + c];
+                    St[(size_t)c * pr.n6 + r] = -acc[r * 6 + c];
+                }
+        }
     }
 }
 

@@ -172,6 +172,53 @@ __device__ __forceinline__ int iround_d(double x)
 }
 
 constexpr u64 ST_INF_KEY = (250ull << 40) | 0xFFFFFFFFFFull;
+constexpr int ST_ROW_BIAS    = 4096;  // rounded rows are clamped to [-4096, 61439] for the index only
+constexpr int ST_SORT_MAX    = 8192;  // right keypoints per image the in-LDS sort handles
+
+// row-sorted index of the right keypoints of every image: (clamped rounded row + bias) << 16 | index
+__global__ __launch_bounds__(256) void stereo_sort_kernel(const snk_kp64* __restrict__ right, const int* __restrict__ nr_dev,
+                                                          int nr_cap, int nr_host, u32* __restrict__ row_sorted)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ssm[];
+    u32* keys     = reinterpret_cast<u32*>(ssm);
+    const int b   = blockIdx.x;
+    const int tid = threadIdx.x;
+    int nr        = nr_dev ? nr_dev[b] : nr_host;
+    nr            = nr < nr_cap ? nr : nr_cap;
+    int n_pow2    = 2;
+    while (n_pow2 < nr) n_pow2 <<= 1;
+    const snk_kp64* rb = right + (size_t)b * nr_cap;
+    for (int i = tid; i < n_pow2; i += 256)
+    {
+        u32 k = 0xFFFFFFFFu;
+        if (i < nr)
+        {
+            int row = (int)floor(rb[i].y + 0.5) + ST_ROW_BIAS;
+            row     = row < 0 ? 0 : (row > 65535 ? 65535 : row);
+            k       = ((u32)row << 16) | (u32)i;
+        }
+        keys[i] = k;
+    }
+    __syncthreads();
+    for (int k = 2; k <= n_pow2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1)
+        {
+            for (int t = tid; t < (n_pow2 >> 1); t += 256)
+            {
+                const int i   = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int ixj = i | j;
+                const bool up = (i & k) == 0;
+                const u32 x = keys[i], y = keys[ixj];
+                if ((x > y) == up)
+                {
+                    keys[i]   = y;
+                    keys[ixj] = x;
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < nr; i += 256) row_sorted[(size_t)b * nr_cap + i] = keys[i];
+}
 
 // Snake::Preprocess::StereoMatching (reference Snake/Preprocess/Preprocess.cpp:161-240) with one
 // wavefront per left keypoint.  The reference walks row buckets y-r..y+r in ascending row, each in
@@ -183,7 +230,8 @@ __global__ __launch_bounds__(256) void stereo_kernel(const snk_kp64* __restrict_
                                                      const snk_kp64* __restrict__ right, const uint4* __restrict__ dr,
                                                      const int* __restrict__ nr_dev, int nr_cap, int nr_host, double bf,
                                                      LevelScales ls, int relaxed, float* __restrict__ right_points,
-                                                     float* __restrict__ depth, int* __restrict__ n_matches)
+                                                     float* __restrict__ depth, int* __restrict__ n_matches,
+                                                     const u32* __restrict__ row_sorted)
 {
     const int b    = blockIdx.y;
     int nl         = nl_dev ? nl_dev[b] : nl_host;
@@ -212,8 +260,32 @@ __global__ __launch_bounds__(256) void stereo_kernel(const snk_kp64* __restrict_
     const float max_disp = (float)(bf * 0.5);
 
     u64 k1 = ST_INF_KEY, k2 = ST_INF_KEY;
-    for (int j = lane; j < nr; j += 64)
+    // With the row-sorted index (biased rounded row << 16 | index, ascending) only the right keypoints
+    // of rows y-r .. y+r are visited; every gate is still evaluated on the true values below.
+    int scan_lo = 0, scan_hi = nr;
+    const u32* srt = row_sorted ? row_sorted + (size_t)b * nr_cap : nullptr;
+    if (srt)
     {
+        const int lo_row = min(max(y - ri + ST_ROW_BIAS, 0), 65535), hi_row = min(max(y + ri + ST_ROW_BIAS, 0), 65535);
+        const u32 lo_key = (u32)lo_row << 16, hi_key = ((u32)hi_row << 16) | 0xFFFFu;
+        int a = 0, c = nr;
+        while (a < c)
+        {
+            const int mid = (a + c) >> 1;
+            if (srt[mid] < lo_key) a = mid + 1; else c = mid;
+        }
+        scan_lo = a;
+        c       = nr;
+        while (a < c)
+        {
+            const int mid = (a + c) >> 1;
+            if (srt[mid] <= hi_key) a = mid + 1; else c = mid;
+        }
+        scan_hi = a;
+    }
+    for (int pos = scan_lo + lane; pos < scan_hi; pos += 64)
+    {
+        const int j       = srt ? (int)(srt[pos] & 0xFFFFu) : pos;
         const snk_kp64 kr = rb[j];
         const int yj      = iround_d(kr.y);
         const int rel     = yj - (y - ri);
@@ -439,9 +511,21 @@ int snk_stereo_match(snk_matcher* m, const snk_kp64* left, const uint64_t (*desc
     SNK_HIP_CHECK(hipMemcpyAsync(rp, right_points, (size_t)nl * 4, hipMemcpyHostToDevice, m->stream));
     SNK_HIP_CHECK(hipMemcpyAsync(dp, depth, (size_t)nl * 4, hipMemcpyHostToDevice, m->stream));
     SNK_HIP_CHECK(hipMemsetAsync(m->cnt.p, 0, sizeof(int), m->stream));
+    const u32* srt = nullptr;
+    if (nr <= ST_SORT_MAX)
+    {
+        if ((rc = m->out.reserve((size_t)nr * 4)) != SNK_OK) return rc;
+        int np2 = 2;
+        while (np2 < nr) np2 <<= 1;
+        SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stereo_sort_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, ST_SORT_MAX * 4));
+        hipLaunchKernelGGL(stereo_sort_kernel, dim3(1), dim3(256), (size_t)np2 * 4, m->stream, (const snk_kp64*)(ab + kl),
+                           (const int*)nullptr, nr, nr, m->out.as<u32>());
+        srt = m->out.as<u32>();
+    }
     hipLaunchKernelGGL(stereo_kernel, dim3(ceil_div(nl, 4), 1), dim3(256), 0, m->stream, (const snk_kp64*)ab,
                        m->q.as<uint4>(), (const int*)nullptr, nl, nl, (const snk_kp64*)(ab + kl), m->t.as<uint4>(),
-                       (const int*)nullptr, nr, nr, bf, ls, relaxed, rp, dp, m->cnt.as<int>());
+                       (const int*)nullptr, nr, nr, bf, ls, relaxed, rp, dp, m->cnt.as<int>(), srt);
     SNK_LAUNCH_CHECK();
     SNK_HIP_CHECK(hipMemcpyAsync(right_points, rp, (size_t)nl * 4, hipMemcpyDeviceToHost, m->stream));
     SNK_HIP_CHECK(hipMemcpyAsync(depth, dp, (size_t)nl * 4, hipMemcpyDeviceToHost, m->stream));
@@ -467,9 +551,21 @@ int snk_stereo_match_batch_dev(snk_matcher* m, const snk_kp64* left_dev, const u
     if (batch == 0 || nl_cap == 0) return SNK_OK;
     SNK_HIP_CHECK(hipSetDevice(m->device));
     SNK_HIP_CHECK(hipMemsetAsync(n_matches_dev, 0, (size_t)batch * sizeof(int), m->stream));
+    const u32* srt = nullptr;
+    if (nr_cap <= ST_SORT_MAX)
+    {
+        if ((rc = m->out.reserve((size_t)batch * nr_cap * 4)) != SNK_OK) return rc;
+        int np2 = 2;
+        while (np2 < nr_cap) np2 <<= 1;
+        SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stereo_sort_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, ST_SORT_MAX * 4));
+        hipLaunchKernelGGL(stereo_sort_kernel, dim3(batch), dim3(256), (size_t)np2 * 4, m->stream, right_dev, nr_dev, nr_cap, 0,
+                           m->out.as<u32>());
+        srt = m->out.as<u32>();
+    }
     hipLaunchKernelGGL(stereo_kernel, dim3(ceil_div(nl_cap, 4), batch), dim3(256), 0, m->stream, left_dev,
                        (const uint4*)desc_left_dev, nl_dev, nl_cap, 0, right_dev, (const uint4*)desc_right_dev, nr_dev,
-                       nr_cap, 0, bf, ls, relaxed, right_points_dev, depth_dev, n_matches_dev);
+                       nr_cap, 0, bf, ls, relaxed, right_points_dev, depth_dev, n_matches_dev, srt);
     SNK_LAUNCH_CHECK();
     return SNK_OK;
 }
