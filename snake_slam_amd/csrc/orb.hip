@@ -8,7 +8,8 @@
 //
 // Pipeline (all kernels batched over B images, blockIdx.y/z = image):
 //   resize_kernel      level l-1 -> level l, 11-bit fixed-point bilinear       (L-1 launches)
-//   blur_kernel        7x7 Gaussian of every level (64x16 tiles, v_alignbyte + v_dot4_u32_u8)
+//   blur_kernel        7x7 Gaussian of every level, streaming: a wavefront walks down a 248-px column
+//                      strip with the 7-row window in registers (v_alignbyte + v_dot4_u32_u8)
 //   fast_kernel        one workgroup per ~30x30 FAST cell: image tile -> LDS (aligned dwords), quick
 //                      opposite-pair bound on every pixel, compaction, exact FAST-9/16 score of the
 //                      survivors in packed 16-bit lanes, in-cell 3x3 NMS, ini/min threshold fallback,
@@ -51,7 +52,7 @@ struct LevelInfo
     long long img_stride;  // bytes between consecutive images of this level
     u8* base;              // level buffer (levels >= 1); level 0 comes from the caller
     u8* blur;              // blurred level (all levels), same pitch / stride as the level buffers
-    int tile_off, tiles_x; // blur tiles of this level in the per-image tile numbering
+    int strip_stride, n_strips, n_bands, unit_off;  // streaming blur: column strips x row bands of this level
     int ncols, nrows, wcell, hcell;
     int cell_off;          // first cell of this level in the per-image cell arrays
     int nfeat;             // features wanted on this level
@@ -69,7 +70,7 @@ struct Layout
     int n_levels;
     int total_cells;
     int total_slots;
-    int total_tiles;
+    int total_units;
     int level_cap;
     // per-wavefront LDS slice of fast_kernel (bytes; sized from the largest cell of the layout)
     int f_tile_pitch_dw, f_s_pitch, f_off_s, f_off_surv, f_off_list, f_off_cnt, f_lds_wave;
@@ -392,80 +393,128 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// 7x7 Gaussian {18,33,49,56,49,33,18}/256 over whole levels (what the descriptors sample).
-// One workgroup = 64x16 output tile: 22x80-byte input tile in LDS (aligned dword loads, reflect-101
-// at the image border), horizontal pass with v_alignbyte + v_dot4_u32_u8 (exact 16-bit rows),
-// vertical pass with one rounding, 4 pixels per lane and one dword store.
+// 7x7 Gaussian {18,33,49,56,49,33,18}/256 of every level (what the descriptors sample), streaming:
+// one WAVEFRONT walks down a column strip of 62 x 4 output pixels (lane = one aligned dword per row,
+// lanes 0 / 63 are the 3-pixel halo) through a band of 64 rows with the 7-row window held in
+// registers — no LDS staging, no halo re-reads inside the band, one coalesced 256-byte load and one
+// 248-byte store per row.  Per row: neighbour dwords by lane shuffle, horizontal pass with
+// v_alignbyte + v_dot4_u32_u8 (exact 16-bit rows), vertical pass over the register window, one rounding.
 // ------------------------------------------------------------------------------------------------
-constexpr int BT_W = 64, BT_H = 16;
-constexpr int BT_PITCH_DW = 20;
-constexpr int BT_WAVE_DW  = (BT_H + 6) * BT_PITCH_DW + (BT_H + 6) * 32;  // tile | 16-bit rows
+constexpr int SM_BH        = 64;         // output rows per band
+constexpr int SM_ROWS      = SM_BH + 6;  // rows streamed per band = 10 * 7 (the window index stays static)
+constexpr int SM_LANES_OUT = 62;
 
-// One WAVEFRONT per 64x16 output tile (4 tiles per workgroup, no workgroup barriers).
 __global__ __launch_bounds__(256) void blur_kernel(Layout L, const u8* __restrict__ img0, int pitch0, long long stride0,
                                                    int aligned0)
 {
-    __shared__ u32 lds[4 * BT_WAVE_DW];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b    = blockIdx.y;
-    const int tl   = blockIdx.x * 4 + wave;
-    if (tl >= L.total_tiles) return;  // whole wavefront
-    u32* tile_dw = lds + wave * BT_WAVE_DW;
-    u32* hb      = tile_dw + (BT_H + 6) * BT_PITCH_DW;  // 64 u16 per row
+    const int unit = blockIdx.x * 4 + wave;
+    if (unit >= L.total_units) return;  // whole wavefront
     int l = 0;
-    while (l + 1 < L.n_levels && tl >= L.lv[l + 1].tile_off) ++l;
+    while (l + 1 < L.n_levels && unit >= L.lv[l + 1].unit_off) ++l;
     const LevelInfo& lv = L.lv[l];
-    const int t   = tl - lv.tile_off;
-    const int ty  = t / lv.tiles_x, tx = t - ty * lv.tiles_x;
-    const int x0 = tx * BT_W, y0 = ty * BT_H;
+    const int u     = unit - lv.unit_off;
+    const int band  = u / lv.n_strips, strip = u - band * lv.n_strips;
+    const int sx0   = strip * lv.strip_stride;
+    const int sx1   = min(sx0 + lv.strip_stride, lv.w);
+    const int xl    = sx0 - 4 + 4 * lane;  // image column of this lane's dword
+    const int yb0   = band * SM_BH, yb1 = min(yb0 + SM_BH, lv.h);
+    const bool out_lane = lane >= 1 && lane <= SM_LANES_OUT && xl < sx1;
     const u8* src      = l == 0 ? img0 + (long long)b * stride0 : lv.base + (long long)b * lv.img_stride;
     const int pitch    = l == 0 ? pitch0 : lv.pitch;
     const bool aligned = l == 0 ? aligned0 != 0 : true;
-    load_tile<6>(tile_dw, BT_PITCH_DW, src, pitch, lv.w, lv.h, x0 - 4, y0 - 3, BT_PITCH_DW, BT_H + 6, aligned, lane, 64);
-    __builtin_amdgcn_wave_barrier();
+    const bool col_ok  = aligned && xl >= 0 && xl + 3 < lv.w;
+    const int xsafe    = min(max(xl, 0), (lv.w - 4) & ~3);  // aligned, inside the row
+    const int xr0 = reflect101(xl, lv.w), xr1 = reflect101(xl + 1, lv.w), xr2 = reflect101(xl + 2, lv.w), xr3 = reflect101(xl + 3, lv.w);
+    u8* blur = lv.blur + (long long)b * lv.img_stride;
     const u32 W0123 = 18u | (33u << 8) | (49u << 16) | (56u << 24);
     const u32 W456  = 49u | (33u << 8) | (18u << 16);
-    for (int i = lane; i < (BT_H + 6) * 16; i += 64)
+
+    u32 h01[7], h23[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) h01[k] = h23[k] = 0;
+
+    for (int k0 = 0; k0 < SM_ROWS; k0 += 7)
     {
-        const int r = i >> 4, g = i & 15;
-        const u32 d0 = tile_dw[r * BT_PITCH_DW + g], d1 = tile_dw[r * BT_PITCH_DW + g + 1], d2 = tile_dw[r * BT_PITCH_DW + g + 2];
-        // output column 4g + j reads tile bytes 4g + 1 + j .. 4g + 7 + j
-        const u32 a = __builtin_amdgcn_alignbyte(d1, d0, 1), bq = __builtin_amdgcn_alignbyte(d2, d1, 1), cq = d2 >> 8;
-        u32 o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
+        // The 7 row loads of a block are issued together and branch-free (a divergent branch around a
+        // load makes the compiler wait for it inside the branch): every lane loads an aligned dword
+        // from a clamped column; lanes on the image border are patched afterwards (border strips only).
+        u32 dn[7];
+        if (aligned)  // wave-uniform
         {
-            const u32 q  = j == 0 ? a : __builtin_amdgcn_alignbyte(bq, a, j);
-            const u32 rq = j == 0 ? bq : __builtin_amdgcn_alignbyte(cq, bq, j);
-            o[j]         = __builtin_amdgcn_udot4(q, W0123, __builtin_amdgcn_udot4(rq, W456, 0u, false), false);
-        }
-        hb[r * 32 + 2 * g]     = o[0] | (o[1] << 16);
-        hb[r * 32 + 2 * g + 1] = o[2] | (o[3] << 16);
-    }
-    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
-    {
-        const int i = lane + 64 * it;
-        const int r = i >> 4, g = i & 15;
-        const int y = y0 + r, x = x0 + 4 * g;
-        if (y < lv.h && x < lv.w)
-        {
-            const int wk[7] = {18, 33, 49, 56, 49, 33, 18};
-            u32 acc[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int k = 0; k < 7; ++k)
+            for (int kk = 0; kk < 7; ++kk)
             {
-                const u32 lo = hb[(r + k) * 32 + 2 * g], hi = hb[(r + k) * 32 + 2 * g + 1];
-                acc[0] += (u32)wk[k] * (lo & 0xFFFFu);
-                acc[1] += (u32)wk[k] * (lo >> 16);
-                acc[2] += (u32)wk[k] * (hi & 0xFFFFu);
-                acc[3] += (u32)wk[k] * (hi >> 16);
+                const int y  = min(yb0 - 3 + k0 + kk, lv.h + 2);
+                const u8* rp = src + (long long)reflect101(y, lv.h) * pitch;
+                dn[kk]       = *reinterpret_cast<const u32*>(rp + xsafe);
             }
-            const u32 packed = ((acc[0] + 32768u) >> 16) | (((acc[1] + 32768u) >> 16) << 8) | (((acc[2] + 32768u) >> 16) << 16) |
-                               (((acc[3] + 32768u) >> 16) << 24);
-            u8* dst = lv.blur + (long long)b * lv.img_stride + (long long)y * lv.pitch + x;
-            *reinterpret_cast<u32*>(dst) = packed;  // pitch is a multiple of 64: columns up to the pitch exist
+            if (__any(!col_ok))  // wave-uniform
+            {
+#pragma unroll
+                for (int kk = 0; kk < 7; ++kk)
+                    if (!col_ok)
+                    {
+                        const int y  = min(yb0 - 3 + k0 + kk, lv.h + 2);
+                        const u8* rp = src + (long long)reflect101(y, lv.h) * pitch;
+                        dn[kk] = (u32)rp[xr0] | ((u32)rp[xr1] << 8) | ((u32)rp[xr2] << 16) | ((u32)rp[xr3] << 24);
+                    }
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int kk = 0; kk < 7; ++kk)
+            {
+                const int y  = min(yb0 - 3 + k0 + kk, lv.h + 2);
+                const u8* rp = src + (long long)reflect101(y, lv.h) * pitch;
+                dn[kk] = (u32)rp[xr0] | ((u32)rp[xr1] << 8) | ((u32)rp[xr2] << 16) | ((u32)rp[xr3] << 24);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 7; ++kk)
+        {
+            const int k = k0 + kk;
+            const int y = yb0 - 3 + k;
+            if (y <= yb1 + 2)  // wave-uniform
+            {
+                const u32 d  = dn[kk];
+                const u32 dl = __shfl_up(d, 1), dr = __shfl_down(d, 1);
+                // horizontal pass: stream bytes [dl | d | dr], output j centred on byte 4 + j
+                const u32 q0 = __builtin_amdgcn_alignbyte(d, dl, 1), q1 = __builtin_amdgcn_alignbyte(d, dl, 2),
+                          q2 = __builtin_amdgcn_alignbyte(d, dl, 3);
+                const u32 r0 = __builtin_amdgcn_alignbyte(dr, d, 1), r1 = __builtin_amdgcn_alignbyte(dr, d, 2),
+                          r2 = __builtin_amdgcn_alignbyte(dr, d, 3);
+                const u32 o0 = __builtin_amdgcn_udot4(q0, W0123, __builtin_amdgcn_udot4(r0, W456, 0u, false), false);
+                const u32 o1 = __builtin_amdgcn_udot4(q1, W0123, __builtin_amdgcn_udot4(r1, W456, 0u, false), false);
+                const u32 o2 = __builtin_amdgcn_udot4(q2, W0123, __builtin_amdgcn_udot4(r2, W456, 0u, false), false);
+                const u32 o3 = __builtin_amdgcn_udot4(d, W0123, __builtin_amdgcn_udot4(dr, W456, 0u, false), false);
+                h01[kk] = o0 | (o1 << 16);
+                h23[kk] = o2 | (o3 << 16);
+                const int yo = y - 3;  // the row whose 7-row window is now complete
+                if (k >= 6 && yo < yb1)
+                {
+                    // vertical pass: rows yo-3 .. yo+3 sit in slots (kk+1)%7 .. (kk+7)%7
+                    const u32 wk[7] = {18, 33, 49, 56, 49, 33, 18};
+                    u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+                    for (int i = 0; i < 7; ++i)
+                    {
+                        const int sl = (kk + 1 + i) % 7;
+                        a0 += wk[i] * (h01[sl] & 0xFFFFu);
+                        a1 += wk[i] * (h01[sl] >> 16);
+                        a2 += wk[i] * (h23[sl] & 0xFFFFu);
+                        a3 += wk[i] * (h23[sl] >> 16);
+                    }
+                    if (out_lane)
+                    {
+                        const u32 packed = ((a0 + 32768u) >> 16) | (((a1 + 32768u) >> 16) << 8) | (((a2 + 32768u) >> 16) << 16) |
+                                           (((a3 + 32768u) >> 16) << 24);
+                        *reinterpret_cast<u32*>(blur + (long long)yo * lv.pitch + xl) = packed;
+                    }
+                }
+            }
         }
     }
 }
@@ -1103,13 +1152,16 @@ static int compute_layout(snk_orb* o, int w, int h)
         slot_off += lv.slot_cap;
         lv.pitch      = (lv.w + 63) & ~63;
         lv.img_stride = (long long)lv.pitch * lv.h;
-        lv.tiles_x    = ceil_div(lv.w, BT_W);
-        lv.tile_off   = tile_off;
-        tile_off += lv.tiles_x * ceil_div(lv.h, BT_H);
+        // streaming blur: balanced strips of <= 62 dwords, bands of 64 rows
+        lv.n_strips     = ceil_div(lv.w, 4 * SM_LANES_OUT);
+        lv.strip_stride = ((ceil_div(lv.w, lv.n_strips) + 3) / 4) * 4;
+        lv.n_bands      = ceil_div(lv.h, SM_BH);
+        lv.unit_off     = tile_off;
+        tile_off += lv.n_strips * lv.n_bands;
     }
     L.total_cells = cell_off;
     L.total_slots = slot_off;
-    L.total_tiles = tile_off;
+    L.total_units = tile_off;
     {
         int mw = 1, mh = 1;
         for (int l = 0; l < p.n_levels; ++l)
@@ -1347,7 +1399,7 @@ static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long i
     }
     const int aligned0 = (reinterpret_cast<uintptr_t>(images_dev) % 4 == 0 && pitch % 4 == 0 && image_stride % 4 == 0) ? 1 : 0;
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[1], o->stream));
-    hipLaunchKernelGGL(blur_kernel, dim3(ceil_div(L.total_tiles, 4), batch), dim3(256), 0, o->stream, L, images_dev, pitch,
+    hipLaunchKernelGGL(blur_kernel, dim3(ceil_div(L.total_units, 4), batch), dim3(256), 0, o->stream, L, images_dev, pitch,
                        image_stride, aligned0);
     SNK_LAUNCH_CHECK();
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[2], o->stream));
