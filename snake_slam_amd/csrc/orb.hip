@@ -134,6 +134,29 @@ __device__ __forceinline__ void load_tile(u32* tile, int pitch_dw, const u8* __r
 {
     const int lc    = ndw <= 8 ? 3 : (ndw <= 16 ? 4 : (ndw <= 32 ? 5 : 6));
     const int total = nrows << lc;
+    if (aligned && xs >= 0 && xs + 4 * ndw <= w && ys >= 0 && ys + nrows <= h)
+    {
+        // interior tile (tile-uniform test): branch-free aligned dword loads, BATCH requests in flight
+        for (int i0 = tid; i0 < total; i0 += nthreads * BATCH)
+        {
+            u32 v[BATCH];
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k)
+            {
+                const int i = min(i0 + k * nthreads, total - 1);
+                const int r = i >> lc, d = min(i & ((1 << lc) - 1), ndw - 1);
+                v[k]        = *reinterpret_cast<const u32*>(src + (long long)(ys + r) * pitch + xs + 4 * d);
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k)
+            {
+                const int i = i0 + k * nthreads;
+                const int r = i >> lc, d = i & ((1 << lc) - 1);
+                if (i < total && d < ndw) tile[r * pitch_dw + d] = v[k];
+            }
+        }
+        return;
+    }
     for (int i0 = tid; i0 < total; i0 += nthreads * BATCH)
     {
         u32 v[BATCH];
