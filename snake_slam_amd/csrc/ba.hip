@@ -24,6 +24,8 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <cstdlib>
+#include <map>
 #include <vector>
 
 namespace snk
@@ -300,19 +302,18 @@ __global__ __launch_bounds__(128) void point_pass(Arrays A, Opt O)
     }
 }
 
-// fixed-order sum of one double per thread over the workgroup (power-of-two size)
+// fixed-order sum of one double per thread over the workgroup: xor butterfly inside each wavefront
+// (shuffles, no barrier), then the wavefront totals in order — 2 barriers instead of log2(THREADS)+1.
 template <int THREADS>
 __device__ __forceinline__ double block_sum(double v, double* red, int tid)
 {
-    red[tid] = v;
-    __syncthreads();
 #pragma unroll
-    for (int off = THREADS / 2; off > 0; off >>= 1)
-    {
-        if (tid < off) red[tid] += red[tid + off];
-        __syncthreads();
-    }
-    const double t = red[0];
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double t = red[0];
+#pragma unroll
+    for (int w = 1; w < THREADS / 64; ++w) t += red[w];
     __syncthreads();
     return t;
 }
@@ -781,6 +782,12 @@ struct snk_ba : HandleBase
         d_cost_new, d_U, d_camstart, d_camitems, d_blkstart, d_blkent, d_S, d_rhs, d_x, d_chi2;
     Arrays arr{};
     std::vector<int> orig_off, orig_n;
+    std::map<int, hipGraphExec_t> graphs;  // LM launch sequence captured per iteration count
+    void drop_graphs()
+    {
+        for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
+        graphs.clear();
+    }
 };
 
 namespace
@@ -837,6 +844,7 @@ int snk_ba_destroy(snk_ba* h)
                      &h->d_bp, &h->d_cost, &h->d_cost_new, &h->d_U, &h->d_camstart, &h->d_camitems, &h->d_blkstart,
                      &h->d_blkent, &h->d_S, &h->d_rhs, &h->d_x, &h->d_chi2};
     for (DevBuf* b : all) b->release();
+    h->drop_graphs();
     h->fini();
     delete h;
     return SNK_OK;
@@ -855,6 +863,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     SNK_REQUIRE(count >= 1 && count <= 65535 && problems != nullptr, "count must be 1..65535");
     SNK_HIP_CHECK(hipSetDevice(h->device));
     SNK_HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->drop_graphs();
 
     std::vector<Prob> probs((size_t)count);
     std::vector<double> pose, pt, ouv2, odepth, oweight;
@@ -1139,11 +1148,8 @@ int snk_ba_reset(snk_ba* h)
     return SNK_OK;
 }
 
-int snk_ba_solve_async(snk_ba* h, int iterations)
+static int enqueue_lm(snk_ba* h, int iterations)
 {
-    SNK_REQUIRE(h != nullptr && h->count > 0, "no problem set");
-    SNK_REQUIRE(iterations >= 0, "negative iteration count");
-    SNK_HIP_CHECK(hipSetDevice(h->device));
     const Opt O     = make_opt(h->opt);
     const Arrays& A = h->arr;
     hipStream_t st  = h->stream;
@@ -1169,6 +1175,47 @@ int snk_ba_solve_async(snk_ba* h, int iterations)
         hipLaunchKernelGGL(accept_pass, dim3(B), dim3(ACC_THREADS), 0, st, A);
         SNK_LAUNCH_CHECK();
     }
+    return SNK_OK;
+}
+
+// The LM loop is a fixed launch sequence (all decisions are taken on the device), so it is captured
+// once per iteration count into a hipGraph and replayed: one graph launch instead of 7 launches per
+// iteration.  SNK_BA_NO_GRAPH=1 falls back to plain launches.
+int snk_ba_solve_async(snk_ba* h, int iterations)
+{
+    SNK_REQUIRE(h != nullptr && h->count > 0, "no problem set");
+    SNK_REQUIRE(iterations >= 0, "negative iteration count");
+    SNK_HIP_CHECK(hipSetDevice(h->device));
+    static const bool no_graph = getenv("SNK_BA_NO_GRAPH") != nullptr;
+    if (no_graph || iterations == 0) return enqueue_lm(h, iterations);
+    auto it = h->graphs.find(iterations);
+    if (it == h->graphs.end())
+    {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            return enqueue_lm(h, iterations);
+        }
+        const int rc = enqueue_lm(h, iterations);
+        const hipError_t e = hipStreamEndCapture(h->stream, &graph);
+        if (rc != SNK_OK || e != hipSuccess || graph == nullptr)
+        {
+            (void)hipGetLastError();
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc != SNK_OK ? rc : enqueue_lm(h, iterations);
+        }
+        hipGraphExec_t exec = nullptr;
+        const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ei != hipSuccess || exec == nullptr)
+        {
+            (void)hipGetLastError();
+            return enqueue_lm(h, iterations);
+        }
+        it = h->graphs.emplace(iterations, exec).first;
+    }
+    SNK_HIP_CHECK(hipGraphLaunch(it->second, h->stream));
     return SNK_OK;
 }
 

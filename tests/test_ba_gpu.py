@@ -109,3 +109,20 @@ def test_batched_windows_match_single(orc):
         pose, pt, _ = ba.state(k)
         assert np.array_equal(pose, p1[k][0]) and np.array_equal(pt, p1[k][1])
     ba.close()
+
+
+def test_global_ba_scale_and_pose_only(orc):
+    """GlobalBundleAdjustment uses the same solver seam with a bigger scene
+    (reference Snake/Optimizer/GlobalBundleAdjustment.cpp:32-43: PCG 40), and PoseRefinement is the
+    same residual with every point constant."""
+    from snake_slam_amd import synth
+
+    # "global" scene: 120 keyframes, 6000 points, reduced system 714 x 714 (S stays in global memory)
+    sc, gt = synth.ba_scene(n_kf=120, n_pt=6000, obs_per_pt=10, seed=31, n_fixed=1)
+    ci, cf, pose, pt = compare(orc, sc, dict(max_iterations=4, max_pcg_iterations=40))
+    assert cf < 0.05 * ci
+    # pose-only: all points constant, cameras free except the first
+    sc2, _ = synth.ba_scene(n_kf=6, n_pt=400, obs_per_pt=6, seed=32)
+    sc2["pt_const"][:] = 1
+    ci, cf, pose, pt = compare(orc, sc2)
+    assert np.array_equal(pt, sc2["pt"]) and cf < ci
