@@ -45,6 +45,7 @@ __constant__ signed char c_pattern[1024] = {
 #include "brief_pattern_31.inc"
 };
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+constexpr unsigned long long UMAX_PACKED = 0x3689abcddeeeffffull;  // the same table, 4 bits per entry (no memory access)
 
 struct LevelInfo
 {
@@ -1011,25 +1012,31 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
         // 31 rows x 9 aligned dwords cover columns kx-15 .. kx+15 (byte offset sh2 inside the first dword)
         const int xa  = (kx - 15) & ~3;
         const int sh2 = (kx - 15) - xa;
+        // branch-free: the 5 dword loads of a lane are all in flight before the first use
+        u32 dwv[5];
+        int rowv[5], dv[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k)
         {
-            const int item = lane + 64 * k;
-            if (item < 31 * 9)
-            {
-                const int row = item / 9, d = item - row * 9;
-                const int vy  = row - 15;
-                const int lim = c_umax[vy < 0 ? -vy : vy];
-                const u32 dwv = *reinterpret_cast<const u32*>(src + (long long)(ky + vy) * pitch + xa + 4 * d);
+            const int item = min(lane + 64 * k, 31 * 9 - 1);
+            rowv[k]        = item / 9;
+            dv[k]          = item - rowv[k] * 9;
+            dwv[k]         = *reinterpret_cast<const u32*>(src + (long long)(ky + rowv[k] - 15) * pitch + xa + 4 * dv[k]);
+        }
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                {
-                    const int ux = 4 * d + j - sh2 - 15;
-                    const int au = ux < 0 ? -ux : ux;
-                    const int p  = au <= lim ? (int)((dwv >> (8 * j)) & 0xFFu) : 0;
-                    m10 += ux * p;
-                    m01 += vy * p;
-                }
+        for (int k = 0; k < 5; ++k)
+        {
+            const bool live = lane + 64 * k < 31 * 9;
+            const int vy    = rowv[k] - 15;
+            const int lim   = live ? (int)((UMAX_PACKED >> (4 * (vy < 0 ? -vy : vy))) & 0xFull) : -1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                const int ux = 4 * dv[k] + j - sh2 - 15;
+                const int au = ux < 0 ? -ux : ux;
+                const int p  = au <= lim ? (int)((dwv[k] >> (8 * j)) & 0xFFu) : 0;
+                m10 += ux * p;
+                m01 += vy * p;
             }
         }
     }
