@@ -7,9 +7,9 @@
 // scalar restatement.
 //
 // Pipeline (all kernels batched over B images, blockIdx.y/z = image):
-//   resize_kernel      level l-1 -> level l, 11-bit fixed-point bilinear       (L-1 launches)
-//   blur_kernel        7x7 Gaussian of every level, streaming: a wavefront walks down a 248-px column
-//                      strip with the 7-row window in registers (v_alignbyte + v_dot4_u32_u8)
+//   level_kernel       one streaming pass per level (L launches): a wavefront walks down a 248-px column
+//                      strip with the 7-row window in registers; 7x7 Gaussian of level l (v_alignbyte +
+//                      v_dot4_u32_u8) and the 11-bit fixed-point bilinear down-scale to level l+1
 //   fast_kernel        one workgroup per ~30x30 FAST cell: image tile -> LDS (aligned dwords), quick
 //                      opposite-pair bound on every pixel, compaction, exact FAST-9/16 score of the
 //                      survivors in packed 16-bit lanes, in-cell 3x3 NMS, ini/min threshold fallback,
@@ -53,7 +53,9 @@ struct LevelInfo
     long long img_stride;  // bytes between consecutive images of this level
     u8* base;              // level buffer (levels >= 1); level 0 comes from the caller
     u8* blur;              // blurred level (all levels), same pitch / stride as the level buffers
-    int strip_stride, n_strips, n_bands, unit_off;  // streaming blur: column strips x row bands of this level
+    int strip_stride, n_strips, n_bands, unit_off;  // streaming pass: column strips x row bands of this level
+    const int* ymap;      // [h] destination row of level l+1 whose upper source row is this row, or -1
+    const int* strip_dx;  // [n_strips + 1] first destination column of level l+1 fed by each strip
     int ncols, nrows, wcell, hcell;
     int cell_off;          // first cell of this level in the per-image cell arrays
     int nfeat;             // features wanted on this level
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
                                                    u16* __restrict__ cell_cnt, int dbg_stop)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int b    = blockIdx.y;
     const int cid  = blockIdx.x * 4 + wave;
     if (cid >= L.total_cells) return;  // whole wavefront
@@ -428,17 +430,28 @@ constexpr int SM_BH        = 64;         // output rows per band
 constexpr int SM_ROWS      = SM_BH + 6;  // rows streamed per band = 10 * 7 (the window index stays static)
 constexpr int SM_LANES_OUT = 62;
 
-__global__ __launch_bounds__(256) void blur_kernel(Layout L, const u8* __restrict__ img0, int pitch0, long long stride0,
-                                                   int aligned0)
+// The same pass also produces level l+1 (make_next): whenever the stream holds source rows sy, sy+1
+// of a destination row, the two raw rows go to a 512-byte LDS buffer of the wavefront and every lane
+// interpolates 4 destination pixels (its column taps / weights are loop-invariant registers).  Each
+// level is therefore read from HBM exactly once for blur + pyramid.
+__device__ __forceinline__ u32 wave_shr1(u32 v) { return __builtin_amdgcn_update_dpp(0u, v, 0x138, 0xf, 0xf, false); }  // lane i <- i-1
+__device__ __forceinline__ u32 wave_shl1(u32 v) { return __builtin_amdgcn_update_dpp(0u, v, 0x130, 0xf, 0xf, false); }  // lane i <- i+1
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32 dot2(u32 pair, u32 w, u32 acc)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pair), __builtin_bit_cast(u16x2, w), acc, false);
+}
+__device__ __forceinline__ u32 mad24(u32 a, u32 b, u32 c) { return __umul24(a, b) + c; }
+
+__global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* __restrict__ img0, int pitch0, long long stride0,
+                                                    int aligned0, int make_next)
+{
+    __shared__ u32 rowbuf[4][64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int b    = blockIdx.y;
-    const int unit = blockIdx.x * 4 + wave;
-    if (unit >= L.total_units) return;  // whole wavefront
-    int l = 0;
-    while (l + 1 < L.n_levels && unit >= L.lv[l + 1].unit_off) ++l;
     const LevelInfo& lv = L.lv[l];
-    const int u     = unit - lv.unit_off;
+    const int u    = blockIdx.x * 4 + wave;
+    if (u >= lv.n_strips * lv.n_bands) return;  // whole wavefront
     const int band  = u / lv.n_strips, strip = u - band * lv.n_strips;
     const int sx0   = strip * lv.strip_stride;
     const int sx1   = min(sx0 + lv.strip_stride, lv.w);
@@ -455,9 +468,47 @@ __global__ __launch_bounds__(256) void blur_kernel(Layout L, const u8* __restric
     const u32 W0123 = 18u | (33u << 8) | (49u << 16) | (56u << 24);
     const u32 W456  = 49u | (33u << 8) | (18u << 16);
 
-    u32 h01[7], h23[7];
+    // ---- loop-invariant set-up of the down-scale (destination pixels xdst .. xdst + 3 of this lane) ----
+    const LevelInfo& nx = L.lv[make_next ? l + 1 : l];
+    u8* nbase           = make_next ? nx.base + (long long)b * nx.img_stride : nullptr;
+    const u8* rb        = reinterpret_cast<const u8*>(rowbuf[wave]);
+    int so[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    u32 wx0[4] = {0, 0, 0, 0}, wx1[4] = {0, 0, 0, 0};
+    u32 vmask = 0;
+    int xdst  = 0;
+    if (make_next)
+    {
+        const int x_lo = lv.strip_dx[strip], x_hi = lv.strip_dx[strip + 1];
+        xdst           = (x_lo & ~3) + 4 * lane;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) h01[k] = h23[k] = 0;
+        for (int j = 0; j < 4; ++j)
+        {
+            const int x = xdst + j;
+            if (x >= x_lo && x < x_hi)
+            {
+                vmask |= 1u << j;
+                const int sx = nx.xofs[x];
+                so[j]  = sx - (sx0 - 4);
+                s1[j]  = min(sx + 1, lv.w - 1) - (sx0 - 4);
+                wx1[j] = (u32)nx.xw1[x];
+                wx0[j] = 2048u - wx1[j];
+            }
+        }
+    }
+    u32 ap[4] = {0, 0, 0, 0};  // horizontally interpolated previous row (<= 255 * 2048)
+    // lane r keeps the destination row / y weight of source row yb0 + r (read back with v_readlane:
+    // dependent scalar loads inside the row loop would serialise it)
+    int dy_tab = -1, wy_tab = 0;
+    if (make_next && yb0 + lane < yb1)
+    {
+        dy_tab = lv.ymap[yb0 + lane];
+        if (dy_tab >= 0) wy_tab = nx.yw1[dy_tab];
+    }
+
+    // vertical window: pr[s][c] = H(row a) | H(row a + 1) << 16 of column c, written in slot (a + 1 - (yb0 - 3)) % 7
+    u32 pr[7][4], hp[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 7; ++k) pr[k][0] = pr[k][1] = pr[k][2] = pr[k][3] = 0;
 
     for (int k0 = 0; k0 < SM_ROWS; k0 += 7)
     {
@@ -503,40 +554,80 @@ __global__ __launch_bounds__(256) void blur_kernel(Layout L, const u8* __restric
             const int y = yb0 - 3 + k;
             if (y <= yb1 + 2)  // wave-uniform
             {
-                const u32 d  = dn[kk];
-                const u32 dl = __shfl_up(d, 1), dr = __shfl_down(d, 1);
-                // horizontal pass: stream bytes [dl | d | dr], output j centred on byte 4 + j
+                const u32 d = dn[kk];
+                // ---- next pyramid level.  Row y is interpolated horizontally once (ac); a destination
+                // row whose source rows are (y-1, y) combines it with the previous row's (ap).  All
+                // products are < 2^24 x 2^24 -> v_mad_u32_u24; with the y weights pre-multiplied by 4
+                // the rounded pixel is byte 3 of the sum (<= 255 * 2^24 + 2^23).
+                if (make_next && y >= yb0 && y <= yb1)  // wave-uniform
+                {
+                    rowbuf[wave][lane] = d;
+                    __builtin_amdgcn_wave_barrier();
+                    u32 ac[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ac[j] = mad24(rb[so[j]], wx0[j], __umul24(rb[s1[j]], wx1[j]));
+                    __builtin_amdgcn_wave_barrier();
+                    const int dy = y > yb0 ? __builtin_amdgcn_readlane(dy_tab, y - 1 - yb0) : -1;
+                    if (dy >= 0)  // wave-uniform
+                    {
+                        const u32 wy1 = 4u * (u32)__builtin_amdgcn_readlane(wy_tab, y - 1 - yb0), wy0 = 8192u - wy1;
+                        u32 v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = mad24(ap[j], wy0, mad24(ac[j], wy1, 1u << 23));
+                        const u32 lo     = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0703u);  // byte 3 of v0, v1
+                        const u32 hi     = __builtin_amdgcn_perm(v[3], v[2], 0x07030c0cu);  // byte 3 of v2, v3 in the top half
+                        const u32 packed = lo | hi;
+                        u8* dp           = nbase + (long long)dy * nx.pitch + xdst;
+                        if (vmask == 0xFu)
+                            *reinterpret_cast<u32*>(dp) = packed;
+                        else if (vmask)
+                        {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (vmask & (1u << j)) dp[j] = (u8)(packed >> (8 * j));
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ap[j] = ac[j];
+                }
+                // ---- horizontal pass: stream bytes [dl | d | dr], output j centred on byte 4 + j ----
+                const u32 dl = wave_shr1(d), dr = wave_shl1(d);
                 const u32 q0 = __builtin_amdgcn_alignbyte(d, dl, 1), q1 = __builtin_amdgcn_alignbyte(d, dl, 2),
                           q2 = __builtin_amdgcn_alignbyte(d, dl, 3);
                 const u32 r0 = __builtin_amdgcn_alignbyte(dr, d, 1), r1 = __builtin_amdgcn_alignbyte(dr, d, 2),
                           r2 = __builtin_amdgcn_alignbyte(dr, d, 3);
-                const u32 o0 = __builtin_amdgcn_udot4(q0, W0123, __builtin_amdgcn_udot4(r0, W456, 0u, false), false);
-                const u32 o1 = __builtin_amdgcn_udot4(q1, W0123, __builtin_amdgcn_udot4(r1, W456, 0u, false), false);
-                const u32 o2 = __builtin_amdgcn_udot4(q2, W0123, __builtin_amdgcn_udot4(r2, W456, 0u, false), false);
-                const u32 o3 = __builtin_amdgcn_udot4(d, W0123, __builtin_amdgcn_udot4(dr, W456, 0u, false), false);
-                h01[kk] = o0 | (o1 << 16);
-                h23[kk] = o2 | (o3 << 16);
-                const int yo = y - 3;  // the row whose 7-row window is now complete
+                u32 hc[4];
+                hc[0] = __builtin_amdgcn_udot4(q0, W0123, __builtin_amdgcn_udot4(r0, W456, 0u, false), false);
+                hc[1] = __builtin_amdgcn_udot4(q1, W0123, __builtin_amdgcn_udot4(r1, W456, 0u, false), false);
+                hc[2] = __builtin_amdgcn_udot4(q2, W0123, __builtin_amdgcn_udot4(r2, W456, 0u, false), false);
+                hc[3] = __builtin_amdgcn_udot4(d, W0123, __builtin_amdgcn_udot4(dr, W456, 0u, false), false);
+                // ---- vertical pass of output row yo = y - 3: rows yo-3 .. yo+3 = pairs (y-6,y-5) (y-4,y-3)
+                // (y-2,y-1) from slots kk-5, kk-3, kk-1 and the row just computed; byte 2 of the rounded
+                // sum (<= 256 * 65280 + 32768 < 2^24) is the pixel ----
+                const int yo = y - 3;
                 if (k >= 6 && yo < yb1)
                 {
-                    // vertical pass: rows yo-3 .. yo+3 sit in slots (kk+1)%7 .. (kk+7)%7
-                    const u32 wk[7] = {18, 33, 49, 56, 49, 33, 18};
-                    u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                    u32 a[4];
 #pragma unroll
-                    for (int i = 0; i < 7; ++i)
+                    for (int c = 0; c < 4; ++c)
                     {
-                        const int sl = (kk + 1 + i) % 7;
-                        a0 += wk[i] * (h01[sl] & 0xFFFFu);
-                        a1 += wk[i] * (h01[sl] >> 16);
-                        a2 += wk[i] * (h23[sl] & 0xFFFFu);
-                        a3 += wk[i] * (h23[sl] >> 16);
+                        u32 t = mad24(hc[c], 18u, 32768u);
+                        t     = dot2(pr[(kk + 6) % 7][c], 49u | (33u << 16), t);
+                        t     = dot2(pr[(kk + 4) % 7][c], 49u | (56u << 16), t);
+                        a[c]  = dot2(pr[(kk + 2) % 7][c], 18u | (33u << 16), t);
                     }
                     if (out_lane)
                     {
-                        const u32 packed = ((a0 + 32768u) >> 16) | (((a1 + 32768u) >> 16) << 8) | (((a2 + 32768u) >> 16) << 16) |
-                                           (((a3 + 32768u) >> 16) << 24);
-                        *reinterpret_cast<u32*>(blur + (long long)yo * lv.pitch + xl) = packed;
+                        const u32 lo = __builtin_amdgcn_perm(a[1], a[0], 0x0c0c0602u);
+                        const u32 hi = __builtin_amdgcn_perm(a[3], a[2], 0x06020c0cu);
+                        *reinterpret_cast<u32*>(blur + (long long)yo * lv.pitch + xl) = lo | hi;
                     }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                {
+                    pr[kk][c] = hp[c] | (hc[c] << 16);
+                    hp[c]     = hc[c];
                 }
             }
         }
@@ -1314,23 +1405,43 @@ int snk_orb_configure(snk_orb* o, int width, int height, int max_batch)
     Layout& L = o->lay;
     // resize tables
     size_t tab_ints = 0;
-    for (int l = 1; l < L.n_levels; ++l) tab_ints += 2 * (size_t)(L.lv[l].w + L.lv[l].h);
+    for (int l = 1; l < L.n_levels; ++l)
+        tab_ints += 2 * (size_t)(L.lv[l].w + L.lv[l].h) + (size_t)L.lv[l - 1].h + (size_t)L.lv[l - 1].n_strips + 1;
     if ((rc = o->tables.reserve((tab_ints + 4) * sizeof(int))) != SNK_OK) return rc;
     {
         int* host = (int*)malloc((tab_ints + 4) * sizeof(int));
         size_t at = 0;
+        int* dev  = o->tables.as<int>();
         for (int l = 1; l < L.n_levels; ++l)
         {
             LevelInfo& lv = L.lv[l];
-            int* dev      = o->tables.as<int>();
+            LevelInfo& sv = L.lv[l - 1];
             lv.xofs = dev + at;
             lv.xw1  = dev + at + lv.w;
-            resize_tables(L.lv[l - 1].w, lv.w, host + at, host + at + lv.w);
+            int* xo = host + at;
+            resize_tables(sv.w, lv.w, host + at, host + at + lv.w);
             at += 2 * (size_t)lv.w;
             lv.yofs = dev + at;
             lv.yw1  = dev + at + lv.h;
-            resize_tables(L.lv[l - 1].h, lv.h, host + at, host + at + lv.h);
+            int* yo = host + at;
+            resize_tables(sv.h, lv.h, host + at, host + at + lv.h);
             at += 2 * (size_t)lv.h;
+            // inverse maps used by the streaming pass of the SOURCE level l-1
+            sv.ymap = dev + at;
+            for (int r = 0; r < sv.h; ++r) host[at + r] = -1;
+            for (int y = 0; y < lv.h; ++y) host[at + yo[y]] = y;  // source rows are distinct for scale > 1
+            at += (size_t)sv.h;
+            sv.strip_dx = dev + at;
+            {
+                int x = 0;
+                for (int st = 0; st <= sv.n_strips; ++st)
+                {
+                    const int lim = st * sv.strip_stride;  // first source column of strip st
+                    while (x < lv.w && xo[x] < lim) ++x;
+                    host[at + st] = st == sv.n_strips ? lv.w : x;
+                }
+            }
+            at += (size_t)sv.n_strips + 1;
         }
         hipError_t e = hipMemcpy(o->tables.p, host, tab_ints * sizeof(int), hipMemcpyHostToDevice);
         free(host);
@@ -1401,36 +1512,17 @@ static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long i
         ev = &o->ev_sets[o->ev_used++];
         SNK_HIP_CHECK(hipEventRecord((*ev)[0], o->stream));
     }
-    // pyramid chain
-    for (int l = 1; l < L.n_levels; ++l)
+    // one streaming pass per level: blur of level l + down-scale to level l+1 (the chain makes the
+    // passes sequential; every level is read once)
+    const int aligned0 = (reinterpret_cast<uintptr_t>(images_dev) % 4 == 0 && pitch % 4 == 0 && image_stride % 4 == 0) ? 1 : 0;
+    for (int l = 0; l < L.n_levels; ++l)
     {
-        const LevelInfo& d = L.lv[l];
-        const LevelInfo& s = L.lv[l - 1];
-        const u8* src      = l == 1 ? images_dev : s.base;
-        const int spitch   = l == 1 ? pitch : s.pitch;
-        const long long ss = l == 1 ? image_stride : s.img_stride;
-        // source rectangle of a 64x16 tile: (64, 16) * scale + 2 (+3 bytes of alignment slack)
-        const double sfx = (double)s.w / d.w, sfy = (double)s.h / d.h;
-        const bool tiled = RT_W * sfx + 8 <= RT_PITCH_DW * 4 && RT_H * sfy + 3 <= RT_ROWS;
-        if (tiled)
-        {
-            const int al = l == 1 ? (reinterpret_cast<uintptr_t>(images_dev) % 4 == 0 && pitch % 4 == 0 && image_stride % 4 == 0) : 1;
-            dim3 grid(ceil_div(d.w, RT_W), ceil_div(d.h, RT_H), batch);
-            hipLaunchKernelGGL(resize_tiled_kernel, grid, dim3(256), 0, o->stream, src, spitch, ss, s.w, s.h, al, d.base,
-                               d.pitch, d.img_stride, d.w, d.h, d.xofs, d.xw1, d.yofs, d.yw1);
-        }
-        else
-        {
-            dim3 grid(ceil_div(ceil_div(d.w, 4), 256), d.h, batch);
-            hipLaunchKernelGGL(resize_kernel, grid, dim3(256), 0, o->stream, src, spitch, ss, s.w, s.h, d.base, d.pitch,
-                               d.img_stride, d.w, d.h, d.xofs, d.xw1, d.yofs, d.yw1);
-        }
+        const LevelInfo& lv = L.lv[l];
+        hipLaunchKernelGGL(level_kernel, dim3(ceil_div(lv.n_strips * lv.n_bands, 4), batch), dim3(256), 0, o->stream, L, l,
+                           images_dev, pitch, image_stride, aligned0, l + 1 < L.n_levels ? 1 : 0);
         SNK_LAUNCH_CHECK();
     }
-    const int aligned0 = (reinterpret_cast<uintptr_t>(images_dev) % 4 == 0 && pitch % 4 == 0 && image_stride % 4 == 0) ? 1 : 0;
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[1], o->stream));
-    hipLaunchKernelGGL(blur_kernel, dim3(ceil_div(L.total_units, 4), batch), dim3(256), 0, o->stream, L, images_dev, pitch,
-                       image_stride, aligned0);
     SNK_LAUNCH_CHECK();
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[2], o->stream));
     if (L.total_cells > 0)
