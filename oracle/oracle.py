@@ -136,7 +136,7 @@ def candidates(img: np.ndarray, ini_th=20, min_th=7, cap=8192) -> np.ndarray:
 
 def distribute(cands: np.ndarray, w: int, h: int, N: int) -> np.ndarray:
     cands = np.ascontiguousarray(cands, CAND)
-    out = np.zeros(N + 8, np.int32)
+    out = np.zeros(lib().orc_orb_distribute_bound(w, h, N) + 8, np.int32)
     lib().orc_orb_distribute.restype = C.c_int
     n = lib().orc_orb_distribute(_p(cands), cands.shape[0], w, h, N, _p(out))
     return out[:n].copy()
@@ -190,7 +190,8 @@ def brief_pattern() -> np.ndarray:
 def orb_detect(p: OrbParams, img: np.ndarray, level_cap: int = 0, threads: int = 1):
     if img.dtype != np.uint8 or img.strides[1] != 1:
         img = np.ascontiguousarray(img, np.uint8)  # row pitch (strides[0]) may exceed the width
-    cap = p.nfeatures + 4 * p.n_levels + 8
+    L = orb_layout(p, img.shape[1], img.shape[0])
+    cap = sum(lib().orc_orb_distribute_bound(L.w[l], L.h[l], L.nfeat[l]) for l in range(L.n_levels)) + 8
     kps = np.zeros(cap, KEYPOINT)
     desc = np.zeros((cap, 4), np.uint64)
     lib().orc_orb_detect.restype = C.c_int

@@ -474,8 +474,18 @@ static int sel_cmp(const void* a, const void* b)
     return p->key < q->key ? -1 : (p->key > q->key ? 1 : 0);
 }
 
+/* Upper bound of the selection size for a w x h level: one careful split adds <= 3 nodes beyond N;
+ * the unconditional first pass turns every root into <= 4 nodes (wide levels: 4 * roots can exceed N). */
+int orc_orb_distribute_bound(int w, int h, int N)
+{
+    int W = w - 2 * MIN_BORDER, H = h - 2 * MIN_BORDER;
+    if (W <= 0 || H <= 0 || N <= 0) return 0;
+    int r = 4 * n_roots(W, H);
+    return N + 3 > r ? N + 3 : r;
+}
+
 /* Select up to ~N of the n candidates of a w x h level.  out_idx receives candidate indices in
- * output order; returns the number selected (<= N + 3). */
+ * output order (capacity orc_orb_distribute_bound); returns the number selected. */
 int orc_orb_distribute(const orc_cand* pts, int n, int w, int h, int N, int* out_idx)
 {
     if (n <= 0 || N <= 0) return 0;
@@ -811,7 +821,7 @@ int orc_orb_detect(const orc_orb_params* p, const uint8_t* img, int w, int h, in
         int lw = L.w[l], lh = L.h[l];
         orc_cand* cand = (orc_cand*)malloc(sizeof(orc_cand) * (size_t)level_cap);
         int nc         = orc_orb_candidates(levels[l], lw, lh, lw, p->ini_th, p->min_th, cand, level_cap);
-        int* sel       = (int*)malloc(sizeof(int) * (size_t)(L.nfeat[l] + 8));
+        int* sel       = (int*)malloc(sizeof(int) * (size_t)(orc_orb_distribute_bound(lw, lh, L.nfeat[l]) + 8));
         int ns         = orc_orb_distribute(cand, nc, lw, lh, L.nfeat[l], sel);
         uint8_t* blurred = (uint8_t*)malloc((size_t)lw * lh);
         orc_blur_image(levels[l], lw, lh, lw, blurred, lw);

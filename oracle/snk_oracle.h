@@ -77,6 +77,7 @@ int orc_fast_score(const uint8_t* img, int pitch, int x, int y);
 void orc_cell_grid(int w, int h, orc_cell_grid_t* g);
 int orc_orb_candidates(const uint8_t* img, int w, int h, int pitch, int ini_th, int min_th, orc_cand* out, int cap);
 uint64_t orc_point_key(int x, int y, int W, int H);
+int orc_orb_distribute_bound(int w, int h, int N); /* capacity of out_idx below */
 int orc_orb_distribute(const orc_cand* pts, int n, int w, int h, int N, int* out_idx);
 void orc_umax(int* umax);
 void orc_ic_moments(const uint8_t* img, int pitch, int x, int y, int* m10, int* m01);

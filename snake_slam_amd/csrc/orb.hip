@@ -55,7 +55,7 @@ struct LevelInfo
     u8* blur;              // blurred level (all levels), same pitch / stride as the level buffers
     int strip_stride, n_strips, n_bands, unit_off;  // streaming pass: column strips x row bands of this level
     const int* ymap;      // [h] destination row of level l+1 whose upper source row is this row, or -1
-    const int* strip_dx;  // [n_strips + 1] first destination column of level l+1 fed by each strip
+    const int* strip_dx;  // [n_strips + 1] first destination dword (4 px) of level l+1 owned by each strip
     int ncols, nrows, wcell, hcell;
     int cell_off;          // first cell of this level in the per-image cell arrays
     int nfeat;             // features wanted on this level
@@ -197,56 +197,6 @@ __device__ __forceinline__ void load_tile(u32* tile, int pitch_dw, const u8* __r
             if (dst[k] >= 0) tile[dst[k]] = v[k];
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// pyramid, tiled: one workgroup produces a 64x16 tile of level l from an LDS copy of the source
-// rectangle it needs (aligned dword loads), 4 output pixels per lane, one dword store.
-// ------------------------------------------------------------------------------------------------
-constexpr int RT_W = 64, RT_H = 16;
-constexpr int RT_PITCH_DW = 36;  // up to 144 source bytes per row
-constexpr int RT_ROWS     = 40;
-
-__global__ __launch_bounds__(256) void resize_tiled_kernel(const u8* __restrict__ src, int spitch, long long sstride, int sw,
-                                                           int sh, int aligned, u8* __restrict__ dst, int dpitch,
-                                                           long long dstride, int dw, int dh, const int* __restrict__ xofs,
-                                                           const int* __restrict__ xw1, const int* __restrict__ yofs,
-                                                           const int* __restrict__ yw1)
-{
-    __shared__ u32 tile_dw[RT_ROWS * RT_PITCH_DW];
-    const int b  = blockIdx.z;
-    const int x0 = blockIdx.x * RT_W, y0 = blockIdx.y * RT_H;
-    const int tid = threadIdx.x;
-    const int xl = min(x0 + RT_W - 1, dw - 1), yl = min(y0 + RT_H - 1, dh - 1);
-    const int sx_lo = xofs[x0], sx_hi = min(xofs[xl] + 1, sw - 1);
-    const int sy_lo = yofs[y0], sy_hi = min(yofs[yl] + 1, sh - 1);
-    const int xs    = sx_lo & ~3;
-    const int ndw   = ((sx_hi - xs) >> 2) + 1;
-    const int nrows = sy_hi - sy_lo + 1;
-    load_tile<8>(tile_dw, RT_PITCH_DW, src + (long long)b * sstride, spitch, sw, sh, xs, sy_lo, ndw, nrows, aligned != 0, tid, 256);
-    __syncthreads();
-    const u8* tile = reinterpret_cast<const u8*>(tile_dw);
-    const int y = y0 + (tid >> 4), x4 = x0 + 4 * (tid & 15);
-    if (y >= dh || x4 >= dw) return;
-    const int sy = yofs[y], wy1 = yw1[y], wy0 = 2048 - wy1;
-    const int sy1 = sy + 1 < sh ? sy + 1 : sh - 1;
-    const u8* r0  = tile + (sy - sy_lo) * (RT_PITCH_DW * 4) - xs;
-    const u8* r1  = tile + (sy1 - sy_lo) * (RT_PITCH_DW * 4) - xs;
-    u32 packed    = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-    {
-        const int x = x4 + k;
-        if (x < dw)
-        {
-            const int sx = xofs[x], wx1 = xw1[x], wx0 = 2048 - wx1;
-            const int sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
-            const int v   = ((int)r0[sx] * wx0 + (int)r0[sx1] * wx1) * wy0 + ((int)r1[sx] * wx0 + (int)r1[sx1] * wx1) * wy1;
-            packed |= (u32)((v + (1 << 21)) >> 22) << (8 * k);
-        }
-    }
-    u8* d = dst + (long long)b * dstride + (long long)y * dpitch + x4;
-    *reinterpret_cast<u32*>(d) = packed;  // dpitch is a multiple of 64: the padding columns exist
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -428,25 +378,24 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
 // ------------------------------------------------------------------------------------------------
 constexpr int SM_BH        = 64;         // output rows per band
 constexpr int SM_ROWS      = SM_BH + 6;  // rows streamed per band = 10 * 7 (the window index stays static)
-constexpr int SM_LANES_OUT = 62;
+constexpr int SM_LANES_OUT = 61;  // strip <= 244 columns: 8 loaded columns remain to the right for the down-scale taps
 
 // The same pass also produces level l+1 (make_next): whenever the stream holds source rows sy, sy+1
 // of a destination row, the two raw rows go to a 512-byte LDS buffer of the wavefront and every lane
 // interpolates 4 destination pixels (its column taps / weights are loop-invariant registers).  Each
 // level is therefore read from HBM exactly once for blur + pyramid.
-__device__ __forceinline__ u32 wave_shr1(u32 v) { return __builtin_amdgcn_update_dpp(0u, v, 0x138, 0xf, 0xf, false); }  // lane i <- i-1
-__device__ __forceinline__ u32 wave_shl1(u32 v) { return __builtin_amdgcn_update_dpp(0u, v, 0x130, 0xf, 0xf, false); }  // lane i <- i+1
+__device__ __forceinline__ u32 wave_shr1(u32 v) { return __builtin_amdgcn_mov_dpp(v, 0x138, 0xf, 0xf, true); }  // lane i <- i-1
+__device__ __forceinline__ u32 wave_shl1(u32 v) { return __builtin_amdgcn_mov_dpp(v, 0x130, 0xf, 0xf, true); }  // lane i <- i+1
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u32 dot2(u32 pair, u32 w, u32 acc)
 {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pair), __builtin_bit_cast(u16x2, w), acc, false);
 }
-__device__ __forceinline__ u32 mad24(u32 a, u32 b, u32 c) { return __umul24(a, b) + c; }
 
 __global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* __restrict__ img0, int pitch0, long long stride0,
                                                     int aligned0, int make_next)
 {
-    __shared__ u32 rowbuf[4][64];
+    __shared__ u32 rowbuf[4][64];  // one raw row per wavefront (down-scale taps)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int b    = blockIdx.y;
     const LevelInfo& lv = L.lv[l];
@@ -459,7 +408,9 @@ __global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* _
     const int yb0   = band * SM_BH, yb1 = min(yb0 + SM_BH, lv.h);
     const bool out_lane = lane >= 1 && lane <= SM_LANES_OUT && xl < sx1;
     const u8* src      = l == 0 ? img0 + (long long)b * stride0 : lv.base + (long long)b * lv.img_stride;
-    const int pitch    = l == 0 ? pitch0 : lv.pitch;
+    // 32-bit offsets inside one image (pitch * h < 2^31), scalars pinned in SGPRs
+    const int pitch    = __builtin_amdgcn_readfirstlane(l == 0 ? pitch0 : lv.pitch);
+    const int bpitch   = __builtin_amdgcn_readfirstlane(lv.pitch);
     const bool aligned = l == 0 ? aligned0 != 0 : true;
     const bool col_ok  = aligned && xl >= 0 && xl + 3 < lv.w;
     const int xsafe    = min(max(xl, 0), (lv.w - 4) & ~3);  // aligned, inside the row
@@ -468,34 +419,36 @@ __global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* _
     const u32 W0123 = 18u | (33u << 8) | (49u << 16) | (56u << 24);
     const u32 W456  = 49u | (33u << 8) | (18u << 16);
 
-    // ---- loop-invariant set-up of the down-scale (destination pixels xdst .. xdst + 3 of this lane) ----
+    // ---- loop-invariant set-up of the down-scale.  A strip owns the destination dwords whose first
+    // pixel has its source column inside the strip; lane i produces dword g0 + i.  The taps of the other
+    // three pixels reach at most 3 * scale + 1 columns further, inside the 8 extra loaded columns
+    // (scale <= 2).  Dwords are written whole: columns >= w of the last one land in the row padding.
     const LevelInfo& nx = L.lv[make_next ? l + 1 : l];
     u8* nbase           = make_next ? nx.base + (long long)b * nx.img_stride : nullptr;
-    const u8* rb        = reinterpret_cast<const u8*>(rowbuf[wave]);
+    const int npitch    = __builtin_amdgcn_readfirstlane(nx.pitch);
+    const u8* rbytes    = reinterpret_cast<const u8*>(&rowbuf[0][0]);
     int so[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
-    u32 wx0[4] = {0, 0, 0, 0}, wx1[4] = {0, 0, 0, 0};
-    u32 vmask = 0;
+    u32 wx[4] = {0, 0, 0, 0};  // (2048 - w1) | w1 << 16
+    bool own  = false;
     int xdst  = 0;
     if (make_next)
     {
-        const int x_lo = lv.strip_dx[strip], x_hi = lv.strip_dx[strip + 1];
-        xdst           = (x_lo & ~3) + 4 * lane;
+        const int g = lv.strip_dx[strip] + lane;
+        own         = g < lv.strip_dx[strip + 1];
+        xdst        = 4 * g;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
         {
-            const int x = xdst + j;
-            if (x >= x_lo && x < x_hi)
-            {
-                vmask |= 1u << j;
-                const int sx = nx.xofs[x];
-                so[j]  = sx - (sx0 - 4);
-                s1[j]  = min(sx + 1, lv.w - 1) - (sx0 - 4);
-                wx1[j] = (u32)nx.xw1[x];
-                wx0[j] = 2048u - wx1[j];
-            }
+            const int x  = min(xdst + j, nx.w - 1);
+            const int sx = own ? nx.xofs[x] : sx0;
+            const u32 w1 = own ? (u32)nx.xw1[x] : 0u;
+            so[j]        = 256 * wave + sx - (sx0 - 4);
+            s1[j]        = 256 * wave + min(sx + 1, lv.w - 1) - (sx0 - 4);
+            wx[j]        = (2048u - w1) | (w1 << 16);
         }
     }
-    u32 ap[4] = {0, 0, 0, 0};  // horizontally interpolated previous row (<= 255 * 2048)
+    // horizontally interpolated rows + 1024 (<= 255 * 2048 + 1024 < 2^24), slot = row parity in the stream
+    u32 ah[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     // lane r keeps the destination row / y weight of source row yb0 + r (read back with v_readlane:
     // dependent scalar loads inside the row loop would serialise it)
     int dy_tab = -1, wy_tab = 0;
@@ -506,12 +459,16 @@ __global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* _
     }
 
     // vertical window: pr[s][c] = H(row a) | H(row a + 1) << 16 of column c, written in slot (a + 1 - (yb0 - 3)) % 7
-    u32 pr[7][4], hp[4] = {0, 0, 0, 0};
+    u32 pr[7][4];
 #pragma unroll
     for (int k = 0; k < 7; ++k) pr[k][0] = pr[k][1] = pr[k][2] = pr[k][3] = 0;
 
-    for (int k0 = 0; k0 < SM_ROWS; k0 += 7)
+    static_assert(SM_ROWS % 14 == 0, "two 7-row blocks per iteration keep the row-parity slots static");
+    for (int k00 = 0; k00 < SM_ROWS; k00 += 14)
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
     {
+        const int k0 = k00 + 7 * half;
         // The 7 row loads of a block are issued together and branch-free (a divergent branch around a
         // load makes the compiler wait for it inside the branch): every lane loads an aligned dword
         // from a clamped column; lanes on the image border are patched afterwards (border strips only).
@@ -522,8 +479,7 @@ __global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* _
             for (int kk = 0; kk < 7; ++kk)
             {
                 const int y  = min(yb0 - 3 + k0 + kk, lv.h + 2);
-                const u8* rp = src + (long long)reflect101(y, lv.h) * pitch;
-                dn[kk]       = *reinterpret_cast<const u32*>(rp + xsafe);
+                dn[kk]       = *reinterpret_cast<const u32*>(src + (u32)(reflect101(y, lv.h) * pitch) + (u32)xsafe);
             }
             if (__any(!col_ok))  // wave-uniform
             {
@@ -532,7 +488,7 @@ __global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* _
                     if (!col_ok)
                     {
                         const int y  = min(yb0 - 3 + k0 + kk, lv.h + 2);
-                        const u8* rp = src + (long long)reflect101(y, lv.h) * pitch;
+                        const u8* rp = src + reflect101(y, lv.h) * pitch;
                         dn[kk] = (u32)rp[xr0] | ((u32)rp[xr1] << 8) | ((u32)rp[xr2] << 16) | ((u32)rp[xr3] << 24);
                     }
             }
@@ -543,7 +499,7 @@ __global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* _
             for (int kk = 0; kk < 7; ++kk)
             {
                 const int y  = min(yb0 - 3 + k0 + kk, lv.h + 2);
-                const u8* rp = src + (long long)reflect101(y, lv.h) * pitch;
+                const u8* rp = src + reflect101(y, lv.h) * pitch;
                 dn[kk] = (u32)rp[xr0] | ((u32)rp[xr1] << 8) | ((u32)rp[xr2] << 16) | ((u32)rp[xr3] << 24);
             }
         }
@@ -555,17 +511,19 @@ __global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* _
             if (y <= yb1 + 2)  // wave-uniform
             {
                 const u32 d = dn[kk];
-                // ---- next pyramid level.  Row y is interpolated horizontally once (ac); a destination
-                // row whose source rows are (y-1, y) combines it with the previous row's (ap).  All
-                // products are < 2^24 x 2^24 -> v_mad_u32_u24; with the y weights pre-multiplied by 4
-                // the rounded pixel is byte 3 of the sum (<= 255 * 2^24 + 2^23).
+                // ---- next pyramid level.  Row y is interpolated horizontally once (ac, v_dot2 of the
+                // tap pair with the weight pair); a destination row whose source rows are (y-1, y)
+                // combines it with the previous row's (ap).  With the y weights pre-multiplied by 4
+                // (sum 2^13) the +1024 carried by ap / ac becomes the rounding term 2^23 and the pixel is
+                // byte 3 of the sum (<= 255 * 2^24 + 2^23).
                 if (make_next && y >= yb0 && y <= yb1)  // wave-uniform
                 {
                     rowbuf[wave][lane] = d;
                     __builtin_amdgcn_wave_barrier();
-                    u32 ac[4];
+                    u32* ac       = ah[(half + kk) & 1];
+                    const u32* ap = ah[(half + kk + 1) & 1];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) ac[j] = mad24(rb[so[j]], wx0[j], __umul24(rb[s1[j]], wx1[j]));
+                    for (int j = 0; j < 4; ++j) ac[j] = dot2((u32)rbytes[so[j]] | ((u32)rbytes[s1[j]] << 16), wx[j], 1024u);
                     __builtin_amdgcn_wave_barrier();
                     const int dy = y > yb0 ? __builtin_amdgcn_readlane(dy_tab, y - 1 - yb0) : -1;
                     if (dy >= 0)  // wave-uniform
@@ -573,22 +531,11 @@ __global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* _
                         const u32 wy1 = 4u * (u32)__builtin_amdgcn_readlane(wy_tab, y - 1 - yb0), wy0 = 8192u - wy1;
                         u32 v[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = mad24(ap[j], wy0, mad24(ac[j], wy1, 1u << 23));
-                        const u32 lo     = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0703u);  // byte 3 of v0, v1
-                        const u32 hi     = __builtin_amdgcn_perm(v[3], v[2], 0x07030c0cu);  // byte 3 of v2, v3 in the top half
-                        const u32 packed = lo | hi;
-                        u8* dp           = nbase + (long long)dy * nx.pitch + xdst;
-                        if (vmask == 0xFu)
-                            *reinterpret_cast<u32*>(dp) = packed;
-                        else if (vmask)
-                        {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (vmask & (1u << j)) dp[j] = (u8)(packed >> (8 * j));
-                        }
+                        for (int j = 0; j < 4; ++j) v[j] = __umul24(ap[j], wy0) + __umul24(ac[j], wy1);
+                        const u32 lo = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0703u);  // byte 3 of v0, v1
+                        const u32 hi = __builtin_amdgcn_perm(v[3], v[2], 0x07030c0cu);  // byte 3 of v2, v3 in the top half
+                        if (own) *reinterpret_cast<u32*>(nbase + (u32)(dy * npitch) + (u32)xdst) = lo | hi;
                     }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) ap[j] = ac[j];
                 }
                 // ---- horizontal pass: stream bytes [dl | d | dr], output j centred on byte 4 + j ----
                 const u32 dl = wave_shr1(d), dr = wave_shl1(d);
@@ -611,7 +558,7 @@ __global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* _
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                     {
-                        u32 t = mad24(hc[c], 18u, 32768u);
+                        u32 t = __umul24(hc[c], 18u) + 32768u;
                         t     = dot2(pr[(kk + 6) % 7][c], 49u | (33u << 16), t);
                         t     = dot2(pr[(kk + 4) % 7][c], 49u | (56u << 16), t);
                         a[c]  = dot2(pr[(kk + 2) % 7][c], 18u | (33u << 16), t);
@@ -620,15 +567,11 @@ __global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* _
                     {
                         const u32 lo = __builtin_amdgcn_perm(a[1], a[0], 0x0c0c0602u);
                         const u32 hi = __builtin_amdgcn_perm(a[3], a[2], 0x06020c0cu);
-                        *reinterpret_cast<u32*>(blur + (long long)yo * lv.pitch + xl) = lo | hi;
+                        *reinterpret_cast<u32*>(blur + (u32)(yo * bpitch) + (u32)xl) = lo | hi;
                     }
                 }
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                {
-                    pr[kk][c] = hp[c] | (hc[c] << 16);
-                    hp[c]     = hc[c];
-                }
+                for (int c = 0; c < 4; ++c) pr[kk][c] = __builtin_amdgcn_alignbit(hc[c], pr[(kk + 6) % 7][c], 16);
             }
         }
     }
@@ -1433,12 +1376,14 @@ int snk_orb_configure(snk_orb* o, int width, int height, int max_batch)
             at += (size_t)sv.h;
             sv.strip_dx = dev + at;
             {
-                int x = 0;
+                // first destination dword (4 pixels) whose leading pixel samples from strip st or later
+                const int n_dw = ceil_div(lv.w, 4);
+                int g          = 0;
                 for (int st = 0; st <= sv.n_strips; ++st)
                 {
                     const int lim = st * sv.strip_stride;  // first source column of strip st
-                    while (x < lv.w && xo[x] < lim) ++x;
-                    host[at + st] = st == sv.n_strips ? lv.w : x;
+                    while (g < n_dw && xo[4 * g] < lim) ++g;
+                    host[at + st] = st == sv.n_strips ? n_dw : g;
                 }
             }
             at += (size_t)sv.n_strips + 1;
@@ -1515,11 +1460,21 @@ static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long i
     // one streaming pass per level: blur of level l + down-scale to level l+1 (the chain makes the
     // passes sequential; every level is read once)
     const int aligned0 = (reinterpret_cast<uintptr_t>(images_dev) % 4 == 0 && pitch % 4 == 0 && image_stride % 4 == 0) ? 1 : 0;
+    const bool fused = o->params.scale_factor <= 2.0f;  // the in-stream down-scale reaches 3 * scale + 1 columns right
     for (int l = 0; l < L.n_levels; ++l)
     {
         const LevelInfo& lv = L.lv[l];
+        if (!fused && l > 0)
+        {
+            const LevelInfo& sv = L.lv[l - 1];
+            dim3 grid(ceil_div(ceil_div(lv.w, 4), 256), lv.h, batch);
+            hipLaunchKernelGGL(resize_kernel, grid, dim3(256), 0, o->stream, l == 1 ? images_dev : sv.base, l == 1 ? pitch : sv.pitch,
+                               l == 1 ? image_stride : sv.img_stride, sv.w, sv.h, lv.base, lv.pitch, lv.img_stride, lv.w, lv.h,
+                               lv.xofs, lv.xw1, lv.yofs, lv.yw1);
+            SNK_LAUNCH_CHECK();
+        }
         hipLaunchKernelGGL(level_kernel, dim3(ceil_div(lv.n_strips * lv.n_bands, 4), batch), dim3(256), 0, o->stream, L, l,
-                           images_dev, pitch, image_stride, aligned0, l + 1 < L.n_levels ? 1 : 0);
+                           images_dev, pitch, image_stride, aligned0, fused && l + 1 < L.n_levels ? 1 : 0);
         SNK_LAUNCH_CHECK();
     }
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[1], o->stream));

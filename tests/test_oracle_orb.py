@@ -259,6 +259,21 @@ def test_point_key_and_distribute_vs_morton_form(orc):
                 assert len(got) >= N
 
 
+def test_distribute_wide_level_exceeds_n_plus_3(orc):
+    """A very wide level has more roots than N / 4: the unconditional first pass alone yields up to
+    4 nodes per root, so the selection can exceed N + 3 (bounded by orc_orb_distribute_bound)."""
+    rng = np.random.default_rng(5)
+    w, h, N = 1111, 69, 93
+    pos = rng.permutation((w - 38) * (h - 38))[:2200]
+    xs, ys = 19 + pos % (w - 38), 19 + pos // (w - 38)
+    sc = rng.integers(8, 60, len(xs))
+    c = np.zeros(len(xs), orc.CAND)
+    c["x"], c["y"], c["score"] = xs, ys, sc
+    got = orc.distribute(c, w, h, N).tolist()
+    assert got == qt_morton.distribute(xs, ys, sc, w, h, N)
+    assert N + 3 < len(got) <= 4 * qt_morton.n_roots(w - 32, h - 32)
+
+
 def test_distribute_clustered_points(orc):
     """Heavily clustered input: deep splits, the 'size unchanged' exit and the careful phase."""
     rng = np.random.default_rng(11)

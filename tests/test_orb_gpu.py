@@ -112,6 +112,25 @@ def test_pitch_and_params_variants(orc):
     check_image(orc, left, 50, 1, 1.2, 20, 7)
 
 
+@pytest.mark.parametrize("scale,levels", [(1.05, 6), (1.5, 4), (2.0, 4), (2.5, 3), (3.0, 3)])
+def test_scale_factor_range(orc, scale, levels):
+    """The streaming level pass makes the next pyramid level in-stream for scale <= 2 and falls
+    back to the stand-alone resize above; both must reproduce the oracle's pyramid bit for bit."""
+    from snake_slam_amd import synth
+
+    left, _ = synth.stereo_frame(5, 752, 480, n_rects=300)
+    check_image(orc, left, 800, levels, scale, 20, 7)
+
+
+@pytest.mark.parametrize("shape", [(120, 1920), (333, 1023), (65, 249), (129, 245)])
+def test_strip_and_band_boundaries(orc, shape):
+    """Widths / heights around the 244-column strip and 64-row band sizes of the level pass."""
+    rng = np.random.default_rng(SEED + shape[1])
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    img[::7, :] //= 2
+    check_image(orc, img, 500, 4, 1.2, 20, 7)
+
+
 def test_batch_dev_matches_single(orc):
     import torch
     from snake_slam_amd import synth
