@@ -41,11 +41,59 @@ constexpr int CELL_SLOTS     = 64;   // strongest candidates kept per cell
 constexpr int KEY_DIGITS     = 16;
 constexpr int DEFAULT_LEVEL_CAP = 8192;
 
-__constant__ signed char c_pattern[1024] = {
+constexpr signed char k_pattern[1024] = {
 #include "brief_pattern_31.inc"
 };
+constexpr int k_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-constexpr unsigned long long UMAX_PACKED = 0x3689abcddeeeffffull;  // the same table, 4 bits per entry (no memory access)
+
+// BRIEF test pairs as floats: entry b = (x0, y0, x1, y1) of bit b (lanes keep 4 entries in registers).
+struct PatternTab
+{
+    float v[256][4];
+};
+constexpr PatternTab make_pattern_tab()
+{
+    PatternTab t{};
+    for (int b = 0; b < 256; ++b)
+        for (int e = 0; e < 4; ++e) t.v[b][e] = (float)k_pattern[4 * b + e];
+    return t;
+}
+__device__ const PatternTab c_pattern_f = make_pattern_tab();
+
+// Intensity-centroid weights of the radius-15 disc for aligned-dword reads.  The 31 x 31 window of a
+// keypoint starts sh (0..3) bytes into its first dword; item = row * 9 + dword (9 dwords per row).
+// Entry [sh][item] = (wx, m): per byte j, m_j = 1 inside the disc else 0 and wx_j = (ux + 15) * m_j with
+// ux the column offset -> m10 = sum dot4(p, wx) - 15 * sum dot4(p, m), m01 = sum vy * dot4(p, m).
+constexpr int MOM_ITEMS = 31 * 9, MOM_PAD = 320;  // padded to 5 x 64 lanes, zero weights
+struct MomentTab
+{
+    u32 v[4][MOM_PAD][2];
+};
+constexpr MomentTab make_moment_tab()
+{
+    MomentTab t{};
+    for (int sh = 0; sh < 4; ++sh)
+        for (int item = 0; item < MOM_ITEMS; ++item)
+        {
+            const int row = item / 9, d = item % 9;
+            const int vy = row - 15, av = vy < 0 ? -vy : vy;
+            u32 wx = 0, m = 0;
+            for (int j = 0; j < 4; ++j)
+            {
+                const int ux = 4 * d + j - sh - 15, au = ux < 0 ? -ux : ux;
+                if (au <= k_umax[av])
+                {
+                    wx |= (u32)(ux + 15) << (8 * j);
+                    m |= 1u << (8 * j);
+                }
+            }
+            t.v[sh][item][0] = wx;
+            t.v[sh][item][1] = m;
+        }
+    return t;
+}
+__device__ const MomentTab c_moment = make_moment_tab();
 
 struct LevelInfo
 {
@@ -1000,22 +1048,40 @@ __device__ __forceinline__ void sincos_deg(float deg, float& s_out, float& c_out
     }
 }
 
-// One wavefront per keypoint.  Moments come from the raw level (31x31 disc, lane = column),
-// the 256 steered tests gather from the blurred level; 4 ballots assemble the descriptor.
+// sum over the 64 lanes, returned wave-uniform: DPP butterflies inside each row of 16 lanes, then the
+// four row sums are read back with v_readlane
+__device__ __forceinline__ int wave_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);  // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+
+// One wavefront describes DESC_KPW consecutive keypoints of a level.  The kernel is bound by load
+// latency, not arithmetic, so every global load a wavefront needs is issued before the first use: for
+// each of its keypoints the 31 x 9 raw dwords of the moment window and the 37 x 10 dwords of the blurred
+// patch that the steered tests can reach (|rotated offset| <= 18).  Moments: v_dot4 against the disc
+// table (LDS copy); the patch goes to the wavefront's LDS slice and the 512 test bytes are LDS reads;
+// 4 ballots assemble the descriptor.
+constexpr int DESC_KPW    = 4;
+constexpr int PATCH_R     = 18, PATCH_DW = 10;                  // 37 rows x 10 dwords
+constexpr int PATCH_ITEMS = (2 * PATCH_R + 1) * PATCH_DW;  // 370 -> 6 loads per lane
+
 __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __restrict__ img0, int pitch0,
                                                        long long stride0, int aligned0, const u32* __restrict__ sel,
                                                        const u8* __restrict__ sel_score, const int* __restrict__ sel_cnt,
                                                        snk_keypoint* __restrict__ kps, u64* __restrict__ desc,
                                                        int* __restrict__ n_out, int out_cap)
 {
-    __shared__ signed char pat[1024];
+    __shared__ uint2 mtab[4 * MOM_PAD];
+    __shared__ u32 patch[4][PATCH_ITEMS + 14];
     const int tid  = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int l    = blockIdx.y;
     const int b    = blockIdx.z;
-    const int slot = blockIdx.x * 4 + wave;
-    for (int i = tid; i < 1024; i += 256) pat[i] = c_pattern[i];
-
     const int* cnts = sel_cnt + b * MAX_LEVELS;
     int offset = 0, total = 0;
     for (int k = 0; k < L.n_levels; ++k)
@@ -1025,116 +1091,160 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
         total += c;
     }
     if (blockIdx.x == 0 && l == 0 && tid == 0) n_out[b] = total < out_cap ? total : out_cap;
-    __syncthreads();
     const LevelInfo& lv = L.lv[l];
-    if (slot >= cnts[l]) return;  // whole wavefront
-    const int oi = offset + slot;
-    if (oi >= out_cap) return;
+    const int cnt_l     = cnts[l];
+    if (blockIdx.x * 4 * DESC_KPW >= cnt_l) return;  // whole workgroup (the grid is sized for the largest level)
+    {
+        const uint2* g = reinterpret_cast<const uint2*>(&c_moment.v[0][0][0]);
+        for (int i = tid; i < 4 * MOM_PAD; i += 256) mtab[i] = g[i];
+    }
+    __syncthreads();
+    const int slot0     = (blockIdx.x * 4 + wave) * DESC_KPW;
+    if (slot0 >= cnt_l || offset + slot0 >= out_cap) return;  // whole wavefront
 
-    const u32 xy    = sel[(long long)b * L.total_slots + lv.slot_off + slot];
-    const int score = sel_score[(long long)b * L.total_slots + lv.slot_off + slot];
-    const int kx = (int)(xy & 0xFFFFu), ky = (int)(xy >> 16);
-    const u8* src   = l == 0 ? img0 + (long long)b * stride0 : lv.base + (long long)b * lv.img_stride;
-    const int pitch = l == 0 ? pitch0 : lv.pitch;
-    const u8* bsrc  = lv.blur + (long long)b * lv.img_stride;
+    const u8* src      = l == 0 ? img0 + (long long)b * stride0 : lv.base + (long long)b * lv.img_stride;
+    const int pitch    = l == 0 ? pitch0 : lv.pitch;
+    const u8* bsrc     = lv.blur + (long long)b * lv.img_stride;
+    const int bpitch   = lv.pitch;
     const bool aligned = l == 0 ? aligned0 != 0 : true;
 
-    // intensity-centroid moments over the radius-15 disc (integers)
-    int m10 = 0, m01 = 0;
-    if (aligned)
+    // per-lane geometry, shared by the keypoints: byte offsets of its moment / patch dwords relative to
+    // the window origins (items past the end repeat the last one; moment weights there are zero)
+    int moff[5], vyv[5], boff[6];
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
     {
-        // 31 rows x 9 aligned dwords cover columns kx-15 .. kx+15 (byte offset sh2 inside the first dword)
-        const int xa  = (kx - 15) & ~3;
-        const int sh2 = (kx - 15) - xa;
-        // branch-free: the 5 dword loads of a lane are all in flight before the first use
-        u32 dwv[5];
-        int rowv[5], dv[5];
-#pragma unroll
-        for (int k = 0; k < 5; ++k)
-        {
-            const int item = min(lane + 64 * k, 31 * 9 - 1);
-            rowv[k]        = item / 9;
-            dv[k]          = item - rowv[k] * 9;
-            dwv[k]         = *reinterpret_cast<const u32*>(src + (long long)(ky + rowv[k] - 15) * pitch + xa + 4 * dv[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < 5; ++k)
-        {
-            const bool live = lane + 64 * k < 31 * 9;
-            const int vy    = rowv[k] - 15;
-            const int lim   = live ? (int)((UMAX_PACKED >> (4 * (vy < 0 ? -vy : vy))) & 0xFull) : -1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-            {
-                const int ux = 4 * dv[k] + j - sh2 - 15;
-                const int au = ux < 0 ? -ux : ux;
-                const int p  = au <= lim ? (int)((dwv[k] >> (8 * j)) & 0xFFu) : 0;
-                m10 += ux * p;
-                m01 += vy * p;
-            }
-        }
-    }
-    else
-    {
-        // byte path: lane & 31 = column, lane >> 5 = row parity
-        const int ux = (lane & 31) - 15;
-        const int au = ux < 0 ? -ux : ux;
-#pragma unroll 4
-        for (int k = 0; k < 16; ++k)
-        {
-            const int vy = 2 * k + (lane >> 5) - 15;
-            const int av = vy < 0 ? -vy : vy;
-            if (vy <= 15 && ux <= 15 && au <= c_umax[av])
-            {
-                const int p = src[(long long)(ky + vy) * pitch + kx + ux];
-                m10 += ux * p;
-                m01 += vy * p;
-            }
-        }
+        const int item = min(lane + 64 * k, MOM_ITEMS - 1);
+        const int row  = item / 9;
+        vyv[k]         = row - 15;
+        moff[k]        = (row - 15) * pitch + 4 * (item - row * 9);
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1)
+    for (int k = 0; k < 6; ++k)
     {
-        m10 += __shfl_xor(m10, off);
-        m01 += __shfl_xor(m01, off);
+        const int item = min(lane + 64 * k, PATCH_ITEMS - 1);
+        const int row  = item / PATCH_DW;
+        boff[k]        = (row - PATCH_R) * bpitch + 4 * (item - row * PATCH_DW);
     }
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
-    float sn, cs;
-    sincos_deg(angle, sn, cs);
 
-    // 256 steered tests on the blurred level; lane computes bits lane, lane+64, lane+128, lane+192
-    u64 word[4];
-    const u8* bc = bsrc + (long long)ky * lv.pitch + kx;
+    // ---- issue every load of the wavefront ----
+    bool valid[DESC_KPW];
+    int kxv[DESC_KPW], kyv[DESC_KPW], scv[DESC_KPW];
+    u32 dwv[DESC_KPW][5], bpv[DESC_KPW][6];
+    const long long sbase = (long long)b * L.total_slots + lv.slot_off;
+#pragma unroll
+    for (int s = 0; s < DESC_KPW; ++s)
+    {
+        const int slot = slot0 + s;
+        valid[s]       = slot < cnt_l && offset + slot < out_cap;
+        const u32 xy   = sel[sbase + (valid[s] ? slot : slot0)];
+        scv[s]         = sel_score[sbase + (valid[s] ? slot : slot0)];
+        kxv[s]         = (int)(xy & 0xFFFFu);
+        kyv[s]         = (int)(xy >> 16);
+    }
+#pragma unroll
+    for (int s = 0; s < DESC_KPW; ++s)
+    {
+        const int xa = (kxv[s] - 15) & ~3, xb = (kxv[s] - PATCH_R) & ~3;
+        const u8* mo = src + ((long long)kyv[s] * pitch + xa);
+        const u8* bo = bsrc + ((long long)kyv[s] * bpitch + xb);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) dwv[s][k] = aligned ? *reinterpret_cast<const u32*>(mo + moff[k]) : 0u;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) bpv[s][k] = *reinterpret_cast<const u32*>(bo + boff[k]);
+    }
+    float pt[4][4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-    {
-        const int bit = k * 64 + lane;
-        int t[2];
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
-        {
-            const float pxf = (float)pat[4 * bit + 2 * e], pyf = (float)pat[4 * bit + 2 * e + 1];
-            const int ry    = __float2int_rn(pxf * sn + pyf * cs);
-            const int rx    = __float2int_rn(pxf * cs - pyf * sn);
-            t[e]            = bc[ry * lv.pitch + rx];
-        }
-        word[k] = __ballot(t[0] < t[1]);
-    }
-    if (lane == 0)
+        for (int e = 0; e < 4; ++e) pt[k][e] = c_pattern_f.v[k * 64 + lane][e];
+
+    const u8* pb = reinterpret_cast<const u8*>(patch[wave]);
+#pragma unroll
+    for (int s = 0; s < DESC_KPW; ++s)
     {
-        snk_keypoint kp;
-        kp.x        = (float)kx * lv.scale;
-        kp.y        = (float)ky * lv.scale;
-        kp.size     = 31.0f * lv.scale;
-        kp.angle    = angle;
-        kp.response = (float)(score - 1);
-        kp.octave   = l;
-        kps[(long long)b * out_cap + oi] = kp;
-        u64* d = desc + ((long long)b * out_cap + oi) * 4;
-        d[0] = word[0];
-        d[1] = word[1];
-        d[2] = word[2];
-        d[3] = word[3];
+        if (!valid[s]) break;  // wave-uniform
+        const int kx = kxv[s], ky = kyv[s];
+        // blurred patch -> LDS (in-order per wavefront: the previous keypoint's reads are done)
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (lane + 64 * k < PATCH_ITEMS) patch[wave][lane + 64 * k] = bpv[s][k];
+
+        // intensity-centroid moments over the radius-15 disc (integers)
+        int m10 = 0, m01 = 0;
+        if (aligned)
+        {
+            const int sh2 = (kx - 15) & 3;
+            u32 sx = 0, s0 = 0;
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+            {
+                const uint2 w = mtab[sh2 * MOM_PAD + lane + 64 * k];
+                sx            = __builtin_amdgcn_udot4(dwv[s][k], w.x, sx, false);
+                const u32 sr  = __builtin_amdgcn_udot4(dwv[s][k], w.y, 0u, false);
+                s0 += sr;
+                m01 += vyv[k] * (int)sr;
+            }
+            m10 = (int)sx - 15 * (int)s0;
+        }
+        else
+        {
+            // byte path: lane & 31 = column, lane >> 5 = row parity
+            const int ux = (lane & 31) - 15;
+            const int au = ux < 0 ? -ux : ux;
+#pragma unroll 4
+            for (int k = 0; k < 16; ++k)
+            {
+                const int vy = 2 * k + (lane >> 5) - 15;
+                const int av = vy < 0 ? -vy : vy;
+                if (vy <= 15 && ux <= 15 && au <= c_umax[av])
+                {
+                    const int p = src[(long long)(ky + vy) * pitch + kx + ux];
+                    m10 += ux * p;
+                    m01 += vy * p;
+                }
+            }
+        }
+        m10 = wave_sum(m10);
+        m01 = wave_sum(m01);
+        const float angle = fast_atan2_deg((float)m01, (float)m10);
+        float sn, cs;
+        sincos_deg(angle, sn, cs);
+
+        // 256 steered tests on the blurred patch; lane computes bits lane, lane+64, lane+128, lane+192
+        const int pc = PATCH_R * (4 * PATCH_DW) + PATCH_R + ((kx - PATCH_R) & 3);  // patch byte of the keypoint
+        u64 word[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+            int t[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+            {
+                const float pxf = pt[k][2 * e], pyf = pt[k][2 * e + 1];
+                const int ry    = __float2int_rn(pxf * sn + pyf * cs);
+                const int rx    = __float2int_rn(pxf * cs - pyf * sn);
+                t[e]            = pb[pc + ry * (4 * PATCH_DW) + rx];
+            }
+            word[k] = __ballot(t[0] < t[1]);
+        }
+        if (lane == 0)
+        {
+            const int oi = offset + slot0 + s;
+            snk_keypoint kp;
+            kp.x        = (float)kx * lv.scale;
+            kp.y        = (float)ky * lv.scale;
+            kp.size     = 31.0f * lv.scale;
+            kp.angle    = angle;
+            kp.response = (float)(scv[s] - 1);
+            kp.octave   = l;
+            kps[(long long)b * out_cap + oi] = kp;
+            u64* d = desc + ((long long)b * out_cap + oi) * 4;
+            d[0] = word[0];
+            d[1] = word[1];
+            d[2] = word[2];
+            d[3] = word[3];
+        }
     }
 }
 }  // namespace
@@ -1505,7 +1615,7 @@ static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long i
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[4], o->stream));
     int max_slot = 1;
     for (int l = 0; l < L.n_levels; ++l) max_slot = L.lv[l].slot_cap > max_slot ? L.lv[l].slot_cap : max_slot;
-    hipLaunchKernelGGL(describe_kernel, dim3(ceil_div(max_slot, 4), L.n_levels, batch), dim3(256), 0, o->stream, L,
+    hipLaunchKernelGGL(describe_kernel, dim3(ceil_div(max_slot, 4 * DESC_KPW), L.n_levels, batch), dim3(256), 0, o->stream, L,
                        images_dev, pitch, image_stride, aligned0, o->sel.as<u32>(), o->sel_score.as<u8>(), o->sel_cnt.as<int>(),
                        kps_dev, (u64*)desc_dev, n_dev, out_cap);
     SNK_LAUNCH_CHECK();
