@@ -298,7 +298,7 @@ __device__ __forceinline__ short2_t fast_score16_pk(const short2_t (&d)[16])
 // image tile | score map with zero ring | quick-test survivors | NMS survivors | 3 counters.
 __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restrict__ img0, int pitch0, long long stride0,
                                                    int aligned0, int ini_th, int min_th, u32* __restrict__ cand,
-                                                   u16* __restrict__ cell_cnt, int dbg_stop)
+                                                   u16* __restrict__ cell_cnt)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
     u8* S             = slice + L.f_off_s;
     u16* surv         = reinterpret_cast<u16*>(slice + L.f_off_surv);
     u32* list         = reinterpret_cast<u32*>(slice + L.f_off_list);
-    volatile int* cnt = reinterpret_cast<volatile int*>(slice + L.f_off_cnt);  // n_surv, n_list, n_ini
+    int* cnt          = reinterpret_cast<int*>(slice + L.f_off_cnt);  // n_surv, n_list, n_ini (LDS atomics)
     const int TPD = L.f_tile_pitch_dw, TP = TPD * 4, SP = L.f_s_pitch;
 
     int l = 0;
@@ -342,7 +342,6 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
     for (int i = lane; i < (ch + 2) * (SP >> 2); i += 64) reinterpret_cast<u32*>(S)[i] = 0;
     __builtin_amdgcn_wave_barrier();
     const u8* tile = reinterpret_cast<const u8*>(tile_dw);
-    if (dbg_stop == 1) { if (lane == 0) cell_cnt[cell_index] = (u16)(tile[lane] > 254 ? 1 : 0) * 0; return; }
 
     // phase A: every 9-arc holds one pixel of each opposite pair -> S <= min_i max(d_i, d_{i+8})
     for (int py = lane >> 5; py < ch; py += 2)
@@ -353,13 +352,12 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
             const int d0 = t[3 * TP] - v, d8 = t[-3 * TP] - v, d4 = t[3] - v, d12 = t[-3] - v;
             const int ub_b = min(max(d0, d8), max(d4, d12));
             const int ub_d = min(max(-d0, -d8), max(-d4, -d12));
-            if (ub_b > min_th || ub_d > min_th) surv[atomicAdd(const_cast<int*>(&cnt[0]), 1)] = (u16)((py << 6) | px);
+            if (ub_b > min_th || ub_d > min_th) surv[atomicAdd(&cnt[0], 1)] = (u16)((py << 6) | px);
         }
     __builtin_amdgcn_wave_barrier();
 
     // phase B: exact score of the survivors, two per lane
-    const int ns = cnt[0];
-    if (dbg_stop == 2) { if (lane == 0) cell_cnt[cell_index] = (u16)(ns > 60000 ? 1 : 0); return; }
+    const int ns = __builtin_amdgcn_readfirstlane(__atomic_load_n(&cnt[0], __ATOMIC_RELAXED));
     for (int j = lane * 2; j < ns; j += 128)
     {
         const int e0 = surv[j], e1 = surv[j + 1 < ns ? j + 1 : j];
@@ -379,7 +377,6 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
     }
     __builtin_amdgcn_wave_barrier();
 
-    if (dbg_stop == 3) { if (lane == 0) cell_cnt[cell_index] = (u16)(S[SP + 1] > 254 ? 1 : 0) * 0; return; }
     // 3x3 non-max suppression (strict) among scores above min_th (all of them are survivors)
     for (int j = lane; j < ns; j += 64)
     {
@@ -393,13 +390,13 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
         {
             // strength key: higher score first, then smaller y, then smaller x
             const u32 key = ((u32)v << 12) | ((u32)(63 - py) << 6) | (u32)(63 - px);
-            list[atomicAdd(const_cast<int*>(&cnt[1]), 1)] = key;
-            if (v > ini_th) atomicAdd(const_cast<int*>(&cnt[2]), 1);
+            list[atomicAdd(&cnt[1], 1)] = key;
+            if (v > ini_th) atomicAdd(&cnt[2], 1);
         }
     }
     __builtin_amdgcn_wave_barrier();
-    const int nl   = cnt[1];
-    const int nini = cnt[2];
+    const int nl   = __builtin_amdgcn_readfirstlane(__atomic_load_n(&cnt[1], __ATOMIC_RELAXED));
+    const int nini = __builtin_amdgcn_readfirstlane(__atomic_load_n(&cnt[2], __ATOMIC_RELAXED));
     const bool ini = nini > 0;
     const u32 thr  = ((u32)(ini ? ini_th : min_th) << 12) | 0xFFFu;  // key > thr  <=>  score > threshold
     const int n    = ini ? nini : nl;
@@ -1595,7 +1592,7 @@ static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long i
         hipLaunchKernelGGL(fast_kernel, dim3(ceil_div(L.total_cells, 4), batch), dim3(256), (size_t)4 * L.f_lds_wave, o->stream, L,
                            images_dev, pitch,
                            image_stride, aligned0, o->params.ini_th_fast, o->params.min_th_fast, o->cand.as<u32>(),
-                           o->cell_cnt.as<u16>(), getenv("SNK_DBG_FAST_STOP") ? atoi(getenv("SNK_DBG_FAST_STOP")) : 0);
+                           o->cell_cnt.as<u16>());
         SNK_LAUNCH_CHECK();
     }
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[3], o->stream));
