@@ -69,14 +69,14 @@ def cpu_baseline(frames, seconds_budget=12.0):
         orc.bf_filter(knn, 60, 0.8)
         done += 1
         el = time.perf_counter() - t0
-        if el >= seconds_budget or done >= 400:
+        if el >= seconds_budget or done >= 2000:
             break
     return {"value": round(done / el, 3), "unit": "frames/s", "cores": 4, "kind": "port",
             "sample": f"{done} stereo frames 752x480 (extract L+R with 2 threads, rectify, stereo match, "
                       f"BF kNN-2 with 4 threads + filter) in {el:.1f} s; CPU restatement of the reference path, not the reference binary"}
 
 
-def cpu_baseline_ba(seconds_budget=5.0):
+def cpu_baseline_ba(seconds_budget=8.0):
     """Oracle LBA solve (1 thread, like the reference's numThreads = 1, LocalBundleAdjustment.cpp:56)."""
     from oracle import oracle as orc
     from snake_slam_amd import synth

@@ -175,8 +175,11 @@ SNK_API int snk_orb_detect_batch_dev(snk_orb* o, const uint8_t* images_dev, int 
                                      int batch, snk_keypoint* kps_dev, uint64_t* desc_dev, int32_t* n_dev,
                                      int out_cap);
 
-/* Optional per-stage timing with HIP events recorded on the handle's stream around the five
- * kernel stages of every detect call (pyramid, blur, FAST cells, distribution, descriptors).
+/* Optional per-stage timing with HIP events recorded on the handle's stream around the kernel
+ * stages of every detect call: ms[0] = the per-level streaming passes (blurred level + next pyramid
+ * level in one pass; plus the stand-alone resize when scale_factor > 2), ms[1] = reserved (the
+ * blur used to be a stage of its own; now ~0), ms[2] = FAST cells, ms[3] = distribution,
+ * ms[4] = descriptors.
  * snk_orb_stage_times synchronises, returns the summed milliseconds per stage over the calls since
  * the last query (ms[5]) and their number, and resets the accumulation. */
 SNK_API int snk_orb_set_profiling(snk_orb* o, int enable);
