@@ -316,6 +316,57 @@ SNK_API int snk_match_project_keyframe(snk_matcher* m, const snk_frame_view* fra
                                        int feature_error, int32_t* match_idx, int* n_matches);
 
 /* ------------------------------------------------------------------------------------------
+ * Pose refinement (the step after every projection matcher)
+ * ------------------------------------------------------------------------------------------ */
+
+/* Saiga ObsBase<double> as the reference fills it per match — Snake/Tracking/PoseRefinement.h:47-55,
+ * PoseRefinement.cpp:46-52: ip = undistorted keypoint, weight = sqrt(InverseSquaredScale(octave)),
+ * depth = frame.depth[i] (> 0 => stereo observation, u_r = u - bf / depth). */
+typedef struct snk_pose_obs
+{
+    double x, y;
+    double depth;
+    double weight;
+} snk_pose_obs;
+
+/* th_mono / th_stereo = reprojectionErrorThreshold{Mono,Stereo} * errorFactor (PoseRefinement.cpp:13-15,
+ * Snake/System/SnakeGlobal.h:145-146).  The optimiser the reference calls
+ * (Saiga::RobustPoseOptimization::optimizePoseRobust, absent submodule) is [DEFINED] as "snk-pose v1"
+ * (DESIGN.md 3c): outer_iterations rounds of inner_iterations damped Gauss-Newton steps over the
+ * current inliers, Huber (delta = threshold) in the first robust_rounds rounds, every match
+ * re-classified after each round (outlier <=> |r|^2 > threshold^2).  Defaults of the Python / C++
+ * mirrors: 4, 10, 3, lambda = 1e-4. */
+typedef struct snk_pose_options
+{
+    double th_mono, th_stereo;
+    int32_t outer_iterations, inner_iterations, robust_rounds, pad;
+    double lambda;
+} snk_pose_options;
+
+/* One frame: wps[i] = position of the map point matched to feature idx[i] (lm.points[lid].position
+ * or pMP->getPosition()), obs[i] as above; pose = frame.Pose() in, optimised pose out (world ->
+ * camera, qx qy qz qw tx ty tz); outlier[i] -> frame.mvbOutlier[idx[i]]; inliers = the return value
+ * of optimizePoseRobust.  prediction / w_rot / w_trans = frame.prediction and
+ * frame.prediction_weight_{rotation,translation} (RobustSmoothPoseOptimization branch,
+ * PoseRefinement.h:68-73); both weights 0 => no prior. */
+typedef struct snk_pose_problem
+{
+    int32_t n;
+    int32_t inliers; /* out */
+    const double (*wps)[3];
+    const snk_pose_obs* obs;
+    uint8_t* outlier; /* out [n] */
+    double pose[7];   /* in / out */
+    double prediction[7];
+    double w_rot, w_trans;
+} snk_pose_problem;
+
+/* Replaces rpo.optimizePoseRobust / rpo_smooth.optimizePoseRobust for a batch of frames (one
+ * wavefront per frame, one launch).  Host pointers, synchronous. */
+SNK_API int snk_pose_refine(snk_matcher* m, const snk_camera* cam, const snk_pose_options* opt,
+                            snk_pose_problem* problems, int n_problems);
+
+/* ------------------------------------------------------------------------------------------
  * Local bundle adjustment
  * ------------------------------------------------------------------------------------------ */
 

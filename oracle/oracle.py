@@ -387,3 +387,50 @@ def match_keyframe(frame, cam, pose, pos, desc, skip, th, feature_error):
     n = lib().orc_match_keyframe(C.byref(v), C.byref(c), _p(pose), _p(pos), _p(desc), _p(skip), C.c_int(len(pos)), C.c_float(th),
                                  C.c_int(feature_error), _p(out))
     return n, out[: len(pos)]
+
+
+# ------------------------------------------------------------------ pose refinement ------------
+class PoseObs(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("depth", C.c_double), ("weight", C.c_double)]
+
+
+POSE_OBS = np.dtype([("x", "f8"), ("y", "f8"), ("depth", "f8"), ("weight", "f8")])
+
+
+class PoseOptions(C.Structure):
+    _fields_ = [("th_mono", C.c_double), ("th_stereo", C.c_double), ("outer_iterations", C.c_int32),
+                ("inner_iterations", C.c_int32), ("robust_rounds", C.c_int32), ("pad", C.c_int32), ("lambda_", C.c_double)]
+
+
+def pose_options(th_mono=2.1, th_stereo=2.3, outer=4, inner=10, robust_rounds=3, lam=1e-4) -> PoseOptions:
+    return PoseOptions(th_mono, th_stereo, outer, inner, robust_rounds, 0, lam)
+
+
+def se3_log_rel(pose, pred) -> np.ndarray:
+    e = np.zeros(6)
+    lib().orc_se3_log_rel(_p(np.ascontiguousarray(pose, np.float64)), _p(np.ascontiguousarray(pred, np.float64)), _p(e))
+    return e
+
+
+def pose_chi2(pose, cam, wps, obs) -> np.ndarray:
+    wps = np.ascontiguousarray(wps, np.float64)
+    obs = np.ascontiguousarray(obs, POSE_OBS)
+    out = np.zeros(len(obs))
+    lib().orc_pose_chi2(_p(np.ascontiguousarray(pose, np.float64)), C.byref(cam), _p(wps), _p(obs), len(obs), _p(out))
+    return out
+
+
+def pose_refine(pose, cam, wps, obs, options: PoseOptions = None, prediction=None, w_rot=0.0, w_trans=0.0):
+    """Returns (pose[7], outlier[n] uint8, inliers)."""
+    options = options or pose_options()
+    pose = np.array(pose, np.float64)
+    wps = np.ascontiguousarray(wps, np.float64)
+    obs = np.ascontiguousarray(obs, POSE_OBS)
+    outl = np.zeros(len(obs), np.uint8)
+    pred = None if prediction is None else np.ascontiguousarray(prediction, np.float64)
+    lib().orc_pose_refine.restype = C.c_int
+    lib().orc_pose_refine.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.c_double, C.c_double, C.c_void_p]
+    n = lib().orc_pose_refine(_p(pose), C.addressof(cam), C.addressof(options), _p(wps), _p(obs), len(obs),
+                              None if pred is None else _p(pred), float(w_rot), float(w_trans), _p(outl))
+    return pose, outl, n

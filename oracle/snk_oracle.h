@@ -188,6 +188,31 @@ int orc_match_fine(const orc_frame_view* f, const orc_camera* cam, const double*
 int orc_match_keyframe(const orc_frame_view* f, const orc_camera* cam, const double* pose, const double (*pos)[3],
                        const uint64_t (*desc)[4], const uint8_t* skip, int m, float th, int feature_error, int32_t* match_idx);
 
+/* ---- pose_oracle.c ---- */
+typedef struct orc_pose_obs /* Saiga ObsBase<double> as PoseRefinement.h:47-55 fills it */
+{
+    double x, y;   /* undistorted keypoint */
+    double depth;  /* > 0 => stereo observation */
+    double weight; /* sqrt(InverseSquaredScale(octave)) */
+} orc_pose_obs;
+
+typedef struct orc_pose_options
+{
+    double th_mono, th_stereo; /* reprojectionErrorThreshold{Mono,Stereo} * errorFactor */
+    int32_t outer_iterations;  /* 4 */
+    int32_t inner_iterations;  /* 10 */
+    int32_t robust_rounds;     /* 3: Huber in rounds 0..2 */
+    int32_t pad;
+    double lambda; /* 1e-4 */
+} orc_pose_options;
+
+void orc_se3_log_rel(const double* pose, const double* pred, double* e);
+void orc_pose_chi2(const double* pose, const orc_camera* cam, const double (*wps)[3], const orc_pose_obs* obs, int n,
+                   double* chi2);
+int orc_pose_refine(double* pose, const orc_camera* cam, const orc_pose_options* opt, const double (*wps)[3],
+                    const orc_pose_obs* obs, int n, const double* prediction, double w_rot, double w_trans,
+                    uint8_t* outlier);
+
 #ifdef __cplusplus
 }
 #endif

@@ -242,6 +242,60 @@ class SnakeORBMatcher
     snk_matcher* h_ = nullptr;
 };
 
+// Snake::PoseRefinement (reference Snake/Tracking/PoseRefinement.h:22-99): the robust pose-only
+// optimisation after every matcher call.  The caller gathers wps / obs / idx exactly as refinePose
+// (:35-60) and RefinePoseWithMatches (PoseRefinement.cpp:37-57) do, then writes outlier[i] to
+// frame.mvbOutlier[idx[i]] and the pose to frame.setPose().
+class PoseRefinement
+{
+   public:
+    explicit PoseRefinement(double errorFactor = 1.0, int device = 0)
+    {
+        check(snk_matcher_create(device, nullptr, &h_), "snk_matcher_create");
+        options.th_mono          = 2.1 * errorFactor;  // reprojectionErrorThresholdMono, SnakeGlobal.h:145
+        options.th_stereo        = 2.3 * errorFactor;  // reprojectionErrorThresholdStereo, SnakeGlobal.h:146
+        options.outer_iterations = 4;
+        options.inner_iterations = 10;
+        options.robust_rounds    = 3;
+        options.pad              = 0;
+        options.lambda           = 1e-4;
+    }
+    ~PoseRefinement() { snk_matcher_destroy(h_); }
+    PoseRefinement(const PoseRefinement&)            = delete;
+    PoseRefinement& operator=(const PoseRefinement&) = delete;
+
+    // rpo.optimizePoseRobust(wps, obs, outlier, pose, cam); with prediction weights > 0 the
+    // rpo_smooth variant (PoseRefinement.h:68-73).  Returns the inlier count.
+    int optimizePoseRobust(const std::vector<std::array<double, 3>>& wps, const std::vector<snk_pose_obs>& obs,
+                           std::vector<uint8_t>& outlier, double pose[7], const snk_camera& cam,
+                           const double* prediction = nullptr, double weight_rotation = 0, double weight_translation = 0)
+    {
+        outlier.assign(obs.size() + 1, 0);
+        snk_pose_problem P{};
+        P.n       = (int)obs.size();
+        P.wps     = reinterpret_cast<const double(*)[3]>(wps.data());
+        P.obs     = obs.data();
+        P.outlier = outlier.data();
+        for (int i = 0; i < 7; ++i) P.pose[i] = pose[i], P.prediction[i] = prediction ? prediction[i] : pose[i];
+        P.w_rot   = prediction ? weight_rotation : 0;
+        P.w_trans = prediction ? weight_translation : 0;
+        check(snk_pose_refine(h_, &cam, &options, &P, 1), "snk_pose_refine");
+        for (int i = 0; i < 7; ++i) pose[i] = P.pose[i];
+        outlier.resize(obs.size());
+        return P.inliers;
+    }
+    // a whole batch of frames in one launch
+    void optimizeBatch(std::vector<snk_pose_problem>& problems, const snk_camera& cam)
+    {
+        check(snk_pose_refine(h_, &cam, &options, problems.data(), (int)problems.size()), "snk_pose_refine");
+    }
+
+    snk_pose_options options{};
+
+   private:
+    snk_matcher* h_ = nullptr;
+};
+
 // The part of Saiga::Scene that MakeLocalScene fills (LocalBundleAdjustment.cpp:187-293), flattened.
 struct Scene
 {

@@ -1,0 +1,414 @@
+// Robust pose-only optimisation ("snk-pose v1") for the step that follows every projection matcher:
+// PoseRefinement::refinePose (Snake/Tracking/PoseRefinement.h:27-87) and
+// PoseRefinement::RefinePoseWithMatches (Snake/Tracking/PoseRefinement.cpp:25-79).  The optimiser
+// the reference calls (Saiga::RobustPoseOptimization::optimizePoseRobust, absent submodule) is
+// [DEFINED] in DESIGN.md §3c and restated on the CPU in oracle/pose_oracle.c.
+//
+// One WAVEFRONT per frame (problem): a lane owns matches lane, lane + 64, ...; each damped
+// Gauss-Newton iteration accumulates the 21 + 6 entries of J^T W J / J^T W r per lane, sums them
+// over the wavefront in a fixed butterfly order (deterministic), and every lane solves the same 6x6
+// system.  No LDS, no workgroup barriers; problems of a batch run side by side.
+#include <cmath>
+
+#include "matcher_handle.hpp"
+
+namespace snk
+{
+namespace
+{
+typedef unsigned char u8;
+
+struct PoseMeta
+{
+    int off, n;
+    int use_prior, pad;
+    double pose[7];
+    double pred[7];
+    double w_rot, w_trans;
+};
+
+struct CamD
+{
+    double fx, fy, cx, cy, bf;
+};
+
+__device__ __forceinline__ void quat_to_R(const double* q, double* R)
+{
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
+    R[3] = 2 * (x * y + z * w);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+    R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
+}
+
+// pose <- exp(delta) * pose, delta = (translation, rotation)
+__device__ void se3_update(double* pose, const double* d)
+{
+    const double wx = d[3], wy = d[4], wz = d[5];
+    const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
+    double B, Cc, qd[4];
+    if (th < 1e-8)
+    {
+        B  = 0.5 - th2 / 24.0;
+        Cc = 1.0 / 6.0 - th2 / 120.0;
+        const double h = 0.5 - th2 / 48.0;
+        qd[0] = h * wx; qd[1] = h * wy; qd[2] = h * wz; qd[3] = 1.0 - th2 / 8.0;
+    }
+    else
+    {
+        const double s = sin(th), c = cos(th);
+        B  = (1.0 - c) / th2;
+        Cc = (th - s) / (th2 * th);
+        const double sh = sin(0.5 * th) / th;
+        qd[0] = sh * wx; qd[1] = sh * wy; qd[2] = sh * wz; qd[3] = cos(0.5 * th);
+    }
+    const double vx = d[0], vy = d[1], vz = d[2];
+    const double cx = wy * vz - wz * vy, cy = wz * vx - wx * vz, cz = wx * vy - wy * vx;
+    const double ccx = wy * cz - wz * cy, ccy = wz * cx - wx * cz, ccz = wx * cy - wy * cx;
+    const double tdx = vx + B * cx + Cc * ccx, tdy = vy + B * cy + Cc * ccy, tdz = vz + B * cz + Cc * ccz;
+    double Rd[9];
+    quat_to_R(qd, Rd);
+    const double tx = pose[4], ty = pose[5], tz = pose[6];
+    const double ax = qd[0], ay = qd[1], az = qd[2], aw = qd[3], bx = pose[0], by = pose[1], bz = pose[2], bw = pose[3];
+    double q[4];
+    q[0] = aw * bx + ax * bw + ay * bz - az * by;
+    q[1] = aw * by - ax * bz + ay * bw + az * bx;
+    q[2] = aw * bz + ax * by - ay * bx + az * bw;
+    q[3] = aw * bw - ax * bx - ay * by - az * bz;
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    pose[0] = q[0] / n; pose[1] = q[1] / n; pose[2] = q[2] / n; pose[3] = q[3] / n;
+    pose[4] = Rd[0] * tx + Rd[1] * ty + Rd[2] * tz + tdx;
+    pose[5] = Rd[3] * tx + Rd[4] * ty + Rd[5] * tz + tdy;
+    pose[6] = Rd[6] * tx + Rd[7] * ty + Rd[8] * tz + tdz;
+}
+
+// e = log(T * T_pred^-1) = (rho, omega)
+__device__ void se3_log_rel(const double* pose, const double* pred, double* e)
+{
+    const double ax = pose[0], ay = pose[1], az = pose[2], aw = pose[3];
+    const double bx = -pred[0], by = -pred[1], bz = -pred[2], bw = pred[3];
+    double q[4];
+    q[0] = aw * bx + ax * bw + ay * bz - az * by;
+    q[1] = aw * by - ax * bz + ay * bw + az * bx;
+    q[2] = aw * bz + ax * by - ay * bx + az * bw;
+    q[3] = aw * bw - ax * bx - ay * by - az * bz;
+    if (q[3] < 0.0)
+        for (int i = 0; i < 4; ++i) q[i] = -q[i];
+    double Re[9];
+    quat_to_R(q, Re);
+    const double tx = pose[4] - (Re[0] * pred[4] + Re[1] * pred[5] + Re[2] * pred[6]);
+    const double ty = pose[5] - (Re[3] * pred[4] + Re[4] * pred[5] + Re[5] * pred[6]);
+    const double tz = pose[6] - (Re[6] * pred[4] + Re[7] * pred[5] + Re[8] * pred[6]);
+    const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2], n = sqrt(n2);
+    double wx, wy, wz, cc;
+    if (n < 1e-10)
+    {
+        const double k = 2.0 / q[3];
+        wx = k * q[0]; wy = k * q[1]; wz = k * q[2];
+        cc = 1.0 / 12.0;
+    }
+    else
+    {
+        const double th = 2.0 * atan2(n, q[3]);
+        const double k  = th / n;
+        wx = k * q[0]; wy = k * q[1]; wz = k * q[2];
+        if (th < 1e-4)
+            cc = 1.0 / 12.0 + th * th / 720.0;
+        else
+            cc = (1.0 - (th * sin(th)) / (2.0 * (1.0 - cos(th)))) / (th * th);
+    }
+    const double c1x = wy * tz - wz * ty, c1y = wz * tx - wx * tz, c1z = wx * ty - wy * tx;
+    const double c2x = wy * c1z - wz * c1y, c2y = wz * c1x - wx * c1z, c2z = wx * c1y - wy * c1x;
+    e[0] = tx - 0.5 * c1x + cc * c2x;
+    e[1] = ty - 0.5 * c1y + cc * c2y;
+    e[2] = tz - 0.5 * c1z + cc * c2z;
+    e[3] = wx; e[4] = wy; e[5] = wz;
+}
+
+// residual (dim 2 / 3) and its 6 derivatives per row; 0 when the point is not in front of the camera
+__device__ __forceinline__ int linearize(const double* R, const double* t, const double* p, const CamD& cam,
+                                         const snk_pose_obs& o, double* r, double* J)
+{
+    const double X = R[0] * p[0] + R[1] * p[1] + R[2] * p[2] + t[0];
+    const double Y = R[3] * p[0] + R[4] * p[1] + R[5] * p[2] + t[1];
+    const double Z = R[6] * p[0] + R[7] * p[1] + R[8] * p[2] + t[2];
+    if (Z <= 0.0) return 0;
+    const double iz = 1.0 / Z, iz2 = iz * iz, w = o.weight;
+    const int dim = o.depth > 0.0 ? 3 : 2;
+    double P[9];
+    r[0] = w * (cam.fx * X * iz + cam.cx - o.x);
+    r[1] = w * (cam.fy * Y * iz + cam.cy - o.y);
+    P[0] = cam.fx * iz; P[1] = 0.0;         P[2] = -cam.fx * X * iz2;
+    P[3] = 0.0;         P[4] = cam.fy * iz; P[5] = -cam.fy * Y * iz2;
+    r[2] = 0.0;
+    P[6] = P[7] = P[8] = 0.0;
+    if (dim == 3)
+    {
+        r[2] = w * ((cam.fx * X * iz + cam.cx - cam.bf * iz) - (o.x - cam.bf / o.depth));
+        P[6] = cam.fx * iz; P[8] = -cam.fx * X * iz2 + cam.bf * iz2;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+    {
+        const double a = w * P[3 * k], b = w * P[3 * k + 1], c = w * P[3 * k + 2];
+        J[6 * k + 0] = a;
+        J[6 * k + 1] = b;
+        J[6 * k + 2] = c;
+        J[6 * k + 3] = -b * Z + c * Y;
+        J[6 * k + 4] = a * Z - c * X;
+        J[6 * k + 5] = -a * Y + b * X;
+    }
+    return dim;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__device__ __forceinline__ double clampd(double v)
+{
+    return v < 1e-6 ? 1e-6 : (v > 1e32 ? 1e32 : v);
+}
+
+__device__ int chol_solve6(const double* A, const double* b, double* x)
+{
+    double L[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) L[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j)
+        {
+            double s = A[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= L[i * 6 + k] * L[j * 6 + k];
+            if (i == j)
+            {
+                if (!(s > 0.0)) return -1;
+                L[i * 6 + i] = sqrt(s);
+            }
+            else
+                L[i * 6 + j] = s / L[j * 6 + j];
+        }
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+    {
+        double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k];
+        y[i] = s / L[i * 6 + i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i)
+    {
+        double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * x[k];
+        x[i] = s / L[i * 6 + i];
+    }
+    return 0;
+}
+
+__global__ __launch_bounds__(64) void pose_kernel(const PoseMeta* __restrict__ meta, const double* __restrict__ wps,
+                                                  const snk_pose_obs* __restrict__ obs, u8* __restrict__ outlier,
+                                                  double* __restrict__ pose_out, int* __restrict__ inliers_out, CamD cam,
+                                                  snk_pose_options opt)
+{
+    const int lane    = threadIdx.x;
+    const PoseMeta& M = meta[blockIdx.x];
+    const int n       = M.n;
+    const double* W   = wps + 3 * (long long)M.off;
+    const snk_pose_obs* O = obs + M.off;
+    u8* out               = outlier + M.off;
+    double pose[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) pose[i] = M.pose[i];
+    for (int i = lane; i < n; i += 64) out[i] = 0;
+
+    int inliers = 0;
+    for (int round = 0; round < opt.outer_iterations; ++round)
+    {
+        const bool robust = round < opt.robust_rounds;
+        for (int it = 0; it < opt.inner_iterations; ++it)
+        {
+            double acc[27];  // upper triangle of H (21, row-major) then b (6)
+#pragma unroll
+            for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+            double R[9];
+            quat_to_R(pose, R);
+            for (int i = lane; i < n; i += 64)
+            {
+                if (out[i]) continue;
+                double r[3], J[18];
+                const double p[3] = {W[3 * i], W[3 * i + 1], W[3 * i + 2]};
+                const snk_pose_obs o = O[i];
+                const int dim        = linearize(R, pose + 4, p, cam, o, r, J);
+                if (!dim) continue;
+                const double s = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];  // r[2] = 0 for mono
+                double wgt     = 1.0;
+                if (robust)
+                {
+                    const double d = dim == 3 ? opt.th_stereo : opt.th_mono;
+                    if (s > d * d) wgt = d / sqrt(s);
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                {
+                    int u = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a)
+                    {
+                        const double ja = wgt * J[6 * k + a];
+                        acc[21 + a] += ja * r[k];
+#pragma unroll
+                        for (int c = a; c < 6; ++c) acc[u++] += ja * J[6 * k + c];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 27; ++i) acc[i] = wave_sum(acc[i]);
+            double H[36], b[6];
+            {
+                int u = 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+                {
+                    b[a] = acc[21 + a];
+#pragma unroll
+                    for (int c = a; c < 6; ++c) H[a * 6 + c] = acc[u++];
+                }
+            }
+            if (M.use_prior)
+            {
+                double e[6];
+                se3_log_rel(pose, M.pred, e);
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+                {
+                    const double w2 = a < 3 ? M.w_trans * M.w_trans : M.w_rot * M.w_rot;
+                    H[a * 6 + a] += w2;
+                    b[a] += w2 * e[a];
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+            {
+                H[a * 6 + a] += opt.lambda * clampd(H[a * 6 + a]);
+#pragma unroll
+                for (int c = 0; c < a; ++c) H[a * 6 + c] = H[c * 6 + a];
+            }
+            double nb[6], d[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) nb[a] = -b[a];
+            if (chol_solve6(H, nb, d) == 0) se3_update(pose, d);
+        }
+        // re-classify every match
+        double R[9];
+        quat_to_R(pose, R);
+        int cnt = 0;
+        for (int i = lane; i < n; i += 64)
+        {
+            double r[3], J[18];
+            const double p[3] = {W[3 * i], W[3 * i + 1], W[3 * i + 2]};
+            const snk_pose_obs o = O[i];
+            const int dim        = linearize(R, pose + 4, p, cam, o, r, J);
+            const double s       = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+            const double d       = dim == 3 ? opt.th_stereo : opt.th_mono;
+            const bool bad       = !dim || s > d * d;
+            out[i]               = bad ? 1 : 0;
+            cnt += bad ? 0 : 1;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+        inliers = cnt;
+    }
+    if (lane == 0)
+    {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) pose_out[7 * blockIdx.x + i] = pose[i];
+        inliers_out[blockIdx.x] = inliers;
+    }
+}
+}  // namespace
+}  // namespace snk
+
+using namespace snk;
+
+extern "C" int snk_pose_refine(snk_matcher* m, const snk_camera* cam, const snk_pose_options* opt, snk_pose_problem* problems,
+                               int n_problems)
+{
+    SNK_REQUIRE(m != nullptr && cam != nullptr && opt != nullptr, "NULL argument");
+    SNK_REQUIRE(n_problems >= 0 && (n_problems == 0 || problems != nullptr), "bad problem array");
+    SNK_REQUIRE(opt->outer_iterations >= 0 && opt->outer_iterations <= 64 && opt->inner_iterations >= 0 &&
+                    opt->inner_iterations <= 1000 && opt->robust_rounds >= 0,
+                "iteration counts out of range");
+    SNK_REQUIRE(opt->th_mono > 0.0 && opt->th_stereo > 0.0 && opt->lambda >= 0.0, "thresholds must be positive");
+    if (n_problems == 0) return SNK_OK;
+    size_t total = 0;
+    for (int i = 0; i < n_problems; ++i)
+    {
+        const snk_pose_problem& P = problems[i];
+        SNK_REQUIRE(P.n >= 0 && (P.n == 0 || (P.wps && P.obs && P.outlier)), "bad match arrays");
+        SNK_REQUIRE(P.w_rot >= 0.0 && P.w_trans >= 0.0, "prior weights must be >= 0");
+        total += (size_t)P.n;
+    }
+    SNK_REQUIRE(total < (size_t)1 << 30, "too many matches");
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    const size_t np     = (size_t)n_problems;
+    const size_t o_wps  = np * sizeof(PoseMeta);
+    const size_t o_obs  = o_wps + total * 24;
+    const size_t in_b   = o_obs + total * sizeof(snk_pose_obs);
+    const size_t o_pose = (total + 7) & ~(size_t)7, o_inl = o_pose + np * 56, out_b = o_inl + np * 4;
+    int rc;
+    if ((rc = m->q.reserve(in_b + 64)) != SNK_OK) return rc;
+    if ((rc = m->out.reserve(out_b + 64)) != SNK_OK) return rc;
+    // stage inputs contiguously on the host, one upload
+    std::string stage(in_b, '\0');
+    PoseMeta* meta = reinterpret_cast<PoseMeta*>(&stage[0]);
+    size_t off     = 0;
+    for (int i = 0; i < n_problems; ++i)
+    {
+        const snk_pose_problem& P = problems[i];
+        PoseMeta& M               = meta[i];
+        M.off                     = (int)off;
+        M.n                       = P.n;
+        M.use_prior               = (P.w_rot > 0.0 || P.w_trans > 0.0) ? 1 : 0;
+        M.pad                     = 0;
+        memcpy(M.pose, P.pose, 56);
+        memcpy(M.pred, P.prediction, 56);
+        M.w_rot   = P.w_rot;
+        M.w_trans = P.w_trans;
+        if (P.n > 0)
+        {
+            memcpy(&stage[o_wps + off * 24], P.wps, (size_t)P.n * 24);
+            memcpy(&stage[o_obs + off * sizeof(snk_pose_obs)], P.obs, (size_t)P.n * sizeof(snk_pose_obs));
+        }
+        off += (size_t)P.n;
+    }
+    char* d = m->q.as<char>();
+    char* o = m->out.as<char>();
+    SNK_HIP_CHECK(hipMemcpyAsync(d, stage.data(), in_b, hipMemcpyHostToDevice, m->stream));
+    CamD C{cam->fx, cam->fy, cam->cx, cam->cy, cam->bf};
+    hipLaunchKernelGGL(pose_kernel, dim3(n_problems), dim3(64), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
+                       reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),
+                       reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), reinterpret_cast<int*>(o + o_inl), C,
+                       *opt);
+    SNK_LAUNCH_CHECK();
+    std::string back(out_b, '\0');
+    SNK_HIP_CHECK(hipMemcpyAsync(&back[0], o, out_b, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    off = 0;
+    for (int i = 0; i < n_problems; ++i)
+    {
+        snk_pose_problem& P = problems[i];
+        if (P.n > 0) memcpy(P.outlier, &back[off], (size_t)P.n);
+        memcpy(P.pose, &back[o_pose + (size_t)i * 56], 56);
+        memcpy(&P.inliers, &back[o_inl + (size_t)i * 4], 4);
+        off += (size_t)P.n;
+    }
+    return SNK_OK;
+}

@@ -3,6 +3,7 @@
 ``SnakeORBMatcher`` mirrors ``Snake::SnakeORBMatcher`` (reference Snake/Tracking/SnakeORBMatcher.h:21-30)
 with the frame passed as a view (the SoA fields of Snake/Map/Features.h + the taken mask) and
 ``FeatureGrid.create`` mirrors ``frame.grid.create`` (reference Snake/Preprocess/Preprocess.cpp:246).
+``PoseRefinement`` mirrors ``Snake::PoseRefinement`` (reference Snake/Tracking/PoseRefinement.h:22-99).
 """
 from __future__ import annotations
 
@@ -109,3 +110,80 @@ class SnakeORBMatcher(_Handle):
                                                         _ptr(sk), len(pos), float(th), int(feature_error), _ptr(out), C.byref(n)),
                    "snk_match_project_keyframe")
         return n.value, out[: len(pos)]
+
+
+# ------------------------------------------------------------------ pose refinement ------------
+POSE_OBS_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("depth", "<f8"), ("weight", "<f8")])
+
+# Snake/System/SnakeGlobal.h:145-146
+REPROJECTION_ERROR_THRESHOLD_MONO = 2.1
+REPROJECTION_ERROR_THRESHOLD_STEREO = 2.3
+
+
+class PoseOptions(C.Structure):
+    _fields_ = [("th_mono", C.c_double), ("th_stereo", C.c_double), ("outer_iterations", C.c_int32),
+                ("inner_iterations", C.c_int32), ("robust_rounds", C.c_int32), ("pad", C.c_int32), ("lambda_", C.c_double)]
+
+
+class PoseProblem(C.Structure):
+    _fields_ = [("n", C.c_int32), ("inliers", C.c_int32), ("wps", C.c_void_p), ("obs", C.c_void_p), ("outlier", C.c_void_p),
+                ("pose", C.c_double * 7), ("prediction", C.c_double * 7), ("w_rot", C.c_double), ("w_trans", C.c_double)]
+
+
+def pose_observations(kps, depth, level_scale):
+    """obs[i] of PoseRefinement.h:47-55 from undistorted keypoints: weight = sqrt(InverseSquaredScale(octave))."""
+    kps = np.ascontiguousarray(kps, KP64_DTYPE)
+    ls = np.asarray(level_scale, np.float64)
+    obs = np.zeros(len(kps), POSE_OBS_DTYPE)
+    obs["x"], obs["y"] = kps["x"], kps["y"]
+    obs["depth"] = np.asarray(depth, np.float64)
+    obs["weight"] = np.sqrt(1.0 / (ls[kps["octave"]] ** 2))
+    return obs
+
+
+class PoseRefinement(_Handle):
+    """``PoseRefinement(errorFactor)``: thresholds = reprojectionErrorThreshold{Mono,Stereo} * errorFactor
+    (reference Snake/Tracking/PoseRefinement.cpp:13-15)."""
+
+    def __init__(self, errorFactor: float = 1.0, device: int = 0, outer: int = 4, inner: int = 10, robust_rounds: int = 3,
+                 lam: float = 1e-4):
+        super().__init__(device)
+        self.options = PoseOptions(REPROJECTION_ERROR_THRESHOLD_MONO * errorFactor, REPROJECTION_ERROR_THRESHOLD_STEREO * errorFactor,
+                                   outer, inner, robust_rounds, 0, lam)
+
+    def refine_batch(self, cam, frames):
+        """frames: list of dict(pose[7], wps[n,3], obs[n], optional prediction[7], w_rot, w_trans).
+        Returns a list of (pose[7], outlier[n] uint8, inliers) — one launch for the whole list."""
+        probs = (PoseProblem * max(len(frames), 1))()
+        keep = []
+        for P, f in zip(probs, frames):
+            wps = np.ascontiguousarray(f["wps"], np.float64).reshape(-1, 3)
+            obs = np.ascontiguousarray(f["obs"], POSE_OBS_DTYPE)
+            if len(wps) != len(obs):
+                raise ValueError("wps / obs length mismatch")
+            outl = np.zeros(max(len(obs), 1), np.uint8)
+            keep.append((wps, obs, outl))
+            P.n = len(obs)
+            P.wps, P.obs, P.outlier = (wps.ctypes.data if wps.size else 0), (obs.ctypes.data if obs.size else 0), outl.ctypes.data
+            P.pose[:] = [float(v) for v in f["pose"]]
+            pred = f.get("prediction")
+            P.prediction[:] = [float(v) for v in (pred if pred is not None else f["pose"])]
+            P.w_rot, P.w_trans = float(f.get("w_rot", 0.0)), float(f.get("w_trans", 0.0))
+        c = Camera(*cam)
+        _lib.check(self._lib.snk_pose_refine(self._h, C.byref(c), C.byref(self.options), probs, len(frames)), "snk_pose_refine")
+        return [(np.array(P.pose[:]), k[2][: P.n].copy(), int(P.inliers)) for P, k in zip(probs, keep)]
+
+    def refinePose(self, cam, pose, wps, obs, prediction=None, prediction_weight_rotation=0.0,
+                   prediction_weight_translation=0.0):
+        """The optimiser call of ``refinePose`` (PoseRefinement.h:62-76): the smooth variant when
+        prediction_weight_rotation > 0.  Returns (pose, outlier, inliers)."""
+        f = dict(pose=pose, wps=wps, obs=obs)
+        if prediction_weight_rotation > 0:
+            f.update(prediction=prediction, w_rot=prediction_weight_rotation, w_trans=prediction_weight_translation)
+        return self.refine_batch(cam, [f])[0]
+
+    def RefinePoseWithMatches(self, cam, pose, wps, obs):
+        """PoseRefinement.cpp:25-79: fewer than 3 correspondences -> 0 inliers, pose untouched."""
+        if len(obs) < 3:
+            return np.array(pose, np.float64), np.zeros(len(obs), np.uint8), 0
+        return self.refine_batch(cam, [dict(pose=pose, wps=wps, obs=obs)])[0]

@@ -62,9 +62,28 @@ def main():
     chi = orc.ba_chi2(sc)
     np.savez_compressed(OUT / "ba_small.npz", **{f"in_{k}": np.asarray(v) for k, v in sc.items()}, pose=pose, pt=pt,
                         cost=np.array([c0, c1]), chi2=chi)
+    make_pose()
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size, "bytes")
 
 
+def make_pose():
+    """Pose refinement (snk-pose v1): one frame with outliers, one with a prediction prior."""
+    import pose_helpers as PH
+
+    orc.build()
+    cam = orc.Camera(*PH.CAM)
+    pr = PH.make_problem(501, 120, outlier_frac=0.2)
+    pose, outl, inl = orc.pose_refine(pr["pose0"], cam, pr["wps"], pr["obs"])
+    pred = PH.perturb(np.random.default_rng(502), pr["pose_gt"], 0.02, 0.05)
+    pose_s, outl_s, inl_s = orc.pose_refine(pr["pose0"], cam, pr["wps"], pr["obs"], prediction=pred, w_rot=50.0, w_trans=20.0)
+    np.savez_compressed(OUT / "pose_small.npz", cam=np.array(PH.CAM), pose0=pr["pose0"], wps=pr["wps"], obs=pr["obs"],
+                        pose=pose, outlier=outl, inliers=inl, prediction=pred, prior=np.array([50.0, 20.0]), pose_s=pose_s,
+                        outlier_s=outl_s, inliers_s=inl_s, chi2=orc.pose_chi2(pose, cam, pr["wps"], pr["obs"]))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "pose":  # regenerate only pose_small.npz
+        make_pose()
+    else:
+        main()
