@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="stereo frames per GPU per step")
     ap.add_argument("--ba-windows", type=int, default=256, help="independent local-BA windows per GPU per step (0 = skip)")
+    ap.add_argument("--pose-frames", type=int, default=256, help="frames per pose-refinement call (0 = skip; single GPU only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events")
     args = ap.parse_args()
@@ -234,6 +235,37 @@ def main():
         ba.close()
         ba1.close()
 
+    # ---- pose refinement after the matchers: 256 frames x 300 matches per call.
+    # Host API (host pointers in, synchronous), so the figure includes staging and PCIe; single GPU only.
+    pose_out = None
+    if world == 1 and args.pose_frames > 0:
+        from snake_slam_amd.tracking import PoseRefinement
+
+        probs = [synth.pose_problem(7000 + k, 300, outlier_frac=0.2) for k in range(8)]
+        batch = [dict(pose=probs[k % 8]["pose0"], wps=probs[k % 8]["wps"], obs=probs[k % 8]["obs"]) for k in range(args.pose_frames)]
+        ref = PoseRefinement(device=local)
+        res = ref.refine_batch(synth.POSE_CAM, batch)
+        tp0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            res = ref.refine_batch(synth.POSE_CAM, batch)
+        tp1 = time.perf_counter()
+        ref.close()
+        pose_out = {"metric": "pose refinements/s (300 matches, 20 % outliers, 4 x 10 GN iterations), host API incl. staging",
+                    "value": round(args.pose_frames * reps / (tp1 - tp0), 1), "unit": "frames/s", "frames_per_call": args.pose_frames,
+                    "ms_per_call": round((tp1 - tp0) / reps * 1e3, 3), "inliers_frame0": int(res[0][2]), "dtype": "f64"}
+        if not args.no_cpu_baseline:
+            from oracle import oracle as orc
+
+            cam = orc.Camera(*synth.POSE_CAM)
+            tc0, done = time.perf_counter(), 0
+            while time.perf_counter() - tc0 < 2.0:
+                pr = probs[done % 8]
+                orc.pose_refine(pr["pose0"], cam, pr["wps"], pr["obs"])
+                done += 1
+            pose_out["cpu_baseline"] = {"value": round(done / (time.perf_counter() - tc0), 1), "unit": "frames/s", "cores": 1,
+                                        "kind": "port", "sample": f"{done} refinements of the same problems"}
+
     # ---- result gather: one fixed-size block per rank (RCCL all_gather over xGMI) ----
     block = torch.tensor([float(B * args.steps), float(nkp.sum().item()), float(n_stereo.sum().item()),
                           float(n_pairs.sum().item()), t1 - t0, 0.0, 0.0, 0.0], dtype=torch.float64, device=dev)
@@ -282,6 +314,8 @@ def main():
             out["stage_ms_per_step"] = {k: round(v / n_calls, 4) for k, v in zip(["pyramid", "blur", "fast", "distribute", "describe"], stage_ms)}
         if ba_out is not None:
             out["ba"] = ba_out
+        if pose_out is not None:
+            out["pose_refine"] = pose_out
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames)
             if ba_out is not None:
