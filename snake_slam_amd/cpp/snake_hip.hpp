@@ -8,6 +8,7 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -376,4 +377,58 @@ class BARec
     snk_ba* h_    = nullptr;
     Scene* scene_ = nullptr;
 };
+
+// ------------------------------------------------------------------------------------------------
+// The `.features` cache either side of the extractor — reference
+// Snake/Preprocess/FeatureDetector.cpp:94-111 (read) and :134-139 / :166-171 (write):
+//   BinaryFile << std::vector<Saiga::KeyPoint<double>> << std::vector<DescriptorORB>
+// Saiga::BinaryFile (absent submodule) streams a vector as its element count followed by the raw
+// elements.  ASSUMED layout (unverified against a file written by a real Snake-SLAM build): count as
+// 64-bit little-endian size_t; KeyPoint<double> = {Vec2d point; double size, angle, response;
+// int octave;} padded to 48 bytes; DescriptorORB = 32 bytes.
+// ------------------------------------------------------------------------------------------------
+struct KeyPointD
+{
+    double x, y;
+    double size, angle, response;
+    int32_t octave;
+    int32_t pad;
+};
+static_assert(sizeof(KeyPointD) == 48, "KeyPoint<double> layout");
+
+inline void WriteFeatures(const std::string& file, const std::vector<KeyPointD>& keypoints,
+                          const std::vector<DescriptorORB>& descriptors)
+{
+    FILE* f = std::fopen(file.c_str(), "wb");
+    if (!f) throw std::runtime_error("cannot open " + file);
+    const uint64_t nk = keypoints.size(), nd = descriptors.size();
+    bool ok = std::fwrite(&nk, 8, 1, f) == 1 && (nk == 0 || std::fwrite(keypoints.data(), sizeof(KeyPointD), nk, f) == nk) &&
+              std::fwrite(&nd, 8, 1, f) == 1 && (nd == 0 || std::fwrite(descriptors.data(), 32, nd, f) == nd);
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok) throw std::runtime_error("short write to " + file);
+}
+
+inline void ReadFeatures(const std::string& file, std::vector<KeyPointD>& keypoints, std::vector<DescriptorORB>& descriptors)
+{
+    FILE* f = std::fopen(file.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + file);
+    auto fail = [&](const char* what) {
+        std::fclose(f);
+        throw std::runtime_error(std::string(what) + " in " + file);
+    };
+    uint64_t nk = 0, nd = 0;
+    if (std::fread(&nk, 8, 1, f) != 1 || nk > (1u << 24)) fail("bad keypoint count");
+    keypoints.resize(nk);
+    if (nk && std::fread(keypoints.data(), sizeof(KeyPointD), nk, f) != nk) fail("truncated keypoints");
+    if (std::fread(&nd, 8, 1, f) != 1 || nd > (1u << 24)) fail("bad descriptor count");
+    descriptors.resize(nd);
+    if (nd && std::fread(descriptors.data(), 32, nd, f) != nd) fail("truncated descriptors");
+    std::fclose(f);
+}
+
+// frame.keypoints.emplace_back(kp.cast<double>()) — FeatureDetector.cpp:128-131
+inline KeyPointD cast_double(const snk_keypoint& k)
+{
+    return KeyPointD{(double)k.x, (double)k.y, (double)k.size, (double)k.angle, (double)k.response, k.octave, 0};
+}
 }  // namespace snake_hip
