@@ -316,6 +316,45 @@ SNK_API int snk_match_project_keyframe(snk_matcher* m, const snk_frame_view* fra
                                        int feature_error, int32_t* match_idx, int* n_matches);
 
 /* ------------------------------------------------------------------------------------------
+ * Keyframe-rate matchers of local mapping
+ * ------------------------------------------------------------------------------------------ */
+
+/* FusionPoint, all fields (Snake/Map/LocalMap.h:57-80). */
+typedef struct snk_fusion_point
+{
+    double pos[3], normal[3];
+    uint64_t desc[4];
+    float reference_depth;
+    int32_t reference_scale_level;
+    int32_t observations;
+    int32_t id;
+} snk_fusion_point;
+
+/* Replaces MappingORBMatcher::Fuse(kf, pose, point_mask, LocalMap<FusionPoint>, fuseCandidates, th,
+ * obs_factor, feature_th) — Snake/LocalMapping/MappingORBMatcher.cpp:359-480 (call sites
+ * Snake/LocalMapping/NeighbourSearch.cpp:177,188).  frame = kf->frame (grid order; `taken` unused),
+ * point_mask may be NULL.  best_idx[i] = keyframe feature point i would be fused into, or -1; the
+ * caller emplaces (best_idx[i], pts[i].id) in point order.  *n_fused = the return value. */
+SNK_API int snk_match_fuse(snk_matcher* m, const snk_frame_view* frame, const snk_camera* cam, const double pose[7],
+                           const snk_fusion_point* pts, const uint8_t* point_mask, int n_pts, float th, float obs_factor,
+                           int feature_th, const float* level_scale, int n_levels, int32_t* best_idx, int* n_fused);
+
+/* Replaces MappingORBMatcher::SearchForTriangulationProject — MappingORBMatcher.cpp:168-249 (call
+ * site Snake/LocalMapping/Triangulator.cpp:170).  depth_grid: row-major [grid_rows][grid_cols], one
+ * depth per 4 x 4 feature-grid cells (:194-195); kps1 / np1 / desc1 / has_mp1: keyframe 1
+ * (undistorted_keypoints, normalized_points, descriptors, GetMapPoint(i) != nullptr), any order;
+ * frame2: keyframe 2 in grid order with taken[i] = GetMapPoint(i) != nullptr, np2 its
+ * normalized_points; E12 row-major.  Saiga::EpipolarDistanceSquared (absent) is [DEFINED] as the
+ * squared distance of np2 to the line E12 * (np1, 1).  match_idx2[i] = feature of keyframe 2 paired
+ * with feature i of keyframe 1, or -1. */
+SNK_API int snk_match_triangulation_project(snk_matcher* m, const double* depth_grid, int grid_rows, int grid_cols,
+                                            const double pose1[7], const double pose2[7], const snk_camera* cam,
+                                            const snk_kp64* kps1, const double (*np1)[2], const uint64_t (*desc1)[4],
+                                            const uint8_t* has_mp1, int n1, const snk_frame_view* frame2,
+                                            const double (*np2)[2], const double E12[9], float epipolar_distance,
+                                            int feature_distance, int32_t* match_idx2, int* n_matches);
+
+/* ------------------------------------------------------------------------------------------
  * Pose refinement (the step after every projection matcher)
  * ------------------------------------------------------------------------------------------ */
 

@@ -389,6 +389,46 @@ def match_keyframe(frame, cam, pose, pos, desc, skip, th, feature_error):
     return n, out[: len(pos)]
 
 
+FUSION_POINT = np.dtype([("pos", "<f8", 3), ("normal", "<f8", 3), ("desc", "<u8", 4), ("reference_depth", "<f4"),
+                         ("reference_scale_level", "<i4"), ("observations", "<i4"), ("id", "<i4")])
+
+
+def match_fuse(frame, cam, pose, pts, point_mask, th, obs_factor, feature_th, level_scale):
+    """MappingORBMatcher::Fuse (LocalMap overload).  Returns (fused, best_idx[m])."""
+    v, keep = make_frame_view(frame)
+    pts = np.ascontiguousarray(pts, FUSION_POINT)
+    ls = np.ascontiguousarray(level_scale, np.float32)
+    pose = np.ascontiguousarray(pose, np.float64)
+    mask = None if point_mask is None else np.ascontiguousarray(point_mask, np.uint8)
+    out = np.zeros(max(len(pts), 1), np.int32)
+    c = Camera(*cam)
+    lib().orc_match_fuse.restype = C.c_int
+    n = lib().orc_match_fuse(C.byref(v), C.byref(c), _p(pose), _p(pts), None if mask is None else _p(mask), C.c_int(len(pts)),
+                             C.c_float(th), C.c_float(obs_factor), C.c_int(feature_th), _p(ls), C.c_int(len(ls)), _p(out))
+    return n, out[: len(pts)]
+
+
+def match_triangulation_project(depth_grid, pose1, pose2, cam, kps1, np1, desc1, has_mp1, frame2, np2, E12, epipolar_distance,
+                                feature_distance):
+    """MappingORBMatcher::SearchForTriangulationProject.  Returns (n, match_idx2[n1])."""
+    v, keep = make_frame_view(frame2)
+    g = np.ascontiguousarray(depth_grid, np.float64)
+    kps1 = np.ascontiguousarray(kps1, KP64)
+    np1 = np.ascontiguousarray(np1, np.float64).reshape(-1, 2)
+    np2 = np.ascontiguousarray(np2, np.float64).reshape(-1, 2)
+    desc1 = np.ascontiguousarray(desc1, np.uint64).reshape(-1, 4)
+    has1 = np.ascontiguousarray(has_mp1, np.uint8)
+    p1, p2 = np.ascontiguousarray(pose1, np.float64), np.ascontiguousarray(pose2, np.float64)
+    E = np.ascontiguousarray(E12, np.float64).reshape(9)
+    out = np.zeros(max(len(kps1), 1), np.int32)
+    c = Camera(*cam)
+    lib().orc_match_triangulation_project.restype = C.c_int
+    n = lib().orc_match_triangulation_project(_p(g), C.c_int(g.shape[0]), C.c_int(g.shape[1]), _p(p1), _p(p2), C.byref(c),
+                                              _p(kps1), _p(np1), _p(desc1), _p(has1), C.c_int(len(kps1)), C.byref(v), _p(np2),
+                                              _p(E), C.c_float(epipolar_distance), C.c_int(feature_distance), _p(out))
+    return n, out[: len(kps1)]
+
+
 # ------------------------------------------------------------------ pose refinement ------------
 class PoseObs(C.Structure):
     _fields_ = [("x", C.c_double), ("y", C.c_double), ("depth", C.c_double), ("weight", C.c_double)]

@@ -188,6 +188,25 @@ int orc_match_fine(const orc_frame_view* f, const orc_camera* cam, const double*
 int orc_match_keyframe(const orc_frame_view* f, const orc_camera* cam, const double* pose, const double (*pos)[3],
                        const uint64_t (*desc)[4], const uint8_t* skip, int m, float th, int feature_error, int32_t* match_idx);
 
+typedef struct orc_fusion_point /* Snake/Map/LocalMap.h:57-80 */
+{
+    double pos[3], normal[3];
+    uint64_t desc[4];
+    float reference_depth;
+    int32_t reference_scale_level;
+    int32_t observations;
+    int32_t id;
+} orc_fusion_point;
+
+int orc_match_fuse(const orc_frame_view* f, const orc_camera* cam, const double* pose, const orc_fusion_point* pts,
+                   const uint8_t* point_mask, int m, float th, float obs_factor, int feature_th, const float* level_scale,
+                   int n_levels, int32_t* best_idx);
+int orc_match_triangulation_project(const double* depth_grid, int grid_rows, int grid_cols, const double* pose1,
+                                    const double* pose2, const orc_camera* cam, const orc_kp64* kps1,
+                                    const double (*np1)[2], const uint64_t (*desc1)[4], const uint8_t* has_mp1, int n1,
+                                    const orc_frame_view* f2, const double (*np2)[2], const double* E12,
+                                    float epipolar_distance, int feature_distance, int32_t* match_idx2);
+
 /* ---- pose_oracle.c ---- */
 typedef struct orc_pose_obs /* Saiga ObsBase<double> as PoseRefinement.h:47-55 fills it */
 {

@@ -455,3 +455,165 @@ int orc_match_keyframe(const orc_frame_view* f, const orc_camera* cam, const dou
     free(taken2);
     return matches;
 }
+
+/* ================================================================================================
+ * Keyframe-rate matchers of local mapping
+ * ================================================================================================ */
+
+/* ---------- MappingORBMatcher::Fuse, LocalMap<FusionPoint> overload —
+ * Snake/LocalMapping/MappingORBMatcher.cpp:359-480 (call sites NeighbourSearch.cpp:177,188).
+ * MATCHING_MIN_MAX_DISTANCE2 and MATCHING_CHECK_SCALE_CONSISTENCY2 are defined
+ * (SnakeGlobal.h:168-169).  Every point is independent: best_idx[i] = feature of the keyframe the
+ * point would be fused into (fuseCandidates gets (best_idx[i], pts[i].id) in point order) or -1. */
+typedef struct fuse_ud
+{
+    const orc_frame_view* f;
+    const uint64_t* desc1;
+    double ipx, ipy, ur; /* projectStereo(np) = (u, v, u - bf / z) */
+    float gate;          /* th_squared * observationFactor */
+    int best_dist, best_idx;
+} fuse_ud;
+
+static int fuse_cand(void* p, int idx)
+{
+    fuse_ud* u        = (fuse_ud*)p;
+    const orc_kp64* kp = &u->f->kps[idx];
+    const double dx = u->ipx - kp->x, dy = u->ipy - kp->y;
+    double e2 = dx * dx + dy * dy;
+    if (u->f->right_points[idx] > 0) /* hasDepth(idx) :447 */
+    {
+        const double dr = u->ur - (double)u->f->right_points[idx];
+        e2 += dr * dr; /* (ips - ips2).squaredNorm() :454 */
+    }
+    if (e2 > (double)u->gate) return 0; /* :455 / :460 */
+    const int dist = orc_hamming(u->desc1, u->f->desc[idx]);
+    if (dist < u->best_dist) /* :465 */
+    {
+        u->best_dist = dist;
+        u->best_idx  = idx;
+    }
+    return 0;
+}
+
+int orc_match_fuse(const orc_frame_view* f, const orc_camera* cam, const double* pose, const orc_fusion_point* pts,
+                   const uint8_t* point_mask, int m, float th, float obs_factor, int feature_th, const float* level_scale,
+                   int n_levels, int32_t* best_idx)
+{
+    view_ctx c;
+    make_ctx(pose, &c);
+    const float th_squared = th * th; /* :370 */
+    const double log_f     = orc_det_log(n_levels > 1 ? (double)level_scale[1] / (double)level_scale[0] : 1.2);
+    const double s_last    = (double)level_scale[n_levels - 1];
+    int fused              = 0;
+    for (int i = 0; i < m; ++i) /* :376 */
+    {
+        best_idx[i] = -1;
+        const orc_fusion_point* lmp = &pts[i];
+        if (point_mask && !point_mask[i]) continue; /* :381 */
+        double np[3];
+        transform(&c, lmp->pos, np);
+        if (np[2] <= 0) continue; /* :391 */
+        const double ipx = cam->fx * np[0] / np[2] + cam->cx, ipy = cam->fy * np[1] / np[2] + cam->cy; /* :393 */
+        if (!in_image(&f->bounds, ipx, ipy)) continue;                                                 /* :394 */
+        const double PO[3] = {c.campos[0] - lmp->pos[0], c.campos[1] - lmp->pos[1], c.campos[2] - lmp->pos[2]};
+        const double dist  = sqrt(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]); /* :397 */
+        int rl             = lmp->reference_scale_level;
+        rl                 = rl < 0 ? 0 : (rl >= n_levels ? n_levels - 1 : rl);
+        const double sref     = (double)level_scale[rl];
+        const double max_dist = 1.2 * (double)lmp->reference_depth * sref; /* EstimateMinMaxDistance :402-407 */
+        const double min_dist = 0.8 * (double)lmp->reference_depth * sref / s_last;
+        if (dist < min_dist || dist > max_dist) continue;
+        if (PO[0] * lmp->normal[0] + PO[1] * lmp->normal[1] + PO[2] * lmp->normal[2] < 0.5 * dist) continue; /* :414 */
+        const float observationFactor = lmp->observations <= 2 ? obs_factor : 1.0f;                           /* :420-424 */
+        const float radius            = observationFactor * th;                                               /* :429 */
+        double prediction = (double)lmp->reference_scale_level + orc_det_log((double)lmp->reference_depth / dist) / log_f; /* :433 */
+        if (prediction < 0.0) prediction = 0.0;
+        if (prediction > (double)(n_levels - 1)) prediction = (double)(n_levels - 1);
+        fuse_ud u;
+        u.f = f; u.desc1 = lmp->desc; u.ipx = ipx; u.ipy = ipy; u.ur = ipx - cam->bf / np[2];
+        u.gate = th_squared * observationFactor;
+        u.best_dist = 256; u.best_idx = -1; /* :447-448 */
+        for_candidates(f, ipx, ipy, (double)radius, (double)radius * (double)radius, 2, 0, 0, prediction, fuse_cand, &u); /* :434 */
+        if (u.best_idx >= 0 && u.best_dist <= feature_th) /* :472 */
+        {
+            best_idx[i] = u.best_idx;
+            fused++;
+        }
+    }
+    return fused;
+}
+
+/* ---------- MappingORBMatcher::SearchForTriangulationProject —
+ * Snake/LocalMapping/MappingORBMatcher.cpp:168-249 (call site Triangulator.cpp:170).
+ * kf1 side: plain arrays (any order); kf2 side: a frame view in grid order whose `taken` flags mean
+ * "already has a map point" (:218) plus its normalized points.  tmp_flags is never set by the
+ * reference, so every feature of kf1 is independent.  [DEFINED] Saiga::EpipolarDistanceSquared
+ * (absent): squared distance of np2 to the epipolar line E * (np1, 1) in image 2. */
+typedef struct tri_ud
+{
+    const orc_frame_view* f;
+    const double (*np2)[2];
+    const uint64_t* desc1;
+    double l[3], th_chi2;
+    int feature_distance, best_dist, best_idx;
+} tri_ud;
+
+static int tri_cand(void* p, int idx2)
+{
+    tri_ud* u = (tri_ud*)p;
+    if (u->f->taken[idx2]) return 0; /* :218 */
+    const double d      = u->np2[idx2][0] * u->l[0] + u->np2[idx2][1] * u->l[1] + u->l[2];
+    const double disepi = d * d / (u->l[0] * u->l[0] + u->l[1] * u->l[1]);
+    if (disepi > u->th_chi2) return 0; /* :224 */
+    const int dist = orc_hamming(u->desc1, u->f->desc[idx2]);
+    if (dist > u->feature_distance || dist > u->best_dist) return 0; /* :232 */
+    u->best_idx  = idx2;
+    u->best_dist = dist;
+    return 0;
+}
+
+int orc_match_triangulation_project(const double* depth_grid, int grid_rows, int grid_cols, const double* pose1,
+                                    const double* pose2, const orc_camera* cam, const orc_kp64* kps1,
+                                    const double (*np1)[2], const uint64_t (*desc1)[4], const uint8_t* has_mp1, int n1,
+                                    const orc_frame_view* f2, const double (*np2)[2], const double* E12,
+                                    float epipolar_distance, int feature_distance, int32_t* match_idx2)
+{
+    view_ctx c1, c2;
+    make_ctx(pose1, &c1);
+    make_ctx(pose2, &c2);
+    const double th_chi1 = (double)epipolar_distance / cam->fx; /* :174 */
+    const double th_chi2 = th_chi1 * th_chi1;
+    int nmatches         = 0;
+    for (int i = 0; i < n1; ++i) /* :187 */
+    {
+        match_idx2[i] = -1;
+        if (has_mp1[i]) continue; /* :191 */
+        const int cx = cell_coord(kps1[i].x, f2->bounds.min_x, f2->cols), cy = cell_coord(kps1[i].y, f2->bounds.min_y, f2->rows);
+        const int gr = cy / 4 < grid_rows ? cy / 4 : grid_rows - 1, gc = cx / 4 < grid_cols ? cx / 4 : grid_cols - 1;
+        const double z = depth_grid[gr * grid_cols + gc]; /* :195 */
+        /* wp = pose1^-1 * K.unproject(point, z) */
+        const double pc[3] = {(kps1[i].x - cam->cx) / cam->fx * z, (kps1[i].y - cam->cy) / cam->fy * z, z};
+        const double d[3]  = {pc[0] - c1.t[0], pc[1] - c1.t[1], pc[2] - c1.t[2]};
+        const double wp[3] = {c1.R[0] * d[0] + c1.R[3] * d[1] + c1.R[6] * d[2], c1.R[1] * d[0] + c1.R[4] * d[1] + c1.R[7] * d[2],
+                              c1.R[2] * d[0] + c1.R[5] * d[1] + c1.R[8] * d[2]};
+        double p2[3];
+        transform(&c2, wp, p2);
+        const double ipx = cam->fx * p2[0] / p2[2] + cam->cx, ipy = cam->fy * p2[1] / p2[2] + cam->cy; /* :198 */
+        if (!in_image(&f2->bounds, ipx, ipy)) continue;                                                 /* :201 */
+        tri_ud u;
+        u.f = f2; u.np2 = np2; u.desc1 = desc1[i];
+        const double x = np1[i][0], y = np1[i][1];
+        u.l[0] = E12[0] * x + E12[1] * y + E12[2];
+        u.l[1] = E12[3] * x + E12[4] * y + E12[5];
+        u.l[2] = E12[6] * x + E12[7] * y + E12[8];
+        u.th_chi2 = th_chi2; u.feature_distance = feature_distance;
+        u.best_dist = 50; u.best_idx = -1; /* TH_LOW :206-207 */
+        for_candidates(f2, ipx, ipy, 20.0, 400.0, 0, 0, 0, 0.0, tri_cand, &u); /* GetFeaturesInArea(ip2, 20) :211 */
+        if (u.best_idx >= 0)
+        {
+            match_idx2[i] = u.best_idx;
+            nmatches++;
+        }
+    }
+    return nmatches;
+}

@@ -53,6 +53,9 @@ SIGNATURES = {
     "snk_match_project_fine": (i32, [vp, vp, vp, vp, vp, i32, f32, f32, vp, i32, vp, vp, C.POINTER(i32)]),
     "snk_match_project_keyframe": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, f32, i32, vp, C.POINTER(i32)]),
     "snk_pose_refine": (i32, [vp, vp, vp, vp, i32]),
+    "snk_match_fuse": (i32, [vp, vp, vp, vp, vp, vp, i32, f32, f32, i32, vp, i32, vp, C.POINTER(i32)]),
+    "snk_match_triangulation_project": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, f32, i32, vp,
+                                              C.POINTER(i32)]),
     "snk_orb_create": (i32, [vp, i32, vp, C.POINTER(vp)]),
     "snk_orb_destroy": (i32, [vp]),
     "snk_orb_sync": (i32, [vp]),

@@ -243,6 +243,62 @@ class SnakeORBMatcher
     snk_matcher* h_ = nullptr;
 };
 
+// Snake::MappingORBMatcher (reference Snake/LocalMapping/MappingORBMatcher.h:15-45): the two keyframe-rate
+// matchers that need no bag-of-words.  MapPoint / Keyframe pointers stay on the Snake side.
+class MappingORBMatcher
+{
+   public:
+    explicit MappingORBMatcher(int device = 0) { check(snk_matcher_create(device, nullptr, &h_), "snk_matcher_create"); }
+    ~MappingORBMatcher() { snk_matcher_destroy(h_); }
+    MappingORBMatcher(const MappingORBMatcher&)            = delete;
+    MappingORBMatcher& operator=(const MappingORBMatcher&) = delete;
+
+    // Fuse(kf, pose, point_mask, LocalMap<FusionPoint>, fuseCandidates, th, obs_factor, feature_th)
+    // — MappingORBMatcher.cpp:359-480; kf_frame = kf->frame as a view, point_mask may be empty (= nullptr)
+    int Fuse(const FrameView& kf_frame, const snk_camera& K, const double pose[7], const std::vector<uint8_t>& point_mask,
+             const std::vector<snk_fusion_point>& points, std::vector<std::pair<int, int>>& fuseCandidates, float th,
+             float obs_factor, int feature_th, const std::vector<float>& level_scale)
+    {
+        fuseCandidates.clear();
+        if (!point_mask.empty() && point_mask.size() != points.size()) throw std::invalid_argument("point_mask size");
+        const snk_frame_view v = kf_frame.view();
+        std::vector<int32_t> best(points.size() + 1, -1);
+        int n = 0;
+        check(snk_match_fuse(h_, &v, &K, pose, points.data(), point_mask.empty() ? nullptr : point_mask.data(), (int)points.size(),
+                             th, obs_factor, feature_th, level_scale.data(), (int)level_scale.size(), best.data(), &n),
+              "snk_match_fuse");
+        for (size_t i = 0; i < points.size(); ++i)
+            if (best[i] >= 0) fuseCandidates.emplace_back(best[i], points[i].id);
+        return n;
+    }
+    // SearchForTriangulationProject(grid, pose1, pose2, kf1, kf2, E12, vMatchedPairs, epipolarDistance,
+    // featureDistance) — MappingORBMatcher.cpp:168-249; pairs are APPENDED like the reference does
+    int SearchForTriangulationProject(const double* grid, int grid_rows, int grid_cols, const double pose1[7],
+                                      const double pose2[7], const snk_camera& K, const std::vector<snk_kp64>& keypoints1,
+                                      const std::vector<std::array<double, 2>>& normalized1,
+                                      const std::vector<DescriptorORB>& descriptors1, const std::vector<uint8_t>& has_mp1,
+                                      const FrameView& kf2_frame, const std::vector<std::array<double, 2>>& normalized2,
+                                      const double E12[9], std::vector<std::pair<int, int>>& vMatchedPairs, float epipolarDistance,
+                                      int featureDistance)
+    {
+        const snk_frame_view v = kf2_frame.view();
+        std::vector<int32_t> match(keypoints1.size() + 1, -1);
+        int n = 0;
+        check(snk_match_triangulation_project(h_, grid, grid_rows, grid_cols, pose1, pose2, &K, keypoints1.data(),
+                                              reinterpret_cast<const double(*)[2]>(normalized1.data()),
+                                              reinterpret_cast<const uint64_t(*)[4]>(descriptors1.data()), has_mp1.data(),
+                                              (int)keypoints1.size(), &v, reinterpret_cast<const double(*)[2]>(normalized2.data()),
+                                              E12, epipolarDistance, featureDistance, match.data(), &n),
+              "snk_match_triangulation_project");
+        for (size_t i = 0; i < keypoints1.size(); ++i)
+            if (match[i] >= 0) vMatchedPairs.emplace_back((int)i, match[i]);
+        return n;
+    }
+
+   private:
+    snk_matcher* h_ = nullptr;
+};
+
 // Snake::PoseRefinement (reference Snake/Tracking/PoseRefinement.h:22-99): the robust pose-only
 // optimisation after every matcher call.  The caller gathers wps / obs / idx exactly as refinePose
 // (:35-60) and RefinePoseWithMatches (PoseRefinement.cpp:37-57) do, then writes outlier[i] to

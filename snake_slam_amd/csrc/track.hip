@@ -457,6 +457,174 @@ __global__ __launch_bounds__(256) void reorder_kernel(const int* __restrict__ or
     dout[(base + p) * 2 + 1] = din[(base + src) * 2 + 1];
 }
 
+// ---- local-mapping matchers (keyframe rate): every point / feature is independent -------------------
+
+__device__ __forceinline__ u32 wave_min_u32(u32 v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+    {
+        const u32 o = __shfl_xor(v, off);
+        v           = o < v ? o : v;
+    }
+    return v;
+}
+
+// MappingORBMatcher::Fuse, LocalMap<FusionPoint> overload (reference
+// Snake/LocalMapping/MappingORBMatcher.cpp:359-480).  One wavefront per point; best[i] = feature or -1.
+__global__ __launch_bounds__(256) void fuse_kernel(FrameDev F, CamDev C, ScalesDev S, const snk_fusion_point* __restrict__ pts,
+                                                   const u8* __restrict__ mask, int m, float th, float obs_factor,
+                                                   int feature_th, int* __restrict__ best)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= m) return;
+    int result = -1;
+    const snk_fusion_point lmp = pts[i];
+    bool go = !(mask && !mask[i]);
+    double ipx = 0, ipy = 0, z = 1, dist = 1;
+    if (go)
+    {
+        const double pcx = C.R[0] * lmp.pos[0] + C.R[1] * lmp.pos[1] + C.R[2] * lmp.pos[2] + C.t[0];
+        const double pcy = C.R[3] * lmp.pos[0] + C.R[4] * lmp.pos[1] + C.R[5] * lmp.pos[2] + C.t[1];
+        z                = C.R[6] * lmp.pos[0] + C.R[7] * lmp.pos[1] + C.R[8] * lmp.pos[2] + C.t[2];
+        go               = !(z <= 0);
+        if (go)
+        {
+            ipx = C.fx * pcx / z + C.cx;
+            ipy = C.fy * pcy / z + C.cy;
+            go  = ipx >= F.min_x && ipx < F.max_x && ipy >= F.min_y && ipy < F.max_y;
+        }
+    }
+    if (go)
+    {
+        const double POx = C.campos[0] - lmp.pos[0], POy = C.campos[1] - lmp.pos[1], POz = C.campos[2] - lmp.pos[2];
+        dist             = sqrt(POx * POx + POy * POy + POz * POz);
+        int rl           = lmp.reference_scale_level;
+        rl               = rl < 0 ? 0 : (rl >= S.n ? S.n - 1 : rl);
+        const double sref     = (double)S.s[rl];
+        const double max_dist = 1.2 * (double)lmp.reference_depth * sref;
+        const double min_dist = 0.8 * (double)lmp.reference_depth * sref / S.s_last;
+        go = !(dist < min_dist || dist > max_dist) &&
+             !(POx * lmp.normal[0] + POy * lmp.normal[1] + POz * lmp.normal[2] < 0.5 * dist);
+    }
+    if (go)
+    {
+        const float of     = lmp.observations <= 2 ? obs_factor : 1.0f;
+        const float radius = of * th;
+        const float gate   = (th * th) * of;
+        double prediction  = (double)lmp.reference_scale_level + det_log((double)lmp.reference_depth / dist) / S.log_f;
+        if (prediction < 0.0) prediction = 0.0;
+        if (prediction > (double)(S.n - 1)) prediction = (double)(S.n - 1);
+        const double r = (double)radius, r2 = r * r, ur = ipx - C.bf / z;
+        uint4 qa, qc;
+        split_desc(lmp.desc, qa, qc);
+        const int cx0 = cell_coord(ipx - r, F.min_x, F.cols), cx1 = cell_coord(ipx + r, F.min_x, F.cols);
+        const int cy0 = cell_coord(ipy - r, F.min_y, F.rows), cy1 = cell_coord(ipy + r, F.min_y, F.rows);
+        u32 k1 = PJ_INF_KEY;
+        for (int cx = cx0; cx <= cx1; ++cx)
+        {
+            const int lo = F.cell_start[cx * F.rows + cy0], hi = F.cell_start[cx * F.rows + cy1 + 1];
+            for (int pid = lo + lane; pid < hi; pid += 64)
+            {
+                const snk_kp64 kp = F.kps[pid];
+                if (fabs(prediction - (double)kp.octave) > 1.0) continue;
+                const double ax = kp.x - ipx, ay = kp.y - ipy;  // area query: (kp.point - position).squaredNorm() < r2
+                if (!(ax * ax + ay * ay < r2)) continue;
+                const double dx = ipx - kp.x, dy = ipy - kp.y;
+                double e2       = dx * dx + dy * dy;
+                const float rp  = F.right_points[pid];
+                if (rp > 0)
+                {
+                    const double dr = ur - (double)rp;
+                    e2 += dr * dr;
+                }
+                if (e2 > (double)gate) continue;
+                const uint4 ta = F.desc[(size_t)pid * 2], tc = F.desc[(size_t)pid * 2 + 1];
+                const u32 d    = (u32)hamming256(qa, qc, ta, tc);
+                const u32 key  = (d << PJ_IDX_BITS) | (u32)pid;
+                k1             = key < k1 ? key : k1;
+            }
+        }
+        k1 = wave_min_u32(k1);
+        if (k1 != PJ_INF_KEY && (int)(k1 >> PJ_IDX_BITS) <= feature_th && (k1 >> PJ_IDX_BITS) < 256u) result = (int)(k1 & PJ_IDX_MASK);
+    }
+    if (lane == 0) best[i] = result;
+}
+
+struct TriDev
+{
+    double R1[9], t1[3], R2[9], t2[3];
+    double fx, fy, cx, cy;
+    double E[9];
+    double th_chi2;
+    int grid_rows, grid_cols, feature_distance;
+};
+
+// MappingORBMatcher::SearchForTriangulationProject (reference
+// Snake/LocalMapping/MappingORBMatcher.cpp:168-249).  One wavefront per feature of keyframe 1.
+__global__ __launch_bounds__(256) void triangulate_kernel(FrameDev F, TriDev T, const double* __restrict__ grid,
+                                                          const snk_kp64* __restrict__ kps1, const double* __restrict__ np1,
+                                                          const uint4* __restrict__ desc1, const u8* __restrict__ has1, int n1,
+                                                          const double* __restrict__ np2, int* __restrict__ out)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= n1) return;
+    int result = -1;
+    if (!has1[i])
+    {
+        const snk_kp64 kp = kps1[i];
+        const int cx = cell_coord(kp.x, F.min_x, F.cols), cy = cell_coord(kp.y, F.min_y, F.rows);
+        const int gr = cy / 4 < T.grid_rows ? cy / 4 : T.grid_rows - 1, gc = cx / 4 < T.grid_cols ? cx / 4 : T.grid_cols - 1;
+        const double z   = grid[gr * T.grid_cols + gc];
+        const double pc0 = (kp.x - T.cx) / T.fx * z, pc1 = (kp.y - T.cy) / T.fy * z;
+        const double d0 = pc0 - T.t1[0], d1 = pc1 - T.t1[1], d2 = z - T.t1[2];
+        const double w0 = T.R1[0] * d0 + T.R1[3] * d1 + T.R1[6] * d2;
+        const double w1 = T.R1[1] * d0 + T.R1[4] * d1 + T.R1[7] * d2;
+        const double w2 = T.R1[2] * d0 + T.R1[5] * d1 + T.R1[8] * d2;
+        const double p0 = T.R2[0] * w0 + T.R2[1] * w1 + T.R2[2] * w2 + T.t2[0];
+        const double p1 = T.R2[3] * w0 + T.R2[4] * w1 + T.R2[5] * w2 + T.t2[1];
+        const double p2 = T.R2[6] * w0 + T.R2[7] * w1 + T.R2[8] * w2 + T.t2[2];
+        const double ipx = T.fx * p0 / p2 + T.cx, ipy = T.fy * p1 / p2 + T.cy;
+        if (ipx >= F.min_x && ipx < F.max_x && ipy >= F.min_y && ipy < F.max_y)
+        {
+            const double x = np1[2 * i], y = np1[2 * i + 1];
+            const double l0 = T.E[0] * x + T.E[1] * y + T.E[2], l1 = T.E[3] * x + T.E[4] * y + T.E[5],
+                         l2 = T.E[6] * x + T.E[7] * y + T.E[8];
+            const double ln = l0 * l0 + l1 * l1;
+            const uint4 qa = desc1[(size_t)i * 2], qc = desc1[(size_t)i * 2 + 1];
+            const double r = 20.0, r2 = 400.0;
+            const int cx0 = cell_coord(ipx - r, F.min_x, F.cols), cx1 = cell_coord(ipx + r, F.min_x, F.cols);
+            const int cy0 = cell_coord(ipy - r, F.min_y, F.rows), cy1 = cell_coord(ipy + r, F.min_y, F.rows);
+            // "dist > bestDist -> continue" keeps the LAST candidate of minimal distance: key = dist | reversed index
+            u32 k1 = PJ_INF_KEY;
+            for (int c = cx0; c <= cx1; ++c)
+            {
+                const int lo = F.cell_start[c * F.rows + cy0], hi = F.cell_start[c * F.rows + cy1 + 1];
+                for (int pid = lo + lane; pid < hi; pid += 64)
+                {
+                    const snk_kp64 k2 = F.kps[pid];
+                    const double ax = k2.x - ipx, ay = k2.y - ipy;
+                    if (!(ax * ax + ay * ay < r2)) continue;
+                    if (F.taken[pid]) continue;
+                    const double dd     = np2[2 * pid] * l0 + np2[2 * pid + 1] * l1 + l2;
+                    const double disepi = dd * dd / ln;
+                    if (disepi > T.th_chi2) continue;
+                    const uint4 ta = F.desc[(size_t)pid * 2], tc = F.desc[(size_t)pid * 2 + 1];
+                    const int d    = hamming256(qa, qc, ta, tc);
+                    if (d > T.feature_distance || d > 50) continue;  // TH_LOW
+                    const u32 key = ((u32)d << PJ_IDX_BITS) | (PJ_IDX_MASK - (u32)pid);
+                    k1            = key < k1 ? key : k1;
+                }
+            }
+            k1 = wave_min_u32(k1);
+            if (k1 != PJ_INF_KEY) result = (int)(PJ_IDX_MASK - (k1 & PJ_IDX_MASK));
+        }
+    }
+    if (lane == 0) out[i] = result;
+}
+
 int make_cam(const snk_camera* cam, const double* pose, CamDev* c)
 {
     SNK_REQUIRE(cam != nullptr && pose != nullptr, "camera / pose is NULL");
@@ -711,6 +879,94 @@ int snk_match_project_keyframe(snk_matcher* m, const snk_frame_view* frame, cons
     SNK_HIP_CHECK(hipMemcpyAsync(match_idx, m->out.p, np * 4, hipMemcpyDeviceToHost, m->stream));
     SNK_HIP_CHECK(hipMemcpyAsync(n_matches, m->cnt.p, 4, hipMemcpyDeviceToHost, m->stream));
     SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return SNK_OK;
+}
+
+int snk_match_fuse(snk_matcher* m, const snk_frame_view* frame, const snk_camera* cam, const double pose[7],
+                   const snk_fusion_point* pts, const uint8_t* point_mask, int n_pts, float th, float obs_factor, int feature_th,
+                   const float* level_scale, int n_levels, int32_t* best_idx, int* n_fused)
+{
+    SNK_REQUIRE(m != nullptr && n_fused != nullptr, "NULL argument");
+    *n_fused = 0;
+    SNK_REQUIRE(n_pts >= 0 && (n_pts == 0 || (pts && best_idx)), "bad point arrays");
+    CamDev C;
+    ScalesDev S;
+    FrameDev F;
+    int rc;
+    if ((rc = make_cam(cam, pose, &C)) != SNK_OK) return rc;
+    if ((rc = make_scales(level_scale, n_levels, &S)) != SNK_OK) return rc;
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    if ((rc = upload_frame(m, frame, &F)) != SNK_OK) return rc;
+    if (n_pts == 0) return SNK_OK;
+    const size_t np = (size_t)n_pts, o_mask = np * sizeof(snk_fusion_point);
+    if ((rc = m->q.reserve(o_mask + np + 16)) != SNK_OK) return rc;
+    if ((rc = m->out.reserve(np * 4)) != SNK_OK) return rc;
+    char* d = m->q.as<char>();
+    SNK_HIP_CHECK(hipMemcpyAsync(d, pts, o_mask, hipMemcpyHostToDevice, m->stream));
+    if (point_mask) SNK_HIP_CHECK(hipMemcpyAsync(d + o_mask, point_mask, np, hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(fuse_kernel, dim3(ceil_div(n_pts, 4)), dim3(256), 0, m->stream, F, C, S,
+                       reinterpret_cast<const snk_fusion_point*>(d), point_mask ? reinterpret_cast<const u8*>(d + o_mask) : nullptr,
+                       n_pts, th, obs_factor, feature_th, m->out.as<int>());
+    SNK_LAUNCH_CHECK();
+    SNK_HIP_CHECK(hipMemcpyAsync(best_idx, m->out.p, np * 4, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    int cnt = 0;
+    for (int i = 0; i < n_pts; ++i) cnt += best_idx[i] >= 0 ? 1 : 0;
+    *n_fused = cnt;
+    return SNK_OK;
+}
+
+int snk_match_triangulation_project(snk_matcher* m, const double* depth_grid, int grid_rows, int grid_cols, const double pose1[7],
+                                    const double pose2[7], const snk_camera* cam, const snk_kp64* kps1, const double (*np1)[2],
+                                    const uint64_t (*desc1)[4], const uint8_t* has_mp1, int n1, const snk_frame_view* frame2,
+                                    const double (*np2)[2], const double E12[9], float epipolar_distance, int feature_distance,
+                                    int32_t* match_idx2, int* n_matches)
+{
+    SNK_REQUIRE(m != nullptr && n_matches != nullptr, "NULL argument");
+    *n_matches = 0;
+    SNK_REQUIRE(depth_grid != nullptr && grid_rows >= 1 && grid_cols >= 1 && E12 != nullptr, "bad depth grid / E");
+    SNK_REQUIRE(n1 >= 0 && (n1 == 0 || (kps1 && np1 && desc1 && has_mp1 && match_idx2)), "bad keyframe-1 arrays");
+    SNK_REQUIRE(frame2 != nullptr && (frame2->n == 0 || np2 != nullptr), "bad keyframe-2 arrays");
+    CamDev C1, C2;
+    FrameDev F;
+    int rc;
+    if ((rc = make_cam(cam, pose1, &C1)) != SNK_OK) return rc;
+    if ((rc = make_cam(cam, pose2, &C2)) != SNK_OK) return rc;
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    if ((rc = upload_frame(m, frame2, &F)) != SNK_OK) return rc;
+    if (n1 == 0) return SNK_OK;
+    TriDev T;
+    memcpy(T.R1, C1.R, sizeof(T.R1));
+    memcpy(T.t1, C1.t, sizeof(T.t1));
+    memcpy(T.R2, C2.R, sizeof(T.R2));
+    memcpy(T.t2, C2.t, sizeof(T.t2));
+    T.fx = cam->fx; T.fy = cam->fy; T.cx = cam->cx; T.cy = cam->cy;
+    memcpy(T.E, E12, sizeof(T.E));
+    const double th_chi1 = (double)epipolar_distance / cam->fx;
+    T.th_chi2            = th_chi1 * th_chi1;
+    T.grid_rows = grid_rows; T.grid_cols = grid_cols; T.feature_distance = feature_distance;
+    const size_t n = (size_t)n1, n2 = (size_t)frame2->n, ng = (size_t)grid_rows * grid_cols;
+    const size_t o_np1 = n * sizeof(snk_kp64), o_d1 = o_np1 + n * 16, o_h1 = o_d1 + n * 32, o_np2 = (o_h1 + n + 15) & ~(size_t)15,
+                 o_grid = o_np2 + n2 * 16, total = o_grid + ng * 8;
+    if ((rc = m->q.reserve(total + 16)) != SNK_OK) return rc;
+    if ((rc = m->out.reserve(n * 4)) != SNK_OK) return rc;
+    char* d = m->q.as<char>();
+    SNK_HIP_CHECK(hipMemcpyAsync(d, kps1, n * sizeof(snk_kp64), hipMemcpyHostToDevice, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(d + o_np1, np1, n * 16, hipMemcpyHostToDevice, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(d + o_d1, desc1, n * 32, hipMemcpyHostToDevice, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(d + o_h1, has_mp1, n, hipMemcpyHostToDevice, m->stream));
+    if (n2) SNK_HIP_CHECK(hipMemcpyAsync(d + o_np2, np2, n2 * 16, hipMemcpyHostToDevice, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(d + o_grid, depth_grid, ng * 8, hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(triangulate_kernel, dim3(ceil_div(n1, 4)), dim3(256), 0, m->stream, F, T,
+                       reinterpret_cast<const double*>(d + o_grid), reinterpret_cast<const snk_kp64*>(d),
+                       reinterpret_cast<const double*>(d + o_np1), reinterpret_cast<const uint4*>(d + o_d1),
+                       reinterpret_cast<const u8*>(d + o_h1), n1, reinterpret_cast<const double*>(d + o_np2), m->out.as<int>());
+    SNK_LAUNCH_CHECK();
+    SNK_HIP_CHECK(hipMemcpyAsync(match_idx2, m->out.p, n * 4, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    int cnt = 0;
+    for (int i = 0; i < n1; ++i) cnt += match_idx2[i] >= 0 ? 1 : 0;
+    *n_matches = cnt;
     return SNK_OK;
 }
 }

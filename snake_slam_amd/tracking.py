@@ -112,6 +112,61 @@ class SnakeORBMatcher(_Handle):
         return n.value, out[: len(pos)]
 
 
+# ------------------------------------------------------------------ local-mapping matchers -----
+FUSION_POINT_DTYPE = np.dtype([("pos", "<f8", 3), ("normal", "<f8", 3), ("desc", "<u8", 4), ("reference_depth", "<f4"),
+                               ("reference_scale_level", "<i4"), ("observations", "<i4"), ("id", "<i4")])
+
+
+class MappingORBMatcher(_Handle):
+    """Mirrors ``Snake::MappingORBMatcher`` (reference Snake/LocalMapping/MappingORBMatcher.h:15-45) for the two
+    matchers that need no bag-of-words: ``Fuse`` (LocalMap overload) and ``SearchForTriangulationProject``."""
+
+    def Fuse(self, frame, cam, pose, points, point_mask, th, obs_factor, feature_th, level_scale):
+        """Returns (fusedPoints, fuseCandidates [(feature index, point id)] in point order, best_idx[m])."""
+        v, keep = _view(frame)
+        pts = np.ascontiguousarray(points, FUSION_POINT_DTYPE)
+        ls = np.ascontiguousarray(level_scale, np.float32)
+        pose = np.ascontiguousarray(pose, np.float64)
+        mask = None if point_mask is None else np.ascontiguousarray(point_mask, np.uint8)
+        if mask is not None and len(mask) != len(pts):
+            raise ValueError("point_mask size")  # SAIGA_ASSERT, MappingORBMatcher.cpp:369
+        out = np.full(max(len(pts), 1), -1, np.int32)
+        n = C.c_int(0)
+        c = Camera(*cam)
+        _lib.check(self._lib.snk_match_fuse(self._h, C.byref(v), C.byref(c), _ptr(pose), _ptr(pts), None if mask is None else _ptr(mask),
+                                            len(pts), float(th), float(obs_factor), int(feature_th), _ptr(ls), len(ls), _ptr(out),
+                                            C.byref(n)), "snk_match_fuse")
+        out = out[: len(pts)]
+        cands = [(int(out[i]), int(pts["id"][i])) for i in np.nonzero(out >= 0)[0]]
+        return n.value, cands, out
+
+    def SearchForTriangulationProject(self, grid, pose1, pose2, cam, kps1, np1, desc1, has_mp1, frame2, np2, E12,
+                                      epipolarDistance, featureDistance):
+        """Returns (nmatches, vMatchedPairs [(idx1, idx2)], match_idx2[n1])."""
+        v, keep = _view(frame2)
+        g = np.ascontiguousarray(grid, np.float64)
+        if g.ndim != 2:
+            raise ValueError("depth grid must be 2-D (rows x cols, row-major)")
+        k1 = np.ascontiguousarray(kps1, KP64_DTYPE)
+        n1 = np.ascontiguousarray(np1, np.float64).reshape(-1, 2)
+        n2 = np.ascontiguousarray(np2, np.float64).reshape(-1, 2)
+        d1 = np.ascontiguousarray(desc1, np.uint64).reshape(-1, 4)
+        h1 = np.ascontiguousarray(has_mp1, np.uint8)
+        if not (len(k1) == len(n1) == len(d1) == len(h1)) or len(n2) != v.n:
+            raise ValueError("array lengths")
+        p1, p2 = np.ascontiguousarray(pose1, np.float64), np.ascontiguousarray(pose2, np.float64)
+        E = np.ascontiguousarray(E12, np.float64).reshape(9)
+        out = np.full(max(len(k1), 1), -1, np.int32)
+        n = C.c_int(0)
+        c = Camera(*cam)
+        _lib.check(self._lib.snk_match_triangulation_project(self._h, _ptr(g), g.shape[0], g.shape[1], _ptr(p1), _ptr(p2), C.byref(c),
+                                                             _ptr(k1), _ptr(n1), _ptr(d1), _ptr(h1), len(k1), C.byref(v), _ptr(n2),
+                                                             _ptr(E), float(epipolarDistance), int(featureDistance), _ptr(out),
+                                                             C.byref(n)), "snk_match_triangulation_project")
+        out = out[: len(k1)]
+        return n.value, [(int(i), int(out[i])) for i in np.nonzero(out >= 0)[0]], out
+
+
 # ------------------------------------------------------------------ pose refinement ------------
 POSE_OBS_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("depth", "<f8"), ("weight", "<f8")])
 

@@ -19,6 +19,9 @@ int main(int argc, char**) {
         std::vector<snk_lm_coarse> lc; om.SearchByProjectionFrameFrame2(fv, cam, pose, lc, 15.f, 75, 0, {1.f, 1.2f}, match);
         std::vector<snk_lm_fine> lf; om.SearchByProjection2(fv, cam, pose, lf, 5.f, 0.8f, {1.f, 1.2f}, match, vis);
         om.SearchByProjectionFrameToKeyframe(fv, cam, pose, {}, {}, {}, 15.f, 100, match);
+        snake_hip::MappingORBMatcher mm; std::vector<snk_fusion_point> fp; std::vector<std::pair<int, int>> fc;
+        mm.Fuse(fv, cam, pose, {}, fp, fc, 4.f, 2.f, 50, {1.f, 1.2f}); double E[9] = {}; double g[4] = {};
+        mm.SearchForTriangulationProject(g, 2, 2, pose, pose, cam, {}, {}, {}, {}, fv, {}, E, fc, 4.f, 50);
         snake_hip::PoseRefinement pr(1.0); std::vector<std::array<double, 3>> wps; std::vector<snk_pose_obs> po;
         pr.optimizePoseRobust(wps, po, vis, pose, cam); std::vector<snk_pose_problem> pb; pr.optimizeBatch(pb, cam);
         snake_hip::Scene sc; snake_hip::BARec ba; ba.create(sc); ba.initAndSolve(); ba.residualsSquared();

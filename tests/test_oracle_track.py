@@ -89,3 +89,34 @@ def test_keyframe_matcher_is_sequential_greedy(orc):
     pts["pos"], pts["normal"] = pos, [[0, 0, -1.0], [0, 0, -1.0]]
     nc, ic = orc.match_coarse(frame, cam, pose, pts, 10.0, 50, 0, np.ones(4, np.float32))
     assert nc == 1 and ic.tolist() == [0, -1]
+
+
+def test_fuse_matches_brute_force(orc):
+    """MappingORBMatcher::Fuse (LocalMap overload): grid query == exhaustive scan, every point independent."""
+    for seed, th, of, fth in [(21, 4.0, 2.0, 50), (22, 3.0, 1.5, 60), (23, 6.0, 3.0, 40)]:
+        rng = np.random.default_rng(SEED + seed)
+        frame, cam, pose, ls, world, _ = T.make_tracking_case(orc, rng, n_clutter=300, m_pts=250)
+        pts = T.fusion_points(orc, rng, world, pose, ls)
+        mask = (rng.random(len(pts)) > 0.2).astype(np.uint8)
+        n, idx = orc.match_fuse(frame, cam, pose, pts, mask, th, of, fth, ls)
+        n2, idx2 = T.brute_fuse(orc, frame, cam, pose, pts, mask, th, of, fth, ls)
+        assert n == n2 and np.array_equal(idx, idx2)
+        assert n > 15 and (idx[mask == 0] == -1).all()
+        # no mask == all-ones mask
+        na, ia = orc.match_fuse(frame, cam, pose, pts, None, th, of, fth, ls)
+        nb, ib = orc.match_fuse(frame, cam, pose, pts, np.ones(len(pts), np.uint8), th, of, fth, ls)
+        assert na == nb and np.array_equal(ia, ib) and na >= n
+
+
+def test_triangulation_project_matches_brute_force(orc):
+    """MappingORBMatcher::SearchForTriangulationProject: depth-grid projection + epipolar + Hamming gates."""
+    for seed, epi, fd in [(31, 4.0, 50), (32, 2.0, 40), (33, 8.0, 64)]:
+        rng = np.random.default_rng(SEED + seed)
+        c = T.make_triangulation_case(orc, rng, m_pts=300, n_clutter=200)
+        n, idx = orc.match_triangulation_project(c["grid"], c["pose1"], c["pose2"], c["cam"], c["kps1"], c["np1"], c["desc1"],
+                                                 c["has1"], c["frame2"], c["np2"], c["E"], epi, fd)
+        n2, idx2 = T.brute_triangulation(c, epi, fd)
+        assert n == n2 and np.array_equal(idx, idx2)
+        assert n > 10 and (idx[c["has1"] == 1] == -1).all()
+        got = idx[idx >= 0]
+        assert (c["frame2"]["taken"][got] == 0).all()

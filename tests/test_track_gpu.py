@@ -114,3 +114,51 @@ def test_feature_grid_batch_dev(orc):
         wk[wperm], wd[wperm] = K[b, :n], D[b, :n]
         assert np.array_equal(okh[b, :n], wk) and np.array_equal(odh[b, :n], wd)
     g.close()
+
+
+# ------------------------------------------------------------------ local-mapping matchers -----
+@pytest.fixture(scope="module")
+def mapping_matcher():
+    from snake_slam_amd.tracking import MappingORBMatcher
+
+    m = MappingORBMatcher()
+    yield m
+    m.close()
+
+
+@pytest.mark.parametrize("seed,th,of,fth,masked", [(41, 4.0, 2.0, 50, True), (42, 3.0, 1.5, 60, False), (43, 6.0, 3.0, 40, True),
+                                                   (44, 2.5, 1.0, 100, False)])
+def test_fuse_parity(orc, mapping_matcher, seed, th, of, fth, masked):
+    rng = np.random.default_rng(SEED + seed)
+    frame, cam, pose, ls, world, _ = T.make_tracking_case(orc, rng, n_clutter=1000, m_pts=2500)
+    pts = T.fusion_points(orc, rng, world, pose, ls)
+    mask = (rng.random(len(pts)) > 0.2).astype(np.uint8) if masked else None
+    n, cands, idx = mapping_matcher.Fuse(frame, cam, pose, pts, mask, th, of, fth, ls)
+    wn, widx = orc.match_fuse(frame, cam, pose, pts, mask, th, of, fth, ls)
+    assert n == wn and np.array_equal(idx, widx)
+    assert n > 100 and len(cands) == n
+    assert cands == [(int(widx[i]), int(pts["id"][i])) for i in np.nonzero(widx >= 0)[0]]
+
+
+@pytest.mark.parametrize("seed,epi,fd", [(51, 4.0, 50), (52, 2.0, 40), (53, 8.0, 64), (54, 1.0, 30)])
+def test_triangulation_project_parity(orc, mapping_matcher, seed, epi, fd):
+    rng = np.random.default_rng(SEED + seed)
+    c = T.make_triangulation_case(orc, rng, m_pts=1500, n_clutter=600)
+    n, pairs, idx = mapping_matcher.SearchForTriangulationProject(c["grid"], c["pose1"], c["pose2"], c["cam"], c["kps1"], c["np1"],
+                                                                  c["desc1"], c["has1"], c["frame2"], c["np2"], c["E"], epi, fd)
+    wn, widx = orc.match_triangulation_project(c["grid"], c["pose1"], c["pose2"], c["cam"], c["kps1"], c["np1"], c["desc1"],
+                                               c["has1"], c["frame2"], c["np2"], c["E"], epi, fd)
+    assert n == wn and np.array_equal(idx, widx)
+    assert n > 20 and pairs == [(int(i), int(widx[i])) for i in np.nonzero(widx >= 0)[0]]
+
+
+def test_mapping_matchers_empty_inputs(orc, mapping_matcher):
+    rng = np.random.default_rng(SEED + 60)
+    frame, cam, pose, ls, world, _ = T.make_tracking_case(orc, rng, n_clutter=50, m_pts=20)
+    n, cands, idx = mapping_matcher.Fuse(frame, cam, pose, np.zeros(0, orc.FUSION_POINT), None, 4.0, 2.0, 50, ls)
+    assert n == 0 and cands == [] and len(idx) == 0
+    c = T.make_triangulation_case(orc, rng, m_pts=30, n_clutter=10)
+    n, pairs, idx = mapping_matcher.SearchForTriangulationProject(c["grid"], c["pose1"], c["pose2"], c["cam"], c["kps1"][:0],
+                                                                  c["np1"][:0], c["desc1"][:0], c["has1"][:0], c["frame2"], c["np2"],
+                                                                  c["E"], 4.0, 50)
+    assert n == 0 and pairs == []

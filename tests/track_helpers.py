@@ -174,3 +174,166 @@ def brute_coarse(frame, cam, pose, pts, th, feature_error, direction, ls):
         if out[i] >= 0 and bins[i] not in (i1, i2, i3):
             out[i] = -1
     return int((out >= 0).sum()), out
+
+
+# ------------------------------------------------------------------ local-mapping matchers -----
+def fusion_points(orc, rng, world, pose, ls):
+    m = len(world["pos"])
+    pts = np.zeros(m, orc.FUSION_POINT)
+    pts["pos"], pts["normal"], pts["desc"] = world["pos"], world["normal"], world["desc"]
+    R = quat_R(pose[:4])
+    campos = -R.T @ pose[4:]
+    dist = np.linalg.norm(world["pos"] - campos, axis=1)
+    pts["reference_scale_level"] = world["octave"]
+    pts["reference_depth"] = (dist * rng.uniform(0.8, 1.25, m)).astype(np.float32)
+    far = rng.random(m) < 0.05
+    pts["reference_depth"][far] *= 10
+    pts["observations"] = rng.integers(1, 6, m)
+    pts["id"] = rng.permutation(10 * m)[:m]
+    return pts
+
+
+def _scale_prediction(orc, ref_depth, ref_level, dist, ls):
+    log_f = orc.det_log(float(ls[1]) / float(ls[0]))
+    p = float(ref_level) + orc.det_log(float(ref_depth) / dist) / log_f
+    return min(max(p, 0.0), float(len(ls) - 1))
+
+
+def brute_fuse(orc, frame, cam, pose, pts, mask, th, obs_factor, feature_th, ls):
+    """Independent restatement without the grid: every feature is tested, lowest index wins ties."""
+    fx, fy, cx, cy, bf = cam
+    R, t = quat_R(pose[:4]), pose[4:]
+    campos = -R.T @ t
+    b = frame["bounds"]
+    kx, ky, koct, rp = frame["kps"]["x"], frame["kps"]["y"], frame["kps"]["octave"], frame["right_points"]
+    best = np.full(len(pts), -1)
+    th2 = np.float32(th) * np.float32(th)
+    for i in range(len(pts)):
+        if mask is not None and not mask[i]:
+            continue
+        pc = R @ pts["pos"][i] + t
+        if pc[2] <= 0:
+            continue
+        ipx, ipy = fx * pc[0] / pc[2] + cx, fy * pc[1] / pc[2] + cy
+        if not (b[0] <= ipx < b[2] and b[1] <= ipy < b[3]):
+            continue
+        PO = campos - pts["pos"][i]
+        dist = np.linalg.norm(PO)
+        lvl = int(np.clip(pts["reference_scale_level"][i], 0, len(ls) - 1))
+        rd = float(pts["reference_depth"][i])
+        if dist < 0.8 * rd * float(ls[lvl]) / float(ls[-1]) or dist > 1.2 * rd * float(ls[lvl]):
+            continue
+        if PO @ pts["normal"][i] < 0.5 * dist:
+            continue
+        of = np.float32(obs_factor) if pts["observations"][i] <= 2 else np.float32(1.0)
+        radius = float(np.float32(of * np.float32(th)))
+        gate = float(np.float32(th2 * of))
+        pred = _scale_prediction(orc, rd, pts["reference_scale_level"][i], dist, ls)
+        e2 = (kx - ipx) ** 2 + (ky - ipy) ** 2
+        ok = (e2 < radius * radius) & (np.abs(pred - koct) <= 1.0)
+        e2 = e2 + np.where(rp > 0, ((ipx - bf / pc[2]) - rp.astype(np.float64)) ** 2, 0.0)
+        ok &= ~(e2 > gate)
+        bd, bi = 256, -1
+        for j in np.nonzero(ok)[0]:
+            d = hamming(pts["desc"][i], frame["desc"][j])
+            if d < bd:
+                bd, bi = d, int(j)
+        if bi >= 0 and bd <= feature_th:
+            best[i] = bi
+    return int((best >= 0).sum()), best
+
+
+def essential(pose1, pose2):
+    """E with x2^T E x1 = 0 for normalized points of the two world->camera poses."""
+    R1, R2 = quat_R(pose1[:4]), quat_R(pose2[:4])
+    R21 = R2 @ R1.T
+    t21 = pose2[4:] - R21 @ pose1[4:]
+    tx = np.array([[0, -t21[2], t21[1]], [t21[2], 0, -t21[0]], [-t21[1], t21[0], 0]])
+    return tx @ R21
+
+
+def make_triangulation_case(orc, rng, m_pts=500, n_clutter=300, n_levels=4):
+    """Two keyframes looking at the same points.  Returns a dict with everything the matcher needs."""
+    fx, fy, cx, cy = K_EUROC
+    poses = []
+    for k in range(2):
+        q = rng.normal(size=4) * 0.02 + np.array([0, 0, 0, 1.0])
+        q /= np.linalg.norm(q)
+        poses.append(np.concatenate([q, rng.normal(size=3) * 0.05 + np.array([0.6 * k, 0, 0])]))
+    R1, t1 = quat_R(poses[0][:4]), poses[0][4:]
+    R2, t2 = quat_R(poses[1][:4]), poses[1][4:]
+    pc1 = np.stack([rng.uniform(-3, 3, m_pts), rng.uniform(-2, 2, m_pts), rng.uniform(3, 9, m_pts)], 1)
+    pw = (pc1 - t1) @ R1
+    pc2 = pw @ R2.T + t2
+    pdesc = rng.integers(0, 2**64, size=(m_pts, 4), dtype=np.uint64)
+
+    def features(pc, noise):
+        u = fx * pc[:, 0] / pc[:, 2] + cx + rng.normal(0, noise, len(pc))
+        v = fy * pc[:, 1] / pc[:, 2] + cy + rng.normal(0, noise, len(pc))
+        d = np.stack([flip_bits(rng, pdesc[i], int(rng.integers(0, 60))) for i in range(len(pc))])
+        cu, cv = rng.uniform(BOUNDS[0], BOUNDS[2], n_clutter), rng.uniform(BOUNDS[1], BOUNDS[3], n_clutter)
+        cd = rng.integers(0, 2**64, size=(n_clutter, 4), dtype=np.uint64)
+        k = np.zeros(len(pc) + n_clutter, orc.KP64)
+        k["x"], k["y"] = np.concatenate([u, cu]), np.concatenate([v, cv])
+        k["octave"] = rng.integers(0, n_levels, len(k))
+        k["angle"] = rng.uniform(0, 360, len(k)).astype(np.float32)
+        return k, np.concatenate([d, cd])
+
+    k1, d1 = features(pc1, 0.3)
+    k2, d2 = features(pc2, 0.3)
+    inb = lambda k: (k["x"] >= BOUNDS[0]) & (k["x"] < BOUNDS[2]) & (k["y"] >= BOUNDS[1]) & (k["y"] < BOUNDS[3])
+    keep1, keep2 = inb(k1), inb(k2)
+    k1, d1, k2, d2 = k1[keep1], d1[keep1], k2[keep2], d2[keep2]
+    o1, o2 = rng.permutation(len(k1)), rng.permutation(len(k2))
+    k1, d1, k2, d2 = k1[o1], d1[o1], k2[o2], d2[o2]
+    perm, cell_start, cols, rows = orc.feature_grid(k2, BOUNDS)
+    g_k2, g_d2 = np.zeros_like(k2), np.zeros_like(d2)
+    g_k2[perm], g_d2[perm] = k2, d2
+    np1 = np.stack([(k1["x"] - cx) / fx, (k1["y"] - cy) / fy], 1)
+    np2 = np.stack([(g_k2["x"] - cx) / fx, (g_k2["y"] - cy) / fy], 1)
+    has1 = (rng.random(len(k1)) < 0.3).astype(np.uint8)
+    has2 = (rng.random(len(k2)) < 0.3).astype(np.uint8)
+    frame2 = dict(kps=g_k2, desc=g_d2, right_points=np.full(len(k2), -1, np.float32), taken=has2, cell_start=cell_start,
+                  bounds=BOUNDS, cols=cols, rows=rows)
+    # coarse depth grid: one value per 4 x 4 cells (80 px), near the true depth range, some far off
+    grid = rng.uniform(4.0, 8.0, ((rows + 3) // 4, (cols + 3) // 4))
+    grid[rng.random(grid.shape) < 0.1] = 40.0
+    return dict(grid=grid, pose1=poses[0], pose2=poses[1], cam=(fx, fy, cx, cy, BF), kps1=k1, np1=np1, desc1=d1, has1=has1,
+                frame2=frame2, np2=np2, E=essential(poses[0], poses[1]))
+
+
+def brute_triangulation(case, epipolar_distance, feature_distance):
+    fx, fy, cx, cy, bf = case["cam"]
+    R1, t1 = quat_R(case["pose1"][:4]), case["pose1"][4:]
+    R2, t2 = quat_R(case["pose2"][:4]), case["pose2"][4:]
+    f2 = case["frame2"]
+    b = f2["bounds"]
+    kx, ky = f2["kps"]["x"], f2["kps"]["y"]
+    cols, rows = f2["cols"], f2["rows"]
+    th2 = (np.float64(np.float32(epipolar_distance)) / fx) ** 2
+    E = case["E"]
+    out = np.full(len(case["kps1"]), -1)
+    for i in range(len(case["kps1"])):
+        if case["has1"][i]:
+            continue
+        x, y = case["kps1"]["x"][i], case["kps1"]["y"][i]
+        cxi = int(np.clip(np.floor((x - b[0]) / 20.0), 0, cols - 1))
+        cyi = int(np.clip(np.floor((y - b[1]) / 20.0), 0, rows - 1))
+        z = case["grid"][cyi // 4, cxi // 4]
+        pc = np.array([(x - cx) / fx * z, (y - cy) / fy * z, z])
+        wp = R1.T @ (pc - t1)
+        p2 = R2 @ wp + t2
+        ipx, ipy = fx * p2[0] / p2[2] + cx, fy * p2[1] / p2[2] + cy
+        if not (b[0] <= ipx < b[2] and b[1] <= ipy < b[3]):
+            continue
+        l = E @ np.array([case["np1"][i][0], case["np1"][i][1], 1.0])
+        d = case["np2"] @ l[:2] + l[2]
+        ok = ((kx - ipx) ** 2 + (ky - ipy) ** 2 < 400.0) & (f2["taken"] == 0) & ~(d * d / (l[0] ** 2 + l[1] ** 2) > th2)
+        bd, bi = 50, -1
+        for j in np.nonzero(ok)[0]:
+            h = hamming(case["desc1"][i], f2["desc"][j])
+            if h > feature_distance or h > bd:
+                continue
+            bd, bi = h, int(j)
+        out[i] = bi
+    return int((out >= 0).sum()), out
