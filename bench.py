@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="stereo frames per GPU per step")
     ap.add_argument("--ba-windows", type=int, default=256, help="independent local-BA windows per GPU per step (0 = skip)")
+    ap.add_argument("--gba-keyframes", type=int, default=300, help="keyframes of the global-BA leg (0 = skip; single GPU only)")
     ap.add_argument("--pose-frames", type=int, default=256, help="frames per pose-refinement call (0 = skip; single GPU only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events")
@@ -234,6 +235,23 @@ def main():
                   "cost_initial": round(float(ci[0]), 3), "cost_final": round(float(cf[0]), 3), "dtype": "f64"}
         ba.close()
         ba1.close()
+        # global BA (GlobalBundleAdjustment::FullBA(4), PCG <= 40): one big scene,
+        # reduced system beyond one workgroup's LDS -> multi-workgroup PCG.  Rank 0 only, single GPU only.
+        if world == 1 and args.gba_keyframes > 0:
+            gsc = synth.ba_scene(n_kf=args.gba_keyframes, n_pt=50 * args.gba_keyframes, obs_per_pt=10, seed=31, n_fixed=1)[0]
+            gba = BARec(lba_options(max_iterations=4, max_pcg_iterations=40), device=local, stream=sh)
+            gba.create(gsc)
+            gci, gcf = gba.initAndSolve()
+            tg0 = time.perf_counter()
+            for _ in range(3):
+                gba.reset()
+                gci, gcf = gba.initAndSolve()
+            tg1 = time.perf_counter()
+            gba.close()
+            ba_out["global_ba"] = {"metric": "FullBA(4) wall time, host call to result", "keyframes": args.gba_keyframes,
+                                   "points": 50 * args.gba_keyframes, "observations": 500 * args.gba_keyframes,
+                                   "ms_per_solve": round((tg1 - tg0) / 3 * 1e3, 3), "cost_initial": round(float(gci[0]), 3),
+                                   "cost_final": round(float(gcf[0]), 3)}
 
     # ---- pose refinement after the matchers: 256 frames x 300 matches per call.
     # Host API (host pointers in, synchronous), so the figure includes staging and PCIe; single GPU only.

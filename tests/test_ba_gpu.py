@@ -126,3 +126,36 @@ def test_global_ba_scale_and_pose_only(orc):
     sc2["pt_const"][:] = 1
     ci, cf, pose, pt = compare(orc, sc2)
     assert np.array_equal(pt, sc2["pt"]) and cf < ci
+
+
+def test_global_ba_multi_workgroup_pcg(orc):
+    """Reduced systems beyond one workgroup's LDS (here 299 free cameras, S = 1794 x 1794) take the
+    multi-workgroup PCG (vectors in HBM, fixed-order partial sums); same tolerance vs the oracle."""
+    from snake_slam_amd import synth
+
+    sc, gt = synth.ba_scene(n_kf=300, n_pt=9000, obs_per_pt=8, seed=41, n_fixed=1)
+    ci, cf, pose, pt = compare(orc, sc, dict(max_iterations=3, max_pcg_iterations=40))
+    assert cf < 0.05 * ci
+    # a batch of two mid-size problems on the same path (per-problem partial sums must not mix)
+    from snake_slam_amd.ba import BARec, lba_options
+
+    scenes = [synth.ba_scene(n_kf=60, n_pt=1500, obs_per_pt=6, seed=42 + k)[0] for k in range(2)]
+    ba = BARec(lba_options(max_iterations=2, max_pcg_iterations=30))
+    ba.create(scenes)
+    ci, cf = ba.initAndSolve()
+    for k in range(2):
+        wpose, wpt, wci, wcf, _ = orc.ba_solve(scenes[k], orc.ba_options(2, 30))
+        pose, pt, _ = ba.state(k)
+        assert abs(cf[k] - wcf) <= 1e-7 * wcf and rmse(pose, wpose) <= TOL and rmse(pt, wpt) <= TOL
+    ba.close()
+
+
+def test_point_only_ba(orc):
+    """GlobalBundleAdjustment::PointBA (reference Snake/Optimizer/GlobalBundleAdjustment.cpp:103-122):
+    every image constant, only the points move (no reduced camera system at all)."""
+    from snake_slam_amd import synth
+
+    sc, _ = synth.ba_scene(n_kf=8, n_pt=500, obs_per_pt=5, seed=51)
+    sc["img_const"][:] = 1
+    ci, cf, pose, pt = compare(orc, sc, dict(max_iterations=4))
+    assert np.array_equal(pose, sc["pose"]) and cf < ci
