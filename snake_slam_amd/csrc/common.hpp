@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -60,6 +61,10 @@ struct DevBuf
         size_t want = n + n / 4 + 256;
         SNK_HIP_CHECK(hipMalloc(&p, want));
         bytes = want;
+        // SNK_DEBUG_POISON=1: fill fresh scratch with a pattern so that a kernel relying on
+        // zero-initialised memory fails reproducibly instead of depending on the allocator's history
+        static const bool poison = getenv("SNK_DEBUG_POISON") != nullptr;
+        if (poison) SNK_HIP_CHECK(hipMemset(p, 0xCD, want));
         return SNK_OK;
     }
     void release()

@@ -459,7 +459,10 @@ __global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* _
     const bool aligned = l == 0 ? aligned0 != 0 : true;
     const bool col_ok  = aligned && xl >= 0 && xl + 3 < lv.w;
     const int xsafe    = min(max(xl, 0), (lv.w - 4) & ~3);  // aligned, inside the row
-    const int xr0 = reflect101(xl, lv.w), xr1 = reflect101(xl + 1, lv.w), xr2 = reflect101(xl + 2, lv.w), xr3 = reflect101(xl + 3, lv.w);
+    // lanes right of the image only matter up to column w + 2 (halo of the last pixel); clamping keeps
+    // reflect101 inside its domain for strips much narrower than the wavefront (w < 126)
+    const int xr0 = reflect101(min(xl, lv.w + 2), lv.w), xr1 = reflect101(min(xl + 1, lv.w + 2), lv.w),
+              xr2 = reflect101(min(xl + 2, lv.w + 2), lv.w), xr3 = reflect101(min(xl + 3, lv.w + 2), lv.w);
     u8* blur = lv.blur + (long long)b * lv.img_stride;
     const u32 W0123 = 18u | (33u << 8) | (49u << 16) | (56u << 24);
     const u32 W456  = 49u | (33u << 8) | (18u << 16);
@@ -1567,11 +1570,15 @@ static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long i
     // one streaming pass per level: blur of level l + down-scale to level l+1 (the chain makes the
     // passes sequential; every level is read once)
     const int aligned0 = (reinterpret_cast<uintptr_t>(images_dev) % 4 == 0 && pitch % 4 == 0 && image_stride % 4 == 0) ? 1 : 0;
-    const bool fused = o->params.scale_factor <= 2.0f;  // the in-stream down-scale reaches 3 * scale + 1 columns right
+    const bool fused_ok = o->params.scale_factor <= 2.0f;  // the in-stream down-scale reaches 3 * scale + 1 columns right
+    // levels below 8 x 8 (deep levels of small images) cannot hold a feature and are outside the domain of
+    // the streaming pass's reflect-101 halo: they are only down-scaled (stand-alone kernel), never blurred
+    auto tiny = [&](int l) { return L.lv[l].w < 8 || L.lv[l].h < 8; };
     for (int l = 0; l < L.n_levels; ++l)
     {
         const LevelInfo& lv = L.lv[l];
-        if (!fused && l > 0)
+        const bool fused    = fused_ok && !tiny(l);
+        if (l > 0 && (!fused_ok || tiny(l - 1)))
         {
             const LevelInfo& sv = L.lv[l - 1];
             dim3 grid(ceil_div(ceil_div(lv.w, 4), 256), lv.h, batch);
@@ -1580,6 +1587,7 @@ static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long i
                                lv.xofs, lv.xw1, lv.yofs, lv.yw1);
             SNK_LAUNCH_CHECK();
         }
+        if (tiny(l)) continue;
         hipLaunchKernelGGL(level_kernel, dim3(ceil_div(lv.n_strips * lv.n_bands, 4), batch), dim3(256), 0, o->stream, L, l,
                            images_dev, pitch, image_stride, aligned0, fused && l + 1 < L.n_levels ? 1 : 0);
         SNK_LAUNCH_CHECK();

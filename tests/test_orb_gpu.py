@@ -131,6 +131,15 @@ def test_strip_and_band_boundaries(orc, shape):
     check_image(orc, img, 500, 4, 1.2, 20, 7)
 
 
+def test_narrow_and_deep_pyramids(orc):
+    """Levels much narrower than one wavefront strip (w < 126: the halo lanes far right of the image must
+    not index outside the row) and levels below 8 x 8 (down-scaled by the stand-alone kernel, never blurred)."""
+    rng = np.random.default_rng(SEED + 77)
+    for shape, levels in [((200, 120), 4), ((60, 100), 16), ((300, 50), 8), ((9, 400), 3)]:
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        check_image(orc, img, 300, levels, 1.2, 20, 7)
+
+
 def test_batch_dev_matches_single(orc):
     import torch
     from snake_slam_amd import synth
