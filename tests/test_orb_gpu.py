@@ -140,6 +140,22 @@ def test_narrow_and_deep_pyramids(orc):
         check_image(orc, img, 300, levels, 1.2, 20, 7)
 
 
+def test_random_shapes_and_parameters(orc):
+    """Small fuzz over image shape / levels / scale / thresholds (seeded)."""
+    from snake_slam_amd import synth
+
+    rng = np.random.default_rng(SEED + 99)
+    for k in range(10):
+        w, h = int(rng.integers(40, 420)), int(rng.integers(40, 320))
+        levels, scale = int(rng.integers(1, 9)), float(rng.choice([1.1, 1.2, 1.3, 1.5, 2.0]))
+        if k % 2:
+            img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        else:
+            img, _ = synth.stereo_frame(200 + k, w, h, n_rects=60)
+        check_image(orc, img, int(rng.integers(50, 1500)), levels, scale, int(rng.integers(10, 40)), int(rng.integers(3, 10)),
+                    stages=(k < 4))
+
+
 def test_batch_dev_matches_single(orc):
     import torch
     from snake_slam_amd import synth
