@@ -179,9 +179,13 @@ SNK_API int snk_orb_detect_batch_dev(snk_orb* o, const uint8_t* images_dev, int 
  * stages of every detect call: ms[0] = the per-level streaming passes (blurred level + next pyramid
  * level in one pass; plus the stand-alone resize when scale_factor > 2), ms[1] = reserved (the
  * blur used to be a stage of its own; now ~0), ms[2] = FAST cells, ms[3] = distribution,
- * ms[4] = descriptors.
- * snk_orb_stage_times synchronises, returns the summed milliseconds per stage over the calls since
- * the last query (ms[5]) and their number, and resets the accumulation. */
+ * ms[4] = descriptors.  A batch of >= 8 images runs as two half-batch launch chains on two streams
+ * (joined on the handle's stream before the call returns control of it); each chain is timed on its
+ * own stream and counts as one entry of n_calls ("launch chains"), so ms[k] / n_calls is the average
+ * duration of one launch and the images per launch are (images processed) / n_calls.
+ * SNK_ORB_ONE_STREAM=1 in the environment disables the split.
+ * snk_orb_stage_times synchronises, returns the summed milliseconds per stage over the launch chains
+ * since the last query (ms[5]) and their number, and resets the accumulation. */
 SNK_API int snk_orb_set_profiling(snk_orb* o, int enable);
 SNK_API int snk_orb_stage_times(snk_orb* o, float* ms, int* n_calls);
 

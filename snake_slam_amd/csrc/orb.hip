@@ -1271,6 +1271,14 @@ struct snk_orb : HandleBase
     bool profiling = false;
     std::vector<std::array<hipEvent_t, 6>> ev_sets;  // pyramid | blur | fast | distribute | describe boundaries
     size_t ev_used = 0;
+    // second stream: a batch is split in two halves whose launch chains overlap (the tail of one half's
+    // launch runs beside the other half's kernels; latency-bound and VALU-bound stages share the CUs)
+    static constexpr int MAX_PARTS = 4;
+    hipStream_t stream2 = nullptr;  // non-null when the extra streams / events below exist
+    hipStream_t extra[MAX_PARTS - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join_n[MAX_PARTS - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_join = nullptr;
+    int split_min_batch = 8, parts = 2;
 };
 
 static int compute_layout(snk_orb* o, int w, int h)
@@ -1409,6 +1417,20 @@ int snk_orb_create(const snk_orb_params* params, int device, void* stream, snk_o
         delete o;
         return rc;
     }
+    // extra streams + fork / join events (best effort: without them every batch runs as one chain)
+    {
+        bool ok = hipEventCreateWithFlags(&o->ev_fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i < snk_orb::MAX_PARTS - 1; ++i)
+            ok = hipStreamCreateWithFlags(&o->extra[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&o->ev_join_n[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        o->stream2 = ok ? o->extra[0] : nullptr;
+        if (const char* e = getenv("SNK_ORB_PARTS"))
+        {
+            const int v = atoi(e);
+            o->parts    = v < 1 ? 1 : (v > snk_orb::MAX_PARTS ? snk_orb::MAX_PARTS : v);
+        }
+    }
     *out = o;
     return SNK_OK;
 }
@@ -1433,6 +1455,11 @@ int snk_orb_destroy(snk_orb* o)
     o->out_n.release();
     for (auto& e : o->ev_sets)
         for (auto& x : e) (void)hipEventDestroy(x);
+    if (o->ev_fork) (void)hipEventDestroy(o->ev_fork);
+    for (auto& e : o->ev_join_n)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& st : o->extra)
+        if (st) (void)hipStreamDestroy(st);
     o->fini();
     delete o;
     return SNK_OK;
@@ -1525,7 +1552,7 @@ int snk_orb_configure(snk_orb* o, int width, int height, int max_batch)
     o->dist_small_cap = L.level_cap < 2048 ? L.level_cap : 2048;
     o->dist_lds       = dist_lds_bytes((size_t)L.level_cap);
     o->dist_lds_small = dist_lds_bytes((size_t)o->dist_small_cap);
-    if ((rc = o->dist_queue.reserve(((size_t)max_batch * MAX_LEVELS + 1) * sizeof(int))) != SNK_OK) return rc;
+    if ((rc = o->dist_queue.reserve(snk_orb::MAX_PARTS * ((size_t)max_batch * MAX_LEVELS + 1) * sizeof(int))) != SNK_OK) return rc;  // one per chain
     SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(distribute_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->dist_lds_small));
     SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1551,10 +1578,28 @@ int snk_orb_max_keypoints(const snk_orb* o, int* out)
     return SNK_OK;
 }
 
-static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long image_stride, int batch,
-                        snk_keypoint* kps_dev, uint64_t* desc_dev, int32_t* n_dev, int out_cap)
+// One launch chain over images [b0, b0 + batch) of a call on stream `st`: every per-image buffer is indexed
+// relative to the chain's first image, so the bases are simply advanced by b0 images.
+static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* images_dev, int pitch, long long image_stride,
+                    int batch, snk_keypoint* kps_dev, uint64_t* desc_dev, int32_t* n_dev, int out_cap)
 {
-    const Layout& L = o->lay;
+    Layout L = o->lay;
+    for (int l = 0; l < L.n_levels; ++l)
+    {
+        if (L.lv[l].base) L.lv[l].base += (long long)b0 * L.lv[l].img_stride;
+        if (L.lv[l].blur) L.lv[l].blur += (long long)b0 * L.lv[l].img_stride;
+    }
+    images_dev += (long long)b0 * image_stride;
+    kps_dev += (long long)b0 * out_cap;
+    desc_dev += (long long)b0 * out_cap * 4;
+    n_dev += b0;
+    u32* d_cand     = o->cand.as<u32>() + (size_t)b0 * L.total_cells * CELL_SLOTS;
+    u16* d_cellcnt  = o->cell_cnt.as<u16>() + (size_t)b0 * L.total_cells;
+    u32* d_sel      = o->sel.as<u32>() + (size_t)b0 * L.total_slots;
+    u8* d_selscore  = o->sel_score.as<u8>() + (size_t)b0 * L.total_slots;
+    int* d_selcnt   = o->sel_cnt.as<int>() + (size_t)b0 * MAX_LEVELS;
+    int* d_candtot  = o->cand_total.as<int>() + (size_t)b0 * MAX_LEVELS;
+    int* d_queue    = o->dist_queue.as<int>() + (size_t)part * ((size_t)o->max_batch * MAX_LEVELS + 1);
     std::array<hipEvent_t, 6>* ev = nullptr;
     if (o->profiling)
     {
@@ -1565,7 +1610,7 @@ static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long i
             o->ev_sets.push_back(e);
         }
         ev = &o->ev_sets[o->ev_used++];
-        SNK_HIP_CHECK(hipEventRecord((*ev)[0], o->stream));
+        SNK_HIP_CHECK(hipEventRecord((*ev)[0], st));
     }
     // one streaming pass per level: blur of level l + down-scale to level l+1 (the chain makes the
     // passes sequential; every level is read once)
@@ -1582,49 +1627,79 @@ static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long i
         {
             const LevelInfo& sv = L.lv[l - 1];
             dim3 grid(ceil_div(ceil_div(lv.w, 4), 256), lv.h, batch);
-            hipLaunchKernelGGL(resize_kernel, grid, dim3(256), 0, o->stream, l == 1 ? images_dev : sv.base, l == 1 ? pitch : sv.pitch,
+            hipLaunchKernelGGL(resize_kernel, grid, dim3(256), 0, st, l == 1 ? images_dev : sv.base, l == 1 ? pitch : sv.pitch,
                                l == 1 ? image_stride : sv.img_stride, sv.w, sv.h, lv.base, lv.pitch, lv.img_stride, lv.w, lv.h,
                                lv.xofs, lv.xw1, lv.yofs, lv.yw1);
             SNK_LAUNCH_CHECK();
         }
         if (tiny(l)) continue;
-        hipLaunchKernelGGL(level_kernel, dim3(ceil_div(lv.n_strips * lv.n_bands, 4), batch), dim3(256), 0, o->stream, L, l,
+        hipLaunchKernelGGL(level_kernel, dim3(ceil_div(lv.n_strips * lv.n_bands, 4), batch), dim3(256), 0, st, L, l,
                            images_dev, pitch, image_stride, aligned0, fused && l + 1 < L.n_levels ? 1 : 0);
         SNK_LAUNCH_CHECK();
     }
-    if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[1], o->stream));
+    if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[1], st));
     SNK_LAUNCH_CHECK();
-    if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[2], o->stream));
+    if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[2], st));
     if (L.total_cells > 0)
     {
-        hipLaunchKernelGGL(fast_kernel, dim3(ceil_div(L.total_cells, 4), batch), dim3(256), (size_t)4 * L.f_lds_wave, o->stream, L,
+        hipLaunchKernelGGL(fast_kernel, dim3(ceil_div(L.total_cells, 4), batch), dim3(256), (size_t)4 * L.f_lds_wave, st, L,
                            images_dev, pitch,
-                           image_stride, aligned0, o->params.ini_th_fast, o->params.min_th_fast, o->cand.as<u32>(),
-                           o->cell_cnt.as<u16>());
+                           image_stride, aligned0, o->params.ini_th_fast, o->params.min_th_fast, d_cand,
+                           d_cellcnt);
         SNK_LAUNCH_CHECK();
     }
-    if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[3], o->stream));
-    SNK_HIP_CHECK(hipMemsetAsync(o->dist_queue.p, 0, sizeof(int), o->stream));
-    hipLaunchKernelGGL(distribute_kernel, dim3(L.n_levels, batch), dim3(DIST_THREADS), o->dist_lds_small, o->stream, L,
-                       o->dist_small_cap, o->cand.as<u32>(), o->cell_cnt.as<u16>(), o->sel.as<u32>(), o->sel_score.as<u8>(),
-                       o->sel_cnt.as<int>(), o->cand_total.as<int>(), o->dist_queue.as<int>());
+    if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[3], st));
+    SNK_HIP_CHECK(hipMemsetAsync(d_queue, 0, sizeof(int), st));
+    hipLaunchKernelGGL(distribute_kernel, dim3(L.n_levels, batch), dim3(DIST_THREADS), o->dist_lds_small, st, L,
+                       o->dist_small_cap, d_cand, d_cellcnt, d_sel, d_selscore,
+                       d_selcnt, d_candtot, d_queue);
     SNK_LAUNCH_CHECK();
     if (o->dist_small_cap < L.level_cap)
     {
         const int workers = L.n_levels * batch < 256 ? L.n_levels * batch : 256;
-        hipLaunchKernelGGL(distribute_large_kernel, dim3(workers), dim3(DIST_THREADS), o->dist_lds, o->stream, L,
-                           o->cand.as<u32>(), o->cell_cnt.as<u16>(), o->sel.as<u32>(), o->sel_score.as<u8>(),
-                           o->sel_cnt.as<int>(), o->cand_total.as<int>(), o->dist_queue.as<int>());
+        hipLaunchKernelGGL(distribute_large_kernel, dim3(workers), dim3(DIST_THREADS), o->dist_lds, st, L,
+                           d_cand, d_cellcnt, d_sel, d_selscore,
+                           d_selcnt, d_candtot, d_queue);
         SNK_LAUNCH_CHECK();
     }
-    if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[4], o->stream));
+    if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[4], st));
     int max_slot = 1;
     for (int l = 0; l < L.n_levels; ++l) max_slot = L.lv[l].slot_cap > max_slot ? L.lv[l].slot_cap : max_slot;
-    hipLaunchKernelGGL(describe_kernel, dim3(ceil_div(max_slot, 4 * DESC_KPW), L.n_levels, batch), dim3(256), 0, o->stream, L,
-                       images_dev, pitch, image_stride, aligned0, o->sel.as<u32>(), o->sel_score.as<u8>(), o->sel_cnt.as<int>(),
+    hipLaunchKernelGGL(describe_kernel, dim3(ceil_div(max_slot, 4 * DESC_KPW), L.n_levels, batch), dim3(256), 0, st, L,
+                       images_dev, pitch, image_stride, aligned0, d_sel, d_selscore, d_selcnt,
                        kps_dev, (u64*)desc_dev, n_dev, out_cap);
     SNK_LAUNCH_CHECK();
-    if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[5], o->stream));
+    if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[5], st));
+    return SNK_OK;
+}
+
+
+// A batch of at least split_min_batch images runs as two half-batch chains on two streams (fork / join
+// with events on the caller-visible stream); smaller batches as one chain.
+static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long image_stride, int batch,
+                        snk_keypoint* kps_dev, uint64_t* desc_dev, int32_t* n_dev, int out_cap)
+{
+    static const bool one_stream = getenv("SNK_ORB_ONE_STREAM") != nullptr;
+    if (one_stream || o->stream2 == nullptr || batch < o->split_min_batch)
+        return run_part(o, o->stream, 0, 0, images_dev, pitch, image_stride, batch, kps_dev, desc_dev, n_dev, out_cap);
+    const int parts = o->parts < batch ? o->parts : batch;
+    if (parts <= 1) return run_part(o, o->stream, 0, 0, images_dev, pitch, image_stride, batch, kps_dev, desc_dev, n_dev, out_cap);
+    SNK_HIP_CHECK(hipEventRecord(o->ev_fork, o->stream));
+    int b0 = 0;
+    for (int p = 0; p < parts; ++p)
+    {
+        const int nb   = (batch - b0) / (parts - p);
+        hipStream_t st = p == 0 ? o->stream : o->extra[p - 1];
+        if (p > 0) SNK_HIP_CHECK(hipStreamWaitEvent(st, o->ev_fork, 0));
+        const int rc = run_part(o, st, p, b0, images_dev, pitch, image_stride, nb, kps_dev, desc_dev, n_dev, out_cap);
+        if (rc != SNK_OK) return rc;
+        if (p > 0)
+        {
+            SNK_HIP_CHECK(hipEventRecord(o->ev_join_n[p - 1], st));
+            SNK_HIP_CHECK(hipStreamWaitEvent(o->stream, o->ev_join_n[p - 1], 0));
+        }
+        b0 += nb;
+    }
     return SNK_OK;
 }
 
@@ -1700,7 +1775,7 @@ int snk_orb_stage_times(snk_orb* o, float* ms /* 5: pyramid, blur, fast, distrib
 {
     SNK_REQUIRE(o != nullptr && ms != nullptr && n_calls != nullptr, "NULL argument");
     SNK_HIP_CHECK(hipSetDevice(o->device));
-    SNK_HIP_CHECK(hipStreamSynchronize(o->stream));
+    SNK_HIP_CHECK(hipStreamSynchronize(o->stream));  // joins the second stream's chain as well
     for (int k = 0; k < 5; ++k) ms[k] = 0.0f;
     for (size_t i = 0; i < o->ev_used; ++i)
         for (int k = 0; k < 5; ++k)

@@ -189,6 +189,42 @@ def test_batch_dev_matches_single(orc):
     ext.close()
 
 
+def test_split_batch_two_streams(orc):
+    """Batches of >= 8 images run as two half-batch launch chains on two streams: every image must come
+    out as if it had been extracted alone, the stage timers count one entry per chain, and work queued on
+    the caller's stream afterwards sees both halves."""
+    import torch
+    from snake_slam_amd import synth
+    from snake_slam_amd.orb import ORBExtractor, KEYPOINT_DTYPE
+
+    B, W, H = 11, 320, 240
+    imgs = [synth.stereo_frame(300 + i, W, H, n_rects=80)[0] for i in range(B)]
+    host = np.stack(imgs)
+    ext = ORBExtractor(400, 1.2, 4, 20, 7)
+    cap = ext.configure(W, H, B)
+    dev = torch.device("cuda:0")
+    d_img = torch.from_numpy(host).to(dev)
+    d_kps = torch.zeros((B, cap, 24), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((B, cap, 4), dtype=torch.int64, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ext.set_profiling(True)
+    ext.detect_batch_dev(d_img, d_kps, d_desc, d_n)
+    ms, chains = ext.stage_times()
+    assert chains == 2 and all(m >= 0 for m in ms)
+    ext.set_profiling(False)
+    ext.sync()
+    n = d_n.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(KEYPOINT_DTYPE).reshape(B, cap)
+    desc = d_desc.cpu().numpy().view(np.uint64)
+    p = orc.orb_params(400, 1.2, 4, 20, 7)
+    for i in range(B):
+        wk, wd = orc.orb_detect(p, imgs[i])
+        assert n[i] == len(wk) and n[i] > 100, f"image {i}"
+        assert np.array_equal(kps[i, : n[i]], wk.astype(KEYPOINT_DTYPE)) and np.array_equal(desc[i, : n[i]], wd)
+    ext.close()
+
+
 def test_unaligned_device_images_take_the_byte_path(orc):
     """Odd base address and odd pitch: the aligned dword loaders must fall back to byte loads."""
     import torch
