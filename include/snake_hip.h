@@ -179,14 +179,21 @@ SNK_API int snk_orb_detect_batch_dev(snk_orb* o, const uint8_t* images_dev, int 
  * stages of every detect call: ms[0] = the per-level streaming passes (blurred level + next pyramid
  * level in one pass; plus the stand-alone resize when scale_factor > 2), ms[1] = reserved (the
  * blur used to be a stage of its own; now ~0), ms[2] = FAST cells, ms[3] = distribution,
- * ms[4] = descriptors.  A batch of >= 8 images runs as two half-batch launch chains on two streams
- * (joined on the handle's stream before the call returns control of it); each chain is timed on its
- * own stream and counts as one entry of n_calls ("launch chains"), so ms[k] / n_calls is the average
- * duration of one launch and the images per launch are (images processed) / n_calls.
- * SNK_ORB_ONE_STREAM=1 in the environment disables the split.
+ * ms[4] = descriptors.  With snk_orb_set_chains(o, 2) a batch of >= 8 images runs as two half-batch
+ * launch chains on two streams; each chain is timed on its own stream and counts as one entry of
+ * n_calls ("launch chains"), so ms[k] / n_calls is the average duration of one launch and the images
+ * per launch are (images processed) / n_calls.
  * snk_orb_stage_times synchronises, returns the summed milliseconds per stage over the launch chains
  * since the last query (ms[5]) and their number, and resets the accumulation. */
 SNK_API int snk_orb_set_profiling(snk_orb* o, int enable);
+
+/* Launch chains per snk_orb_detect_batch_dev call (1..4, default 1; environment SNK_ORB_PARTS sets the
+ * default).  With more than one chain a batch of >= 8 images is split into equal parts whose kernel
+ * sequences run on the handle's stream and on streams owned by the handle, forked from and joined on
+ * the handle's stream with events, so the caller-visible ordering is unchanged.  Measured on MI355X:
+ * 2 chains +3 % frames/s (the tail of one chain's launch overlaps the other chain), 3-4 chains slower;
+ * per-kernel durations are no longer additive.  No reference counterpart. */
+SNK_API int snk_orb_set_chains(snk_orb* o, int chains);
 SNK_API int snk_orb_stage_times(snk_orb* o, float* ms, int* n_calls);
 
 /* Intermediate results of the last call (tests / debugging). */

@@ -1278,7 +1278,7 @@ struct snk_orb : HandleBase
     hipStream_t extra[MAX_PARTS - 1] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join_n[MAX_PARTS - 1] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_join = nullptr;
-    int split_min_batch = 8, parts = 2;
+    int split_min_batch = 8, parts = 1;  // launch chains per batch: 1 by default, snk_orb_set_chains / SNK_ORB_PARTS
 };
 
 static int compute_layout(snk_orb* o, int w, int h)
@@ -1768,6 +1768,21 @@ int snk_orb_set_profiling(snk_orb* o, int enable)
     SNK_HIP_CHECK(hipStreamSynchronize(o->stream));
     o->profiling = enable != 0;
     o->ev_used   = 0;
+    return SNK_OK;
+}
+
+int snk_orb_set_chains(snk_orb* o, int chains)
+{
+    SNK_REQUIRE(o != nullptr, "orb is NULL");
+    SNK_REQUIRE(chains >= 1 && chains <= snk_orb::MAX_PARTS, "chains must be 1..4");
+    if (chains > 1 && o->stream2 == nullptr)
+    {
+        set_error("the extra streams could not be created");
+        return SNK_ERR_HIP;
+    }
+    SNK_HIP_CHECK(hipSetDevice(o->device));
+    SNK_HIP_CHECK(hipStreamSynchronize(o->stream));
+    o->parts = chains;
     return SNK_OK;
 }
 

@@ -87,6 +87,10 @@ class ORBExtractor:
     def set_profiling(self, enable: bool) -> None:
         _lib.check(self._lib.snk_orb_set_profiling(self._h, int(enable)), "snk_orb_set_profiling")
 
+    def set_chains(self, chains: int) -> None:
+        """Launch chains per detect_batch_dev call (1 = one chain on the handle's stream, 2 = two half batches on two streams)."""
+        _lib.check(self._lib.snk_orb_set_chains(self._h, int(chains)), "snk_orb_set_chains")
+
     def stage_times(self):
         """(ms per stage [pyramid, blur, fast, distribute, describe] summed over calls, number of calls)."""
         ms = (C.c_float * 5)()

@@ -190,7 +190,7 @@ def test_batch_dev_matches_single(orc):
 
 
 def test_split_batch_two_streams(orc):
-    """Batches of >= 8 images run as two half-batch launch chains on two streams: every image must come
+    """With set_chains(2) batches of >= 8 images run as two half-batch launch chains on two streams: every image must come
     out as if it had been extracted alone, the stage timers count one entry per chain, and work queued on
     the caller's stream afterwards sees both halves."""
     import torch
@@ -208,6 +208,7 @@ def test_split_batch_two_streams(orc):
     d_desc = torch.zeros((B, cap, 4), dtype=torch.int64, device=dev)
     d_n = torch.zeros(B, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
+    ext.set_chains(2)
     ext.set_profiling(True)
     ext.detect_batch_dev(d_img, d_kps, d_desc, d_n)
     ms, chains = ext.stage_times()
