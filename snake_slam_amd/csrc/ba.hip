@@ -41,6 +41,8 @@ struct Prob
     int vec_off;        // n6-vectors (rhs, x)
     long long s_off;    // S (n6 * n6 doubles)
     int orig_off;       // first caller-order observation of this problem
+    int n_wv;           // wavefront work items of point_wave (whole points, <= 64 observations each); 0: not available
+    int wv_off;
     int pad;
     double K[4];
     double bf;
@@ -77,6 +79,8 @@ struct Arrays
     const double* o_depth;
     const double* o_weight;
     const int* o_orig;             // caller-order index (global over problems)
+    const int* o_pt;               // point index (inside the problem) of the observation
+    const int* wv_pt;              // [n_wv + 1] per problem: first point of every point_wave work item
     const unsigned char* outlier;  // caller order
     double* o_Jc;  // [obs][18] scaled pose Jacobian
     double* o_r;   // [obs][4]  scaled residual, [3] = dim (0: inactive in this iteration)
@@ -299,6 +303,198 @@ __global__ __launch_bounds__(128) void point_pass(Arrays A, Opt O)
             Yp[a * 3 + 2] = y2;
             yb[a]         = y0 * bp[0] + y1 * bp[1] + y2 * bp[2];
         }
+    }
+}
+
+// Linearisation (MODE 0 of point_pass) with one WAVEFRONT per <= 64 consecutive observations that
+// belong to whole points.  point_pass gives a thread one point and lets it walk its observations: every
+// lane then writes 8-byte words 144 bytes apart and the L2 sees ~1100 partial-line writes per 64
+// observations.  Here lane = observation for the per-observation math (coalesced reads), lane = point
+// for the small per-point part (V, b_p, V^-1; same summation order as point_pass, so the results are
+// bit-identical), and the 18-double rows of J_c, W, Y leave through an LDS transpose as full 128-byte
+// lines.  LDS per wavefront: 14 + 9 + 18 doubles per lane = 20.5 KB.
+constexpr int PW_JP = 14;  // Jp[9], r[3], cost, dim
+constexpr int PW_PV = 9;   // Vinv[6], bp[3]
+__global__ __launch_bounds__(64) void point_wave(Arrays A, Opt O)
+{
+    __shared__ double s_jp[64 * PW_JP];
+    __shared__ double s_pv[64 * PW_PV];
+    __shared__ double s_st[64 * 18];
+    const int lane = threadIdx.x;
+    const int pb   = blockIdx.y;
+    const Prob pr  = A.prob[pb];
+    const int w    = blockIdx.x;
+    if (w >= pr.n_wv) return;
+    const int p0 = A.wv_pt[pr.wv_off + w], p1 = A.wv_pt[pr.wv_off + w + 1];
+    const int sb = A.pt_start[pr.ptstart_off + p0], se = A.pt_start[pr.ptstart_off + p1];
+    const int nob = se - sb, npt = p1 - p0;
+    const double* poses = A.pose + (size_t)pr.img_off * 7;
+    const size_t gbase  = (size_t)pr.obs_off + sb;  // first observation of the work item
+
+    // ---- phase 1: lane = observation ----
+    const bool act = lane < nob;
+    const size_t go = gbase + (act ? lane : 0);
+    double r[3] = {0, 0, 0}, Jc[18], Jp[9];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) Jc[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Jp[k] = 0.0;
+    int dim = 0, c = -1, lp = 0;
+    double cost = 0.0;
+    if (act)
+    {
+        lp = A.o_pt[go] - p0;
+        c  = A.o_cam[go];
+        if (!A.outlier[A.o_orig[go]])
+        {
+            const double* ptp  = A.pt + (size_t)(pr.pt_off + p0 + lp) * 3;
+            const double pt[3] = {ptp[0], ptp[1], ptp[2]};
+            const double* pose = poses + (size_t)A.o_img[go] * 7;
+            double R[9];
+            quat_to_R(pose, R);
+            const double2 uv = A.o_uv[go];
+            dim = obs_linearize<true>(pose, R, pt, pr.K, pr.bf, uv.x, uv.y, A.o_depth[go], A.o_weight[go], r, Jc, Jp);
+            if (dim)
+            {
+                const double sq = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+                double sw;
+                cost = huber_rho(sq, dim == 3 ? O.huber_stereo : O.huber_mono, sw);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) r[k] *= sw;
+#pragma unroll
+                for (int k = 0; k < 18; ++k) Jc[k] *= sw;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Jp[k] *= sw;
+            }
+            else
+            {
+                r[0] = r[1] = r[2] = 0.0;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s_jp[lane * PW_JP + k] = Jp[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s_jp[lane * PW_JP + 9 + k] = r[k];
+    s_jp[lane * PW_JP + 12] = cost;
+    s_jp[lane * PW_JP + 13] = (double)dim;
+    if (act)  // [go][4]: 32 contiguous bytes per lane, coalesced as is
+    {
+        double2* rr = reinterpret_cast<double2*>(A.o_r + go * 4);
+        rr[0] = make_double2(r[0], r[1]);
+        rr[1] = make_double2(r[2], (double)dim);
+    }
+    // J_c rows through the transpose buffer (rows of inactive couplings are written as zeros)
+#pragma unroll
+    for (int k = 0; k < 18; ++k) s_st[lane * 18 + k] = (dim && c >= 0) ? Jc[k] : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    {
+        double* dst = A.o_Jc + gbase * 18;
+        for (int i = lane; i < nob * 18; i += 64) dst[i] = s_st[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- phase 2: lane = point ----
+    if (lane < npt)
+    {
+        const int p  = p0 + lane;
+        const int gp = pr.pt_off + p;
+        const bool pfree = !A.pt_const[gp];
+        const int a0 = A.pt_start[pr.ptstart_off + p] - sb, a1 = A.pt_start[pr.ptstart_off + p + 1] - sb;
+        double V[6] = {0, 0, 0, 0, 0, 0}, bp[3] = {0, 0, 0};
+        double cst = 0.0;
+        for (int a = a0; a < a1; ++a)
+        {
+            const double* q = s_jp + a * PW_JP;
+            if (q[13] == 0.0) continue;
+            cst += q[12];
+            if (pfree)
+            {
+                V[0] += q[0] * q[0] + q[3] * q[3] + q[6] * q[6];
+                V[1] += q[0] * q[1] + q[3] * q[4] + q[6] * q[7];
+                V[2] += q[0] * q[2] + q[3] * q[5] + q[6] * q[8];
+                V[3] += q[1] * q[1] + q[4] * q[4] + q[7] * q[7];
+                V[4] += q[1] * q[2] + q[4] * q[5] + q[7] * q[8];
+                V[5] += q[2] * q[2] + q[5] * q[5] + q[8] * q[8];
+#pragma unroll
+                for (int b = 0; b < 3; ++b) bp[b] -= q[b] * q[9] + q[3 + b] * q[10] + q[6 + b] * q[11];
+            }
+        }
+        A.cost_pt[gp] = cst;
+        double Vi[6] = {0, 0, 0, 0, 0, 0};
+        if (pfree)
+        {
+            const double lambda = A.state[pb].lambda;
+            V[0] += lambda * clampd(V[0]);
+            V[3] += lambda * clampd(V[3]);
+            V[5] += lambda * clampd(V[5]);
+            const double a = V[0], b = V[1], cc = V[2], d = V[3], e = V[4], f = V[5];
+            const double Aa = d * f - e * e, Bb = cc * e - b * f, Cc = b * e - cc * d;
+            const double det = a * Aa + b * Bb + cc * Cc;
+            const double id  = det == 0.0 ? 0.0 : 1.0 / det;
+            Vi[0] = Aa * id;
+            Vi[1] = Bb * id;
+            Vi[2] = Cc * id;
+            Vi[3] = (a * f - cc * cc) * id;
+            Vi[4] = (b * cc - a * e) * id;
+            Vi[5] = (a * d - b * b) * id;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) A.Vinv[(size_t)gp * 6 + k] = Vi[k];
+            A.bp[(size_t)gp * 3 + 0] = bp[0];
+            A.bp[(size_t)gp * 3 + 1] = bp[1];
+            A.bp[(size_t)gp * 3 + 2] = bp[2];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s_pv[lane * PW_PV + k] = Vi[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s_pv[lane * PW_PV + 6 + k] = bp[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- phase 3: lane = observation: W = Jc^T Jp, Y = W V^-1, Y b_p ----
+    const bool cpl = act && dim && c >= 0 && !A.pt_const[pr.pt_off + p0 + lp];
+    double Wm[18], Ym[18], yb[6];
+    {
+        const double* pv = s_pv + lp * PW_PV;
+        const double v0 = pv[0], v1 = pv[1], v2 = pv[2], v3 = pv[3], v4 = pv[4], v5 = pv[5];
+        const double b0 = pv[6], b1 = pv[7], b2 = pv[8];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+        {
+#pragma unroll
+            for (int b = 0; b < 3; ++b) Wm[a * 3 + b] = cpl ? Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b] + Jc[12 + a] * Jp[6 + b] : 0.0;
+            const double w0 = Wm[a * 3], w1 = Wm[a * 3 + 1], w2 = Wm[a * 3 + 2];
+            const double y0 = w0 * v0 + w1 * v1 + w2 * v2;
+            const double y1 = w0 * v1 + w1 * v3 + w2 * v4;
+            const double y2 = w0 * v2 + w1 * v4 + w2 * v5;
+            Ym[a * 3]     = y0;
+            Ym[a * 3 + 1] = y1;
+            Ym[a * 3 + 2] = y2;
+            yb[a]         = y0 * b0 + y1 * b1 + y2 * b2;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 18; ++k) s_st[lane * 18 + k] = Wm[k];
+    __builtin_amdgcn_wave_barrier();
+    {
+        double* dst = A.o_W + gbase * 18;
+        for (int i = lane; i < nob * 18; i += 64) dst[i] = s_st[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 18; ++k) s_st[lane * 18 + k] = Ym[k];
+    __builtin_amdgcn_wave_barrier();
+    {
+        double* dst = A.o_Y + gbase * 18;
+        for (int i = lane; i < nob * 18; i += 64) dst[i] = s_st[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s_st[lane * 6 + k] = yb[k];
+    __builtin_amdgcn_wave_barrier();
+    {
+        double* dst = A.o_yb + gbase * 6;
+        for (int i = lane; i < nob * 6; i += 64) dst[i] = s_st[i];
     }
 }
 
@@ -1001,7 +1197,9 @@ struct snk_ba : HandleBase
     int max_np = 0, max_nfc = 0, max_n6 = 0, max_ni = 0;
     DevBuf d_prob, d_state, d_pose, d_pose_new, d_pose0, d_pt, d_pt_new, d_pt0, d_ptc, d_camidx, d_ptstart, d_oimg, d_ocam,
         d_optfree, d_ouv, d_odepth, d_oweight, d_oorig, d_outlier, d_Jc, d_r, d_W, d_Y, d_yb, d_Vinv, d_bp, d_cost,
-        d_cost_new, d_U, d_camstart, d_camitems, d_blkstart, d_blkent, d_S, d_rhs, d_x, d_chi2, d_pcgw;
+        d_cost_new, d_U, d_camstart, d_camitems, d_blkstart, d_blkent, d_S, d_rhs, d_x, d_chi2, d_pcgw, d_optidx, d_wvpt;
+    int max_wv = 0;
+    bool point_wave_ok = false;  // every problem has a point_wave work list (no point with > 64 observations)
     PcgLarge pcgw{};     // work arrays of the multi-workgroup PCG (only when the reduced system exceeds the LDS)
     bool pcg_large = false;
     Arrays arr{};
@@ -1092,7 +1290,9 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     std::vector<Prob> probs((size_t)count);
     std::vector<double> pose, pt, ouv2, odepth, oweight;
     std::vector<unsigned char> ptc, optfree;
-    std::vector<int> camidx, ptstart, oimg, ocam, oorig, camstart, camitems, blkstart;
+    std::vector<int> camidx, ptstart, oimg, ocam, oorig, camstart, camitems, blkstart, optidx, wvpt;
+    int max_wv = 0;
+    bool wave_ok = true;
     std::vector<int2> blkent;
     h->orig_off.assign((size_t)count, 0);
     h->orig_n.assign((size_t)count, 0);
@@ -1173,6 +1373,36 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             odepth.push_back(P.obs_depth[o]);
             oweight.push_back(P.obs_weight[o]);
             oorig.push_back(orig_off + o);
+            optidx.push_back(p);
+        }
+        // point_wave work items: consecutive whole points with <= 64 observations in total
+        pr.wv_off = (int)wvpt.size();
+        pr.n_wv   = 0;
+        {
+            bool ok = true;
+            std::vector<int> wv;
+            int p = 0;
+            while (p < P.n_pt && ok)
+            {
+                wv.push_back(p);
+                int n = 0, q = p;
+                while (q < P.n_pt && q - p < 64 && n + (pstart[(size_t)q + 1] - pstart[(size_t)q]) <= 64)
+                {
+                    n += pstart[(size_t)q + 1] - pstart[(size_t)q];
+                    ++q;
+                }
+                if (q == p) ok = false;  // a point with more than 64 observations: point_pass handles the problem
+                p = q;
+            }
+            if (ok)
+            {
+                wv.push_back(P.n_pt);
+                pr.n_wv = (int)wv.size() - 1;
+                wvpt.insert(wvpt.end(), wv.begin(), wv.end());
+                max_wv = std::max(max_wv, pr.n_wv);
+            }
+            else
+                wave_ok = false;
         }
         // camera lists
         pr.camstart_off = (int)camstart.size();
@@ -1248,6 +1478,8 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     h->tot_img = img_off; h->tot_pt = pt_off; h->tot_obs = obs_off; h->tot_cam = cam_off; h->tot_orig = orig_off;
     h->tot_vec = vec_off; h->tot_s = s_off;
     h->max_np = max_np; h->max_nfc = max_nfc; h->max_n6 = max_n6; h->max_ni = max_ni;
+    h->max_wv = max_wv;
+    h->point_wave_ok = wave_ok && max_wv > 0;
 
     int rc;
     hipStream_t st = h->stream;
@@ -1271,6 +1503,8 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     UP(d_camitems, camitems);
     UP(d_blkstart, blkstart);
     UP(d_blkent, blkent);
+    UP(d_optidx, optidx);
+    UP(d_wvpt, wvpt);
 #undef UP
     const size_t nobs = (size_t)std::max(obs_off, 1), npt = (size_t)std::max(pt_off, 1);
 #define RS(buf, bytes) if ((rc = h->buf.reserve(bytes)) != SNK_OK) return rc
@@ -1342,6 +1576,8 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     A.o_depth   = h->d_odepth.as<double>();
     A.o_weight  = h->d_oweight.as<double>();
     A.o_orig    = h->d_oorig.as<int>();
+    A.o_pt      = h->d_optidx.as<int>();
+    A.wv_pt     = h->d_wvpt.as<int>();
     A.outlier   = h->d_outlier.as<unsigned char>();
     A.o_Jc      = h->d_Jc.as<double>();
     A.o_r       = h->d_r.as<double>();
@@ -1410,7 +1646,11 @@ static int enqueue_lm(snk_ba* h, int iterations)
     if (s_in_lds) pcg_lds += s_bytes;
     for (int it = 0; it < iterations; ++it)
     {
-        hipLaunchKernelGGL(point_pass<0>, gpt, dim3(128), 0, st, A, O);
+        static const bool no_wave = getenv("SNK_BA_NO_POINT_WAVE") != nullptr;
+        if (h->point_wave_ok && !no_wave)
+            hipLaunchKernelGGL(point_wave, dim3(h->max_wv, B), dim3(64), 0, st, A, O);
+        else
+            hipLaunchKernelGGL(point_pass<0>, gpt, dim3(128), 0, st, A, O);
         if (h->max_nfc > 0)
         {
             hipLaunchKernelGGL(cam_pass, dim3(h->max_nfc, B), dim3(CAM_THREADS), 0, st, A);
