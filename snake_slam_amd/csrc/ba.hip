@@ -585,7 +585,7 @@ __global__ __launch_bounds__(CAM_THREADS) void cam_pass(Arrays A)
 // S block (c1, c2) = [c1 == c2] U - sum over co-observations of Y(c1) W(c2)^T.  One wavefront per
 // block: lanes stride over the block's co-observation list, each accumulating a full 6x6 product in
 // registers (36 + 36 operands from two contiguous 144-byte rows), then a fixed xor-butterfly sum.
-__global__ __launch_bounds__(256) void schur_pass(Arrays A)
+__global__ __launch_bounds__(256) void schur_pass(Arrays A, int zero_rows)
 {
     const int pb   = blockIdx.y;
     const Prob pr  = A.prob[pb];
@@ -598,11 +598,16 @@ __global__ __launch_bounds__(256) void schur_pass(Arrays A)
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+    // zero_rows: the linearisation wrote zero rows for inactive observations (point_wave), so their
+    // products vanish and the dependent activity lookup is skipped; the next list entry is fetched before
+    // the current rows are consumed (one latency level per iteration instead of three)
+    int2 en_next = e0 + lane < e1 ? A.blk_ent[pr.ent_off + e0 + lane] : make_int2(0, 0);
     for (int k = e0 + lane; k < e1; k += 64)
     {
-        const int2 en = A.blk_ent[pr.ent_off + k];
+        const int2 en = en_next;
+        if (k + 64 < e1) en_next = A.blk_ent[pr.ent_off + k + 64];
         const int g1 = pr.obs_off + en.x, g2 = pr.obs_off + en.y;
-        if (A.o_r[(size_t)g1 * 4 + 3] == 0.0 || A.o_r[(size_t)g2 * 4 + 3] == 0.0) continue;
+        if (!zero_rows && (A.o_r[(size_t)g1 * 4 + 3] == 0.0 || A.o_r[(size_t)g2 * 4 + 3] == 0.0)) continue;
         const double2* Yp = reinterpret_cast<const double2*>(A.o_Y + (size_t)g1 * 18);
         const double2* Wp = reinterpret_cast<const double2*>(A.o_W + (size_t)g2 * 18);
         double y[18], w[18];
@@ -1654,7 +1659,8 @@ static int enqueue_lm(snk_ba* h, int iterations)
         if (h->max_nfc > 0)
         {
             hipLaunchKernelGGL(cam_pass, dim3(h->max_nfc, B), dim3(CAM_THREADS), 0, st, A);
-            hipLaunchKernelGGL(schur_pass, dim3(ceil_div(h->max_nfc * h->max_nfc, 4), B), dim3(256), 0, st, A);
+            hipLaunchKernelGGL(schur_pass, dim3(ceil_div(h->max_nfc * h->max_nfc, 4), B), dim3(256), 0, st, A,
+                               h->point_wave_ok && !no_wave ? 1 : 0);
             if (!h->pcg_large)
                 hipLaunchKernelGGL(pcg_solve, dim3(B), dim3(PCG_THREADS), pcg_lds, st, A, O, s_in_lds);
             else
