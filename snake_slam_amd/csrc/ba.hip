@@ -585,12 +585,19 @@ __global__ __launch_bounds__(CAM_THREADS) void cam_pass(Arrays A)
 // S block (c1, c2) = [c1 == c2] U - sum over co-observations of Y(c1) W(c2)^T.  One wavefront per
 // block: lanes stride over the block's co-observation list, each accumulating a full 6x6 product in
 // registers (36 + 36 operands from two contiguous 144-byte rows), then a fixed xor-butterfly sum.
-__global__ __launch_bounds__(256) void schur_pass(Arrays A, int zero_rows)
+// XCD-aware launch: workgroup L of the 1-D grid runs on XCD L % 8 (observed dispatch order; a speed
+// matter only).  All workgroups of a window are given the same L % 8, so the window's Y / W rows (4.6 MB,
+// each re-read ~4.5 times by different blocks) are served by ONE XCD's L2 instead of being pulled into all
+// eight: windows w = 8 j + xcd live on XCD xcd.
+__global__ __launch_bounds__(256) void schur_pass(Arrays A, int zero_rows, int nbx, int B)
 {
-    const int pb   = blockIdx.y;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pb  = (slot / nbx) * 8 + xcd;
+    if (pb >= B) return;
+    const int bx   = slot - (slot / nbx) * nbx;
     const Prob pr  = A.prob[pb];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int blk  = blockIdx.x * 4 + wave;
+    const int blk  = bx * 4 + wave;
     if (blk >= pr.nfc * pr.nfc) return;
     const int c1 = blk / pr.nfc, c2 = blk - c1 * pr.nfc;
     if (c2 < c1) return;  // S is symmetric: the lower blocks are written as transposes of the upper ones
@@ -1659,8 +1666,11 @@ static int enqueue_lm(snk_ba* h, int iterations)
         if (h->max_nfc > 0)
         {
             hipLaunchKernelGGL(cam_pass, dim3(h->max_nfc, B), dim3(CAM_THREADS), 0, st, A);
-            hipLaunchKernelGGL(schur_pass, dim3(ceil_div(h->max_nfc * h->max_nfc, 4), B), dim3(256), 0, st, A,
-                               h->point_wave_ok && !no_wave ? 1 : 0);
+            {
+                const int nbx = ceil_div(h->max_nfc * h->max_nfc, 4);
+                hipLaunchKernelGGL(schur_pass, dim3(nbx * 8 * ceil_div(B, 8)), dim3(256), 0, st, A,
+                                   h->point_wave_ok && !no_wave ? 1 : 0, nbx, B);
+            }
             if (!h->pcg_large)
                 hipLaunchKernelGGL(pcg_solve, dim3(B), dim3(PCG_THREADS), pcg_lds, st, A, O, s_in_lds);
             else
