@@ -85,7 +85,6 @@ struct Arrays
     double* o_Jc;  // [obs][18] scaled pose Jacobian
     double* o_r;   // [obs][4]  scaled residual, [3] = dim (0: inactive in this iteration)
     double* o_W;   // [obs][18]
-    double* o_Y;   // [obs][18]
     double* o_yb;  // [obs][6]
     double* Vinv;  // [pt][6]
     double* bp;    // [pt][3]
@@ -95,7 +94,7 @@ struct Arrays
     const int* cam_start;
     const int* cam_items;
     const int* blk_start;
-    const int2* blk_ent;
+    const int4* blk_ent;  // (observation of c1, observation of c2, point, 0), observation indices relative to the problem
     double* S;
     double* rhs;
     double* x;
@@ -289,7 +288,6 @@ __global__ __launch_bounds__(128) void point_pass(Arrays A, Opt O)
         const int go = pr.obs_off + s;
         if (A.o_cam[go] < 0 || A.o_r[(size_t)go * 4 + 3] == 0.0) continue;
         const double* Wp = A.o_W + (size_t)go * 18;
-        double* Yp       = A.o_Y + (size_t)go * 18;
         double* yb       = A.o_yb + (size_t)go * 6;
 #pragma unroll
         for (int a = 0; a < 6; ++a)
@@ -298,9 +296,6 @@ __global__ __launch_bounds__(128) void point_pass(Arrays A, Opt O)
             const double y0 = w0 * Vi[0] + w1 * Vi[1] + w2 * Vi[2];
             const double y1 = w0 * Vi[1] + w1 * Vi[3] + w2 * Vi[4];
             const double y2 = w0 * Vi[2] + w1 * Vi[4] + w2 * Vi[5];
-            Yp[a * 3]     = y0;
-            Yp[a * 3 + 1] = y1;
-            Yp[a * 3 + 2] = y2;
             yb[a]         = y0 * bp[0] + y1 * bp[1] + y2 * bp[2];
         }
     }
@@ -453,7 +448,7 @@ __global__ __launch_bounds__(64) void point_wave(Arrays A, Opt O)
 
     // ---- phase 3: lane = observation: W = Jc^T Jp, Y = W V^-1, Y b_p ----
     const bool cpl = act && dim && c >= 0 && !A.pt_const[pr.pt_off + p0 + lp];
-    double Wm[18], Ym[18], yb[6];
+    double Wm[18], yb[6];
     {
         const double* pv = s_pv + lp * PW_PV;
         const double v0 = pv[0], v1 = pv[1], v2 = pv[2], v3 = pv[3], v4 = pv[4], v5 = pv[5];
@@ -467,9 +462,6 @@ __global__ __launch_bounds__(64) void point_wave(Arrays A, Opt O)
             const double y0 = w0 * v0 + w1 * v1 + w2 * v2;
             const double y1 = w0 * v1 + w1 * v3 + w2 * v4;
             const double y2 = w0 * v2 + w1 * v4 + w2 * v5;
-            Ym[a * 3]     = y0;
-            Ym[a * 3 + 1] = y1;
-            Ym[a * 3 + 2] = y2;
             yb[a]         = y0 * b0 + y1 * b1 + y2 * b2;
         }
     }
@@ -478,14 +470,6 @@ __global__ __launch_bounds__(64) void point_wave(Arrays A, Opt O)
     __builtin_amdgcn_wave_barrier();
     {
         double* dst = A.o_W + gbase * 18;
-        for (int i = lane; i < nob * 18; i += 64) dst[i] = s_st[i];
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int k = 0; k < 18; ++k) s_st[lane * 18 + k] = Ym[k];
-    __builtin_amdgcn_wave_barrier();
-    {
-        double* dst = A.o_Y + gbase * 18;
         for (int i = lane; i < nob * 18; i += 64) dst[i] = s_st[i];
     }
     __builtin_amdgcn_wave_barrier();
@@ -608,22 +592,35 @@ __global__ __launch_bounds__(256) void schur_pass(Arrays A, int zero_rows, int n
     // zero_rows: the linearisation wrote zero rows for inactive observations (point_wave), so their
     // products vanish and the dependent activity lookup is skipped; the next list entry is fetched before
     // the current rows are consumed (one latency level per iteration instead of three)
-    int2 en_next = e0 + lane < e1 ? A.blk_ent[pr.ent_off + e0 + lane] : make_int2(0, 0);
+    int4 en_next = e0 + lane < e1 ? A.blk_ent[pr.ent_off + e0 + lane] : make_int4(0, 0, 0, 0);
     for (int k = e0 + lane; k < e1; k += 64)
     {
-        const int2 en = en_next;
+        const int4 en = en_next;
         if (k + 64 < e1) en_next = A.blk_ent[pr.ent_off + k + 64];
         const int g1 = pr.obs_off + en.x, g2 = pr.obs_off + en.y;
         if (!zero_rows && (A.o_r[(size_t)g1 * 4 + 3] == 0.0 || A.o_r[(size_t)g2 * 4 + 3] == 0.0)) continue;
-        const double2* Yp = reinterpret_cast<const double2*>(A.o_Y + (size_t)g1 * 18);
+        // Y(c1) = W(c1) V^-1 is rebuilt from W and the point's 6 V^-1 entries instead of being stored per
+        // observation: the rows the blocks of a window re-read are then W only (2.3 MB, fits one XCD's L2)
+        const double2* Ap = reinterpret_cast<const double2*>(A.o_W + (size_t)g1 * 18);
         const double2* Wp = reinterpret_cast<const double2*>(A.o_W + (size_t)g2 * 18);
-        double y[18], w[18];
+        const double2* Vp = reinterpret_cast<const double2*>(A.Vinv + (size_t)(pr.pt_off + en.z) * 6);
+        double wa[18], w[18], y[18];
 #pragma unroll
         for (int q = 0; q < 9; ++q)
         {
-            const double2 a = Yp[q], b = Wp[q];
-            y[2 * q] = a.x; y[2 * q + 1] = a.y;
+            const double2 a = Ap[q], b = Wp[q];
+            wa[2 * q] = a.x; wa[2 * q + 1] = a.y;
             w[2 * q] = b.x; w[2 * q + 1] = b.y;
+        }
+        const double2 v01 = Vp[0], v23 = Vp[1], v45 = Vp[2];
+        const double v0 = v01.x, v1 = v01.y, v2 = v23.x, v3 = v23.y, v4 = v45.x, v5 = v45.y;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+        {
+            const double w0 = wa[a * 3], w1 = wa[a * 3 + 1], w2 = wa[a * 3 + 2];
+            y[a * 3]     = w0 * v0 + w1 * v1 + w2 * v2;
+            y[a * 3 + 1] = w0 * v1 + w1 * v3 + w2 * v4;
+            y[a * 3 + 2] = w0 * v2 + w1 * v4 + w2 * v5;
         }
 #pragma unroll
         for (int r = 0; r < 6; ++r)
@@ -1305,7 +1302,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     std::vector<int> camidx, ptstart, oimg, ocam, oorig, camstart, camitems, blkstart, optidx, wvpt;
     int max_wv = 0;
     bool wave_ok = true;
-    std::vector<int2> blkent;
+    std::vector<int4> blkent;
     h->orig_off.assign((size_t)count, 0);
     h->orig_n.assign((size_t)count, 0);
     int img_off = 0, pt_off = 0, obs_off = 0, cam_off = 0, orig_off = 0, vec_off = 0;
@@ -1448,7 +1445,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                 }
             }
             for (size_t k = 0; k < nb; ++k) bs[k + 1] += bs[k];
-            std::vector<int2> ent((size_t)bs[nb]);
+            std::vector<int4> ent((size_t)bs[nb]);
             std::vector<int> fill(bs.begin(), bs.end() - 1);
             for (int p = 0; p < P.n_pt; ++p)
             {
@@ -1459,9 +1456,11 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                     for (int c = pstart[(size_t)p]; c < pstart[(size_t)p + 1]; ++c)
                         if (s_cam[(size_t)c] >= 0)
                         {
-                            int2 e;
+                            int4 e;
                             e.x = a;
                             e.y = c;
+                            e.z = p;
+                            e.w = 0;
                             ent[(size_t)fill[(size_t)s_cam[(size_t)a] * nfc + s_cam[(size_t)c]]++] = e;
                         }
                 }
@@ -1528,7 +1527,6 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     RS(d_Jc, nobs * 18 * 8);
     RS(d_r, nobs * 4 * 8);
     RS(d_W, nobs * 18 * 8);
-    RS(d_Y, nobs * 18 * 8);
     RS(d_yb, nobs * 6 * 8);
     RS(d_Vinv, npt * 6 * 8);
     RS(d_bp, npt * 3 * 8);
@@ -1594,7 +1592,6 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     A.o_Jc      = h->d_Jc.as<double>();
     A.o_r       = h->d_r.as<double>();
     A.o_W       = h->d_W.as<double>();
-    A.o_Y       = h->d_Y.as<double>();
     A.o_yb      = h->d_yb.as<double>();
     A.Vinv      = h->d_Vinv.as<double>();
     A.bp        = h->d_bp.as<double>();
@@ -1604,7 +1601,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     A.cam_start = h->d_camstart.as<int>();
     A.cam_items = h->d_camitems.as<int>();
     A.blk_start = h->d_blkstart.as<int>();
-    A.blk_ent   = h->d_blkent.as<int2>();
+    A.blk_ent   = h->d_blkent.as<int4>();
     A.S         = h->d_S.as<double>();
     A.rhs       = h->d_rhs.as<double>();
     A.x         = h->d_x.as<double>();
