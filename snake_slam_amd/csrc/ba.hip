@@ -482,6 +482,126 @@ __global__ __launch_bounds__(64) void point_wave(Arrays A, Opt O)
     }
 }
 
+// Back-substitution of the points with the point_wave work items: lane = observation forms W^T dc
+// (three sums of six products), lane = point subtracts them from b_p in observation order and applies V^-1.
+__global__ __launch_bounds__(256) void update_wave(Arrays A)
+{
+    __shared__ double s_t[4][64 * 3];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int pb   = blockIdx.y;
+    const Prob pr  = A.prob[pb];
+    const int w    = blockIdx.x * 4 + wave;
+    if (w >= pr.n_wv) return;
+    const int p0 = A.wv_pt[pr.wv_off + w], p1 = A.wv_pt[pr.wv_off + w + 1];
+    const int sb = A.pt_start[pr.ptstart_off + p0], se = A.pt_start[pr.ptstart_off + p1];
+    const int nob = se - sb, npt = p1 - p0;
+    const double* x = A.x + pr.vec_off;
+    double t[3] = {0, 0, 0};
+    if (lane < nob)
+    {
+        const size_t go = (size_t)pr.obs_off + sb + lane;
+        const int c     = A.o_cam[go];
+        if (c >= 0 && A.o_r[go * 4 + 3] != 0.0)
+        {
+            const double2* Wp = reinterpret_cast<const double2*>(A.o_W + go * 18);
+            double wv[18];
+#pragma unroll
+            for (int q = 0; q < 9; ++q)
+            {
+                const double2 v = Wp[q];
+                wv[2 * q] = v.x;
+                wv[2 * q + 1] = v.y;
+            }
+            const double* xc = x + c * 6;
+            double xv[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) xv[a] = xc[a];
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int a = 0; a < 6; ++a) t[b] += wv[a * 3 + b] * xv[a];
+        }
+    }
+    s_t[wave][lane * 3] = t[0];
+    s_t[wave][lane * 3 + 1] = t[1];
+    s_t[wave][lane * 3 + 2] = t[2];
+    __builtin_amdgcn_wave_barrier();
+    if (lane < npt)
+    {
+        const int p  = p0 + lane;
+        const int gp = pr.pt_off + p;
+        double* out  = A.pt_new + (size_t)gp * 3;
+        const double* cur = A.pt + (size_t)gp * 3;
+        if (A.pt_const[gp])
+        {
+            out[0] = cur[0];
+            out[1] = cur[1];
+            out[2] = cur[2];
+        }
+        else
+        {
+            double g[3] = {A.bp[(size_t)gp * 3], A.bp[(size_t)gp * 3 + 1], A.bp[(size_t)gp * 3 + 2]};
+            const int a0 = A.pt_start[pr.ptstart_off + p] - sb, a1 = A.pt_start[pr.ptstart_off + p + 1] - sb;
+            for (int a = a0; a < a1; ++a)
+            {
+                g[0] -= s_t[wave][a * 3];
+                g[1] -= s_t[wave][a * 3 + 1];
+                g[2] -= s_t[wave][a * 3 + 2];
+            }
+            const double* Vi = A.Vinv + (size_t)gp * 6;
+            out[0] = cur[0] + (Vi[0] * g[0] + Vi[1] * g[1] + Vi[2] * g[2]);
+            out[1] = cur[1] + (Vi[1] * g[0] + Vi[3] * g[1] + Vi[4] * g[2]);
+            out[2] = cur[2] + (Vi[2] * g[0] + Vi[4] * g[1] + Vi[5] * g[2]);
+        }
+    }
+}
+
+// Robust cost at the trial state (MODE 1 of point_pass) with the point_wave work items: lane = observation
+// evaluates the residual, lane = point adds the costs in observation order (bit-identical to point_pass<1>).
+__global__ __launch_bounds__(256) void cost_wave(Arrays A, Opt O)
+{
+    __shared__ double s_c[4][64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int pb   = blockIdx.y;
+    const Prob pr  = A.prob[pb];
+    const int w    = blockIdx.x * 4 + wave;
+    if (w >= pr.n_wv) return;
+    const int p0 = A.wv_pt[pr.wv_off + w], p1 = A.wv_pt[pr.wv_off + w + 1];
+    const int sb = A.pt_start[pr.ptstart_off + p0], se = A.pt_start[pr.ptstart_off + p1];
+    const int nob = se - sb, npt = p1 - p0;
+    double cost = 0.0;
+    if (lane < nob)
+    {
+        const size_t go = (size_t)pr.obs_off + sb + lane;
+        if (!A.outlier[A.o_orig[go]])
+        {
+            const int lp       = A.o_pt[go];
+            const double* ptp  = A.pt_new + (size_t)(pr.pt_off + lp) * 3;
+            const double pt[3] = {ptp[0], ptp[1], ptp[2]};
+            const double* pose = A.pose_new + ((size_t)pr.img_off + A.o_img[go]) * 7;
+            double R[9], r[3], Jc[1], Jp[1];
+            quat_to_R(pose, R);
+            const double2 uv = A.o_uv[go];
+            const int dim = obs_linearize<false>(pose, R, pt, pr.K, pr.bf, uv.x, uv.y, A.o_depth[go], A.o_weight[go], r, Jc, Jp);
+            if (dim)
+            {
+                double sw;
+                cost = huber_rho(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], dim == 3 ? O.huber_stereo : O.huber_mono, sw);
+            }
+        }
+    }
+    s_c[wave][lane] = cost;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < npt)
+    {
+        const int p  = p0 + lane;
+        const int a0 = A.pt_start[pr.ptstart_off + p] - sb, a1 = A.pt_start[pr.ptstart_off + p + 1] - sb;
+        double c = 0.0;
+        for (int a = a0; a < a1; ++a) c += s_c[wave][a];
+        A.cost_pt_new[pr.pt_off + p] = c;
+    }
+}
+
 // fixed-order sum of one double per thread over the workgroup: xor butterfly inside each wavefront
 // (shuffles, no barrier), then the wavefront totals in order — 2 barriers instead of log2(THREADS)+1.
 template <int THREADS>
@@ -1080,11 +1200,11 @@ __device__ void se3_update(const double* pose, const double* d, double* out)
 }
 
 // threads [0, np): back-substitution dp = V^-1 (b_p - sum W^T dc); threads [np, np + ni): trial poses
-__global__ __launch_bounds__(128) void update_pass(Arrays A)
+__global__ __launch_bounds__(128) void update_pass(Arrays A, int images_only)
 {
     const int pb  = blockIdx.y;
     const Prob pr = A.prob[pb];
-    const int t   = blockIdx.x * 128 + threadIdx.x;
+    const int t   = blockIdx.x * 128 + threadIdx.x + (images_only ? pr.np : 0);  // update_wave does the points
     const double* x = A.x + pr.vec_off;
     if (t < pr.np)
     {
@@ -1686,8 +1806,18 @@ static int enqueue_lm(snk_ba* h, int iterations)
                 }
             }
         }
-        hipLaunchKernelGGL(update_pass, dim3(std::max(1, ceil_div(h->max_np + h->max_ni, 128)), B), dim3(128), 0, st, A);
-        hipLaunchKernelGGL(point_pass<1>, gpt, dim3(128), 0, st, A, O);
+        if (h->point_wave_ok && !no_wave)
+        {
+            const dim3 gwv(ceil_div(h->max_wv, 4), B);
+            hipLaunchKernelGGL(update_wave, gwv, dim3(256), 0, st, A);
+            hipLaunchKernelGGL(update_pass, dim3(std::max(1, ceil_div(h->max_ni, 128)), B), dim3(128), 0, st, A, 1);
+            hipLaunchKernelGGL(cost_wave, gwv, dim3(256), 0, st, A, O);
+        }
+        else
+        {
+            hipLaunchKernelGGL(update_pass, dim3(std::max(1, ceil_div(h->max_np + h->max_ni, 128)), B), dim3(128), 0, st, A, 0);
+            hipLaunchKernelGGL(point_pass<1>, gpt, dim3(128), 0, st, A, O);
+        }
         hipLaunchKernelGGL(accept_pass, dim3(B), dim3(ACC_THREADS), 0, st, A);
         SNK_LAUNCH_CHECK();
     }
