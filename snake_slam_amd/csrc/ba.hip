@@ -695,10 +695,19 @@ __global__ __launch_bounds__(CAM_THREADS) void cam_pass(Arrays A)
 // eight: windows w = 8 j + xcd live on XCD xcd.
 __global__ __launch_bounds__(256) void schur_pass(Arrays A, int zero_rows, int nbx, int B)
 {
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int pb  = (slot / nbx) * 8 + xcd;
+    int pb, bx;
+    if (B >= 16)  // batched windows: one XCD per window
+    {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        pb = (slot / nbx) * 8 + xcd;
+        bx = slot - (slot / nbx) * nbx;
+    }
+    else  // few big problems (global BA): spread every problem over all XCDs
+    {
+        pb = blockIdx.x / nbx;
+        bx = blockIdx.x - pb * nbx;
+    }
     if (pb >= B) return;
-    const int bx   = slot - (slot / nbx) * nbx;
     const Prob pr  = A.prob[pb];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int blk  = bx * 4 + wave;
