@@ -1074,14 +1074,30 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
                                                        long long stride0, int aligned0, const u32* __restrict__ sel,
                                                        const u8* __restrict__ sel_score, const int* __restrict__ sel_cnt,
                                                        snk_keypoint* __restrict__ kps, u64* __restrict__ desc,
-                                                       int* __restrict__ n_out, int out_cap)
+                                                       int* __restrict__ n_out, int out_cap, int gx, int batch)
 {
     __shared__ uint2 mtab[4 * MOM_PAD];
     __shared__ u32 patch[4][PATCH_ITEMS + 14];
     const int tid  = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int l    = blockIdx.y;
-    const int b    = blockIdx.z;
+    // XCD-aware 1-D grid (workgroup L runs on XCD L % 8, a speed matter only): every workgroup of an image
+    // gets the same L % 8, so the image's raw / blurred windows are served by one XCD's L2
+    const int per_img = gx * L.n_levels;
+    int b, rem;
+    if (batch >= 16)
+    {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        b   = (slot / per_img) * 8 + xcd;
+        rem = slot - (slot / per_img) * per_img;
+    }
+    else
+    {
+        b   = blockIdx.x / per_img;
+        rem = blockIdx.x - b * per_img;
+    }
+    if (b >= batch) return;
+    const int l  = rem / gx;
+    const int bx = rem - l * gx;
     const int* cnts = sel_cnt + b * MAX_LEVELS;
     int offset = 0, total = 0;
     for (int k = 0; k < L.n_levels; ++k)
@@ -1090,16 +1106,16 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
         offset += k < l ? c : 0;
         total += c;
     }
-    if (blockIdx.x == 0 && l == 0 && tid == 0) n_out[b] = total < out_cap ? total : out_cap;
+    if (bx == 0 && l == 0 && tid == 0) n_out[b] = total < out_cap ? total : out_cap;
     const LevelInfo& lv = L.lv[l];
     const int cnt_l     = cnts[l];
-    if (blockIdx.x * 4 * DESC_KPW >= cnt_l) return;  // whole workgroup (the grid is sized for the largest level)
+    if (bx * 4 * DESC_KPW >= cnt_l) return;  // whole workgroup (the grid is sized for the largest level)
     {
         const uint2* g = reinterpret_cast<const uint2*>(&c_moment.v[0][0][0]);
         for (int i = tid; i < 4 * MOM_PAD; i += 256) mtab[i] = g[i];
     }
     __syncthreads();
-    const int slot0     = (blockIdx.x * 4 + wave) * DESC_KPW;
+    const int slot0     = (bx * 4 + wave) * DESC_KPW;
     if (slot0 >= cnt_l || offset + slot0 >= out_cap) return;  // whole wavefront
 
     const u8* src      = l == 0 ? img0 + (long long)b * stride0 : lv.base + (long long)b * lv.img_stride;
@@ -1665,9 +1681,12 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[4], st));
     int max_slot = 1;
     for (int l = 0; l < L.n_levels; ++l) max_slot = L.lv[l].slot_cap > max_slot ? L.lv[l].slot_cap : max_slot;
-    hipLaunchKernelGGL(describe_kernel, dim3(ceil_div(max_slot, 4 * DESC_KPW), L.n_levels, batch), dim3(256), 0, st, L,
-                       images_dev, pitch, image_stride, aligned0, d_sel, d_selscore, d_selcnt,
-                       kps_dev, (u64*)desc_dev, n_dev, out_cap);
+    {
+        const int gx = ceil_div(max_slot, 4 * DESC_KPW);
+        const int nb = batch >= 16 ? 8 * ceil_div(batch, 8) : batch;
+        hipLaunchKernelGGL(describe_kernel, dim3(gx * L.n_levels * nb), dim3(256), 0, st, L, images_dev, pitch, image_stride,
+                           aligned0, d_sel, d_selscore, d_selcnt, kps_dev, (u64*)desc_dev, n_dev, out_cap, gx, batch);
+    }
     SNK_LAUNCH_CHECK();
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[5], st));
     return SNK_OK;
