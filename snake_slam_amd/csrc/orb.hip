@@ -290,6 +290,26 @@ __device__ __forceinline__ short2_t fast_score16_pk(const short2_t (&d)[16])
     return pk_max(bright, -dark);
 }
 
+// XCD-aware 1-D grids: workgroup L runs on XCD L % 8 (observed dispatch order, a speed matter only).  All
+// workgroups of an image get the same L % 8 in every kernel of the chain, so what one stage writes for an
+// image (next level, blurred level, candidates) is read by the next stage through the same XCD's L2.
+__device__ __forceinline__ bool xcd_image_map(int gx, int batch, int& b, int& bx)
+{
+    if (batch >= 16)
+    {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        b  = (slot / gx) * 8 + xcd;
+        bx = slot - (slot / gx) * gx;
+    }
+    else
+    {
+        b  = blockIdx.x / gx;
+        bx = blockIdx.x - b * gx;
+    }
+    return b < batch;
+}
+static inline int xcd_grid(int gx, int batch) { return gx * (batch >= 16 ? 8 * ((batch + 7) / 8) : batch); }
+
 // One WAVEFRONT per FAST cell (4 cells per workgroup, no workgroup barriers: the phases of a cell
 // only communicate through that wavefront's own LDS slice, which the LDS serves in program order).
 // Phase A runs the cheap opposite-pair bound on every pixel and compacts the ~10 % that can still
@@ -298,12 +318,13 @@ __device__ __forceinline__ short2_t fast_score16_pk(const short2_t (&d)[16])
 // image tile | score map with zero ring | quick-test survivors | NMS survivors | 3 counters.
 __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restrict__ img0, int pitch0, long long stride0,
                                                    int aligned0, int ini_th, int min_th, u32* __restrict__ cand,
-                                                   u16* __restrict__ cell_cnt)
+                                                   u16* __restrict__ cell_cnt, int gx, int batch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int b    = blockIdx.y;
-    const int cid  = blockIdx.x * 4 + wave;
+    int b, bxi;
+    if (!xcd_image_map(gx, batch, b, bxi)) return;
+    const int cid  = bxi * 4 + wave;
     if (cid >= L.total_cells) return;  // whole wavefront
     unsigned char* slice = fsm + wave * L.f_lds_wave;
     u32* tile_dw      = reinterpret_cast<u32*>(slice);
@@ -438,13 +459,14 @@ __device__ __forceinline__ u32 dot2(u32 pair, u32 w, u32 acc)
 }
 
 __global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* __restrict__ img0, int pitch0, long long stride0,
-                                                    int aligned0, int make_next)
+                                                    int aligned0, int make_next, int gx, int batch)
 {
     __shared__ u32 rowbuf[4][64];  // one raw row per wavefront (down-scale taps)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int b    = blockIdx.y;
+    int b, bxi;
+    if (!xcd_image_map(gx, batch, b, bxi)) return;
     const LevelInfo& lv = L.lv[l];
-    const int u    = blockIdx.x * 4 + wave;
+    const int u    = bxi * 4 + wave;
     if (u >= lv.n_strips * lv.n_bands) return;  // whole wavefront
     const int band  = u / lv.n_strips, strip = u - band * lv.n_strips;
     const int sx0   = strip * lv.strip_stride;
@@ -1649,8 +1671,11 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
             SNK_LAUNCH_CHECK();
         }
         if (tiny(l)) continue;
-        hipLaunchKernelGGL(level_kernel, dim3(ceil_div(lv.n_strips * lv.n_bands, 4), batch), dim3(256), 0, st, L, l,
-                           images_dev, pitch, image_stride, aligned0, fused && l + 1 < L.n_levels ? 1 : 0);
+        {
+            const int gx = ceil_div(lv.n_strips * lv.n_bands, 4);
+            hipLaunchKernelGGL(level_kernel, dim3(xcd_grid(gx, batch)), dim3(256), 0, st, L, l, images_dev, pitch, image_stride,
+                               aligned0, fused && l + 1 < L.n_levels ? 1 : 0, gx, batch);
+        }
         SNK_LAUNCH_CHECK();
     }
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[1], st));
@@ -1658,10 +1683,9 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[2], st));
     if (L.total_cells > 0)
     {
-        hipLaunchKernelGGL(fast_kernel, dim3(ceil_div(L.total_cells, 4), batch), dim3(256), (size_t)4 * L.f_lds_wave, st, L,
-                           images_dev, pitch,
-                           image_stride, aligned0, o->params.ini_th_fast, o->params.min_th_fast, d_cand,
-                           d_cellcnt);
+        const int gx = ceil_div(L.total_cells, 4);
+        hipLaunchKernelGGL(fast_kernel, dim3(xcd_grid(gx, batch)), dim3(256), (size_t)4 * L.f_lds_wave, st, L, images_dev, pitch,
+                           image_stride, aligned0, o->params.ini_th_fast, o->params.min_th_fast, d_cand, d_cellcnt, gx, batch);
         SNK_LAUNCH_CHECK();
     }
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[3], st));

@@ -226,6 +226,39 @@ def test_split_batch_two_streams(orc):
     ext.close()
 
 
+def test_xcd_mapped_batch(orc):
+    """Batches of >= 16 images use the XCD-aware 1-D grids (image b on XCD b % 8); 17 is not a multiple of 8,
+    so the padded part of the grid must fall out cleanly."""
+    import torch
+    from snake_slam_amd import synth
+    from snake_slam_amd.orb import ORBExtractor, KEYPOINT_DTYPE
+
+    B, W, H = 17, 200, 160
+    imgs = [synth.stereo_frame(400 + i, W, H, n_rects=50)[0] for i in range(B)]
+    ext = ORBExtractor(300, 1.2, 3, 20, 7)
+    cap = ext.configure(W, H, B)
+    dev = torch.device("cuda:0")
+    d_img = torch.from_numpy(np.stack(imgs)).to(dev)
+    d_kps = torch.zeros((B, cap, 24), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((B, cap, 4), dtype=torch.int64, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for chains in (1, 2):
+        ext.set_chains(chains)
+        d_n.zero_()
+        ext.detect_batch_dev(d_img, d_kps, d_desc, d_n)
+        ext.sync()
+        n = d_n.cpu().numpy()
+        kps = d_kps.cpu().numpy().view(KEYPOINT_DTYPE).reshape(B, cap)
+        desc = d_desc.cpu().numpy().view(np.uint64)
+        p = orc.orb_params(300, 1.2, 3, 20, 7)
+        for i in range(B):
+            wk, wd = orc.orb_detect(p, imgs[i])
+            assert n[i] == len(wk) and n[i] > 50, f"image {i} chains {chains}"
+            assert np.array_equal(kps[i, : n[i]], wk.astype(KEYPOINT_DTYPE)) and np.array_equal(desc[i, : n[i]], wd)
+    ext.close()
+
+
 def test_unaligned_device_images_take_the_byte_path(orc):
     """Odd base address and odd pitch: the aligned dword loaders must fall back to byte loads."""
     import torch
