@@ -237,6 +237,10 @@ def main():
                   "windows_per_gpu_per_step": NW, "ms_per_step": round(float(tba.item()) / args.steps * 1e3, 4),
                   "single_window_ms_per_solve": round((tl1 - tl0) / 10 * 1e3, 4),
                   "cost_initial": round(float(ci[0]), 3), "cost_final": round(float(cf[0]), 3), "dtype": "f64"}
+        # ~5.65 MB algorithmic per LM iteration of the 20 x 2000 x 8 window
+        ba_out["roofline"] = {"bound": "hbm", "algorithmic_bytes_per_lm_iteration": 5650000,
+                              "achieved": round(5.65e6 * ba_out["value"] / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(5.65e6 * ba_out["value"] / 1e9 / HBM_PEAK_GBS, 5)}
         ba.close()
         ba1.close()
         # global BA (GlobalBundleAdjustment::FullBA(4), PCG <= 40): one big scene,
@@ -338,6 +342,14 @@ def main():
                                "images_per_launch": images_per_launch, "launches_per_step": n_calls // args.steps}
             # summed over the launch chains of a step (with --orb-chains 2 the chains overlap and the sum exceeds the step time)
             out["stage_ms_per_step"] = {k: round(v / args.steps, 4) for k, v in zip(["pyramid", "blur", "fast", "distribute", "describe"], stage_ms)}
+        # whole front-end against the HBM roofline: A_orb = 3 P + 56 N bytes per mono image,
+        # BF / stereo matching (N1 + N2) * 32 + N1 * 16 bytes each
+        n_kp = float(blocks[0][1].item()) / (2 * B)
+        a_frame = 2 * (3 * P + 56 * n_kp) + 2 * (2 * n_kp * 32 + n_kp * 16)
+        out["pipeline_roofline"] = {"bound": "hbm", "algorithmic_bytes_per_frame": int(a_frame),
+                                    "achieved": round(a_frame * value / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(a_frame * value / 1e9 / HBM_PEAK_GBS, 5),
+                                    "note": "extract (L+R) + stereo match + BF match, algorithmic bytes only"}
         if ba_out is not None:
             out["ba"] = ba_out
         if pose_out is not None:
