@@ -333,6 +333,124 @@ __global__ __launch_bounds__(256) void stereo_kernel(const snk_kp64* __restrict_
     depth[(size_t)b * nl_cap + i]        = (float)(bf / disparity);
     atomicAdd(&n_matches[b], 1);
 }
+
+// Same matcher with SIXTEEN lanes per left keypoint (16 keypoints per workgroup) for the indexed case:
+// a row band holds ~15-30 candidates, so a whole wavefront per keypoint left three quarters of the lanes
+// idle, and the two binary searches over the row index were ~20 dependent global loads per keypoint.  The
+// workgroup stages the image's row index in LDS once, every 16-lane group searches it there, strides over
+// its band and merges the two smallest keys with 4 xor steps inside the group.
+__global__ __launch_bounds__(256) void stereo_kernel16(const snk_kp64* __restrict__ left, const uint4* __restrict__ dl,
+                                                     const int* __restrict__ nl_dev, int nl_cap, int nl_host,
+                                                     const snk_kp64* __restrict__ right, const uint4* __restrict__ dr,
+                                                     const int* __restrict__ nr_dev, int nr_cap, int nr_host, double bf,
+                                                     LevelScales ls, int relaxed, float* __restrict__ right_points,
+                                                     float* __restrict__ depth, int* __restrict__ n_matches,
+                                                     const u32* __restrict__ row_sorted)
+{
+    const int b    = blockIdx.y;
+    int nl         = nl_dev ? nl_dev[b] : nl_host;
+    int nr         = nr_dev ? nr_dev[b] : nr_host;
+    nl             = nl < nl_cap ? nl : nl_cap;
+    nr             = nr < nr_cap ? nr : nr_cap;
+    extern __shared__ u32 s_srt[];
+    const int lane = threadIdx.x & 15;
+    const int i    = blockIdx.x * 16 + (threadIdx.x >> 4);
+    {
+        const u32* g = row_sorted + (size_t)b * nr_cap;
+        for (int t = threadIdx.x; t < nr; t += 256) s_srt[t] = g[t];
+    }
+    __syncthreads();
+    if (i >= nl || nr <= 0) return;
+
+    const snk_kp64* lb = left + (size_t)b * nl_cap;
+    const snk_kp64* rb = right + (size_t)b * nr_cap;
+    const uint4* dlb   = dl + (size_t)b * nl_cap * 2;
+    const uint4* drb   = dr + (size_t)b * nr_cap * 2;
+
+    const snk_kp64 kp = lb[i];
+    const uint4 qa    = dlb[(size_t)i * 2];
+    const uint4 qc    = dlb[(size_t)i * 2 + 1];
+    const int y       = iround_d(kp.y);
+    int oct           = kp.octave;
+    oct               = oct < 0 ? 0 : (oct >= ls.n ? ls.n - 1 : oct);
+    const float r     = ceilf(2.0f * ls.s[oct]);
+    const int ri      = (int)r;
+    const float min_disp = 0.0f;
+    const float max_disp = (float)(bf * 0.5);
+
+    u64 k1 = ST_INF_KEY, k2 = ST_INF_KEY;
+    // With the row-sorted index (biased rounded row << 16 | index, ascending) only the right keypoints
+    // of rows y-r .. y+r are visited; every gate is still evaluated on the true values below.
+    int scan_lo = 0, scan_hi = nr;
+    const u32* srt = s_srt;
+    {
+        const int lo_row = min(max(y - ri + ST_ROW_BIAS, 0), 65535), hi_row = min(max(y + ri + ST_ROW_BIAS, 0), 65535);
+        const u32 lo_key = (u32)lo_row << 16, hi_key = ((u32)hi_row << 16) | 0xFFFFu;
+        int a = 0, c = nr;
+        while (a < c)
+        {
+            const int mid = (a + c) >> 1;
+            if (srt[mid] < lo_key) a = mid + 1; else c = mid;
+        }
+        scan_lo = a;
+        c       = nr;
+        while (a < c)
+        {
+            const int mid = (a + c) >> 1;
+            if (srt[mid] <= hi_key) a = mid + 1; else c = mid;
+        }
+        scan_hi = a;
+    }
+    for (int pos = scan_lo + lane; pos < scan_hi; pos += 16)
+    {
+        const int j       = (int)(srt[pos] & 0xFFFFu);
+        const snk_kp64 kr = rb[j];
+        const int yj      = iround_d(kr.y);
+        const int rel     = yj - (y - ri);
+        if (rel < 0 || rel > 2 * ri) continue;
+        const double disparity = kp.x - kr.x;
+        if (disparity < (double)min_disp || disparity > (double)max_disp) continue;
+        int doct = kp.octave - kr.octave;
+        doct     = doct < 0 ? -doct : doct;
+        if (doct > 1) continue;
+        const uint4 ta = drb[(size_t)j * 2];
+        const uint4 tc = drb[(size_t)j * 2 + 1];
+        const int dist = hamming256(qa, qc, ta, tc);
+        if (dist >= 250) continue;
+        const u64 key = ((u64)dist << 40) | ((u64)rel << 24) | (u64)j;
+        insert2(k1, k2, key);
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1)
+    {
+        u64 o1 = __shfl_xor(k1, off, 16);
+        u64 o2 = __shfl_xor(k2, off, 16);
+        merge2(k1, k2, o1, o2);
+    }
+    if (lane != 0) return;
+
+    const int best_dist        = (int)(k1 >> 40);
+    const int second_best_dist = (int)(k2 >> 40);
+    if (best_dist > (relaxed ? 75 : 40)) return;
+    if ((double)best_dist > (relaxed ? 0.9 : 0.7) * (double)second_best_dist) return;
+    const int best_id  = (int)(k1 & 0xFFFFFFull);
+    const snk_kp64 kb  = rb[best_id];
+    const float angle1 = kp.angle;
+    const float angle2 = kb.angle;
+    const float rot    = fminf(fabsf(angle1 - angle2), fminf(fabsf((angle1 + 365.0f) - angle2), fabsf(angle1 - (angle2 + 365.0f))));
+    if (rot > (relaxed ? 25.0f : 5.0f)) return;
+
+    double right_point = kb.x;
+    double disparity   = kp.x - right_point;
+    if (disparity <= 0.001)
+    {
+        disparity   = 0.001;
+        right_point = kp.x - disparity;
+    }
+    right_points[(size_t)b * nl_cap + i] = (float)right_point;
+    depth[(size_t)b * nl_cap + i]        = (float)(bf / disparity);
+    atomicAdd(&n_matches[b], 1);
+}
 }  // namespace
 }  // namespace snk
 
@@ -519,13 +637,20 @@ int snk_stereo_match(snk_matcher* m, const snk_kp64* left, const uint64_t (*desc
         while (np2 < nr) np2 <<= 1;
         SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stereo_sort_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, ST_SORT_MAX * 4));
+        SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stereo_kernel16),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, ST_SORT_MAX * 4));
         hipLaunchKernelGGL(stereo_sort_kernel, dim3(1), dim3(256), (size_t)np2 * 4, m->stream, (const snk_kp64*)(ab + kl),
                            (const int*)nullptr, nr, nr, m->out.as<u32>());
         srt = m->out.as<u32>();
     }
-    hipLaunchKernelGGL(stereo_kernel, dim3(ceil_div(nl, 4), 1), dim3(256), 0, m->stream, (const snk_kp64*)ab,
-                       m->q.as<uint4>(), (const int*)nullptr, nl, nl, (const snk_kp64*)(ab + kl), m->t.as<uint4>(),
-                       (const int*)nullptr, nr, nr, bf, ls, relaxed, rp, dp, m->cnt.as<int>(), srt);
+    if (srt)
+        hipLaunchKernelGGL(stereo_kernel16, dim3(ceil_div(nl, 16), 1), dim3(256), (size_t)nr * 4, m->stream, (const snk_kp64*)ab,
+                           m->q.as<uint4>(), (const int*)nullptr, nl, nl, (const snk_kp64*)(ab + kl), m->t.as<uint4>(),
+                           (const int*)nullptr, nr, nr, bf, ls, relaxed, rp, dp, m->cnt.as<int>(), srt);
+    else
+        hipLaunchKernelGGL(stereo_kernel, dim3(ceil_div(nl, 4), 1), dim3(256), 0, m->stream, (const snk_kp64*)ab,
+                           m->q.as<uint4>(), (const int*)nullptr, nl, nl, (const snk_kp64*)(ab + kl), m->t.as<uint4>(),
+                           (const int*)nullptr, nr, nr, bf, ls, relaxed, rp, dp, m->cnt.as<int>(), srt);
     SNK_LAUNCH_CHECK();
     SNK_HIP_CHECK(hipMemcpyAsync(right_points, rp, (size_t)nl * 4, hipMemcpyDeviceToHost, m->stream));
     SNK_HIP_CHECK(hipMemcpyAsync(depth, dp, (size_t)nl * 4, hipMemcpyDeviceToHost, m->stream));
@@ -559,13 +684,20 @@ int snk_stereo_match_batch_dev(snk_matcher* m, const snk_kp64* left_dev, const u
         while (np2 < nr_cap) np2 <<= 1;
         SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stereo_sort_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, ST_SORT_MAX * 4));
+        SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stereo_kernel16),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, ST_SORT_MAX * 4));
         hipLaunchKernelGGL(stereo_sort_kernel, dim3(batch), dim3(256), (size_t)np2 * 4, m->stream, right_dev, nr_dev, nr_cap, 0,
                            m->out.as<u32>());
         srt = m->out.as<u32>();
     }
-    hipLaunchKernelGGL(stereo_kernel, dim3(ceil_div(nl_cap, 4), batch), dim3(256), 0, m->stream, left_dev,
-                       (const uint4*)desc_left_dev, nl_dev, nl_cap, 0, right_dev, (const uint4*)desc_right_dev, nr_dev,
-                       nr_cap, 0, bf, ls, relaxed, right_points_dev, depth_dev, n_matches_dev, srt);
+    if (srt)
+        hipLaunchKernelGGL(stereo_kernel16, dim3(ceil_div(nl_cap, 16), batch), dim3(256), (size_t)nr_cap * 4, m->stream, left_dev,
+                           (const uint4*)desc_left_dev, nl_dev, nl_cap, 0, right_dev, (const uint4*)desc_right_dev, nr_dev,
+                           nr_cap, 0, bf, ls, relaxed, right_points_dev, depth_dev, n_matches_dev, srt);
+    else
+        hipLaunchKernelGGL(stereo_kernel, dim3(ceil_div(nl_cap, 4), batch), dim3(256), 0, m->stream, left_dev,
+                           (const uint4*)desc_left_dev, nl_dev, nl_cap, 0, right_dev, (const uint4*)desc_right_dev, nr_dev,
+                           nr_cap, 0, bf, ls, relaxed, right_points_dev, depth_dev, n_matches_dev, srt);
     SNK_LAUNCH_CHECK();
     return SNK_OK;
 }
