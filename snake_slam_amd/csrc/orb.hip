@@ -670,11 +670,41 @@ __device__ __forceinline__ u64 point_key(int x, int y, int W, int H, int nroots)
     return key;  // 8 + 32 bits
 }
 
-// in-LDS bitonic sort of n_pow2 u64 keys (ascending), all threads of the block participate
+// Bitonic sort of n_pow2 keys in LDS (ascending), all threads of the block participate.  Every wavefront
+// owns a contiguous segment of n_pow2 / waves keys: compare-exchange stages whose partner distance stays
+// inside the segment need no workgroup barrier (the LDS serves a wavefront in program order), only the
+// stages that cross segments do -- 9 barriers instead of 66 for 2048 keys and 8 wavefronts.
 __device__ void bitonic_sort(u64* a, int n_pow2, int tid, int nthreads)
 {
+    const int nw = nthreads >> 6, wave = tid >> 6, lane = tid & 63;
+    const int seg = n_pow2 / nw;  // keys per wavefront segment
+    if (seg < 128)
+    {
+        for (int k = 2; k <= n_pow2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1)
+            {
+                for (int t = tid; t < (n_pow2 >> 1); t += nthreads)
+                {
+                    const int i   = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int ixj = i | j;
+                    const bool up = (i & k) == 0;
+                    const u64 x = a[i], y = a[ixj];
+                    if ((x > y) == up)
+                    {
+                        a[i]   = y;
+                        a[ixj] = x;
+                    }
+                }
+                __syncthreads();
+            }
+        return;
+    }
+    const int base = wave * seg;
     for (int k = 2; k <= n_pow2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1)
+    {
+        int j = k >> 1;
+        if (j >= seg) __syncthreads();  // the previous segment-local stages are visible to every wavefront
+        for (; j >= seg; j >>= 1)      // stages across segments
         {
             for (int t = tid; t < (n_pow2 >> 1); t += nthreads)
             {
@@ -690,6 +720,24 @@ __device__ void bitonic_sort(u64* a, int n_pow2, int tid, int nthreads)
             }
             __syncthreads();
         }
+        for (; j > 0; j >>= 1)  // stages inside the wavefront's own segment
+        {
+            for (int t = lane; t < (seg >> 1); t += 64)
+            {
+                const int i   = base + (((t & ~(j - 1)) << 1) | (t & (j - 1)));
+                const int ixj = i | j;
+                const bool up = (i & k) == 0;
+                const u64 x = a[i], y = a[ixj];
+                if ((x > y) == up)
+                {
+                    a[i]   = y;
+                    a[ixj] = x;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
 }
 
 // block-wide inclusive scan of one int per thread (512 threads = 8 waves)
