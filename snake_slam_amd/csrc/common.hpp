@@ -64,7 +64,11 @@ struct DevBuf
         // SNK_DEBUG_POISON=1: fill fresh scratch with a pattern so that a kernel relying on
         // zero-initialised memory fails reproducibly instead of depending on the allocator's history
         static const bool poison = getenv("SNK_DEBUG_POISON") != nullptr;
-        if (poison) SNK_HIP_CHECK(hipMemset(p, 0xCD, want));
+        if (poison)
+        {
+            SNK_HIP_CHECK(hipMemset(p, 0xCD, want));
+            SNK_HIP_CHECK(hipDeviceSynchronize());  // the fill must not overtake / trail the handle stream's uploads
+        }
         return SNK_OK;
     }
     void release()
