@@ -438,6 +438,20 @@ typedef struct snk_ba_options
  * images[i] = {se3 (world -> camera; quaternion x y z w, translation), constant};
  * worldPoints[j] = {p, constant}; one entry per StereoImagePoint = {image, wp, point (pixels),
  * depth (> 0 => stereo observation; u_r = u - bf/depth), weight}; intrinsics[0] = K; scene.bf. */
+/* Saiga RelPoseConstraint as MakeLocalScene fills it when the IMU is enabled
+ * (LocalBundleAdjustment.cpp:294-346): img1 / img2 = id_in_scene of two consecutive keyframes,
+ * rel_pose = the pre-integrated relative pose, weight_rotation = gyro weight / dt,
+ * weight_translation = acc weight / dt (0 for dt > 2 s).  [DEFINED] (the residual lives in the absent
+ * saiga): rel_pose is T_img2 * T_img1^-1 for world -> camera poses; e = log(T2 T1^-1 rel^-1) = (rho,
+ * omega); r = (weight_translation * rho, weight_rotation * omega); cost += |r|^2 (no robust kernel);
+ * Gauss-Newton Jacobians with J_l^-1 ~ I: d r / d delta2 = W, d r / d delta1 = -W Ad(T2 T1^-1). */
+typedef struct snk_ba_rpc
+{
+    int32_t img1, img2;
+    double rel_pose[7];
+    double weight_rotation, weight_translation;
+} snk_ba_rpc;
+
 typedef struct snk_ba_problem
 {
     int32_t n_img, n_pt, n_obs;
@@ -452,6 +466,9 @@ typedef struct snk_ba_problem
     const double* obs_weight;
     double K[4]; /* fx fy cx cy */
     double bf;
+    int32_t n_rpc; /* scene.rel_pose_constraints (0 without IMU) */
+    int32_t pad;
+    const snk_ba_rpc* rpc;
 } snk_ba_problem;
 
 typedef struct snk_ba snk_ba;

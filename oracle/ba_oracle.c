@@ -20,6 +20,9 @@
  *             v = 2, on failure lambda *= v, v *= 2 and the step is reverted;
  *   PCG       block-Jacobi (6x6) preconditioner, x0 = 0, stop when |r| <= tol * |rhs| or after
  *             max_pcg iterations; exactly max_iterations LM iterations are run.
+ *   rel. pose  (IMU scenes, :294-346) e = log(T2 T1^-1 rel^-1) = (rho, omega), r = (w_t rho, w_r omega),
+ *             cost += |r|^2 without robust kernel; d r / d delta2 = W, d r / d delta1 = -W Ad(T2 T1^-1)
+ *             (J_l^-1 ~ I); constraints with both images constant or bad indices are ignored.
  * Double precision throughout.
  */
 #include <math.h>
@@ -132,6 +135,48 @@ static int obs_linearize(const double* pose, const double* pt, const double* K, 
     return dim;
 }
 
+/* Relative pose constraint: r (6) and J1 = d r / d delta1 (6x6, row-major); d r / d delta2 = W =
+ * diag(w_t, w_t, w_t, w_r, w_r, w_r). */
+int orc_ba_rpc_linearize(const double* pose1, const double* pose2, const orc_ba_rpc* c, double* r, double* J1)
+{
+    /* T21 = T2 * T1^-1 */
+    double q1c[4] = {-pose1[0], -pose1[1], -pose1[2], pose1[3]}, T21[7], R21[9];
+    quat_mul(pose2, q1c, T21);
+    quat_to_R(T21, R21);
+    T21[4] = pose2[4] - (R21[0] * pose1[4] + R21[1] * pose1[5] + R21[2] * pose1[6]);
+    T21[5] = pose2[5] - (R21[3] * pose1[4] + R21[4] * pose1[5] + R21[5] * pose1[6]);
+    T21[6] = pose2[6] - (R21[6] * pose1[4] + R21[7] * pose1[5] + R21[8] * pose1[6]);
+    double e[6];
+    orc_se3_log_rel(T21, c->rel_pose, e);
+    const double wt = c->weight_translation, wr = c->weight_rotation;
+    for (int a = 0; a < 3; ++a)
+    {
+        r[a]     = wt * e[a];
+        r[3 + a] = wr * e[3 + a];
+    }
+    /* Ad(T21) = [[R, [t]x R], [0, R]] for twists (v, omega) */
+    const double tx = T21[4], ty = T21[5], tz = T21[6];
+    const double K[9] = {0, -tz, ty, tz, 0, -tx, -ty, tx, 0};
+    double KR[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) KR[i * 3 + j] = K[i * 3] * R21[j] + K[i * 3 + 1] * R21[3 + j] + K[i * 3 + 2] * R21[6 + j];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+        {
+            J1[i * 6 + j]           = -wt * R21[i * 3 + j];
+            J1[i * 6 + 3 + j]       = -wt * KR[i * 3 + j];
+            J1[(3 + i) * 6 + j]     = 0.0;
+            J1[(3 + i) * 6 + 3 + j] = -wr * R21[i * 3 + j];
+        }
+    return 1;
+}
+
+static int rpc_valid(const orc_ba_problem* P, const orc_ba_rpc* c)
+{
+    if (c->img1 < 0 || c->img2 < 0 || c->img1 >= P->n_img || c->img2 >= P->n_img || c->img1 == c->img2) return 0;
+    return !(P->img_const[c->img1] && P->img_const[c->img2]);
+}
+
 static double huber_rho(double s, double d, double* sqrt_w)
 {
     const double d2 = d * d;
@@ -181,6 +226,13 @@ static double total_cost(const orc_ba_problem* P, const orc_ba_options* O, doubl
         double s = 0;
         for (int k = 0; k < dim; ++k) s += r[k] * r[k];
         c += huber_rho(s, dim == 3 ? O->huber_stereo : O->huber_mono, &sw);
+    }
+    for (int k = 0; k < P->n_rpc; ++k)
+    {
+        if (!rpc_valid(P, &P->rpc[k])) continue;
+        double r[6], J1[36];
+        orc_ba_rpc_linearize(pose[P->rpc[k].img1], pose[P->rpc[k].img2], &P->rpc[k], r, J1);
+        for (int a = 0; a < 6; ++a) c += r[a] * r[a];
     }
     return c;
 }
@@ -341,6 +393,37 @@ int orc_ba_solve(orc_ba_problem* P, const orc_ba_options* O, int iterations, dou
                     }
             }
         }
+        /* 1b. relative pose constraints: camera-camera terms (diagonal blocks now, cross blocks after the
+         * Schur complement of the points) */
+        for (int k = 0; k < P->n_rpc; ++k)
+        {
+            const orc_ba_rpc* q = &P->rpc[k];
+            if (!rpc_valid(P, q)) continue;
+            double r[6], J1[36];
+            orc_ba_rpc_linearize(P->pose[q->img1], P->pose[q->img2], q, r, J1);
+            const double w[6] = {q->weight_translation, q->weight_translation, q->weight_translation,
+                                 q->weight_rotation,    q->weight_rotation,    q->weight_rotation};
+            const int c1 = cam_idx[q->img1], c2 = cam_idx[q->img2];
+            if (c1 >= 0)
+                for (int a = 0; a < 6; ++a)
+                {
+                    for (int b = 0; b < 6; ++b)
+                    {
+                        double s2 = 0;
+                        for (int m = 0; m < 6; ++m) s2 += J1[m * 6 + a] * J1[m * 6 + b];
+                        U[c1 * 36 + a * 6 + b] += s2;
+                    }
+                    double g = 0;
+                    for (int m = 0; m < 6; ++m) g += J1[m * 6 + a] * r[m];
+                    bc[c1 * 6 + a] -= g;
+                }
+            if (c2 >= 0)
+                for (int a = 0; a < 6; ++a)
+                {
+                    U[c2 * 36 + a * 7] += w[a] * w[a];
+                    bc[c2 * 6 + a] -= w[a] * r[a];
+                }
+        }
         /* 2. damping */
         for (int c = 0; c < nfc; ++c)
             for (int a = 0; a < 6; ++a) U[c * 36 + a * 7] += lambda * clampd(U[c * 36 + a * 7]);
@@ -358,6 +441,24 @@ int orc_ba_solve(orc_ba_problem* P, const orc_ba_options* O, int iterations, dou
                 for (int b = 0; b < 6; ++b) S[(size_t)(c * 6 + a) * n6 + c * 6 + b] = U[c * 36 + a * 6 + b];
                 rhs[c * 6 + a] = bc[c * 6 + a];
             }
+        for (int k = 0; k < P->n_rpc; ++k)
+        {
+            const orc_ba_rpc* q = &P->rpc[k];
+            if (!rpc_valid(P, q)) continue;
+            const int c1 = cam_idx[q->img1], c2 = cam_idx[q->img2];
+            if (c1 < 0 || c2 < 0) continue;
+            double r[6], J1[36];
+            orc_ba_rpc_linearize(P->pose[q->img1], P->pose[q->img2], q, r, J1);
+            const double w[6] = {q->weight_translation, q->weight_translation, q->weight_translation,
+                                 q->weight_rotation,    q->weight_rotation,    q->weight_rotation};
+            for (int a = 0; a < 6; ++a)
+                for (int b = 0; b < 6; ++b)
+                {
+                    const double h = J1[b * 6 + a] * w[b]; /* (J1^T W)(a, b) */
+                    S[(size_t)(c1 * 6 + a) * n6 + c2 * 6 + b] += h;
+                    S[(size_t)(c2 * 6 + b) * n6 + c1 * 6 + a] += h;
+                }
+        }
         /* per point: the observations that couple it to free cameras */
         {
             int* start = (int*)calloc((size_t)np + 2, sizeof(int));

@@ -236,7 +236,12 @@ class BaProblem(C.Structure):
     _fields_ = [("n_img", C.c_int32), ("n_pt", C.c_int32), ("n_obs", C.c_int32), ("pose", C.c_void_p),
                 ("img_const", C.c_void_p), ("pt", C.c_void_p), ("pt_const", C.c_void_p), ("obs_img", C.c_void_p),
                 ("obs_pt", C.c_void_p), ("obs_uv", C.c_void_p), ("obs_depth", C.c_void_p), ("obs_weight", C.c_void_p),
-                ("obs_outlier", C.c_void_p), ("K", C.c_double * 4), ("bf", C.c_double)]
+                ("obs_outlier", C.c_void_p), ("K", C.c_double * 4), ("bf", C.c_double), ("n_rpc", C.c_int32), ("pad", C.c_int32),
+                ("rpc", C.c_void_p)]
+
+
+BA_RPC = np.dtype([("img1", "<i4"), ("img2", "<i4"), ("rel_pose", "<f8", 7), ("weight_rotation", "<f8"),
+                   ("weight_translation", "<f8")])
 
 
 def ba_options(max_iterations=3, max_pcg_iterations=30, pcg_tol=1e-10, huber_mono=2.1, huber_stereo=2.3, lambda_init=0.0):
@@ -267,7 +272,19 @@ def _ba_pack(scene, outlier=None):
     P.obs_outlier = a["obs_outlier"].ctypes.data if outlier is not None else 0
     P.K[:] = list(scene["K"])
     P.bf = float(scene["bf"])
+    a["rpc"] = np.ascontiguousarray(scene.get("rpc", np.zeros(0, BA_RPC)), BA_RPC)
+    P.n_rpc, P.pad = len(a["rpc"]), 0
+    P.rpc = a["rpc"].ctypes.data if a["rpc"].size else 0
     return P, a
+
+
+def ba_rpc_linearize(pose1, pose2, rpc):
+    """(r[6], J1[6,6]) of one relative pose constraint (d r / d delta2 = diag(w_t x3, w_r x3))."""
+    q = np.ascontiguousarray(rpc, BA_RPC).reshape(1)
+    r, J1 = np.zeros(6), np.zeros((6, 6))
+    lib().orc_ba_rpc_linearize(_p(np.ascontiguousarray(pose1, np.float64)), _p(np.ascontiguousarray(pose2, np.float64)), _p(q),
+                               _p(r), _p(J1))
+    return r, J1
 
 
 def ba_chi2(scene, outlier=None) -> np.ndarray:

@@ -114,6 +114,13 @@ typedef struct orc_ba_options
     double lambda_init; /* 0 -> 1e-4 */
 } orc_ba_options;
 
+typedef struct orc_ba_rpc /* Saiga RelPoseConstraint, LocalBundleAdjustment.cpp:294-346 */
+{
+    int32_t img1, img2;
+    double rel_pose[7]; /* T_img2 * T_img1^-1 */
+    double weight_rotation, weight_translation;
+} orc_ba_rpc;
+
 typedef struct orc_ba_problem
 {
     int32_t n_img, n_pt, n_obs;
@@ -129,9 +136,13 @@ typedef struct orc_ba_problem
     const uint8_t* obs_outlier; /* may be NULL */
     double K[4];                /* fx fy cx cy */
     double bf;
+    int32_t n_rpc;
+    int32_t pad;
+    const orc_ba_rpc* rpc;
 } orc_ba_problem;
 
 void orc_se3_update(const double* pose, const double* d, double* out);
+int orc_ba_rpc_linearize(const double* pose1, const double* pose2, const orc_ba_rpc* c, double* r, double* J1);
 void orc_ba_chi2(const orc_ba_problem* P, double* chi2);
 int orc_ba_solve(orc_ba_problem* P, const orc_ba_options* O, int iterations, double* cost_initial, double* cost_final,
                  int* pcg_iterations_total);

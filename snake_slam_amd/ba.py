@@ -23,7 +23,12 @@ class BaProblem(C.Structure):
     _fields_ = [("n_img", C.c_int32), ("n_pt", C.c_int32), ("n_obs", C.c_int32), ("pose", C.c_void_p),
                 ("img_const", C.c_void_p), ("pt", C.c_void_p), ("pt_const", C.c_void_p), ("obs_img", C.c_void_p),
                 ("obs_pt", C.c_void_p), ("obs_uv", C.c_void_p), ("obs_depth", C.c_void_p), ("obs_weight", C.c_void_p),
-                ("K", C.c_double * 4), ("bf", C.c_double)]
+                ("K", C.c_double * 4), ("bf", C.c_double), ("n_rpc", C.c_int32), ("pad", C.c_int32), ("rpc", C.c_void_p)]
+
+
+# Saiga RelPoseConstraint (IMU scenes, reference LocalBundleAdjustment.cpp:294-346)
+BA_RPC_DTYPE = np.dtype([("img1", "<i4"), ("img2", "<i4"), ("rel_pose", "<f8", 7), ("weight_rotation", "<f8"),
+                         ("weight_translation", "<f8")])
 
 
 def lba_options(max_iterations=3, max_pcg_iterations=30, pcg_tol=1e-10, huber_mono=2.1, huber_stereo=2.3, lambda_init=0.0):
@@ -49,6 +54,9 @@ def _pack(scene):
         setattr(P, k, v.ctypes.data if v.size else 0)
     P.K[:] = list(scene["K"])
     P.bf = float(scene["bf"])
+    a["rpc"] = np.ascontiguousarray(scene.get("rpc", np.zeros(0, BA_RPC_DTYPE)), BA_RPC_DTYPE)
+    P.n_rpc, P.pad = len(a["rpc"]), 0
+    P.rpc = a["rpc"].ctypes.data if a["rpc"].size else 0
     return P, a
 
 

@@ -366,6 +366,7 @@ struct Scene
     std::vector<uint8_t> obs_outlier;               // .outlier
     double K[4] = {1, 1, 0, 0};                     // intrinsics[0]
     double bf   = 0;
+    std::vector<snk_ba_rpc> rel_pose_constraints;   // scene.rel_pose_constraints (IMU), LocalBundleAdjustment.cpp:294-346
 };
 
 struct OptimizationResults
@@ -404,7 +405,9 @@ class BARec
         p.obs_depth  = scene.obs_depth.data();
         p.obs_weight = scene.obs_weight.data();
         for (int k = 0; k < 4; ++k) p.K[k] = scene.K[k];
-        p.bf = scene.bf;
+        p.bf    = scene.bf;
+        p.n_rpc = (int)scene.rel_pose_constraints.size();
+        p.rpc   = scene.rel_pose_constraints.data();
         check(snk_ba_set_problem(h_, &p), "snk_ba_set_problem");
     }
     OptimizationResults initAndSolve() { return solve(); }

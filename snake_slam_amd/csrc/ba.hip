@@ -43,6 +43,9 @@ struct Prob
     int orig_off;       // first caller-order observation of this problem
     int n_wv;           // wavefront work items of point_wave (whole points, <= 64 observations each); 0: not available
     int wv_off;
+    int n_rpc;          // valid relative pose constraints (IMU scenes)
+    int rpc_off;        // into rpc_meta / rpc_out
+    int camrpc_off;     // into cam_rpc_start (nfc + 1 entries per problem)
     int pad;
     double K[4];
     double bf;
@@ -59,6 +62,15 @@ struct State  // per problem, device resident
     double cost, cost_new, lambda, vfac, cost_initial;
     int accepted, iter, pcg_iters, pad;
 };
+
+struct RpcMeta
+{
+    int img1, img2;  // image index inside the problem
+    int c1, c2;      // free-camera index or -1
+    double rel[7];
+    double w_rot, w_trans;
+};
+constexpr int RPC_STRIDE = 72;
 
 struct Arrays
 {
@@ -81,6 +93,13 @@ struct Arrays
     const int* o_orig;             // caller-order index (global over problems)
     const int* o_pt;               // point index (inside the problem) of the observation
     const int* wv_pt;              // [n_wv + 1] per problem: first point of every point_wave work item
+    // relative pose constraints
+    const RpcMeta* rpc_meta;       // [rpc]
+    double* rpc_out;               // [rpc][RPC_STRIDE]: cost, trial cost, g1[6], g2[6], H11 upper[21], H12[36]
+    const int* cam_rpc_start;      // [nfc + 1] per problem
+    const int* cam_rpc_items;      // rpc index (inside the problem) * 2 + side (0: the camera is img1, 1: img2)
+    const int* blk_rpc;            // [nfc * nfc] per problem (at blkstart_off - problem index): 0 or 1 + (rpc * 2 + transposed)
+    const int* rpc_next;           // [rpc] chain of further constraints on the same camera pair, same encoding
     const unsigned char* outlier;  // caller order
     double* o_Jc;  // [obs][18] scaled pose Jacobian
     double* o_r;   // [obs][4]  scaled residual, [3] = dim (0: inactive in this iteration)
@@ -618,6 +637,129 @@ __device__ __forceinline__ double block_sum(double v, double* red, int tid)
     return t;
 }
 
+// ---- relative pose constraints (IMU scenes): e = log(T2 T1^-1 rel^-1), r = W e ----
+__device__ void se3_log_rel(const double* pose, const double* pred, double* e)
+{
+    const double ax = pose[0], ay = pose[1], az = pose[2], aw = pose[3];
+    const double bx = -pred[0], by = -pred[1], bz = -pred[2], bw = pred[3];
+    double q[4];
+    q[0] = aw * bx + ax * bw + ay * bz - az * by;
+    q[1] = aw * by - ax * bz + ay * bw + az * bx;
+    q[2] = aw * bz + ax * by - ay * bx + az * bw;
+    q[3] = aw * bw - ax * bx - ay * by - az * bz;
+    if (q[3] < 0.0)
+        for (int i = 0; i < 4; ++i) q[i] = -q[i];
+    double Re[9];
+    quat_to_R(q, Re);
+    const double tx = pose[4] - (Re[0] * pred[4] + Re[1] * pred[5] + Re[2] * pred[6]);
+    const double ty = pose[5] - (Re[3] * pred[4] + Re[4] * pred[5] + Re[5] * pred[6]);
+    const double tz = pose[6] - (Re[6] * pred[4] + Re[7] * pred[5] + Re[8] * pred[6]);
+    const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2], n = sqrt(n2);
+    double wx, wy, wz, cc;
+    if (n < 1e-10)
+    {
+        const double k = 2.0 / q[3];
+        wx = k * q[0]; wy = k * q[1]; wz = k * q[2];
+        cc = 1.0 / 12.0;
+    }
+    else
+    {
+        const double th = 2.0 * atan2(n, q[3]);
+        const double k  = th / n;
+        wx = k * q[0]; wy = k * q[1]; wz = k * q[2];
+        if (th < 1e-4)
+            cc = 1.0 / 12.0 + th * th / 720.0;
+        else
+            cc = (1.0 - (th * sin(th)) / (2.0 * (1.0 - cos(th)))) / (th * th);
+    }
+    const double c1x = wy * tz - wz * ty, c1y = wz * tx - wx * tz, c1z = wx * ty - wy * tx;
+    const double c2x = wy * c1z - wz * c1y, c2y = wz * c1x - wx * c1z, c2z = wx * c1y - wy * c1x;
+    e[0] = tx - 0.5 * c1x + cc * c2x;
+    e[1] = ty - 0.5 * c1y + cc * c2y;
+    e[2] = tz - 0.5 * c1z + cc * c2z;
+    e[3] = wx; e[4] = wy; e[5] = wz;
+}
+
+// r (6) and J1 = d r / d delta1 (6x6 row-major); d r / d delta2 = W
+__device__ void rpc_linearize(const double* pose1, const double* pose2, const RpcMeta& c, double* r, double* J1)
+{
+    double T21[7], R21[9];
+    {
+        const double ax = pose2[0], ay = pose2[1], az = pose2[2], aw = pose2[3];
+        const double bx = -pose1[0], by = -pose1[1], bz = -pose1[2], bw = pose1[3];
+        T21[0] = aw * bx + ax * bw + ay * bz - az * by;
+        T21[1] = aw * by - ax * bz + ay * bw + az * bx;
+        T21[2] = aw * bz + ax * by - ay * bx + az * bw;
+        T21[3] = aw * bw - ax * bx - ay * by - az * bz;
+    }
+    quat_to_R(T21, R21);
+    T21[4] = pose2[4] - (R21[0] * pose1[4] + R21[1] * pose1[5] + R21[2] * pose1[6]);
+    T21[5] = pose2[5] - (R21[3] * pose1[4] + R21[4] * pose1[5] + R21[5] * pose1[6]);
+    T21[6] = pose2[6] - (R21[6] * pose1[4] + R21[7] * pose1[5] + R21[8] * pose1[6]);
+    double e[6];
+    se3_log_rel(T21, c.rel, e);
+    const double wt = c.w_trans, wr = c.w_rot;
+    for (int a = 0; a < 3; ++a)
+    {
+        r[a]     = wt * e[a];
+        r[3 + a] = wr * e[3 + a];
+    }
+    const double tx = T21[4], ty = T21[5], tz = T21[6];
+    const double K[9] = {0, -tz, ty, tz, 0, -tx, -ty, tx, 0};
+    double KR[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) KR[i * 3 + j] = K[i * 3] * R21[j] + K[i * 3 + 1] * R21[3 + j] + K[i * 3 + 2] * R21[6 + j];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+        {
+            J1[i * 6 + j]           = -wt * R21[i * 3 + j];
+            J1[i * 6 + 3 + j]       = -wt * KR[i * 3 + j];
+            J1[(3 + i) * 6 + j]     = 0.0;
+            J1[(3 + i) * 6 + 3 + j] = -wr * R21[i * 3 + j];
+        }
+}
+
+// one thread per constraint.  trial == 0: residual, cost and the normal-equation terms at the current poses;
+// trial == 1: cost at the trial poses.
+__global__ __launch_bounds__(64) void rpc_pass(Arrays A, int trial)
+{
+    const int pb  = blockIdx.y;
+    const Prob pr = A.prob[pb];
+    const int k   = blockIdx.x * 64 + threadIdx.x;
+    if (k >= pr.n_rpc) return;
+    const RpcMeta m = A.rpc_meta[pr.rpc_off + k];
+    const double* P = (trial ? A.pose_new : A.pose) + (size_t)pr.img_off * 7;
+    double r[6], J1[36];
+    rpc_linearize(P + (size_t)m.img1 * 7, P + (size_t)m.img2 * 7, m, r, J1);
+    double cost = 0.0;
+    for (int a = 0; a < 6; ++a) cost += r[a] * r[a];
+    double* o = A.rpc_out + (size_t)(pr.rpc_off + k) * RPC_STRIDE;
+    if (trial)
+    {
+        o[1] = cost;
+        return;
+    }
+    o[0] = cost;
+    const double w[6] = {m.w_trans, m.w_trans, m.w_trans, m.w_rot, m.w_rot, m.w_rot};
+    for (int a = 0; a < 6; ++a)
+    {
+        double g = 0.0;
+        for (int q = 0; q < 6; ++q) g += J1[q * 6 + a] * r[q];
+        o[2 + a] = -g;            // b1 = -J1^T r
+        o[8 + a] = -(w[a] * r[a]);  // b2 = -W r
+    }
+    int u = 14;
+    for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b)
+        {
+            double s2 = 0.0;
+            for (int q = 0; q < 6; ++q) s2 += J1[q * 6 + a] * J1[q * 6 + b];
+            o[u++] = s2;  // H11 upper
+        }
+    for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) o[35 + a * 6 + b] = J1[b * 6 + a] * w[b];  // H12 = J1^T W
+}
+
 constexpr int CAM_THREADS = 256;
 __global__ __launch_bounds__(CAM_THREADS) void cam_pass(Arrays A)
 {
@@ -671,6 +813,32 @@ __global__ __launch_bounds__(CAM_THREADS) void cam_pass(Arrays A)
     {
         double tot[33];
         for (int k = 0; k < 33; ++k) tot[k] = ((part[0][k] + part[1][k]) + part[2][k]) + part[3][k];
+        if (pr.n_rpc > 0)  // relative pose constraints incident to this camera (fixed order)
+        {
+            const int r0 = A.cam_rpc_start[pr.camrpc_off + c], r1 = A.cam_rpc_start[pr.camrpc_off + c + 1];
+            for (int q = r0; q < r1; ++q)
+            {
+                const int item  = A.cam_rpc_items[q];
+                const int k     = item >> 1;
+                const double* o = A.rpc_out + (size_t)(pr.rpc_off + k) * RPC_STRIDE;
+                if ((item & 1) == 0)
+                {
+                    for (int u = 0; u < 21; ++u) tot[u] += o[14 + u];
+                    for (int a = 0; a < 6; ++a) tot[21 + a] += o[2 + a];
+                }
+                else
+                {
+                    const RpcMeta m = A.rpc_meta[pr.rpc_off + k];
+                    const double w2[6] = {m.w_trans * m.w_trans, m.w_trans * m.w_trans, m.w_trans * m.w_trans,
+                                          m.w_rot * m.w_rot,     m.w_rot * m.w_rot,     m.w_rot * m.w_rot};
+                    int u = 0;
+                    for (int a = 0; a < 6; ++a)
+                        for (int b = a; b < 6; ++b, ++u)
+                            if (a == b) tot[u] += w2[a];
+                    for (int a = 0; a < 6; ++a) tot[21 + a] += o[8 + a];
+                }
+            }
+        }
         const double lambda = A.state[pb].lambda;
         double* U = A.U + (size_t)(pr.cam_off + c) * 36;
         int q = 0;
@@ -784,6 +952,18 @@ __global__ __launch_bounds__(256) void schur_pass(Arrays A, int zero_rows, int n
         }
         else
         {
+            if (pr.n_rpc > 0)  // camera-camera terms J(c1)^T J(c2) of the relative pose constraints of this pair
+            {
+                int code = A.blk_rpc[pr.blkstart_off - pb + blk];
+                while (code != 0)
+                {
+                    const int k = (code - 1) >> 1, tr = (code - 1) & 1;
+                    const double* H = A.rpc_out + (size_t)(pr.rpc_off + k) * RPC_STRIDE + 35;
+                    for (int r = 0; r < 6; ++r)
+                        for (int c = 0; c < 6; ++c) acc[r * 6 + c] -= tr ? H[c * 6 + r] : H[r * 6 + c];
+                    code = A.rpc_next[pr.rpc_off + k];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -1280,8 +1460,14 @@ __global__ __launch_bounds__(ACC_THREADS) void accept_pass(Arrays A)
             c1 += A.cost_pt_new[pr.pt_off + p];
         }
     }
-    const double cost     = block_sum<ACC_THREADS>(c0, red, tid);
-    const double cost_new = block_sum<ACC_THREADS>(c1, red, tid);
+    double cost     = block_sum<ACC_THREADS>(c0, red, tid);
+    double cost_new = block_sum<ACC_THREADS>(c1, red, tid);
+    for (int k = 0; k < pr.n_rpc; ++k)  // few (<= one per keyframe pair), fixed order, same value in every thread
+    {
+        const double* o = A.rpc_out + (size_t)(pr.rpc_off + k) * RPC_STRIDE;
+        cost += o[0];
+        cost_new += o[1];
+    }
     State& st = A.state[pb];
     if (tid == 0)
     {
@@ -1335,7 +1521,8 @@ struct snk_ba : HandleBase
     int max_np = 0, max_nfc = 0, max_n6 = 0, max_ni = 0;
     DevBuf d_prob, d_state, d_pose, d_pose_new, d_pose0, d_pt, d_pt_new, d_pt0, d_ptc, d_camidx, d_ptstart, d_oimg, d_ocam,
         d_optfree, d_ouv, d_odepth, d_oweight, d_oorig, d_outlier, d_Jc, d_r, d_W, d_Y, d_yb, d_Vinv, d_bp, d_cost,
-        d_cost_new, d_U, d_camstart, d_camitems, d_blkstart, d_blkent, d_S, d_rhs, d_x, d_chi2, d_pcgw, d_optidx, d_wvpt;
+        d_cost_new, d_U, d_camstart, d_camitems, d_blkstart, d_blkent, d_S, d_rhs, d_x, d_chi2, d_pcgw, d_optidx, d_wvpt, d_rpcmeta, d_rpcnext, d_camrpcstart, d_camrpcitems, d_blkrpc, d_rpcout;
+    int max_rpc = 0;
     int max_wv = 0;
     bool point_wave_ok = false;  // every problem has a point_wave work list (no point with > 64 observations)
     PcgLarge pcgw{};     // work arrays of the multi-workgroup PCG (only when the reduced system exceeds the LDS)
@@ -1428,7 +1615,10 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     std::vector<Prob> probs((size_t)count);
     std::vector<double> pose, pt, ouv2, odepth, oweight;
     std::vector<unsigned char> ptc, optfree;
-    std::vector<int> camidx, ptstart, oimg, ocam, oorig, camstart, camitems, blkstart, optidx, wvpt;
+    std::vector<int> camidx, ptstart, oimg, ocam, oorig, camstart, camitems, blkstart, optidx, wvpt, rpcnext, camrpcstart,
+        camrpcitems, blkrpc;
+    std::vector<RpcMeta> rpcmeta;
+    int max_rpc = 0;
     int max_wv = 0;
     bool wave_ok = true;
     std::vector<int4> blkent;
@@ -1445,6 +1635,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         SNK_REQUIRE(P.n_img == 0 || (P.pose && P.img_const), "NULL pose arrays");
         SNK_REQUIRE(P.n_pt == 0 || (P.pt && P.pt_const), "NULL point arrays");
         SNK_REQUIRE(P.n_obs == 0 || (P.obs_img && P.obs_pt && P.obs_uv && P.obs_depth && P.obs_weight), "NULL observation arrays");
+        SNK_REQUIRE(P.n_rpc >= 0 && (P.n_rpc == 0 || P.rpc != nullptr), "bad relative pose constraints");
         Prob& pr = probs[(size_t)b];
         memset(&pr, 0, sizeof(pr));
         pr.ni = P.n_img;
@@ -1597,6 +1788,53 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             blkstart.insert(blkstart.end(), bs.begin(), bs.end());
             blkent.insert(blkent.end(), ent.begin(), ent.end());
         }
+        // relative pose constraints (IMU scenes): valid ones, per-camera incidence, per-block chains
+        {
+            pr.rpc_off    = (int)rpcmeta.size();
+            pr.camrpc_off = (int)camrpcstart.size();
+            std::vector<int> cs((size_t)nfc + 1, 0);
+            std::vector<RpcMeta> mine;
+            for (int k = 0; k < P.n_rpc; ++k)
+            {
+                const snk_ba_rpc& q = P.rpc[k];
+                if (q.img1 < 0 || q.img2 < 0 || q.img1 >= P.n_img || q.img2 >= P.n_img || q.img1 == q.img2) continue;
+                if (P.img_const[q.img1] && P.img_const[q.img2]) continue;
+                SNK_REQUIRE(q.weight_rotation >= 0.0 && q.weight_translation >= 0.0, "negative constraint weight");
+                RpcMeta m;
+                m.img1 = q.img1; m.img2 = q.img2;
+                m.c1 = cidx[(size_t)q.img1]; m.c2 = cidx[(size_t)q.img2];
+                for (int t = 0; t < 7; ++t) m.rel[t] = q.rel_pose[t];
+                m.w_rot = q.weight_rotation; m.w_trans = q.weight_translation;
+                mine.push_back(m);
+                if (m.c1 >= 0) cs[(size_t)m.c1 + 1]++;
+                if (m.c2 >= 0) cs[(size_t)m.c2 + 1]++;
+            }
+            pr.n_rpc = (int)mine.size();
+            max_rpc  = std::max(max_rpc, pr.n_rpc);
+            for (int c = 0; c < nfc; ++c) cs[(size_t)c + 1] += cs[(size_t)c];
+            const int item_base = (int)camrpcitems.size();
+            std::vector<int> items((size_t)cs[(size_t)nfc]), fill(cs.begin(), cs.end() - 1);
+            std::vector<int> brpc((size_t)nfc * nfc, 0), nxt(mine.size(), 0);
+            for (int k = 0; k < (int)mine.size(); ++k)
+            {
+                const RpcMeta& m = mine[(size_t)k];
+                if (m.c1 >= 0) items[(size_t)fill[(size_t)m.c1]++] = k * 2;
+                if (m.c2 >= 0) items[(size_t)fill[(size_t)m.c2]++] = k * 2 + 1;
+                if (m.c1 >= 0 && m.c2 >= 0)
+                {
+                    // the upper block (lo, hi) holds J(lo)^T J(hi): H12 when img1 is `lo`, its transpose otherwise
+                    const int lo = std::min(m.c1, m.c2), hi = std::max(m.c1, m.c2);
+                    const int code = 1 + (k * 2 + (m.c1 == lo ? 0 : 1));
+                    nxt[(size_t)k]                 = brpc[(size_t)lo * nfc + hi];
+                    brpc[(size_t)lo * nfc + hi] = code;
+                }
+            }
+            for (int c = 0; c <= nfc; ++c) camrpcstart.push_back(item_base + cs[(size_t)c]);
+            camrpcitems.insert(camrpcitems.end(), items.begin(), items.end());
+            blkrpc.insert(blkrpc.end(), brpc.begin(), brpc.end());
+            rpcnext.insert(rpcnext.end(), nxt.begin(), nxt.end());
+            rpcmeta.insert(rpcmeta.end(), mine.begin(), mine.end());
+        }
         img_off += P.n_img;
         pt_off += P.n_pt;
         obs_off += no;
@@ -1619,6 +1857,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     h->tot_vec = vec_off; h->tot_s = s_off;
     h->max_np = max_np; h->max_nfc = max_nfc; h->max_n6 = max_n6; h->max_ni = max_ni;
     h->max_wv = max_wv;
+    h->max_rpc = max_rpc;
     h->point_wave_ok = wave_ok && max_wv > 0;
 
     int rc;
@@ -1645,6 +1884,11 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     UP(d_blkent, blkent);
     UP(d_optidx, optidx);
     UP(d_wvpt, wvpt);
+    UP(d_rpcmeta, rpcmeta);
+    UP(d_rpcnext, rpcnext);
+    UP(d_camrpcstart, camrpcstart);
+    UP(d_camrpcitems, camrpcitems);
+    UP(d_blkrpc, blkrpc);
 #undef UP
     const size_t nobs = (size_t)std::max(obs_off, 1), npt = (size_t)std::max(pt_off, 1);
 #define RS(buf, bytes) if ((rc = h->buf.reserve(bytes)) != SNK_OK) return rc
@@ -1665,6 +1909,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     RS(d_S, (size_t)std::max<long long>(s_off, 1) * 8);
     RS(d_rhs, (size_t)std::max(vec_off, 1) * 8);
     RS(d_x, (size_t)std::max(vec_off, 1) * 8);
+    RS(d_rpcout, std::max<size_t>(rpcmeta.size(), 1) * RPC_STRIDE * 8);
     if (h->pcg_large)
     {
         PcgLarge& W = h->pcgw;
@@ -1717,6 +1962,12 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     A.o_orig    = h->d_oorig.as<int>();
     A.o_pt      = h->d_optidx.as<int>();
     A.wv_pt     = h->d_wvpt.as<int>();
+    A.rpc_meta  = h->d_rpcmeta.as<RpcMeta>();
+    A.rpc_out   = h->d_rpcout.as<double>();
+    A.cam_rpc_start = h->d_camrpcstart.as<int>();
+    A.cam_rpc_items = h->d_camrpcitems.as<int>();
+    A.blk_rpc   = h->d_blkrpc.as<int>();
+    A.rpc_next  = h->d_rpcnext.as<int>();
     A.outlier   = h->d_outlier.as<unsigned char>();
     A.o_Jc      = h->d_Jc.as<double>();
     A.o_r       = h->d_r.as<double>();
@@ -1791,6 +2042,7 @@ static int enqueue_lm(snk_ba* h, int iterations)
             hipLaunchKernelGGL(point_pass<0>, gpt, dim3(128), 0, st, A, O);
         if (h->max_nfc > 0)
         {
+            if (h->max_rpc > 0) hipLaunchKernelGGL(rpc_pass, dim3(ceil_div(h->max_rpc, 64), B), dim3(64), 0, st, A, 0);
             hipLaunchKernelGGL(cam_pass, dim3(h->max_nfc, B), dim3(CAM_THREADS), 0, st, A);
             {
                 const int nbx = ceil_div(h->max_nfc * h->max_nfc, 4);
@@ -1827,6 +2079,7 @@ static int enqueue_lm(snk_ba* h, int iterations)
             hipLaunchKernelGGL(update_pass, dim3(std::max(1, ceil_div(h->max_np + h->max_ni, 128)), B), dim3(128), 0, st, A, 0);
             hipLaunchKernelGGL(point_pass<1>, gpt, dim3(128), 0, st, A, O);
         }
+        if (h->max_rpc > 0 && h->max_nfc > 0) hipLaunchKernelGGL(rpc_pass, dim3(ceil_div(h->max_rpc, 64), B), dim3(64), 0, st, A, 1);
         hipLaunchKernelGGL(accept_pass, dim3(B), dim3(ACC_THREADS), 0, st, A);
         SNK_LAUNCH_CHECK();
     }

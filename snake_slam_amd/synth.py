@@ -129,6 +129,28 @@ def ba_scene(n_kf: int = 20, n_pt: int = 2000, obs_per_pt: int = 8, seed: int = 
     return scene, dict(pose=gt_pose, pt=pts)
 
 
+def ba_add_rpcs(scene, gt, seed: int = 0, weight_rotation: float = 30.0, weight_translation: float = 8.0,
+                noise_rot: float = 2e-3, noise_trans: float = 5e-3):
+    """Relative pose constraints between consecutive keyframes (what MakeLocalScene adds from the IMU
+    pre-integration, reference LocalBundleAdjustment.cpp:294-346): rel_pose = T_{i+1} T_i^-1 of the ground
+    truth with a little noise.  Adds scene["rpc"] in place and returns the scene."""
+    rng = np.random.default_rng(seed)
+    dt = np.dtype([("img1", "<i4"), ("img2", "<i4"), ("rel_pose", "<f8", 7), ("weight_rotation", "<f8"),
+                   ("weight_translation", "<f8")])
+    n = len(gt["pose"])
+    rp = np.zeros(max(n - 1, 0), dt)
+    for i in range(n - 1):
+        R1, t1 = quat_to_R(gt["pose"][i][:4]), gt["pose"][i][4:]
+        R2, t2 = quat_to_R(gt["pose"][i + 1][:4]), gt["pose"][i + 1][4:]
+        R21 = _rot(rng.normal(size=3), noise_rot * rng.uniform(0.2, 1.0)) @ R2 @ R1.T
+        t21 = t2 - R2 @ R1.T @ t1 + rng.normal(0, noise_trans / np.sqrt(3), 3)
+        rp[i]["img1"], rp[i]["img2"] = i, i + 1
+        rp[i]["rel_pose"] = np.concatenate([_quat_from_R(R21), t21])
+        rp[i]["weight_rotation"], rp[i]["weight_translation"] = weight_rotation, weight_translation
+    scene["rpc"] = rp
+    return scene
+
+
 # ------------------------------------------------------------------ pose refinement ------------
 POSE_CAM = (458.654, 457.296, 367.215, 248.375, 47.9)  # fx fy cx cy bf (EuRoC-like, SURVEY.md §8d)
 

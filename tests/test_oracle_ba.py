@@ -100,3 +100,92 @@ def test_benchmark_scene_shape(orc):
     _, pt, c0, c1, _ = orc.ba_solve(sc, orc.ba_options())
     assert c1 < 0.05 * c0
     assert np.sqrt(((pt - gt["pt"]) ** 2).sum(1).mean()) < np.sqrt(((sc["pt"] - gt["pt"]) ** 2).sum(1).mean())
+
+
+# ------------------------------------------------------------------ relative pose constraints ---
+def _rpc_residual_numpy(p1, p2, rpc):
+    """Independent restatement: r = W * log(T2 T1^-1 rel^-1) with scipy's matrix logarithm."""
+    from scipy.linalg import logm
+
+    def mat(p):
+        T = np.eye(4)
+        T[:3, :3] = ba_numpy.quat_R(p[:4])
+        T[:3, 3] = p[4:]
+        return T
+
+    E = mat(p2) @ np.linalg.inv(mat(p1)) @ np.linalg.inv(mat(rpc["rel_pose"]))
+    L = np.real(logm(E))
+    e = np.array([L[0, 3], L[1, 3], L[2, 3], L[2, 1], L[0, 2], L[1, 0]])
+    w = np.array([rpc["weight_translation"]] * 3 + [rpc["weight_rotation"]] * 3)
+    return w * e
+
+
+def _se3_update(orc, pose, d):
+    import ctypes as C
+
+    pose = np.ascontiguousarray(pose, np.float64)
+    d = np.ascontiguousarray(d, np.float64)
+    out = np.zeros(7)
+    orc.lib().orc_se3_update(C.c_void_p(pose.ctypes.data), C.c_void_p(d.ctypes.data), C.c_void_p(out.ctypes.data))
+    return out
+
+
+def test_rpc_residual_and_jacobians(orc):
+    """r matches the matrix logarithm; J1 / J2 = W match finite differences of left perturbations to first
+    order (the definition drops J_l^-1(e), so the check is made at a small residual)."""
+    from snake_slam_amd import synth
+
+    sc, gt = synth.ba_scene(n_kf=5, n_pt=20, obs_per_pt=3, seed=3)
+    synth.ba_add_rpcs(sc, gt, seed=4, noise_rot=1e-4, noise_trans=1e-4)
+    rng = np.random.default_rng(5)
+    for k in range(4):
+        q = sc["rpc"][k]
+        p1, p2 = gt["pose"][q["img1"]], gt["pose"][q["img2"]]
+        r, J1 = orc.ba_rpc_linearize(p1, p2, q)
+        assert np.allclose(r, _rpc_residual_numpy(p1, p2, q), atol=1e-10)
+        w = np.array([q["weight_translation"]] * 3 + [q["weight_rotation"]] * 3)
+        h = 1e-6
+        for a in range(6):
+            d = np.zeros(6)
+            d[a] = h
+            r1, _ = orc.ba_rpc_linearize(_se3_update(orc, p1, d), p2, q)
+            r2, _ = orc.ba_rpc_linearize(p1, _se3_update(orc, p2, d), q)
+            assert np.allclose((r1 - r) / h, J1[:, a], atol=2e-2 * np.abs(J1).max())
+            e = np.zeros(6)
+            e[a] = w[a]
+            assert np.allclose((r2 - r) / h, e, atol=2e-2 * w.max())
+    # far from the constraint the residual is still exact
+    p1, p2 = sc["pose"][1], sc["pose"][3]
+    r, _ = orc.ba_rpc_linearize(p1, p2, sc["rpc"][0])
+    assert np.allclose(r, _rpc_residual_numpy(p1, p2, sc["rpc"][0]), atol=1e-9)
+    assert rng is not None
+
+
+def test_rpc_terms_enter_cost_and_solution(orc):
+    from snake_slam_amd import synth
+
+    sc, gt = synth.ba_scene(n_kf=8, n_pt=200, obs_per_pt=4, seed=21)
+    pose_a, pt_a, ci_a, cf_a, _ = orc.ba_solve(sc, orc.ba_options())
+    synth.ba_add_rpcs(sc, gt, seed=22)
+    pose_b, pt_b, ci_b, cf_b, _ = orc.ba_solve(sc, orc.ba_options())
+    extra = sum(float(_rpc_residual_numpy(sc["pose"][q["img1"]], sc["pose"][q["img2"]], q) @
+                      _rpc_residual_numpy(sc["pose"][q["img1"]], sc["pose"][q["img2"]], q)) for q in sc["rpc"])
+    assert abs((ci_b - ci_a) - extra) <= 1e-9 * max(1.0, extra) and extra > 0
+    assert cf_b < ci_b
+    # very stiff exact constraints pin the relative poses of the free cameras
+    sc2, gt2 = synth.ba_scene(n_kf=6, n_pt=150, obs_per_pt=4, seed=23)
+    synth.ba_add_rpcs(sc2, gt2, seed=24, weight_rotation=3e3, weight_translation=3e3, noise_rot=0.0, noise_trans=0.0)
+    pose_c, _, ci_c, cf_c, _ = orc.ba_solve(sc2, orc.ba_options(max_iterations=6))
+    for q in sc2["rpc"]:
+        r = _rpc_residual_numpy(pose_c[q["img1"]], pose_c[q["img2"]], q) / 3e3
+        assert np.abs(r).max() < 2e-4
+    # constraints between constant images or with bad indices are ignored
+    sc3, gt3 = synth.ba_scene(n_kf=5, n_pt=60, obs_per_pt=3, seed=25, n_fixed=2)
+    base = orc.ba_solve(sc3, orc.ba_options())
+    synth.ba_add_rpcs(sc3, gt3, seed=26)
+    sc3["rpc"] = sc3["rpc"][:1].copy()          # images 0 and 1: both constant
+    bad = sc3["rpc"].copy()
+    bad["img2"] = 99
+    sc3["rpc"] = np.concatenate([sc3["rpc"], bad])
+    again = orc.ba_solve(sc3, orc.ba_options())
+    assert np.array_equal(base[0], again[0]) and base[2] == again[2] and base[3] == again[3]
