@@ -72,7 +72,7 @@ def cpu_baseline(frames, seconds_budget=12.0):
         if el >= seconds_budget or done >= 2000:
             break
     return {"value": round(done / el, 3), "unit": "frames/s", "cores": 4, "kind": "port",
-            "sample": f"{done} stereo frames 752x480 (extract L+R with 2 threads, rectify, stereo match, "
+            "sample": f"{done} stereo frames {W}x{H} (extract L+R with 2 threads, rectify, stereo match, "
                       f"BF kNN-2 with 4 threads + filter) in {el:.1f} s; CPU restatement of the reference path, not the reference binary"}
 
 
@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="stereo frames per GPU per step")
     ap.add_argument("--ba-windows", type=int, default=256, help="independent local-BA windows per GPU per step (0 = skip)")
+    ap.add_argument("--workload", choices=["euroc", "kitti"], default="euroc",
+                    help="euroc = BASELINE.json's metric config (752x480, 1000 features, 4 levels); kitti = configs[2] "
+                         "(1241x376, 2000 features, 7 levels), an extra measured case")
     ap.add_argument("--orb-chains", type=int, default=1, help="launch chains per ORB batch (2 = two half batches on two streams, +3 %%; "
                     "per-kernel timings then overlap)")
     ap.add_argument("--gba-keyframes", type=int, default=300, help="keyframes of the global-BA leg (0 = skip; single GPU only)")
@@ -107,6 +110,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events")
     args = ap.parse_args()
+    global W, H, ORB
+    if args.workload == "kitti":  # reference configs/kitti.ini:30-34
+        W, H = 1241, 376
+        ORB = dict(nfeatures=2000, scale_factor=1.2, n_levels=7, ini_th_fast=20, min_th_fast=7)
 
     import torch
 
@@ -127,7 +134,7 @@ def main():
     B = args.batch
     # ---- synthetic frames (seeded; a few distinct pairs tiled over the batch), resident in HBM ----
     frames = [synth.stereo_frame(rank * N_DISTINCT + i, W, H) for i in range(N_DISTINCT)]
-    pitch = 768
+    pitch = (W + 63) & ~63
     host = np.zeros((2 * B, H, pitch), np.uint8)  # [0,B): left images, [B,2B): right images
     for b in range(B):
         l, r = frames[b % N_DISTINCT]
@@ -145,7 +152,7 @@ def main():
     pre = Preprocess(local, sh)
     bf = BruteForceMatcher(local, sh)
     grid = FeatureGrid(local, sh)
-    GRID_BOUNDS = (0.0, 0.0, float(W), float(H))  # featureGridBounds of an undistorted 752x480 image
+    GRID_BOUNDS = (0.0, 0.0, float(W), float(H))  # featureGridBounds of the undistorted image
     n_cells = int(np.ceil(W / 20.0)) * int(np.ceil(H / 20.0))
     rect = Rectification.make((1.0, 1.0, 0.0, 0.0))  # synthetic pairs are already rectified
     level_scale = (np.float32(ORB["scale_factor"]) ** np.arange(ORB["n_levels"])).astype(np.float32)
@@ -302,7 +309,7 @@ def main():
         value = total_frames / elapsed
         P = pyramid_pixels()
         out = {
-            "metric": "frames/s ORB extract+match @752x480",
+            "metric": f"frames/s ORB extract+match @{W}x{H}",
             "value": round(value, 2),
             "unit": "frames/s",
             "n_gpus": world,
@@ -313,8 +320,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": f"synthetic: seeded 752x480 stereo pairs (gradient + 400 rectangles + noise), {N_DISTINCT} distinct pairs tiled over the batch, resident in HBM",
-            "config": {"workload": "EuRoC stereo 752x480: ORB extract (L+R, 1000 feat, 4 levels) + stereo row-band match + BF kNN-2 Hamming match",
+            "data": f"synthetic: seeded {W}x{H} stereo pairs (gradient + 400 rectangles + noise), {N_DISTINCT} distinct pairs tiled over the batch, resident in HBM",
+            "config": {"workload": ("EuRoC" if args.workload == "euroc" else "KITTI") + f" stereo {W}x{H}: ORB extract (L+R, {ORB['nfeatures']} feat, {ORB['n_levels']} levels) + stereo row-band match + BF kNN-2 Hamming match",
                        "frames_per_gpu_per_step": B, "images_per_frame": 2, "orb": ORB,
                        "parallelism": f"{world} x independent batches (one per GPU), RCCL all_gather of results only"},
             "keypoints_per_image": round(float(blocks[0][1].item()) / (2 * B), 1),
