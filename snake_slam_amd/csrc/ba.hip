@@ -13,14 +13,21 @@
 // lists, no floating-point atomics; (3) many windows per launch (blockIdx.y = problem) so that
 // disjoint keyframe windows / sequences fill the 256 CUs.
 //
-//   point_pass<0> thread per point : residuals + Jacobians of its observations, V, b_p, W, damping,
-//                                    V^-1, Y = W V^-1, Y b_p, robust cost of the point
-//   cam_pass      workgroup per free camera : U, b_c, rhs = b_c - sum Y b_p (fixed-order tree sums)
-//   schur_pass    36 threads per camera-pair block : S = U - sum Y W^T over the co-observations
-//   pcg_solve     one workgroup per problem : block-Jacobi PCG, vectors in LDS, S streamed from L2
-//   update_pass   thread per point / camera : back-substitution, trial points and poses (SE3 exp)
-//   point_pass<1> thread per point : robust cost at the trial state
+//   point_wave    wavefront per <= 64 observations of whole points : lane = observation (residual,
+//                 Jacobians, W; rows leave through an LDS transpose as full lines), lane = point (V, b_p,
+//                 damping, V^-1, cost).  point_pass<0> (thread per point) is the fallback for points with
+//                 more than 64 observations
+//   rpc_pass      thread per relative pose constraint (IMU scenes) : cost, -J^T r, J1^T J1, J1^T W
+//   cam_pass      workgroup per free camera : U, b_c, rhs = b_c - sum Y b_p (+ constraint terms), fixed-order sums
+//   schur_pass    wavefront per upper camera-pair block : S = U - sum (W V^-1) W^T over the co-observations
+//                 (+ constraint cross blocks); XCD-per-window launch for batches
+//   pcg_solve     one workgroup per problem : block-Jacobi PCG, vectors (and S when it fits) in LDS
+//   pcgl_*        multi-workgroup PCG for reduced systems beyond the LDS (global BA): vectors in HBM,
+//                 (row chunk x column part) matvec, fixed-order partial sums, 5 launches per iteration
+//   update_wave / update_pass : back-substitution of the points / trial poses (SE3 exp)
+//   cost_wave     robust cost at the trial state (point_pass<1> as fallback); rpc_pass(trial) for constraints
 //   accept_pass   one workgroup per problem : fixed-order cost sums, accept / reject, lambda schedule
+//   point_pass<2> chi-square per caller observation (snk_ba_residuals)
 #include "common.hpp"
 
 #include <algorithm>
