@@ -6,19 +6,21 @@
 // built with -ffp-contract=off, so the few float expressions below round exactly like their
 // scalar restatement.
 //
-// Pipeline (all kernels batched over B images, blockIdx.y/z = image):
-//   level_kernel       one streaming pass per level (L launches): a wavefront walks down a 248-px column
+// Pipeline (all kernels batched over B images; level / FAST / describe run on XCD-aware 1-D grids so that
+// an image's whole chain stays on one XCD's L2; a batch can be split into launch chains on two streams):
+//   level_kernel       one streaming pass per level (L launches): a wavefront walks down a <= 244-px column
 //                      strip with the 7-row window in registers; 7x7 Gaussian of level l (v_alignbyte +
-//                      v_dot4_u32_u8) and the 11-bit fixed-point bilinear down-scale to level l+1
-//   fast_kernel        one workgroup per ~30x30 FAST cell: image tile -> LDS (aligned dwords), quick
-//                      opposite-pair bound on every pixel, compaction, exact FAST-9/16 score of the
+//                      v_dot4_u32_u8 + v_dot2_u32_u16) and the 11-bit fixed-point bilinear down-scale to
+//                      level l+1 in the same pass (resize_kernel when scale > 2 or the level is < 8 px)
+//   fast_kernel        one WAVEFRONT per ~30x30 FAST cell: image tile -> its LDS slice (aligned dwords),
+//                      quick opposite-pair bound on every pixel, compaction, exact FAST-9/16 score of the
 //                      survivors in packed 16-bit lanes, in-cell 3x3 NMS, ini/min threshold fallback,
 //                      candidates ranked by strength
 //   distribute_kernel  one workgroup per (image, level): quadtree distribution on sorted
 //                      subdivision keys (bitonic sort in LDS + histogram of common-prefix lengths)
-//   describe_kernel    one wavefront per keypoint: integer IC moments from the raw level,
-//                      polynomial atan2, 256 steered BRIEF tests gathered from the blurred level,
-//                      4 ballots assemble the 256-bit descriptor
+//   describe_kernel    one wavefront per 4 keypoints, all loads issued up front: integer IC moments
+//                      (v_dot4 against a disc table), polynomial atan2, 256 steered BRIEF tests read from an
+//                      LDS copy of the blurred patch, 4 ballots assemble the 256-bit descriptor
 #include "common.hpp"
 
 #include <array>
