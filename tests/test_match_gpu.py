@@ -25,7 +25,8 @@ def st():
     m.close()
 
 
-@pytest.mark.parametrize("nq,nt", [(1, 1), (5, 0), (7, 1), (3, 2), (64, 64), (65, 63), (1000, 1000), (2000, 2000), (1500, 777)])
+@pytest.mark.parametrize("nq,nt", [(1, 1), (5, 0), (7, 1), (3, 2), (64, 64), (65, 63), (1000, 1000), (2000, 2000), (1500, 777),
+                                   (6000, 9001)])
 def test_bf_knn2_parity(bf, orc, nq, nt):
     rng = np.random.default_rng(SEED + nq * 7 + nt)
     q, t = rand_desc(rng, nq), rand_desc(rng, nt)
@@ -98,7 +99,8 @@ def test_bf_batch_dev_parity(bf, orc):
         assert np.array_equal(pairs_h[b, : np_h[b]], wp)
 
 
-@pytest.mark.parametrize("nl,nr,relaxed", [(1000, 1000, True), (1000, 1000, False), (257, 63, True), (5, 2000, True), (300, 1, True)])
+@pytest.mark.parametrize("nl,nr,relaxed", [(1000, 1000, True), (1000, 1000, False), (257, 63, True), (5, 2000, True), (300, 1, True),
+                                           (500, 8192, True), (400, 9000, True)])  # 9000 > the LDS row index: unindexed kernel
 def test_stereo_parity(st, orc, nl, nr, relaxed):
     rng = np.random.default_rng(SEED + nl + nr)
     left, dl, right, dr, bfv, ls = make_stereo_case(rng, nl, nr)
