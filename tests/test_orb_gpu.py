@@ -156,6 +156,16 @@ def test_random_shapes_and_parameters(orc):
                     stages=(k < 4))
 
 
+def test_large_image(orc):
+    """A 2000 x 1500 image with 5000 features and 8 levels: 9 strips x 24 bands at level 0, ~3300 FAST cells,
+    levels above the 2048-candidate LDS carve of the distribution kernel."""
+    from snake_slam_amd import synth
+
+    img, _ = synth.stereo_frame(77, 2000, 1500, n_rects=2500)
+    n = check_image(orc, img, 5000, 8, 1.2, 20, 7, stages=False)
+    assert n >= 5000
+
+
 def test_batch_dev_matches_single(orc):
     import torch
     from snake_slam_amd import synth
