@@ -1,0 +1,37 @@
+"""GPU: bench.py honours the driver's contract — exactly one JSON line on stdout with the required keys."""
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+pytestmark = pytest.mark.gpu
+
+REQUIRED = {"metric": str, "value": float, "unit": str, "n_gpus": int, "steps": int, "warmup": int, "ms_per_step": float,
+            "higher_is_better": bool, "scaling": str, "dtype": str, "data": str, "config": dict, "roofline": dict}
+
+
+def test_bench_prints_one_json_line():
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "16",
+                        "--ba-windows", "8", "--pose-frames", "8", "--gba-keyframes", "0", "--no-cpu-baseline"],
+                       capture_output=True, text=True, cwd=str(ROOT), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k, t in REQUIRED.items():
+        assert k in d and isinstance(d[k], t), k
+    assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "u8" and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["kernel"] == "fast_kernel"
+    assert d["value"] > 0 and d["ba"]["value"] > 0 and d["pose_refine"]["value"] > 0
+
+
+def test_committed_default_line_has_the_cpu_baseline():
+    d = json.loads((ROOT / "profiles" / "r01h_bench_default.json").read_text())
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 4 and cb["value"] > 0 and "sample" in cb and cb["ba"]["cores"] == 1
