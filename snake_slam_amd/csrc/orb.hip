@@ -189,24 +189,26 @@ __device__ __forceinline__ void load_tile(u32* tile, int pitch_dw, const u8* __r
     const int total = nrows << lc;
     if (aligned && xs >= 0 && xs + 4 * ndw <= w && ys >= 0 && ys + nrows <= h)
     {
-        // interior tile (tile-uniform test): branch-free aligned dword loads, BATCH requests in flight
-        for (int i0 = tid; i0 < total; i0 += nthreads * BATCH)
+        // interior tile (tile-uniform test): branch-free aligned dword loads, BATCH requests in flight.
+        // Items are numbered densely (row = item / ndw via an exact float reciprocal): a power-of-two row
+        // length would waste 6 of 16 slots for the usual 10-dword FAST tile and cost a second batch.
+        const int dense   = nrows * ndw;
+        const float inv_n = 1.0f / (float)ndw;
+        for (int i0 = tid; i0 < dense; i0 += nthreads * BATCH)
         {
             u32 v[BATCH];
+            int at[BATCH];
 #pragma unroll
             for (int k = 0; k < BATCH; ++k)
             {
-                const int i = min(i0 + k * nthreads, total - 1);
-                const int r = i >> lc, d = min(i & ((1 << lc) - 1), ndw - 1);
-                v[k]        = *reinterpret_cast<const u32*>(src + (long long)(ys + r) * pitch + xs + 4 * d);
+                const int i = min(i0 + k * nthreads, dense - 1);
+                const int r = (int)(((float)i + 0.5f) * inv_n), d = i - r * ndw;
+                at[k]       = r * pitch_dw + d;
+                v[k]        = *reinterpret_cast<const u32*>(src + (u32)((ys + r) * pitch + xs + 4 * d));
             }
 #pragma unroll
             for (int k = 0; k < BATCH; ++k)
-            {
-                const int i = i0 + k * nthreads;
-                const int r = i >> lc, d = i & ((1 << lc) - 1);
-                if (i < total && d < ndw) tile[r * pitch_dw + d] = v[k];
-            }
+                if (i0 + k * nthreads < dense) tile[at[k]] = v[k];
         }
         return;
     }
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
     const int xs  = (x0 - 3) & ~3;
     const int sh  = (x0 - 3) - xs;  // tile byte column of cell pixel px is px + 3 + sh
     const int ndw = (sh + cw + 6 + 3) >> 2;
-    load_tile<8>(tile_dw, TPD, src, pitch, lv.w, lv.h, xs, y0 - 3, ndw, ch + 6, aligned, lane, 64);
+    load_tile<6>(tile_dw, TPD, src, pitch, lv.w, lv.h, xs, y0 - 3, ndw, ch + 6, aligned, lane, 64);
     for (int i = lane; i < (ch + 2) * (SP >> 2); i += 64) reinterpret_cast<u32*>(S)[i] = 0;
     __builtin_amdgcn_wave_barrier();
     const u8* tile = reinterpret_cast<const u8*>(tile_dw);
