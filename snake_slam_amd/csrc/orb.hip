@@ -127,6 +127,7 @@ struct Layout
     int level_cap;
     // per-wavefront LDS slice of fast_kernel (bytes; sized from the largest cell of the layout)
     int f_tile_pitch_dw, f_s_pitch, f_off_s, f_off_surv, f_off_list, f_off_cnt, f_lds_wave;
+    const int4* cell_tab;  // [total_cells] (x0, y0, cw | ch << 16, level) of every FAST cell: one scalar load instead of a level search and two integer divisions per cell
     LevelInfo lv[MAX_LEVELS];
 };
 
@@ -338,16 +339,11 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
     int* cnt          = reinterpret_cast<int*>(slice + L.f_off_cnt);  // n_surv, n_list, n_ini (LDS atomics)
     const int TPD = L.f_tile_pitch_dw, TP = TPD * 4, SP = L.f_s_pitch;
 
-    int l = 0;
-    while (l + 1 < L.n_levels && cid >= L.lv[l + 1].cell_off) ++l;
+    const int4 ct = L.cell_tab[cid];
+    const int l   = ct.w;
     const LevelInfo& lv = L.lv[l];
-    const int c   = cid - lv.cell_off;
-    const int ci  = c / lv.ncols, cj = c - ci * lv.ncols;
-    const int x0  = EDGE_THRESHOLD + cj * lv.wcell;
-    const int y0  = EDGE_THRESHOLD + ci * lv.hcell;
-    const int x1  = min(x0 + lv.wcell, lv.w - EDGE_THRESHOLD);
-    const int y1  = min(y0 + lv.hcell, lv.h - EDGE_THRESHOLD);
-    const int cw = x1 - x0, ch = y1 - y0;
+    const int x0 = ct.x, y0 = ct.y;
+    const int cw = (int)(short)(ct.z & 0xFFFF), ch = (int)(short)((unsigned)ct.z >> 16);
     const long long cell_index = (long long)b * L.total_cells + cid;
     if (cw <= 0 || ch <= 0)
     {
@@ -1360,6 +1356,7 @@ struct snk_orb : HandleBase
     DevBuf pyr[MAX_LEVELS];   // levels >= 1
     DevBuf blur[MAX_LEVELS];  // blurred levels (all)
     DevBuf tables;           // resize tables
+    DevBuf cell_tab;         // FAST cell geometry
     DevBuf img0;             // level-0 staging for the host API
     DevBuf cand, cell_cnt, sel, sel_score, sel_cnt, cand_total, dist_queue;
     DevBuf out_kps, out_desc, out_n;  // host-API staging
@@ -1544,6 +1541,7 @@ int snk_orb_destroy(snk_orb* o)
     o->img0.release();
     o->cand.release();
     o->cell_cnt.release();
+    o->cell_tab.release();
     o->sel.release();
     o->sel_score.release();
     o->sel_cnt.release();
@@ -1637,6 +1635,28 @@ int snk_orb_configure(snk_orb* o, int width, int height, int max_batch)
     {
         if ((rc = o->blur[l].reserve((size_t)L.lv[l].img_stride * max_batch + 64)) != SNK_OK) return rc;
         L.lv[l].blur = o->blur[l].as<u8>();
+    }
+    {
+        std::vector<int4> ct((size_t)(L.total_cells > 0 ? L.total_cells : 1));
+        for (int l = 0; l < L.n_levels; ++l)
+        {
+            const LevelInfo& lv = L.lv[l];
+            for (int c = 0; c < lv.ncols * lv.nrows; ++c)
+            {
+                const int ci = c / lv.ncols, cj = c - ci * lv.ncols;
+                const int x0 = EDGE_THRESHOLD + cj * lv.wcell, y0 = EDGE_THRESHOLD + ci * lv.hcell;
+                const int x1 = std::min(x0 + lv.wcell, lv.w - EDGE_THRESHOLD), y1 = std::min(y0 + lv.hcell, lv.h - EDGE_THRESHOLD);
+                int4 e;
+                e.x = x0;
+                e.y = y0;
+                e.z = (int)(((unsigned)(x1 - x0) & 0xFFFFu) | ((unsigned)(y1 - y0) << 16));
+                e.w = l;
+                ct[(size_t)lv.cell_off + c] = e;
+            }
+        }
+        if ((rc = o->cell_tab.reserve(ct.size() * sizeof(int4))) != SNK_OK) return rc;
+        SNK_HIP_CHECK(hipMemcpy(o->cell_tab.p, ct.data(), ct.size() * sizeof(int4), hipMemcpyHostToDevice));
+        L.cell_tab = o->cell_tab.as<int4>();
     }
     const size_t cells = (size_t)(L.total_cells > 0 ? L.total_cells : 1) * max_batch;
     const size_t slots = (size_t)(L.total_slots > 0 ? L.total_slots : 1) * max_batch;
