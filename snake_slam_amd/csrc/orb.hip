@@ -336,7 +336,6 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
     u8* S             = slice + L.f_off_s;
     u16* surv         = reinterpret_cast<u16*>(slice + L.f_off_surv);
     u32* list         = reinterpret_cast<u32*>(slice + L.f_off_list);
-    int* cnt          = reinterpret_cast<int*>(slice + L.f_off_cnt);  // n_surv, n_list, n_ini (LDS atomics)
     const int TPD = L.f_tile_pitch_dw, TP = TPD * 4, SP = L.f_s_pitch;
 
     const int4 ct = L.cell_tab[cid];
@@ -354,7 +353,6 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
     const int pitch    = l == 0 ? pitch0 : lv.pitch;
     const bool aligned = l == 0 ? aligned0 != 0 : true;
 
-    if (lane < 3) cnt[lane] = 0;
     // image tile with the 3-pixel ring halo (always inside the image: cells start at x,y >= 19)
     const int xs  = (x0 - 3) & ~3;
     const int sh  = (x0 - 3) - xs;  // tile byte column of cell pixel px is px + 3 + sh
@@ -364,21 +362,29 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
     __builtin_amdgcn_wave_barrier();
     const u8* tile = reinterpret_cast<const u8*>(tile_dw);
 
-    // phase A: every 9-arc holds one pixel of each opposite pair -> S <= min_i max(d_i, d_{i+8})
-    for (int py = lane >> 5; py < ch; py += 2)
-        for (int px = lane & 31; px < cw; px += 32)
+    // phase A: every 9-arc holds one pixel of each opposite pair -> S <= min_i max(d_i, d_{i+8}).  The loops
+    // are wave-uniform (lanes outside the cell are predicated), so the running survivor count lives in a
+    // scalar register: position = count + prefix population of the ballot, no LDS atomic.
+    int ns = 0;
+    const int lpy = lane >> 5, lpx = lane & 31;
+    for (int py0 = 0; py0 < ch; py0 += 2)
+        for (int px0 = 0; px0 < cw; px0 += 32)
         {
-            const u8* t  = tile + (py + 3) * TP + px + 3 + sh;
+            const int py = py0 + lpy, px = px0 + lpx;
+            const bool in = py < ch && px < cw;
+            const u8* t  = tile + (min(py, ch - 1) + 3) * TP + min(px, cw - 1) + 3 + sh;
             const int v  = t[0];
             const int d0 = t[3 * TP] - v, d8 = t[-3 * TP] - v, d4 = t[3] - v, d12 = t[-3] - v;
             const int ub_b = min(max(d0, d8), max(d4, d12));
             const int ub_d = min(max(-d0, -d8), max(-d4, -d12));
-            if (ub_b > min_th || ub_d > min_th) surv[atomicAdd(&cnt[0], 1)] = (u16)((py << 6) | px);
+            const bool sv  = in && (ub_b > min_th || ub_d > min_th);
+            const u64 m    = __ballot(sv);
+            if (sv) surv[ns + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u))] = (u16)((py << 6) | px);
+            ns += __popcll(m);
         }
     __builtin_amdgcn_wave_barrier();
 
     // phase B: exact score of the survivors, two per lane
-    const int ns = __builtin_amdgcn_readfirstlane(__atomic_load_n(&cnt[0], __ATOMIC_RELAXED));
     for (int j = lane * 2; j < ns; j += 128)
     {
         const int e0 = surv[j], e1 = surv[j + 1 < ns ? j + 1 : j];
@@ -398,26 +404,27 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
     }
     __builtin_amdgcn_wave_barrier();
 
-    // 3x3 non-max suppression (strict) among scores above min_th (all of them are survivors)
-    for (int j = lane; j < ns; j += 64)
+    // 3x3 non-max suppression (strict) among scores above min_th (all of them are survivors); the list of
+    // corners is appended the same way (wave-uniform loop, ballot prefix, counts in scalar registers)
+    int nl = 0, nini = 0;
+    for (int j0 = 0; j0 < ns; j0 += 64)
     {
-        const int e  = surv[j];
+        const int j  = j0 + lane;
+        const int e  = surv[min(j, ns - 1)];
         const int px = e & 63, py = e >> 6;
         const u8* s  = &S[(py + 1) * SP + px + 1];
         const int v  = s[0];
-        if (v <= min_th) continue;
-        if (v > s[-1] && v > s[1] && v > s[-SP - 1] && v > s[-SP] && v > s[-SP + 1] && v > s[SP - 1] && v > s[SP] &&
-            v > s[SP + 1])
-        {
-            // strength key: higher score first, then smaller y, then smaller x
-            const u32 key = ((u32)v << 12) | ((u32)(63 - py) << 6) | (u32)(63 - px);
-            list[atomicAdd(&cnt[1], 1)] = key;
-            if (v > ini_th) atomicAdd(&cnt[2], 1);
-        }
+        const bool keep = j < ns && v > min_th && v > s[-1] && v > s[1] && v > s[-SP - 1] && v > s[-SP] && v > s[-SP + 1] &&
+                          v > s[SP - 1] && v > s[SP] && v > s[SP + 1];
+        const u64 m = __ballot(keep);
+        // strength key: higher score first, then smaller y, then smaller x
+        if (keep)
+            list[nl + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u))] =
+                ((u32)v << 12) | ((u32)(63 - py) << 6) | (u32)(63 - px);
+        nl += __popcll(m);
+        nini += __popcll(__ballot(keep && v > ini_th));
     }
     __builtin_amdgcn_wave_barrier();
-    const int nl   = __builtin_amdgcn_readfirstlane(__atomic_load_n(&cnt[1], __ATOMIC_RELAXED));
-    const int nini = __builtin_amdgcn_readfirstlane(__atomic_load_n(&cnt[2], __ATOMIC_RELAXED));
     const bool ini = nini > 0;
     const u32 thr  = ((u32)(ini ? ini_th : min_th) << 12) | 0xFFFu;  // key > thr  <=>  score > threshold
     const int n    = ini ? nini : nl;
