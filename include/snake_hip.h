@@ -365,6 +365,65 @@ SNK_API int snk_match_triangulation_project(snk_matcher* m, const double* depth_
                                             const double (*np2)[2], const double E12[9], float epipolar_distance,
                                             int feature_distance, int32_t* match_idx2, int* n_matches);
 
+/* frame->bow_feature_vec (an ordered map vocabulary node -> feature indices, filled by the reference's
+ * bag-of-words transform) flattened: node_id strictly ascending, node_start[n_nodes + 1] offsets into
+ * `features`, each node's features in the order the reference iterates them. */
+typedef struct snk_bow_features
+{
+    int32_t n_nodes;
+    int32_t pad;
+    const uint32_t* node_id;
+    const int32_t* node_start;
+    const int32_t* features;
+} snk_bow_features;
+
+/* Replaces MappingORBMatcher::SearchForTriangulation2 — Snake/LocalMapping/MappingORBMatcher.cpp:14-99
+ * (call site Snake/LocalMapping/Triangulator.cpp:164).  np / desc / has_mp: normalized_points,
+ * descriptors, GetMapPoint(i) != nullptr of each keyframe (any order; the bag-of-words vectors index
+ * them).  pairs must hold bow1->node_start[n_nodes] entries; it receives (idx1, idx2) in the order the
+ * reference emplaces them; *n_matches = the return value.  tmp_flags of the reference is never set
+ * (:26-27, :59), so a keyframe-2 feature may be paired with several keyframe-1 features, as there. */
+SNK_API int snk_match_triangulation_bow(snk_matcher* m, const snk_camera* cam, const double E12[9], const double (*np1)[2],
+                                        const uint64_t (*desc1)[4], const uint8_t* has_mp1, int n1,
+                                        const snk_bow_features* bow1, const double (*np2)[2], const uint64_t (*desc2)[4],
+                                        const uint8_t* has_mp2, int n2, const snk_bow_features* bow2,
+                                        float epipolar_distance, int feature_distance, int32_t (*pairs)[2], int* n_matches);
+
+/* Replaces MappingORBMatcher::SearchForTriangulationBF — MappingORBMatcher.cpp:102-165: all pairs,
+ * epipolar gate of 10 px (:107; the reference ignores its epipolarDistance argument), then the
+ * descriptor gate.  match_idx2[i] = feature of keyframe 2 paired with feature i of keyframe 1, or -1. */
+SNK_API int snk_match_triangulation_bf(snk_matcher* m, const snk_camera* cam, const double E12[9], const double (*np1)[2],
+                                       const uint64_t (*desc1)[4], const uint8_t* has_mp1, int n1, const double (*np2)[2],
+                                       const uint64_t (*desc2)[4], const uint8_t* has_mp2, int n2, int feature_distance,
+                                       int32_t* match_idx2, int* n_matches);
+
+/* One (keyframe feature, map point) observation of DeferredMapper::Relink — Snake/Optimizer/DeferredMapper.cpp:61-99. */
+typedef struct snk_relink_query
+{
+    double pos[3];        /* mp->getPosition() */
+    uint64_t desc[4];     /* mp->descriptor */
+    uint64_t alt_desc[4]; /* descriptor of mp's first observation in another keyframe (:90-98), if has_alt */
+    int32_t feature;      /* i: the feature of the keyframe that holds mp (grid order) */
+    int32_t has_alt;
+} snk_relink_query;
+
+#define SNK_RELINK_KEEP 0
+#define SNK_RELINK_ERASE 1  /* behind the camera or reprojection error > outlier_threshold (:75-81) */
+#define SNK_RELINK_MOVE 2   /* best_idx = a closer feature with a strictly better descriptor (:101-138) */
+
+/* Replaces the per-observation search of DeferredMapper::Relink — Snake/Optimizer/DeferredMapper.cpp:39-165
+ * (call site :32); reference constants: radius 0.8, outlier_threshold = reprojectionErrorThresholdMono
+ * = 2.1, feature_threshold 25 (:41-43).  frame = kf->frame (grid order; `taken` unused), pose =
+ * kf->Pose().  The map edits stay on the caller's side, in feature order as in the reference: ERASE ->
+ * EraseMapPointMatch / EraseObservation; MOVE -> if kf->GetMapPoint(best_idx) is a good point at that
+ * moment erase (:143-152) else relink (:155-161).  A point moved to a LATER feature is visited again
+ * by the reference's loop with its recomputed descriptor: the caller queries it again (n = 1).
+ * stereo_cam.LeftPointToRight(x, z) (absent saiga) is [DEFINED] as x - bf / z.
+ * *n_changed = number of queries with action != KEEP. */
+SNK_API int snk_match_relink(snk_matcher* m, const snk_frame_view* frame, const snk_camera* cam, const double pose[7],
+                             const snk_relink_query* queries, int n, float radius, double outlier_threshold,
+                             int feature_threshold, int32_t* action, int32_t* best_idx, int* n_changed);
+
 /* ------------------------------------------------------------------------------------------
  * Pose refinement (the step after every projection matcher)
  * ------------------------------------------------------------------------------------------ */

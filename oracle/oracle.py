@@ -446,6 +446,67 @@ def match_triangulation_project(depth_grid, pose1, pose2, cam, kps1, np1, desc1,
     return n, out[: len(kps1)]
 
 
+RELINK_QUERY = np.dtype([("pos", "f8", 3), ("desc", "u8", 4), ("alt_desc", "u8", 4), ("feature", "i4"), ("has_alt", "i4")])
+
+
+def match_relink(frame, cam, pose, queries, radius=0.8, outlier_threshold=2.1, feature_threshold=25):
+    """DeferredMapper::Relink, per-observation search.  Returns (n_changed, action[n], best_idx[n])."""
+    v, keep = make_frame_view(frame)
+    q = np.ascontiguousarray(queries, RELINK_QUERY)
+    p = np.ascontiguousarray(pose, np.float64)
+    action = np.zeros(max(len(q), 1), np.int32)
+    best = np.zeros(max(len(q), 1), np.int32)
+    c = Camera(*cam)
+    lib().orc_match_relink.restype = C.c_int
+    n = lib().orc_match_relink(C.byref(v), C.byref(c), _p(p), _p(q), C.c_int(len(q)), C.c_float(radius), C.c_double(outlier_threshold),
+                               C.c_int(feature_threshold), _p(action), _p(best))
+    return n, action[: len(q)], best[: len(q)]
+
+
+def bow_arrays(bow):
+    """bow: (node_id[k] ascending, node_start[k + 1], features[...]) -> contiguous arrays of the C layout."""
+    ids = np.ascontiguousarray(bow[0], np.uint32)
+    start = np.ascontiguousarray(bow[1], np.int32)
+    feat = np.ascontiguousarray(bow[2], np.int32)
+    assert len(start) == len(ids) + 1 and (len(ids) == 0 or start[-1] == len(feat))
+    return ids, start, feat
+
+
+def match_triangulation_bow(cam, E12, np1, desc1, has_mp1, bow1, np2, desc2, has_mp2, bow2, epipolar_distance, feature_distance):
+    """MappingORBMatcher::SearchForTriangulation2.  Returns (n, pairs[n, 2]) in the reference's emplace order."""
+    np1 = np.ascontiguousarray(np1, np.float64).reshape(-1, 2)
+    np2 = np.ascontiguousarray(np2, np.float64).reshape(-1, 2)
+    d1 = np.ascontiguousarray(desc1, np.uint64).reshape(-1, 4)
+    d2 = np.ascontiguousarray(desc2, np.uint64).reshape(-1, 4)
+    h1, h2 = np.ascontiguousarray(has_mp1, np.uint8), np.ascontiguousarray(has_mp2, np.uint8)
+    i1, s1, f1 = bow_arrays(bow1)
+    i2, s2, f2 = bow_arrays(bow2)
+    E = np.ascontiguousarray(E12, np.float64).reshape(9)
+    pairs = np.zeros((max(len(f1), 1), 2), np.int32)
+    c = Camera(*cam)
+    lib().orc_match_triangulation_bow.restype = C.c_int
+    n = lib().orc_match_triangulation_bow(C.byref(c), _p(E), _p(np1), _p(d1), _p(h1), C.c_int(len(i1)), _p(i1), _p(s1), _p(f1),
+                                          _p(np2), _p(d2), _p(h2), C.c_int(len(i2)), _p(i2), _p(s2), _p(f2),
+                                          C.c_float(epipolar_distance), C.c_int(feature_distance), _p(pairs))
+    return n, pairs[:n]
+
+
+def match_triangulation_bf(cam, E12, np1, desc1, has_mp1, np2, desc2, has_mp2, feature_distance):
+    """MappingORBMatcher::SearchForTriangulationBF.  Returns (n, match_idx2[n1])."""
+    np1 = np.ascontiguousarray(np1, np.float64).reshape(-1, 2)
+    np2 = np.ascontiguousarray(np2, np.float64).reshape(-1, 2)
+    d1 = np.ascontiguousarray(desc1, np.uint64).reshape(-1, 4)
+    d2 = np.ascontiguousarray(desc2, np.uint64).reshape(-1, 4)
+    h1, h2 = np.ascontiguousarray(has_mp1, np.uint8), np.ascontiguousarray(has_mp2, np.uint8)
+    E = np.ascontiguousarray(E12, np.float64).reshape(9)
+    out = np.zeros(max(len(np1), 1), np.int32)
+    c = Camera(*cam)
+    lib().orc_match_triangulation_bf.restype = C.c_int
+    n = lib().orc_match_triangulation_bf(C.byref(c), _p(E), _p(np1), _p(d1), _p(h1), C.c_int(len(np1)), _p(np2), _p(d2), _p(h2),
+                                         C.c_int(len(np2)), C.c_int(feature_distance), _p(out))
+    return n, out[: len(np1)]
+
+
 # ------------------------------------------------------------------ pose refinement ------------
 class PoseObs(C.Structure):
     _fields_ = [("x", C.c_double), ("y", C.c_double), ("depth", C.c_double), ("weight", C.c_double)]

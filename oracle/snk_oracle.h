@@ -217,6 +217,24 @@ int orc_match_triangulation_project(const double* depth_grid, int grid_rows, int
                                     const double (*np1)[2], const uint64_t (*desc1)[4], const uint8_t* has_mp1, int n1,
                                     const orc_frame_view* f2, const double (*np2)[2], const double* E12,
                                     float epipolar_distance, int feature_distance, int32_t* match_idx2);
+typedef struct orc_relink_query /* one (keyframe feature, map point) observation — DeferredMapper.cpp:61-99 */
+{
+    double pos[3];        /* mp->getPosition() */
+    uint64_t desc[4];     /* mp->descriptor */
+    uint64_t alt_desc[4]; /* descriptor of the first observation of mp in another keyframe (:90-98) */
+    int32_t feature;      /* i */
+    int32_t has_alt;
+} orc_relink_query;
+int orc_match_relink(const orc_frame_view* f, const orc_camera* cam, const double* pose, const orc_relink_query* queries, int n,
+                     float radius, double outlier_threshold, int feature_threshold, int32_t* action, int32_t* best_idx);
+int orc_match_triangulation_bow(const orc_camera* cam, const double* E12, const double (*np1)[2], const uint64_t (*desc1)[4],
+                                const uint8_t* has_mp1, int n_nodes1, const uint32_t* node_id1, const int32_t* node_start1,
+                                const int32_t* feat1, const double (*np2)[2], const uint64_t (*desc2)[4], const uint8_t* has_mp2,
+                                int n_nodes2, const uint32_t* node_id2, const int32_t* node_start2, const int32_t* feat2,
+                                float epipolar_distance, int feature_distance, int32_t (*pairs)[2]);
+int orc_match_triangulation_bf(const orc_camera* cam, const double* E12, const double (*np1)[2], const uint64_t (*desc1)[4],
+                               const uint8_t* has_mp1, int n1, const double (*np2)[2], const uint64_t (*desc2)[4],
+                               const uint8_t* has_mp2, int n2, int feature_distance, int32_t* match_idx2);
 
 /* ---- pose_oracle.c ---- */
 typedef struct orc_pose_obs /* Saiga ObsBase<double> as PoseRefinement.h:47-55 fills it */

@@ -617,3 +617,182 @@ int orc_match_triangulation_project(const double* depth_grid, int grid_rows, int
     }
     return nmatches;
 }
+
+/* MappingORBMatcher::SearchForTriangulation2 — reference Snake/LocalMapping/MappingORBMatcher.cpp:14-99 (call site
+ * Snake/LocalMapping/Triangulator.cpp:164).  The bag-of-words feature vector of a keyframe (an ordered map node id ->
+ * feature indices, frame->bow_feature_vec) arrives flattened: node_id ascending, node_start[n_nodes + 1] offsets into
+ * `features`.  tmp_flags (:26-27) is never set by the reference, so every feature of keyframe 1 is independent.
+ * pairs receives (idx1, idx2) in the reference's emplace order; returns nmatches. */
+int orc_match_triangulation_bow(const orc_camera* cam, const double* E12, const double (*np1)[2], const uint64_t (*desc1)[4],
+                                const uint8_t* has_mp1, int n_nodes1, const uint32_t* node_id1, const int32_t* node_start1,
+                                const int32_t* feat1, const double (*np2)[2], const uint64_t (*desc2)[4], const uint8_t* has_mp2,
+                                int n_nodes2, const uint32_t* node_id2, const int32_t* node_start2, const int32_t* feat2,
+                                float epipolar_distance, int feature_distance, int32_t (*pairs)[2])
+{
+    const double th_chi1 = (double)(epipolar_distance * 2) / cam->fx; /* :20 (float product, then double division) */
+    const double th_chi2 = th_chi1 * th_chi1;
+    int nmatches         = 0;
+    int a = 0, b = 0;
+    while (a < n_nodes1 && b < n_nodes2) /* :34 */
+    {
+        if (node_id1[a] == node_id2[b])
+        {
+            for (int u = node_start1[a]; u < node_start1[a + 1]; ++u) /* :38 */
+            {
+                const int idx1 = feat1[u];
+                if (has_mp1[idx1]) continue; /* :43 */
+                const double x = np1[idx1][0], y = np1[idx1][1];
+                const double l0 = E12[0] * x + E12[1] * y + E12[2], l1 = E12[3] * x + E12[4] * y + E12[5],
+                             l2 = E12[6] * x + E12[7] * y + E12[8];
+                int best_dist = 50, best_idx2 = -1; /* TH_LOW :50-51 */
+                for (int v = node_start2[b]; v < node_start2[b + 1]; ++v) /* :54 */
+                {
+                    const int idx2 = feat2[v];
+                    if (has_mp2[idx2]) continue; /* :59 */
+                    const int dist = orc_hamming(desc1[idx1], desc2[idx2]);
+                    if (dist > feature_distance || dist > best_dist) continue; /* :66 */
+                    const double d      = np2[idx2][0] * l0 + np2[idx2][1] * l1 + l2;
+                    const double disepi = d * d / (l0 * l0 + l1 * l1);
+                    if (disepi < th_chi2) /* :72 */
+                    {
+                        best_idx2 = idx2;
+                        best_dist = dist;
+                    }
+                }
+                if (best_idx2 >= 0) /* :79 */
+                {
+                    pairs[nmatches][0] = idx1;
+                    pairs[nmatches][1] = best_idx2;
+                    nmatches++;
+                }
+            }
+            ++a;
+            ++b;
+        }
+        else if (node_id1[a] < node_id2[b]) /* lower_bound jumps :88-97 == advance to the first id >= the other */
+        {
+            while (a < n_nodes1 && node_id1[a] < node_id2[b]) ++a;
+        }
+        else
+        {
+            while (b < n_nodes2 && node_id2[b] < node_id1[a]) ++b;
+        }
+    }
+    return nmatches;
+}
+
+/* MappingORBMatcher::SearchForTriangulationBF — reference Snake/LocalMapping/MappingORBMatcher.cpp:102-165: every
+ * unmatched feature of keyframe 1 against every unmatched feature of keyframe 2, epipolar gate 10 px first (:107, the
+ * epipolarDistance argument is unused), then the descriptor gate.  match_idx2[i] = idx2 or -1. */
+int orc_match_triangulation_bf(const orc_camera* cam, const double* E12, const double (*np1)[2], const uint64_t (*desc1)[4],
+                               const uint8_t* has_mp1, int n1, const double (*np2)[2], const uint64_t (*desc2)[4],
+                               const uint8_t* has_mp2, int n2, int feature_distance, int32_t* match_idx2)
+{
+    const double th_chi1 = 10 / cam->fx; /* :107 */
+    const double th_chi2 = th_chi1 * th_chi1;
+    int nmatches         = 0;
+    for (int idx1 = 0; idx1 < n1; ++idx1) /* :116 */
+    {
+        match_idx2[idx1] = -1;
+        if (has_mp1[idx1]) continue; /* :120 */
+        const double x = np1[idx1][0], y = np1[idx1][1];
+        const double l0 = E12[0] * x + E12[1] * y + E12[2], l1 = E12[3] * x + E12[4] * y + E12[5],
+                     l2 = E12[6] * x + E12[7] * y + E12[8];
+        int best_dist = 50, best_idx2 = -1;
+        for (int idx2 = 0; idx2 < n2; ++idx2) /* :129 */
+        {
+            if (has_mp2[idx2]) continue; /* :134 */
+            const double d      = np2[idx2][0] * l0 + np2[idx2][1] * l1 + l2;
+            const double disepi = d * d / (l0 * l0 + l1 * l1);
+            if (disepi > th_chi2) continue; /* :140 */
+            const int dist = orc_hamming(desc1[idx1], desc2[idx2]);
+            if (dist > feature_distance || dist > best_dist) continue; /* :148 */
+            best_idx2 = idx2;
+            best_dist = dist;
+        }
+        if (best_idx2 >= 0)
+        {
+            match_idx2[idx1] = best_idx2;
+            nmatches++;
+        }
+    }
+    return nmatches;
+}
+
+/* DeferredMapper::Relink — reference Snake/Optimizer/DeferredMapper.cpp:39-165, the per-observation search (the data
+ * parallel part).  One query = one feature of the keyframe that holds a good map point (:63-64).  action[q]:
+ * 0 = keep, 1 = erase the observation (:75-81), 2 = relink candidate best_idx[q] (:140-163; the caller looks at
+ * kf->GetMapPoint(best_idx) at that moment, erases or relinks, and re-queries a point it moved to a LATER slot with the
+ * recomputed descriptor, as the sequential loop of the reference would revisit it).
+ * stereo_cam.LeftPointToRight(x, z) (absent saiga) is [DEFINED] as x - bf / z, as in the tracking matchers. */
+typedef struct relink_ud
+{
+    const orc_frame_view* f;
+    const orc_relink_query* q;
+    const orc_camera* cam;
+    double ipx, ipy, z, rep2;
+    int feature_threshold, best_dist, best_idx;
+} relink_ud;
+
+static int relink_cand(void* p, int j)
+{
+    relink_ud* u = (relink_ud*)p;
+    if (j == u->q->feature) return 0; /* :107 */
+    const double dx = u->ipx - u->f->kps[j].x, dy = u->ipy - u->f->kps[j].y;
+    const double error_squared = dx * dx + dy * dy;
+    if (error_squared > u->rep2) return 0; /* :113 */
+    if (u->f->right_points[j] > 0)         /* :115 */
+    {
+        const double disp = u->ipx - u->cam->bf / u->z;
+        const double er   = disp - (double)u->f->right_points[j];
+        if (er * er > u->rep2 * 2.0) return 0; /* :119 */
+    }
+    const int d2 = orc_hamming(u->q->desc, u->f->desc[j]);
+    if (d2 < u->feature_threshold && d2 < u->best_dist) /* :126 */
+    {
+        u->best_dist = d2;
+        u->best_idx  = j;
+    }
+    return 0;
+}
+
+int orc_match_relink(const orc_frame_view* f, const orc_camera* cam, const double* pose, const orc_relink_query* queries, int n,
+                     float radius, double outlier_threshold, int feature_threshold, int32_t* action, int32_t* best_idx)
+{
+    view_ctx c;
+    make_ctx(pose, &c);
+    const double out2 = outlier_threshold * outlier_threshold; /* :54 */
+    const float r2f   = radius * radius;                       /* Features.cpp:17 (float) */
+    int changed       = 0;
+    for (int q = 0; q < n; ++q)
+    {
+        const orc_relink_query* Q = &queries[q];
+        action[q]   = 0;
+        best_idx[q] = -1;
+        double np[3];
+        transform(&c, Q->pos, np); /* :70 */
+        const double z   = np[2];
+        const double ipx = cam->fx * np[0] / z + cam->cx, ipy = cam->fy * np[1] / z + cam->cy; /* :72 */
+        const double ex = ipx - f->kps[Q->feature].x, ey = ipy - f->kps[Q->feature].y;
+        const double rep2 = ex * ex + ey * ey;
+        if (z <= 0 || rep2 > out2) /* :75 */
+        {
+            action[q] = 1;
+            changed++;
+            continue;
+        }
+        int feature_dist = orc_hamming(Q->desc, f->desc[Q->feature]);          /* :85 */
+        if (feature_dist == 0 && Q->has_alt) feature_dist = orc_hamming(Q->desc, Q->alt_desc); /* :87-99 */
+        relink_ud u;
+        u.f = f; u.q = Q; u.cam = cam; u.ipx = ipx; u.ipy = ipy; u.z = z; u.rep2 = rep2;
+        u.feature_threshold = feature_threshold; u.best_dist = feature_dist; u.best_idx = -1; /* :101-102 */
+        for_candidates(f, ipx, ipy, (double)radius, (double)r2f, 0, 0, 0, 0.0, relink_cand, &u); /* :100 */
+        if (u.best_idx != -1)
+        {
+            action[q]   = 2;
+            best_idx[q] = u.best_idx;
+            changed++;
+        }
+    }
+    return changed;
+}

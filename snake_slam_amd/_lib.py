@@ -56,6 +56,9 @@ SIGNATURES = {
     "snk_match_fuse": (i32, [vp, vp, vp, vp, vp, vp, i32, f32, f32, i32, vp, i32, vp, C.POINTER(i32)]),
     "snk_match_triangulation_project": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, f32, i32, vp,
                                               C.POINTER(i32)]),
+    "snk_match_triangulation_bow": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, f32, i32, vp, C.POINTER(i32)]),
+    "snk_match_triangulation_bf": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, C.POINTER(i32)]),
+    "snk_match_relink": (i32, [vp, vp, vp, vp, vp, i32, f32, f64, i32, vp, vp, C.POINTER(i32)]),
     "snk_orb_create": (i32, [vp, i32, vp, C.POINTER(vp)]),
     "snk_orb_destroy": (i32, [vp]),
     "snk_orb_sync": (i32, [vp]),

@@ -295,6 +295,102 @@ class MappingORBMatcher
         return n;
     }
 
+    // frame->bow_feature_vec (std::map<node id, std::vector<feature index>>-like, ordered) flattened for the C ABI
+    struct BowFeatureVector
+    {
+        std::vector<uint32_t> node_id;
+        std::vector<int32_t> node_start{0}, features;
+        template <typename Map>
+        static BowFeatureVector from(const Map& fv)
+        {
+            BowFeatureVector b;
+            for (const auto& node : fv)
+            {
+                b.node_id.push_back((uint32_t)node.first);
+                for (auto f : node.second) b.features.push_back((int32_t)f);
+                b.node_start.push_back((int32_t)b.features.size());
+            }
+            return b;
+        }
+        snk_bow_features view() const { return {(int32_t)node_id.size(), 0, node_id.data(), node_start.data(), features.data()}; }
+    };
+    // SearchForTriangulation2(kf1, kf2, E, vMatchedPairs, epipolarDistance, featureDistance) — MappingORBMatcher.cpp:14-99;
+    // pairs are APPENDED in the reference's order
+    int SearchForTriangulation2(const snk_camera& K, const double E[9], const std::vector<std::array<double, 2>>& normalized1,
+                                const std::vector<DescriptorORB>& descriptors1, const std::vector<uint8_t>& has_mp1,
+                                const BowFeatureVector& bow1, const std::vector<std::array<double, 2>>& normalized2,
+                                const std::vector<DescriptorORB>& descriptors2, const std::vector<uint8_t>& has_mp2,
+                                const BowFeatureVector& bow2, std::vector<std::pair<int, int>>& vMatchedPairs,
+                                float epipolarDistance, int featureDistance)
+    {
+        const snk_bow_features b1 = bow1.view(), b2 = bow2.view();
+        std::vector<std::array<int32_t, 2>> pairs(bow1.features.size() + 1);
+        int n = 0;
+        check(snk_match_triangulation_bow(h_, &K, E, reinterpret_cast<const double(*)[2]>(normalized1.data()),
+                                          reinterpret_cast<const uint64_t(*)[4]>(descriptors1.data()), has_mp1.data(),
+                                          (int)normalized1.size(), &b1, reinterpret_cast<const double(*)[2]>(normalized2.data()),
+                                          reinterpret_cast<const uint64_t(*)[4]>(descriptors2.data()), has_mp2.data(),
+                                          (int)normalized2.size(), &b2, epipolarDistance, featureDistance,
+                                          reinterpret_cast<int32_t(*)[2]>(pairs.data()), &n),
+              "snk_match_triangulation_bow");
+        for (int i = 0; i < n; ++i) vMatchedPairs.emplace_back(pairs[i][0], pairs[i][1]);
+        return n;
+    }
+    // SearchForTriangulationBF(pose1, pose2, kf1, kf2, E12, vMatchedPairs, epipolarDistance, featureDistance) —
+    // MappingORBMatcher.cpp:102-165 (poses and epipolarDistance are unused there)
+    int SearchForTriangulationBF(const snk_camera& K, const double E12[9], const std::vector<std::array<double, 2>>& normalized1,
+                                 const std::vector<DescriptorORB>& descriptors1, const std::vector<uint8_t>& has_mp1,
+                                 const std::vector<std::array<double, 2>>& normalized2,
+                                 const std::vector<DescriptorORB>& descriptors2, const std::vector<uint8_t>& has_mp2,
+                                 std::vector<std::pair<int, int>>& vMatchedPairs, int featureDistance)
+    {
+        std::vector<int32_t> match(normalized1.size() + 1, -1);
+        int n = 0;
+        check(snk_match_triangulation_bf(h_, &K, E12, reinterpret_cast<const double(*)[2]>(normalized1.data()),
+                                         reinterpret_cast<const uint64_t(*)[4]>(descriptors1.data()), has_mp1.data(),
+                                         (int)normalized1.size(), reinterpret_cast<const double(*)[2]>(normalized2.data()),
+                                         reinterpret_cast<const uint64_t(*)[4]>(descriptors2.data()), has_mp2.data(),
+                                         (int)normalized2.size(), featureDistance, match.data(), &n),
+              "snk_match_triangulation_bf");
+        for (size_t i = 0; i < normalized1.size(); ++i)
+            if (match[i] >= 0) vMatchedPairs.emplace_back((int)i, match[i]);
+        return n;
+    }
+
+   private:
+    snk_matcher* h_ = nullptr;
+};
+
+// The per-observation search of Snake::DeferredMapper::Relink (reference Snake/Optimizer/DeferredMapper.cpp:39-165).
+// The caller builds one query per feature i with a good map point (:61-64: position, descriptor, the descriptor of the
+// point's first observation in another keyframe), calls RelinkSearch once, then applies the actions in feature order
+// under map.LockFull() exactly as :75-163 do (ERASE / MOVE with the live GetMapPoint(best_idx) test).
+class DeferredMapper
+{
+   public:
+    static constexpr float relink_reprojection_error_threshold = 0.8f;  // :41
+    static constexpr double relink_outlier_threshold           = 2.1;   // :42 reprojectionErrorThresholdMono
+    static constexpr int relink_feature_threshold              = 25;    // :43
+    explicit DeferredMapper(int device = 0) { check(snk_matcher_create(device, nullptr, &h_), "snk_matcher_create"); }
+    ~DeferredMapper() { snk_matcher_destroy(h_); }
+    DeferredMapper(const DeferredMapper&)            = delete;
+    DeferredMapper& operator=(const DeferredMapper&) = delete;
+    // returns the number of observations whose action is not SNK_RELINK_KEEP
+    int RelinkSearch(const FrameView& kf_frame, const snk_camera& K, const double pose[7], const std::vector<snk_relink_query>& queries,
+                     std::vector<int32_t>& action, std::vector<int32_t>& best_idx)
+    {
+        const snk_frame_view v = kf_frame.view();
+        action.assign(queries.size() + 1, 0);
+        best_idx.assign(queries.size() + 1, -1);
+        int n = 0;
+        check(snk_match_relink(h_, &v, &K, pose, queries.data(), (int)queries.size(), relink_reprojection_error_threshold,
+                               relink_outlier_threshold, relink_feature_threshold, action.data(), best_idx.data(), &n),
+              "snk_match_relink");
+        action.resize(queries.size());
+        best_idx.resize(queries.size());
+        return n;
+    }
+
    private:
     snk_matcher* h_ = nullptr;
 };

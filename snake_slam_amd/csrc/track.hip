@@ -625,6 +625,172 @@ __global__ __launch_bounds__(256) void triangulate_kernel(FrameDev F, TriDev T, 
     if (lane == 0) out[i] = result;
 }
 
+struct EpiDev
+{
+    double E[9];
+    double th_chi2;
+    int feature_distance;
+};
+
+// Epipolar line of a keyframe-1 feature in keyframe 2 and the squared distance of a keyframe-2 feature to it, operation
+// for operation as the oracle (and triangulate_kernel) evaluate them.
+__device__ __forceinline__ void epi_line(const EpiDev& T, double x, double y, double& l0, double& l1, double& l2, double& ln)
+{
+    l0 = T.E[0] * x + T.E[1] * y + T.E[2];
+    l1 = T.E[3] * x + T.E[4] * y + T.E[5];
+    l2 = T.E[6] * x + T.E[7] * y + T.E[8];
+    ln = l0 * l0 + l1 * l1;
+}
+
+// MappingORBMatcher::SearchForTriangulation2 (reference Snake/LocalMapping/MappingORBMatcher.cpp:14-99).  The host
+// intersects the two bag-of-words feature vectors; an item = (feature of keyframe 1, [lo, hi) of the matching node's
+// list in feat2).  Node lists are short (a handful of features), so 16 lanes share one item.
+__global__ __launch_bounds__(256) void triangulate_bow_kernel(EpiDev T, const int4* __restrict__ items, int n_items,
+                                                              const double* __restrict__ np1, const uint4* __restrict__ desc1,
+                                                              const double* __restrict__ np2, const uint4* __restrict__ desc2,
+                                                              const u8* __restrict__ has2, const int* __restrict__ feat2,
+                                                              int* __restrict__ out)
+{
+    const int item = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const int4 it  = items[item < n_items ? item : n_items - 1];
+    const int idx1 = it.x, lo = it.y, hi = it.z;
+    double l0, l1, l2, ln;
+    epi_line(T, np1[2 * idx1], np1[2 * idx1 + 1], l0, l1, l2, ln);
+    const uint4 qa = desc1[(size_t)idx1 * 2], qc = desc1[(size_t)idx1 * 2 + 1];
+    // "dist > bestDist -> continue" keeps the LAST candidate of minimal distance: key = dist | reversed list position
+    u32 k1 = PJ_INF_KEY;
+    for (int v = lo + sub; v < hi; v += 16)
+    {
+        const int idx2 = feat2[v];
+        if (has2[idx2]) continue;
+        const uint4 ta = desc2[(size_t)idx2 * 2], tc = desc2[(size_t)idx2 * 2 + 1];
+        const int d    = hamming256(qa, qc, ta, tc);
+        if (d > T.feature_distance || d > 50) continue;  // TH_LOW
+        const double dd = np2[2 * idx2] * l0 + np2[2 * idx2 + 1] * l1 + l2;
+        if (!(dd * dd / ln < T.th_chi2)) continue;
+        const u32 key = ((u32)d << PJ_IDX_BITS) | (PJ_IDX_MASK - (u32)(v - lo));
+        k1            = key < k1 ? key : k1;
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1)
+    {
+        const u32 o = __shfl_xor(k1, off);
+        k1          = o < k1 ? o : k1;
+    }
+    if (sub == 0 && item < n_items) out[item] = k1 != PJ_INF_KEY ? feat2[lo + (int)(PJ_IDX_MASK - (k1 & PJ_IDX_MASK))] : -1;
+}
+
+// MappingORBMatcher::SearchForTriangulationBF (reference Snake/LocalMapping/MappingORBMatcher.cpp:102-165).  One
+// wavefront per feature of keyframe 1 against every feature of keyframe 2: epipolar gate first, then Hamming.
+__global__ __launch_bounds__(256) void triangulate_bf_kernel(EpiDev T, const double* __restrict__ np1, const uint4* __restrict__ desc1,
+                                                             const u8* __restrict__ has1, int n1, const double* __restrict__ np2,
+                                                             const uint4* __restrict__ desc2, const u8* __restrict__ has2, int n2,
+                                                             int* __restrict__ out)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= n1) return;
+    int result = -1;
+    if (!has1[i])
+    {
+        double l0, l1, l2, ln;
+        epi_line(T, np1[2 * i], np1[2 * i + 1], l0, l1, l2, ln);
+        const uint4 qa = desc1[(size_t)i * 2], qc = desc1[(size_t)i * 2 + 1];
+        u32 k1 = PJ_INF_KEY;
+        for (int j = lane; j < n2; j += 64)
+        {
+            if (has2[j]) continue;
+            const double dd = np2[2 * j] * l0 + np2[2 * j + 1] * l1 + l2;
+            if (dd * dd / ln > T.th_chi2) continue;
+            const uint4 ta = desc2[(size_t)j * 2], tc = desc2[(size_t)j * 2 + 1];
+            const int d    = hamming256(qa, qc, ta, tc);
+            if (d > T.feature_distance || d > 50) continue;  // TH_LOW
+            const u32 key = ((u32)d << PJ_IDX_BITS) | (PJ_IDX_MASK - (u32)j);
+            k1            = key < k1 ? key : k1;
+        }
+        k1 = wave_min_u32(k1);
+        if (k1 != PJ_INF_KEY) result = (int)(PJ_IDX_MASK - (k1 & PJ_IDX_MASK));
+    }
+    if (lane == 0) out[i] = result;
+}
+
+// DeferredMapper::Relink, per-observation search (reference Snake/Optimizer/DeferredMapper.cpp:61-138).  The query disc
+// (0.8 px) touches 1-4 grid cells with a handful of features: 16 lanes per query.
+__global__ __launch_bounds__(256) void relink_kernel(FrameDev F, CamDev C, const snk_relink_query* __restrict__ qs, int n,
+                                                     float radius, double out2, int feature_threshold, int* __restrict__ action,
+                                                     int* __restrict__ best)
+{
+    const int q = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const snk_relink_query& Q = qs[q < n ? q : n - 1];
+    const int i      = Q.feature;
+    const double pcx = C.R[0] * Q.pos[0] + C.R[1] * Q.pos[1] + C.R[2] * Q.pos[2] + C.t[0];
+    const double pcy = C.R[3] * Q.pos[0] + C.R[4] * Q.pos[1] + C.R[5] * Q.pos[2] + C.t[1];
+    const double z   = C.R[6] * Q.pos[0] + C.R[7] * Q.pos[1] + C.R[8] * Q.pos[2] + C.t[2];
+    const double ipx = C.fx * pcx / z + C.cx, ipy = C.fy * pcy / z + C.cy;
+    const snk_kp64 ki = F.kps[i];
+    const double ex = ipx - ki.x, ey = ipy - ki.y;
+    const double rep2 = ex * ex + ey * ey;
+    int act = 0, res = -1;
+    if (z <= 0 || rep2 > out2)
+        act = 1;  // also covers a NaN / infinite projection of a point on the camera plane only through z <= 0
+    u32 k1 = PJ_INF_KEY;
+    if (act == 0)
+    {
+        uint4 qa, qc;
+        split_desc(Q.desc, qa, qc);
+        int fd = hamming256(qa, qc, F.desc[(size_t)i * 2], F.desc[(size_t)i * 2 + 1]);
+        if (fd == 0 && Q.has_alt)
+        {
+            uint4 aa, ac;
+            split_desc(Q.alt_desc, aa, ac);
+            fd = hamming256(qa, qc, aa, ac);
+        }
+        const double r = (double)radius, r2 = (double)(radius * radius), ur = ipx - C.bf / z;
+        const int cx0 = cell_coord(ipx - r, F.min_x, F.cols), cx1 = cell_coord(ipx + r, F.min_x, F.cols);
+        const int cy0 = cell_coord(ipy - r, F.min_y, F.rows), cy1 = cell_coord(ipy + r, F.min_y, F.rows);
+        // "featureDist2 < bestDist" keeps the FIRST candidate of minimal distance: key = dist | index (grid order ==
+        // iteration order)
+        for (int cx = cx0; cx <= cx1; ++cx)
+        {
+            const int lo = F.cell_start[cx * F.rows + cy0], hi = F.cell_start[cx * F.rows + cy1 + 1];
+            for (int pid = lo + sub; pid < hi; pid += 16)
+            {
+                const snk_kp64 kp = F.kps[pid];
+                const double ax = kp.x - ipx, ay = kp.y - ipy;
+                if (!(ax * ax + ay * ay < r2) || pid == i) continue;
+                const double dx = ipx - kp.x, dy = ipy - kp.y;
+                if (dx * dx + dy * dy > rep2) continue;
+                const float rp = F.right_points[pid];
+                if (rp > 0)
+                {
+                    const double er = ur - (double)rp;
+                    if (er * er > rep2 * 2.0) continue;
+                }
+                const int d2 = hamming256(qa, qc, F.desc[(size_t)pid * 2], F.desc[(size_t)pid * 2 + 1]);
+                if (!(d2 < feature_threshold && d2 < fd)) continue;
+                const u32 key = ((u32)d2 << PJ_IDX_BITS) | (u32)pid;
+                k1            = key < k1 ? key : k1;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1)
+    {
+        const u32 o = __shfl_xor(k1, off);
+        k1          = o < k1 ? o : k1;
+    }
+    if (k1 != PJ_INF_KEY)
+    {
+        act = 2;
+        res = (int)(k1 & PJ_IDX_MASK);
+    }
+    if (sub == 0 && q < n)
+    {
+        action[q] = act;
+        best[q]   = res;
+    }
+}
+
 int make_cam(const snk_camera* cam, const double* pose, CamDev* c)
 {
     SNK_REQUIRE(cam != nullptr && pose != nullptr, "camera / pose is NULL");
@@ -967,6 +1133,189 @@ int snk_match_triangulation_project(snk_matcher* m, const double* depth_grid, in
     int cnt = 0;
     for (int i = 0; i < n1; ++i) cnt += match_idx2[i] >= 0 ? 1 : 0;
     *n_matches = cnt;
+    return SNK_OK;
+}
+
+namespace
+{
+int check_bow(const snk_bow_features* b, int n)
+{
+    SNK_REQUIRE(b != nullptr && b->n_nodes >= 0, "bag-of-words feature vector is NULL");
+    if (b->n_nodes == 0) return SNK_OK;
+    SNK_REQUIRE(b->node_id && b->node_start && b->node_start[0] >= 0, "NULL bag-of-words arrays");
+    for (int k = 0; k < b->n_nodes; ++k)
+    {
+        SNK_REQUIRE(b->node_start[k + 1] >= b->node_start[k], "node_start must be non-decreasing");
+        SNK_REQUIRE(k == 0 || b->node_id[k] > b->node_id[k - 1], "node ids must be strictly ascending");
+    }
+    SNK_REQUIRE(b->node_start[b->n_nodes] == b->node_start[0] || b->features != nullptr, "NULL bag-of-words feature list");
+    for (int v = b->node_start[0]; v < b->node_start[b->n_nodes]; ++v)
+        SNK_REQUIRE(b->features[v] >= 0 && b->features[v] < n, "bag-of-words feature index out of range");
+    return SNK_OK;
+}
+
+// np | desc | has of one keyframe, packed into `buf`
+struct KfDev
+{
+    const double* np;
+    const uint4* desc;
+    const u8* has;
+};
+int upload_kf(snk_matcher* m, snk::DevBuf& buf, const double (*np)[2], const uint64_t (*desc)[4], const uint8_t* has, int n,
+              size_t extra, KfDev* K, char** extra_ptr)
+{
+    const size_t nn = (size_t)n, o_d = nn * 16, o_h = o_d + nn * 32, o_x = (o_h + nn + 15) & ~(size_t)15;
+    int rc = buf.reserve(o_x + extra + 16);
+    if (rc != SNK_OK) return rc;
+    char* d = buf.as<char>();
+    if (n)
+    {
+        SNK_HIP_CHECK(hipMemcpyAsync(d, np, nn * 16, hipMemcpyHostToDevice, m->stream));
+        SNK_HIP_CHECK(hipMemcpyAsync(d + o_d, desc, nn * 32, hipMemcpyHostToDevice, m->stream));
+        SNK_HIP_CHECK(hipMemcpyAsync(d + o_h, has, nn, hipMemcpyHostToDevice, m->stream));
+    }
+    K->np   = reinterpret_cast<const double*>(d);
+    K->desc = reinterpret_cast<const uint4*>(d + o_d);
+    K->has  = reinterpret_cast<const u8*>(d + o_h);
+    if (extra_ptr) *extra_ptr = d + o_x;
+    return SNK_OK;
+}
+}  // namespace
+
+int snk_match_triangulation_bow(snk_matcher* m, const snk_camera* cam, const double E12[9], const double (*np1)[2],
+                                const uint64_t (*desc1)[4], const uint8_t* has_mp1, int n1, const snk_bow_features* bow1,
+                                const double (*np2)[2], const uint64_t (*desc2)[4], const uint8_t* has_mp2, int n2,
+                                const snk_bow_features* bow2, float epipolar_distance, int feature_distance, int32_t (*pairs)[2],
+                                int* n_matches)
+{
+    SNK_REQUIRE(m != nullptr && n_matches != nullptr, "NULL argument");
+    *n_matches = 0;
+    SNK_REQUIRE(cam != nullptr && E12 != nullptr, "camera / E is NULL");
+    SNK_REQUIRE(n1 >= 0 && n1 < (int)PJ_IDX_MASK && (n1 == 0 || (np1 && desc1 && has_mp1)), "bad keyframe-1 arrays");
+    SNK_REQUIRE(n2 >= 0 && n2 < (int)PJ_IDX_MASK && (n2 == 0 || (np2 && desc2 && has_mp2)), "bad keyframe-2 arrays");
+    int rc;
+    if ((rc = check_bow(bow1, n1)) != SNK_OK) return rc;
+    if ((rc = check_bow(bow2, n2)) != SNK_OK) return rc;
+    // intersect the two ascending node lists (:34-98); one item per unmatched keyframe-1 feature of a common node,
+    // in the order the reference visits them
+    std::vector<int4> items;
+    for (int a = 0, b = 0; a < bow1->n_nodes && b < bow2->n_nodes;)
+    {
+        if (bow1->node_id[a] == bow2->node_id[b])
+        {
+            const int lo = bow2->node_start[b], hi = bow2->node_start[b + 1];
+            if (hi > lo)
+                for (int u = bow1->node_start[a]; u < bow1->node_start[a + 1]; ++u)
+                    if (!has_mp1[bow1->features[u]]) items.push_back(make_int4(bow1->features[u], lo, hi, 0));
+            ++a;
+            ++b;
+        }
+        else if (bow1->node_id[a] < bow2->node_id[b])
+            ++a;
+        else
+            ++b;
+    }
+    const int n_items = (int)items.size();
+    if (n_items == 0) return SNK_OK;
+    SNK_REQUIRE(pairs != nullptr, "pairs is NULL");
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    const size_t nf2 = (size_t)bow2->node_start[bow2->n_nodes];
+    KfDev K1, K2;
+    char *x1 = nullptr, *x2 = nullptr;
+    if ((rc = upload_kf(m, m->q, np1, desc1, has_mp1, n1, (size_t)n_items * sizeof(int4), &K1, &x1)) != SNK_OK) return rc;
+    if ((rc = upload_kf(m, m->t, np2, desc2, has_mp2, n2, nf2 * 4, &K2, &x2)) != SNK_OK) return rc;
+    if ((rc = m->out.reserve((size_t)n_items * 4)) != SNK_OK) return rc;
+    SNK_HIP_CHECK(hipMemcpyAsync(x1, items.data(), (size_t)n_items * sizeof(int4), hipMemcpyHostToDevice, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(x2, bow2->features, nf2 * 4, hipMemcpyHostToDevice, m->stream));
+    EpiDev T;
+    memcpy(T.E, E12, sizeof(T.E));
+    const double th_chi1 = (double)(epipolar_distance * 2) / cam->fx;  // :20
+    T.th_chi2            = th_chi1 * th_chi1;
+    T.feature_distance   = feature_distance;
+    hipLaunchKernelGGL(triangulate_bow_kernel, dim3(ceil_div(n_items, 16)), dim3(256), 0, m->stream, T,
+                       reinterpret_cast<const int4*>(x1), n_items, K1.np, K1.desc, K2.np, K2.desc, K2.has,
+                       reinterpret_cast<const int*>(x2), m->out.as<int>());
+    SNK_LAUNCH_CHECK();
+    std::vector<int> best((size_t)n_items);
+    SNK_HIP_CHECK(hipMemcpyAsync(best.data(), m->out.p, (size_t)n_items * 4, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    int cnt = 0;
+    for (int k = 0; k < n_items; ++k)
+        if (best[k] >= 0)
+        {
+            pairs[cnt][0] = items[k].x;
+            pairs[cnt][1] = best[k];
+            ++cnt;
+        }
+    *n_matches = cnt;
+    return SNK_OK;
+}
+
+int snk_match_triangulation_bf(snk_matcher* m, const snk_camera* cam, const double E12[9], const double (*np1)[2],
+                               const uint64_t (*desc1)[4], const uint8_t* has_mp1, int n1, const double (*np2)[2],
+                               const uint64_t (*desc2)[4], const uint8_t* has_mp2, int n2, int feature_distance,
+                               int32_t* match_idx2, int* n_matches)
+{
+    SNK_REQUIRE(m != nullptr && n_matches != nullptr, "NULL argument");
+    *n_matches = 0;
+    SNK_REQUIRE(cam != nullptr && E12 != nullptr, "camera / E is NULL");
+    SNK_REQUIRE(n1 >= 0 && (n1 == 0 || (np1 && desc1 && has_mp1 && match_idx2)), "bad keyframe-1 arrays");
+    SNK_REQUIRE(n2 >= 0 && n2 < (int)PJ_IDX_MASK && (n2 == 0 || (np2 && desc2 && has_mp2)), "bad keyframe-2 arrays");
+    if (n1 == 0) return SNK_OK;
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    int rc;
+    KfDev K1, K2;
+    if ((rc = upload_kf(m, m->q, np1, desc1, has_mp1, n1, 0, &K1, nullptr)) != SNK_OK) return rc;
+    if ((rc = upload_kf(m, m->t, np2, desc2, has_mp2, n2, 0, &K2, nullptr)) != SNK_OK) return rc;
+    if ((rc = m->out.reserve((size_t)n1 * 4)) != SNK_OK) return rc;
+    EpiDev T;
+    memcpy(T.E, E12, sizeof(T.E));
+    const double th_chi1 = 10 / cam->fx;  // :107 (the epipolarDistance argument is not used by the reference)
+    T.th_chi2            = th_chi1 * th_chi1;
+    T.feature_distance   = feature_distance;
+    hipLaunchKernelGGL(triangulate_bf_kernel, dim3(ceil_div(n1, 4)), dim3(256), 0, m->stream, T, K1.np, K1.desc, K1.has, n1, K2.np,
+                       K2.desc, K2.has, n2, m->out.as<int>());
+    SNK_LAUNCH_CHECK();
+    SNK_HIP_CHECK(hipMemcpyAsync(match_idx2, m->out.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    int cnt = 0;
+    for (int i = 0; i < n1; ++i) cnt += match_idx2[i] >= 0 ? 1 : 0;
+    *n_matches = cnt;
+    return SNK_OK;
+}
+
+int snk_match_relink(snk_matcher* m, const snk_frame_view* frame, const snk_camera* cam, const double pose[7],
+                     const snk_relink_query* queries, int n, float radius, double outlier_threshold, int feature_threshold,
+                     int32_t* action, int32_t* best_idx, int* n_changed)
+{
+    SNK_REQUIRE(m != nullptr && n_changed != nullptr, "NULL argument");
+    *n_changed = 0;
+    SNK_REQUIRE(n >= 0 && (n == 0 || (queries && action && best_idx)), "bad query arrays");
+    SNK_REQUIRE(radius >= 0.f && outlier_threshold >= 0.0, "bad thresholds");
+    CamDev C;
+    FrameDev F;
+    int rc;
+    if ((rc = make_cam(cam, pose, &C)) != SNK_OK) return rc;
+    SNK_REQUIRE(frame != nullptr, "frame view is NULL");
+    for (int q = 0; q < n; ++q) SNK_REQUIRE(queries[q].feature >= 0 && queries[q].feature < frame->n, "query feature out of range");
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    if ((rc = upload_frame(m, frame, &F)) != SNK_OK) return rc;
+    if (n == 0) return SNK_OK;
+    const size_t nq = (size_t)n;
+    if ((rc = m->q.reserve(nq * sizeof(snk_relink_query))) != SNK_OK) return rc;
+    if ((rc = m->out.reserve(nq * 8)) != SNK_OK) return rc;
+    SNK_HIP_CHECK(hipMemcpyAsync(m->q.p, queries, nq * sizeof(snk_relink_query), hipMemcpyHostToDevice, m->stream));
+    int* d_action = m->out.as<int>();
+    int* d_best   = d_action + nq;
+    hipLaunchKernelGGL(relink_kernel, dim3(ceil_div(n, 16)), dim3(256), 0, m->stream, F, C, m->q.as<snk_relink_query>(), n, radius,
+                       outlier_threshold * outlier_threshold, feature_threshold, d_action, d_best);
+    SNK_LAUNCH_CHECK();
+    SNK_HIP_CHECK(hipMemcpyAsync(action, d_action, nq * 4, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(best_idx, d_best, nq * 4, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    int cnt = 0;
+    for (int q = 0; q < n; ++q) cnt += action[q] != 0 ? 1 : 0;
+    *n_changed = cnt;
     return SNK_OK;
 }
 }

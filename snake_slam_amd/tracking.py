@@ -118,8 +118,9 @@ FUSION_POINT_DTYPE = np.dtype([("pos", "<f8", 3), ("normal", "<f8", 3), ("desc",
 
 
 class MappingORBMatcher(_Handle):
-    """Mirrors ``Snake::MappingORBMatcher`` (reference Snake/LocalMapping/MappingORBMatcher.h:15-45) for the two
-    matchers that need no bag-of-words: ``Fuse`` (LocalMap overload) and ``SearchForTriangulationProject``."""
+    """Mirrors ``Snake::MappingORBMatcher`` (reference Snake/LocalMapping/MappingORBMatcher.h:15-45): ``Fuse``
+    (LocalMap overload), ``SearchForTriangulation2`` (bag-of-words feature vectors as input),
+    ``SearchForTriangulationBF`` and ``SearchForTriangulationProject``."""
 
     def Fuse(self, frame, cam, pose, points, point_mask, th, obs_factor, feature_th, level_scale):
         """Returns (fusedPoints, fuseCandidates [(feature index, point id)] in point order, best_idx[m])."""
@@ -165,6 +166,95 @@ class MappingORBMatcher(_Handle):
                                                              C.byref(n)), "snk_match_triangulation_project")
         out = out[: len(k1)]
         return n.value, [(int(i), int(out[i])) for i in np.nonzero(out >= 0)[0]], out
+
+
+    @staticmethod
+    def _kf(np_, desc, has_mp):
+        p = np.ascontiguousarray(np_, np.float64).reshape(-1, 2)
+        d = np.ascontiguousarray(desc, np.uint64).reshape(-1, 4)
+        h = np.ascontiguousarray(has_mp, np.uint8)
+        if not (len(p) == len(d) == len(h)):
+            raise ValueError("array lengths")
+        return p, d, h
+
+    def SearchForTriangulation2(self, cam, E, np1, desc1, has_mp1, bow1, np2, desc2, has_mp2, bow2, epipolarDistance,
+                                featureDistance):
+        """bow = (node_id ascending, node_start[k + 1], features) = frame->bow_feature_vec flattened.
+        Returns (nmatches, vMatchedPairs [(idx1, idx2)] in the reference's emplace order)."""
+        p1, d1, h1 = self._kf(np1, desc1, has_mp1)
+        p2, d2, h2 = self._kf(np2, desc2, has_mp2)
+        b1, keep1 = bow_features(bow1)
+        b2, keep2 = bow_features(bow2)
+        Ef = np.ascontiguousarray(E, np.float64).reshape(9)
+        pairs = np.zeros((max(len(keep1[2]), 1), 2), np.int32)
+        n = C.c_int(0)
+        c = Camera(*cam)
+        _lib.check(self._lib.snk_match_triangulation_bow(self._h, C.byref(c), _ptr(Ef), _ptr(p1), _ptr(d1), _ptr(h1), len(p1),
+                                                         C.byref(b1), _ptr(p2), _ptr(d2), _ptr(h2), len(p2), C.byref(b2),
+                                                         float(epipolarDistance), int(featureDistance), _ptr(pairs), C.byref(n)),
+                   "snk_match_triangulation_bow")
+        return n.value, [(int(a), int(b)) for a, b in pairs[: n.value]]
+
+    def SearchForTriangulationBF(self, cam, E12, np1, desc1, has_mp1, np2, desc2, has_mp2, featureDistance):
+        """Returns (nmatches, vMatchedPairs [(idx1, idx2)], match_idx2[n1])."""
+        p1, d1, h1 = self._kf(np1, desc1, has_mp1)
+        p2, d2, h2 = self._kf(np2, desc2, has_mp2)
+        Ef = np.ascontiguousarray(E12, np.float64).reshape(9)
+        out = np.full(max(len(p1), 1), -1, np.int32)
+        n = C.c_int(0)
+        c = Camera(*cam)
+        _lib.check(self._lib.snk_match_triangulation_bf(self._h, C.byref(c), _ptr(Ef), _ptr(p1), _ptr(d1), _ptr(h1), len(p1), _ptr(p2),
+                                                        _ptr(d2), _ptr(h2), len(p2), int(featureDistance), _ptr(out), C.byref(n)),
+                   "snk_match_triangulation_bf")
+        out = out[: len(p1)]
+        return n.value, [(int(i), int(out[i])) for i in np.nonzero(out >= 0)[0]], out
+
+
+RELINK_QUERY_DTYPE = np.dtype([("pos", "<f8", 3), ("desc", "<u8", 4), ("alt_desc", "<u8", 4), ("feature", "<i4"), ("has_alt", "<i4")])
+RELINK_KEEP, RELINK_ERASE, RELINK_MOVE = 0, 1, 2
+
+
+class DeferredMapper(_Handle):
+    """The per-observation search of ``Snake::DeferredMapper::Relink`` (reference
+    Snake/Optimizer/DeferredMapper.cpp:39-165).  The map edits stay with the caller (see ``snk_match_relink``)."""
+
+    # reference constants, DeferredMapper.cpp:41-43
+    relink_reprojection_error_threshold = 0.8
+    relink_outlier_threshold = 2.1
+    relink_feature_threshold = 25
+
+    def RelinkSearch(self, frame, cam, pose, queries):
+        """queries: RELINK_QUERY_DTYPE, one per feature of the keyframe holding a good map point.
+        Returns (n_changed, action[n], best_idx[n])."""
+        v, keep = _view(frame)
+        q = np.ascontiguousarray(queries, RELINK_QUERY_DTYPE)
+        pose = np.ascontiguousarray(pose, np.float64)
+        action = np.zeros(max(len(q), 1), np.int32)
+        best = np.full(max(len(q), 1), -1, np.int32)
+        n = C.c_int(0)
+        c = Camera(*cam)
+        _lib.check(self._lib.snk_match_relink(self._h, C.byref(v), C.byref(c), _ptr(pose), _ptr(q), len(q),
+                                              float(self.relink_reprojection_error_threshold), float(self.relink_outlier_threshold),
+                                              int(self.relink_feature_threshold), _ptr(action), _ptr(best), C.byref(n)),
+                   "snk_match_relink")
+        return n.value, action[: len(q)], best[: len(q)]
+
+
+class BowFeatures(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("pad", C.c_int32), ("node_id", C.c_void_p), ("node_start", C.c_void_p),
+                ("features", C.c_void_p)]
+
+
+def bow_features(bow):
+    """(node_id, node_start, features) -> (snk_bow_features, arrays to keep alive)."""
+    ids = np.ascontiguousarray(bow[0], np.uint32)
+    start = np.ascontiguousarray(bow[1], np.int32)
+    feat = np.ascontiguousarray(bow[2], np.int32)
+    if len(start) != len(ids) + 1:
+        raise ValueError("node_start must have n_nodes + 1 entries")
+    b = BowFeatures(len(ids), 0, ids.ctypes.data if len(ids) else None, start.ctypes.data,
+                    feat.ctypes.data if len(feat) else None)
+    return b, (ids, start, feat)
 
 
 # ------------------------------------------------------------------ pose refinement ------------

@@ -6,6 +6,7 @@ ROOT = Path(__file__).resolve().parent.parent
 
 SRC = r'''
 #include "snake_hip.hpp"
+#include <map>
 int main(int argc, char**) {
     if (argc > 100) {  // never executed here (no GPU); exercises every template / inline path at compile time
         snake_hip::ORBExtractor ext(1000, 1.2f, 4, 20, 7, 2);
@@ -22,6 +23,11 @@ int main(int argc, char**) {
         snake_hip::MappingORBMatcher mm; std::vector<snk_fusion_point> fp; std::vector<std::pair<int, int>> fc;
         mm.Fuse(fv, cam, pose, {}, fp, fc, 4.f, 2.f, 50, {1.f, 1.2f}); double E[9] = {}; double g[4] = {};
         mm.SearchForTriangulationProject(g, 2, 2, pose, pose, cam, {}, {}, {}, {}, fv, {}, E, fc, 4.f, 50);
+        std::map<unsigned, std::vector<unsigned>> bowmap{{3u, {0u, 1u}}};
+        auto bow = snake_hip::MappingORBMatcher::BowFeatureVector::from(bowmap);
+        mm.SearchForTriangulation2(cam, E, {}, {}, {}, bow, {}, {}, {}, bow, fc, 4.f, 50);
+        mm.SearchForTriangulationBF(cam, E, {}, {}, {}, {}, {}, {}, fc, 50);
+        snake_hip::DeferredMapper dm; std::vector<snk_relink_query> rq; dm.RelinkSearch(fv, cam, pose, rq, match, match);
         snake_hip::PoseRefinement pr(1.0); std::vector<std::array<double, 3>> wps; std::vector<snk_pose_obs> po;
         pr.optimizePoseRobust(wps, po, vis, pose, cam); std::vector<snk_pose_problem> pb; pr.optimizeBatch(pb, cam);
         snake_hip::Scene sc; snake_hip::BARec ba; ba.create(sc); ba.initAndSolve(); ba.residualsSquared();

@@ -120,3 +120,90 @@ def test_triangulation_project_matches_brute_force(orc):
         assert n > 10 and (idx[c["has1"] == 1] == -1).all()
         got = idx[idx >= 0]
         assert (c["frame2"]["taken"][got] == 0).all()
+
+
+def _bow_call(orc, c, epi, fd):
+    return orc.match_triangulation_bow(c["cam"], c["E"], c["np1"], c["desc1"], c["has1"], c["bow1"], c["np2"], c["desc2"],
+                                       c["has2"], c["bow2"], epi, fd)
+
+
+def test_triangulation_bow_matches_brute_force(orc):
+    """MappingORBMatcher::SearchForTriangulation2: common vocabulary nodes, Hamming gate, then epipolar gate."""
+    for seed, epi, fd in [(41, 4.0, 50), (42, 1.0, 40), (43, 8.0, 64), (44, 4.0, 20)]:
+        rng = np.random.default_rng(SEED + seed)
+        c = T.make_bow_case(rng, m_pts=300, n_clutter=150, n_nodes=40)
+        n, pairs = _bow_call(orc, c, epi, fd)
+        want = T.brute_triangulation_bow(c, epi, fd)
+        assert n == len(want) and [tuple(p) for p in pairs.tolist()] == want
+        assert n > 10
+        assert (c["has1"][pairs[:, 0]] == 0).all() and (c["has2"][pairs[:, 1]] == 0).all()
+
+
+def test_triangulation_bow_edge_cases(orc):
+    rng = np.random.default_rng(SEED + 45)
+    c = T.make_bow_case(rng, m_pts=60, n_clutter=20, n_nodes=8)
+    # no common node
+    c2 = dict(c)
+    ids2, s2, f2 = c["bow2"]
+    c2["bow2"] = ((ids2 + 1).astype(np.uint32), s2, f2)
+    assert _bow_call(orc, c2, 4.0, 50)[0] == 0
+    # empty feature vectors
+    empty = (np.zeros(0, np.uint32), np.zeros(1, np.int32), np.zeros(0, np.int32))
+    c3 = dict(c, bow1=empty)
+    assert _bow_call(orc, c3, 4.0, 50)[0] == 0
+    c4 = dict(c, bow2=empty)
+    assert _bow_call(orc, c4, 4.0, 50)[0] == 0
+    # every feature of keyframe 2 already holds a point
+    c5 = dict(c, has2=np.ones_like(c["has2"]))
+    assert _bow_call(orc, c5, 4.0, 50)[0] == 0
+    # ties in Hamming distance: identical descriptors in one node -> the LAST candidate of the node's list wins (:66)
+    c6 = dict(c)
+    c6["desc2"] = np.repeat(c["desc1"][:1], len(c["desc2"]), 0)
+    c6["desc1"] = np.repeat(c["desc1"][:1], len(c["desc1"]), 0)
+    c6["has1"] = np.zeros_like(c["has1"])
+    c6["has2"] = np.zeros_like(c["has2"])
+    n, pairs = _bow_call(orc, c6, 1e6, 50)
+    want = T.brute_triangulation_bow(c6, 1e6, 50)
+    assert [tuple(p) for p in pairs.tolist()] == want and n > 0
+    ids2, s2, f2 = c6["bow2"]
+    last_of = {int(nid): int(f2[s2[k + 1] - 1]) for k, nid in enumerate(ids2) if s2[k + 1] > s2[k]}
+    ids1, s1, f1 = c6["bow1"]
+    node_of1 = {int(f): int(ids1[k]) for k in range(len(ids1)) for f in f1[s1[k]:s1[k + 1]]}
+    for i, j in pairs.tolist():
+        assert j == last_of[node_of1[i]]
+
+
+def test_triangulation_bf_matches_brute_force(orc):
+    """MappingORBMatcher::SearchForTriangulationBF: epipolar gate (10 px) then Hamming, all pairs."""
+    for seed, fd in [(51, 50), (52, 35), (53, 64)]:
+        rng = np.random.default_rng(SEED + seed)
+        c = T.make_bow_case(rng, m_pts=200, n_clutter=100)
+        n, idx = orc.match_triangulation_bf(c["cam"], c["E"], c["np1"], c["desc1"], c["has1"], c["np2"], c["desc2"], c["has2"], fd)
+        want = T.brute_triangulation_bf(c, fd)
+        assert np.array_equal(idx, want) and n == (want >= 0).sum()
+        assert n > 10 and (idx[c["has1"] == 1] == -1).all()
+    # empty sides
+    z2, zd, zh = np.zeros((0, 2)), np.zeros((0, 4), np.uint64), np.zeros(0, np.uint8)
+    assert orc.match_triangulation_bf(c["cam"], c["E"], z2, zd, zh, c["np2"], c["desc2"], c["has2"], 50)[0] == 0
+    n, idx = orc.match_triangulation_bf(c["cam"], c["E"], c["np1"], c["desc1"], c["has1"], z2, zd, zh, 50)
+    assert n == 0 and (idx == -1).all()
+
+
+def test_relink_matches_brute_force(orc):
+    """DeferredMapper::Relink per-observation search: outlier erase, radius query, stereo gate, strict improvement."""
+    for seed in (61, 62, 63):
+        rng = np.random.default_rng(SEED + seed)
+        frame, cam, pose, qs = T.make_relink_case(orc, rng, n_base=300)
+        n, action, best = orc.match_relink(frame, cam, pose, qs)
+        wa, wb = T.brute_relink(frame, cam, pose, qs)
+        assert np.array_equal(action, wa) and np.array_equal(best, wb)
+        assert n == (wa != 0).sum()
+        assert (wa == 1).sum() > 10 and (wa == 2).sum() > 10 and (wa == 0).sum() > 10
+        assert (best[action == 2] != qs["feature"][action == 2]).all()
+    assert orc.match_relink(frame, cam, pose, qs[:0])[0] == 0
+    # a tighter feature threshold can only remove relinks; thresholds are strict (<)
+    n25, a25, b25 = orc.match_relink(frame, cam, pose, qs, feature_threshold=25)
+    n1, a1, b1 = orc.match_relink(frame, cam, pose, qs, feature_threshold=1)
+    assert ((a1 == 2) <= (a25 == 2)).all()
+    for k in np.nonzero(a1 == 2)[0]:
+        assert T._ham(qs["desc"][k], frame["desc"][b1[k]]) == 0

@@ -162,3 +162,101 @@ def test_mapping_matchers_empty_inputs(orc, mapping_matcher):
                                                                   c["np1"][:0], c["desc1"][:0], c["has1"][:0], c["frame2"], c["np2"],
                                                                   c["E"], 4.0, 50)
     assert n == 0 and pairs == []
+
+
+def _orc_bow(orc, c, epi, fd):
+    n, pairs = orc.match_triangulation_bow(c["cam"], c["E"], c["np1"], c["desc1"], c["has1"], c["bow1"], c["np2"], c["desc2"],
+                                           c["has2"], c["bow2"], epi, fd)
+    return n, [tuple(p) for p in pairs.tolist()]
+
+
+def _gpu_bow(mm, c, epi, fd):
+    return mm.SearchForTriangulation2(c["cam"], c["E"], c["np1"], c["desc1"], c["has1"], c["bow1"], c["np2"], c["desc2"], c["has2"],
+                                      c["bow2"], epi, fd)
+
+
+@pytest.mark.parametrize("seed,epi,fd,nodes", [(71, 4.0, 50, 120), (72, 1.0, 40, 30), (73, 8.0, 64, 400), (74, 4.0, 20, 3)])
+def test_triangulation_bow_parity(orc, mapping_matcher, seed, epi, fd, nodes):
+    """SearchForTriangulation2 through the C ABI == oracle, pair for pair in the reference's order.  3 nodes: lists far
+    longer than the 16 lanes that share an item; 400 nodes: mostly 0-3 features per node."""
+    rng = np.random.default_rng(SEED + seed)
+    c = T.make_bow_case(rng, m_pts=1400, n_clutter=600, n_nodes=nodes)
+    n, pairs = _gpu_bow(mapping_matcher, c, epi, fd)
+    wn, wpairs = _orc_bow(orc, c, epi, fd)
+    assert n == wn and pairs == wpairs
+    assert n > 20
+
+
+def test_triangulation_bow_ties_and_edges(orc, mapping_matcher):
+    rng = np.random.default_rng(SEED + 75)
+    c = T.make_bow_case(rng, m_pts=300, n_clutter=100, n_nodes=6)
+    # identical descriptors everywhere: every candidate ties, the LAST of the node's list inside the band must win
+    c6 = dict(c, desc1=np.repeat(c["desc1"][:1], len(c["desc1"]), 0), desc2=np.repeat(c["desc1"][:1], len(c["desc2"]), 0))
+    for epi in (2.0, 1e6):
+        n, pairs = _gpu_bow(mapping_matcher, c6, epi, 50)
+        wn, wpairs = _orc_bow(orc, c6, epi, 50)
+        assert n == wn and pairs == wpairs and n > 0
+    empty = (np.zeros(0, np.uint32), np.zeros(1, np.int32), np.zeros(0, np.int32))
+    assert _gpu_bow(mapping_matcher, dict(c, bow1=empty), 4.0, 50) == (0, [])
+    assert _gpu_bow(mapping_matcher, dict(c, bow2=empty), 4.0, 50) == (0, [])
+    ids2, s2, f2 = c["bow2"]
+    assert _gpu_bow(mapping_matcher, dict(c, bow2=((ids2 + 1).astype(np.uint32), s2, f2)), 4.0, 50) == (0, [])
+    assert _gpu_bow(mapping_matcher, dict(c, has1=np.ones_like(c["has1"])), 4.0, 50) == (0, [])
+    assert _gpu_bow(mapping_matcher, dict(c, has2=np.ones_like(c["has2"])), 4.0, 50) == (0, [])
+    # malformed feature vectors are refused, not read
+    from snake_slam_amd._lib import SnakeHipError
+    bad = (c["bow1"][0], c["bow1"][1], c["bow1"][2].copy())
+    bad[2][0] = len(c["np1"])
+    with pytest.raises(SnakeHipError):
+        _gpu_bow(mapping_matcher, dict(c, bow1=bad), 4.0, 50)
+    with pytest.raises(SnakeHipError):
+        _gpu_bow(mapping_matcher, dict(c, bow2=(c["bow2"][0][::-1].copy(), c["bow2"][1], c["bow2"][2])), 4.0, 50)
+
+
+@pytest.mark.parametrize("seed,fd,m,clutter", [(81, 50, 1400, 600), (82, 35, 700, 1300), (83, 64, 40, 10)])
+def test_triangulation_bf_parity(orc, mapping_matcher, seed, fd, m, clutter):
+    rng = np.random.default_rng(SEED + seed)
+    c = T.make_bow_case(rng, m_pts=m, n_clutter=clutter)
+    n, pairs, idx = mapping_matcher.SearchForTriangulationBF(c["cam"], c["E"], c["np1"], c["desc1"], c["has1"], c["np2"], c["desc2"],
+                                                             c["has2"], fd)
+    wn, widx = orc.match_triangulation_bf(c["cam"], c["E"], c["np1"], c["desc1"], c["has1"], c["np2"], c["desc2"], c["has2"], fd)
+    assert n == wn and np.array_equal(idx, widx)
+    assert n > 5 and pairs == [(int(i), int(widx[i])) for i in np.nonzero(widx >= 0)[0]]
+    # empty sides
+    z2, zd, zh = np.zeros((0, 2)), np.zeros((0, 4), np.uint64), np.zeros(0, np.uint8)
+    assert mapping_matcher.SearchForTriangulationBF(c["cam"], c["E"], z2, zd, zh, c["np2"], c["desc2"], c["has2"], fd)[0] == 0
+    n, pairs, idx = mapping_matcher.SearchForTriangulationBF(c["cam"], c["E"], c["np1"], c["desc1"], c["has1"], z2, zd, zh, fd)
+    assert n == 0 and (idx == -1).all()
+
+
+@pytest.fixture(scope="module")
+def deferred_mapper():
+    from snake_slam_amd.tracking import DeferredMapper
+    return DeferredMapper()
+
+
+@pytest.mark.parametrize("seed,n_base", [(91, 1200), (92, 400), (93, 2500)])
+def test_relink_parity(orc, deferred_mapper, seed, n_base):
+    """DeferredMapper::Relink search through the C ABI == oracle (actions and targets)."""
+    rng = np.random.default_rng(SEED + seed)
+    frame, cam, pose, qs = T.make_relink_case(orc, rng, n_base=n_base)
+    n, action, best = deferred_mapper.RelinkSearch(frame, cam, pose, qs)
+    wn, wa, wb = orc.match_relink(frame, cam, pose, qs)
+    assert n == wn and np.array_equal(action, wa) and np.array_equal(best, wb)
+    assert (wa == 1).sum() > 10 and (wa == 2).sum() > 10 and (wa == 0).sum() > 10
+
+
+def test_relink_edges(orc, deferred_mapper):
+    from snake_slam_amd._lib import SnakeHipError
+    rng = np.random.default_rng(SEED + 94)
+    frame, cam, pose, qs = T.make_relink_case(orc, rng, n_base=100)
+    n, action, best = deferred_mapper.RelinkSearch(frame, cam, pose, qs[:0])
+    assert n == 0 and len(action) == 0
+    # 17 queries: one full 16-query block plus a ragged one
+    n, action, best = deferred_mapper.RelinkSearch(frame, cam, pose, qs[:17])
+    wn, wa, wb = orc.match_relink(frame, cam, pose, qs[:17])
+    assert n == wn and np.array_equal(action, wa) and np.array_equal(best, wb)
+    bad = qs[:3].copy()
+    bad["feature"][1] = len(frame["kps"])
+    with pytest.raises(SnakeHipError):
+        deferred_mapper.RelinkSearch(frame, cam, pose, bad)

@@ -337,3 +337,217 @@ def brute_triangulation(case, epipolar_distance, feature_distance):
             bd, bi = h, int(j)
         out[i] = bi
     return int((out >= 0).sum()), out
+
+
+# ---- bag-of-words / brute-force triangulation matchers (MappingORBMatcher::SearchForTriangulation2 / BF) ----
+def make_bow(labels):
+    """Flatten 'feature i belongs to vocabulary node labels[i]' into (node_id ascending, node_start, features), the
+    order DBoW2 fills a FeatureVector in (features of a node in ascending index)."""
+    labels = np.asarray(labels)
+    ids = np.unique(labels)
+    start, feat = [0], []
+    for nid in ids:
+        members = np.nonzero(labels == nid)[0]
+        feat.extend(members.tolist())
+        start.append(len(feat))
+    return ids.astype(np.uint32), np.asarray(start, np.int32), np.asarray(feat, np.int32)
+
+
+def make_bow_case(rng, m_pts=400, n_clutter=200, n_nodes=60, max_flip=60, has_frac=0.3):
+    """Two keyframes seeing the same points; node labels agree for most true correspondences."""
+    fx, fy, cx, cy = K_EUROC
+    poses = []
+    for k in range(2):
+        q = rng.normal(size=4) * 0.02 + np.array([0, 0, 0, 1.0])
+        q /= np.linalg.norm(q)
+        poses.append(np.concatenate([q, rng.normal(size=3) * 0.05 + np.array([0.6 * k, 0, 0])]))
+    R1, t1 = quat_R(poses[0][:4]), poses[0][4:]
+    R2, t2 = quat_R(poses[1][:4]), poses[1][4:]
+    pc1 = np.stack([rng.uniform(-3, 3, m_pts), rng.uniform(-2, 2, m_pts), rng.uniform(3, 9, m_pts)], 1)
+    pw = (pc1 - t1) @ R1
+    pc2 = pw @ R2.T + t2
+    pdesc = rng.integers(0, 2**64, size=(m_pts, 4), dtype=np.uint64)
+    plabel = rng.integers(0, n_nodes, m_pts) * 7 + 3  # sparse, non-contiguous node ids
+
+    def view(pc):
+        n = len(pc) + n_clutter
+        xy = np.zeros((n, 2))
+        xy[: len(pc), 0] = pc[:, 0] / pc[:, 2] + rng.normal(0, 0.3 / fx, len(pc))
+        xy[: len(pc), 1] = pc[:, 1] / pc[:, 2] + rng.normal(0, 0.3 / fy, len(pc))
+        xy[len(pc):] = rng.uniform(-0.7, 0.7, (n_clutter, 2))
+        d = np.concatenate([np.stack([flip_bits(rng, pdesc[i], int(rng.integers(0, max_flip + 1))) for i in range(len(pc))])
+                            if len(pc) else np.zeros((0, 4), np.uint64),
+                            rng.integers(0, 2**64, size=(n_clutter, 4), dtype=np.uint64)])
+        lab = np.concatenate([np.where(rng.random(len(pc)) < 0.9, plabel, rng.integers(0, n_nodes, len(pc)) * 7 + 3),
+                              rng.integers(0, n_nodes + 10, n_clutter) * 7 + 3])
+        o = rng.permutation(n)
+        return xy[o], d[o], lab[o], (rng.random(n) < has_frac).astype(np.uint8)
+
+    np1, d1, l1, h1 = view(pc1)
+    np2, d2, l2, h2 = view(pc2)
+    return dict(cam=(fx, fy, cx, cy, BF), E=essential(poses[0], poses[1]), np1=np1, desc1=d1, has1=h1, bow1=make_bow(l1),
+                np2=np2, desc2=d2, has2=h2, bow2=make_bow(l2))
+
+
+def _epi2(E, p1, p2):
+    l = E @ np.array([p1[0], p1[1], 1.0])
+    d = p2[0] * l[0] + p2[1] * l[1] + l[2]
+    return d * d / (l[0] * l[0] + l[1] * l[1])
+
+
+def _ham(a, b):
+    return sum(bin(int(x) ^ int(y)).count("1") for x, y in zip(a, b))
+
+
+def brute_triangulation_bow(c, epipolar_distance, feature_distance):
+    """numpy / python restatement: for every common node, every unmatched feature of keyframe 1 takes the LAST feature
+    of minimal Hamming distance (<= min(feature_distance, 50)) among the node's unmatched features of keyframe 2 that
+    lie strictly inside the epipolar band."""
+    fx = c["cam"][0]
+    th2 = (np.float64(np.float32(epipolar_distance) * np.float32(2)) / fx) ** 2
+    ids1, s1, f1 = c["bow1"]
+    ids2, s2, f2 = c["bow2"]
+    pos2 = {int(n): k for k, n in enumerate(ids2)}
+    pairs = []
+    for a, nid in enumerate(ids1):
+        if int(nid) not in pos2:
+            continue
+        b = pos2[int(nid)]
+        for i in f1[s1[a]:s1[a + 1]]:
+            if c["has1"][i]:
+                continue
+            best, bd = -1, 10**9
+            for j in f2[s2[b]:s2[b + 1]]:
+                if c["has2"][j]:
+                    continue
+                d = _ham(c["desc1"][i], c["desc2"][j])
+                if d > feature_distance or d > 50 or not (_epi2(c["E"], c["np1"][i], c["np2"][j]) < th2):
+                    continue
+                if d <= bd:
+                    best, bd = int(j), d
+            if best >= 0:
+                pairs.append((int(i), best))
+    return pairs
+
+
+def brute_triangulation_bf(c, feature_distance):
+    fx = c["cam"][0]
+    th2 = (10 / fx) ** 2
+    out = np.full(len(c["np1"]), -1)
+    E = c["E"]
+    d1 = c["desc1"]
+    d2 = c["desc2"]
+    x2 = d2[None, :, :]
+    for i in range(len(out)):
+        if c["has1"][i]:
+            continue
+        l = E @ np.array([c["np1"][i][0], c["np1"][i][1], 1.0])
+        dd = c["np2"][:, 0] * l[0] + c["np2"][:, 1] * l[1] + l[2]
+        ok = ~(dd * dd / (l[0] * l[0] + l[1] * l[1]) > th2) & (c["has2"] == 0)
+        if not ok.any():
+            continue
+        x = d2 ^ d1[i][None, :]
+        ham = np.zeros(len(d2), np.int64)
+        for w in range(4):
+            ham += np.array([bin(int(v)).count("1") for v in x[:, w]])
+        ok &= (ham <= feature_distance) & (ham <= 50)
+        if ok.any():
+            m = ham[ok].min()
+            out[i] = np.nonzero(ok & (ham == m))[0][-1]
+    return out
+
+
+# ---- DeferredMapper::Relink (per-observation search) ----
+def make_relink_case(orc, rng, n_base=500, twin_frac=0.5, point_frac=0.8):
+    """A keyframe whose features hold map points, with 'twin' features within a pixel of many projections.
+    Returns (frame dict in grid order, cam, pose, queries)."""
+    fx, fy, cx, cy = K_EUROC
+    q = rng.normal(size=4) * 0.05 + np.array([0, 0, 0, 1.0])
+    q /= np.linalg.norm(q)
+    pose = np.concatenate([q, rng.normal(size=3) * 0.2])
+    R, t = quat_R(q), pose[4:]
+    bx = rng.uniform(BOUNDS[0] + 5, BOUNDS[2] - 5, n_base)
+    by = rng.uniform(BOUNDS[1] + 5, BOUNDS[3] - 5, n_base)
+    feats, queries = [], []  # feats: (x, y, desc, right)
+    for i in range(n_base):
+        dmp = rng.integers(0, 2**64, size=4, dtype=np.uint64)
+        z = rng.uniform(3, 9)
+        # projection of the point: near the feature, sometimes an outlier, sometimes behind the camera
+        off = rng.normal(0, 0.7, 2) if rng.random() < 0.85 else rng.normal(0, 3.0, 2)
+        ipx, ipy = bx[i] + off[0], by[i] + off[1]
+        kd = flip_bits(rng, dmp, int(rng.choice([0, 0, 3, 10, 20, 30, 40])))
+        right = -1.0 if rng.random() < 0.5 else ipx - BF / z + rng.normal(0, 0.5)
+        me = len(feats)
+        feats.append((bx[i], by[i], kd, right))
+        if rng.random() < twin_frac:
+            for _ in range(int(rng.integers(1, 4))):
+                d = rng.normal(0, 0.45, 2)
+                td = flip_bits(rng, dmp, int(rng.choice([0, 2, 5, 10, 20, 24, 25, 30])))
+                tr = -1.0 if rng.random() < 0.5 else ipx - BF / z + rng.normal(0, 0.8)
+                feats.append((ipx + d[0], ipy + d[1], td, tr))
+        if rng.random() < point_frac:
+            if rng.random() < 0.03:
+                z = -z
+            pc = np.array([(ipx - cx) / fx * z, (ipy - cy) / fy * z, z])
+            wp = R.T @ (pc - t)
+            has_alt = int(rng.random() < 0.6)
+            alt = flip_bits(rng, dmp, int(rng.integers(0, 40)))
+            queries.append((wp, dmp, alt, me, has_alt))
+    n = len(feats)
+    k = np.zeros(n, orc.KP64)
+    k["x"] = np.clip([f[0] for f in feats], BOUNDS[0], BOUNDS[2] - 1e-6)
+    k["y"] = np.clip([f[1] for f in feats], BOUNDS[1], BOUNDS[3] - 1e-6)
+    k["octave"] = rng.integers(0, 4, n)
+    d = np.stack([f[2] for f in feats])
+    rp = np.array([f[3] for f in feats], np.float32)
+    perm, cell_start, cols, rows = orc.feature_grid(k, BOUNDS)
+    g_k, g_d, g_r = np.zeros_like(k), np.zeros_like(d), np.zeros_like(rp)
+    g_k[perm], g_d[perm], g_r[perm] = k, d, rp
+    frame = dict(kps=g_k, desc=g_d, right_points=g_r, taken=np.zeros(n, np.uint8), cell_start=cell_start, bounds=BOUNDS,
+                 cols=cols, rows=rows)
+    qs = np.zeros(len(queries), orc.RELINK_QUERY)
+    for j, (wp, dmp, alt, me, has_alt) in enumerate(queries):
+        qs["pos"][j], qs["desc"][j], qs["alt_desc"][j] = wp, dmp, alt
+        qs["feature"][j], qs["has_alt"][j] = perm[me], has_alt
+    return frame, (fx, fy, cx, cy, BF), pose, qs
+
+
+def brute_relink(frame, cam, pose, qs, radius=0.8, outlier_threshold=2.1, feature_threshold=25):
+    """Exhaustive restatement: scan EVERY feature of the keyframe instead of the grid cells."""
+    fx, fy, cx, cy, bf = cam
+    R, t = quat_R(pose[:4]), pose[4:]
+    kx, ky, rp = frame["kps"]["x"], frame["kps"]["y"], frame["right_points"]
+    r2 = np.float64(np.float32(radius) * np.float32(radius))
+    action, best = np.zeros(len(qs), np.int32), np.full(len(qs), -1, np.int32)
+    for n in range(len(qs)):
+        i = int(qs["feature"][n])
+        pc = R @ qs["pos"][n] + t
+        z = pc[2]
+        if z <= 0:
+            action[n] = 1
+            continue
+        ipx, ipy = fx * pc[0] / z + cx, fy * pc[1] / z + cy
+        rep2 = (ipx - kx[i]) ** 2 + (ipy - ky[i]) ** 2
+        if rep2 > outlier_threshold * outlier_threshold:
+            action[n] = 1
+            continue
+        fd = _ham(qs["desc"][n], frame["desc"][i])
+        if fd == 0 and qs["has_alt"][n]:
+            fd = _ham(qs["desc"][n], qs["alt_desc"][n])
+        e2 = (kx - ipx) ** 2 + (ky - ipy) ** 2
+        cand = np.nonzero(e2 < r2)[0]
+        bd, bi = fd, -1
+        # grid iteration order == ascending index in grid order (cells x-major, then y, then members)
+        for j in cand:
+            if j == i or (ipx - kx[j]) ** 2 + (ipy - ky[j]) ** 2 > rep2:
+                continue
+            if rp[j] > 0:
+                er = (ipx - bf / z) - np.float64(rp[j])
+                if er * er > rep2 * 2.0:
+                    continue
+            d2 = _ham(qs["desc"][n], frame["desc"][j])
+            if d2 < feature_threshold and d2 < bd:
+                bd, bi = d2, int(j)
+        if bi >= 0:
+            action[n], best[n] = 2, bi
+    return action, best
