@@ -252,6 +252,41 @@ __device__ __forceinline__ void load_tile(u32* tile, int pitch_dw, const u8* __r
     }
 }
 
+// Interior FAST tile with a row pitch of NQ 16-byte quads: item i = (row, quad) lands at LDS byte 16 * i, so a lane
+// moves 16 bytes with a handful of address instructions (the dword loader above pays ~25 per dword, three of them
+// quarter-rate 32-bit multiplies).  Global addresses are only 4-byte aligned; quads right of the tile are skipped.
+typedef u32 u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef u32 u32x4_a16 __attribute__((ext_vector_type(4), aligned(16)));
+
+template <int NQ>
+__device__ __forceinline__ void load_tile_quads(u32* tile, const u8* __restrict__ src, int pitch, int xs, int ys, int ndw, int nrows,
+                                                int lane)
+{
+    static_assert(NQ == 3 || NQ == 4, "row pitch of 48 or 64 bytes");
+    constexpr int B = 3;
+    const int items = nrows * NQ;
+    const u8* base  = src + (u32)(__mul24(ys, pitch) + xs);
+    u32x4_a16* tq   = reinterpret_cast<u32x4_a16*>(tile);
+    for (int i0 = lane; i0 < items; i0 += 64 * B)
+    {
+        u32x4_a4 v[B];
+        bool ok[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k)
+        {
+            const int i = i0 + 64 * k;
+            const int r = NQ == 4 ? i >> 2 : (i * 171) >> 9;  // i / 3 for i < 512
+            const int c = i - r * NQ;
+            ok[k]       = i < items && 4 * c < ndw;
+            v[k]        = u32x4_a4{0, 0, 0, 0};
+            if (ok[k]) v[k] = *reinterpret_cast<const u32x4_a4*>(base + (u32)(__mul24(r, pitch) + 16 * c));
+        }
+#pragma unroll
+        for (int k = 0; k < B; ++k)
+            if (ok[k]) tq[i0 + 64 * k] = v[k];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // FAST-9/16 score: S = max over the 16 arcs of 9 of min(ring - c), and of min(c - ring).
 // corner(t) <=> S > t.  Sliding-window minima by doubling (2,4,8,+1), two pixels per lane in packed
@@ -321,6 +356,9 @@ static inline int xcd_grid(int gx, int batch) { return gx * (batch >= 16 ? 8 * (
 // be corners; phase B evaluates the exact score only for those, densely, two per lane; NMS and the
 // threshold fallback then walk the compacted list.  LDS slice per wavefront (sizes from the layout):
 // image tile | score map with zero ring | quick-test survivors | NMS survivors | 3 counters.
+// NQ = 3 / 4: compile-time tile row pitch of 48 / 64 bytes and score-map pitch of 40 / 64 (what the layout picks
+// for cells up to 36 / 52 pixels wide): row addressing by shifts and the quad loader; NQ = 0: pitches from the layout.
+template <int NQ>
 __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restrict__ img0, int pitch0, long long stride0,
                                                    int aligned0, int ini_th, int min_th, u32* __restrict__ cand,
                                                    u16* __restrict__ cell_cnt, int gx, int batch)
@@ -336,7 +374,7 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
     u8* S             = slice + L.f_off_s;
     u16* surv         = reinterpret_cast<u16*>(slice + L.f_off_surv);
     u32* list         = reinterpret_cast<u32*>(slice + L.f_off_list);
-    const int TPD = L.f_tile_pitch_dw, TP = TPD * 4, SP = L.f_s_pitch;
+    const int TPD = NQ ? NQ * 4 : L.f_tile_pitch_dw, TP = TPD * 4, SP = NQ == 3 ? 40 : (NQ == 4 ? 64 : L.f_s_pitch);
 
     const int4 ct = L.cell_tab[cid];
     const int l   = ct.w;
@@ -357,8 +395,14 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
     const int xs  = (x0 - 3) & ~3;
     const int sh  = (x0 - 3) - xs;  // tile byte column of cell pixel px is px + 3 + sh
     const int ndw = (sh + cw + 6 + 3) >> 2;
-    load_tile<6>(tile_dw, TPD, src, pitch, lv.w, lv.h, xs, y0 - 3, ndw, ch + 6, aligned, lane, 64);
-    for (int i = lane; i < (ch + 2) * (SP >> 2); i += 64) reinterpret_cast<u32*>(S)[i] = 0;
+    // (tile-uniform) interior test of the quad loader: the last quad read of a row ends inside that row
+    if (NQ != 0 && aligned && xs >= 0 && xs + 16 * ((ndw + 3) >> 2) <= lv.w && y0 - 3 >= 0 && y0 + ch + 3 <= lv.h)
+    {
+        if constexpr (NQ != 0) load_tile_quads<NQ>(tile_dw, src, pitch, xs, y0 - 3, ndw, ch + 6, lane);
+    }
+    else
+        load_tile<6>(tile_dw, TPD, src, pitch, lv.w, lv.h, xs, y0 - 3, ndw, ch + 6, aligned, lane, 64);
+    for (int i = lane; i < (((ch + 2) * SP + 15) >> 4); i += 64) reinterpret_cast<u32x4_a16*>(S)[i] = u32x4_a16{0, 0, 0, 0};
     __builtin_amdgcn_wave_barrier();
     const u8* tile = reinterpret_cast<const u8*>(tile_dw);
 
@@ -367,21 +411,35 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
     // scalar register: position = count + prefix population of the ballot, no LDS atomic.
     int ns = 0;
     const int lpy = lane >> 5, lpx = lane & 31;
-    for (int py0 = 0; py0 < ch; py0 += 2)
-        for (int px0 = 0; px0 < cw; px0 += 32)
+    for (int px0 = 0; px0 < cw; px0 += 32)
+    {
+        // two rows of 32 pixels per step; a lane walks down its column: address and (py << 6 | px) code advance by
+        // constants, "inside the cell" is one compare of the code and a loop-invariant column mask.  Rows
+        // below / columns right of the cell read whatever follows in the wavefront's slice; they are masked.
+        const int px  = px0 + lpx;
+        const u8* t   = tile + (lpy + 3) * TP + px + 3 + sh;
+        u32 code      = ((u32)lpy << 6) | (u32)px;  // (py << 6) | px
+        const bool inx = px < cw;
+        const u64 mx   = __builtin_amdgcn_ballot_w64(inx);
+        const u64 mlo  = mx & 0xFFFFFFFFull;  // odd cell height: the last step only has its first row
+        auto step = [&](bool row_ok, u64 mrow)
         {
-            const int py = py0 + lpy, px = px0 + lpx;
-            const bool in = py < ch && px < cw;
-            const u8* t  = tile + (min(py, ch - 1) + 3) * TP + min(px, cw - 1) + 3 + sh;
             const int v  = t[0];
             const int d0 = t[3 * TP] - v, d8 = t[-3 * TP] - v, d4 = t[3] - v, d12 = t[-3] - v;
             const int ub_b = min(max(d0, d8), max(d4, d12));
             const int ub_d = min(max(-d0, -d8), max(-d4, -d12));
-            const bool sv  = in && (ub_b > min_th || ub_d > min_th);
-            const u64 m    = __ballot(sv);
-            if (sv) surv[ns + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u))] = (u16)((py << 6) | px);
+            const int ub   = max(ub_b, ub_d);
+            const bool sv  = row_ok && ub > min_th;
+            // ballot of the compare ANDed with the loop-invariant mask in scalar registers (a ballot of `sv` costs two
+            // more vector instructions per step)
+            const u64 m = mrow & __builtin_amdgcn_ballot_w64(ub > min_th);
+            if (sv) surv[ns + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u))] = (u16)code;
             ns += __popcll(m);
-        }
+        };
+        int py0 = 0;
+        for (; py0 + 2 <= ch; py0 += 2, t += 2 * TP, code += 128u) step(inx, mx);
+        if (py0 < ch) step(inx && lpy == 0, mlo);
+    }
     __builtin_amdgcn_wave_barrier();
 
     // phase B: exact score of the survivors, two per lane
@@ -416,13 +474,13 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
         const int v  = s[0];
         const bool keep = j < ns && v > min_th && v > s[-1] && v > s[1] && v > s[-SP - 1] && v > s[-SP] && v > s[-SP + 1] &&
                           v > s[SP - 1] && v > s[SP] && v > s[SP + 1];
-        const u64 m = __ballot(keep);
+        const u64 m = __builtin_amdgcn_ballot_w64(keep);
         // strength key: higher score first, then smaller y, then smaller x
         if (keep)
             list[nl + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u))] =
                 ((u32)v << 12) | ((u32)(63 - py) << 6) | (u32)(63 - px);
         nl += __popcll(m);
-        nini += __popcll(__ballot(keep && v > ini_th));
+        nini += __popcll(__builtin_amdgcn_ballot_w64(keep && v > ini_th));
     }
     __builtin_amdgcn_wave_barrier();
     const bool ini = nini > 0;
@@ -439,6 +497,17 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
         if (r < CELL_SLOTS) out[r] = k;
     }
     if (lane == 0) cell_cnt[cell_index] = (u16)(n > 65535 ? 65535 : n);
+}
+
+static inline int fast_quads(const Layout& L)
+{
+    return L.f_tile_pitch_dw == 12 && L.f_s_pitch == 40 ? 3 : (L.f_tile_pitch_dw == 16 && L.f_s_pitch == 64 ? 4 : 0);
+}
+static inline const void* fast_kernel_for(const Layout& L)
+{
+    const int fq = fast_quads(L);
+    return fq == 3 ? reinterpret_cast<const void*>(fast_kernel<3>)
+                   : (fq == 4 ? reinterpret_cast<const void*>(fast_kernel<4>) : reinterpret_cast<const void*>(fast_kernel<0>));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1458,8 +1527,11 @@ static int compute_layout(snk_orb* o, int w, int h)
         auto up16 = [](int v) { return (v + 15) & ~15; };
         L.f_tile_pitch_dw = (mw + 6 + 3 + 3) / 4;
         L.f_s_pitch       = (mw + 2 + 3) & ~3;
+        // compile-time pitches (fast_kernel<3> / <4>) when the widest cell allows, see fast_quads()
+        if (L.f_tile_pitch_dw <= 12 && L.f_s_pitch <= 40 && mh + 6 <= 128) { L.f_tile_pitch_dw = 12; L.f_s_pitch = 40; }
+        else if (L.f_tile_pitch_dw <= 16 && L.f_s_pitch <= 64 && mh + 6 <= 128) { L.f_tile_pitch_dw = 16; L.f_s_pitch = 64; }
         const int tile_b  = up16((mh + 6) * L.f_tile_pitch_dw * 4);
-        const int s_b     = up16((mh + 2) * L.f_s_pitch);
+        const int s_b     = up16((mh + 2) * L.f_s_pitch) + 16;  // zero-filled in 16-byte stores
         const int surv_b  = up16(mw * mh * 2);
         const int list_b  = up16(((mw + 1) / 2) * ((mh + 1) / 2) * 4);
         L.f_off_s    = tile_b;
@@ -1681,8 +1753,7 @@ int snk_orb_configure(snk_orb* o, int width, int height, int max_batch)
     if ((rc = o->dist_queue.reserve(snk_orb::MAX_PARTS * ((size_t)max_batch * MAX_LEVELS + 1) * sizeof(int))) != SNK_OK) return rc;  // one per chain
     SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(distribute_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->dist_lds_small));
-    SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      4 * L.f_lds_wave));
+    SNK_HIP_CHECK(hipFuncSetAttribute(fast_kernel_for(L), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * L.f_lds_wave));
     SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(distribute_large_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->dist_lds));
     o->width      = width;
@@ -1772,7 +1843,9 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
     if (L.total_cells > 0)
     {
         const int gx = ceil_div(L.total_cells, 4);
-        hipLaunchKernelGGL(fast_kernel, dim3(xcd_grid(gx, batch)), dim3(256), (size_t)4 * L.f_lds_wave, st, L, images_dev, pitch,
+        const int fq = fast_quads(L);
+        auto fk      = fq == 3 ? fast_kernel<3> : (fq == 4 ? fast_kernel<4> : fast_kernel<0>);
+        hipLaunchKernelGGL(fk, dim3(xcd_grid(gx, batch)), dim3(256), (size_t)4 * L.f_lds_wave, st, L, images_dev, pitch,
                            image_stride, aligned0, o->params.ini_th_fast, o->params.min_th_fast, d_cand, d_cellcnt, gx, batch);
         SNK_LAUNCH_CHECK();
     }

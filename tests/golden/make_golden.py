@@ -63,6 +63,7 @@ def main():
     np.savez_compressed(OUT / "ba_small.npz", **{f"in_{k}": np.asarray(v) for k, v in sc.items()}, pose=pose, pt=pt,
                         cost=np.array([c0, c1]), chi2=chi)
     make_pose()
+    make_track()
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size, "bytes")
 
@@ -82,8 +83,54 @@ def make_pose():
                         outlier_s=outl_s, inliers_s=inl_s, chi2=orc.pose_chi2(pose, cam, pr["wps"], pr["obs"]))
 
 
+def _flat_frame(prefix, frame):
+    return {f"{prefix}_{k}": np.asarray(v) for k, v in frame.items()}
+
+
+def make_track():
+    """Grid + projection matchers + keyframe-rate matchers: small seeded cases, inputs and oracle outputs."""
+    import track_helpers as T
+
+    orc.build()
+    out = {}
+    rng = np.random.default_rng(SEED + 900)
+    frame, cam, pose, ls, world, _ = T.make_tracking_case(orc, rng, n_clutter=150, m_pts=120)
+    out.update(_flat_frame("f", frame), cam=np.array(cam), pose=pose, ls=ls)
+    pc = T.lm_coarse(orc, world)
+    n, idx = orc.match_coarse(frame, cam, pose, pc, 15.0, 75, 0, ls)
+    out.update(coarse_pts=pc, coarse_idx=idx, coarse_n=n)
+    pf = T.lm_fine(orc, rng, world, pose, ls)
+    n, idx, vis, valid = orc.match_fine(frame, cam, pose, pf, 5.0, 0.8, ls)
+    out.update(fine_pts=pf, fine_idx=idx, fine_vis=vis, fine_valid=valid, fine_n=n)
+    skip = (rng.random(len(world["pos"])) < 0.1).astype(np.uint8)
+    n, idx = orc.match_keyframe(frame, cam, pose, world["pos"], world["desc"], skip, 15.0, 100)
+    out.update(kf_pos=world["pos"], kf_desc=world["desc"], kf_skip=skip, kf_idx=idx, kf_n=n)
+    fp = T.fusion_points(orc, rng, world, pose, ls)
+    mask = (rng.random(len(fp)) > 0.2).astype(np.uint8)
+    n, idx = orc.match_fuse(frame, cam, pose, fp, mask, 4.0, 2.0, 50, ls)
+    out.update(fuse_pts=fp, fuse_mask=mask, fuse_idx=idx, fuse_n=n)
+    c = T.make_triangulation_case(orc, rng, m_pts=150, n_clutter=80)
+    n, idx = orc.match_triangulation_project(c["grid"], c["pose1"], c["pose2"], c["cam"], c["kps1"], c["np1"], c["desc1"], c["has1"],
+                                             c["frame2"], c["np2"], c["E"], 4.0, 50)
+    out.update(_flat_frame("t2", c["frame2"]), t_grid=c["grid"], t_pose1=c["pose1"], t_pose2=c["pose2"], t_cam=np.array(c["cam"]),
+               t_kps1=c["kps1"], t_np1=c["np1"], t_desc1=c["desc1"], t_has1=c["has1"], t_np2=c["np2"], t_E=c["E"], t_idx=idx, t_n=n)
+    b = T.make_bow_case(rng, m_pts=150, n_clutter=80, n_nodes=25)
+    n, pairs = orc.match_triangulation_bow(b["cam"], b["E"], b["np1"], b["desc1"], b["has1"], b["bow1"], b["np2"], b["desc2"],
+                                           b["has2"], b["bow2"], 4.0, 50)
+    nb, ib = orc.match_triangulation_bf(b["cam"], b["E"], b["np1"], b["desc1"], b["has1"], b["np2"], b["desc2"], b["has2"], 50)
+    out.update(b_cam=np.array(b["cam"]), b_E=b["E"], b_np1=b["np1"], b_desc1=b["desc1"], b_has1=b["has1"], b_np2=b["np2"],
+               b_desc2=b["desc2"], b_has2=b["has2"], b_ids1=b["bow1"][0], b_start1=b["bow1"][1], b_feat1=b["bow1"][2],
+               b_ids2=b["bow2"][0], b_start2=b["bow2"][1], b_feat2=b["bow2"][2], b_pairs=pairs, b_n=n, bf_idx=ib, bf_n=nb)
+    rframe, rcam, rpose, qs = T.make_relink_case(orc, rng, n_base=120)
+    n, action, best = orc.match_relink(rframe, rcam, rpose, qs)
+    out.update(_flat_frame("r", rframe), r_cam=np.array(rcam), r_pose=rpose, r_queries=qs, r_action=action, r_best=best, r_n=n)
+    np.savez_compressed(OUT / "track_small.npz", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pose":  # regenerate only pose_small.npz
         make_pose()
+    elif len(sys.argv) > 1 and sys.argv[1] == "track":  # regenerate only track_small.npz
+        make_track()
     else:
         main()
