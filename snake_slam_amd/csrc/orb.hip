@@ -603,6 +603,11 @@ __global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* _
         dy_tab = lv.ymap[yb0 + lane];
         if (dy_tab >= 0) wy_tab = nx.yw1[dy_tab];
     }
+    // The two tables come from global loads issued before the row loop.  Inside the loop the compiler can no longer
+    // tell how many memory operations were issued after them and guards every v_readlane of them with
+    // s_waitcnt vmcnt(0) -- which also waits for all row loads in flight and for the previous rows' stores.
+    // Passing them through an empty asm makes them plain register values (one wait here, none in the loop).
+    asm volatile("" : "+v"(dy_tab), "+v"(wy_tab));
 
     // vertical window: pr[s][c] = H(row a) | H(row a + 1) << 16 of column c, written in slot (a + 1 - (yb0 - 3)) % 7
     u32 pr[7][4];
