@@ -556,11 +556,29 @@ __global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* _
     const int bpitch   = __builtin_amdgcn_readfirstlane(lv.pitch);
     const bool aligned = l == 0 ? aligned0 != 0 : true;
     const bool col_ok  = aligned && xl >= 0 && xl + 3 < lv.w;
-    const int xsafe    = min(max(xl, 0), (lv.w - 4) & ~3);  // aligned, inside the row
+    // aligned dword inside the row pitch; the dword holding column w - 1 may reach up to 3 bytes into the row padding
+    const int xsafe    = min(max(xl, 0), (lv.w - 1) & ~3);
     // lanes right of the image only matter up to column w + 2 (halo of the last pixel); clamping keeps
     // reflect101 inside its domain for strips much narrower than the wavefront (w < 126)
     const int xr0 = reflect101(min(xl, lv.w + 2), lv.w), xr1 = reflect101(min(xl + 1, lv.w + 2), lv.w),
               xr2 = reflect101(min(xl + 2, lv.w + 2), lv.w), xr3 = reflect101(min(xl + 3, lv.w + 2), lv.w);
+    // Border lanes (left halo of the first strip, lanes at / right of column w - 1) need reflect101 pixels.  Those
+    // are bytes of at most two other lanes' dwords of the same row: two ds_bpermute pulls and a byte select per row
+    // (per-lane source lanes / selector fixed for the whole band; interior lanes pull themselves) instead of
+    // dependent byte loads from global memory.
+    int pull_a = 4 * lane, pull_b = 4 * lane;
+    u32 pull_sel = 0x03020100u;
+    if (aligned && !col_ok)
+    {
+        const int org = sx0 - 4;
+        const int l0 = (xr0 - org) >> 2, l1 = (xr1 - org) >> 2, l2 = (xr2 - org) >> 2, l3 = (xr3 - org) >> 2;
+        const int la = min(min(l0, l1), min(l2, l3)), lb = max(max(l0, l1), max(l2, l3));
+        pull_a   = 4 * la;
+        pull_b   = 4 * lb;
+        pull_sel = (u32)((l0 == la ? 0 : 4) + (xr0 & 3)) | ((u32)((l1 == la ? 0 : 4) + (xr1 & 3)) << 8) |
+                   ((u32)((l2 == la ? 0 : 4) + (xr2 & 3)) << 16) | ((u32)((l3 == la ? 0 : 4) + (xr3 & 3)) << 24);
+    }
+    const bool border_strip = aligned && __any(!col_ok);  // wave-uniform
     u8* blur = lv.blur + (long long)b * lv.img_stride;
     const u32 W0123 = 18u | (33u << 8) | (49u << 16) | (56u << 24);
     const u32 W456  = 49u | (33u << 8) | (18u << 16);
@@ -622,7 +640,7 @@ __global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* _
         const int k0 = k00 + 7 * half;
         // The 7 row loads of a block are issued together and branch-free (a divergent branch around a
         // load makes the compiler wait for it inside the branch): every lane loads an aligned dword
-        // from a clamped column; lanes on the image border are patched afterwards (border strips only).
+        // from a clamped column; lanes on the image border are patched per row (border strips only).
         u32 dn[7];
         if (aligned)  // wave-uniform
         {
@@ -631,17 +649,6 @@ __global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* _
             {
                 const int y  = min(yb0 - 3 + k0 + kk, lv.h + 2);
                 dn[kk]       = *reinterpret_cast<const u32*>(src + (u32)(reflect101(y, lv.h) * pitch) + (u32)xsafe);
-            }
-            if (__any(!col_ok))  // wave-uniform
-            {
-#pragma unroll
-                for (int kk = 0; kk < 7; ++kk)
-                    if (!col_ok)
-                    {
-                        const int y  = min(yb0 - 3 + k0 + kk, lv.h + 2);
-                        const u8* rp = src + reflect101(y, lv.h) * pitch;
-                        dn[kk] = (u32)rp[xr0] | ((u32)rp[xr1] << 8) | ((u32)rp[xr2] << 16) | ((u32)rp[xr3] << 24);
-                    }
             }
         }
         else
@@ -661,7 +668,12 @@ __global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* _
             const int y = yb0 - 3 + k;
             if (y <= yb1 + 2)  // wave-uniform
             {
-                const u32 d = dn[kk];
+                u32 d = dn[kk];
+                if (border_strip)
+                {
+                    const u32 pa = (u32)__builtin_amdgcn_ds_bpermute(pull_a, (int)d), pb = (u32)__builtin_amdgcn_ds_bpermute(pull_b, (int)d);
+                    d            = __builtin_amdgcn_perm(pb, pa, pull_sel);
+                }
                 // ---- next pyramid level.  Row y is interpolated horizontally once (ac, v_dot2 of the
                 // tap pair with the weight pair); a destination row whose source rows are (y-1, y)
                 // combines it with the previous row's (ap).  With the y weights pre-multiplied by 4
