@@ -534,8 +534,11 @@ __device__ __forceinline__ u32 dot2(u32 pair, u32 w, u32 acc)
     return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pair), __builtin_bit_cast(u16x2, w), acc, false);
 }
 
+// ALIGNED = false: level 0 of an input whose base / pitch is not a multiple of 4 (byte loads; its own instantiation so
+// that the usual one does not carry the byte-column registers).
+template <bool ALIGNED>
 __global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* __restrict__ img0, int pitch0, long long stride0,
-                                                    int aligned0, int make_next, int gx, int batch)
+                                                    int make_next, int gx, int batch)
 {
     __shared__ u32 rowbuf[4][64];  // one raw row per wavefront (down-scale taps)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* _
     // 32-bit offsets inside one image (pitch * h < 2^31), scalars pinned in SGPRs
     const int pitch    = __builtin_amdgcn_readfirstlane(l == 0 ? pitch0 : lv.pitch);
     const int bpitch   = __builtin_amdgcn_readfirstlane(lv.pitch);
-    const bool aligned = l == 0 ? aligned0 != 0 : true;
+    constexpr bool aligned = ALIGNED;
     const bool col_ok  = aligned && xl >= 0 && xl + 3 < lv.w;
     // aligned dword inside the row pitch; the dword holding column w - 1 may reach up to 3 bytes into the row padding
     const int xsafe    = min(max(xl, 0), (lv.w - 1) & ~3);
@@ -1849,8 +1852,9 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
         if (tiny(l)) continue;
         {
             const int gx = ceil_div(lv.n_strips * lv.n_bands, 4);
-            hipLaunchKernelGGL(level_kernel, dim3(xcd_grid(gx, batch)), dim3(256), 0, st, L, l, images_dev, pitch, image_stride,
-                               aligned0, fused && l + 1 < L.n_levels ? 1 : 0, gx, batch);
+            auto lk = l == 0 && !aligned0 ? level_kernel<false> : level_kernel<true>;
+            hipLaunchKernelGGL(lk, dim3(xcd_grid(gx, batch)), dim3(256), 0, st, L, l, images_dev, pitch, image_stride,
+                               fused && l + 1 < L.n_levels ? 1 : 0, gx, batch);
         }
         SNK_LAUNCH_CHECK();
     }
