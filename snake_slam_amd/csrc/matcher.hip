@@ -121,6 +121,138 @@ __global__ __launch_bounds__(256) void bf_knn2_kernel(const uint4* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// kNN-2 on the matrix cores.  The 256-bit Hamming distance is h = |q| + |t| - 2 (q . t) with q . t the dot product of
+// the descriptors' bits -- an exact int8 GEMM.  The all-pairs scan is bound by the vector popcount rate (22 VALU
+// instructions per pair in bf_knn2_kernel); v_mfma_i32_32x32x32_i8 computes 32 x 32 dot products over 32 bit-bytes in
+// one instruction, leaving the vector ALU the top-2 bookkeeping (4 instructions per pair).
+//   workgroup = 4 wavefronts = 4 blocks of 32 queries; train descriptors go by in tiles of 32.
+//   bit -> byte expansion: byte c of dword ((w >> kc) & 0x01010101) is bit kc + 8 c of descriptor word w; lane group
+//   g = lane >> 5 takes the g-th 128-bit half, MFMA step kc the shift kc.  Queries (B operand) are expanded once into
+//   32 registers; every train tile is expanded once per workgroup into LDS (8 KiB, double buffered) and read as the
+//   A operand by the four wavefronts.  C[row = train][col = query]: lane holds 16 trains of query lane & 31
+//   (row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).
+//   keys: |t| << 20 | train index (per tile in LDS, sentinel for rows past nt) minus dot << 21 orders a query's
+//   candidates like distance << 20 | index (the query's own popcount is a constant, added at the end).
+// ------------------------------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+constexpr int BFM_SENTINEL = 0x7F000000;  // "no train": larger than any key, survives the subtraction of dot << 21 (dot = 0)
+
+__device__ __forceinline__ v4i expand_bits(const uint4& h, int kc)
+{
+    const u32 M = 0x01010101u;
+    return v4i{(int)((h.x >> kc) & M), (int)((h.y >> kc) & M), (int)((h.z >> kc) & M), (int)((h.w >> kc) & M)};
+}
+__device__ __forceinline__ int popc128(const uint4& h) { return __popc(h.x) + __popc(h.y) + __popc(h.z) + __popc(h.w); }
+__device__ __forceinline__ void insert2s(int& k1, int& k2, int key)
+{
+    const int hi = max(k1, key);
+    k1           = min(k1, key);
+    k2           = min(k2, hi);
+}
+
+__global__ __launch_bounds__(256) void bf_knn2_mfma_kernel(const uint4* __restrict__ query, const int* __restrict__ nq_dev,
+                                                           int nq_cap, int nq_host, const uint4* __restrict__ train,
+                                                           const int* __restrict__ nt_dev, int nt_cap, int nt_host,
+                                                           snk_knn2* __restrict__ out)
+{
+    __shared__ v4i As[2][8 * 2 * 32];  // [buffer][(kc * 2 + g) * 32 + train row]
+    __shared__ __attribute__((aligned(16))) int ptk[2][32];
+    const int b = blockIdx.y;
+    int nq      = nq_dev ? nq_dev[b] : nq_host;
+    int nt      = nt_dev ? nt_dev[b] : nt_host;
+    nq          = nq < nq_cap ? nq : nq_cap;
+    nt          = nt < nt_cap ? nt : nt_cap;
+    if ((int)blockIdx.x * 128 >= nq) return;  // whole workgroup
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int j = lane & 31, g = lane >> 5;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const uint4* qb = query + (size_t)b * nq_cap * 2;
+    const uint4* tb = train + (size_t)b * nt_cap * 2;
+
+    // B operand: this lane's half of query q0 + j, all 8 shifts
+    const int qi   = min(q0 + j, nq - 1);
+    const uint4 qh = qb[(size_t)qi * 2 + g], qo = qb[(size_t)qi * 2 + (1 - g)];
+    const int pq   = popc128(qh) + popc128(qo);
+    v4i B[8];
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) B[kc] = expand_bits(qh, kc);
+
+    // expansion role of this lane: train row e_i of the tile, half e_g, shifts 2 e_k and 2 e_k + 1
+    const int e_i = wave * 8 + (lane & 7), e_g = (lane >> 3) & 1, e_k = lane >> 4;
+    const int ntiles = (nt + 31) >> 5;
+    auto fetch = [&](int t, uint4& h, uint4& o)
+    {
+        const int ti = t * 32 + e_i;
+        h = o = uint4{0u, 0u, 0u, 0u};
+        if (ti < nt)
+        {
+            h = tb[(size_t)ti * 2 + e_g];
+            if (lane < 8) o = tb[(size_t)ti * 2 + 1];  // lanes 0..7 (e_g = 0, e_k = 0) also write the tile's popcount keys
+        }
+    };
+    auto expand = [&](int t, int buf, const uint4& h, const uint4& o)
+    {
+        As[buf][((2 * e_k) * 2 + e_g) * 32 + e_i]     = expand_bits(h, 2 * e_k);
+        As[buf][((2 * e_k + 1) * 2 + e_g) * 32 + e_i] = expand_bits(h, 2 * e_k + 1);
+        if (lane < 8)
+        {
+            const int ti   = t * 32 + e_i;
+            ptk[buf][e_i] = ti < nt ? (((popc128(h) + popc128(o)) << BF_IDX_BITS) | ti) : BFM_SENTINEL;
+        }
+    };
+
+    int k1 = BFM_SENTINEL, k2 = BFM_SENTINEL;
+    uint4 h, o;
+    if (ntiles > 0)
+    {
+        fetch(0, h, o);
+        expand(0, 0, h, o);
+        if (ntiles > 1) fetch(1, h, o);
+    }
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t)
+    {
+        const int buf = t & 1;
+        if (t + 1 < ntiles)
+        {
+            expand(t + 1, buf ^ 1, h, o);            // loaded one iteration ago
+            if (t + 2 < ntiles) fetch(t + 2, h, o);  // lands during this iteration
+        }
+        v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(As[buf][(kc * 2 + g) * 32 + j], B[kc], acc, 0, 0, 0);
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+        {
+            const v4i pk = *reinterpret_cast<const v4i*>(&ptk[buf][8 * rq + 4 * g]);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) insert2s(k1, k2, pk[rr] - (acc[4 * rq + rr] << (BF_IDX_BITS + 1)));
+        }
+        __syncthreads();
+    }
+    // the two halves of the wavefront hold disjoint trains of the same query
+    {
+        const int o1 = __shfl_xor(k1, 32), o2 = __shfl_xor(k2, 32);
+        const int lo = min(k1, o1), hi = max(k1, o1), m = min(k2, o2);
+        k1 = lo;
+        k2 = min(hi, m);
+    }
+    if (lane < 32 && q0 + lane < nq)
+    {
+        snk_knn2 r;
+        const int a1 = k1 >= BFM_SENTINEL - (1 << 30) ? -1 : k1 + (pq << BF_IDX_BITS);
+        const int a2 = k2 >= BFM_SENTINEL - (1 << 30) ? -1 : k2 + (pq << BF_IDX_BITS);
+        const bool v1 = a1 >= 0 && (a1 >> BF_IDX_BITS) < SNK_DIST_INF, v2 = a2 >= 0 && (a2 >> BF_IDX_BITS) < SNK_DIST_INF;
+        r.dist1 = v1 ? a1 >> BF_IDX_BITS : SNK_DIST_INF;
+        r.idx1  = v1 ? (int)((u32)a1 & BF_IDX_MASK) : -1;
+        r.dist2 = v2 ? a2 >> BF_IDX_BITS : SNK_DIST_INF;
+        r.idx2  = v2 ? (int)((u32)a2 & BF_IDX_MASK) : -1;
+        out[(size_t)b * nq_cap + q0 + lane] = r;
+    }
+}
+
 // Order-preserving compaction of the accepted (query, train) pairs; one workgroup per batch entry.
 __global__ __launch_bounds__(256) void bf_filter_kernel(const snk_knn2* __restrict__ knn, const int* __restrict__ nq_dev,
                                                         int nq_cap, int nq_host, int threshold, float ratio,
@@ -501,6 +633,16 @@ static int launch_knn2(snk_matcher* m, const uint64_t* q, const int32_t* nq_dev,
                        const uint64_t* t, const int32_t* nt_dev, int nt_cap, int nt_host, int batch, snk_knn2* out)
 {
     if (batch <= 0 || nq_cap <= 0) return SNK_OK;
+    // Matrix-core path once a query block (32) and a train tile (32) are mostly full; the vector kernel below for
+    // small sets (SNK_BF_NO_MFMA=1 forces it, for A/B measurements).
+    static const bool no_mfma = getenv("SNK_BF_NO_MFMA") != nullptr;
+    if (!no_mfma && nq_cap >= 24 && nt_cap >= 24)
+    {
+        hipLaunchKernelGGL(bf_knn2_mfma_kernel, dim3(ceil_div(nq_cap, 128), batch), dim3(256), 0, m->stream, (const uint4*)q, nq_dev,
+                           nq_cap, nq_host, (const uint4*)t, nt_dev, nt_cap, nt_host, out);
+        SNK_LAUNCH_CHECK();
+        return SNK_OK;
+    }
     // 4 queries per wavefront once there is enough work to fill 256 CUs, else 1 (latency).
     const bool wide = (long long)batch * nq_cap >= 16384;
     const int qw    = wide ? 4 : 1;
