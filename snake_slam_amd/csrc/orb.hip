@@ -1285,13 +1285,8 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
     const LevelInfo& lv = L.lv[l];
     const int cnt_l     = cnts[l];
     if (bx * 4 * DESC_KPW >= cnt_l) return;  // whole workgroup (the grid is sized for the largest level)
-    {
-        const uint2* g = reinterpret_cast<const uint2*>(&c_moment.v[0][0][0]);
-        for (int i = tid; i < 4 * MOM_PAD; i += 256) mtab[i] = g[i];
-    }
-    __syncthreads();
     const int slot0     = (bx * 4 + wave) * DESC_KPW;
-    if (slot0 >= cnt_l || offset + slot0 >= out_cap) return;  // whole wavefront
+    const bool work     = slot0 < cnt_l && offset + slot0 < out_cap;  // whole wavefront
 
     const u8* src      = l == 0 ? img0 + (long long)b * stride0 : lv.base + (long long)b * lv.img_stride;
     const int pitch    = l == 0 ? pitch0 : lv.pitch;
@@ -1318,7 +1313,8 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
         boff[k]        = (row - PATCH_R) * bpitch + 4 * (item - row * PATCH_DW);
     }
 
-    // ---- issue every load of the wavefront ----
+    // ---- issue every load of the wavefront; the copy of the moment table to LDS (and its barrier) comes after, so
+    // that its latency overlaps theirs ----
     bool valid[DESC_KPW];
     int kxv[DESC_KPW], kyv[DESC_KPW], scv[DESC_KPW];
     u32 dwv[DESC_KPW][5], bpv[DESC_KPW][6];
@@ -1327,41 +1323,57 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
     for (int s = 0; s < DESC_KPW; ++s)
     {
         const int slot = slot0 + s;
-        valid[s]       = slot < cnt_l && offset + slot < out_cap;
-        const u32 xy   = sel[sbase + (valid[s] ? slot : slot0)];
-        scv[s]         = sel_score[sbase + (valid[s] ? slot : slot0)];
-        kxv[s]         = (int)(xy & 0xFFFFu);
-        kyv[s]         = (int)(xy >> 16);
-    }
+        valid[s]       = work && slot < cnt_l && offset + slot < out_cap;
+        kxv[s] = kyv[s] = scv[s] = 0;
 #pragma unroll
-    for (int s = 0; s < DESC_KPW; ++s)
+        for (int k = 0; k < 5; ++k) dwv[s][k] = 0u;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) bpv[s][k] = 0u;
+    }
+    if (work)
     {
-        const int xa = (kxv[s] - 15) & ~3, xb = (kxv[s] - PATCH_R) & ~3;
-        const u8* mo = src + ((long long)kyv[s] * pitch + xa);
-        const u8* bo = bsrc + ((long long)kyv[s] * bpitch + xb);
 #pragma unroll
-        for (int k = 0; k < 5; ++k) dwv[s][k] = aligned ? *reinterpret_cast<const u32*>(mo + moff[k]) : 0u;
+        for (int s = 0; s < DESC_KPW; ++s)
+        {
+            const int slot = slot0 + s;
+            const u32 xy   = sel[sbase + (valid[s] ? slot : slot0)];
+            scv[s]         = sel_score[sbase + (valid[s] ? slot : slot0)];
+            kxv[s]         = (int)(xy & 0xFFFFu);
+            kyv[s]         = (int)(xy >> 16);
+        }
 #pragma unroll
-        for (int k = 0; k < 6; ++k) bpv[s][k] = *reinterpret_cast<const u32*>(bo + boff[k]);
+        for (int s = 0; s < DESC_KPW; ++s)
+        {
+            const int xa = (kxv[s] - 15) & ~3, xb = (kxv[s] - PATCH_R) & ~3;
+            const u8* mo = src + ((long long)kyv[s] * pitch + xa);
+            const u8* bo = bsrc + ((long long)kyv[s] * bpitch + xb);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) dwv[s][k] = aligned ? *reinterpret_cast<const u32*>(mo + moff[k]) : 0u;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) bpv[s][k] = *reinterpret_cast<const u32*>(bo + boff[k]);
+        }
     }
+    {
+        const uint2* g = reinterpret_cast<const uint2*>(&c_moment.v[0][0][0]);
+        for (int i = tid; i < 4 * MOM_PAD; i += 256) mtab[i] = g[i];
+    }
+    __syncthreads();
+    if (!work) return;
     float pt[4][4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int e = 0; e < 4; ++e) pt[k][e] = c_pattern_f.v[k * 64 + lane][e];
 
-    const u8* pb = reinterpret_cast<const u8*>(patch[wave]);
+    // ---- orientation of the wavefront's keypoints: intensity-centroid moments over the radius-15 disc (integers),
+    // then ONE evaluation of atan2 / sincos with the rows of 16 lanes working on different keypoints (the values are
+    // wave-uniform per keypoint; evaluating them keypoint by keypoint costs every lane the same work four times)
+    static_assert(DESC_KPW == 4, "one row of 16 lanes per keypoint");
+    int m10v[DESC_KPW], m01v[DESC_KPW];
 #pragma unroll
     for (int s = 0; s < DESC_KPW; ++s)
     {
-        if (!valid[s]) break;  // wave-uniform
         const int kx = kxv[s], ky = kyv[s];
-        // blurred patch -> LDS (in-order per wavefront: the previous keypoint's reads are done)
-#pragma unroll
-        for (int k = 0; k < 6; ++k)
-            if (lane + 64 * k < PATCH_ITEMS) patch[wave][lane + 64 * k] = bpv[s][k];
-
-        // intensity-centroid moments over the radius-15 disc (integers)
         int m10 = 0, m01 = 0;
         if (aligned)
         {
@@ -1396,11 +1408,31 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
                 }
             }
         }
-        m10 = wave_sum(m10);
-        m01 = wave_sum(m01);
-        const float angle = fast_atan2_deg((float)m01, (float)m10);
-        float sn, cs;
-        sincos_deg(angle, sn, cs);
+        m10v[s] = wave_sum(m10);
+        m01v[s] = wave_sum(m01);
+    }
+    float angle_l, sn_l, cs_l;
+    {
+        const int row = lane >> 4;
+        const int a10 = row == 0 ? m10v[0] : (row == 1 ? m10v[1] : (row == 2 ? m10v[2] : m10v[3]));
+        const int a01 = row == 0 ? m01v[0] : (row == 1 ? m01v[1] : (row == 2 ? m01v[2] : m01v[3]));
+        angle_l       = fast_atan2_deg((float)a01, (float)a10);
+        sincos_deg(angle_l, sn_l, cs_l);
+    }
+
+    const u8* pb = reinterpret_cast<const u8*>(patch[wave]);
+#pragma unroll
+    for (int s = 0; s < DESC_KPW; ++s)
+    {
+        if (!valid[s]) break;  // wave-uniform
+        const int kx = kxv[s], ky = kyv[s];
+        // blurred patch -> LDS (in-order per wavefront: the previous keypoint's reads are done)
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (lane + 64 * k < PATCH_ITEMS) patch[wave][lane + 64 * k] = bpv[s][k];
+        const float angle = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, angle_l), 16 * s));
+        const float sn    = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sn_l), 16 * s));
+        const float cs    = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cs_l), 16 * s));
 
         // 256 steered tests on the blurred patch; lane computes bits lane, lane+64, lane+128, lane+192
         const int pc = PATCH_R * (4 * PATCH_DW) + PATCH_R + ((kx - PATCH_R) & 3);  // patch byte of the keypoint
