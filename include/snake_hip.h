@@ -170,7 +170,10 @@ SNK_API int snk_orb_detect(snk_orb* o, const uint8_t* img, int width, int height
                            uint64_t (*desc)[4], int capacity, int* n_out);
 
 /* Batched, device-resident form: image b starts at images_dev + b*image_stride (row pitch
- * pitch_bytes); outputs kps_dev[b*out_cap ...], desc_dev[(b*out_cap + i)*4 ...], n_dev[b]. */
+ * pitch_bytes); outputs kps_dev[b*out_cap ...], desc_dev[(b*out_cap + i)*4 ...], n_dev[b].
+ * Every image must span pitch_bytes * height readable bytes (image_stride >= that): rows are
+ * read in aligned 4-byte units, so up to 3 bytes of a row's padding right of `width` may be
+ * read (never used).  Base, pitch and stride that are multiples of 4 take the fast path. */
 SNK_API int snk_orb_detect_batch_dev(snk_orb* o, const uint8_t* images_dev, int pitch_bytes, size_t image_stride,
                                      int batch, snk_keypoint* kps_dev, uint64_t* desc_dev, int32_t* n_dev,
                                      int out_cap);
@@ -196,7 +199,8 @@ SNK_API int snk_orb_set_profiling(snk_orb* o, int enable);
 SNK_API int snk_orb_set_chains(snk_orb* o, int chains);
 SNK_API int snk_orb_stage_times(snk_orb* o, float* ms, int* n_calls);
 
-/* Intermediate results of the last call (tests / debugging). */
+/* Intermediate results of the last call (tests / debugging); no counterpart in the reference — the stages are
+ * those of the absent Saiga::ORBExtractor behind Snake/Preprocess/FeatureDetector.cpp:119. */
 enum
 {
     SNK_ORB_DEBUG_PYRAMID         = 1, /* u8 rows of the level (level >= 1), `pitch` bytes each */

@@ -1972,6 +1972,7 @@ int snk_orb_detect_batch_dev(snk_orb* o, const uint8_t* images_dev, int pitch, s
     SNK_REQUIRE(batch >= 0 && batch <= o->max_batch, "batch exceeds the configured max_batch");
     SNK_REQUIRE(images_dev && kps_dev && desc_dev && n_dev, "NULL device buffer");
     SNK_REQUIRE(pitch >= o->width, "pitch smaller than the image width");
+    SNK_REQUIRE(batch <= 1 || image_stride >= (size_t)pitch * (size_t)o->height, "image_stride smaller than pitch * height");
     SNK_REQUIRE(out_cap >= 1, "out_cap must be >= 1");
     if (batch == 0) return SNK_OK;
     SNK_HIP_CHECK(hipSetDevice(o->device));
