@@ -1,0 +1,83 @@
+"""GPU: the reference calls the seams of this path from different OS threads at the same time (FeatureDetection ||
+Preprocess || Tracking || LocalBundleAdjustment, SURVEY.md section 8b: one thread per seam, no shared handle).  Four
+threads, each with its own handle(s) and stream, hammer their seam concurrently; every result must equal the result
+of the same call made alone."""
+import threading
+
+import numpy as np
+import pytest
+
+import track_helpers as T
+from helpers import SEED, make_stereo_case, rand_desc
+
+pytestmark = pytest.mark.gpu
+
+ROUNDS = 12
+
+
+def test_seams_run_concurrently_on_their_own_handles(orc):
+    from snake_slam_amd import synth
+    from snake_slam_amd.ba import BARec, lba_options
+    from snake_slam_amd.matcher import BruteForceMatcher, Preprocess
+    from snake_slam_amd.orb import ORBExtractor
+    from snake_slam_amd.tracking import SnakeORBMatcher
+
+    rng = np.random.default_rng(SEED + 4242)
+    imgs = [synth.stereo_frame(i, 320, 240, n_rects=90)[0] for i in range(3)]
+    stereo = [make_stereo_case(rng, 300, 280) for _ in range(3)]
+    bf_sets = [(rand_desc(rng, 257), rand_desc(rng, 301)) for _ in range(3)]
+    track = [T.make_tracking_case(orc, rng, n_clutter=300, m_pts=250) for _ in range(3)]
+    scenes = [synth.ba_scene(n_kf=8, n_pt=150, obs_per_pt=4, seed=900 + i)[0] for i in range(3)]
+
+    def run_orb(ext, k):
+        kps, desc = ext.Detect(imgs[k % 3])
+        return kps.tobytes() + desc.tobytes()
+
+    def run_pre(h, k):
+        left, dl, right, dr, bf, ls = stereo[k % 3]
+        n, rp, dp = h[0].StereoMatching(left, dl, right, dr, bf, ls, True)
+        q, t = bf_sets[k % 3]
+        h[1].matchKnn2(q, t)
+        m = h[1].filterMatches(90, 0.9)
+        return bytes([n & 255]) + rp.tobytes() + dp.tobytes() + np.asarray(h[1].matches).tobytes() + bytes([m & 255])
+
+    def run_track(m, k):
+        frame, cam, pose, ls, world, _ = track[k % 3]
+        n, idx = m.SearchByProjectionFrameFrame2(frame, cam, pose, T.lm_coarse(orc, world), 15.0, 75, 0, ls)
+        return bytes([n & 255]) + idx.tobytes()
+
+    def run_ba(ba, k):
+        ba.create(scenes[k % 3])
+        ci, cf = ba.initAndSolve()
+        pose, pt, it = ba.state(0)
+        return ci.tobytes() + cf.tobytes() + pose.tobytes() + pt.tobytes()
+
+    ext = ORBExtractor(300, 1.2, 3, 20, 7)
+    pre, bfm, trk, ba = Preprocess(), BruteForceMatcher(), SnakeORBMatcher(), BARec(lba_options())
+    seams = [(run_orb, ext), (run_pre, (pre, bfm)), (run_track, trk), (run_ba, ba)]
+    try:
+        want = [[fn(h, k) for k in range(3)] for fn, h in seams]  # each call alone
+        errors, got = [], [[None] * ROUNDS for _ in seams]
+        start = threading.Barrier(len(seams))
+
+        def worker(si):
+            fn, h = seams[si]
+            try:
+                start.wait()
+                for k in range(ROUNDS):
+                    got[si][k] = fn(h, k)
+            except Exception as e:  # noqa: BLE001
+                errors.append((si, repr(e)))
+
+        threads = [threading.Thread(target=worker, args=(si,)) for si in range(len(seams))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=120)
+        assert not any(t.is_alive() for t in threads), "a seam hung"
+        assert errors == []
+        for si in range(len(seams)):
+            for k in range(ROUNDS):
+                assert got[si][k] == want[si][k % 3], (si, k)
+    finally:
+        ext.close(), pre.close(), bfm.close(), trk.close(), ba.close()
