@@ -583,6 +583,174 @@ __global__ __launch_bounds__(256) void stereo_kernel16(const snk_kp64* __restric
     depth[(size_t)b * nl_cap + i]        = (float)(bf / disparity);
     atomicAdd(&n_matches[b], 1);
 }
+
+// The same matcher for a BATCH of frames: ONE workgroup of 1024 threads per frame keeps the frame's whole right side
+// in LDS -- x, rounded row, octave, angle, descriptor and a row-bucket index (56 bytes per keypoint) -- so that the
+// candidate scan of a 16-lane group (band lookup, gates, Hamming) never leaves the CU.  stereo_kernel16 pays two
+// dependent global gathers per candidate step plus the index copy per 16 left keypoints and is bound by their
+// latency; here only the left keypoint / descriptor of the next round is a global load, issued one round ahead.
+// The index is a counting sort by row (LDS histogram, one block scan, scatter): bucket = row - first row, clamped to
+// ST_ROWS - 1, so a band is start[bucket(lo)] .. start[bucket(hi) + 1] without a search; the order inside a bucket is
+// whatever the atomics gave -- the result is the minimum of (distance, row, index) keys and every gate is evaluated
+// on the true values, so neither that order nor the clamping can change it.
+// Replaces stereo_sort_kernel + stereo_kernel16 when the right side fits (nr_cap <= ST_FRAME_MAX).
+constexpr int ST_FRAME_MAX = 2560;
+constexpr int ST_ROWS      = 2048;
+__host__ __device__ inline size_t stereo_frame_lds(int nr_cap) { return (size_t)nr_cap * 56 + (size_t)(ST_ROWS + 2) * 4 + 16; }
+
+__global__ __launch_bounds__(1024) void stereo_frame_kernel(const snk_kp64* __restrict__ left, const uint4* __restrict__ dl,
+                                                            const int* __restrict__ nl_dev, int nl_cap, int nl_host,
+                                                            const snk_kp64* __restrict__ right, const uint4* __restrict__ dr,
+                                                            const int* __restrict__ nr_dev, int nr_cap, int nr_host,
+                                                            double bf, LevelScales ls, int relaxed, float* __restrict__ right_points,
+                                                            float* __restrict__ depth, int* __restrict__ n_matches)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+    __shared__ int s_cnt, s_row0, s_wtot[16];
+    const int b   = blockIdx.x;
+    const int tid = threadIdx.x;
+    int nl        = nl_dev ? nl_dev[b] : nl_host;
+    int nr        = nr_dev ? nr_dev[b] : nr_host;
+    nl            = nl < nl_cap ? nl : nl_cap;
+    nr            = nr < nr_cap ? nr : nr_cap;
+    if (nl <= 0 || nr <= 0) return;  // whole workgroup; n_matches[b] was cleared by the caller
+    uint4* sdesc = reinterpret_cast<uint4*>(fsm);                          // [2 * nr_cap]
+    double* sx   = reinterpret_cast<double*>(fsm + (size_t)nr_cap * 32);  // [nr_cap]
+    int* syj     = reinterpret_cast<int*>(fsm + (size_t)nr_cap * 40);
+    int* soct    = syj + nr_cap;
+    float* sang  = reinterpret_cast<float*>(soct + nr_cap);
+    int* srt     = reinterpret_cast<int*>(sang + nr_cap);  // [nr_cap] right indices grouped by row bucket
+    int* start   = srt + nr_cap;                            // [ST_ROWS + 1]
+    const snk_kp64* lb = left + (size_t)b * nl_cap;
+    const snk_kp64* rb = right + (size_t)b * nr_cap;
+    const uint4* dlb   = dl + (size_t)b * nl_cap * 2;
+    const uint4* drb   = dr + (size_t)b * nr_cap * 2;
+
+    if (tid == 0)
+    {
+        s_cnt  = 0;
+        s_row0 = 65535;
+    }
+    for (int t = tid; t <= ST_ROWS; t += 1024) start[t] = 0;
+    __syncthreads();
+    for (int t = tid; t < 2 * nr; t += 1024) sdesc[t] = drb[t];
+    constexpr int PER = (ST_FRAME_MAX + 1023) / 1024;
+    int row[PER], rank[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+    {
+        const int t = tid + 1024 * u;
+        row[u]      = -1;
+        if (t < nr)
+        {
+            const snk_kp64 kr = rb[t];
+            sx[t]   = kr.x;
+            syj[t]  = iround_d(kr.y);
+            soct[t] = kr.octave;
+            sang[t] = kr.angle;
+            int r   = (int)floor(kr.y + 0.5) + ST_ROW_BIAS;  // the row of stereo_sort_kernel's index
+            row[u]  = r < 0 ? 0 : (r > 65535 ? 65535 : r);
+            atomicMin(&s_row0, row[u]);
+        }
+    }
+    __syncthreads();
+    const int row0 = s_row0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+        if (row[u] >= 0)
+        {
+            row[u]  = min(row[u] - row0, ST_ROWS - 1);
+            rank[u] = atomicAdd(&start[row[u]], 1);
+        }
+    __syncthreads();
+    {
+        // exclusive scan of the ST_ROWS bucket counts, two per thread
+        const int a = start[2 * tid], c = start[2 * tid + 1];
+        int x       = a + c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1)
+        {
+            const int y = __shfl_up(x, off);
+            if ((tid & 63) >= off) x += y;
+        }
+        if ((tid & 63) == 63) s_wtot[tid >> 6] = x;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < (tid >> 6); ++w) base += s_wtot[w];
+        const int excl     = base + x - (a + c);
+        start[2 * tid]     = excl;
+        start[2 * tid + 1] = excl + a;
+        if (tid == 1023) start[ST_ROWS] = base + x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+        if (row[u] >= 0) srt[start[row[u]] + rank[u]] = tid + 1024 * u;
+    __syncthreads();
+
+    const int lane = tid & 15, grp = tid >> 4;  // 64 groups of 16 lanes
+    const float max_disp = (float)(bf * 0.5);
+    snk_kp64 kp_n = lb[min(grp, nl - 1)];
+    uint4 qa_n = dlb[(size_t)min(grp, nl - 1) * 2], qc_n = dlb[(size_t)min(grp, nl - 1) * 2 + 1];
+    for (int i = grp; i < nl; i += 64)
+    {
+        const snk_kp64 kp = kp_n;
+        const uint4 qa = qa_n, qc = qc_n;
+        {
+            const int in = min(i + 64, nl - 1);  // next round's keypoint is in flight during this one
+            kp_n = lb[in];
+            qa_n = dlb[(size_t)in * 2];
+            qc_n = dlb[(size_t)in * 2 + 1];
+        }
+        const int y = iround_d(kp.y);
+        int oct     = kp.octave;
+        oct         = oct < 0 ? 0 : (oct >= ls.n ? ls.n - 1 : oct);
+        const int ri = (int)ceilf(2.0f * ls.s[oct]);
+        const int lo_row  = min(max(y - ri + ST_ROW_BIAS, 0), 65535), hi_row = min(max(y + ri + ST_ROW_BIAS, 0), 65535);
+        const int scan_lo = start[min(max(lo_row - row0, 0), ST_ROWS - 1)], scan_hi = start[min(max(hi_row - row0, 0), ST_ROWS - 1) + 1];
+        u64 k1 = ST_INF_KEY, k2 = ST_INF_KEY;
+        for (int pos = scan_lo + lane; pos < scan_hi; pos += 16)
+        {
+            const int j   = srt[pos];
+            const int rel = syj[j] - (y - ri);
+            if (rel < 0 || rel > 2 * ri) continue;
+            const double disparity = kp.x - sx[j];
+            if (disparity < 0.0 || disparity > (double)max_disp) continue;
+            int doct = kp.octave - soct[j];
+            doct     = doct < 0 ? -doct : doct;
+            if (doct > 1) continue;
+            const int dist = hamming256(qa, qc, sdesc[2 * j], sdesc[2 * j + 1]);
+            if (dist >= 250) continue;
+            insert2(k1, k2, ((u64)dist << 40) | ((u64)rel << 24) | (u64)j);
+        }
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1)
+        {
+            const u64 o1 = __shfl_xor(k1, off, 16), o2 = __shfl_xor(k2, off, 16);
+            merge2(k1, k2, o1, o2);
+        }
+        if (lane != 0) continue;
+        const int best_dist = (int)(k1 >> 40), second_best_dist = (int)(k2 >> 40);
+        if (best_dist > (relaxed ? 75 : 40)) continue;
+        if ((double)best_dist > (relaxed ? 0.9 : 0.7) * (double)second_best_dist) continue;
+        const int best_id  = (int)(k1 & 0xFFFFFFull);
+        const float angle1 = kp.angle, angle2 = sang[best_id];
+        const float rot    = fminf(fabsf(angle1 - angle2), fminf(fabsf((angle1 + 365.0f) - angle2), fabsf(angle1 - (angle2 + 365.0f))));
+        if (rot > (relaxed ? 25.0f : 5.0f)) continue;
+        double right_point = sx[best_id];
+        double disparity   = kp.x - right_point;
+        if (disparity <= 0.001)
+        {
+            disparity   = 0.001;
+            right_point = kp.x - disparity;
+        }
+        right_points[(size_t)b * nl_cap + i] = (float)right_point;
+        depth[(size_t)b * nl_cap + i]        = (float)(bf / disparity);
+        atomicAdd(&s_cnt, 1);
+    }
+    __syncthreads();
+    if (tid == 0) n_matches[b] = s_cnt;
+}
 }  // namespace
 }  // namespace snk
 
@@ -819,6 +987,18 @@ int snk_stereo_match_batch_dev(snk_matcher* m, const snk_kp64* left_dev, const u
     SNK_HIP_CHECK(hipSetDevice(m->device));
     SNK_HIP_CHECK(hipMemsetAsync(n_matches_dev, 0, (size_t)batch * sizeof(int), m->stream));
     const u32* srt = nullptr;
+    static const bool no_frame_kernel = getenv("SNK_STEREO_NO_FRAME_KERNEL") != nullptr;  // A/B measurements
+    if (!no_frame_kernel && nr_cap <= ST_FRAME_MAX && batch >= 8)
+    {
+        // enough frames to give every CU its own: one workgroup per frame, the right side resident in LDS
+        SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stereo_frame_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)stereo_frame_lds(ST_FRAME_MAX)));
+        hipLaunchKernelGGL(stereo_frame_kernel, dim3(batch), dim3(1024), stereo_frame_lds(nr_cap), m->stream, left_dev,
+                           (const uint4*)desc_left_dev, nl_dev, nl_cap, 0, right_dev, (const uint4*)desc_right_dev, nr_dev, nr_cap,
+                           0, bf, ls, relaxed, right_points_dev, depth_dev, n_matches_dev);
+        SNK_LAUNCH_CHECK();
+        return SNK_OK;
+    }
     if (nr_cap <= ST_SORT_MAX)
     {
         if ((rc = m->out.reserve((size_t)batch * nr_cap * 4)) != SNK_OK) return rc;

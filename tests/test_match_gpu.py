@@ -122,11 +122,13 @@ def test_stereo_empty(st):
     assert n == 0 and rp.size == 0
 
 
-def test_stereo_batch_dev_parity(st, orc):
+@pytest.mark.parametrize("B,relaxed", [(6, True), (10, True), (10, False), (9, True)])
+def test_stereo_batch_dev_parity(st, orc, B, relaxed):
+    """B < 8: row-index sort + 16-lane kernel; B >= 8: one workgroup per frame with the right side in LDS."""
     import torch
 
-    rng = np.random.default_rng(SEED + 99)
-    B, capl, capr = 6, 700, 650
+    rng = np.random.default_rng(SEED + 99 + B)
+    capl, capr = 700, 650
     dev = torch.device("cuda:0")
     from oracle.oracle import KP64
 
@@ -134,8 +136,8 @@ def test_stereo_batch_dev_parity(st, orc):
     R = np.zeros((B, capr), KP64)
     DL = np.zeros((B, capl, 4), np.uint64)
     DR = np.zeros((B, capr, 4), np.uint64)
-    nl = np.array([700, 0, 123, 699, 64, 1], np.int32)
-    nr = np.array([650, 10, 0, 1, 650, 333], np.int32)
+    nl = np.array([700, 0, 123, 699, 64, 1, 700, 333, 17, 650][:B], np.int32)
+    nr = np.array([650, 10, 0, 1, 650, 333, 649, 2, 650, 65][:B], np.int32)
     cases = []
     for b in range(B):
         if nl[b] and nr[b]:
@@ -151,11 +153,11 @@ def test_stereo_batch_dev_parity(st, orc):
     dp = torch.full((B, capl), -1000.0, dtype=torch.float32, device=dev)
     nm = torch.full((B,), -1, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
-    st.match_batch_dev(Ld, DLd, nld, Rd, DRd, nrd, 47.9, ls, True, rp, dp, nm)
+    st.match_batch_dev(Ld, DLd, nld, Rd, DRd, nrd, 47.9, ls, relaxed, rp, dp, nm)
     st.sync()
     rp_h, dp_h, nm_h = rp.cpu().numpy(), dp.cpu().numpy(), nm.cpu().numpy()
     for b in range(B):
-        n2, rp2, dp2 = orc.stereo_match(L[b, : nl[b]], DL[b, : nl[b]], R[b, : nr[b]], DR[b, : nr[b]], 47.9, ls, True)
+        n2, rp2, dp2 = orc.stereo_match(L[b, : nl[b]], DL[b, : nl[b]], R[b, : nr[b]], DR[b, : nr[b]], 47.9, ls, relaxed)
         assert nm_h[b] == n2, f"batch {b}"
         assert np.array_equal(rp_h[b, : nl[b]], rp2) and np.array_equal(dp_h[b, : nl[b]], dp2)
         assert (rp_h[b, nl[b]:] == -1000).all()
