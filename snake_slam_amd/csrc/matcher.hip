@@ -185,21 +185,21 @@ __global__ __launch_bounds__(256) void bf_knn2_mfma_kernel(const uint4* __restri
     auto fetch = [&](int t, uint4& h, uint4& o)
     {
         const int ti = t * 32 + e_i;
-        h = o = uint4{0u, 0u, 0u, 0u};
-        if (ti < nt)
-        {
-            h = tb[(size_t)ti * 2 + e_g];
-            if (lane < 8) o = tb[(size_t)ti * 2 + 1];  // lanes 0..7 (e_g = 0, e_k = 0) also write the tile's popcount keys
-        }
+        h = uint4{0u, 0u, 0u, 0u};
+        if (ti < nt) h = tb[(size_t)ti * 2 + e_g];
+        (void)o;
     };
-    auto expand = [&](int t, int buf, const uint4& h, const uint4& o)
+    auto expand = [&](int t, int buf, const uint4& h, const uint4&)
     {
         As[buf][((2 * e_k) * 2 + e_g) * 32 + e_i]     = expand_bits(h, 2 * e_k);
         As[buf][((2 * e_k + 1) * 2 + e_g) * 32 + e_i] = expand_bits(h, 2 * e_k + 1);
+        // |t| of the row: this lane's half + the other half, which the lane 8 further (e_g = 1, same e_i, e_k) holds
+        const int ph = popc128(h);
+        const int pt = ph + __shfl_down(ph, 8);
         if (lane < 8)
         {
-            const int ti   = t * 32 + e_i;
-            ptk[buf][e_i] = ti < nt ? (((popc128(h) + popc128(o)) << BF_IDX_BITS) | ti) : BFM_SENTINEL;
+            const int ti  = t * 32 + e_i;
+            ptk[buf][e_i] = ti < nt ? ((pt << BF_IDX_BITS) | ti) : BFM_SENTINEL;
         }
     };
 
@@ -221,15 +221,18 @@ __global__ __launch_bounds__(256) void bf_knn2_mfma_kernel(const uint4* __restri
             if (t + 2 < ntiles) fetch(t + 2, h, o);  // lands during this iteration
         }
         v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        v4i a[8], pk[4];
 #pragma unroll
-        for (int kc = 0; kc < 8; ++kc) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(As[buf][(kc * 2 + g) * 32 + j], B[kc], acc, 0, 0, 0);
+        for (int kc = 0; kc < 8; ++kc) a[kc] = As[buf][(kc * 2 + g) * 32 + j];  // all LDS reads in flight before the MFMA chain
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) pk[rq] = *reinterpret_cast<const v4i*>(&ptk[buf][8 * rq + 4 * g]);
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kc], B[kc], acc, 0, 0, 0);
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq)
-        {
-            const v4i pk = *reinterpret_cast<const v4i*>(&ptk[buf][8 * rq + 4 * g]);
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) insert2s(k1, k2, pk[rr] - (acc[4 * rq + rr] << (BF_IDX_BITS + 1)));
-        }
+            for (int rr = 0; rr < 4; ++rr)  // key' = (|t| << 20 | idx) - (dot << 21): one v_mad_i32_i24
+                insert2s(k1, k2, __mul24(acc[4 * rq + rr], -(1 << (BF_IDX_BITS + 1))) + pk[rq][rr]);
         __syncthreads();
     }
     // the two halves of the wavefront hold disjoint trains of the same query
