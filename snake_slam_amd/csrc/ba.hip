@@ -79,6 +79,14 @@ struct RpcMeta
 };
 constexpr int RPC_STRIDE = 72;
 
+// What cam_pass needs of an observation that never changes during a solve, stored in the order of the camera lists
+// so that a camera's workgroup streams it (48 bytes).
+struct CamObs
+{
+    double u, v, depth, weight;
+    int pt, orig, img, ptfree;
+};
+
 struct Arrays
 {
     const Prob* prob;
@@ -108,10 +116,10 @@ struct Arrays
     const int* blk_rpc;            // [nfc * nfc] per problem (at blkstart_off - problem index): 0 or 1 + (rpc * 2 + transposed)
     const int* rpc_next;           // [rpc] chain of further constraints on the same camera pair, same encoding
     const unsigned char* outlier;  // caller order
-    double* o_Jc;  // [obs][18] scaled pose Jacobian
     double* o_r;   // [obs][4]  scaled residual, [3] = dim (0: inactive in this iteration)
     double* o_W;   // [obs][18]
-    double* o_yb;  // [obs][6]
+    double* ptv;   // [pt][6]   point position of the linearisation | V^-1 b_p (cam_pass rebuilds J_c, r, Y b_p from them)
+    const CamObs* cs_obs;  // static observation records in camera order (indexed like cam_items)
     double* Vinv;  // [pt][6]
     double* bp;    // [pt][3]
     double* cost_pt;
@@ -250,12 +258,6 @@ __global__ __launch_bounds__(128) void point_pass(Arrays A, Opt O)
             rr[1] = r[1];
             rr[2] = r[2];
             rr[3] = (double)dim;
-            if (c >= 0)
-            {
-                double* jc = A.o_Jc + (size_t)go * 18;
-#pragma unroll
-                for (int k = 0; k < 18; ++k) jc[k] = Jc[k];
-            }
             if (pfree)
             {
                 // V (upper: 00 01 02 11 12 22), b_p = -Jp^T r
@@ -285,6 +287,11 @@ __global__ __launch_bounds__(128) void point_pass(Arrays A, Opt O)
         return;
     }
     A.cost_pt[gp] = cost;
+    {
+        double* pv = A.ptv + (size_t)gp * 6;
+        pv[0] = pt[0]; pv[1] = pt[1]; pv[2] = pt[2];
+        pv[3] = pv[4] = pv[5] = 0.0;
+    }
     if (!pfree) return;
     const double lambda = A.state[pb].lambda;
     V[0] += lambda * clampd(V[0]);
@@ -308,22 +315,12 @@ __global__ __launch_bounds__(128) void point_pass(Arrays A, Opt O)
     A.bp[(size_t)gp * 3 + 0] = bp[0];
     A.bp[(size_t)gp * 3 + 1] = bp[1];
     A.bp[(size_t)gp * 3 + 2] = bp[2];
-    // Y = W V^-1 and Y b_p for every active coupling observation of this point
-    for (int s = s0; s < s1; ++s)
+    // V^-1 b_p: cam_pass forms the camera right-hand sides' Y b_p = J_c^T (J_p V^-1 b_p) from it
     {
-        const int go = pr.obs_off + s;
-        if (A.o_cam[go] < 0 || A.o_r[(size_t)go * 4 + 3] == 0.0) continue;
-        const double* Wp = A.o_W + (size_t)go * 18;
-        double* yb       = A.o_yb + (size_t)go * 6;
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-        {
-            const double w0 = Wp[a * 3], w1 = Wp[a * 3 + 1], w2 = Wp[a * 3 + 2];
-            const double y0 = w0 * Vi[0] + w1 * Vi[1] + w2 * Vi[2];
-            const double y1 = w0 * Vi[1] + w1 * Vi[3] + w2 * Vi[4];
-            const double y2 = w0 * Vi[2] + w1 * Vi[4] + w2 * Vi[5];
-            yb[a]         = y0 * bp[0] + y1 * bp[1] + y2 * bp[2];
-        }
+        double* pv = A.ptv + (size_t)gp * 6;
+        pv[3] = Vi[0] * bp[0] + Vi[1] * bp[1] + Vi[2] * bp[2];
+        pv[4] = Vi[1] * bp[0] + Vi[3] * bp[1] + Vi[4] * bp[2];
+        pv[5] = Vi[2] * bp[0] + Vi[4] * bp[1] + Vi[5] * bp[2];
     }
 }
 
@@ -332,14 +329,12 @@ __global__ __launch_bounds__(128) void point_pass(Arrays A, Opt O)
 // lane then writes 8-byte words 144 bytes apart and the L2 sees ~1100 partial-line writes per 64
 // observations.  Here lane = observation for the per-observation math (coalesced reads), lane = point
 // for the small per-point part (V, b_p, V^-1; same summation order as point_pass, so the results are
-// bit-identical), and the 18-double rows of J_c, W, Y leave through an LDS transpose as full 128-byte
-// lines.  LDS per wavefront: 14 + 9 + 18 doubles per lane = 20.5 KB.
+// bit-identical), and the 18-double rows of W leave through an LDS transpose as full 128-byte
+// lines.  LDS per wavefront: 14 + 18 doubles per lane = 16 KB.
 constexpr int PW_JP = 14;  // Jp[9], r[3], cost, dim
-constexpr int PW_PV = 9;   // Vinv[6], bp[3]
 __global__ __launch_bounds__(64) void point_wave(Arrays A, Opt O)
 {
     __shared__ double s_jp[64 * PW_JP];
-    __shared__ double s_pv[64 * PW_PV];
     __shared__ double s_st[64 * 18];
     const int lane = threadIdx.x;
     const int pb   = blockIdx.y;
@@ -405,14 +400,6 @@ __global__ __launch_bounds__(64) void point_wave(Arrays A, Opt O)
         rr[0] = make_double2(r[0], r[1]);
         rr[1] = make_double2(r[2], (double)dim);
     }
-    // J_c rows through the transpose buffer (rows of inactive couplings are written as zeros)
-#pragma unroll
-    for (int k = 0; k < 18; ++k) s_st[lane * 18 + k] = (dim && c >= 0) ? Jc[k] : 0.0;
-    __builtin_amdgcn_wave_barrier();
-    {
-        double* dst = A.o_Jc + gbase * 18;
-        for (int i = lane; i < nob * 18; i += 64) dst[i] = s_st[i];
-    }
     __builtin_amdgcn_wave_barrier();
 
     // ---- phase 2: lane = point ----
@@ -443,6 +430,7 @@ __global__ __launch_bounds__(64) void point_wave(Arrays A, Opt O)
         }
         A.cost_pt[gp] = cst;
         double Vi[6] = {0, 0, 0, 0, 0, 0};
+        double vb[3] = {0, 0, 0};
         if (pfree)
         {
             const double lambda = A.state[pb].lambda;
@@ -464,47 +452,31 @@ __global__ __launch_bounds__(64) void point_wave(Arrays A, Opt O)
             A.bp[(size_t)gp * 3 + 0] = bp[0];
             A.bp[(size_t)gp * 3 + 1] = bp[1];
             A.bp[(size_t)gp * 3 + 2] = bp[2];
+            vb[0] = Vi[0] * bp[0] + Vi[1] * bp[1] + Vi[2] * bp[2];
+            vb[1] = Vi[1] * bp[0] + Vi[3] * bp[1] + Vi[4] * bp[2];
+            vb[2] = Vi[2] * bp[0] + Vi[4] * bp[1] + Vi[5] * bp[2];
         }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) s_pv[lane * PW_PV + k] = Vi[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) s_pv[lane * PW_PV + 6 + k] = bp[k];
+        {
+            // position of this linearisation | V^-1 b_p: what cam_pass gathers per observation instead of J_c, r, Y b_p
+            const double* ptp = A.pt + (size_t)gp * 3;
+            double* pv        = A.ptv + (size_t)gp * 6;
+            pv[0] = ptp[0]; pv[1] = ptp[1]; pv[2] = ptp[2];
+            pv[3] = vb[0]; pv[4] = vb[1]; pv[5] = vb[2];
+        }
     }
     __builtin_amdgcn_wave_barrier();
 
-    // ---- phase 3: lane = observation: W = Jc^T Jp, Y = W V^-1, Y b_p ----
+    // ---- phase 3: lane = observation: W = Jc^T Jp (zero rows for inactive couplings) ----
     const bool cpl = act && dim && c >= 0 && !A.pt_const[pr.pt_off + p0 + lp];
-    double Wm[18], yb[6];
-    {
-        const double* pv = s_pv + lp * PW_PV;
-        const double v0 = pv[0], v1 = pv[1], v2 = pv[2], v3 = pv[3], v4 = pv[4], v5 = pv[5];
-        const double b0 = pv[6], b1 = pv[7], b2 = pv[8];
 #pragma unroll
-        for (int a = 0; a < 6; ++a)
-        {
+    for (int a = 0; a < 6; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) Wm[a * 3 + b] = cpl ? Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b] + Jc[12 + a] * Jp[6 + b] : 0.0;
-            const double w0 = Wm[a * 3], w1 = Wm[a * 3 + 1], w2 = Wm[a * 3 + 2];
-            const double y0 = w0 * v0 + w1 * v1 + w2 * v2;
-            const double y1 = w0 * v1 + w1 * v3 + w2 * v4;
-            const double y2 = w0 * v2 + w1 * v4 + w2 * v5;
-            yb[a]         = y0 * b0 + y1 * b1 + y2 * b2;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 18; ++k) s_st[lane * 18 + k] = Wm[k];
+        for (int b = 0; b < 3; ++b)
+            s_st[lane * 18 + a * 3 + b] = cpl ? Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b] + Jc[12 + a] * Jp[6 + b] : 0.0;
     __builtin_amdgcn_wave_barrier();
     {
         double* dst = A.o_W + gbase * 18;
         for (int i = lane; i < nob * 18; i += 64) dst[i] = s_st[i];
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int k = 0; k < 6; ++k) s_st[lane * 6 + k] = yb[k];
-    __builtin_amdgcn_wave_barrier();
-    {
-        double* dst = A.o_yb + gbase * 6;
-        for (int i = lane; i < nob * 6; i += 64) dst[i] = s_st[i];
     }
 }
 
@@ -768,7 +740,7 @@ __global__ __launch_bounds__(64) void rpc_pass(Arrays A, int trial)
 }
 
 constexpr int CAM_THREADS = 256;
-__global__ __launch_bounds__(CAM_THREADS) void cam_pass(Arrays A)
+__global__ __launch_bounds__(CAM_THREADS) void cam_pass(Arrays A, Opt O)
 {
     __shared__ double part[4][33];
     const int pb  = blockIdx.y;
@@ -780,27 +752,53 @@ __global__ __launch_bounds__(CAM_THREADS) void cam_pass(Arrays A)
     double acc[33];  // 21 (U upper) | 6 (b_c) | 6 (sum Y b_p)
 #pragma unroll
     for (int k = 0; k < 33; ++k) acc[k] = 0.0;
+    // J_c, r and Y b_p of an observation are REBUILT here from its static record (streamed in camera order), the pose
+    // of this camera and one 48-byte gather per observation (point position of the linearisation | V^-1 b_p) with the
+    // same code that point_wave ran -- instead of being written there per observation (224 bytes) and gathered back
+    // here in camera order, which made this pass and point_wave bound by HBM / texture-address traffic.
+    double R[9];
+    const double* pose = nullptr;
+    if (s1 > s0)
+    {
+        pose = A.pose + (size_t)(pr.img_off + A.cs_obs[pr.citem_off + s0].img) * 7;
+        quat_to_R(pose, R);
+    }
     for (int s = s0 + tid; s < s1; s += CAM_THREADS)
     {
-        const int go     = pr.obs_off + A.cam_items[pr.citem_off + s];
-        const double* rr = A.o_r + (size_t)go * 4;
-        if (rr[3] == 0.0) continue;
-        const double* jc = A.o_Jc + (size_t)go * 18;
-        double J[18];
+        const CamObs ob = A.cs_obs[pr.citem_off + s];
+        if (A.outlier[ob.orig]) continue;
+        const double* pv   = A.ptv + (size_t)(pr.pt_off + ob.pt) * 6;
+        const double pt[3] = {pv[0], pv[1], pv[2]};
+        const double vb[3] = {pv[3], pv[4], pv[5]};
+        double r[3], J[18], Jp[9];
+        const int dim = obs_linearize<true>(pose, R, pt, pr.K, pr.bf, ob.u, ob.v, ob.depth, ob.weight, r, J, Jp);
+        if (!dim) continue;
+        {
+            const double sq = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+            double sw;
+            (void)huber_rho(sq, dim == 3 ? O.huber_stereo : O.huber_mono, sw);
 #pragma unroll
-        for (int k = 0; k < 18; ++k) J[k] = jc[k];
+            for (int k = 0; k < 3; ++k) r[k] *= sw;
+#pragma unroll
+            for (int k = 0; k < 18; ++k) J[k] *= sw;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Jp[k] *= sw;
+        }
         int q = 0;
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
             for (int b = a; b < 6; ++b) acc[q++] += J[a] * J[b] + J[6 + a] * J[6 + b] + J[12 + a] * J[12 + b];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) acc[21 + a] -= J[a] * rr[0] + J[6 + a] * rr[1] + J[12 + a] * rr[2];
-        if (A.o_ptfree[go])
+        for (int a = 0; a < 6; ++a) acc[21 + a] -= J[a] * r[0] + J[6 + a] * r[1] + J[12 + a] * r[2];
+        if (ob.ptfree)
         {
-            const double* yb = A.o_yb + (size_t)go * 6;
+            // Y b_p = W V^-1 b_p = J_c^T (J_p (V^-1 b_p))
+            const double t0 = Jp[0] * vb[0] + Jp[1] * vb[1] + Jp[2] * vb[2];
+            const double t1 = Jp[3] * vb[0] + Jp[4] * vb[1] + Jp[5] * vb[2];
+            const double t2 = Jp[6] * vb[0] + Jp[7] * vb[1] + Jp[8] * vb[2];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) acc[27 + a] += yb[a];
+            for (int a = 0; a < 6; ++a) acc[27 + a] += J[a] * t0 + J[6 + a] * t1 + J[12 + a] * t2;
         }
     }
     // fixed-order reduction: xor butterfly inside each wavefront, then the 4 wavefronts in order
@@ -1527,7 +1525,7 @@ struct snk_ba : HandleBase
     long long tot_s = 0;
     int max_np = 0, max_nfc = 0, max_n6 = 0, max_ni = 0;
     DevBuf d_prob, d_state, d_pose, d_pose_new, d_pose0, d_pt, d_pt_new, d_pt0, d_ptc, d_camidx, d_ptstart, d_oimg, d_ocam,
-        d_optfree, d_ouv, d_odepth, d_oweight, d_oorig, d_outlier, d_Jc, d_r, d_W, d_Y, d_yb, d_Vinv, d_bp, d_cost,
+        d_optfree, d_ouv, d_odepth, d_oweight, d_oorig, d_outlier, d_csobs, d_r, d_W, d_Y, d_ptv, d_Vinv, d_bp, d_cost,
         d_cost_new, d_U, d_camstart, d_camitems, d_blkstart, d_blkent, d_S, d_rhs, d_x, d_chi2, d_pcgw, d_optidx, d_wvpt, d_rpcmeta, d_rpcnext, d_camrpcstart, d_camrpcitems, d_blkrpc, d_rpcout;
     int max_rpc = 0;
     int max_wv = 0;
@@ -1594,7 +1592,7 @@ int snk_ba_destroy(snk_ba* h)
     (void)hipSetDevice(h->device);
     DevBuf* all[] = {&h->d_prob, &h->d_state, &h->d_pose, &h->d_pose_new, &h->d_pose0, &h->d_pt, &h->d_pt_new, &h->d_pt0,
                      &h->d_ptc, &h->d_camidx, &h->d_ptstart, &h->d_oimg, &h->d_ocam, &h->d_optfree, &h->d_ouv, &h->d_odepth,
-                     &h->d_oweight, &h->d_oorig, &h->d_outlier, &h->d_Jc, &h->d_r, &h->d_W, &h->d_Y, &h->d_yb, &h->d_Vinv,
+                     &h->d_oweight, &h->d_oorig, &h->d_outlier, &h->d_csobs, &h->d_r, &h->d_W, &h->d_Y, &h->d_ptv, &h->d_Vinv,
                      &h->d_bp, &h->d_cost, &h->d_cost_new, &h->d_U, &h->d_camstart, &h->d_camitems, &h->d_blkstart,
                      &h->d_blkent, &h->d_S, &h->d_rhs, &h->d_x, &h->d_chi2};
     for (DevBuf* b : all) b->release();
@@ -1622,6 +1620,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     std::vector<Prob> probs((size_t)count);
     std::vector<double> pose, pt, ouv2, odepth, oweight;
     std::vector<unsigned char> ptc, optfree;
+    std::vector<CamObs> csobs;
     std::vector<int> camidx, ptstart, oimg, ocam, oorig, camstart, camitems, blkstart, optidx, wvpt, rpcnext, camrpcstart,
         camrpcitems, blkrpc;
     std::vector<RpcMeta> rpcmeta;
@@ -1754,6 +1753,14 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                 if (s_cam[(size_t)s] >= 0) items[(size_t)fill[(size_t)s_cam[(size_t)s]]++] = s;
             camstart.insert(camstart.end(), cs.begin(), cs.end());
             camitems.insert(camitems.end(), items.begin(), items.end());
+            for (int s : items)  // the same list as static records (what cam_pass streams)
+            {
+                const int o = order[(size_t)s];
+                CamObs rec;
+                rec.u = P.obs_uv[o][0]; rec.v = P.obs_uv[o][1]; rec.depth = P.obs_depth[o]; rec.weight = P.obs_weight[o];
+                rec.pt = P.obs_pt[o]; rec.orig = orig_off + o; rec.img = P.obs_img[o]; rec.ptfree = P.pt_const[P.obs_pt[o]] ? 0 : 1;
+                csobs.push_back(rec);
+            }
         }
         // camera-pair blocks: co-observations of every ordered pair (dense block grid, empty blocks allowed)
         pr.blkstart_off = (int)blkstart.size();
@@ -1887,6 +1894,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     UP(d_oorig, oorig);
     UP(d_camstart, camstart);
     UP(d_camitems, camitems);
+    UP(d_csobs, csobs);
     UP(d_blkstart, blkstart);
     UP(d_blkent, blkent);
     UP(d_optidx, optidx);
@@ -1904,10 +1912,9 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     RS(d_pt_new, npt * 3 * 8);
     RS(d_outlier, (size_t)std::max(orig_off, 1));
     RS(d_chi2, (size_t)std::max(orig_off, 1) * 8);
-    RS(d_Jc, nobs * 18 * 8);
     RS(d_r, nobs * 4 * 8);
     RS(d_W, nobs * 18 * 8);
-    RS(d_yb, nobs * 6 * 8);
+    RS(d_ptv, npt * 6 * 8);
     RS(d_Vinv, npt * 6 * 8);
     RS(d_bp, npt * 3 * 8);
     RS(d_cost, npt * 8);
@@ -1976,10 +1983,10 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     A.blk_rpc   = h->d_blkrpc.as<int>();
     A.rpc_next  = h->d_rpcnext.as<int>();
     A.outlier   = h->d_outlier.as<unsigned char>();
-    A.o_Jc      = h->d_Jc.as<double>();
     A.o_r       = h->d_r.as<double>();
     A.o_W       = h->d_W.as<double>();
-    A.o_yb      = h->d_yb.as<double>();
+    A.ptv       = h->d_ptv.as<double>();
+    A.cs_obs    = h->d_csobs.as<CamObs>();
     A.Vinv      = h->d_Vinv.as<double>();
     A.bp        = h->d_bp.as<double>();
     A.cost_pt   = h->d_cost.as<double>();
@@ -2050,7 +2057,7 @@ static int enqueue_lm(snk_ba* h, int iterations)
         if (h->max_nfc > 0)
         {
             if (h->max_rpc > 0) hipLaunchKernelGGL(rpc_pass, dim3(ceil_div(h->max_rpc, 64), B), dim3(64), 0, st, A, 0);
-            hipLaunchKernelGGL(cam_pass, dim3(h->max_nfc, B), dim3(CAM_THREADS), 0, st, A);
+            hipLaunchKernelGGL(cam_pass, dim3(h->max_nfc, B), dim3(CAM_THREADS), 0, st, A, O);
             {
                 const int nbx = ceil_div(h->max_nfc * h->max_nfc, 4);
                 hipLaunchKernelGGL(schur_pass, dim3(nbx * 8 * ceil_div(B, 8)), dim3(256), 0, st, A,
