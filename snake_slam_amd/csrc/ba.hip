@@ -53,6 +53,9 @@ struct Prob
     int n_rpc;          // valid relative pose constraints (IMU scenes)
     int rpc_off;        // into rpc_meta / rpc_out
     int camrpc_off;     // into cam_rpc_start (nfc + 1 entries per problem)
+    int n_set;          // work items of schur_set (0: not available for this problem)
+    int set_off;        // into set_items
+    int cblk_off;       // into cblk_start (nfc * nfc + 1 entries per problem)
     int pad;
     double K[4];
     double bf;
@@ -85,6 +88,17 @@ struct CamObs
 {
     double u, v, depth, weight;
     int pt, orig, img, ptfree;
+};
+
+// One wavefront's share of the point-major Schur pass: <= SET_CHUNK points that are all observed by the same cameras
+// in the same order (same "camera set"), so that lane q owns pair slot q = rows (ra, rb) of a point's run for all of
+// them and the 6 x 6 sum of block (camera(ra), camera(rb)) stays in its registers.
+struct SetItem
+{
+    int pts_off, n_pts;    // into set_pts; n_pts <= SET_CHUNK <= 64 (one list entry per lane)
+    int pair_off, npairs;  // into set_pairs: ra | rb << 8, camera(ra) < camera(rb) or ra == rb
+    int part_off;          // first of its npairs partial sums in s_part (36 doubles each)
+    int run;               // observations per point of this set
 };
 
 struct Arrays
@@ -129,6 +143,12 @@ struct Arrays
     const int* cam_items;
     const int* blk_start;
     const int4* blk_ent;  // (observation of c1, observation of c2, point, 0), observation indices relative to the problem
+    const SetItem* set_items;
+    const int2* set_pts;  // (point, first observation of the point) inside the problem
+    const int* set_pairs;
+    const int* cblk_start;  // per problem, per block: its partial sums in cblk_items (fixed order)
+    const int* cblk_items;  // index into s_part
+    double* s_part;         // [partial][36]
     double* S;
     double* rhs;
     double* x;
@@ -866,6 +886,216 @@ __global__ __launch_bounds__(CAM_THREADS) void cam_pass(Arrays A, Opt O)
 // matter only).  All workgroups of a window are given the same L % 8, so the window's Y / W rows (4.6 MB,
 // each re-read ~4.5 times by different blocks) are served by ONE XCD's L2 instead of being pulled into all
 // eight: windows w = 8 j + xcd live on XCD xcd.
+// ---- point-major Schur pass ----
+// schur_pass (below) walks one camera pair's co-observation list with lane = entry: every lane gathers its own two
+// 144-byte W rows and 48 V^-1 bytes, so each of the 21 dwordx4 loads of a pass touches 64 different cache lines and the
+// texture-address unit (about one line per clock) is the limit -- PMC: TA 75 % busy, VALU 22 %.  The rows of ONE point
+// are contiguous (observations are sorted by point) and all of its k (k + 1) / 2 camera pairs need them, so here a
+// wavefront takes points: the point's run of rows and its V^-1 are copied to LDS with consecutive lanes on consecutive
+// 16-byte chunks (2-3 load instructions per point instead of 21 x pairs / 64), lane q < npairs multiplies the pair
+// (ra, rb) it owns, and because all points of a work item share one camera set (SetItem) the lane's 36 sums stay in
+// registers across the item.  The item's sums go to s_part; schur_sum adds the partial sums of a block in a fixed
+// order and writes S.  The next two points' rows are in flight (two register sets) while one is multiplied.
+constexpr int SET_CHUNK   = 56;  // points per work item
+constexpr int SET_MAX_RUN = 14;  // observations of a point (rows staged per point)
+constexpr int SET_MAX_K   = 10;  // free-camera observations of a point: 55 pairs <= 64 lanes
+constexpr int SET_SLOT    = SET_MAX_RUN * 144 + 48;  // LDS bytes of one staged point (2064)
+constexpr int SET_QUADS   = (SET_SLOT / 16 + 63) / 64;  // load instructions per point (3)
+
+__global__ __launch_bounds__(256) void schur_set(Arrays A, int nbx, int B)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_stage[4][2][SET_SLOT];
+    int pb, bx;
+    if (B >= 16)  // batched windows: one XCD per window
+    {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        pb = (slot / nbx) * 8 + xcd;
+        bx = slot - (slot / nbx) * nbx;
+    }
+    else
+    {
+        pb = blockIdx.x / nbx;
+        bx = blockIdx.x - pb * nbx;
+    }
+    if (pb >= B) return;
+    const Prob pr  = A.prob[pb];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int it   = bx * 4 + wave;
+    if (it >= pr.n_set) return;  // whole wavefront
+    const SetItem si = A.set_items[pr.set_off + it];
+    // the item's point list sits in one register per lane and is broadcast with v_readlane: no dependent index loads
+    // in front of the row loads
+    const int2 my_pt = lane < si.n_pts ? A.set_pts[si.pts_off + lane] : make_int2(0, 0);
+    const unsigned char* Wb = reinterpret_cast<const unsigned char*>(A.o_W + (size_t)pr.obs_off * 18);
+    const unsigned char* Vb = reinterpret_cast<const unsigned char*>(A.Vinv + (size_t)pr.pt_off * 6);
+    const int wchunks = si.run * 9, nch = wchunks + 3;  // 16-byte chunks of a point: rows | V^-1
+    const bool mine = lane < si.npairs;
+    int ra = 0, rb = 0;
+    if (mine)
+    {
+        const int pq = A.set_pairs[si.pair_off + lane];
+        ra = pq & 255;
+        rb = pq >> 8;
+    }
+    double acc[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+
+    auto fetch = [&](int n, uint4 (&st)[SET_QUADS])
+    {
+        const int p  = __builtin_amdgcn_readlane(my_pt.x, n);
+        const int s0 = __builtin_amdgcn_readlane(my_pt.y, n);
+#pragma unroll
+        for (int u = 0; u < SET_QUADS; ++u)
+        {
+            const int ch = lane + 64 * u;
+            st[u]        = uint4{0u, 0u, 0u, 0u};
+            if (ch < nch)
+                st[u] = *reinterpret_cast<const uint4*>(ch < wchunks ? Wb + (size_t)s0 * 144 + ch * 16 : Vb + (size_t)p * 48 + (ch - wchunks) * 16);
+        }
+    };
+    auto consume = [&](int slot, const uint4 (&st)[SET_QUADS])
+    {
+        unsigned char* base = s_stage[wave][slot];
+#pragma unroll
+        for (int u = 0; u < SET_QUADS; ++u)
+            if (lane + 64 * u < nch) *reinterpret_cast<uint4*>(base + (lane + 64 * u) * 16) = st[u];
+        __builtin_amdgcn_wave_barrier();
+        if (mine)
+        {
+            const double2* rowa = reinterpret_cast<const double2*>(base + ra * 144);
+            const double2* rowb = reinterpret_cast<const double2*>(base + rb * 144);
+            const double2* vv   = reinterpret_cast<const double2*>(base + wchunks * 16);
+            const double2 v01 = vv[0], v23 = vv[1], v45 = vv[2];
+            const double v0 = v01.x, v1 = v01.y, v2 = v23.x, v3 = v23.y, v4 = v45.x, v5 = v45.y;
+            double wa[18], w[18], y[18];
+#pragma unroll
+            for (int q = 0; q < 9; ++q)
+            {
+                const double2 a = rowa[q], b = rowb[q];
+                wa[2 * q] = a.x; wa[2 * q + 1] = a.y;
+                w[2 * q] = b.x; w[2 * q + 1] = b.y;
+            }
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+            {
+                const double w0 = wa[a * 3], w1 = wa[a * 3 + 1], w2 = wa[a * 3 + 2];
+                y[a * 3]     = w0 * v0 + w1 * v1 + w2 * v2;
+                y[a * 3 + 1] = w0 * v1 + w1 * v3 + w2 * v4;
+                y[a * 3 + 2] = w0 * v2 + w1 * v4 + w2 * v5;
+            }
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) acc[r * 6 + c] += y[r * 3] * w[c * 3] + y[r * 3 + 1] * w[c * 3 + 1] + y[r * 3 + 2] * w[c * 3 + 2];
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    uint4 sa[SET_QUADS], sb[SET_QUADS];
+    fetch(0, sa);
+    if (si.n_pts > 1) fetch(1, sb);
+    for (int n = 0; n < si.n_pts; n += 2)
+    {
+        {
+            uint4 cur[SET_QUADS];
+#pragma unroll
+            for (int u = 0; u < SET_QUADS; ++u) cur[u] = sa[u];
+            if (n + 2 < si.n_pts) fetch(n + 2, sa);
+            consume(0, cur);
+        }
+        if (n + 1 < si.n_pts)
+        {
+            uint4 cur[SET_QUADS];
+#pragma unroll
+            for (int u = 0; u < SET_QUADS; ++u) cur[u] = sb[u];
+            if (n + 3 < si.n_pts) fetch(n + 3, sb);
+            consume(1, cur);
+        }
+    }
+    if (mine)
+    {
+        double2* out = reinterpret_cast<double2*>(A.s_part + (size_t)(si.part_off + lane) * 36);
+#pragma unroll
+        for (int q = 0; q < 18; ++q) out[q] = make_double2(acc[2 * q], acc[2 * q + 1]);
+    }
+}
+
+// S(c1, c2) = U(c1) [c1 == c2] - sum of the block's partial sums (fixed order) - relative-pose cross terms; lane = element.
+__global__ __launch_bounds__(256) void schur_sum(Arrays A, int nbx, int B)
+{
+    int pb, bx;
+    if (B >= 16)
+    {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        pb = (slot / nbx) * 8 + xcd;
+        bx = slot - (slot / nbx) * nbx;
+    }
+    else
+    {
+        pb = blockIdx.x / nbx;
+        bx = blockIdx.x - pb * nbx;
+    }
+    if (pb >= B) return;
+    const Prob pr  = A.prob[pb];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int blk  = bx * 4 + wave;
+    if (blk >= pr.nfc * pr.nfc) return;
+    const int c1 = blk / pr.nfc, c2 = blk - c1 * pr.nfc;
+    if (c2 < c1) return;
+    const int e0 = A.cblk_start[pr.cblk_off + blk], e1 = A.cblk_start[pr.cblk_off + blk + 1];
+    const int el = lane < 36 ? lane : 0, r = el / 6, c = el - 6 * r;
+    // the list (one entry per lane) and then four partial sums at a time are in flight; the order of the adds is the list's
+    const int my_item = e0 + lane < e1 ? A.cblk_items[e0 + lane] : 0;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < e1 - e0; k0 += 64)
+    {
+        const int chunk = min(64, e1 - e0 - k0);
+        const int items = k0 == 0 ? my_item : (e0 + k0 + lane < e1 ? A.cblk_items[e0 + k0 + lane] : 0);
+        for (int k = 0; k < chunk; k += 4)
+        {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+            {
+                const int idx = __builtin_amdgcn_readlane(items, min(k + u, chunk - 1));
+                v[u]          = A.s_part[(size_t)idx * 36 + el];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k + u < chunk) acc += v[u];
+        }
+    }
+    double* S  = A.S + pr.s_off + (size_t)(c1 * 6) * pr.n6 + c2 * 6;
+    double* St = A.S + pr.s_off + (size_t)(c2 * 6) * pr.n6 + c1 * 6;
+    if (c1 == c2)
+    {
+        // symmetrise the diagonal block (Y W^T of one camera is symmetric up to rounding)
+        const double at = __shfl(acc, c * 6 + r);
+        const double v  = A.U[(size_t)(pr.cam_off + c1) * 36 + (r <= c ? r * 6 + c : c * 6 + r)] - 0.5 * (acc + at);
+        if (lane < 36) S[(size_t)r * pr.n6 + c] = v;
+    }
+    else
+    {
+        if (pr.n_rpc > 0)  // camera-camera terms J(c1)^T J(c2) of the relative pose constraints of this pair
+        {
+            int code = A.blk_rpc[pr.blkstart_off - pb + blk];
+            while (code != 0)
+            {
+                const int k = (code - 1) >> 1, tr = (code - 1) & 1;
+                const double* H = A.rpc_out + (size_t)(pr.rpc_off + k) * RPC_STRIDE + 35;
+                acc -= tr ? H[c * 6 + r] : H[r * 6 + c];
+                code = A.rpc_next[pr.rpc_off + k];
+            }
+        }
+        if (lane < 36)
+        {
+            S[(size_t)r * pr.n6 + c]  = -acc;
+            St[(size_t)c * pr.n6 + r] = -acc;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void schur_pass(Arrays A, int zero_rows, int nbx, int B)
 {
     int pb, bx;
@@ -1523,7 +1753,9 @@ struct snk_ba : HandleBase
     std::vector<Prob> probs;
     int tot_img = 0, tot_pt = 0, tot_obs = 0, tot_cam = 0, tot_orig = 0, tot_vec = 0;
     long long tot_s = 0;
-    int max_np = 0, max_nfc = 0, max_n6 = 0, max_ni = 0;
+    int max_np = 0, max_nfc = 0, max_n6 = 0, max_ni = 0, max_set_items = 0;
+    bool set_ok = false;
+    DevBuf d_setitems, d_setpts, d_setpairs, d_cblkstart, d_cblkitems, d_spart;
     DevBuf d_prob, d_state, d_pose, d_pose_new, d_pose0, d_pt, d_pt_new, d_pt0, d_ptc, d_camidx, d_ptstart, d_oimg, d_ocam,
         d_optfree, d_ouv, d_odepth, d_oweight, d_oorig, d_outlier, d_csobs, d_r, d_W, d_Y, d_ptv, d_Vinv, d_bp, d_cost,
         d_cost_new, d_U, d_camstart, d_camitems, d_blkstart, d_blkent, d_S, d_rhs, d_x, d_chi2, d_pcgw, d_optidx, d_wvpt, d_rpcmeta, d_rpcnext, d_camrpcstart, d_camrpcitems, d_blkrpc, d_rpcout;
@@ -1621,6 +1853,11 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     std::vector<double> pose, pt, ouv2, odepth, oweight;
     std::vector<unsigned char> ptc, optfree;
     std::vector<CamObs> csobs;
+    std::vector<SetItem> setitems;
+    std::vector<int2> setpts;
+    std::vector<int> setpairs, cblkstart, cblkitems;
+    int n_partials = 0, max_set_items = 0;
+    bool set_ok = true;  // every problem can run the point-major Schur pass
     std::vector<int> camidx, ptstart, oimg, ocam, oorig, camstart, camitems, blkstart, optidx, wvpt, rpcnext, camrpcstart,
         camrpcitems, blkrpc;
     std::vector<RpcMeta> rpcmeta;
@@ -1802,6 +2039,111 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             blkstart.insert(blkstart.end(), bs.begin(), bs.end());
             blkent.insert(blkent.end(), ent.begin(), ent.end());
         }
+        // point-major Schur pass: points grouped by camera set, work items of <= SET_CHUNK points, per-block lists of
+        // the partial sums they produce
+        pr.set_off  = (int)setitems.size();
+        pr.cblk_off = (int)cblkstart.size();
+        pr.n_set    = 0;
+        {
+            const size_t nb = (size_t)nfc * nfc;
+            std::map<std::vector<int>, int> gid;
+            std::vector<std::vector<int>> gpts;
+            std::vector<std::vector<int>> gsig;
+            bool ok = nfc > 0;
+            for (int p = 0; p < P.n_pt && ok; ++p)
+            {
+                if (P.pt_const[p]) continue;
+                const int a0 = pstart[(size_t)p], a1 = pstart[(size_t)p + 1];
+                std::vector<int> sig;
+                int k = 0;
+                for (int a = a0; a < a1; ++a)
+                {
+                    const int c = s_cam[(size_t)a];
+                    sig.push_back(c);
+                    if (c < 0) continue;
+                    ++k;
+                    for (int b = a0; b < a; ++b)
+                        if (s_cam[(size_t)b] == c) ok = false;  // one camera twice on a point: block-major pass only
+                }
+                if (k == 0) continue;
+                if (k > SET_MAX_K || a1 - a0 > SET_MAX_RUN) ok = false;
+                auto f = gid.find(sig);
+                if (f == gid.end())
+                {
+                    gid.emplace(sig, (int)gpts.size());
+                    gpts.emplace_back();
+                    gsig.push_back(sig);
+                    gpts.back().push_back(p);
+                }
+                else
+                    gpts[(size_t)f->second].push_back(p);
+            }
+            std::vector<std::vector<int>> contrib(nb);
+            std::vector<SetItem> items;
+            std::vector<int2> ipts;
+            std::vector<int> ipairs;
+            int parts = n_partials;
+            if (ok)
+            {
+                // groups in order of their first point (std::map order would do as well: any fixed order)
+                for (size_t g = 0; g < gpts.size(); ++g)
+                {
+                    const std::vector<int>& sig = gsig[g];
+                    const int pair_off = (int)(setpairs.size() + ipairs.size());
+                    std::vector<int> blocks;
+                    for (size_t i = 0; i < sig.size(); ++i)
+                        for (size_t j = i; j < sig.size(); ++j)
+                        {
+                            if (sig[i] < 0 || sig[j] < 0) continue;
+                            const bool sw = sig[i] > sig[j];
+                            const int ra = (int)(sw ? j : i), rb = (int)(sw ? i : j);
+                            ipairs.push_back(ra | (rb << 8));
+                            blocks.push_back(sig[(size_t)ra] * nfc + sig[(size_t)rb]);
+                        }
+                    const int npairs = (int)blocks.size();
+                    for (size_t q0 = 0; q0 < gpts[g].size(); q0 += SET_CHUNK)
+                    {
+                        SetItem si;
+                        si.pts_off  = (int)(setpts.size() + ipts.size());
+                        si.n_pts    = (int)std::min<size_t>(SET_CHUNK, gpts[g].size() - q0);
+                        si.pair_off = pair_off;
+                        si.npairs   = npairs;
+                        si.part_off = parts;
+                        si.run      = (int)sig.size();
+                        for (int q = 0; q < si.n_pts; ++q)
+                        {
+                            const int pp = gpts[g][q0 + (size_t)q];
+                            ipts.push_back(make_int2(pp, pstart[(size_t)pp]));
+                        }
+                        for (int q = 0; q < npairs; ++q) contrib[(size_t)blocks[(size_t)q]].push_back(parts + q);
+                        parts += npairs;
+                        items.push_back(si);
+                    }
+                }
+            }
+            if (ok)
+            {
+                pr.n_set   = (int)items.size();
+                n_partials = parts;
+                setitems.insert(setitems.end(), items.begin(), items.end());
+                setpts.insert(setpts.end(), ipts.begin(), ipts.end());
+                setpairs.insert(setpairs.end(), ipairs.begin(), ipairs.end());
+                max_set_items = std::max(max_set_items, pr.n_set);
+            }
+            else
+                set_ok = false;
+            int run = (int)cblkitems.size();
+            for (size_t k = 0; k < nb; ++k)
+            {
+                cblkstart.push_back(run);
+                if (ok)
+                {
+                    cblkitems.insert(cblkitems.end(), contrib[k].begin(), contrib[k].end());
+                    run += (int)contrib[k].size();
+                }
+            }
+            cblkstart.push_back(run);
+        }
         // relative pose constraints (IMU scenes): valid ones, per-camera incidence, per-block chains
         {
             pr.rpc_off    = (int)rpcmeta.size();
@@ -1895,6 +2237,11 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     UP(d_camstart, camstart);
     UP(d_camitems, camitems);
     UP(d_csobs, csobs);
+    UP(d_setitems, setitems);
+    UP(d_setpts, setpts);
+    UP(d_setpairs, setpairs);
+    UP(d_cblkstart, cblkstart);
+    UP(d_cblkitems, cblkitems);
     UP(d_blkstart, blkstart);
     UP(d_blkent, blkent);
     UP(d_optidx, optidx);
@@ -1915,6 +2262,9 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     RS(d_r, nobs * 4 * 8);
     RS(d_W, nobs * 18 * 8);
     RS(d_ptv, npt * 6 * 8);
+    RS(d_spart, (size_t)std::max(n_partials, 1) * 36 * 8);
+    h->set_ok = set_ok && max_set_items > 0;
+    h->max_set_items = max_set_items;
     RS(d_Vinv, npt * 6 * 8);
     RS(d_bp, npt * 3 * 8);
     RS(d_cost, npt * 8);
@@ -1987,6 +2337,12 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     A.o_W       = h->d_W.as<double>();
     A.ptv       = h->d_ptv.as<double>();
     A.cs_obs    = h->d_csobs.as<CamObs>();
+    A.set_items = h->d_setitems.as<SetItem>();
+    A.set_pts   = h->d_setpts.as<int2>();
+    A.set_pairs = h->d_setpairs.as<int>();
+    A.cblk_start = h->d_cblkstart.as<int>();
+    A.cblk_items = h->d_cblkitems.as<int>();
+    A.s_part    = h->d_spart.as<double>();
     A.Vinv      = h->d_Vinv.as<double>();
     A.bp        = h->d_bp.as<double>();
     A.cost_pt   = h->d_cost.as<double>();
@@ -2060,8 +2416,17 @@ static int enqueue_lm(snk_ba* h, int iterations)
             hipLaunchKernelGGL(cam_pass, dim3(h->max_nfc, B), dim3(CAM_THREADS), 0, st, A, O);
             {
                 const int nbx = ceil_div(h->max_nfc * h->max_nfc, 4);
-                hipLaunchKernelGGL(schur_pass, dim3(nbx * 8 * ceil_div(B, 8)), dim3(256), 0, st, A,
-                                   h->point_wave_ok && !no_wave ? 1 : 0, nbx, B);
+                static const bool no_set = getenv("SNK_BA_NO_SCHUR_SET") != nullptr;  // A/B measurements
+                // a single small window has too few work items to fill the chip: the block-major pass is quicker there
+                if (h->point_wave_ok && !no_wave && h->set_ok && !no_set && (long long)h->max_set_items * B >= 256)
+                {
+                    const int nsx = ceil_div(h->max_set_items, 4);
+                    hipLaunchKernelGGL(schur_set, dim3(nsx * 8 * ceil_div(B, 8)), dim3(256), 0, st, A, nsx, B);
+                    hipLaunchKernelGGL(schur_sum, dim3(nbx * 8 * ceil_div(B, 8)), dim3(256), 0, st, A, nbx, B);
+                }
+                else
+                    hipLaunchKernelGGL(schur_pass, dim3(nbx * 8 * ceil_div(B, 8)), dim3(256), 0, st, A,
+                                       h->point_wave_ok && !no_wave ? 1 : 0, nbx, B);
             }
             if (!h->pcg_large)
                 hipLaunchKernelGGL(pcg_solve, dim3(B), dim3(PCG_THREADS), pcg_lds, st, A, O, s_in_lds);
