@@ -902,6 +902,10 @@ constexpr int SET_MAX_K   = 10;  // free-camera observations of a point: 55 pair
 constexpr int SET_SLOT    = SET_MAX_RUN * 144 + 48;  // LDS bytes of one staged point (2064)
 constexpr int SET_QUADS   = (SET_SLOT / 16 + 63) / 64;  // load instructions per point (3)
 
+// ROUNDS x 64 lanes >= 6 x pairs, QUADS x 64 lanes >= 16-byte chunks of a point: <4, 2> serves points with <= 8
+// free-camera observations out of <= 13 (42 row units... 36 pairs), <6, 3> the limits above; fewer rounds = fewer
+// registers = more wavefronts per SIMD, and this kernel lives on latency hiding.
+template <int ROUNDS, int QUADS>
 __global__ __launch_bounds__(256) void schur_set(Arrays A, int nbx, int B)
 {
     __shared__ __attribute__((aligned(16))) unsigned char s_stage[4][2][SET_SLOT];
@@ -929,24 +933,32 @@ __global__ __launch_bounds__(256) void schur_set(Arrays A, int nbx, int B)
     const unsigned char* Wb = reinterpret_cast<const unsigned char*>(A.o_W + (size_t)pr.obs_off * 18);
     const unsigned char* Vb = reinterpret_cast<const unsigned char*>(A.Vinv + (size_t)pr.pt_off * 6);
     const int wchunks = si.run * 9, nch = wchunks + 3;  // 16-byte chunks of a point: rows | V^-1
-    const bool mine = lane < si.npairs;
-    int ra = 0, rb = 0;
-    if (mine)
-    {
-        const int pq = A.set_pairs[si.pair_off + lane];
-        ra = pq & 255;
-        rb = pq >> 8;
-    }
-    double acc[36];
+    // Work unit = one ROW of one pair's 6 x 6 block: (W_a V^-1) row r times W_b^T, 27 multiply-adds.  With a pair per lane
+    // 36 of 64 lanes work for the usual 8 observations per point; with 6 npairs units over ceil(units / 64) rounds 84 %
+    // do.  Unit u = 64 round + lane -> pair u / 6, row u % 6; its 6 sums stay in registers across the item's points.
+    static_assert(ROUNDS <= (SET_MAX_K * (SET_MAX_K + 1) / 2 * 6 + 63) / 64 && QUADS <= SET_QUADS, "limits");
+    const int nunits = si.npairs * 6, nrounds = (nunits + 63) >> 6;
+    int ua[ROUNDS], ub[ROUNDS];  // LDS byte offsets of row r of W_a and of W_b inside a staged point
 #pragma unroll
-    for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+    for (int t = 0; t < ROUNDS; ++t)
+    {
+        const int u = 64 * t + lane, q = (u * 10923) >> 16, r = u - 6 * q;  // u / 6, u % 6 (u < 384)
+        const int pq = u < nunits ? A.set_pairs[si.pair_off + q] : 0;
+        ua[t] = (pq & 255) * 144 + r * 24;
+        ub[t] = (pq >> 8) * 144;
+    }
+    double acc[ROUNDS][6];
+#pragma unroll
+    for (int t = 0; t < ROUNDS; ++t)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc[t][c] = 0.0;
 
-    auto fetch = [&](int n, uint4 (&st)[SET_QUADS])
+    auto fetch = [&](int n, uint4 (&st)[QUADS])
     {
         const int p  = __builtin_amdgcn_readlane(my_pt.x, n);
         const int s0 = __builtin_amdgcn_readlane(my_pt.y, n);
 #pragma unroll
-        for (int u = 0; u < SET_QUADS; ++u)
+        for (int u = 0; u < QUADS; ++u)
         {
             const int ch = lane + 64 * u;
             st[u]        = uint4{0u, 0u, 0u, 0u};
@@ -954,70 +966,71 @@ __global__ __launch_bounds__(256) void schur_set(Arrays A, int nbx, int B)
                 st[u] = *reinterpret_cast<const uint4*>(ch < wchunks ? Wb + (size_t)s0 * 144 + ch * 16 : Vb + (size_t)p * 48 + (ch - wchunks) * 16);
         }
     };
-    auto consume = [&](int slot, const uint4 (&st)[SET_QUADS])
+    auto consume = [&](int slot, const uint4 (&st)[QUADS])
     {
         unsigned char* base = s_stage[wave][slot];
 #pragma unroll
-        for (int u = 0; u < SET_QUADS; ++u)
+        for (int u = 0; u < QUADS; ++u)
             if (lane + 64 * u < nch) *reinterpret_cast<uint4*>(base + (lane + 64 * u) * 16) = st[u];
         __builtin_amdgcn_wave_barrier();
-        if (mine)
-        {
-            const double2* rowa = reinterpret_cast<const double2*>(base + ra * 144);
-            const double2* rowb = reinterpret_cast<const double2*>(base + rb * 144);
-            const double2* vv   = reinterpret_cast<const double2*>(base + wchunks * 16);
-            const double2 v01 = vv[0], v23 = vv[1], v45 = vv[2];
-            const double v0 = v01.x, v1 = v01.y, v2 = v23.x, v3 = v23.y, v4 = v45.x, v5 = v45.y;
-            double wa[18], w[18], y[18];
+        const double2* vv = reinterpret_cast<const double2*>(base + wchunks * 16);
+        const double2 v01 = vv[0], v23 = vv[1], v45 = vv[2];
+        const double v0 = v01.x, v1 = v01.y, v2 = v23.x, v3 = v23.y, v4 = v45.x, v5 = v45.y;
 #pragma unroll
-            for (int q = 0; q < 9; ++q)
+        for (int t = 0; t < ROUNDS; ++t)
+            if (t < nrounds)  // wave-uniform; lanes past the last unit multiply row 0 of pair 0 and are never stored
             {
-                const double2 a = rowa[q], b = rowb[q];
-                wa[2 * q] = a.x; wa[2 * q + 1] = a.y;
-                w[2 * q] = b.x; w[2 * q + 1] = b.y;
+                const double* wa   = reinterpret_cast<const double*>(base + ua[t]);
+                const double2* rwb = reinterpret_cast<const double2*>(base + ub[t]);
+                const double w0 = wa[0], w1 = wa[1], w2 = wa[2];
+                const double y0 = w0 * v0 + w1 * v1 + w2 * v2;
+                const double y1 = w0 * v1 + w1 * v3 + w2 * v4;
+                const double y2 = w0 * v2 + w1 * v4 + w2 * v5;
+                double w[18];
+#pragma unroll
+                for (int q = 0; q < 9; ++q)
+                {
+                    const double2 b = rwb[q];
+                    w[2 * q] = b.x; w[2 * q + 1] = b.y;
+                }
+#pragma unroll
+                for (int c = 0; c < 6; ++c) acc[t][c] += y0 * w[c * 3] + y1 * w[c * 3 + 1] + y2 * w[c * 3 + 2];
             }
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-            {
-                const double w0 = wa[a * 3], w1 = wa[a * 3 + 1], w2 = wa[a * 3 + 2];
-                y[a * 3]     = w0 * v0 + w1 * v1 + w2 * v2;
-                y[a * 3 + 1] = w0 * v1 + w1 * v3 + w2 * v4;
-                y[a * 3 + 2] = w0 * v2 + w1 * v4 + w2 * v5;
-            }
-#pragma unroll
-            for (int r = 0; r < 6; ++r)
-#pragma unroll
-                for (int c = 0; c < 6; ++c) acc[r * 6 + c] += y[r * 3] * w[c * 3] + y[r * 3 + 1] * w[c * 3 + 1] + y[r * 3 + 2] * w[c * 3 + 2];
-        }
         __builtin_amdgcn_wave_barrier();
     };
 
-    uint4 sa[SET_QUADS], sb[SET_QUADS];
+    uint4 sa[QUADS], sb[QUADS];
     fetch(0, sa);
     if (si.n_pts > 1) fetch(1, sb);
     for (int n = 0; n < si.n_pts; n += 2)
     {
         {
-            uint4 cur[SET_QUADS];
+            uint4 cur[QUADS];
 #pragma unroll
-            for (int u = 0; u < SET_QUADS; ++u) cur[u] = sa[u];
+            for (int u = 0; u < QUADS; ++u) cur[u] = sa[u];
             if (n + 2 < si.n_pts) fetch(n + 2, sa);
             consume(0, cur);
         }
         if (n + 1 < si.n_pts)
         {
-            uint4 cur[SET_QUADS];
+            uint4 cur[QUADS];
 #pragma unroll
-            for (int u = 0; u < SET_QUADS; ++u) cur[u] = sb[u];
+            for (int u = 0; u < QUADS; ++u) cur[u] = sb[u];
             if (n + 3 < si.n_pts) fetch(n + 3, sb);
             consume(1, cur);
         }
     }
-    if (mine)
-    {
-        double2* out = reinterpret_cast<double2*>(A.s_part + (size_t)(si.part_off + lane) * 36);
 #pragma unroll
-        for (int q = 0; q < 18; ++q) out[q] = make_double2(acc[2 * q], acc[2 * q + 1]);
+    for (int t = 0; t < ROUNDS; ++t)
+    {
+        const int u = 64 * t + lane;
+        if (u < nunits)
+        {
+            double2* out = reinterpret_cast<double2*>(A.s_part + (size_t)si.part_off * 36 + (size_t)u * 6);
+            out[0] = make_double2(acc[t][0], acc[t][1]);
+            out[1] = make_double2(acc[t][2], acc[t][3]);
+            out[2] = make_double2(acc[t][4], acc[t][5]);
+        }
     }
 }
 
@@ -1754,7 +1767,7 @@ struct snk_ba : HandleBase
     int tot_img = 0, tot_pt = 0, tot_obs = 0, tot_cam = 0, tot_orig = 0, tot_vec = 0;
     long long tot_s = 0;
     int max_np = 0, max_nfc = 0, max_n6 = 0, max_ni = 0, max_set_items = 0;
-    bool set_ok = false;
+    bool set_ok = false, set_small = false;
     DevBuf d_setitems, d_setpts, d_setpairs, d_cblkstart, d_cblkitems, d_spart;
     DevBuf d_prob, d_state, d_pose, d_pose_new, d_pose0, d_pt, d_pt_new, d_pt0, d_ptc, d_camidx, d_ptstart, d_oimg, d_ocam,
         d_optfree, d_ouv, d_odepth, d_oweight, d_oorig, d_outlier, d_csobs, d_r, d_W, d_Y, d_ptv, d_Vinv, d_bp, d_cost,
@@ -1856,7 +1869,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     std::vector<SetItem> setitems;
     std::vector<int2> setpts;
     std::vector<int> setpairs, cblkstart, cblkitems;
-    int n_partials = 0, max_set_items = 0;
+    int n_partials = 0, max_set_items = 0, max_set_pairs = 0, max_set_run = 0;
     bool set_ok = true;  // every problem can run the point-major Schur pass
     std::vector<int> camidx, ptstart, oimg, ocam, oorig, camstart, camitems, blkstart, optidx, wvpt, rpcnext, camrpcstart,
         camrpcitems, blkrpc;
@@ -2118,6 +2131,8 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                         for (int q = 0; q < npairs; ++q) contrib[(size_t)blocks[(size_t)q]].push_back(parts + q);
                         parts += npairs;
                         items.push_back(si);
+                        max_set_pairs = std::max(max_set_pairs, npairs);
+                        max_set_run   = std::max(max_set_run, si.run);
                     }
                 }
             }
@@ -2265,6 +2280,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     RS(d_spart, (size_t)std::max(n_partials, 1) * 36 * 8);
     h->set_ok = set_ok && max_set_items > 0;
     h->max_set_items = max_set_items;
+    h->set_small     = max_set_pairs * 6 <= 4 * 64 && max_set_run * 9 + 3 <= 2 * 64;
     RS(d_Vinv, npt * 6 * 8);
     RS(d_bp, npt * 3 * 8);
     RS(d_cost, npt * 8);
@@ -2421,7 +2437,10 @@ static int enqueue_lm(snk_ba* h, int iterations)
                 if (h->point_wave_ok && !no_wave && h->set_ok && !no_set && (long long)h->max_set_items * B >= 256)
                 {
                     const int nsx = ceil_div(h->max_set_items, 4);
-                    hipLaunchKernelGGL(schur_set, dim3(nsx * 8 * ceil_div(B, 8)), dim3(256), 0, st, A, nsx, B);
+                    if (h->set_small)
+                        hipLaunchKernelGGL((schur_set<4, 2>), dim3(nsx * 8 * ceil_div(B, 8)), dim3(256), 0, st, A, nsx, B);
+                    else
+                        hipLaunchKernelGGL((schur_set<6, 3>), dim3(nsx * 8 * ceil_div(B, 8)), dim3(256), 0, st, A, nsx, B);
                     hipLaunchKernelGGL(schur_sum, dim3(nbx * 8 * ceil_div(B, 8)), dim3(256), 0, st, A, nbx, B);
                 }
                 else
