@@ -896,7 +896,7 @@ __global__ __launch_bounds__(CAM_THREADS) void cam_pass(Arrays A, Opt O)
 // (ra, rb) it owns, and because all points of a work item share one camera set (SetItem) the lane's 36 sums stay in
 // registers across the item.  The item's sums go to s_part; schur_sum adds the partial sums of a block in a fixed
 // order and writes S.  The next two points' rows are in flight (two register sets) while one is multiplied.
-constexpr int SET_CHUNK   = 56;  // points per work item
+constexpr int SET_CHUNK   = 50;  // points per work item (a set's points are cut into equal items of at most this many)
 constexpr int SET_MAX_RUN = 14;  // observations of a point (rows staged per point)
 constexpr int SET_MAX_K   = 10;  // free-camera observations of a point: 55 pairs <= 64 lanes
 constexpr int SET_SLOT    = SET_MAX_RUN * 144 + 48;  // LDS bytes of one staged point (2064)
@@ -2114,11 +2114,13 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                             blocks.push_back(sig[(size_t)ra] * nfc + sig[(size_t)rb]);
                         }
                     const int npairs = (int)blocks.size();
-                    for (size_t q0 = 0; q0 < gpts[g].size(); q0 += SET_CHUNK)
+                    const size_t n_in_set = gpts[g].size(), n_cuts = (n_in_set + SET_CHUNK - 1) / SET_CHUNK;
+                    const size_t cut = (n_in_set + n_cuts - 1) / n_cuts;  // equal items: a launch ends with its longest item
+                    for (size_t q0 = 0; q0 < n_in_set; q0 += cut)
                     {
                         SetItem si;
                         si.pts_off  = (int)(setpts.size() + ipts.size());
-                        si.n_pts    = (int)std::min<size_t>(SET_CHUNK, gpts[g].size() - q0);
+                        si.n_pts    = (int)std::min<size_t>(cut, n_in_set - q0);
                         si.pair_off = pair_off;
                         si.npairs   = npairs;
                         si.part_off = parts;
