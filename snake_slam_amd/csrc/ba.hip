@@ -354,8 +354,10 @@ __global__ __launch_bounds__(128) void point_pass(Arrays A, Opt O)
 constexpr int PW_JP = 14;  // Jp[9], r[3], cost, dim
 __global__ __launch_bounds__(64) void point_wave(Arrays A, Opt O)
 {
-    __shared__ double s_jp[64 * PW_JP];
+    // one buffer: the per-observation scratch of phases 1 / 2 (14 doubles per lane) is dead when phase 3 transposes the W
+    // rows through it (18 per lane); 9 KB per wavefront instead of 16 lets 17 instead of 10 wavefronts share a CU
     __shared__ double s_st[64 * 18];
+    double* s_jp = s_st;
     const int lane = threadIdx.x;
     const int pb   = blockIdx.y;
     const Prob pr  = A.prob[pb];
