@@ -18,9 +18,13 @@
 //                 damping, V^-1, cost).  point_pass<0> (thread per point) is the fallback for points with
 //                 more than 64 observations
 //   rpc_pass      thread per relative pose constraint (IMU scenes) : cost, -J^T r, J1^T J1, J1^T W
-//   cam_pass      workgroup per free camera : U, b_c, rhs = b_c - sum Y b_p (+ constraint terms), fixed-order sums
-//   schur_pass    wavefront per upper camera-pair block : S = U - sum (W V^-1) W^T over the co-observations
-//                 (+ constraint cross blocks); XCD-per-window launch for batches
+//   cam_pass      workgroup per free camera : U, b_c, rhs = b_c - sum Y b_p (+ constraint terms), fixed-order sums;
+//                 J_c, r, Y b_p rebuilt from static camera-ordered records + one 48-byte gather per observation
+//   schur_set     point-major Schur pass (batches, global BA): wavefront per <= 50 points of one camera set, the point's
+//   + schur_sum   rows staged once in LDS, (pair, row) work units with their sums in registers; then wavefront per upper
+//                 block adds the partial sums in fixed order: S = U - sum (W V^-1) W^T (+ constraint cross blocks)
+//   schur_pass    block-major form of the same (wavefront per upper camera-pair block over its co-observation list):
+//                 single windows and problems outside schur_set's limits; XCD-per-window launch for batches
 //   pcg_solve     one workgroup per problem : block-Jacobi PCG, vectors (and S when it fits) in LDS
 //   pcgl_*        multi-workgroup PCG for reduced systems beyond the LDS (global BA): vectors in HBM,
 //                 (row chunk x column part) matvec, fixed-order partial sums, 5 launches per iteration
