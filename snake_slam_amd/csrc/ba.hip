@@ -2442,7 +2442,8 @@ static int enqueue_lm(snk_ba* h, int iterations)
                 const int nbx = ceil_div(h->max_nfc * h->max_nfc, 4);
                 static const bool no_set = getenv("SNK_BA_NO_SCHUR_SET") != nullptr;  // A/B measurements
                 // a single small window has too few work items to fill the chip: the block-major pass is quicker there
-                if (h->point_wave_ok && !no_wave && h->set_ok && !no_set && (long long)h->max_set_items * B >= 256)
+                static const long long set_min = getenv("SNK_BA_SCHUR_SET_MIN_ITEMS") ? atoll(getenv("SNK_BA_SCHUR_SET_MIN_ITEMS")) : 256;  // tests: 1
+                if (h->point_wave_ok && !no_wave && h->set_ok && !no_set && (long long)h->max_set_items * B >= set_min)
                 {
                     const int nsx = ceil_div(h->max_set_items, 4);
                     if (h->set_small)

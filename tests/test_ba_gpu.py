@@ -204,3 +204,32 @@ def test_relative_pose_constraints(orc):
     ci2, cf2 = ba.initAndSolve()
     assert np.array_equal(ci, ci2) and np.array_equal(cf, cf2)
     ba.close()
+
+
+def test_irregular_camera_sets_and_point_major_limits(orc):
+    """Shapes around the limits of the point-major Schur pass (<= 10 free-camera observations out of <= 14 per point, a
+    camera at most once per point): random camera subsets (hundreds of different camera sets, most of them with a
+    single point), points with 12 observations, one camera twice on a point.  Whatever pass is chosen must agree
+    with the oracle (tests/test_ba_variants_gpu.py runs this file with each pass forced)."""
+    from snake_slam_amd import synth
+
+    rng = np.random.default_rng(77)
+    # random subsets: every point picks 3..9 of 12 cameras
+    sc, _ = synth.ba_scene(n_kf=12, n_pt=300, obs_per_pt=9, seed=81, n_fixed=1)
+    keep = np.ones(len(sc["obs_img"]), bool)
+    for p in range(300):
+        idx = np.nonzero(sc["obs_pt"] == p)[0]
+        drop = rng.permutation(idx)[: int(rng.integers(0, 7))]
+        keep[drop] = False
+    sub = dict(sc)
+    for k in ("obs_img", "obs_pt", "obs_uv", "obs_depth", "obs_weight"):
+        sub[k] = sc[k][keep]
+    compare(orc, sub)
+    # 12 observations per point: beyond the pair-slot limit
+    compare(orc, synth.ba_scene(n_kf=14, n_pt=150, obs_per_pt=12, seed=82, n_fixed=1)[0])
+    # one camera observes a point twice (duplicated observations)
+    sc2, _ = synth.ba_scene(n_kf=6, n_pt=80, obs_per_pt=4, seed=83)
+    dup = dict(sc2)
+    for k in ("obs_img", "obs_pt", "obs_uv", "obs_depth", "obs_weight"):
+        dup[k] = np.concatenate([sc2[k], sc2[k][:5]])
+    compare(orc, dup)
