@@ -642,6 +642,34 @@ __device__ __forceinline__ double block_sum(double v, double* red, int tid)
     return t;
 }
 
+// two sums at once (same tree for each): one pair of barriers instead of two
+template <int THREADS>
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* red, int tid)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+    {
+        a += __shfl_xor(a, off);
+        b += __shfl_xor(b, off);
+    }
+    if ((tid & 63) == 0)
+    {
+        red[tid >> 6]                = a;
+        red[THREADS / 64 + (tid >> 6)] = b;
+    }
+    __syncthreads();
+    double ta = red[0], tb = red[THREADS / 64];
+#pragma unroll
+    for (int w = 1; w < THREADS / 64; ++w)
+    {
+        ta += red[w];
+        tb += red[THREADS / 64 + w];
+    }
+    __syncthreads();
+    a = ta;
+    b = tb;
+}
+
 // ---- relative pose constraints (IMU scenes): e = log(T2 T1^-1 rel^-1), r = W e ----
 __device__ void se3_log_rel(const double* pose, const double* pred, double* e)
 {
@@ -1292,7 +1320,8 @@ __global__ __launch_bounds__(PCG_THREADS) void pcg_solve(Arrays A, Opt O, int s_
     double* p  = z + n6;
     double* Ap = p + n6;
     double* ps = Ap + n6;       // [4][n6] partial sums of the split matvec
-    double* Mi = ps + 4 * n6;
+    double* xs = ps + 4 * n6;   // the solution stays in LDS until the end (a global read-modify-write per iteration cost a memory round trip)
+    double* Mi = xs + n6;
     double* Sl = Mi + nfc * 36;
     const double* Sg  = A.S + pr.s_off;
     const double* rhs = A.rhs + pr.vec_off;
@@ -1307,7 +1336,7 @@ __global__ __launch_bounds__(PCG_THREADS) void pcg_solve(Arrays A, Opt O, int s_
     {
         const double v = rhs[q];
         r[q] = v;
-        x[q] = 0.0;
+        xs[q] = 0.0;
         part += v * v;
     }
     const double bnorm2 = block_sum<PCG_THREADS>(part, red, tid);
@@ -1322,6 +1351,7 @@ __global__ __launch_bounds__(PCG_THREADS) void pcg_solve(Arrays A, Opt O, int s_
         part += r[q] * s;
     }
     double rz = block_sum<PCG_THREADS>(part, red, tid);
+    double rn2 = bnorm2;  // |r|^2 of the current residual (x = 0: r = rhs); later iterations get it with r.z in one reduction
     const double stop2 = O.pcg_tol * O.pcg_tol * bnorm2;
     // matvec split: `parts` threads share a row, each a contiguous column chunk (fixed combine order)
     int parts = PCG_THREADS / n6;
@@ -1330,9 +1360,6 @@ __global__ __launch_bounds__(PCG_THREADS) void pcg_solve(Arrays A, Opt O, int s_
     int iters = 0;
     for (int k = 0; k < O.max_pcg; ++k)
     {
-        part = 0.0;
-        for (int q = tid; q < n6; q += PCG_THREADS) part += r[q] * r[q];
-        const double rn2 = block_sum<PCG_THREADS>(part, red, tid);
         if (rn2 <= stop2) break;
         for (int t = tid; t < n6 * parts; t += PCG_THREADS)
         {
@@ -1356,11 +1383,12 @@ __global__ __launch_bounds__(PCG_THREADS) void pcg_solve(Arrays A, Opt O, int s_
         const double alpha = rz / pAp;
         for (int q = tid; q < n6; q += PCG_THREADS)
         {
-            x[q] += alpha * p[q];
+            xs[q] += alpha * p[q];
             r[q] -= alpha * Ap[q];
         }
         __syncthreads();
         part = 0.0;
+        double part_rr = 0.0;
         for (int q = tid; q < n6; q += PCG_THREADS)
         {
             const int c = q / 6, a = q - c * 6;
@@ -1368,14 +1396,18 @@ __global__ __launch_bounds__(PCG_THREADS) void pcg_solve(Arrays A, Opt O, int s_
             for (int b = 0; b < 6; ++b) s += Mi[c * 36 + a * 6 + b] * r[c * 6 + b];
             z[q] = s;
             part += r[q] * s;
+            part_rr += r[q] * r[q];
         }
-        const double rz_new = block_sum<PCG_THREADS>(part, red, tid);
+        block_sum2<PCG_THREADS>(part, part_rr, red, tid);
+        const double rz_new = part;
+        rn2                 = part_rr;
         const double beta   = rz_new / rz;
         rz                  = rz_new;
         for (int q = tid; q < n6; q += PCG_THREADS) p[q] = z[q] + beta * p[q];
         __syncthreads();
         ++iters;
     }
+    for (int q = tid; q < n6; q += PCG_THREADS) x[q] = xs[q];
     if (tid == 0) A.state[pb].pcg_iters += iters;
 }
 
@@ -2226,7 +2258,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         max_nfc = std::max(max_nfc, nfc);
         max_n6  = std::max(max_n6, pr.n6);
     }
-    const size_t pcg_lds = (size_t)max_n6 * 8 * 8 + (size_t)max_nfc * 36 * 8;
+    const size_t pcg_lds = (size_t)max_n6 * 9 * 8 + (size_t)max_nfc * 36 * 8;
     // S (and the vectors) of the largest problem fit one workgroup's LDS -> one workgroup per problem;
     // otherwise the multi-workgroup PCG (measured: 120 keyframes 38 ms -> 9 ms, 600 keyframes 21 ms)
     h->pcg_large = pcg_lds + (size_t)max_n6 * max_n6 * 8 > 158 * 1024;
@@ -2423,7 +2455,7 @@ static int enqueue_lm(snk_ba* h, int iterations)
     hipLaunchKernelGGL(begin_solve, dim3(ceil_div(B, 64)), dim3(64), 0, st, h->d_state.as<State>(), B, O.lambda_init);
     SNK_LAUNCH_CHECK();
     const dim3 gpt(std::max(1, ceil_div(h->max_np, 128)), B);
-    size_t pcg_lds        = (size_t)h->max_n6 * 8 * 8 + (size_t)h->max_nfc * 36 * 8;
+    size_t pcg_lds        = (size_t)h->max_n6 * 9 * 8 + (size_t)h->max_nfc * 36 * 8;
     const size_t s_bytes  = (size_t)h->max_n6 * h->max_n6 * 8;
     const int s_in_lds    = pcg_lds + s_bytes <= 158 * 1024 ? 1 : 0;
     if (s_in_lds) pcg_lds += s_bytes;
