@@ -1366,7 +1366,20 @@ __global__ __launch_bounds__(PCG_THREADS) void pcg_solve(Arrays A, Opt O, int s_
             const int pi = t / n6, q = t - pi * n6;
             const int t0 = pi * chunk, t1 = min(t0 + chunk, n6);
             double s = 0.0;
-            for (int u = t0; u < t1; ++u) s += S[(size_t)u * n6 + q] * p[u];  // column q == row q (symmetric)
+            int u = t0;
+            for (; u + 8 <= t1; u += 8)  // 16 LDS reads in flight; the adds keep their order
+            {
+                double a[8], b[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                {
+                    a[e] = S[(size_t)(u + e) * n6 + q];  // column q == row q (symmetric)
+                    b[e] = p[u + e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += a[e] * b[e];
+            }
+            for (; u < t1; ++u) s += S[(size_t)u * n6 + q] * p[u];
             ps[pi * n6 + q] = s;
         }
         __syncthreads();
