@@ -817,13 +817,28 @@ __global__ __launch_bounds__(CAM_THREADS) void cam_pass(Arrays A, Opt O)
         pose = A.pose + (size_t)(pr.img_off + A.cs_obs[pr.citem_off + s0].img) * 7;
         quat_to_R(pose, R);
     }
+    // a thread runs ~3 observations: the record, the outlier flag and the 48-byte gather of the NEXT one are in flight
+    // while the current one is linearised (record -> gather is a dependent pair of memory round trips)
+    CamObs ob_n{};
+    double pv_n[6] = {0, 0, 0, 0, 0, 0};
+    unsigned char out_n = 1;
+    auto fetch = [&](int s)
+    {
+        ob_n  = A.cs_obs[pr.citem_off + s];
+        out_n = A.outlier[ob_n.orig];
+        const double2* pv = reinterpret_cast<const double2*>(A.ptv + (size_t)(pr.pt_off + ob_n.pt) * 6);
+        const double2 a = pv[0], b = pv[1], c = pv[2];
+        pv_n[0] = a.x; pv_n[1] = a.y; pv_n[2] = b.x; pv_n[3] = b.y; pv_n[4] = c.x; pv_n[5] = c.y;
+    };
+    if (s0 + tid < s1) fetch(s0 + tid);
     for (int s = s0 + tid; s < s1; s += CAM_THREADS)
     {
-        const CamObs ob = A.cs_obs[pr.citem_off + s];
-        if (A.outlier[ob.orig]) continue;
-        const double* pv   = A.ptv + (size_t)(pr.pt_off + ob.pt) * 6;
-        const double pt[3] = {pv[0], pv[1], pv[2]};
-        const double vb[3] = {pv[3], pv[4], pv[5]};
+        const CamObs ob = ob_n;
+        const bool skip = out_n != 0;
+        const double pt[3] = {pv_n[0], pv_n[1], pv_n[2]};
+        const double vb[3] = {pv_n[3], pv_n[4], pv_n[5]};
+        if (s + CAM_THREADS < s1) fetch(s + CAM_THREADS);
+        if (skip) continue;
         double r[3], J[18], Jp[9];
         const int dim = obs_linearize<true>(pose, R, pt, pr.K, pr.bf, ob.u, ob.v, ob.depth, ob.weight, r, J, Jp);
         if (!dim) continue;
