@@ -385,17 +385,25 @@ __global__ __launch_bounds__(64) void point_wave(Arrays A, Opt O)
     double cost = 0.0;
     if (act)
     {
-        lp = A.o_pt[go] - p0;
-        c  = A.o_cam[go];
-        if (!A.outlier[A.o_orig[go]])
+        // two rounds of loads instead of four dependent ones: everything indexed by the observation first, then the
+        // gathers through those indices (point, pose, outlier flag); the flag only masks the result
+        const int opt = A.o_pt[go], oimg = A.o_img[go], oorig = A.o_orig[go];
+        c = A.o_cam[go];
+        const double2 uv = A.o_uv[go];
+        const double odepth = A.o_depth[go], oweight = A.o_weight[go];
+        lp = opt - p0;
+        const double* ptp  = A.pt + (size_t)(pr.pt_off + opt) * 3;
+        const double pt[3] = {ptp[0], ptp[1], ptp[2]};
+        const double* posep = poses + (size_t)oimg * 7;
+        double pose[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) pose[k] = posep[k];
+        const bool is_out = A.outlier[oorig] != 0;
+        if (!is_out)
         {
-            const double* ptp  = A.pt + (size_t)(pr.pt_off + p0 + lp) * 3;
-            const double pt[3] = {ptp[0], ptp[1], ptp[2]};
-            const double* pose = poses + (size_t)A.o_img[go] * 7;
             double R[9];
             quat_to_R(pose, R);
-            const double2 uv = A.o_uv[go];
-            dim = obs_linearize<true>(pose, R, pt, pr.K, pr.bf, uv.x, uv.y, A.o_depth[go], A.o_weight[go], r, Jc, Jp);
+            dim = obs_linearize<true>(pose, R, pt, pr.K, pr.bf, uv.x, uv.y, odepth, oweight, r, Jc, Jp);
             if (dim)
             {
                 const double sq = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
@@ -485,8 +493,9 @@ __global__ __launch_bounds__(64) void point_wave(Arrays A, Opt O)
         {
             // position of this linearisation | V^-1 b_p: what cam_pass gathers per observation instead of J_c, r, Y b_p
             const double* ptp = A.pt + (size_t)gp * 3;
+            const double px = ptp[0], py = ptp[1], pz = ptp[2];  // loads first: pt and ptv may alias for the compiler
             double* pv        = A.ptv + (size_t)gp * 6;
-            pv[0] = ptp[0]; pv[1] = ptp[1]; pv[2] = ptp[2];
+            pv[0] = px; pv[1] = py; pv[2] = pz;
             pv[3] = vb[0]; pv[4] = vb[1]; pv[5] = vb[2];
         }
     }
