@@ -39,6 +39,9 @@
 #include <map>
 #include <vector>
 
+// This file is compiled with -ffp-contract=fast (snake_slam_amd/build.py): BA is specified by a tolerance, its kernels
+// are bound by fp64 issue slots, and a * b + c as one v_fma_f64 halves them.  Results stay deterministic.
+
 namespace snk
 {
 namespace
