@@ -1864,7 +1864,7 @@ struct snk_ba : HandleBase
     bool set_ok = false, set_small = false;
     DevBuf d_setitems, d_setpts, d_setpairs, d_cblkstart, d_cblkitems, d_spart;
     DevBuf d_prob, d_state, d_pose, d_pose_new, d_pose0, d_pt, d_pt_new, d_pt0, d_ptc, d_camidx, d_ptstart, d_oimg, d_ocam,
-        d_optfree, d_ouv, d_odepth, d_oweight, d_oorig, d_outlier, d_csobs, d_r, d_W, d_Y, d_ptv, d_Vinv, d_bp, d_cost,
+        d_optfree, d_ouv, d_odepth, d_oweight, d_oorig, d_outlier, d_csobs, d_r, d_W, d_ptv, d_Vinv, d_bp, d_cost,
         d_cost_new, d_U, d_camstart, d_camitems, d_blkstart, d_blkent, d_S, d_rhs, d_x, d_chi2, d_pcgw, d_optidx, d_wvpt, d_rpcmeta, d_rpcnext, d_camrpcstart, d_camrpcitems, d_blkrpc, d_rpcout;
     int max_rpc = 0;
     int max_wv = 0;
@@ -1929,11 +1929,15 @@ int snk_ba_destroy(snk_ba* h)
 {
     if (!h) return SNK_OK;
     (void)hipSetDevice(h->device);
-    DevBuf* all[] = {&h->d_prob, &h->d_state, &h->d_pose, &h->d_pose_new, &h->d_pose0, &h->d_pt, &h->d_pt_new, &h->d_pt0,
-                     &h->d_ptc, &h->d_camidx, &h->d_ptstart, &h->d_oimg, &h->d_ocam, &h->d_optfree, &h->d_ouv, &h->d_odepth,
-                     &h->d_oweight, &h->d_oorig, &h->d_outlier, &h->d_csobs, &h->d_r, &h->d_W, &h->d_Y, &h->d_ptv, &h->d_Vinv,
-                     &h->d_bp, &h->d_cost, &h->d_cost_new, &h->d_U, &h->d_camstart, &h->d_camitems, &h->d_blkstart,
-                     &h->d_blkent, &h->d_S, &h->d_rhs, &h->d_x, &h->d_chi2};
+    // every device buffer of the handle (the struct's DevBuf members)
+    DevBuf* all[] = {&h->d_setitems, &h->d_setpts, &h->d_setpairs, &h->d_cblkstart, &h->d_cblkitems, &h->d_spart,
+                     &h->d_prob, &h->d_state, &h->d_pose, &h->d_pose_new, &h->d_pose0, &h->d_pt, &h->d_pt_new,
+                     &h->d_pt0, &h->d_ptc, &h->d_camidx, &h->d_ptstart, &h->d_oimg, &h->d_ocam, &h->d_optfree,
+                     &h->d_ouv, &h->d_odepth, &h->d_oweight, &h->d_oorig, &h->d_outlier, &h->d_csobs, &h->d_r,
+                     &h->d_W, &h->d_ptv, &h->d_Vinv, &h->d_bp, &h->d_cost, &h->d_cost_new, &h->d_U, &h->d_camstart,
+                     &h->d_camitems, &h->d_blkstart, &h->d_blkent, &h->d_S, &h->d_rhs, &h->d_x, &h->d_chi2,
+                     &h->d_pcgw, &h->d_optidx, &h->d_wvpt, &h->d_rpcmeta, &h->d_rpcnext, &h->d_camrpcstart,
+                     &h->d_camrpcitems, &h->d_blkrpc, &h->d_rpcout};
     for (DevBuf* b : all) b->release();
     h->drop_graphs();
     h->fini();

@@ -233,3 +233,30 @@ def test_irregular_camera_sets_and_point_major_limits(orc):
     for k in ("obs_img", "obs_pt", "obs_uv", "obs_depth", "obs_weight"):
         dup[k] = np.concatenate([sc2[k], sc2[k][:5]])
     compare(orc, dup)
+
+
+def test_handles_release_their_device_memory(orc):
+    """create / set_problem / solve / destroy in a loop must not leak device memory (every buffer of the handle is
+    released by snk_ba_destroy)."""
+    import torch
+
+    from snake_slam_amd import synth
+    from snake_slam_amd.ba import BARec, lba_options
+
+    sc, gt = synth.ba_scene(n_kf=12, n_pt=800, obs_per_pt=6, seed=91)
+    sc_rpc = synth.ba_add_rpcs(dict(sc), gt, seed=3)
+
+    def cycle(scene):
+        ba = BARec(lba_options())
+        ba.create([scene] * 8)
+        ba.solve(2)
+        ba.close()
+
+    cycle(sc), cycle(sc_rpc)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(25):
+        cycle(sc), cycle(sc_rpc)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20, (free0 - free1) >> 20  # a leak of the small tables alone was ~1.5 MB per cycle
