@@ -65,6 +65,32 @@ def test_bf_extremes(bf, orc):
     assert np.array_equal(got, knn_to_array(orc.bf_knn2(z, o)))
 
 
+def test_bf_matrix_core_extremes(bf, orc):
+    """Sizes that take the MFMA kernel with the extreme popcounts: all-zero / all-one descriptors (dot products 0 and
+    256, distances 0 and the 'infinite' 256), single-bit descriptors, a train set that is exactly one tile and one
+    that is one past a tile."""
+    rng = np.random.default_rng(SEED + 404)
+    z = np.zeros(4, np.uint64)
+    o = np.full(4, np.uint64(0xFFFFFFFFFFFFFFFF))
+    one_bit = np.zeros((256, 4), np.uint64)
+    for b in range(256):
+        one_bit[b, b >> 6] = np.uint64(1) << np.uint64(b & 63)
+    for nt in (32, 33, 64, 97):
+        q = np.stack([z] * 20 + [o] * 20 + list(one_bit[:40]) + list(rand_desc(rng, 17)))
+        t = np.stack(([o] * 10 + [z] * 5 + list(one_bit[100:110]) + list(rand_desc(rng, 200)))[:nt])
+        bf.matchKnn2(q, t)
+        assert np.array_equal(knn_to_array(bf.knn), knn_to_array(orc.bf_knn2(q, t))), nt
+    # every pair at distance 256: nothing is a neighbour
+    bf.matchKnn2(np.stack([z] * 40), np.stack([o] * 40))
+    got = knn_to_array(bf.knn)
+    assert (got[:, 0] == -1).all() and (got[:, 1] == 256).all() and (got[:, 2] == -1).all() and (got[:, 3] == 256).all()
+    # every bit position on its own: the bit -> operand-byte mapping must be the same on both sides
+    bf.matchKnn2(one_bit, one_bit)
+    got = knn_to_array(bf.knn)
+    assert (got[:, 0] == np.arange(256)).all() and (got[:, 1] == 0).all() and (got[:, 3] == 2).all()
+    assert np.array_equal(got, knn_to_array(orc.bf_knn2(one_bit, one_bit)))
+
+
 def test_bf_batch_dev_parity(bf, orc):
     import torch
 
