@@ -431,12 +431,9 @@ __global__ __launch_bounds__(64) void point_wave(Arrays A, Opt O)
     for (int k = 0; k < 3; ++k) s_jp[lane * PW_JP + 9 + k] = r[k];
     s_jp[lane * PW_JP + 12] = cost;
     s_jp[lane * PW_JP + 13] = (double)dim;
-    if (act)  // [go][4]: 32 contiguous bytes per lane, coalesced as is
-    {
-        double2* rr = reinterpret_cast<double2*>(A.o_r + go * 4);
-        rr[0] = make_double2(r[0], r[1]);
-        rr[1] = make_double2(r[2], (double)dim);
-    }
+    // o_r (scaled residual | activity flag) is not written here: its readers are the fallback passes that run with
+    // point_pass<0> (schur_pass with activity lookups, the point part of update_pass); with point_wave inactive rows
+    // of W are zero and cam_pass / update_wave rebuild what they need
     __builtin_amdgcn_wave_barrier();
 
     // ---- phase 2: lane = point ----
