@@ -363,7 +363,7 @@ __global__ __launch_bounds__(64) void point_wave(Arrays A, Opt O)
 {
     // one buffer: the per-observation scratch of phases 1 / 2 (14 doubles per lane) is dead when phase 3 transposes the W
     // rows through it (18 per lane); 9 KB per wavefront instead of 16 lets 17 instead of 10 wavefronts share a CU
-    __shared__ double s_st[64 * 18];
+    __shared__ __attribute__((aligned(16))) double s_st[64 * 18];
     double* s_jp = s_st;
     const int lane = threadIdx.x;
     const int pb   = blockIdx.y;
@@ -510,8 +510,10 @@ __global__ __launch_bounds__(64) void point_wave(Arrays A, Opt O)
             s_st[lane * 18 + a * 3 + b] = cpl ? Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b] + Jc[12 + a] * Jp[6 + b] : 0.0;
     __builtin_amdgcn_wave_barrier();
     {
-        double* dst = A.o_W + gbase * 18;
-        for (int i = lane; i < nob * 18; i += 64) dst[i] = s_st[i];
+        // 16 bytes per lane and store: the rows are a contiguous run of nob * 144 bytes on both sides
+        double2* dst       = reinterpret_cast<double2*>(A.o_W + gbase * 18);
+        const double2* src = reinterpret_cast<const double2*>(s_st);
+        for (int i = lane; i < nob * 9; i += 64) dst[i] = src[i];
     }
 }
 
