@@ -335,20 +335,23 @@ __device__ __forceinline__ short2_t fast_score16_pk(const short2_t (&d)[16])
 // image (next level, blurred level, candidates) is read by the next stage through the same XCD's L2.
 __device__ __forceinline__ bool xcd_image_map(int gx, int batch, int& b, int& bx)
 {
+    // 2-D grids (x fastest in the dispatch order): for batches of >= 16 images grid.x = 8 * gx, so the linear workgroup
+    // index is congruent to blockIdx.x mod 8 and image 8 * blockIdx.y + (blockIdx.x & 7) stays on one XCD -- shifts and
+    // masks only (the 1-D form needed an integer division per wavefront, ~35 instructions of the ~860 of a FAST cell)
     if (batch >= 16)
     {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        b  = (slot / gx) * 8 + xcd;
-        bx = slot - (slot / gx) * gx;
+        b  = blockIdx.y * 8 + (blockIdx.x & 7);
+        bx = blockIdx.x >> 3;
     }
     else
     {
-        b  = blockIdx.x / gx;
-        bx = blockIdx.x - b * gx;
+        b  = blockIdx.y;
+        bx = blockIdx.x;
     }
+    (void)gx;
     return b < batch;
 }
-static inline int xcd_grid(int gx, int batch) { return gx * (batch >= 16 ? 8 * ((batch + 7) / 8) : batch); }
+static inline dim3 xcd_grid(int gx, int batch) { return batch >= 16 ? dim3(8 * gx, (batch + 7) / 8) : dim3(gx, batch); }
 
 // One WAVEFRONT per FAST cell (4 cells per workgroup, no workgroup barriers: the phases of a cell
 // only communicate through that wavefront's own LDS slice, which the LDS serves in program order).
@@ -1888,7 +1891,7 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
         {
             const int gx = ceil_div(lv.n_strips * lv.n_bands, 4);
             auto lk = l == 0 && !aligned0 ? level_kernel<false> : level_kernel<true>;
-            hipLaunchKernelGGL(lk, dim3(xcd_grid(gx, batch)), dim3(256), 0, st, L, l, images_dev, pitch, image_stride,
+            hipLaunchKernelGGL(lk, xcd_grid(gx, batch), dim3(256), 0, st, L, l, images_dev, pitch, image_stride,
                                fused && l + 1 < L.n_levels ? 1 : 0, gx, batch);
         }
         SNK_LAUNCH_CHECK();
@@ -1901,7 +1904,7 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
         const int gx = ceil_div(L.total_cells, 4);
         const int fq = fast_quads(L);
         auto fk      = fq == 3 ? fast_kernel<3> : (fq == 4 ? fast_kernel<4> : fast_kernel<0>);
-        hipLaunchKernelGGL(fk, dim3(xcd_grid(gx, batch)), dim3(256), (size_t)4 * L.f_lds_wave, st, L, images_dev, pitch,
+        hipLaunchKernelGGL(fk, xcd_grid(gx, batch), dim3(256), (size_t)4 * L.f_lds_wave, st, L, images_dev, pitch,
                            image_stride, aligned0, o->params.ini_th_fast, o->params.min_th_fast, d_cand, d_cellcnt, gx, batch);
         SNK_LAUNCH_CHECK();
     }
