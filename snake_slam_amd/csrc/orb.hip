@@ -330,7 +330,7 @@ __device__ __forceinline__ short2_t fast_score16_pk(const short2_t (&d)[16])
     return pk_max(bright, -dark);
 }
 
-// XCD-aware 1-D grids: workgroup L runs on XCD L % 8 (observed dispatch order, a speed matter only).  All
+// XCD-aware grids: workgroup L (linear index, x fastest) runs on XCD L % 8 (observed dispatch order, a speed matter only).  All
 // workgroups of an image get the same L % 8 in every kernel of the chain, so what one stage writes for an
 // image (next level, blurred level, candidates) is read by the next stage through the same XCD's L2.
 __device__ __forceinline__ bool xcd_image_map(int gx, int batch, int& b, int& bx)
