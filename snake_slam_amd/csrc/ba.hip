@@ -623,17 +623,23 @@ __global__ __launch_bounds__(256) void cost_wave(Arrays A, Opt O)
     double cost = 0.0;
     if (lane < nob)
     {
+        // observation-indexed loads first, then the gathers through them (two dependent round trips, not four); the
+        // outlier flag only masks the result
         const size_t go = (size_t)pr.obs_off + sb + lane;
-        if (!A.outlier[A.o_orig[go]])
+        const int lp = A.o_pt[go], oimg = A.o_img[go], oorig = A.o_orig[go];
+        const double2 uv = A.o_uv[go];
+        const double odepth = A.o_depth[go], oweight = A.o_weight[go];
+        const double* ptp   = A.pt_new + (size_t)(pr.pt_off + lp) * 3;
+        const double pt[3]  = {ptp[0], ptp[1], ptp[2]};
+        const double* posep = A.pose_new + ((size_t)pr.img_off + oimg) * 7;
+        double pose[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) pose[k] = posep[k];
+        if (!A.outlier[oorig])
         {
-            const int lp       = A.o_pt[go];
-            const double* ptp  = A.pt_new + (size_t)(pr.pt_off + lp) * 3;
-            const double pt[3] = {ptp[0], ptp[1], ptp[2]};
-            const double* pose = A.pose_new + ((size_t)pr.img_off + A.o_img[go]) * 7;
             double R[9], r[3], Jc[1], Jp[1];
             quat_to_R(pose, R);
-            const double2 uv = A.o_uv[go];
-            const int dim = obs_linearize<false>(pose, R, pt, pr.K, pr.bf, uv.x, uv.y, A.o_depth[go], A.o_weight[go], r, Jc, Jp);
+            const int dim = obs_linearize<false>(pose, R, pt, pr.K, pr.bf, uv.x, uv.y, odepth, oweight, r, Jc, Jp);
             if (dim)
             {
                 double sw;
