@@ -1355,8 +1355,13 @@ __device__ void inv6_spd(const double* Ain, int lda, double* Ai)
 
 constexpr int PCG_THREADS = 256;
 // dynamic LDS: r, z, p, Ap (n6 each) | partial sums (4 * n6) | Minv (nfc*36) | S (n6*n6, when s_in_lds)
-__global__ __launch_bounds__(PCG_THREADS) void pcg_solve(Arrays A, Opt O, int s_in_lds)
+// S_IN_LDS is a template parameter, not an argument: with `S = s_in_lds ? Sl : Sg` the matvec read S through a generic
+// pointer, i.e. FLAT loads that resolve the LDS aperture per access (texture-address unit 36 % busy in a kernel that
+// should not touch it); the instantiations read it with ds_read / global_load.
+template <bool S_IN_LDS>
+__global__ __launch_bounds__(PCG_THREADS) void pcg_solve(Arrays A, Opt O)
 {
+    constexpr int s_in_lds = S_IN_LDS ? 1 : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ double red[PCG_THREADS];
     const int pb  = blockIdx.x;
@@ -1377,7 +1382,6 @@ __global__ __launch_bounds__(PCG_THREADS) void pcg_solve(Arrays A, Opt O, int s_
     if (n6 == 0) return;
     if (s_in_lds)
         for (int i = tid; i < n6 * n6; i += PCG_THREADS) Sl[i] = Sg[i];
-    const double* S = s_in_lds ? Sl : Sg;
     for (int c = tid; c < nfc; c += PCG_THREADS) inv6_spd(Sg + (size_t)(c * 6) * n6 + c * 6, n6, Mi + c * 36);
     double part = 0.0;
     for (int q = tid; q < n6; q += PCG_THREADS)
@@ -1415,19 +1419,19 @@ __global__ __launch_bounds__(PCG_THREADS) void pcg_solve(Arrays A, Opt O, int s_
             const int t0 = pi * chunk, t1 = min(t0 + chunk, n6);
             double s = 0.0;
             int u = t0;
-            for (; u + 8 <= t1; u += 8)  // 16 LDS reads in flight; the adds keep their order
+            for (; u + 8 <= t1; u += 8)  // 16 reads in flight; the adds keep their order
             {
                 double a[8], b[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                 {
-                    a[e] = S[(size_t)(u + e) * n6 + q];  // column q == row q (symmetric)
+                    a[e] = S_IN_LDS ? Sl[(u + e) * n6 + q] : Sg[(size_t)(u + e) * n6 + q];  // column q == row q (symmetric)
                     b[e] = p[u + e];
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s += a[e] * b[e];
             }
-            for (; u < t1; ++u) s += S[(size_t)u * n6 + q] * p[u];
+            for (; u < t1; ++u) s += (S_IN_LDS ? Sl[u * n6 + q] : Sg[(size_t)u * n6 + q]) * p[u];
             ps[pi * n6 + q] = s;
         }
         __syncthreads();
@@ -2425,8 +2429,11 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     SNK_HIP_CHECK(hipMemsetAsync(h->d_r.p, 0, nobs * 4 * 8, st));
     SNK_HIP_CHECK(hipMemsetAsync(h->d_x.p, 0, (size_t)std::max(vec_off, 1) * 8, st));
     if (!h->pcg_large)
-        SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pcg_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)std::min<size_t>(pcg_lds + (size_t)max_n6 * max_n6 * 8, 158 * 1024)));
+    {
+        const int lds_max = (int)std::min<size_t>(pcg_lds + (size_t)max_n6 * max_n6 * 8, 158 * 1024);
+        SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pcg_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pcg_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    }
 
     Arrays& A   = h->arr;
     A.prob      = h->d_prob.as<Prob>();
@@ -2554,7 +2561,10 @@ static int enqueue_lm(snk_ba* h, int iterations)
                                        h->point_wave_ok && !no_wave ? 1 : 0, nbx, B);
             }
             if (!h->pcg_large)
-                hipLaunchKernelGGL(pcg_solve, dim3(B), dim3(PCG_THREADS), pcg_lds, st, A, O, s_in_lds);
+                if (s_in_lds)
+                    hipLaunchKernelGGL(pcg_solve<true>, dim3(B), dim3(PCG_THREADS), pcg_lds, st, A, O);
+                else
+                    hipLaunchKernelGGL(pcg_solve<false>, dim3(B), dim3(PCG_THREADS), pcg_lds, st, A, O);
             else
             {
                 const PcgLarge& W = h->pcgw;
