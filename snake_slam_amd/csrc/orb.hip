@@ -474,9 +474,11 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
         const int e  = surv[min(j, ns - 1)];
         const int px = e & 63, py = e >> 6;
         const u8* s  = &S[(py + 1) * SP + px + 1];
-        const int v  = s[0];
-        const bool keep = j < ns && v > min_th && v > s[-1] && v > s[1] && v > s[-SP - 1] && v > s[-SP] && v > s[-SP + 1] &&
-                          v > s[SP - 1] && v > s[SP] && v > s[SP + 1];
+        // all nine reads in one go (a short-circuit chain is nine dependent LDS round trips under divergent branches)
+        const int v = s[0], n0 = s[-1], n1 = s[1], n2 = s[-SP - 1], n3 = s[-SP], n4 = s[-SP + 1], n5 = s[SP - 1], n6 = s[SP],
+                  n7 = s[SP + 1];
+        const int nmax  = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
+        const bool keep = j < ns && v > min_th && v > nmax;
         const u64 m = __builtin_amdgcn_ballot_w64(keep);
         // strength key: higher score first, then smaller y, then smaller x
         if (keep)
