@@ -498,7 +498,13 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
         const u32 k = list[i];
         if (k <= thr) continue;
         int r = 0;
-        for (int j = 0; j < nl; ++j) r += list[j] > k ? 1 : 0;
+        int j = 0;
+        for (; j + 4 <= nl; j += 4)  // four broadcast reads in flight
+        {
+            const u32 a0 = list[j], a1 = list[j + 1], a2 = list[j + 2], a3 = list[j + 3];
+            r += (a0 > k ? 1 : 0) + (a1 > k ? 1 : 0) + (a2 > k ? 1 : 0) + (a3 > k ? 1 : 0);
+        }
+        for (; j < nl; ++j) r += list[j] > k ? 1 : 0;
         if (r < CELL_SLOTS) out[r] = k;
     }
     if (lane == 0) cell_cnt[cell_index] = (u16)(n > 65535 ? 65535 : n);
