@@ -1048,12 +1048,13 @@ __global__ __launch_bounds__(256) void schur_set(Arrays A, int nbx, int B)
                 st[u] = *reinterpret_cast<const uint4*>(ch < wchunks ? Wb + (size_t)s0 * 144 + ch * 16 : Vb + (size_t)p * 48 + (ch - wchunks) * 16);
         }
     };
-    auto consume = [&](int slot, const uint4 (&st)[QUADS])
+    auto consume = [&](int slot, uint4 (&st)[QUADS], int refill)
     {
         unsigned char* base = s_stage[wave][slot];
 #pragma unroll
         for (int u = 0; u < QUADS; ++u)
             if (lane + 64 * u < nch) *reinterpret_cast<uint4*>(base + (lane + 64 * u) * 16) = st[u];
+        if (refill < si.n_pts) fetch(refill, st);
         __builtin_amdgcn_wave_barrier();
         const double2* vv = reinterpret_cast<const double2*>(base + wchunks * 16);
         const double2 v01 = vv[0], v23 = vv[1], v45 = vv[2];
@@ -1086,21 +1087,10 @@ __global__ __launch_bounds__(256) void schur_set(Arrays A, int nbx, int B)
     if (si.n_pts > 1) fetch(1, sb);
     for (int n = 0; n < si.n_pts; n += 2)
     {
-        {
-            uint4 cur[QUADS];
-#pragma unroll
-            for (int u = 0; u < QUADS; ++u) cur[u] = sa[u];
-            if (n + 2 < si.n_pts) fetch(n + 2, sa);
-            consume(0, cur);
-        }
-        if (n + 1 < si.n_pts)
-        {
-            uint4 cur[QUADS];
-#pragma unroll
-            for (int u = 0; u < QUADS; ++u) cur[u] = sb[u];
-            if (n + 3 < si.n_pts) fetch(n + 3, sb);
-            consume(1, cur);
-        }
+        // a register set is refilled right after its chunks went to LDS (inside consume): no copy, the refill is in
+        // flight during the multiplications
+        consume(0, sa, n + 2);
+        if (n + 1 < si.n_pts) consume(1, sb, n + 3);
     }
 #pragma unroll
     for (int t = 0; t < ROUNDS; ++t)
