@@ -252,6 +252,7 @@ int orc_match_coarse(const orc_frame_view* f, const orc_camera* cam, const doubl
             if (rot < 0.0) rot += 360.0f;
             int bin = (int)roundf(rot * factor); /* :313 */
             if (bin == 30) bin = 0;
+            if (!(bin >= 0 && bin < 30)) continue; /* :316 asserts; angles outside [0,360) / NaN: unmatched */
             best[i] = u.best_idx;
             bins[i] = bin;
         }

@@ -37,6 +37,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <map>
+#include <tuple>
+#include <utility>
 #include <vector>
 
 // This file is compiled with -ffp-contract=fast (snake_slam_amd/build.py): BA is specified by a tolerance, its kernels
@@ -1873,10 +1875,12 @@ struct snk_ba : HandleBase
     Arrays arr{};
     std::vector<int> orig_off, orig_n;
     std::map<int, hipGraphExec_t> graphs;  // LM launch sequence captured per iteration count
+    std::map<int, int> plain_runs;         // solves issued with plain launches since set_problems, per iteration count
     void drop_graphs()
     {
         for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
         graphs.clear();
+        plain_runs.clear();
     }
 };
 
@@ -1902,6 +1906,50 @@ int upload(DevBuf& b, const std::vector<T>& v, hipStream_t s)
     return SNK_OK;
 }
 }  // namespace
+
+// One launch sequence, two ways to issue it: plain launches on the handle's stream, or kernel nodes appended to an
+// explicitly built hipGraph (a linear chain).  No stream capture anywhere: capture is process-visible state that any
+// other seam's thread (FeatureDetection || Preprocess || Tracking || LBA all run at once) can
+// invalidate with an allocation or a synchronous copy; hipGraphAddKernelNode touches nothing but this handle's graph.
+struct Launcher
+{
+    hipStream_t st      = nullptr;
+    hipGraph_t graph    = nullptr;  // non-null: record instead of launching
+    hipGraphNode_t last = nullptr;
+    hipError_t err      = hipSuccess;
+    int line            = 0;
+    template <typename... P, typename... A>
+    void operator()(int at, void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, A&&... a)
+    {
+        static_assert(sizeof...(P) == sizeof...(A), "kernel argument count");
+        if (err != hipSuccess) return;
+        std::tuple<P...> args{static_cast<P>(a)...};
+        void* ptrs[sizeof...(P)];
+        fill(ptrs, args, std::index_sequence_for<P...>{});
+        if (!graph)
+            err = hipLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, ptrs, lds, st);
+        else
+        {
+            hipKernelNodeParams np{};
+            np.func           = reinterpret_cast<void*>(kernel);
+            np.gridDim        = grid;
+            np.blockDim       = block;
+            np.sharedMemBytes = (unsigned)lds;
+            np.kernelParams   = ptrs;
+            np.extra          = nullptr;
+            hipGraphNode_t node = nullptr;
+            err = hipGraphAddKernelNode(&node, graph, last ? &last : nullptr, last ? 1 : 0, &np);
+            last = node;
+        }
+        if (err != hipSuccess) line = at;
+    }
+    template <typename T, size_t... I>
+    static void fill(void** ptrs, T& args, std::index_sequence<I...>)
+    {
+        ((ptrs[I] = &std::get<I>(args)), ...);
+    }
+};
+#define LAUNCH(...) L(__LINE__, __VA_ARGS__)
 
 extern "C" {
 
@@ -2420,9 +2468,9 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     SNK_HIP_CHECK(hipMemsetAsync(h->d_x.p, 0, (size_t)std::max(vec_off, 1) * 8, st));
     if (!h->pcg_large)
     {
-        const int lds_max = (int)std::min<size_t>(pcg_lds + (size_t)max_n6 * max_n6 * 8, 158 * 1024);
-        SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pcg_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-        SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pcg_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        // process-wide, once, to the most the kernels can use (enqueue_lm keeps S in LDS only when it fits 158 KB)
+        if ((rc = set_max_lds_once(reinterpret_cast<const void*>(pcg_solve<true>), 158 * 1024)) != SNK_OK) return rc;
+        if ((rc = set_max_lds_once(reinterpret_cast<const void*>(pcg_solve<false>), 158 * 1024)) != SNK_OK) return rc;
     }
 
     Arrays& A   = h->arr;
@@ -2508,14 +2556,12 @@ int snk_ba_reset(snk_ba* h)
     return SNK_OK;
 }
 
-static int enqueue_lm(snk_ba* h, int iterations)
+static int enqueue_lm(snk_ba* h, int iterations, Launcher& L)
 {
     const Opt O     = make_opt(h->opt);
     const Arrays& A = h->arr;
-    hipStream_t st  = h->stream;
     const int B     = h->count;
-    hipLaunchKernelGGL(begin_solve, dim3(ceil_div(B, 64)), dim3(64), 0, st, h->d_state.as<State>(), B, O.lambda_init);
-    SNK_LAUNCH_CHECK();
+    LAUNCH(begin_solve, dim3(ceil_div(B, 64)), dim3(64), 0, h->d_state.as<State>(), B, O.lambda_init);
     const dim3 gpt(std::max(1, ceil_div(h->max_np, 128)), B);
     size_t pcg_lds        = (size_t)h->max_n6 * 9 * 8 + (size_t)h->max_nfc * 36 * 8;
     const size_t s_bytes  = (size_t)h->max_n6 * h->max_n6 * 8;
@@ -2525,13 +2571,13 @@ static int enqueue_lm(snk_ba* h, int iterations)
     {
         static const bool no_wave = getenv("SNK_BA_NO_POINT_WAVE") != nullptr;
         if (h->point_wave_ok && !no_wave)
-            hipLaunchKernelGGL(point_wave, dim3(h->max_wv, B), dim3(64), 0, st, A, O);
+            LAUNCH(point_wave, dim3(h->max_wv, B), dim3(64), 0, A, O);
         else
-            hipLaunchKernelGGL(point_pass<0>, gpt, dim3(128), 0, st, A, O);
+            LAUNCH(point_pass<0>, gpt, dim3(128), 0, A, O);
         if (h->max_nfc > 0)
         {
-            if (h->max_rpc > 0) hipLaunchKernelGGL(rpc_pass, dim3(ceil_div(h->max_rpc, 64), B), dim3(64), 0, st, A, 0);
-            hipLaunchKernelGGL(cam_pass, dim3(h->max_nfc, B), dim3(CAM_THREADS), 0, st, A, O);
+            if (h->max_rpc > 0) LAUNCH(rpc_pass, dim3(ceil_div(h->max_rpc, 64), B), dim3(64), 0, A, 0);
+            LAUNCH(cam_pass, dim3(h->max_nfc, B), dim3(CAM_THREADS), 0, A, O);
             {
                 const int nbx = ceil_div(h->max_nfc * h->max_nfc, 4);
                 static const bool no_set = getenv("SNK_BA_NO_SCHUR_SET") != nullptr;  // A/B measurements
@@ -2541,89 +2587,97 @@ static int enqueue_lm(snk_ba* h, int iterations)
                 {
                     const int nsx = ceil_div(h->max_set_items, 4);
                     if (h->set_small)
-                        hipLaunchKernelGGL((schur_set<4, 2>), dim3(nsx * 8 * ceil_div(B, 8)), dim3(256), 0, st, A, nsx, B);
+                        LAUNCH((schur_set<4, 2>), dim3(nsx * 8 * ceil_div(B, 8)), dim3(256), 0, A, nsx, B);
                     else
-                        hipLaunchKernelGGL((schur_set<6, 3>), dim3(nsx * 8 * ceil_div(B, 8)), dim3(256), 0, st, A, nsx, B);
-                    hipLaunchKernelGGL(schur_sum, dim3(nbx * 8 * ceil_div(B, 8)), dim3(256), 0, st, A, nbx, B);
+                        LAUNCH((schur_set<6, 3>), dim3(nsx * 8 * ceil_div(B, 8)), dim3(256), 0, A, nsx, B);
+                    LAUNCH(schur_sum, dim3(nbx * 8 * ceil_div(B, 8)), dim3(256), 0, A, nbx, B);
                 }
                 else
-                    hipLaunchKernelGGL(schur_pass, dim3(nbx * 8 * ceil_div(B, 8)), dim3(256), 0, st, A,
+                    LAUNCH(schur_pass, dim3(nbx * 8 * ceil_div(B, 8)), dim3(256), 0, A,
                                        h->point_wave_ok && !no_wave ? 1 : 0, nbx, B);
             }
             if (!h->pcg_large)
                 if (s_in_lds)
-                    hipLaunchKernelGGL(pcg_solve<true>, dim3(B), dim3(PCG_THREADS), pcg_lds, st, A, O);
+                    LAUNCH(pcg_solve<true>, dim3(B), dim3(PCG_THREADS), pcg_lds, A, O);
                 else
-                    hipLaunchKernelGGL(pcg_solve<false>, dim3(B), dim3(PCG_THREADS), pcg_lds, st, A, O);
+                    LAUNCH(pcg_solve<false>, dim3(B), dim3(PCG_THREADS), pcg_lds, A, O);
             else
             {
                 const PcgLarge& W = h->pcgw;
                 const dim3 gcam(W.G, B);
                 const dim3 gmv(ceil_div(h->max_n6, 256) * W.parts, B);
-                hipLaunchKernelGGL(pcgl_init, gcam, dim3(64), 0, st, A, O, W);
+                LAUNCH(pcgl_init, gcam, dim3(64), 0, A, O, W);
                 for (int k = 0; k < O.max_pcg; ++k)
                 {
-                    hipLaunchKernelGGL(pcgl_matvec, gmv, dim3(256), 0, st, A, O, W, k);
-                    hipLaunchKernelGGL(pcgl_combine, gcam, dim3(64), 0, st, A, O, W, k);
-                    hipLaunchKernelGGL(pcgl_update, gcam, dim3(64), 0, st, A, O, W, k);
-                    hipLaunchKernelGGL(pcgl_direction, gcam, dim3(64), 0, st, A, O, W, k);
-                    hipLaunchKernelGGL(pcgl_latch, dim3(ceil_div(B, 64)), dim3(64), 0, st, A, O, W, k);
+                    LAUNCH(pcgl_matvec, gmv, dim3(256), 0, A, O, W, k);
+                    LAUNCH(pcgl_combine, gcam, dim3(64), 0, A, O, W, k);
+                    LAUNCH(pcgl_update, gcam, dim3(64), 0, A, O, W, k);
+                    LAUNCH(pcgl_direction, gcam, dim3(64), 0, A, O, W, k);
+                    LAUNCH(pcgl_latch, dim3(ceil_div(B, 64)), dim3(64), 0, A, O, W, k);
                 }
             }
         }
         if (h->point_wave_ok && !no_wave)
         {
             const dim3 gwv(ceil_div(h->max_wv, 4), B);
-            hipLaunchKernelGGL(update_wave, gwv, dim3(256), 0, st, A, O);
-            hipLaunchKernelGGL(update_pass, dim3(std::max(1, ceil_div(h->max_ni, 128)), B), dim3(128), 0, st, A, 1);
-            hipLaunchKernelGGL(cost_wave, gwv, dim3(256), 0, st, A, O);
+            LAUNCH(update_wave, gwv, dim3(256), 0, A, O);
+            LAUNCH(update_pass, dim3(std::max(1, ceil_div(h->max_ni, 128)), B), dim3(128), 0, A, 1);
+            LAUNCH(cost_wave, gwv, dim3(256), 0, A, O);
         }
         else
         {
-            hipLaunchKernelGGL(update_pass, dim3(std::max(1, ceil_div(h->max_np + h->max_ni, 128)), B), dim3(128), 0, st, A, 0);
-            hipLaunchKernelGGL(point_pass<1>, gpt, dim3(128), 0, st, A, O);
+            LAUNCH(update_pass, dim3(std::max(1, ceil_div(h->max_np + h->max_ni, 128)), B), dim3(128), 0, A, 0);
+            LAUNCH(point_pass<1>, gpt, dim3(128), 0, A, O);
         }
-        if (h->max_rpc > 0 && h->max_nfc > 0) hipLaunchKernelGGL(rpc_pass, dim3(ceil_div(h->max_rpc, 64), B), dim3(64), 0, st, A, 1);
-        hipLaunchKernelGGL(accept_pass, dim3(B), dim3(ACC_THREADS), 0, st, A);
-        SNK_LAUNCH_CHECK();
+        if (h->max_rpc > 0 && h->max_nfc > 0) LAUNCH(rpc_pass, dim3(ceil_div(h->max_rpc, 64), B), dim3(64), 0, A, 1);
+        LAUNCH(accept_pass, dim3(B), dim3(ACC_THREADS), 0, A);
+    }
+    if (L.err != hipSuccess)
+    {
+        set_error("bundle adjustment launch failed: %s (%s:%d)", hipGetErrorString(L.err), __FILE__, L.line);
+        return SNK_ERR_HIP;
     }
     return SNK_OK;
 }
 
-// The LM loop is a fixed launch sequence (all decisions are taken on the device), so it is captured
-// once per iteration count into a hipGraph and replayed: one graph launch instead of 7 launches per
-// iteration.  SNK_BA_NO_GRAPH=1 falls back to plain launches.
+// The LM loop is a fixed launch sequence (all decisions are taken on the device).  A sequence that is issued again for
+// the same problem set and iteration count is replayed as ONE graph launch instead of 7+ launches per iteration; the
+// graph is built explicitly, node by node (see Launcher), never by stream capture.  The reference's local-BA call
+// pattern is a NEW scene per keyframe solved once or twice (LocalBundleAdjustment.cpp:353-413), where building and
+// instantiating a graph costs more than it saves: the first solve with a given iteration count after set_problems
+// uses plain launches, a repeat builds the graph (measured: DESIGN.md section 4).  SNK_BA_NO_GRAPH=1: never,
+// SNK_BA_GRAPH_FIRST=1: already on the first use.
 int snk_ba_solve_async(snk_ba* h, int iterations)
 {
     SNK_REQUIRE(h != nullptr && h->count > 0, "no problem set");
     SNK_REQUIRE(iterations >= 0, "negative iteration count");
     SNK_HIP_CHECK(hipSetDevice(h->device));
-    static const bool no_graph = getenv("SNK_BA_NO_GRAPH") != nullptr;
-    if (no_graph || iterations == 0) return enqueue_lm(h, iterations);
+    static const bool no_graph    = getenv("SNK_BA_NO_GRAPH") != nullptr;
+    static const bool graph_first = getenv("SNK_BA_GRAPH_FIRST") != nullptr;
+    Launcher direct;
+    direct.st = h->stream;
+    if (no_graph || iterations == 0) return enqueue_lm(h, iterations, direct);
     auto it = h->graphs.find(iterations);
     if (it == h->graphs.end())
     {
-        hipGraph_t graph = nullptr;
-        if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess)
+        if (!graph_first && h->plain_runs[iterations]++ == 0) return enqueue_lm(h, iterations, direct);
+        Launcher rec;
+        rec.st = h->stream;
+        if (hipGraphCreate(&rec.graph, 0) != hipSuccess)
         {
             (void)hipGetLastError();
-            return enqueue_lm(h, iterations);
+            return enqueue_lm(h, iterations, direct);
         }
-        const int rc = enqueue_lm(h, iterations);
-        const hipError_t e = hipStreamEndCapture(h->stream, &graph);
-        if (rc != SNK_OK || e != hipSuccess || graph == nullptr)
-        {
-            (void)hipGetLastError();
-            if (graph) (void)hipGraphDestroy(graph);
-            return rc != SNK_OK ? rc : enqueue_lm(h, iterations);
-        }
+        const int rc       = enqueue_lm(h, iterations, rec);
         hipGraphExec_t exec = nullptr;
-        const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (ei != hipSuccess || exec == nullptr)
+        hipError_t ei       = hipErrorUnknown;
+        if (rc == SNK_OK) ei = hipGraphInstantiate(&exec, rec.graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(rec.graph);
+        if (rc != SNK_OK || ei != hipSuccess || exec == nullptr)
         {
+            // nothing has been enqueued yet (recording only adds nodes): issue the sequence directly instead
             (void)hipGetLastError();
-            return enqueue_lm(h, iterations);
+            return enqueue_lm(h, iterations, direct);
         }
         it = h->graphs.emplace(iterations, exec).first;
     }

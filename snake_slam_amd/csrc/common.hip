@@ -2,6 +2,8 @@
 #include "common.hpp"
 
 #include <cstdarg>
+#include <map>
+#include <mutex>
 
 namespace snk
 {
@@ -13,6 +15,18 @@ void set_error(const char* fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+int set_max_lds_once(const void* kernel, int bytes)
+{
+    static std::mutex mu;
+    static std::map<const void*, int> done;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = done.find(kernel);
+    if (it != done.end() && it->second >= bytes) return SNK_OK;
+    SNK_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done[kernel] = bytes;
+    return SNK_OK;
 }
 
 int HandleBase::init(int dev, void* user_stream)

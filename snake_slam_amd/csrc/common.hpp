@@ -66,8 +66,10 @@ struct DevBuf
         static const bool poison = getenv("SNK_DEBUG_POISON") != nullptr;
         if (poison)
         {
-            SNK_HIP_CHECK(hipMemset(p, 0xCD, want));
-            SNK_HIP_CHECK(hipDeviceSynchronize());  // the fill must not overtake / trail the handle stream's uploads
+            // on the calling thread's own stream (never the legacy stream: other seams run beside this one), complete
+            // before the handle's stream touches the buffer
+            SNK_HIP_CHECK(hipMemsetAsync(p, 0xCD, want, hipStreamPerThread));
+            SNK_HIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
         }
         return SNK_OK;
     }
@@ -83,6 +85,53 @@ struct DevBuf
         return reinterpret_cast<T*>(p);
     }
 };
+
+// Grow-only pinned host staging buffer: device -> host results land here with ONE asynchronous copy on the handle's
+// stream and are handed to the caller's (pageable) arrays with memcpy after the stream synchronisation.
+struct HostBuf
+{
+    void* p      = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t n)
+    {
+        if (n <= bytes) return SNK_OK;
+        if (p) (void)hipHostFree(p);
+        p     = nullptr;
+        bytes = 0;
+        size_t want = n + n / 4 + 256;
+        SNK_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+        bytes = want;
+        return SNK_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p     = nullptr;
+        bytes = 0;
+    }
+    template <typename T>
+    T* as() const
+    {
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+// Blocking copy on the handle's own stream.  The library never touches the legacy (NULL) stream: the seams are called
+// from different OS threads at the same time and a legacy-stream call synchronises with -- and,
+// during a stream capture, invalidates -- every other handle's work.
+inline int copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t stream)
+{
+    if (bytes == 0) return SNK_OK;
+    SNK_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, kind, stream));
+    SNK_HIP_CHECK(hipStreamSynchronize(stream));
+    return SNK_OK;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is per-kernel, process-wide state: it is set ONCE per kernel to the
+// largest carve the kernel supports (never from per-handle or per-call sizes, which would race between handles).
+int set_max_lds_once(const void* kernel, int bytes);
+
+constexpr int LDS_MAX_BYTES = 160 * 1024;  // gfx950: 160 KB of LDS per workgroup
 
 struct HandleBase
 {

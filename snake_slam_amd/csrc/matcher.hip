@@ -763,15 +763,24 @@ using namespace snk;
 
 extern "C" {
 
+int snk_matcher_destroy(snk_matcher* m);
+
 int snk_matcher_create(int device, void* stream, snk_matcher** out)
 {
     SNK_REQUIRE(out != nullptr, "out is NULL");
     *out           = nullptr;
     snk_matcher* m = new snk_matcher();
     int rc         = m->init(device, stream);
+    // scratch for the per-frame (host pointer) calls is sized here -- 4 MB per buffer holds any call up to ~40 000
+    // features / map points -- so that the seams allocate nothing while other seams' threads are running
+    // (hipMalloc / hipFree synchronise the whole device); larger calls still grow the buffers once
+    constexpr size_t SCRATCH = 4u << 20;
+    for (snk::DevBuf* b : {&m->q, &m->t, &m->out, &m->aux, &m->aux2, &m->view})
+        if (rc == SNK_OK) rc = b->reserve(SCRATCH);
+    if (rc == SNK_OK) rc = m->cnt.reserve(256);
     if (rc != SNK_OK)
     {
-        delete m;
+        snk_matcher_destroy(m);
         return rc;
     }
     *out = m;
@@ -788,6 +797,7 @@ int snk_matcher_destroy(snk_matcher* m)
     m->aux.release();
     m->aux2.release();
     m->cnt.release();
+    m->view.release();
     m->fini();
     delete m;
     return SNK_OK;
@@ -883,7 +893,7 @@ int snk_bf_filter(snk_matcher* m, const snk_knn2* knn, int nq, int threshold, fl
     int n = 0;
     SNK_HIP_CHECK(hipMemcpyAsync(&n, m->cnt.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
     SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
-    if (n > 0) SNK_HIP_CHECK(hipMemcpy(pairs, m->aux.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (n > 0 && (rc = copy_sync(pairs, m->aux.p, (size_t)n * 8, hipMemcpyDeviceToHost, m->stream)) != SNK_OK) return rc;
     *n_pairs = n;
     return SNK_OK;
 }
@@ -948,10 +958,8 @@ int snk_stereo_match(snk_matcher* m, const snk_kp64* left, const uint64_t (*desc
         if ((rc = m->out.reserve((size_t)nr * 4)) != SNK_OK) return rc;
         int np2 = 2;
         while (np2 < nr) np2 <<= 1;
-        SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stereo_sort_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, ST_SORT_MAX * 4));
-        SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stereo_kernel16),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, ST_SORT_MAX * 4));
+        if ((rc = set_max_lds_once(reinterpret_cast<const void*>(stereo_sort_kernel), ST_SORT_MAX * 4)) != SNK_OK) return rc;
+        if ((rc = set_max_lds_once(reinterpret_cast<const void*>(stereo_kernel16), ST_SORT_MAX * 4)) != SNK_OK) return rc;
         hipLaunchKernelGGL(stereo_sort_kernel, dim3(1), dim3(256), (size_t)np2 * 4, m->stream, (const snk_kp64*)(ab + kl),
                            (const int*)nullptr, nr, nr, m->out.as<u32>());
         srt = m->out.as<u32>();
@@ -994,8 +1002,7 @@ int snk_stereo_match_batch_dev(snk_matcher* m, const snk_kp64* left_dev, const u
     if (!no_frame_kernel && nr_cap <= ST_FRAME_MAX && batch >= 8)
     {
         // enough frames to give every CU its own: one workgroup per frame, the right side resident in LDS
-        SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stereo_frame_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)stereo_frame_lds(ST_FRAME_MAX)));
+        if ((rc = set_max_lds_once(reinterpret_cast<const void*>(stereo_frame_kernel), (int)stereo_frame_lds(ST_FRAME_MAX))) != SNK_OK) return rc;
         hipLaunchKernelGGL(stereo_frame_kernel, dim3(batch), dim3(1024), stereo_frame_lds(nr_cap), m->stream, left_dev,
                            (const uint4*)desc_left_dev, nl_dev, nl_cap, 0, right_dev, (const uint4*)desc_right_dev, nr_dev, nr_cap,
                            0, bf, ls, relaxed, right_points_dev, depth_dev, n_matches_dev);
@@ -1007,10 +1014,8 @@ int snk_stereo_match_batch_dev(snk_matcher* m, const snk_kp64* left_dev, const u
         if ((rc = m->out.reserve((size_t)batch * nr_cap * 4)) != SNK_OK) return rc;
         int np2 = 2;
         while (np2 < nr_cap) np2 <<= 1;
-        SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stereo_sort_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, ST_SORT_MAX * 4));
-        SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stereo_kernel16),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, ST_SORT_MAX * 4));
+        if ((rc = set_max_lds_once(reinterpret_cast<const void*>(stereo_sort_kernel), ST_SORT_MAX * 4)) != SNK_OK) return rc;
+        if ((rc = set_max_lds_once(reinterpret_cast<const void*>(stereo_kernel16), ST_SORT_MAX * 4)) != SNK_OK) return rc;
         hipLaunchKernelGGL(stereo_sort_kernel, dim3(batch), dim3(256), (size_t)np2 * 4, m->stream, right_dev, nr_dev, nr_cap, 0,
                            m->out.as<u32>());
         srt = m->out.as<u32>();

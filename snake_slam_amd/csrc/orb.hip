@@ -1501,7 +1501,8 @@ struct snk_orb : HandleBase
     DevBuf cell_tab;         // FAST cell geometry
     DevBuf img0;             // level-0 staging for the host API
     DevBuf cand, cell_cnt, sel, sel_score, sel_cnt, cand_total, dist_queue;
-    DevBuf out_kps, out_desc, out_n;  // host-API staging
+    DevBuf out_kps;          // host-API staging: [count | pad to 64 B][cap keypoints][cap descriptors], fetched with ONE copy
+    HostBuf h_out, h_img;    // pinned mirrors of out_kps / img0
     int pitch0_host = 0;
     size_t dist_lds = 0, dist_lds_small = 0;
     int dist_small_cap = 0;
@@ -1693,8 +1694,8 @@ int snk_orb_destroy(snk_orb* o)
     o->cand_total.release();
     o->dist_queue.release();
     o->out_kps.release();
-    o->out_desc.release();
-    o->out_n.release();
+    o->h_out.release();
+    o->h_img.release();
     for (auto& e : o->ev_sets)
         for (auto& x : e) (void)hipEventDestroy(x);
     if (o->ev_fork) (void)hipEventDestroy(o->ev_fork);
@@ -1767,9 +1768,9 @@ int snk_orb_configure(snk_orb* o, int width, int height, int max_batch)
             }
             at += (size_t)sv.n_strips + 1;
         }
-        hipError_t e = hipMemcpy(o->tables.p, host, tab_ints * sizeof(int), hipMemcpyHostToDevice);
+        rc = copy_sync(o->tables.p, host, tab_ints * sizeof(int), hipMemcpyHostToDevice, o->stream);
         free(host);
-        SNK_HIP_CHECK(e);
+        if (rc != SNK_OK) return rc;
     }
     for (int l = 1; l < L.n_levels; ++l)
     {
@@ -1800,7 +1801,7 @@ int snk_orb_configure(snk_orb* o, int width, int height, int max_batch)
             }
         }
         if ((rc = o->cell_tab.reserve(ct.size() * sizeof(int4))) != SNK_OK) return rc;
-        SNK_HIP_CHECK(hipMemcpy(o->cell_tab.p, ct.data(), ct.size() * sizeof(int4), hipMemcpyHostToDevice));
+        if ((rc = copy_sync(o->cell_tab.p, ct.data(), ct.size() * sizeof(int4), hipMemcpyHostToDevice, o->stream)) != SNK_OK) return rc;
         L.cell_tab = o->cell_tab.as<int4>();
     }
     const size_t cells = (size_t)(L.total_cells > 0 ? L.total_cells : 1) * max_batch;
@@ -1817,11 +1818,21 @@ int snk_orb_configure(snk_orb* o, int width, int height, int max_batch)
     o->dist_lds       = dist_lds_bytes((size_t)L.level_cap);
     o->dist_lds_small = dist_lds_bytes((size_t)o->dist_small_cap);
     if ((rc = o->dist_queue.reserve(snk_orb::MAX_PARTS * ((size_t)max_batch * MAX_LEVELS + 1) * sizeof(int))) != SNK_OK) return rc;  // one per chain
-    SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(distribute_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->dist_lds_small));
-    SNK_HIP_CHECK(hipFuncSetAttribute(fast_kernel_for(L), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * L.f_lds_wave));
-    SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(distribute_large_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->dist_lds));
+    // process-wide, once per kernel, to the largest carve any handle can ask for (never per-handle sizes: two extractors
+    // with different image sizes / level_cap would overwrite each other's limit)
+    SNK_REQUIRE(4 * L.f_lds_wave <= LDS_MAX_BYTES, "FAST cells too large for the LDS (image too small for its cell grid?)");
+    if ((rc = set_max_lds_once(reinterpret_cast<const void*>(distribute_kernel), (int)dist_lds_bytes(2048))) != SNK_OK) return rc;
+    if ((rc = set_max_lds_once(reinterpret_cast<const void*>(distribute_large_kernel), (int)dist_lds_bytes(8192))) != SNK_OK) return rc;
+    if ((rc = set_max_lds_once(fast_kernel_for(L), LDS_MAX_BYTES)) != SNK_OK) return rc;
+    // host-API staging (snk_orb_detect): sized here so that the per-image call allocates nothing
+    {
+        const int dpitch = (width + 63) & ~63;
+        const int cap    = L.total_slots > 0 ? L.total_slots : 1;
+        if ((rc = o->img0.reserve((size_t)dpitch * height + 64)) != SNK_OK) return rc;
+        if ((rc = o->out_kps.reserve((size_t)cap * (sizeof(snk_keypoint) + 32) + 128)) != SNK_OK) return rc;
+        if ((rc = o->h_out.reserve((size_t)cap * (sizeof(snk_keypoint) + 32) + 128)) != SNK_OK) return rc;
+        if ((rc = o->h_img.reserve((size_t)dpitch * height)) != SNK_OK) return rc;
+    }
     o->width      = width;
     o->height     = height;
     o->max_batch  = max_batch;
@@ -2007,17 +2018,20 @@ int snk_orb_detect(snk_orb* o, const uint8_t* img, int w, int h, int pitch, snk_
     SNK_HIP_CHECK(hipSetDevice(o->device));
     const int dpitch = (w + 63) & ~63;
     const int cap    = o->lay.total_slots > 0 ? o->lay.total_slots : 1;
-    if ((rc = o->img0.reserve((size_t)dpitch * h + 64)) != SNK_OK) return rc;
-    if ((rc = o->out_kps.reserve((size_t)cap * sizeof(snk_keypoint))) != SNK_OK) return rc;
-    if ((rc = o->out_desc.reserve((size_t)cap * 32)) != SNK_OK) return rc;
-    if ((rc = o->out_n.reserve(64)) != SNK_OK) return rc;
-    SNK_HIP_CHECK(hipMemcpy2DAsync(o->img0.p, dpitch, img, pitch, w, h, hipMemcpyHostToDevice, o->stream));
-    rc = run_pipeline(o, o->img0.as<u8>(), dpitch, (long long)dpitch * h, 1, o->out_kps.as<snk_keypoint>(),
-                      o->out_desc.as<uint64_t>(), o->out_n.as<int32_t>(), cap);
+    // staging was sized by snk_orb_configure: [count, 64 B][cap keypoints][cap descriptors] on the device, a pinned
+    // mirror on the host.  One upload, the launch chain, ONE download, one synchronisation -- all on the handle's stream.
+    u8* dbase            = o->out_kps.as<u8>();
+    snk_keypoint* d_kps  = reinterpret_cast<snk_keypoint*>(dbase + 64);
+    const size_t desc_at = (64 + (size_t)cap * sizeof(snk_keypoint) + 63) & ~(size_t)63;
+    uint64_t* d_desc     = reinterpret_cast<uint64_t*>(dbase + desc_at);
+    const size_t out_len = desc_at + (size_t)cap * 32;
+    for (int r = 0; r < h; ++r) memcpy(o->h_img.as<u8>() + (size_t)r * dpitch, img + (size_t)r * pitch, (size_t)w);
+    SNK_HIP_CHECK(hipMemcpyAsync(o->img0.p, o->h_img.p, (size_t)dpitch * h, hipMemcpyHostToDevice, o->stream));
+    rc = run_pipeline(o, o->img0.as<u8>(), dpitch, (long long)dpitch * h, 1, d_kps, d_desc, reinterpret_cast<int32_t*>(dbase), cap);
     if (rc != SNK_OK) return rc;
-    int n = 0;
-    SNK_HIP_CHECK(hipMemcpyAsync(&n, o->out_n.p, sizeof(int), hipMemcpyDeviceToHost, o->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(o->h_out.p, dbase, out_len, hipMemcpyDeviceToHost, o->stream));
     SNK_HIP_CHECK(hipStreamSynchronize(o->stream));
+    const int n = *o->h_out.as<int32_t>();
     if (n > capacity)
     {
         set_error("capacity %d too small for %d keypoints (see snk_orb_max_keypoints)", capacity, n);
@@ -2026,8 +2040,8 @@ int snk_orb_detect(snk_orb* o, const uint8_t* img, int w, int h, int pitch, snk_
     }
     if (n > 0)
     {
-        SNK_HIP_CHECK(hipMemcpy(kps, o->out_kps.p, (size_t)n * sizeof(snk_keypoint), hipMemcpyDeviceToHost));
-        SNK_HIP_CHECK(hipMemcpy(desc, o->out_desc.p, (size_t)n * 32, hipMemcpyDeviceToHost));
+        memcpy(kps, o->h_out.as<u8>() + 64, (size_t)n * sizeof(snk_keypoint));
+        memcpy(desc, o->h_out.as<u8>() + desc_at, (size_t)n * 32);
     }
     *n_out = n;
     return SNK_OK;
@@ -2126,7 +2140,7 @@ int snk_orb_debug_fetch(snk_orb* o, int what, int image, int level, void* out, s
         default: SNK_REQUIRE(false, "unknown debug selector");
     }
     SNK_REQUIRE(out != nullptr && cap_bytes >= bytes, "buffer too small");
-    if (bytes) SNK_HIP_CHECK(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
+    if (int rc = copy_sync(out, src, bytes, hipMemcpyDeviceToHost, o->stream)) return rc;
     *n_bytes = bytes;
     return SNK_OK;
 }

@@ -195,6 +195,9 @@ __global__ __launch_bounds__(256) void coarse_kernel(FrameDev F, CamDev C, Scale
             if (rot < 0.0f) rot += 360.0f;
             bin = (int)roundf(rot * (1.0f / 30));
             if (bin == 30) bin = 0;
+            // the reference asserts 0 <= bin < HISTO_LENGTH (:316); angles outside [0, 360) or NaN have no bin:
+            // such a point is left unmatched instead of indexing outside the histogram
+            if (!(bin >= 0 && bin < 30)) { result = -1; bin = 0; }
         }
     }
     if (lane == 0)
@@ -899,8 +902,7 @@ int snk_feature_grid(snk_matcher* m, const snk_kp64* undistorted, int n, const s
     int* d_perm = m->aux2.as<int>();
     int* d_cs   = d_perm + (n > 0 ? n : 1);
     if (n) SNK_HIP_CHECK(hipMemcpyAsync(m->aux.p, undistorted, (size_t)n * sizeof(snk_kp64), hipMemcpyHostToDevice, m->stream));
-    SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      16384 * 4));
+    if ((rc = set_max_lds_once(reinterpret_cast<const void*>(grid_kernel), 16384 * 4)) != SNK_OK) return rc;
     hipLaunchKernelGGL(grid_kernel, dim3(1), dim3(256), (size_t)n_pow2 * 4, m->stream, m->aux.as<snk_kp64>(), (const int*)nullptr,
                        n, n > 0 ? n : 1, bounds->min_x, bounds->min_y, cols, rows, d_perm, (int*)nullptr, d_cs);
     SNK_LAUNCH_CHECK();
@@ -926,8 +928,7 @@ int snk_feature_grid_batch_dev(snk_matcher* m, const snk_grid_bounds* bounds, co
     if ((rc = m->aux2.reserve((size_t)batch * cap * 4)) != SNK_OK) return rc;
     int cap_pow2 = 2;
     while (cap_pow2 < cap) cap_pow2 <<= 1;
-    SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      16384 * 4));
+    if ((rc = set_max_lds_once(reinterpret_cast<const void*>(grid_kernel), 16384 * 4)) != SNK_OK) return rc;
     hipLaunchKernelGGL(grid_kernel, dim3(batch), dim3(256), (size_t)cap_pow2 * 4, m->stream, kps_dev, n_dev, 0, cap, bounds->min_x,
                        bounds->min_y, cols, rows, perm_dev, m->aux2.as<int>(), cell_start_dev);
     hipLaunchKernelGGL(reorder_kernel, dim3(ceil_div(cap, 256), batch), dim3(256), 0, m->stream, m->aux2.as<int>(), n_dev, cap,
@@ -1036,8 +1037,7 @@ int snk_match_project_keyframe(snk_matcher* m, const snk_frame_view* frame, cons
     SNK_HIP_CHECK(hipMemcpyAsync(d, positions, np * 24, hipMemcpyHostToDevice, m->stream));
     SNK_HIP_CHECK(hipMemcpyAsync(d + o_desc, descriptors, np * 32, hipMemcpyHostToDevice, m->stream));
     SNK_HIP_CHECK(hipMemcpyAsync(d + o_skip, skip, np, hipMemcpyHostToDevice, m->stream));
-    SNK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(keyframe_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, KF_MAX_FEATURES));
+    if ((rc = set_max_lds_once(reinterpret_cast<const void*>(keyframe_kernel), KF_MAX_FEATURES + 16)) != SNK_OK) return rc;
     hipLaunchKernelGGL(keyframe_kernel, dim3(1), dim3(64), (size_t)((F.n + 15) & ~15) + 16, m->stream, F, C,
                        reinterpret_cast<const double*>(d), reinterpret_cast<const uint4*>(d + o_desc),
                        reinterpret_cast<const u8*>(d + o_skip), n_pts, th, feature_error, m->out.as<int>(), m->cnt.as<int>());
