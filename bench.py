@@ -93,6 +93,104 @@ def cpu_baseline_ba(seconds_budget=8.0):
             "sample": f"{done} solves of the 20x2000x8 window (3 LM iterations each) in {el:.1f} s"}
 
 
+TRACK_M_COARSE = 1500   # maxFeatures: last-frame + last-keyframe points (reference SnakeGlobal.h:120, TrackingCoarse.cpp:94-127)
+TRACK_M_FINE = 10000    # reserved size of the fine local map (reference Map/LocalMap.h:88)
+TRACK_CAM = (458.654, 457.296, 367.215, 248.375, BF_SYNTH)
+
+
+def tracking_points(kps, desc, n, depth, rng, m_coarse, m_fine, level_scale):
+    """Synthetic local map of ONE frame built from the frame's own features (host numpy, untimed): every point is a feature
+    back-projected to its stereo depth (or a seeded depth in [2, 12] m) with 1.5 px of reprojection noise, its descriptor the
+    feature's with ~24 of 256 bits flipped.  The local map has more points than the frame has features (1 500 / 10 000 vs
+    ~1 000), so features are drawn with repetition: several points compete for one feature, as in a real local map.
+    Camera pose = identity.  Returns (snk_lm_coarse[m_coarse], snk_lm_fine[m_fine])."""
+    from snake_slam_amd.tracking import LM_COARSE_DTYPE, LM_FINE_DTYPE
+
+    fx, fy, cx, cy, _ = TRACK_CAM
+
+    def make(m, dtype):
+        out = np.zeros(m, dtype)
+        if n == 0:
+            return out, np.zeros(m, np.int64), np.zeros(m)
+        j = rng.integers(0, n, m)
+        z = np.where(depth[j] > 0, np.clip(depth[j].astype(np.float64), 0.5, 60.0), rng.uniform(2.0, 12.0, m))
+        u = kps["x"][j] + rng.normal(0, 1.5, m)
+        v = kps["y"][j] + rng.normal(0, 1.5, m)
+        pos = np.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], 1)
+        out["pos"] = pos
+        nrm = -pos / np.linalg.norm(pos, axis=1, keepdims=True)
+        out["normal"] = nrm
+        flip = rng.integers(0, 2**64, (m, 4), dtype=np.uint64) & rng.integers(0, 2**64, (m, 4), dtype=np.uint64) \
+            & rng.integers(0, 2**64, (m, 4), dtype=np.uint64) & (rng.integers(0, 2**64, (m, 4), dtype=np.uint64) | rng.integers(0, 2**64, (m, 4), dtype=np.uint64))
+        out["desc"] = desc[j] ^ flip
+        return out, j, np.linalg.norm(pos, axis=1)
+
+    if n == 0:
+        return make(m_coarse, LM_COARSE_DTYPE)[0], make(m_fine, LM_FINE_DTYPE)[0]
+    pc, j, _ = make(m_coarse, LM_COARSE_DTYPE)
+    pc["octave"] = kps["octave"][j]
+    pc["angle"] = np.mod(kps["angle"][j] + rng.normal(0, 6.0, m_coarse), 360.0).astype(np.float32)
+    pf, j, dist = make(m_fine, LM_FINE_DTYPE)
+    pf["reference_depth"] = dist.astype(np.float32)
+    pf["reference_scale_level"] = kps["octave"][j]
+    pf["valid"] = 1
+    return pc, pf
+
+
+def sequence_mode(args, rank, world, local, dev):
+    """BASELINE.json config 5 ("8 sequences one-per-GPU, RCCL/xGMI gather"): rank r tracks sequence r, one frame per step,
+    through the host (PCIe-inclusive, synchronous) entry points in the order the reference's threads call them; after the
+    timed region ONE all_gather carries every rank's padded TUM trajectory block (SURVEY.md section 8e,
+    reference Snake/System/System.cpp:552-563).  No collective on the data path."""
+    import torch
+
+    from snake_slam_amd import parallel, synth
+    from snake_slam_amd.sequence import SequenceTracker, trajectory_block, trajectory_rows
+
+    n_frames = args.warmup + args.steps
+    frames = list(synth.sequence_frames(rank, n_frames, W, H))
+    trk = SequenceTracker(TRACK_CAM, orb=ORB, device=local, width=W, height=H)
+    for t in range(args.warmup):
+        trk.process(*frames[t], float(t))
+    torch.cuda.synchronize()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(args.warmup, n_frames):
+        trk.process(*frames[t], float(t))
+    torch.cuda.synchronize()
+    parallel.barrier()
+    t1 = time.perf_counter()
+    elapsed = parallel.max_over_ranks(t1 - t0, dev)
+    block = torch.from_numpy(trajectory_block(trk.rows, n_frames)).to(dev)
+    blocks = parallel.gather_blocks(block)  # one RCCL all_gather of (1 + 8 * frames) doubles per rank
+    if rank == 0:
+        baseline_m = TRACK_CAM[4] / TRACK_CAM[0]
+        per_rank = []
+        for r, b in enumerate(blocks):
+            rows = trajectory_rows(b.cpu().numpy())
+            gt = 0.05 * baseline_m * rows[-1, 0]
+            per_rank.append({"rank": r, "frames": int(len(rows)), "final_position": [round(float(v), 5) for v in rows[-1, 1:4]],
+                             "ground_truth_x": round(float(gt), 5)})
+        st = trk.stats
+        out = {"metric": f"frames/s, sequence mode (per-frame tracking chain through the host API) @{W}x{H}",
+               "value": round(world * args.steps / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "u8", "data": f"synthetic: one seeded {W}x{H} stereo sequence per rank (rig moving 0.05 baselines per frame)",
+               "config": {"workload": f"{world} independent stereo sequences, one per GPU: Detect L+R, rectify, feature grid, StereoMatching, "
+                                      "matchKnn2 + filterMatches vs the previous frame, RefinePoseWithMatches; host API (PCIe inclusive)",
+                          "parallelism": f"{world} x one sequence per GPU, one all_gather of the TUM trajectory blocks"},
+               "keypoints_per_image": round(st["keypoints"] / max(1, 2 * st["frames"]), 1),
+               "stereo_matches_per_frame": round(st["stereo"] / max(1, st["frames"]), 1),
+               "bf_pairs_per_frame": round(st["bf_pairs"] / max(1, st["frames"] - 1), 1),
+               "pose_inliers_per_frame": round(st["inliers"] / max(1, st["frames"] - 1), 1),
+               "trajectory_block_bytes": int(block.numel() * 8), "trajectories": per_rank,
+               "roofline": None,  # a latency path (one frame at a time); the roofline object belongs to the batch mode
+               "cpu_baseline": None}
+        print(json.dumps(out), flush=True)
+    trk.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,6 +205,12 @@ def main():
                     "per-kernel timings then overlap)")
     ap.add_argument("--gba-keyframes", type=int, default=300, help="keyframes of the global-BA leg (0 = skip; single GPU only)")
     ap.add_argument("--pose-frames", type=int, default=256, help="frames per pose-refinement call (0 = skip; single GPU only)")
+    ap.add_argument("--track-frames", type=int, default=64, help="frames of the tracking-matcher leg (device-resident coarse + fine "
+                    "projection matchers on the frames the front-end left in HBM; 0 = skip)")
+    ap.add_argument("--mode", choices=["batch", "sequence"], default="batch",
+                    help="batch = the headline throughput benchmark (default); sequence = BASELINE.json config 5: every rank walks its "
+                         "own synthetic stereo sequence frame by frame through the host entry points (one step = one frame per rank) "
+                         "and the ranks' TUM trajectories are gathered with one all_gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events")
     args = ap.parse_args()
@@ -127,6 +231,12 @@ def main():
     rank, world = parallel.init_distributed(dev)  # "nccl" = RCCL over xGMI; used for barrier + result gather only
 
     from snake_slam_amd import synth
+
+    if args.mode == "sequence":
+        sequence_mode(args, rank, world, local, dev)
+        parallel.shutdown()
+        return
+
     from snake_slam_amd.matcher import BruteForceMatcher, Preprocess, Rectification
     from snake_slam_amd.orb import ORBExtractor
     from snake_slam_amd.tracking import FeatureGrid
@@ -299,6 +409,94 @@ def main():
             pose_out["cpu_baseline"] = {"value": round(done / (time.perf_counter() - tc0), 1), "unit": "frames/s", "cores": 1,
                                         "kind": "port", "sample": f"{done} refinements of the same problems"}
 
+    # ---- tracking matchers on the frames the front-end left in HBM: SearchByProjectionFrameFrame2 with
+    # M = 1500 points, `mvpMapPoints[idx] = mp` on the device, SearchByProjection2 with M = 10 000 points -- the 1-2 coarse + 1
+    # fine call the Tracking thread makes per frame (TrackingCoarse.cpp:234, TrackingFine.cpp:149), for a batch of frames, device
+    # resident (kp64_g / desc_g / cell_start / right_points are consumed where the batched front-end wrote them).
+    track_out = None
+    if world == 1 and args.track_frames > 0 and args.workload == "euroc":
+        from snake_slam_amd.tracking import KP64_DTYPE, SnakeORBMatcher, frames_dev
+
+        TB = min(args.track_frames, B)
+        h_kps = kp64_g[:TB].cpu().numpy().view(KP64_DTYPE).reshape(TB, cap)
+        h_desc = desc_g[:TB].cpu().numpy().view(np.uint64)
+        h_n = nkp[:TB].cpu().numpy()
+        h_depth = depth[:TB].cpu().numpy()
+        rng = np.random.default_rng(synth.SEED + 4711)
+        lm = [tracking_points(h_kps[b], h_desc[b], int(h_n[b]), h_depth[b], rng, TRACK_M_COARSE, TRACK_M_FINE, level_scale)
+              for b in range(TB)]
+        d_pc = torch.from_numpy(np.stack([x[0] for x in lm]).view(np.uint8).reshape(TB, TRACK_M_COARSE, 88)).to(dev)
+        pf_host = np.stack([x[1] for x in lm])
+        d_pf0 = torch.from_numpy(pf_host.view(np.uint8).reshape(TB, TRACK_M_FINE, 96)).to(dev)
+        d_pf = d_pf0.clone()
+        d_mc = torch.full((TB,), TRACK_M_COARSE, dtype=torch.int32, device=dev)
+        d_mf = torch.full((TB,), TRACK_M_FINE, dtype=torch.int32, device=dev)
+        ident = np.zeros((TB, 7))
+        ident[:, 3] = 1.0
+        d_pose = torch.from_numpy(ident).to(dev)
+        taken = torch.zeros((TB, cap), dtype=torch.uint8, device=dev)
+        mi_c = torch.zeros((TB, TRACK_M_COARSE), dtype=torch.int32, device=dev)
+        mi_f = torch.zeros((TB, TRACK_M_FINE), dtype=torch.int32, device=dev)
+        vis = torch.zeros((TB, TRACK_M_FINE), dtype=torch.uint8, device=dev)
+        n_c = torch.zeros(TB, dtype=torch.int32, device=dev)
+        n_f = torch.zeros(TB, dtype=torch.int32, device=dev)
+        trk = SnakeORBMatcher(local, sh)
+        fd = frames_dev(GRID_BOUNDS, nkp[:TB], kp64_g[:TB], desc_g[:TB], right_points[:TB], taken, cell_start[:TB])
+
+        def track_step():
+            taken.zero_()
+            d_pf.copy_(d_pf0)  # the fine matcher clears .valid in place
+            trk.coarse_batch_dev(fd, TRACK_CAM, d_pose, d_pc, d_mc, 10.0, 75, 0, level_scale, mi_c, n_c)   # th 10: stereo, Tracking.h:184
+            trk.mark_taken_batch_dev(mi_c, d_mc, taken)
+            trk.fine_batch_dev(fd, TRACK_CAM, d_pose, d_pf, d_mf, 4.0, 0.8, level_scale, mi_f, vis, n_f)    # th 4: stereo, Tracking.h:189
+
+        with torch.cuda.stream(stream):
+            for _ in range(max(1, args.warmup)):
+                track_step()
+            torch.cuda.synchronize()
+            tt0 = time.perf_counter()
+            for _ in range(args.steps):
+                track_step()
+            torch.cuda.synchronize()
+            tt1 = time.perf_counter()
+        # algorithmic bytes per frame (same accounting as the other matchers): the frame's features once
+        # (24 + 32 + 4 + 1 B each) + every local-map point once (88 / 96 B) + 4 B (+1) of result per point
+        n_feat = float(h_n.mean())
+        a_track = n_feat * 61 + TRACK_M_COARSE * (88 + 4) + n_feat * 61 + TRACK_M_FINE * (96 + 5)
+        fps = TB * args.steps / (tt1 - tt0)
+        track_out = {"metric": "frames/s of the tracking matchers (coarse M=1500 th=10 + fine M=10000 th=4), device resident",
+                     "value": round(fps, 1), "unit": "frames/s", "frames_per_step": TB, "ms_per_step": round((tt1 - tt0) / args.steps * 1e3, 4),
+                     "coarse_matches_per_frame": round(float(n_c.float().mean().item()), 1),
+                     "fine_matches_per_frame": round(float(n_f.float().mean().item()), 1), "dtype": "u8 descriptors, f64 geometry",
+                     "roofline": {"bound": "hbm", "algorithmic_bytes_per_frame": int(a_track),
+                                  "achieved": round(a_track * fps / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(a_track * fps / 1e9 / HBM_PEAK_GBS, 6)}}
+        if not args.no_cpu_baseline:
+            from oracle import oracle as orc
+
+            orc.build()
+            orc.set_match_threads(4)  # num_tracking_threads (reference Settings.h:88)
+            h_rp = right_points[:TB].cpu().numpy()
+            h_cs = cell_start[:TB].cpu().numpy()
+            gcols, grows = int(np.ceil(W / 20.0)), int(np.ceil(H / 20.0))
+            tc0, done, same = time.perf_counter(), 0, True
+            h_mi_c, h_mi_f = mi_c.cpu().numpy(), mi_f.cpu().numpy()
+            while time.perf_counter() - tc0 < 4.0 and done < TB:
+                b = done
+                nb = int(h_n[b])
+                fr = dict(kps=h_kps[b, :nb], desc=h_desc[b, :nb], right_points=h_rp[b, :nb], taken=np.zeros(nb, np.uint8),
+                          cell_start=h_cs[b], bounds=GRID_BOUNDS, cols=gcols, rows=grows)
+                _, wi = orc.match_coarse(fr, TRACK_CAM, ident[0], lm[b][0], 10.0, 75, 0, level_scale)
+                fr["taken"][wi[wi >= 0]] = 1
+                _, wf, _, _ = orc.match_fine(fr, TRACK_CAM, ident[0], lm[b][1].copy(), 4.0, 0.8, level_scale)
+                same = same and np.array_equal(wi, h_mi_c[b]) and np.array_equal(wf, h_mi_f[b])
+                done += 1
+            orc.set_match_threads(1)
+            track_out["cpu_baseline"] = {"value": round(done / (time.perf_counter() - tc0), 2), "unit": "frames/s", "cores": 4, "kind": "port",
+                                         "sample": f"{done} frames of the same inputs (coarse + fine), 4 OpenMP threads",
+                                         "identical_to_gpu": bool(same)}
+        trk.close()
+
     # ---- result gather: one fixed-size block per rank (RCCL all_gather over xGMI) ----
     block = torch.tensor([float(B * args.steps), float(nkp.sum().item()), float(n_stereo.sum().item()),
                           float(n_pairs.sum().item()), t1 - t0, 0.0, 0.0, 0.0], dtype=torch.float64, device=dev)
@@ -361,6 +559,8 @@ def main():
             out["ba"] = ba_out
         if pose_out is not None:
             out["pose_refine"] = pose_out
+        if track_out is not None:
+            out["tracking"] = track_out
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames)
             if ba_out is not None:

@@ -321,6 +321,46 @@ SNK_API int snk_match_project_fine(snk_matcher* m, const snk_frame_view* frame, 
                                    snk_lm_fine* pts, int n_pts, float th, float ratio, const float* level_scale, int n_levels,
                                    int32_t* match_idx, uint8_t* visible, int* n_matches);
 
+/* Device-resident, batched forms of the two per-frame tracking matchers: frame b of the batch is what the batched
+ * front-end leaves in HBM -- keypoints and descriptors in feature-grid order and cell_start
+ * (snk_feature_grid_batch_dev), right_points (snk_stereo_match_batch_dev) -- so the matchers consume it without a
+ * host round trip.  All per-feature arrays are [batch][cap]; cell_start is [batch][cols * rows + 1] for the 20-px grid
+ * of `bounds`; taken[b][i] != 0 <=> mvpMapPoints[i] != nullptr (all zero for a fresh frame; snk_match_mark_taken_batch_dev
+ * applies the adaptor's `mvpMapPoints[idx] = mp` between the coarse and the fine call). */
+typedef struct snk_frames_dev
+{
+    int32_t batch, cap;
+    const int32_t* n;           /* [batch] features per frame */
+    const snk_kp64* kps;        /* [batch][cap] undistorted keypoints, grid order */
+    const uint64_t* desc;       /* [batch][cap][4] */
+    const float* right_points;  /* [batch][cap] */
+    const uint8_t* taken;       /* [batch][cap] */
+    const int32_t* cell_start;  /* [batch][cols * rows + 1] */
+    snk_grid_bounds bounds;
+} snk_frames_dev;
+
+/* SearchByProjectionFrameFrame2 for every frame of the batch (same rules and results as snk_match_project_coarse).
+ * poses_dev: [batch][7] doubles ON THE DEVICE (qx qy qz qw tx ty tz; e.g. left there by the previous frame's pose
+ * refinement); pts_dev [batch][pts_cap], n_pts_dev [batch]; outputs match_idx_dev [batch][pts_cap] (-1 = none, also for
+ * entries past n_pts) and n_matches_dev [batch].  Asynchronous on the handle's stream. */
+SNK_API int snk_match_project_coarse_batch_dev(snk_matcher* m, const snk_frames_dev* frames, const snk_camera* cam,
+                                               const double* poses_dev, const snk_lm_coarse* pts_dev,
+                                               const int32_t* n_pts_dev, int pts_cap, float th, int feature_error,
+                                               int direction, const float* level_scale, int n_levels,
+                                               int32_t* match_idx_dev, int32_t* n_matches_dev);
+
+/* SearchByProjection2 for every frame of the batch (same rules and results as snk_match_project_fine; pts_dev[..].valid is
+ * updated in place, visible_dev [batch][pts_cap]). */
+SNK_API int snk_match_project_fine_batch_dev(snk_matcher* m, const snk_frames_dev* frames, const snk_camera* cam,
+                                             const double* poses_dev, snk_lm_fine* pts_dev, const int32_t* n_pts_dev,
+                                             int pts_cap, float th, float ratio, const float* level_scale, int n_levels,
+                                             int32_t* match_idx_dev, uint8_t* visible_dev, int32_t* n_matches_dev);
+
+/* taken_dev[b][match_idx_dev[b][i]] = 1 for every matched point: `CurrentFrame.mvpMapPoints[idx] = mp`
+ * (SnakeORBMatcher.cpp:330, :522) applied on the device between two matcher calls on the same frames. */
+SNK_API int snk_match_mark_taken_batch_dev(snk_matcher* m, const int32_t* match_idx_dev, const int32_t* n_pts_dev, int pts_cap,
+                                           int batch, uint8_t* taken_dev, int cap);
+
 /* Replaces SnakeORBMatcher::SearchByProjectionFrameToKeyframe — Snake/Tracking/SnakeORBMatcher.cpp:71-188.
  * positions / descriptors: mp->getPosition() / mp->GetDescriptor() of kf.GetMapPointMatches();
  * skip[i] != 0 where the keyframe has no point or the frame already holds it (:102-103).

@@ -364,6 +364,11 @@ def make_frame_view(frame):
     return v, a
 
 
+def set_match_threads(n: int) -> None:
+    """Threads of the per-point phase of match_coarse / match_fine (the reference: num_tracking_threads = 4)."""
+    lib().orc_set_match_threads(C.c_int(int(n)))
+
+
 def match_coarse(frame, cam, pose, pts, th, feature_error, direction, level_scale):
     v, keep = make_frame_view(frame)
     pts = np.ascontiguousarray(pts, LM_COARSE)

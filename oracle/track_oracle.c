@@ -212,6 +212,12 @@ static int coarse_cand(void* p, int i2)
     return 0;
 }
 
+/* The reference runs the per-point phase of both tracking matchers under `#pragma omp parallel for num_threads(threads)`
+ * (SnakeORBMatcher.cpp:219, :379; threads = num_tracking_threads = 4, Settings.h:88).  Every iteration writes only its own
+ * best[i] / bins[i] / visible[i] / valid, so the result does not depend on the thread count; bench.py's cpu_baseline sets 4. */
+static int g_match_threads = 1;
+void orc_set_match_threads(int n) { g_match_threads = n < 1 ? 1 : n; }
+
 int orc_match_coarse(const orc_frame_view* f, const orc_camera* cam, const double* pose, const orc_lm_coarse* pts, int m,
                      float th, int feature_error, int direction, const float* level_scale, int n_levels, int32_t* match_idx)
 {
@@ -221,6 +227,7 @@ int orc_match_coarse(const orc_frame_view* f, const orc_camera* cam, const doubl
     int* best         = (int*)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
     const float factor = 1.0f / 30; /* :203 */
     (void)n_levels;
+#pragma omp parallel for num_threads(g_match_threads) schedule(static)
     for (int i = 0; i < m; ++i) /* :221 */
     {
         best[i] = -1; /* :223 */
@@ -336,6 +343,7 @@ int orc_match_fine(const orc_frame_view* f, const orc_camera* cam, const double*
     const double log_f     = orc_det_log(n_levels > 1 ? (double)level_scale[1] / (double)level_scale[0] : 1.2);
     const double s_last    = (double)level_scale[n_levels - 1];
     int* best              = (int*)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
+#pragma omp parallel for num_threads(g_match_threads) schedule(static)
     for (int i = 0; i < m; ++i) /* :381 */
     {
         best[i]    = -1;

@@ -151,16 +151,41 @@ __device__ __forceinline__ void scan_window(const FrameDev& F, const u8* taken, 
     }
 }
 
-// coarse: best[i] = feature index or -1, bins[i] = rotation bin
-__global__ __launch_bounds__(256) void coarse_kernel(FrameDev F, CamDev C, ScalesDev S, const snk_lm_coarse* __restrict__ pts,
-                                                     int m, float th, int feature_error, int direction,
-                                                     int* __restrict__ best, int* __restrict__ bins)
+// Batch of grid-ordered frames resident on the device (the arrays snk_feature_grid_batch_dev / snk_stereo_match_batch_dev
+// leave behind): per-feature arrays are [batch][cap], cell_start is [batch][cols * rows + 1].
+struct FramesDev
 {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + wave;
-    if (i >= m) return;
-    const snk_lm_coarse lmp = pts[i];
-    int result = -1, bin = 0;
+    int cap, cols, rows;
+    const int* n;
+    const snk_kp64* kps;
+    const uint4* desc;
+    const float* right_points;
+    const u8* taken;
+    const int* cell_start;
+    double min_x, min_y, max_x, max_y;
+};
+
+__device__ __forceinline__ FrameDev frame_of(const FramesDev& B, int b)
+{
+    FrameDev F;
+    F.n            = B.n[b];
+    F.cols         = B.cols;
+    F.rows         = B.rows;
+    F.kps          = B.kps + (size_t)b * B.cap;
+    F.desc         = B.desc + (size_t)b * B.cap * 2;
+    F.right_points = B.right_points + (size_t)b * B.cap;
+    F.taken        = B.taken + (size_t)b * B.cap;
+    F.cell_start   = B.cell_start + (size_t)b * (B.cols * B.rows + 1);
+    F.min_x = B.min_x; F.min_y = B.min_y; F.max_x = B.max_x; F.max_y = B.max_y;
+    return F;
+}
+
+// one local-map point of the coarse matcher (SnakeORBMatcher.cpp:221-318), evaluated by one wavefront
+__device__ __forceinline__ void coarse_point(const FrameDev& F, const CamDev& C, const ScalesDev& S, const snk_lm_coarse& lmp, float th,
+                                             int feature_error, int direction, int lane, int& result, int& bin)
+{
+    result = -1;
+    bin    = 0;
     const double pcx = C.R[0] * lmp.pos[0] + C.R[1] * lmp.pos[1] + C.R[2] * lmp.pos[2] + C.t[0];
     const double pcy = C.R[3] * lmp.pos[0] + C.R[4] * lmp.pos[1] + C.R[5] * lmp.pos[2] + C.t[1];
     const double z   = C.R[6] * lmp.pos[0] + C.R[7] * lmp.pos[1] + C.R[8] * lmp.pos[2] + C.t[2];
@@ -200,6 +225,19 @@ __global__ __launch_bounds__(256) void coarse_kernel(FrameDev F, CamDev C, Scale
             if (!(bin >= 0 && bin < 30)) { result = -1; bin = 0; }
         }
     }
+}
+
+// coarse: best[i] = feature index or -1, bins[i] = rotation bin
+__global__ __launch_bounds__(256) void coarse_kernel(FrameDev F, CamDev C, ScalesDev S, const snk_lm_coarse* __restrict__ pts,
+                                                     int m, float th, int feature_error, int direction,
+                                                     int* __restrict__ best, int* __restrict__ bins)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= m) return;
+    const snk_lm_coarse lmp = pts[i];
+    int result, bin;
+    coarse_point(F, C, S, lmp, th, feature_error, direction, lane, result, bin);
     if (lane == 0)
     {
         best[i] = result;
@@ -207,13 +245,32 @@ __global__ __launch_bounds__(256) void coarse_kernel(FrameDev F, CamDev C, Scale
     }
 }
 
-__global__ __launch_bounds__(256) void fine_kernel(FrameDev F, CamDev C, ScalesDev S, snk_lm_fine* __restrict__ pts, int m,
-                                                   float th, float ratio, int* __restrict__ best, u8* __restrict__ visible)
+// batched form: blockIdx.y = frame; points [batch][m_cap], counts m_dev[batch]
+__global__ __launch_bounds__(256) void coarse_batch_kernel(FramesDev Fb, const CamDev* __restrict__ cams, ScalesDev S,
+                                                           const snk_lm_coarse* __restrict__ pts, const int* __restrict__ m_dev,
+                                                           int m_cap, float th, int feature_error, int direction,
+                                                           int* __restrict__ best, int* __restrict__ bins)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + wave;
+    const int b = blockIdx.y, i = blockIdx.x * 4 + wave;
+    const int m = min(m_dev[b], m_cap);
     if (i >= m) return;
-    const snk_lm_fine lmp = pts[i];
+    const FrameDev F = frame_of(Fb, b);
+    const CamDev C   = cams[b];
+    const snk_lm_coarse lmp = pts[(size_t)b * m_cap + i];
+    int result, bin;
+    coarse_point(F, C, S, lmp, th, feature_error, direction, lane, result, bin);
+    if (lane == 0)
+    {
+        best[(size_t)b * m_cap + i] = result;
+        bins[(size_t)b * m_cap + i] = bin;
+    }
+}
+
+// one local-map point of the fine matcher (SnakeORBMatcher.cpp:388-512), evaluated by one wavefront
+__device__ __forceinline__ void fine_point(const FrameDev& F, const CamDev& C, const ScalesDev& S, const snk_lm_fine& lmp, float th,
+                                           float ratio, int lane, int& result_out, u8& vis_out, u8& valid_out)
+{
     int result = -1;
     u8 vis = 0, valid = lmp.valid;
     if (valid)
@@ -263,6 +320,21 @@ __global__ __launch_bounds__(256) void fine_kernel(FrameDev F, CamDev C, ScalesD
             }
         }
     }
+    result_out = result;
+    vis_out    = vis;
+    valid_out  = valid;
+}
+
+__global__ __launch_bounds__(256) void fine_kernel(FrameDev F, CamDev C, ScalesDev S, snk_lm_fine* __restrict__ pts, int m,
+                                                   float th, float ratio, int* __restrict__ best, u8* __restrict__ visible)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= m) return;
+    const snk_lm_fine lmp = pts[i];
+    int result;
+    u8 vis, valid;
+    fine_point(F, C, S, lmp, th, ratio, lane, result, vis, valid);
     if (lane == 0)
     {
         best[i]      = result;
@@ -271,11 +343,34 @@ __global__ __launch_bounds__(256) void fine_kernel(FrameDev F, CamDev C, ScalesD
     }
 }
 
+__global__ __launch_bounds__(256) void fine_batch_kernel(FramesDev Fb, const CamDev* __restrict__ cams, ScalesDev S,
+                                                         snk_lm_fine* __restrict__ pts, const int* __restrict__ m_dev, int m_cap,
+                                                         float th, float ratio, int* __restrict__ best, u8* __restrict__ visible)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int b = blockIdx.y, i = blockIdx.x * 4 + wave;
+    const int m = min(m_dev[b], m_cap);
+    if (i >= m) return;
+    const FrameDev F = frame_of(Fb, b);
+    const CamDev C   = cams[b];
+    const size_t at  = (size_t)b * m_cap + i;
+    const snk_lm_fine lmp = pts[at];
+    int result;
+    u8 vis, valid;
+    fine_point(F, C, S, lmp, th, ratio, lane, result, vis, valid);
+    if (lane == 0)
+    {
+        best[at]      = result;
+        visible[at]   = vis;
+        pts[at].valid = valid;
+    }
+}
+
 // first claimant (lowest local-map index) of every feature wins; coarse additionally applies the
-// rotation-histogram filter.  One workgroup.
-__global__ __launch_bounds__(256) void resolve_kernel(const int* __restrict__ best, const int* __restrict__ bins, int m,
-                                                      const u8* __restrict__ taken, int* __restrict__ claim, int n_feat,
-                                                      int with_rotation, int* __restrict__ match_idx, int* __restrict__ n_out)
+// rotation-histogram filter.  One workgroup per frame.
+__device__ __forceinline__ void resolve_body(const int* __restrict__ best, const int* __restrict__ bins, int m,
+                                             const u8* __restrict__ taken, int* __restrict__ claim, int n_feat,
+                                             int with_rotation, int* __restrict__ match_idx, int* __restrict__ n_out)
 {
     __shared__ int hist[30];
     __shared__ int keep[3];
@@ -338,6 +433,56 @@ __global__ __launch_bounds__(256) void resolve_kernel(const int* __restrict__ be
     atomicAdd(&count, local);
     __syncthreads();
     if (tid == 0) *n_out = count;
+}
+
+__global__ __launch_bounds__(256) void resolve_kernel(const int* __restrict__ best, const int* __restrict__ bins, int m,
+                                                      const u8* __restrict__ taken, int* __restrict__ claim, int n_feat,
+                                                      int with_rotation, int* __restrict__ match_idx, int* __restrict__ n_out)
+{
+    resolve_body(best, bins, m, taken, claim, n_feat, with_rotation, match_idx, n_out);
+}
+
+__global__ __launch_bounds__(256) void resolve_batch_kernel(const int* __restrict__ best, const int* __restrict__ bins,
+                                                            const int* __restrict__ m_dev, int m_cap, FramesDev Fb,
+                                                            int* __restrict__ claim, int with_rotation,
+                                                            int* __restrict__ match_idx, int* __restrict__ n_out)
+{
+    const int b = blockIdx.x;
+    const int m = min(m_dev[b], m_cap);
+    resolve_body(best + (size_t)b * m_cap, bins ? bins + (size_t)b * m_cap : nullptr, m, Fb.taken + (size_t)b * Fb.cap,
+                 claim + (size_t)b * Fb.cap, min(Fb.n[b], Fb.cap), with_rotation, match_idx + (size_t)b * m_cap, n_out + b);
+    // entries past the frame's point count read as "no match"
+    for (int i = m + threadIdx.x; i < m_cap; i += 256) match_idx[(size_t)b * m_cap + i] = -1;
+}
+
+// CamDev of every frame of a batch from its pose (same operations, in the same order, as make_cam on the host)
+__global__ void cam_batch_kernel(snk_camera cam, const double* __restrict__ poses, int batch, CamDev* __restrict__ out)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const double* pose = poses + (size_t)b * 7;
+    CamDev c;
+    c.fx = cam.fx; c.fy = cam.fy; c.cx = cam.cx; c.cy = cam.cy; c.bf = cam.bf;
+    const double x = pose[0], y = pose[1], z = pose[2], w = pose[3];
+    double* R = c.R;
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
+    R[3] = 2 * (x * y + z * w);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+    R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
+    c.t[0] = pose[4]; c.t[1] = pose[5]; c.t[2] = pose[6];
+    c.campos[0] = -(R[0] * c.t[0] + R[3] * c.t[1] + R[6] * c.t[2]);
+    c.campos[1] = -(R[1] * c.t[0] + R[4] * c.t[1] + R[7] * c.t[2]);
+    c.campos[2] = -(R[2] * c.t[0] + R[5] * c.t[1] + R[8] * c.t[2]);
+    out[b] = c;
+}
+
+// taken[b][match_idx[b][i]] = 1: the adaptor's mvpMapPoints[idx] = mp after a matcher call, kept on the device
+__global__ void mark_taken_kernel(const int* __restrict__ match_idx, const int* __restrict__ m_dev, int m_cap, u8* __restrict__ taken,
+                                  int cap)
+{
+    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= min(m_dev[b], m_cap)) return;
+    const int f = match_idx[(size_t)b * m_cap + i];
+    if (f >= 0 && f < cap) taken[(size_t)b * cap + f] = 1;
 }
 
 // greedy sequential keyframe matcher: one wavefront, taken mask in LDS
@@ -1010,6 +1155,112 @@ int snk_match_project_fine(snk_matcher* m, const snk_frame_view* frame, const sn
     SNK_HIP_CHECK(hipMemcpyAsync(pts, m->q.p, np * sizeof(snk_lm_fine), hipMemcpyDeviceToHost, m->stream));
     SNK_HIP_CHECK(hipMemcpyAsync(n_matches, m->cnt.p, 4, hipMemcpyDeviceToHost, m->stream));
     SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return SNK_OK;
+}
+
+namespace
+{
+int make_frames(const snk_frames_dev* f, FramesDev* F)
+{
+    SNK_REQUIRE(f != nullptr, "frames is NULL");
+    SNK_REQUIRE(f->batch >= 0 && f->cap >= 1 && f->cap < (int)PJ_IDX_MASK, "bad batch / cap");
+    SNK_REQUIRE(f->n && f->kps && f->desc && f->right_points && f->taken && f->cell_start, "NULL device array in frames");
+    grid_dims(&f->bounds, &F->cols, &F->rows);
+    SNK_REQUIRE((long long)F->cols * F->rows < 65535, "grid too large");
+    F->cap          = f->cap;
+    F->n            = f->n;
+    F->kps          = f->kps;
+    F->desc         = reinterpret_cast<const uint4*>(f->desc);
+    F->right_points = f->right_points;
+    F->taken        = f->taken;
+    F->cell_start   = f->cell_start;
+    F->min_x = f->bounds.min_x; F->min_y = f->bounds.min_y; F->max_x = f->bounds.max_x; F->max_y = f->bounds.max_y;
+    return SNK_OK;
+}
+
+// scratch of the batched matchers: aux = CamDev[batch], out = best | bins ([batch][m_cap] each), t = claim [batch][cap]
+int batch_scratch(snk_matcher* m, int batch, int m_cap, int cap, const snk_camera* cam, const double* poses_dev, CamDev** cams,
+                  int** best, int** bins, int** claim)
+{
+    int rc;
+    if ((rc = m->aux.reserve((size_t)batch * sizeof(CamDev))) != SNK_OK) return rc;
+    if ((rc = m->out.reserve((size_t)batch * m_cap * 8)) != SNK_OK) return rc;
+    if ((rc = m->t.reserve((size_t)batch * cap * 4)) != SNK_OK) return rc;
+    *cams  = m->aux.as<CamDev>();
+    *best  = m->out.as<int>();
+    *bins  = *best + (size_t)batch * m_cap;
+    *claim = m->t.as<int>();
+    hipLaunchKernelGGL(cam_batch_kernel, dim3(ceil_div(batch, 64)), dim3(64), 0, m->stream, *cam, poses_dev, batch, *cams);
+    return SNK_OK;
+}
+}  // namespace
+
+int snk_match_project_coarse_batch_dev(snk_matcher* m, const snk_frames_dev* frames, const snk_camera* cam,
+                                       const double* poses_dev, const snk_lm_coarse* pts_dev, const int32_t* n_pts_dev,
+                                       int pts_cap, float th, int feature_error, int direction, const float* level_scale,
+                                       int n_levels, int32_t* match_idx_dev, int32_t* n_matches_dev)
+{
+    SNK_REQUIRE(m != nullptr && cam != nullptr, "NULL argument");
+    SNK_REQUIRE(poses_dev && pts_dev && n_pts_dev && match_idx_dev && n_matches_dev, "NULL device buffer");
+    SNK_REQUIRE(pts_cap >= 1, "pts_cap must be >= 1");
+    SNK_REQUIRE(direction >= 0 && direction <= 2, "direction must be 0 (none), 1 (forward) or 2 (backward)");
+    FramesDev F;
+    ScalesDev S;
+    int rc;
+    if ((rc = make_frames(frames, &F)) != SNK_OK) return rc;
+    if ((rc = make_scales(level_scale, n_levels, &S)) != SNK_OK) return rc;
+    const int batch = frames->batch;
+    if (batch == 0) return SNK_OK;
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    CamDev* cams;
+    int *best, *bins, *claim;
+    if ((rc = batch_scratch(m, batch, pts_cap, F.cap, cam, poses_dev, &cams, &best, &bins, &claim)) != SNK_OK) return rc;
+    hipLaunchKernelGGL(coarse_batch_kernel, dim3(ceil_div(pts_cap, 4), batch), dim3(256), 0, m->stream, F, (const CamDev*)cams, S,
+                       pts_dev, n_pts_dev, pts_cap, th, feature_error, direction, best, bins);
+    hipLaunchKernelGGL(resolve_batch_kernel, dim3(batch), dim3(256), 0, m->stream, (const int*)best, (const int*)bins, n_pts_dev,
+                       pts_cap, F, claim, 1, match_idx_dev, n_matches_dev);
+    SNK_LAUNCH_CHECK();
+    return SNK_OK;
+}
+
+int snk_match_project_fine_batch_dev(snk_matcher* m, const snk_frames_dev* frames, const snk_camera* cam, const double* poses_dev,
+                                     snk_lm_fine* pts_dev, const int32_t* n_pts_dev, int pts_cap, float th, float ratio,
+                                     const float* level_scale, int n_levels, int32_t* match_idx_dev, uint8_t* visible_dev,
+                                     int32_t* n_matches_dev)
+{
+    SNK_REQUIRE(m != nullptr && cam != nullptr, "NULL argument");
+    SNK_REQUIRE(poses_dev && pts_dev && n_pts_dev && match_idx_dev && visible_dev && n_matches_dev, "NULL device buffer");
+    SNK_REQUIRE(pts_cap >= 1, "pts_cap must be >= 1");
+    FramesDev F;
+    ScalesDev S;
+    int rc;
+    if ((rc = make_frames(frames, &F)) != SNK_OK) return rc;
+    if ((rc = make_scales(level_scale, n_levels, &S)) != SNK_OK) return rc;
+    const int batch = frames->batch;
+    if (batch == 0) return SNK_OK;
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    CamDev* cams;
+    int *best, *bins, *claim;
+    if ((rc = batch_scratch(m, batch, pts_cap, F.cap, cam, poses_dev, &cams, &best, &bins, &claim)) != SNK_OK) return rc;
+    SNK_HIP_CHECK(hipMemsetAsync(visible_dev, 0, (size_t)batch * pts_cap, m->stream));
+    hipLaunchKernelGGL(fine_batch_kernel, dim3(ceil_div(pts_cap, 4), batch), dim3(256), 0, m->stream, F, (const CamDev*)cams, S,
+                       pts_dev, n_pts_dev, pts_cap, th, ratio, best, visible_dev);
+    hipLaunchKernelGGL(resolve_batch_kernel, dim3(batch), dim3(256), 0, m->stream, (const int*)best, (const int*)nullptr, n_pts_dev,
+                       pts_cap, F, claim, 0, match_idx_dev, n_matches_dev);
+    SNK_LAUNCH_CHECK();
+    return SNK_OK;
+}
+
+int snk_match_mark_taken_batch_dev(snk_matcher* m, const int32_t* match_idx_dev, const int32_t* n_pts_dev, int pts_cap, int batch,
+                                   uint8_t* taken_dev, int cap)
+{
+    SNK_REQUIRE(m != nullptr && match_idx_dev && n_pts_dev && taken_dev, "NULL argument");
+    SNK_REQUIRE(batch >= 0 && pts_cap >= 1 && cap >= 1, "bad sizes");
+    if (batch == 0) return SNK_OK;
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    hipLaunchKernelGGL(mark_taken_kernel, dim3(ceil_div(pts_cap, 256), batch), dim3(256), 0, m->stream, match_idx_dev, n_pts_dev,
+                       pts_cap, taken_dev, cap);
+    SNK_LAUNCH_CHECK();
     return SNK_OK;
 }
 

@@ -67,6 +67,18 @@ def gather_result_blocks(block: torch.Tensor) -> list[torch.Tensor]:
     return out
 
 
+def gather_blocks(block: torch.Tensor) -> list[torch.Tensor]:
+    """all_gather of one equally sized 1-D block per rank -- the per-rank trajectory block of the sequence mode
+    (`{n, [t, tx, ty, tz, qx, qy, qz, qw] x frames}`; reference Snake/System/System.cpp:552-563).
+    Every rank must pass the same number of elements (blocks are padded to the longest sequence)."""
+    assert block.dim() == 1
+    if not is_distributed():
+        return [block]
+    out = [torch.zeros_like(block) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, block)
+    return out
+
+
 def shutdown() -> None:
     if dist.is_available() and dist.is_initialized():
         dist.barrier()

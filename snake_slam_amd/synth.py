@@ -49,6 +49,38 @@ def stereo_frame(index: int = 0, width: int = 752, height: int = 480, n_rects: i
     return (np.clip(np.rint(left), 0, 255).astype(np.uint8), np.clip(np.rint(right), 0, 255).astype(np.uint8))
 
 
+def sequence_frames(sequence: int, n_frames: int, width: int = 752, height: int = 480, n_rects: int = 400, step: float = 0.05,
+                    seed: int = SEED):
+    """A synthetic stereo SEQUENCE (BASELINE.json config 5): the scene of `stereo_frame` seen by a rig that moves `step`
+    baselines to the right per frame.  A rectangle of disparity d (depth bf / d) therefore moves d * step pixels to the
+    left per frame in both images -- physically consistent with a pure x-translation, so a tracker that back-projects with
+    the same bf recovers it: ground-truth camera position of frame t = (t * step * baseline, 0, 0).
+    Yields (left, right) uint8 images."""
+    rng = np.random.default_rng(seed + 7919 * (sequence + 1))
+    yy, xx = np.mgrid[0:height, 0:width]
+    base = 96.0 + 40.0 * np.sin(xx / width * 2.1 + 0.3) + 30.0 * np.cos(yy / height * 1.7)
+    rects = []
+    for _ in range(n_rects):
+        # a little wider than the image so that content enters as the rig moves
+        cx, cy = rng.uniform(0, width * 1.15), rng.uniform(0, height)
+        hw, hh = rng.uniform(4, 40), rng.uniform(4, 40)
+        ang = rng.uniform(0, np.pi) if rng.random() < 0.5 else 0.0
+        g = rng.uniform(10, 245)
+        rects.append((cx, cy, hw, hh, ang, g))
+    disp = rng.uniform(2, 60, n_rects)
+    order = np.argsort(disp)  # far rectangles first, near ones painted over them (consistent occlusion)
+    rects = [rects[i] for i in order]
+    disp = disp[order]
+    for t in range(n_frames):
+        nrng = np.random.default_rng([seed, sequence, t])
+        left, right = base.copy(), base.copy()
+        _draw_rects(left, rects, disp * (step * t))
+        _draw_rects(right, rects, disp * (step * t + 1.0))
+        left += nrng.normal(0, 2.0, left.shape)
+        right += nrng.normal(0, 2.0, right.shape)
+        yield (np.clip(np.rint(left), 0, 255).astype(np.uint8), np.clip(np.rint(right), 0, 255).astype(np.uint8))
+
+
 def random_descriptors(n: int, seed: int = SEED):
     rng = np.random.default_rng(seed)
     return rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)

@@ -44,6 +44,24 @@ def _view(frame):
     return v, a
 
 
+class FramesDev(C.Structure):
+    """snk_frames_dev: a batch of grid-ordered frames resident on the device."""
+    _fields_ = [("batch", C.c_int32), ("cap", C.c_int32), ("n", C.c_void_p), ("kps", C.c_void_p), ("desc", C.c_void_p),
+                ("right_points", C.c_void_p), ("taken", C.c_void_p), ("cell_start", C.c_void_p), ("bounds", GridBounds)]
+
+
+def frames_dev(bounds, n, kps, desc, right_points, taken, cell_start) -> FramesDev:
+    """Device tensors: n [B] int32, kps [B, cap, 24] uint8 (snk_kp64), desc [B, cap, 4] int64, right_points [B, cap] float32,
+    taken [B, cap] uint8, cell_start [B, cols*rows+1] int32 -- the outputs of FeatureGrid.create_batch_dev /
+    Preprocess.match_batch_dev.  The tensors must outlive the calls that use the view."""
+    f = FramesDev()
+    f.batch, f.cap = int(desc.shape[0]), int(desc.shape[1])
+    f.n, f.kps, f.desc = n.data_ptr(), kps.data_ptr(), desc.data_ptr()
+    f.right_points, f.taken, f.cell_start = right_points.data_ptr(), taken.data_ptr(), cell_start.data_ptr()
+    f.bounds = GridBounds(*bounds)
+    return f
+
+
 class FeatureGrid(_Handle):
     def create(self, bounds, undistorted_keypoints):
         """Returns (perm, cell_start, cols, rows); perm[i] = new index of feature i."""
@@ -96,6 +114,33 @@ class SnakeORBMatcher(_Handle):
                                                     float(ratio), _ptr(ls), len(ls), _ptr(out), _ptr(vis), C.byref(n)),
                    "snk_match_project_fine")
         return n.value, out[: len(pts)], vis[: len(pts)], pts["valid"].copy()
+
+    # ---- device-resident, batched forms (frames = frames_dev(...); every other argument a device tensor) ----
+    def coarse_batch_dev(self, frames: FramesDev, cam, poses, pts, n_pts, th, feature_error, direction, level_scale, match_idx,
+                         n_matches):
+        """poses [B, 7] float64; pts [B, m_cap, 88] uint8 (snk_lm_coarse); n_pts [B] int32; outputs match_idx [B, m_cap] int32,
+        n_matches [B] int32.  Asynchronous on the handle's stream."""
+        ls = np.ascontiguousarray(level_scale, np.float32)
+        c = Camera(*cam)
+        _lib.check(self._lib.snk_match_project_coarse_batch_dev(self._h, C.byref(frames), C.byref(c), poses.data_ptr(), pts.data_ptr(),
+                                                                n_pts.data_ptr(), int(pts.shape[1]), float(th), int(feature_error),
+                                                                int(direction), _ptr(ls), len(ls), match_idx.data_ptr(),
+                                                                n_matches.data_ptr()), "snk_match_project_coarse_batch_dev")
+
+    def fine_batch_dev(self, frames: FramesDev, cam, poses, pts, n_pts, th, ratio, level_scale, match_idx, visible, n_matches):
+        """pts [B, m_cap, 96] uint8 (snk_lm_fine, .valid updated in place); visible [B, m_cap] uint8."""
+        ls = np.ascontiguousarray(level_scale, np.float32)
+        c = Camera(*cam)
+        _lib.check(self._lib.snk_match_project_fine_batch_dev(self._h, C.byref(frames), C.byref(c), poses.data_ptr(), pts.data_ptr(),
+                                                              n_pts.data_ptr(), int(pts.shape[1]), float(th), float(ratio), _ptr(ls),
+                                                              len(ls), match_idx.data_ptr(), visible.data_ptr(), n_matches.data_ptr()),
+                   "snk_match_project_fine_batch_dev")
+
+    def mark_taken_batch_dev(self, match_idx, n_pts, taken):
+        """taken[b, match_idx[b, i]] = 1 for every matched point (the adaptor's mvpMapPoints[idx] = mp, on the device)."""
+        _lib.check(self._lib.snk_match_mark_taken_batch_dev(self._h, match_idx.data_ptr(), n_pts.data_ptr(), int(match_idx.shape[1]),
+                                                            int(match_idx.shape[0]), taken.data_ptr(), int(taken.shape[1])),
+                   "snk_match_mark_taken_batch_dev")
 
     def SearchByProjectionFrameToKeyframe(self, frame, cam, pose, positions, descriptors, skip, th, feature_error):
         v, keep = _view(frame)

@@ -207,3 +207,21 @@ def test_relink_matches_brute_force(orc):
     assert ((a1 == 2) <= (a25 == 2)).all()
     for k in np.nonzero(a1 == 2)[0]:
         assert T._ham(qs["desc"][k], frame["desc"][b1[k]]) == 0
+
+
+def test_matchers_do_not_depend_on_the_thread_count(orc):
+    """The reference runs the per-point phase with 4 OpenMP threads (SnakeORBMatcher.cpp:219, :379); bench.py's CPU baseline
+    does the same with the oracle.  The result must be the single-threaded one."""
+    rng = np.random.default_rng(SEED + 321)
+    frame, cam, pose, ls, world, _ = T.make_tracking_case(orc, rng, n_clutter=500, m_pts=900)
+    pc, pf = T.lm_coarse(orc, world), T.lm_fine(orc, rng, world, pose, ls)
+    a = orc.match_coarse(frame, cam, pose, pc, 15.0, 75, 0, ls)
+    b = orc.match_fine(frame, cam, pose, pf, 5.0, 0.8, ls)
+    orc.set_match_threads(4)
+    try:
+        a4 = orc.match_coarse(frame, cam, pose, pc, 15.0, 75, 0, ls)
+        b4 = orc.match_fine(frame, cam, pose, pf, 5.0, 0.8, ls)
+    finally:
+        orc.set_match_threads(1)
+    assert a[0] == a4[0] and np.array_equal(a[1], a4[1])
+    assert b[0] == b4[0] and all(np.array_equal(x, y) for x, y in zip(b[1:], b4[1:]))

@@ -302,3 +302,30 @@ def test_unaligned_device_images_take_the_byte_path(orc):
         assert n[i] == len(wk) and len(wk) > 100
         assert np.array_equal(kps[i, : n[i]], wk.astype(KEYPOINT_DTYPE)) and np.array_equal(desc[i, : n[i]], wd)
     ext.close()
+
+
+@pytest.mark.parametrize("workload", ["euroc", "kitti"])
+def test_candidate_budget_is_inactive_on_every_bench_frame(workload):
+    """the per-cell top-64 / level_cap (8192) candidate budget is this repository's definition, not
+    ORB-SLAM2's; the claim that it has no effect on ordinary images is checked here on every synthetic frame bench.py
+    uses (8 distinct stereo pairs per workload): no FAST cell holds more than 64 candidates and no level more than 8192,
+    so the budget never truncates and the result is the un-budgeted algorithm's."""
+    from snake_slam_amd import orb as O
+    from snake_slam_amd import synth
+
+    if workload == "euroc":
+        w, h, prm = 752, 480, (1000, 1.2, 4, 20, 7)
+    else:
+        w, h, prm = 1241, 376, (2000, 1.2, 7, 20, 7)
+    ext = O.ORBExtractor(*prm)
+    worst_cell, worst_level = 0, 0
+    for i in range(8):
+        for img in synth.stereo_frame(i, w, h):
+            ext.Detect(img)
+            for l in range(prm[2]):
+                cnt = ext.debug_fetch(O.DEBUG_CELL_COUNTS, 0, l, np.uint16)
+                worst_cell = max(worst_cell, int(cnt.max()))
+                worst_level = max(worst_level, int(cnt.astype(np.int64).sum()))
+    ext.close()
+    assert 0 < worst_cell <= 64, worst_cell
+    assert worst_level <= 8192, worst_level

@@ -30,6 +30,21 @@ blocks = P.gather_result_blocks(blk)
 assert len(blocks) == 2 and [float(b[0]) for b in blocks] == [6.0, 5.0] and float(blocks[1][1]) == 200.0
 total_units = sum(float(b[0]) for b in blocks)
 assert total_units / t == 5.5
+# sequence mode: every rank contributes its padded TUM trajectory block {n, [t tx ty tz qx qy qz qw] x frames}
+import numpy as np
+from snake_slam_amd.sequence import trajectory_block, trajectory_rows, inverse_pose_tum
+n_mine = 5 + 2 * rank  # sequences of different lengths, blocks padded to the longest (9)
+rows = np.array([np.concatenate([[float(t)], inverse_pose_tum([0, 0, 0, 1.0, -0.01 * t * (rank + 1), 0, 0])]) for t in range(n_mine)])
+blk = torch.from_numpy(trajectory_block(rows, 9))
+assert blk.numel() == 1 + 8 * 9
+got = P.gather_blocks(blk)
+assert len(got) == 2
+for r in range(2):
+    tr = trajectory_rows(got[r].numpy())
+    assert len(tr) == 5 + 2 * r
+    assert np.allclose(tr[:, 0], np.arange(5 + 2 * r))
+    assert np.allclose(tr[:, 1], 0.01 * np.arange(5 + 2 * r) * (r + 1))   # camera position = inverse of the pose translation
+    assert np.allclose(tr[:, 4:], [0, 0, 0, 1])
 P.barrier()
 P.shutdown()
 print("rank", rank, "ok")
@@ -70,3 +85,29 @@ def test_shard_range_properties():
             flat = [i for p in parts for i in p]
             assert flat == list(range(n))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_trajectory_block_roundtrip_and_tum_layout(tmp_path):
+    import numpy as np
+
+    from snake_slam_amd import synth
+    from snake_slam_amd.sequence import inverse_pose_tum, trajectory_block, trajectory_rows, write_tum
+
+    rng = np.random.default_rng(5)
+    poses = [synth.random_pose(rng) for _ in range(7)]
+    rows = np.array([np.concatenate([[0.05 * i], inverse_pose_tum(p)]) for i, p in enumerate(poses)])
+    blk = trajectory_block(rows, 10)
+    assert blk.shape == (81,) and blk[0] == 7 and not blk[1 + 56:].any()
+    assert np.array_equal(trajectory_rows(blk), rows)
+    # inverse pose: R^T, -R^T t (System.cpp:553-555), unit quaternion with w >= 0
+    for p, r in zip(poses, rows):
+        R = synth.quat_to_R(p[:4])
+        assert np.allclose(r[1:4], -R.T @ p[4:]) and np.allclose(synth.quat_to_R(r[4:8]), R.T) and r[7] >= 0
+    write_tum(tmp_path / "traj.txt", rows)
+    back = np.loadtxt(tmp_path / "traj.txt")
+    assert back.shape == (7, 8) and np.allclose(back, rows, rtol=1e-14, atol=0)
+    try:
+        trajectory_block(rows, 3)
+        assert False
+    except ValueError:
+        pass

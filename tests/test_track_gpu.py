@@ -260,3 +260,88 @@ def test_relink_edges(orc, deferred_mapper):
     bad["feature"][1] = len(frame["kps"])
     with pytest.raises(SnakeHipError):
         deferred_mapper.RelinkSearch(frame, cam, pose, bad)
+
+
+def _pack_frames_dev(frames, cap):
+    """Host frame dicts (grid order) -> padded device tensors of the batched, device-resident view."""
+    import torch
+
+    from snake_slam_amd.tracking import KP64_DTYPE
+
+    B = len(frames)
+    ncell = frames[0]["cols"] * frames[0]["rows"] + 1
+    kps = np.zeros((B, cap), KP64_DTYPE)
+    desc = np.zeros((B, cap, 4), np.uint64)
+    rp = np.full((B, cap), -1.0, np.float32)
+    taken = np.zeros((B, cap), np.uint8)
+    cs = np.zeros((B, ncell), np.int32)
+    n = np.zeros(B, np.int32)
+    for b, f in enumerate(frames):
+        k = len(f["kps"])
+        n[b] = k
+        kps[b, :k], desc[b, :k], rp[b, :k], taken[b, :k], cs[b] = f["kps"], f["desc"], f["right_points"], f["taken"], f["cell_start"]
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(a.shape[0], -1)).to(dev)
+    return dict(n=torch.from_numpy(n).to(dev), kps=t(kps).view(B, cap, 24), desc=torch.from_numpy(desc.view(np.int64)).to(dev),
+                right_points=torch.from_numpy(rp).to(dev), taken=torch.from_numpy(taken).to(dev), cell_start=torch.from_numpy(cs).to(dev))
+
+
+def test_coarse_then_fine_batch_dev_parity(orc, matcher):
+    """The device-resident, batched forms (frames as the batched front-end leaves them in HBM, poses on the device)
+    against the oracle, frame by frame: coarse -> `mvpMapPoints[idx] = mp` applied on the device -> fine, i.e. the
+    per-frame chain of TrackingCoarse.cpp:234 / TrackingFine.cpp:149 for a whole batch in three launches per matcher."""
+    import torch
+
+    from snake_slam_amd.tracking import LM_COARSE_DTYPE, LM_FINE_DTYPE, frames_dev
+
+    rng = np.random.default_rng(SEED + 77)
+    sizes = [(300, 400, 900), (900, 1200, 2500), (0, 50, 40), (600, 1500, 3000), (1000, 700, 10)]
+    cases = [T.make_tracking_case(orc, rng, n_clutter=c, m_pts=mp) for c, mp, _ in sizes]
+    frames = [c[0] for c in cases]
+    cam, ls = cases[0][1], cases[0][3]
+    cap = max(len(f["kps"]) for f in frames) + 7
+    B = len(cases)
+    mc_cap = max(len(c[4]["pos"]) for c in cases) + 3
+    coarse = [T.lm_coarse(orc, c[4]) for c in cases]
+    fine = [T.lm_fine(orc, rng, c[4], c[2], ls)[: s[2]] for c, s in zip(cases, sizes)]
+    mf_cap = max(len(f) for f in fine) + 5
+    pc = np.zeros((B, mc_cap), LM_COARSE_DTYPE)
+    pf = np.zeros((B, mf_cap), LM_FINE_DTYPE)
+    nc, nf = np.zeros(B, np.int32), np.zeros(B, np.int32)
+    for b in range(B):
+        nc[b], nf[b] = len(coarse[b]), len(fine[b])
+        pc[b, : nc[b]], pf[b, : nf[b]] = coarse[b], fine[b]
+    dev = torch.device("cuda", 0)
+    D = _pack_frames_dev(frames, cap)
+    poses = torch.from_numpy(np.stack([c[2] for c in cases])).to(dev)
+    d_pc = torch.from_numpy(pc.view(np.uint8).reshape(B, mc_cap, 88)).to(dev)
+    d_pf = torch.from_numpy(pf.view(np.uint8).reshape(B, mf_cap, 96)).to(dev)
+    d_nc, d_nf = torch.from_numpy(nc).to(dev), torch.from_numpy(nf).to(dev)
+    mi_c = torch.full((B, mc_cap), -7, dtype=torch.int32, device=dev)
+    mi_f = torch.full((B, mf_cap), -7, dtype=torch.int32, device=dev)
+    vis = torch.full((B, mf_cap), 9, dtype=torch.uint8, device=dev)
+    n_c = torch.zeros(B, dtype=torch.int32, device=dev)
+    n_f = torch.zeros(B, dtype=torch.int32, device=dev)
+    fd = frames_dev(T.BOUNDS, D["n"], D["kps"], D["desc"], D["right_points"], D["taken"], D["cell_start"])
+    torch.cuda.synchronize()
+    matcher.coarse_batch_dev(fd, cam, poses, d_pc, d_nc, 15.0, 75, 0, ls, mi_c, n_c)
+    matcher.mark_taken_batch_dev(mi_c, d_nc, D["taken"])
+    matcher.fine_batch_dev(fd, cam, poses, d_pf, d_nf, 5.0, 0.8, ls, mi_f, vis, n_f)
+    matcher.sync()
+    mi_c, mi_f, vis, n_c, n_f = mi_c.cpu().numpy(), mi_f.cpu().numpy(), vis.cpu().numpy(), n_c.cpu().numpy(), n_f.cpu().numpy()
+    taken_after = D["taken"].cpu().numpy()
+    pf_after = d_pf.cpu().numpy().view(LM_FINE_DTYPE).reshape(B, mf_cap)
+    total = 0
+    for b, (frame, _, pose, _, _, _) in enumerate(cases):
+        wn, widx = orc.match_coarse(frame, cam, pose, coarse[b], 15.0, 75, 0, ls)
+        assert n_c[b] == wn and np.array_equal(mi_c[b, : nc[b]], widx), b
+        assert (mi_c[b, nc[b]:] == -1).all()
+        f2 = dict(frame)
+        f2["taken"] = frame["taken"].copy()
+        f2["taken"][widx[widx >= 0]] = 1
+        assert np.array_equal(taken_after[b, : len(frame["kps"])], f2["taken"]), b
+        wn, widx, wvis, wvalid = orc.match_fine(f2, cam, pose, fine[b], 5.0, 0.8, ls)
+        assert n_f[b] == wn and np.array_equal(mi_f[b, : nf[b]], widx), b
+        assert np.array_equal(vis[b, : nf[b]], wvis) and np.array_equal(pf_after[b, : nf[b]]["valid"], wvalid), b
+        total += int(n_c[b]) + int(n_f[b])
+    assert total > 500
