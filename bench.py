@@ -205,7 +205,7 @@ def main():
                     "per-kernel timings then overlap)")
     ap.add_argument("--gba-keyframes", type=int, default=300, help="keyframes of the global-BA leg (0 = skip; single GPU only)")
     ap.add_argument("--pose-frames", type=int, default=256, help="frames per pose-refinement call (0 = skip; single GPU only)")
-    ap.add_argument("--track-frames", type=int, default=64, help="frames of the tracking-matcher leg (device-resident coarse + fine "
+    ap.add_argument("--track-frames", type=int, default=256, help="frames of the tracking-matcher leg (device-resident coarse + fine "
                     "projection matchers on the frames the front-end left in HBM; 0 = skip)")
     ap.add_argument("--mode", choices=["batch", "sequence"], default="batch",
                     help="batch = the headline throughput benchmark (default); sequence = BASELINE.json config 5: every rank walks its "
@@ -535,9 +535,14 @@ def main():
             traffic = None
             tj = ROOT / "profiles" / "fast_kernel_traffic.json"
             if tj.exists():
+                # PMC bytes of a separate rocprofv3 --pmc run (tools/profile_gpu.sh + tools/collect_traffic.py); only valid for the
+                # kernel source it was collected on: a file whose recorded source hash is not the current one is refused
                 try:
+                    import hashlib
+
                     t = json.loads(tj.read_text())
-                    if t.get("images_per_launch"):  # PMC bytes scale with the images of a launch
+                    cur = hashlib.sha256((ROOT / t.get("source", "snake_slam_amd/csrc/orb.hip")).read_bytes()).hexdigest()
+                    if t.get("source_sha256") == cur and t.get("images_per_launch"):
                         traffic = int(t.get("hbm_bytes_per_launch") * images_per_launch / t.get("images_per_launch"))
                 except Exception:
                     traffic = None
