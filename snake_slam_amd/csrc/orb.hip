@@ -330,6 +330,63 @@ __device__ __forceinline__ short2_t fast_score16_pk(const short2_t (&d)[16])
     return pk_max(bright, -dark);
 }
 
+// The same score on RAW ring bytes, two pixels per lane, with gfx950's three-input packed minimum / maximum:
+// min over a 9-window of (ring - c) = (min over the window of ring) - c, so the network runs on the bytes themselves.
+// A byte b in a 16-bit half is the f16 DENORMAL b * 2^-24; positive f16 values order like their bit patterns and the
+// kernel runs with f16 denormals preserved (the compiler default, .amdhsa_float_denorm_mode_16_64 = 3; checked on the
+// hardware by tools/probes/pk_min3_probe.hip), so v_pk_minimum3_f16 / v_pk_maximum3_f16 are exact integer min3 / max3 of
+// the two halves.  9-window = 3 windows of 3: 16 + 16 + 8 instructions per polarity instead of 16 + 16 + 32 + 16.
+__device__ __forceinline__ u32 pk_min3(u32 a, u32 b, u32 c)
+{
+    u32 o;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+    return o;
+}
+__device__ __forceinline__ u32 pk_max3(u32 a, u32 b, u32 c)
+{
+    u32 o;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+    return o;
+}
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32 pku_min(u32 a, u32 b)
+{
+    return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(ushort2_t, a), __builtin_bit_cast(ushort2_t, b)));
+}
+__device__ __forceinline__ u32 pku_max(u32 a, u32 b)
+{
+    return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(ushort2_t, a), __builtin_bit_cast(ushort2_t, b)));
+}
+__device__ __forceinline__ short2_t pk_sub(u32 a, u32 b)
+{
+    return __builtin_bit_cast(short2_t, a) - __builtin_bit_cast(short2_t, b);
+}
+
+// r[i]: ring byte i of pixel 0 | ring byte i of pixel 1 << 16; c likewise for the centres.  Returns the two scores.
+__device__ __forceinline__ short2_t fast_score16_raw(const u32 (&r)[16], u32 c)
+{
+    u32 a3[16], b3[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+    {
+        a3[i] = pk_min3(r[i], r[(i + 1) & 15], r[(i + 2) & 15]);
+        b3[i] = pk_max3(r[i], r[(i + 1) & 15], r[(i + 2) & 15]);
+    }
+    u32 a9[16], b9[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+    {
+        a9[i] = pk_min3(a3[i], a3[(i + 3) & 15], a3[(i + 6) & 15]);
+        b9[i] = pk_max3(b3[i], b3[(i + 3) & 15], b3[(i + 6) & 15]);
+    }
+    // max of the 16 window minima / min of the 16 window maxima: 16 -> 6 -> 2 -> 1
+    const u32 hi = pk_max3(pk_max3(pk_max3(a9[0], a9[1], a9[2]), pk_max3(a9[3], a9[4], a9[5]), pk_max3(a9[6], a9[7], a9[8])),
+                           pk_max3(pk_max3(a9[9], a9[10], a9[11]), pk_max3(a9[12], a9[13], a9[14]), a9[15]), a9[15]);
+    const u32 lo = pk_min3(pk_min3(pk_min3(b9[0], b9[1], b9[2]), pk_min3(b9[3], b9[4], b9[5]), pk_min3(b9[6], b9[7], b9[8])),
+                           pk_min3(pk_min3(b9[9], b9[10], b9[11]), pk_min3(b9[12], b9[13], b9[14]), b9[15]), b9[15]);
+    return pk_max(pk_sub(hi, c), pk_sub(c, lo));
+}
+
 // XCD-aware grids: workgroup L (linear index, x fastest) runs on XCD L % 8 (observed dispatch order, a speed matter only).  All
 // workgroups of an image get the same L % 8 in every kernel of the chain, so what one stage writes for an
 // image (next level, blurred level, candidates) is read by the next stage through the same XCD's L2.
@@ -414,34 +471,80 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
     // scalar register: position = count + prefix population of the ballot, no LDS atomic.
     int ns = 0;
     const int lpy = lane >> 5, lpx = lane & 31;
-    for (int px0 = 0; px0 < cw; px0 += 32)
+    if constexpr (NQ != 0)
     {
-        // two rows of 32 pixels per step; a lane walks down its column: address and (py << 6 | px) code advance by
-        // constants, "inside the cell" is one compare of the code and a loop-invariant column mask.  Rows
-        // below / columns right of the cell read whatever follows in the wavefront's slice; they are masked.
-        const int px  = px0 + lpx;
-        const u8* t   = tile + (lpy + 3) * TP + px + 3 + sh;
-        u32 code      = ((u32)lpy << 6) | (u32)px;  // (py << 6) | px
-        const bool inx = px < cw;
-        const u64 mx   = __builtin_amdgcn_ballot_w64(inx);
-        const u64 mlo  = mx & 0xFFFFFFFFull;  // odd cell height: the last step only has its first row
-        auto step = [&](bool row_ok, u64 mrow)
+        // Compile-time pitch: FOUR rows of 32 pixels per step, two pixels per lane in the 16-bit halves of a register (rows
+        // py0 + lpy and py0 + lpy + 2), the bound evaluated on the raw bytes with packed 16-bit min / max:
+        //   ub = max(min(max(r0, r8), max(r4, r12)) - c, c - max(min(r0, r8), min(r4, r12)))
+        // 5 packs + 9 packed operations + 2 compares per 128 pixels (the one-pixel form: 14 per 64).
+        for (int px0 = 0; px0 < cw; px0 += 32)
         {
-            const int v  = t[0];
-            const int d0 = t[3 * TP] - v, d8 = t[-3 * TP] - v, d4 = t[3] - v, d12 = t[-3] - v;
-            const int ub_b = min(max(d0, d8), max(d4, d12));
-            const int ub_d = min(max(-d0, -d8), max(-d4, -d12));
-            const int ub   = max(ub_b, ub_d);
-            const bool sv  = row_ok && ub > min_th;
-            // ballot of the compare ANDed with the loop-invariant mask in scalar registers (a ballot of `sv` costs two
-            // more vector instructions per step)
-            const u64 m = mrow & __builtin_amdgcn_ballot_w64(ub > min_th);
-            if (sv) surv[ns + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u))] = (u16)code;
-            ns += __popcll(m);
-        };
-        int py0 = 0;
-        for (; py0 + 2 <= ch; py0 += 2, t += 2 * TP, code += 128u) step(inx, mx);
-        if (py0 < ch) step(inx && lpy == 0, mlo);
+            const int px   = px0 + lpx;
+            const u8* t    = tile + (lpy + 3) * TP + px + 3 + sh;
+            u32 code       = ((u32)lpy << 6) | (u32)px;  // (py << 6) | px of the low half; the high half is two rows below
+            const bool inx = px < cw;
+            const u64 mx   = __builtin_amdgcn_ballot_w64(inx);
+            auto step = [&](bool ok_lo, u64 m_lo, bool ok_hi, u64 m_hi)
+            {
+                const u32 c   = (u32)t[0] | ((u32)t[2 * TP] << 16);
+                const u32 r0  = (u32)t[3 * TP] | ((u32)t[5 * TP] << 16);
+                const u32 r8  = (u32)t[-3 * TP] | ((u32)t[-TP] << 16);
+                const u32 r4  = (u32)t[3] | ((u32)t[2 * TP + 3] << 16);
+                const u32 r12 = (u32)t[-3] | ((u32)t[2 * TP - 3] << 16);
+                const u32 hi  = pku_min(pku_max(r0, r8), pku_max(r4, r12));
+                const u32 lo  = pku_max(pku_min(r0, r8), pku_min(r4, r12));
+                const short2_t ub = pk_max(pk_sub(hi, c), pk_sub(c, lo));
+                const bool s_lo = (int)ub.x > min_th;
+                const bool s_hi = __builtin_bit_cast(int, ub) > ((min_th << 16) | 0xFFFF);  // high half > min_th
+                const u64 ml = m_lo & __builtin_amdgcn_ballot_w64(s_lo);
+                if (ok_lo && s_lo) surv[ns + __builtin_amdgcn_mbcnt_hi((u32)(ml >> 32), __builtin_amdgcn_mbcnt_lo((u32)ml, 0u))] = (u16)code;
+                ns += __popcll(ml);
+                const u64 mh = m_hi & __builtin_amdgcn_ballot_w64(s_hi);
+                if (ok_hi && s_hi)
+                    surv[ns + __builtin_amdgcn_mbcnt_hi((u32)(mh >> 32), __builtin_amdgcn_mbcnt_lo((u32)mh, 0u))] = (u16)(code + 128u);
+                ns += __popcll(mh);
+            };
+            int py0 = 0;
+            for (; py0 + 4 <= ch; py0 += 4, t += 4 * TP, code += 256u) step(inx, mx, inx, mx);
+            const int rem = ch - py0;  // 0..3 rows left: low halves hold rows py0 + lpy, high halves py0 + lpy + 2
+            if (rem > 0)
+            {
+                const u64 lanes_lo = rem >= 2 ? ~0ull : 0xFFFFFFFFull, lanes_hi = rem >= 3 ? 0xFFFFFFFFull : 0ull;
+                step(inx && lpy < rem, mx & lanes_lo, inx && lpy + 2 < rem, mx & lanes_hi);
+            }
+        }
+    }
+    else
+    {
+        for (int px0 = 0; px0 < cw; px0 += 32)
+        {
+            // two rows of 32 pixels per step; a lane walks down its column: address and (py << 6 | px) code advance by
+            // constants, "inside the cell" is one compare of the code and a loop-invariant column mask.  Rows
+            // below / columns right of the cell read whatever follows in the wavefront's slice; they are masked.
+            const int px  = px0 + lpx;
+            const u8* t   = tile + (lpy + 3) * TP + px + 3 + sh;
+            u32 code      = ((u32)lpy << 6) | (u32)px;  // (py << 6) | px
+            const bool inx = px < cw;
+            const u64 mx   = __builtin_amdgcn_ballot_w64(inx);
+            const u64 mlo  = mx & 0xFFFFFFFFull;  // odd cell height: the last step only has its first row
+            auto step = [&](bool row_ok, u64 mrow)
+            {
+                const int v  = t[0];
+                const int d0 = t[3 * TP] - v, d8 = t[-3 * TP] - v, d4 = t[3] - v, d12 = t[-3] - v;
+                const int ub_b = min(max(d0, d8), max(d4, d12));
+                const int ub_d = min(max(-d0, -d8), max(-d4, -d12));
+                const int ub   = max(ub_b, ub_d);
+                const bool sv  = row_ok && ub > min_th;
+                // ballot of the compare ANDed with the loop-invariant mask in scalar registers (a ballot of `sv` costs two
+                // more vector instructions per step)
+                const u64 m = mrow & __builtin_amdgcn_ballot_w64(ub > min_th);
+                if (sv) surv[ns + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u))] = (u16)code;
+                ns += __popcll(m);
+            };
+            int py0 = 0;
+            for (; py0 + 2 <= ch; py0 += 2, t += 2 * TP, code += 128u) step(inx, mx);
+            if (py0 < ch) step(inx && lpy == 0, mlo);
+        }
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -452,14 +555,28 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
         const int px0 = e0 & 63, py0 = e0 >> 6, px1 = e1 & 63, py1 = e1 >> 6;
         const u8* t0 = tile + (py0 + 3) * TP + px0 + 3 + sh;
         const u8* t1 = tile + (py1 + 3) * TP + px1 + 3 + sh;
-        const short v0 = t0[0], v1 = t1[0];
-        short2_t d[16];
-#define RING(i, dx, dy) d[i] = short2_t{(short)(t0[(dy)*TP + (dx)] - v0), (short)(t1[(dy)*TP + (dx)] - v1)};
-        RING(0, 0, 3) RING(1, 1, 3) RING(2, 2, 2) RING(3, 3, 1) RING(4, 3, 0) RING(5, 3, -1) RING(6, 2, -2) RING(7, 1, -3)
-        RING(8, 0, -3) RING(9, -1, -3) RING(10, -2, -2) RING(11, -3, -1) RING(12, -3, 0) RING(13, -3, 1) RING(14, -2, 2)
-        RING(15, -1, 3)
+        short2_t s;
+        if constexpr (NQ != 0)
+        {
+            u32 r[16];
+#define RING(i, dx, dy) r[i] = (u32)t0[(dy)*TP + (dx)] | ((u32)t1[(dy)*TP + (dx)] << 16);
+            RING(0, 0, 3) RING(1, 1, 3) RING(2, 2, 2) RING(3, 3, 1) RING(4, 3, 0) RING(5, 3, -1) RING(6, 2, -2) RING(7, 1, -3)
+            RING(8, 0, -3) RING(9, -1, -3) RING(10, -2, -2) RING(11, -3, -1) RING(12, -3, 0) RING(13, -3, 1) RING(14, -2, 2)
+            RING(15, -1, 3)
 #undef RING
-        const short2_t s = fast_score16_pk(d);
+            s = fast_score16_raw(r, (u32)t0[0] | ((u32)t1[0] << 16));
+        }
+        else
+        {
+            const short v0 = t0[0], v1 = t1[0];
+            short2_t d[16];
+#define RING(i, dx, dy) d[i] = short2_t{(short)(t0[(dy)*TP + (dx)] - v0), (short)(t1[(dy)*TP + (dx)] - v1)};
+            RING(0, 0, 3) RING(1, 1, 3) RING(2, 2, 2) RING(3, 3, 1) RING(4, 3, 0) RING(5, 3, -1) RING(6, 2, -2) RING(7, 1, -3)
+            RING(8, 0, -3) RING(9, -1, -3) RING(10, -2, -2) RING(11, -3, -1) RING(12, -3, 0) RING(13, -3, 1) RING(14, -2, 2)
+            RING(15, -1, 3)
+#undef RING
+            s = fast_score16_pk(d);
+        }
         S[(py0 + 1) * SP + px0 + 1] = (u8)(s.x < 0 ? 0 : s.x);
         if (j + 1 < ns) S[(py1 + 1) * SP + px1 + 1] = (u8)(s.y < 0 ? 0 : s.y);
     }
