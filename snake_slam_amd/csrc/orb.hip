@@ -1373,8 +1373,11 @@ __device__ __forceinline__ int wave_sum(int v)
 // table (LDS copy); the patch goes to the wavefront's LDS slice and the 512 test bytes are LDS reads;
 // 4 ballots assemble the descriptor.
 constexpr int DESC_KPW    = 4;
-constexpr int PATCH_R     = 18, PATCH_DW = 10;                  // 37 rows x 10 dwords
-constexpr int PATCH_ITEMS = (2 * PATCH_R + 1) * PATCH_DW;  // 370 -> 6 loads per lane
+constexpr int PATCH_R     = 18, PATCH_DW = 12;                  // 37 rows x 12 dwords (10 needed): a row is 3 lanes x 16 bytes
+constexpr int PATCH_QUADS = (2 * PATCH_R + 1) * 3;              // 111 sixteen-byte items -> 2 loads per lane
+constexpr int PATCH_ITEMS = (2 * PATCH_R + 1) * PATCH_DW;
+constexpr int MOM_TRIPLES = 31 * 3;                             // a moment-window row (9 dwords) is 3 lanes x 12 bytes -> 2 loads per lane
+typedef u32 u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
 
 __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __restrict__ img0, int pitch0,
                                                        long long stride0, int aligned0, const u32* __restrict__ sel,
@@ -1383,7 +1386,7 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
                                                        int* __restrict__ n_out, int out_cap, int gx, int batch)
 {
     __shared__ uint2 mtab[4 * MOM_PAD];
-    __shared__ u32 patch[4][PATCH_ITEMS + 14];
+    __shared__ __attribute__((aligned(16))) u32 patch[4][PATCH_ITEMS + 16];
     const int tid  = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     // XCD-aware 1-D grid (workgroup L runs on XCD L % 8, a speed matter only): every workgroup of an image
@@ -1425,30 +1428,33 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
     const int bpitch   = lv.pitch;
     const bool aligned = l == 0 ? aligned0 != 0 : true;
 
-    // per-lane geometry, shared by the keypoints: byte offsets of its moment / patch dwords relative to
-    // the window origins (items past the end repeat the last one; moment weights there are zero)
-    int moff[5], vyv[5], boff[6];
+    // per-lane geometry, shared by the keypoints: byte offsets of its moment / patch items relative to the window
+    // origins.  A lane moves 12 (moment window) or 16 (patch) bytes per load: the texture-address unit works through a
+    // wavefront load 4 lanes per cycle however few bytes a lane asks for, and with one dword per lane the 44 loads of a
+    // wavefront (11 per keypoint) kept it busy for ~700 cycles; now 16 loads carry the same rows.
+    int moff[2], vyv[2], boff[2];
+    bool mok[2], bok[2];
 #pragma unroll
-    for (int k = 0; k < 5; ++k)
+    for (int k = 0; k < 2; ++k)
     {
-        const int item = min(lane + 64 * k, MOM_ITEMS - 1);
-        const int row  = item / 9;
+        const int item = lane + 64 * k;
+        mok[k]         = item < MOM_TRIPLES;
+        const int it   = mok[k] ? item : MOM_TRIPLES - 1;
+        const int row  = (it * 171) >> 9;  // it / 3
         vyv[k]         = row - 15;
-        moff[k]        = (row - 15) * pitch + 4 * (item - row * 9);
-    }
-#pragma unroll
-    for (int k = 0; k < 6; ++k)
-    {
-        const int item = min(lane + 64 * k, PATCH_ITEMS - 1);
-        const int row  = item / PATCH_DW;
-        boff[k]        = (row - PATCH_R) * bpitch + 4 * (item - row * PATCH_DW);
+        moff[k]        = (row - 15) * pitch + 12 * (it - row * 3);
+        bok[k]         = item < PATCH_QUADS;
+        const int ib   = bok[k] ? item : PATCH_QUADS - 1;
+        const int rb   = (ib * 171) >> 9;
+        boff[k]        = (rb - PATCH_R) * bpitch + 16 * (ib - rb * 3);
     }
 
     // ---- issue every load of the wavefront; the copy of the moment table to LDS (and its barrier) comes after, so
     // that its latency overlaps theirs ----
     bool valid[DESC_KPW];
     int kxv[DESC_KPW], kyv[DESC_KPW], scv[DESC_KPW];
-    u32 dwv[DESC_KPW][5], bpv[DESC_KPW][6];
+    u32x3_a4 dwv[DESC_KPW][2];
+    u32x4_a4 bpv[DESC_KPW][2];
     const long long sbase = (long long)b * L.total_slots + lv.slot_off;
 #pragma unroll
     for (int s = 0; s < DESC_KPW; ++s)
@@ -1457,9 +1463,11 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
         valid[s]       = work && slot < cnt_l && offset + slot < out_cap;
         kxv[s] = kyv[s] = scv[s] = 0;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) dwv[s][k] = 0u;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) bpv[s][k] = 0u;
+        for (int k = 0; k < 2; ++k)
+        {
+            dwv[s][k] = u32x3_a4{0u, 0u, 0u};
+            bpv[s][k] = u32x4_a4{0u, 0u, 0u, 0u};
+        }
     }
     if (work)
     {
@@ -1478,10 +1486,13 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
             const int xa = (kxv[s] - 15) & ~3, xb = (kxv[s] - PATCH_R) & ~3;
             const u8* mo = src + ((long long)kyv[s] * pitch + xa);
             const u8* bo = bsrc + ((long long)kyv[s] * bpitch + xb);
+            // lanes past the last item repeat it (no divergent branch around a load); their moment weights are zeroed
+            // below and their patch quads are not stored
 #pragma unroll
-            for (int k = 0; k < 5; ++k) dwv[s][k] = aligned ? *reinterpret_cast<const u32*>(mo + moff[k]) : 0u;
+            for (int k = 0; k < 2; ++k)
+                if (aligned) dwv[s][k] = *reinterpret_cast<const u32x3_a4*>(mo + moff[k]);
 #pragma unroll
-            for (int k = 0; k < 6; ++k) bpv[s][k] = *reinterpret_cast<const u32*>(bo + boff[k]);
+            for (int k = 0; k < 2; ++k) bpv[s][k] = *reinterpret_cast<const u32x4_a4*>(bo + boff[k]);
         }
     }
     {
@@ -1511,11 +1522,19 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
             const int sh2 = (kx - 15) & 3;
             u32 sx = 0, s0 = 0;
 #pragma unroll
-            for (int k = 0; k < 5; ++k)
+            for (int k = 0; k < 2; ++k)
             {
-                const uint2 w = mtab[sh2 * MOM_PAD + lane + 64 * k];
-                sx            = __builtin_amdgcn_udot4(dwv[s][k], w.x, sx, false);
-                const u32 sr  = __builtin_amdgcn_udot4(dwv[s][k], w.y, 0u, false);
+                // item = (row, third of the row): its three dwords are dwords 3 * item .. 3 * item + 2 of the window
+                const int it = mok[k] ? lane + 64 * k : 0;
+                u32 sr       = 0;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                {
+                    const uint2 w = mtab[sh2 * MOM_PAD + 3 * it + j];
+                    const u32 d   = mok[k] ? dwv[s][k][j] : 0u;
+                    sx            = __builtin_amdgcn_udot4(d, w.x, sx, false);
+                    sr            = __builtin_amdgcn_udot4(d, w.y, sr, false);
+                }
                 s0 += sr;
                 m01 += vyv[k] * (int)sr;
             }
@@ -1559,8 +1578,8 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
         const int kx = kxv[s], ky = kyv[s];
         // blurred patch -> LDS (in-order per wavefront: the previous keypoint's reads are done)
 #pragma unroll
-        for (int k = 0; k < 6; ++k)
-            if (lane + 64 * k < PATCH_ITEMS) patch[wave][lane + 64 * k] = bpv[s][k];
+        for (int k = 0; k < 2; ++k)
+            if (bok[k]) reinterpret_cast<u32x4_a16*>(patch[wave])[lane + 64 * k] = bpv[s][k];
         const float angle = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, angle_l), 16 * s));
         const float sn    = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sn_l), 16 * s));
         const float cs    = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cs_l), 16 * s));
