@@ -108,6 +108,8 @@ struct SetItem
     int pair_off, npairs;  // into set_pairs: ra | rb << 8, camera(ra) < camera(rb) or ra == rb
     int part_off;          // first of its npairs partial sums in s_part (36 doubles each)
     int run;               // observations per point of this set
+    int nfree;             // free-camera observations per point (k)
+    int aux_off;           // into set_pairs: k run positions ordered by camera index, then the k x k table "pair slot of (i, j)", i <= j
 };
 
 struct Arrays
@@ -1011,6 +1013,7 @@ __global__ __launch_bounds__(256) void schur_set(Arrays A, int nbx, int B)
     const int it   = bx * 4 + wave;
     if (it >= pr.n_set) return;  // whole wavefront
     const SetItem si = A.set_items[pr.set_off + it];
+    if (si.npairs == 0) return;  // linearisation-only item of schur_fused
     // the item's point list sits in one register per lane and is broadcast with v_readlane: no dependent index loads
     // in front of the row loads
     const int2 my_pt = lane < si.n_pts ? A.set_pts[si.pts_off + lane] : make_int2(0, 0);
@@ -1106,6 +1109,373 @@ __global__ __launch_bounds__(256) void schur_set(Arrays A, int nbx, int B)
             out[2] = make_double2(acc[t][4], acc[t][5]);
         }
     }
+}
+
+// ---- point-major Schur pass on the matrix cores ----
+// The same work items, staging and partial sums as schur_set, but a point's products are ONE small matrix product on the
+// MFMA pipe: with the point's k free rows ordered by camera index, M = (W V^-1) W^T is a 6k x 6k matrix whose upper
+// triangle holds exactly the 6 x 6 blocks of the set's pairs.  It is covered by T(T + 1) / 2 tiles of
+// v_mfma_f64_16x16x4_f64 (T = ceil(6k / 16): 3 for k <= 8, 4 for k <= 10; inner dimension 3 of 4), accumulated over the
+// item's points in the accumulator registers.  Per point a lane reads T x 3 doubles of W from LDS (the vector form: ~70),
+// does T x 3 multiply-adds for its element of W V^-1, and the 6 (10) matrix instructions carry the 27 multiply-adds per
+// (pair, row) unit of schur_set.  fp64 throughput of the two pipes is the same on MI355X (tools/probes/f64_rate_probe.hip:
+// 55.9 vs 49.3 TFLOP/s measured), so the gain is not arithmetic rate: it is the operand traffic -- the vector ALU and the
+// LDS no longer carry the products -- and the two pipes running side by side.
+// Operand / result layout of the instruction (probed on the hardware): lane l supplies A[l & 15][l >> 4] and
+// B[l >> 4][l & 15], and receives D[(l >> 4) + 4 j][l & 15] in register j.
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+template <int T, int QUADS>
+__global__ __launch_bounds__(256) void schur_mfma(Arrays A, int nbx, int B)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_stage[4][2][SET_SLOT];
+    int pb, bx;
+    if (B >= 16)  // batched windows: one XCD per window
+    {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        pb = (slot / nbx) * 8 + xcd;
+        bx = slot - (slot / nbx) * nbx;
+    }
+    else
+    {
+        pb = blockIdx.x / nbx;
+        bx = blockIdx.x - pb * nbx;
+    }
+    if (pb >= B) return;
+    const Prob pr  = A.prob[pb];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int it   = bx * 4 + wave;
+    if (it >= pr.n_set) return;  // whole wavefront
+    const SetItem si = A.set_items[pr.set_off + it];
+    if (si.npairs == 0) return;  // linearisation-only item of schur_fused
+    const int2 my_pt = lane < si.n_pts ? A.set_pts[si.pts_off + lane] : make_int2(0, 0);
+    const unsigned char* Wb = reinterpret_cast<const unsigned char*>(A.o_W + (size_t)pr.obs_off * 18);
+    const unsigned char* Vb = reinterpret_cast<const unsigned char*>(A.Vinv + (size_t)pr.pt_off * 6);
+    const int wchunks = si.run * 9, nch = wchunks + 3;  // 16-byte chunks of a point: rows | V^-1
+    const int nrows = si.nfree * 6;                      // rows of M
+    const int kk = lane >> 4, mr = lane & 15;            // inner index / row (column) inside a tile of this lane's operands
+    // LDS byte offset of row 16 t + mr of M inside a staged point (rows beyond 6k and the 4th inner index supply zeros)
+    int roff[T];
+    bool rok[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+    {
+        const int m = 16 * t + mr, i = (m * 43) >> 8, r = m - 6 * i;  // m / 6, m % 6 (m < 64)
+        rok[t]      = m < nrows && kk < 3;
+        const int pos = m < nrows ? A.set_pairs[si.aux_off + i] : 0;
+        roff[t]     = pos * 144 + r * 24;
+    }
+    double4_t acc[T * (T + 1) / 2];
+#pragma unroll
+    for (int q = 0; q < T * (T + 1) / 2; ++q) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
+
+    auto fetch = [&](int n, uint4 (&st)[QUADS])
+    {
+        const int p  = __builtin_amdgcn_readlane(my_pt.x, n);
+        const int s0 = __builtin_amdgcn_readlane(my_pt.y, n);
+#pragma unroll
+        for (int u = 0; u < QUADS; ++u)
+        {
+            const int ch = lane + 64 * u;
+            st[u]        = uint4{0u, 0u, 0u, 0u};
+            if (ch < nch)
+                st[u] = *reinterpret_cast<const uint4*>(ch < wchunks ? Wb + (size_t)s0 * 144 + ch * 16 : Vb + (size_t)p * 48 + (ch - wchunks) * 16);
+        }
+    };
+    auto consume = [&](int slot, uint4 (&st)[QUADS], int refill)
+    {
+        unsigned char* base = s_stage[wave][slot];
+#pragma unroll
+        for (int u = 0; u < QUADS; ++u)
+            if (lane + 64 * u < nch) *reinterpret_cast<uint4*>(base + (lane + 64 * u) * 16) = st[u];
+        if (refill < si.n_pts) fetch(refill, st);
+        __builtin_amdgcn_wave_barrier();
+        const double* vv = reinterpret_cast<const double*>(base + wchunks * 16);
+        // column kk of the symmetric V^-1 (entries 0 1 2 / 1 3 4 / 2 4 5)
+        const double vc0 = vv[kk == 0 ? 0 : (kk == 1 ? 1 : 2)], vc1 = vv[kk == 0 ? 1 : (kk == 1 ? 3 : 4)], vc2 = vv[kk == 0 ? 2 : (kk == 1 ? 4 : 5)];
+        double ya[T], wb[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+        {
+            const double* w = reinterpret_cast<const double*>(base + roff[t]);
+            const double w0 = w[0], w1 = w[1], w2 = w[2];
+            ya[t] = rok[t] ? w0 * vc0 + w1 * vc1 + w2 * vc2 : 0.0;                  // (W V^-1)[row][kk]
+            wb[t] = rok[t] ? (kk == 0 ? w0 : (kk == 1 ? w1 : w2)) : 0.0;           // W[row][kk]
+        }
+        int q = 0;
+#pragma unroll
+        for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+            for (int tj = ti; tj < T; ++tj, ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[ti], wb[tj], acc[q], 0, 0, 0);
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    uint4 sa[QUADS], sb[QUADS];
+    fetch(0, sa);
+    if (si.n_pts > 1) fetch(1, sb);
+    for (int n = 0; n < si.n_pts; n += 2)
+    {
+        consume(0, sa, n + 2);
+        if (n + 1 < si.n_pts) consume(1, sb, n + 3);
+    }
+    // the tiles -> the item's partial sums (pair slot q: 36 doubles, row-major block (W_ra V^-1) W_rb^T)
+    const int* tab = A.set_pairs + si.aux_off + si.nfree;
+    double* part   = A.s_part + (size_t)si.part_off * 36;
+    int q = 0;
+#pragma unroll
+    for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+        for (int tj = ti; tj < T; ++tj, ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                const int m = 16 * ti + kk + 4 * j, n = 16 * tj + mr;
+                if (m >= nrows || n >= nrows) continue;
+                const int ia = (m * 43) >> 8, r = m - 6 * ia, ib = (n * 43) >> 8, c = n - 6 * ib;
+                if (ia > ib) continue;  // lower triangle inside a diagonal tile: not a pair
+                const int slot = tab[ia * si.nfree + ib];
+                const double v = acc[q][j];
+                part[(size_t)slot * 36 + r * 6 + c] = v;
+                // a diagonal block that straddles two tiles has its lower-left corner in a tile that is not computed:
+                // M is symmetric, the mirror element stands in (schur_sum symmetrises diagonal blocks anyway)
+                if (ia == ib && ti != tj) part[(size_t)slot * 36 + c * 6 + r] = v;
+            }
+}
+
+// ---- linearisation + point-major Schur pass in one kernel: W never reaches HBM ----
+// point_wave writes W = J_c^T J_p (144 bytes per observation, 590 MB per LM iteration of 256 benchmark windows) only for
+// the Schur pass to read it back.  Here a wavefront that owns a work item of schur_mfma linearises the item's points itself,
+// 64 / run points at a time (lane = (point of the group, observation of the point); the same arithmetic, in the same order,
+// as point_wave: phase 1 per observation, phase 2 per point in observation order), leaves the rows in LDS and multiplies
+// them on the matrix cores right there.  It also writes what point_wave writes per POINT (cost, V^-1, b_p, position | V^-1 b_p),
+// so point_wave is not launched at all; points without Schur products (constant points, points of constant cameras only)
+// come as work items without pairs.  Observation inputs are read once (48 bytes + cached point / pose gathers).
+template <int T>
+__global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int B)
+{
+    // per wavefront: 64 x 18 doubles (phase 1/2 scratch of 14 per lane, then the W rows) | V^-1 of the group's points
+    // (up to 64 points per group when a point has one observation)
+    __shared__ __attribute__((aligned(16))) double s_buf[4][64 * 18 + 64 * 6];
+    int pb, bx;
+    if (B >= 16)  // batched windows: one XCD per window
+    {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        pb = (slot / nbx) * 8 + xcd;
+        bx = slot - (slot / nbx) * nbx;
+    }
+    else
+    {
+        pb = blockIdx.x / nbx;
+        bx = blockIdx.x - pb * nbx;
+    }
+    if (pb >= B) return;
+    const Prob pr  = A.prob[pb];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int it   = bx * 4 + wave;
+    if (it >= pr.n_set) return;  // whole wavefront
+    const SetItem si = A.set_items[pr.set_off + it];
+    const int2 my_pt = lane < si.n_pts ? A.set_pts[si.pts_off + lane] : make_int2(0, 0);
+    double* s_st   = s_buf[wave];
+    double* s_vi   = s_buf[wave] + 64 * 18;
+    const int run  = si.run, G = 64 / run;  // run <= SET_MAX_RUN = 14: at least 4 points per group
+    const int lg   = lane / run, la = lane - lg * run;  // point of the group / observation of the point
+    const double* poses = A.pose + (size_t)pr.img_off * 7;
+    const double lambda = A.state[pb].lambda;
+
+    const int nrows = si.nfree * 6;
+    const int kk = lane >> 4, mr = lane & 15;
+    int roff[T];
+    bool rok[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+    {
+        const int m = 16 * t + mr, i = (m * 43) >> 8, r = m - 6 * i;
+        rok[t]      = m < nrows && kk < 3;
+        const int pos = m < nrows ? A.set_pairs[si.aux_off + i] : 0;
+        roff[t]     = pos * 18 + r * 3;  // in doubles, relative to the point's first row
+    }
+    double4_t acc[T * (T + 1) / 2];
+#pragma unroll
+    for (int q = 0; q < T * (T + 1) / 2; ++q) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
+
+    for (int n0 = 0; n0 < si.n_pts; n0 += G)
+    {
+        const int gc = min(G, si.n_pts - n0);  // points of this group
+        // ---- phase 1: lane = observation ----
+        const bool act = lg < gc;
+        const int2 mp  = make_int2(__shfl(my_pt.x, n0 + (act ? lg : 0)), __shfl(my_pt.y, n0 + (act ? lg : 0)));
+        const size_t go = (size_t)pr.obs_off + mp.y + la;
+        const int gp    = pr.pt_off + mp.x;
+        double r[3] = {0, 0, 0}, Jc[18], Jp[9];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) Jc[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Jp[k] = 0.0;
+        int dim = 0, c = -1;
+        double cost = 0.0;
+        bool pfree_o = false;
+        if (act)
+        {
+            const int oimg = A.o_img[go], oorig = A.o_orig[go];
+            c = A.o_cam[go];
+            const double2 uv = A.o_uv[go];
+            const double odepth = A.o_depth[go], oweight = A.o_weight[go];
+            const double* ptp  = A.pt + (size_t)gp * 3;
+            const double pt[3] = {ptp[0], ptp[1], ptp[2]};
+            const double* posep = poses + (size_t)oimg * 7;
+            double pose[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) pose[k] = posep[k];
+            const bool is_out = A.outlier[oorig] != 0;
+            pfree_o           = !A.pt_const[gp];
+            if (!is_out)
+            {
+                double R[9];
+                quat_to_R(pose, R);
+                dim = obs_linearize<true>(pose, R, pt, pr.K, pr.bf, uv.x, uv.y, odepth, oweight, r, Jc, Jp);
+                if (dim)
+                {
+                    const double sq = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+                    double sw;
+                    cost = huber_rho(sq, dim == 3 ? O.huber_stereo : O.huber_mono, sw);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) r[k] *= sw;
+#pragma unroll
+                    for (int k = 0; k < 18; ++k) Jc[k] *= sw;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) Jp[k] *= sw;
+                }
+                else
+                {
+                    r[0] = r[1] = r[2] = 0.0;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s_st[lane * PW_JP + k] = Jp[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s_st[lane * PW_JP + 9 + k] = r[k];
+        s_st[lane * PW_JP + 12] = cost;
+        s_st[lane * PW_JP + 13] = (double)dim;
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- phase 2: lane = point of the group (sums in observation order, as point_wave) ----
+        const int p2 = __shfl(my_pt.x, min(n0 + lane, 63));  // outside the branch: a shuffle reads 0 from inactive lanes
+        if (lane < gc)
+        {
+            const int gp2 = pr.pt_off + p2;
+            const bool pfree = !A.pt_const[gp2];
+            double V[6] = {0, 0, 0, 0, 0, 0}, bp[3] = {0, 0, 0};
+            double cst = 0.0;
+            for (int a = 0; a < run; ++a)
+            {
+                const double* q = s_st + (lane * run + a) * PW_JP;
+                if (q[13] == 0.0) continue;
+                cst += q[12];
+                if (pfree)
+                {
+                    V[0] += q[0] * q[0] + q[3] * q[3] + q[6] * q[6];
+                    V[1] += q[0] * q[1] + q[3] * q[4] + q[6] * q[7];
+                    V[2] += q[0] * q[2] + q[3] * q[5] + q[6] * q[8];
+                    V[3] += q[1] * q[1] + q[4] * q[4] + q[7] * q[7];
+                    V[4] += q[1] * q[2] + q[4] * q[5] + q[7] * q[8];
+                    V[5] += q[2] * q[2] + q[5] * q[5] + q[8] * q[8];
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) bp[b] -= q[b] * q[9] + q[3 + b] * q[10] + q[6 + b] * q[11];
+                }
+            }
+            A.cost_pt[gp2] = cst;
+            double Vi[6] = {0, 0, 0, 0, 0, 0};
+            double vb[3] = {0, 0, 0};
+            if (pfree)
+            {
+                V[0] += lambda * clampd(V[0]);
+                V[3] += lambda * clampd(V[3]);
+                V[5] += lambda * clampd(V[5]);
+                const double a = V[0], b = V[1], cc = V[2], d = V[3], e = V[4], f = V[5];
+                const double Aa = d * f - e * e, Bb = cc * e - b * f, Cc = b * e - cc * d;
+                const double det = a * Aa + b * Bb + cc * Cc;
+                const double id  = det == 0.0 ? 0.0 : 1.0 / det;
+                Vi[0] = Aa * id;
+                Vi[1] = Bb * id;
+                Vi[2] = Cc * id;
+                Vi[3] = (a * f - cc * cc) * id;
+                Vi[4] = (b * cc - a * e) * id;
+                Vi[5] = (a * d - b * b) * id;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) A.Vinv[(size_t)gp2 * 6 + k] = Vi[k];
+                A.bp[(size_t)gp2 * 3 + 0] = bp[0];
+                A.bp[(size_t)gp2 * 3 + 1] = bp[1];
+                A.bp[(size_t)gp2 * 3 + 2] = bp[2];
+                vb[0] = Vi[0] * bp[0] + Vi[1] * bp[1] + Vi[2] * bp[2];
+                vb[1] = Vi[1] * bp[0] + Vi[3] * bp[1] + Vi[4] * bp[2];
+                vb[2] = Vi[2] * bp[0] + Vi[4] * bp[1] + Vi[5] * bp[2];
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s_vi[lane * 6 + k] = Vi[k];
+            {
+                const double* ptp = A.pt + (size_t)gp2 * 3;
+                const double px = ptp[0], py = ptp[1], pz = ptp[2];
+                double* pv        = A.ptv + (size_t)gp2 * 6;
+                pv[0] = px; pv[1] = py; pv[2] = pz;
+                pv[3] = vb[0]; pv[4] = vb[1]; pv[5] = vb[2];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (si.nfree == 0) continue;  // a work item without pairs: linearisation only (wave-uniform)
+
+        // ---- phase 3: W = Jc^T Jp of every observation into LDS (zero rows for inactive couplings) ----
+        const bool cpl = act && dim && c >= 0 && pfree_o;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+                s_st[lane * 18 + a * 3 + b] = cpl ? Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b] + Jc[12 + a] * Jp[6 + b] : 0.0;
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- phase 4: (W V^-1) W^T of every point of the group on the matrix cores ----
+        for (int g = 0; g < gc; ++g)
+        {
+            const double* base = s_st + g * run * 18;
+            const double* vv   = s_vi + g * 6;
+            const double vc0 = vv[kk == 0 ? 0 : (kk == 1 ? 1 : 2)], vc1 = vv[kk == 0 ? 1 : (kk == 1 ? 3 : 4)], vc2 = vv[kk == 0 ? 2 : (kk == 1 ? 4 : 5)];
+            double ya[T], wb[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+            {
+                const double* w = base + roff[t];
+                const double w0 = w[0], w1 = w[1], w2 = w[2];
+                ya[t] = rok[t] ? w0 * vc0 + w1 * vc1 + w2 * vc2 : 0.0;
+                wb[t] = rok[t] ? (kk == 0 ? w0 : (kk == 1 ? w1 : w2)) : 0.0;
+            }
+            int q = 0;
+#pragma unroll
+            for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+                for (int tj = ti; tj < T; ++tj, ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[ti], wb[tj], acc[q], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (si.nfree == 0) return;
+    const int* tab = A.set_pairs + si.aux_off + si.nfree;
+    double* part   = A.s_part + (size_t)si.part_off * 36;
+    int q = 0;
+#pragma unroll
+    for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+        for (int tj = ti; tj < T; ++tj, ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                const int m = 16 * ti + kk + 4 * j, n = 16 * tj + mr;
+                if (m >= nrows || n >= nrows) continue;
+                const int ia = (m * 43) >> 8, r = m - 6 * ia, ib = (n * 43) >> 8, c = n - 6 * ib;
+                if (ia > ib) continue;
+                const int slot = tab[ia * si.nfree + ib];
+                const double v = acc[q][j];
+                part[(size_t)slot * 36 + r * 6 + c] = v;
+                if (ia == ib && ti != tj) part[(size_t)slot * 36 + c * 6 + r] = v;
+            }
 }
 
 // S(c1, c2) = U(c1) [c1 == c2] - sum of the block's partial sums (fixed order) - relative-pose cross terms; lane = element.
@@ -1863,6 +2233,7 @@ struct snk_ba : HandleBase
     long long tot_s = 0;
     int max_np = 0, max_nfc = 0, max_n6 = 0, max_ni = 0, max_set_items = 0;
     bool set_ok = false, set_small = false;
+    int set_k_max = 0, set_run_max = 0;
     DevBuf d_setitems, d_setpts, d_setpairs, d_cblkstart, d_cblkitems, d_spart;
     DevBuf d_prob, d_state, d_pose, d_pose_new, d_pose0, d_pt, d_pt_new, d_pt0, d_ptc, d_camidx, d_ptstart, d_oimg, d_ocam,
         d_optfree, d_ouv, d_odepth, d_oweight, d_oorig, d_outlier, d_csobs, d_r, d_W, d_ptv, d_Vinv, d_bp, d_cost,
@@ -2014,7 +2385,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     std::vector<SetItem> setitems;
     std::vector<int2> setpts;
     std::vector<int> setpairs, cblkstart, cblkitems;
-    int n_partials = 0, max_set_items = 0, max_set_pairs = 0, max_set_run = 0;
+    int n_partials = 0, max_set_items = 0, max_set_pairs = 0, max_set_run = 0, max_set_k = 0;
     bool set_ok = true;  // every problem can run the point-major Schur pass
     std::vector<int> camidx, ptstart, oimg, ocam, oorig, camstart, camitems, blkstart, optidx, wvpt, rpcnext, camrpcstart,
         camrpcitems, blkrpc;
@@ -2208,10 +2579,32 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             std::vector<std::vector<int>> gpts;
             std::vector<std::vector<int>> gsig;
             bool ok = nfc > 0;
+            // points that produce no Schur products (constant points, points seen by constant cameras only) still need their
+            // linearisation (cost, V, b_p): they form groups of their own, keyed by their run length, with no pairs
+            auto plain_group = [&](int p, int run)
+            {
+                const std::vector<int> key = {-1000, run};
+                auto f = gid.find(key);
+                if (f == gid.end())
+                {
+                    gid.emplace(key, (int)gpts.size());
+                    gpts.emplace_back();
+                    gsig.push_back(std::vector<int>((size_t)run, -1));
+                    gpts.back().push_back(p);
+                }
+                else
+                    gpts[(size_t)f->second].push_back(p);
+            };
             for (int p = 0; p < P.n_pt && ok; ++p)
             {
-                if (P.pt_const[p]) continue;
                 const int a0 = pstart[(size_t)p], a1 = pstart[(size_t)p + 1];
+                if (a1 - a0 > SET_MAX_RUN) ok = false;
+                if (a1 == a0) continue;  // a point without observations: nothing to linearise (update_wave keeps it in place)
+                if (P.pt_const[p])
+                {
+                    plain_group(p, a1 - a0);
+                    continue;
+                }
                 std::vector<int> sig;
                 int k = 0;
                 for (int a = a0; a < a1; ++a)
@@ -2223,7 +2616,11 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                     for (int b = a0; b < a; ++b)
                         if (s_cam[(size_t)b] == c) ok = false;  // one camera twice on a point: block-major pass only
                 }
-                if (k == 0) continue;
+                if (k == 0)
+                {
+                    plain_group(p, a1 - a0);
+                    continue;
+                }
                 if (k > SET_MAX_K || a1 - a0 > SET_MAX_RUN) ok = false;
                 auto f = gid.find(sig);
                 if (f == gid.end())
@@ -2259,8 +2656,34 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                             blocks.push_back(sig[(size_t)ra] * nfc + sig[(size_t)rb]);
                         }
                     const int npairs = (int)blocks.size();
+                    // matrix-core form (schur_mfma): the point's free rows ordered by camera index, so that every pair
+                    // (ra, rb) -- camera(ra) < camera(rb) -- lies in the upper triangle of Y W^T, and the slot of each
+                    const int aux_off = (int)(setpairs.size() + ipairs.size());
+                    {
+                        std::vector<int> fpos;
+                        for (size_t i = 0; i < sig.size(); ++i)
+                            if (sig[i] >= 0) fpos.push_back((int)i);
+                        std::sort(fpos.begin(), fpos.end(), [&](int a, int b) { return sig[(size_t)a] < sig[(size_t)b]; });
+                        const int kf = (int)fpos.size();
+                        for (int v : fpos) ipairs.push_back(v);
+                        for (int i = 0; i < kf; ++i)
+                            for (int j = 0; j < kf; ++j)
+                            {
+                                int slot = -1;
+                                if (i <= j)
+                                    for (int q = 0; q < npairs; ++q)
+                                        if (ipairs[(size_t)(pair_off - (int)setpairs.size()) + (size_t)q] == (fpos[(size_t)i] | (fpos[(size_t)j] << 8))) slot = q;
+                                ipairs.push_back(slot);
+                            }
+                        max_set_k = std::max(max_set_k, kf);
+                    }
                     const size_t n_in_set = gpts[g].size(), n_cuts = (n_in_set + SET_CHUNK - 1) / SET_CHUNK;
-                    const size_t cut = (n_in_set + n_cuts - 1) / n_cuts;  // equal items: a launch ends with its longest item
+                    size_t cut = (n_in_set + n_cuts - 1) / n_cuts;  // equal items: a launch ends with its longest item
+                    {
+                        // schur_fused linearises 64 / run points at a time: whole groups of that many per item where possible
+                        const size_t grp = (size_t)(64 / std::max<size_t>(sig.size(), 1));
+                        cut = std::min<size_t>((cut + grp - 1) / grp * grp, 64);
+                    }
                     for (size_t q0 = 0; q0 < n_in_set; q0 += cut)
                     {
                         SetItem si;
@@ -2270,6 +2693,9 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                         si.npairs   = npairs;
                         si.part_off = parts;
                         si.run      = (int)sig.size();
+                        si.aux_off  = aux_off;
+                        si.nfree    = 0;
+                        for (int v : sig) si.nfree += v >= 0 ? 1 : 0;
                         for (int q = 0; q < si.n_pts; ++q)
                         {
                             const int pp = gpts[g][q0 + (size_t)q];
@@ -2428,6 +2854,8 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     h->set_ok = set_ok && max_set_items > 0;
     h->max_set_items = max_set_items;
     h->set_small     = max_set_pairs * 6 <= 4 * 64 && max_set_run * 9 + 3 <= 2 * 64;
+    h->set_k_max     = max_set_k;
+    h->set_run_max   = max_set_run;
     RS(d_Vinv, npt * 6 * 8);
     RS(d_bp, npt * 3 * 8);
     RS(d_cost, npt * 8);
@@ -2466,6 +2894,10 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     SNK_HIP_CHECK(hipMemsetAsync(h->d_state.p, 0, (size_t)count * sizeof(State), st));
     SNK_HIP_CHECK(hipMemsetAsync(h->d_r.p, 0, nobs * 4 * 8, st));
     SNK_HIP_CHECK(hipMemsetAsync(h->d_x.p, 0, (size_t)std::max(vec_off, 1) * 8, st));
+    // points without observations are in no work item of schur_fused: their cost, V^-1 and b_p are zero once and for all
+    SNK_HIP_CHECK(hipMemsetAsync(h->d_cost.p, 0, npt * 8, st));
+    SNK_HIP_CHECK(hipMemsetAsync(h->d_Vinv.p, 0, npt * 6 * 8, st));
+    SNK_HIP_CHECK(hipMemsetAsync(h->d_bp.p, 0, npt * 3 * 8, st));
     if (!h->pcg_large)
     {
         // process-wide, once, to the most the kernels can use (enqueue_lm keeps S in LDS only when it fits 158 KB)
@@ -2570,7 +3002,23 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L)
     for (int it = 0; it < iterations; ++it)
     {
         static const bool no_wave = getenv("SNK_BA_NO_POINT_WAVE") != nullptr;
-        if (h->point_wave_ok && !no_wave)
+        static const bool no_set = getenv("SNK_BA_NO_SCHUR_SET") != nullptr;  // A/B measurements
+        // a single small window has too few work items to fill the chip: the block-major pass is quicker there
+        static const long long set_min = getenv("SNK_BA_SCHUR_SET_MIN_ITEMS") ? atoll(getenv("SNK_BA_SCHUR_SET_MIN_ITEMS")) : 256;  // tests: 1
+        static const bool no_mfma  = getenv("SNK_BA_NO_SCHUR_MFMA") != nullptr;   // A/B: the vector-ALU form (schur_set)
+        static const bool no_fused = getenv("SNK_BA_NO_SCHUR_FUSED") != nullptr;  // A/B: point_wave + schur_mfma through W in HBM
+        const bool use_set = h->max_nfc > 0 && h->point_wave_ok && !no_wave && h->set_ok && !no_set && (long long)h->max_set_items * B >= set_min;
+        const bool fused   = use_set && !no_mfma && !no_fused;
+        const int nsx      = ceil_div(std::max(h->max_set_items, 1), 4);
+        if (fused)
+        {
+            // linearisation + Schur products in one kernel (W stays in LDS); it writes what point_wave writes per point
+            if (h->set_k_max <= 8)
+                LAUNCH((schur_fused<3>), dim3(nsx * 8 * ceil_div(B, 8)), dim3(256), 0, A, O, nsx, B);
+            else
+                LAUNCH((schur_fused<4>), dim3(nsx * 8 * ceil_div(B, 8)), dim3(256), 0, A, O, nsx, B);
+        }
+        else if (h->point_wave_ok && !no_wave)
             LAUNCH(point_wave, dim3(h->max_wv, B), dim3(64), 0, A, O);
         else
             LAUNCH(point_pass<0>, gpt, dim3(128), 0, A, O);
@@ -2580,13 +3028,19 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L)
             LAUNCH(cam_pass, dim3(h->max_nfc, B), dim3(CAM_THREADS), 0, A, O);
             {
                 const int nbx = ceil_div(h->max_nfc * h->max_nfc, 4);
-                static const bool no_set = getenv("SNK_BA_NO_SCHUR_SET") != nullptr;  // A/B measurements
-                // a single small window has too few work items to fill the chip: the block-major pass is quicker there
-                static const long long set_min = getenv("SNK_BA_SCHUR_SET_MIN_ITEMS") ? atoll(getenv("SNK_BA_SCHUR_SET_MIN_ITEMS")) : 256;  // tests: 1
-                if (h->point_wave_ok && !no_wave && h->set_ok && !no_set && (long long)h->max_set_items * B >= set_min)
+                if (use_set)
                 {
-                    const int nsx = ceil_div(h->max_set_items, 4);
-                    if (h->set_small)
+                    const bool q2 = h->set_run_max * 9 + 3 <= 2 * 64;
+                    if (fused)
+                        ;  // the partial sums are there already
+                    else if (!no_mfma && h->set_k_max <= 8)
+                    {
+                        if (q2) LAUNCH((schur_mfma<3, 2>), dim3(nsx * 8 * ceil_div(B, 8)), dim3(256), 0, A, nsx, B);
+                        else LAUNCH((schur_mfma<3, 3>), dim3(nsx * 8 * ceil_div(B, 8)), dim3(256), 0, A, nsx, B);
+                    }
+                    else if (!no_mfma)
+                        LAUNCH((schur_mfma<4, 3>), dim3(nsx * 8 * ceil_div(B, 8)), dim3(256), 0, A, nsx, B);
+                    else if (h->set_small)
                         LAUNCH((schur_set<4, 2>), dim3(nsx * 8 * ceil_div(B, 8)), dim3(256), 0, A, nsx, B);
                     else
                         LAUNCH((schur_set<6, 3>), dim3(nsx * 8 * ceil_div(B, 8)), dim3(256), 0, A, nsx, B);

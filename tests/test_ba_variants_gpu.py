@@ -13,11 +13,13 @@ ROOT = Path(__file__).resolve().parent.parent
 
 
 @pytest.mark.parametrize("env", [
-    {"SNK_BA_SCHUR_SET_MIN_ITEMS": "1"},  # point-major Schur pass (schur_set + schur_sum) for every scene, however small
+    {"SNK_BA_SCHUR_SET_MIN_ITEMS": "1"},  # schur_fused (linearisation + matrix-core Schur products) + schur_sum for every scene, however small
     {"SNK_BA_NO_SCHUR_SET": "1"},         # block-major schur_pass everywhere
     {"SNK_BA_NO_POINT_WAVE": "1"},        # thread-per-point linearisation + schur_pass with activity lookups
     {"SNK_BA_SCHUR_SET_MIN_ITEMS": "1", "SNK_BA_NO_GRAPH": "1"},
-    {"SNK_BA_GRAPH_FIRST": "1"},          # explicitly built hipGraph already for the first solve of every scene
+    {"SNK_BA_GRAPH_FIRST": "1"},
+    {"SNK_BA_SCHUR_SET_MIN_ITEMS": "1", "SNK_BA_NO_SCHUR_FUSED": "1"},  # point_wave + schur_mfma (W through HBM)
+    {"SNK_BA_SCHUR_SET_MIN_ITEMS": "1", "SNK_BA_NO_SCHUR_MFMA": "1"},   # point_wave + the vector-ALU schur_set          # explicitly built hipGraph already for the first solve of every scene
 ])
 def test_ba_parity_suite_with_forced_path(env):
     r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_ba_gpu.py"), "-m", "gpu", "-x", "-q", "-p",
