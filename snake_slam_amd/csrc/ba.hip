@@ -110,6 +110,16 @@ struct SetItem
     int run;               // observations per point of this set
     int nfree;             // free-camera observations per point (k)
     int aux_off;           // into set_pairs: k run positions ordered by camera index, then the k x k table "pair slot of (i, j)", i <= j
+    int rec_off;           // into set_obs: n_pts x run static observation records in (point of the item, observation) order
+    int pad;
+};
+
+// Static part of an observation in the order schur_fused walks it (item, point of the item, observation of the point): a lane's
+// record is at rec_off + group * run + lane, so the first round of loads of a group is three coalesced 16-byte loads.
+struct SetObs
+{
+    double u, v, depth, weight;
+    int img, orig, cam, ptfree;  // image inside the problem, caller-order index (global), free-camera index or -1, point is an unknown
 };
 
 struct Arrays
@@ -157,6 +167,7 @@ struct Arrays
     const SetItem* set_items;
     const int2* set_pts;  // (point, first observation of the point) inside the problem
     const int* set_pairs;
+    const SetObs* set_obs;
     const int* cblk_start;  // per problem, per block: its partial sums in cblk_items (fixed order)
     const int* cblk_items;  // index into s_part
     double* s_part;         // [partial][36]
@@ -1250,12 +1261,25 @@ __global__ __launch_bounds__(256) void schur_mfma(Arrays A, int nbx, int B)
 // them on the matrix cores right there.  It also writes what point_wave writes per POINT (cost, V^-1, b_p, position | V^-1 b_p),
 // so point_wave is not launched at all; points without Schur products (constant points, points of constant cameras only)
 // come as work items without pairs.  Observation inputs are read once (48 bytes + cached point / pose gathers).
+constexpr int SF_GMAX = 16;  // points linearised at a time (64 / run, at most this many: bounds the per-point LDS arrays)
+constexpr int SF_NC   = 10;  // per-observation contributions summed per point: V (6), b_p (3), cost
+struct SfObs  // first round of loads of a lane: its static observation record and its point (both known without a lookup)
+{
+    SetObs rec;
+    double pt[3];
+    bool act;
+};
+struct SfGather  // second round: through the record's indices
+{
+    double pose[7];
+    bool is_out;
+};
 template <int T>
 __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int B)
 {
-    // per wavefront: 64 x 18 doubles (phase 1/2 scratch of 14 per lane, then the W rows) | V^-1 of the group's points
-    // (up to 64 points per group when a point has one observation)
-    __shared__ __attribute__((aligned(16))) double s_buf[4][64 * 18 + 64 * 6];
+    // per wavefront: the W rows of the group (64 x 18 doubles) | the observations' contributions (64 x 10) | the sums of
+    // the group's points | their V^-1.  16.4 KB: two workgroups per CU, which is also what the registers allow.
+    __shared__ __attribute__((aligned(16))) double s_buf[4][64 * 18 + 64 * SF_NC + SF_GMAX * (SF_NC + 6)];
     int pb, bx;
     if (B >= 16)  // batched windows: one XCD per window
     {
@@ -1275,10 +1299,12 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
     if (it >= pr.n_set) return;  // whole wavefront
     const SetItem si = A.set_items[pr.set_off + it];
     const int2 my_pt = lane < si.n_pts ? A.set_pts[si.pts_off + lane] : make_int2(0, 0);
-    double* s_st   = s_buf[wave];
-    double* s_vi   = s_buf[wave] + 64 * 18;
-    const int run  = si.run, G = 64 / run;  // run <= SET_MAX_RUN = 14: at least 4 points per group
-    const int lg   = lane / run, la = lane - lg * run;  // point of the group / observation of the point
+    double* s_w    = s_buf[wave];
+    double* s_con  = s_w + 64 * 18;
+    double* s_sum  = s_con + 64 * SF_NC;
+    double* s_vi   = s_sum + SF_GMAX * SF_NC;
+    const int run  = si.run, G = min(64 / run, SF_GMAX);  // run <= SET_MAX_RUN = 14: at least 4 points per group
+    const int lg   = lane / run, la = lane - lg * run;     // point of the group / observation of the point
     const double* poses = A.pose + (size_t)pr.img_off * 7;
     const double lambda = A.state[pb].lambda;
 
@@ -1298,93 +1324,116 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
 #pragma unroll
     for (int q = 0; q < T * (T + 1) / 2; ++q) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
 
-    for (int n0 = 0; n0 < si.n_pts; n0 += G)
+    // The two dependent rounds of loads of a group are issued one group ahead: round 1 (indexed by the observation) at the
+    // top of the previous group's work, round 2 (point, pose, flags: through round 1's indices) in front of its matrix
+    // products -- only two wavefronts fit a SIMD here, so the latency has to be hidden inside the wavefront.
+    const char* rec_base = reinterpret_cast<const char*>(A.set_obs + si.rec_off);
+    const unsigned n_rec = (unsigned)(si.n_pts * run);
+    auto load1 = [&](int n0, SfObs& o)
     {
-        const int gc = min(G, si.n_pts - n0);  // points of this group
-        // ---- phase 1: lane = observation ----
-        const bool act = lg < gc;
-        const int2 mp  = make_int2(__shfl(my_pt.x, n0 + (act ? lg : 0)), __shfl(my_pt.y, n0 + (act ? lg : 0)));
-        const size_t go = (size_t)pr.obs_off + mp.y + la;
-        const int gp    = pr.pt_off + mp.x;
-        double r[3] = {0, 0, 0}, Jc[18], Jp[9];
+        const int gc = min(G, si.n_pts - n0);
+        o.act        = lg < gc;
+        // 32-bit offsets from uniform bases: one address instruction per load
+        const unsigned ri = min((unsigned)(n0 * run + lane), n_rec - 1u);
+        const uint4* rp   = reinterpret_cast<const uint4*>(rec_base + ri * 48u);
+        const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+        const int px   = __shfl(my_pt.x, min(n0 + (o.act ? lg : 0), 63));
+        const double* ptp = reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.pt) + (unsigned)(pr.pt_off + px) * 24u);
+        o.pt[0] = ptp[0]; o.pt[1] = ptp[1]; o.pt[2] = ptp[2];
+        o.rec.u      = __hiloint2double((int)r0.y, (int)r0.x);
+        o.rec.v      = __hiloint2double((int)r0.w, (int)r0.z);
+        o.rec.depth  = __hiloint2double((int)r1.y, (int)r1.x);
+        o.rec.weight = __hiloint2double((int)r1.w, (int)r1.z);
+        o.rec.img = (int)r2.x; o.rec.orig = (int)r2.y; o.rec.cam = (int)r2.z; o.rec.ptfree = (int)r2.w;
+    };
+    auto load2 = [&](const SfObs& o, SfGather& g)
+    {
+        const double* posep = reinterpret_cast<const double*>(reinterpret_cast<const char*>(poses) + (unsigned)o.rec.img * 56u);
 #pragma unroll
-        for (int k = 0; k < 18; ++k) Jc[k] = 0.0;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Jp[k] = 0.0;
-        int dim = 0, c = -1;
-        double cost = 0.0;
-        bool pfree_o = false;
-        if (act)
+        for (int k = 0; k < 7; ++k) g.pose[k] = posep[k];
+        g.is_out = A.outlier[(unsigned)o.rec.orig] != 0;
+    };
+    // one group: `ob` / `gt` are its inputs (already loaded), `obn` / `gtn` receive the next group's
+    auto process = [&](int n0, const SfObs& ob, const SfGather& gt, SfObs& obn, SfGather& gtn)
+    {
+        const int gc    = min(G, si.n_pts - n0);  // points of this group (wave-uniform)
+        const bool more = n0 + G < si.n_pts;      // wave-uniform
+        if (more) load1(n0 + G, obn);
+        // ---- phase 1: lane = observation: residual, Jacobians, its terms of V / b_p / cost, its row W = Jc^T Jp ----
         {
-            const int oimg = A.o_img[go], oorig = A.o_orig[go];
-            c = A.o_cam[go];
-            const double2 uv = A.o_uv[go];
-            const double odepth = A.o_depth[go], oweight = A.o_weight[go];
-            const double* ptp  = A.pt + (size_t)gp * 3;
-            const double pt[3] = {ptp[0], ptp[1], ptp[2]};
-            const double* posep = poses + (size_t)oimg * 7;
-            double pose[7];
+            double con[SF_NC];
 #pragma unroll
-            for (int k = 0; k < 7; ++k) pose[k] = posep[k];
-            const bool is_out = A.outlier[oorig] != 0;
-            pfree_o           = !A.pt_const[gp];
-            if (!is_out)
+            for (int k = 0; k < SF_NC; ++k) con[k] = 0.0;
+            bool cpl = false;  // the observation couples a free camera with a free point: it has a row of W
+            double Jc[18], Jp[9];
+#pragma unroll
+            for (int k = 0; k < 18; ++k) Jc[k] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Jp[k] = 0.0;
+            if (ob.act && !gt.is_out)
             {
-                double R[9];
-                quat_to_R(pose, R);
-                dim = obs_linearize<true>(pose, R, pt, pr.K, pr.bf, uv.x, uv.y, odepth, oweight, r, Jc, Jp);
+                double R[9], r[3];
+                quat_to_R(gt.pose, R);
+                const int dim = obs_linearize<true>(gt.pose, R, ob.pt, pr.K, pr.bf, ob.rec.u, ob.rec.v, ob.rec.depth, ob.rec.weight, r, Jc, Jp);
                 if (dim)
                 {
                     const double sq = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
                     double sw;
-                    cost = huber_rho(sq, dim == 3 ? O.huber_stereo : O.huber_mono, sw);
+                    con[9] = huber_rho(sq, dim == 3 ? O.huber_stereo : O.huber_mono, sw);
 #pragma unroll
                     for (int k = 0; k < 3; ++k) r[k] *= sw;
 #pragma unroll
                     for (int k = 0; k < 18; ++k) Jc[k] *= sw;
 #pragma unroll
                     for (int k = 0; k < 9; ++k) Jp[k] *= sw;
-                }
-                else
-                {
-                    r[0] = r[1] = r[2] = 0.0;
+                    if (ob.rec.ptfree)
+                    {
+                        con[0] = Jp[0] * Jp[0] + Jp[3] * Jp[3] + Jp[6] * Jp[6];
+                        con[1] = Jp[0] * Jp[1] + Jp[3] * Jp[4] + Jp[6] * Jp[7];
+                        con[2] = Jp[0] * Jp[2] + Jp[3] * Jp[5] + Jp[6] * Jp[8];
+                        con[3] = Jp[1] * Jp[1] + Jp[4] * Jp[4] + Jp[7] * Jp[7];
+                        con[4] = Jp[1] * Jp[2] + Jp[4] * Jp[5] + Jp[7] * Jp[8];
+                        con[5] = Jp[2] * Jp[2] + Jp[5] * Jp[5] + Jp[8] * Jp[8];
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) con[6 + b] = -(Jp[b] * r[0] + Jp[3 + b] * r[1] + Jp[6 + b] * r[2]);
+                        cpl = ob.rec.cam >= 0;
+                    }
                 }
             }
+#pragma unroll
+            for (int k = 0; k < SF_NC; ++k) s_con[lane * SF_NC + k] = con[k];
+            if (si.nfree != 0)
+            {
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b)
+                        s_w[lane * 18 + a * 3 + b] = cpl ? Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b] + Jc[12 + a] * Jp[6 + b] : 0.0;
+            }
         }
-#pragma unroll
-        for (int k = 0; k < 9; ++k) s_st[lane * PW_JP + k] = Jp[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) s_st[lane * PW_JP + 9 + k] = r[k];
-        s_st[lane * PW_JP + 12] = cost;
-        s_st[lane * PW_JP + 13] = (double)dim;
         __builtin_amdgcn_wave_barrier();
 
-        // ---- phase 2: lane = point of the group (sums in observation order, as point_wave) ----
+        // ---- phase 2a: lane = (point of the group, term): the point's sums in observation order ----
+        for (int idx = lane; idx < gc * SF_NC; idx += 64)
+        {
+            const int g = (idx * 205) >> 11, comp = idx - g * SF_NC;  // idx / 10 (idx < 160)
+            const double* q = s_con + g * run * SF_NC + comp;
+            double sum = 0.0;
+            for (int a = 0; a < run; ++a) sum += q[a * SF_NC];
+            s_sum[idx] = sum;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (more) load2(obn, gtn);
+        // ---- phase 2b: lane = point of the group: damping, V^-1, the per-point outputs of point_wave ----
         const int p2 = __shfl(my_pt.x, min(n0 + lane, 63));  // outside the branch: a shuffle reads 0 from inactive lanes
         if (lane < gc)
         {
             const int gp2 = pr.pt_off + p2;
             const bool pfree = !A.pt_const[gp2];
-            double V[6] = {0, 0, 0, 0, 0, 0}, bp[3] = {0, 0, 0};
-            double cst = 0.0;
-            for (int a = 0; a < run; ++a)
-            {
-                const double* q = s_st + (lane * run + a) * PW_JP;
-                if (q[13] == 0.0) continue;
-                cst += q[12];
-                if (pfree)
-                {
-                    V[0] += q[0] * q[0] + q[3] * q[3] + q[6] * q[6];
-                    V[1] += q[0] * q[1] + q[3] * q[4] + q[6] * q[7];
-                    V[2] += q[0] * q[2] + q[3] * q[5] + q[6] * q[8];
-                    V[3] += q[1] * q[1] + q[4] * q[4] + q[7] * q[7];
-                    V[4] += q[1] * q[2] + q[4] * q[5] + q[7] * q[8];
-                    V[5] += q[2] * q[2] + q[5] * q[5] + q[8] * q[8];
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) bp[b] -= q[b] * q[9] + q[3 + b] * q[10] + q[6 + b] * q[11];
-                }
-            }
-            A.cost_pt[gp2] = cst;
+            const double* sm = s_sum + lane * SF_NC;
+            double V[6] = {sm[0], sm[1], sm[2], sm[3], sm[4], sm[5]};
+            const double bp[3] = {sm[6], sm[7], sm[8]};
+            A.cost_pt[gp2] = sm[9];
             double Vi[6] = {0, 0, 0, 0, 0, 0};
             double vb[3] = {0, 0, 0};
             if (pfree)
@@ -1422,39 +1471,40 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (si.nfree == 0) continue;  // a work item without pairs: linearisation only (wave-uniform)
 
-        // ---- phase 3: W = Jc^T Jp of every observation into LDS (zero rows for inactive couplings) ----
-        const bool cpl = act && dim && c >= 0 && pfree_o;
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b)
-                s_st[lane * 18 + a * 3 + b] = cpl ? Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b] + Jc[12 + a] * Jp[6 + b] : 0.0;
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- phase 4: (W V^-1) W^T of every point of the group on the matrix cores ----
-        for (int g = 0; g < gc; ++g)
-        {
-            const double* base = s_st + g * run * 18;
-            const double* vv   = s_vi + g * 6;
-            const double vc0 = vv[kk == 0 ? 0 : (kk == 1 ? 1 : 2)], vc1 = vv[kk == 0 ? 1 : (kk == 1 ? 3 : 4)], vc2 = vv[kk == 0 ? 2 : (kk == 1 ? 4 : 5)];
-            double ya[T], wb[T];
-#pragma unroll
-            for (int t = 0; t < T; ++t)
+        // ---- phase 3: (W V^-1) W^T of every point of the group on the matrix cores ----
+        if (si.nfree != 0)  // wave-uniform; a work item without pairs is linearisation only
+            for (int g = 0; g < gc; ++g)
             {
-                const double* w = base + roff[t];
-                const double w0 = w[0], w1 = w[1], w2 = w[2];
-                ya[t] = rok[t] ? w0 * vc0 + w1 * vc1 + w2 * vc2 : 0.0;
-                wb[t] = rok[t] ? (kk == 0 ? w0 : (kk == 1 ? w1 : w2)) : 0.0;
+                const double* base = s_w + g * run * 18;
+                const double* vv   = s_vi + g * 6;
+                const double vc0 = vv[kk == 0 ? 0 : (kk == 1 ? 1 : 2)], vc1 = vv[kk == 0 ? 1 : (kk == 1 ? 3 : 4)], vc2 = vv[kk == 0 ? 2 : (kk == 1 ? 4 : 5)];
+                double ya[T], wb[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                {
+                    const double* w = base + roff[t];
+                    const double w0 = w[0], w1 = w[1], w2 = w[2];
+                    ya[t] = rok[t] ? w0 * vc0 + w1 * vc1 + w2 * vc2 : 0.0;
+                    wb[t] = rok[t] ? (kk == 0 ? w0 : (kk == 1 ? w1 : w2)) : 0.0;
+                }
+                int q = 0;
+#pragma unroll
+                for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+                    for (int tj = ti; tj < T; ++tj, ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[ti], wb[tj], acc[q], 0, 0, 0);
             }
-            int q = 0;
-#pragma unroll
-            for (int ti = 0; ti < T; ++ti)
-#pragma unroll
-                for (int tj = ti; tj < T; ++tj, ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[ti], wb[tj], acc[q], 0, 0, 0);
-        }
         __builtin_amdgcn_wave_barrier();
+    };
+    // two register sets, used alternately: no copies between the groups
+    SfObs oa, obb;
+    SfGather ga, gb;
+    load1(0, oa);
+    load2(oa, ga);
+    for (int n0 = 0; n0 < si.n_pts; n0 += 2 * G)
+    {
+        process(n0, oa, ga, obb, gb);
+        if (n0 + G < si.n_pts) process(n0 + G, obb, gb, oa, ga);
     }
     if (si.nfree == 0) return;
     const int* tab = A.set_pairs + si.aux_off + si.nfree;
@@ -2234,7 +2284,7 @@ struct snk_ba : HandleBase
     int max_np = 0, max_nfc = 0, max_n6 = 0, max_ni = 0, max_set_items = 0;
     bool set_ok = false, set_small = false;
     int set_k_max = 0, set_run_max = 0;
-    DevBuf d_setitems, d_setpts, d_setpairs, d_cblkstart, d_cblkitems, d_spart;
+    DevBuf d_setitems, d_setpts, d_setpairs, d_setobs, d_cblkstart, d_cblkitems, d_spart;
     DevBuf d_prob, d_state, d_pose, d_pose_new, d_pose0, d_pt, d_pt_new, d_pt0, d_ptc, d_camidx, d_ptstart, d_oimg, d_ocam,
         d_optfree, d_ouv, d_odepth, d_oweight, d_oorig, d_outlier, d_csobs, d_r, d_W, d_ptv, d_Vinv, d_bp, d_cost,
         d_cost_new, d_U, d_camstart, d_camitems, d_blkstart, d_blkent, d_S, d_rhs, d_x, d_chi2, d_pcgw, d_optidx, d_wvpt, d_rpcmeta, d_rpcnext, d_camrpcstart, d_camrpcitems, d_blkrpc, d_rpcout;
@@ -2348,7 +2398,7 @@ int snk_ba_destroy(snk_ba* h)
     if (!h) return SNK_OK;
     (void)hipSetDevice(h->device);
     // every device buffer of the handle (the struct's DevBuf members)
-    DevBuf* all[] = {&h->d_setitems, &h->d_setpts, &h->d_setpairs, &h->d_cblkstart, &h->d_cblkitems, &h->d_spart,
+    DevBuf* all[] = {&h->d_setitems, &h->d_setpts, &h->d_setpairs, &h->d_setobs, &h->d_cblkstart, &h->d_cblkitems, &h->d_spart,
                      &h->d_prob, &h->d_state, &h->d_pose, &h->d_pose_new, &h->d_pose0, &h->d_pt, &h->d_pt_new,
                      &h->d_pt0, &h->d_ptc, &h->d_camidx, &h->d_ptstart, &h->d_oimg, &h->d_ocam, &h->d_optfree,
                      &h->d_ouv, &h->d_odepth, &h->d_oweight, &h->d_oorig, &h->d_outlier, &h->d_csobs, &h->d_r,
@@ -2383,6 +2433,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     std::vector<unsigned char> ptc, optfree;
     std::vector<CamObs> csobs;
     std::vector<SetItem> setitems;
+    std::vector<SetObs> setobs;
     std::vector<int2> setpts;
     std::vector<int> setpairs, cblkstart, cblkitems;
     int n_partials = 0, max_set_items = 0, max_set_pairs = 0, max_set_run = 0, max_set_k = 0;
@@ -2681,7 +2732,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                     size_t cut = (n_in_set + n_cuts - 1) / n_cuts;  // equal items: a launch ends with its longest item
                     {
                         // schur_fused linearises 64 / run points at a time: whole groups of that many per item where possible
-                        const size_t grp = (size_t)(64 / std::max<size_t>(sig.size(), 1));
+                        const size_t grp = std::min<size_t>(64 / std::max<size_t>(sig.size(), 1), 16);  // SF_GMAX
                         cut = std::min<size_t>((cut + grp - 1) / grp * grp, 64);
                     }
                     for (size_t q0 = 0; q0 < n_in_set; q0 += cut)
@@ -2695,11 +2746,23 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                         si.run      = (int)sig.size();
                         si.aux_off  = aux_off;
                         si.nfree    = 0;
+                        si.pad      = 0;
+                        si.rec_off  = (int)setobs.size();
                         for (int v : sig) si.nfree += v >= 0 ? 1 : 0;
                         for (int q = 0; q < si.n_pts; ++q)
                         {
                             const int pp = gpts[g][q0 + (size_t)q];
                             ipts.push_back(make_int2(pp, pstart[(size_t)pp]));
+                            for (int a = 0; a < si.run; ++a)
+                            {
+                                const int sidx = pstart[(size_t)pp] + a, o = order[(size_t)sidx];
+                                SetObs rec;
+                                rec.u = P.obs_uv[o][0]; rec.v = P.obs_uv[o][1];
+                                rec.depth = P.obs_depth[o]; rec.weight = P.obs_weight[o];
+                                rec.img = P.obs_img[o]; rec.orig = orig_off + o;
+                                rec.cam = s_cam[(size_t)sidx]; rec.ptfree = P.pt_const[pp] ? 0 : 1;
+                                setobs.push_back(rec);
+                            }
                         }
                         for (int q = 0; q < npairs; ++q) contrib[(size_t)blocks[(size_t)q]].push_back(parts + q);
                         parts += npairs;
@@ -2826,6 +2889,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     UP(d_camitems, camitems);
     UP(d_csobs, csobs);
     UP(d_setitems, setitems);
+    UP(d_setobs, setobs);
     UP(d_setpts, setpts);
     UP(d_setpairs, setpairs);
     UP(d_cblkstart, cblkstart);
@@ -2936,6 +3000,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     A.ptv       = h->d_ptv.as<double>();
     A.cs_obs    = h->d_csobs.as<CamObs>();
     A.set_items = h->d_setitems.as<SetItem>();
+    A.set_obs   = h->d_setobs.as<SetObs>();
     A.set_pts   = h->d_setpts.as<int2>();
     A.set_pairs = h->d_setpairs.as<int>();
     A.cblk_start = h->d_cblkstart.as<int>();
