@@ -3073,7 +3073,11 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L)
         static const bool no_mfma  = getenv("SNK_BA_NO_SCHUR_MFMA") != nullptr;   // A/B: the vector-ALU form (schur_set)
         static const bool no_fused = getenv("SNK_BA_NO_SCHUR_FUSED") != nullptr;  // A/B: point_wave + schur_mfma through W in HBM
         const bool use_set = h->max_nfc > 0 && h->point_wave_ok && !no_wave && h->set_ok && !no_set && (long long)h->max_set_items * B >= set_min;
-        const bool fused   = use_set && !no_mfma && !no_fused;
+        // points with 9 or 10 free observations need a fourth tile row: 260 registers, one wavefront per SIMD -- there the
+        // linearisation stays in point_wave and schur_mfma<4> reads W (measured on the 300-keyframe global BA: 14.7 vs 15.5 ms);
+        // SNK_BA_FUSED_K10=1 forces the fused form (tests)
+        static const bool fused_k10 = getenv("SNK_BA_FUSED_K10") != nullptr;
+        const bool fused   = use_set && !no_mfma && !no_fused && (h->set_k_max <= 8 || fused_k10);
         const int nsx      = ceil_div(std::max(h->max_set_items, 1), 4);
         if (fused)
         {
