@@ -1528,6 +1528,182 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
             }
 }
 
+// ---- back-substitution of the points + robust cost at the trial state, one kernel over the work items of schur_fused ----
+// update_wave and cost_wave are short-lived wavefronts behind a chain of five dependent loads (work item -> point range ->
+// observation indices -> point / pose gathers -> per-point data): 81 % of their wavefront cycles wait (PMC r02f).  Here a
+// wavefront walks a whole set item (<= 64 points) group by group with the next group's records in flight, reads the static
+// observation records in the order it walks them (coalesced), and the trial cost is evaluated right after the group's new
+// points exist (in LDS) -- the observation, point and pose loads are shared by the two passes.  Needs pose_new:
+// update_pass(images) runs BEFORE this kernel.  Same arithmetic and summation order as update_wave / cost_wave.
+__global__ __launch_bounds__(256) void update_cost(Arrays A, Opt O, int nbx, int B)
+{
+    // per wavefront: t = J_p^T (J_c dc) per observation (64 x 3) | cost per observation (64) | b_p - sum t per point (16 x 3) | new points (16 x 3)
+    __shared__ double s_buf[4][64 * 3 + 64 + SF_GMAX * 6];
+    int pb, bx;
+    if (B >= 16)  // batched windows: one XCD per window
+    {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        pb = (slot / nbx) * 8 + xcd;
+        bx = slot - (slot / nbx) * nbx;
+    }
+    else
+    {
+        pb = blockIdx.x / nbx;
+        bx = blockIdx.x - pb * nbx;
+    }
+    if (pb >= B) return;
+    const Prob pr  = A.prob[pb];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int it   = bx * 4 + wave;
+    if (it >= pr.n_set) return;  // whole wavefront
+    const SetItem si = A.set_items[pr.set_off + it];
+    const int2 my_pt = lane < si.n_pts ? A.set_pts[si.pts_off + lane] : make_int2(0, 0);
+    double* s_t  = s_buf[wave];
+    double* s_c  = s_t + 64 * 3;
+    double* s_g  = s_c + 64;
+    double* s_pn = s_g + SF_GMAX * 3;
+    const int run = si.run, G = min(64 / run, SF_GMAX);
+    const int lg  = lane / run, la = lane - lg * run;
+    const char* rec_base = reinterpret_cast<const char*>(A.set_obs + si.rec_off);
+    const unsigned n_rec = (unsigned)(si.n_pts * run);
+    const double* x = A.x + pr.vec_off;
+
+    auto load1 = [&](int n0, SfObs& o)
+    {
+        const int gc = min(G, si.n_pts - n0);
+        o.act        = lg < gc;
+        const unsigned ri = min((unsigned)(n0 * run + lane), n_rec - 1u);
+        const uint4* rp   = reinterpret_cast<const uint4*>(rec_base + ri * 48u);
+        const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+        const int px   = __shfl(my_pt.x, min(n0 + (o.act ? lg : 0), 63));
+        const double* ptp = reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.pt) + (unsigned)(pr.pt_off + px) * 24u);
+        o.pt[0] = ptp[0]; o.pt[1] = ptp[1]; o.pt[2] = ptp[2];
+        o.rec.u      = __hiloint2double((int)r0.y, (int)r0.x);
+        o.rec.v      = __hiloint2double((int)r0.w, (int)r0.z);
+        o.rec.depth  = __hiloint2double((int)r1.y, (int)r1.x);
+        o.rec.weight = __hiloint2double((int)r1.w, (int)r1.z);
+        o.rec.img = (int)r2.x; o.rec.orig = (int)r2.y; o.rec.cam = (int)r2.z; o.rec.ptfree = (int)r2.w;
+    };
+    SfObs ob;
+    load1(0, ob);
+    for (int n0 = 0; n0 < si.n_pts; n0 += G)
+    {
+        const int gc    = min(G, si.n_pts - n0);
+        const bool more = n0 + G < si.n_pts;
+        // second round for this group (pose at the linearisation point and at the trial state, dc of the camera, outlier flag);
+        // first round for the next one
+        double pose[7], posen[7], xv[6];
+        {
+            const double* posep = reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.pose) + (unsigned)(pr.img_off + ob.rec.img) * 56u);
+            const double* posnp = reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.pose_new) + (unsigned)(pr.img_off + ob.rec.img) * 56u);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) pose[k] = posep[k];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) posen[k] = posnp[k];
+            const double* xc = x + (ob.rec.cam < 0 ? 0 : ob.rec.cam) * 6;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) xv[a] = xc[a];
+        }
+        const bool is_out = A.outlier[(unsigned)ob.rec.orig] != 0;
+        // per point of the group: b_p by lanes (point, component), V^-1 / position / constancy by lane = point
+        const int p2  = __shfl(my_pt.x, min(n0 + lane, 63));
+        const int gp2 = pr.pt_off + p2;
+        double bpv = 0.0;
+        {
+            const int g = (lane * 171) >> 9, b = lane - 3 * g;  // lane / 3
+            const int pg = __shfl(my_pt.x, min(n0 + g, 63));    // outside the branch: a shuffle reads 0 from inactive lanes
+            if (lane < gc * 3) bpv = A.bp[(size_t)(pr.pt_off + pg) * 3 + b];
+        }
+        double Vi[6] = {0, 0, 0, 0, 0, 0}, cur[3] = {0, 0, 0};
+        bool pconst = true;
+        if (lane < gc)
+        {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) Vi[k] = A.Vinv[(size_t)gp2 * 6 + k];
+            cur[0] = A.pt[(size_t)gp2 * 3]; cur[1] = A.pt[(size_t)gp2 * 3 + 1]; cur[2] = A.pt[(size_t)gp2 * 3 + 2];
+            pconst = A.pt_const[gp2] != 0;
+        }
+        SfObs obn = ob;
+        if (more) load1(n0 + G, obn);
+
+        // ---- lane = observation: t = J_p^T (J_c dc) (update_wave) ----
+        double t[3] = {0, 0, 0};
+        if (ob.act && !(is_out || ob.rec.cam < 0 || !ob.rec.ptfree))
+        {
+            double R[9], r[3], Jc[18], Jp[9];
+            quat_to_R(pose, R);
+            const int dim = obs_linearize<true>(pose, R, ob.pt, pr.K, pr.bf, ob.rec.u, ob.rec.v, ob.rec.depth, ob.rec.weight, r, Jc, Jp);
+            if (dim)
+            {
+                const double sq = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+                double sw;
+                (void)huber_rho(sq, dim == 3 ? O.huber_stereo : O.huber_mono, sw);
+                const double s2 = sw * sw;  // J_c and J_p each carry the IRLS scale
+                double u[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    u[k] = s2 * (Jc[6 * k] * xv[0] + Jc[6 * k + 1] * xv[1] + Jc[6 * k + 2] * xv[2] + Jc[6 * k + 3] * xv[3] + Jc[6 * k + 4] * xv[4] +
+                                 Jc[6 * k + 5] * xv[5]);
+#pragma unroll
+                for (int b = 0; b < 3; ++b) t[b] = Jp[b] * u[0] + Jp[3 + b] * u[1] + Jp[6 + b] * u[2];
+            }
+        }
+        s_t[lane * 3] = t[0];
+        s_t[lane * 3 + 1] = t[1];
+        s_t[lane * 3 + 2] = t[2];
+        __builtin_amdgcn_wave_barrier();
+        // ---- lane = (point, component): g = b_p - sum of t in observation order ----
+        if (lane < gc * 3)
+        {
+            const int g = (lane * 171) >> 9, b = lane - 3 * g;
+            double v = bpv;
+            for (int a = 0; a < run; ++a) v -= s_t[(g * run + a) * 3 + b];
+            s_g[lane] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- lane = point: the new position ----
+        if (lane < gc)
+        {
+            double out[3] = {cur[0], cur[1], cur[2]};
+            if (!pconst)
+            {
+                const double g0 = s_g[lane * 3], g1 = s_g[lane * 3 + 1], g2 = s_g[lane * 3 + 2];
+                out[0] = cur[0] + (Vi[0] * g0 + Vi[1] * g1 + Vi[2] * g2);
+                out[1] = cur[1] + (Vi[1] * g0 + Vi[3] * g1 + Vi[4] * g2);
+                out[2] = cur[2] + (Vi[2] * g0 + Vi[4] * g1 + Vi[5] * g2);
+            }
+            double* po = A.pt_new + (size_t)gp2 * 3;
+            po[0] = out[0]; po[1] = out[1]; po[2] = out[2];
+            s_pn[lane * 3] = out[0]; s_pn[lane * 3 + 1] = out[1]; s_pn[lane * 3 + 2] = out[2];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- lane = observation: robust cost at the trial state (cost_wave) ----
+        double cost = 0.0;
+        if (ob.act && !is_out)
+        {
+            const double ptn[3] = {s_pn[lg * 3], s_pn[lg * 3 + 1], s_pn[lg * 3 + 2]};
+            double R[9], r[3], Jc[1], Jp[1];
+            quat_to_R(posen, R);
+            const int dim = obs_linearize<false>(posen, R, ptn, pr.K, pr.bf, ob.rec.u, ob.rec.v, ob.rec.depth, ob.rec.weight, r, Jc, Jp);
+            if (dim)
+            {
+                double sw;
+                cost = huber_rho(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], dim == 3 ? O.huber_stereo : O.huber_mono, sw);
+            }
+        }
+        s_c[lane] = cost;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < gc)
+        {
+            double c = 0.0;
+            for (int a = 0; a < run; ++a) c += s_c[lane * run + a];
+            A.cost_pt_new[gp2] = c;
+        }
+        __builtin_amdgcn_wave_barrier();
+        ob = obn;
+    }
+}
+
 // S(c1, c2) = U(c1) [c1 == c2] - sum of the block's partial sums (fixed order) - relative-pose cross terms; lane = element.
 __global__ __launch_bounds__(256) void schur_sum(Arrays A, int nbx, int B)
 {
@@ -2960,6 +3136,8 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     SNK_HIP_CHECK(hipMemsetAsync(h->d_x.p, 0, (size_t)std::max(vec_off, 1) * 8, st));
     // points without observations are in no work item of schur_fused: their cost, V^-1 and b_p are zero once and for all
     SNK_HIP_CHECK(hipMemsetAsync(h->d_cost.p, 0, npt * 8, st));
+    SNK_HIP_CHECK(hipMemsetAsync(h->d_cost_new.p, 0, npt * 8, st));
+    SNK_HIP_CHECK(hipMemcpyAsync(h->d_pt_new.p, h->d_pt.p, npt * 3 * 8, hipMemcpyDeviceToDevice, st));  // points without observations stay put
     SNK_HIP_CHECK(hipMemsetAsync(h->d_Vinv.p, 0, npt * 6 * 8, st));
     SNK_HIP_CHECK(hipMemsetAsync(h->d_bp.p, 0, npt * 3 * 8, st));
     if (!h->pcg_large)
@@ -3140,7 +3318,14 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L)
                 }
             }
         }
-        if (h->point_wave_ok && !no_wave)
+        static const bool no_uc = getenv("SNK_BA_NO_UPDATE_COST") != nullptr;  // A/B: update_wave + cost_wave
+        if (use_set && !no_uc)
+        {
+            // the work items of the set cover every point that has observations (schur_fused's linearisation-only items included)
+            LAUNCH(update_pass, dim3(std::max(1, ceil_div(h->max_ni, 128)), B), dim3(128), 0, A, 1);
+            LAUNCH(update_cost, dim3(nsx * 8 * ceil_div(B, 8)), dim3(256), 0, A, O, nsx, B);
+        }
+        else if (h->point_wave_ok && !no_wave)
         {
             const dim3 gwv(ceil_div(h->max_wv, 4), B);
             LAUNCH(update_wave, gwv, dim3(256), 0, A, O);
