@@ -841,10 +841,13 @@ __global__ __launch_bounds__(64) void rpc_pass(Arrays A, int trial)
         for (int b = 0; b < 6; ++b) o[35 + a * 6 + b] = J1[b * 6 + a] * w[b];  // H12 = J1^T W
 }
 
-constexpr int CAM_THREADS = 256;
+// CAM_THREADS threads per camera.  The 33 sums of a wavefront are reduced with a 6-step butterfly (~600 instructions), as much as
+// linearising three observations: with many windows per launch ONE wavefront per camera (12 observations per thread for the
+// benchmark window) is fastest -- 143 us (4 wavefronts) -> 102 (2) -> 86 (1) per 256 windows; a single window keeps 4 for latency.
+template <int CAM_THREADS>
 __global__ __launch_bounds__(CAM_THREADS) void cam_pass(Arrays A, Opt O)
 {
-    __shared__ double part[4][33];
+    __shared__ double part[CAM_THREADS / 64][33];
     const int pb  = blockIdx.y;
     const Prob pr = A.prob[pb];
     const int c   = blockIdx.x;
@@ -934,7 +937,11 @@ __global__ __launch_bounds__(CAM_THREADS) void cam_pass(Arrays A, Opt O)
     if (tid == 0)
     {
         double tot[33];
-        for (int k = 0; k < 33; ++k) tot[k] = ((part[0][k] + part[1][k]) + part[2][k]) + part[3][k];
+        for (int k = 0; k < 33; ++k)
+        {
+            tot[k] = part[0][k];
+            for (int w = 1; w < CAM_THREADS / 64; ++w) tot[k] += part[w][k];
+        }
         if (pr.n_rpc > 0)  // relative pose constraints incident to this camera (fixed order)
         {
             const int r0 = A.cam_rpc_start[pr.camrpc_off + c], r1 = A.cam_rpc_start[pr.camrpc_off + c + 1];
@@ -3272,7 +3279,10 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L)
         if (h->max_nfc > 0)
         {
             if (h->max_rpc > 0) LAUNCH(rpc_pass, dim3(ceil_div(h->max_rpc, 64), B), dim3(64), 0, A, 0);
-            LAUNCH(cam_pass, dim3(h->max_nfc, B), dim3(CAM_THREADS), 0, A, O);
+            if (B >= 16)
+                LAUNCH(cam_pass<64>, dim3(h->max_nfc, B), dim3(64), 0, A, O);
+            else
+                LAUNCH(cam_pass<256>, dim3(h->max_nfc, B), dim3(256), 0, A, O);
             {
                 const int nbx = ceil_div(h->max_nfc * h->max_nfc, 4);
                 if (use_set)
