@@ -1286,7 +1286,7 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
 {
     // per wavefront: the W rows of the group (64 x 18 doubles) | the observations' contributions (64 x 10) | the sums of
     // the group's points | their V^-1.  16.4 KB: two workgroups per CU, which is also what the registers allow.
-    __shared__ __attribute__((aligned(16))) double s_buf[4][64 * 18 + 64 * SF_NC + SF_GMAX * (SF_NC + 6)];
+    __shared__ __attribute__((aligned(16))) double s_buf[4][64 * 18 + 64 * SF_NC + SF_GMAX * (SF_NC + 6) + 4];
     int pb, bx;
     if (B >= 16)  // batched windows: one XCD per window
     {
@@ -1310,23 +1310,31 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
     double* s_con  = s_w + 64 * 18;
     double* s_sum  = s_con + 64 * SF_NC;
     double* s_vi   = s_sum + SF_GMAX * SF_NC;
+    double* s_zero = s_vi + SF_GMAX * 6;  // 4 zeros: what the operand lanes outside the matrix read
     const int run  = si.run, G = min(64 / run, SF_GMAX);  // run <= SET_MAX_RUN = 14: at least 4 points per group
     const int lg   = lane / run, la = lane - lg * run;     // point of the group / observation of the point
     const double* poses = A.pose + (size_t)pr.img_off * 7;
     const double lambda = A.state[pb].lambda;
+    if (lane < 4) s_zero[lane] = 0.0;
 
     const int nrows = si.nfree * 6;
     const int kk = lane >> 4, mr = lane & 15;
-    int roff[T];
-    bool rok[T];
+    // Operand addressing of the matrix products without selects: lane (row 16 t + mr, inner index kk) reads its row of W at
+    // wrow[t] + point * wstep[t]; lanes outside the matrix (row >= 6k, or kk == 3) have their pointer parked on four zeros
+    // with a zero step, so they read zeros and need no masking.
+    const double* wrow0[T];
+    int wstep[T];
 #pragma unroll
     for (int t = 0; t < T; ++t)
     {
         const int m = 16 * t + mr, i = (m * 43) >> 8, r = m - 6 * i;
-        rok[t]      = m < nrows && kk < 3;
+        const bool ok = m < nrows && kk < 3;
         const int pos = m < nrows ? A.set_pairs[si.aux_off + i] : 0;
-        roff[t]     = pos * 18 + r * 3;  // in doubles, relative to the point's first row
+        wrow0[t]    = ok ? s_w + pos * 18 + r * 3 : s_zero;
+        wstep[t]    = ok ? run * 18 : 0;
     }
+    const int vsel0 = kk == 0 ? 0 : (kk == 1 ? 1 : 2), vsel1 = kk == 0 ? 1 : (kk == 1 ? 3 : 4), vsel2 = kk == 0 ? 2 : (kk == 1 ? 4 : 5);
+    const int ksel  = kk < 3 ? kk : 0;
     double4_t acc[T * (T + 1) / 2];
 #pragma unroll
     for (int q = 0; q < T * (T + 1) / 2; ++q) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
@@ -1481,19 +1489,22 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
 
         // ---- phase 3: (W V^-1) W^T of every point of the group on the matrix cores ----
         if (si.nfree != 0)  // wave-uniform; a work item without pairs is linearisation only
-            for (int g = 0; g < gc; ++g)
+        {
+            const double* wr[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) wr[t] = wrow0[t];
+            const double* vv = s_vi;
+            for (int g = 0; g < gc; ++g, vv += 6)
             {
-                const double* base = s_w + g * run * 18;
-                const double* vv   = s_vi + g * 6;
-                const double vc0 = vv[kk == 0 ? 0 : (kk == 1 ? 1 : 2)], vc1 = vv[kk == 0 ? 1 : (kk == 1 ? 3 : 4)], vc2 = vv[kk == 0 ? 2 : (kk == 1 ? 4 : 5)];
+                const double vc0 = vv[vsel0], vc1 = vv[vsel1], vc2 = vv[vsel2];  // column kk of the symmetric V^-1
                 double ya[T], wb[T];
 #pragma unroll
                 for (int t = 0; t < T; ++t)
                 {
-                    const double* w = base + roff[t];
-                    const double w0 = w[0], w1 = w[1], w2 = w[2];
-                    ya[t] = rok[t] ? w0 * vc0 + w1 * vc1 + w2 * vc2 : 0.0;
-                    wb[t] = rok[t] ? (kk == 0 ? w0 : (kk == 1 ? w1 : w2)) : 0.0;
+                    const double* w = wr[t];
+                    ya[t] = w[0] * vc0 + w[1] * vc1 + w[2] * vc2;  // (W V^-1)[row][kk]
+                    wb[t] = w[ksel];                               // W[row][kk]
+                    wr[t] += wstep[t];
                 }
                 int q = 0;
 #pragma unroll
@@ -1501,6 +1512,7 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
 #pragma unroll
                     for (int tj = ti; tj < T; ++tj, ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[ti], wb[tj], acc[q], 0, 0, 0);
             }
+        }
         __builtin_amdgcn_wave_barrier();
     };
     // two register sets, used alternately: no copies between the groups
