@@ -421,7 +421,7 @@ static inline dim3 xcd_grid(int gx, int batch) { return batch >= 16 ? dim3(8 * g
 template <int NQ>
 __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restrict__ img0, int pitch0, long long stride0,
                                                    int aligned0, int ini_th, int min_th, u32* __restrict__ cand,
-                                                   u16* __restrict__ cell_cnt, int gx, int batch)
+                                                   u16* __restrict__ cell_cnt, int gx, int batch, int dbg_stop)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -465,6 +465,7 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
     for (int i = lane; i < (((ch + 2) * SP + 15) >> 4); i += 64) reinterpret_cast<u32x4_a16*>(S)[i] = u32x4_a16{0, 0, 0, 0};
     __builtin_amdgcn_wave_barrier();
     const u8* tile = reinterpret_cast<const u8*>(tile_dw);
+    if (dbg_stop == 1) return;  // SNK_ORB_FAST_STOP (timing experiments only, results are then meaningless): after the tile load
 
     // phase A: every 9-arc holds one pixel of each opposite pair -> S <= min_i max(d_i, d_{i+8}).  The loops
     // are wave-uniform (lanes outside the cell are predicated), so the running survivor count lives in a
@@ -547,6 +548,7 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
         }
     }
     __builtin_amdgcn_wave_barrier();
+    if (dbg_stop == 2) return;  // after the quick test
 
     // phase B: exact score of the survivors, two per lane
     for (int j = lane * 2; j < ns; j += 128)
@@ -582,6 +584,7 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
     }
     __builtin_amdgcn_wave_barrier();
 
+    if (dbg_stop == 3) return;  // after the exact scores
     // 3x3 non-max suppression (strict) among scores above min_th (all of them are survivors); the list of
     // corners is appended the same way (wave-uniform loop, ballot prefix, counts in scalar registers)
     int nl = 0, nini = 0;
@@ -605,6 +608,7 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
         nini += __popcll(__builtin_amdgcn_ballot_w64(keep && v > ini_th));
     }
     __builtin_amdgcn_wave_barrier();
+    if (dbg_stop == 4) return;  // after the non-maximum suppression
     const bool ini = nini > 0;
     const u32 thr  = ((u32)(ini ? ini_th : min_th) << 12) | 0xFFFu;  // key > thr  <=>  score > threshold
     const int n    = ini ? nini : nl;
@@ -2058,9 +2062,10 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
     {
         const int gx = ceil_div(L.total_cells, 4);
         const int fq = fast_quads(L);
+        static const int fast_stop = getenv("SNK_ORB_FAST_STOP") ? atoi(getenv("SNK_ORB_FAST_STOP")) : 0;  // timing experiments
         auto fk      = fq == 3 ? fast_kernel<3> : (fq == 4 ? fast_kernel<4> : fast_kernel<0>);
         hipLaunchKernelGGL(fk, xcd_grid(gx, batch), dim3(256), (size_t)4 * L.f_lds_wave, st, L, images_dev, pitch,
-                           image_stride, aligned0, o->params.ini_th_fast, o->params.min_th_fast, d_cand, d_cellcnt, gx, batch);
+                           image_stride, aligned0, o->params.ini_th_fast, o->params.min_th_fast, d_cand, d_cellcnt, gx, batch, fast_stop);
         SNK_LAUNCH_CHECK();
     }
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[3], st));

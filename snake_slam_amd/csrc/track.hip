@@ -180,162 +180,189 @@ __device__ __forceinline__ FrameDev frame_of(const FramesDev& B, int b)
     return F;
 }
 
-// one local-map point of the coarse matcher (SnakeORBMatcher.cpp:221-318), evaluated by one wavefront
-__device__ __forceinline__ void coarse_point(const FrameDev& F, const CamDev& C, const ScalesDev& S, const snk_lm_coarse& lmp, float th,
-                                             int feature_error, int direction, int lane, int& result, int& bin)
+// Broadcast of one lane's value to the wavefront (the lane index is wave-uniform: it comes from a scalar bit scan).
+__device__ __forceinline__ double bcast_d(double v, int src)
 {
-    result = -1;
-    bin    = 0;
-    const double pcx = C.R[0] * lmp.pos[0] + C.R[1] * lmp.pos[1] + C.R[2] * lmp.pos[2] + C.t[0];
-    const double pcy = C.R[3] * lmp.pos[0] + C.R[4] * lmp.pos[1] + C.R[5] * lmp.pos[2] + C.t[1];
-    const double z   = C.R[6] * lmp.pos[0] + C.R[7] * lmp.pos[1] + C.R[8] * lmp.pos[2] + C.t[2];
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ u32 bcast_u(u32 v, int src) { return (u32)__builtin_amdgcn_readlane((int)v, src); }
+__device__ __forceinline__ uint4 bcast_u4(const uint4& v, int src)
+{
+    return make_uint4(bcast_u(v.x, src), bcast_u(v.y, src), bcast_u(v.z, src), bcast_u(v.w, src));
+}
+
+// The matchers work on 64 local-map points per wavefront in two phases.  Phase 1, lane = point: projection, culls, search
+// radius (fp64, with the fixed-order log / exp series of the fine matcher) -- ONCE per point; the first version had all 64 lanes
+// of a wavefront repeat this per point and was bound by exactly that (790 vector instructions per point, VALU 100 % busy,
+// PMC r02t).  Phase 2: the points that passed are visited one after the other (scalar bit scan of the ballot), the point's
+// numbers are broadcast with v_readlane and the 64 lanes share its window scan.  Same arithmetic per point as before.
+
+// coarse (SnakeORBMatcher.cpp:221-318): 64 points starting at i0; results to best[] / bins[] (indexed like pts)
+__device__ __forceinline__ void coarse_wave64(const FrameDev& F, const CamDev& C, const ScalesDev& S, const snk_lm_coarse* __restrict__ pts,
+                                              int m, int i0, int ppw, float th, int feature_error, int direction, int lane,
+                                              int* __restrict__ best, int* __restrict__ bins)
+{
+    const int i   = i0 + lane;
+    const bool in = lane < ppw && i < m;  // ppw points per wavefront: 64 for large batches, fewer when the points are few
+    const snk_lm_coarse* lp = pts + (in ? i : i0);
+    const double px = lp->pos[0], py = lp->pos[1], pz = lp->pos[2];
+    const int oct  = lp->octave;
+    const float ang = lp->angle;
+    uint4 qa, qc;
+    split_desc(lp->desc, qa, qc);
+    const double pcx = C.R[0] * px + C.R[1] * py + C.R[2] * pz + C.t[0];
+    const double pcy = C.R[3] * px + C.R[4] * py + C.R[5] * pz + C.t[1];
+    const double z   = C.R[6] * px + C.R[7] * py + C.R[8] * pz + C.t[2];
     const double ipx = C.fx * pcx / z + C.cx, ipy = C.fy * pcy / z + C.cy;
-    bool ok = z > 0 && ipx >= F.min_x && ipx < F.max_x && ipy >= F.min_y && ipy < F.max_y;
+    bool ok = in && z > 0 && ipx >= F.min_x && ipx < F.max_x && ipy >= F.min_y && ipy < F.max_y;
     if (ok)
     {
-        const double POx = C.campos[0] - lmp.pos[0], POy = C.campos[1] - lmp.pos[1], POz = C.campos[2] - lmp.pos[2];
+        const double POx = C.campos[0] - px, POy = C.campos[1] - py, POz = C.campos[2] - pz;
         const double dist    = sqrt(POx * POx + POy * POy + POz * POz);
-        const double viewCos = (POx * lmp.normal[0] + POy * lmp.normal[1] + POz * lmp.normal[2]) / dist;
+        const double viewCos = (POx * lp->normal[0] + POy * lp->normal[1] + POz * lp->normal[2]) / dist;
         ok = !(viewCos < 0.5);
     }
-    if (ok)
+    int lvl = oct;
+    lvl     = lvl < 0 ? 0 : (lvl >= S.n ? S.n - 1 : lvl);
+    float r = th;
+    r *= S.s[lvl];
+    int result = -1, bin = 0;
+    u64 todo = __builtin_amdgcn_ballot_w64(ok);
+    while (todo)
     {
-        int lvl = lmp.octave;
-        lvl     = lvl < 0 ? 0 : (lvl >= S.n ? S.n - 1 : lvl);
-        float r = th;
-        r *= S.s[lvl];
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const double bx = bcast_d(ipx, src), by = bcast_d(ipy, src), bz = bcast_d(z, src);
+        const float br  = __builtin_bit_cast(float, bcast_u(__builtin_bit_cast(u32, r), src));
+        const int boct  = __builtin_amdgcn_readlane(oct, src);
+        const uint4 ba = bcast_u4(qa, src), bc = bcast_u4(qc, src);
         int mn, mx;
-        if (direction == 1) { mn = lmp.octave - 1; mx = 100; }
-        else if (direction == 2) { mn = 0; mx = lmp.octave; }
-        else { mn = lmp.octave - 1; mx = lmp.octave + 1; }
-        uint4 qa, qc;
-        split_desc(lmp.desc, qa, qc);
+        if (direction == 1) { mn = boct - 1; mx = 100; }
+        else if (direction == 2) { mn = 0; mx = boct; }
+        else { mn = boct - 1; mx = boct + 1; }
         u32 k1 = PJ_INF_KEY, k2 = PJ_INF_KEY;
-        scan_window<1>(F, F.taken, ipx, ipy, z, C.bf, (double)r, (double)r * (double)r, mn, mx, 0.0, qa, qc, lane, k1, k2);
+        scan_window<1>(F, F.taken, bx, by, bz, C.bf, (double)br, (double)br * (double)br, mn, mx, 0.0, ba, bc, lane, k1, k2);
         const int bd = (int)(k1 >> PJ_IDX_BITS);
         if (bd <= feature_error && k1 != PJ_INF_KEY)
         {
-            result    = (int)(k1 & PJ_IDX_MASK);
-            float rot = lmp.angle - F.kps[result].angle;
+            int res   = (int)(k1 & PJ_IDX_MASK);
+            const float bang = __builtin_bit_cast(float, bcast_u(__builtin_bit_cast(u32, ang), src));
+            float rot = bang - F.kps[res].angle;
             if (rot < 0.0f) rot += 360.0f;
-            bin = (int)roundf(rot * (1.0f / 30));
-            if (bin == 30) bin = 0;
+            int b = (int)roundf(rot * (1.0f / 30));
+            if (b == 30) b = 0;
             // the reference asserts 0 <= bin < HISTO_LENGTH (:316); angles outside [0, 360) or NaN have no bin:
             // such a point is left unmatched instead of indexing outside the histogram
-            if (!(bin >= 0 && bin < 30)) { result = -1; bin = 0; }
+            if (!(b >= 0 && b < 30)) { res = -1; b = 0; }
+            if (lane == src) { result = res; bin = b; }
         }
     }
-}
-
-// coarse: best[i] = feature index or -1, bins[i] = rotation bin
-__global__ __launch_bounds__(256) void coarse_kernel(FrameDev F, CamDev C, ScalesDev S, const snk_lm_coarse* __restrict__ pts,
-                                                     int m, float th, int feature_error, int direction,
-                                                     int* __restrict__ best, int* __restrict__ bins)
-{
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + wave;
-    if (i >= m) return;
-    const snk_lm_coarse lmp = pts[i];
-    int result, bin;
-    coarse_point(F, C, S, lmp, th, feature_error, direction, lane, result, bin);
-    if (lane == 0)
+    if (in)
     {
         best[i] = result;
         bins[i] = bin;
     }
 }
 
+// coarse: best[i] = feature index or -1, bins[i] = rotation bin
+__global__ __launch_bounds__(256) void coarse_kernel(FrameDev F, CamDev C, ScalesDev S, const snk_lm_coarse* __restrict__ pts,
+                                                     int m, int ppw, float th, int feature_error, int direction,
+                                                     int* __restrict__ best, int* __restrict__ bins)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i0 = (blockIdx.x * 4 + wave) * ppw;
+    if (i0 >= m) return;
+    coarse_wave64(F, C, S, pts, m, i0, ppw, th, feature_error, direction, lane, best, bins);
+}
+
 // batched form: blockIdx.y = frame; points [batch][m_cap], counts m_dev[batch]
 __global__ __launch_bounds__(256) void coarse_batch_kernel(FramesDev Fb, const CamDev* __restrict__ cams, ScalesDev S,
                                                            const snk_lm_coarse* __restrict__ pts, const int* __restrict__ m_dev,
-                                                           int m_cap, float th, int feature_error, int direction,
+                                                           int m_cap, int ppw, float th, int feature_error, int direction,
                                                            int* __restrict__ best, int* __restrict__ bins)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int b = blockIdx.y, i = blockIdx.x * 4 + wave;
+    const int b = blockIdx.y, i0 = (blockIdx.x * 4 + wave) * ppw;
     const int m = min(m_dev[b], m_cap);
-    if (i >= m) return;
+    if (i0 >= m) return;
     const FrameDev F = frame_of(Fb, b);
     const CamDev C   = cams[b];
-    const snk_lm_coarse lmp = pts[(size_t)b * m_cap + i];
-    int result, bin;
-    coarse_point(F, C, S, lmp, th, feature_error, direction, lane, result, bin);
-    if (lane == 0)
-    {
-        best[(size_t)b * m_cap + i] = result;
-        bins[(size_t)b * m_cap + i] = bin;
-    }
+    coarse_wave64(F, C, S, pts + (size_t)b * m_cap, m, i0, ppw, th, feature_error, direction, lane, best + (size_t)b * m_cap,
+                  bins + (size_t)b * m_cap);
 }
 
-// one local-map point of the fine matcher (SnakeORBMatcher.cpp:388-512), evaluated by one wavefront
-__device__ __forceinline__ void fine_point(const FrameDev& F, const CamDev& C, const ScalesDev& S, const snk_lm_fine& lmp, float th,
-                                           float ratio, int lane, int& result_out, u8& vis_out, u8& valid_out)
+// fine (SnakeORBMatcher.cpp:388-512): 64 points starting at i0; best[], visible[] and pts[].valid (in place)
+__device__ __forceinline__ void fine_wave64(const FrameDev& F, const CamDev& C, const ScalesDev& S, snk_lm_fine* __restrict__ pts, int m,
+                                            int i0, int ppw, float th, float ratio, int lane, int* __restrict__ best, u8* __restrict__ visible)
 {
-    int result = -1;
-    u8 vis = 0, valid = lmp.valid;
+    const int i   = i0 + lane;
+    const bool in = lane < ppw && i < m;
+    const snk_lm_fine* lp = pts + (in ? i : i0);
+    const double px = lp->pos[0], py = lp->pos[1], pz = lp->pos[2];
+    uint4 qa, qc;
+    split_desc(lp->desc, qa, qc);
+    u8 vis = 0, valid = in ? lp->valid : (u8)0;
+    double ipx = 0, ipy = 0, z = 1, prediction = 0;
+    float r = 0;
+    bool scan = false;
     if (valid)
     {
-        const double pcx = C.R[0] * lmp.pos[0] + C.R[1] * lmp.pos[1] + C.R[2] * lmp.pos[2] + C.t[0];
-        const double pcy = C.R[3] * lmp.pos[0] + C.R[4] * lmp.pos[1] + C.R[5] * lmp.pos[2] + C.t[1];
-        const double z   = C.R[6] * lmp.pos[0] + C.R[7] * lmp.pos[1] + C.R[8] * lmp.pos[2] + C.t[2];
-        const double ipx = C.fx * pcx / z + C.cx, ipy = C.fy * pcy / z + C.cy;
+        const double pcx = C.R[0] * px + C.R[1] * py + C.R[2] * pz + C.t[0];
+        const double pcy = C.R[3] * px + C.R[4] * py + C.R[5] * pz + C.t[1];
+        z   = C.R[6] * px + C.R[7] * py + C.R[8] * pz + C.t[2];
+        ipx = C.fx * pcx / z + C.cx;
+        ipy = C.fy * pcy / z + C.cy;
         if (z < 0 || !(ipx >= F.min_x && ipx < F.max_x && ipy >= F.min_y && ipy < F.max_y))
             valid = 0;
         else
         {
-            const double POx = C.campos[0] - lmp.pos[0], POy = C.campos[1] - lmp.pos[1], POz = C.campos[2] - lmp.pos[2];
+            const double POx = C.campos[0] - px, POy = C.campos[1] - py, POz = C.campos[2] - pz;
             const double dist = sqrt(POx * POx + POy * POy + POz * POz);
-            int rl            = lmp.reference_scale_level;
+            int rl            = lp->reference_scale_level;
             rl                = rl < 0 ? 0 : (rl >= S.n ? S.n - 1 : rl);
             const double sref = (double)S.s[rl];
-            const double max_dist = 1.2 * (double)lmp.reference_depth * sref;
-            const double min_dist = 0.8 * (double)lmp.reference_depth * sref / S.s_last;
-            const double viewCos  = (POx * lmp.normal[0] + POy * lmp.normal[1] + POz * lmp.normal[2]) / dist;
+            const double max_dist = 1.2 * (double)lp->reference_depth * sref;
+            const double min_dist = 0.8 * (double)lp->reference_depth * sref / S.s_last;
+            const double viewCos  = (POx * lp->normal[0] + POy * lp->normal[1] + POz * lp->normal[2]) / dist;
             if (dist < min_dist || dist > max_dist || viewCos < 0.5)
                 valid = 0;
             else
             {
                 vis = 1;
                 const float vcf = (float)viewCos;
-                float r         = (double)vcf > 0.998 ? 2.5f : 4.0f;
+                r               = (double)vcf > 0.998 ? 2.5f : 4.0f;
                 if (th != 1.0f) r *= th;
-                double prediction = (double)lmp.reference_scale_level + det_log((double)lmp.reference_depth / dist) / S.log_f;
+                prediction = (double)lp->reference_scale_level + det_log((double)lp->reference_depth / dist) / S.log_f;
                 if (prediction < 0.0) prediction = 0.0;
                 if (prediction > (double)(S.n - 1)) prediction = (double)(S.n - 1);
-                r = (float)((double)r * det_exp(prediction * S.log_f));
-                uint4 qa, qc;
-                split_desc(lmp.desc, qa, qc);
-                u32 k1 = PJ_INF_KEY, k2 = PJ_INF_KEY;
-                scan_window<2>(F, F.taken, ipx, ipy, z, C.bf, (double)r, (double)r * (double)r, 0, 0, prediction, qa, qc, lane, k1,
-                               k2);
-                const int bd = (int)(k1 >> PJ_IDX_BITS);
-                if (k1 != PJ_INF_KEY && bd <= 100)
-                {
-                    const int bi  = (int)(k1 & PJ_IDX_MASK);
-                    const int bd2 = (int)(k2 >> PJ_IDX_BITS);
-                    const int l1  = F.kps[bi].octave;
-                    const int l2  = k2 != PJ_INF_KEY ? F.kps[k2 & PJ_IDX_MASK].octave : -1;
-                    if (!(l1 == l2 && (float)bd > ratio * (float)bd2)) result = bi;
-                }
+                r    = (float)((double)r * det_exp(prediction * S.log_f));
+                scan = true;
             }
         }
     }
-    result_out = result;
-    vis_out    = vis;
-    valid_out  = valid;
-}
-
-__global__ __launch_bounds__(256) void fine_kernel(FrameDev F, CamDev C, ScalesDev S, snk_lm_fine* __restrict__ pts, int m,
-                                                   float th, float ratio, int* __restrict__ best, u8* __restrict__ visible)
-{
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + wave;
-    if (i >= m) return;
-    const snk_lm_fine lmp = pts[i];
-    int result;
-    u8 vis, valid;
-    fine_point(F, C, S, lmp, th, ratio, lane, result, vis, valid);
-    if (lane == 0)
+    int result = -1;
+    u64 todo = __builtin_amdgcn_ballot_w64(scan);
+    while (todo)
+    {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const double bx = bcast_d(ipx, src), by = bcast_d(ipy, src), bz = bcast_d(z, src), bpred = bcast_d(prediction, src);
+        const float br  = __builtin_bit_cast(float, bcast_u(__builtin_bit_cast(u32, r), src));
+        const uint4 ba = bcast_u4(qa, src), bc = bcast_u4(qc, src);
+        u32 k1 = PJ_INF_KEY, k2 = PJ_INF_KEY;
+        scan_window<2>(F, F.taken, bx, by, bz, C.bf, (double)br, (double)br * (double)br, 0, 0, bpred, ba, bc, lane, k1, k2);
+        const int bd = (int)(k1 >> PJ_IDX_BITS);
+        if (k1 != PJ_INF_KEY && bd <= 100)
+        {
+            const int bi  = (int)(k1 & PJ_IDX_MASK);
+            const int bd2 = (int)(k2 >> PJ_IDX_BITS);
+            const int l1  = F.kps[bi].octave;
+            const int l2  = k2 != PJ_INF_KEY ? F.kps[k2 & PJ_IDX_MASK].octave : -1;
+            if (!(l1 == l2 && (float)bd > ratio * (float)bd2) && lane == src) result = bi;
+        }
+    }
+    if (in)
     {
         best[i]      = result;
         visible[i]   = vis;
@@ -343,27 +370,26 @@ __global__ __launch_bounds__(256) void fine_kernel(FrameDev F, CamDev C, ScalesD
     }
 }
 
+__global__ __launch_bounds__(256) void fine_kernel(FrameDev F, CamDev C, ScalesDev S, snk_lm_fine* __restrict__ pts, int m, int ppw,
+                                                   float th, float ratio, int* __restrict__ best, u8* __restrict__ visible)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i0 = (blockIdx.x * 4 + wave) * ppw;
+    if (i0 >= m) return;
+    fine_wave64(F, C, S, pts, m, i0, ppw, th, ratio, lane, best, visible);
+}
+
 __global__ __launch_bounds__(256) void fine_batch_kernel(FramesDev Fb, const CamDev* __restrict__ cams, ScalesDev S,
-                                                         snk_lm_fine* __restrict__ pts, const int* __restrict__ m_dev, int m_cap,
+                                                         snk_lm_fine* __restrict__ pts, const int* __restrict__ m_dev, int m_cap, int ppw,
                                                          float th, float ratio, int* __restrict__ best, u8* __restrict__ visible)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int b = blockIdx.y, i = blockIdx.x * 4 + wave;
+    const int b = blockIdx.y, i0 = (blockIdx.x * 4 + wave) * ppw;
     const int m = min(m_dev[b], m_cap);
-    if (i >= m) return;
+    if (i0 >= m) return;
     const FrameDev F = frame_of(Fb, b);
     const CamDev C   = cams[b];
-    const size_t at  = (size_t)b * m_cap + i;
-    const snk_lm_fine lmp = pts[at];
-    int result;
-    u8 vis, valid;
-    fine_point(F, C, S, lmp, th, ratio, lane, result, vis, valid);
-    if (lane == 0)
-    {
-        best[at]      = result;
-        visible[at]   = vis;
-        pts[at].valid = valid;
-    }
+    fine_wave64(F, C, S, pts + (size_t)b * m_cap, m, i0, ppw, th, ratio, lane, best + (size_t)b * m_cap, visible + (size_t)b * m_cap);
 }
 
 // first claimant (lowest local-map index) of every feature wins; coarse additionally applies the
@@ -939,6 +965,15 @@ __global__ __launch_bounds__(256) void relink_kernel(FrameDev F, CamDev C, const
     }
 }
 
+// Points per wavefront of the projection matchers: a wavefront does the per-point geometry for `ppw` points at once and then
+// visits them one after the other, so many points per wavefront save the redundant geometry, few keep the chip busy when the
+// points are few (one frame of the host API): aim for >= ~8 wavefronts per SIMD.
+int points_per_wave(long long total_points)
+{
+    const long long want = total_points / 8192;
+    return (int)(want < 1 ? 1 : (want > 64 ? 64 : want));
+}
+
 int make_cam(const snk_camera* cam, const double* pose, CamDev* c)
 {
     SNK_REQUIRE(cam != nullptr && pose != nullptr, "camera / pose is NULL");
@@ -1109,7 +1144,8 @@ int snk_match_project_coarse(snk_matcher* m, const snk_frame_view* frame, const 
     int* d_bins = d_best + np;
     int* d_match = d_bins + np;
     SNK_HIP_CHECK(hipMemcpyAsync(m->q.p, pts, np * sizeof(snk_lm_coarse), hipMemcpyHostToDevice, m->stream));
-    hipLaunchKernelGGL(coarse_kernel, dim3(ceil_div(n_pts, 4)), dim3(256), 0, m->stream, F, C, S, m->q.as<snk_lm_coarse>(), n_pts,
+    const int ppw = points_per_wave(n_pts);
+    hipLaunchKernelGGL(coarse_kernel, dim3(ceil_div(n_pts, 4 * ppw)), dim3(256), 0, m->stream, F, C, S, m->q.as<snk_lm_coarse>(), n_pts, ppw,
                        th, feature_error, direction, d_best, d_bins);
     hipLaunchKernelGGL(resolve_kernel, dim3(1), dim3(256), 0, m->stream, d_best, d_bins, n_pts, F.taken, m->t.as<int>(), F.n, 1,
                        d_match, m->cnt.as<int>());
@@ -1145,7 +1181,8 @@ int snk_match_project_fine(snk_matcher* m, const snk_frame_view* frame, const sn
     int* d_match = d_best + np;
     u8* d_vis    = reinterpret_cast<u8*>(d_match + np);
     SNK_HIP_CHECK(hipMemcpyAsync(m->q.p, pts, np * sizeof(snk_lm_fine), hipMemcpyHostToDevice, m->stream));
-    hipLaunchKernelGGL(fine_kernel, dim3(ceil_div(n_pts, 4)), dim3(256), 0, m->stream, F, C, S, m->q.as<snk_lm_fine>(), n_pts, th,
+    const int ppw = points_per_wave(n_pts);
+    hipLaunchKernelGGL(fine_kernel, dim3(ceil_div(n_pts, 4 * ppw)), dim3(256), 0, m->stream, F, C, S, m->q.as<snk_lm_fine>(), n_pts, ppw, th,
                        ratio, d_best, d_vis);
     hipLaunchKernelGGL(resolve_kernel, dim3(1), dim3(256), 0, m->stream, d_best, (const int*)nullptr, n_pts, F.taken,
                        m->t.as<int>(), F.n, 0, d_match, m->cnt.as<int>());
@@ -1215,8 +1252,9 @@ int snk_match_project_coarse_batch_dev(snk_matcher* m, const snk_frames_dev* fra
     CamDev* cams;
     int *best, *bins, *claim;
     if ((rc = batch_scratch(m, batch, pts_cap, F.cap, cam, poses_dev, &cams, &best, &bins, &claim)) != SNK_OK) return rc;
-    hipLaunchKernelGGL(coarse_batch_kernel, dim3(ceil_div(pts_cap, 4), batch), dim3(256), 0, m->stream, F, (const CamDev*)cams, S,
-                       pts_dev, n_pts_dev, pts_cap, th, feature_error, direction, best, bins);
+    const int ppw = points_per_wave((long long)pts_cap * batch);
+    hipLaunchKernelGGL(coarse_batch_kernel, dim3(ceil_div(pts_cap, 4 * ppw), batch), dim3(256), 0, m->stream, F, (const CamDev*)cams, S,
+                       pts_dev, n_pts_dev, pts_cap, ppw, th, feature_error, direction, best, bins);
     hipLaunchKernelGGL(resolve_batch_kernel, dim3(batch), dim3(256), 0, m->stream, (const int*)best, (const int*)bins, n_pts_dev,
                        pts_cap, F, claim, 1, match_idx_dev, n_matches_dev);
     SNK_LAUNCH_CHECK();
@@ -1243,8 +1281,9 @@ int snk_match_project_fine_batch_dev(snk_matcher* m, const snk_frames_dev* frame
     int *best, *bins, *claim;
     if ((rc = batch_scratch(m, batch, pts_cap, F.cap, cam, poses_dev, &cams, &best, &bins, &claim)) != SNK_OK) return rc;
     SNK_HIP_CHECK(hipMemsetAsync(visible_dev, 0, (size_t)batch * pts_cap, m->stream));
-    hipLaunchKernelGGL(fine_batch_kernel, dim3(ceil_div(pts_cap, 4), batch), dim3(256), 0, m->stream, F, (const CamDev*)cams, S,
-                       pts_dev, n_pts_dev, pts_cap, th, ratio, best, visible_dev);
+    const int ppw = points_per_wave((long long)pts_cap * batch);
+    hipLaunchKernelGGL(fine_batch_kernel, dim3(ceil_div(pts_cap, 4 * ppw), batch), dim3(256), 0, m->stream, F, (const CamDev*)cams, S,
+                       pts_dev, n_pts_dev, pts_cap, ppw, th, ratio, best, visible_dev);
     hipLaunchKernelGGL(resolve_batch_kernel, dim3(batch), dim3(256), 0, m->stream, (const int*)best, (const int*)nullptr, n_pts_dev,
                        pts_cap, F, claim, 0, match_idx_dev, n_matches_dev);
     SNK_LAUNCH_CHECK();
