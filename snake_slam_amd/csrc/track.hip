@@ -112,7 +112,7 @@ __device__ __forceinline__ void merge2(u32& k1, u32& k2, u32 o1, u32 o2)
 
 // Candidate scan of one search window by one wavefront.  MODE 0: radius only; 1: octave window;
 // 2: predicted scale.  `taken` may point to LDS (keyframe matcher) or global memory.
-template <int MODE>
+template <int MODE, int LANES = 64>
 __device__ __forceinline__ void scan_window(const FrameDev& F, const u8* taken, double ipx, double ipy, double z, double bf,
                                             double r, double r2, int min_oct, int max_oct, double pred, const uint4& qa,
                                             const uint4& qc, int lane, u32& k1, u32& k2)
@@ -123,7 +123,7 @@ __device__ __forceinline__ void scan_window(const FrameDev& F, const u8* taken, 
     for (int cx = cx0; cx <= cx1; ++cx)
     {
         const int lo = F.cell_start[cx * F.rows + cy0], hi = F.cell_start[cx * F.rows + cy1 + 1];
-        for (int pid = lo + lane; pid < hi; pid += 64)
+        for (int pid = lo + lane; pid < hi; pid += LANES)  // `lane` = index inside the group of LANES lanes that shares the window
         {
             const snk_kp64 kp = F.kps[pid];
             if (MODE == 1 && (kp.octave < min_oct || kp.octave > max_oct)) continue;
@@ -144,11 +144,32 @@ __device__ __forceinline__ void scan_window(const FrameDev& F, const u8* taken, 
         }
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1)
+    for (int off = LANES / 2; off >= 1; off >>= 1)
     {
         const u32 o1 = __shfl_xor(k1, off), o2 = __shfl_xor(k2, off);
         merge2(k1, k2, o1, o2);
     }
+}
+
+// The next (up to) four set bits of `todo`, one per group of 16 lanes: group g gets the g-th; -1 = none.  Clears them.
+__device__ __forceinline__ int take4(u64& todo, int grp)
+{
+    int s[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+        s[k] = todo ? __builtin_ctzll(todo) : -1;
+        todo &= todo - 1;  // 0 stays 0
+    }
+    return grp == 0 ? s[0] : (grp == 1 ? s[1] : (grp == 2 ? s[2] : s[3]));
+}
+__device__ __forceinline__ double shfl_d(double v, int src)
+{
+    return __hiloint2double(__shfl(__double2hiint(v), src), __shfl(__double2loint(v), src));
+}
+__device__ __forceinline__ uint4 shfl_u4(const uint4& v, int src)
+{
+    return make_uint4((u32)__shfl((int)v.x, src), (u32)__shfl((int)v.y, src), (u32)__shfl((int)v.z, src), (u32)__shfl((int)v.w, src));
 }
 
 // Batch of grid-ordered frames resident on the device (the arrays snk_feature_grid_batch_dev / snk_stereo_match_batch_dev
@@ -227,41 +248,57 @@ __device__ __forceinline__ void coarse_wave64(const FrameDev& F, const CamDev& C
     lvl     = lvl < 0 ? 0 : (lvl >= S.n ? S.n - 1 : lvl);
     float r = th;
     r *= S.s[lvl];
-    int result = -1, bin = 0;
+    // results go through the wavefront's LDS slice (served in program order): default "no match", the group leaders overwrite
+    __shared__ int s_res[4][2][64];
+    int* my_res = s_res[(threadIdx.x >> 6) & 3][0];
+    int* my_bin = s_res[(threadIdx.x >> 6) & 3][1];
+    my_res[lane] = -1;
+    my_bin[lane] = 0;
+    // Phase 2: a window holds a few dozen candidates, so 16 lanes share one and four points are scanned at a time
+    const int grp = lane >> 4, sub = lane & 15;
     u64 todo = __builtin_amdgcn_ballot_w64(ok);
     while (todo)
     {
-        const int src = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const double bx = bcast_d(ipx, src), by = bcast_d(ipy, src), bz = bcast_d(z, src);
-        const float br  = __builtin_bit_cast(float, bcast_u(__builtin_bit_cast(u32, r), src));
-        const int boct  = __builtin_amdgcn_readlane(oct, src);
-        const uint4 ba = bcast_u4(qa, src), bc = bcast_u4(qc, src);
-        int mn, mx;
-        if (direction == 1) { mn = boct - 1; mx = 100; }
-        else if (direction == 2) { mn = 0; mx = boct; }
-        else { mn = boct - 1; mx = boct + 1; }
-        u32 k1 = PJ_INF_KEY, k2 = PJ_INF_KEY;
-        scan_window<1>(F, F.taken, bx, by, bz, C.bf, (double)br, (double)br * (double)br, mn, mx, 0.0, ba, bc, lane, k1, k2);
-        const int bd = (int)(k1 >> PJ_IDX_BITS);
-        if (bd <= feature_error && k1 != PJ_INF_KEY)
+        const int src  = take4(todo, grp);
+        const bool has = src >= 0;
+        const int sl   = has ? src : 0;
+        const double bx = shfl_d(ipx, sl), by = shfl_d(ipy, sl), bz = shfl_d(z, sl);
+        const float br  = __shfl(r, sl);
+        const int boct  = __shfl(oct, sl);
+        const float bang = __shfl(ang, sl);
+        const uint4 ba = shfl_u4(qa, sl), bc = shfl_u4(qc, sl);
+        if (has)
         {
-            int res   = (int)(k1 & PJ_IDX_MASK);
-            const float bang = __builtin_bit_cast(float, bcast_u(__builtin_bit_cast(u32, ang), src));
-            float rot = bang - F.kps[res].angle;
-            if (rot < 0.0f) rot += 360.0f;
-            int b = (int)roundf(rot * (1.0f / 30));
-            if (b == 30) b = 0;
-            // the reference asserts 0 <= bin < HISTO_LENGTH (:316); angles outside [0, 360) or NaN have no bin:
-            // such a point is left unmatched instead of indexing outside the histogram
-            if (!(b >= 0 && b < 30)) { res = -1; b = 0; }
-            if (lane == src) { result = res; bin = b; }
+            int mn, mx;
+            if (direction == 1) { mn = boct - 1; mx = 100; }
+            else if (direction == 2) { mn = 0; mx = boct; }
+            else { mn = boct - 1; mx = boct + 1; }
+            u32 k1 = PJ_INF_KEY, k2 = PJ_INF_KEY;
+            scan_window<1, 16>(F, F.taken, bx, by, bz, C.bf, (double)br, (double)br * (double)br, mn, mx, 0.0, ba, bc, sub, k1, k2);
+            const int bd = (int)(k1 >> PJ_IDX_BITS);
+            if (bd <= feature_error && k1 != PJ_INF_KEY)
+            {
+                int res   = (int)(k1 & PJ_IDX_MASK);
+                float rot = bang - F.kps[res].angle;
+                if (rot < 0.0f) rot += 360.0f;
+                int b = (int)roundf(rot * (1.0f / 30));
+                if (b == 30) b = 0;
+                // the reference asserts 0 <= bin < HISTO_LENGTH (:316); angles outside [0, 360) or NaN have no bin:
+                // such a point is left unmatched instead of indexing outside the histogram
+                if (!(b >= 0 && b < 30)) { res = -1; b = 0; }
+                if (sub == 0)
+                {
+                    my_res[src] = res;
+                    my_bin[src] = b;
+                }
+            }
         }
     }
+    __builtin_amdgcn_wave_barrier();
     if (in)
     {
-        best[i] = result;
-        bins[i] = bin;
+        best[i] = my_res[lane];
+        bins[i] = my_bin[lane];
     }
 }
 
@@ -341,30 +378,38 @@ __device__ __forceinline__ void fine_wave64(const FrameDev& F, const CamDev& C, 
             }
         }
     }
-    int result = -1;
+    __shared__ int s_resf[4][64];
+    int* my_res = s_resf[(threadIdx.x >> 6) & 3];
+    my_res[lane] = -1;
+    const int grp = lane >> 4, sub = lane & 15;
     u64 todo = __builtin_amdgcn_ballot_w64(scan);
     while (todo)
     {
-        const int src = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const double bx = bcast_d(ipx, src), by = bcast_d(ipy, src), bz = bcast_d(z, src), bpred = bcast_d(prediction, src);
-        const float br  = __builtin_bit_cast(float, bcast_u(__builtin_bit_cast(u32, r), src));
-        const uint4 ba = bcast_u4(qa, src), bc = bcast_u4(qc, src);
-        u32 k1 = PJ_INF_KEY, k2 = PJ_INF_KEY;
-        scan_window<2>(F, F.taken, bx, by, bz, C.bf, (double)br, (double)br * (double)br, 0, 0, bpred, ba, bc, lane, k1, k2);
-        const int bd = (int)(k1 >> PJ_IDX_BITS);
-        if (k1 != PJ_INF_KEY && bd <= 100)
+        const int src  = take4(todo, grp);
+        const bool has = src >= 0;
+        const int sl   = has ? src : 0;
+        const double bx = shfl_d(ipx, sl), by = shfl_d(ipy, sl), bz = shfl_d(z, sl), bpred = shfl_d(prediction, sl);
+        const float br  = __shfl(r, sl);
+        const uint4 ba = shfl_u4(qa, sl), bc = shfl_u4(qc, sl);
+        if (has)
         {
-            const int bi  = (int)(k1 & PJ_IDX_MASK);
-            const int bd2 = (int)(k2 >> PJ_IDX_BITS);
-            const int l1  = F.kps[bi].octave;
-            const int l2  = k2 != PJ_INF_KEY ? F.kps[k2 & PJ_IDX_MASK].octave : -1;
-            if (!(l1 == l2 && (float)bd > ratio * (float)bd2) && lane == src) result = bi;
+            u32 k1 = PJ_INF_KEY, k2 = PJ_INF_KEY;
+            scan_window<2, 16>(F, F.taken, bx, by, bz, C.bf, (double)br, (double)br * (double)br, 0, 0, bpred, ba, bc, sub, k1, k2);
+            const int bd = (int)(k1 >> PJ_IDX_BITS);
+            if (k1 != PJ_INF_KEY && bd <= 100)
+            {
+                const int bi  = (int)(k1 & PJ_IDX_MASK);
+                const int bd2 = (int)(k2 >> PJ_IDX_BITS);
+                const int l1  = F.kps[bi].octave;
+                const int l2  = k2 != PJ_INF_KEY ? F.kps[k2 & PJ_IDX_MASK].octave : -1;
+                if (!(l1 == l2 && (float)bd > ratio * (float)bd2) && sub == 0) my_res[src] = bi;
+            }
         }
     }
+    __builtin_amdgcn_wave_barrier();
     if (in)
     {
-        best[i]      = result;
+        best[i]      = my_res[lane];
         visible[i]   = vis;
         pts[i].valid = valid;
     }
