@@ -36,6 +36,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <chrono>
 #include <map>
 #include <tuple>
 #include <utility>
@@ -2622,6 +2623,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     SNK_HIP_CHECK(hipSetDevice(h->device));
     SNK_HIP_CHECK(hipStreamSynchronize(h->stream));
     h->drop_graphs();
+    const auto t_begin = std::chrono::steady_clock::now();
 
     std::vector<Prob> probs((size_t)count);
     std::vector<double> pose, pt, ouv2, odepth, oweight;
@@ -2786,8 +2788,8 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                 for (int a = pstart[(size_t)p]; a < pstart[(size_t)p + 1]; ++a)
                 {
                     if (s_cam[(size_t)a] < 0) continue;
-                    for (int c = pstart[(size_t)p]; c < pstart[(size_t)p + 1]; ++c)
-                        if (s_cam[(size_t)c] >= 0) bs[(size_t)s_cam[(size_t)a] * nfc + s_cam[(size_t)c] + 1]++;
+                    for (int c = pstart[(size_t)p]; c < pstart[(size_t)p + 1]; ++c)  // upper blocks only: schur_pass never reads the others
+                        if (s_cam[(size_t)c] >= s_cam[(size_t)a]) bs[(size_t)s_cam[(size_t)a] * nfc + s_cam[(size_t)c] + 1]++;
                 }
             }
             for (size_t k = 0; k < nb; ++k) bs[k + 1] += bs[k];
@@ -2800,7 +2802,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                 {
                     if (s_cam[(size_t)a] < 0) continue;
                     for (int c = pstart[(size_t)p]; c < pstart[(size_t)p + 1]; ++c)
-                        if (s_cam[(size_t)c] >= 0)
+                        if (s_cam[(size_t)c] >= s_cam[(size_t)a])
                         {
                             int4 e;
                             e.x = a;
@@ -2824,7 +2826,13 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             std::map<std::vector<int>, int> gid;
             std::vector<std::vector<int>> gpts;
             std::vector<std::vector<int>> gsig;
-            bool ok = nfc > 0;
+            // The point-major kernels (schur_fused / schur_mfma / update_cost) are only chosen when the launch has enough work
+            // items (max_set_items * count >= SNK_BA_SCHUR_SET_MIN_ITEMS, default 256): for the reference's per-keyframe
+            // call -- ONE window of a few thousand points -- their lists are never used, and building + uploading them
+            // (0.8 MB of records alone) was a quarter of the 0.9 ms a scene hand-over cost.  Built for batches and for big
+            // single scenes (global BA); forced when the threshold is lowered by the environment (tests).
+            static const bool sets_forced = getenv("SNK_BA_SCHUR_SET_MIN_ITEMS") != nullptr;
+            bool ok = nfc > 0 && (count >= 8 || P.n_pt >= 8000 || sets_forced);
             // points that produce no Schur products (constant points, points seen by constant cameras only) still need their
             // linearisation (cost, V, b_p): they form groups of their own, keyed by their run length, with no pairs
             auto plain_group = [&](int p, int run)
@@ -3064,6 +3072,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
 
     int rc;
     hipStream_t st = h->stream;
+    const auto t_lists = std::chrono::steady_clock::now();
 #define UP(buf, vec) if ((rc = upload(h->buf, vec, st)) != SNK_OK) return rc
     UP(d_prob, probs);
     UP(d_pose, pose);
@@ -3099,6 +3108,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     UP(d_camrpcitems, camrpcitems);
     UP(d_blkrpc, blkrpc);
 #undef UP
+    const auto t_up = std::chrono::steady_clock::now();
     const size_t nobs = (size_t)std::max(obs_off, 1), npt = (size_t)std::max(pt_off, 1);
 #define RS(buf, bytes) if ((rc = h->buf.reserve(bytes)) != SNK_OK) return rc
     RS(d_state, (size_t)count * sizeof(State));
@@ -3216,7 +3226,16 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     A.rhs       = h->d_rhs.as<double>();
     A.x         = h->d_x.as<double>();
     A.chi2      = h->d_chi2.as<double>();
+    const auto t_rs = std::chrono::steady_clock::now();
     SNK_HIP_CHECK(hipStreamSynchronize(st));
+    static const bool prof = getenv("SNK_BA_PROFILE_CREATE") != nullptr;  // host-side cost of a scene hand-over, in microseconds
+    if (prof)
+    {
+        const auto t_end = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+        fprintf(stderr, "[snk_ba_set_problems] lists %lld us, uploads %lld us, reserve+memset %lld us, sync %lld us\n", us(t_begin, t_lists),
+                us(t_lists, t_up), us(t_up, t_rs), us(t_rs, t_end));
+    }
     return SNK_OK;
 }
 

@@ -1015,6 +1015,8 @@ __global__ __launch_bounds__(256) void relink_kernel(FrameDev F, CamDev C, const
 // points are few (one frame of the host API): aim for >= ~8 wavefronts per SIMD.
 int points_per_wave(long long total_points)
 {
+    static const int forced = getenv("SNK_TRACK_PPW") ? atoi(getenv("SNK_TRACK_PPW")) : 0;  // tests: force a value
+    if (forced >= 1 && forced <= 64) return forced;
     const long long want = total_points / 8192;
     return (int)(want < 1 ? 1 : (want > 64 ? 64 : want));
 }

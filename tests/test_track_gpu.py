@@ -1,4 +1,6 @@
 """GPU: feature grid and projection matchers vs the oracle through the C ABI — bit-exact indices."""
+import os
+
 import numpy as np
 import pytest
 
@@ -345,3 +347,23 @@ def test_coarse_then_fine_batch_dev_parity(orc, matcher):
         assert np.array_equal(vis[b, : nf[b]], wvis) and np.array_equal(pf_after[b, : nf[b]]["valid"], wvalid), b
         total += int(n_c[b]) + int(n_f[b])
     assert total > 500
+
+
+@pytest.mark.skipif(os.environ.get("SNK_TRACK_NO_RECURSE") == "1", reason="child run")
+@pytest.mark.parametrize("ppw", ["64", "7"])
+def test_tracking_matchers_with_many_points_per_wavefront(ppw):
+    """The projection matchers pick the number of points per wavefront from the size of the call (1 for a single frame,
+    64 for bench-sized batches).  The parity tests above are small calls; here they run again in a child process with the
+    value forced (SNK_TRACK_PPW), so that the multi-point path (geometry by lane = point, four 16-lane window scans at a
+    time, results through LDS) is compared with the oracle too."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, "-m", "pytest", str(root / "tests" / "test_track_gpu.py"), str(root / "tests" / "test_tracking_chain_gpu.py"),
+                        "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", "-k", "coarse or fine or chain or refine"],
+                       env=dict(os.environ, SNK_TRACK_PPW=ppw, SNK_TRACK_NO_RECURSE="1"), capture_output=True, text=True, cwd=str(root), timeout=600)
+    assert r.returncode == 0, (ppw, r.stdout[-2000:], r.stderr[-1000:])
+    assert " passed" in r.stdout
