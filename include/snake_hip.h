@@ -304,6 +304,15 @@ typedef struct snk_lm_fine
     uint8_t pad[7];
 } snk_lm_fine;
 
+/* The Tracking thread looks at one frame with 1-2 coarse calls and one fine call (TrackingCoarse.cpp:234,
+ * TrackingFine.cpp:149): snk_match_bind_frame uploads the frame view ONCE and keeps it bound to the handle; the matchers
+ * that take a `const snk_frame_view* frame` (snk_match_project_coarse / _fine / _keyframe, snk_match_fuse,
+ * snk_match_triangulation_project's frame2; not snk_match_relink, which validates its queries against the view)
+ * called with frame == NULL then use the bound frame instead of uploading a view per call.  The view's arrays may be changed or freed after the call.  frame == NULL unbinds. */
+SNK_API int snk_match_bind_frame(snk_matcher* m, const snk_frame_view* frame);
+/* New `taken` mask (n bytes) for the bound frame: mvpMapPoints changed between two matcher calls. */
+SNK_API int snk_match_bound_taken(snk_matcher* m, const uint8_t* taken);
+
 /* Replaces SnakeORBMatcher::SearchByProjectionFrameFrame2 — Snake/Tracking/SnakeORBMatcher.cpp:191-354
  * (call site Snake/Tracking/TrackingCoarse.cpp:234).  pose = CurrentFrame.Pose() (qx qy qz qw tx ty tz).
  * direction: 0 none, 1 bForward, 2 bBackward (:210-212).  match_idx[i] = feature matched to

@@ -49,6 +49,8 @@ SIGNATURES = {
     "snk_rectify_batch_dev": (i32, [vp, vp, vp, vp, i32, i32, vp, vp]),
     "snk_feature_grid": (i32, [vp, vp, i32, vp, vp, vp, C.POINTER(i32), C.POINTER(i32)]),
     "snk_feature_grid_batch_dev": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]),
+    "snk_match_bind_frame": (i32, [vp, vp]),
+    "snk_match_bound_taken": (i32, [vp, vp]),
     "snk_match_project_coarse": (i32, [vp, vp, vp, vp, vp, i32, f32, i32, i32, vp, i32, vp, C.POINTER(i32)]),
     "snk_match_project_fine": (i32, [vp, vp, vp, vp, vp, i32, f32, f32, vp, i32, vp, vp, C.POINTER(i32)]),
     "snk_match_project_coarse_batch_dev": (i32, [vp, vp, vp, vp, vp, vp, i32, f32, i32, i32, vp, i32, vp, vp]),

@@ -194,6 +194,25 @@ class SnakeORBMatcher
         perm.resize((size_t)n);
         return perm;
     }
+    // The Tracking thread makes 1-2 coarse calls and one fine call on the same frame: BindFrame uploads the frame once, the
+    // Search* calls given THAT FrameView object then send nothing but the points; after changing frame.taken
+    // (mvpMapPoints[idx] = mp) call UpdateTaken.  UnbindFrame (or destroying the FrameView's contents) ends it.
+    void BindFrame(const FrameView& frame)
+    {
+        const snk_frame_view v = frame.view();
+        check(snk_match_bind_frame(h_, &v), "snk_match_bind_frame");
+        bound_ = &frame;
+    }
+    void UpdateTaken()
+    {
+        if (bound_) check(snk_match_bound_taken(h_, bound_->taken.data()), "snk_match_bound_taken");
+    }
+    void UnbindFrame()
+    {
+        check(snk_match_bind_frame(h_, nullptr), "snk_match_bind_frame");
+        bound_ = nullptr;
+    }
+
     // match[i] = feature index for local-map point i or -1; the caller sets mvpMapPoints[match[i]] = lm.points[i].mp
     int SearchByProjectionFrameFrame2(const FrameView& frame, const snk_camera& K, const double pose[7],
                                       const std::vector<snk_lm_coarse>& lm, float th, int featureError, int direction,
@@ -202,7 +221,7 @@ class SnakeORBMatcher
         const snk_frame_view v = frame.view();
         match.assign(lm.size() + 1, -1);
         int n = 0;
-        check(snk_match_project_coarse(h_, &v, &K, pose, lm.data(), (int)lm.size(), th, featureError, direction,
+        check(snk_match_project_coarse(h_, &frame == bound_ ? nullptr : &v, &K, pose, lm.data(), (int)lm.size(), th, featureError, direction,
                                        level_scale.data(), (int)level_scale.size(), match.data(), &n),
               "snk_match_project_coarse");
         match.resize(lm.size());
@@ -216,7 +235,7 @@ class SnakeORBMatcher
         match.assign(lm.size() + 1, -1);
         visible.assign(lm.size() + 1, 0);
         int n = 0;
-        check(snk_match_project_fine(h_, &v, &K, pose, lm.data(), (int)lm.size(), th, ratio, level_scale.data(),
+        check(snk_match_project_fine(h_, &frame == bound_ ? nullptr : &v, &K, pose, lm.data(), (int)lm.size(), th, ratio, level_scale.data(),
                                      (int)level_scale.size(), match.data(), visible.data(), &n),
               "snk_match_project_fine");
         match.resize(lm.size());
@@ -241,6 +260,7 @@ class SnakeORBMatcher
 
    private:
     snk_matcher* h_ = nullptr;
+    const FrameView* bound_ = nullptr;
 };
 
 // Snake::MappingORBMatcher (reference Snake/LocalMapping/MappingORBMatcher.h:15-45): the two keyframe-rate

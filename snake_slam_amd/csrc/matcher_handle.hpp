@@ -8,6 +8,7 @@ struct snk_matcher : snk::HandleBase
     // device copy of the frame the projection matchers were last called with (track.hip): 1-2 coarse calls and one
     // fine call per frame (TrackingCoarse.cpp:234, TrackingFine.cpp:149) look at the same frame, which is uploaded once
     snk::DevBuf view;
-    unsigned long long view_key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    bool view_valid                = false;
+    bool view_valid = false;  // snk_match_bind_frame: the arrays below live in `view`
+    int view_n = 0, view_cols = 0, view_rows = 0;
+    double view_bounds[4] = {0, 0, 0, 0};
 };

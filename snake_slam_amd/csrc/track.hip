@@ -1070,35 +1070,67 @@ void grid_dims(const snk_grid_bounds* b, int* cols, int* rows)
     *rows = r < 1 ? 1 : r;
 }
 
-// upload a host frame view into the handle's scratch; returns the device view
-int upload_frame(snk_matcher* m, const snk_frame_view* f, FrameDev* F)
+// byte offsets of the arrays of a frame of n features inside one device buffer
+struct FrameLayout
 {
-    SNK_REQUIRE(f != nullptr, "frame view is NULL");
+    size_t o_desc, o_rp, o_tk, o_cs, total;
+};
+FrameLayout frame_layout(size_t n, size_t nc)
+{
+    FrameLayout L;
+    L.o_desc = (n * sizeof(snk_kp64) + 15) & ~(size_t)15;
+    L.o_rp   = L.o_desc + n * 32;
+    L.o_tk   = L.o_rp + n * 4;
+    L.o_cs   = (L.o_tk + n + 15) & ~(size_t)15;
+    L.total  = L.o_cs + nc * 4;
+    return L;
+}
+void frame_pointers(char* d, const FrameLayout& L, FrameDev* F)
+{
+    F->kps          = reinterpret_cast<const snk_kp64*>(d);
+    F->desc         = reinterpret_cast<const uint4*>(d + L.o_desc);
+    F->right_points = reinterpret_cast<const float*>(d + L.o_rp);
+    F->taken        = reinterpret_cast<const u8*>(d + L.o_tk);
+    F->cell_start   = reinterpret_cast<const int*>(d + L.o_cs);
+}
+
+int upload_frame_to(snk_matcher* m, DevBuf& buf, const snk_frame_view* f, FrameDev* F)
+{
     SNK_REQUIRE(f->n >= 0 && f->n < (int)PJ_IDX_MASK && f->cols >= 1 && f->rows >= 1, "bad frame view sizes");
     SNK_REQUIRE(f->n == 0 || (f->kps && f->desc && f->right_points && f->taken), "NULL frame arrays");
     SNK_REQUIRE(f->cell_start != nullptr, "cell_start is NULL");
     const size_t n = (size_t)f->n, nc = (size_t)f->cols * f->rows + 1;
-    const size_t o_desc = (n * sizeof(snk_kp64) + 15) & ~(size_t)15, o_rp = o_desc + n * 32, o_tk = o_rp + n * 4,
-                 o_cs = (o_tk + n + 15) & ~(size_t)15, total = o_cs + nc * 4;
-    int rc = m->aux.reserve(total + 16);
+    const FrameLayout L = frame_layout(n, nc);
+    int rc = buf.reserve(L.total + 16);
     if (rc != SNK_OK) return rc;
-    char* d = m->aux.as<char>();
+    char* d = buf.as<char>();
     if (n)
     {
         SNK_HIP_CHECK(hipMemcpyAsync(d, f->kps, n * sizeof(snk_kp64), hipMemcpyHostToDevice, m->stream));
-        SNK_HIP_CHECK(hipMemcpyAsync(d + o_desc, f->desc, n * 32, hipMemcpyHostToDevice, m->stream));
-        SNK_HIP_CHECK(hipMemcpyAsync(d + o_rp, f->right_points, n * 4, hipMemcpyHostToDevice, m->stream));
-        SNK_HIP_CHECK(hipMemcpyAsync(d + o_tk, f->taken, n, hipMemcpyHostToDevice, m->stream));
+        SNK_HIP_CHECK(hipMemcpyAsync(d + L.o_desc, f->desc, n * 32, hipMemcpyHostToDevice, m->stream));
+        SNK_HIP_CHECK(hipMemcpyAsync(d + L.o_rp, f->right_points, n * 4, hipMemcpyHostToDevice, m->stream));
+        SNK_HIP_CHECK(hipMemcpyAsync(d + L.o_tk, f->taken, n, hipMemcpyHostToDevice, m->stream));
     }
-    SNK_HIP_CHECK(hipMemcpyAsync(d + o_cs, f->cell_start, nc * 4, hipMemcpyHostToDevice, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(d + L.o_cs, f->cell_start, nc * 4, hipMemcpyHostToDevice, m->stream));
     F->n = f->n; F->cols = f->cols; F->rows = f->rows;
-    F->kps          = reinterpret_cast<const snk_kp64*>(d);
-    F->desc         = reinterpret_cast<const uint4*>(d + o_desc);
-    F->right_points = reinterpret_cast<const float*>(d + o_rp);
-    F->taken        = reinterpret_cast<const u8*>(d + o_tk);
-    F->cell_start   = reinterpret_cast<const int*>(d + o_cs);
+    frame_pointers(d, L, F);
     F->min_x = f->bounds.min_x; F->min_y = f->bounds.min_y; F->max_x = f->bounds.max_x; F->max_y = f->bounds.max_y;
     return SNK_OK;
+}
+
+// The frame a matcher call looks at: a host view is uploaded into the handle's scratch (every call); frame == NULL means the
+// frame bound with snk_match_bind_frame, which is already on the device.
+int upload_frame(snk_matcher* m, const snk_frame_view* f, FrameDev* F)
+{
+    if (f == nullptr)
+    {
+        SNK_REQUIRE(m->view_valid, "frame view is NULL and no frame is bound (snk_match_bind_frame)");
+        F->n = m->view_n; F->cols = m->view_cols; F->rows = m->view_rows;
+        frame_pointers(m->view.as<char>(), frame_layout((size_t)m->view_n, (size_t)m->view_cols * m->view_rows + 1), F);
+        F->min_x = m->view_bounds[0]; F->min_y = m->view_bounds[1]; F->max_x = m->view_bounds[2]; F->max_y = m->view_bounds[3];
+        return SNK_OK;
+    }
+    return upload_frame_to(m, m->aux, f, F);
 }
 }  // namespace
 }  // namespace snk
@@ -1162,6 +1194,32 @@ int snk_feature_grid_batch_dev(snk_matcher* m, const snk_grid_bounds* bounds, co
                        kps_dev, reinterpret_cast<const uint4*>(desc_dev), kps_out_dev, reinterpret_cast<uint4*>(desc_out_dev));
     SNK_LAUNCH_CHECK();
     return SNK_OK;
+}
+
+int snk_match_bind_frame(snk_matcher* m, const snk_frame_view* frame)
+{
+    SNK_REQUIRE(m != nullptr, "matcher is NULL");
+    m->view_valid = false;
+    if (frame == nullptr) return SNK_OK;  // unbind
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    FrameDev F;
+    int rc = upload_frame_to(m, m->view, frame, &F);
+    if (rc != SNK_OK) return rc;
+    SNK_HIP_CHECK(hipStreamSynchronize(m->stream));  // the caller's arrays may change after the call
+    m->view_n = frame->n; m->view_cols = frame->cols; m->view_rows = frame->rows;
+    m->view_bounds[0] = frame->bounds.min_x; m->view_bounds[1] = frame->bounds.min_y;
+    m->view_bounds[2] = frame->bounds.max_x; m->view_bounds[3] = frame->bounds.max_y;
+    m->view_valid = true;
+    return SNK_OK;
+}
+
+int snk_match_bound_taken(snk_matcher* m, const uint8_t* taken)
+{
+    SNK_REQUIRE(m != nullptr && m->view_valid, "no frame is bound (snk_match_bind_frame)");
+    SNK_REQUIRE(m->view_n == 0 || taken != nullptr, "taken is NULL");
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    const FrameLayout L = frame_layout((size_t)m->view_n, (size_t)m->view_cols * m->view_rows + 1);
+    return copy_sync(m->view.as<char>() + L.o_tk, taken, (size_t)m->view_n, hipMemcpyHostToDevice, m->stream);
 }
 
 int snk_match_project_coarse(snk_matcher* m, const snk_frame_view* frame, const snk_camera* cam, const double pose[7],

@@ -33,6 +33,8 @@ class Camera(C.Structure):
 
 
 def _view(frame):
+    if frame is None:
+        return None, None
     a = {"kps": np.ascontiguousarray(frame["kps"], KP64_DTYPE), "desc": np.ascontiguousarray(frame["desc"], np.uint64),
          "right_points": np.ascontiguousarray(frame["right_points"], np.float32),
          "taken": np.ascontiguousarray(frame["taken"], np.uint8), "cell_start": np.ascontiguousarray(frame["cell_start"], np.int32)}
@@ -86,6 +88,17 @@ class FeatureGrid(_Handle):
 
 
 class SnakeORBMatcher(_Handle):
+    def bind_frame(self, frame) -> None:
+        """Uploads the frame view once; the Search* methods called with frame=None then use it (1-2 coarse calls and one fine
+        call look at the same frame).  frame=None unbinds."""
+        v, keep = _view(frame)
+        _lib.check(self._lib.snk_match_bind_frame(self._h, C.byref(v) if v is not None else None), "snk_match_bind_frame")
+
+    def bound_taken(self, taken) -> None:
+        """New taken mask (mvpMapPoints[i] != nullptr) for the bound frame."""
+        t = np.ascontiguousarray(taken, np.uint8)
+        _lib.check(self._lib.snk_match_bound_taken(self._h, _ptr(t)), "snk_match_bound_taken")
+
     def SearchByProjectionFrameFrame2(self, frame, cam, pose, lm_points, th, feature_error, direction, level_scale):
         """Coarse tracking match.  Returns (matches, match_idx[m])."""
         v, keep = _view(frame)
@@ -95,7 +108,7 @@ class SnakeORBMatcher(_Handle):
         out = np.full(max(len(pts), 1), -1, np.int32)
         n = C.c_int(0)
         c = Camera(*cam)
-        _lib.check(self._lib.snk_match_project_coarse(self._h, C.byref(v), C.byref(c), _ptr(pose), _ptr(pts), len(pts), float(th),
+        _lib.check(self._lib.snk_match_project_coarse(self._h, (C.byref(v) if v is not None else None), C.byref(c), _ptr(pose), _ptr(pts), len(pts), float(th),
                                                       int(feature_error), int(direction), _ptr(ls), len(ls), _ptr(out),
                                                       C.byref(n)), "snk_match_project_coarse")
         return n.value, out[: len(pts)]
@@ -110,7 +123,7 @@ class SnakeORBMatcher(_Handle):
         vis = np.zeros(max(len(pts), 1), np.uint8)
         n = C.c_int(0)
         c = Camera(*cam)
-        _lib.check(self._lib.snk_match_project_fine(self._h, C.byref(v), C.byref(c), _ptr(pose), _ptr(pts), len(pts), float(th),
+        _lib.check(self._lib.snk_match_project_fine(self._h, (C.byref(v) if v is not None else None), C.byref(c), _ptr(pose), _ptr(pts), len(pts), float(th),
                                                     float(ratio), _ptr(ls), len(ls), _ptr(out), _ptr(vis), C.byref(n)),
                    "snk_match_project_fine")
         return n.value, out[: len(pts)], vis[: len(pts)], pts["valid"].copy()
@@ -151,7 +164,7 @@ class SnakeORBMatcher(_Handle):
         out = np.full(max(len(pos), 1), -1, np.int32)
         n = C.c_int(0)
         c = Camera(*cam)
-        _lib.check(self._lib.snk_match_project_keyframe(self._h, C.byref(v), C.byref(c), _ptr(pose), _ptr(pos), _ptr(desc),
+        _lib.check(self._lib.snk_match_project_keyframe(self._h, (C.byref(v) if v is not None else None), C.byref(c), _ptr(pose), _ptr(pos), _ptr(desc),
                                                         _ptr(sk), len(pos), float(th), int(feature_error), _ptr(out), C.byref(n)),
                    "snk_match_project_keyframe")
         return n.value, out[: len(pos)]
@@ -179,7 +192,7 @@ class MappingORBMatcher(_Handle):
         out = np.full(max(len(pts), 1), -1, np.int32)
         n = C.c_int(0)
         c = Camera(*cam)
-        _lib.check(self._lib.snk_match_fuse(self._h, C.byref(v), C.byref(c), _ptr(pose), _ptr(pts), None if mask is None else _ptr(mask),
+        _lib.check(self._lib.snk_match_fuse(self._h, (C.byref(v) if v is not None else None), C.byref(c), _ptr(pose), _ptr(pts), None if mask is None else _ptr(mask),
                                             len(pts), float(th), float(obs_factor), int(feature_th), _ptr(ls), len(ls), _ptr(out),
                                             C.byref(n)), "snk_match_fuse")
         out = out[: len(pts)]
@@ -206,7 +219,7 @@ class MappingORBMatcher(_Handle):
         n = C.c_int(0)
         c = Camera(*cam)
         _lib.check(self._lib.snk_match_triangulation_project(self._h, _ptr(g), g.shape[0], g.shape[1], _ptr(p1), _ptr(p2), C.byref(c),
-                                                             _ptr(k1), _ptr(n1), _ptr(d1), _ptr(h1), len(k1), C.byref(v), _ptr(n2),
+                                                             _ptr(k1), _ptr(n1), _ptr(d1), _ptr(h1), len(k1), (C.byref(v) if v is not None else None), _ptr(n2),
                                                              _ptr(E), float(epipolarDistance), int(featureDistance), _ptr(out),
                                                              C.byref(n)), "snk_match_triangulation_project")
         out = out[: len(k1)]
@@ -278,7 +291,7 @@ class DeferredMapper(_Handle):
         best = np.full(max(len(q), 1), -1, np.int32)
         n = C.c_int(0)
         c = Camera(*cam)
-        _lib.check(self._lib.snk_match_relink(self._h, C.byref(v), C.byref(c), _ptr(pose), _ptr(q), len(q),
+        _lib.check(self._lib.snk_match_relink(self._h, (C.byref(v) if v is not None else None), C.byref(c), _ptr(pose), _ptr(q), len(q),
                                               float(self.relink_reprojection_error_threshold), float(self.relink_outlier_threshold),
                                               int(self.relink_feature_threshold), _ptr(action), _ptr(best), C.byref(n)),
                    "snk_match_relink")

@@ -109,6 +109,13 @@ int main(int argc, char** argv)
             int n = om.SearchByProjectionFrameFrame2(fv, cam[0], pose.data(), lc, 15.0f, 75, 0, ls, match);
             match.push_back(n);
             wr("out_tr_coarse", match);
+            // the same call on the bound frame (uploaded once) must give the same answer
+            om.BindFrame(fv);
+            std::vector<int32_t> match_b;
+            const int nb = om.SearchByProjectionFrameFrame2(fv, cam[0], pose.data(), lc, 15.0f, 75, 0, ls, match_b);
+            match_b.push_back(nb);
+            if (match_b != match) throw std::runtime_error("bound frame: coarse result differs");
+            om.UpdateTaken();
             auto lf = rd<snk_lm_fine>("tr_fine");
             std::vector<uint8_t> vis;
             n = om.SearchByProjection2(fv, cam[0], pose.data(), lf, 5.0f, 0.8f, ls, match, vis);
@@ -118,6 +125,7 @@ int main(int argc, char** argv)
             std::vector<uint8_t> valid;
             for (const auto& p : lf) valid.push_back(p.valid);
             wr("out_tr_fine_valid", valid);
+            om.UnbindFrame();
         }
         {  // PoseRefinement::refinePose (PoseRefinement.h:27-66)
             const auto cam = rd<snk_camera>("po_cam");

@@ -367,3 +367,28 @@ def test_tracking_matchers_with_many_points_per_wavefront(ppw):
                        env=dict(os.environ, SNK_TRACK_PPW=ppw, SNK_TRACK_NO_RECURSE="1"), capture_output=True, text=True, cwd=str(root), timeout=600)
     assert r.returncode == 0, (ppw, r.stdout[-2000:], r.stderr[-1000:])
     assert " passed" in r.stdout
+
+
+def test_bound_frame_gives_the_same_matches(orc, matcher):
+    """snk_match_bind_frame: the frame view is uploaded once, the matchers are called with frame = NULL; between the coarse
+    and the fine call only the taken mask is sent again (the adaptor's mvpMapPoints[idx] = mp)."""
+    rng = np.random.default_rng(SEED + 505)
+    frame, cam, pose, ls, world, _ = T.make_tracking_case(orc, rng, n_clutter=700, m_pts=1100)
+    pc = T.lm_coarse(orc, world)
+    pf = T.lm_fine(orc, rng, world, pose, ls)
+    wn, widx = orc.match_coarse(frame, cam, pose, pc, 15.0, 75, 0, ls)
+    f2 = dict(frame)
+    f2["taken"] = frame["taken"].copy()
+    f2["taken"][widx[widx >= 0]] = 1
+    wn2, widx2, wvis, wvalid = orc.match_fine(f2, cam, pose, pf, 5.0, 0.8, ls)
+    matcher.bind_frame(frame)
+    try:
+        n, idx = matcher.SearchByProjectionFrameFrame2(None, cam, pose, pc, 15.0, 75, 0, ls)
+        assert n == wn and np.array_equal(idx, widx)
+        matcher.bound_taken(f2["taken"])
+        n2, idx2, vis, valid = matcher.SearchByProjection2(None, cam, pose, pf, 5.0, 0.8, ls)
+        assert n2 == wn2 and np.array_equal(idx2, widx2) and np.array_equal(vis, wvis) and np.array_equal(valid, wvalid)
+    finally:
+        matcher.bind_frame(None)
+    with pytest.raises(Exception):
+        matcher.SearchByProjectionFrameFrame2(None, cam, pose, pc, 15.0, 75, 0, ls)  # nothing bound any more
