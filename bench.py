@@ -415,7 +415,7 @@ def main():
     # resident (kp64_g / desc_g / cell_start / right_points are consumed where the batched front-end wrote them).
     track_out = None
     if world == 1 and args.track_frames > 0 and args.workload == "euroc":
-        from snake_slam_amd.tracking import KP64_DTYPE, SnakeORBMatcher, frames_dev
+        from snake_slam_amd.tracking import KP64_DTYPE, PoseRefinement, SnakeORBMatcher, frames_dev, pose_observations
 
         TB = min(args.track_frames, B)
         h_kps = kp64_g[:TB].cpu().numpy().view(KP64_DTYPE).reshape(TB, cap)
@@ -441,12 +441,18 @@ def main():
         n_c = torch.zeros(TB, dtype=torch.int32, device=dev)
         n_f = torch.zeros(TB, dtype=torch.int32, device=dev)
         trk = SnakeORBMatcher(local, sh)
+        refp = PoseRefinement(device=local, stream=sh)  # on the SAME stream as the matchers: one ordered chain
         fd = frames_dev(GRID_BOUNDS, nkp[:TB], kp64_g[:TB], desc_g[:TB], right_points[:TB], taken, cell_start[:TB])
+        d_pose0 = d_pose.clone()
+        outl_c = torch.zeros((TB, TRACK_M_COARSE), dtype=torch.uint8, device=dev)
+        inl_c = torch.zeros(TB, dtype=torch.int32, device=dev)
 
         def track_step():
             taken.zero_()
+            d_pose.copy_(d_pose0)
             d_pf.copy_(d_pf0)  # the fine matcher clears .valid in place
             trk.coarse_batch_dev(fd, TRACK_CAM, d_pose, d_pc, d_mc, 10.0, 75, 0, level_scale, mi_c, n_c)   # th 10: stereo, Tracking.h:184
+            refp.refine_matches_batch_dev(fd, depth[:TB], TRACK_CAM, d_pc, mi_c, d_mc, level_scale, d_pose, outl_c, inl_c)  # TrackingCoarse.cpp:270
             trk.mark_taken_batch_dev(mi_c, d_mc, taken)
             trk.fine_batch_dev(fd, TRACK_CAM, d_pose, d_pf, d_mf, 4.0, 0.8, level_scale, mi_f, vis, n_f)    # th 4: stereo, Tracking.h:189
 
@@ -464,10 +470,11 @@ def main():
         n_feat = float(h_n.mean())
         a_track = n_feat * 61 + TRACK_M_COARSE * (88 + 4) + n_feat * 61 + TRACK_M_FINE * (96 + 5)
         fps = TB * args.steps / (tt1 - tt0)
-        track_out = {"metric": "frames/s of the tracking matchers (coarse M=1500 th=10 + fine M=10000 th=4), device resident",
+        track_out = {"metric": "frames/s of the tracking chain (coarse M=1500 th=10 -> RefinePoseWithMatches -> fine M=10000 th=4), device resident",
                      "value": round(fps, 1), "unit": "frames/s", "frames_per_step": TB, "ms_per_step": round((tt1 - tt0) / args.steps * 1e3, 4),
                      "coarse_matches_per_frame": round(float(n_c.float().mean().item()), 1),
-                     "fine_matches_per_frame": round(float(n_f.float().mean().item()), 1), "dtype": "u8 descriptors, f64 geometry",
+                     "fine_matches_per_frame": round(float(n_f.float().mean().item()), 1),
+                     "pose_inliers_per_frame": round(float(inl_c.float().mean().item()), 1), "dtype": "u8 descriptors, f64 geometry",
                      "roofline": {"bound": "hbm", "algorithmic_bytes_per_frame": int(a_track),
                                   "achieved": round(a_track * fps / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(a_track * fps / 1e9 / HBM_PEAK_GBS, 6)}}
@@ -480,22 +487,29 @@ def main():
             h_cs = cell_start[:TB].cpu().numpy()
             gcols, grows = int(np.ceil(W / 20.0)), int(np.ceil(H / 20.0))
             tc0, done, same = time.perf_counter(), 0, True
-            h_mi_c, h_mi_f = mi_c.cpu().numpy(), mi_f.cpu().numpy()
+            h_mi_c, h_mi_f, h_pose = mi_c.cpu().numpy(), mi_f.cpu().numpy(), d_pose.cpu().numpy()
+            ocam = orc.Camera(*TRACK_CAM)
             while time.perf_counter() - tc0 < 4.0 and done < TB:
                 b = done
                 nb = int(h_n[b])
                 fr = dict(kps=h_kps[b, :nb], desc=h_desc[b, :nb], right_points=h_rp[b, :nb], taken=np.zeros(nb, np.uint8),
                           cell_start=h_cs[b], bounds=GRID_BOUNDS, cols=gcols, rows=grows)
                 _, wi = orc.match_coarse(fr, TRACK_CAM, ident[0], lm[b][0], 10.0, 75, 0, level_scale)
-                fr["taken"][wi[wi >= 0]] = 1
-                _, wf, _, _ = orc.match_fine(fr, TRACK_CAM, ident[0], lm[b][1].copy(), 4.0, 0.8, level_scale)
-                same = same and np.array_equal(wi, h_mi_c[b]) and np.array_equal(wf, h_mi_f[b])
+                sel = np.nonzero(wi >= 0)[0]
+                wpose = ident[0]
+                if len(sel) >= 3:
+                    wobs = pose_observations(fr["kps"][wi[sel]], h_depth[b][wi[sel]], level_scale)
+                    wpose, _, _ = orc.pose_refine(ident[0], ocam, lm[b][0]["pos"][sel], wobs)
+                fr["taken"][wi[sel]] = 1
+                _, wf, _, _ = orc.match_fine(fr, TRACK_CAM, wpose, lm[b][1].copy(), 4.0, 0.8, level_scale)
+                same = same and np.array_equal(wi, h_mi_c[b]) and np.array_equal(wf, h_mi_f[b]) and bool(np.allclose(wpose, h_pose[b], rtol=0, atol=1e-9))
                 done += 1
             orc.set_match_threads(1)
             track_out["cpu_baseline"] = {"value": round(done / (time.perf_counter() - tc0), 2), "unit": "frames/s", "cores": 4, "kind": "port",
-                                         "sample": f"{done} frames of the same inputs (coarse + fine), 4 OpenMP threads",
+                                         "sample": f"{done} frames of the same inputs (coarse, pose refinement, fine), matchers with 4 OpenMP threads",
                                          "identical_to_gpu": bool(same)}
         trk.close()
+        refp.close()
 
     # ---- result gather: one fixed-size block per rank (RCCL all_gather over xGMI) ----
     block = torch.tensor([float(B * args.steps), float(nkp.sum().item()), float(n_stereo.sum().item()),

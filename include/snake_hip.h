@@ -528,6 +528,20 @@ typedef struct snk_pose_problem
 SNK_API int snk_pose_refine(snk_matcher* m, const snk_camera* cam, const snk_pose_options* opt,
                             snk_pose_problem* problems, int n_problems);
 
+/* Device-resident PoseRefinement::RefinePoseWithMatches (Snake/Tracking/PoseRefinement.cpp:25-79) for every frame of a batch,
+ * fed by the result of a batched projection matcher: for local-map point i with match_idx[b][i] = f >= 0 the pair
+ * (world point = 3 doubles at pts_dev + (b * pts_cap + i) * pts_stride -- snk_lm_coarse / snk_lm_fine both start with it --,
+ * observation = frames->kps[b][f], depth_dev[b][f] (> 0 => stereo), weight sqrt(InverseSquaredScale(octave))) enters in
+ * point order.  poses_dev [batch][7] is the start pose and receives the refined one (untouched with fewer than 3 pairs);
+ * outlier_dev [batch][pts_cap] gets the flag of every matched point (0 elsewhere), inliers_dev [batch] the return value.
+ * Asynchronous on the handle's stream; with snk_match_project_coarse_batch_dev before and _fine_batch_dev after it a frame's
+ * tracking chain (TrackingCoarse.cpp:234-270, TrackingFine.cpp:149-158) runs without a host round trip. */
+SNK_API int snk_pose_refine_matches_batch_dev(snk_matcher* m, const snk_frames_dev* frames, const float* depth_dev,
+                                              const snk_camera* cam, const snk_pose_options* opt, const void* pts_dev,
+                                              int pts_stride, const int32_t* match_idx_dev, const int32_t* n_pts_dev,
+                                              int pts_cap, const float* level_scale, int n_levels, double* poses_dev,
+                                              uint8_t* outlier_dev, int32_t* inliers_dev);
+
 /* ------------------------------------------------------------------------------------------
  * Local bundle adjustment
  * ------------------------------------------------------------------------------------------ */

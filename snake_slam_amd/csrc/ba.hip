@@ -1313,7 +1313,7 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
     double* s_vi   = s_sum + SF_GMAX * SF_NC;
     double* s_zero = s_vi + SF_GMAX * 6;  // 4 zeros: what the operand lanes outside the matrix read
     const int run  = si.run, G = min(64 / run, SF_GMAX);  // run <= SET_MAX_RUN = 14: at least 4 points per group
-    const int lg   = lane / run, la = lane - lg * run;     // point of the group / observation of the point
+    const int lg   = lane / run;                           // point of the group (its observation is lane - lg * run)
     const double* poses = A.pose + (size_t)pr.img_off * 7;
     const double lambda = A.state[pb].lambda;
     if (lane < 4) s_zero[lane] = 0.0;
@@ -1583,7 +1583,7 @@ __global__ __launch_bounds__(256) void update_cost(Arrays A, Opt O, int nbx, int
     double* s_g  = s_c + 64;
     double* s_pn = s_g + SF_GMAX * 3;
     const int run = si.run, G = min(64 / run, SF_GMAX);
-    const int lg  = lane / run, la = lane - lg * run;
+    const int lg  = lane / run;
     const char* rec_base = reinterpret_cast<const char*>(A.set_obs + si.rec_off);
     const unsigned n_rec = (unsigned)(si.n_pts * run);
     const double* x = A.x + pr.vec_off;

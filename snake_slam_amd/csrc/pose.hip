@@ -333,6 +333,78 @@ __global__ __launch_bounds__(64) void pose_kernel(const PoseMeta* __restrict__ m
         inliers_out[blockIdx.x] = inliers;
     }
 }
+
+// ---- device-resident form: the matches of a projection matcher -> (world point, observation) pairs per frame ----
+// One wavefront per frame walks the local-map points in order (ballot prefix: the pairs keep the points' order, which is the
+// order RefinePoseWithMatches gathers them, PoseRefinement.cpp:37-57) and writes the frame's PoseMeta.
+__global__ __launch_bounds__(64) void gather_matches_kernel(const snk_kp64* __restrict__ kps, const float* __restrict__ depth, int cap,
+                                                            const unsigned char* __restrict__ pts, int pts_stride,
+                                                            const int* __restrict__ match_idx, const int* __restrict__ n_pts,
+                                                            int pts_cap, const double* __restrict__ poses, float s0, float s1, float s2,
+                                                            float s3, float s4, float s5, float s6, float s7, int n_levels,
+                                                            PoseMeta* __restrict__ meta, double* __restrict__ wps,
+                                                            snk_pose_obs* __restrict__ obs, int* __restrict__ slot_of)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int m = min(n_pts[b], pts_cap);
+    const float ls[8] = {s0, s1, s2, s3, s4, s5, s6, s7};
+    const size_t base = (size_t)b * pts_cap;
+    int count = 0;
+    for (int i0 = 0; i0 < m; i0 += 64)
+    {
+        const int i = i0 + lane;
+        const int f = i < m ? match_idx[base + i] : -1;
+        const bool has = f >= 0 && f < cap;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(has);
+        if (has)
+        {
+            const int k = count + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            const double* pp = reinterpret_cast<const double*>(pts + (base + i) * (size_t)pts_stride);
+            double* w = wps + (base + k) * 3;
+            w[0] = pp[0]; w[1] = pp[1]; w[2] = pp[2];
+            const snk_kp64 kp = kps[(size_t)b * cap + f];
+            int oc = kp.octave;
+            oc     = oc < 0 ? 0 : (oc >= n_levels ? n_levels - 1 : oc);
+            const double sc = (double)ls[oc];
+            snk_pose_obs o;
+            o.x = kp.x; o.y = kp.y;
+            o.depth  = (double)depth[(size_t)b * cap + f];
+            o.weight = sqrt(1.0 / (sc * sc));  // sqrt(InverseSquaredScale(octave)), PoseRefinement.h:52
+            obs[base + k]     = o;
+            slot_of[base + k] = i;
+        }
+        count += __popcll(mask);
+    }
+    if (lane == 0)
+    {
+        PoseMeta M;
+        M.off = (int)base; M.n = count >= 3 ? count : 0;  // fewer than 3 correspondences: nothing to refine (PoseRefinement.cpp:59)
+        M.use_prior = 0; M.pad = count;
+        for (int k = 0; k < 7; ++k) M.pose[k] = M.pred[k] = poses[(size_t)b * 7 + k];
+        M.w_rot = M.w_trans = 0.0;
+        meta[b] = M;
+    }
+}
+
+// results back to where the caller keeps them: the pose of every frame, the outlier flag per local-map point
+__global__ __launch_bounds__(64) void scatter_pose_kernel(const PoseMeta* __restrict__ meta, const double* __restrict__ pose_out,
+                                                          const u8* __restrict__ outl, const int* __restrict__ slot_of, int pts_cap,
+                                                          double* __restrict__ poses, u8* __restrict__ outlier_pt,
+                                                          int* __restrict__ inliers)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const PoseMeta M = meta[b];
+    const size_t base = (size_t)b * pts_cap;
+    for (int i = lane; i < pts_cap; i += 64) outlier_pt[base + i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (M.n == 0)
+    {
+        if (lane == 0) inliers[b] = 0;  // pose untouched
+        return;
+    }
+    for (int k = lane; k < M.n; k += 64) outlier_pt[base + slot_of[base + k]] = outl[base + k];
+    if (lane < 7) poses[(size_t)b * 7 + lane] = pose_out[(size_t)b * 7 + lane];
+}
 }  // namespace
 }  // namespace snk
 
@@ -410,5 +482,51 @@ extern "C" int snk_pose_refine(snk_matcher* m, const snk_camera* cam, const snk_
         memcpy(&P.inliers, &back[o_inl + (size_t)i * 4], 4);
         off += (size_t)P.n;
     }
+    return SNK_OK;
+}
+
+extern "C" int snk_pose_refine_matches_batch_dev(snk_matcher* m, const snk_frames_dev* frames, const float* depth_dev,
+                                                 const snk_camera* cam, const snk_pose_options* opt, const void* pts_dev,
+                                                 int pts_stride, const int32_t* match_idx_dev, const int32_t* n_pts_dev, int pts_cap,
+                                                 const float* level_scale, int n_levels, double* poses_dev, uint8_t* outlier_dev,
+                                                 int32_t* inliers_dev)
+{
+    SNK_REQUIRE(m != nullptr && frames != nullptr && cam != nullptr && opt != nullptr, "NULL argument");
+    SNK_REQUIRE(frames->batch >= 0 && frames->cap >= 1 && frames->kps != nullptr, "bad frames");
+    SNK_REQUIRE(depth_dev && pts_dev && match_idx_dev && n_pts_dev && poses_dev && outlier_dev && inliers_dev, "NULL device buffer");
+    SNK_REQUIRE(pts_stride >= 24 && pts_stride % 8 == 0 && pts_cap >= 1, "pts_stride must be a multiple of 8, >= 24");
+    SNK_REQUIRE(level_scale != nullptr && n_levels >= 1 && n_levels <= 8, "level_scale / n_levels (1..8)");
+    SNK_REQUIRE(opt->outer_iterations >= 0 && opt->outer_iterations <= 64 && opt->inner_iterations >= 0 &&
+                    opt->inner_iterations <= 1000 && opt->robust_rounds >= 0,
+                "iteration counts out of range");
+    SNK_REQUIRE(opt->th_mono > 0.0 && opt->th_stereo > 0.0 && opt->lambda >= 0.0, "thresholds must be positive");
+    const int batch = frames->batch;
+    if (batch == 0) return SNK_OK;
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    const size_t total = (size_t)batch * pts_cap;
+    // q: meta | wps | obs | slot_of      out: outlier (pair order) | pose_out | inliers
+    const size_t o_wps = ((size_t)batch * sizeof(PoseMeta) + 15) & ~(size_t)15, o_obs = o_wps + total * 24;
+    const size_t o_slot = o_obs + total * sizeof(snk_pose_obs), in_b = o_slot + total * 4;
+    const size_t o_pose = (total + 7) & ~(size_t)7, o_inl = o_pose + (size_t)batch * 56, out_b = o_inl + (size_t)batch * 4;
+    int rc;
+    if ((rc = m->q.reserve(in_b + 64)) != SNK_OK) return rc;
+    if ((rc = m->out.reserve(out_b + 64)) != SNK_OK) return rc;
+    char* d = m->q.as<char>();
+    char* o = m->out.as<char>();
+    float ls[8];
+    for (int i = 0; i < 8; ++i) ls[i] = level_scale[i < n_levels ? i : n_levels - 1];
+    hipLaunchKernelGGL(gather_matches_kernel, dim3(batch), dim3(64), 0, m->stream, frames->kps, depth_dev, frames->cap,
+                       reinterpret_cast<const unsigned char*>(pts_dev), pts_stride, match_idx_dev, n_pts_dev, pts_cap,
+                       (const double*)poses_dev, ls[0], ls[1], ls[2], ls[3], ls[4], ls[5], ls[6], ls[7], n_levels,
+                       reinterpret_cast<PoseMeta*>(d), reinterpret_cast<double*>(d + o_wps), reinterpret_cast<snk_pose_obs*>(d + o_obs),
+                       reinterpret_cast<int*>(d + o_slot));
+    CamD C{cam->fx, cam->fy, cam->cx, cam->cy, cam->bf};
+    hipLaunchKernelGGL(pose_kernel, dim3(batch), dim3(64), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
+                       reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),
+                       reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), inliers_dev, C, *opt);
+    hipLaunchKernelGGL(scatter_pose_kernel, dim3(batch), dim3(64), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
+                       reinterpret_cast<const double*>(o + o_pose), reinterpret_cast<const u8*>(o), reinterpret_cast<const int*>(d + o_slot),
+                       pts_cap, poses_dev, outlier_dev, inliers_dev);
+    SNK_LAUNCH_CHECK();
     return SNK_OK;
 }

@@ -349,8 +349,8 @@ class PoseRefinement(_Handle):
     (reference Snake/Tracking/PoseRefinement.cpp:13-15)."""
 
     def __init__(self, errorFactor: float = 1.0, device: int = 0, outer: int = 4, inner: int = 10, robust_rounds: int = 3,
-                 lam: float = 1e-4):
-        super().__init__(device)
+                 lam: float = 1e-4, stream: int | None = None):
+        super().__init__(device, stream)
         self.options = PoseOptions(REPROJECTION_ERROR_THRESHOLD_MONO * errorFactor, REPROJECTION_ERROR_THRESHOLD_STEREO * errorFactor,
                                    outer, inner, robust_rounds, 0, lam)
 
@@ -375,6 +375,17 @@ class PoseRefinement(_Handle):
         c = Camera(*cam)
         _lib.check(self._lib.snk_pose_refine(self._h, C.byref(c), C.byref(self.options), probs, len(frames)), "snk_pose_refine")
         return [(np.array(P.pose[:]), k[2][: P.n].copy(), int(P.inliers)) for P, k in zip(probs, keep)]
+
+    def refine_matches_batch_dev(self, frames: FramesDev, depth, cam, pts, match_idx, n_pts, level_scale, poses, outlier, inliers):
+        """Device-resident RefinePoseWithMatches for a batch: frames = frames_dev(...), depth [B, cap] float32, pts [B, m_cap, stride]
+        uint8 (snk_lm_coarse / snk_lm_fine), match_idx [B, m_cap] int32 (a batched matcher's output), n_pts [B] int32, poses [B, 7]
+        float64 in / out, outlier [B, m_cap] uint8 out, inliers [B] int32 out.  Asynchronous on the handle's stream."""
+        ls = np.ascontiguousarray(level_scale, np.float32)
+        c = Camera(*cam)
+        _lib.check(self._lib.snk_pose_refine_matches_batch_dev(self._h, C.byref(frames), depth.data_ptr(), C.byref(c), C.byref(self.options),
+                                                               pts.data_ptr(), int(pts.shape[2]), match_idx.data_ptr(), n_pts.data_ptr(),
+                                                               int(pts.shape[1]), _ptr(ls), len(ls), poses.data_ptr(), outlier.data_ptr(),
+                                                               inliers.data_ptr()), "snk_pose_refine_matches_batch_dev")
 
     def refinePose(self, cam, pose, wps, obs, prediction=None, prediction_weight_rotation=0.0,
                    prediction_weight_translation=0.0):
