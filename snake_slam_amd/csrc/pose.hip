@@ -213,12 +213,20 @@ __device__ int chol_solve6(const double* A, const double* b, double* x)
     return 0;
 }
 
-__global__ __launch_bounds__(64) void pose_kernel(const PoseMeta* __restrict__ meta, const double* __restrict__ wps,
-                                                  const snk_pose_obs* __restrict__ obs, u8* __restrict__ outlier,
-                                                  double* __restrict__ pose_out, int* __restrict__ inliers_out, CamD cam,
-                                                  snk_pose_options opt)
+// WAVES wavefronts per frame: a match per thread and stride 64 * WAVES; the 27 sums of a step are reduced inside each
+// wavefront (fixed butterfly) and then across the wavefronts in order through LDS (two barriers per step).  One wavefront
+// per frame is right for a few dozen matches; with the ~770 matches a coarse tracking pass produces, one wavefront spends
+// 12 linearisations per lane and step behind each other (0.71 ms per 256 frames), four do three each.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void pose_kernel(const PoseMeta* __restrict__ meta, const double* __restrict__ wps,
+                                                          const snk_pose_obs* __restrict__ obs, u8* __restrict__ outlier,
+                                                          double* __restrict__ pose_out, int* __restrict__ inliers_out, CamD cam,
+                                                          snk_pose_options opt)
 {
-    const int lane    = threadIdx.x;
+    constexpr int STRIDE = 64 * WAVES;
+    __shared__ double s_part[WAVES][28];
+    const int lane    = threadIdx.x;  // thread of the frame's workgroup
+    const int wave    = threadIdx.x >> 6;
     const PoseMeta& M = meta[blockIdx.x];
     const int n       = M.n;
     const double* W   = wps + 3 * (long long)M.off;
@@ -227,7 +235,8 @@ __global__ __launch_bounds__(64) void pose_kernel(const PoseMeta* __restrict__ m
     double pose[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) pose[i] = M.pose[i];
-    for (int i = lane; i < n; i += 64) out[i] = 0;
+    for (int i = lane; i < n; i += STRIDE) out[i] = 0;
+    if (WAVES > 1) __syncthreads();
 
     int inliers = 0;
     for (int round = 0; round < opt.outer_iterations; ++round)
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(64) void pose_kernel(const PoseMeta* __restrict__ m
             for (int i = 0; i < 27; ++i) acc[i] = 0.0;
             double R[9];
             quat_to_R(pose, R);
-            for (int i = lane; i < n; i += 64)
+            for (int i = lane; i < n; i += STRIDE)
             {
                 if (out[i]) continue;
                 double r[3], J[18];
@@ -271,6 +280,22 @@ __global__ __launch_bounds__(64) void pose_kernel(const PoseMeta* __restrict__ m
             }
 #pragma unroll
             for (int i = 0; i < 27; ++i) acc[i] = wave_sum(acc[i]);
+            if (WAVES > 1)
+            {
+                if ((lane & 63) == 0)
+#pragma unroll
+                    for (int i = 0; i < 27; ++i) s_part[wave][i] = acc[i];
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 27; ++i)
+                {
+                    double v = s_part[0][i];
+#pragma unroll
+                    for (int w = 1; w < WAVES; ++w) v += s_part[w][i];
+                    acc[i] = v;
+                }
+                __syncthreads();
+            }
             double H[36], b[6];
             {
                 int u = 0;
@@ -310,7 +335,7 @@ __global__ __launch_bounds__(64) void pose_kernel(const PoseMeta* __restrict__ m
         double R[9];
         quat_to_R(pose, R);
         int cnt = 0;
-        for (int i = lane; i < n; i += 64)
+        for (int i = lane; i < n; i += STRIDE)
         {
             double r[3], J[18];
             const double p[3] = {W[3 * i], W[3 * i + 1], W[3 * i + 2]};
@@ -324,6 +349,15 @@ __global__ __launch_bounds__(64) void pose_kernel(const PoseMeta* __restrict__ m
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+        if (WAVES > 1)
+        {
+            if ((lane & 63) == 0) s_part[wave][27] = (double)cnt;
+            __syncthreads();  // also: every thread's flags of this round are written before the next round reads them
+            cnt = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) cnt += (int)s_part[w][27];
+            __syncthreads();
+        }
         inliers = cnt;
     }
     if (lane == 0)
@@ -465,10 +499,14 @@ extern "C" int snk_pose_refine(snk_matcher* m, const snk_camera* cam, const snk_
     char* o = m->out.as<char>();
     SNK_HIP_CHECK(hipMemcpyAsync(d, stage.data(), in_b, hipMemcpyHostToDevice, m->stream));
     CamD C{cam->fx, cam->fy, cam->cx, cam->cy, cam->bf};
-    hipLaunchKernelGGL(pose_kernel, dim3(n_problems), dim3(64), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
-                       reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),
-                       reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), reinterpret_cast<int*>(o + o_inl), C,
-                       *opt);
+    if (total >= (size_t)n_problems * 192)  // ~200 matches per frame and more: four wavefronts per frame
+        hipLaunchKernelGGL(pose_kernel<4>, dim3(n_problems), dim3(256), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
+                           reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),
+                           reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), reinterpret_cast<int*>(o + o_inl), C, *opt);
+    else
+        hipLaunchKernelGGL(pose_kernel<1>, dim3(n_problems), dim3(64), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
+                           reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),
+                           reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), reinterpret_cast<int*>(o + o_inl), C, *opt);
     SNK_LAUNCH_CHECK();
     std::string back(out_b, '\0');
     SNK_HIP_CHECK(hipMemcpyAsync(&back[0], o, out_b, hipMemcpyDeviceToHost, m->stream));
@@ -521,9 +559,14 @@ extern "C" int snk_pose_refine_matches_batch_dev(snk_matcher* m, const snk_frame
                        reinterpret_cast<PoseMeta*>(d), reinterpret_cast<double*>(d + o_wps), reinterpret_cast<snk_pose_obs*>(d + o_obs),
                        reinterpret_cast<int*>(d + o_slot));
     CamD C{cam->fx, cam->fy, cam->cx, cam->cy, cam->bf};
-    hipLaunchKernelGGL(pose_kernel, dim3(batch), dim3(64), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
-                       reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),
-                       reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), inliers_dev, C, *opt);
+    if (pts_cap >= 256)
+        hipLaunchKernelGGL(pose_kernel<4>, dim3(batch), dim3(256), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
+                           reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),
+                           reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), inliers_dev, C, *opt);
+    else
+        hipLaunchKernelGGL(pose_kernel<1>, dim3(batch), dim3(64), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
+                           reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),
+                           reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), inliers_dev, C, *opt);
     hipLaunchKernelGGL(scatter_pose_kernel, dim3(batch), dim3(64), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
                        reinterpret_cast<const double*>(o + o_pose), reinterpret_cast<const u8*>(o), reinterpret_cast<const int*>(d + o_slot),
                        pts_cap, poses_dev, outlier_dev, inliers_dev);
