@@ -201,6 +201,54 @@ __device__ __forceinline__ FrameDev frame_of(const FramesDev& B, int b)
     return F;
 }
 
+// A frame's arrays copied into the workgroup's LDS (dynamic, 16-byte aligned): every wavefront of the workgroup matches points of
+// the same frame and every window scan is a chain of dependent gathers (cell range -> keypoint -> flags -> descriptor) -- out of
+// LDS those cost tens of cycles instead of L2 round trips.  ~61 bytes per feature + 4 per grid cell: a 1 000-feature frame is 65 KB.
+__device__ __forceinline__ size_t frame_lds_bytes(int cap, int ncell1)
+{
+    return (((size_t)cap * 24 + 15) & ~(size_t)15) + (size_t)cap * 32 + (((size_t)cap * 4 + 15) & ~(size_t)15) + (((size_t)cap + 15) & ~(size_t)15) +
+           (size_t)ncell1 * 4;
+}
+__device__ __forceinline__ FrameDev stage_frame_lds(const FrameDev& G, unsigned char* lds, int nthreads)
+{
+    const int n = G.n, ncell1 = G.cols * G.rows + 1;
+    unsigned char* p_kps  = lds;
+    unsigned char* p_desc = p_kps + (((size_t)n * 24 + 15) & ~(size_t)15);
+    unsigned char* p_rp   = p_desc + (size_t)n * 32;
+    unsigned char* p_tk   = p_rp + (((size_t)n * 4 + 15) & ~(size_t)15);
+    unsigned char* p_cs   = p_tk + (((size_t)n + 15) & ~(size_t)15);
+    const int tid = threadIdx.x;
+    {
+        const u32* src = reinterpret_cast<const u32*>(G.kps);
+        u32* dst       = reinterpret_cast<u32*>(p_kps);
+        for (int i = tid; i < n * 6; i += nthreads) dst[i] = src[i];
+    }
+    {
+        const uint4* src = G.desc;
+        uint4* dst       = reinterpret_cast<uint4*>(p_desc);
+        for (int i = tid; i < n * 2; i += nthreads) dst[i] = src[i];
+    }
+    {
+        const float* src = G.right_points;
+        float* dst       = reinterpret_cast<float*>(p_rp);
+        for (int i = tid; i < n; i += nthreads) dst[i] = src[i];
+        u8* dt = p_tk;
+        for (int i = tid; i < n; i += nthreads) dt[i] = G.taken[i];
+    }
+    {
+        int* dst = reinterpret_cast<int*>(p_cs);
+        for (int i = tid; i < ncell1; i += nthreads) dst[i] = G.cell_start[i];
+    }
+    FrameDev F     = G;
+    F.kps          = reinterpret_cast<const snk_kp64*>(p_kps);
+    F.desc         = reinterpret_cast<const uint4*>(p_desc);
+    F.right_points = reinterpret_cast<const float*>(p_rp);
+    F.taken        = p_tk;
+    F.cell_start   = reinterpret_cast<const int*>(p_cs);
+    __syncthreads();
+    return F;
+}
+
 // Broadcast of one lane's value to the wavefront (the lane index is wave-uniform: it comes from a scalar bit scan).
 __device__ __forceinline__ double bcast_d(double v, int src)
 {
@@ -249,9 +297,9 @@ __device__ __forceinline__ void coarse_wave64(const FrameDev& F, const CamDev& C
     float r = th;
     r *= S.s[lvl];
     // results go through the wavefront's LDS slice (served in program order): default "no match", the group leaders overwrite
-    __shared__ int s_res[4][2][64];
-    int* my_res = s_res[(threadIdx.x >> 6) & 3][0];
-    int* my_bin = s_res[(threadIdx.x >> 6) & 3][1];
+    __shared__ int s_res[16][2][64];  // up to 16 wavefronts per workgroup (the frame-resident kernels)
+    int* my_res = s_res[(threadIdx.x >> 6) & 15][0];
+    int* my_bin = s_res[(threadIdx.x >> 6) & 15][1];
     my_res[lane] = -1;
     my_bin[lane] = 0;
     // Phase 2: a window holds a few dozen candidates, so 16 lanes share one and four points are scanned at a time
@@ -378,8 +426,8 @@ __device__ __forceinline__ void fine_wave64(const FrameDev& F, const CamDev& C, 
             }
         }
     }
-    __shared__ int s_resf[4][64];
-    int* my_res = s_resf[(threadIdx.x >> 6) & 3];
+    __shared__ int s_resf[16][64];
+    int* my_res = s_resf[(threadIdx.x >> 6) & 15];
     my_res[lane] = -1;
     const int grp = lane >> 4, sub = lane & 15;
     u64 todo = __builtin_amdgcn_ballot_w64(scan);
@@ -435,6 +483,39 @@ __global__ __launch_bounds__(256) void fine_batch_kernel(FramesDev Fb, const Cam
     const FrameDev F = frame_of(Fb, b);
     const CamDev C   = cams[b];
     fine_wave64(F, C, S, pts + (size_t)b * m_cap, m, i0, ppw, th, ratio, lane, best + (size_t)b * m_cap, visible + (size_t)b * m_cap);
+}
+
+// Frame-resident forms of the two batched matchers: 1024 threads (16 wavefronts, 1024 points) per workgroup, the frame in LDS.
+__global__ __launch_bounds__(1024) void coarse_frame_kernel(FramesDev Fb, const CamDev* __restrict__ cams, ScalesDev S,
+                                                            const snk_lm_coarse* __restrict__ pts, const int* __restrict__ m_dev,
+                                                            int m_cap, float th, int feature_error, int direction,
+                                                            int* __restrict__ best, int* __restrict__ bins)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char frame_lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int b = blockIdx.y, i0 = (blockIdx.x * 16 + wave) * 64;
+    const int m = min(m_dev[b], m_cap);
+    if (blockIdx.x * 1024 >= m) return;  // whole workgroup
+    const FrameDev F = stage_frame_lds(frame_of(Fb, b), frame_lds, 1024);
+    if (i0 >= m) return;
+    const CamDev C = cams[b];
+    coarse_wave64(F, C, S, pts + (size_t)b * m_cap, m, i0, 64, th, feature_error, direction, lane, best + (size_t)b * m_cap,
+                  bins + (size_t)b * m_cap);
+}
+
+__global__ __launch_bounds__(1024) void fine_frame_kernel(FramesDev Fb, const CamDev* __restrict__ cams, ScalesDev S,
+                                                          snk_lm_fine* __restrict__ pts, const int* __restrict__ m_dev, int m_cap, float th,
+                                                          float ratio, int* __restrict__ best, u8* __restrict__ visible)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char frame_lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int b = blockIdx.y, i0 = (blockIdx.x * 16 + wave) * 64;
+    const int m = min(m_dev[b], m_cap);
+    if (blockIdx.x * 1024 >= m) return;  // whole workgroup
+    const FrameDev F = stage_frame_lds(frame_of(Fb, b), frame_lds, 1024);
+    if (i0 >= m) return;
+    const CamDev C = cams[b];
+    fine_wave64(F, C, S, pts + (size_t)b * m_cap, m, i0, 64, th, ratio, lane, best + (size_t)b * m_cap, visible + (size_t)b * m_cap);
 }
 
 // first claimant (lowest local-map index) of every feature wins; coarse additionally applies the
@@ -1013,6 +1094,18 @@ __global__ __launch_bounds__(256) void relink_kernel(FrameDev F, CamDev C, const
 // Points per wavefront of the projection matchers: a wavefront does the per-point geometry for `ppw` points at once and then
 // visits them one after the other, so many points per wavefront save the redundant geometry, few keep the chip busy when the
 // points are few (one frame of the host API): aim for >= ~8 wavefronts per SIMD.
+constexpr int FRAME_LDS_MAX = 144 * 1024;  // LDS carve of the frame-resident matchers (one workgroup per CU above 80 KB)
+size_t frame_lds_host(int cap, int ncell1)
+{
+    return (((size_t)cap * 24 + 15) & ~(size_t)15) + (size_t)cap * 32 + (((size_t)cap * 4 + 15) & ~(size_t)15) + (((size_t)cap + 15) & ~(size_t)15) +
+           (size_t)ncell1 * 4 + 64;
+}
+bool no_frame_lds()
+{
+    static const bool v = getenv("SNK_TRACK_NO_FRAME_LDS") != nullptr;  // A/B: the batched matchers with global-memory gathers
+    return v;
+}
+
 int points_per_wave(long long total_points)
 {
     static const int forced = getenv("SNK_TRACK_PPW") ? atoi(getenv("SNK_TRACK_PPW")) : 0;  // tests: force a value
@@ -1358,8 +1451,16 @@ int snk_match_project_coarse_batch_dev(snk_matcher* m, const snk_frames_dev* fra
     int *best, *bins, *claim;
     if ((rc = batch_scratch(m, batch, pts_cap, F.cap, cam, poses_dev, &cams, &best, &bins, &claim)) != SNK_OK) return rc;
     const int ppw = points_per_wave((long long)pts_cap * batch);
-    hipLaunchKernelGGL(coarse_batch_kernel, dim3(ceil_div(pts_cap, 4 * ppw), batch), dim3(256), 0, m->stream, F, (const CamDev*)cams, S,
-                       pts_dev, n_pts_dev, pts_cap, ppw, th, feature_error, direction, best, bins);
+    const size_t flds = frame_lds_host(F.cap, F.cols * F.rows + 1);
+    if (ppw == 64 && flds <= FRAME_LDS_MAX && !no_frame_lds())
+    {
+        if ((rc = set_max_lds_once(reinterpret_cast<const void*>(coarse_frame_kernel), FRAME_LDS_MAX)) != SNK_OK) return rc;
+        hipLaunchKernelGGL(coarse_frame_kernel, dim3(ceil_div(pts_cap, 1024), batch), dim3(1024), flds, m->stream, F, (const CamDev*)cams,
+                           S, pts_dev, n_pts_dev, pts_cap, th, feature_error, direction, best, bins);
+    }
+    else
+        hipLaunchKernelGGL(coarse_batch_kernel, dim3(ceil_div(pts_cap, 4 * ppw), batch), dim3(256), 0, m->stream, F, (const CamDev*)cams, S,
+                           pts_dev, n_pts_dev, pts_cap, ppw, th, feature_error, direction, best, bins);
     hipLaunchKernelGGL(resolve_batch_kernel, dim3(batch), dim3(256), 0, m->stream, (const int*)best, (const int*)bins, n_pts_dev,
                        pts_cap, F, claim, 1, match_idx_dev, n_matches_dev);
     SNK_LAUNCH_CHECK();
@@ -1387,8 +1488,16 @@ int snk_match_project_fine_batch_dev(snk_matcher* m, const snk_frames_dev* frame
     if ((rc = batch_scratch(m, batch, pts_cap, F.cap, cam, poses_dev, &cams, &best, &bins, &claim)) != SNK_OK) return rc;
     SNK_HIP_CHECK(hipMemsetAsync(visible_dev, 0, (size_t)batch * pts_cap, m->stream));
     const int ppw = points_per_wave((long long)pts_cap * batch);
-    hipLaunchKernelGGL(fine_batch_kernel, dim3(ceil_div(pts_cap, 4 * ppw), batch), dim3(256), 0, m->stream, F, (const CamDev*)cams, S,
-                       pts_dev, n_pts_dev, pts_cap, ppw, th, ratio, best, visible_dev);
+    const size_t flds = frame_lds_host(F.cap, F.cols * F.rows + 1);
+    if (ppw == 64 && flds <= FRAME_LDS_MAX && !no_frame_lds())
+    {
+        if ((rc = set_max_lds_once(reinterpret_cast<const void*>(fine_frame_kernel), FRAME_LDS_MAX)) != SNK_OK) return rc;
+        hipLaunchKernelGGL(fine_frame_kernel, dim3(ceil_div(pts_cap, 1024), batch), dim3(1024), flds, m->stream, F, (const CamDev*)cams, S,
+                           pts_dev, n_pts_dev, pts_cap, th, ratio, best, visible_dev);
+    }
+    else
+        hipLaunchKernelGGL(fine_batch_kernel, dim3(ceil_div(pts_cap, 4 * ppw), batch), dim3(256), 0, m->stream, F, (const CamDev*)cams, S,
+                           pts_dev, n_pts_dev, pts_cap, ppw, th, ratio, best, visible_dev);
     hipLaunchKernelGGL(resolve_batch_kernel, dim3(batch), dim3(256), 0, m->stream, (const int*)best, (const int*)nullptr, n_pts_dev,
                        pts_cap, F, claim, 0, match_idx_dev, n_matches_dev);
     SNK_LAUNCH_CHECK();
