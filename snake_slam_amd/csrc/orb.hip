@@ -768,42 +768,34 @@ __global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* _
     for (int k = 0; k < 7; ++k) pr[k][0] = pr[k][1] = pr[k][2] = pr[k][3] = 0;
 
     static_assert(SM_ROWS % 14 == 0, "two 7-row blocks per iteration keep the row-parity slots static");
+    // Rolling prefetch: row k + 7 is requested into the register row k just left (branch-free: every lane loads an aligned
+    // dword from a clamped column, rows past the band are clamped too; lanes on the image border are patched per row, border
+    // strips only), so seven row loads are ALWAYS in flight -- the first version requested a block of seven rows, waited for
+    // them, worked through them and only then asked for the next seven.
+    auto row_load = [&](int k) -> u32
+    {
+        const int y = min(yb0 - 3 + k, lv.h + 2);
+        if (aligned) return *reinterpret_cast<const u32*>(src + (u32)(reflect101(y, lv.h) * pitch) + (u32)xsafe);
+        const u8* rp = src + reflect101(y, lv.h) * pitch;
+        return (u32)rp[xr0] | ((u32)rp[xr1] << 8) | ((u32)rp[xr2] << 16) | ((u32)rp[xr3] << 24);
+    };
+    u32 dn[7];
+#pragma unroll
+    for (int kk = 0; kk < 7; ++kk) dn[kk] = row_load(kk);
     for (int k00 = 0; k00 < SM_ROWS; k00 += 14)
 #pragma unroll
     for (int half = 0; half < 2; ++half)
     {
         const int k0 = k00 + 7 * half;
-        // The 7 row loads of a block are issued together and branch-free (a divergent branch around a
-        // load makes the compiler wait for it inside the branch): every lane loads an aligned dword
-        // from a clamped column; lanes on the image border are patched per row (border strips only).
-        u32 dn[7];
-        if (aligned)  // wave-uniform
-        {
-#pragma unroll
-            for (int kk = 0; kk < 7; ++kk)
-            {
-                const int y  = min(yb0 - 3 + k0 + kk, lv.h + 2);
-                dn[kk]       = *reinterpret_cast<const u32*>(src + (u32)(reflect101(y, lv.h) * pitch) + (u32)xsafe);
-            }
-        }
-        else
-        {
-#pragma unroll
-            for (int kk = 0; kk < 7; ++kk)
-            {
-                const int y  = min(yb0 - 3 + k0 + kk, lv.h + 2);
-                const u8* rp = src + reflect101(y, lv.h) * pitch;
-                dn[kk] = (u32)rp[xr0] | ((u32)rp[xr1] << 8) | ((u32)rp[xr2] << 16) | ((u32)rp[xr3] << 24);
-            }
-        }
 #pragma unroll
         for (int kk = 0; kk < 7; ++kk)
         {
             const int k = k0 + kk;
             const int y = yb0 - 3 + k;
+            u32 d  = dn[kk];
+            dn[kk] = row_load(min(k + 7, SM_ROWS - 1));
             if (y <= yb1 + 2)  // wave-uniform
             {
-                u32 d = dn[kk];
                 if (border_strip)
                 {
                     const u32 pa = (u32)__builtin_amdgcn_ds_bpermute(pull_a, (int)d), pb = (u32)__builtin_amdgcn_ds_bpermute(pull_b, (int)d);
