@@ -35,7 +35,6 @@ W, H = 752, 480
 ORB = dict(nfeatures=1000, scale_factor=1.2, n_levels=4, ini_th_fast=20, min_th_fast=7)  # reference configs/euroc.ini:32-36
 BF_SYNTH = 47.9 * 2.5  # bf such that the synthetic disparities (2..60 px) fall inside [0, bf/2]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-N_DISTINCT = 8         # distinct synthetic stereo pairs, tiled to fill the batch
 
 
 def pyramid_pixels():
@@ -211,6 +210,8 @@ def main():
                     help="batch = the headline throughput benchmark (default); sequence = BASELINE.json config 5: every rank walks its "
                          "own synthetic stereo sequence frame by frame through the host entry points (one step = one frame per rank) "
                          "and the ranks' TUM trajectories are gathered with one all_gather")
+    ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic stereo pairs / BA scenes per rank (0 = all of them: every "
+                    "frame of the batch and every BA window is its own seeded scene; n = n of each, tiled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events")
     args = ap.parse_args()
@@ -219,18 +220,26 @@ def main():
         W, H = 1241, 376
         ORB = dict(nfeatures=2000, scale_factor=1.2, n_levels=7, ini_th_fast=20, min_th_fast=7)
 
+    from snake_slam_amd import parallel, synth
+
+    env_rank, _, local = parallel.env_rank_world()
+    # Synthetic inputs first (worker processes are forked here, before this process owns a HIP context): EVERY frame of the batch
+    # and EVERY BA window is its own seeded scene, so the data-dependent kernels (FAST survivors, quadtree, stereo bands, the
+    # camera-set grouping of BA) see B / NW different workloads, not a handful tiled.
+    n_dpairs = min(args.batch, args.distinct) if args.distinct > 0 else args.batch
+    n_dscenes = min(args.ba_windows, args.distinct) if args.distinct > 0 else args.ba_windows
+    frames, ba_distinct = [], []
+    if args.mode == "batch":
+        frames = synth.stereo_frames([env_rank * args.batch + i for i in range(n_dpairs)], W, H)
+        ba_distinct = synth.ba_scenes([synth.SEED + 1000 * env_rank + k for k in range(n_dscenes)])
+
     import torch
 
-    from snake_slam_amd import parallel
-
-    _, _, local = parallel.env_rank_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     rank, world = parallel.init_distributed(dev)  # "nccl" = RCCL over xGMI; used for barrier + result gather only
-
-    from snake_slam_amd import synth
 
     if args.mode == "sequence":
         sequence_mode(args, rank, world, local, dev)
@@ -242,12 +251,11 @@ def main():
     from snake_slam_amd.tracking import FeatureGrid
 
     B = args.batch
-    # ---- synthetic frames (seeded; a few distinct pairs tiled over the batch), resident in HBM ----
-    frames = [synth.stereo_frame(rank * N_DISTINCT + i, W, H) for i in range(N_DISTINCT)]
+    # ---- synthetic frames (seeded, generated above), resident in HBM ----
     pitch = (W + 63) & ~63
     host = np.zeros((2 * B, H, pitch), np.uint8)  # [0,B): left images, [B,2B): right images
     for b in range(B):
-        l, r = frames[b % N_DISTINCT]
+        l, r = frames[b % n_dpairs]
         host[b, :, :W] = l
         host[B + b, :, :W] = r
     images = torch.from_numpy(host).to(dev)
@@ -319,9 +327,9 @@ def main():
         from snake_slam_amd.ba import BARec, lba_options
 
         NW, LM_IT = args.ba_windows, 3
-        distinct = [synth.ba_scene(seed=synth.SEED + 1000 * rank + k)[0] for k in range(4)]
+        distinct = ba_distinct
         ba = BARec(lba_options(), device=local, stream=sh)
-        ba.create([distinct[k % 4] for k in range(NW)])
+        ba.create([distinct[k % n_dscenes] for k in range(NW)])
         with torch.cuda.stream(stream):
             for _ in range(max(1, args.warmup)):
                 ba.reset()
@@ -353,7 +361,8 @@ def main():
                   "value": round(world * NW * LM_IT * args.steps / float(tba.item()), 1), "unit": "LM iterations/s",
                   "windows_per_gpu_per_step": NW, "ms_per_step": round(float(tba.item()) / args.steps * 1e3, 4),
                   "single_window_ms_per_solve": round((tl1 - tl0) / 10 * 1e3, 4),
-                  "cost_initial": round(float(ci[0]), 3), "cost_final": round(float(cf[0]), 3), "dtype": "f64"}
+                  "cost_initial": round(float(ci[0]), 3), "cost_final": round(float(cf[0]), 3), "dtype": "f64",
+                  "data": f"synthetic: {n_dscenes} distinct seeded scenes per rank over {NW} windows"}
         # ~5.65 MB algorithmic per LM iteration of the 20 x 2000 x 8 window
         ba_out["roofline"] = {"bound": "hbm", "algorithmic_bytes_per_lm_iteration": 5650000,
                               "achieved": round(5.65e6 * ba_out["value"] / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -532,7 +541,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": f"synthetic: seeded {W}x{H} stereo pairs (gradient + 400 rectangles + noise), {N_DISTINCT} distinct pairs tiled over the batch, resident in HBM",
+            "data": f"synthetic: seeded {W}x{H} stereo pairs (gradient + 400 rectangles + noise), {n_dpairs} distinct pairs per rank over a batch of {B}, resident in HBM",
             "config": {"workload": ("EuRoC" if args.workload == "euroc" else "KITTI") + f" stereo {W}x{H}: ORB extract (L+R, {ORB['nfeatures']} feat, {ORB['n_levels']} levels) + stereo row-band match + BF kNN-2 Hamming match",
                        "frames_per_gpu_per_step": B, "images_per_frame": 2, "orb": ORB,
                        "parallelism": f"{world} x independent batches (one per GPU), RCCL all_gather of results only"},

@@ -132,3 +132,29 @@ class BARec:
         out = np.zeros(max(n, 1), np.float64)
         _lib.check(self._lib.snk_ba_residuals(self._h, problem, C.c_void_p(out.ctypes.data)), "snk_ba_residuals")
         return out[:n]
+
+
+def gba_options(max_iterations=4, max_pcg_iterations=40, pcg_tol=1e-10, huber_mono=2.1, huber_stereo=2.3, lambda_init=0.0):
+    """global_op_options / global_ba_options of the reference (GlobalBundleAdjustment.cpp:32-43)."""
+    return BaOptions(max_iterations, max_pcg_iterations, pcg_tol, huber_mono, huber_stereo, lambda_init)
+
+
+class BAPointOnly(BARec):
+    """`Saiga::BAPointOnly` as GlobalBundleAdjustment::PointBA uses it (GlobalBundleAdjustment.cpp:103-122): create(scene),
+    initAndSolve() -- world points optimised, every camera held.  [DEFINED] (the solver lives in the absent saiga): the same
+    robust LM iteration as BARec ("snk-ba v1") on the scene with every image constant; the reduced camera system is then
+    empty and each point solves its own damped 3x3 system."""
+
+    def create(self, scene_or_scenes) -> None:
+        scenes = scene_or_scenes if isinstance(scene_or_scenes, (list, tuple)) else [scene_or_scenes]
+        super().create([dict(s, img_const=np.ones(len(s["pose"]), np.uint8)) for s in scenes])
+
+
+class BAPoseOnly(BARec):
+    """`Saiga::BAPoseOnly` as GlobalBundleAdjustment::RealignIntermiediateFrames uses it (GlobalBundleAdjustment.cpp:306-316):
+    camera poses optimised (constant images stay), every world point held.  [DEFINED]: the same LM iteration as BARec on the
+    scene with every point constant; the reduced system is then block diagonal (one 6x6 block per free camera)."""
+
+    def create(self, scene_or_scenes) -> None:
+        scenes = scene_or_scenes if isinstance(scene_or_scenes, (list, tuple)) else [scene_or_scenes]
+        super().create([dict(s, pt_const=np.ones(len(s["pt"]), np.uint8)) for s in scenes])

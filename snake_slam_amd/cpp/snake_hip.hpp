@@ -512,9 +512,11 @@ class BARec
         p.n_pt       = (int)scene.points.size();
         p.n_obs      = (int)scene.obs_image.size();
         p.pose       = reinterpret_cast<double(*)[7]>(scene.poses.data());
-        p.img_const  = scene.image_constant.data();
         p.pt         = reinterpret_cast<double(*)[3]>(scene.points.data());
-        p.pt_const   = scene.point_constant.data();
+        // BAPointOnly holds every image, BAPoseOnly every point (GlobalBundleAdjustment.cpp:103-122, 306-316)
+        all_const_.assign(std::max(scene.poses.size(), scene.points.size()) + 1, 1);
+        p.img_const  = hold_images_ ? all_const_.data() : scene.image_constant.data();
+        p.pt_const   = hold_points_ ? all_const_.data() : scene.point_constant.data();
         p.obs_img    = scene.obs_image.data();
         p.obs_pt     = scene.obs_point.data();
         p.obs_uv     = reinterpret_cast<const double(*)[2]>(scene.obs_pixel.data());
@@ -547,10 +549,38 @@ class BARec
         return chi2;
     }
 
+   protected:
+    bool hold_images_ = false, hold_points_ = false;
+
    private:
     int device_;
     snk_ba* h_    = nullptr;
     Scene* scene_ = nullptr;
+    std::vector<uint8_t> all_const_;
+};
+
+// Saiga::BAPointOnly as GlobalBundleAdjustment::PointBA uses it (GlobalBundleAdjustment.cpp:103-122): create(scene),
+// initAndSolve() -- world points optimised, every camera held.  [DEFINED]: the BARec iteration with every image constant.
+class BAPointOnly : public BARec
+{
+   public:
+    explicit BAPointOnly(int device = 0) : BARec(device)
+    {
+        optimizationOptions = {4, 40, 1e-10, 2.1, 2.3, 0.0};  // GlobalBundleAdjustment.cpp:32-43
+        hold_images_        = true;
+    }
+};
+
+// Saiga::BAPoseOnly as RealignIntermiediateFrames uses it (GlobalBundleAdjustment.cpp:306-316): camera poses optimised, every
+// world point held.  [DEFINED]: the BARec iteration with every point constant.
+class BAPoseOnly : public BARec
+{
+   public:
+    explicit BAPoseOnly(int device = 0) : BARec(device)
+    {
+        optimizationOptions = {4, 40, 1e-10, 2.1, 2.3, 0.0};
+        hold_points_        = true;
+    }
 };
 
 // ------------------------------------------------------------------------------------------------

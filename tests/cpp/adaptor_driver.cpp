@@ -171,6 +171,25 @@ int main(int argc, char** argv)
             wr("out_ba_cost2", std::vector<double>{r2.cost_initial, r2.cost_final, (double)n_out});
             wr("out_ba_outlier", sc.obs_outlier);
             wr("out_ba_pose2", sc.poses);
+            // GlobalBundleAdjustment::PointBA (:103-122) and the BAPoseOnly of RealignIntermiediateFrames (:306-316), each from
+            // the scene as it was read
+            Scene sp = sc;
+            sp.poses  = rd<std::array<double, 7>>("ba_pose");
+            sp.points = rd<std::array<double, 3>>("ba_pt");
+            sp.obs_outlier.clear();
+            Scene sq = sp;
+            BAPointOnly pba;
+            pba.create(sp);
+            const OptimizationResults rp = pba.initAndSolve();
+            wr("out_pba_pt", sp.points);
+            wr("out_pba_pose", sp.poses);
+            wr("out_pba_cost", std::vector<double>{rp.cost_initial, rp.cost_final});
+            BAPoseOnly qba;
+            qba.create(sq);
+            const OptimizationResults rq = qba.initAndSolve();
+            wr("out_qba_pt", sq.points);
+            wr("out_qba_pose", sq.poses);
+            wr("out_qba_cost", std::vector<double>{rq.cost_initial, rq.cost_final});
         }
     }
     catch (const std::exception& e)

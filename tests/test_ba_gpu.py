@@ -285,3 +285,29 @@ def test_handles_release_their_device_memory(orc):
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 8 << 20, (free0 - free1) >> 20  # a leak of the small tables alone was ~1.5 MB per cycle
+
+
+def test_point_only_and_pose_only_adaptors_at_global_scale(orc):
+    """`BAPointOnly` / `BAPoseOnly` (reference Snake/Optimizer/GlobalBundleAdjustment.cpp:103-122, 306-316) on a global-BA
+    sized scene (200 keyframes, 8000 points): the adaptors hold every image / every point of the scene handed to create()
+    and leave the caller's scene untouched; result = the oracle on the scene with those flags set."""
+    from snake_slam_amd import synth
+    from snake_slam_amd.ba import BAPointOnly, BAPoseOnly, gba_options
+
+    sc, _ = synth.ba_scene(n_kf=200, n_pt=8000, obs_per_pt=8, seed=71, n_fixed=1)
+    for cls, hold in ((BAPointOnly, "img_const"), (BAPoseOnly, "pt_const")):
+        ba = cls(gba_options())
+        ba.create(sc)
+        ci, cf = ba.initAndSolve()
+        pose, pt, _ = ba.state(0)
+        ba.close()
+        assert not sc["pt_const"].any() and int(sc["img_const"].sum()) == 1  # caller's flags untouched
+        held = dict(sc)
+        held[hold] = np.ones_like(sc[hold])
+        wpose, wpt, wci, wcf, _ = orc.ba_solve(held, orc.ba_options(4, 40))
+        assert abs(ci[0] - wci) <= 1e-9 * wci and abs(cf[0] - wcf) <= 1e-7 * wcf and cf[0] < 0.6 * ci[0]
+        assert rmse(pose, wpose) <= TOL and rmse(pt, wpt) <= TOL
+        if hold == "img_const":
+            assert np.array_equal(pose, sc["pose"])
+        else:
+            assert np.array_equal(pt, sc["pt"])

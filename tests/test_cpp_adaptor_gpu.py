@@ -111,3 +111,17 @@ def test_cpp_adaptor_runs_the_pipeline_and_matches_golden(tmp_path, orc):
     c2 = get("ba_cost2", np.float64)
     assert int(c2[2]) == int(outl.sum()) and np.allclose(c2[:2], [wc0, wc1], rtol=1e-7)
     assert rm(get("ba_pose2", np.float64).reshape(-1, 7), wpose) <= 1e-5
+    # BAPointOnly / BAPoseOnly (GlobalBundleAdjustment.cpp:103-122, 306-316): the oracle on the scene with every image /
+    # every point held, global options (4 iterations, PCG <= 40)
+    s0 = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
+    for tag, hold in (("pba", "img_const"), ("qba", "pt_const")):
+        sh = dict(s0)
+        sh[hold] = np.ones_like(s0[hold])
+        wpose, wpt, wc0, wc1, _ = orc.ba_solve(sh, orc.ba_options(4, 40, 1e-10, 2.1, 2.3, 0.0))
+        assert np.allclose(get(f"{tag}_cost", np.float64), [wc0, wc1], rtol=1e-7) and wc1 < wc0
+        gp, gq = get(f"{tag}_pose", np.float64).reshape(-1, 7), get(f"{tag}_pt", np.float64).reshape(-1, 3)
+        assert rm(gp, wpose) <= 1e-5 and rm(gq, wpt) <= 1e-5
+        if hold == "img_const":
+            assert np.array_equal(gp, s0["pose"]) and not np.array_equal(gq, s0["pt"])
+        else:
+            assert np.array_equal(gq, s0["pt"]) and not np.array_equal(gp, s0["pose"])

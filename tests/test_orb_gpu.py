@@ -308,7 +308,7 @@ def test_unaligned_device_images_take_the_byte_path(orc):
 def test_candidate_budget_is_inactive_on_every_bench_frame(workload):
     """the per-cell top-64 / level_cap (8192) candidate budget is this repository's definition, not
     ORB-SLAM2's; the claim that it has no effect on ordinary images is checked here on every synthetic frame bench.py
-    uses (8 distinct stereo pairs per workload): no FAST cell holds more than 64 candidates and no level more than 8192,
+    uses (one distinct stereo pair per frame of the batch; the first 64 of each workload are checked here): no FAST cell holds more than 64 candidates and no level more than 8192,
     so the budget never truncates and the result is the un-budgeted algorithm's."""
     from snake_slam_amd import orb as O
     from snake_slam_amd import synth
@@ -319,8 +319,8 @@ def test_candidate_budget_is_inactive_on_every_bench_frame(workload):
         w, h, prm = 1241, 376, (2000, 1.2, 7, 20, 7)
     ext = O.ORBExtractor(*prm)
     worst_cell, worst_level = 0, 0
-    for i in range(8):
-        for img in synth.stereo_frame(i, w, h):
+    for pair in synth.stereo_frames(range(64), w, h):
+        for img in pair:
             ext.Detect(img)
             for l in range(prm[2]):
                 cnt = ext.debug_fetch(O.DEBUG_CELL_COUNTS, 0, l, np.uint16)
