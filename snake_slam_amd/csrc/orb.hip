@@ -126,7 +126,7 @@ struct Layout
     int total_units;
     int level_cap;
     // per-wavefront LDS slice of fast_kernel (bytes; sized from the largest cell of the layout)
-    int f_tile_pitch_dw, f_s_pitch, f_off_s, f_off_surv, f_off_list, f_off_cnt, f_lds_wave;
+    int f_tile_pitch_dw, f_s_pitch, f_off_s, f_off_surv, f_off_list, f_off_cnt, f_lds_wave, f_surv_cap;
     const int4* cell_tab;  // [total_cells] (x0, y0, cw | ch << 16, level) of every FAST cell: one scalar load instead of a level search and two integer divisions per cell
     LevelInfo lv[MAX_LEVELS];
 };
@@ -467,10 +467,60 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
     const u8* tile = reinterpret_cast<const u8*>(tile_dw);
     if (dbg_stop == 1) return;  // SNK_ORB_FAST_STOP (timing experiments only, results are then meaningless): after the tile load
 
+    // phase B: exact score of the survivors, two per lane
+    auto score_survivors = [&](int ns)
+    {
+    for (int j = lane * 2; j < ns; j += 128)
+    {
+        const int e0 = surv[j], e1 = surv[j + 1 < ns ? j + 1 : j];
+        const int px0 = e0 & 63, py0 = e0 >> 6, px1 = e1 & 63, py1 = e1 >> 6;
+        const u8* t0 = tile + (py0 + 3) * TP + px0 + 3 + sh;
+        const u8* t1 = tile + (py1 + 3) * TP + px1 + 3 + sh;
+        short2_t s;
+        if constexpr (NQ != 0)
+        {
+            u32 r[16];
+#define RING(i, dx, dy) r[i] = (u32)t0[(dy)*TP + (dx)] | ((u32)t1[(dy)*TP + (dx)] << 16);
+            RING(0, 0, 3) RING(1, 1, 3) RING(2, 2, 2) RING(3, 3, 1) RING(4, 3, 0) RING(5, 3, -1) RING(6, 2, -2) RING(7, 1, -3)
+            RING(8, 0, -3) RING(9, -1, -3) RING(10, -2, -2) RING(11, -3, -1) RING(12, -3, 0) RING(13, -3, 1) RING(14, -2, 2)
+            RING(15, -1, 3)
+#undef RING
+            s = fast_score16_raw(r, (u32)t0[0] | ((u32)t1[0] << 16));
+        }
+        else
+        {
+            const short v0 = t0[0], v1 = t1[0];
+            short2_t d[16];
+#define RING(i, dx, dy) d[i] = short2_t{(short)(t0[(dy)*TP + (dx)] - v0), (short)(t1[(dy)*TP + (dx)] - v1)};
+            RING(0, 0, 3) RING(1, 1, 3) RING(2, 2, 2) RING(3, 3, 1) RING(4, 3, 0) RING(5, 3, -1) RING(6, 2, -2) RING(7, 1, -3)
+            RING(8, 0, -3) RING(9, -1, -3) RING(10, -2, -2) RING(11, -3, -1) RING(12, -3, 0) RING(13, -3, 1) RING(14, -2, 2)
+            RING(15, -1, 3)
+#undef RING
+            s = fast_score16_pk(d);
+        }
+        S[(py0 + 1) * SP + px0 + 1] = (u8)(s.x < 0 ? 0 : s.x);
+        if (j + 1 < ns) S[(py1 + 1) * SP + px1 + 1] = (u8)(s.y < 0 ? 0 : s.y);
+    }
+    };
+
     // phase A: every 9-arc holds one pixel of each opposite pair -> S <= min_i max(d_i, d_{i+8}).  The loops
     // are wave-uniform (lanes outside the cell are predicated), so the running survivor count lives in a
     // scalar register: position = count + prefix population of the ballot, no LDS atomic.
+    // The survivor list holds surv_cap entries (half of the largest cell, >= 256), not one per pixel: the LDS slice of a
+    // wavefront decides how many cells a compute unit works on at once.  A cell with more survivors than that (noise, dense
+    // texture) scores the list whenever the next step might not fit and starts it again; the non-maximum pass then walks the
+    // score map instead of the list.  Same scores, same corners, either way.
     int ns = 0;
+    bool spilled        = false;
+    const int surv_cap = L.f_surv_cap;
+    auto flush = [&]()
+    {
+        __builtin_amdgcn_wave_barrier();
+        score_survivors(ns);
+        __builtin_amdgcn_wave_barrier();
+        ns      = 0;
+        spilled = true;
+    };
     const int lpy = lane >> 5, lpx = lane & 31;
     if constexpr (NQ != 0)
     {
@@ -506,10 +556,15 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
                 ns += __popcll(mh);
             };
             int py0 = 0;
-            for (; py0 + 4 <= ch; py0 += 4, t += 4 * TP, code += 256u) step(inx, mx, inx, mx);
+            for (; py0 + 4 <= ch; py0 += 4, t += 4 * TP, code += 256u)
+            {
+                if (ns + 128 > surv_cap) flush();  // wave-uniform
+                step(inx, mx, inx, mx);
+            }
             const int rem = ch - py0;  // 0..3 rows left: low halves hold rows py0 + lpy, high halves py0 + lpy + 2
             if (rem > 0)
             {
+                if (ns + 128 > surv_cap) flush();
                 const u64 lanes_lo = rem >= 2 ? ~0ull : 0xFFFFFFFFull, lanes_hi = rem >= 3 ? 0xFFFFFFFFull : 0ull;
                 step(inx && lpy < rem, mx & lanes_lo, inx && lpy + 2 < rem, mx & lanes_hi);
             }
@@ -543,62 +598,51 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
                 ns += __popcll(m);
             };
             int py0 = 0;
-            for (; py0 + 2 <= ch; py0 += 2, t += 2 * TP, code += 128u) step(inx, mx);
-            if (py0 < ch) step(inx && lpy == 0, mlo);
+            for (; py0 + 2 <= ch; py0 += 2, t += 2 * TP, code += 128u)
+            {
+                if (ns + 64 > surv_cap) flush();  // wave-uniform
+                step(inx, mx);
+            }
+            if (py0 < ch)
+            {
+                if (ns + 64 > surv_cap) flush();
+                step(inx && lpy == 0, mlo);
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
     if (dbg_stop == 2) return;  // after the quick test
 
-    // phase B: exact score of the survivors, two per lane
-    for (int j = lane * 2; j < ns; j += 128)
-    {
-        const int e0 = surv[j], e1 = surv[j + 1 < ns ? j + 1 : j];
-        const int px0 = e0 & 63, py0 = e0 >> 6, px1 = e1 & 63, py1 = e1 >> 6;
-        const u8* t0 = tile + (py0 + 3) * TP + px0 + 3 + sh;
-        const u8* t1 = tile + (py1 + 3) * TP + px1 + 3 + sh;
-        short2_t s;
-        if constexpr (NQ != 0)
-        {
-            u32 r[16];
-#define RING(i, dx, dy) r[i] = (u32)t0[(dy)*TP + (dx)] | ((u32)t1[(dy)*TP + (dx)] << 16);
-            RING(0, 0, 3) RING(1, 1, 3) RING(2, 2, 2) RING(3, 3, 1) RING(4, 3, 0) RING(5, 3, -1) RING(6, 2, -2) RING(7, 1, -3)
-            RING(8, 0, -3) RING(9, -1, -3) RING(10, -2, -2) RING(11, -3, -1) RING(12, -3, 0) RING(13, -3, 1) RING(14, -2, 2)
-            RING(15, -1, 3)
-#undef RING
-            s = fast_score16_raw(r, (u32)t0[0] | ((u32)t1[0] << 16));
-        }
-        else
-        {
-            const short v0 = t0[0], v1 = t1[0];
-            short2_t d[16];
-#define RING(i, dx, dy) d[i] = short2_t{(short)(t0[(dy)*TP + (dx)] - v0), (short)(t1[(dy)*TP + (dx)] - v1)};
-            RING(0, 0, 3) RING(1, 1, 3) RING(2, 2, 2) RING(3, 3, 1) RING(4, 3, 0) RING(5, 3, -1) RING(6, 2, -2) RING(7, 1, -3)
-            RING(8, 0, -3) RING(9, -1, -3) RING(10, -2, -2) RING(11, -3, -1) RING(12, -3, 0) RING(13, -3, 1) RING(14, -2, 2)
-            RING(15, -1, 3)
-#undef RING
-            s = fast_score16_pk(d);
-        }
-        S[(py0 + 1) * SP + px0 + 1] = (u8)(s.x < 0 ? 0 : s.x);
-        if (j + 1 < ns) S[(py1 + 1) * SP + px1 + 1] = (u8)(s.y < 0 ? 0 : s.y);
-    }
+    score_survivors(ns);
     __builtin_amdgcn_wave_barrier();
 
     if (dbg_stop == 3) return;  // after the exact scores
     // 3x3 non-max suppression (strict) among scores above min_th (all of them are survivors); the list of
     // corners is appended the same way (wave-uniform loop, ballot prefix, counts in scalar registers)
     int nl = 0, nini = 0;
-    for (int j0 = 0; j0 < ns; j0 += 64)
+    const int n_items = spilled ? ch * 64 : ns;  // spilled: every (row, lane = column) of the cell
+    for (int j0 = 0; j0 < n_items; j0 += 64)
     {
         const int j  = j0 + lane;
-        const int e  = surv[min(j, ns - 1)];
+        int e;
+        bool valid;
+        if (spilled)
+        {
+            e     = j0 | min(lane, cw - 1);  // (py << 6) | px
+            valid = lane < cw;
+        }
+        else
+        {
+            e     = surv[min(j, ns - 1)];
+            valid = j < ns;
+        }
         const int px = e & 63, py = e >> 6;
         const u8* s  = &S[(py + 1) * SP + px + 1];
         // all nine reads in one go (a short-circuit chain is nine dependent LDS round trips under divergent branches)
         const int v = s[0], n0 = s[-1], n1 = s[1], n2 = s[-SP - 1], n3 = s[-SP], n4 = s[-SP + 1], n5 = s[SP - 1], n6 = s[SP],
                   n7 = s[SP + 1];
         const int nmax  = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
-        const bool keep = j < ns && v > min_th && v > nmax;
+        const bool keep = valid && v > min_th && v > nmax;
         const u64 m = __builtin_amdgcn_ballot_w64(keep);
         // strength key: higher score first, then smaller y, then smaller x
         if (keep)
@@ -1731,12 +1775,19 @@ static int compute_layout(snk_orb* o, int w, int h)
         else if (L.f_tile_pitch_dw <= 16 && L.f_s_pitch <= 64 && mh + 6 <= 128) { L.f_tile_pitch_dw = 16; L.f_s_pitch = 64; }
         const int tile_b  = up16((mh + 6) * L.f_tile_pitch_dw * 4);
         const int s_b     = up16((mh + 2) * L.f_s_pitch) + 16;  // zero-filled in 16-byte stores
-        const int surv_b  = up16(mw * mh * 2);
+        // survivors of the quick test kept at a time (fast_kernel scores and restarts the list when a cell has more); the
+        // override is for the tests that force the spill path on ordinary images
+        L.f_surv_cap = (mw * mh / 2 + 63) & ~63;  // measured: 0.60 / 0.55 / 0.50 / 0.485 / 0.54 ms at 320 / 384 / 512 / 640 / all pixels
+        if (L.f_surv_cap < 256) L.f_surv_cap = 256;
+        if (const char* e = getenv("SNK_ORB_FAST_SURV_CAP")) L.f_surv_cap = atoi(e) < 128 ? 128 : atoi(e);
+        const int surv_b  = up16(L.f_surv_cap * 2);
         const int list_b  = up16(((mw + 1) / 2) * ((mh + 1) / 2) * 4);
+        // the list of non-maximum-suppression survivors is written after the last read of the image tile: same bytes
+        SNK_REQUIRE(list_b <= tile_b, "FAST: corner list larger than the tile it aliases");
         L.f_off_s    = tile_b;
         L.f_off_surv = L.f_off_s + s_b;
-        L.f_off_list = L.f_off_surv + surv_b;
-        L.f_off_cnt  = L.f_off_list + list_b;
+        L.f_off_list = 0;
+        L.f_off_cnt  = L.f_off_surv + surv_b;
         L.f_lds_wave = L.f_off_cnt + 16;
     }
     return SNK_OK;

@@ -329,3 +329,22 @@ def test_candidate_budget_is_inactive_on_every_bench_frame(workload):
     ext.close()
     assert 0 < worst_cell <= 64, worst_cell
     assert worst_level <= 8192, worst_level
+
+
+@pytest.mark.skipif(__import__("os").environ.get("SNK_ORB_NO_RECURSE") == "1", reason="child run")
+def test_fast_survivor_list_spill_path_on_ordinary_images():
+    """fast_kernel keeps a bounded list of quick-test survivors per cell (half of the cell's pixels) and, when a cell
+    has more, scores the list and starts it again; non-maximum suppression then walks the score map.  Noise images take that
+    path by themselves; here the whole ORB parity file runs again in a child process with the list forced down to 128 entries
+    (SNK_ORB_FAST_SURV_CAP), so that ordinary images -- every stage compared with the oracle -- take it as well."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, "-m", "pytest", str(root / "tests" / "test_orb_gpu.py"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "not budget_is_inactive"],
+                       env=dict(os.environ, SNK_ORB_FAST_SURV_CAP="128", SNK_ORB_NO_RECURSE="1"), capture_output=True, text=True, cwd=str(root), timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-1000:])
+    assert " passed" in r.stdout
