@@ -923,8 +923,11 @@ __device__ __forceinline__ u64 point_key(int x, int y, int W, int H, int nroots)
     int x0 = (int)(((u32)root * uw + un - 1u) / un), x1 = (int)(((u32)(root + 1) * uw + un - 1u) / un);
     int y0 = 0, y1 = H;
     u64 key = (u64)root;
-#pragma unroll
-    for (int d = 0; d < KEY_DIGITS; ++d)
+    // A node's extent at least halves (rounded up) per level, so after nd = ceil(log2(max(W, H))) levels it is one pixel in both
+    // axes and every further digit is 0 (the midpoint of [x, x + 1) is x + 1): the loop stops there, the rest is a shift.
+    const int ext = max(max(W, H), 2);
+    const int nd  = min(KEY_DIGITS, 32 - __clz(ext - 1));
+    for (int d = 0; d < nd; ++d)
     {
         const int mx = x0 + (x1 - x0 + 1) / 2, my = y0 + (y1 - y0 + 1) / 2;
         const int cx = x >= mx, cy = y >= my;
@@ -934,7 +937,7 @@ __device__ __forceinline__ u64 point_key(int x, int y, int W, int H, int nroots)
         y1 = cy ? y1 : my;
         key = (key << 2) | (u64)(cx + 2 * cy);
     }
-    return key;  // 8 + 32 bits
+    return key << (2 * (KEY_DIGITS - nd));  // 8 + 32 bits
 }
 
 // Bitonic sort of n_pow2 keys in LDS (ascending), all threads of the block participate.  Every wavefront
@@ -1027,6 +1030,70 @@ __device__ int block_scan_incl(int v, int tid, int* wave_tot /* >= 8 */)
     return x + base;
 }
 
+// Sort of n distinct subdivision keys (step 3 of distribute_body) by BUCKET + RANK instead of a comparison network.  The bitonic
+// network does 1024 compare-exchanges in each of 66 stages for 2048 keys and is bound by exactly that work (51 k cycles per
+// workgroup with four workgroups per compute unit, a third of the kernel; holding the keys in registers with lane shuffles did not
+// help: 59 k).  The keys are quadtree paths, so their leading digits spread the points evenly: bucket = root and the first T digits
+// (at most nb_max buckets), one LDS atomic per key counts the buckets, one scan places them, one more atomic per key lists the
+// members, and a key's final position is its bucket's start plus the number of smaller keys in the bucket (a handful; at most the
+// candidates of the few FAST cells a bucket's region overlaps).  Distinct keys: the result does not depend on the atomics' order.
+// tmp: cap * 4 bytes (the node list of the careful phase, free at this point): u16 idx[n] | int hist[nb + 1].
+__device__ void bucket_rank_sort(u64* keys, int n, int cap, int nroots, unsigned char* tmp, int tid, int* wave_tot)
+{
+    u16* idx  = reinterpret_cast<u16*>(tmp);
+    int* hist = reinterpret_cast<int*>(tmp + 2 * cap);
+    const int nb_max = min(1023, cap / 2 - 1);
+    int T = 4;
+    while (T > 0 && (nroots << (2 * T)) > nb_max) --T;
+    const int nb    = nroots << (2 * T);  // nroots <= 255 <= nb_max for every carve this is called with (cap >= 512)
+    const int shift = 13 + 32 - 2 * T;    // key = (root << 32 | 16 digits) << 13 | slot
+    for (int i = tid; i <= nb; i += DIST_THREADS) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += DIST_THREADS) atomicAdd(&hist[(int)(keys[i] >> shift)], 1);
+    __syncthreads();
+    {
+        // exclusive scan of the bucket counts, two buckets per thread
+        const int b0 = 2 * tid, c0 = b0 < nb ? hist[b0] : 0, c1 = b0 + 1 < nb ? hist[b0 + 1] : 0;
+        const int incl = block_scan_incl(c0 + c1, tid, wave_tot);
+        if (b0 < nb) hist[b0] = incl - c0 - c1;
+        if (b0 + 1 < nb) hist[b0 + 1] = incl - c1;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += DIST_THREADS) idx[atomicAdd(&hist[(int)(keys[i] >> shift)], 1)] = (u16)i;
+    __syncthreads();
+    // hist[b] is now the END of bucket b.  At most four keys per thread (n <= 2048): rank them, then move them.
+    u64 mine[4];
+    int dest[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+    {
+        const int i = tid + u * DIST_THREADS;
+        mine[u] = 0;
+        dest[u] = -1;
+        if (i < n)
+        {
+            const u64 k = keys[i];
+            const int b = (int)(k >> shift);
+            const int s = b > 0 ? hist[b - 1] : 0, e = hist[b];
+            int r       = s;
+            int q       = s;
+            for (; q + 2 <= e; q += 2)  // two members in flight
+            {
+                const u64 a0 = keys[idx[q]], a1 = keys[idx[q + 1]];
+                r += (a0 < k ? 1 : 0) + (a1 < k ? 1 : 0);
+            }
+            if (q < e) r += keys[idx[q]] < k ? 1 : 0;
+            mine[u] = k;
+            dest[u] = r;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (dest[u] >= 0) keys[dest[u]] = mine[u];
+    __syncthreads();
+}
+
 // Dynamic LDS carve (cap = level_cap, a power of two):
 //   keys  u64[cap]      sort keys: subdivision key << 13 | candidate slot
 //   nodes u64[cap/2]    careful-phase node list
@@ -1039,7 +1106,8 @@ __device__ int block_scan_incl(int v, int tid, int* wave_tot /* >= 8 */)
 __device__ bool distribute_body(const Layout& L, int b, int l, int lds_cap, const u32* __restrict__ cand,
                                 const u16* __restrict__ cell_cnt, u32* __restrict__ sel /* [B][total_slots] x|y<<16 */,
                                 u8* __restrict__ sel_score, int* __restrict__ sel_cnt,
-                                int* __restrict__ cand_total /* debug: [B][levels] */)
+                                int* __restrict__ cand_total /* debug: [B][levels] */,
+                                unsigned long long* __restrict__ dbg_t = nullptr /* SNK_ORB_DIST_TIMING: [levels][16] cycle sums */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int cap     = lds_cap;      // LDS carve of this launch
@@ -1056,6 +1124,16 @@ __device__ bool distribute_body(const Layout& L, int b, int l, int lds_cap, cons
     __shared__ int s_n, s_k, s_D, s_careful, s_size, s_nnodes, s_finish, s_jstar, s_out;
 
     const int tid = threadIdx.x;
+    unsigned long long t_prev = dbg_t ? __builtin_readcyclecounter() : 0ull;
+    auto mark = [&](int phase)  // SNK_ORB_DIST_TIMING (diagnostic): cycles of thread 0 since the previous mark
+    {
+        if (dbg_t && tid == 0)
+        {
+            const unsigned long long t = __builtin_readcyclecounter();
+            atomicAdd(&dbg_t[l * 16 + phase], t - t_prev);
+            t_prev = t;
+        }
+    };
     const LevelInfo& lv = L.lv[l];
     const int ncell = lv.ncols * lv.nrows;
     const int N     = lv.nfeat;
@@ -1080,6 +1158,7 @@ __device__ bool distribute_body(const Layout& L, int b, int l, int lds_cap, cons
     }
     const int kcell = s_k;
     const int n     = s_n;
+    mark(0);
     if (n > cap) return false;
     if (tid == 0 && cand_total) cand_total[b * MAX_LEVELS + l] = n;
     if (n == 0 || N <= 0)
@@ -1104,21 +1183,28 @@ __device__ bool distribute_body(const Layout& L, int b, int l, int lds_cap, cons
             {
                 const int ci = c / lv.ncols, cj = c - ci * lv.ncols;
                 const int x0 = EDGE_THRESHOLD + cj * lv.wcell, y0 = EDGE_THRESHOLD + ci * lv.hcell;
-                // 8 slots in flight per thread (a slot-by-slot walk paid a full memory latency per slot)
+                // 32 slots in flight per thread (a full cell is two memory latencies; slot by slot it was 64, in eights 8)
                 const uint4* cq = reinterpret_cast<const uint4*>(cd + (long long)c * CELL_SLOTS);
-                for (int i = 0; i < cnt; i += 8)
+                for (int i = 0; i < cnt; i += 32)
                 {
-                    const uint4 q0 = cq[i >> 2], q1 = cq[(i >> 2) + 1];
-                    const u32 kk[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                    uint4 q[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (i + u < cnt)
-                        {
-                            const u32 k = kk[u];
-                            px[off + i + u] = (u16)(x0 + 63 - (int)(k & 63u));
-                            py[off + i + u] = (u16)(y0 + 63 - (int)((k >> 6) & 63u));
-                            sc[off + i + u] = (u8)(k >> 12);
-                        }
+                    for (int v = 0; v < 8; ++v) q[v] = i + 4 * v < cnt ? cq[(i >> 2) + v] : uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int v = 0; v < 8; ++v)
+                    {
+                        const u32 kk[4] = {q[v].x, q[v].y, q[v].z, q[v].w};
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (i + 4 * v + u < cnt)
+                            {
+                                const u32 k = kk[u];
+                                const int o = off + i + 4 * v + u;
+                                px[o] = (u16)(x0 + 63 - (int)(k & 63u));
+                                py[o] = (u16)(y0 + 63 - (int)((k >> 6) & 63u));
+                                sc[o] = (u8)(k >> 12);
+                            }
+                    }
                 }
             }
             if (tid == DIST_THREADS - 1) s_out = incl;
@@ -1127,13 +1213,19 @@ __device__ bool distribute_body(const Layout& L, int b, int l, int lds_cap, cons
             __syncthreads();
         }
     }
+    mark(1);
     const int W = lv.w - 2 * MIN_BORDER, H = lv.h - 2 * MIN_BORDER;
     for (int i = tid; i < n_pow2; i += DIST_THREADS)
         keys[i] = i < n ? ((point_key(px[i] - MIN_BORDER, py[i] - MIN_BORDER, W, H, lv.nroots) << 13) | (u64)i) : ~0ull;
     __syncthreads();
 
+    mark(2);
     // ---- 3. sort by subdivision key -------------------------------------------------------------
-    bitonic_sort(keys, n_pow2, tid, DIST_THREADS);
+    if (n <= 4 * DIST_THREADS && cap >= 512)
+        bucket_rank_sort(keys, n, cap, lv.nroots, reinterpret_cast<unsigned char*>(nodes), tid, wave_tot);
+    else
+        bitonic_sort(keys, n_pow2, tid, DIST_THREADS);  // the full-budget launch (levels with > 2048 candidates)
+    mark(3);
 
     // ---- 4. common-prefix lengths and the per-depth node statistics ------------------------------
     if (tid < 20)
@@ -1164,6 +1256,7 @@ __device__ bool distribute_body(const Layout& L, int b, int l, int lds_cap, cons
     }
     __syncthreads();
 
+    mark(4);
     // ---- 5. replay ORB-SLAM2's split passes on the statistics (one thread, <= 16 steps) -----------
     if (tid == 0)
     {
@@ -1201,9 +1294,128 @@ __device__ bool distribute_body(const Layout& L, int b, int l, int lds_cap, cons
     for (int i = tid; i < n; i += DIST_THREADS) fd[i] = (u8)D;
     __syncthreads();
 
+    mark(5);
     // ---- 6. careful phase: split the fullest nodes first until N nodes exist ----------------------
-    if (s_careful)
+    if (s_careful && n <= 4 * DIST_THREADS)
     {
+        // Rounds without a sorted node list (thread t owns positions 4 t .. 4 t + 3, at most four node heads, kept in registers): "the fullest nodes
+        // first, ties by position, until N nodes exist" only needs the count class c* in which the running total reaches N --
+        // a histogram of the new-node counts by point count and one suffix scan -- and, inside that class, a prefix over the
+        // heads in position order.  Sorting the nodes (a bitonic network per round) was 27 % of the kernel.
+        int* hist = reinterpret_cast<int*>(nodes);  // cap / 2 * 8 bytes = cap ints >= n - 1 entries (count c at c - 2)
+        const int HN = n - 1;
+        for (int dd = D; dd < KEY_DIGITS; ++dd)
+        {
+            for (int k = tid; k < HN; k += DIST_THREADS) hist[k] = 0;
+            if (tid == 0) s_jstar = HN;  // "the total never reaches N"
+            if (dbg_t && tid == 0) atomicAdd(&dbg_t[l * 16 + 14], 1ull);  // rounds
+            __syncthreads();
+            int cntv[4], delv[4];
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+            {
+                const int i = 4 * tid + u;
+                cntv[u] = delv[u] = 0;
+                if (i < n && fd[i] == dd && (int)lcp[i] < dd)
+                {
+                    int e = i + 1, delta = 0;
+                    for (;;)
+                    {
+                        // four entries per LDS round trip (lcp has 16 bytes of slack behind entry n; entries at or behind
+                        // n are cut by the index test)
+                        const int l0 = lcp[e], l1 = lcp[e + 1], l2 = lcp[e + 2], l3 = lcp[e + 3];
+                        const bool c0 = e < n && l0 >= dd, c1 = c0 && e + 1 < n && l1 >= dd, c2 = c1 && e + 2 < n && l2 >= dd,
+                                   c3 = c2 && e + 3 < n && l3 >= dd;
+                        delta += (c0 && l0 == dd ? 1 : 0) + (c1 && l1 == dd ? 1 : 0) + (c2 && l2 == dd ? 1 : 0) + (c3 && l3 == dd ? 1 : 0);
+                        e += (c0 ? 1 : 0) + (c1 ? 1 : 0) + (c2 ? 1 : 0) + (c3 ? 1 : 0);
+                        if (!c3) break;
+                    }
+                    if (e - i > 1)
+                    {
+                        cntv[u] = e - i;
+                        delv[u] = delta;
+                        any     = true;
+                        if (delta) atomicAdd(&hist[e - i - 2], delta);
+                    }
+                }
+            }
+            mark(8);
+            if (!__syncthreads_or(any ? 1 : 0)) break;  // no node with more than one point left
+            mark(9);
+            // suffix sums over the count classes, fullest first: k = 0 is count n, entry HN - 1 - k
+            int before_mine = 0;
+            {
+                int loc[4], sum = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                {
+                    const int k = 4 * tid + u;
+                    loc[u]      = k < HN ? hist[HN - 1 - k] : 0;
+                    sum += loc[u];
+                }
+                const int incl = block_scan_incl(sum, tid, wave_tot);
+                int run        = s_size + incl - sum;  // nodes before this thread's first class
+                int found      = -1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                {
+                    if (found < 0 && loc[u] > 0 && run + loc[u] >= N) { found = 4 * tid + u; before_mine = run; }
+                    run += loc[u];
+                }
+                if (found >= 0) atomicMin(&s_jstar, found);
+                if (tid == DIST_THREADS - 1) s_out = run - s_size;  // new nodes if every node is split
+            }
+            __syncthreads();
+            mark(10);
+            const int kstar = s_jstar;
+            if (kstar < HN && 4 * tid <= kstar && kstar < 4 * tid + 4) s_nnodes = before_mine;  // running total above class c*
+            __syncthreads();
+            const int cstar  = kstar < HN ? HN - 1 - kstar + 2 : 0;  // 0: every node is split
+            const int before = kstar < HN ? s_nnodes : 0;
+            int my_add = 0;
+            bool split[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) split[u] = cntv[u] > 0 && (cstar == 0 || cntv[u] > cstar);
+            if (cstar != 0)  // wave-uniform: the ties of class c* in position order, until the total reaches N
+            {
+                int d[4], sum = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                {
+                    d[u] = cntv[u] == cstar ? delv[u] : 0;
+                    sum += d[u];
+                }
+                int run = before + block_scan_incl(sum, tid, wave_tot) - sum;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                {
+                    if (cntv[u] == cstar && run < N) split[u] = true;
+                    run += d[u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (split[u]) my_add += delv[u];
+            mark(11);
+            const int add = block_scan_incl(my_add, tid, wave_tot);
+            if (tid == DIST_THREADS - 1)
+            {
+                s_finish = (s_size + add >= N || add == 0) ? 1 : 0;
+                s_size += add;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (split[u])
+                    for (int e = 4 * tid + u, e1 = e + cntv[u]; e < e1; ++e) fd[e] = (u8)(dd + 1);
+            __syncthreads();
+            mark(12);
+            if (s_finish) break;
+        }
+    }
+    else if (s_careful)
+    {
+        // the full-budget launch (more than 2048 candidates): sorted node list
         // round r works on nodes of depth dd = D + r whose points have fd == dd ("active")
         for (int dd = D; dd < KEY_DIGITS; ++dd)
         {
@@ -1254,12 +1466,17 @@ __device__ bool distribute_body(const Layout& L, int b, int l, int lds_cap, cons
             const int jstar = s_jstar;
             const int last  = jstar < m ? jstar : m - 1;  // nodes 0..last are split
             // size after this round
-            if (tid == 0)
             {
-                int add = 0;
-                for (int j = 0; j <= last; ++j) add += (int)(nodes[j] & 0xFFFFu);
-                s_finish = (s_size + add >= N || add == 0) ? 1 : 0;
-                s_size += add;
+                // nodes created by this round's splits: block-wide sum (one thread walking the list paid an LDS round trip
+                // per node)
+                int part = 0;
+                for (int j = tid; j <= last; j += DIST_THREADS) part += (int)(nodes[j] & 0xFFFFu);
+                const int add = block_scan_incl(part, tid, wave_tot);
+                if (tid == DIST_THREADS - 1)
+                {
+                    s_finish = (s_size + add >= N || add == 0) ? 1 : 0;
+                    s_size += add;
+                }
             }
             for (int j = tid; j <= last; j += DIST_THREADS)
             {
@@ -1277,42 +1494,50 @@ __device__ bool distribute_body(const Layout& L, int b, int l, int lds_cap, cons
     }
     __syncthreads();
 
+    mark(6);
     // ---- 7. one keypoint per final node: highest score, then smallest y, then smallest x ----------
+    // Every point knows its node's output slot without looking for the node's head: slot = number of node heads at or before
+    // it (the block scan of the head flags), and the winner of a node is an LDS atomic maximum of the packed priority
+    // score | 0xFFFF - y | 0xFFFF - x, which also carries everything the output needs -- no walk along the node's points.
     {
         u32* out    = sel + (long long)b * L.total_slots + lv.slot_off;
         u8* out_sc  = sel_score + (long long)b * L.total_slots + lv.slot_off;
+        // the priorities replace the keys in place; after that the node list and the coordinate arrays are dead and their
+        // 8 * cap contiguous bytes (nodes | px | py) hold one winner slot per possible node (<= n <= cap)
+        for (int i = tid; i < n; i += DIST_THREADS)
+        {
+            const int c = (int)(keys[i] & 0x1FFFu);
+            keys[i]     = ((u64)sc[c] << 32) | ((u64)(0xFFFFu - py[c]) << 16) | (u64)(0xFFFFu - px[c]);
+        }
+        __syncthreads();
+        unsigned long long* best = reinterpret_cast<unsigned long long*>(nodes);
+        const int best_cap = min(n, lv.slot_cap);
+        for (int k = tid; k < best_cap; k += DIST_THREADS) best[k] = 0ull;
+        __syncthreads();
         int base = 0;
         for (int i0 = 0; i0 < n; i0 += DIST_THREADS)
         {
-            const int i    = i0 + tid;
+            const int i     = i0 + tid;
             const bool head = i < n && (int)lcp[i] < (int)fd[i];
             const int incl  = block_scan_incl(head ? 1 : 0, tid, wave_tot);
-            if (head)
-            {
-                const int depth = fd[i];
-                int best = (int)(keys[i] & 0x1FFFu);
-                int e    = i + 1;
-                while (e < n && (int)lcp[e] >= depth)
-                {
-                    const int c = (int)(keys[e] & 0x1FFFu);
-                    if (sc[c] > sc[best] || (sc[c] == sc[best] && (py[c] < py[best] || (py[c] == py[best] && px[c] < px[best]))))
-                        best = c;
-                    ++e;
-                }
-                const int pos = base + incl - 1;
-                if (pos < lv.slot_cap)
-                {
-                    out[pos]    = (u32)px[best] | ((u32)py[best] << 16);
-                    out_sc[pos] = sc[best];
-                }
-            }
+            const int pos   = base + incl - 1;
+            if (i < n && pos < best_cap) atomicMax(&best[pos], (unsigned long long)keys[i]);
             if (tid == DIST_THREADS - 1) s_out = incl;
             __syncthreads();
             base += s_out;
             __syncthreads();
         }
-        if (tid == 0) *out_cnt = base < lv.slot_cap ? base : lv.slot_cap;
+        const int count = base < lv.slot_cap ? base : lv.slot_cap;
+        for (int k = tid; k < count; k += DIST_THREADS)
+        {
+            const unsigned long long w = best[k];
+            out[k]    = (0xFFFFu - (u32)(w & 0xFFFFu)) | ((0xFFFFu - (u32)((w >> 16) & 0xFFFFu)) << 16);
+            out_sc[k] = (u8)(w >> 32);
+        }
+        if (tid == 0) *out_cnt = count;
     }
+    mark(7);
+    if (dbg_t && tid == 0) atomicAdd(&dbg_t[l * 16 + 15], (unsigned long long)n);
     return true;
 }
 
@@ -1320,10 +1545,11 @@ __device__ bool distribute_body(const Layout& L, int b, int l, int lds_cap, cons
 __global__ __launch_bounds__(DIST_THREADS) void distribute_kernel(Layout L, int lds_cap, const u32* __restrict__ cand,
                                                                   const u16* __restrict__ cell_cnt, u32* __restrict__ sel,
                                                                   u8* __restrict__ sel_score, int* __restrict__ sel_cnt,
-                                                                  int* __restrict__ cand_total, int* __restrict__ queue)
+                                                                  int* __restrict__ cand_total, int* __restrict__ queue,
+                                                                  unsigned long long* __restrict__ dbg_t)
 {
     const int l = blockIdx.x, b = blockIdx.y;
-    if (!distribute_body(L, b, l, lds_cap, cand, cell_cnt, sel, sel_score, sel_cnt, cand_total) && threadIdx.x == 0)
+    if (!distribute_body(L, b, l, lds_cap, cand, cell_cnt, sel, sel_score, sel_cnt, cand_total, dbg_t) && threadIdx.x == 0)
         queue[1 + atomicAdd(&queue[0], 1)] = b * MAX_LEVELS + l;
 }
 
@@ -2113,10 +2339,32 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
     }
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[3], st));
     SNK_HIP_CHECK(hipMemsetAsync(d_queue, 0, sizeof(int), st));
+    // SNK_ORB_DIST_TIMING=1 (diagnostic): cycle sums per phase and level, printed after a synchronisation
+    static const bool dist_timing = getenv("SNK_ORB_DIST_TIMING") != nullptr;
+    unsigned long long* d_dbg = nullptr;
+    if (dist_timing)
+    {
+        SNK_HIP_CHECK(hipMalloc(&d_dbg, MAX_LEVELS * 16 * sizeof(unsigned long long)));
+        SNK_HIP_CHECK(hipMemsetAsync(d_dbg, 0, MAX_LEVELS * 16 * sizeof(unsigned long long), st));
+    }
     hipLaunchKernelGGL(distribute_kernel, dim3(L.n_levels, batch), dim3(DIST_THREADS), o->dist_lds_small, st, L,
                        o->dist_small_cap, d_cand, d_cellcnt, d_sel, d_selscore,
-                       d_selcnt, d_candtot, d_queue);
+                       d_selcnt, d_candtot, d_queue, d_dbg);
     SNK_LAUNCH_CHECK();
+    if (dist_timing)
+    {
+        unsigned long long h[MAX_LEVELS * 16];
+        SNK_HIP_CHECK(hipStreamSynchronize(st));
+        SNK_HIP_CHECK(hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost));
+        SNK_HIP_CHECK(hipFree(d_dbg));
+        for (int l = 0; l < L.n_levels; ++l)
+        {
+            fprintf(stderr, "[dist timing] level %d (avg candidates %.0f, %.2f careful rounds), cycles per workgroup:", l,
+                    (double)h[l * 16 + 15] / batch, (double)h[l * 16 + 14] / batch);
+            for (int ph = 0; ph < 13; ++ph) fprintf(stderr, " %.0f", (double)h[l * 16 + ph] / batch);
+            fprintf(stderr, "\n");
+        }
+    }
     if (o->dist_small_cap < L.level_cap)
     {
         const int workers = L.n_levels * batch < 256 ? L.n_levels * batch : 256;
