@@ -1961,6 +1961,29 @@ __device__ void inv6_spd(const double* Ain, int lda, double* Ai)
     }
 }
 
+// Sum over the 64 lanes of a double, returned to every lane, without the LDS: four DPP butterflies inside each row of 16 lanes
+// (two 32-bit moves per step), then the four row sums are read back with v_readlane and added in a fixed order.  The
+// __shfl_xor tree above is twelve dependent ds_bpermute round trips per sum.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane64(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double wave_sum64_dpp(double v)
+{
+    v += dpp_mov64<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov64<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov64<0x141>(v);  // row_half_mirror
+    v += dpp_mov64<0x140>(v);  // row_mirror
+    return (readlane64(v, 0) + readlane64(v, 16)) + (readlane64(v, 32) + readlane64(v, 48));
+}
+
 constexpr int PCG_THREADS = 256;
 // dynamic LDS: r, z, p, Ap (n6 each) | partial sums (4 * n6) | Minv (nfc*36) | S (n6*n6, when s_in_lds)
 // S_IN_LDS is a template parameter, not an argument: with `S = s_in_lds ? Sl : Sg` the matvec read S through a generic
@@ -2013,6 +2036,141 @@ __global__ __launch_bounds__(PCG_THREADS) void pcg_solve(Arrays A, Opt O)
     double rz = block_sum<PCG_THREADS>(part, red, tid);
     double rn2 = bnorm2;  // |r|^2 of the current residual (x = 0: r = rhs); later iterations get it with r.z in one reduction
     const double stop2 = O.pcg_tol * O.pcg_tol * bnorm2;
+    if constexpr (S_IN_LDS)
+        if (n6 <= 128)
+        {
+            // Local-BA sized systems (<= 21 free cameras).  Every wavefront holds the WHOLE iteration state in registers (two
+            // rows per lane: r, p, x, its rows of the block-Jacobi inverse) and runs the same arithmetic on it, so the four
+            // wavefronts never have to tell each other anything except their quarter of S p: each multiplies its column
+            // quarter (two rows of S per ds_read2st64_b64 -- a wavefront can only keep ~16 LDS operations outstanding, the
+            // number of instructions is what counts), the four partial products meet in a double-buffered LDS block, and that
+            // is the ONE workgroup barrier of the iteration.  The private copies of r and p that the preconditioner and the
+            // product read back from LDS are per wavefront (program order, no barrier), the scalar products are DPP sums.
+            // The general form below pays seven barriers and five LDS trees per iteration: 3.4 us against ~1.
+            __syncthreads();
+            const int wave = tid >> 6, lane = tid & 63;
+            const bool v0 = lane < n6, v1 = lane + 64 < n6;
+            const int q0 = v0 ? lane : 0, q1 = v1 ? lane + 64 : 0;
+            double r0 = v0 ? r[q0] : 0.0, r1 = v1 ? r[q1] : 0.0;
+            double p0 = v0 ? p[q0] : 0.0, p1 = v1 ? p[q1] : 0.0;
+            double x0 = 0.0, x1 = 0.0;
+            const int c0 = q0 / 6, c1 = q1 / 6;
+            double m0[6], m1[6];
+#pragma unroll
+            for (int b = 0; b < 6; ++b)
+            {
+                m0[b] = v0 ? Mi[c0 * 36 + (q0 - c0 * 6) * 6 + b] : 0.0;
+                m1[b] = v1 ? Mi[c1 * 36 + (q1 - c1 * 6) * 6 + b] : 0.0;
+            }
+            __syncthreads();                  // everybody has read r / p: the vector block is re-used
+            double* rw = r + wave * n6;       // r, z, p, Ap: 4 * n6 doubles -> one private r per wavefront
+            double* pw = ps + wave * n6;      // ps: 4 * n6 doubles -> one private p per wavefront
+            double* ex = Sl + n6 * n6 + 128;  // [2][4][128] partial products (behind S and its read padding)
+            if (v0) pw[q0] = p0;
+            if (v1) pw[q1] = p1;
+            // this wavefront's column quarter (even bounds: p is read two columns at a time)
+            const int cb = (((n6 + 3) >> 2) + 1) & ~1;
+            const int ub = min(wave * cb, n6), ue = min(ub + cb, n6);
+            const double* Sq = Sl + lane;
+            int iters = 0, par = 0;
+            for (int k = 0; k < O.max_pcg; ++k)
+            {
+                if (rn2 <= stop2) break;  // the same decision in every wavefront (identical arithmetic)
+                double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0;
+                struct Blk
+                {
+                    double a[8], b[8], pu[8];
+                };
+                auto load = [&](Blk& B, int u)
+                {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                    {
+                        const double* row = Sq + (u + e) * n6;
+                        B.a[e]            = row[0];
+                        B.b[e]            = row[64];  // rows that do not exist read what follows (padding) and are masked
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2)
+                    {
+                        const double2 pv = *reinterpret_cast<const double2*>(pw + u + e);  // 16-byte aligned: n6, u even
+                        B.pu[e]          = pv.x;
+                        B.pu[e + 1]      = pv.y;
+                    }
+                };
+                auto proc = [&](const Blk& B)
+                {
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2)
+                    {
+                        s0 += B.a[e] * B.pu[e];
+                        s1 += B.b[e] * B.pu[e];
+                        t0 += B.a[e + 1] * B.pu[e + 1];
+                        t1 += B.b[e + 1] * B.pu[e + 1];
+                    }
+                };
+                const int nblk = (ue - ub) >> 3;
+                Blk B0, B1;
+                if (nblk > 0) load(B0, ub);
+                for (int kb = 0; kb < nblk; kb += 2)
+                {
+                    if (kb + 1 < nblk) load(B1, ub + 8 * (kb + 1));
+                    proc(B0);
+                    if (kb + 1 < nblk)
+                    {
+                        if (kb + 2 < nblk) load(B0, ub + 8 * (kb + 2));
+                        proc(B1);
+                    }
+                }
+                for (int u = ub + 8 * nblk; u < ue; ++u)
+                {
+                    const double pu = pw[u];
+                    s0 += Sq[u * n6] * pu;
+                    s1 += Sq[u * n6 + 64] * pu;
+                }
+                double* exw = ex + par * 512;
+                exw[wave * 128 + lane]      = v0 ? s0 + t0 : 0.0;
+                exw[wave * 128 + 64 + lane] = v1 ? s1 + t1 : 0.0;
+                __syncthreads();
+                s0  = (exw[lane] + exw[128 + lane]) + (exw[256 + lane] + exw[384 + lane]);
+                s1  = (exw[64 + lane] + exw[192 + lane]) + (exw[320 + lane] + exw[448 + lane]);
+                par ^= 1;
+                const double pAp = wave_sum64_dpp(p0 * s0 + p1 * s1);  // p is 0 in rows that do not exist
+                if (pAp <= 0.0) break;
+                const double alpha = rz / pAp;
+                x0 += alpha * p0;
+                x1 += alpha * p1;
+                r0 = v0 ? r0 - alpha * s0 : 0.0;
+                r1 = v1 ? r1 - alpha * s1 : 0.0;
+                if (v0) rw[q0] = r0;
+                if (v1) rw[q1] = r1;
+                __builtin_amdgcn_wave_barrier();
+                double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+                for (int b = 0; b < 6; ++b)
+                {
+                    z0 += m0[b] * rw[c0 * 6 + b];
+                    z1 += m1[b] * rw[c1 * 6 + b];
+                }
+                const double rz_new = wave_sum64_dpp(r0 * z0 + r1 * z1);
+                rn2                 = wave_sum64_dpp(r0 * r0 + r1 * r1);
+                const double beta   = rz_new / rz;
+                rz                  = rz_new;
+                p0                  = z0 + beta * p0;
+                p1                  = z1 + beta * p1;
+                if (v0) pw[q0] = p0;
+                if (v1) pw[q1] = p1;
+                __builtin_amdgcn_wave_barrier();
+                ++iters;
+            }
+            if (wave == 0)
+            {
+                if (v0) x[q0] = x0;
+                if (v1) x[q1] = x1;
+                if (lane == 0) A.state[pb].pcg_iters += iters;
+            }
+            return;
+        }
     // matvec split: `parts` threads share a row, each a contiguous column chunk (fixed combine order)
     int parts = PCG_THREADS / n6;
     parts     = parts < 1 ? 1 : (parts > 4 ? 4 : parts);
@@ -3278,8 +3436,9 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L)
     const dim3 gpt(std::max(1, ceil_div(h->max_np, 128)), B);
     size_t pcg_lds        = (size_t)h->max_n6 * 9 * 8 + (size_t)h->max_nfc * 36 * 8;
     const size_t s_bytes  = (size_t)h->max_n6 * h->max_n6 * 8;
-    const int s_in_lds    = pcg_lds + s_bytes <= 158 * 1024 ? 1 : 0;
-    if (s_in_lds) pcg_lds += s_bytes;
+    // + 128 doubles read padding behind S (rows lane and lane + 64 are read unmasked) + [2][4][128] partial products
+    const int s_in_lds    = pcg_lds + s_bytes + 1024 + 8192 <= 158 * 1024 ? 1 : 0;
+    if (s_in_lds) pcg_lds += s_bytes + 1024 + 8192;
     for (int it = 0; it < iterations; ++it)
     {
         static const bool no_wave = getenv("SNK_BA_NO_POINT_WAVE") != nullptr;
