@@ -2011,9 +2011,28 @@ __global__ __launch_bounds__(PCG_THREADS) void pcg_solve(Arrays A, Opt O)
     const double* rhs = A.rhs + pr.vec_off;
     double* x         = A.x + pr.vec_off;
     if (n6 == 0) return;
-    if (s_in_lds)
-        for (int i = tid; i < n6 * n6; i += PCG_THREADS) Sl[i] = Sg[i];
-    for (int c = tid; c < nfc; c += PCG_THREADS) inv6_spd(Sg + (size_t)(c * 6) * n6 + c * 6, n6, Mi + c * 36);
+    if constexpr (S_IN_LDS)
+    {
+        // S to LDS with sixteen 16-byte loads in flight per thread (n6 is even and s_off a multiple of n6^2: 16-byte aligned), then the
+        // block inverses read their 6x6 blocks from LDS: element by element from global memory the copy and the 36 dependent loads
+        // of a Cholesky were ~25 us of a 70 us single-window solve
+        const double2* Sg2 = reinterpret_cast<const double2*>(Sg);
+        double2* Sl2       = reinterpret_cast<double2*>(Sl);
+        const int n2       = (n6 * n6) >> 1;
+        for (int i0 = tid; i0 < n2; i0 += 16 * PCG_THREADS)
+        {
+            double2 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = i0 + u * PCG_THREADS < n2 ? Sg2[i0 + u * PCG_THREADS] : double2{0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (i0 + u * PCG_THREADS < n2) Sl2[i0 + u * PCG_THREADS] = v[u];
+        }
+        __syncthreads();
+        for (int c = tid; c < nfc; c += PCG_THREADS) inv6_spd(Sl + (c * 6) * n6 + c * 6, n6, Mi + c * 36);
+    }
+    else
+        for (int c = tid; c < nfc; c += PCG_THREADS) inv6_spd(Sg + (size_t)(c * 6) * n6 + c * 6, n6, Mi + c * 36);
     double part = 0.0;
     for (int q = tid; q < n6; q += PCG_THREADS)
     {
