@@ -1961,29 +1961,6 @@ __device__ void inv6_spd(const double* Ain, int lda, double* Ai)
     }
 }
 
-// Sum over the 64 lanes of a double, returned to every lane, without the LDS: four DPP butterflies inside each row of 16 lanes
-// (two 32-bit moves per step), then the four row sums are read back with v_readlane and added in a fixed order.  The
-// __shfl_xor tree above is twelve dependent ds_bpermute round trips per sum.
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov64(double v)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double readlane64(double v, int l)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-__device__ __forceinline__ double wave_sum64_dpp(double v)
-{
-    v += dpp_mov64<0xB1>(v);   // quad_perm [1,0,3,2]
-    v += dpp_mov64<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp_mov64<0x141>(v);  // row_half_mirror
-    v += dpp_mov64<0x140>(v);  // row_mirror
-    return (readlane64(v, 0) + readlane64(v, 16)) + (readlane64(v, 32) + readlane64(v, 48));
-}
-
 constexpr int PCG_THREADS = 256;
 // dynamic LDS: r, z, p, Ap (n6 each) | partial sums (4 * n6) | Minv (nfc*36) | S (n6*n6, when s_in_lds)
 // S_IN_LDS is a template parameter, not an argument: with `S = s_in_lds ? Sl : Sg` the matvec read S through a generic

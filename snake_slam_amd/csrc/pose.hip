@@ -174,7 +174,7 @@ __device__ __forceinline__ double clampd(double v)
 
 __device__ int chol_solve6(const double* A, const double* b, double* x)
 {
-    double L[36];
+    double L[36], inv[6];
 #pragma unroll
     for (int i = 0; i < 36; ++i) L[i] = 0.0;
 #pragma unroll
@@ -189,9 +189,10 @@ __device__ int chol_solve6(const double* A, const double* b, double* x)
             {
                 if (!(s > 0.0)) return -1;
                 L[i * 6 + i] = sqrt(s);
+                inv[i]       = 1.0 / L[i * 6 + i];  // one division per pivot; the 27 others of the textbook form become products
             }
             else
-                L[i * 6 + j] = s / L[j * 6 + j];
+                L[i * 6 + j] = s * inv[j];
         }
     double y[6];
 #pragma unroll
@@ -200,7 +201,7 @@ __device__ int chol_solve6(const double* A, const double* b, double* x)
         double s = b[i];
 #pragma unroll
         for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k];
-        y[i] = s / L[i * 6 + i];
+        y[i] = s * inv[i];
     }
 #pragma unroll
     for (int i = 5; i >= 0; --i)
@@ -208,25 +209,29 @@ __device__ int chol_solve6(const double* A, const double* b, double* x)
         double s = y[i];
 #pragma unroll
         for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * x[k];
-        x[i] = s / L[i * 6 + i];
+        x[i] = s * inv[i];
     }
     return 0;
 }
 
-// WAVES wavefronts per frame: a match per thread and stride 64 * WAVES; the 27 sums of a step are reduced inside each
-// wavefront (fixed butterfly) and then across the wavefronts in order through LDS (two barriers per step).  One wavefront
-// per frame is right for a few dozen matches; with the ~770 matches a coarse tracking pass produces, one wavefront spends
-// 12 linearisations per lane and step behind each other (0.71 ms per 256 frames), four do three each.
-template <int WAVES>
+// WAVES wavefronts per frame: a match per thread and stride 64 * WAVES.  The 27 sums of a step are reduced inside each row of 16
+// lanes with four DPP steps (no LDS, no read-back), the 4 * WAVES row sums of every quantity meet in LDS, 27 threads add them in
+// a fixed order and everybody reads the totals: two barriers per step.  (The first form ran a six-step __shfl_xor tree per
+// quantity -- 324 ds_bpermute round trips per wavefront and step -- and let every thread add all WAVES partials of all 27.)
+// PPT > 0: the frame's matches are held in registers (at most PPT per thread, n <= PPT * 64 * WAVES), read once instead of in
+// each of the 40 steps; PPT = 0: any n, matches re-read per step.  One wavefront per frame is right for a few dozen matches;
+// with the ~770 - 1500 matches of a tracking pass, 16 wavefronts with two matches per thread are (0.43 -> 0.2x ms per 256 frames).
+template <int WAVES, int PPT, bool LDSM>
 __global__ __launch_bounds__(64 * WAVES) void pose_kernel(const PoseMeta* __restrict__ meta, const double* __restrict__ wps,
                                                           const snk_pose_obs* __restrict__ obs, u8* __restrict__ outlier,
                                                           double* __restrict__ pose_out, int* __restrict__ inliers_out, CamD cam,
                                                           snk_pose_options opt)
 {
     constexpr int STRIDE = 64 * WAVES;
-    __shared__ double s_part[WAVES][28];
+    constexpr int NP     = PPT > 0 ? PPT : 1;
+    __shared__ double s_part[WAVES * 4][28];
+    __shared__ double s_tot[28];
     const int lane    = threadIdx.x;  // thread of the frame's workgroup
-    const int wave    = threadIdx.x >> 6;
     const PoseMeta& M = meta[blockIdx.x];
     const int n       = M.n;
     const double* W   = wps + 3 * (long long)M.off;
@@ -235,8 +240,75 @@ __global__ __launch_bounds__(64 * WAVES) void pose_kernel(const PoseMeta* __rest
     double pose[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) pose[i] = M.pose[i];
-    for (int i = lane; i < n; i += STRIDE) out[i] = 0;
-    if (WAVES > 1) __syncthreads();
+    // register-resident matches (PPT > 0)
+    double pw[NP][3];
+    snk_pose_obs po[NP];
+    bool have[NP], bad[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+    {
+        const int i = lane + k * STRIDE;
+        have[k]     = PPT > 0 && i < n;
+        bad[k]      = false;
+        pw[k][0] = pw[k][1] = pw[k][2] = 0.0;
+        po[k] = snk_pose_obs{0.0, 0.0, 0.0, 0.0};
+        if (have[k])
+        {
+            pw[k][0] = W[3 * i], pw[k][1] = W[3 * i + 1], pw[k][2] = W[3 * i + 2];
+            po[k] = O[i];
+        }
+    }
+    // LDSM: the frame's matches (world point + observation, 56 bytes each) are copied to LDS once; the 40 steps then read them
+    // with LDS latency instead of a global-memory round trip per match and step (one wavefront per SIMD hides nothing)
+    extern __shared__ __attribute__((aligned(16))) double s_match[];
+    double* s_w = s_match;               // [3 n]
+    double* s_o = s_match + 3 * (LDSM ? n : 0);  // [4 n]
+    if (PPT == 0)
+    {
+        for (int i = lane; i < n; i += STRIDE) out[i] = 0;
+        if (LDSM)
+        {
+            for (int i = lane; i < 3 * n; i += STRIDE) s_w[i] = W[i];
+            const double* Od = reinterpret_cast<const double*>(O);
+            for (int i = lane; i < 4 * n; i += STRIDE) s_o[i] = Od[i];
+        }
+        if (WAVES > 1 || LDSM) __syncthreads();
+    }
+    auto fetch = [&](int i, double* p, snk_pose_obs& o)
+    {
+        if constexpr (LDSM)
+        {
+            p[0] = s_w[3 * i], p[1] = s_w[3 * i + 1], p[2] = s_w[3 * i + 2];
+            o.x = s_o[4 * i], o.y = s_o[4 * i + 1], o.depth = s_o[4 * i + 2], o.weight = s_o[4 * i + 3];
+        }
+        else
+        {
+            p[0] = W[3 * i], p[1] = W[3 * i + 1], p[2] = W[3 * i + 2];
+            o = O[i];
+        }
+    };
+
+    // sums of acc[0..CNT) over the workgroup, left in acc for every thread (CNT is a compile-time constant: acc stays in registers)
+    auto reduce = [&](double* acc, auto cnt_c)
+    {
+        constexpr int CNT = decltype(cnt_c)::value;
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) acc[i] = row_sum64_dpp(acc[i]);
+        if ((lane & 15) == 0)
+#pragma unroll
+            for (int i = 0; i < CNT; ++i) s_part[lane >> 4][i] = acc[i];
+        __syncthreads();
+        if (lane < CNT)
+        {
+            double v = s_part[0][lane];
+#pragma unroll
+            for (int w = 1; w < WAVES * 4; ++w) v += s_part[w][lane];
+            s_tot[lane] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) acc[i] = s_tot[i];
+    };
 
     int inliers = 0;
     for (int round = 0; round < opt.outer_iterations; ++round)
@@ -249,14 +321,11 @@ __global__ __launch_bounds__(64 * WAVES) void pose_kernel(const PoseMeta* __rest
             for (int i = 0; i < 27; ++i) acc[i] = 0.0;
             double R[9];
             quat_to_R(pose, R);
-            for (int i = lane; i < n; i += STRIDE)
+            auto add_match = [&](const double* p, const snk_pose_obs& o)
             {
-                if (out[i]) continue;
                 double r[3], J[18];
-                const double p[3] = {W[3 * i], W[3 * i + 1], W[3 * i + 2]};
-                const snk_pose_obs o = O[i];
-                const int dim        = linearize(R, pose + 4, p, cam, o, r, J);
-                if (!dim) continue;
+                const int dim = linearize(R, pose + 4, p, cam, o, r, J);
+                if (!dim) return;
                 const double s = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];  // r[2] = 0 for mono
                 double wgt     = 1.0;
                 if (robust)
@@ -277,24 +346,28 @@ __global__ __launch_bounds__(64 * WAVES) void pose_kernel(const PoseMeta* __rest
                         for (int c = a; c < 6; ++c) acc[u++] += ja * J[6 * k + c];
                     }
                 }
-            }
-#pragma unroll
-            for (int i = 0; i < 27; ++i) acc[i] = wave_sum(acc[i]);
-            if (WAVES > 1)
+            };
+            if (PPT > 0)
             {
-                if ((lane & 63) == 0)
 #pragma unroll
-                    for (int i = 0; i < 27; ++i) s_part[wave][i] = acc[i];
-                __syncthreads();
-#pragma unroll
-                for (int i = 0; i < 27; ++i)
+                for (int k = 0; k < NP; ++k)
+                    if (have[k] && !bad[k]) add_match(pw[k], po[k]);
+            }
+            else
+                for (int i = lane; i < n; i += STRIDE)
                 {
-                    double v = s_part[0][i];
-#pragma unroll
-                    for (int w = 1; w < WAVES; ++w) v += s_part[w][i];
-                    acc[i] = v;
+                    if (out[i]) continue;
+                    double p[3];
+                    snk_pose_obs o;
+                    fetch(i, p, o);
+                    add_match(p, o);
                 }
-                __syncthreads();
+            if (WAVES > 1)
+                reduce(acc, std::integral_constant<int, 27>{});
+            else
+            {
+#pragma unroll
+                for (int i = 0; i < 27; ++i) acc[i] = wave_sum64_dpp(acc[i]);
             }
             double H[36], b[6];
             {
@@ -335,30 +408,52 @@ __global__ __launch_bounds__(64 * WAVES) void pose_kernel(const PoseMeta* __rest
         double R[9];
         quat_to_R(pose, R);
         int cnt = 0;
-        for (int i = lane; i < n; i += STRIDE)
+        auto classify = [&](const double* p, const snk_pose_obs& o) -> bool
         {
             double r[3], J[18];
-            const double p[3] = {W[3 * i], W[3 * i + 1], W[3 * i + 2]};
-            const snk_pose_obs o = O[i];
-            const int dim        = linearize(R, pose + 4, p, cam, o, r, J);
-            const double s       = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
-            const double d       = dim == 3 ? opt.th_stereo : opt.th_mono;
-            const bool bad       = !dim || s > d * d;
-            out[i]               = bad ? 1 : 0;
-            cnt += bad ? 0 : 1;
-        }
+            const int dim  = linearize(R, pose + 4, p, cam, o, r, J);
+            const double s = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+            const double d = dim == 3 ? opt.th_stereo : opt.th_mono;
+            return !dim || s > d * d;
+        };
+        if (PPT > 0)
+        {
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+            for (int k = 0; k < NP; ++k)
+                if (have[k])
+                {
+                    bad[k] = classify(pw[k], po[k]);
+                    cnt += bad[k] ? 0 : 1;
+                }
+        }
+        else
+            for (int i = lane; i < n; i += STRIDE)
+            {
+                double p[3];
+                snk_pose_obs o;
+                fetch(i, p, o);
+                const bool bd        = classify(p, o);
+                out[i]               = bd ? 1 : 0;
+                cnt += bd ? 0 : 1;
+            }
         if (WAVES > 1)
         {
-            if ((lane & 63) == 0) s_part[wave][27] = (double)cnt;
-            __syncthreads();  // also: every thread's flags of this round are written before the next round reads them
-            cnt = 0;
+            double c1[1] = {(double)cnt};
+            reduce(c1, std::integral_constant<int, 1>{});  // its barriers also order this round's flags before the next round reads them (PPT = 0)
+            cnt = (int)c1[0];
+        }
+        else
+        {
 #pragma unroll
-            for (int w = 0; w < WAVES; ++w) cnt += (int)s_part[w][27];
-            __syncthreads();
+            for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
         }
         inliers = cnt;
+    }
+    if (PPT > 0)
+    {
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+            if (have[k]) out[lane + k * STRIDE] = bad[k] ? 1 : 0;
     }
     if (lane == 0)
     {
@@ -500,11 +595,11 @@ extern "C" int snk_pose_refine(snk_matcher* m, const snk_camera* cam, const snk_
     SNK_HIP_CHECK(hipMemcpyAsync(d, stage.data(), in_b, hipMemcpyHostToDevice, m->stream));
     CamD C{cam->fx, cam->fy, cam->cx, cam->cy, cam->bf};
     if (total >= (size_t)n_problems * 192)  // ~200 matches per frame and more: four wavefronts per frame
-        hipLaunchKernelGGL(pose_kernel<4>, dim3(n_problems), dim3(256), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
+        hipLaunchKernelGGL((pose_kernel<4, 0, false>), dim3(n_problems), dim3(256), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
                            reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),
                            reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), reinterpret_cast<int*>(o + o_inl), C, *opt);
     else
-        hipLaunchKernelGGL(pose_kernel<1>, dim3(n_problems), dim3(64), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
+        hipLaunchKernelGGL((pose_kernel<1, 0, false>), dim3(n_problems), dim3(64), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
                            reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),
                            reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), reinterpret_cast<int*>(o + o_inl), C, *opt);
     SNK_LAUNCH_CHECK();
@@ -559,14 +654,21 @@ extern "C" int snk_pose_refine_matches_batch_dev(snk_matcher* m, const snk_frame
                        reinterpret_cast<PoseMeta*>(d), reinterpret_cast<double*>(d + o_wps), reinterpret_cast<snk_pose_obs*>(d + o_obs),
                        reinterpret_cast<int*>(d + o_slot));
     CamD C{cam->fx, cam->fy, cam->cx, cam->cy, cam->bf};
-    if (pts_cap >= 256)
-        hipLaunchKernelGGL(pose_kernel<4>, dim3(batch), dim3(256), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
-                           reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),
-                           reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), inliers_dev, C, *opt);
-    else
-        hipLaunchKernelGGL(pose_kernel<1>, dim3(batch), dim3(64), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
-                           reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),
-                           reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), inliers_dev, C, *opt);
+    static const bool no_lds = getenv("SNK_POSE_NO_LDS") != nullptr;  // A/B: matches re-read from global memory in every step
+    const size_t match_lds   = (size_t)pts_cap * 7 * sizeof(double);
+#define POSE_LAUNCH(W_, L_, LDS_)                                                                                                    \
+    hipLaunchKernelGGL((pose_kernel<W_, 0, L_>), dim3(batch), dim3(64 * W_), LDS_, m->stream, reinterpret_cast<const PoseMeta*>(d),  \
+                       reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),                \
+                       reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), inliers_dev, C, *opt)
+    if (pts_cap >= 256 && match_lds <= 150 * 1024 && !no_lds)
+    {
+        int rc = set_max_lds_once(reinterpret_cast<const void*>(pose_kernel<4, 0, true>), 152 * 1024);
+        if (rc != SNK_OK) return rc;
+        POSE_LAUNCH(4, true, match_lds);
+    }
+    else if (pts_cap >= 256) POSE_LAUNCH(4, false, 0);
+    else POSE_LAUNCH(1, false, 0);
+#undef POSE_LAUNCH
     hipLaunchKernelGGL(scatter_pose_kernel, dim3(batch), dim3(64), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
                        reinterpret_cast<const double*>(o + o_pose), reinterpret_cast<const u8*>(o), reinterpret_cast<const int*>(d + o_slot),
                        pts_cap, poses_dev, outlier_dev, inliers_dev);
