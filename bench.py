@@ -212,6 +212,8 @@ def main():
                          "and the ranks' TUM trajectories are gathered with one all_gather")
     ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic stereo pairs / BA scenes per rank (0 = all of them: every "
                     "frame of the batch and every BA window is its own seeded scene; n = n of each, tiled)")
+    ap.add_argument("--no-overlap", action="store_true", help="post-extraction stage on the extractor's stream (no overlap of batch i's "
+                    "stage with batch i + 1's extraction)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events")
     args = ap.parse_args()
@@ -267,17 +269,26 @@ def main():
     cap = ext.configure(W, H, 2 * B)
     if args.orb_chains != 1:
         ext.set_chains(args.orb_chains)
-    pre = Preprocess(local, sh)
-    bf = BruteForceMatcher(local, sh)
-    grid = FeatureGrid(local, sh)
+    # Two streams, two sets of extractor outputs: the post-extraction stage of batch i (rectify, grid, stereo, kNN-2 + filter --
+    # small kernels that leave most of the chip idle) runs on stream B beside the extraction of batch i + 1 on stream A.  Batches
+    # are independent frames; all K steps are complete inside the timed region (synchronize + barrier).  --no-overlap: one stream.
+    overlap = not args.no_overlap
+    stream_b = torch.cuda.Stream(device=dev) if overlap else stream
+    shb = stream_b.cuda_stream
+    pre = Preprocess(local, shb)
+    bf = BruteForceMatcher(local, shb)
+    grid = FeatureGrid(local, shb)
     GRID_BOUNDS = (0.0, 0.0, float(W), float(H))  # featureGridBounds of the undistorted image
     n_cells = int(np.ceil(W / 20.0)) * int(np.ceil(H / 20.0))
     rect = Rectification.make((1.0, 1.0, 0.0, 0.0))  # synthetic pairs are already rectified
     level_scale = (np.float32(ORB["scale_factor"]) ** np.arange(ORB["n_levels"])).astype(np.float32)
 
-    kps = torch.zeros((2 * B, cap, 24), dtype=torch.uint8, device=dev)
-    desc = torch.zeros((2 * B, cap, 4), dtype=torch.int64, device=dev)
-    nkp = torch.zeros(2 * B, dtype=torch.int32, device=dev)
+    n_sets = 2 if overlap else 1
+    out_sets = [(torch.zeros((2 * B, cap, 24), dtype=torch.uint8, device=dev), torch.zeros((2 * B, cap, 4), dtype=torch.int64, device=dev),
+                 torch.zeros(2 * B, dtype=torch.int32, device=dev)) for _ in range(n_sets)]
+    ev_a = [torch.cuda.Event() for _ in range(n_sets)]  # extraction of the set done (stream A)
+    ev_b = [torch.cuda.Event() for _ in range(n_sets)]  # post-extraction stage has finished reading the set (stream B)
+    kps, desc, nkp = out_sets[0]
     kp64 = torch.zeros((2 * B, cap, 24), dtype=torch.uint8, device=dev)
     kp64_g = torch.zeros((B, cap, 24), dtype=torch.uint8, device=dev)  # left keypoints / descriptors in feature-grid order
     desc_g = torch.zeros((B, cap, 4), dtype=torch.int64, device=dev)
@@ -290,21 +301,35 @@ def main():
     pairs = torch.zeros((B, cap, 2), dtype=torch.int32, device=dev)
     n_pairs = torch.zeros(B, dtype=torch.int32, device=dev)
 
+    step_no = [0]
+
     def step():
+        k = step_no[0] % n_sets
+        step_no[0] += 1
+        kps, desc, nkp = out_sets[k]
+        if overlap:
+            stream.wait_event(ev_b[k])  # the stage that read this set two steps ago is done (no-op for a fresh event)
         ext.detect_batch_dev(images, kps, desc, nkp)
+        if overlap:
+            ev_a[k].record(stream)
+            stream_b.wait_event(ev_a[k])
         pre.rectify_batch_dev(rect, kps, nkp, kp64)                                   # undistortKeypoints / rect.Forward
         grid.create_batch_dev(GRID_BOUNDS, kp64[:B], desc[:B], nkp[:B], kp64_g, desc_g, perm, cell_start)  # computeFeatureGrid
         pre.match_batch_dev(kp64_g, desc_g, nkp[:B], kp64[B:], desc[B:], nkp[B:], BF_SYNTH, level_scale, True,
                             right_points, depth, n_stereo)                            # StereoMatching
         bf.knn2_batch_dev(desc_g, nkp[:B], desc[B:], nkp[B:], knn)                    # matchKnn2 + filterMatches
         bf.filter_batch_dev(knn, nkp[:B], 60, 0.8, pairs, n_pairs)
+        if overlap:
+            ev_b[k].record(stream_b)
 
     barrier = parallel.barrier
 
     with torch.cuda.stream(stream):
         for _ in range(args.warmup):
+            torch.cuda.synchronize()
             right_points.fill_(-1000.0)
             depth.fill_(-1000.0)
+            torch.cuda.synchronize()
             step()
         torch.cuda.synchronize()
         ext.set_profiling(not args.no_stage_events)
@@ -316,6 +341,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         t1 = time.perf_counter()
+    kps, desc, nkp = out_sets[(step_no[0] - 1) % n_sets]  # what the last step left in HBM (the legs below read it)
     stage_ms, n_calls = ext.stage_times() if not args.no_stage_events else ([0, 0, 0, 0, 0], 0)
     ext.set_profiling(False)
 
@@ -544,7 +570,9 @@ def main():
             "data": f"synthetic: seeded {W}x{H} stereo pairs (gradient + 400 rectangles + noise), {n_dpairs} distinct pairs per rank over a batch of {B}, resident in HBM",
             "config": {"workload": ("EuRoC" if args.workload == "euroc" else "KITTI") + f" stereo {W}x{H}: ORB extract (L+R, {ORB['nfeatures']} feat, {ORB['n_levels']} levels) + stereo row-band match + BF kNN-2 Hamming match",
                        "frames_per_gpu_per_step": B, "images_per_frame": 2, "orb": ORB,
-                       "parallelism": f"{world} x independent batches (one per GPU), RCCL all_gather of results only"},
+                       "parallelism": f"{world} x independent batches (one per GPU), RCCL all_gather of results only",
+                       "streams": ("2: the post-extraction stage of batch i (rectify, grid, stereo, kNN-2) overlaps the extraction of batch i + 1"
+                                   if overlap else "1")},
             "keypoints_per_image": round(float(blocks[0][1].item()) / (2 * B), 1),
             "stereo_matches_per_frame": round(float(blocks[0][2].item()) / B, 1),
             "bf_pairs_per_frame": round(float(blocks[0][3].item()) / B, 1),
