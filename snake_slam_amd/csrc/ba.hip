@@ -2879,6 +2879,19 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     int max_wv = 0;
     bool wave_ok = true;
     auto& blkent = LS.blkent;
+    {
+        // the big lists are sized by the totals of the call: growing a pinned vector re-pins and copies it every time it doubles
+        size_t t_img = 0, t_pt = 0, t_obs = 0;
+        for (int b = 0; b < count; ++b)
+        {
+            t_img += (size_t)std::max(problems[b].n_img, 0);
+            t_pt += (size_t)std::max(problems[b].n_pt, 0);
+            t_obs += (size_t)std::max(problems[b].n_obs, 0);
+        }
+        pose.reserve(7 * t_img), pt.reserve(3 * t_pt), ptc.reserve(t_pt), camidx.reserve(t_img), ptstart.reserve(t_pt + (size_t)count);
+        ouv2.reserve(2 * t_obs), odepth.reserve(t_obs), oweight.reserve(t_obs), optfree.reserve(t_obs), oimg.reserve(t_obs);
+        ocam.reserve(t_obs), oorig.reserve(t_obs), optidx.reserve(t_obs), csobs.reserve(t_obs), camitems.reserve(t_obs);
+    }
     h->orig_off.assign((size_t)count, 0);
     h->orig_n.assign((size_t)count, 0);
     int img_off = 0, pt_off = 0, obs_off = 0, cam_off = 0, orig_off = 0, vec_off = 0;
@@ -3359,7 +3372,11 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
 #undef UP
     if (tab.n > 0)
     {
-        hipLaunchKernelGGL(copy_table_kernel, dim3(16, tab.n), dim3(256), 0, st, tab);
+        // enough workgroups per array to keep the bus busy: one per 64 KB of the largest list, 16 .. 256
+        unsigned big = 0;
+        for (int e = 0; e < tab.n; ++e) big = std::max(big, tab.bytes[e]);
+        const int gx = (int)std::min(256u, std::max(16u, big >> 16));
+        hipLaunchKernelGGL(copy_table_kernel, dim3(gx, tab.n), dim3(256), 0, st, tab);
         SNK_LAUNCH_CHECK();
     }
     const auto t_up = std::chrono::steady_clock::now();

@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_cache_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --ba-windows 0 --gba-keyframes 0 --pose-frames 0 --track-frames 0 --distinct 32"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-overlap --ba-windows 0 --gba-keyframes 0 --pose-frames 0 --track-frames 0 --distinct 32"
 i=0
 for G in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" "TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum"; do
   i=$((i+1))
