@@ -112,14 +112,20 @@ __device__ __forceinline__ void merge2(u32& k1, u32& k2, u32 o1, u32 o2)
 
 // Candidate scan of one search window by one wavefront.  MODE 0: radius only; 1: octave window;
 // 2: predicted scale.  `taken` may point to LDS (keyframe matcher) or global memory.
-template <int MODE, int LANES = 64>
-__device__ __forceinline__ void scan_window(const FrameDev& F, const u8* taken, double ipx, double ipy, double z, double bf,
-                                            double r, double r2, int min_oct, int max_oct, double pred, const uint4& qa,
-                                            const uint4& qc, int lane, u32& k1, u32& k2)
+// The window's cell range, packed (cx0 | cx1 << 16, cy0 | cy1 << 16) -- cols * rows < 65535 at every entry point: four fp64
+// divisions that the batched matchers evaluate once per point in the lane = point phase instead of in every window scan.
+__device__ __forceinline__ uint2 window_cells(const FrameDev& F, double ipx, double ipy, double r)
 {
     const int cx0 = cell_coord(ipx - r, F.min_x, F.cols), cx1 = cell_coord(ipx + r, F.min_x, F.cols);
     const int cy0 = cell_coord(ipy - r, F.min_y, F.rows), cy1 = cell_coord(ipy + r, F.min_y, F.rows);
-    const double disp = ipx - bf / z;
+    return make_uint2((u32)cx0 | ((u32)cx1 << 16), (u32)cy0 | ((u32)cy1 << 16));
+}
+template <int MODE, int LANES = 64>
+__device__ __forceinline__ void scan_window_cells(const FrameDev& F, const u8* taken, double ipx, double ipy, double disp, uint2 cells,
+                                                  double r, double r2, int min_oct, int max_oct, double pred, const uint4& qa,
+                                                  const uint4& qc, int lane, u32& k1, u32& k2)
+{
+    const int cx0 = (int)(cells.x & 0xFFFFu), cx1 = (int)(cells.x >> 16), cy0 = (int)(cells.y & 0xFFFFu), cy1 = (int)(cells.y >> 16);
     for (int cx = cx0; cx <= cx1; ++cx)
     {
         const int lo = F.cell_start[cx * F.rows + cy0], hi = F.cell_start[cx * F.rows + cy1 + 1];
@@ -149,6 +155,14 @@ __device__ __forceinline__ void scan_window(const FrameDev& F, const u8* taken, 
         const u32 o1 = __shfl_xor(k1, off), o2 = __shfl_xor(k2, off);
         merge2(k1, k2, o1, o2);
     }
+}
+template <int MODE, int LANES = 64>
+__device__ __forceinline__ void scan_window(const FrameDev& F, const u8* taken, double ipx, double ipy, double z, double bf,
+                                            double r, double r2, int min_oct, int max_oct, double pred, const uint4& qa,
+                                            const uint4& qc, int lane, u32& k1, u32& k2)
+{
+    scan_window_cells<MODE, LANES>(F, taken, ipx, ipy, ipx - bf / z, window_cells(F, ipx, ipy, r), r, r2, min_oct, max_oct, pred, qa,
+                                   qc, lane, k1, k2);
 }
 
 // The next (up to) four set bits of `todo`, one per group of 16 lanes: group g gets the g-th; -1 = none.  Clears them.
@@ -296,6 +310,9 @@ __device__ __forceinline__ void coarse_wave64(const FrameDev& F, const CamDev& C
     lvl     = lvl < 0 ? 0 : (lvl >= S.n ? S.n - 1 : lvl);
     float r = th;
     r *= S.s[lvl];
+    // the window's cell range and the expected disparity, once per point (lanes that fail the culls compute on harmless values)
+    const uint2 cells = window_cells(F, ok ? ipx : F.min_x, ok ? ipy : F.min_y, (double)r);
+    const double disp = ipx - C.bf / (ok ? z : 1.0);
     // results go through the wavefront's LDS slice (served in program order): default "no match", the group leaders overwrite
     __shared__ int s_res[16][2][64];  // up to 16 wavefronts per workgroup (the frame-resident kernels)
     int* my_res = s_res[(threadIdx.x >> 6) & 15][0];
@@ -310,7 +327,8 @@ __device__ __forceinline__ void coarse_wave64(const FrameDev& F, const CamDev& C
         const int src  = take4(todo, grp);
         const bool has = src >= 0;
         const int sl   = has ? src : 0;
-        const double bx = shfl_d(ipx, sl), by = shfl_d(ipy, sl), bz = shfl_d(z, sl);
+        const double bx = shfl_d(ipx, sl), by = shfl_d(ipy, sl), bdisp = shfl_d(disp, sl);
+        const uint2 bcells = make_uint2((u32)__shfl((int)cells.x, sl), (u32)__shfl((int)cells.y, sl));
         const float br  = __shfl(r, sl);
         const int boct  = __shfl(oct, sl);
         const float bang = __shfl(ang, sl);
@@ -322,7 +340,8 @@ __device__ __forceinline__ void coarse_wave64(const FrameDev& F, const CamDev& C
             else if (direction == 2) { mn = 0; mx = boct; }
             else { mn = boct - 1; mx = boct + 1; }
             u32 k1 = PJ_INF_KEY, k2 = PJ_INF_KEY;
-            scan_window<1, 16>(F, F.taken, bx, by, bz, C.bf, (double)br, (double)br * (double)br, mn, mx, 0.0, ba, bc, sub, k1, k2);
+            scan_window_cells<1, 16>(F, F.taken, bx, by, bdisp, bcells, (double)br, (double)br * (double)br, mn, mx, 0.0, ba, bc, sub, k1,
+                                     k2);
             const int bd = (int)(k1 >> PJ_IDX_BITS);
             if (bd <= feature_error && k1 != PJ_INF_KEY)
             {
@@ -426,6 +445,8 @@ __device__ __forceinline__ void fine_wave64(const FrameDev& F, const CamDev& C, 
             }
         }
     }
+    const uint2 cells = window_cells(F, scan ? ipx : F.min_x, scan ? ipy : F.min_y, (double)r);
+    const double disp = ipx - C.bf / (scan ? z : 1.0);
     __shared__ int s_resf[16][64];
     int* my_res = s_resf[(threadIdx.x >> 6) & 15];
     my_res[lane] = -1;
@@ -436,13 +457,15 @@ __device__ __forceinline__ void fine_wave64(const FrameDev& F, const CamDev& C, 
         const int src  = take4(todo, grp);
         const bool has = src >= 0;
         const int sl   = has ? src : 0;
-        const double bx = shfl_d(ipx, sl), by = shfl_d(ipy, sl), bz = shfl_d(z, sl), bpred = shfl_d(prediction, sl);
+        const double bx = shfl_d(ipx, sl), by = shfl_d(ipy, sl), bdisp = shfl_d(disp, sl), bpred = shfl_d(prediction, sl);
+        const uint2 bcells = make_uint2((u32)__shfl((int)cells.x, sl), (u32)__shfl((int)cells.y, sl));
         const float br  = __shfl(r, sl);
         const uint4 ba = shfl_u4(qa, sl), bc = shfl_u4(qc, sl);
         if (has)
         {
             u32 k1 = PJ_INF_KEY, k2 = PJ_INF_KEY;
-            scan_window<2, 16>(F, F.taken, bx, by, bz, C.bf, (double)br, (double)br * (double)br, 0, 0, bpred, ba, bc, sub, k1, k2);
+            scan_window_cells<2, 16>(F, F.taken, bx, by, bdisp, bcells, (double)br, (double)br * (double)br, 0, 0, bpred, ba, bc, sub, k1,
+                                     k2);
             const int bd = (int)(k1 >> PJ_IDX_BITS);
             if (k1 != PJ_INF_KEY && bd <= 100)
             {
