@@ -165,17 +165,19 @@ __device__ __forceinline__ void scan_window(const FrameDev& F, const u8* taken, 
                                    qc, lane, k1, k2);
 }
 
-// The next (up to) four set bits of `todo`, one per group of 16 lanes: group g gets the g-th; -1 = none.  Clears them.
-__device__ __forceinline__ int take4(u64& todo, int grp)
+// The next (up to) NG set bits of `todo`, one per group of 64 / NG lanes: group g gets the g-th; -1 = none.  Clears them.
+template <int NG>
+__device__ __forceinline__ int take_groups(u64& todo, int grp)
 {
-    int s[4];
+    int res = -1;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < NG; ++k)
     {
-        s[k] = todo ? __builtin_ctzll(todo) : -1;
+        const int s = todo ? __builtin_ctzll(todo) : -1;
         todo &= todo - 1;  // 0 stays 0
+        res = grp == k ? s : res;
     }
-    return grp == 0 ? s[0] : (grp == 1 ? s[1] : (grp == 2 ? s[2] : s[3]));
+    return res;
 }
 __device__ __forceinline__ double shfl_d(double v, int src)
 {
@@ -185,6 +187,17 @@ __device__ __forceinline__ uint4 shfl_u4(const uint4& v, int src)
 {
     return make_uint4((u32)__shfl((int)v.x, src), (u32)__shfl((int)v.y, src), (u32)__shfl((int)v.z, src), (u32)__shfl((int)v.w, src));
 }
+
+// Lanes that share one window scan in the batched matchers.  A frame has ~1 feature per grid cell, a window a handful of
+// candidates per grid column: measured per 256 frames (coarse 1500 + fine 10 000 points + refinement) 16 lanes x 4 points at a time
+// 1.08 ms, 8 x 8 0.92, 4 x 16 0.86, 2 x 32 0.86, and ONE lane per window (every lane scans its own point's window, nothing is
+// broadcast: 17 lane shuffles per round of points gone) 0.84 -- the default.  Any power of two up to 16 works.
+constexpr int PJ_GROUP = 1;
+// group broadcasts: with one lane per window a point's numbers are already where they are needed
+__device__ __forceinline__ double gsh_d(double v, int src) { return PJ_GROUP == 1 ? v : shfl_d(v, src); }
+__device__ __forceinline__ float gsh_f(float v, int src) { return PJ_GROUP == 1 ? v : __shfl(v, src); }
+__device__ __forceinline__ int gsh_i(int v, int src) { return PJ_GROUP == 1 ? v : __shfl(v, src); }
+__device__ __forceinline__ uint4 gsh_u4(const uint4& v, int src) { return PJ_GROUP == 1 ? v : shfl_u4(v, src); }
 
 // Batch of grid-ordered frames resident on the device (the arrays snk_feature_grid_batch_dev / snk_stereo_match_batch_dev
 // leave behind): per-feature arrays are [batch][cap], cell_start is [batch][cols * rows + 1].
@@ -320,19 +333,19 @@ __device__ __forceinline__ void coarse_wave64(const FrameDev& F, const CamDev& C
     my_res[lane] = -1;
     my_bin[lane] = 0;
     // Phase 2: a window holds a few dozen candidates, so 16 lanes share one and four points are scanned at a time
-    const int grp = lane >> 4, sub = lane & 15;
+    const int grp = lane / PJ_GROUP, sub = lane % PJ_GROUP;
     u64 todo = __builtin_amdgcn_ballot_w64(ok);
-    while (todo)
+    for (int pass = 0; PJ_GROUP == 1 ? pass < 1 : todo != 0; ++pass)
     {
-        const int src  = take4(todo, grp);
+        const int src  = PJ_GROUP == 1 ? (ok ? lane : -1) : take_groups<(PJ_GROUP == 1 ? 1 : 64 / PJ_GROUP)>(todo, grp);
         const bool has = src >= 0;
         const int sl   = has ? src : 0;
-        const double bx = shfl_d(ipx, sl), by = shfl_d(ipy, sl), bdisp = shfl_d(disp, sl);
-        const uint2 bcells = make_uint2((u32)__shfl((int)cells.x, sl), (u32)__shfl((int)cells.y, sl));
-        const float br  = __shfl(r, sl);
-        const int boct  = __shfl(oct, sl);
-        const float bang = __shfl(ang, sl);
-        const uint4 ba = shfl_u4(qa, sl), bc = shfl_u4(qc, sl);
+        const double bx = gsh_d(ipx, sl), by = gsh_d(ipy, sl), bdisp = gsh_d(disp, sl);
+        const uint2 bcells = make_uint2((u32)gsh_i((int)cells.x, sl), (u32)gsh_i((int)cells.y, sl));
+        const float br  = gsh_f(r, sl);
+        const int boct  = gsh_i(oct, sl);
+        const float bang = gsh_f(ang, sl);
+        const uint4 ba = gsh_u4(qa, sl), bc = gsh_u4(qc, sl);
         if (has)
         {
             int mn, mx;
@@ -340,7 +353,7 @@ __device__ __forceinline__ void coarse_wave64(const FrameDev& F, const CamDev& C
             else if (direction == 2) { mn = 0; mx = boct; }
             else { mn = boct - 1; mx = boct + 1; }
             u32 k1 = PJ_INF_KEY, k2 = PJ_INF_KEY;
-            scan_window_cells<1, 16>(F, F.taken, bx, by, bdisp, bcells, (double)br, (double)br * (double)br, mn, mx, 0.0, ba, bc, sub, k1,
+            scan_window_cells<1, PJ_GROUP>(F, F.taken, bx, by, bdisp, bcells, (double)br, (double)br * (double)br, mn, mx, 0.0, ba, bc, sub, k1,
                                      k2);
             const int bd = (int)(k1 >> PJ_IDX_BITS);
             if (bd <= feature_error && k1 != PJ_INF_KEY)
@@ -450,21 +463,21 @@ __device__ __forceinline__ void fine_wave64(const FrameDev& F, const CamDev& C, 
     __shared__ int s_resf[16][64];
     int* my_res = s_resf[(threadIdx.x >> 6) & 15];
     my_res[lane] = -1;
-    const int grp = lane >> 4, sub = lane & 15;
+    const int grp = lane / PJ_GROUP, sub = lane % PJ_GROUP;
     u64 todo = __builtin_amdgcn_ballot_w64(scan);
-    while (todo)
+    for (int pass = 0; PJ_GROUP == 1 ? pass < 1 : todo != 0; ++pass)
     {
-        const int src  = take4(todo, grp);
+        const int src  = PJ_GROUP == 1 ? (scan ? lane : -1) : take_groups<(PJ_GROUP == 1 ? 1 : 64 / PJ_GROUP)>(todo, grp);
         const bool has = src >= 0;
         const int sl   = has ? src : 0;
-        const double bx = shfl_d(ipx, sl), by = shfl_d(ipy, sl), bdisp = shfl_d(disp, sl), bpred = shfl_d(prediction, sl);
-        const uint2 bcells = make_uint2((u32)__shfl((int)cells.x, sl), (u32)__shfl((int)cells.y, sl));
-        const float br  = __shfl(r, sl);
-        const uint4 ba = shfl_u4(qa, sl), bc = shfl_u4(qc, sl);
+        const double bx = gsh_d(ipx, sl), by = gsh_d(ipy, sl), bdisp = gsh_d(disp, sl), bpred = gsh_d(prediction, sl);
+        const uint2 bcells = make_uint2((u32)gsh_i((int)cells.x, sl), (u32)gsh_i((int)cells.y, sl));
+        const float br  = gsh_f(r, sl);
+        const uint4 ba = gsh_u4(qa, sl), bc = gsh_u4(qc, sl);
         if (has)
         {
             u32 k1 = PJ_INF_KEY, k2 = PJ_INF_KEY;
-            scan_window_cells<2, 16>(F, F.taken, bx, by, bdisp, bcells, (double)br, (double)br * (double)br, 0, 0, bpred, ba, bc, sub, k1,
+            scan_window_cells<2, PJ_GROUP>(F, F.taken, bx, by, bdisp, bcells, (double)br, (double)br * (double)br, 0, 0, bpred, ba, bc, sub, k1,
                                      k2);
             const int bd = (int)(k1 >> PJ_IDX_BITS);
             if (k1 != PJ_INF_KEY && bd <= 100)
