@@ -556,25 +556,28 @@ __global__ __launch_bounds__(1024) void fine_frame_kernel(FramesDev Fb, const Ca
 
 // first claimant (lowest local-map index) of every feature wins; coarse additionally applies the
 // rotation-histogram filter.  One workgroup per frame.
+// CLAIM: int* in global memory (any number of features) or in LDS (the batched kernel: the claims of a frame's features fit, and
+// an LDS atomic per local-map point instead of a global one is most of the kernel's time)
+template <typename CLAIM>
 __device__ __forceinline__ void resolve_body(const int* __restrict__ best, const int* __restrict__ bins, int m,
-                                             const u8* __restrict__ taken, int* __restrict__ claim, int n_feat,
+                                             const u8* __restrict__ taken, CLAIM claim, int n_feat,
                                              int with_rotation, int* __restrict__ match_idx, int* __restrict__ n_out)
 {
     __shared__ int hist[30];
     __shared__ int keep[3];
     __shared__ int count;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nthr = blockDim.x;
     if (tid < 30) hist[tid] = 0;
     if (tid == 0) count = 0;
-    for (int f = tid; f < n_feat; f += 256) claim[f] = 0x7FFFFFFF;
+    for (int f = tid; f < n_feat; f += nthr) claim[f] = 0x7FFFFFFF;
     __syncthreads();
-    for (int i = tid; i < m; i += 256)
+    for (int i = tid; i < m; i += nthr)
     {
         const int b = best[i];
         if (b >= 0 && !taken[b]) atomicMin(&claim[b], i);
     }
     __syncthreads();
-    for (int i = tid; i < m; i += 256)
+    for (int i = tid; i < m; i += nthr)
     {
         const int b   = best[i];
         const bool win = b >= 0 && !taken[b] && claim[b] == i;
@@ -604,7 +607,7 @@ __device__ __forceinline__ void resolve_body(const int* __restrict__ best, const
     }
     __syncthreads();
     int local = 0;
-    for (int i = tid; i < m; i += 256)
+    for (int i = tid; i < m; i += nthr)
     {
         int v = match_idx[i];
         if (v >= 0 && with_rotation)
@@ -630,17 +633,25 @@ __global__ __launch_bounds__(256) void resolve_kernel(const int* __restrict__ be
     resolve_body(best, bins, m, taken, claim, n_feat, with_rotation, match_idx, n_out);
 }
 
-__global__ __launch_bounds__(256) void resolve_batch_kernel(const int* __restrict__ best, const int* __restrict__ bins,
-                                                            const int* __restrict__ m_dev, int m_cap, FramesDev Fb,
-                                                            int* __restrict__ claim, int with_rotation,
-                                                            int* __restrict__ match_idx, int* __restrict__ n_out)
+// LDS_CLAIM: dynamic LDS of Fb.cap ints holds the claims (frames up to RESOLVE_LDS_FEATURES features); 1024 threads per frame
+constexpr int RESOLVE_LDS_FEATURES = 32768;
+template <bool LDS_CLAIM>
+__global__ __launch_bounds__(1024) void resolve_batch_kernel(const int* __restrict__ best, const int* __restrict__ bins,
+                                                             const int* __restrict__ m_dev, int m_cap, FramesDev Fb,
+                                                             int* __restrict__ claim, int with_rotation,
+                                                             int* __restrict__ match_idx, int* __restrict__ n_out)
 {
+    extern __shared__ __attribute__((aligned(16))) int s_claim[];
     const int b = blockIdx.x;
     const int m = min(m_dev[b], m_cap);
-    resolve_body(best + (size_t)b * m_cap, bins ? bins + (size_t)b * m_cap : nullptr, m, Fb.taken + (size_t)b * Fb.cap,
-                 claim + (size_t)b * Fb.cap, min(Fb.n[b], Fb.cap), with_rotation, match_idx + (size_t)b * m_cap, n_out + b);
+    if constexpr (LDS_CLAIM)
+        resolve_body(best + (size_t)b * m_cap, bins ? bins + (size_t)b * m_cap : nullptr, m, Fb.taken + (size_t)b * Fb.cap, s_claim,
+                     min(Fb.n[b], Fb.cap), with_rotation, match_idx + (size_t)b * m_cap, n_out + b);
+    else
+        resolve_body(best + (size_t)b * m_cap, bins ? bins + (size_t)b * m_cap : nullptr, m, Fb.taken + (size_t)b * Fb.cap,
+                     claim + (size_t)b * Fb.cap, min(Fb.n[b], Fb.cap), with_rotation, match_idx + (size_t)b * m_cap, n_out + b);
     // entries past the frame's point count read as "no match"
-    for (int i = m + threadIdx.x; i < m_cap; i += 256) match_idx[(size_t)b * m_cap + i] = -1;
+    for (int i = m + threadIdx.x; i < m_cap; i += blockDim.x) match_idx[(size_t)b * m_cap + i] = -1;
 }
 
 // CamDev of every frame of a batch from its pose (same operations, in the same order, as make_cam on the host)
@@ -1466,6 +1477,23 @@ int batch_scratch(snk_matcher* m, int batch, int m_cap, int cap, const snk_camer
 }
 }  // namespace
 
+static int launch_resolve_batch(snk_matcher* m, int batch, int cap, const int* best, const int* bins, const int* n_pts_dev, int pts_cap,
+                                const FramesDev& F, int* claim, int with_rotation, int* match_idx_dev, int* n_matches_dev)
+{
+    if (cap <= RESOLVE_LDS_FEATURES)
+    {
+        int rc = set_max_lds_once(reinterpret_cast<const void*>(resolve_batch_kernel<true>), RESOLVE_LDS_FEATURES * (int)sizeof(int) + 1024);
+        if (rc != SNK_OK) return rc;
+        hipLaunchKernelGGL(resolve_batch_kernel<true>, dim3(batch), dim3(1024), (size_t)cap * sizeof(int), m->stream, best, bins, n_pts_dev,
+                           pts_cap, F, claim, with_rotation, match_idx_dev, n_matches_dev);
+    }
+    else
+        hipLaunchKernelGGL(resolve_batch_kernel<false>, dim3(batch), dim3(1024), 0, m->stream, best, bins, n_pts_dev, pts_cap, F, claim,
+                           with_rotation, match_idx_dev, n_matches_dev);
+    SNK_LAUNCH_CHECK();
+    return SNK_OK;
+}
+
 int snk_match_project_coarse_batch_dev(snk_matcher* m, const snk_frames_dev* frames, const snk_camera* cam,
                                        const double* poses_dev, const snk_lm_coarse* pts_dev, const int32_t* n_pts_dev,
                                        int pts_cap, float th, int feature_error, int direction, const float* level_scale,
@@ -1497,9 +1525,9 @@ int snk_match_project_coarse_batch_dev(snk_matcher* m, const snk_frames_dev* fra
     else
         hipLaunchKernelGGL(coarse_batch_kernel, dim3(ceil_div(pts_cap, 4 * ppw), batch), dim3(256), 0, m->stream, F, (const CamDev*)cams, S,
                            pts_dev, n_pts_dev, pts_cap, ppw, th, feature_error, direction, best, bins);
-    hipLaunchKernelGGL(resolve_batch_kernel, dim3(batch), dim3(256), 0, m->stream, (const int*)best, (const int*)bins, n_pts_dev,
-                       pts_cap, F, claim, 1, match_idx_dev, n_matches_dev);
-    SNK_LAUNCH_CHECK();
+    if ((rc = launch_resolve_batch(m, batch, frames->cap, (const int*)best, (const int*)bins, n_pts_dev, pts_cap, F, claim, 1, match_idx_dev,
+                                   n_matches_dev)) != SNK_OK)
+        return rc;
     return SNK_OK;
 }
 
@@ -1534,9 +1562,9 @@ int snk_match_project_fine_batch_dev(snk_matcher* m, const snk_frames_dev* frame
     else
         hipLaunchKernelGGL(fine_batch_kernel, dim3(ceil_div(pts_cap, 4 * ppw), batch), dim3(256), 0, m->stream, F, (const CamDev*)cams, S,
                            pts_dev, n_pts_dev, pts_cap, ppw, th, ratio, best, visible_dev);
-    hipLaunchKernelGGL(resolve_batch_kernel, dim3(batch), dim3(256), 0, m->stream, (const int*)best, (const int*)nullptr, n_pts_dev,
-                       pts_cap, F, claim, 0, match_idx_dev, n_matches_dev);
-    SNK_LAUNCH_CHECK();
+    if ((rc = launch_resolve_batch(m, batch, frames->cap, (const int*)best, (const int*)nullptr, n_pts_dev, pts_cap, F, claim, 0,
+                                   match_idx_dev, n_matches_dev)) != SNK_OK)
+        return rc;
     return SNK_OK;
 }
 
