@@ -469,7 +469,7 @@ __global__ __launch_bounds__(64 * WAVES) void pose_kernel(const PoseMeta* __rest
 // ---- device-resident form: the matches of a projection matcher -> (world point, observation) pairs per frame ----
 // One wavefront per frame walks the local-map points in order (ballot prefix: the pairs keep the points' order, which is the
 // order RefinePoseWithMatches gathers them, PoseRefinement.cpp:37-57) and writes the frame's PoseMeta.
-__global__ __launch_bounds__(64) void gather_matches_kernel(const snk_kp64* __restrict__ kps, const float* __restrict__ depth, int cap,
+__global__ __launch_bounds__(256) void gather_matches_kernel(const snk_kp64* __restrict__ kps, const float* __restrict__ depth, int cap,
                                                             const unsigned char* __restrict__ pts, int pts_stride,
                                                             const int* __restrict__ match_idx, const int* __restrict__ n_pts,
                                                             int pts_cap, const double* __restrict__ poses, float s0, float s1, float s2,
@@ -477,20 +477,33 @@ __global__ __launch_bounds__(64) void gather_matches_kernel(const snk_kp64* __re
                                                             PoseMeta* __restrict__ meta, double* __restrict__ wps,
                                                             snk_pose_obs* __restrict__ obs, int* __restrict__ slot_of)
 {
-    const int b = blockIdx.x, lane = threadIdx.x;
+    // four wavefronts per frame, 256 points per round: ballot prefix inside a wavefront, the wavefronts' counts through LDS
+    // (double-buffered by round parity: one barrier per round) -- the pairs keep the points' order
+    __shared__ int s_wcnt[2][4];
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
     const int m = min(n_pts[b], pts_cap);
     const float ls[8] = {s0, s1, s2, s3, s4, s5, s6, s7};
     const size_t base = (size_t)b * pts_cap;
     int count = 0;
-    for (int i0 = 0; i0 < m; i0 += 64)
+    for (int i0 = 0, par = 0; i0 < m; i0 += 256, par ^= 1)
     {
-        const int i = i0 + lane;
+        const int i = i0 + tid;
         const int f = i < m ? match_idx[base + i] : -1;
         const bool has = f >= 0 && f < cap;
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(has);
+        if ((tid & 63) == 0) s_wcnt[par][wave] = __popcll(mask);
+        __syncthreads();
+        int before = 0, round_total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+        {
+            const int c = s_wcnt[par][w];
+            before += w < wave ? c : 0;
+            round_total += c;
+        }
         if (has)
         {
-            const int k = count + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            const int k = count + before + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
             const double* pp = reinterpret_cast<const double*>(pts + (base + i) * (size_t)pts_stride);
             double* w = wps + (base + k) * 3;
             w[0] = pp[0]; w[1] = pp[1]; w[2] = pp[2];
@@ -505,9 +518,9 @@ __global__ __launch_bounds__(64) void gather_matches_kernel(const snk_kp64* __re
             obs[base + k]     = o;
             slot_of[base + k] = i;
         }
-        count += __popcll(mask);
+        count += round_total;
     }
-    if (lane == 0)
+    if (tid == 0)
     {
         PoseMeta M;
         M.off = (int)base; M.n = count >= 3 ? count : 0;  // fewer than 3 correspondences: nothing to refine (PoseRefinement.cpp:59)
@@ -651,7 +664,7 @@ extern "C" int snk_pose_refine_matches_batch_dev(snk_matcher* m, const snk_frame
     char* o = m->out.as<char>();
     float ls[8];
     for (int i = 0; i < 8; ++i) ls[i] = level_scale[i < n_levels ? i : n_levels - 1];
-    hipLaunchKernelGGL(gather_matches_kernel, dim3(batch), dim3(64), 0, m->stream, frames->kps, depth_dev, frames->cap,
+    hipLaunchKernelGGL(gather_matches_kernel, dim3(batch), dim3(256), 0, m->stream, frames->kps, depth_dev, frames->cap,
                        reinterpret_cast<const unsigned char*>(pts_dev), pts_stride, match_idx_dev, n_pts_dev, pts_cap,
                        (const double*)poses_dev, ls[0], ls[1], ls[2], ls[3], ls[4], ls[5], ls[6], ls[7], n_levels,
                        reinterpret_cast<PoseMeta*>(d), reinterpret_cast<double*>(d + o_wps), reinterpret_cast<snk_pose_obs*>(d + o_obs),
