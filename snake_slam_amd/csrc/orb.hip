@@ -1976,9 +1976,19 @@ static int compute_layout(snk_orb* o, int w, int h)
         lv.pitch      = (lv.w + 63) & ~63;
         lv.img_stride = (long long)lv.pitch * lv.h;
         // streaming blur: balanced strips of <= 62 dwords, bands of 64 rows
-        lv.n_strips     = ceil_div(lv.w, 4 * SM_LANES_OUT);
-        lv.strip_stride = ((ceil_div(lv.w, lv.n_strips) + 3) / 4) * 4;
-        lv.n_bands      = ceil_div(lv.h, SM_BH);
+        if (lv.w > 0 && lv.h > 0)
+        {
+            lv.n_strips     = ceil_div(lv.w, 4 * SM_LANES_OUT);
+            lv.strip_stride = ((ceil_div(lv.w, lv.n_strips) + 3) / 4) * 4;
+            lv.n_bands      = ceil_div(lv.h, SM_BH);
+        }
+        else  // a level scaled down to nothing (small image, many levels, large scale factor): no strips, no work
+        {
+            lv.w = lv.w > 0 ? lv.w : 0;
+            lv.h = lv.h > 0 ? lv.h : 0;
+            lv.n_strips = lv.n_bands = 0;
+            lv.strip_stride = 4;
+        }
         lv.unit_off     = tile_off;
         tile_off += lv.n_strips * lv.n_bands;
     }
@@ -2306,6 +2316,7 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
     {
         const LevelInfo& lv = L.lv[l];
         const bool fused    = fused_ok && !tiny(l);
+        if (lv.w <= 0 || lv.h <= 0) continue;  // a level scaled down to nothing (small image, many levels): no pixels, no cells
         if (l > 0 && (!fused_ok || tiny(l - 1)))
         {
             const LevelInfo& sv = L.lv[l - 1];
@@ -2320,7 +2331,7 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
             const int gx = ceil_div(lv.n_strips * lv.n_bands, 4);
             auto lk = l == 0 && !aligned0 ? level_kernel<false> : level_kernel<true>;
             hipLaunchKernelGGL(lk, xcd_grid(gx, batch), dim3(256), 0, st, L, l, images_dev, pitch, image_stride,
-                               fused && l + 1 < L.n_levels ? 1 : 0, gx, batch);
+                               fused && l + 1 < L.n_levels && L.lv[l + 1].w > 0 && L.lv[l + 1].h > 0 ? 1 : 0, gx, batch);
         }
         SNK_LAUNCH_CHECK();
     }

@@ -348,3 +348,13 @@ def test_fast_survivor_list_spill_path_on_ordinary_images():
                        env=dict(os.environ, SNK_ORB_FAST_SURV_CAP="128", SNK_ORB_NO_RECURSE="1"), capture_output=True, text=True, cwd=str(root), timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-1000:])
     assert " passed" in r.stdout
+
+
+def test_levels_scaled_down_to_nothing(orc):
+    """Small images with many levels and a large scale factor: deep levels round to zero width and / or height (found by
+    tools/fuzz_orb.py: a zero grid dimension in one case, an integer division by the zero strip count in another).  Such levels
+    have no pixels and no cells; the levels above them are unaffected."""
+    rng = np.random.default_rng(SEED + 1234)
+    for shape, levels, scale in [((40, 1300), 8, 2.5), ((60, 45), 8, 2.5), ((45, 70), 8, 2.0), ((800, 48), 7, 2.5)]:
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        check_image(orc, img, 400, levels, scale, 20, 7, stages=False)
