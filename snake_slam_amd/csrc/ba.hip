@@ -74,6 +74,7 @@ struct Prob
 struct Opt
 {
     int max_pcg;
+    int pcg_general;  // SNK_BA_PCG_GENERAL=1: the 256-thread PCG loop for every size (A/B against the replicated one)
     double pcg_tol, huber_mono, huber_stereo, lambda_init;
 };
 
@@ -2033,7 +2034,7 @@ __global__ __launch_bounds__(PCG_THREADS) void pcg_solve(Arrays A, Opt O)
     double rn2 = bnorm2;  // |r|^2 of the current residual (x = 0: r = rhs); later iterations get it with r.z in one reduction
     const double stop2 = O.pcg_tol * O.pcg_tol * bnorm2;
     if constexpr (S_IN_LDS)
-        if (n6 <= 128)
+        if (n6 <= 128 && !O.pcg_general)
         {
             // Local-BA sized systems (<= 21 free cameras).  Every wavefront holds the WHOLE iteration state in registers (two
             // rows per lane: r, p, x, its rows of the block-Jacobi inverse) and runs the same arithmetic on it, so the four
@@ -2710,6 +2711,8 @@ Opt make_opt(const snk_ba_options& o)
 {
     Opt d;
     d.max_pcg      = o.max_pcg_iterations;
+    static const bool pcg_general = getenv("SNK_BA_PCG_GENERAL") != nullptr;
+    d.pcg_general  = pcg_general ? 1 : 0;
     d.pcg_tol      = o.pcg_tol;
     d.huber_mono   = o.huber_mono;
     d.huber_stereo = o.huber_stereo;

@@ -18,6 +18,7 @@ ROOT = Path(__file__).resolve().parent.parent
     {"SNK_BA_NO_POINT_WAVE": "1"},        # thread-per-point linearisation + schur_pass with activity lookups
     {"SNK_BA_SCHUR_SET_MIN_ITEMS": "1", "SNK_BA_NO_GRAPH": "1"},
     {"SNK_BA_GRAPH_FIRST": "1"},
+    {"SNK_BA_PCG_GENERAL": "1"},          # the 256-thread PCG loop instead of the replicated four-wavefront one
     {"SNK_BA_SCHUR_SET_MIN_ITEMS": "1", "SNK_BA_FUSED_K10": "1"},       # schur_fused<4> also where points have 9-10 free observations
     {"SNK_BA_SCHUR_SET_MIN_ITEMS": "1", "SNK_BA_NO_SCHUR_FUSED": "1"},  # point_wave + schur_mfma (W through HBM)
     {"SNK_BA_SCHUR_SET_MIN_ITEMS": "1", "SNK_BA_NO_SCHUR_MFMA": "1"},   # point_wave + the vector-ALU schur_set          # explicitly built hipGraph already for the first solve of every scene

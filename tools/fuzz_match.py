@@ -1,0 +1,101 @@
+"""Seeded fuzz of the matchers against the oracle (bit-exact): brute-force kNN-2 + filter, the stereo row-band matcher, the
+projection matchers (coarse / fine / keyframe) through the host API, with random sizes (including 0, 1, one more / less than a
+wavefront), thresholds, radii and descriptor entropies.  Not part of the test suite; run after changes to matcher.hip / track.hip:
+
+    python tools/fuzz_match.py [--seconds 120] [--seed 1]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import track_helpers as T  # noqa: E402
+from helpers import knn_to_array, make_stereo_case, rand_desc  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+from snake_slam_amd.matcher import BruteForceMatcher, StereoMatcher  # noqa: E402
+from snake_slam_amd.tracking import SnakeORBMatcher  # noqa: E402
+
+
+def sizes(rng, hi):
+    return int(rng.choice([0, 1, 2, 63, 64, 65, int(rng.integers(3, hi)), int(rng.integers(3, hi))]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    orc.build()
+    rng = np.random.default_rng(a.seed)
+    bf, st, pm = BruteForceMatcher(0), StereoMatcher(0), SnakeORBMatcher(0)
+    t0, n = time.time(), {"bf": 0, "stereo": 0, "coarse": 0, "fine": 0, "keyframe": 0}
+    while time.time() - t0 < a.seconds:
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            nq, nt = sizes(rng, 2500), sizes(rng, 2500)
+            q, t = rand_desc(rng, nq), rand_desc(rng, nt)
+            if rng.random() < 0.3 and nq and nt:  # low entropy: ties everywhere
+                base = rand_desc(rng, 4)
+                q, t = base[rng.integers(0, 4, nq)], base[rng.integers(0, 4, nt)]
+            bf.matchKnn2(q, t)
+            want = orc.bf_knn2(q, t)
+            ok = np.array_equal(knn_to_array(bf.knn), knn_to_array(want))
+            th, ratio = int(rng.integers(1, 257)), float(rng.choice([0.6, 0.75, 0.8, 0.9, 1.0]))
+            cnt = bf.filterMatches(th, ratio)
+            wp = orc.bf_filter(want, th, ratio)
+            ok = ok and cnt == wp.shape[0] and np.array_equal(bf.matches, wp)
+            what = f"bf {nq}x{nt} th {th} ratio {ratio}"
+            n["bf"] += 1
+        elif kind == 1:
+            nl, nr = sizes(rng, 3000), sizes(rng, 3000)
+            relaxed = bool(rng.integers(0, 2))
+            if nl == 0 or nr == 0:
+                continue  # make_stereo_case needs one keypoint on each side; the empty cases are in the test suite
+            kl, dl, kr, dr, bfv, ls = make_stereo_case(rng, nl, nr, n_levels=int(rng.integers(1, 8)))
+            got = st.StereoMatching(kl, dl, kr, dr, bfv, ls, relaxed)
+            want = orc.stereo_match(kl, dl, kr, dr, bfv, ls, relaxed)
+            ok = got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+            what = f"stereo {nl}x{nr} relaxed {relaxed}"
+            n["stereo"] += 1
+        else:
+            frame, cam, pose, ls, world, _ = T.make_tracking_case(orc, rng, n_clutter=sizes(rng, 2500), m_pts=max(20, sizes(rng, 3000)),
+                                                                  n_levels=int(rng.integers(1, 8)), stereo_frac=float(rng.random()),
+                                                                  taken_frac=float(rng.random()) * 0.3)
+            if kind == 2:
+                pts = T.lm_coarse(orc, world)
+                th, fe, direction = float(rng.uniform(2, 40)), int(rng.integers(20, 150)), int(rng.integers(0, 3))
+                got = pm.SearchByProjectionFrameFrame2(frame, cam, pose, pts, th, fe, direction, ls)
+                want = orc.match_coarse(frame, cam, pose, pts, th, fe, direction, ls)
+                ok = got[0] == want[0] and np.array_equal(got[1], want[1])
+                what, key = f"coarse m {len(pts)} n {len(frame['kps'])} th {th} fe {fe} dir {direction}", "coarse"
+            elif kind == 3:
+                pts = T.lm_fine(orc, rng, world, pose, ls)
+                th, ratio = float(rng.uniform(0.5, 8)), float(rng.choice([0.6, 0.8, 0.9]))
+                got = pm.SearchByProjection2(frame, cam, pose, pts.copy(), th, ratio, ls)
+                want = orc.match_fine(frame, cam, pose, pts.copy(), th, ratio, ls)
+                ok = got[0] == want[0] and all(np.array_equal(g, w) for g, w in zip(got[1:], want[1:]))
+                what, key = f"fine m {len(pts)} n {len(frame['kps'])} th {th} ratio {ratio}", "fine"
+            else:
+                skip = (rng.random(len(world["pos"])) < 0.1).astype(np.uint8)
+                th, fe = float(rng.uniform(2, 40)), int(rng.integers(20, 150))
+                got = pm.SearchByProjectionFrameToKeyframe(frame, cam, pose, world["pos"], world["desc"], skip, th, fe)
+                want = orc.match_keyframe(frame, cam, pose, world["pos"], world["desc"], skip, th, fe)
+                ok = got[0] == want[0] and np.array_equal(got[1], want[1])
+                what, key = f"keyframe m {len(skip)} n {len(frame['kps'])} th {th} fe {fe}", "keyframe"
+            n[key] += 1
+        if not ok:
+            print(f"MISMATCH: {what} (seed {a.seed}, case {sum(n.values())})")
+            return 1
+    print(f"fuzz_match: {n}, all bit-exact (seed {a.seed}, {time.time() - t0:.0f} s)")
+    for h in (bf, st, pm):
+        h.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
