@@ -1,5 +1,6 @@
 """Seeded fuzz of the matchers against the oracle (bit-exact): brute-force kNN-2 + filter, the stereo row-band matcher, the
-projection matchers (coarse / fine / keyframe) through the host API, with random sizes (including 0, 1, one more / less than a
+projection matchers (coarse / fine / keyframe) and the local-mapping matchers (fuse, triangulation by projection / BoW / brute force,
+relink) through the host API, with random sizes (including 0, 1, one more / less than a
 wavefront), thresholds, radii and descriptor entropies.  Not part of the test suite; run after changes to matcher.hip / track.hip:
 
     python tools/fuzz_match.py [--seconds 120] [--seed 1]
@@ -18,7 +19,7 @@ import track_helpers as T  # noqa: E402
 from helpers import knn_to_array, make_stereo_case, rand_desc  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 from snake_slam_amd.matcher import BruteForceMatcher, StereoMatcher  # noqa: E402
-from snake_slam_amd.tracking import SnakeORBMatcher  # noqa: E402
+from snake_slam_amd.tracking import DeferredMapper, MappingORBMatcher, SnakeORBMatcher  # noqa: E402
 
 
 def sizes(rng, hi):
@@ -32,10 +33,11 @@ def main():
     a = ap.parse_args()
     orc.build()
     rng = np.random.default_rng(a.seed)
-    bf, st, pm = BruteForceMatcher(0), StereoMatcher(0), SnakeORBMatcher(0)
-    t0, n = time.time(), {"bf": 0, "stereo": 0, "coarse": 0, "fine": 0, "keyframe": 0}
+    bf, st, pm, mm, dm = BruteForceMatcher(0), StereoMatcher(0), SnakeORBMatcher(0), MappingORBMatcher(), DeferredMapper()
+    t0, n = time.time(), {"bf": 0, "stereo": 0, "coarse": 0, "fine": 0, "keyframe": 0, "fuse": 0, "tri_project": 0, "tri_bow": 0,
+                          "tri_bf": 0, "relink": 0}
     while time.time() - t0 < a.seconds:
-        kind = int(rng.integers(0, 5))
+        kind = int(rng.integers(0, 10))
         if kind == 0:
             nq, nt = sizes(rng, 2500), sizes(rng, 2500)
             q, t = rand_desc(rng, nq), rand_desc(rng, nt)
@@ -62,6 +64,48 @@ def main():
             ok = got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
             what = f"stereo {nl}x{nr} relaxed {relaxed}"
             n["stereo"] += 1
+        elif kind >= 5:
+            m_pts, clutter = max(30, sizes(rng, 2000)), sizes(rng, 1500)
+            if kind == 5:
+                frame, cam, pose, ls, world, _ = T.make_tracking_case(orc, rng, n_clutter=clutter, m_pts=m_pts, n_levels=int(rng.integers(2, 8)))
+                pts = T.fusion_points(orc, rng, world, pose, ls)
+                mask = (rng.random(len(pts)) > 0.2).astype(np.uint8) if rng.random() < 0.5 else None
+                th, of, fth = float(rng.uniform(1, 8)), float(rng.uniform(0.5, 4)), int(rng.integers(20, 120))
+                got = mm.Fuse(frame, cam, pose, pts, mask, th, of, fth, ls)
+                want = orc.match_fuse(frame, cam, pose, pts, mask, th, of, fth, ls)
+                ok = got[0] == want[0] and np.array_equal(got[2], want[1])
+                what, key = f"fuse m {len(pts)} n {len(frame['kps'])} th {th} of {of} fth {fth}", "fuse"
+            elif kind == 6:
+                c = T.make_triangulation_case(orc, rng, m_pts=m_pts, n_clutter=clutter)
+                epi, fd = float(rng.uniform(0.5, 10)), int(rng.integers(20, 100))
+                args = (c["grid"], c["pose1"], c["pose2"], c["cam"], c["kps1"], c["np1"], c["desc1"], c["has1"], c["frame2"], c["np2"], c["E"], epi, fd)
+                got = mm.SearchForTriangulationProject(*args)
+                want = orc.match_triangulation_project(*args)
+                ok = got[0] == want[0] and np.array_equal(got[2], want[1])
+                what, key = f"tri_project m {m_pts} clutter {clutter} epi {epi} fd {fd}", "tri_project"
+            elif kind == 7:
+                c = T.make_bow_case(rng, m_pts=m_pts, n_clutter=clutter, n_nodes=int(rng.choice([1, 3, 30, 120, 400])))
+                epi, fd = float(rng.uniform(0.5, 10)), int(rng.integers(20, 100))
+                args = (c["cam"], c["E"], c["np1"], c["desc1"], c["has1"], c["bow1"], c["np2"], c["desc2"], c["has2"], c["bow2"], epi, fd)
+                got = mm.SearchForTriangulation2(*args)
+                want = orc.match_triangulation_bow(*args)
+                ok = got[0] == want[0] and [tuple(map(int, p)) for p in got[1]] == [tuple(p) for p in np.asarray(want[1]).tolist()]
+                what, key = f"tri_bow m {m_pts} clutter {clutter} epi {epi} fd {fd}", "tri_bow"
+            elif kind == 8:
+                c = T.make_bow_case(rng, m_pts=m_pts, n_clutter=clutter)
+                fd = int(rng.integers(20, 100))
+                args = (c["cam"], c["E"], c["np1"], c["desc1"], c["has1"], c["np2"], c["desc2"], c["has2"], fd)
+                got = mm.SearchForTriangulationBF(*args)
+                want = orc.match_triangulation_bf(*args)
+                ok = got[0] == want[0] and np.array_equal(got[2], want[1])
+                what, key = f"tri_bf m {m_pts} clutter {clutter} fd {fd}", "tri_bf"
+            else:
+                frame, cam, pose, qs = T.make_relink_case(orc, rng, n_base=max(20, sizes(rng, 2500)))
+                got = dm.RelinkSearch(frame, cam, pose, qs)
+                want = orc.match_relink(frame, cam, pose, qs)
+                ok = got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+                what, key = f"relink n {len(frame['kps'])} q {len(qs)}", "relink"
+            n[key] += 1
         else:
             frame, cam, pose, ls, world, _ = T.make_tracking_case(orc, rng, n_clutter=sizes(rng, 2500), m_pts=max(20, sizes(rng, 3000)),
                                                                   n_levels=int(rng.integers(1, 8)), stereo_frac=float(rng.random()),
@@ -92,7 +136,7 @@ def main():
             print(f"MISMATCH: {what} (seed {a.seed}, case {sum(n.values())})")
             return 1
     print(f"fuzz_match: {n}, all bit-exact (seed {a.seed}, {time.time() - t0:.0f} s)")
-    for h in (bf, st, pm):
+    for h in (bf, st, pm, mm):
         h.close()
     return 0
 
