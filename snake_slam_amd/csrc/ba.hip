@@ -1970,7 +1970,6 @@ constexpr int PCG_THREADS = 256;
 template <bool S_IN_LDS>
 __global__ __launch_bounds__(PCG_THREADS) void pcg_solve(Arrays A, Opt O)
 {
-    constexpr int s_in_lds = S_IN_LDS ? 1 : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ double red[PCG_THREADS];
     const int pb  = blockIdx.x;
