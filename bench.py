@@ -225,6 +225,8 @@ def main():
     from snake_slam_amd import parallel, synth
 
     env_rank, _, local = parallel.env_rank_world()
+    if os.environ.get("SNK_BENCH_DEVICE"):  # rehearsal of the N > 1 code on a one-GPU box (with SNK_DIST_BACKEND=gloo): every rank on this device
+        local = int(os.environ["SNK_BENCH_DEVICE"])
     # Synthetic inputs first (worker processes are forked here, before this process owns a HIP context): EVERY frame of the batch
     # and EVERY BA window is its own seeded scene, so the data-dependent kernels (FAST survivors, quadtree, stereo bands, the
     # camera-set grouping of BA) see B / NW different workloads, not a handful tiled.

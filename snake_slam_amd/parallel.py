@@ -27,7 +27,9 @@ def init_distributed(device: torch.device | None = None, backend: str | None = N
     os.environ.setdefault("MASTER_PORT", "29531")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend is None:
-        backend = "nccl" if (device is not None and device.type == "cuda") else "gloo"
+        # SNK_DIST_BACKEND=gloo: rehearsal of the multi-rank code on a box with one GPU (every rank on the same device, see
+        # bench.py SNK_BENCH_DEVICE); RCCL refuses two ranks on one device
+        backend = os.environ.get("SNK_DIST_BACKEND") or ("nccl" if (device is not None and device.type == "cuda") else "gloo")
     kw = {"device_id": device} if backend == "nccl" and device is not None else {}
     dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world
@@ -50,8 +52,12 @@ def shard_range(n_items: int, rank: int, world: int) -> range:
     return range(lo, lo + base + (1 if rank < rem else 0))
 
 
+def _host_backend() -> bool:
+    return is_distributed() and dist.get_backend() == "gloo"
+
+
 def max_over_ranks(value: float, device: torch.device) -> float:
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if _host_backend() else device)
     if is_distributed():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
@@ -62,9 +68,14 @@ def gather_result_blocks(block: torch.Tensor) -> list[torch.Tensor]:
     assert block.numel() == RESULT_BLOCK and block.dtype == torch.float64
     if not is_distributed():
         return [block]
-    out = [torch.zeros_like(block) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, block)
-    return out
+    return _all_gather(block)
+
+
+def _all_gather(block: torch.Tensor) -> list[torch.Tensor]:
+    src = block.cpu() if _host_backend() else block  # gloo gathers host tensors
+    out = [torch.zeros_like(src) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, src)
+    return [o.to(block.device) for o in out]
 
 
 def gather_blocks(block: torch.Tensor) -> list[torch.Tensor]:
@@ -74,9 +85,7 @@ def gather_blocks(block: torch.Tensor) -> list[torch.Tensor]:
     assert block.dim() == 1
     if not is_distributed():
         return [block]
-    out = [torch.zeros_like(block) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, block)
-    return out
+    return _all_gather(block)
 
 
 def shutdown() -> None:

@@ -35,3 +35,27 @@ def test_committed_default_line_has_the_cpu_baseline():
     d = json.loads((ROOT / "profiles" / "r01h_bench_default.json").read_text())
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 4 and cb["value"] > 0 and "sample" in cb and cb["ba"]["cores"] == 1
+
+
+@pytest.mark.parametrize("mode", ["batch", "sequence"])
+def test_two_ranks_rehearsal_on_one_gpu(mode):
+    """The N > 1 code of bench.py (per-rank data, barriers, max over ranks, result / trajectory gather, rank 0 prints) launched the
+    way the driver launches it, with both ranks on cuda:0 and gloo standing in for RCCL (which refuses two ranks on one
+    device): the line must report n_gpus = 2 and the work of two ranks."""
+    import os
+
+    env = dict(os.environ, SNK_DIST_BACKEND="gloo", SNK_BENCH_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--mode", mode]
+    if mode == "batch":
+        cmd += ["--batch", "16", "--ba-windows", "8", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(ROOT), timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    if mode == "batch":
+        assert d["config"]["frames_per_gpu_per_step"] == 16 and d["ba"]["value"] > 0
+    else:
+        assert len(d["trajectories"]) == 2 if "trajectories" in d else True
