@@ -468,11 +468,16 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
     if (dbg_stop == 1) return;  // SNK_ORB_FAST_STOP (timing experiments only, results are then meaningless): after the tile load
 
     // phase B: exact score of the survivors, two per lane
-    auto score_survivors = [&](int ns)
+    // Returns how many of the ns survivors score above min_th; those are moved to the front of the list (in place: a round writes
+    // no further than it has read), so that the non-maximum pass only walks real corners -- about a third of the survivors.
+    auto score_survivors = [&](int ns) -> int
     {
-    for (int j = lane * 2; j < ns; j += 128)
+    int n2 = 0;
+    for (int j0 = 0; j0 < ns; j0 += 128)  // wave-uniform rounds (ballots inside)
     {
-        const int e0 = surv[j], e1 = surv[j + 1 < ns ? j + 1 : j];
+        const int j = j0 + lane * 2;
+        const bool a0 = j < ns, a1 = j + 1 < ns;
+        const int e0 = surv[a0 ? j : ns - 1], e1 = surv[a1 ? j + 1 : ns - 1];
         const int px0 = e0 & 63, py0 = e0 >> 6, px1 = e1 & 63, py1 = e1 >> 6;
         const u8* t0 = tile + (py0 + 3) * TP + px0 + 3 + sh;
         const u8* t1 = tile + (py1 + 3) * TP + px1 + 3 + sh;
@@ -498,9 +503,16 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
 #undef RING
             s = fast_score16_pk(d);
         }
-        S[(py0 + 1) * SP + px0 + 1] = (u8)(s.x < 0 ? 0 : s.x);
-        if (j + 1 < ns) S[(py1 + 1) * SP + px1 + 1] = (u8)(s.y < 0 ? 0 : s.y);
+        if (a0) S[(py0 + 1) * SP + px0 + 1] = (u8)(s.x < 0 ? 0 : s.x);
+        if (a1) S[(py1 + 1) * SP + px1 + 1] = (u8)(s.y < 0 ? 0 : s.y);
+        const bool k0 = a0 && (int)s.x > min_th, k1 = a1 && (int)s.y > min_th;
+        const u64 m0 = __builtin_amdgcn_ballot_w64(k0), m1 = __builtin_amdgcn_ballot_w64(k1);
+        const int c0 = __popcll(m0);
+        if (k0) surv[n2 + __builtin_amdgcn_mbcnt_hi((u32)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m0, 0u))] = (u16)e0;
+        if (k1) surv[n2 + c0 + __builtin_amdgcn_mbcnt_hi((u32)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m1, 0u))] = (u16)e1;
+        n2 += c0 + __popcll(m1);
     }
+    return n2;
     };
 
     // phase A: every 9-arc holds one pixel of each opposite pair -> S <= min_i max(d_i, d_{i+8}).  The loops
@@ -516,7 +528,7 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
     auto flush = [&]()
     {
         __builtin_amdgcn_wave_barrier();
-        score_survivors(ns);
+        (void)score_survivors(ns);
         __builtin_amdgcn_wave_barrier();
         ns      = 0;
         spilled = true;
@@ -613,14 +625,14 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
     __builtin_amdgcn_wave_barrier();
     if (dbg_stop == 2) return;  // after the quick test
 
-    score_survivors(ns);
+    const int ns2 = score_survivors(ns);  // corners' positions are now surv[0 .. ns2)
     __builtin_amdgcn_wave_barrier();
 
     if (dbg_stop == 3) return;  // after the exact scores
     // 3x3 non-max suppression (strict) among scores above min_th (all of them are survivors); the list of
     // corners is appended the same way (wave-uniform loop, ballot prefix, counts in scalar registers)
     int nl = 0, nini = 0;
-    const int n_items = spilled ? ch * 64 : ns;  // spilled: every (row, lane = column) of the cell
+    const int n_items = spilled ? ch * 64 : ns2;  // spilled: every (row, lane = column) of the cell
     for (int j0 = 0; j0 < n_items; j0 += 64)
     {
         const int j  = j0 + lane;
@@ -633,8 +645,8 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
         }
         else
         {
-            e     = surv[min(j, ns - 1)];
-            valid = j < ns;
+            e     = surv[min(j, ns2 - 1)];
+            valid = j < ns2;
         }
         const int px = e & 63, py = e >> 6;
         const u8* s  = &S[(py + 1) * SP + px + 1];
