@@ -47,36 +47,116 @@ def pyramid_pixels():
     return tot
 
 
-def cpu_baseline(frames, seconds_budget=12.0):
+def cpu_baseline(frames, gpu=None, seconds_budget=12.0):
     """Oracle pipeline on host cores with the reference's thread configuration: extractor 2
-    threads (fd_threads), matchers 4 threads (num_tracking_threads)."""
+    threads (fd_threads), matchers 4 threads (num_tracking_threads).
+
+    The oracle's results are KEPT (first visit of every distinct frame) and, after the clock has stopped, compared bit for bit
+    with what the timed steps left in HBM (`gpu`, host copies made by `snapshot_outputs`): keypoints / descriptors / counts of
+    BOTH extractor output sets (the two-stream pipeline alternates between them; an ordering bug between the streams would show
+    here), the grid-ordered left features, `right_points` / `depth` / match count of StereoMatching, the kNN-2 table and the
+    filtered pairs.  The line reports `identical_to_gpu` and `frames_checked`."""
     from oracle import oracle as orc
 
     orc.build()
     p = orc.orb_params(ORB["nfeatures"], ORB["scale_factor"], ORB["n_levels"], ORB["ini_th_fast"], ORB["min_th_fast"])
     ls = (np.float32(ORB["scale_factor"]) ** np.arange(ORB["n_levels"])).astype(np.float32)
     rect = orc.rectification((1.0, 1.0, 0.0, 0.0))
+    bounds = (0.0, 0.0, float(W), float(H))
+    kept = {}
     done, t0 = 0, time.perf_counter()
     while True:
-        left, right = frames[done % len(frames)]
+        i = done % len(frames)
+        left, right = frames[i]
         kl, dl = orc.orb_detect(p, left, threads=2)
         kr, dr = orc.orb_detect(p, right, threads=2)
         rl, _ = orc.rectify(rect, kl)
         rr, _ = orc.rectify(rect, kr)
-        orc.stereo_match(rl, dl, rr, dr, BF_SYNTH, ls, True)
-        knn = orc.bf_knn2(dl, dr, threads=4)
-        orc.bf_filter(knn, 60, 0.8)
+        perm, _, _, _ = orc.feature_grid(rl, bounds)          # computeFeatureGrid: left features into grid order
+        g, gd = np.zeros_like(rl), np.zeros_like(dl)
+        g[perm], gd[perm] = rl, dl
+        ns, rp, dp = orc.stereo_match(g, gd, rr, dr, BF_SYNTH, ls, True)
+        knn = orc.bf_knn2(gd, dr, threads=4)
+        pairs = orc.bf_filter(knn, 60, 0.8)
+        if i not in kept:
+            kept[i] = (kl, dl, kr, dr, g, gd, rr, ns, rp, dp, knn, pairs)
         done += 1
         el = time.perf_counter() - t0
         if el >= seconds_budget or done >= 2000:
             break
-    return {"value": round(done / el, 3), "unit": "frames/s", "cores": 4, "kind": "port",
-            "sample": f"{done} stereo frames {W}x{H} (extract L+R with 2 threads, rectify, stereo match, "
-                      f"BF kNN-2 with 4 threads + filter) in {el:.1f} s; CPU restatement of the reference path, not the reference binary"}
+    out = {"value": round(done / el, 3), "unit": "frames/s", "cores": 4, "kind": "port",
+           "sample": f"{done} stereo frames {W}x{H} (extract L+R with 2 threads, rectify, feature grid, stereo match, "
+                     f"BF kNN-2 with 4 threads + filter) in {el:.1f} s; CPU restatement of the reference path, not the reference binary"}
+    if gpu is not None:
+        bad = compare_with_oracle(gpu, kept)
+        out["identical_to_gpu"] = not bad
+        out["frames_checked"] = len(kept)
+        out["checked"] = ("keypoints, descriptors and counts of both extractor output sets (L+R), grid-ordered left features, "
+                          "right_points, depth, stereo count, kNN-2 table, filtered pairs -- bit for bit against the oracle")
+        if bad:
+            out["first_differences"] = bad[:8]
+    return out
 
 
-def cpu_baseline_ba(seconds_budget=8.0):
-    """Oracle LBA solve (1 thread, like the reference's numThreads = 1, LocalBundleAdjustment.cpp:56)."""
+def snapshot_outputs(B, out_sets, kp64, kp64_g, desc_g, right_points, depth, n_stereo, knn, pairs, n_pairs, n_check):
+    """Host copies of what the timed steps left in HBM for the first n_check frames of the batch (frame b holds distinct pair
+    b): both extractor output sets and the single-buffered outputs of the post-extraction stage."""
+    from snake_slam_amd.matcher import KNN2_DTYPE, KP64_DTYPE
+    from snake_slam_amd.orb import KEYPOINT_DTYPE
+
+    n = n_check
+    cap = kp64_g.shape[1]
+    sets = []
+    for kps, desc, nkp in out_sets:
+        sets.append({
+            "kl": kps[:n].cpu().numpy().view(KEYPOINT_DTYPE).reshape(n, cap), "kr": kps[B:B + n].cpu().numpy().view(KEYPOINT_DTYPE).reshape(n, cap),
+            "dl": desc[:n].cpu().numpy().view(np.uint64), "dr": desc[B:B + n].cpu().numpy().view(np.uint64),
+            "nl": nkp[:n].cpu().numpy(), "nr": nkp[B:B + n].cpu().numpy()})
+    return {"sets": sets, "rr": kp64[B:B + n].cpu().numpy().view(KP64_DTYPE).reshape(n, cap),
+            "g": kp64_g[:n].cpu().numpy().view(KP64_DTYPE).reshape(n, cap), "gd": desc_g[:n].cpu().numpy().view(np.uint64),
+            "rp": right_points[:n].cpu().numpy(), "dp": depth[:n].cpu().numpy(), "ns": n_stereo[:n].cpu().numpy(),
+            "knn": knn[:n].cpu().numpy().view(KNN2_DTYPE).reshape(n, cap), "pairs": pairs[:n].cpu().numpy(), "np": n_pairs[:n].cpu().numpy()}
+
+
+def compare_with_oracle(gpu, kept):
+    """-> list of "frame b: what" strings (empty = identical).  Exact comparison of every field (floats bit for bit)."""
+    bad = []
+
+    def same(a, b):
+        a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+        return a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes()
+
+    for b, (kl, dl, kr, dr, g, gd, rr, ns, rp, dp, knn, pairs) in sorted(kept.items()):
+        if b >= len(gpu["ns"]):
+            continue
+        nl, nr = len(kl), len(kr)
+        for si, st in enumerate(gpu["sets"]):
+            if int(st["nl"][b]) != nl or int(st["nr"][b]) != nr:
+                bad.append(f"frame {b} set {si}: keypoint counts {int(st['nl'][b])}/{int(st['nr'][b])} vs oracle {nl}/{nr}")
+                continue
+            for name, got, want in (("left keypoints", st["kl"][b, :nl], kl), ("right keypoints", st["kr"][b, :nr], kr),
+                                    ("left descriptors", st["dl"][b, :nl], dl), ("right descriptors", st["dr"][b, :nr], dr)):
+                if not same(got, want):
+                    bad.append(f"frame {b} set {si}: {name}")
+        if len(bad) > 16:
+            break
+        checks = (("rectified right keypoints", gpu["rr"][b, :nr], rr), ("grid-ordered left keypoints", gpu["g"][b, :nl], g),
+                  ("grid-ordered left descriptors", gpu["gd"][b, :nl], gd), ("right_points", gpu["rp"][b, :nl], rp),
+                  ("depth", gpu["dp"][b, :nl], dp), ("kNN-2 table", gpu["knn"][b, :nl], knn),
+                  ("filtered pairs", gpu["pairs"][b, :int(gpu["np"][b])], pairs))
+        for name, got, want in checks:
+            if not same(got, want):
+                bad.append(f"frame {b}: {name}")
+        if int(gpu["ns"][b]) != int(ns):
+            bad.append(f"frame {b}: stereo match count {int(gpu['ns'][b])} vs {int(ns)}")
+    return bad
+
+
+def cpu_baseline_ba(ba_check=None, seconds_budget=8.0):
+    """Oracle LBA solve (1 thread, like the reference's numThreads = 1, LocalBundleAdjustment.cpp:56).  `ba_check` holds, for
+    three windows of the timed batch, (scene, cost_initial, cost_final, poses, points) as the LAST timed solve left them: the
+    oracle solves the same scenes and the line reports the largest relative cost difference and pose / point RMSE
+    (north_star: <= 1e-5 RMSE)."""
     from oracle import oracle as orc
     from snake_slam_amd import synth
 
@@ -88,8 +168,22 @@ def cpu_baseline_ba(seconds_budget=8.0):
         el = time.perf_counter() - t0
         if el > seconds_budget:
             break
-    return {"value": round(done * 3 / el, 2), "unit": "LM iterations/s", "cores": 1, "kind": "port",
-            "sample": f"{done} solves of the 20x2000x8 window (3 LM iterations each) in {el:.1f} s"}
+    out = {"value": round(done * 3 / el, 2), "unit": "LM iterations/s", "cores": 1, "kind": "port",
+           "sample": f"{done} solves of the 20x2000x8 window (3 LM iterations each) in {el:.1f} s"}
+    if ba_check:
+        worst = {"cost_initial_rel": 0.0, "cost_final_rel": 0.0, "pose_rmse": 0.0, "point_rmse": 0.0}
+        for k, (scene, ci, cf, pose, pt) in ba_check.items():
+            wpose, wpt, wci, wcf, _ = orc.ba_solve(scene, orc.ba_options())
+            worst["cost_initial_rel"] = max(worst["cost_initial_rel"], abs(ci - wci) / max(abs(wci), 1e-300))
+            worst["cost_final_rel"] = max(worst["cost_final_rel"], abs(cf - wcf) / max(abs(wcf), 1e-300))
+            worst["pose_rmse"] = max(worst["pose_rmse"], float(np.sqrt(np.mean((pose - wpose) ** 2))))
+            worst["point_rmse"] = max(worst["point_rmse"], float(np.sqrt(np.mean((pt - wpt) ** 2))))
+        ok = worst["cost_initial_rel"] <= 1e-9 and worst["cost_final_rel"] <= 1e-7 and worst["pose_rmse"] <= 1e-5 and worst["point_rmse"] <= 1e-5
+        out["identical_to_gpu"] = bool(ok)
+        out["windows_checked"] = sorted(ba_check)
+        out["tolerance"] = "pose / point RMSE <= 1e-5 (north_star), cost_initial 1e-9 / cost_final 1e-7 relative"
+        out["worst"] = {k: float(f"{v:.3e}") for k, v in worst.items()}
+    return out
 
 
 TRACK_M_COARSE = 1500   # maxFeatures: last-frame + last-keyframe points (reference SnakeGlobal.h:120, TrackingCoarse.cpp:94-127)
@@ -173,7 +267,7 @@ def sequence_mode(args, rank, world, local, dev):
                              "ground_truth_x": round(float(gt), 5)})
         st = trk.stats
         out = {"metric": f"frames/s, sequence mode (per-frame tracking chain through the host API) @{W}x{H}",
-               "value": round(world * args.steps / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+               "value": round(world * args.steps / elapsed, 2), "unit": "frames/s", "n_gpus": world, "dist": parallel.describe(), "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "u8", "data": f"synthetic: one seeded {W}x{H} stereo sequence per rank (rig moving 0.05 baselines per frame)",
                "config": {"workload": f"{world} independent stereo sequences, one per GPU: Detect L+R, rectify, feature grid, StereoMatching, "
@@ -188,6 +282,39 @@ def sequence_mode(args, rank, world, local, dev):
                "cpu_baseline": None}
         print(json.dumps(out), flush=True)
     trk.close()
+
+
+def spawn_ranks_if_needed(args):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset) starts its own N ranks: it re-executes this very command
+    line under `torch.distributed.run --nproc-per-node N` on 127.0.0.1 (one process per GPU, rank r on GPU r) and exits with the
+    launcher's status; rank 0 of the children prints the one JSON line.  Under a launcher (the driver's torch.distributed.run)
+    WORLD_SIZE must equal --gpus.  Fails loudly when the box has fewer than N GPUs -- N ranks on fewer devices would be a
+    different experiment (SNK_BENCH_DEVICE, the one-GPU rehearsal of the tests, is the explicit exception)."""
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is not None:
+        if int(world_env) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_env} ranks")
+        return
+    if args.gpus == 1:
+        return
+    import socket
+    import subprocess
+
+    import torch
+
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus and not os.environ.get("SNK_BENCH_DEVICE"):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} asked for but this box has {have} GPU(s) "
+                         "(torch.cuda.device_count()); refusing to run N ranks on fewer devices")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
@@ -218,8 +345,14 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="post-extraction stage on the extractor's stream (no overlap of batch i's "
                     "stage with batch i + 1's extraction)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline of the front-end")
+    ap.add_argument("--check-frames", type=int, default=256, help="frames of the last timed step whose outputs in HBM are compared "
+                    "bit for bit with the oracle's (those the CPU baseline reaches in its time budget)")
     ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    spawn_ranks_if_needed(args)
     global W, H, ORB
     if args.workload == "kitti":  # reference configs/kitti.ini:30-34
         W, H = 1241, 376
@@ -351,6 +484,11 @@ def main():
     ext.set_profiling(False)
 
     elapsed = parallel.max_over_ranks(t1 - t0, dev)
+    verify = not args.no_cpu_baseline and world == 1
+    gpu_snapshot = None
+    if verify:  # what the LAST timed steps left in HBM (both extractor sets), before any other leg runs
+        gpu_snapshot = snapshot_outputs(B, out_sets, kp64, kp64_g, desc_g, right_points, depth, n_stereo, knn, pairs, n_pairs,
+                                        min(B, n_dpairs, args.check_frames))
 
     # ---- second half of the metric: local-BA LM iterations/s (20 KF x 2000 pts x 8 obs/pt) ----
     ba_out = None
@@ -375,6 +513,9 @@ def main():
             barrier()
             tb1 = time.perf_counter()
         ci, cf = ba.solve(0)
+        ba_check = None
+        if verify:  # state of three windows after the LAST timed solve (reset + 3 LM iterations), compared with the oracle below
+            ba_check = {k: (distinct[k % n_dscenes], float(ci[k]), float(cf[k])) + ba.state(k)[:2] for k in sorted({0, NW // 2 - 1 if NW > 1 else 0, NW - 1})}
         # single-window latency (one problem per launch sequence)
         ba1 = BARec(lba_options(), device=local, stream=sh)
         ba1.create(distinct[0])
@@ -565,9 +706,11 @@ def main():
             "value": round(value, 2),
             "unit": "frames/s",
             "n_gpus": world,
+            "dist": parallel.describe(),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "timed_region_s": round(elapsed, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -623,9 +766,9 @@ def main():
         if track_out is not None:
             out["tracking"] = track_out
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(frames)
+            out["cpu_baseline"] = cpu_baseline(frames, gpu_snapshot, seconds_budget=args.cpu_seconds)
             if ba_out is not None:
-                out["cpu_baseline"]["ba"] = cpu_baseline_ba()
+                out["cpu_baseline"]["ba"] = cpu_baseline_ba(ba_check)
         print(json.dumps(out), flush=True)
 
     parallel.shutdown()

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <map>
 #include <mutex>
+#include <utility>
 
 namespace snk
 {
@@ -19,13 +20,19 @@ void set_error(const char* fmt, ...)
 
 int set_max_lds_once(const void* kernel, int bytes)
 {
+    // The attribute belongs to the kernel's function object ON THE CURRENT DEVICE (every entry point has called hipSetDevice
+    // for its handle's device before it gets here), so the "already set" state is kept per (device, kernel): one process may
+    // hold handles on several GPUs.
     static std::mutex mu;
-    static std::map<const void*, int> done;
+    static std::map<std::pair<int, const void*>, int> done;
+    int dev = 0;
+    SNK_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(mu);
-    auto it = done.find(kernel);
+    const auto key = std::make_pair(dev, kernel);
+    auto it        = done.find(key);
     if (it != done.end() && it->second >= bytes) return SNK_OK;
     SNK_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    done[kernel] = bytes;
+    done[key] = bytes;
     return SNK_OK;
 }
 

@@ -127,8 +127,9 @@ inline int copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kin
     return SNK_OK;
 }
 
-// hipFuncAttributeMaxDynamicSharedMemorySize is per-kernel, process-wide state: it is set ONCE per kernel to the
-// largest carve the kernel supports (never from per-handle or per-call sizes, which would race between handles).
+// hipFuncAttributeMaxDynamicSharedMemorySize is per-(device, kernel), process-wide state: it is set ONCE per kernel and
+// device (the current one -- callers have done hipSetDevice) to the largest carve the kernel supports (never from
+// per-handle or per-call sizes, which would race between handles).
 int set_max_lds_once(const void* kernel, int bytes);
 
 constexpr int LDS_MAX_BYTES = 160 * 1024;  // gfx950: 160 KB of LDS per workgroup

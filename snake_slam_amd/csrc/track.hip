@@ -216,7 +216,7 @@ struct FramesDev
 __device__ __forceinline__ FrameDev frame_of(const FramesDev& B, int b)
 {
     FrameDev F;
-    F.n            = B.n[b];
+    F.n            = min(max(B.n[b], 0), B.cap);  // device-side counts cannot be validated by the host: never past the frame's slab / LDS carve
     F.cols         = B.cols;
     F.rows         = B.rows;
     F.kps          = B.kps + (size_t)b * B.cap;
@@ -1237,6 +1237,7 @@ void frame_pointers(char* d, const FrameLayout& L, FrameDev* F)
 int upload_frame_to(snk_matcher* m, DevBuf& buf, const snk_frame_view* f, FrameDev* F)
 {
     SNK_REQUIRE(f->n >= 0 && f->n < (int)PJ_IDX_MASK && f->cols >= 1 && f->rows >= 1, "bad frame view sizes");
+    SNK_REQUIRE((long long)f->cols * f->rows < 65535, "grid too large (window cell ranges are packed in 16 bits)");
     SNK_REQUIRE(f->n == 0 || (f->kps && f->desc && f->right_points && f->taken), "NULL frame arrays");
     SNK_REQUIRE(f->cell_start != nullptr, "cell_start is NULL");
     const size_t n = (size_t)f->n, nc = (size_t)f->cols * f->rows + 1;
@@ -1660,7 +1661,10 @@ int snk_match_triangulation_project(snk_matcher* m, const double* depth_grid, in
     *n_matches = 0;
     SNK_REQUIRE(depth_grid != nullptr && grid_rows >= 1 && grid_cols >= 1 && E12 != nullptr, "bad depth grid / E");
     SNK_REQUIRE(n1 >= 0 && (n1 == 0 || (kps1 && np1 && desc1 && has_mp1 && match_idx2)), "bad keyframe-1 arrays");
-    SNK_REQUIRE(frame2 != nullptr && (frame2->n == 0 || np2 != nullptr), "bad keyframe-2 arrays");
+    // frame2 == NULL: the frame bound with snk_match_bind_frame (already on the device), like the other matchers
+    SNK_REQUIRE(frame2 != nullptr || m->view_valid, "frame2 is NULL and no frame is bound (snk_match_bind_frame)");
+    const int n2_frame = frame2 ? frame2->n : m->view_n;
+    SNK_REQUIRE(n2_frame == 0 || np2 != nullptr, "bad keyframe-2 arrays");
     CamDev C1, C2;
     FrameDev F;
     int rc;
@@ -1679,7 +1683,7 @@ int snk_match_triangulation_project(snk_matcher* m, const double* depth_grid, in
     const double th_chi1 = (double)epipolar_distance / cam->fx;
     T.th_chi2            = th_chi1 * th_chi1;
     T.grid_rows = grid_rows; T.grid_cols = grid_cols; T.feature_distance = feature_distance;
-    const size_t n = (size_t)n1, n2 = (size_t)frame2->n, ng = (size_t)grid_rows * grid_cols;
+    const size_t n = (size_t)n1, n2 = (size_t)n2_frame, ng = (size_t)grid_rows * grid_cols;
     const size_t o_np1 = n * sizeof(snk_kp64), o_d1 = o_np1 + n * 16, o_h1 = o_d1 + n * 32, o_np2 = (o_h1 + n + 15) & ~(size_t)15,
                  o_grid = o_np2 + n2 * 16, total = o_grid + ng * 8;
     if ((rc = m->q.reserve(total + 16)) != SNK_OK) return rc;

@@ -39,6 +39,14 @@ def is_distributed() -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+def describe() -> dict:
+    """What carried the barriers / gathers of this run (goes into bench.py's line): world size as torch.distributed sees it and
+    the backend ("nccl" = RCCL over xGMI; "gloo" only in the one-GPU rehearsal and the CPU tests; "none" for one rank)."""
+    if not is_distributed():
+        return {"world_size": 1, "backend": "none"}
+    return {"world_size": int(dist.get_world_size()), "backend": str(dist.get_backend())}
+
+
 def barrier() -> None:
     if is_distributed():
         dist.barrier()

@@ -87,7 +87,9 @@ class FeatureGrid(_Handle):
                                                         perm.data_ptr(), cell_start.data_ptr()), "snk_feature_grid_batch_dev")
 
 
-class SnakeORBMatcher(_Handle):
+class _FrameBinding(_Handle):
+    """snk_match_bind_frame / snk_match_bound_taken of a matcher handle (shared by the tracking and the mapping matchers)."""
+
     def bind_frame(self, frame) -> None:
         """Uploads the frame view once; the Search* methods called with frame=None then use it (1-2 coarse calls and one fine
         call look at the same frame).  frame=None unbinds."""
@@ -99,6 +101,8 @@ class SnakeORBMatcher(_Handle):
         t = np.ascontiguousarray(taken, np.uint8)
         _lib.check(self._lib.snk_match_bound_taken(self._h, _ptr(t)), "snk_match_bound_taken")
 
+
+class SnakeORBMatcher(_FrameBinding):
     def SearchByProjectionFrameFrame2(self, frame, cam, pose, lm_points, th, feature_error, direction, level_scale):
         """Coarse tracking match.  Returns (matches, match_idx[m])."""
         v, keep = _view(frame)
@@ -175,7 +179,7 @@ FUSION_POINT_DTYPE = np.dtype([("pos", "<f8", 3), ("normal", "<f8", 3), ("desc",
                                ("reference_scale_level", "<i4"), ("observations", "<i4"), ("id", "<i4")])
 
 
-class MappingORBMatcher(_Handle):
+class MappingORBMatcher(_FrameBinding):
     """Mirrors ``Snake::MappingORBMatcher`` (reference Snake/LocalMapping/MappingORBMatcher.h:15-45): ``Fuse``
     (LocalMap overload), ``SearchForTriangulation2`` (bag-of-words feature vectors as input),
     ``SearchForTriangulationBF`` and ``SearchForTriangulationProject``."""
@@ -211,8 +215,8 @@ class MappingORBMatcher(_Handle):
         n2 = np.ascontiguousarray(np2, np.float64).reshape(-1, 2)
         d1 = np.ascontiguousarray(desc1, np.uint64).reshape(-1, 4)
         h1 = np.ascontiguousarray(has_mp1, np.uint8)
-        if not (len(k1) == len(n1) == len(d1) == len(h1)) or len(n2) != v.n:
-            raise ValueError("array lengths")
+        if not (len(k1) == len(n1) == len(d1) == len(h1)) or (v is not None and len(n2) != v.n):
+            raise ValueError("array lengths")  # frame2 = None: the bound frame (bind_frame); np2 must hold its feature count
         p1, p2 = np.ascontiguousarray(pose1, np.float64), np.ascontiguousarray(pose2, np.float64)
         E = np.ascontiguousarray(E12, np.float64).reshape(9)
         out = np.full(max(len(k1), 1), -1, np.int32)

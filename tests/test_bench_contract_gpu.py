@@ -31,10 +31,51 @@ def test_bench_prints_one_json_line():
     assert d["value"] > 0 and d["ba"]["value"] > 0 and d["pose_refine"]["value"] > 0
 
 
-def test_committed_default_line_has_the_cpu_baseline():
-    d = json.loads((ROOT / "profiles" / "r01h_bench_default.json").read_text())
+def test_line_carries_verified_cpu_baseline():
+    """The default line's `cpu_baseline` is not only a timing: the oracle's results for the frames it processed are compared
+    bit for bit with what the last timed steps left in HBM (both extractor output sets of the two-stream pipeline, the
+    stereo / kNN-2 / filter outputs), and three BA windows with the oracle's solve.  Small batch, short CPU budget."""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "24",
+                        "--distinct", "6", "--ba-windows", "8", "--pose-frames", "0", "--gba-keyframes", "0", "--track-frames", "0",
+                        "--cpu-seconds", "1.0"], capture_output=True, text=True, cwd=str(ROOT), timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][0])
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] == 4 and cb["value"] > 0 and "sample" in cb and cb["ba"]["cores"] == 1
+    assert cb["kind"] == "port" and cb["cores"] == 4 and cb["value"] > 0 and "sample" in cb
+    assert cb["identical_to_gpu"] is True and cb["frames_checked"] == 6, cb
+    assert cb["ba"]["cores"] == 1 and cb["ba"]["identical_to_gpu"] is True and cb["ba"]["windows_checked"] == [0, 3, 7], cb["ba"]
+    assert d["timed_region_s"] > 0 and d["dist"] == {"world_size": 1, "backend": "none"}
+
+
+def test_gpus_flag_without_a_launcher_on_a_one_gpu_box():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset spawns its own ranks -- and refuses when the box has fewer GPUs."""
+    import os
+
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has two GPUs: the refusal cannot be provoked")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SNK_BENCH_DEVICE")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--batch", "16"], capture_output=True, text=True,
+                       cwd=str(ROOT), timeout=300, env=env)
+    assert r.returncode != 0 and "--gpus 2" in r.stderr and "GPU(s)" in r.stderr, (r.returncode, r.stderr[-500:])
+    assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+
+
+def test_gpus_flag_spawns_its_own_ranks():
+    """Same rehearsal as below but WITHOUT an external launcher: bench.py --gpus 2 re-executes itself under
+    torch.distributed.run (both ranks on cuda:0, gloo instead of RCCL) and the one line says n_gpus = 2."""
+    import os
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(SNK_DIST_BACKEND="gloo", SNK_BENCH_DEVICE="0")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16",
+                        "--ba-windows", "8", "--no-cpu-baseline"], capture_output=True, text=True, cwd=str(ROOT), timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dist"] == {"world_size": 2, "backend": "gloo"} and d["value"] > 0
 
 
 @pytest.mark.parametrize("mode", ["batch", "sequence"])
@@ -55,6 +96,7 @@ def test_two_ranks_rehearsal_on_one_gpu(mode):
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["dist"] == {"world_size": 2, "backend": "gloo"}
     if mode == "batch":
         assert d["config"]["frames_per_gpu_per_step"] == 16 and d["ba"]["value"] > 0
     else:

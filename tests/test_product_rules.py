@@ -45,6 +45,24 @@ def test_bench_refuses_to_run_without_a_gpu():
     assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
 
 
+def test_bench_gpus_flag_refuses_fewer_devices_than_ranks():
+    """`python bench.py --gpus N` without a launcher spawns N ranks itself, and refuses -- before spawning anything -- when the
+    box has fewer than N GPUs; under a launcher WORLD_SIZE must equal --gpus (the round-2 bench ignored the flag)."""
+    import os
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SNK_BENCH_DEVICE")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8"], capture_output=True, text=True, cwd=str(ROOT),
+                       timeout=300, env=env)
+    assert r.returncode != 0 and "--gpus 8" in r.stderr and "0 GPU(s)" in r.stderr, r.stderr[-600:]
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4"], capture_output=True, text=True, cwd=str(ROOT),
+                       timeout=300, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr, r.stderr[-600:]
+
+
 def test_handles_fail_loudly_without_a_device():
     import torch
 

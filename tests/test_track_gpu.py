@@ -154,6 +154,25 @@ def test_triangulation_project_parity(orc, mapping_matcher, seed, epi, fd):
     assert n > 20 and pairs == [(int(i), int(widx[i])) for i in np.nonzero(widx >= 0)[0]]
 
 
+def test_triangulation_project_with_a_bound_frame(orc, mapping_matcher):
+    """include/snake_hip.h documents frame2 == NULL = the frame bound with snk_match_bind_frame for this entry point too
+    (round 2 rejected it); unbound + NULL must be an error, not a crash."""
+    from snake_slam_amd import SnakeHipError
+
+    rng = np.random.default_rng(SEED + 55)
+    c = T.make_triangulation_case(orc, rng, m_pts=1200, n_clutter=500)
+    args = (c["grid"], c["pose1"], c["pose2"], c["cam"], c["kps1"], c["np1"], c["desc1"], c["has1"])
+    want = mapping_matcher.SearchForTriangulationProject(*args, c["frame2"], c["np2"], c["E"], 4.0, 50)
+    mapping_matcher.bind_frame(c["frame2"])
+    try:
+        got = mapping_matcher.SearchForTriangulationProject(*args, None, c["np2"], c["E"], 4.0, 50)
+    finally:
+        mapping_matcher.bind_frame(None)
+    assert got[0] == want[0] > 20 and got[1] == want[1] and np.array_equal(got[2], want[2])
+    with pytest.raises(SnakeHipError):
+        mapping_matcher.SearchForTriangulationProject(*args, None, c["np2"], c["E"], 4.0, 50)
+
+
 def test_mapping_matchers_empty_inputs(orc, mapping_matcher):
     rng = np.random.default_rng(SEED + 60)
     frame, cam, pose, ls, world, _ = T.make_tracking_case(orc, rng, n_clutter=50, m_pts=20)
