@@ -342,6 +342,9 @@ def main():
     ap.add_argument("--distinct", type=int, default=256, help="distinct synthetic stereo pairs / BA scenes per rank, tiled over the batch / the "
                     "windows (0 = every frame of the batch and every BA window is its own seeded scene; 256 keeps the input generation of the "
                     "default batch at ~10 s)")
+    ap.add_argument("--scene", choices=["textured", "flat"], default="textured",
+                    help="textured (default since round 3) = a textured far wall + a few textured objects: ~40 %% of the left keypoints find "
+                         "a stereo match, ~29 %% a BF pair; flat = the round-1/2 images (400 flat rectangles in draw order: ~12 %% / 6 %%)")
     ap.add_argument("--no-overlap", action="store_true", help="post-extraction stage on the extractor's stream (no overlap of batch i's "
                     "stage with batch i + 1's extraction)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -370,7 +373,8 @@ def main():
     n_dscenes = min(args.ba_windows, args.distinct) if args.distinct > 0 else args.ba_windows
     frames, ba_distinct = [], []
     if args.mode == "batch":
-        frames = synth.stereo_frames([env_rank * args.batch + i for i in range(n_dpairs)], W, H)
+        frames = synth.stereo_frames([env_rank * args.batch + i for i in range(n_dpairs)], W, H,
+                                     texture=0.0 if args.scene == "flat" else None)
         ba_distinct = synth.ba_scenes([synth.SEED + 1000 * env_rank + k for k in range(n_dscenes)])
 
     import torch
@@ -715,8 +719,10 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": f"synthetic: seeded {W}x{H} stereo pairs (gradient + 400 rectangles + noise), {n_dpairs} distinct pairs per rank over a batch of {B}, resident in HBM",
+            "data": (f"synthetic: seeded {W}x{H} stereo pairs (" + ("gradient + 400 flat rectangles + noise" if args.scene == "flat" else
+                     "gradient + textured far wall + 20 textured objects + noise") + f"), {n_dpairs} distinct pairs per rank over a batch of {B}, resident in HBM"),
             "config": {"workload": ("EuRoC" if args.workload == "euroc" else "KITTI") + f" stereo {W}x{H}: ORB extract (L+R, {ORB['nfeatures']} feat, {ORB['n_levels']} levels) + stereo row-band match + BF kNN-2 Hamming match",
+                       "scene": args.scene,
                        "frames_per_gpu_per_step": B, "images_per_frame": 2, "orb": ORB,
                        "parallelism": f"{world} x independent batches (one per GPU), RCCL all_gather of results only",
                        "streams": ("2: the post-extraction stage of batch i (rectify, grid, stereo, kNN-2) overlaps the extraction of batch i + 1"
@@ -724,6 +730,8 @@ def main():
             "keypoints_per_image": round(float(blocks[0][1].item()) / (2 * B), 1),
             "stereo_matches_per_frame": round(float(blocks[0][2].item()) / B, 1),
             "bf_pairs_per_frame": round(float(blocks[0][3].item()) / B, 1),
+            "stereo_yield": round(float(blocks[0][2].item()) / max(1.0, float(blocks[0][1].item()) / 2), 4),   # matches per left keypoint
+            "bf_yield": round(float(blocks[0][3].item()) / max(1.0, float(blocks[0][1].item()) / 2), 4),
         }
         if n_calls > 0:
             # n_calls counts launch chains (1 per step unless --orb-chains > 1), each timed on its own stream

@@ -39,7 +39,7 @@ def main():
                         pairs=pairs, filter_args=np.array([120, 0.9]), left=left, dl=dl, right=right, dr=dr, bf=bf, ls=ls,
                         n=n, rp=rp, dp=dp)
     # --- ORB ---
-    img, _ = synth.stereo_frame(3, 160, 120, n_rects=40)
+    img, _ = synth.stereo_frame(3, 160, 120, n_rects=40, texture=0.0)  # the image the committed fixture was made from (flat rectangles)
     p = orc.orb_params(200, 1.2, 3, 20, 7)
     kps, desc = orc.orb_detect(p, img)
     np.savez_compressed(OUT / "orb_small.npz", img=img, params=np.array([200, 1.2, 3, 20, 7]), kps=kps, desc=desc)

@@ -13,6 +13,10 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("w,h,orb,cam", [
     (752, 480, (1000, 1.2, 4, 20, 7), S.CAM),
     (640, 400, (800, 1.2, 4, 20, 7), (400.0, 400.0, 320.0, 200.0, 100.0)),
+    # BASELINE.json configs[2]: KITTI 1241x376, 2000 features, 7 levels (reference configs/kitti.ini:30-34), the FULL stereo
+    # chain -- extract L+R, rectify, grid, StereoMatching, kNN-2 + filter vs the previous frame, pose refinement -- against
+    # the oracle chain (camera: KITTI sequence 00's P0 / bf)
+    (1241, 376, (2000, 1.2, 7, 20, 7), (718.856, 718.856, 607.1928, 185.2157, 386.1448)),
 ])
 def test_sequence_trajectory_matches_the_oracle_chain(orc, w, h, orb, cam):
     from snake_slam_amd import synth
