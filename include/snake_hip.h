@@ -50,6 +50,18 @@ SNK_API const char* snk_last_error(void);  /* thread-local text of the last fail
 SNK_API const char* snk_version(void);
 SNK_API int snk_device_count(void);        /* number of visible HIP devices (0 = none) */
 
+/* Run-time switches for choices this library had to DEFINE because the arithmetic lives in the absent saiga submodule
+ * (reference .gitmodules:1-3): a maintainer who can read saiga selects the matching rule without editing a kernel.
+ * Process-wide, read by every later call; also settable at start-up with SNK_DEFINITIONS="key=value,key=value".
+ *   "bf_filter.threshold_strict"  Saiga::BruteForceMatcher::filterMatches(th, ratio), call site
+ *                                 Snake/Tracking/TrackingCoarse.cpp:352: 0 = keep d1 <= th (default), 1 = keep d1 < th
+ *   "bf_filter.ratio_strict"      same call: 0 = keep d1 <= ratio * d2 (default), 1 = keep d1 < ratio * d2
+ *   "iround.mode"                 Saiga::iRound as Preprocess::StereoMatching uses it (Snake/Preprocess/Preprocess.cpp:155,165):
+ *                                 0 = floor(x + 0.5) (default), 1 = round half away from zero, 2 = round half to even
+ * Unknown key / out-of-range value: SNK_ERR_INVALID_ARG, nothing changes.  The oracle mirrors every key (orc_set_definition). */
+SNK_API int snk_set_definition(const char* key, int value);
+SNK_API int snk_get_definition(const char* key, int* value);
+
 /* ------------------------------------------------------------------------------------------
  * Descriptor matching
  * ------------------------------------------------------------------------------------------ */

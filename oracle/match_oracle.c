@@ -64,14 +64,26 @@ void orc_bf_knn2(const uint64_t (*q)[4], int nq, const uint64_t (*t)[4], int nt,
  * Snake/Tracking/TrackingCoarse.cpp:352; `matches` consumed at :373-387 as (query, train)).
  * Definition chosen (operator strictness unknown in saiga): keep when dist1 <= threshold and
  * dist1 <= ratio * dist2, float arithmetic. */
+/* Mirror of the library's snk_set_definition (include/snake_hip.h): the [DEFINED] comparison / rounding rules that a reader
+ * of saiga may have to flip.  Same keys, same values, same defaults. */
+static int g_def_th_strict = 0, g_def_ratio_strict = 0, g_def_iround = 0;
+int orc_set_definition(const char* key, int value)
+{
+    if (key && strcmp(key, "bf_filter.threshold_strict") == 0 && (value == 0 || value == 1)) { g_def_th_strict = value; return 0; }
+    if (key && strcmp(key, "bf_filter.ratio_strict") == 0 && (value == 0 || value == 1)) { g_def_ratio_strict = value; return 0; }
+    if (key && strcmp(key, "iround.mode") == 0 && value >= 0 && value <= 2) { g_def_iround = value; return 0; }
+    return 1;
+}
+
 int orc_bf_filter(const orc_knn2* knn, int nq, int threshold, float ratio, int32_t (*pairs)[2])
 {
     int n = 0;
     for (int i = 0; i < nq; ++i)
     {
         if (knn[i].idx1 < 0) continue;
-        if (knn[i].dist1 > threshold) continue;
-        if ((float)knn[i].dist1 > ratio * (float)knn[i].dist2) continue;
+        const float rd2 = ratio * (float)knn[i].dist2;
+        if (g_def_th_strict ? knn[i].dist1 >= threshold : knn[i].dist1 > threshold) continue;
+        if (g_def_ratio_strict ? (float)knn[i].dist1 >= rd2 : (float)knn[i].dist1 > rd2) continue;
         pairs[n][0] = i;
         pairs[n][1] = knn[i].idx1;
         ++n;
@@ -79,10 +91,12 @@ int orc_bf_filter(const orc_knn2* knn, int nq, int threshold, float ratio, int32
     return n;
 }
 
-/* Saiga::iRound (absent).  Definition chosen: floor(x + 0.5). */
+/* Saiga::iRound (absent).  Definition chosen: floor(x + 0.5); "iround.mode" 1 = half away from zero, 2 = half to even. */
 static int orc_iround(double x)
 {
-    return (int)floor(x + 0.5);
+    if (g_def_iround == 0) return (int)floor(x + 0.5);
+    if (g_def_iround == 1) return (int)(x < 0.0 ? -floor(0.5 - x) : floor(x + 0.5));
+    return (int)rint(x);
 }
 
 /* Snake::Preprocess::StereoMatching — Snake/Preprocess/Preprocess.cpp:122-242, line by line.

@@ -49,6 +49,13 @@ def hamming(a, b) -> int:
     return lib().orc_hamming(_p(a), _p(b))
 
 
+def set_definition(key: str, value: int) -> None:
+    """Mirror of snk_set_definition: the same keys / values select the same [DEFINED] rule in the oracle."""
+    lib().orc_set_definition.restype = C.c_int
+    if lib().orc_set_definition(key.encode(), C.c_int(int(value))) != 0:
+        raise ValueError(f"oracle: unknown definition {key!r} or bad value {value}")
+
+
 def bf_knn2(q, t, threads: int = 1) -> np.ndarray:
     q = np.ascontiguousarray(q, np.uint64).reshape(-1, 4)
     t = np.ascontiguousarray(t, np.uint64).reshape(-1, 4)

@@ -192,6 +192,7 @@ double orc_det_log(double x);
 double orc_det_exp(double y);
 void orc_grid_dims(const orc_grid_bounds* b, int* cols, int* rows);
 void orc_feature_grid(const orc_kp64* kps, int n, const orc_grid_bounds* b, int32_t* perm, int32_t* cell_start);
+int orc_set_definition(const char* key, int value); /* mirror of snk_set_definition (0 = ok, 1 = unknown key / bad value) */
 void orc_set_match_threads(int n); /* threads of the per-point phase of orc_match_coarse / orc_match_fine */
 int orc_match_coarse(const orc_frame_view* f, const orc_camera* cam, const double* pose, const orc_lm_coarse* pts, int m,
                      float th, int feature_error, int direction, const float* level_scale, int n_levels, int32_t* match_idx);

@@ -76,6 +76,8 @@ SIGNATURES = {
     "snk_orb_set_chains": (i32, [vp, i32]),
     "snk_orb_stage_times": (i32, [vp, vp, C.POINTER(i32)]),
     "snk_orb_debug_fetch": (i32, [vp, i32, i32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "snk_set_definition": (i32, [C.c_char_p, i32]),
+    "snk_get_definition": (i32, [C.c_char_p, C.POINTER(i32)]),
     "snk_ba_create": (i32, [vp, i32, vp, C.POINTER(vp)]),
     "snk_ba_destroy": (i32, [vp]),
     "snk_ba_sync": (i32, [vp]),
@@ -130,3 +132,17 @@ def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = load().snk_last_error().decode(errors="replace")
         raise SnakeHipError(f"{what} failed with status {rc}: {msg}")
+
+
+DEFINITIONS = {"bf_filter.threshold_strict": (0, 1), "bf_filter.ratio_strict": (0, 1), "iround.mode": (0, 2)}  # key -> (min, max); default 0
+
+
+def set_definition(key: str, value: int) -> None:
+    """snk_set_definition: select one of the [DEFINED] comparison / rounding rules (include/snake_hip.h); process-wide."""
+    check(load().snk_set_definition(key.encode(), int(value)), "snk_set_definition")
+
+
+def get_definition(key: str) -> int:
+    v = C.c_int32(0)
+    check(load().snk_get_definition(key.encode(), C.byref(v)), "snk_get_definition")
+    return int(v.value)

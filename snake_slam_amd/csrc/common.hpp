@@ -134,6 +134,19 @@ int set_max_lds_once(const void* kernel, int bytes);
 
 constexpr int LDS_MAX_BYTES = 160 * 1024;  // gfx950: 160 KB of LDS per workgroup
 
+// Run-time switches for the [DEFINED] choices that are pure comparisons / rounding rules: the arithmetic
+// lives in the absent saiga, so a maintainer who can read it flips the definition with snk_set_definition (or the
+// SNK_DEFINITIONS environment variable) instead of editing kernels.  Process-wide, read at every call, mirrored by the oracle
+// (orc_set_definition).  Values and defaults: include/snake_hip.h.
+enum DefKey
+{
+    DEF_BF_FILTER_THRESHOLD_STRICT = 0,  // filterMatches: 0 = keep d1 <= th (default), 1 = keep d1 < th
+    DEF_BF_FILTER_RATIO_STRICT,          // filterMatches: 0 = keep d1 <= ratio * d2 (default), 1 = keep d1 < ratio * d2
+    DEF_IROUND_MODE,                     // Saiga::iRound: 0 = floor(x + 0.5) (default), 1 = half away from zero, 2 = half to even
+    DEF_COUNT
+};
+int definition(DefKey k);
+
 struct HandleBase
 {
     int device          = 0;

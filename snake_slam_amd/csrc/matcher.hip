@@ -261,8 +261,8 @@ __global__ __launch_bounds__(256) void bf_knn2_mfma_kernel(const uint4* __restri
 
 // Order-preserving compaction of the accepted (query, train) pairs; one workgroup per batch entry.
 __global__ __launch_bounds__(256) void bf_filter_kernel(const snk_knn2* __restrict__ knn, const int* __restrict__ nq_dev,
-                                                        int nq_cap, int nq_host, int threshold, float ratio,
-                                                        int2* __restrict__ pairs, int* __restrict__ n_pairs)
+                                                        int nq_cap, int nq_host, int threshold, float ratio, int th_strict,
+                                                        int ratio_strict, int2* __restrict__ pairs, int* __restrict__ n_pairs)
 {
     __shared__ int wave_cnt[4];
     __shared__ int base_s;
@@ -282,7 +282,10 @@ __global__ __launch_bounds__(256) void bf_filter_kernel(const snk_knn2* __restri
         if (i < nq)
         {
             k    = knn[(size_t)b * nq_cap + i];
-            keep = k.idx1 >= 0 && k.dist1 <= threshold && (float)k.dist1 <= ratio * (float)k.dist2;
+            // [DEFINED] operator strictness of filterMatches: definitions "bf_filter.threshold_strict" / "bf_filter.ratio_strict"
+            const float rd2 = ratio * (float)k.dist2;
+            keep = k.idx1 >= 0 && (th_strict ? k.dist1 < threshold : k.dist1 <= threshold) &&
+                   (ratio_strict ? (float)k.dist1 < rd2 : (float)k.dist1 <= rd2);
         }
         const u64 mask   = __ballot(keep);
         const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
@@ -302,11 +305,15 @@ struct LevelScales
 {
     float s[32];
     int n;
+    int iround_mode;  // definition "iround.mode" at the time of the call (make_scales)
 };
 
-__device__ __forceinline__ int iround_d(double x)
+// Saiga::iRound [DEFINED]: 0 = floor(x + 0.5), 1 = half away from zero, 2 = half to even (exact operations on both sides)
+__device__ __forceinline__ int iround_d(double x, int mode)
 {
-    return (int)floor(x + 0.5);
+    if (mode == 0) return (int)floor(x + 0.5);
+    if (mode == 1) return (int)(x < 0.0 ? -floor(0.5 - x) : floor(x + 0.5));
+    return (int)rint(x);
 }
 
 constexpr u64 ST_INF_KEY = (250ull << 40) | 0xFFFFFFFFFFull;
@@ -315,7 +322,7 @@ constexpr int ST_SORT_MAX    = 8192;  // right keypoints per image the in-LDS so
 
 // row-sorted index of the right keypoints of every image: (clamped rounded row + bias) << 16 | index
 __global__ __launch_bounds__(256) void stereo_sort_kernel(const snk_kp64* __restrict__ right, const int* __restrict__ nr_dev,
-                                                          int nr_cap, int nr_host, u32* __restrict__ row_sorted)
+                                                          int nr_cap, int nr_host, int iround_mode, u32* __restrict__ row_sorted)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ssm[];
     u32* keys     = reinterpret_cast<u32*>(ssm);
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(256) void stereo_sort_kernel(const snk_kp64* __rest
         u32 k = 0xFFFFFFFFu;
         if (i < nr)
         {
-            int row = (int)floor(rb[i].y + 0.5) + ST_ROW_BIAS;
+            int row = iround_d(rb[i].y, iround_mode) + ST_ROW_BIAS;
             row     = row < 0 ? 0 : (row > 65535 ? 65535 : row);
             k       = ((u32)row << 16) | (u32)i;
         }
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(256) void stereo_kernel(const snk_kp64* __restrict_
     const snk_kp64 kp = lb[i];
     const uint4 qa    = dlb[(size_t)i * 2];
     const uint4 qc    = dlb[(size_t)i * 2 + 1];
-    const int y       = iround_d(kp.y);
+    const int y       = iround_d(kp.y, ls.iround_mode);
     int oct           = kp.octave;
     oct               = oct < 0 ? 0 : (oct >= ls.n ? ls.n - 1 : oct);
     const float r     = ceilf(2.0f * ls.s[oct]);
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(256) void stereo_kernel(const snk_kp64* __restrict_
     {
         const int j       = srt ? (int)(srt[pos] & 0xFFFFu) : pos;
         const snk_kp64 kr = rb[j];
-        const int yj      = iround_d(kr.y);
+        const int yj      = iround_d(kr.y, ls.iround_mode);
         const int rel     = yj - (y - ri);
         if (rel < 0 || rel > 2 * ri) continue;
         const double disparity = kp.x - kr.x;
@@ -508,7 +515,7 @@ __global__ __launch_bounds__(256) void stereo_kernel16(const snk_kp64* __restric
     const snk_kp64 kp = lb[i];
     const uint4 qa    = dlb[(size_t)i * 2];
     const uint4 qc    = dlb[(size_t)i * 2 + 1];
-    const int y       = iround_d(kp.y);
+    const int y       = iround_d(kp.y, ls.iround_mode);
     int oct           = kp.octave;
     oct               = oct < 0 ? 0 : (oct >= ls.n ? ls.n - 1 : oct);
     const float r     = ceilf(2.0f * ls.s[oct]);
@@ -543,7 +550,7 @@ __global__ __launch_bounds__(256) void stereo_kernel16(const snk_kp64* __restric
     {
         const int j       = (int)(srt[pos] & 0xFFFFu);
         const snk_kp64 kr = rb[j];
-        const int yj      = iround_d(kr.y);
+        const int yj      = iround_d(kr.y, ls.iround_mode);
         const int rel     = yj - (y - ri);
         if (rel < 0 || rel > 2 * ri) continue;
         const double disparity = kp.x - kr.x;
@@ -652,7 +659,7 @@ __global__ __launch_bounds__(1024) void stereo_frame_kernel(const snk_kp64* __re
         {
             const snk_kp64 kr = rb[t];
             sx[t]   = kr.x;
-            syj[t]  = iround_d(kr.y);
+            syj[t]  = iround_d(kr.y, ls.iround_mode);
             soct[t] = kr.octave;
             sang[t] = kr.angle;
             int r   = (int)floor(kr.y + 0.5) + ST_ROW_BIAS;  // the row of stereo_sort_kernel's index
@@ -711,7 +718,7 @@ __global__ __launch_bounds__(1024) void stereo_frame_kernel(const snk_kp64* __re
             qa_n = dlb[(size_t)in * 2];
             qc_n = dlb[(size_t)in * 2 + 1];
         }
-        const int y = iround_d(kp.y);
+        const int y = iround_d(kp.y, ls.iround_mode);
         int oct     = kp.octave;
         oct         = oct < 0 ? 0 : (oct >= ls.n ? ls.n - 1 : oct);
         const int ri = (int)ceilf(2.0f * ls.s[oct]);
@@ -894,7 +901,8 @@ int snk_bf_filter(snk_matcher* m, const snk_knn2* knn, int nq, int threshold, fl
     if ((rc = m->cnt.reserve(64)) != SNK_OK) return rc;
     SNK_HIP_CHECK(hipMemcpyAsync(m->out.p, knn, (size_t)nq * sizeof(snk_knn2), hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(bf_filter_kernel, dim3(1), dim3(256), 0, m->stream, m->out.as<snk_knn2>(), (const int*)nullptr,
-                       nq, nq, threshold, ratio, m->aux.as<int2>(), m->cnt.as<int>());
+                       nq, nq, threshold, ratio, definition(DEF_BF_FILTER_THRESHOLD_STRICT), definition(DEF_BF_FILTER_RATIO_STRICT),
+                       m->aux.as<int2>(), m->cnt.as<int>());
     SNK_LAUNCH_CHECK();
     int n = 0;
     SNK_HIP_CHECK(hipMemcpyAsync(&n, m->cnt.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
@@ -913,7 +921,8 @@ int snk_bf_filter_batch_dev(snk_matcher* m, const snk_knn2* knn_dev, const int32
     if (batch == 0) return SNK_OK;
     SNK_HIP_CHECK(hipSetDevice(m->device));
     hipLaunchKernelGGL(bf_filter_kernel, dim3(batch), dim3(256), 0, m->stream, knn_dev, nq_dev, nq_cap, 0, threshold,
-                       ratio, (int2*)pairs_dev, n_pairs_dev);
+                       ratio, definition(DEF_BF_FILTER_THRESHOLD_STRICT), definition(DEF_BF_FILTER_RATIO_STRICT), (int2*)pairs_dev,
+                       n_pairs_dev);
     SNK_LAUNCH_CHECK();
     return SNK_OK;
 }
@@ -922,7 +931,8 @@ static int make_scales(const float* level_scale, int n_levels, LevelScales* ls)
 {
     SNK_REQUIRE(level_scale != nullptr && n_levels >= 1 && n_levels <= 32, "level_scale / n_levels (1..32)");
     for (int i = 0; i < 32; ++i) ls->s[i] = i < n_levels ? level_scale[i] : level_scale[n_levels - 1];
-    ls->n = n_levels;
+    ls->n           = n_levels;
+    ls->iround_mode = definition(DEF_IROUND_MODE);
     return SNK_OK;
 }
 
@@ -967,7 +977,7 @@ int snk_stereo_match(snk_matcher* m, const snk_kp64* left, const uint64_t (*desc
         if ((rc = set_max_lds_once(reinterpret_cast<const void*>(stereo_sort_kernel), ST_SORT_MAX * 4)) != SNK_OK) return rc;
         if ((rc = set_max_lds_once(reinterpret_cast<const void*>(stereo_kernel16), ST_SORT_MAX * 4)) != SNK_OK) return rc;
         hipLaunchKernelGGL(stereo_sort_kernel, dim3(1), dim3(256), (size_t)np2 * 4, m->stream, (const snk_kp64*)(ab + kl),
-                           (const int*)nullptr, nr, nr, m->out.as<u32>());
+                           (const int*)nullptr, nr, nr, ls.iround_mode, m->out.as<u32>());
         srt = m->out.as<u32>();
     }
     if (srt)
@@ -1023,7 +1033,7 @@ int snk_stereo_match_batch_dev(snk_matcher* m, const snk_kp64* left_dev, const u
         if ((rc = set_max_lds_once(reinterpret_cast<const void*>(stereo_sort_kernel), ST_SORT_MAX * 4)) != SNK_OK) return rc;
         if ((rc = set_max_lds_once(reinterpret_cast<const void*>(stereo_kernel16), ST_SORT_MAX * 4)) != SNK_OK) return rc;
         hipLaunchKernelGGL(stereo_sort_kernel, dim3(batch), dim3(256), (size_t)np2 * 4, m->stream, right_dev, nr_dev, nr_cap, 0,
-                           m->out.as<u32>());
+                           ls.iround_mode, m->out.as<u32>());
         srt = m->out.as<u32>();
     }
     if (srt)

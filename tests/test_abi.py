@@ -1,6 +1,8 @@
 """CPU: the C-ABI library exists, loads, and exports every symbol include/snake_hip.h declares."""
 import ctypes
 import re
+
+import pytest
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
@@ -60,3 +62,22 @@ def test_single_hip_runtime_in_process():
 
     _lib.load()
     assert len(_lib.hip_runtimes_mapped()) == 1, _lib.hip_runtimes_mapped()
+
+
+def test_definition_switches_abi():
+    """snk_set_definition / snk_get_definition need no device: defaults are 0, unknown keys and out-of-range values are
+    refused with SNK_ERR_INVALID_ARG and change nothing."""
+    from snake_slam_amd import SnakeHipError, _lib
+
+    for key, (lo, hi) in _lib.DEFINITIONS.items():
+        assert _lib.get_definition(key) == 0
+        _lib.set_definition(key, hi)
+        assert _lib.get_definition(key) == hi
+        with pytest.raises(SnakeHipError):
+            _lib.set_definition(key, hi + 1)
+        assert _lib.get_definition(key) == hi
+        _lib.set_definition(key, 0)
+    with pytest.raises(SnakeHipError):
+        _lib.set_definition("no.such.key", 0)
+    with pytest.raises(SnakeHipError):
+        _lib.get_definition("no.such.key")

@@ -199,3 +199,59 @@ def test_invalid_args_return_status(bf):
     assert b"NULL" in lib.snk_last_error() or b"invalid" in lib.snk_last_error()
     h = C.c_void_p()
     assert lib.snk_matcher_create(9999, None, C.byref(h)) != 0
+
+
+DEFS = [("bf_filter.threshold_strict", 1), ("bf_filter.ratio_strict", 1), ("iround.mode", 1), ("iround.mode", 2)]
+
+
+@pytest.fixture
+def definitions(orc):
+    """Sets a [DEFINED] switch in the library AND in the oracle; everything is back at its default afterwards."""
+    from snake_slam_amd import _lib
+
+    def set_both(key, value):
+        _lib.set_definition(key, value)
+        orc.set_definition(key, value)
+
+    yield set_both
+    for key in _lib.DEFINITIONS:
+        _lib.set_definition(key, 0)
+        orc.set_definition(key, 0)
+
+
+@pytest.mark.parametrize("key,value", DEFS)
+def test_definition_switches_parity(bf, st, orc, definitions, key, value):
+    """snk_set_definition: every [DEFINED] comparison / rounding rule can be flipped at run time, the oracle mirrors it, and the
+    two still agree bit for bit -- on inputs built so that the rule DECIDES something (the result differs from the default's)."""
+    rng = np.random.default_rng(SEED + 9000 + value)
+    # kNN-2 table with exact ties on both filter rules: dist1 == threshold and dist1 == ratio * dist2 (ratio 0.5, representable)
+    q, t = rand_desc(rng, 400), rand_desc(rng, 300)
+    bf.matchKnn2(q, t)
+    knn = bf.knn.copy()
+    th = int(np.sort(knn["dist1"])[len(knn) // 3])           # a threshold that some dist1 equal exactly
+    knn["dist2"][::3] = 2 * knn["dist1"][::3]                  # every third row sits exactly on the ratio 0.5
+    # stereo case with rows exactly on .5 (positive and negative halves) so that the three rounding rules disagree
+    left, dl, right, dr, bfv, ls = make_stereo_case(rng, 300, 280)
+    right["y"] = np.floor(right["y"]) + 0.5
+    left["y"] = np.floor(left["y"]) + 0.5
+    right["y"][:40] -= 60.0                                    # some negative rows (rectification can push points above the image)
+    left["y"][:40] -= 60.0
+
+    def run():
+        bf.knn = knn.copy()
+        n = bf.filterMatches(th, 0.5)
+        got_pairs = bf.matches.copy()
+        want_pairs = orc.bf_filter(knn, th, 0.5)
+        ns, rp, dp = st.StereoMatching(left, dl, right, dr, bfv, ls, True)
+        wn, wrp, wdp = orc.stereo_match(left, dl, right, dr, bfv, ls, True)
+        assert n == len(want_pairs) and np.array_equal(got_pairs, want_pairs)
+        assert ns == wn and np.array_equal(rp, wrp) and np.array_equal(dp, wdp)
+        return got_pairs, rp
+
+    base_pairs, base_rp = run()
+    definitions(key, value)
+    pairs, rp = run()
+    if key.startswith("bf_filter"):
+        assert len(pairs) < len(base_pairs)      # the strict operator drops the rows that sit exactly on the bound
+    else:
+        assert not np.array_equal(rp, base_rp)   # another rounding of the .5 rows moves the row bands

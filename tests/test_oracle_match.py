@@ -3,6 +3,7 @@
 The reference holds no golden vectors for this path — parity is unpinned; these
 tests pin the oracle to the written definition instead."""
 import numpy as np
+import pytest
 
 from helpers import SEED, knn_to_array, make_stereo_case, np_hamming_matrix, np_knn2, rand_desc
 
@@ -170,3 +171,56 @@ def test_stereo_matches_independent_restatement(orc):
         n2, rp2, dp2 = _stereo_numpy(left, dl, right, dr, bf, ls, relaxed)
         assert n == n2 and n > 0 or nr == 1
         assert np.array_equal(rp, rp2) and np.array_equal(dp, dp2)
+
+
+def test_definition_switches_of_the_oracle(orc):
+    """orc_set_definition mirrors snk_set_definition (include/snake_hip.h): filterMatches operator strictness and the
+    iRound rule.  Checked on hand-built rows where each rule decides."""
+    knn = np.zeros(4, orc.KNN2)
+    knn["idx1"], knn["idx2"] = [0, 1, 2, 3], [1, 2, 3, 0]
+    knn["dist1"], knn["dist2"] = [60, 59, 40, 40], [200, 200, 80, 81]   # row 0 on the threshold, row 2 on the ratio 0.5
+    try:
+        assert orc.bf_filter(knn, 60, 0.5)[:, 0].tolist() == [0, 1, 2, 3]
+        orc.set_definition("bf_filter.threshold_strict", 1)
+        assert orc.bf_filter(knn, 60, 0.5)[:, 0].tolist() == [1, 2, 3]
+        orc.set_definition("bf_filter.ratio_strict", 1)
+        assert orc.bf_filter(knn, 60, 0.5)[:, 0].tolist() == [1, 3]
+        with pytest.raises(ValueError):
+            orc.set_definition("iround.mode", 3)
+        with pytest.raises(ValueError):
+            orc.set_definition("no.such.key", 0)
+        # iRound: one left keypoint at y = 10.5 (r = 2 at octave 0), right keypoints at y = 7.5 / 8.5 / 12.5 / 13.5, same descriptor
+        left = np.zeros(1, orc.KP64)
+        left["x"], left["y"] = 100.0, 10.5
+        d = np.full((1, 4), np.uint64(0x0123456789ABCDEF))
+        ls = np.array([1.0], np.float32)
+
+        def hit(ry):
+            right = np.zeros(1, orc.KP64)
+            right["x"], right["y"] = 90.0, ry
+            return orc.stereo_match(left, d, right, d, 100.0, ls, True)[0]
+
+        # floor(x + 0.5): rows 11 vs 8 / 9 / 13 / 14 -> band 9..13
+        orc.set_definition("iround.mode", 0)
+        assert [hit(7.5), hit(8.5), hit(12.5), hit(13.5)] == [0, 1, 1, 0]
+        # half to even: 10.5 -> 10, band 8..12; 7.5 -> 8, 8.5 -> 8, 12.5 -> 12, 13.5 -> 14
+        orc.set_definition("iround.mode", 2)
+        assert [hit(7.5), hit(8.5), hit(12.5), hit(13.5)] == [1, 1, 1, 0]
+        # half away from zero equals mode 0 for positive rows and differs for negative ones: -10.5 -> -11 (mode 1) / -10 (mode 0)
+        left["y"] = -10.5
+        orc.set_definition("iround.mode", 0)
+        a = [hit(-13.5), hit(-7.5)]      # rows -13 / -7 against band -12..-8
+        orc.set_definition("iround.mode", 1)
+        b = [hit(-13.5), hit(-7.5)]      # rows -14 / -8 against band -13..-9
+        assert a == [0, 0] and b == [0, 0]
+        a2 = (orc.set_definition("iround.mode", 0), hit(-12.5))[1]   # row -12 in band -12..-8
+        b2 = (orc.set_definition("iround.mode", 1), hit(-12.5))[1]   # row -13 in band -13..-9
+        assert a2 == 1 and b2 == 1
+        orc.set_definition("iround.mode", 0)
+        c0 = hit(-8.5)   # row -8, band -12..-8 -> in
+        orc.set_definition("iround.mode", 1)
+        c1 = hit(-8.5)   # row -9, band -13..-9 -> in
+        assert c0 == 1 and c1 == 1
+    finally:
+        for k in ("bf_filter.threshold_strict", "bf_filter.ratio_strict", "iround.mode"):
+            orc.set_definition(k, 0)

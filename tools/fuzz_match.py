@@ -36,8 +36,15 @@ def main():
     bf, st, pm, mm, dm = BruteForceMatcher(0), StereoMatcher(0), SnakeORBMatcher(0), MappingORBMatcher(), DeferredMapper()
     t0, n = time.time(), {"bf": 0, "stereo": 0, "coarse": 0, "fine": 0, "keyframe": 0, "fuse": 0, "tri_project": 0, "tri_bow": 0,
                           "tri_bf": 0, "relink": 0}
+    from snake_slam_amd import _lib  # noqa: E402
+
     while time.time() - t0 < a.seconds:
         kind = int(rng.integers(0, 10))
+        if kind <= 1:  # the [DEFINED] switches (snk_set_definition), the same random setting in the library and in the oracle
+            for key, (lo, hi) in _lib.DEFINITIONS.items():
+                v = int(rng.integers(lo, hi + 1)) if rng.random() < 0.5 else 0
+                _lib.set_definition(key, v)
+                orc.set_definition(key, v)
         if kind == 0:
             nq, nt = sizes(rng, 2500), sizes(rng, 2500)
             q, t = rand_desc(rng, nq), rand_desc(rng, nt)
@@ -59,6 +66,10 @@ def main():
             if nl == 0 or nr == 0:
                 continue  # make_stereo_case needs one keypoint on each side; the empty cases are in the test suite
             kl, dl, kr, dr, bfv, ls = make_stereo_case(rng, nl, nr, n_levels=int(rng.integers(1, 8)))
+            if rng.random() < 0.5:  # rows exactly on .5 (where the iRound definitions differ), some of them negative
+                kl["y"], kr["y"] = np.floor(kl["y"]) + 0.5, np.floor(kr["y"]) + 0.5
+                kl["y"][: nl // 8] -= 70.0
+                kr["y"][: nr // 8] -= 70.0
             got = st.StereoMatching(kl, dl, kr, dr, bfv, ls, relaxed)
             want = orc.stereo_match(kl, dl, kr, dr, bfv, ls, relaxed)
             ok = got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
