@@ -194,23 +194,33 @@ class SnakeORBMatcher
         perm.resize((size_t)n);
         return perm;
     }
-    // The Tracking thread makes 1-2 coarse calls and one fine call on the same frame: BindFrame uploads the frame once, the
-    // Search* calls given THAT FrameView object then send nothing but the points; after changing frame.taken
-    // (mvpMapPoints[idx] = mp) call UpdateTaken.  UnbindFrame (or destroying the FrameView's contents) ends it.
-    void BindFrame(const FrameView& frame)
+    // The Tracking thread makes 1-2 coarse calls and one fine call on the same frame: BindFrame uploads the frame once and returns
+    // a TOKEN; the Search* overloads that take the token send nothing but the points.  The binding is explicit -- a FrameView
+    // object that is refilled or re-created at the same address can never be mistaken for the frame on the device (round 2
+    // compared addresses) -- and a token of an earlier binding is refused (std::logic_error).  After changing mvpMapPoints
+    // (taken) between two calls: UpdateTaken(token, taken).  The Search* overloads that take a FrameView upload it, always.
+    struct BoundFrame
+    {
+        uint64_t id = 0;
+        int n       = 0;
+    };
+    BoundFrame BindFrame(const FrameView& frame)
     {
         const snk_frame_view v = frame.view();
         check(snk_match_bind_frame(h_, &v), "snk_match_bind_frame");
-        bound_ = &frame;
+        bound_ = BoundFrame{++bind_counter_, v.n};
+        return bound_;
     }
-    void UpdateTaken()
+    void UpdateTaken(const BoundFrame& b, const std::vector<uint8_t>& taken)
     {
-        if (bound_) check(snk_match_bound_taken(h_, bound_->taken.data()), "snk_match_bound_taken");
+        require_bound(b);
+        if ((int)taken.size() != b.n) throw std::invalid_argument("UpdateTaken: taken mask size differs from the bound frame's");
+        check(snk_match_bound_taken(h_, taken.data()), "snk_match_bound_taken");
     }
     void UnbindFrame()
     {
         check(snk_match_bind_frame(h_, nullptr), "snk_match_bind_frame");
-        bound_ = nullptr;
+        bound_ = BoundFrame{};
     }
 
     // match[i] = feature index for local-map point i or -1; the caller sets mvpMapPoints[match[i]] = lm.points[i].mp
@@ -219,28 +229,28 @@ class SnakeORBMatcher
                                       const std::vector<float>& level_scale, std::vector<int32_t>& match)
     {
         const snk_frame_view v = frame.view();
-        match.assign(lm.size() + 1, -1);
-        int n = 0;
-        check(snk_match_project_coarse(h_, &frame == bound_ ? nullptr : &v, &K, pose, lm.data(), (int)lm.size(), th, featureError, direction,
-                                       level_scale.data(), (int)level_scale.size(), match.data(), &n),
-              "snk_match_project_coarse");
-        match.resize(lm.size());
-        return n;
+        return coarse(&v, K, pose, lm, th, featureError, direction, level_scale, match);
+    }
+    int SearchByProjectionFrameFrame2(const BoundFrame& b, const snk_camera& K, const double pose[7],
+                                      const std::vector<snk_lm_coarse>& lm, float th, int featureError, int direction,
+                                      const std::vector<float>& level_scale, std::vector<int32_t>& match)
+    {
+        require_bound(b);
+        return coarse(nullptr, K, pose, lm, th, featureError, direction, level_scale, match);
     }
     int SearchByProjection2(const FrameView& frame, const snk_camera& K, const double pose[7], std::vector<snk_lm_fine>& lm,
                             float th, float ratio, const std::vector<float>& level_scale, std::vector<int32_t>& match,
                             std::vector<uint8_t>& visible)
     {
         const snk_frame_view v = frame.view();
-        match.assign(lm.size() + 1, -1);
-        visible.assign(lm.size() + 1, 0);
-        int n = 0;
-        check(snk_match_project_fine(h_, &frame == bound_ ? nullptr : &v, &K, pose, lm.data(), (int)lm.size(), th, ratio, level_scale.data(),
-                                     (int)level_scale.size(), match.data(), visible.data(), &n),
-              "snk_match_project_fine");
-        match.resize(lm.size());
-        visible.resize(lm.size());
-        return n;
+        return fine(&v, K, pose, lm, th, ratio, level_scale, match, visible);
+    }
+    int SearchByProjection2(const BoundFrame& b, const snk_camera& K, const double pose[7], std::vector<snk_lm_fine>& lm, float th,
+                            float ratio, const std::vector<float>& level_scale, std::vector<int32_t>& match,
+                            std::vector<uint8_t>& visible)
+    {
+        require_bound(b);
+        return fine(nullptr, K, pose, lm, th, ratio, level_scale, match, visible);
     }
     int SearchByProjectionFrameToKeyframe(const FrameView& frame, const snk_camera& K, const double pose[7],
                                           const std::vector<std::array<double, 3>>& positions,
@@ -259,8 +269,37 @@ class SnakeORBMatcher
     }
 
    private:
+    void require_bound(const BoundFrame& b) const
+    {
+        if (b.id == 0 || b.id != bound_.id) throw std::logic_error("stale or empty frame binding (BindFrame again)");
+    }
+    int coarse(const snk_frame_view* v, const snk_camera& K, const double pose[7], const std::vector<snk_lm_coarse>& lm, float th,
+               int featureError, int direction, const std::vector<float>& level_scale, std::vector<int32_t>& match)
+    {
+        match.assign(lm.size() + 1, -1);
+        int n = 0;
+        check(snk_match_project_coarse(h_, v, &K, pose, lm.data(), (int)lm.size(), th, featureError, direction, level_scale.data(),
+                                       (int)level_scale.size(), match.data(), &n),
+              "snk_match_project_coarse");
+        match.resize(lm.size());
+        return n;
+    }
+    int fine(const snk_frame_view* v, const snk_camera& K, const double pose[7], std::vector<snk_lm_fine>& lm, float th, float ratio,
+             const std::vector<float>& level_scale, std::vector<int32_t>& match, std::vector<uint8_t>& visible)
+    {
+        match.assign(lm.size() + 1, -1);
+        visible.assign(lm.size() + 1, 0);
+        int n = 0;
+        check(snk_match_project_fine(h_, v, &K, pose, lm.data(), (int)lm.size(), th, ratio, level_scale.data(),
+                                     (int)level_scale.size(), match.data(), visible.data(), &n),
+              "snk_match_project_fine");
+        match.resize(lm.size());
+        visible.resize(lm.size());
+        return n;
+    }
     snk_matcher* h_ = nullptr;
-    const FrameView* bound_ = nullptr;
+    BoundFrame bound_{};
+    uint64_t bind_counter_ = 0;
 };
 
 // Snake::MappingORBMatcher (reference Snake/LocalMapping/MappingORBMatcher.h:15-45): the two keyframe-rate

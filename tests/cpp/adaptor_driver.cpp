@@ -110,15 +110,35 @@ int main(int argc, char** argv)
             match.push_back(n);
             wr("out_tr_coarse", match);
             // the same call on the bound frame (uploaded once) must give the same answer
-            om.BindFrame(fv);
+            const auto stale = om.BindFrame(fv);
+            const auto bound = om.BindFrame(fv);  // a second binding: the first token is stale from here on
             std::vector<int32_t> match_b;
-            const int nb = om.SearchByProjectionFrameFrame2(fv, cam[0], pose.data(), lc, 15.0f, 75, 0, ls, match_b);
+            const int nb = om.SearchByProjectionFrameFrame2(bound, cam[0], pose.data(), lc, 15.0f, 75, 0, ls, match_b);
             match_b.push_back(nb);
             if (match_b != match) throw std::runtime_error("bound frame: coarse result differs");
-            om.UpdateTaken();
+            bool refused = false;
+            try
+            {
+                om.SearchByProjectionFrameFrame2(stale, cam[0], pose.data(), lc, 15.0f, 75, 0, ls, match_b);
+            }
+            catch (const std::logic_error&)
+            {
+                refused = true;
+            }
+            if (!refused) throw std::runtime_error("a stale binding token was accepted");
+            // the caller refills the SAME FrameView object for another frame (the usual pattern): the bound copy on the device must
+            // not change and the FrameView overload must upload the new contents (round 2 matched against the stale copy here)
+            FrameView other = fv;
+            std::swap(fv.taken, other.taken);
+            for (auto& t : fv.taken) t = 1;  // every feature taken: no match possible on the refilled view
+            std::vector<int32_t> match_r;
+            if (om.SearchByProjectionFrameFrame2(fv, cam[0], pose.data(), lc, 15.0f, 75, 0, ls, match_r) != 0)
+                throw std::runtime_error("refilled FrameView was not uploaded");
+            fv.taken = other.taken;
+            om.UpdateTaken(bound, fv.taken);
             auto lf = rd<snk_lm_fine>("tr_fine");
             std::vector<uint8_t> vis;
-            n = om.SearchByProjection2(fv, cam[0], pose.data(), lf, 5.0f, 0.8f, ls, match, vis);
+            n = om.SearchByProjection2(bound, cam[0], pose.data(), lf, 5.0f, 0.8f, ls, match, vis);
             match.push_back(n);
             wr("out_tr_fine", match);
             wr("out_tr_fine_vis", vis);

@@ -50,3 +50,19 @@ def test_adaptor_compiles_and_links(tmp_path):
     # the binary runs without a GPU: snk_device_count() reports 0 devices instead of failing
     r = subprocess.run([str(tmp_path / "adaptor_check")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_reference_signature_shims_compile_against_mock_snake_types(tmp_path):
+    """snake_hip_reference.hpp -- SearchByProjectionFrameFrame2(Frame&, const LocalMap<CoarseTrackingPoint>&, ...) and the other
+    reference signatures -- instantiated with mock structs that carry exactly the member names of Snake/Map/{Frame,Features,
+    LocalMap}.h and of the Saiga::Scene MakeLocalScene fills (tests/cpp/reference_shims_driver.cpp).  Compiled and linked here;
+    executed on the golden inputs by tests/test_cpp_reference_shims_gpu.py."""
+    lib = ROOT / "snake_slam_amd" / "lib"
+    cmd = ["g++", "-std=c++17", "-Wall", "-Werror", f"-I{ROOT / 'include'}", f"-I{ROOT / 'snake_slam_amd' / 'cpp'}",
+           str(ROOT / "tests" / "cpp" / "reference_shims_driver.cpp"), f"-L{lib}", "-lsnake_hip", "-L/opt/rocm/lib", "-lamdhip64",
+           f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(tmp_path / "ref_driver")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # without inputs / a GPU it must fail cleanly (exception text, status 1), not crash
+    r = subprocess.run([str(tmp_path / "ref_driver"), str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 1 and "reference_shims_driver:" in r.stderr
