@@ -333,7 +333,7 @@ def main():
                     "per-kernel timings then overlap)")
     ap.add_argument("--gba-keyframes", type=int, default=300, help="keyframes of the global-BA leg (0 = skip; single GPU only)")
     ap.add_argument("--pose-frames", type=int, default=256, help="frames per pose-refinement call (0 = skip; single GPU only)")
-    ap.add_argument("--track-frames", type=int, default=256, help="frames of the tracking-matcher leg (device-resident coarse + fine "
+    ap.add_argument("--track-frames", type=int, default=1024, help="frames of the tracking-matcher leg (device-resident coarse + fine "
                     "projection matchers on the frames the front-end left in HBM; 0 = skip)")
     ap.add_argument("--mode", choices=["batch", "sequence"], default="batch",
                     help="batch = the headline throughput benchmark (default); sequence = BASELINE.json config 5: every rank walks its "

@@ -1661,7 +1661,7 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
                                                        long long stride0, int aligned0, const u32* __restrict__ sel,
                                                        const u8* __restrict__ sel_score, const int* __restrict__ sel_cnt,
                                                        snk_keypoint* __restrict__ kps, u64* __restrict__ desc,
-                                                       int* __restrict__ n_out, int out_cap, int gx, int batch)
+                                                       int* __restrict__ n_out, int out_cap, int gx, int batch, int dbg_fake)
 {
     __shared__ uint2 mtab[4 * MOM_PAD];
     __shared__ __attribute__((aligned(16))) u32 patch[4][PATCH_ITEMS + 16];
@@ -1720,11 +1720,13 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
         const int it   = mok[k] ? item : MOM_TRIPLES - 1;
         const int row  = (it * 171) >> 9;  // it / 3
         vyv[k]         = row - 15;
-        moff[k]        = (row - 15) * pitch + 12 * (it - row * 3);
+        // dbg_fake (SNK_ORB_DESC_FAKE=1, timing experiment only, results meaningless): the window's bytes from ONE contiguous run
+        // behind the keypoint instead of 31 / 37 rows -- what the kernel would cost with ~46 instead of ~111 sectors per keypoint
+        moff[k]        = dbg_fake ? 12 * it : (row - 15) * pitch + 12 * (it - row * 3);
         bok[k]         = item < PATCH_QUADS;
         const int ib   = bok[k] ? item : PATCH_QUADS - 1;
         const int rb   = (ib * 171) >> 9;
-        boff[k]        = (rb - PATCH_R) * bpitch + 16 * (ib - rb * 3);
+        boff[k]        = dbg_fake ? 16 * ib : (rb - PATCH_R) * bpitch + 16 * (ib - rb * 3);
     }
 
     // ---- issue every load of the wavefront; the copy of the moment table to LDS (and its barrier) comes after, so
@@ -2403,7 +2405,8 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
         const int gx = ceil_div(max_slot, 4 * DESC_KPW);
         const int nb = batch >= 16 ? 8 * ceil_div(batch, 8) : batch;
         hipLaunchKernelGGL(describe_kernel, dim3(gx * L.n_levels * nb), dim3(256), 0, st, L, images_dev, pitch, image_stride,
-                           aligned0, d_sel, d_selscore, d_selcnt, kps_dev, (u64*)desc_dev, n_dev, out_cap, gx, batch);
+                           aligned0, d_sel, d_selscore, d_selcnt, kps_dev, (u64*)desc_dev, n_dev, out_cap, gx, batch,
+                           getenv("SNK_ORB_DESC_FAKE") ? 1 : 0);
     }
     SNK_LAUNCH_CHECK();
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[5], st));

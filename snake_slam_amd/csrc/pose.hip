@@ -228,7 +228,7 @@ template <int WAVES, int PPT, bool LDSM>
 __global__ __launch_bounds__(64 * WAVES) void pose_kernel(const PoseMeta* __restrict__ meta, const double* __restrict__ wps,
                                                           const snk_pose_obs* __restrict__ obs, u8* __restrict__ outlier,
                                                           double* __restrict__ pose_out, int* __restrict__ inliers_out, CamD cam,
-                                                          snk_pose_options opt)
+                                                          snk_pose_options opt, int lds_matches)
 {
     constexpr int STRIDE = 64 * WAVES;
     constexpr int NP     = PPT > 0 ? PPT : 1;
@@ -263,23 +263,27 @@ __global__ __launch_bounds__(64 * WAVES) void pose_kernel(const PoseMeta* __rest
     }
     // LDSM: the frame's matches (world point + observation, 56 bytes each) are copied to LDS once; the 40 steps then read them
     // with LDS latency instead of a global-memory round trip per match and step (one wavefront per SIMD hides nothing)
+    // The LDS carve holds the first `lds_matches` matches of the frame (the launch sizes it so that several frames share a compute
+    // unit: a frame's 40 steps are a chain of latencies, and with one workgroup per CU every SIMD holds ONE wavefront); matches
+    // beyond it -- a frame with more matches than the usual half of its local map -- are read from global memory, same values.
     extern __shared__ __attribute__((aligned(16))) double s_match[];
-    double* s_w = s_match;               // [3 n]
-    double* s_o = s_match + 3 * (LDSM ? n : 0);  // [4 n]
+    const int nl = LDSM ? min(n, lds_matches) : 0;
+    double* s_w = s_match;           // [3 nl]
+    double* s_o = s_match + 3 * nl;  // [4 nl]
     if (PPT == 0)
     {
         for (int i = lane; i < n; i += STRIDE) out[i] = 0;
         if (LDSM)
         {
-            for (int i = lane; i < 3 * n; i += STRIDE) s_w[i] = W[i];
+            for (int i = lane; i < 3 * nl; i += STRIDE) s_w[i] = W[i];
             const double* Od = reinterpret_cast<const double*>(O);
-            for (int i = lane; i < 4 * n; i += STRIDE) s_o[i] = Od[i];
+            for (int i = lane; i < 4 * nl; i += STRIDE) s_o[i] = Od[i];
         }
         if (WAVES > 1 || LDSM) __syncthreads();
     }
     auto fetch = [&](int i, double* p, snk_pose_obs& o)
     {
-        if constexpr (LDSM)
+        if (LDSM && i < nl)
         {
             p[0] = s_w[3 * i], p[1] = s_w[3 * i + 1], p[2] = s_w[3 * i + 2];
             o.x = s_o[4 * i], o.y = s_o[4 * i + 1], o.depth = s_o[4 * i + 2], o.weight = s_o[4 * i + 3];
@@ -613,11 +617,11 @@ extern "C" int snk_pose_refine(snk_matcher* m, const snk_camera* cam, const snk_
     if (total >= (size_t)n_problems * 192)  // ~200 matches per frame and more: four wavefronts per frame
         hipLaunchKernelGGL((pose_kernel<4, 0, false>), dim3(n_problems), dim3(256), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
                            reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),
-                           reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), reinterpret_cast<int*>(o + o_inl), C, *opt);
+                           reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), reinterpret_cast<int*>(o + o_inl), C, *opt, 0);
     else
         hipLaunchKernelGGL((pose_kernel<1, 0, false>), dim3(n_problems), dim3(64), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
                            reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),
-                           reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), reinterpret_cast<int*>(o + o_inl), C, *opt);
+                           reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), reinterpret_cast<int*>(o + o_inl), C, *opt, 0);
     SNK_LAUNCH_CHECK();
     std::string back(out_b, '\0');
     SNK_HIP_CHECK(hipMemcpyAsync(&back[0], o, out_b, hipMemcpyDeviceToHost, m->stream));
@@ -671,12 +675,20 @@ extern "C" int snk_pose_refine_matches_batch_dev(snk_matcher* m, const snk_frame
                        reinterpret_cast<int*>(d + o_slot));
     CamD C{cam->fx, cam->fy, cam->cx, cam->cy, cam->bf};
     static const bool no_lds = getenv("SNK_POSE_NO_LDS") != nullptr;  // A/B: matches re-read from global memory in every step
-    const size_t match_lds   = (size_t)pts_cap * 7 * sizeof(double);
+    // matches of a frame kept in LDS (56 bytes each): the whole local map when few frames are in flight (one workgroup per CU
+    // anyway), otherwise at most POSE_LDS_MATCHES so that three frames share a compute unit (a tracking pass matches about half
+    // of its local map; SNK_POSE_LDS_MATCHES overrides, tests force the global-memory tail with a small value)
+    static const int lds_env = getenv("SNK_POSE_LDS_MATCHES") ? atoi(getenv("SNK_POSE_LDS_MATCHES")) : 0;
+    int lds_matches = pts_cap;
+    if (lds_env > 0) lds_matches = lds_env < pts_cap ? lds_env : pts_cap;
+    else if (batch > 256 && lds_matches > 896) lds_matches = 896;
+    if ((size_t)lds_matches * 56 > 150 * 1024) lds_matches = 150 * 1024 / 56;
+    const size_t match_lds = (size_t)lds_matches * 7 * sizeof(double);
 #define POSE_LAUNCH(W_, L_, LDS_)                                                                                                    \
     hipLaunchKernelGGL((pose_kernel<W_, 0, L_>), dim3(batch), dim3(64 * W_), LDS_, m->stream, reinterpret_cast<const PoseMeta*>(d),  \
                        reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),                \
-                       reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), inliers_dev, C, *opt)
-    if (pts_cap >= 256 && match_lds <= 150 * 1024 && !no_lds)
+                       reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), inliers_dev, C, *opt, lds_matches)
+    if (pts_cap >= 256 && !no_lds)
     {
         int rc = set_max_lds_once(reinterpret_cast<const void*>(pose_kernel<4, 0, true>), 152 * 1024);
         if (rc != SNK_OK) return rc;

@@ -291,8 +291,8 @@ __device__ __forceinline__ uint4 bcast_u4(const uint4& v, int src)
 // The matchers work on 64 local-map points per wavefront in two phases.  Phase 1, lane = point: projection, culls, search
 // radius (fp64, with the fixed-order log / exp series of the fine matcher) -- ONCE per point; the first version had all 64 lanes
 // of a wavefront repeat this per point and was bound by exactly that (790 vector instructions per point, VALU 100 % busy,
-// PMC r02t).  Phase 2: the points that passed are visited one after the other (scalar bit scan of the ballot), the point's
-// numbers are broadcast with v_readlane and the 64 lanes share its window scan.  Same arithmetic per point as before.
+// PMC r02t).  Phase 2: PJ_GROUP lanes share one window scan; with PJ_GROUP = 1 (the measured optimum, r02u) every lane scans
+// the window of its own point and nothing is broadcast.  Same arithmetic per point as before.
 
 // coarse (SnakeORBMatcher.cpp:221-318): 64 points starting at i0; results to best[] / bins[] (indexed like pts)
 __device__ __forceinline__ void coarse_wave64(const FrameDev& F, const CamDev& C, const ScalesDev& S, const snk_lm_coarse* __restrict__ pts,
@@ -1138,9 +1138,13 @@ __global__ __launch_bounds__(256) void relink_kernel(FrameDev F, CamDev C, const
     }
 }
 
-// Points per wavefront of the projection matchers: a wavefront does the per-point geometry for `ppw` points at once and then
-// visits them one after the other, so many points per wavefront save the redundant geometry, few keep the chip busy when the
-// points are few (one frame of the host API): aim for >= ~8 wavefronts per SIMD.
+// Points per wavefront of the projection matchers: a wavefront does the per-point geometry for `ppw` points at once and, with
+// PJ_GROUP = 1, every lane then scans its own point's window.  Many points per wavefront fill the lanes (throughput of the
+// batched forms), few spread a single frame's points over the chip: for the host calls (one frame, the reference's call
+// pattern) ONE point per wavefront is the lowest latency -- measured on MI355X with the frame bound (tools/latency_track.py,
+// profiles/r03/r03b_latency_track.log): SearchByProjectionFrameFrame2 with 1500 points 0.089 / 0.097 / 0.104 / 0.113 ms and
+// SearchByProjection2 with 10 000 points 0.785 / 0.797 / 0.800 / 0.907 ms at 1 / 4 / 16 / 64 points per wavefront -- a lane's
+// serial window scan is the critical path either way, and more wavefronts only add parallel scans.
 constexpr int FRAME_LDS_MAX = 144 * 1024;  // LDS carve of the frame-resident matchers (one workgroup per CU above 80 KB)
 size_t frame_lds_host(int cap, int ncell1)
 {

@@ -230,12 +230,16 @@ def test_definition_switches_parity(bf, st, orc, definitions, key, value):
     knn = bf.knn.copy()
     th = int(np.sort(knn["dist1"])[len(knn) // 3])           # a threshold that some dist1 equal exactly
     knn["dist2"][::3] = 2 * knn["dist1"][::3]                  # every third row sits exactly on the ratio 0.5
-    # stereo case with rows exactly on .5 (positive and negative halves) so that the three rounding rules disagree
+    # stereo case in which the rounding rule decides band membership: right rows exactly on .5, left rows on integers (which no
+    # rule moves).  floor(x + 0.5) and half-to-even differ on positive .5 rows with an even floor; floor(x + 0.5) and
+    # half-away-from-zero only differ on NEGATIVE .5 rows (rectification can push points above the image), so for that rule the
+    # whole case sits above the image
     left, dl, right, dr, bfv, ls = make_stereo_case(rng, 300, 280)
     right["y"] = np.floor(right["y"]) + 0.5
-    left["y"] = np.floor(left["y"]) + 0.5
-    right["y"][:40] -= 60.0                                    # some negative rows (rectification can push points above the image)
-    left["y"][:40] -= 60.0
+    left["y"] = np.floor(left["y"])
+    if key == "iround.mode" and value == 1:
+        right["y"] -= 600.0
+        left["y"] -= 600.0
 
     def run():
         bf.knn = knn.copy()

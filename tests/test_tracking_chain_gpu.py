@@ -158,3 +158,22 @@ def test_device_resident_chain_coarse_refine_fine(orc):
         # candidate sits within that of a gate, which these seeded cases do not have
         assert n_f[b] == wn2 and np.array_equal(mi_f[b, : nfp[b]], widx2), b
     assert inl[:3].min() > 20 and inl[3] == 0
+
+
+@pytest.mark.skipif(__import__("os").environ.get("SNK_POSE_NO_RECURSE") == "1", reason="child run")
+def test_device_resident_chain_with_a_small_pose_lds_carve():
+    """pose_kernel keeps the first `lds_matches` matches of a frame in LDS (sized so that several frames share a compute unit) and
+    reads the rest from global memory; the device-resident chain runs again in a child process with the carve forced down to 100
+    matches (SNK_POSE_LDS_MATCHES), so that most matches of every frame take the global-memory tail -- same poses."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, "-m", "pytest", str(Path(__file__).resolve()), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "device_resident_chain_coarse_refine_fine"],
+                       env=dict(os.environ, SNK_POSE_LDS_MATCHES="100", SNK_POSE_NO_RECURSE="1"), capture_output=True, text=True,
+                       cwd=str(root), timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-1000:])
+    assert "1 passed" in r.stdout
