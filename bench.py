@@ -35,6 +35,7 @@ W, H = 752, 480
 ORB = dict(nfeatures=1000, scale_factor=1.2, n_levels=4, ini_th_fast=20, min_th_fast=7)  # reference configs/euroc.ini:32-36
 BF_SYNTH = 47.9 * 2.5  # bf such that the synthetic disparities (2..60 px) fall inside [0, bf/2]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_CLOCK_HZ = 2.4e9  # MI355X_MICROARCH.md: max clock
 
 
 def pyramid_pixels():
@@ -740,6 +741,7 @@ def main():
             alg_bytes = P * images_per_launch  # read every pyramid pixel once (the FAST+score pass of A_orb)
             achieved = alg_bytes / (fast_ms * 1e-3) / 1e9
             traffic = None
+            valu = None
             tj = ROOT / "profiles" / "fast_kernel_traffic.json"
             if tj.exists():
                 # PMC bytes of a separate rocprofv3 --pmc run (tools/profile_gpu.sh + tools/collect_traffic.py); only valid for the
@@ -750,13 +752,27 @@ def main():
                     t = json.loads(tj.read_text())
                     cur = hashlib.sha256((ROOT / t.get("source", "snake_slam_amd/csrc/orb.hip")).read_bytes()).hexdigest()
                     if t.get("source_sha256") == cur and t.get("images_per_launch"):
-                        traffic = int(t.get("hbm_bytes_per_launch") * images_per_launch / t.get("images_per_launch"))
+                        scale = images_per_launch / t.get("images_per_launch")
+                        traffic = int(t.get("hbm_bytes_per_launch") * scale)
+                        if t.get("valu_insts_per_launch"):
+                            # The kernel is instruction-bound, not HBM-bound (traffic ~ algorithmic bytes, nothing re-read): its
+                            # vector-instruction roofline.  Peak: 256 CUs x 4 SIMDs, one wave64 integer / packed-16 VALU instruction per
+                            # 4 cycles (SIMD16 issue; measured on level_kernel) at the 2.4 GHz maximum clock.
+                            n_valu = t["valu_insts_per_launch"] * scale
+                            peak = 1024 * VALU_CLOCK_HZ / 4.0
+                            valu = {"instr_per_launch": int(n_valu), "issue_peak": peak, "unit": "wave64 VALU instructions/s",
+                                    "achieved": round(n_valu / (fast_ms * 1e-3), 1), "frac": round(n_valu / (fast_ms * 1e-3) / peak, 4),
+                                    "instr_per_wave": round(t["valu_insts_per_launch"] / max(1, t.get("waves_per_launch") or 1), 1),
+                                    "source": "SQ_INSTS_VALU of a separate rocprofv3 --pmc pass (profiles/fast_kernel_traffic.json)"}
+                            if t.get("busy_cycles_per_launch"):  # the clock the chip actually held during the profiled launch
+                                valu["frac_at_profiled_clock"] = round(t["valu_insts_per_launch"] * 4.0 / (1024 * t["busy_cycles_per_launch"]), 4)
                 except Exception:
-                    traffic = None
+                    traffic, valu = None, None
             out["roofline"] = {"bound": "hbm", "kernel": "fast_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(fast_ms, 4),
-                               "images_per_launch": images_per_launch, "launches_per_step": n_calls // args.steps}
+                               "images_per_launch": images_per_launch, "launches_per_step": n_calls // args.steps,
+                               "limited_by": "valu" if valu else None, "valu": valu}
             # summed over the launch chains of a step (with --orb-chains 2 the chains overlap and the sum exceeds the step time)
             out["stage_ms_per_step"] = {k: round(v / args.steps, 4) for k, v in zip(["pyramid", "blur", "fast", "distribute", "describe"], stage_ms)}
         # whole front-end against the HBM roofline: A_orb = 3 P + 56 N bytes per mono image,

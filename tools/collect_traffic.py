@@ -43,7 +43,15 @@ def main():
         raise SystemExit(f"no {prefix} dispatches with FETCH_SIZE / WRITE_SIZE under {d}")
     FETCH_CORRECTION = 2.0
     hbm = int(fetch_kb * 1024 * FETCH_CORRECTION + write_kb * 1024)
+    # instruction counters of the same kernel (tools/profile_gpu.sh passes pmc_sq / pmc_sq2): what bench.py's `roofline.valu`
+    # is computed from.  The counters of a dispatch add up over the XCDs; GRBM_GUI_ACTIVE / 8 = busy cycles of the launch.
+    valu, _ = mean_counter(d / "pmc_sq", "SQ_INSTS_VALU", prefix)
+    salu, _ = mean_counter(d / "pmc_sq", "SQ_INSTS_SALU", prefix)
+    waves, _ = mean_counter(d / "pmc_sq", "SQ_WAVES", prefix)
+    gui, _ = mean_counter(d / "pmc_sq2", "GRBM_GUI_ACTIVE", prefix)
     out = {"kernel": "fast_kernel", "images_per_launch": images, "hbm_bytes_per_launch": hbm,
+           "valu_insts_per_launch": None if valu is None else int(valu), "salu_insts_per_launch": None if salu is None else int(salu),
+           "waves_per_launch": None if waves is None else int(waves), "busy_cycles_per_launch": None if gui is None else int(gui / 8),
            "raw": {"FETCH_SIZE_KB": round(fetch_kb, 1), "WRITE_SIZE_KB": round(write_kb, 1), "dispatches": [nf, nw], "run": d.name},
            "fetch_correction": FETCH_CORRECTION,
            "note": "MI355X_MICROARCH.md section HBM: gfx950 FETCH_SIZE = 1/2 of the bytes of a 16-B-per-lane coalesced read "
