@@ -370,12 +370,38 @@ __global__ __launch_bounds__(64 * WAVES) void pose_kernel(const PoseMeta* __rest
                     add_match(p, o);
                 }
             if (WAVES > 1)
-                reduce(acc, std::integral_constant<int, 27>{});
+            {
+                // The 6 x 6 solve and the pose update are the same numbers for every thread: only the FIRST wavefront runs them
+                // (the others wait at the barrier and leave their SIMDs to the other frames of the compute unit -- with several
+                // frames per CU the redundant Cholesky, 6 square roots and 6 divisions in fp64, was a third of the kernel's vector
+                // instructions) and hands the new pose over through LDS.  Same arithmetic, same order: bit-identical poses.
+#pragma unroll
+                for (int i = 0; i < 27; ++i) acc[i] = row_sum64_dpp(acc[i]);
+                if ((lane & 15) == 0)
+#pragma unroll
+                    for (int i = 0; i < 27; ++i) s_part[lane >> 4][i] = acc[i];
+                __syncthreads();
+                if (lane < 64)
+                {
+                    if (lane < 27)
+                    {
+                        double v = s_part[0][lane];
+#pragma unroll
+                        for (int w = 1; w < WAVES * 4; ++w) v += s_part[w][lane];
+                        s_tot[lane] = v;
+                    }
+                    __builtin_amdgcn_wave_barrier();  // one wavefront: the LDS serves it in program order
+#pragma unroll
+                    for (int i = 0; i < 27; ++i) acc[i] = s_tot[i];
+                }
+            }
             else
             {
 #pragma unroll
                 for (int i = 0; i < 27; ++i) acc[i] = wave_sum64_dpp(acc[i]);
             }
+            if (WAVES == 1 || lane < 64)
+            {
             double H[36], b[6];
             {
                 int u = 0;
@@ -410,6 +436,18 @@ __global__ __launch_bounds__(64 * WAVES) void pose_kernel(const PoseMeta* __rest
 #pragma unroll
             for (int a = 0; a < 6; ++a) nb[a] = -b[a];
             if (chol_solve6(H, nb, d) == 0) se3_update(pose, d);
+            }
+            if (WAVES > 1)
+            {
+                if (lane == 0)
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) s_tot[i] = pose[i];  // s_tot's sums have been consumed (by this wavefront, in order)
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 7; ++i) pose[i] = s_tot[i];
+                // no third barrier: the next write of s_tot (lane < 27 of the first wavefront) comes after the next step's
+                // barrier, which every thread reaches only after these reads
+            }
         }
         // re-classify every match
         double R[9];
@@ -681,7 +719,8 @@ extern "C" int snk_pose_refine_matches_batch_dev(snk_matcher* m, const snk_frame
     static const int lds_env = getenv("SNK_POSE_LDS_MATCHES") ? atoi(getenv("SNK_POSE_LDS_MATCHES")) : 0;
     int lds_matches = pts_cap;
     if (lds_env > 0) lds_matches = lds_env < pts_cap ? lds_env : pts_cap;
-    else if (batch > 256 && lds_matches > 896) lds_matches = 896;
+    else if (batch > 768 && lds_matches > 656) lds_matches = 656;  // four frames per CU (656 x 56 B + 3.8 KB static <= 40 KB): 1024 frames are ONE round of the 256 CUs
+    else if (batch > 256 && lds_matches > 896) lds_matches = 896;  // three
     if ((size_t)lds_matches * 56 > 150 * 1024) lds_matches = 150 * 1024 / 56;
     const size_t match_lds = (size_t)lds_matches * 7 * sizeof(double);
 #define POSE_LAUNCH(W_, L_, LDS_)                                                                                                    \
