@@ -21,7 +21,10 @@ def env_rank_world():
 def init_distributed(device: torch.device | None = None, backend: str | None = None) -> tuple[int, int]:
     """Initialise torch.distributed from the torchrun environment (no-op for world size 1)."""
     rank, world, _ = env_rank_world()
-    if world <= 1:
+    # SNK_DIST_FORCE=1: a process group also for ONE rank, so that a one-GPU box exercises the same RCCL initialisation, barrier,
+    # all_reduce and all_gather calls (device tensors, device_id binding) that the N > 1 runs make -- the only RCCL rehearsal
+    # possible without a multi-GPU lease (tests/test_bench_contract_gpu.py)
+    if world <= 1 and not os.environ.get("SNK_DIST_FORCE"):
         return 0, 1
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")
@@ -36,7 +39,7 @@ def init_distributed(device: torch.device | None = None, backend: str | None = N
 
 
 def is_distributed() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or bool(os.environ.get("SNK_DIST_FORCE")))
 
 
 def describe() -> dict:

@@ -101,3 +101,20 @@ def test_two_ranks_rehearsal_on_one_gpu(mode):
         assert d["config"]["frames_per_gpu_per_step"] == 16 and d["ba"]["value"] > 0
     else:
         assert len(d["trajectories"]) == 2 if "trajectories" in d else True
+
+
+def test_one_rank_process_group_on_rccl():
+    """RCCL itself on the GPU box: with SNK_DIST_FORCE=1 bench.py creates a ONE-rank "nccl" (= RCCL) process group bound to
+    cuda:0 and runs the very barrier / all_reduce(MAX) / all_gather calls of the N > 1 runs on device tensors.  A one-GPU box
+    cannot show xGMI traffic, but it does show that RCCL initialises in this environment (HSA_ENABLE_IPC_MODE_LEGACY, device_id
+    binding) and that the collective calls are issued with tensors RCCL accepts."""
+    import os
+
+    env = {k: v for k, v in os.environ.items() if k not in ("SNK_DIST_BACKEND", "SNK_BENCH_DEVICE")}
+    env.update(SNK_DIST_FORCE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29578")
+    for extra in (["--batch", "16", "--ba-windows", "8", "--track-frames", "0"], ["--mode", "sequence"]):
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                            "--gba-keyframes", "0", "--pose-frames", "0"] + extra, capture_output=True, text=True, cwd=str(ROOT), timeout=900, env=env)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][0])
+        assert d["dist"] == {"world_size": 1, "backend": "nccl"} and d["n_gpus"] == 1 and d["value"] > 0

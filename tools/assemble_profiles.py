@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Copies the summaries of one measurement round from gpurun_out/ (scratch) into profiles/r02/ (tracked).
+"""Copies the summaries of one measurement round from gpurun_out/ (scratch) into profiles/r03/ (tracked; SNK_PROFILE_ROUND selects the directory).
 
-usage: assemble_profiles.py <tag>      e.g. r02w -> profiles/r02/r02w_*  (+ profiles/fast_kernel_traffic.json)
+usage: assemble_profiles.py <tag>      e.g. r03h -> profiles/r03/r03h_*  (+ profiles/fast_kernel_traffic.json)
 
 Expects what tools/profile_gpu.sh, profile_track.sh, profile_ba.sh and the bench / pytest commands of a round leave under
 gpurun_out/prof_<tag>, prof_track_<tag>, prof_ba_<tag> and gpurun_out/<tag>/; whatever is absent is skipped."""
 import csv
+import os
 import re
 import shutil
 import subprocess
@@ -14,7 +15,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 G = ROOT / "gpurun_out"
-P = ROOT / "profiles" / "r02"
+P = ROOT / "profiles" / os.environ.get("SNK_PROFILE_ROUND", "r03")
 
 
 def kstats(src: Path, dst: Path):
@@ -31,7 +32,7 @@ def kstats(src: Path, dst: Path):
 
 def main(tag):
     P.mkdir(parents=True, exist_ok=True)
-    for d, name in ((f"prof_{tag}", "bench_b256"), (f"prof_track_{tag}", "bench_with_tracking_chain"), (f"prof_ba_{tag}", "ba_b256_only")):
+    for d, name in ((f"prof_{tag}", "bench_b1024"), (f"prof_track_{tag}", "bench_with_tracking_chain"), (f"prof_ba_{tag}", "ba_b1024_only")):
         src = G / d / "trace" / "t_kernel_stats.csv"
         if src.exists():
             kstats(src, P / f"{tag}_kernel_stats_{name}.csv")
