@@ -6,10 +6,13 @@ API raises.  Tests and the bench call the kernels only through this binding.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "lib" / "libsnake_hip.so"
+if os.environ.get("SNK_HIP_LIB"):  # build-time A/B variants of the SAME library (snake_slam_amd.build.build_variant); measurements only
+    LIB_PATH = Path(os.environ["SNK_HIP_LIB"]).resolve()
 
 
 class SnakeHipError(RuntimeError):

@@ -72,5 +72,20 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     return LIB
 
 
+def build_variant(name: str, defines: dict, source: str = "ba.hip") -> Path:
+    """A/B measurements of build-time choices: `lib/variants/libsnake_hip_<name>.so` = the library with `source` recompiled
+    under -D<key>=<value>.  Select it with SNK_HIP_LIB=<path> (snake_slam_amd/_lib.py)."""
+    build_library()
+    vdir = LIBDIR / "variants"
+    vdir.mkdir(exist_ok=True)
+    obj = CSRC / "build" / f"{Path(source).stem}_{name}.o"
+    _run([HIPCC, *HIP_FLAGS, *HIP_FLAGS_PER_SOURCE.get(source, []), *[f"-D{k}={v}" for k, v in defines.items()], "-c", str(CSRC / source),
+          "-o", str(obj)])
+    others = [CSRC / "build" / (s.stem + ".o") for s in sorted(CSRC.glob("*.hip")) if s.name != source]
+    out = vdir / f"libsnake_hip_{name}.so"
+    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", str(obj), *map(str, others), "-o", str(out)])
+    return out
+
+
 if __name__ == "__main__":
     build_library(force="--force" in sys.argv, verbose=True)

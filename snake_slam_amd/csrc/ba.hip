@@ -45,6 +45,15 @@
 // This file is compiled with -ffp-contract=fast (snake_slam_amd/build.py): BA is specified by a tolerance, its kernels
 // are bound by fp64 issue slots, and a * b + c as one v_fma_f64 halves them.  Results stay deterministic.
 
+// Occupancy experiments (build-time A/B): minimum wavefronts per SIMD the register allocator must leave room
+// for in cam_pass / update_cost (1 = no constraint: the allocator's own choice, two wavefronts per SIMD at ~195 registers).
+#ifndef SNK_BA_CAM_WAVES
+#define SNK_BA_CAM_WAVES 1
+#endif
+#ifndef SNK_BA_UC_WAVES
+#define SNK_BA_UC_WAVES 1
+#endif
+
 namespace snk
 {
 namespace
@@ -847,7 +856,7 @@ __global__ __launch_bounds__(64) void rpc_pass(Arrays A, int trial)
 // linearising three observations: with many windows per launch ONE wavefront per camera (12 observations per thread for the
 // benchmark window) is fastest -- 143 us (4 wavefronts) -> 102 (2) -> 86 (1) per 256 windows; a single window keeps 4 for latency.
 template <int CAM_THREADS>
-__global__ __launch_bounds__(CAM_THREADS) void cam_pass(Arrays A, Opt O)
+__global__ __launch_bounds__(CAM_THREADS, SNK_BA_CAM_WAVES) void cam_pass(Arrays A, Opt O)
 {
     __shared__ double part[CAM_THREADS / 64][33];
     const int pb  = blockIdx.y;
@@ -1556,7 +1565,7 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
 // observation records in the order it walks them (coalesced), and the trial cost is evaluated right after the group's new
 // points exist (in LDS) -- the observation, point and pose loads are shared by the two passes.  Needs pose_new:
 // update_pass(images) runs BEFORE this kernel.  Same arithmetic and summation order as update_wave / cost_wave.
-__global__ __launch_bounds__(256) void update_cost(Arrays A, Opt O, int nbx, int B)
+__global__ __launch_bounds__(256, SNK_BA_UC_WAVES) void update_cost(Arrays A, Opt O, int nbx, int B)
 {
     // per wavefront: t = J_p^T (J_c dc) per observation (64 x 3) | cost per observation (64) | b_p - sum t per point (16 x 3) | new points (16 x 3)
     __shared__ double s_buf[4][64 * 3 + 64 + SF_GMAX * 6];
