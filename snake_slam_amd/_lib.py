@@ -79,6 +79,8 @@ SIGNATURES = {
     "snk_orb_set_chains": (i32, [vp, i32]),
     "snk_orb_stage_times": (i32, [vp, vp, C.POINTER(i32)]),
     "snk_orb_debug_fetch": (i32, [vp, i32, i32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "snk_track_bf_matches_batch_dev": (i32, [vp, vp, vp, vp, i32, i32, vp]),
+    "snk_track_backproject_batch_dev": (i32, [vp, vp, vp, vp, vp, vp, vp]),
     "snk_set_definition": (i32, [C.c_char_p, i32]),
     "snk_get_definition": (i32, [C.c_char_p, C.POINTER(i32)]),
     "snk_ba_create": (i32, [vp, i32, vp, C.POINTER(vp)]),

@@ -592,10 +592,91 @@ __global__ __launch_bounds__(64) void scatter_pose_kernel(const PoseMeta* __rest
     for (int k = lane; k < M.n; k += 64) outlier_pt[base + slot_of[base + k]] = outl[base + k];
     if (lane < 7) poses[(size_t)b * 7 + lane] = pose_out[(size_t)b * 7 + lane];
 }
+// ---- sequences in lockstep (BASELINE.json config 5 with several sequences per GPU): the two glue steps between the batched BF
+// matcher and the batched pose refinement, so that a frame of every sequence is tracked without a host round trip ----
+// TrackBruteForce (Snake/Tracking/TrackingCoarse.cpp:342-387): the filtered matches whose reference feature has a map point become
+// (world point, observation) pairs.  Here the reference features' points are the previous frame's stereo points: pair (q, t) of
+// the filtered list (q = previous feature, t = current feature) is kept when prev_has[q]; match_idx[q] = t, everything else -1.
+__global__ __launch_bounds__(256) void bf_matches_kernel(const int2* __restrict__ pairs, const int* __restrict__ n_pairs,
+                                                         const u8* __restrict__ prev_has, int cap, int* __restrict__ match_idx)
+{
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const size_t base = (size_t)b * cap;
+    for (int i = tid; i < cap; i += 256) match_idx[base + i] = -1;
+    __syncthreads();  // the -1 fill and the scatter below touch the same words
+    const int n = min(max(n_pairs[b], 0), cap);
+    for (int j = tid; j < n; j += 256)
+    {
+        const int2 pr = pairs[base + j];  // queries are distinct (one pair per query at most): no two threads write one word
+        if (pr.x >= 0 && pr.x < cap && pr.y >= 0 && pr.y < cap && prev_has[base + pr.x]) match_idx[base + pr.x] = pr.y;
+    }
+}
+
+// The frame's stereo points in the world (what the next frame is tracked against): feature i with depth z > 0 is
+// p_c = ((x - cx) / fx * z, (y - cy) / fy * z, z) and p_w = R^T (p_c - t) with the frame's pose (R, t) = world -> camera
+// (the inverse of `currentPose * wp`, SnakeORBMatcher.cpp:229); has[i] = depth > 0, features without depth get z = 1 (never used).
+__global__ __launch_bounds__(256) void backproject_kernel(const snk_kp64* __restrict__ kps, const float* __restrict__ depth,
+                                                          const int* __restrict__ n_feat, int cap, CamD cam,
+                                                          const double* __restrict__ poses, double* __restrict__ world,
+                                                          u8* __restrict__ has)
+{
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cap) return;
+    const size_t k = (size_t)b * cap + i;
+    const int n = min(max(n_feat[b], 0), cap);
+    if (i >= n)
+    {
+        has[k] = 0;
+        world[3 * k] = world[3 * k + 1] = world[3 * k + 2] = 0.0;
+        return;
+    }
+    double R[9];
+    quat_to_R(poses + (size_t)b * 7, R);
+    const double tx = poses[(size_t)b * 7 + 4], ty = poses[(size_t)b * 7 + 5], tz = poses[(size_t)b * 7 + 6];
+    const float d  = depth[k];
+    const bool h   = d > 0.0f;
+    const double z = h ? (double)d : 1.0;
+    const snk_kp64 kp = kps[k];
+    const double px = (kp.x - cam.cx) / cam.fx * z - tx, py = (kp.y - cam.cy) / cam.fy * z - ty, pz = z - tz;
+    world[3 * k + 0] = px * R[0] + py * R[3] + pz * R[6];
+    world[3 * k + 1] = px * R[1] + py * R[4] + pz * R[7];
+    world[3 * k + 2] = px * R[2] + py * R[5] + pz * R[8];
+    has[k] = h ? 1 : 0;
+}
 }  // namespace
 }  // namespace snk
 
 using namespace snk;
+
+extern "C" int snk_track_bf_matches_batch_dev(snk_matcher* m, const int32_t* pairs_dev, const int32_t* n_pairs_dev,
+                                              const uint8_t* prev_has_dev, int cap, int batch, int32_t* match_idx_dev)
+{
+    SNK_REQUIRE(m != nullptr, "matcher is NULL");
+    SNK_REQUIRE(batch >= 0 && cap >= 1, "bad sizes");
+    SNK_REQUIRE(pairs_dev && n_pairs_dev && prev_has_dev && match_idx_dev, "NULL device buffer");
+    if (batch == 0) return SNK_OK;
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    hipLaunchKernelGGL(bf_matches_kernel, dim3(batch), dim3(256), 0, m->stream, reinterpret_cast<const int2*>(pairs_dev), n_pairs_dev,
+                       prev_has_dev, cap, match_idx_dev);
+    SNK_LAUNCH_CHECK();
+    return SNK_OK;
+}
+
+extern "C" int snk_track_backproject_batch_dev(snk_matcher* m, const snk_frames_dev* frames, const float* depth_dev,
+                                               const snk_camera* cam, const double* poses_dev, double* world_dev, uint8_t* has_dev)
+{
+    SNK_REQUIRE(m != nullptr && frames != nullptr && cam != nullptr, "NULL argument");
+    SNK_REQUIRE(frames->batch >= 0 && frames->cap >= 1 && frames->kps != nullptr && frames->n != nullptr, "bad frames");
+    SNK_REQUIRE(depth_dev && poses_dev && world_dev && has_dev, "NULL device buffer");
+    SNK_REQUIRE(cam->fx != 0.0 && cam->fy != 0.0, "fx / fy must not be 0");
+    if (frames->batch == 0) return SNK_OK;
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    CamD C{cam->fx, cam->fy, cam->cx, cam->cy, cam->bf};
+    hipLaunchKernelGGL(backproject_kernel, dim3(ceil_div(frames->cap, 256), frames->batch), dim3(256), 0, m->stream, frames->kps,
+                       depth_dev, frames->n, frames->cap, C, poses_dev, world_dev, has_dev);
+    SNK_LAUNCH_CHECK();
+    return SNK_OK;
+}
 
 extern "C" int snk_pose_refine(snk_matcher* m, const snk_camera* cam, const snk_pose_options* opt, snk_pose_problem* problems,
                                int n_problems)

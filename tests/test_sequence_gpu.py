@@ -42,3 +42,42 @@ def test_sequence_trajectory_matches_the_oracle_chain(orc, w, h, orb, cam):
     assert (np.diff(rows[:, 1]) > 0).all()
     assert 0.65 * 4 * step < rows[-1, 1] < 1.35 * 4 * step
     assert abs(rows[-1, 2]) < 0.5 * 4 * step and abs(rows[-1, 3]) < 0.6 * 4 * step
+
+
+def test_sequences_in_lockstep_match_the_oracle_chain(orc):
+    """MultiSequenceTracker: S sequences on one GPU in lockstep, device resident (batched entry points + the two glue kernels
+    snk_track_bf_matches_batch_dev / snk_track_backproject_batch_dev): every sequence's trajectory equals the oracle chain's
+    (poses within 1e-9: everything before the pose refinement is bit-exact) and the host-API tracker's counters."""
+    from snake_slam_amd import synth
+    from snake_slam_amd.sequence import MultiSequenceTracker, SequenceTracker
+
+    w, h, orb, cam = 640, 400, (800, 1.2, 4, 20, 7), (400.0, 400.0, 320.0, 200.0, 100.0)
+    okw = dict(nfeatures=orb[0], scale_factor=orb[1], n_levels=orb[2], ini_th_fast=orb[3], min_th_fast=orb[4])
+    S, T = 3, 4
+    seqs = [list(synth.sequence_frames(10 + s, T, w, h, n_rects=300)) for s in range(S)]
+    mt = MultiSequenceTracker(cam, S, T, orb=okw, width=w, height=h)
+    try:
+        for t in range(T):
+            mt.process([seqs[s][t][0] for s in range(S)], [seqs[s][t][1] for s in range(S)], float(t))
+        rows, stats = mt.results()
+    finally:
+        mt.close()
+    tot = dict(keypoints=0, stereo=0, bf_pairs=0, inliers=0)
+    for s in range(S):
+        want, _ = S_helpers_oracle(orc, seqs[s], w, h, orb, cam)
+        assert rows[s].shape == want.shape == (T, 8)
+        assert np.allclose(rows[s], want, rtol=0, atol=1e-9), s
+        trk = SequenceTracker(cam, orb=okw, width=w, height=h)
+        try:
+            for t, (l, r) in enumerate(seqs[s]):
+                trk.process(l, r, float(t))
+            for k in tot:
+                tot[k] += trk.stats[k]
+        finally:
+            trk.close()
+    assert stats["frames"] == S * T and all(stats[k] == tot[k] for k in tot), (stats, tot)
+    assert stats["bf_pairs"] > S * (T - 1) * 50 and stats["inliers"] > S * (T - 1) * 20
+
+
+def S_helpers_oracle(orc, frames, w, h, orb, cam):
+    return S.oracle_sequence(orc, frames, w, h, orb=orb, cam=cam)
