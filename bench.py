@@ -242,6 +242,8 @@ def sequence_mode(args, rank, world, local, dev):
     from snake_slam_amd.sequence import SequenceTracker, trajectory_block, trajectory_rows
 
     n_frames = args.warmup + args.steps
+    if args.seqs_per_gpu > 1:
+        return lockstep_sequence_mode(args, rank, world, local, dev, n_frames)
     frames = list(synth.sequence_frames(rank, n_frames, W, H))
     trk = SequenceTracker(TRACK_CAM, orb=ORB, device=local, width=W, height=H)
     for t in range(args.warmup):
@@ -281,6 +283,68 @@ def sequence_mode(args, rank, world, local, dev):
                "trajectory_block_bytes": int(block.numel() * 8), "trajectories": per_rank,
                "roofline": None,  # a latency path (one frame at a time); the roofline object belongs to the batch mode
                "cpu_baseline": None}
+        print(json.dumps(out), flush=True)
+    trk.close()
+
+
+def lockstep_sequence_mode(args, rank, world, local, dev, n_frames):
+    """Config 5 the MI355X way: S sequences per GPU in lockstep, device resident (snake_slam_amd.sequence.MultiSequenceTracker) --
+    frame t of every sequence is one batch through the batched entry points, images are the only per-step PCIe traffic (double
+    buffered beside the kernels), poses stay on the device until the end.  One step = frame t of all S sequences of a rank;
+    value = sequences x steps / time over all ranks; one all_gather of the ranks' S trajectory blocks."""
+    import torch
+
+    from snake_slam_amd import parallel, synth
+    from snake_slam_amd.sequence import MultiSequenceTracker, trajectory_block, trajectory_rows
+
+    S = args.seqs_per_gpu
+    seqs = args.sequences  # generated in main() before the HIP context existed (forked workers)
+    trk = MultiSequenceTracker(TRACK_CAM, S, n_frames, orb=ORB, device=local, width=W, height=H)
+
+    def step(t):
+        trk.process([seqs[s][t][0] for s in range(S)], [seqs[s][t][1] for s in range(S)], float(t))
+
+    for t in range(args.warmup):
+        step(t)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(args.warmup, n_frames):
+        step(t)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    t1 = time.perf_counter()
+    elapsed = parallel.max_over_ranks(t1 - t0, dev)
+    rows, st = trk.results()
+    block = torch.from_numpy(np.concatenate([trajectory_block(r, n_frames) for r in rows])).to(dev)
+    blocks = parallel.gather_blocks(block)  # one all_gather: S x (1 + 8 * frames) doubles per rank
+    if rank == 0:
+        baseline_m = TRACK_CAM[4] / TRACK_CAM[0]
+        per = 1 + 8 * n_frames
+        per_rank = []
+        for r, b in enumerate(blocks):
+            bb = b.cpu().numpy()
+            finals = [trajectory_rows(bb[s * per:(s + 1) * per])[-1] for s in range(S)]
+            per_rank.append({"rank": r, "sequences": S, "frames_per_sequence": n_frames,
+                             "mean_final_x": round(float(np.mean([f[1] for f in finals])), 5),
+                             "ground_truth_x": round(float(0.05 * baseline_m * finals[0][0]), 5)})
+        out = {"metric": f"frames/s, sequence mode, {S} sequences per GPU in lockstep (device-resident tracking chain) @{W}x{H}",
+               "value": round(world * S * args.steps / elapsed, 2), "unit": "frames/s", "n_gpus": world, "dist": parallel.describe(),
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+               "data": f"synthetic: {S} seeded {W}x{H} stereo sequences per rank (rig moving 0.05 baselines per frame), images uploaded per step",
+               "config": {"workload": f"{world} x {S} independent stereo sequences in lockstep: Detect L+R, rectify, feature grid, StereoMatching, "
+                                      "matchKnn2 + filterMatches vs the previous frame, RefinePoseWithMatches, all device resident; images over PCIe "
+                                      "(double buffered)",
+                          "sequences_per_gpu": S,
+                          "parallelism": f"{world} GPUs x {S} sequences per GPU, one all_gather of the TUM trajectory blocks"},
+               "keypoints_per_image": round(st["keypoints"] / max(1, 2 * st["frames"]), 1),
+               "stereo_matches_per_frame": round(st["stereo"] / max(1, st["frames"]), 1),
+               "bf_pairs_per_frame": round(st["bf_pairs"] / max(1, st["frames"] - S), 1),
+               "pose_inliers_per_frame": round(st["inliers"] / max(1, st["frames"] - S), 1),
+               "image_bytes_per_step": int(2 * S * W * H), "trajectory_block_bytes": int(block.numel() * 8), "trajectories": per_rank,
+               "roofline": None, "cpu_baseline": None}
         print(json.dumps(out), flush=True)
     trk.close()
 
@@ -342,6 +406,9 @@ def main():
                     help="batch = the headline throughput benchmark (default); sequence = BASELINE.json config 5: every rank walks its "
                          "own synthetic stereo sequence frame by frame through the host entry points (one step = one frame per rank) "
                          "and the ranks' TUM trajectories are gathered with one all_gather")
+    ap.add_argument("--seqs-per-gpu", type=int, default=1, help="--mode sequence: sequences per GPU.  1 = one sequence through the host "
+                    "entry points, one synchronous call per seam (BASELINE.json config 5 as written); S > 1 = S sequences in lockstep, "
+                    "device resident (frame t of every sequence is one batch)")
     ap.add_argument("--distinct", type=int, default=256, help="distinct synthetic stereo pairs / BA scenes per rank, tiled over the batch / the "
                     "windows (0 = every frame of the batch and every BA window is its own seeded scene; 256 keeps the input generation of the "
                     "default batch at ~10 s)")
@@ -379,6 +446,8 @@ def main():
         frames = synth.stereo_frames([env_rank * args.batch + i for i in range(n_dpairs)], W, H,
                                      texture=0.0 if args.scene == "flat" else None)
         ba_distinct = synth.ba_scenes([synth.SEED + 1000 * env_rank + k for k in range(n_dscenes)])
+    elif args.seqs_per_gpu > 1:  # lockstep sequence mode: S sequences of this rank, generated by forked workers before HIP is touched
+        args.sequences = synth.sequences([env_rank * args.seqs_per_gpu + s for s in range(args.seqs_per_gpu)], args.warmup + args.steps, W, H)
 
     import torch
 

@@ -215,6 +215,16 @@ def sequence_frames(sequence: int, n_frames: int, width: int = 752, height: int 
         yield (np.clip(np.rint(left), 0, 255).astype(np.uint8), np.clip(np.rint(right), 0, 255).astype(np.uint8))
 
 
+def _sequence_job(a):
+    return list(sequence_frames(*a))
+
+
+def sequences(ids, n_frames: int, width: int = 752, height: int = 480, n_rects: int = 400, workers=None):
+    """[list(sequence_frames(i, n_frames, ...)) for i in ids], generated by several processes (one job per sequence)."""
+    jobs = [(int(i), int(n_frames), width, height, n_rects) for i in ids]
+    return _pool_map(_sequence_job, jobs, default_workers() if workers is None else workers)
+
+
 def random_descriptors(n: int, seed: int = SEED):
     rng = np.random.default_rng(seed)
     return rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
