@@ -118,3 +118,17 @@ def test_one_rank_process_group_on_rccl():
         assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
         d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][0])
         assert d["dist"] == {"world_size": 1, "backend": "nccl"} and d["n_gpus"] == 1 and d["value"] > 0
+
+
+def test_lockstep_sequence_mode_line():
+    """`--mode sequence --seqs-per-gpu S`: S sequences per GPU in lockstep (device-resident chain); the line reports S x steps
+    frames per rank and every sequence's recovered motion (the rig moves 0.05 baselines per frame)."""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--mode", "sequence", "--seqs-per-gpu", "4", "--steps", "5",
+                        "--warmup", "1"], capture_output=True, text=True, cwd=str(ROOT), timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert d["config"]["sequences_per_gpu"] == 4 and d["n_gpus"] == 1 and d["steps"] == 5 and d["value"] > 0
+    assert abs(d["value"] - 4 * 5 / (d["ms_per_step"] * 5e-3)) < 0.01 * d["value"]
+    t = d["trajectories"][0]
+    assert t["sequences"] == 4 and t["frames_per_sequence"] == 6 and 0.6 * t["ground_truth_x"] < t["mean_final_x"] < 1.4 * t["ground_truth_x"]
+    assert d["stereo_matches_per_frame"] > 100 and d["pose_inliers_per_frame"] > 30
