@@ -402,6 +402,9 @@ def main():
                          "(1241x376, 2000 features, 7 levels), an extra measured case")
     ap.add_argument("--orb-chains", type=int, default=1, help="launch chains per ORB batch (2 = two half batches on two streams, +3 %%; "
                     "per-kernel timings then overlap)")
+    ap.add_argument("--orb-stagger", type=int, default=0, help="staggered schedule of the extractor: the batch in this many parts, front "
+                    "halves (level passes, FAST) back to back, the back half (distribution, descriptors) of part p on a second stream "
+                    "beside the front half of part p + 1 (0 = off)")
     ap.add_argument("--gba-keyframes", type=int, default=300, help="keyframes of the global-BA leg (0 = skip; single GPU only)")
     ap.add_argument("--pose-frames", type=int, default=256, help="frames per pose-refinement call (0 = skip; single GPU only)")
     ap.add_argument("--track-frames", type=int, default=1024, help="frames of the tracking-matcher leg (device-resident coarse + fine "
@@ -487,6 +490,8 @@ def main():
     cap = ext.configure(W, H, 2 * B)
     if args.orb_chains != 1:
         ext.set_chains(args.orb_chains)
+    if args.orb_stagger:
+        ext.set_stagger(args.orb_stagger)
     # Two streams, two sets of extractor outputs: the post-extraction stage of batch i (rectify, grid, stereo, kNN-2 + filter --
     # small kernels that leave most of the chip idle) runs on stream B beside the extraction of batch i + 1 on stream A.  Batches
     # are independent frames; all K steps are complete inside the timed region (synchronize + barrier).  --no-overlap: one stream.

@@ -209,6 +209,11 @@ SNK_API int snk_orb_set_profiling(snk_orb* o, int enable);
  * 2 chains +3 % frames/s (the tail of one chain's launch overlaps the other chain), 3-4 chains slower;
  * per-kernel durations are no longer additive.  No reference counterpart. */
 SNK_API int snk_orb_set_chains(snk_orb* o, int chains);
+/* Staggered schedule of a batch (>= 2 * parts images): the batch is cut into `parts` (2..16; 0 = off) ranges, the front halves
+ * (pyramid / blur passes, FAST cells -- bound by vector-instruction issue) run back to back on the handle's stream and the back
+ * half of range p (distribution, descriptors -- bound by LDS / cache latency) on a second stream beside the front half of range
+ * p + 1.  Same results; the per-kernel times of snk_orb_stage_times then overlap. */
+SNK_API int snk_orb_set_stagger(snk_orb* o, int parts);
 SNK_API int snk_orb_stage_times(snk_orb* o, float* ms, int* n_calls);
 
 /* Intermediate results of the last call (tests / debugging); no counterpart in the reference — the stages are

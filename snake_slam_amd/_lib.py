@@ -77,6 +77,7 @@ SIGNATURES = {
     "snk_orb_detect_batch_dev": (i32, [vp, vp, i32, C.c_size_t, i32, vp, vp, vp, i32]),
     "snk_orb_set_profiling": (i32, [vp, i32]),
     "snk_orb_set_chains": (i32, [vp, i32]),
+    "snk_orb_set_stagger": (i32, [vp, i32]),
     "snk_orb_stage_times": (i32, [vp, vp, C.POINTER(i32)]),
     "snk_orb_debug_fetch": (i32, [vp, i32, i32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "snk_track_bf_matches_batch_dev": (i32, [vp, vp, vp, vp, i32, i32, vp]),

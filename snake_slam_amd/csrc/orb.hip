@@ -1924,7 +1924,7 @@ struct snk_orb : HandleBase
     int dist_small_cap = 0;
     // optional per-stage timing with HIP events on the handle's stream (bench.py roofline leg)
     bool profiling = false;
-    std::vector<std::array<hipEvent_t, 6>> ev_sets;  // pyramid | blur | fast | distribute | describe boundaries
+    std::vector<std::array<hipEvent_t, 7>> ev_sets;  // pyramid | blur | fast | distribute | describe boundaries; [6] = start of the back half (staggered schedule)
     size_t ev_used = 0;
     // second stream: a batch is split in two halves whose launch chains overlap (the tail of one half's
     // launch runs beside the other half's kernels; latency-bound and VALU-bound stages share the CUs)
@@ -1934,6 +1934,12 @@ struct snk_orb : HandleBase
     hipEvent_t ev_fork = nullptr, ev_join_n[MAX_PARTS - 1] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_join = nullptr;
     int split_min_batch = 8, parts = 1;  // launch chains per batch: 1 by default, snk_orb_set_chains / SNK_ORB_PARTS
+    // staggered schedule (snk_orb_set_stagger / SNK_ORB_STAGGER): the batch is cut into `stagger` parts, the front halves run one
+    // after the other on the handle's stream and every part's back half on the second stream as soon as its front half is done
+    static constexpr int MAX_STAGGER = 16;
+    int stagger = 0;
+    hipEvent_t ev_front[MAX_STAGGER] = {};
+    size_t part_ev[MAX_STAGGER]      = {};  // event set of each part of the current call (profiling)
 };
 
 static int compute_layout(snk_orb* o, int w, int h)
@@ -2105,6 +2111,11 @@ int snk_orb_create(const snk_orb_params* params, int device, void* stream, snk_o
             const int v = atoi(e);
             o->parts    = v < 1 ? 1 : (v > snk_orb::MAX_PARTS ? snk_orb::MAX_PARTS : v);
         }
+        if (const char* e = getenv("SNK_ORB_STAGGER"))
+        {
+            const int v = atoi(e);
+            o->stagger  = ok && v >= 2 ? (v > snk_orb::MAX_STAGGER ? snk_orb::MAX_STAGGER : v) : 0;
+        }
     }
     *out = o;
     return SNK_OK;
@@ -2132,6 +2143,8 @@ int snk_orb_destroy(snk_orb* o)
     for (auto& e : o->ev_sets)
         for (auto& x : e) (void)hipEventDestroy(x);
     if (o->ev_fork) (void)hipEventDestroy(o->ev_fork);
+    for (auto& e : o->ev_front)
+        if (e) (void)hipEventDestroy(e);
     for (auto& e : o->ev_join_n)
         if (e) (void)hipEventDestroy(e);
     for (auto& st : o->extra)
@@ -2287,8 +2300,9 @@ int snk_orb_max_keypoints(const snk_orb* o, int* out)
 
 // One launch chain over images [b0, b0 + batch) of a call on stream `st`: every per-image buffer is indexed
 // relative to the chain's first image, so the bases are simply advanced by b0 images.
+// stages: 1 = the front half (pyramid / blur passes + FAST cells), 2 = the back half (distribution + descriptors), 3 = both
 static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* images_dev, int pitch, long long image_stride,
-                    int batch, snk_keypoint* kps_dev, uint64_t* desc_dev, int32_t* n_dev, int out_cap)
+                    int batch, snk_keypoint* kps_dev, uint64_t* desc_dev, int32_t* n_dev, int out_cap, int stages = 3)
 {
     Layout L = o->lay;
     for (int l = 0; l < L.n_levels; ++l)
@@ -2307,18 +2321,24 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
     int* d_selcnt   = o->sel_cnt.as<int>() + (size_t)b0 * MAX_LEVELS;
     int* d_candtot  = o->cand_total.as<int>() + (size_t)b0 * MAX_LEVELS;
     int* d_queue    = o->dist_queue.as<int>() + (size_t)part * ((size_t)o->max_batch * MAX_LEVELS + 1);
-    std::array<hipEvent_t, 6>* ev = nullptr;
+    std::array<hipEvent_t, 7>* ev = nullptr;
     if (o->profiling)
     {
-        if (o->ev_used == o->ev_sets.size())
+        if (stages & 1)
         {
-            std::array<hipEvent_t, 6> e{};
-            for (auto& x : e) SNK_HIP_CHECK(hipEventCreate(&x));
-            o->ev_sets.push_back(e);
+            if (o->ev_used == o->ev_sets.size())
+            {
+                std::array<hipEvent_t, 7> e{};
+                for (auto& x : e) SNK_HIP_CHECK(hipEventCreate(&x));
+                o->ev_sets.push_back(e);
+            }
+            o->part_ev[part] = o->ev_used++;
         }
-        ev = &o->ev_sets[o->ev_used++];
-        SNK_HIP_CHECK(hipEventRecord((*ev)[0], st));
+        ev = &o->ev_sets[o->part_ev[part]];
+        if (stages & 1) SNK_HIP_CHECK(hipEventRecord((*ev)[0], st));
     }
+    if (stages & 1)
+    {
     // one streaming pass per level: blur of level l + down-scale to level l+1 (the chain makes the
     // passes sequential; every level is read once)
     const int aligned0 = (reinterpret_cast<uintptr_t>(images_dev) % 4 == 0 && pitch % 4 == 0 && image_stride % 4 == 0) ? 1 : 0;
@@ -2363,6 +2383,11 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
         SNK_LAUNCH_CHECK();
     }
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[3], st));
+    }
+    if (!(stages & 2)) return SNK_OK;
+    if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[6], st));
+    {
+    const int aligned0 = (reinterpret_cast<uintptr_t>(images_dev) % 4 == 0 && pitch % 4 == 0 && image_stride % 4 == 0) ? 1 : 0;
     SNK_HIP_CHECK(hipMemsetAsync(d_queue, 0, sizeof(int), st));
     // SNK_ORB_DIST_TIMING=1 (diagnostic): cycle sums per phase and level, printed after a synchronisation
     static const bool dist_timing = getenv("SNK_ORB_DIST_TIMING") != nullptr;
@@ -2410,6 +2435,7 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
     }
     SNK_LAUNCH_CHECK();
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[5], st));
+    }
     return SNK_OK;
 }
 
@@ -2422,6 +2448,32 @@ static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long i
     static const bool one_stream = getenv("SNK_ORB_ONE_STREAM") != nullptr;
     if (one_stream || o->stream2 == nullptr || batch < o->split_min_batch)
         return run_part(o, o->stream, 0, 0, images_dev, pitch, image_stride, batch, kps_dev, desc_dev, n_dev, out_cap);
+    if (o->stagger >= 2 && batch >= 2 * o->stagger)
+    {
+        // Front halves (VALU-bound: level passes, FAST) back to back on the handle's stream; the back half of part p (latency-bound:
+        // distribution, descriptors) on the second stream beside the front half of part p + 1.  Parts are disjoint image ranges
+        // with their own scratch, the only ordering is front(p) -> back(p).
+        const int P = o->stagger;
+        hipStream_t sf = o->stream, sb = o->extra[0];
+        SNK_HIP_CHECK(hipEventRecord(o->ev_fork, sf));
+        SNK_HIP_CHECK(hipStreamWaitEvent(sb, o->ev_fork, 0));
+        int b0 = 0;
+        for (int p = 0; p < P; ++p)
+        {
+            const int nb = (batch - b0) / (P - p);
+            if (!o->ev_front[p]) SNK_HIP_CHECK(hipEventCreateWithFlags(&o->ev_front[p], hipEventDisableTiming));
+            int rc = run_part(o, sf, p % snk_orb::MAX_PARTS, b0, images_dev, pitch, image_stride, nb, kps_dev, desc_dev, n_dev, out_cap, 1);
+            if (rc != SNK_OK) return rc;
+            SNK_HIP_CHECK(hipEventRecord(o->ev_front[p], sf));
+            SNK_HIP_CHECK(hipStreamWaitEvent(sb, o->ev_front[p], 0));
+            rc = run_part(o, sb, p % snk_orb::MAX_PARTS, b0, images_dev, pitch, image_stride, nb, kps_dev, desc_dev, n_dev, out_cap, 2);
+            if (rc != SNK_OK) return rc;
+            b0 += nb;
+        }
+        SNK_HIP_CHECK(hipEventRecord(o->ev_join_n[0], sb));
+        SNK_HIP_CHECK(hipStreamWaitEvent(o->stream, o->ev_join_n[0], 0));
+        return SNK_OK;
+    }
     const int parts = o->parts < batch ? o->parts : batch;
     if (parts <= 1) return run_part(o, o->stream, 0, 0, images_dev, pitch, image_stride, batch, kps_dev, desc_dev, n_dev, out_cap);
     SNK_HIP_CHECK(hipEventRecord(o->ev_fork, o->stream));
@@ -2530,6 +2582,21 @@ int snk_orb_set_chains(snk_orb* o, int chains)
     return SNK_OK;
 }
 
+int snk_orb_set_stagger(snk_orb* o, int parts)
+{
+    SNK_REQUIRE(o != nullptr, "orb is NULL");
+    SNK_REQUIRE(parts == 0 || (parts >= 2 && parts <= snk_orb::MAX_STAGGER), "parts must be 0 (off) or 2..16");
+    if (parts > 1 && o->stream2 == nullptr)
+    {
+        set_error("the extra streams could not be created");
+        return SNK_ERR_HIP;
+    }
+    SNK_HIP_CHECK(hipSetDevice(o->device));
+    SNK_HIP_CHECK(hipStreamSynchronize(o->stream));
+    o->stagger = parts;
+    return SNK_OK;
+}
+
 int snk_orb_stage_times(snk_orb* o, float* ms /* 5: pyramid, blur, fast, distribute, describe */, int* n_calls)
 {
     SNK_REQUIRE(o != nullptr && ms != nullptr && n_calls != nullptr, "NULL argument");
@@ -2540,7 +2607,8 @@ int snk_orb_stage_times(snk_orb* o, float* ms /* 5: pyramid, blur, fast, distrib
         for (int k = 0; k < 5; ++k)
         {
             float t = 0.0f;
-            SNK_HIP_CHECK(hipEventElapsedTime(&t, o->ev_sets[i][k], o->ev_sets[i][k + 1]));
+            // distribution: from the start of the back half ([6], its own stream in the staggered schedule) to its end
+            SNK_HIP_CHECK(hipEventElapsedTime(&t, o->ev_sets[i][k == 3 ? 6 : k], o->ev_sets[i][k + 1]));
             ms[k] += t;
         }
     *n_calls   = (int)o->ev_used;

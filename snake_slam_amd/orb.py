@@ -91,6 +91,11 @@ class ORBExtractor:
         """Launch chains per detect_batch_dev call (1 = one chain on the handle's stream, 2 = two half batches on two streams)."""
         _lib.check(self._lib.snk_orb_set_chains(self._h, int(chains)), "snk_orb_set_chains")
 
+    def set_stagger(self, parts: int) -> None:
+        """Staggered schedule (0 = off, 2..16 parts): front halves back to back on the handle's stream, the back half of part p on a
+        second stream beside the front half of part p + 1."""
+        _lib.check(self._lib.snk_orb_set_stagger(self._h, int(parts)), "snk_orb_set_stagger")
+
     def stage_times(self):
         """(ms per stage [pyramid, blur, fast, distribute, describe] summed over calls, number of calls)."""
         ms = (C.c_float * 5)()
