@@ -236,6 +236,44 @@ def test_split_batch_two_streams(orc):
     ext.close()
 
 
+def test_staggered_schedule(orc):
+    """snk_orb_set_stagger(3): the batch in three ranges, front halves (level passes, FAST) back to back on the handle's stream, the
+    back half (distribution, descriptors) of range p on a second stream beside the front half of range p + 1 -- every image as if
+    extracted alone, the stage timers count one entry per range, work queued on the caller's stream afterwards sees everything."""
+    import torch
+    from snake_slam_amd import synth
+    from snake_slam_amd.orb import ORBExtractor, KEYPOINT_DTYPE
+
+    B, W, H = 13, 320, 240
+    imgs = [synth.stereo_frame(500 + i, W, H, n_rects=80)[0] for i in range(B)]
+    ext = ORBExtractor(400, 1.2, 4, 20, 7)
+    cap = ext.configure(W, H, B)
+    dev = torch.device("cuda:0")
+    d_img = torch.from_numpy(np.stack(imgs)).to(dev)
+    d_kps = torch.zeros((B, cap, 24), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((B, cap, 4), dtype=torch.int64, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ext.set_stagger(3)
+    ext.set_profiling(True)
+    for _ in range(2):  # twice: the second call reuses the events of the first
+        ext.detect_batch_dev(d_img, d_kps, d_desc, d_n)
+    ms, parts = ext.stage_times()
+    assert parts == 6 and all(m >= 0 for m in ms)
+    ext.set_profiling(False)
+    ext.sync()
+    n = d_n.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(KEYPOINT_DTYPE).reshape(B, cap)
+    desc = d_desc.cpu().numpy().view(np.uint64)
+    p = orc.orb_params(400, 1.2, 4, 20, 7)
+    for i in range(B):
+        wk, wd = orc.orb_detect(p, imgs[i])
+        assert n[i] == len(wk) and n[i] > 100, f"image {i}"
+        assert np.array_equal(kps[i, : n[i]], wk.astype(KEYPOINT_DTYPE)) and np.array_equal(desc[i, : n[i]], wd)
+    ext.set_stagger(0)
+    ext.close()
+
+
 def test_xcd_mapped_batch(orc):
     """Batches of >= 16 images use the XCD-aware 1-D grids (image b on XCD b % 8); 17 is not a multiple of 8,
     so the padded part of the grid must fall out cleanly."""
