@@ -78,7 +78,7 @@ def test_gpus_flag_spawns_its_own_ranks():
     assert d["n_gpus"] == 2 and d["dist"] == {"world_size": 2, "backend": "gloo"} and d["value"] > 0
 
 
-@pytest.mark.parametrize("mode", ["batch", "sequence"])
+@pytest.mark.parametrize("mode", ["batch", "sequence", "lockstep"])
 def test_two_ranks_rehearsal_on_one_gpu(mode):
     """The N > 1 code of bench.py (per-rank data, barriers, max over ranks, result / trajectory gather, rank 0 prints) launched the
     way the driver launches it, with both ranks on cuda:0 and gloo standing in for RCCL (which refuses two ranks on one
@@ -87,7 +87,10 @@ def test_two_ranks_rehearsal_on_one_gpu(mode):
 
     env = dict(os.environ, SNK_DIST_BACKEND="gloo", SNK_BENCH_DEVICE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29577", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--mode", mode]
+           "--master-port", "29577", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--mode",
+           "sequence" if mode == "lockstep" else mode]
+    if mode == "lockstep":
+        cmd += ["--seqs-per-gpu", "3"]
     if mode == "batch":
         cmd += ["--batch", "16", "--ba-windows", "8", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(ROOT), timeout=900, env=env)
@@ -99,6 +102,8 @@ def test_two_ranks_rehearsal_on_one_gpu(mode):
     assert d["dist"] == {"world_size": 2, "backend": "gloo"}
     if mode == "batch":
         assert d["config"]["frames_per_gpu_per_step"] == 16 and d["ba"]["value"] > 0
+    elif mode == "lockstep":
+        assert len(d["trajectories"]) == 2 and all(t["sequences"] == 3 for t in d["trajectories"]) and d["config"]["sequences_per_gpu"] == 3
     else:
         assert len(d["trajectories"]) == 2 if "trajectories" in d else True
 

@@ -177,3 +177,74 @@ def test_device_resident_chain_with_a_small_pose_lds_carve():
                        cwd=str(root), timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-1000:])
     assert "1 passed" in r.stdout
+
+
+def test_lockstep_glue_kernels_against_numpy():
+    """snk_track_bf_matches_batch_dev / snk_track_backproject_batch_dev (the two glue steps of MultiSequenceTracker) on a ragged
+    batch -- an empty frame, a frame without pairs, pairs whose reference feature has no point, out-of-range indices -- against
+    plain numpy.  Integer work exact; the world points to 1e-12 (three multiply-adds per coordinate)."""
+    import ctypes as C
+
+    import torch
+
+    from snake_slam_amd import _lib, synth
+    from snake_slam_amd.matcher import KP64_DTYPE
+    from snake_slam_amd.tracking import Camera, PoseRefinement, frames_dev
+
+    rng = np.random.default_rng(SEED + 321) if "SEED" in globals() else np.random.default_rng(321)
+    B, cap = 5, 300
+    dev = torch.device("cuda:0")
+    n = np.array([250, 0, 300, 17, 120], np.int32)
+    n_pairs = np.array([100, 0, 0, 17, 300], np.int32)
+    pairs = rng.integers(0, cap, (B, cap, 2)).astype(np.int32)
+    for b in range(B):  # distinct queries per frame (one pair per query at most, as filterMatches produces them)
+        pairs[b, :, 0] = rng.permutation(cap)
+    pairs[0, 3] = (-1, 5)
+    pairs[0, 4] = (7, cap + 3)
+    has = (rng.random((B, cap)) < 0.6).astype(np.uint8)
+    ref = PoseRefinement(device=0)
+    lib = _lib.load()
+    d_pairs, d_np, d_has = torch.from_numpy(pairs).to(dev), torch.from_numpy(n_pairs).to(dev), torch.from_numpy(has).to(dev)
+    d_mi = torch.full((B, cap), 7, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    _lib.check(lib.snk_track_bf_matches_batch_dev(ref._h, d_pairs.data_ptr(), d_np.data_ptr(), d_has.data_ptr(), cap, B, d_mi.data_ptr()), "bf_matches")
+    ref.sync()
+    want = np.full((B, cap), -1, np.int32)
+    for b in range(B):
+        for q, t in pairs[b, : n_pairs[b]]:
+            if 0 <= q < cap and 0 <= t < cap and has[b, q]:
+                want[b, q] = t
+    assert np.array_equal(d_mi.cpu().numpy(), want) and (want >= 0).sum() > 100
+
+    kps = np.zeros((B, cap), KP64_DTYPE)
+    kps["x"], kps["y"] = rng.uniform(0, 752, (B, cap)), rng.uniform(0, 480, (B, cap))
+    depth = np.where(rng.random((B, cap)) < 0.5, rng.uniform(0.5, 30.0, (B, cap)), -1000.0).astype(np.float32)
+    poses = np.zeros((B, 7))
+    for b in range(B):
+        q = rng.normal(size=4)
+        poses[b, :4] = q / np.linalg.norm(q)
+        poses[b, 4:] = rng.normal(size=3)
+    cam = (458.654, 457.296, 367.215, 248.375, 119.75)
+    d_kps = torch.from_numpy(kps.view(np.uint8).reshape(B, cap, 24)).to(dev)
+    d_n, d_depth, d_poses = torch.from_numpy(n).to(dev), torch.from_numpy(depth).to(dev), torch.from_numpy(poses).to(dev)
+    d_desc = torch.zeros((B, cap, 4), dtype=torch.int64, device=dev)
+    d_rp, d_tk = torch.zeros((B, cap), dtype=torch.float32, device=dev), torch.zeros((B, cap), dtype=torch.uint8, device=dev)
+    d_cs = torch.zeros((B, 38 * 24 + 1), dtype=torch.int32, device=dev)
+    fd = frames_dev((0.0, 0.0, 752.0, 480.0), d_n, d_kps, d_desc, d_rp, d_tk, d_cs)
+    d_world = torch.full((B, cap, 3), 9.0, dtype=torch.float64, device=dev)
+    d_h = torch.full((B, cap), 9, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    c = Camera(*cam)
+    _lib.check(lib.snk_track_backproject_batch_dev(ref._h, C.byref(fd), d_depth.data_ptr(), C.byref(c), d_poses.data_ptr(), d_world.data_ptr(),
+                                                   d_h.data_ptr()), "backproject")
+    ref.sync()
+    got_w, got_h = d_world.cpu().numpy(), d_h.cpu().numpy()
+    for b in range(B):
+        m = int(n[b])
+        hb = depth[b, :m] > 0
+        z = np.where(hb, depth[b, :m], 1.0).astype(np.float64)
+        pc = np.stack([(kps["x"][b, :m] - cam[2]) / cam[0] * z, (kps["y"][b, :m] - cam[3]) / cam[1] * z, z], 1)
+        w = (pc - poses[b, 4:]) @ synth.quat_to_R(poses[b, :4])
+        assert np.array_equal(got_h[b, :m], hb.astype(np.uint8)) and np.allclose(got_w[b, :m], w, rtol=0, atol=1e-12)
+        assert not got_h[b, m:].any() and not got_w[b, m:].any()   # beyond the frame's features: no point
+    ref.close()
