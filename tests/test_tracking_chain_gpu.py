@@ -191,7 +191,7 @@ def test_lockstep_glue_kernels_against_numpy():
     from snake_slam_amd.matcher import KP64_DTYPE
     from snake_slam_amd.tracking import Camera, PoseRefinement, frames_dev
 
-    rng = np.random.default_rng(SEED + 321) if "SEED" in globals() else np.random.default_rng(321)
+    rng = np.random.default_rng(SEED + 321)
     B, cap = 5, 300
     dev = torch.device("cuda:0")
     n = np.array([250, 0, 300, 17, 120], np.int32)
