@@ -42,6 +42,10 @@ constexpr int CELL_W         = 30;
 constexpr int CELL_SLOTS     = 64;   // strongest candidates kept per cell
 constexpr int KEY_DIGITS     = 16;
 constexpr int DEFAULT_LEVEL_CAP = 8192;
+#ifndef SNK_FAST_MIN_WAVES
+#define SNK_FAST_MIN_WAVES 1  // build-time A/B: wavefronts per SIMD the register allocator must leave room for in fast_kernel
+#endif
+constexpr int FAST_CPW_DEFAULT  = 1;     // FAST cells per wavefront (SNK_ORB_FAST_CPW; measured in DESIGN.md section 5)
 
 constexpr signed char k_pattern[1024] = {
 #include "brief_pattern_31.inc"
@@ -418,17 +422,25 @@ static inline dim3 xcd_grid(int gx, int batch) { return batch >= 16 ? dim3(8 * g
 // image tile | score map with zero ring | quick-test survivors | NMS survivors | 3 counters.
 // NQ = 3 / 4: compile-time tile row pitch of 48 / 64 bytes and score-map pitch of 40 / 64 (what the layout picks
 // for cells up to 36 / 52 pixels wide): row addressing by shifts and the quad loader; NQ = 0: pitches from the layout.
-template <int NQ>
-__global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restrict__ img0, int pitch0, long long stride0,
+template <int NQ, bool LOOP>
+__global__ __launch_bounds__(256, SNK_FAST_MIN_WAVES) void fast_kernel(Layout L, const u8* __restrict__ img0, int pitch0, long long stride0,
                                                    int aligned0, int ini_th, int min_th, u32* __restrict__ cand,
-                                                   u16* __restrict__ cell_cnt, int gx, int batch, int dbg_stop)
+                                                   u16* __restrict__ cell_cnt, int gx, int batch, int dbg_stop, int cpw)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int b, bxi;
     if (!xcd_image_map(gx, batch, b, bxi)) return;
-    const int cid  = bxi * 4 + wave;
-    if (cid >= L.total_cells) return;  // whole wavefront
+    // cpw cells per wavefront, one after the other (cells bxi * 4 * cpw + wave + 4 k): a cell is ~7 us of work, and with one cell per
+    // wavefront the workgroup turnover (launch, teardown) left 6.2 of the 8 wavefront slots of a SIMD filled on average
+    // (PMC r03g: wave cycles / busy cycles); longer-lived workgroups keep the slots occupied.  Nothing is carried from cell to cell.
+    // LOOP = false: the one-cell form without the loop (53 registers, 8 wavefronts per SIMD; the loop form keeps more values live:
+    // 71 registers, 7 wavefronts)
+    for (int kc = 0; kc < (LOOP ? cpw : 1); ++kc)
+    {
+    const int cid  = LOOP ? (bxi * cpw + kc) * 4 + wave : bxi * 4 + wave;
+    if (cid >= L.total_cells) return;  // whole wavefront (cells ascend with kc)
+    __builtin_amdgcn_wave_barrier();   // the previous cell's LDS reads are done (one wavefront: program order)
     unsigned char* slice = fsm + wave * L.f_lds_wave;
     u32* tile_dw      = reinterpret_cast<u32*>(slice);
     u8* S             = slice + L.f_off_s;
@@ -445,6 +457,7 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
     if (cw <= 0 || ch <= 0)
     {
         if (lane == 0) cell_cnt[cell_index] = 0;
+        if (LOOP) continue;
         return;
     }
     const u8* src      = l == 0 ? img0 + (long long)b * stride0 : lv.base + (long long)b * lv.img_stride;
@@ -685,17 +698,21 @@ __global__ __launch_bounds__(256) void fast_kernel(Layout L, const u8* __restric
         if (r < CELL_SLOTS) out[r] = k;
     }
     if (lane == 0) cell_cnt[cell_index] = (u16)(n > 65535 ? 65535 : n);
+    }
 }
 
 static inline int fast_quads(const Layout& L)
 {
     return L.f_tile_pitch_dw == 12 && L.f_s_pitch == 40 ? 3 : (L.f_tile_pitch_dw == 16 && L.f_s_pitch == 64 ? 4 : 0);
 }
-static inline const void* fast_kernel_for(const Layout& L)
+static inline const void* fast_kernel_for(const Layout& L, bool loop)
 {
     const int fq = fast_quads(L);
-    return fq == 3 ? reinterpret_cast<const void*>(fast_kernel<3>)
-                   : (fq == 4 ? reinterpret_cast<const void*>(fast_kernel<4>) : reinterpret_cast<const void*>(fast_kernel<0>));
+    if (loop)
+        return fq == 3 ? reinterpret_cast<const void*>(fast_kernel<3, true>)
+                       : (fq == 4 ? reinterpret_cast<const void*>(fast_kernel<4, true>) : reinterpret_cast<const void*>(fast_kernel<0, true>));
+    return fq == 3 ? reinterpret_cast<const void*>(fast_kernel<3, false>)
+                   : (fq == 4 ? reinterpret_cast<const void*>(fast_kernel<4, false>) : reinterpret_cast<const void*>(fast_kernel<0, false>));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2269,7 +2286,8 @@ int snk_orb_configure(snk_orb* o, int width, int height, int max_batch)
     SNK_REQUIRE(4 * L.f_lds_wave <= LDS_MAX_BYTES, "FAST cells too large for the LDS (image too small for its cell grid?)");
     if ((rc = set_max_lds_once(reinterpret_cast<const void*>(distribute_kernel), (int)dist_lds_bytes(2048))) != SNK_OK) return rc;
     if ((rc = set_max_lds_once(reinterpret_cast<const void*>(distribute_large_kernel), (int)dist_lds_bytes(8192))) != SNK_OK) return rc;
-    if ((rc = set_max_lds_once(fast_kernel_for(L), LDS_MAX_BYTES)) != SNK_OK) return rc;
+    if ((rc = set_max_lds_once(fast_kernel_for(L, false), LDS_MAX_BYTES)) != SNK_OK) return rc;
+    if ((rc = set_max_lds_once(fast_kernel_for(L, true), LDS_MAX_BYTES)) != SNK_OK) return rc;
     // host-API staging (snk_orb_detect): sized here so that the per-image call allocates nothing
     {
         const int dpitch = (width + 63) & ~63;
@@ -2374,12 +2392,19 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[2], st));
     if (L.total_cells > 0)
     {
-        const int gx = ceil_div(L.total_cells, 4);
+        // cells per wavefront: 1 for small launches (keep the chip filled), more once there are plenty of workgroups
+        static const int cpw_env = getenv("SNK_ORB_FAST_CPW") ? atoi(getenv("SNK_ORB_FAST_CPW")) : 0;
+        const long long cell_waves = (long long)L.total_cells * batch;
+        int cpw = cpw_env >= 1 && cpw_env <= 64 ? cpw_env : FAST_CPW_DEFAULT;
+        while (cpw > 1 && cell_waves / cpw < 256 * 32 * 4) cpw >>= 1;  // at least four rounds of the chip's 8192 wavefront slots
+        const int gx = ceil_div(L.total_cells, 4 * cpw);
         const int fq = fast_quads(L);
         static const int fast_stop = getenv("SNK_ORB_FAST_STOP") ? atoi(getenv("SNK_ORB_FAST_STOP")) : 0;  // timing experiments
-        auto fk      = fq == 3 ? fast_kernel<3> : (fq == 4 ? fast_kernel<4> : fast_kernel<0>);
+        auto fk      = cpw > 1 ? (fq == 3 ? fast_kernel<3, true> : (fq == 4 ? fast_kernel<4, true> : fast_kernel<0, true>))
+                               : (fq == 3 ? fast_kernel<3, false> : (fq == 4 ? fast_kernel<4, false> : fast_kernel<0, false>));
         hipLaunchKernelGGL(fk, xcd_grid(gx, batch), dim3(256), (size_t)4 * L.f_lds_wave, st, L, images_dev, pitch,
-                           image_stride, aligned0, o->params.ini_th_fast, o->params.min_th_fast, d_cand, d_cellcnt, gx, batch, fast_stop);
+                           image_stride, aligned0, o->params.ini_th_fast, o->params.min_th_fast, d_cand, d_cellcnt, gx, batch, fast_stop,
+                           cpw);
         SNK_LAUNCH_CHECK();
     }
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[3], st));
