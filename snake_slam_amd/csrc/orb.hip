@@ -45,7 +45,7 @@ constexpr int DEFAULT_LEVEL_CAP = 8192;
 #ifndef SNK_FAST_MIN_WAVES
 #define SNK_FAST_MIN_WAVES 1  // build-time A/B: wavefronts per SIMD the register allocator must leave room for in fast_kernel
 #endif
-constexpr int FAST_CPW_DEFAULT  = 1;     // FAST cells per wavefront (SNK_ORB_FAST_CPW; measured in DESIGN.md section 5)
+constexpr int FAST_CPW_DEFAULT  = 8;     // FAST cells per wavefront for big launches (SNK_ORB_FAST_CPW; measured in DESIGN.md section 5)
 
 constexpr signed char k_pattern[1024] = {
 #include "brief_pattern_31.inc"
