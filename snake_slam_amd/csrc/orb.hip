@@ -42,6 +42,9 @@ constexpr int CELL_W         = 30;
 constexpr int CELL_SLOTS     = 64;   // strongest candidates kept per cell
 constexpr int KEY_DIGITS     = 16;
 constexpr int DEFAULT_LEVEL_CAP = 8192;
+#ifndef SNK_DIST_MIN_WAVES
+#define SNK_DIST_MIN_WAVES 1  // build-time A/B: 8 = distribute_kernel must fit four 512-thread workgroups per CU (<= 64 VGPRs, <= 80 SGPRs)
+#endif
 #ifndef SNK_FAST_MIN_WAVES
 #define SNK_FAST_MIN_WAVES 1  // build-time A/B: wavefronts per SIMD the register allocator must leave room for in fast_kernel
 #endif
@@ -1571,7 +1574,7 @@ __device__ bool distribute_body(const Layout& L, int b, int l, int lds_cap, cons
 }
 
 // small-LDS launch over every (level, image); levels that do not fit are queued
-__global__ __launch_bounds__(DIST_THREADS) void distribute_kernel(Layout L, int lds_cap, const u32* __restrict__ cand,
+__global__ __launch_bounds__(DIST_THREADS, SNK_DIST_MIN_WAVES) void distribute_kernel(Layout L, int lds_cap, const u32* __restrict__ cand,
                                                                   const u16* __restrict__ cell_cnt, u32* __restrict__ sel,
                                                                   u8* __restrict__ sel_score, int* __restrict__ sel_cnt,
                                                                   int* __restrict__ cand_total, int* __restrict__ queue,
