@@ -242,7 +242,7 @@ def sequence_mode(args, rank, world, local, dev):
     from snake_slam_amd.sequence import SequenceTracker, trajectory_block, trajectory_rows
 
     n_frames = args.warmup + args.steps
-    if args.seqs_per_gpu > 1:
+    if not args.host_api:
         return lockstep_sequence_mode(args, rank, world, local, dev, n_frames)
     frames = list(synth.sequence_frames(rank, n_frames, W, H))
     trk = SequenceTracker(TRACK_CAM, orb=ORB, device=local, width=W, height=H)
@@ -413,9 +413,11 @@ def main():
                     help="batch = the headline throughput benchmark (default); sequence = BASELINE.json config 5: every rank walks its "
                          "own synthetic stereo sequence frame by frame through the host entry points (one step = one frame per rank) "
                          "and the ranks' TUM trajectories are gathered with one all_gather")
-    ap.add_argument("--seqs-per-gpu", type=int, default=1, help="--mode sequence: sequences per GPU.  1 = one sequence through the host "
-                    "entry points, one synchronous call per seam (BASELINE.json config 5 as written); S > 1 = S sequences in lockstep, "
-                    "device resident (frame t of every sequence is one batch)")
+    ap.add_argument("--seqs-per-gpu", type=int, default=1, help="--mode sequence: sequences per GPU (1 = BASELINE.json config 5 as written: "
+                    "one sequence per GPU); S sequences run in lockstep, frame t of every sequence is one batch of the device-resident chain")
+    ap.add_argument("--host-api", action="store_true", help="--mode sequence: ONE sequence per GPU through the host entry points, one "
+                    "synchronous call per seam in the order the reference's threads make them (the round-2 form of the mode, ~800 frames/s); "
+                    "default: the device-resident chain (snake_slam_amd.sequence.MultiSequenceTracker)")
     ap.add_argument("--distinct", type=int, default=256, help="distinct synthetic stereo pairs / BA scenes per rank, tiled over the batch / the "
                     "windows (0 = every frame of the batch and every BA window is its own seeded scene; 256 keeps the input generation of the "
                     "default batch at ~10 s)")
@@ -453,7 +455,7 @@ def main():
         frames = synth.stereo_frames([env_rank * args.batch + i for i in range(n_dpairs)], W, H,
                                      texture=0.0 if args.scene == "flat" else None)
         ba_distinct = synth.ba_scenes([synth.SEED + 1000 * env_rank + k for k in range(n_dscenes)])
-    elif args.seqs_per_gpu > 1:  # lockstep sequence mode: S sequences of this rank, generated by forked workers before HIP is touched
+    elif not args.host_api:  # device-resident sequence mode: S sequences of this rank, generated by forked workers before HIP is touched
         args.sequences = synth.sequences([env_rank * args.seqs_per_gpu + s for s in range(args.seqs_per_gpu)], args.warmup + args.steps, W, H)
 
     import torch

@@ -91,6 +91,8 @@ def test_two_ranks_rehearsal_on_one_gpu(mode):
            "sequence" if mode == "lockstep" else mode]
     if mode == "lockstep":
         cmd += ["--seqs-per-gpu", "3"]
+    if mode == "sequence":
+        cmd += ["--host-api"]
     if mode == "batch":
         cmd += ["--batch", "16", "--ba-windows", "8", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(ROOT), timeout=900, env=env)
@@ -117,7 +119,7 @@ def test_one_rank_process_group_on_rccl():
 
     env = {k: v for k, v in os.environ.items() if k not in ("SNK_DIST_BACKEND", "SNK_BENCH_DEVICE")}
     env.update(SNK_DIST_FORCE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29578")
-    for extra in (["--batch", "16", "--ba-windows", "8", "--track-frames", "0"], ["--mode", "sequence"]):
+    for extra in (["--batch", "16", "--ba-windows", "8", "--track-frames", "0"], ["--mode", "sequence"], ["--mode", "sequence", "--host-api"]):
         r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                             "--gba-keyframes", "0", "--pose-frames", "0"] + extra, capture_output=True, text=True, cwd=str(ROOT), timeout=900, env=env)
         assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
