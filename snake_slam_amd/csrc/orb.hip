@@ -2398,8 +2398,9 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
         // cells per wavefront: 1 for small launches (keep the chip filled), more once there are plenty of workgroups
         static const int cpw_env = getenv("SNK_ORB_FAST_CPW") ? atoi(getenv("SNK_ORB_FAST_CPW")) : 0;
         const long long cell_waves = (long long)L.total_cells * batch;
-        int cpw = cpw_env >= 1 && cpw_env <= 64 ? cpw_env : FAST_CPW_DEFAULT;
+        int cpw = FAST_CPW_DEFAULT;
         while (cpw > 1 && cell_waves / cpw < 256 * 32 * 4) cpw >>= 1;  // at least four rounds of the chip's 8192 wavefront slots
+        if (cpw_env >= 1 && cpw_env <= 64) cpw = cpw_env;               // forced (tests, measurements): whatever the launch size
         const int gx = ceil_div(L.total_cells, 4 * cpw);
         const int fq = fast_quads(L);
         static const int fast_stop = getenv("SNK_ORB_FAST_STOP") ? atoi(getenv("SNK_ORB_FAST_STOP")) : 0;  // timing experiments

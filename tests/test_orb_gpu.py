@@ -388,6 +388,24 @@ def test_fast_survivor_list_spill_path_on_ordinary_images():
     assert " passed" in r.stdout
 
 
+@pytest.mark.skipif(__import__("os").environ.get("SNK_ORB_NO_RECURSE") == "1", reason="child run")
+def test_fast_kernel_loop_form_on_ordinary_images():
+    """Big launches run fast_kernel with several cells per wavefront (the loop form); the parity file runs again
+    in a child process with THREE cells per wavefront forced for every launch size (SNK_ORB_FAST_CPW; 3 does not divide the cell
+    counts, so the last wavefronts of an image run out of cells mid-loop)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, "-m", "pytest", str(root / "tests" / "test_orb_gpu.py"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "not budget_is_inactive"],
+                       env=dict(os.environ, SNK_ORB_FAST_CPW="3", SNK_ORB_NO_RECURSE="1"), capture_output=True, text=True, cwd=str(root), timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-1000:])
+    assert " passed" in r.stdout
+
+
 def test_levels_scaled_down_to_nothing(orc):
     """Small images with many levels and a large scale factor: deep levels round to zero width and / or height (found by
     tools/fuzz_orb.py: a zero grid dimension in one case, an integer division by the zero strip count in another).  Such levels
