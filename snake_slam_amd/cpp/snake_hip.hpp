@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -668,6 +669,61 @@ inline void ReadFeatures(const std::string& file, std::vector<KeyPointD>& keypoi
     descriptors.resize(nd);
     if (nd && std::fread(descriptors.data(), 32, nd, f) != nd) fail("truncated descriptors");
     std::fclose(f);
+}
+
+// A file of unknown provenance (a real Snake-SLAM build: saiga's BinaryFile layout is not known here): tries the plausible
+// layouts -- 64 / 32-bit counts; KeyPoint<double> of 48 bytes, packed 44, KeyPoint<float> of 24 -- and keeps the first one
+// that accounts for every byte of the file (same probing as snake_slam_amd/features_io.py::probe_layout).  Returns the layout
+// as "count bytes / keypoint bytes", e.g. "8/48".
+inline std::string ReadFeaturesAny(const std::string& file, std::vector<KeyPointD>& keypoints, std::vector<DescriptorORB>& descriptors)
+{
+    FILE* f = std::fopen(file.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + file);
+    std::vector<unsigned char> buf;
+    unsigned char tmp[65536];
+    size_t got;
+    while ((got = std::fread(tmp, 1, sizeof(tmp), f)) > 0) buf.insert(buf.end(), tmp, tmp + got);
+    std::fclose(f);
+    auto rd = [&](size_t off, int bytes) {
+        uint64_t v = 0;
+        for (int i = 0; i < bytes; ++i) v |= (uint64_t)buf[off + (size_t)i] << (8 * i);
+        return v;
+    };
+    for (int cw : {8, 4})
+        for (int ks : {48, 44, 24})
+        {
+            if (buf.size() < 2 * (size_t)cw) continue;
+            const uint64_t nk = rd(0, cw);
+            const size_t off  = (size_t)cw + (size_t)nk * (size_t)ks;
+            if (nk > (1u << 24) || off + (size_t)cw > buf.size()) continue;
+            const uint64_t nd = rd(off, cw);
+            if (nd != nk || off + (size_t)cw + (size_t)nd * 32 != buf.size()) continue;
+            keypoints.resize(nk);
+            descriptors.resize(nd);
+            for (uint64_t i = 0; i < nk; ++i)
+            {
+                const unsigned char* p = buf.data() + cw + i * (size_t)ks;
+                KeyPointD k{};
+                if (ks == 24)
+                {
+                    float v[5];
+                    std::memcpy(v, p, 20);
+                    std::memcpy(&k.octave, p + 20, 4);
+                    k.x = v[0], k.y = v[1], k.size = v[2], k.angle = v[3], k.response = v[4];
+                }
+                else
+                {
+                    double v[5];
+                    std::memcpy(v, p, 40);
+                    std::memcpy(&k.octave, p + 40, 4);
+                    k.x = v[0], k.y = v[1], k.size = v[2], k.angle = v[3], k.response = v[4];
+                }
+                keypoints[i] = k;
+            }
+            if (nd) std::memcpy(descriptors.data(), buf.data() + off + cw, (size_t)nd * 32);
+            return std::to_string(cw) + "/" + std::to_string(ks);
+        }
+    throw std::runtime_error("no known layout accounts for the size of " + file);
 }
 
 // frame.keypoints.emplace_back(kp.cast<double>()) — FeatureDetector.cpp:128-131

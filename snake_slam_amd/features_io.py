@@ -44,6 +44,46 @@ def write_features(path: str, keypoints, descriptors) -> None:
         f.write(d.tobytes())
 
 
+# The layouts a `BinaryFile << vector<KeyPoint<T>> << vector<DescriptorORB>` could plausibly have (saiga is absent, so the one
+# written by `write_features` is an assumption): 64- or 32-bit element counts; KeyPoint<double> padded to 48 bytes, packed to
+# 44, or KeyPoint<float> (24).  `probe_layout` keeps the first variant that accounts for every byte of a file.
+KEYPOINT_LAYOUTS = {
+    "f64x5+i32+pad (48 B)": KEYPOINT_D_DTYPE,
+    "f64x5+i32 packed (44 B)": np.dtype([("x", "<f8"), ("y", "<f8"), ("size", "<f8"), ("angle", "<f8"), ("response", "<f8"), ("octave", "<i4")]),
+    "f32x5+i32 (24 B)": np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4")]),
+}
+
+
+def probe_layout(buf: bytes):
+    """-> (layout name, count width in bytes, keypoints, descriptors [n, 4] uint64) for the first known layout with
+    [count][nk keypoints][count][nd descriptors of 32 bytes], nk == nd, that accounts for every byte; ValueError otherwise."""
+    buf = bytes(buf)
+    for cw in (8, 4):
+        if len(buf) < 2 * cw:
+            continue
+        nk = int.from_bytes(buf[:cw], "little")
+        for name, dt in KEYPOINT_LAYOUTS.items():
+            off = cw + nk * dt.itemsize
+            if nk > MAX_COUNT or off + cw > len(buf):
+                continue
+            nd = int.from_bytes(buf[off:off + cw], "little")
+            if nd == nk and off + cw + nd * 32 == len(buf):
+                kps = np.frombuffer(buf, dt, nk, cw).copy()
+                desc = np.frombuffer(buf, "<u8", nd * 4, off + cw).reshape(-1, 4).copy()
+                return name, cw, kps, desc
+    raise ValueError("no known layout accounts for the file's size")
+
+
+def read_features_any(path: str):
+    """`read_features` for a file of unknown provenance: probes the plausible layouts and returns
+    (keypoints as KEYPOINT_D_DTYPE, descriptors, layout name)."""
+    name, _, k, d = probe_layout(open(path, "rb").read())
+    out = np.zeros(len(k), KEYPOINT_D_DTYPE)
+    for f in ("x", "y", "size", "angle", "response", "octave"):
+        out[f] = k[f]
+    return out, d, name
+
+
 def read_features(path: str):
     """Returns (keypoints [n] KEYPOINT_D_DTYPE, descriptors [m, 4] uint64).  Raises ValueError on a
     truncated or implausible file (the reference would read garbage)."""

@@ -65,9 +65,15 @@ int main(int argc, char** argv) {
     snake_hip::ReadFeatures(argv[1], k, d);          // written by the Python mirror
     for (auto& kp : k) kp.response += 1.0;           // touch the data, write it back
     snake_hip::WriteFeatures(argv[2], k, d);
-    try { snake_hip::ReadFeatures(argv[3], k, d); return 2; } catch (const std::runtime_error&) {}
+    // layouts of unknown provenance: the packed 44-byte / 32-bit-count variant written by the test, and the default one
+    std::vector<snake_hip::KeyPointD> k2; std::vector<snake_hip::DescriptorORB> d2;
+    if (snake_hip::ReadFeaturesAny(argv[4], k2, d2) != "4/44" || k2.size() != k.size() || d2 != d) return 3;
+    for (size_t i = 0; i < k.size(); ++i) if (k2[i].x != k[i].x || k2[i].response + 1.0 != k[i].response || k2[i].octave != k[i].octave) return 4;
+    if (snake_hip::ReadFeaturesAny(argv[1], k2, d2) != "8/48" || d2 != d) return 5;
+    try { snake_hip::ReadFeaturesAny(argv[3], k2, d2); return 6; } catch (const std::runtime_error&) {}
+    try { snake_hip::ReadFeatures(argv[3], k, d); return 2; } catch (const std::runtime_error&) {}  // (clobbers k / d: last)
     snk_keypoint f{1.5f, 2.5f, 31.f, 90.f, 20.f, 2};
-    return snake_hip::cast_double(f).octave == 2 && argc == 4 ? 0 : 1;
+    return snake_hip::cast_double(f).octave == 2 && argc == 5 ? 0 : 1;
 }
 """
 
@@ -85,8 +91,15 @@ def test_cpp_adaptor_reads_and_writes_the_same_bytes(tmp_path):
            f"-L{lib}", "-lsnake_hip", "-L/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    r = subprocess.run([exe, a, b, bad], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
+    packed = str(tmp_path / "packed.features")  # 32-bit counts, KeyPoint<double> packed to 44 bytes
+    kk = np.zeros(len(k), FIO.KEYPOINT_LAYOUTS["f64x5+i32 packed (44 B)"])
+    for f in ("x", "y", "size", "angle", "response", "octave"):
+        kk[f] = k[f]
+    Path(packed).write_bytes(np.uint32(len(k)).tobytes() + kk.tobytes() + np.uint32(len(d)).tobytes() + np.ascontiguousarray(d).tobytes())
+    k3, d3, name = FIO.read_features_any(packed)
+    assert name.startswith("f64x5+i32 packed") and np.array_equal(k3, k) and np.array_equal(d3, d)
+    r = subprocess.run([exe, a, b, bad, packed], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stderr)
     k2, d2 = FIO.read_features(b)
     k["response"] += 1.0
     assert np.array_equal(k2, k) and np.array_equal(d2, d)

@@ -35,31 +35,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-KP_LAYOUTS = {
-    # name: (item size, dtype)
-    "f64x5+i32+pad (48 B)": np.dtype([("x", "<f8"), ("y", "<f8"), ("size", "<f8"), ("angle", "<f8"), ("response", "<f8"), ("octave", "<i4"), ("pad", "<i4")]),
-    "f64x5+i32 packed (44 B)": np.dtype([("x", "<f8"), ("y", "<f8"), ("size", "<f8"), ("angle", "<f8"), ("response", "<f8"), ("octave", "<i4")]),
-    "f32x5+i32 (24 B)": np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4")]),
-}
-
-
-def probe_layout(buf: bytes):
-    """-> (layout name, count width, keypoints, descriptors) for the first variant that accounts for every byte:
-    [count][nk keypoints][count][nd descriptors of 32 bytes] with nk == nd."""
-    for cw in (8, 4):
-        if len(buf) < 2 * cw:
-            continue
-        nk = int.from_bytes(buf[:cw], "little")
-        for name, dt in KP_LAYOUTS.items():
-            off = cw + nk * dt.itemsize
-            if nk > (1 << 24) or off + cw > len(buf):
-                continue
-            nd = int.from_bytes(buf[off:off + cw], "little")
-            if nd == nk and off + cw + nd * 32 == len(buf):
-                kps = np.frombuffer(buf, dt, nk, cw).copy()
-                desc = np.frombuffer(buf, "<u8", nd * 4, off + cw).reshape(-1, 4).copy()
-                return name, cw, kps, desc
-    raise ValueError("no known layout accounts for the file's size")
+from snake_slam_amd.features_io import KEYPOINT_LAYOUTS as KP_LAYOUTS, probe_layout  # noqa: E402  (the probing lives with the format)
 
 
 def _png_gray(data: bytes) -> np.ndarray:
