@@ -1,5 +1,7 @@
 #!/bin/bash
-# Runs on the GPU box: FETCH_SIZE of fast_kernel and its launch time under processing-order / cells-per-wavefront variants.
+# Runs on the GPU box: FETCH_SIZE of fast_kernel and its launch time by cells per wavefront (SNK_ORB_FAST_CPW).  The run that is
+# kept in profiles/r03/r03q_fast_traffic_ab.log also had a column-major processing order of the cells (an experiment that was
+# reverted: 3.1 x the algorithmic bytes); its "row_*" lines are what this script measures.
 # usage: tools/fast_traffic_ab.sh   -> prints "variant fetch_KB_per_launch avg_us"
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
@@ -21,8 +23,6 @@ vals=list(v.values())
 print("$name", "FETCH_KB %.0f" % (sum(vals)/max(1,len(vals))), "x2/alg %.3f" % (2*1024*sum(vals)/max(1,len(vals))/1856544768), "avg_us %.1f" % (sum(t[0])/max(1,len(t[0]))))
 PY
 }
-run col_cpw8 A=1
-run row_cpw8 SNK_ORB_CELLS_ROW_MAJOR=1
-run col_cpw1 SNK_ORB_FAST_CPW=1
-run row_cpw1 SNK_ORB_CELLS_ROW_MAJOR=1 SNK_ORB_FAST_CPW=1
-run col_cpw4 SNK_ORB_FAST_CPW=4
+run row_cpw8 SNK_ORB_FAST_CPW=8
+run row_cpw1 SNK_ORB_FAST_CPW=1
+run row_cpw4 SNK_ORB_FAST_CPW=4
