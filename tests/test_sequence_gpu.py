@@ -81,3 +81,36 @@ def test_sequences_in_lockstep_match_the_oracle_chain(orc):
 
 def S_helpers_oracle(orc, frames, w, h, orb, cam):
     return S.oracle_sequence(orc, frames, w, h, orb=orb, cam=cam)
+
+
+def test_lockstep_with_an_empty_sequence_and_a_single_sequence(orc):
+    """Edge cases of the lockstep tracker: a sequence of featureless images next to ordinary ones (no keypoints, no pairs: its
+    pose stays the identity and the others are unaffected), and S = 1 (a batch of two images, the small-launch paths)."""
+    from snake_slam_amd import synth
+    from snake_slam_amd.sequence import MultiSequenceTracker
+
+    w, h, orb, cam = 640, 400, (800, 1.2, 4, 20, 7), (400.0, 400.0, 320.0, 200.0, 100.0)
+    okw = dict(nfeatures=orb[0], scale_factor=orb[1], n_levels=orb[2], ini_th_fast=orb[3], min_th_fast=orb[4])
+    T = 3
+    real = [list(synth.sequence_frames(20 + s, T, w, h, n_rects=300)) for s in range(2)]
+    blank = [(np.full((h, w), 90, np.uint8), np.full((h, w), 90, np.uint8)) for _ in range(T)]
+    seqs = [real[0], blank, real[1]]
+    mt = MultiSequenceTracker(cam, 3, T, orb=okw, width=w, height=h)
+    try:
+        for t in range(T):
+            mt.process([s[t][0] for s in seqs], [s[t][1] for s in seqs], float(t))
+        rows, stats = mt.results()
+    finally:
+        mt.close()
+    for k, s in ((0, 0), (2, 1)):
+        want, _ = S.oracle_sequence(orc, real[s], w, h, orb=orb, cam=cam)
+        assert np.allclose(rows[k], want, rtol=0, atol=1e-9), k
+    assert np.allclose(rows[1][:, 1:4], 0.0) and np.allclose(rows[1][:, 4:], [0, 0, 0, 1])  # identity throughout
+    one = MultiSequenceTracker(cam, 1, T, orb=okw, width=w, height=h)
+    try:
+        for t in range(T):
+            one.process([real[0][t][0]], [real[0][t][1]], float(t))
+        r1, _ = one.results()
+    finally:
+        one.close()
+    assert np.array_equal(r1[0], rows[0])  # the same sequence alone: bit-identical trajectory (no cross-talk between sequences)
