@@ -44,6 +44,27 @@ def test_sequence_trajectory_matches_the_oracle_chain(orc, w, h, orb, cam):
     assert abs(rows[-1, 2]) < 0.5 * 4 * step and abs(rows[-1, 3]) < 0.6 * 4 * step
 
 
+def test_lockstep_kitti_shape(orc):
+    """The lockstep tracker at BASELINE.json configs[2]'s shape (1241x376, 2000 features, 7 levels): two sequences, three frames."""
+    from snake_slam_amd import synth
+    from snake_slam_amd.sequence import MultiSequenceTracker
+
+    w, h, orb, cam = 1241, 376, (2000, 1.2, 7, 20, 7), (718.856, 718.856, 607.1928, 185.2157, 386.1448)
+    okw = dict(nfeatures=orb[0], scale_factor=orb[1], n_levels=orb[2], ini_th_fast=orb[3], min_th_fast=orb[4])
+    seqs = [list(synth.sequence_frames(30 + s, 3, w, h)) for s in range(2)]
+    mt = MultiSequenceTracker(cam, 2, 3, orb=okw, width=w, height=h)
+    try:
+        for t in range(3):
+            mt.process([q[t][0] for q in seqs], [q[t][1] for q in seqs], float(t))
+        rows, stats = mt.results()
+    finally:
+        mt.close()
+    for s in range(2):
+        want, _ = S.oracle_sequence(orc, seqs[s], w, h, orb=orb, cam=cam)
+        assert np.allclose(rows[s], want, rtol=0, atol=1e-9), s
+    assert stats["keypoints"] > 2 * 3 * 2 * 1900 and stats["inliers"] > 2 * 2 * 100
+
+
 def test_sequences_in_lockstep_match_the_oracle_chain(orc):
     """MultiSequenceTracker: S sequences on one GPU in lockstep, device resident (batched entry points + the two glue kernels
     snk_track_bf_matches_batch_dev / snk_track_backproject_batch_dev): every sequence's trajectory equals the oracle chain's
