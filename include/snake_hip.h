@@ -662,6 +662,19 @@ SNK_API int snk_ba_get_state(snk_ba* h, int problem, double (*pose)[7], double (
  * current state (0 for skipped observations), n_obs entries in caller order. */
 SNK_API int snk_ba_residuals(snk_ba* h, int problem, double* chi2_per_obs);
 
+/* LocalBundleAdjustment::SolveLocalScene after scene creation in ONE call (LocalBundleAdjustment.cpp:357-410): initAndSolve with
+ * the handle's max_iterations (:357-365), the chi-square pass on the device (:368-397: every observation that is valid, not
+ * yet an outlier and has chi2 > (depth > 0 ? chi2_stereo : chi2_mono) becomes an outlier), `extra_iterations` more iterations
+ * when anything was marked (:399-410; the reference uses 1).  One 4-byte count crosses the bus in between instead of the chi2
+ * array down and the mask up.  Results: *n_marked (outlierPoints), the FIRST solve's costs (what :412 returns), the optimised
+ * poses / points of `problem` and its observation outlier flags after the pass (n_obs bytes, caller order); each may be NULL
+ * except n_marked.  Same results as snk_ba_solve -> snk_ba_residuals -> host threshold -> snk_ba_set_outliers -> snk_ba_solve.
+ * With several problems loaded every problem is solved and marked, and each one that had something marked gets the extra
+ * iterations (decided on the device: the call synchronises once, at the end); the outputs are those of `problem`. */
+SNK_API int snk_ba_solve_local_scene(snk_ba* h, int problem, double chi2_mono, double chi2_stereo, int extra_iterations,
+                                     uint8_t* obs_outlier, int* n_marked, double* cost_initial, double* cost_final,
+                                     double (*pose)[7], double (*pt)[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,6 +95,7 @@ SIGNATURES = {
     "snk_ba_reset": (i32, [vp]),
     "snk_ba_get_state": (i32, [vp, i32, vp, vp, C.POINTER(i32)]),
     "snk_ba_residuals": (i32, [vp, i32, vp]),
+    "snk_ba_solve_local_scene": (i32, [vp, i32, f64, f64, i32, vp, vp, vp, vp, vp, vp]),
 }
 
 

@@ -127,6 +127,21 @@ class BARec:
                                               C.byref(it)), "snk_ba_get_state")
         return pose, pt, it.value
 
+    def solve_local_scene(self, chi2_mono: float, chi2_stereo: float, problem: int = 0, extra_iterations: int = 1):
+        """`LocalBundleAdjustment::SolveLocalScene` after create() in one call (LocalBundleAdjustment.cpp:357-410): initAndSolve,
+        the chi-square pass on the device, one more iteration when anything was marked.  Returns (outlierPoints, cost_initial,
+        cost_final of the FIRST solve, poses, points, observation outlier flags)."""
+        s = self._scenes[problem]
+        pose = np.zeros((len(s["pose"]), 7), np.float64)
+        pt = np.zeros((len(s["pt"]), 3), np.float64)
+        flags = np.zeros(max(len(s["obs_img"]), 1), np.uint8)
+        n, ci, cf = C.c_int(0), C.c_double(0), C.c_double(0)
+        _lib.check(self._lib.snk_ba_solve_local_scene(self._h, problem, float(chi2_mono), float(chi2_stereo), int(extra_iterations),
+                                                      C.c_void_p(flags.ctypes.data), C.byref(n), C.byref(ci), C.byref(cf),
+                                                      C.c_void_p(pose.ctypes.data), C.c_void_p(pt.ctypes.data)),
+                   "snk_ba_solve_local_scene")
+        return n.value, ci.value, cf.value, pose, pt, flags[:len(s["obs_img"])]
+
     def residuals(self, problem: int = 0) -> np.ndarray:
         n = len(self._scenes[problem]["obs_img"])
         out = np.zeros(max(n, 1), np.float64)

@@ -544,9 +544,17 @@ class BARec
     void create(Scene& scene)
     {
         scene_ = &scene;
-        if (h_) snk_ba_destroy(h_);
-        h_ = nullptr;
-        check(snk_ba_create(&optimizationOptions, device_, nullptr, &h_), "snk_ba_create");
+        // the handle (device buffers, pinned staging) survives from scene to scene; only changed options need a new one
+        if (h_ && std::memcmp(&created_with_, &optimizationOptions, sizeof(snk_ba_options)) != 0)
+        {
+            snk_ba_destroy(h_);
+            h_ = nullptr;
+        }
+        if (!h_)
+        {
+            check(snk_ba_create(&optimizationOptions, device_, nullptr, &h_), "snk_ba_create");
+            created_with_ = optimizationOptions;
+        }
         snk_ba_problem p{};
         p.n_img      = (int)scene.poses.size();
         p.n_pt       = (int)scene.points.size();
@@ -580,6 +588,26 @@ class BARec
               "snk_ba_get_state");
         return r;
     }
+    // LocalBundleAdjustment::SolveLocalScene after create() in one library call (LocalBundleAdjustment.cpp:357-410): initAndSolve,
+    // the chi-square pass on the device, one more iteration when anything was marked.  The scene's poses, points and
+    // obs_outlier are updated; *outlierPoints = how many observations the pass marked; returns the FIRST solve's costs (:412).
+    OptimizationResults solveLocalScene(double chi2Mono, double chi2Stereo, int* outlierPoints)
+    {
+        if (scene_->obs_outlier.size() != scene_->obs_image.size()) scene_->obs_outlier.assign(scene_->obs_image.size(), 0);
+        bool any = false;
+        for (uint8_t f : scene_->obs_outlier) any |= f != 0;
+        check(snk_ba_set_outliers(h_, 0, any ? scene_->obs_outlier.data() : nullptr), "snk_ba_set_outliers");  // NULL: a device memset
+        OptimizationResults r;
+        int marked = 0;
+        scene_->obs_outlier.push_back(0);  // never hand out a null pointer for an empty scene
+        check(snk_ba_solve_local_scene(h_, 0, chi2Mono, chi2Stereo, 1, scene_->obs_outlier.data(), &marked, &r.cost_initial, &r.cost_final,
+                                       reinterpret_cast<double(*)[7]>(scene_->poses.data()),
+                                       reinterpret_cast<double(*)[3]>(scene_->points.data())),
+              "snk_ba_solve_local_scene");
+        scene_->obs_outlier.pop_back();
+        if (outlierPoints) *outlierPoints = marked;
+        return r;
+    }
     // squared norms of Scene::residual3 / residual2 for every observation
     std::vector<double> residualsSquared()
     {
@@ -596,6 +624,7 @@ class BARec
     int device_;
     snk_ba* h_    = nullptr;
     Scene* scene_ = nullptr;
+    snk_ba_options created_with_{};
     std::vector<uint8_t> all_const_;
 };
 

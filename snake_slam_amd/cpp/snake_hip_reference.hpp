@@ -368,27 +368,14 @@ inline std::tuple<int, double, double> SolveLocalScene(BARec& cba, SaigaScene& s
     std::vector<std::pair<int, int>> where;
     Scene s = flatten(scene, &where);
     cba.create(s);
-    const int its            = cba.optimizationOptions.max_iterations;
-    OptimizationResults res  = cba.initAndSolve();
-    const auto chi2          = cba.residualsSquared();
-    int outlierPoints        = 0;
-    for (size_t o = 0; o < chi2.size(); ++o)
-    {
-        auto& ip = scene.images[(size_t)where[o].first].stereoPoints[(size_t)where[o].second];
-        if (!ip) continue;                                                        // :376 (invalid or already an outlier)
-        if (chi2[o] > (ip.depth > 0 ? chi2Stereo : chi2Mono))                     // :377-394
-        {
-            ip.outlier       = true;
-            s.obs_outlier[o] = 1;
-            outlierPoints++;
-        }
-    }
-    if (outlierPoints > 0)
-    {
-        cba.optimizationOptions.max_iterations = 1;  // :402-403
-        cba.solve();                                 // the reference returns the FIRST solve's costs (:412; its inner `res` shadows)
-        cba.optimizationOptions.max_iterations = its;
-    }
+    // initAndSolve (:357-365), the chi-square pass (:368-397) and the extra iteration (:399-410) in one library call; the pass
+    // runs on the device with the reference's rule: valid, not yet an outlier, chi2 > (depth > 0 ? chi2Stereo : chi2Mono)
+    const std::vector<uint8_t> before = s.obs_outlier;
+    int outlierPoints                 = 0;
+    OptimizationResults res           = cba.solveLocalScene(chi2Mono, chi2Stereo, &outlierPoints);
+    for (size_t o = 0; o < s.obs_outlier.size(); ++o)
+        if (s.obs_outlier[o] && (before.size() != s.obs_outlier.size() || !before[o]))
+            scene.images[(size_t)where[o].first].stereoPoints[(size_t)where[o].second].outlier = true;  // :379, :391
     unflatten(s, scene, make_se3);
     return {outlierPoints, res.cost_initial, res.cost_final};
 }

@@ -75,6 +75,8 @@ struct Prob
     int n_set;          // work items of schur_set (0: not available for this problem)
     int set_off;        // into set_items
     int cblk_off;       // into cblk_start (nfc * nfc + 1 entries per problem)
+    int be_nch;         // device-built block entries: 64-item chunks of the longest camera list
+    int becnt_off;      // ... and this problem's [nfc][be_nch][nfc] counters
     int pad;
     double K[4];
     double bf;
@@ -90,7 +92,9 @@ struct Opt
 struct State  // per problem, device resident
 {
     double cost, cost_new, lambda, vfac, cost_initial;
-    int accepted, iter, pcg_iters, pad;
+    int accepted, iter, pcg_iters;
+    int marked;  // observations the chi-square pass after this solve marked (mark_outliers_kernel); begin_solve resets it
+    double first_cost_initial, first_cost;  // the costs at the time of that pass (a conditional extra iteration overwrites the others)
 };
 
 struct RpcMeta
@@ -545,9 +549,15 @@ __global__ __launch_bounds__(64) void point_wave(Arrays A, Opt O)
 
 // Back-substitution of the points with the point_wave work items: lane = observation forms W^T dc
 // (three sums of six products), lane = point subtracts them from b_p in observation order and applies V^-1.
-__global__ __launch_bounds__(256) void update_wave(Arrays A, Opt O)
+__device__ inline void trial_poses_block(const Arrays& A, int pb, int block);
+__global__ __launch_bounds__(256) void update_wave(Arrays A, Opt O, int wave_blocks)
 {
     __shared__ double s_t[4][64 * 3];
+    if ((int)blockIdx.x >= wave_blocks)  // the workgroups behind the point work items update the poses (was a launch of its own)
+    {
+        trial_poses_block(A, blockIdx.y, (int)blockIdx.x - wave_blocks);
+        return;
+    }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int pb   = blockIdx.y;
     const Prob pr  = A.prob[pb];
@@ -1809,8 +1819,13 @@ __global__ __launch_bounds__(256) void schur_sum(Arrays A, int nbx, int B)
     }
 }
 
+// WPB = wavefronts per block: 1 -- four blocks per workgroup, one wavefront each (batches, big scenes); 4 -- the whole workgroup
+// on one block (a single local window: ~190 upper blocks of ~380 entries each leave most of the chip idle and every wavefront
+// with six dependent trips through its list; four wavefronts per block make that two, measured 32 -> 15 us per LM iteration).
+template <int WPB>
 __global__ __launch_bounds__(256) void schur_pass(Arrays A, int zero_rows, int nbx, int B)
 {
+    __shared__ double s_red[WPB > 1 ? WPB * 36 : 1];
     int pb, bx;
     if (B >= 16)  // batched windows: one XCD per window
     {
@@ -1826,11 +1841,12 @@ __global__ __launch_bounds__(256) void schur_pass(Arrays A, int zero_rows, int n
     if (pb >= B) return;
     const Prob pr  = A.prob[pb];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int blk  = bx * 4 + wave;
+    const int blk  = WPB == 1 ? bx * 4 + wave : bx;
     if (blk >= pr.nfc * pr.nfc) return;
     const int c1 = blk / pr.nfc, c2 = blk - c1 * pr.nfc;
     if (c2 < c1) return;  // S is symmetric: the lower blocks are written as transposes of the upper ones
-    const int e0 = A.blk_start[pr.blkstart_off + blk], e1 = A.blk_start[pr.blkstart_off + blk + 1];
+    const int e0 = A.blk_start[pr.blkstart_off + blk] + (WPB == 1 ? 0 : wave * 64), e1 = A.blk_start[pr.blkstart_off + blk + 1];
+    constexpr int STEP = 64 * WPB;
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; ++k) acc[k] = 0.0;
@@ -1838,10 +1854,10 @@ __global__ __launch_bounds__(256) void schur_pass(Arrays A, int zero_rows, int n
     // products vanish and the dependent activity lookup is skipped; the next list entry is fetched before
     // the current rows are consumed (one latency level per iteration instead of three)
     int4 en_next = e0 + lane < e1 ? A.blk_ent[pr.ent_off + e0 + lane] : make_int4(0, 0, 0, 0);
-    for (int k = e0 + lane; k < e1; k += 64)
+    for (int k = e0 + lane; k < e1; k += STEP)
     {
         const int4 en = en_next;
-        if (k + 64 < e1) en_next = A.blk_ent[pr.ent_off + k + 64];
+        if (k + STEP < e1) en_next = A.blk_ent[pr.ent_off + k + STEP];
         const int g1 = pr.obs_off + en.x, g2 = pr.obs_off + en.y;
         if (!zero_rows && (A.o_r[(size_t)g1 * 4 + 3] == 0.0 || A.o_r[(size_t)g2 * 4 + 3] == 0.0)) continue;
         // Y(c1) = W(c1) V^-1 is rebuilt from W and the point's 6 V^-1 entries instead of being stored per
@@ -1879,6 +1895,22 @@ __global__ __launch_bounds__(256) void schur_pass(Arrays A, int zero_rows, int n
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
         acc[k] = v;
+    }
+    if (WPB > 1)  // the wavefronts' sums in a fixed order (the whole workgroup is on this block: no early return above diverged)
+    {
+        if (lane == 0)
+#pragma unroll
+            for (int k = 0; k < 36; ++k) s_red[wave * 36 + k] = acc[k];
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int k = 0; k < 36; ++k)
+        {
+            double v = s_red[k];
+#pragma unroll
+            for (int w = 1; w < WPB; ++w) v += s_red[w * 36 + k];
+            acc[k] = v;
+        }
     }
     if (lane == 0)
     {
@@ -2510,6 +2542,27 @@ __device__ void se3_update(const double* pose, const double* d, double* out)
     out[6] = Rd[6] * tx + Rd[7] * ty + Rd[8] * tz + tdz;
 }
 
+// the trial pose of image i: exp(dc) * pose for a free camera, the pose itself for a constant one
+__device__ inline void trial_pose(const Arrays& A, const Prob& pr, int i)
+{
+    const int gi = pr.img_off + i;
+    const int c  = A.cam_idx[gi];
+    const double* cur = A.pose + (size_t)gi * 7;
+    double* out       = A.pose_new + (size_t)gi * 7;
+    if (c < 0)
+        for (int k = 0; k < 7; ++k) out[k] = cur[k];
+    else
+        se3_update(cur, A.x + pr.vec_off + c * 6, out);
+}
+
+// update_wave's workgroups behind the point work items (blockIdx.x >= wave_blocks): the trial poses, 256 images each
+__device__ inline void trial_poses_block(const Arrays& A, int pb, int block)
+{
+    const Prob pr = A.prob[pb];
+    const int i   = block * 256 + threadIdx.x;
+    if (i < pr.ni) trial_pose(A, pr, i);
+}
+
 // threads [0, np): back-substitution dp = V^-1 (b_p - sum W^T dc); threads [np, np + ni): trial poses
 __global__ __launch_bounds__(128) void update_pass(Arrays A, int images_only)
 {
@@ -2549,25 +2602,16 @@ __global__ __launch_bounds__(128) void update_pass(Arrays A, int images_only)
         out[2] = cur[2] + (Vi[2] * g[0] + Vi[4] * g[1] + Vi[5] * g[2]);
     }
     else if (t < pr.np + pr.ni)
-    {
-        const int i  = t - pr.np;
-        const int gi = pr.img_off + i;
-        const int c  = A.cam_idx[gi];
-        const double* cur = A.pose + (size_t)gi * 7;
-        double* out       = A.pose_new + (size_t)gi * 7;
-        if (c < 0)
-            for (int k = 0; k < 7; ++k) out[k] = cur[k];
-        else
-            se3_update(cur, x + c * 6, out);
-    }
+        trial_pose(A, pr, t - pr.np);
 }
 
 constexpr int ACC_THREADS = 256;
-__global__ __launch_bounds__(ACC_THREADS) void accept_pass(Arrays A)
+__global__ __launch_bounds__(ACC_THREADS) void accept_pass(Arrays A, int only_marked)
 {
     __shared__ double red[ACC_THREADS];
     __shared__ int s_acc;
     const int pb  = blockIdx.x;
+    if (only_marked && A.state[pb].marked == 0) return;
     const Prob pr = A.prob[pb];
     const int tid = threadIdx.x;
     // fixed-order sums: contiguous chunk per thread, then the tree
@@ -2614,19 +2658,35 @@ __global__ __launch_bounds__(ACC_THREADS) void accept_pass(Arrays A)
     }
     __syncthreads();
     if (!s_acc) return;
-    for (int k = tid; k < pr.np * 3; k += ACC_THREADS) A.pt[(size_t)pr.pt_off * 3 + k] = A.pt_new[(size_t)pr.pt_off * 3 + k];
+    {
+        // eight loads in flight per thread (one at a time the 6000 doubles of a window's points were 24 dependent round trips)
+        const double* src = A.pt_new + (size_t)pr.pt_off * 3;
+        double* dst       = A.pt + (size_t)pr.pt_off * 3;
+        const int n       = pr.np * 3;
+        for (int k0 = tid; k0 < n; k0 += 8 * ACC_THREADS)
+        {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = k0 + u * ACC_THREADS < n ? src[k0 + u * ACC_THREADS] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k0 + u * ACC_THREADS < n) dst[k0 + u * ACC_THREADS] = v[u];
+        }
+    }
     for (int k = tid; k < pr.ni * 7; k += ACC_THREADS) A.pose[(size_t)pr.img_off * 7 + k] = A.pose_new[(size_t)pr.img_off * 7 + k];
 }
 
-__global__ void begin_solve(State* st, int n, double lambda_init)
+__global__ void begin_solve(State* st, int n, double lambda_init, int only_marked)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (only_marked && st[i].marked == 0) return;  // a conditional extra iteration (select_marked) leaves unmarked problems alone
     st[i].lambda    = lambda_init;
     st[i].vfac      = 2.0;
     st[i].iter      = 0;
     st[i].pcg_iters = 0;
     st[i].accepted  = 0;
+    if (!only_marked) st[i].marked = 0;
 }
 }  // namespace
 }  // namespace snk
@@ -2685,6 +2745,8 @@ struct snk_ba : HandleBase
 {
     BaLists lists;
     HostBuf h_stage;  // pinned staging of the small per-call transfers (outlier masks)
+    DevBuf d_becnt;   // per (camera, 64-item chunk, camera) counters of the device-built block entries
+    DevBuf d_probcond;  // the problem table of a conditional extra iteration (select_marked)
     snk_ba_options opt{};
     int count = 0;
     std::vector<Prob> probs;
@@ -2731,7 +2793,7 @@ Opt make_opt(const snk_ba_options& o)
 
 // The hand-over's lists reach the device with ONE kernel that reads the pinned host vectors over the bus (hipHostMalloc memory is
 // device-visible) and writes the device arrays: 33 separate copies cost ~6 us each on the copy engine whatever their size.
-constexpr int COPY_TAB_MAX = 40;
+constexpr int COPY_TAB_MAX = 48;
 struct CopyTab
 {
     const void* src[COPY_TAB_MAX];
@@ -2739,12 +2801,195 @@ struct CopyTab
     unsigned bytes[COPY_TAB_MAX];
     int n;
 };
+// ---- scene lists built on the device -------------------------------------------------------------------------------------------
+// The static per-camera observation records (what cam_pass streams) are a gather of the sorted observation arrays through the
+// camera lists: 40 bytes per observation that neither the host loop nor the bus has to touch.
+__global__ __launch_bounds__(256) void gather_cam_records(Arrays A, CamObs* __restrict__ out)
+{
+    const Prob pr = A.prob[blockIdx.y];
+    const int n   = A.cam_start[pr.camstart_off + pr.nfc];
+    const int k   = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int go = pr.obs_off + A.cam_items[pr.citem_off + k];
+    const double2 uv = A.o_uv[go];
+    CamObs rec;
+    rec.u = uv.x; rec.v = uv.y; rec.depth = A.o_depth[go]; rec.weight = A.o_weight[go];
+    rec.pt = A.o_pt[go]; rec.orig = A.o_orig[go]; rec.img = A.o_img[go]; rec.ptfree = A.o_ptfree[go];
+    out[pr.citem_off + k] = rec;
+}
+
+// The camera-pair block entries of schur_pass -- for every upper block (c1, c2) the co-observations (observation of c1,
+// observation of c2, point) in ascending order -- built by three launches instead of a host loop over every pair of every
+// point (half of a scene hand-over's host time, and 1.1 MB over the bus for a 20 x 2000 x 8 window).  Requirements (checked
+// on the host, which keeps its own builder for the other scenes): <= 64 free cameras, no camera twice on a point.
+// One wavefront per (camera c1, 64 items of its list): lane = one observation a of c1; the free cameras >= c1 in its point's
+// run are a 64-bit mask; ballot(c2 in mask) ranks the lane inside the chunk for block (c1, c2).  Order inside a block = list
+// order of c1 = ascending observation index = ascending point: the host builder's order.
+__device__ inline void block_entry_item(const Arrays& A, const Prob& pr, int c1, int chunk, int lane, int& a, int& p, int& r0, int& r1,
+                                        unsigned long long& mask)
+{
+    const int s0 = A.cam_start[pr.camstart_off + c1], s1 = A.cam_start[pr.camstart_off + c1 + 1];
+    const int k  = s0 + chunk * 64 + lane;
+    a = -1, p = 0, r0 = 0, r1 = 0, mask = 0ull;
+    if (k >= s1) return;
+    const int s  = A.cam_items[pr.citem_off + k];
+    const int go = pr.obs_off + s;
+    if (!A.o_ptfree[go]) return;  // constant points produce no Schur products
+    a  = s;
+    p  = A.o_pt[go];
+    r0 = A.pt_start[pr.ptstart_off + p], r1 = A.pt_start[pr.ptstart_off + p + 1];
+    for (int c = r0; c < r1; ++c)
+    {
+        const int cc = A.o_cam[pr.obs_off + c];
+        if (cc >= c1) mask |= 1ull << cc;
+    }
+}
+
+__global__ __launch_bounds__(64) void block_entries_count(Arrays A, int* __restrict__ cnt)
+{
+    const Prob pr = A.prob[blockIdx.y];
+    const int w   = blockIdx.x;
+    if (pr.be_nch <= 0 || w >= pr.nfc * pr.be_nch) return;
+    const int c1 = w / pr.be_nch, chunk = w - c1 * pr.be_nch, lane = threadIdx.x;
+    int a, p, r0, r1;
+    unsigned long long mask;
+    block_entry_item(A, pr, c1, chunk, lane, a, p, r0, r1, mask);
+    int mine = 0;
+    for (int c2 = c1; c2 < pr.nfc; ++c2)
+    {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64((mask >> c2) & 1ull);
+        if (lane == c2) mine = __popcll(m);
+    }
+    if (lane < pr.nfc) cnt[pr.becnt_off + (size_t)(c1 * pr.be_nch + chunk) * pr.nfc + lane] = mine;
+}
+
+// per problem: chunk counts -> chunk bases (in place), block totals -> blk_start (exclusive scan over the nfc * nfc blocks)
+__global__ __launch_bounds__(256) void block_entries_scan(Arrays A, int* __restrict__ cnt, int* __restrict__ blk_start)
+{
+    __shared__ int s_scan[256];
+    __shared__ int s_run;
+    const Prob pr = A.prob[blockIdx.x];
+    const int nb = pr.nfc * pr.nfc, tid = threadIdx.x;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 256)
+    {
+        const int blk = base + tid;
+        int tot = 0;
+        if (blk < nb && pr.be_nch > 0)
+        {
+            const int c1 = blk / pr.nfc, c2 = blk - c1 * pr.nfc;
+            for (int ch = 0; ch < pr.be_nch; ++ch)
+            {
+                int* q = cnt + pr.becnt_off + (size_t)(c1 * pr.be_nch + ch) * pr.nfc + c2;
+                const int v = *q;
+                *q = tot;
+                tot += v;
+            }
+        }
+        s_scan[tid] = tot;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1)  // inclusive scan
+        {
+            const int v = tid >= off ? s_scan[tid - off] : 0;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        const int run = s_run;
+        if (blk < nb) blk_start[pr.blkstart_off + blk] = run + s_scan[tid] - tot;
+        __syncthreads();
+        if (tid == 255) s_run = run + s_scan[255];
+        __syncthreads();
+    }
+    if (tid == 0) blk_start[pr.blkstart_off + nb] = s_run;
+}
+
+__global__ __launch_bounds__(64) void block_entries_fill(Arrays A, const int* __restrict__ cnt, int4* __restrict__ blk_ent)
+{
+    __shared__ unsigned long long s_ball[64];
+    __shared__ int s_base[64];
+    const Prob pr = A.prob[blockIdx.y];
+    const int w   = blockIdx.x;
+    if (pr.be_nch <= 0 || w >= pr.nfc * pr.be_nch) return;
+    const int c1 = w / pr.be_nch, chunk = w - c1 * pr.be_nch, lane = threadIdx.x;
+    int a, p, r0, r1;
+    unsigned long long mask;
+    block_entry_item(A, pr, c1, chunk, lane, a, p, r0, r1, mask);
+    unsigned long long mine = 0ull;
+    for (int c2 = c1; c2 < pr.nfc; ++c2)
+    {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64((mask >> c2) & 1ull);
+        if (lane == c2) mine = m;
+    }
+    s_ball[lane] = mine;
+    s_base[lane] = lane >= c1 && lane < pr.nfc ? A.blk_start[pr.blkstart_off + c1 * pr.nfc + lane] +
+                                                     cnt[pr.becnt_off + (size_t)(c1 * pr.be_nch + chunk) * pr.nfc + lane]
+                                               : 0;
+    __syncthreads();
+    if (a < 0) return;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int c = r0; c < r1; ++c)
+    {
+        const int cc = A.o_cam[pr.obs_off + c];
+        if (cc < c1) continue;
+        blk_ent[(size_t)pr.ent_off + s_base[cc] + __popcll(s_ball[cc] & below)] = make_int4(a, c, p, 0);
+    }
+}
+
+// The chi-square pass of SolveLocalScene (reference Snake/Optimizer/LocalBundleAdjustment.cpp:368-397) on the device: every observation
+// that is not yet an outlier and whose squared residual (A.chi2, caller order, written by point_pass<2>) exceeds its threshold
+// becomes one; state[problem].marked = how many were marked (reset by begin_solve).  Integer atomics only (order independent).
+// A.chi2 is read for VALID observations only (point_pass<2> writes every one of them), so it needs no clearing first.
+__global__ __launch_bounds__(256) void mark_outliers_kernel(Arrays A, unsigned char* __restrict__ outlier_w, double chi2_mono,
+                                                            double chi2_stereo)
+{
+    const int pb  = blockIdx.y;
+    const Prob pr = A.prob[pb];
+    const int s   = blockIdx.x * 256 + threadIdx.x;
+    bool mark     = false;
+    if (s < pr.no)
+    {
+        const int orig = A.o_orig[pr.obs_off + s];
+        mark = !outlier_w[orig] && A.chi2[orig] > (A.o_depth[pr.obs_off + s] > 0.0 ? chi2_stereo : chi2_mono);
+        if (mark) outlier_w[orig] = 1;
+    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(mark);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&A.state[pb].marked, __popcll(m));
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+    {
+        A.state[pb].first_cost_initial = A.state[pb].cost_initial;
+        A.state[pb].first_cost         = A.state[pb].cost;
+    }
+}
+
+// The extra iteration of SolveLocalScene runs only for scenes whose chi-square pass marked something
+// (LocalBundleAdjustment.cpp:399).  Instead of reading the count back and deciding on the host, the iteration is enqueued
+// behind the pass with THIS table of problems: an unmarked problem appears with every size zero, so each kernel of the
+// iteration finds nothing to do for it (the same way an empty scene in a batch does); begin_solve and accept_pass, which touch
+// the per-problem state whatever the sizes, take the condition as an argument.
+__global__ __launch_bounds__(64) void select_marked(const Prob* __restrict__ prob, Prob* __restrict__ out, const State* __restrict__ st, int n)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    Prob p = prob[i];
+    if (st[i].marked == 0) p.ni = p.np = p.no = p.nfc = p.n6 = p.n_wv = p.n_rpc = p.n_set = p.be_nch = 0;
+    out[i] = p;
+}
+
 __global__ __launch_bounds__(256) void copy_table_kernel(CopyTab T)
 {
     const int e = blockIdx.y;
     const unsigned nb = T.bytes[e], nq = nb >> 4;
     const uint4* s4 = static_cast<const uint4*>(T.src[e]);  // both sides are at least 256-byte aligned (hipHostMalloc / hipMalloc)
     uint4* d4       = static_cast<uint4*>(T.dst[e]);
+    if (s4 == nullptr)  // a buffer that starts as zeros
+    {
+        for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < nq; i += gridDim.x * 256u) d4[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (blockIdx.x == 0)
+            for (unsigned i = (nq << 4) + threadIdx.x; i < nb; i += 256u) static_cast<unsigned char*>(T.dst[e])[i] = 0;
+        return;
+    }
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < nq; i += gridDim.x * 256u) d4[i] = s4[i];
     if (blockIdx.x == 0)
     {
@@ -2846,7 +3091,7 @@ int snk_ba_destroy(snk_ba* h)
                      &h->d_W, &h->d_ptv, &h->d_Vinv, &h->d_bp, &h->d_cost, &h->d_cost_new, &h->d_U, &h->d_camstart,
                      &h->d_camitems, &h->d_blkstart, &h->d_blkent, &h->d_S, &h->d_rhs, &h->d_x, &h->d_chi2,
                      &h->d_pcgw, &h->d_optidx, &h->d_wvpt, &h->d_rpcmeta, &h->d_rpcnext, &h->d_camrpcstart,
-                     &h->d_camrpcitems, &h->d_blkrpc, &h->d_rpcout};
+                     &h->d_camrpcitems, &h->d_blkrpc, &h->d_rpcout, &h->d_becnt, &h->d_probcond};
     for (DevBuf* b : all) b->release();
     h->h_stage.release();
     h->drop_graphs();
@@ -2911,146 +3156,18 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     long long s_off = 0;
     int max_np = 0, max_nfc = 0, max_n6 = 0, max_ni = 0;
 
-    for (int b = 0; b < count; ++b)
+    bool dev_entries_ok = true;  // every problem can have its block entries built on the device
+    std::vector<long long> ent_bound((size_t)count, 0);
+    int blkstart_total = 0, max_citems = 0;
+    // camera-pair blocks on the host: co-observations of every ordered pair (dense block grid, empty blocks allowed).  The
+    // builder for scenes the device kernels do not take (more than 64 free cameras, one camera twice on a point), and their checker.
+    auto host_block_entries = [&](int b, pvec<int>& blkstart, pvec<int4>& blkent)
     {
         const snk_ba_problem& P = problems[b];
-        SNK_REQUIRE(P.n_img >= 0 && P.n_pt >= 0 && P.n_obs >= 0, "negative problem size");
-        SNK_REQUIRE(P.n_img == 0 || (P.pose && P.img_const), "NULL pose arrays");
-        SNK_REQUIRE(P.n_pt == 0 || (P.pt && P.pt_const), "NULL point arrays");
-        SNK_REQUIRE(P.n_obs == 0 || (P.obs_img && P.obs_pt && P.obs_uv && P.obs_depth && P.obs_weight), "NULL observation arrays");
-        SNK_REQUIRE(P.n_rpc >= 0 && (P.n_rpc == 0 || P.rpc != nullptr), "bad relative pose constraints");
-        Prob& pr = probs[(size_t)b];
-        memset(&pr, 0, sizeof(pr));
-        pr.ni = P.n_img;
-        pr.np = P.n_pt;
-        for (int k = 0; k < 4; ++k) pr.K[k] = P.K[k];
-        pr.bf       = P.bf;
-        pr.img_off  = img_off;
-        pr.pt_off   = pt_off;
-        pr.obs_off  = obs_off;
-        pr.cam_off  = cam_off;
-        pr.orig_off = orig_off;
-        pr.vec_off  = vec_off;
-        pr.s_off    = s_off;
-        h->orig_off[(size_t)b] = orig_off;
-        h->orig_n[(size_t)b]   = P.n_obs;
-        // values
-        for (int i = 0; i < P.n_img; ++i)
-            for (int k = 0; k < 7; ++k) pose.push_back(P.pose[i][k]);
-        for (int p = 0; p < P.n_pt; ++p)
-        {
-            for (int k = 0; k < 3; ++k) pt.push_back(P.pt[p][k]);
-            ptc.push_back(P.pt_const[p] ? 1 : 0);
-        }
-        // free cameras
-        int nfc = 0;
-        std::vector<int> cidx((size_t)P.n_img);
-        for (int i = 0; i < P.n_img; ++i) cidx[(size_t)i] = P.img_const[i] ? -1 : nfc++;
-        camidx.insert(camidx.end(), cidx.begin(), cidx.end());
-        pr.nfc = nfc;
-        pr.n6  = 6 * nfc;
-        // valid observations, counting sort by point (stable: caller order inside a point)
-        std::vector<int> pstart((size_t)P.n_pt + 1, 0);
-        std::vector<char> valid((size_t)P.n_obs, 0);
-        for (int o = 0; o < P.n_obs; ++o)
-        {
-            const int i = P.obs_img[o], p = P.obs_pt[o];
-            if (i < 0 || i >= P.n_img || p < 0 || p >= P.n_pt) continue;
-            if (P.img_const[i] && P.pt_const[p]) continue;  // reference LocalBundleAdjustment.cpp:286
-            valid[(size_t)o] = 1;
-            pstart[(size_t)p + 1]++;
-        }
-        for (int p = 0; p < P.n_pt; ++p) pstart[(size_t)p + 1] += pstart[(size_t)p];
-        const int no = pstart[(size_t)P.n_pt];
-        pr.no        = no;
-        std::vector<int> order((size_t)no);
-        {
-            std::vector<int> fill(pstart.begin(), pstart.end() - 1);
-            for (int o = 0; o < P.n_obs; ++o)
-                if (valid[(size_t)o]) order[(size_t)fill[(size_t)P.obs_pt[o]]++] = o;
-        }
-        pr.ptstart_off = (int)ptstart.size();
-        ptstart.insert(ptstart.end(), pstart.begin(), pstart.end());
-        std::vector<int> s_cam((size_t)no);
-        {
-            // sized once, written by index (nine push_backs per observation were a fifth of the hand-over's host time)
-            const size_t at = oimg.size();
-            oimg.resize(at + (size_t)no), ocam.resize(at + (size_t)no), optfree.resize(at + (size_t)no), ouv2.resize(2 * (at + (size_t)no));
-            odepth.resize(at + (size_t)no), oweight.resize(at + (size_t)no), oorig.resize(at + (size_t)no), optidx.resize(at + (size_t)no);
-            int* q_img = oimg.data() + at, *q_cam = ocam.data() + at, *q_orig = oorig.data() + at, *q_pt = optidx.data() + at;
-            unsigned char* q_free = optfree.data() + at;
-            double *q_uv = ouv2.data() + 2 * at, *q_d = odepth.data() + at, *q_w = oweight.data() + at;
-            for (int s = 0; s < no; ++s)
-            {
-                const int o = order[(size_t)s];
-                const int i = P.obs_img[o], p = P.obs_pt[o];
-                q_img[s]  = i;
-                q_cam[s]  = cidx[(size_t)i];
-                s_cam[(size_t)s] = cidx[(size_t)i];
-                q_free[s] = P.pt_const[p] ? 0 : 1;
-                q_uv[2 * s]     = P.obs_uv[o][0];
-                q_uv[2 * s + 1] = P.obs_uv[o][1];
-                q_d[s]    = P.obs_depth[o];
-                q_w[s]    = P.obs_weight[o];
-                q_orig[s] = orig_off + o;
-                q_pt[s]   = p;
-            }
-        }
-        // point_wave work items: consecutive whole points with <= 64 observations in total
-        pr.wv_off = (int)wvpt.size();
-        pr.n_wv   = 0;
-        {
-            bool ok = true;
-            std::vector<int> wv;
-            int p = 0;
-            while (p < P.n_pt && ok)
-            {
-                wv.push_back(p);
-                int n = 0, q = p;
-                while (q < P.n_pt && q - p < 64 && n + (pstart[(size_t)q + 1] - pstart[(size_t)q]) <= 64)
-                {
-                    n += pstart[(size_t)q + 1] - pstart[(size_t)q];
-                    ++q;
-                }
-                if (q == p) ok = false;  // a point with more than 64 observations: point_pass handles the problem
-                p = q;
-            }
-            if (ok)
-            {
-                wv.push_back(P.n_pt);
-                pr.n_wv = (int)wv.size() - 1;
-                wvpt.insert(wvpt.end(), wv.begin(), wv.end());
-                max_wv = std::max(max_wv, pr.n_wv);
-            }
-            else
-                wave_ok = false;
-        }
-        // camera lists
-        pr.camstart_off = (int)camstart.size();
-        pr.citem_off    = (int)camitems.size();
-        {
-            std::vector<int> cs((size_t)nfc + 1, 0);
-            for (int s = 0; s < no; ++s)
-                if (s_cam[(size_t)s] >= 0) cs[(size_t)s_cam[(size_t)s] + 1]++;
-            for (int c = 0; c < nfc; ++c) cs[(size_t)c + 1] += cs[(size_t)c];
-            std::vector<int> items((size_t)cs[(size_t)nfc]);
-            std::vector<int> fill(cs.begin(), cs.end() - 1);
-            for (int s = 0; s < no; ++s)
-                if (s_cam[(size_t)s] >= 0) items[(size_t)fill[(size_t)s_cam[(size_t)s]]++] = s;
-            camstart.insert(camstart.end(), cs.begin(), cs.end());
-            camitems.insert(camitems.end(), items.begin(), items.end());
-            for (int s : items)  // the same list as static records (what cam_pass streams)
-            {
-                const int o = order[(size_t)s];
-                CamObs rec;
-                rec.u = P.obs_uv[o][0]; rec.v = P.obs_uv[o][1]; rec.depth = P.obs_depth[o]; rec.weight = P.obs_weight[o];
-                rec.pt = P.obs_pt[o]; rec.orig = orig_off + o; rec.img = P.obs_img[o]; rec.ptfree = P.pt_const[P.obs_pt[o]] ? 0 : 1;
-                csobs.push_back(rec);
-            }
-        }
-        // camera-pair blocks: co-observations of every ordered pair (dense block grid, empty blocks allowed)
-        pr.blkstart_off = (int)blkstart.size();
-        pr.ent_off      = (int)blkent.size();
+        const Prob& pr          = probs[(size_t)b];
+        const int nfc           = pr.nfc;
+        const int* pstart       = ptstart.data() + pr.ptstart_off;
+        const int* s_cam        = ocam.data() + pr.obs_off;
         {
             const size_t nb = (size_t)nfc * nfc;
             std::vector<int> bs(nb + 1, 0);
@@ -3089,6 +3206,180 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             }
             blkstart.insert(blkstart.end(), bs.begin(), bs.end());
         }
+    };
+    static const bool prof_sections = getenv("SNK_BA_PROFILE_CREATE") != nullptr;
+    long long sec_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto sec_t = std::chrono::steady_clock::now();
+    auto mark = [&](int k)
+    {
+        if (!prof_sections) return;
+        const auto now = std::chrono::steady_clock::now();
+        sec_us[k] += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(now - sec_t).count();
+        sec_t = now;
+    };
+    for (int b = 0; b < count; ++b)
+    {
+        const snk_ba_problem& P = problems[b];
+        mark(7);
+        SNK_REQUIRE(P.n_img >= 0 && P.n_pt >= 0 && P.n_obs >= 0, "negative problem size");
+        SNK_REQUIRE(P.n_img == 0 || (P.pose && P.img_const), "NULL pose arrays");
+        SNK_REQUIRE(P.n_pt == 0 || (P.pt && P.pt_const), "NULL point arrays");
+        SNK_REQUIRE(P.n_obs == 0 || (P.obs_img && P.obs_pt && P.obs_uv && P.obs_depth && P.obs_weight), "NULL observation arrays");
+        SNK_REQUIRE(P.n_rpc >= 0 && (P.n_rpc == 0 || P.rpc != nullptr), "bad relative pose constraints");
+        Prob& pr = probs[(size_t)b];
+        memset(&pr, 0, sizeof(pr));
+        pr.ni = P.n_img;
+        pr.np = P.n_pt;
+        for (int k = 0; k < 4; ++k) pr.K[k] = P.K[k];
+        pr.bf       = P.bf;
+        pr.img_off  = img_off;
+        pr.pt_off   = pt_off;
+        pr.obs_off  = obs_off;
+        pr.cam_off  = cam_off;
+        pr.orig_off = orig_off;
+        pr.vec_off  = vec_off;
+        pr.s_off    = s_off;
+        h->orig_off[(size_t)b] = orig_off;
+        h->orig_n[(size_t)b]   = P.n_obs;
+        // values
+        if (P.n_img) pose.insert(pose.end(), &P.pose[0][0], &P.pose[0][0] + (size_t)P.n_img * 7);
+        if (P.n_pt)
+        {
+            pt.insert(pt.end(), &P.pt[0][0], &P.pt[0][0] + (size_t)P.n_pt * 3);
+            const size_t at = ptc.size();
+            ptc.resize(at + (size_t)P.n_pt);
+            for (int p = 0; p < P.n_pt; ++p) ptc[at + (size_t)p] = P.pt_const[p] ? 1 : 0;
+        }
+        // free cameras
+        int nfc = 0;
+        std::vector<int> cidx((size_t)P.n_img);
+        for (int i = 0; i < P.n_img; ++i) cidx[(size_t)i] = P.img_const[i] ? -1 : nfc++;
+        camidx.insert(camidx.end(), cidx.begin(), cidx.end());
+        pr.nfc = nfc;
+        pr.n6  = 6 * nfc;
+        // valid observations, counting sort by point (stable: caller order inside a point)
+        std::vector<int> pstart((size_t)P.n_pt + 1, 0);
+        std::vector<char> valid((size_t)P.n_obs, 0);
+        for (int o = 0; o < P.n_obs; ++o)
+        {
+            const int i = P.obs_img[o], p = P.obs_pt[o];
+            if (i < 0 || i >= P.n_img || p < 0 || p >= P.n_pt) continue;
+            if (P.img_const[i] && P.pt_const[p]) continue;  // reference LocalBundleAdjustment.cpp:286
+            valid[(size_t)o] = 1;
+            pstart[(size_t)p + 1]++;
+        }
+        for (int p = 0; p < P.n_pt; ++p) pstart[(size_t)p + 1] += pstart[(size_t)p];
+        const int no = pstart[(size_t)P.n_pt];
+        pr.no        = no;
+        std::vector<int> order((size_t)no);
+        {
+            std::vector<int> fill(pstart.begin(), pstart.end() - 1);
+            for (int o = 0; o < P.n_obs; ++o)
+                if (valid[(size_t)o]) order[(size_t)fill[(size_t)P.obs_pt[o]]++] = o;
+        }
+        pr.ptstart_off = (int)ptstart.size();
+        ptstart.insert(ptstart.end(), pstart.begin(), pstart.end());
+        mark(0);
+        std::vector<int> s_cam((size_t)no);
+        {
+            // sized once, written by index (nine push_backs per observation were a fifth of the hand-over's host time)
+            const size_t at = oimg.size();
+            oimg.resize(at + (size_t)no), ocam.resize(at + (size_t)no), optfree.resize(at + (size_t)no), ouv2.resize(2 * (at + (size_t)no));
+            odepth.resize(at + (size_t)no), oweight.resize(at + (size_t)no), oorig.resize(at + (size_t)no), optidx.resize(at + (size_t)no);
+            int* q_img = oimg.data() + at, *q_cam = ocam.data() + at, *q_orig = oorig.data() + at, *q_pt = optidx.data() + at;
+            unsigned char* q_free = optfree.data() + at;
+            double *q_uv = ouv2.data() + 2 * at, *q_d = odepth.data() + at, *q_w = oweight.data() + at;
+            unsigned long long seen = 0ull;  // free cameras of the current point (device-built block entries: no camera twice)
+            int seen_pt             = -1;
+            for (int s = 0; s < no; ++s)
+            {
+                const int o = order[(size_t)s];
+                const int i = P.obs_img[o], p = P.obs_pt[o];
+                if (p != seen_pt) seen = 0ull, seen_pt = p;
+                if (cidx[(size_t)i] >= 0 && nfc <= 64)
+                {
+                    const unsigned long long bit = 1ull << cidx[(size_t)i];
+                    if (seen & bit) dev_entries_ok = false;
+                    seen |= bit;
+                }
+                q_img[s]  = i;
+                q_cam[s]  = cidx[(size_t)i];
+                s_cam[(size_t)s] = cidx[(size_t)i];
+                q_free[s] = P.pt_const[p] ? 0 : 1;
+                q_uv[2 * s]     = P.obs_uv[o][0];
+                q_uv[2 * s + 1] = P.obs_uv[o][1];
+                q_d[s]    = P.obs_depth[o];
+                q_w[s]    = P.obs_weight[o];
+                q_orig[s] = orig_off + o;
+                q_pt[s]   = p;
+            }
+        }
+        mark(1);
+        // point_wave work items: consecutive whole points with <= 64 observations in total
+        pr.wv_off = (int)wvpt.size();
+        pr.n_wv   = 0;
+        {
+            bool ok = true;
+            std::vector<int> wv;
+            int p = 0;
+            while (p < P.n_pt && ok)
+            {
+                wv.push_back(p);
+                int n = 0, q = p;
+                while (q < P.n_pt && q - p < 64 && n + (pstart[(size_t)q + 1] - pstart[(size_t)q]) <= 64)
+                {
+                    n += pstart[(size_t)q + 1] - pstart[(size_t)q];
+                    ++q;
+                }
+                if (q == p) ok = false;  // a point with more than 64 observations: point_pass handles the problem
+                p = q;
+            }
+            if (ok)
+            {
+                wv.push_back(P.n_pt);
+                pr.n_wv = (int)wv.size() - 1;
+                wvpt.insert(wvpt.end(), wv.begin(), wv.end());
+                max_wv = std::max(max_wv, pr.n_wv);
+            }
+            else
+                wave_ok = false;
+        }
+        mark(2);
+        // camera lists
+        pr.camstart_off = (int)camstart.size();
+        pr.citem_off    = (int)camitems.size();
+        {
+            std::vector<int> cs((size_t)nfc + 1, 0);
+            for (int s = 0; s < no; ++s)
+                if (s_cam[(size_t)s] >= 0) cs[(size_t)s_cam[(size_t)s] + 1]++;
+            for (int c = 0; c < nfc; ++c) cs[(size_t)c + 1] += cs[(size_t)c];
+            std::vector<int> items((size_t)cs[(size_t)nfc]);
+            std::vector<int> fill(cs.begin(), cs.end() - 1);
+            for (int s = 0; s < no; ++s)
+                if (s_cam[(size_t)s] >= 0) items[(size_t)fill[(size_t)s_cam[(size_t)s]]++] = s;
+            camstart.insert(camstart.end(), cs.begin(), cs.end());
+            camitems.insert(camitems.end(), items.begin(), items.end());
+            max_citems = std::max(max_citems, (int)items.size());
+            int longest = 0;
+            for (int c = 0; c < nfc; ++c) longest = std::max(longest, cs[(size_t)c + 1] - cs[(size_t)c]);
+            pr.be_nch = ceil_div(longest, 64);
+            // (the same list as static records -- what cam_pass streams -- is gathered on the device: gather_cam_records)
+        }
+        if (nfc > 64) dev_entries_ok = false;
+        {
+            // room for the block entries when the device builds them: every pair of a point's run is the most there can be
+            long long bound = 0;
+            for (int p = 0; p < P.n_pt; ++p)
+            {
+                const long long run = pstart[(size_t)p + 1] - pstart[(size_t)p];
+                bound += run * run;
+            }
+            ent_bound[(size_t)b] = bound;
+        }
+        pr.blkstart_off = blkstart_total;
+        blkstart_total += nfc * nfc + 1;
+        mark(3);
+        mark(4);
         // point-major Schur pass: points grouped by camera set, work items of <= SET_CHUNK points, per-block lists of
         // the partial sums they produce
         pr.set_off  = (int)setitems.size();
@@ -3271,6 +3562,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             }
             cblkstart.push_back(run);
         }
+        mark(5);
         // relative pose constraints (IMU scenes): valid ones, per-camera incidence, per-block chains
         {
             pr.rpc_off    = (int)rpcmeta.size();
@@ -3318,6 +3610,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             rpcnext.insert(rpcnext.end(), nxt.begin(), nxt.end());
             rpcmeta.insert(rpcmeta.end(), mine.begin(), mine.end());
         }
+        mark(6);
         img_off += P.n_img;
         pt_off += P.n_pt;
         obs_off += no;
@@ -3343,6 +3636,36 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     h->max_rpc = max_rpc;
     h->point_wave_ok = wave_ok && max_wv > 0;
 
+    // block entries: on the device when every problem qualifies, by the host builder otherwise
+    static const bool host_entries = getenv("SNK_BA_HOST_ENTRIES") != nullptr;  // A/B and tests
+    const bool dev_entries = dev_entries_ok && !host_entries;
+    long long ent_total = 0, becnt_total = 0;
+    int max_be_waves = 0;
+    if (dev_entries)
+    {
+        for (int b = 0; b < count; ++b)
+        {
+            Prob& pr = probs[(size_t)b];
+            SNK_REQUIRE(ent_total + ent_bound[(size_t)b] < (1ll << 31), "scene list too large (block entries)");
+            pr.ent_off   = (int)ent_total;
+            pr.becnt_off = (int)becnt_total;
+            ent_total += ent_bound[(size_t)b];
+            becnt_total += (long long)pr.nfc * pr.be_nch * pr.nfc;
+            SNK_REQUIRE(becnt_total < (1ll << 31), "scene list too large (block entry counters)");
+            max_be_waves = std::max(max_be_waves, pr.nfc * pr.be_nch);
+        }
+    }
+    else
+    {
+        for (int b = 0; b < count; ++b)
+        {
+            probs[(size_t)b].be_nch  = 0;
+            probs[(size_t)b].ent_off = (int)blkent.size();
+            host_block_entries(b, LS.blkstart, LS.blkent);
+        }
+    }
+    h->probs.assign(probs.begin(), probs.end());  // again: with the block-entry offsets
+    mark(4);
     int rc;
     hipStream_t st = h->stream;
     const auto t_lists = std::chrono::steady_clock::now();
@@ -3366,15 +3689,24 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     UP(d_oorig, oorig);
     UP(d_camstart, camstart);
     UP(d_camitems, camitems);
-    UP(d_csobs, csobs);
+    if ((rc = h->d_csobs.reserve(std::max<size_t>(camitems.size(), 1) * sizeof(CamObs))) != SNK_OK) return rc;  // gather_cam_records
     UP(d_setitems, setitems);
     UP(d_setobs, setobs);
     UP(d_setpts, setpts);
     UP(d_setpairs, setpairs);
     UP(d_cblkstart, cblkstart);
     UP(d_cblkitems, cblkitems);
-    UP(d_blkstart, blkstart);
-    UP(d_blkent, blkent);
+    if (dev_entries)
+    {
+        if ((rc = h->d_blkstart.reserve((size_t)std::max(blkstart_total, 1) * sizeof(int))) != SNK_OK) return rc;
+        if ((rc = h->d_blkent.reserve((size_t)std::max<long long>(ent_total, 1) * sizeof(int4))) != SNK_OK) return rc;
+        if ((rc = h->d_becnt.reserve((size_t)std::max<long long>(becnt_total, 1) * sizeof(int))) != SNK_OK) return rc;
+    }
+    else
+    {
+        UP(d_blkstart, blkstart);
+        UP(d_blkent, blkent);
+    }
     UP(d_optidx, optidx);
     UP(d_wvpt, wvpt);
     UP(d_rpcmeta, rpcmeta);
@@ -3382,16 +3714,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     UP(d_camrpcstart, camrpcstart);
     UP(d_camrpcitems, camrpcitems);
     UP(d_blkrpc, blkrpc);
-#undef UP
-    if (tab.n > 0)
-    {
-        // enough workgroups per array to keep the bus busy: one per 64 KB of the largest list, 16 .. 256
-        unsigned big = 0;
-        for (int e = 0; e < tab.n; ++e) big = std::max(big, tab.bytes[e]);
-        const int gx = (int)std::min(256u, std::max(16u, big >> 16));
-        hipLaunchKernelGGL(copy_table_kernel, dim3(gx, tab.n), dim3(256), 0, st, tab);
-        SNK_LAUNCH_CHECK();
-    }
+    UP(d_pt_new, pt);  // points without observations stay put
     const auto t_up = std::chrono::steady_clock::now();
     const size_t nobs = (size_t)std::max(obs_off, 1), npt = (size_t)std::max(pt_off, 1);
 #define RS(buf, bytes) if ((rc = h->buf.reserve(bytes)) != SNK_OK) return rc
@@ -3443,16 +3766,33 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         W.scal = w;
     }
 #undef RS
-    SNK_HIP_CHECK(hipMemsetAsync(h->d_outlier.p, 0, (size_t)std::max(orig_off, 1), st));
-    SNK_HIP_CHECK(hipMemsetAsync(h->d_state.p, 0, (size_t)count * sizeof(State), st));
-    SNK_HIP_CHECK(hipMemsetAsync(h->d_r.p, 0, nobs * 4 * 8, st));
-    SNK_HIP_CHECK(hipMemsetAsync(h->d_x.p, 0, (size_t)std::max(vec_off, 1) * 8, st));
+#undef UP
+    // ... and the buffers that start as zeros are entries of the same table (source NULL): nine fill launches of ~5 us each
+    // stood between the upload and the first kernel of the solve
+    auto zero = [&](DevBuf& b, size_t bytes) -> int
+    {
+        SNK_REQUIRE(tab.n < COPY_TAB_MAX && bytes < (1ull << 32), "scene list too large for the upload table");
+        tab.src[tab.n] = nullptr, tab.dst[tab.n] = b.p, tab.bytes[tab.n] = (unsigned)bytes;
+        ++tab.n;
+        return SNK_OK;
+    };
+    if ((rc = zero(h->d_outlier, (size_t)std::max(orig_off, 1))) != SNK_OK) return rc;
+    if ((rc = zero(h->d_state, (size_t)count * sizeof(State))) != SNK_OK) return rc;
+    if ((rc = zero(h->d_r, nobs * 4 * 8)) != SNK_OK) return rc;
+    if ((rc = zero(h->d_x, (size_t)std::max(vec_off, 1) * 8)) != SNK_OK) return rc;
     // points without observations are in no work item of schur_fused: their cost, V^-1 and b_p are zero once and for all
-    SNK_HIP_CHECK(hipMemsetAsync(h->d_cost.p, 0, npt * 8, st));
-    SNK_HIP_CHECK(hipMemsetAsync(h->d_cost_new.p, 0, npt * 8, st));
-    SNK_HIP_CHECK(hipMemcpyAsync(h->d_pt_new.p, h->d_pt.p, npt * 3 * 8, hipMemcpyDeviceToDevice, st));  // points without observations stay put
-    SNK_HIP_CHECK(hipMemsetAsync(h->d_Vinv.p, 0, npt * 6 * 8, st));
-    SNK_HIP_CHECK(hipMemsetAsync(h->d_bp.p, 0, npt * 3 * 8, st));
+    if ((rc = zero(h->d_cost, npt * 8)) != SNK_OK) return rc;
+    if ((rc = zero(h->d_cost_new, npt * 8)) != SNK_OK) return rc;
+    if ((rc = zero(h->d_Vinv, npt * 6 * 8)) != SNK_OK) return rc;
+    if ((rc = zero(h->d_bp, npt * 3 * 8)) != SNK_OK) return rc;
+    {
+        // enough workgroups per array to keep the bus busy: one per 64 KB of the largest list, 16 .. 256
+        unsigned big = 0;
+        for (int e = 0; e < tab.n; ++e) big = std::max(big, tab.bytes[e]);
+        const int gx = (int)std::min(256u, std::max(16u, big >> 16));
+        hipLaunchKernelGGL(copy_table_kernel, dim3(gx, tab.n), dim3(256), 0, st, tab);
+        SNK_LAUNCH_CHECK();
+    }
     if (!h->pcg_large)
     {
         // process-wide, once, to the most the kernels can use (enqueue_lm keeps S in LDS only when it fits 158 KB)
@@ -3510,15 +3850,86 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     A.rhs       = h->d_rhs.as<double>();
     A.x         = h->d_x.as<double>();
     A.chi2      = h->d_chi2.as<double>();
+    // the lists the device builds from the uploaded ones (stream ordered behind copy_table_kernel)
+    if (max_citems > 0)
+    {
+        hipLaunchKernelGGL(gather_cam_records, dim3(ceil_div(max_citems, 256), count), dim3(256), 0, st, A, h->d_csobs.as<CamObs>());
+        SNK_LAUNCH_CHECK();
+    }
+    if (dev_entries)
+    {
+        if (max_be_waves > 0)
+        {
+            hipLaunchKernelGGL(block_entries_count, dim3(max_be_waves, count), dim3(64), 0, st, A, h->d_becnt.as<int>());
+            SNK_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(block_entries_scan, dim3(count), dim3(256), 0, st, A, h->d_becnt.as<int>(), h->d_blkstart.as<int>());
+        SNK_LAUNCH_CHECK();
+        if (max_be_waves > 0)
+        {
+            hipLaunchKernelGGL(block_entries_fill, dim3(max_be_waves, count), dim3(64), 0, st, A, h->d_becnt.as<int>(), h->d_blkent.as<int4>());
+            SNK_LAUNCH_CHECK();
+        }
+    }
     const auto t_rs = std::chrono::steady_clock::now();
-    SNK_HIP_CHECK(hipStreamSynchronize(st));
     static const bool prof = getenv("SNK_BA_PROFILE_CREATE") != nullptr;  // host-side cost of a scene hand-over, in microseconds
+    static const bool check_lists = getenv("SNK_BA_CHECK_LISTS") != nullptr;  // tests / fuzzers: device-built lists against the host builder
+    if (check_lists)
+    {
+        // the host builder's lists (never uploaded here) against what the kernels wrote
+        SNK_HIP_CHECK(hipStreamSynchronize(st));
+        std::vector<CamObs> d_rec(camitems.size());
+        if (!d_rec.empty()) SNK_HIP_CHECK(hipMemcpy(d_rec.data(), h->d_csobs.p, d_rec.size() * sizeof(CamObs), hipMemcpyDeviceToHost));
+        for (int b = 0; b < count; ++b)
+        {
+            const snk_ba_problem& P = problems[b];
+            const Prob& pr          = probs[(size_t)b];
+            const int n_items       = camstart[(size_t)pr.camstart_off + (size_t)pr.nfc];
+            for (int k = 0; k < n_items; ++k)
+            {
+                const int s = camitems[(size_t)pr.citem_off + (size_t)k], o = oorig[(size_t)pr.obs_off + (size_t)s] - pr.orig_off;
+                const CamObs& r = d_rec[(size_t)pr.citem_off + (size_t)k];
+                const bool same = r.u == P.obs_uv[o][0] && r.v == P.obs_uv[o][1] && r.depth == P.obs_depth[o] && r.weight == P.obs_weight[o] &&
+                                  r.pt == P.obs_pt[o] && r.orig == pr.orig_off + o && r.img == P.obs_img[o] &&
+                                  r.ptfree == (P.pt_const[P.obs_pt[o]] ? 0 : 1);
+                SNK_REQUIRE(same, "SNK_BA_CHECK_LISTS: a device-gathered camera record differs from the caller's observation");
+            }
+        }
+        if (dev_entries)
+        {
+            std::vector<int> d_bs((size_t)blkstart_total);
+            std::vector<int4> d_ent((size_t)ent_total);
+            SNK_HIP_CHECK(hipMemcpy(d_bs.data(), h->d_blkstart.p, d_bs.size() * sizeof(int), hipMemcpyDeviceToHost));
+            if (!d_ent.empty()) SNK_HIP_CHECK(hipMemcpy(d_ent.data(), h->d_blkent.p, d_ent.size() * sizeof(int4), hipMemcpyDeviceToHost));
+            pvec<int> h_bs;
+            pvec<int4> h_ent;
+            for (int b = 0; b < count; ++b)
+            {
+                const Prob& pr  = probs[(size_t)b];
+                const size_t nb = (size_t)pr.nfc * pr.nfc, bs_at = h_bs.size(), ent_at = h_ent.size();
+                host_block_entries(b, h_bs, h_ent);
+                for (size_t k = 0; k <= nb; ++k)
+                    SNK_REQUIRE(d_bs[(size_t)pr.blkstart_off + k] == h_bs[bs_at + k], "SNK_BA_CHECK_LISTS: device-built block starts differ from the host builder's");
+                SNK_REQUIRE((long long)h_bs[bs_at + nb] <= ent_bound[(size_t)b], "SNK_BA_CHECK_LISTS: block entries exceed their bound");
+                for (int k = 0; k < h_bs[bs_at + nb]; ++k)
+                {
+                    const int4 d = d_ent[(size_t)pr.ent_off + (size_t)k], w = h_ent[ent_at + (size_t)k];
+                    SNK_REQUIRE(d.x == w.x && d.y == w.y && d.z == w.z, "SNK_BA_CHECK_LISTS: device-built block entries differ from the host builder's");
+                }
+            }
+        }
+    }
     if (prof)
     {
+        SNK_HIP_CHECK(hipStreamSynchronize(st));
         const auto t_end = std::chrono::steady_clock::now();
         auto us = [](auto a, auto b) { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
         fprintf(stderr, "[snk_ba_set_problems] lists %lld us, uploads %lld us, reserve+memset %lld us, sync %lld us\n", us(t_begin, t_lists),
                 us(t_lists, t_up), us(t_up, t_rs), us(t_rs, t_end));
+        fprintf(stderr, "[snk_ba_set_problems] lists in us: values+sort %lld, observation arrays %lld, wave items %lld, camera lists %lld, "
+                        "block entries %lld, point sets %lld, constraints %lld, rest %lld\n",
+                sec_us[0] / 1000, sec_us[1] / 1000, sec_us[2] / 1000, sec_us[3] / 1000, sec_us[4] / 1000, sec_us[5] / 1000, sec_us[6] / 1000,
+                sec_us[7] / 1000);
     }
     return SNK_OK;
 }
@@ -3560,12 +3971,20 @@ int snk_ba_reset(snk_ba* h)
     return SNK_OK;
 }
 
-static int enqueue_lm(snk_ba* h, int iterations, Launcher& L)
+static int enqueue_lm(snk_ba* h, int iterations, Launcher& L, bool only_marked = false)
 {
-    const Opt O     = make_opt(h->opt);
-    const Arrays& A = h->arr;
-    const int B     = h->count;
-    LAUNCH(begin_solve, dim3(ceil_div(B, 64)), dim3(64), 0, h->d_state.as<State>(), B, O.lambda_init);
+    const Opt O = make_opt(h->opt);
+    const int B = h->count;
+    Arrays A    = h->arr;
+    const int cond = only_marked ? 1 : 0;
+    if (only_marked)
+    {
+        int rc = h->d_probcond.reserve((size_t)B * sizeof(Prob));
+        if (rc != SNK_OK) return rc;
+        LAUNCH(select_marked, dim3(ceil_div(B, 64)), dim3(64), 0, h->d_prob.as<Prob>(), h->d_probcond.as<Prob>(), h->d_state.as<State>(), B);
+        A.prob = h->d_probcond.as<Prob>();
+    }
+    LAUNCH(begin_solve, dim3(ceil_div(B, 64)), dim3(64), 0, h->d_state.as<State>(), B, O.lambda_init, cond);
     const dim3 gpt(std::max(1, ceil_div(h->max_np, 128)), B);
     size_t pcg_lds        = (size_t)h->max_n6 * 9 * 8 + (size_t)h->max_nfc * 36 * 8;
     const size_t s_bytes  = (size_t)h->max_n6 * h->max_n6 * 8;
@@ -3627,8 +4046,15 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L)
                     LAUNCH(schur_sum, dim3(nbx * 8 * ceil_div(B, 8)), dim3(256), 0, A, nbx, B);
                 }
                 else
-                    LAUNCH(schur_pass, dim3(nbx * 8 * ceil_div(B, 8)), dim3(256), 0, A,
-                                       h->point_wave_ok && !no_wave ? 1 : 0, nbx, B);
+                {
+                    static const bool wide_off = getenv("SNK_BA_NO_SCHUR_WIDE") != nullptr;  // A/B
+                    const int nb = h->max_nfc * h->max_nfc;
+                    if (B < 16 && (long long)nb * B <= 8192 && !wide_off)
+                        LAUNCH(schur_pass<4>, dim3(nb * B), dim3(256), 0, A, h->point_wave_ok && !no_wave ? 1 : 0, nb, B);
+                    else
+                        LAUNCH(schur_pass<1>, dim3(nbx * 8 * ceil_div(B, 8)), dim3(256), 0, A,
+                                           h->point_wave_ok && !no_wave ? 1 : 0, nbx, B);
+                }
             }
             if (!h->pcg_large)
                 if (s_in_lds)
@@ -3661,8 +4087,7 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L)
         else if (h->point_wave_ok && !no_wave)
         {
             const dim3 gwv(ceil_div(h->max_wv, 4), B);
-            LAUNCH(update_wave, gwv, dim3(256), 0, A, O);
-            LAUNCH(update_pass, dim3(std::max(1, ceil_div(h->max_ni, 128)), B), dim3(128), 0, A, 1);
+            LAUNCH(update_wave, dim3(gwv.x + std::max(1, ceil_div(h->max_ni, 256)), B), dim3(256), 0, A, O, (int)gwv.x);
             LAUNCH(cost_wave, gwv, dim3(256), 0, A, O);
         }
         else
@@ -3671,7 +4096,7 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L)
             LAUNCH(point_pass<1>, gpt, dim3(128), 0, A, O);
         }
         if (h->max_rpc > 0 && h->max_nfc > 0) LAUNCH(rpc_pass, dim3(ceil_div(h->max_rpc, 64), B), dim3(64), 0, A, 1);
-        LAUNCH(accept_pass, dim3(B), dim3(ACC_THREADS), 0, A);
+        LAUNCH(accept_pass, dim3(B), dim3(ACC_THREADS), 0, A, cond);
     }
     if (L.err != hipSuccess)
     {
@@ -3738,6 +4163,88 @@ int snk_ba_solve(snk_ba* h, int iterations, double* cost_initial, double* cost_f
         if (cost_initial) cost_initial[b] = st[(size_t)b].cost_initial;
         if (cost_final) cost_final[b] = st[(size_t)b].cost;
     }
+    return SNK_OK;
+}
+
+int snk_ba_solve_local_scene(snk_ba* h, int problem, double chi2_mono, double chi2_stereo, int extra_iterations, uint8_t* obs_outlier,
+                             int* n_marked, double* cost_initial, double* cost_final, double (*pose)[7], double (*pt)[3])
+{
+    SNK_REQUIRE(h != nullptr && h->count > 0, "no problem set");
+    SNK_REQUIRE(problem >= 0 && problem < h->count && n_marked != nullptr, "bad arguments");
+    SNK_REQUIRE(chi2_mono > 0.0 && chi2_stereo > 0.0 && extra_iterations >= 0, "thresholds must be positive, extra_iterations >= 0");
+    SNK_HIP_CHECK(hipSetDevice(h->device));
+    int rc = snk_ba_solve_async(h, h->opt.max_iterations);  // initAndSolve
+    if (rc != SNK_OK) return rc;
+    const Opt O = make_opt(h->opt);
+    // chi-square pass at the solved state, marking on the device (the count and the costs of this moment stay in the state)
+    hipLaunchKernelGGL(point_pass<2>, dim3(std::max(1, ceil_div(h->max_np, 128)), h->count), dim3(128), 0, h->stream, h->arr, O);
+    SNK_LAUNCH_CHECK();
+    int max_no = 1;
+    for (const Prob& q : h->probs) max_no = q.no > max_no ? q.no : max_no;
+    hipLaunchKernelGGL(mark_outliers_kernel, dim3(ceil_div(max_no, 256), h->count), dim3(256), 0, h->stream, h->arr,
+                       h->d_outlier.as<unsigned char>(), chi2_mono, chi2_stereo);
+    SNK_LAUNCH_CHECK();
+    // The extra iteration(s) (:399-410) run for the problems that had something marked.  Default: enqueued right behind the
+    // pass, conditional on the device (select_marked) -- the whole call is ONE synchronisation.  SNK_BA_LOCAL_SYNC=1 (A/B), and
+    // scenes on the multi-workgroup PCG (whose launch sequence sizes itself on the host): read the count back and decide here.
+    static const bool sync_env = getenv("SNK_BA_LOCAL_SYNC") != nullptr;
+    const bool on_device       = !sync_env && !h->pcg_large;
+    State st{};
+    bool have_state = false;
+    if (extra_iterations > 0 && on_device)
+    {
+        Launcher direct;
+        direct.st = h->stream;
+        if ((rc = enqueue_lm(h, extra_iterations, direct, true)) != SNK_OK) return rc;
+    }
+    else if (extra_iterations > 0)
+    {
+        if ((rc = h->h_stage.reserve(64 + sizeof(State))) != SNK_OK) return rc;
+        SNK_HIP_CHECK(hipMemcpyAsync(h->h_stage.p, h->d_state.as<State>() + problem, sizeof(State), hipMemcpyDeviceToHost, h->stream));
+        SNK_HIP_CHECK(hipStreamSynchronize(h->stream));
+        memcpy(&st, h->h_stage.p, sizeof(State));
+        have_state = true;
+        // every problem of a batch is solved again when the one asked for has marks (the documented behaviour of this path)
+        if (st.marked > 0 && (rc = snk_ba_solve_async(h, extra_iterations)) != SNK_OK) return rc;
+    }
+    // One kernel writes the results into the pinned buffer (device visible) instead of one copy-engine transfer each; its
+    // 16-byte loads want aligned sources: every piece is copied from the 16-byte boundary below it.
+    const Prob& pr = h->probs[(size_t)problem];
+    const size_t n = (size_t)h->orig_n[(size_t)problem];
+    const char* src[4] = {reinterpret_cast<const char*>(h->d_pose.as<double>() + (size_t)pr.img_off * 7),
+                          reinterpret_cast<const char*>(h->d_pt.as<double>() + (size_t)pr.pt_off * 3),
+                          reinterpret_cast<const char*>(h->d_outlier.as<unsigned char>() + h->orig_off[(size_t)problem]),
+                          reinterpret_cast<const char*>(h->d_state.as<State>() + problem)};
+    void* dst[4]          = {pose, pt, obs_outlier, &st};
+    const size_t bytes[4] = {pose ? (size_t)pr.ni * 56 : 0, pt ? (size_t)pr.np * 24 : 0, obs_outlier ? n : 0, have_state ? 0 : sizeof(State)};
+    size_t at[4], shift[4], total = 0;
+    for (int k = 0; k < 4; ++k)
+    {
+        shift[k] = (size_t)(reinterpret_cast<uintptr_t>(src[k]) & 15u);
+        at[k]    = total;
+        total += (bytes[k] + shift[k] + 255) & ~(size_t)255;
+    }
+    if ((rc = h->h_stage.reserve(total + 64)) != SNK_OK) return rc;
+    char* hs = h->h_stage.as<char>();
+    CopyTab tab;
+    tab.n = 0;
+    for (int k = 0; k < 4; ++k)
+    {
+        if (!bytes[k]) continue;
+        tab.src[tab.n] = src[k] - shift[k], tab.dst[tab.n] = hs + at[k], tab.bytes[tab.n] = (unsigned)(bytes[k] + shift[k]);
+        ++tab.n;
+    }
+    if (tab.n > 0)
+    {
+        hipLaunchKernelGGL(copy_table_kernel, dim3(4, tab.n), dim3(256), 0, h->stream, tab);
+        SNK_LAUNCH_CHECK();
+    }
+    SNK_HIP_CHECK(hipStreamSynchronize(h->stream));
+    for (int k = 0; k < 4; ++k)
+        if (bytes[k]) memcpy(dst[k], hs + at[k] + shift[k], bytes[k]);
+    *n_marked = st.marked;
+    if (cost_initial) *cost_initial = st.first_cost_initial;  // the reference returns the FIRST solve's costs (LocalBundleAdjustment.cpp:412)
+    if (cost_final) *cost_final = st.first_cost;
     return SNK_OK;
 }
 

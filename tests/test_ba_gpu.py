@@ -311,3 +311,97 @@ def test_point_only_and_pose_only_adaptors_at_global_scale(orc):
             assert np.array_equal(pose, sc["pose"])
         else:
             assert np.array_equal(pt, sc["pt"])
+
+
+def _local_scene_by_steps(ba, sc, problem, pre):
+    """The reference's sequence call by call (LocalBundleAdjustment.cpp:357-410), the thresholding on the host."""
+    if pre is not None:
+        ba.set_outliers(problem, pre)
+    ci, cf = ba.initAndSolve()
+    chi = ba.residuals(problem)
+    thr = np.where(np.asarray(sc["obs_depth"]) > 0, 2.3**2, 2.1**2)
+    mark = chi > thr  # chi is 0 for invalid observations and for those already flagged
+    flags = mark.astype(np.uint8) if pre is None else (mark | (pre != 0)).astype(np.uint8)
+    if mark.any():
+        ba.set_outliers(problem, flags)
+        ba.solve(1)
+    pose, pt, _ = ba.state(problem)
+    return int(mark.sum()), ci[problem], cf[problem], pose, pt, flags
+
+
+@pytest.mark.parametrize("case", ["outliers", "clean", "preset", "invalid"])
+def test_solve_local_scene_equals_the_call_sequence(orc, case):
+    """snk_ba_solve_local_scene == solve -> residuals -> host threshold -> set_outliers -> solve(1) -> get_state, bit for bit
+    (same kernels in the same order; only the thresholding moved to the device)."""
+    from snake_slam_amd import synth
+    from snake_slam_amd.ba import BARec, lba_options
+
+    sc, _ = synth.ba_scene(n_kf=8, n_pt=300, obs_per_pt=5, seed=21, outlier_frac=0.0 if case == "clean" else 0.05,
+                           pixel_noise=0.05 if case == "clean" else 0.5)
+    pre = None
+    if case == "preset":
+        pre = (np.random.default_rng(3).random(len(sc["obs_img"])) < 0.1).astype(np.uint8)
+    if case == "invalid":
+        sc["obs_img"] = sc["obs_img"].copy()
+        sc["obs_pt"] = sc["obs_pt"].copy()
+        sc["obs_img"][7] = -1
+        sc["obs_pt"][11] = 10**6
+        sc["obs_uv"] = sc["obs_uv"].copy()
+        sc["obs_uv"][7] += 500.0   # would be far above the threshold if it were looked at
+        sc["obs_uv"][11] += 500.0
+    a, b = BARec(lba_options()), BARec(lba_options())
+    a.create(sc)
+    b.create(sc)
+    want = _local_scene_by_steps(a, sc, 0, pre)
+    if pre is not None:
+        b.set_outliers(0, pre)
+    got = b.solve_local_scene(2.1**2, 2.3**2)
+    assert got[0] == want[0] and (got[0] == 0) == (case == "clean")
+    assert got[1] == want[1] and got[2] == want[2]
+    assert np.array_equal(got[3], want[3]) and np.array_equal(got[4], want[4])
+    assert np.array_equal(got[5], want[5])
+    if case == "invalid":
+        assert got[5][7] == 0 and got[5][11] == 0
+    # and the oracle agrees with the whole sequence
+    wpose, wpt, _, _, _ = orc.ba_solve(sc, orc.ba_options(), iterations=3, outlier=pre)
+    if got[0]:
+        sc2 = dict(sc, pose=wpose, pt=wpt)
+        wpose, wpt, _, _, _ = orc.ba_solve(sc2, orc.ba_options(), iterations=1, outlier=got[5])
+    assert rmse(got[4], wpt) <= TOL and rmse(got[3][:, 4:], wpose[:, 4:]) <= TOL and rmse(got[3][:, :4], wpose[:, :4]) <= TOL
+    # a second scene through the same handles: counts and staging are reset
+    sc3, _ = synth.ba_scene(n_kf=6, n_pt=150, obs_per_pt=4, seed=22, outlier_frac=0.1)
+    a.create(sc3)
+    b.create(sc3)
+    want = _local_scene_by_steps(a, sc3, 0, None)
+    got = b.solve_local_scene(2.1**2, 2.3**2)
+    assert got[0] == want[0] > 0 and np.array_equal(got[3], want[3]) and np.array_equal(got[4], want[4]) and np.array_equal(got[5], want[5])
+    a.close()
+    b.close()
+
+
+def test_solve_local_scene_in_a_batch(orc):
+    """Several windows loaded: every window is solved and marked; the outputs are those of the window asked for."""
+    from snake_slam_amd import synth
+    from snake_slam_amd.ba import BARec, lba_options
+
+    scs = [synth.ba_scene(n_kf=6, n_pt=120 + 30 * i, obs_per_pt=4, seed=40 + i, outlier_frac=0.05 * i)[0] for i in range(3)]
+    for problem in (0, 2):
+        one, many = BARec(lba_options()), BARec(lba_options())
+        one.create(scs[problem])
+        many.create(scs)
+        want = one.solve_local_scene(2.1**2, 2.3**2)
+        got = many.solve_local_scene(2.1**2, 2.3**2, problem=problem)
+        assert got[0] == want[0]
+        assert rmse(got[3], want[3]) <= 1e-9 and rmse(got[4], want[4]) <= 1e-9 and np.array_equal(got[5], want[5])
+        one.close()
+        many.close()
+    import ctypes as C
+
+    ba = BARec(lba_options())
+    n = C.c_int(0)
+    assert ba._lib.snk_ba_solve_local_scene(ba._h, 0, 4.0, 5.0, 1, None, C.byref(n), None, None, None, None) != 0  # no scene loaded
+    ba.create(scs[0])
+    assert ba._lib.snk_ba_solve_local_scene(ba._h, 1, 4.0, 5.0, 1, None, C.byref(n), None, None, None, None) != 0  # index out of range
+    assert ba._lib.snk_ba_solve_local_scene(ba._h, 0, 4.0, 5.0, 1, None, None, None, None, None, None) != 0        # n_marked is required
+    assert ba._lib.snk_ba_solve_local_scene(ba._h, 0, 4.0, 5.0, 1, None, C.byref(n), None, None, None, None) == 0  # every output optional
+    ba.close()

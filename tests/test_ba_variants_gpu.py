@@ -22,9 +22,65 @@ ROOT = Path(__file__).resolve().parent.parent
     {"SNK_BA_SCHUR_SET_MIN_ITEMS": "1", "SNK_BA_FUSED_K10": "1"},       # schur_fused<4> also where points have 9-10 free observations
     {"SNK_BA_SCHUR_SET_MIN_ITEMS": "1", "SNK_BA_NO_SCHUR_FUSED": "1"},  # point_wave + schur_mfma (W through HBM)
     {"SNK_BA_SCHUR_SET_MIN_ITEMS": "1", "SNK_BA_NO_SCHUR_MFMA": "1"},   # point_wave + the vector-ALU schur_set          # explicitly built hipGraph already for the first solve of every scene
+    {"SNK_BA_CHECK_LISTS": "1", "SNK_BA_NO_SCHUR_SET": "1"},            # every scene hand-over compares the device-built lists (camera records, block entries) with the host builder's
+    {"SNK_BA_HOST_ENTRIES": "1", "SNK_BA_NO_SCHUR_SET": "1"},           # block entries by the host builder (what scenes with > 64 free cameras use)
+    {"SNK_BA_LOCAL_SYNC": "1"},                                         # snk_ba_solve_local_scene decides about the extra iteration on the host (count read back)
+    {"SNK_BA_NO_SCHUR_WIDE": "1", "SNK_BA_NO_SCHUR_SET": "1"},          # block-major schur_pass with one wavefront per block also for single windows
 ])
 def test_ba_parity_suite_with_forced_path(env):
     r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_ba_gpu.py"), "-m", "gpu", "-x", "-q", "-p",
                         "no:cacheprovider"], env=dict(os.environ, **env), capture_output=True, text=True, cwd=str(ROOT), timeout=600)
     assert r.returncode == 0, (env, r.stdout[-2000:], r.stderr[-1000:])
     assert " passed" in r.stdout
+
+
+def test_device_built_lists_equal_the_host_builders():
+    """The camera records and camera-pair block entries are built by kernels (gather_cam_records, block_entries_*) when a scene
+    has <= 64 free cameras and no camera twice on a point.  Child process with SNK_BA_CHECK_LISTS=1: snk_ba_set_problems
+    compares them with the host builder element by element (and fails on a difference); SNK_BA_HOST_ENTRIES=1 must give
+    bit-identical solutions (same lists, same kernels)."""
+    code = r"""
+import numpy as np, os, sys
+from snake_slam_amd import synth
+from snake_slam_amd.ba import BARec, lba_options
+rng = np.random.default_rng(5)
+scenes = []
+for seed, (kf, npt, opp) in enumerate([(20, 2000, 8), (3, 10, 2), (8, 300, 5), (64, 500, 12), (66, 400, 6), (5, 1, 5), (12, 700, 12)]):
+    sc, _ = synth.ba_scene(n_kf=kf, n_pt=npt, obs_per_pt=opp, seed=100 + seed, outlier_frac=0.02, n_fixed=1 + seed % 3)
+    sc["pt_const"][: npt // 7] = 1
+    sc["obs_img"] = sc["obs_img"].copy(); sc["obs_pt"] = sc["obs_pt"].copy()
+    if len(sc["obs_img"]) > 20:
+        sc["obs_img"][3] = -1; sc["obs_pt"][7] = 10**6
+    scenes.append(sc)
+dup, _ = synth.ba_scene(n_kf=6, n_pt=80, obs_per_pt=4, seed=77)    # one camera twice on a point: host builder
+dup["obs_img"] = dup["obs_img"].copy(); dup["obs_img"][1] = dup["obs_img"][0]
+allc, _ = synth.ba_scene(n_kf=4, n_pt=50, obs_per_pt=3, seed=78)   # every camera constant: no blocks at all
+allc["img_const"][:] = 1
+empty = dict(scenes[1], obs_img=scenes[1]["obs_img"][:0], obs_pt=scenes[1]["obs_pt"][:0], obs_uv=scenes[1]["obs_uv"][:0],
+             obs_depth=scenes[1]["obs_depth"][:0], obs_weight=scenes[1]["obs_weight"][:0])
+out = []
+ba = BARec(lba_options())
+for group in [[s] for s in scenes] + [[dup], [allc], [empty], scenes[:3] + [allc, empty] + scenes[3:4], scenes[:2] + [dup]]:
+    ba.create(group)
+    ba.initAndSolve()
+    for i in range(len(group)):
+        pose, pt, _ = ba.state(i)
+        out.append(pose); out.append(pt)
+ba.close()
+np.savez(sys.argv[1], *out)
+print("ok")
+"""
+    import numpy as np
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        res = {}
+        for name, env in (("device", {"SNK_BA_CHECK_LISTS": "1"}), ("host", {"SNK_BA_HOST_ENTRIES": "1"})):
+            f = os.path.join(d, name + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, PYTHONPATH=str(ROOT), **env), capture_output=True, text=True,
+                               cwd=str(ROOT), timeout=600)
+            assert r.returncode == 0 and "ok" in r.stdout, (name, r.stdout[-1500:], r.stderr[-1500:])
+            res[name] = np.load(f)
+        assert len(res["device"].files) == len(res["host"].files) > 0
+        for k in res["device"].files:
+            assert np.array_equal(res["device"][k], res["host"][k]), k
