@@ -191,6 +191,25 @@ int main(int argc, char** argv)
             wr("out_ba_cost2", std::vector<double>{r2.cost_initial, r2.cost_final, (double)n_out});
             wr("out_ba_outlier", sc.obs_outlier);
             wr("out_ba_pose2", sc.poses);
+            wr("out_ba_pt2", sc.points);
+            for (int round = 0; round < 2; ++round)
+            {
+                // BARec::solveLocalScene (one library call) from the scene as it was read: with the reference's thresholds (this
+                // scene has nothing to mark: the result is the first solve's) and with thresholds that mark a good part of it
+                Scene sf = sc;
+                sf.poses  = rd<std::array<double, 7>>("ba_pose");
+                sf.points = rd<std::array<double, 3>>("ba_pt");
+                sf.obs_outlier.clear();
+                BARec bf;
+                bf.create(sf);
+                int marked = -1;
+                const OptimizationResults rf = round == 0 ? bf.solveLocalScene(4.41, 5.29, &marked) : bf.solveLocalScene(0.3, 0.4, &marked);
+                const std::string tag = round == 0 ? "out_ba_fused" : "out_ba_fused_low";
+                wr(tag + "_pose", sf.poses);
+                wr(tag + "_pt", sf.points);
+                wr(tag + "_outlier", sf.obs_outlier);
+                wr(tag + "_cost", std::vector<double>{rf.cost_initial, rf.cost_final, (double)marked});
+            }
             // GlobalBundleAdjustment::PointBA (:103-122) and the BAPoseOnly of RealignIntermiediateFrames (:306-316), each from
             // the scene as it was read
             Scene sp = sc;

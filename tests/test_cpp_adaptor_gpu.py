@@ -111,6 +111,27 @@ def test_cpp_adaptor_runs_the_pipeline_and_matches_golden(tmp_path, orc):
     c2 = get("ba_cost2", np.float64)
     assert int(c2[2]) == int(outl.sum()) and np.allclose(c2[:2], [wc0, wc1], rtol=1e-7)
     assert rm(get("ba_pose2", np.float64).reshape(-1, 7), wpose) <= 1e-5
+    # BARec::solveLocalScene (snk_ba_solve_local_scene), bit for bit the call-by-call sequence of the Python mirror: with the
+    # reference's thresholds this scene has nothing to mark (no extra iteration: the first solve's result), with low ones it has
+    from snake_slam_amd.ba import BARec, lba_options
+
+    s_in = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
+    for tag, (t_mono, t_stereo) in (("ba_fused", (4.41, 5.29)), ("ba_fused_low", (0.3, 0.4))):
+        ba = BARec(lba_options())
+        ba.create(s_in)
+        ci, cf_ = ba.initAndSolve()
+        mask = (ba.residuals(0) > np.where(s_in["obs_depth"] > 0, t_stereo, t_mono)).astype(np.uint8)
+        if mask.any():
+            ba.set_outliers(0, mask)
+            ba.solve(1)
+        wp, wx, _ = ba.state(0)
+        ba.close()
+        assert (mask.sum() > 0) == (tag == "ba_fused_low")
+        assert np.array_equal(get(tag + "_pose", np.float64).reshape(-1, 7), wp) and np.array_equal(get(tag + "_pt", np.float64).reshape(-1, 3), wx)
+        assert np.array_equal(get(tag + "_outlier", np.uint8), mask)
+        cfu = get(tag + "_cost", np.float64)
+        assert int(cfu[2]) == int(mask.sum()) and cfu[0] == ci[0] and cfu[1] == cf_[0]
+    assert np.array_equal(get("ba_fused_pose", np.float64), get("ba_pose", np.float64))
     # BAPointOnly / BAPoseOnly (GlobalBundleAdjustment.cpp:103-122, 306-316): the oracle on the scene with every image /
     # every point held, global options (4 iterations, PCG <= 40)
     s0 = {k[3:]: g[k] for k in g.files if k.startswith("in_")}

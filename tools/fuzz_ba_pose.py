@@ -97,7 +97,14 @@ def check_pose(rng, ref):
     opt = orc.pose_options()
     pose_w, out_w, inl_w = orc.pose_refine(pr["pose0"], cam, pr["wps"], pr["obs"], opt)
     if not np.allclose(got[0], pose_w, rtol=0, atol=1e-9 if n >= 7 else 1e-5):  # 3 matches: barely determined, differences in the last bits are amplified
-        return f"pose n {n}: max |d| {np.abs(got[0] - pose_w).max():.3g}"
+        flat = False
+        if n < 7:
+            # ... without bound when outlier rounds leave fewer constraints than unknowns: then the two poses must at least be
+            # equally good (same residuals along the flat direction) -- seed 11, case 8073: |d| 1.1e-4, chi2 equal to 1e-9
+            c_got, c_want = (orc.pose_chi2(p_, cam, pr["wps"], pr["obs"]) for p_ in (got[0], pose_w))
+            flat = bool(np.allclose(c_got, c_want, rtol=1e-6, atol=1e-9))
+        if not flat:
+            return f"pose n {n}: max |d| {np.abs(got[0] - pose_w).max():.3g}"
     diff = np.nonzero(got[1] != out_w)[0]
     if len(diff):
         chi2 = orc.pose_chi2(pose_w, cam, pr["wps"], pr["obs"])
