@@ -2279,6 +2279,163 @@ __global__ __launch_bounds__(PCG_THREADS) void pcg_solve(Arrays A, Opt O)
     if (tid == 0) A.state[pb].pcg_iters += iters;
 }
 
+// Local-BA sized systems (n6 <= 128), S in REGISTERS.  Same algorithm, same summation order as the replicated
+// four-wavefront loop of pcg_solve<true> (bit-identical results), but each wavefront keeps its column quarter of S -- two
+// rows per lane x <= 32 columns = <= 64 doubles -- in VGPRs, loaded once straight from global memory: the 58 ds_reads of S
+// per lane and iteration are gone (what is left reads p, a broadcast), and without the 104 KB of S in LDS two workgroups
+// share a compute unit (the loop is a dependency chain: a second one fills its bubbles).  LDS: r, z, p, Ap | ps | xs |
+// Minv | diagonal blocks | [2][4][128] partial products = 27 KB for 19 free cameras.
+constexpr int PCG_SMALL_COLS = 32;
+__global__ __launch_bounds__(PCG_THREADS, 2) void pcg_small(Arrays A, Opt O)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ double red[PCG_THREADS];
+    const int pb  = blockIdx.x;
+    const Prob pr = A.prob[pb];
+    const int n6 = pr.n6, nfc = pr.nfc;
+    const int tid = threadIdx.x;
+    double* r  = reinterpret_cast<double*>(smem_raw);
+    double* z  = r + n6;
+    double* p  = z + n6;
+    double* ps = p + 2 * n6;   // behind Ap's slot (the vector block r, z, p, Ap becomes the wavefronts' private r)
+    double* Mi = ps + 5 * n6;  // ps [4][n6] + xs [n6] (xs unused here: x lives in registers)
+    double* Sd = Mi + nfc * 36;
+    double* ex = Sd + nfc * 36;  // [2][4][128]
+    const double* Sg  = A.S + pr.s_off;
+    const double* rhs = A.rhs + pr.vec_off;
+    double* x         = A.x + pr.vec_off;
+    if (n6 == 0) return;
+    const int wave = tid >> 6, lane = tid & 63;
+    const bool v0 = lane < n6, v1 = lane + 64 < n6;
+    // this wavefront's column quarter (even bounds, as in pcg_solve) into registers; issued first, consumed after the set-up
+    const int cb = (((n6 + 3) >> 2) + 1) & ~1;
+    const int ub = min(wave * cb, n6), ue = min(ub + cb, n6);
+    const int ncols = ue - ub, nb8 = (ncols >> 3) << 3;
+    double sa[PCG_SMALL_COLS], sb[PCG_SMALL_COLS];
+#pragma unroll
+    for (int j = 0; j < PCG_SMALL_COLS; ++j)
+    {
+        const double* row = Sg + (size_t)(ub + j) * n6 + lane;  // column q == row q (symmetric): coalesced along the row
+        sa[j] = j < ncols && v0 ? row[0] : 0.0;
+        sb[j] = j < ncols && v1 ? row[64] : 0.0;
+    }
+    // the diagonal blocks through LDS (one load per thread instead of 36 dependent ones in the Cholesky), then the block inverses
+    for (int t = tid; t < nfc * 36; t += PCG_THREADS)
+    {
+        const int c = t / 36, e = t - c * 36, i = e / 6, j = e - i * 6;
+        Sd[t] = Sg[(size_t)(c * 6 + i) * n6 + c * 6 + j];
+    }
+    __syncthreads();
+    for (int c = tid; c < nfc; c += PCG_THREADS) inv6_spd(Sd + c * 36, 6, Mi + c * 36);
+    double part = 0.0;
+    for (int q = tid; q < n6; q += PCG_THREADS)
+    {
+        const double v = rhs[q];
+        r[q] = v;
+        part += v * v;
+    }
+    const double bnorm2 = block_sum<PCG_THREADS>(part, red, tid);
+    part = 0.0;
+    for (int q = tid; q < n6; q += PCG_THREADS)
+    {
+        const int c = q / 6, a = q - c * 6;
+        double sacc = 0.0;
+        for (int b = 0; b < 6; ++b) sacc += Mi[c * 36 + a * 6 + b] * r[c * 6 + b];
+        z[q] = sacc;
+        p[q] = sacc;
+        part += r[q] * sacc;
+    }
+    double rz = block_sum<PCG_THREADS>(part, red, tid);
+    double rn2 = bnorm2;
+    const double stop2 = O.pcg_tol * O.pcg_tol * bnorm2;
+    __syncthreads();
+    const int q0 = v0 ? lane : 0, q1 = v1 ? lane + 64 : 0;
+    double r0 = v0 ? r[q0] : 0.0, r1 = v1 ? r[q1] : 0.0;
+    double p0 = v0 ? p[q0] : 0.0, p1 = v1 ? p[q1] : 0.0;
+    double x0 = 0.0, x1 = 0.0;
+    const int c0 = q0 / 6, c1 = q1 / 6;
+    double m0[6], m1[6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b)
+    {
+        m0[b] = v0 ? Mi[c0 * 36 + (q0 - c0 * 6) * 6 + b] : 0.0;
+        m1[b] = v1 ? Mi[c1 * 36 + (q1 - c1 * 6) * 6 + b] : 0.0;
+    }
+    __syncthreads();              // everybody has read r / p: the vector block is re-used
+    double* rw = r + wave * n6;   // r, z, p, Ap: 4 * n6 doubles -> one private r per wavefront
+    double* pw = ps + wave * n6;  // ps: 4 * n6 doubles -> one private p per wavefront
+    if (v0) pw[q0] = p0;
+    if (v1) pw[q1] = p1;
+    __builtin_amdgcn_wave_barrier();
+    int iters = 0, par = 0;
+    for (int k = 0; k < O.max_pcg; ++k)
+    {
+        if (rn2 <= stop2) break;  // the same decision in every wavefront (identical arithmetic)
+        double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0;
+        const double* pq = pw + ub;
+#pragma unroll
+        for (int j = 0; j < PCG_SMALL_COLS; j += 2)
+        {
+            if (j < ncols)  // ub and ncols are even: p two columns at a time, 16-byte aligned
+            {
+                const double2 pv = *reinterpret_cast<const double2*>(pq + j);
+                s0 += sa[j] * pv.x;
+                s1 += sb[j] * pv.x;
+                if (j + 1 < nb8)  // inside the blocks of eight the odd columns have their own accumulator (pcg_solve's order)
+                {
+                    t0 += sa[j + 1] * pv.y;
+                    t1 += sb[j + 1] * pv.y;
+                }
+                else if (j + 1 < ncols)
+                {
+                    s0 += sa[j + 1] * pv.y;
+                    s1 += sb[j + 1] * pv.y;
+                }
+            }
+        }
+        double* exw = ex + par * 512;
+        exw[wave * 128 + lane]      = v0 ? s0 + t0 : 0.0;
+        exw[wave * 128 + 64 + lane] = v1 ? s1 + t1 : 0.0;
+        __syncthreads();
+        s0  = (exw[lane] + exw[128 + lane]) + (exw[256 + lane] + exw[384 + lane]);
+        s1  = (exw[64 + lane] + exw[192 + lane]) + (exw[320 + lane] + exw[448 + lane]);
+        par ^= 1;
+        const double pAp = wave_sum64_dpp(p0 * s0 + p1 * s1);  // p is 0 in rows that do not exist
+        if (pAp <= 0.0) break;
+        const double alpha = rz / pAp;
+        x0 += alpha * p0;
+        x1 += alpha * p1;
+        r0 = v0 ? r0 - alpha * s0 : 0.0;
+        r1 = v1 ? r1 - alpha * s1 : 0.0;
+        if (v0) rw[q0] = r0;
+        if (v1) rw[q1] = r1;
+        __builtin_amdgcn_wave_barrier();
+        double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+        for (int b = 0; b < 6; ++b)
+        {
+            z0 += m0[b] * rw[c0 * 6 + b];
+            z1 += m1[b] * rw[c1 * 6 + b];
+        }
+        const double rz_new = wave_sum64_dpp(r0 * z0 + r1 * z1);
+        rn2                 = wave_sum64_dpp(r0 * r0 + r1 * r1);
+        const double beta   = rz_new / rz;
+        rz                  = rz_new;
+        p0                  = z0 + beta * p0;
+        p1                  = z1 + beta * p1;
+        if (v0) pw[q0] = p0;
+        if (v1) pw[q1] = p1;
+        __builtin_amdgcn_wave_barrier();
+        ++iters;
+    }
+    if (wave == 0)
+    {
+        if (v0) x[q0] = x0;
+        if (v1) x[q1] = x1;
+        if (lane == 0) A.state[pb].pcg_iters += iters;
+    }
+}
+
 // ---- PCG for reduced systems that do not fit one workgroup's LDS (global BA: hundreds of keyframes) ----
 // Same algorithm as pcg_solve, spread over the chip: vectors live in HBM, S p is a (row chunk x column
 // part) grid of workgroups with the column parts combined in fixed order, the scalar products are
@@ -4056,7 +4213,10 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L, bool only_marked =
                                            h->point_wave_ok && !no_wave ? 1 : 0, nbx, B);
                 }
             }
-            if (!h->pcg_large)
+            static const bool pcg_in_lds = getenv("SNK_BA_PCG_LDS") != nullptr;  // A/B: S in LDS (pcg_solve<true>) also for local-BA sizes
+            if (!h->pcg_large && h->max_n6 <= 128 && !O.pcg_general && !pcg_in_lds)
+                LAUNCH(pcg_small, dim3(B), dim3(PCG_THREADS), ((size_t)h->max_n6 * 9 + (size_t)h->max_nfc * 72) * 8 + 8192, A, O);
+            else if (!h->pcg_large)
                 if (s_in_lds)
                     LAUNCH(pcg_solve<true>, dim3(B), dim3(PCG_THREADS), pcg_lds, A, O);
                 else

@@ -24,6 +24,7 @@ ROOT = Path(__file__).resolve().parent.parent
     {"SNK_BA_SCHUR_SET_MIN_ITEMS": "1", "SNK_BA_NO_SCHUR_MFMA": "1"},   # point_wave + the vector-ALU schur_set          # explicitly built hipGraph already for the first solve of every scene
     {"SNK_BA_CHECK_LISTS": "1", "SNK_BA_NO_SCHUR_SET": "1"},            # every scene hand-over compares the device-built lists (camera records, block entries) with the host builder's
     {"SNK_BA_HOST_ENTRIES": "1", "SNK_BA_NO_SCHUR_SET": "1"},           # block entries by the host builder (what scenes with > 64 free cameras use)
+    {"SNK_BA_PCG_LDS": "1"},                                            # S in LDS (pcg_solve<true>) instead of registers (pcg_small) for local-BA sized systems
     {"SNK_BA_LOCAL_SYNC": "1"},                                         # snk_ba_solve_local_scene decides about the extra iteration on the host (count read back)
     {"SNK_BA_NO_SCHUR_WIDE": "1", "SNK_BA_NO_SCHUR_SET": "1"},          # block-major schur_pass with one wavefront per block also for single windows
 ])
@@ -34,11 +35,16 @@ def test_ba_parity_suite_with_forced_path(env):
     assert " passed" in r.stdout
 
 
-def test_device_built_lists_equal_the_host_builders():
-    """The camera records and camera-pair block entries are built by kernels (gather_cam_records, block_entries_*) when a scene
-    has <= 64 free cameras and no camera twice on a point.  Child process with SNK_BA_CHECK_LISTS=1: snk_ba_set_problems
-    compares them with the host builder element by element (and fails on a difference); SNK_BA_HOST_ENTRIES=1 must give
-    bit-identical solutions (same lists, same kernels)."""
+@pytest.mark.parametrize("pair", [
+    (("device", {"SNK_BA_CHECK_LISTS": "1"}), ("host", {"SNK_BA_HOST_ENTRIES": "1"})),
+    (("registers", {}), ("lds", {"SNK_BA_PCG_LDS": "1"})),
+], ids=["block-entries-device-vs-host", "pcg-registers-vs-lds"])
+def test_equivalent_paths_give_bit_identical_solutions(pair):
+    """Pairs of paths that run the same arithmetic in the same order, in two child processes, must agree bit for bit:
+    * the camera records and camera-pair block entries are built by kernels (gather_cam_records, block_entries_*) when a scene has
+      <= 64 free cameras and no camera twice on a point.  With SNK_BA_CHECK_LISTS=1 snk_ba_set_problems compares them with the
+      host builder element by element (and fails on a difference); SNK_BA_HOST_ENTRIES=1 uses the host builder's lists;
+    * pcg_small keeps its quarter of S in registers, pcg_solve<true> reads it from LDS -- same summation order."""
     code = r"""
 import numpy as np, os, sys
 from snake_slam_amd import synth
@@ -75,12 +81,13 @@ print("ok")
 
     with tempfile.TemporaryDirectory() as d:
         res = {}
-        for name, env in (("device", {"SNK_BA_CHECK_LISTS": "1"}), ("host", {"SNK_BA_HOST_ENTRIES": "1"})):
+        for name, env in pair:
             f = os.path.join(d, name + ".npz")
             r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, PYTHONPATH=str(ROOT), **env), capture_output=True, text=True,
                                cwd=str(ROOT), timeout=600)
             assert r.returncode == 0 and "ok" in r.stdout, (name, r.stdout[-1500:], r.stderr[-1500:])
             res[name] = np.load(f)
-        assert len(res["device"].files) == len(res["host"].files) > 0
-        for k in res["device"].files:
-            assert np.array_equal(res["device"][k], res["host"][k]), k
+        ra, rb = res[pair[0][0]], res[pair[1][0]]
+        assert len(ra.files) == len(rb.files) > 0
+        for k in ra.files:
+            assert np.array_equal(ra[k], rb[k]), k
