@@ -75,9 +75,9 @@ struct Prob
     int n_set;          // work items of schur_set (0: not available for this problem)
     int set_off;        // into set_items
     int cblk_off;       // into cblk_start (nfc * nfc + 1 entries per problem)
+    int ccam_off;       // into cc_start (nfc + 1 entries per problem): the per-camera lists of cam_part partial sums
     int be_nch;         // device-built block entries: 64-item chunks of the longest camera list
     int becnt_off;      // ... and this problem's [nfc][be_nch][nfc] counters
-    int pad;
     double K[4];
     double bf;
 };
@@ -126,8 +126,12 @@ struct SetItem
     int nfree;             // free-camera observations per point (k)
     int aux_off;           // into set_pairs: k run positions ordered by camera index, then the k x k table "pair slot of (i, j)", i <= j
     int rec_off;           // into set_obs: n_pts x run static observation records in (point of the item, observation) order
-    int pad;
+    int cpart_off;         // first of its nfree per-camera partial sums in cam_part (schur_fused<3, true>; 33 doubles each)
 };
+
+// camera sums of schur_fused<3, true>: 33 terms per (work item, free camera), in passes of eight: 0..7, 8..15, 16..23,
+// 24..26 (from J_c and r) and 27..32 (W V^-1 b_p)
+constexpr int CS_TERMS = 33, CS_PASSES = 5;
 
 // Static part of an observation in the order schur_fused walks it (item, point of the item, observation of the point): a lane's
 // record is at rec_off + group * run + lane, so the first round of loads of a group is three coalesced 16-byte loads.
@@ -186,6 +190,9 @@ struct Arrays
     const int* cblk_start;  // per problem, per block: its partial sums in cblk_items (fixed order)
     const int* cblk_items;  // index into s_part
     double* s_part;         // [partial][36]
+    const int* cc_start;    // per problem, per free camera: its per-item partial sums in cc_items (fixed order)
+    const int* cc_items;    // index into cam_part
+    double* cam_part;       // [partial][33]: b_c (6) | U upper (21) | Y b_p (6) of one camera over one work item's points
     double* S;
     double* rhs;
     double* x;
@@ -862,6 +869,50 @@ __global__ __launch_bounds__(64) void rpc_pass(Arrays A, int trial)
         for (int b = 0; b < 6; ++b) o[35 + a * 6 + b] = J1[b * 6 + a] * w[b];  // H12 = J1^T W
 }
 
+// The end of a camera's pass over its observations: tot = U upper (21) | b_c (6) | sum Y b_p (6).  Adds the relative pose
+// constraints incident to the camera, damps the diagonal, writes U and the reduced right-hand side.
+__device__ inline void cam_finish(const Arrays& A, const Prob& pr, int pb, int c, double* tot)
+{
+    if (pr.n_rpc > 0)  // relative pose constraints incident to this camera (fixed order)
+    {
+        const int r0 = A.cam_rpc_start[pr.camrpc_off + c], r1 = A.cam_rpc_start[pr.camrpc_off + c + 1];
+        for (int q = r0; q < r1; ++q)
+        {
+            const int item  = A.cam_rpc_items[q];
+            const int k     = item >> 1;
+            const double* o = A.rpc_out + (size_t)(pr.rpc_off + k) * RPC_STRIDE;
+            if ((item & 1) == 0)
+            {
+                for (int u = 0; u < 21; ++u) tot[u] += o[14 + u];
+                for (int a = 0; a < 6; ++a) tot[21 + a] += o[2 + a];
+            }
+            else
+            {
+                const RpcMeta m = A.rpc_meta[pr.rpc_off + k];
+                const double w2[6] = {m.w_trans * m.w_trans, m.w_trans * m.w_trans, m.w_trans * m.w_trans,
+                                      m.w_rot * m.w_rot,     m.w_rot * m.w_rot,     m.w_rot * m.w_rot};
+                int u = 0;
+                for (int a = 0; a < 6; ++a)
+                    for (int b = a; b < 6; ++b, ++u)
+                        if (a == b) tot[u] += w2[a];
+                for (int a = 0; a < 6; ++a) tot[21 + a] += o[8 + a];
+            }
+        }
+    }
+    const double lambda = A.state[pb].lambda;
+    double* U = A.U + (size_t)(pr.cam_off + c) * 36;
+    int q = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b)
+        {
+            double v = tot[q++];
+            if (a == b) v += lambda * clampd(v);
+            U[a * 6 + b] = v;
+            U[b * 6 + a] = v;
+        }
+    for (int a = 0; a < 6; ++a) A.rhs[pr.vec_off + c * 6 + a] = tot[21 + a] - tot[27 + a];
+}
+
 // CAM_THREADS threads per camera.  The 33 sums of a wavefront are reduced with a 6-step butterfly (~600 instructions), as much as
 // linearising three observations: with many windows per launch ONE wavefront per camera (12 observations per thread for the
 // benchmark window) is fastest -- 143 us (4 wavefronts) -> 102 (2) -> 86 (1) per 256 windows; a single window keeps 4 for latency.
@@ -963,44 +1014,48 @@ __global__ __launch_bounds__(CAM_THREADS, SNK_BA_CAM_WAVES) void cam_pass(Arrays
             tot[k] = part[0][k];
             for (int w = 1; w < CAM_THREADS / 64; ++w) tot[k] += part[w][k];
         }
-        if (pr.n_rpc > 0)  // relative pose constraints incident to this camera (fixed order)
+        cam_finish(A, pr, pb, c, tot);
+    }
+}
+
+// cam_pass for the batches whose linearisation kernel (schur_fused<3, true>) already left every camera's sums as one partial
+// sum per work item: one wavefront per camera adds them in list order (lane = term, four partial sums in flight).
+__global__ __launch_bounds__(64) void cam_sum(Arrays A)
+{
+    __shared__ double s_tot[CS_TERMS];
+    const int pb  = blockIdx.y;
+    const Prob pr = A.prob[pb];
+    const int c   = blockIdx.x, lane = threadIdx.x;
+    if (c >= pr.nfc) return;
+    const int e0 = A.cc_start[pr.ccam_off + c], e1 = A.cc_start[pr.ccam_off + c + 1];
+    const int t  = lane < CS_TERMS ? lane : 0;
+    double acc   = 0.0;
+    for (int k0 = 0; k0 < e1 - e0; k0 += 64)
+    {
+        const int chunk = min(64, e1 - e0 - k0);
+        const int items = k0 + lane < e1 - e0 ? A.cc_items[e0 + k0 + lane] : 0;
+        for (int k = 0; k < chunk; k += 4)
         {
-            const int r0 = A.cam_rpc_start[pr.camrpc_off + c], r1 = A.cam_rpc_start[pr.camrpc_off + c + 1];
-            for (int q = r0; q < r1; ++q)
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
             {
-                const int item  = A.cam_rpc_items[q];
-                const int k     = item >> 1;
-                const double* o = A.rpc_out + (size_t)(pr.rpc_off + k) * RPC_STRIDE;
-                if ((item & 1) == 0)
-                {
-                    for (int u = 0; u < 21; ++u) tot[u] += o[14 + u];
-                    for (int a = 0; a < 6; ++a) tot[21 + a] += o[2 + a];
-                }
-                else
-                {
-                    const RpcMeta m = A.rpc_meta[pr.rpc_off + k];
-                    const double w2[6] = {m.w_trans * m.w_trans, m.w_trans * m.w_trans, m.w_trans * m.w_trans,
-                                          m.w_rot * m.w_rot,     m.w_rot * m.w_rot,     m.w_rot * m.w_rot};
-                    int u = 0;
-                    for (int a = 0; a < 6; ++a)
-                        for (int b = a; b < 6; ++b, ++u)
-                            if (a == b) tot[u] += w2[a];
-                    for (int a = 0; a < 6; ++a) tot[21 + a] += o[8 + a];
-                }
+                const int idx = __builtin_amdgcn_readlane(items, min(k + u, chunk - 1));
+                v[u]          = A.cam_part[(size_t)idx * CS_TERMS + t];
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k + u < chunk) acc += v[u];
         }
-        const double lambda = A.state[pb].lambda;
-        double* U = A.U + (size_t)(pr.cam_off + c) * 36;
-        int q = 0;
-        for (int a = 0; a < 6; ++a)
-            for (int b = a; b < 6; ++b)
-            {
-                double v = tot[q++];
-                if (a == b) v += lambda * clampd(v);
-                U[a * 6 + b] = v;
-                U[b * 6 + a] = v;
-            }
-        for (int a = 0; a < 6; ++a) A.rhs[pr.vec_off + c * 6 + a] = tot[21 + a] - tot[27 + a];
+    }
+    // the partial sums hold b_c (6) | U upper (21) | Y b_p (6); cam_finish wants U | b_c | Y b_p
+    if (lane < CS_TERMS) s_tot[lane < 6 ? 21 + lane : (lane < 27 ? lane - 6 : lane)] = acc;
+    __syncthreads();
+    if (lane == 0)
+    {
+        double tot[CS_TERMS];
+        for (int k = 0; k < CS_TERMS; ++k) tot[k] = s_tot[k];
+        cam_finish(A, pr, pb, c, tot);
     }
 }
 
@@ -1302,12 +1357,29 @@ struct SfGather  // second round: through the record's indices
     double pose[7];
     bool is_out;
 };
-template <int T>
+// CS (camera sums, T == 3 only): the wavefront also emits what cam_pass computes -- per free camera b_c = -sum J_c^T r,
+// U = sum J_c^T J_c, sum Y b_p -- as ONE partial sum per (work item, free camera of its set): all points of an item see the
+// same cameras in the same run positions, so lane (point g, position a) of a group contributes to camera(a).  The observation
+// is linearised here anyway; cam_pass re-read every record, gathered the point again and linearised a second time (294 us per
+// 1024 windows).  33 terms per observation go through the contribution buffer eight at a time (lane = observation writes,
+// lane = (free camera f, term k) sums the group's points in order and keeps a running sum per pass: five passes, five
+// accumulators); cam_sum adds a camera's partial sums in list order and finishes like cam_pass (damping, U, rhs).
+__device__ __forceinline__ double cam_term(int t, const double* Jc, const double* r)  // t < 27: b_c (6) | U upper (21)
+{
+    constexpr int PA[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+    constexpr int PB[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
+    if (t < 6) return -(Jc[t] * r[0] + Jc[6 + t] * r[1] + Jc[12 + t] * r[2]);
+    const int a = PA[t - 6], b = PB[t - 6];
+    return Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b] + Jc[12 + a] * Jc[12 + b];
+}
+
+template <int T, bool CS>
 __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int B)
 {
+    static_assert(!CS || T == 3, "camera sums: at most 8 free cameras per set (lane = (camera, term of eight))");
     // per wavefront: the W rows of the group (64 x 18 doubles) | the observations' contributions (64 x 10) | the sums of
-    // the group's points | their V^-1.  16.4 KB: two workgroups per CU, which is also what the registers allow.
-    __shared__ __attribute__((aligned(16))) double s_buf[4][64 * 18 + 64 * SF_NC + SF_GMAX * (SF_NC + 6) + 4];
+    // the group's points | their V^-1 | V^-1 b_p.  16.8 KB: two workgroups per CU, which is also what the registers allow.
+    __shared__ __attribute__((aligned(16))) double s_buf[4][64 * 18 + 64 * SF_NC + SF_GMAX * (SF_NC + 6) + 4 + SF_GMAX * 3];
     int pb, bx;
     if (B >= 16)  // batched windows: one XCD per window
     {
@@ -1332,6 +1404,7 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
     double* s_sum  = s_con + 64 * SF_NC;
     double* s_vi   = s_sum + SF_GMAX * SF_NC;
     double* s_zero = s_vi + SF_GMAX * 6;  // 4 zeros: what the operand lanes outside the matrix read
+    double* s_vb   = s_zero + 4;          // V^-1 b_p of the group's points (camera sums)
     const int run  = si.run, G = min(64 / run, SF_GMAX);  // run <= SET_MAX_RUN = 14: at least 4 points per group
     const int lg   = lane / run;                           // point of the group (its observation is lane - lg * run)
     const double* poses = A.pose + (size_t)pr.img_off * 7;
@@ -1359,6 +1432,28 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
     double4_t acc[T * (T + 1) / 2];
 #pragma unroll
     for (int q = 0; q < T * (T + 1) / 2; ++q) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
+    // camera sums: lane = (free camera f of the set, term k of the pass); cs_row = f's run position
+    const int cs_f = lane >> 3, cs_k = lane & 7;
+    const bool cs_on = CS && cs_f < si.nfree;
+    const int cs_row = cs_on ? A.set_pairs[si.aux_off + cs_f] : 0;
+    double cs_acc[CS ? CS_PASSES : 1];
+#pragma unroll
+    for (int q = 0; q < (CS ? CS_PASSES : 1); ++q) cs_acc[q] = 0.0;
+    // one pass: every lane's eight terms through the contribution buffer, summed over the group's points in order
+    auto cs_pass = [&](int pass, const double* term, int gc)
+    {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s_con[lane * 8 + k] = term[k];
+        __builtin_amdgcn_wave_barrier();
+        if (cs_on)
+        {
+            const double* q = s_con + cs_row * 8 + cs_k;
+            double sum = 0.0;
+            for (int g = 0; g < gc; ++g) sum += q[g * run * 8];  // (all reads first, then the adds: measured slower, 1437 -> 1460 / 1504 us)
+            cs_acc[pass] += sum;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
 
     // The two dependent rounds of loads of a group are issued one group ahead: round 1 (indexed by the observation) at the
     // top of the previous group's work, round 2 (point, pose, flags: through round 1's indices) in front of its matrix
@@ -1402,15 +1497,18 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
             for (int k = 0; k < SF_NC; ++k) con[k] = 0.0;
             bool cpl = false;  // the observation couples a free camera with a free point: it has a row of W
             double Jc[18], Jp[9];
+            double r[3] = {0.0, 0.0, 0.0};
+            bool lin = false;  // the observation is active in this iteration (what cam_pass sums)
 #pragma unroll
             for (int k = 0; k < 18; ++k) Jc[k] = 0.0;
 #pragma unroll
             for (int k = 0; k < 9; ++k) Jp[k] = 0.0;
             if (ob.act && !gt.is_out)
             {
-                double R[9], r[3];
+                double R[9];
                 quat_to_R(gt.pose, R);
                 const int dim = obs_linearize<true>(gt.pose, R, ob.pt, pr.K, pr.bf, ob.rec.u, ob.rec.v, ob.rec.depth, ob.rec.weight, r, Jc, Jp);
+                lin           = dim != 0;
                 if (dim)
                 {
                     const double sq = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
@@ -1446,19 +1544,31 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
                     for (int b = 0; b < 3; ++b)
                         s_w[lane * 18 + a * 3 + b] = cpl ? Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b] + Jc[12 + a] * Jp[6 + b] : 0.0;
             }
-        }
-        __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_wave_barrier();
 
-        // ---- phase 2a: lane = (point of the group, term): the point's sums in observation order ----
-        for (int idx = lane; idx < gc * SF_NC; idx += 64)
-        {
-            const int g = (idx * 205) >> 11, comp = idx - g * SF_NC;  // idx / 10 (idx < 160)
-            const double* q = s_con + g * run * SF_NC + comp;
-            double sum = 0.0;
-            for (int a = 0; a < run; ++a) sum += q[a * SF_NC];
-            s_sum[idx] = sum;
+            // ---- phase 2a: lane = (point of the group, term): the point's sums in observation order ----
+            for (int idx = lane; idx < gc * SF_NC; idx += 64)
+            {
+                const int g = (idx * 205) >> 11, comp = idx - g * SF_NC;  // idx / 10 (idx < 160)
+                const double* q = s_con + g * run * SF_NC + comp;
+                double sum = 0.0;
+                for (int a = 0; a < run; ++a) sum += q[a * SF_NC];
+                s_sum[idx] = sum;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- camera sums, the 27 terms of J_c and r (the contribution buffer is free again; J_c dies here) ----
+            if (CS && si.nfree != 0)
+            {
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass)
+                {
+                    double term[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) term[k] = pass * 8 + k < 27 && lin ? cam_term(pass * 8 + k, Jc, r) : 0.0;
+                    cs_pass(pass, term, gc);
+                }
+            }
         }
-        __builtin_amdgcn_wave_barrier();
         if (more) load2(obn, gtn);
         // ---- phase 2b: lane = point of the group: damping, V^-1, the per-point outputs of point_wave ----
         const int p2 = __shfl(my_pt.x, min(n0 + lane, 63));  // outside the branch: a shuffle reads 0 from inactive lanes
@@ -1498,6 +1608,12 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
             }
 #pragma unroll
             for (int k = 0; k < 6; ++k) s_vi[lane * 6 + k] = Vi[k];
+            if (CS)
+            {
+                s_vb[lane * 3 + 0] = vb[0];
+                s_vb[lane * 3 + 1] = vb[1];
+                s_vb[lane * 3 + 2] = vb[2];
+            }
             {
                 const double* ptp = A.pt + (size_t)gp2 * 3;
                 const double px = ptp[0], py = ptp[1], pz = ptp[2];
@@ -1507,6 +1623,17 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
             }
         }
         __builtin_amdgcn_wave_barrier();
+        if (CS && si.nfree != 0)
+        {
+            // ---- camera sums, Y b_p = W (V^-1 b_p): the lane's row of W (zero unless the observation couples) times its point's vector ----
+            const int gl = min(lg, gc - 1);
+            const double b0 = s_vb[gl * 3], b1 = s_vb[gl * 3 + 1], b2 = s_vb[gl * 3 + 2];
+            double term[8];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) term[a] = lg < gc ? s_w[lane * 18 + a * 3] * b0 + s_w[lane * 18 + a * 3 + 1] * b1 + s_w[lane * 18 + a * 3 + 2] * b2 : 0.0;
+            term[6] = term[7] = 0.0;
+            cs_pass(4, term, gc);
+        }
 
         // ---- phase 3: (W V^-1) W^T of every point of the group on the matrix cores ----
         if (si.nfree != 0)  // wave-uniform; a work item without pairs is linearisation only
@@ -1547,6 +1674,14 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
         if (n0 + G < si.n_pts) process(n0 + G, obb, gb, oa, ga);
     }
     if (si.nfree == 0) return;
+    if (cs_on)
+    {
+        double* cp = A.cam_part + (size_t)(si.cpart_off + cs_f) * CS_TERMS;
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass) cp[pass * 8 + cs_k] = cs_acc[pass];
+        if (cs_k < 3) cp[24 + cs_k] = cs_acc[3];
+        if (cs_k < 6) cp[27 + cs_k] = cs_acc[4];
+    }
     const int* tab = A.set_pairs + si.aux_off + si.nfree;
     double* part   = A.s_part + (size_t)si.part_off * 36;
     int q = 0;
@@ -2884,7 +3019,7 @@ struct BaLists
     pvec<SetItem> setitems;
     pvec<SetObs> setobs;
     pvec<int2> setpts;
-    pvec<int> setpairs, cblkstart, cblkitems;
+    pvec<int> setpairs, cblkstart, cblkitems, ccstart, ccitems;
     pvec<int> camidx, ptstart, oimg, ocam, oorig, camstart, camitems, blkstart, optidx, wvpt, rpcnext, camrpcstart, camrpcitems, blkrpc;
     pvec<RpcMeta> rpcmeta;
     pvec<int4> blkent;
@@ -2894,7 +3029,7 @@ struct BaLists
         csobs.clear(), setitems.clear(), setobs.clear(), setpts.clear(), setpairs.clear(), cblkstart.clear(), cblkitems.clear();
         camidx.clear(), ptstart.clear(), oimg.clear(), ocam.clear(), oorig.clear(), camstart.clear(), camitems.clear();
         blkstart.clear(), optidx.clear(), wvpt.clear(), rpcnext.clear(), camrpcstart.clear(), camrpcitems.clear(), blkrpc.clear();
-        rpcmeta.clear(), blkent.clear();
+        rpcmeta.clear(), blkent.clear(), ccstart.clear(), ccitems.clear();
     }
 };
 
@@ -2904,6 +3039,8 @@ struct snk_ba : HandleBase
     HostBuf h_stage;  // pinned staging of the small per-call transfers (outlier masks)
     DevBuf d_becnt;   // per (camera, 64-item chunk, camera) counters of the device-built block entries
     DevBuf d_probcond;  // the problem table of a conditional extra iteration (select_marked)
+    DevBuf d_campart, d_ccstart, d_ccitems;  // per (work item, free camera) sums of schur_fused<3, true> and the per-camera lists of them
+    bool cam_sums_ok = false;                // every observation of a free camera belongs to a work item with pairs (no constant point seen by a free camera)
     snk_ba_options opt{};
     int count = 0;
     std::vector<Prob> probs;
@@ -3248,7 +3385,7 @@ int snk_ba_destroy(snk_ba* h)
                      &h->d_W, &h->d_ptv, &h->d_Vinv, &h->d_bp, &h->d_cost, &h->d_cost_new, &h->d_U, &h->d_camstart,
                      &h->d_camitems, &h->d_blkstart, &h->d_blkent, &h->d_S, &h->d_rhs, &h->d_x, &h->d_chi2,
                      &h->d_pcgw, &h->d_optidx, &h->d_wvpt, &h->d_rpcmeta, &h->d_rpcnext, &h->d_camrpcstart,
-                     &h->d_camrpcitems, &h->d_blkrpc, &h->d_rpcout, &h->d_becnt, &h->d_probcond};
+                     &h->d_camrpcitems, &h->d_blkrpc, &h->d_rpcout, &h->d_becnt, &h->d_probcond, &h->d_campart, &h->d_ccstart, &h->d_ccitems};
     for (DevBuf* b : all) b->release();
     h->h_stage.release();
     h->drop_graphs();
@@ -3283,8 +3420,10 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     auto& setitems = LS.setitems;
     auto& setobs   = LS.setobs;
     auto& setpts   = LS.setpts;
-    auto &setpairs = LS.setpairs, &cblkstart = LS.cblkstart, &cblkitems = LS.cblkitems;
+    auto &setpairs = LS.setpairs, &cblkstart = LS.cblkstart, &cblkitems = LS.cblkitems, &ccstart = LS.ccstart, &ccitems = LS.ccitems;
     int n_partials = 0, max_set_items = 0, max_set_pairs = 0, max_set_run = 0, max_set_k = 0;
+    int n_cparts = 0;          // per (work item, free camera) partial sums of the camera pass
+    bool cam_sums_ok = true;   // no constant point is seen by a free camera (its observations are in no work item with pairs)
     bool set_ok = true;  // every problem can run the point-major Schur pass
     auto &camidx = LS.camidx, &ptstart = LS.ptstart, &oimg = LS.oimg, &ocam = LS.ocam, &oorig = LS.oorig, &camstart = LS.camstart,
          &camitems = LS.camitems, &blkstart = LS.blkstart, &optidx = LS.optidx, &wvpt = LS.wvpt, &rpcnext = LS.rpcnext,
@@ -3577,6 +3716,8 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                 if (a1 == a0) continue;  // a point without observations: nothing to linearise (update_wave keeps it in place)
                 if (P.pt_const[p])
                 {
+                    for (int a = a0; a < a1; ++a)
+                        if (s_cam[(size_t)a] >= 0) cam_sums_ok = false;
                     plain_group(p, a1 - a0);
                     continue;
                 }
@@ -3609,6 +3750,8 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                     gpts[(size_t)f->second].push_back(p);
             }
             std::vector<std::vector<int>> contrib(nb);
+            std::vector<std::vector<int>> ccontrib((size_t)nfc);  // per free camera: its partial sums in cam_part
+            int cparts = n_cparts;
             std::vector<SetItem> items;
             std::vector<int2> ipts;
             std::vector<int> ipairs;
@@ -3634,6 +3777,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                     // matrix-core form (schur_mfma): the point's free rows ordered by camera index, so that every pair
                     // (ra, rb) -- camera(ra) < camera(rb) -- lies in the upper triangle of Y W^T, and the slot of each
                     const int aux_off = (int)(setpairs.size() + ipairs.size());
+                    std::vector<int> fcams;  // the set's free cameras in ascending order (= the order of the k run positions)
                     {
                         std::vector<int> fpos;
                         for (size_t i = 0; i < sig.size(); ++i)
@@ -3641,6 +3785,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                         std::sort(fpos.begin(), fpos.end(), [&](int a, int b) { return sig[(size_t)a] < sig[(size_t)b]; });
                         const int kf = (int)fpos.size();
                         for (int v : fpos) ipairs.push_back(v);
+                        for (int v : fpos) fcams.push_back(sig[(size_t)v]);
                         for (int i = 0; i < kf; ++i)
                             for (int j = 0; j < kf; ++j)
                             {
@@ -3670,9 +3815,11 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                         si.run      = (int)sig.size();
                         si.aux_off  = aux_off;
                         si.nfree    = 0;
-                        si.pad      = 0;
                         si.rec_off  = (int)setobs.size();
                         for (int v : sig) si.nfree += v >= 0 ? 1 : 0;
+                        si.cpart_off = cparts;
+                        for (int f = 0; f < si.nfree; ++f) ccontrib[(size_t)fcams[(size_t)f]].push_back(cparts + f);
+                        cparts += si.nfree;
                         for (int q = 0; q < si.n_pts; ++q)
                         {
                             const int pp = gpts[g][q0 + (size_t)q];
@@ -3696,10 +3843,25 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                     }
                 }
             }
+            pr.ccam_off = (int)ccstart.size();
+            {
+                int crun = (int)ccitems.size();
+                for (int c = 0; c < nfc; ++c)
+                {
+                    ccstart.push_back(crun);
+                    if (ok)
+                    {
+                        ccitems.insert(ccitems.end(), ccontrib[(size_t)c].begin(), ccontrib[(size_t)c].end());
+                        crun += (int)ccontrib[(size_t)c].size();
+                    }
+                }
+                ccstart.push_back(crun);
+            }
             if (ok)
             {
                 pr.n_set   = (int)items.size();
                 n_partials = parts;
+                n_cparts   = cparts;
                 setitems.insert(setitems.end(), items.begin(), items.end());
                 setpts.insert(setpts.end(), ipts.begin(), ipts.end());
                 setpairs.insert(setpairs.end(), ipairs.begin(), ipairs.end());
@@ -3853,6 +4015,8 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     UP(d_setpairs, setpairs);
     UP(d_cblkstart, cblkstart);
     UP(d_cblkitems, cblkitems);
+    UP(d_ccstart, LS.ccstart);
+    UP(d_ccitems, LS.ccitems);
     if (dev_entries)
     {
         if ((rc = h->d_blkstart.reserve((size_t)std::max(blkstart_total, 1) * sizeof(int))) != SNK_OK) return rc;
@@ -3884,6 +4048,8 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     RS(d_W, nobs * 18 * 8);
     RS(d_ptv, npt * 6 * 8);
     RS(d_spart, (size_t)std::max(n_partials, 1) * 36 * 8);
+    RS(d_campart, (size_t)std::max(n_cparts, 1) * CS_TERMS * 8);
+    h->cam_sums_ok = cam_sums_ok;
     h->set_ok = set_ok && max_set_items > 0;
     h->max_set_items = max_set_items;
     h->set_small     = max_set_pairs * 6 <= 4 * 64 && max_set_run * 9 + 3 <= 2 * 64;
@@ -3991,6 +4157,9 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     A.set_obs   = h->d_setobs.as<SetObs>();
     A.set_pts   = h->d_setpts.as<int2>();
     A.set_pairs = h->d_setpairs.as<int>();
+    A.cc_start   = h->d_ccstart.as<int>();
+    A.cc_items   = h->d_ccitems.as<int>();
+    A.cam_part   = h->d_campart.as<double>();
     A.cblk_start = h->d_cblkstart.as<int>();
     A.cblk_items = h->d_cblkitems.as<int>();
     A.s_part    = h->d_spart.as<double>();
@@ -4163,13 +4332,21 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L, bool only_marked =
         static const bool fused_k10 = getenv("SNK_BA_FUSED_K10") != nullptr;
         const bool fused   = use_set && !no_mfma && !no_fused && (h->set_k_max <= 8 || fused_k10);
         const int nsx      = ceil_div(std::max(h->max_set_items, 1), 4);
+        // SNK_BA_CAM_SUMS=1: the camera pass as per-item partial sums out of schur_fused<3, true> + cam_sum instead of cam_pass.
+        // Built because cam_pass linearises every observation a second time (294 us per 1024 windows); measured: schur_fused
+        // 1127 -> 1437 us for the five passes through the contribution buffer, cam_sum 29 us -- 46 us SLOWER per LM iteration
+        // (profiles/r03/r03aa_*).  Kept selectable and tested, not the default.
+        static const bool want_cam_sums = getenv("SNK_BA_CAM_SUMS") != nullptr;
+        const bool cam_sums = fused && h->set_k_max <= 8 && h->cam_sums_ok && want_cam_sums;
         if (fused)
         {
             // linearisation + Schur products in one kernel (W stays in LDS); it writes what point_wave writes per point
-            if (h->set_k_max <= 8)
-                LAUNCH((schur_fused<3>), dim3(nsx * 8 * ceil_div(B, 8)), dim3(256), 0, A, O, nsx, B);
+            if (h->set_k_max <= 8 && cam_sums)
+                LAUNCH((schur_fused<3, true>), dim3(nsx * 8 * ceil_div(B, 8)), dim3(256), 0, A, O, nsx, B);
+            else if (h->set_k_max <= 8)
+                LAUNCH((schur_fused<3, false>), dim3(nsx * 8 * ceil_div(B, 8)), dim3(256), 0, A, O, nsx, B);
             else
-                LAUNCH((schur_fused<4>), dim3(nsx * 8 * ceil_div(B, 8)), dim3(256), 0, A, O, nsx, B);
+                LAUNCH((schur_fused<4, false>), dim3(nsx * 8 * ceil_div(B, 8)), dim3(256), 0, A, O, nsx, B);
         }
         else if (h->point_wave_ok && !no_wave)
             LAUNCH(point_wave, dim3(h->max_wv, B), dim3(64), 0, A, O);
@@ -4178,7 +4355,9 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L, bool only_marked =
         if (h->max_nfc > 0)
         {
             if (h->max_rpc > 0) LAUNCH(rpc_pass, dim3(ceil_div(h->max_rpc, 64), B), dim3(64), 0, A, 0);
-            if (B >= 16)
+            if (cam_sums)
+                LAUNCH(cam_sum, dim3(h->max_nfc, B), dim3(64), 0, A);
+            else if (B >= 16)
                 LAUNCH(cam_pass<64>, dim3(h->max_nfc, B), dim3(64), 0, A, O);
             else
                 LAUNCH(cam_pass<256>, dim3(h->max_nfc, B), dim3(256), 0, A, O);
