@@ -1077,6 +1077,11 @@ __global__ __launch_bounds__(64) void cam_sum(Arrays A)
 // registers across the item.  The item's sums go to s_part; schur_sum adds the partial sums of a block in a fixed
 // order and writes S.  The next two points' rows are in flight (two register sets) while one is multiplied.
 constexpr int SET_CHUNK   = 50;  // points per work item (a set's points are cut into equal items of at most this many)
+// Big batches (>= 256 problems, every set with <= 8 free cameras, default kernels): items of up to 128 points.  Every item
+// writes one 288-byte partial sum per camera pair whatever its size: with 100 points per camera set (the benchmark window) one
+// item per set instead of two halves what schur_fused writes and schur_sum reads back (425 MB per LM iteration of 1024 windows).
+// Only schur_fused / update_cost walk such items (two list registers); the alternative paths keep <= 64.
+constexpr int SET_CHUNK_BIG = 104;
 constexpr int SET_MAX_RUN = 14;  // observations of a point (rows staged per point)
 constexpr int SET_MAX_K   = 10;  // free-camera observations of a point: 55 pairs <= 64 lanes
 constexpr int SET_SLOT    = SET_MAX_RUN * 144 + 48;  // LDS bytes of one staged point (2064)
@@ -1399,6 +1404,13 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
     if (it >= pr.n_set) return;  // whole wavefront
     const SetItem si = A.set_items[pr.set_off + it];
     const int2 my_pt = lane < si.n_pts ? A.set_pts[si.pts_off + lane] : make_int2(0, 0);
+    // items of up to 128 points (big batches, SET_CHUNK_BIG): the second half of the list in a second register
+    const int my_pt_hi = 64 + lane < si.n_pts ? A.set_pts[si.pts_off + 64 + lane].x : 0;
+    auto pt_at = [&](int idx) -> int  // point idx of the item; both shuffles outside any branch (a shuffle reads 0 from inactive lanes)
+    {
+        const int lo = __shfl(my_pt.x, min(idx, 63)), hi = __shfl(my_pt_hi, min(max(idx - 64, 0), 63));
+        return idx < 64 ? lo : hi;
+    };
     double* s_w    = s_buf[wave];
     double* s_con  = s_w + 64 * 18;
     double* s_sum  = s_con + 64 * SF_NC;
@@ -1468,7 +1480,7 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
         const unsigned ri = min((unsigned)(n0 * run + lane), n_rec - 1u);
         const uint4* rp   = reinterpret_cast<const uint4*>(rec_base + ri * 48u);
         const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
-        const int px   = __shfl(my_pt.x, min(n0 + (o.act ? lg : 0), 63));
+        const int px   = pt_at(n0 + (o.act ? lg : 0));
         const double* ptp = reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.pt) + (unsigned)(pr.pt_off + px) * 24u);
         o.pt[0] = ptp[0]; o.pt[1] = ptp[1]; o.pt[2] = ptp[2];
         o.rec.u      = __hiloint2double((int)r0.y, (int)r0.x);
@@ -1571,7 +1583,7 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
         }
         if (more) load2(obn, gtn);
         // ---- phase 2b: lane = point of the group: damping, V^-1, the per-point outputs of point_wave ----
-        const int p2 = __shfl(my_pt.x, min(n0 + lane, 63));  // outside the branch: a shuffle reads 0 from inactive lanes
+        const int p2 = pt_at(min(n0 + lane, si.n_pts - 1));  // outside the branch
         if (lane < gc)
         {
             const int gp2 = pr.pt_off + p2;
@@ -1733,6 +1745,13 @@ __global__ __launch_bounds__(256, SNK_BA_UC_WAVES) void update_cost(Arrays A, Op
     if (it >= pr.n_set) return;  // whole wavefront
     const SetItem si = A.set_items[pr.set_off + it];
     const int2 my_pt = lane < si.n_pts ? A.set_pts[si.pts_off + lane] : make_int2(0, 0);
+    // items of up to 128 points (big batches, SET_CHUNK_BIG): the second half of the list in a second register
+    const int my_pt_hi = 64 + lane < si.n_pts ? A.set_pts[si.pts_off + 64 + lane].x : 0;
+    auto pt_at = [&](int idx) -> int  // point idx of the item; both shuffles outside any branch (a shuffle reads 0 from inactive lanes)
+    {
+        const int lo = __shfl(my_pt.x, min(idx, 63)), hi = __shfl(my_pt_hi, min(max(idx - 64, 0), 63));
+        return idx < 64 ? lo : hi;
+    };
     double* s_t  = s_buf[wave];
     double* s_c  = s_t + 64 * 3;
     double* s_g  = s_c + 64;
@@ -1750,7 +1769,7 @@ __global__ __launch_bounds__(256, SNK_BA_UC_WAVES) void update_cost(Arrays A, Op
         const unsigned ri = min((unsigned)(n0 * run + lane), n_rec - 1u);
         const uint4* rp   = reinterpret_cast<const uint4*>(rec_base + ri * 48u);
         const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
-        const int px   = __shfl(my_pt.x, min(n0 + (o.act ? lg : 0), 63));
+        const int px   = pt_at(n0 + (o.act ? lg : 0));
         const double* ptp = reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.pt) + (unsigned)(pr.pt_off + px) * 24u);
         o.pt[0] = ptp[0]; o.pt[1] = ptp[1]; o.pt[2] = ptp[2];
         o.rec.u      = __hiloint2double((int)r0.y, (int)r0.x);
@@ -1781,12 +1800,12 @@ __global__ __launch_bounds__(256, SNK_BA_UC_WAVES) void update_cost(Arrays A, Op
         }
         const bool is_out = A.outlier[(unsigned)ob.rec.orig] != 0;
         // per point of the group: b_p by lanes (point, component), V^-1 / position / constancy by lane = point
-        const int p2  = __shfl(my_pt.x, min(n0 + lane, 63));
+        const int p2  = pt_at(min(n0 + lane, si.n_pts - 1));
         const int gp2 = pr.pt_off + p2;
         double bpv = 0.0;
         {
             const int g = (lane * 171) >> 9, b = lane - 3 * g;  // lane / 3
-            const int pg = __shfl(my_pt.x, min(n0 + g, 63));    // outside the branch: a shuffle reads 0 from inactive lanes
+            const int pg = pt_at(min(n0 + g, si.n_pts - 1));    // outside the branch
             if (lane < gc * 3) bpv = A.bp[(size_t)(pr.pt_off + pg) * 3 + b];
         }
         double Vi[6] = {0, 0, 0, 0, 0, 0}, cur[3] = {0, 0, 0};
@@ -3452,6 +3471,32 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     long long s_off = 0;
     int max_np = 0, max_nfc = 0, max_n6 = 0, max_ni = 0;
 
+    // work items of up to 128 points: see SET_CHUNK_BIG.  Needs the default point-major kernels (the A/B switches that select
+    // the others are read here as well) and at most 8 free observations per point in EVERY problem (else the batch runs
+    // point_wave + schur_mfma<4>), which is known only after a look at all of them.
+    bool big_items = false;
+    {
+        static const bool alt_paths = getenv("SNK_BA_NO_SCHUR_FUSED") || getenv("SNK_BA_NO_SCHUR_MFMA") || getenv("SNK_BA_NO_UPDATE_COST") ||
+                                      getenv("SNK_BA_FUSED_K10") || getenv("SNK_BA_NO_SCHUR_SET") || getenv("SNK_BA_NO_POINT_WAVE") ||
+                                      getenv("SNK_BA_NO_BIG_ITEMS");
+        if (count >= 256 && !alt_paths)
+        {
+            big_items = true;
+            std::vector<unsigned char> kfree;
+            for (int b = 0; b < count && big_items; ++b)
+            {
+                const snk_ba_problem& P = problems[b];
+                if (P.n_pt <= 0 || P.n_obs <= 0 || !P.obs_img || !P.obs_pt || !P.img_const) continue;
+                kfree.assign((size_t)P.n_pt, 0);
+                for (int o = 0; o < P.n_obs; ++o)
+                {
+                    const int i = P.obs_img[o], p = P.obs_pt[o];
+                    if (i < 0 || i >= P.n_img || p < 0 || p >= P.n_pt || P.img_const[i]) continue;
+                    if (++kfree[(size_t)p] > 8) big_items = false;
+                }
+            }
+        }
+    }
     bool dev_entries_ok = true;  // every problem can have its block entries built on the device
     std::vector<long long> ent_bound((size_t)count, 0);
     int blkstart_total = 0, max_citems = 0;
@@ -3797,12 +3842,13 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                             }
                         max_set_k = std::max(max_set_k, kf);
                     }
-                    const size_t n_in_set = gpts[g].size(), n_cuts = (n_in_set + SET_CHUNK - 1) / SET_CHUNK;
+                    const size_t chunk    = big_items ? SET_CHUNK_BIG : SET_CHUNK;
+                    const size_t n_in_set = gpts[g].size(), n_cuts = (n_in_set + chunk - 1) / chunk;
                     size_t cut = (n_in_set + n_cuts - 1) / n_cuts;  // equal items: a launch ends with its longest item
                     {
                         // schur_fused linearises 64 / run points at a time: whole groups of that many per item where possible
                         const size_t grp = std::min<size_t>(64 / std::max<size_t>(sig.size(), 1), 16);  // SF_GMAX
-                        cut = std::min<size_t>((cut + grp - 1) / grp * grp, 64);
+                        cut = std::min<size_t>((cut + grp - 1) / grp * grp, big_items ? 128 : 64);
                     }
                     for (size_t q0 = 0; q0 < n_in_set; q0 += cut)
                     {
