@@ -3463,7 +3463,22 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         }
         pose.reserve(7 * t_img), pt.reserve(3 * t_pt), ptc.reserve(t_pt), camidx.reserve(t_img), ptstart.reserve(t_pt + (size_t)count);
         ouv2.reserve(2 * t_obs), odepth.reserve(t_obs), oweight.reserve(t_obs), optfree.reserve(t_obs), oimg.reserve(t_obs);
-        ocam.reserve(t_obs), oorig.reserve(t_obs), optidx.reserve(t_obs), csobs.reserve(t_obs), camitems.reserve(t_obs);
+        ocam.reserve(t_obs), oorig.reserve(t_obs), optidx.reserve(t_obs), camitems.reserve(t_obs);
+        // ... and so are the lists of the point-major pass when they will be built (batches, big scenes): on a 300-keyframe
+        // scene the doubling of setobs / cblkstart / cblkitems through fresh pinned allocations was 17 of the 26 ms of a
+        // first hand-over (the same scene again on the handle, capacities kept: 8 ms)
+        size_t t_blk = 0;
+        bool sets_likely = count >= 8 || getenv("SNK_BA_SCHUR_SET_MIN_ITEMS") != nullptr;
+        for (int b = 0; b < count; ++b)
+        {
+            size_t nfc = 0;
+            if (problems[b].img_const)
+                for (int i = 0; i < problems[b].n_img; ++i) nfc += problems[b].img_const[i] ? 0 : 1;
+            t_blk += nfc * nfc + 1;
+            sets_likely |= problems[b].n_pt >= 8000;
+        }
+        cblkstart.reserve(t_blk);
+        if (sets_likely) setobs.reserve(t_obs), setpts.reserve(t_pt), cblkitems.reserve(2 * t_obs), ccitems.reserve(t_obs);
     }
     h->orig_off.assign((size_t)count, 0);
     h->orig_n.assign((size_t)count, 0);
@@ -3497,6 +3512,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             }
         }
     }
+    size_t blkrpc_logical = 0;   // entries of blk_rpc up to the current problem (materialised only for problems with constraints)
     bool dev_entries_ok = true;  // every problem can have its block entries built on the device
     std::vector<long long> ent_bound((size_t)count, 0);
     int blkstart_total = 0, max_citems = 0;
@@ -3549,7 +3565,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         }
     };
     static const bool prof_sections = getenv("SNK_BA_PROFILE_CREATE") != nullptr;
-    long long sec_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long sec_us[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto sec_t = std::chrono::steady_clock::now();
     auto mark = [&](int k)
     {
@@ -3794,6 +3810,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                 else
                     gpts[(size_t)f->second].push_back(p);
             }
+            mark(8);
             std::vector<std::vector<int>> contrib(nb);
             std::vector<std::vector<int>> ccontrib((size_t)nfc);  // per free camera: its partial sums in cam_part
             int cparts = n_cparts;
@@ -3889,6 +3906,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                     }
                 }
             }
+            mark(9);
             pr.ccam_off = (int)ccstart.size();
             {
                 int crun = (int)ccitems.size();
@@ -3916,16 +3934,19 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             else
                 set_ok = false;
             int run = (int)cblkitems.size();
+            const size_t cb_at = cblkstart.size();
+            cblkstart.resize(cb_at + nb + 1);
+            int* cb = cblkstart.data() + cb_at;
             for (size_t k = 0; k < nb; ++k)
             {
-                cblkstart.push_back(run);
-                if (ok)
+                cb[k] = run;
+                if (ok && !contrib[k].empty())
                 {
                     cblkitems.insert(cblkitems.end(), contrib[k].begin(), contrib[k].end());
                     run += (int)contrib[k].size();
                 }
             }
-            cblkstart.push_back(run);
+            cb[nb] = run;
         }
         mark(5);
         // relative pose constraints (IMU scenes): valid ones, per-camera incidence, per-block chains
@@ -3954,7 +3975,8 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             for (int c = 0; c < nfc; ++c) cs[(size_t)c + 1] += cs[(size_t)c];
             const int item_base = (int)camrpcitems.size();
             std::vector<int> items((size_t)cs[(size_t)nfc]), fill(cs.begin(), cs.end() - 1);
-            std::vector<int> brpc((size_t)nfc * nfc, 0), nxt(mine.size(), 0);
+            // the per-block chains are only read for problems that HAVE constraints: the others advance the offset and write nothing
+            std::vector<int> brpc(mine.empty() ? 0 : (size_t)nfc * nfc, 0), nxt(mine.size(), 0);
             for (int k = 0; k < (int)mine.size(); ++k)
             {
                 const RpcMeta& m = mine[(size_t)k];
@@ -3971,7 +3993,12 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             }
             for (int c = 0; c <= nfc; ++c) camrpcstart.push_back(item_base + cs[(size_t)c]);
             camrpcitems.insert(camrpcitems.end(), items.begin(), items.end());
-            blkrpc.insert(blkrpc.end(), brpc.begin(), brpc.end());
+            if (!mine.empty())
+            {
+                blkrpc.resize(blkrpc_logical, 0);  // zeros for the problems without constraints in front of this one
+                blkrpc.insert(blkrpc.end(), brpc.begin(), brpc.end());
+            }
+            blkrpc_logical += (size_t)nfc * nfc;
             rpcnext.insert(rpcnext.end(), nxt.begin(), nxt.end());
             rpcmeta.insert(rpcmeta.end(), mine.begin(), mine.end());
         }
@@ -4022,6 +4049,10 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     }
     else
     {
+        long long bound = 0;
+        for (int b = 0; b < count; ++b) bound += ent_bound[(size_t)b];
+        LS.blkent.reserve((size_t)bound);  // one pinned allocation instead of a doubling chain
+        LS.blkstart.reserve((size_t)blkstart_total);
         for (int b = 0; b < count; ++b)
         {
             probs[(size_t)b].be_nch  = 0;
@@ -4299,9 +4330,9 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         fprintf(stderr, "[snk_ba_set_problems] lists %lld us, uploads %lld us, reserve+memset %lld us, sync %lld us\n", us(t_begin, t_lists),
                 us(t_lists, t_up), us(t_up, t_rs), us(t_rs, t_end));
         fprintf(stderr, "[snk_ba_set_problems] lists in us: values+sort %lld, observation arrays %lld, wave items %lld, camera lists %lld, "
-                        "block entries %lld, point sets %lld, constraints %lld, rest %lld\n",
-                sec_us[0] / 1000, sec_us[1] / 1000, sec_us[2] / 1000, sec_us[3] / 1000, sec_us[4] / 1000, sec_us[5] / 1000, sec_us[6] / 1000,
-                sec_us[7] / 1000);
+                        "block entries %lld, point sets %lld (grouping %lld, work items %lld, block lists %lld), constraints %lld, rest %lld\n",
+                sec_us[0] / 1000, sec_us[1] / 1000, sec_us[2] / 1000, sec_us[3] / 1000, sec_us[4] / 1000,
+                (sec_us[5] + sec_us[8] + sec_us[9]) / 1000, sec_us[8] / 1000, sec_us[9] / 1000, sec_us[5] / 1000, sec_us[6] / 1000, sec_us[7] / 1000);
     }
     return SNK_OK;
 }

@@ -9,6 +9,9 @@ for n_kf, n_pt in [(120, 6000), (300, 15000), (600, 30000)]:
     ba = BARec(lba_options(max_iterations=4, max_pcg_iterations=40))
     t0 = time.perf_counter(); ba.create(sc); t1 = time.perf_counter()
     ci, cf = ba.initAndSolve(); t2 = time.perf_counter()
+    ta = time.perf_counter(); ba.create(sc); tb = time.perf_counter()  # the same handle again: buffers and pinned lists keep their capacity
+    print("   second create on the handle %.1f ms" % ((tb - ta) * 1e3), flush=True)
+    ba.initAndSolve()
     ba.reset(); t3 = time.perf_counter(); ci, cf = ba.initAndSolve(); t4 = time.perf_counter()
     print(n_kf, n_pt, "create %.1f ms solve(first) %.1f ms solve %.1f ms" % ((t1-t0)*1e3, (t2-t1)*1e3, (t4-t3)*1e3), ci[0], cf[0], flush=True)
     pose, pt, _ = ba.state(0)
