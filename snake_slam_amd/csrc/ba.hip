@@ -3134,16 +3134,19 @@ __global__ __launch_bounds__(256) void gather_cam_records(Arrays A, CamObs* __re
 // The camera-pair block entries of schur_pass -- for every upper block (c1, c2) the co-observations (observation of c1,
 // observation of c2, point) in ascending order -- built by three launches instead of a host loop over every pair of every
 // point (half of a scene hand-over's host time, and 1.1 MB over the bus for a 20 x 2000 x 8 window).  Requirements (checked
-// on the host, which keeps its own builder for the other scenes): <= 64 free cameras, no camera twice on a point.
+// on the host, which keeps its own builder for the other scenes): <= BE_MAX_CAMS free cameras, no camera twice on a point.
 // One wavefront per (camera c1, 64 items of its list): lane = one observation a of c1; the free cameras >= c1 in its point's
-// run are a 64-bit mask; ballot(c2 in mask) ranks the lane inside the chunk for block (c1, c2).  Order inside a block = list
-// order of c1 = ascending observation index = ascending point: the host builder's order.
+// run are a bit mask (BE_WORDS x 64 bits in registers); ballot(c2 in mask) ranks the lane inside the chunk for block (c1, c2).
+// Order inside a block = list order of c1 = ascending observation index = ascending point: the host builder's order.
+constexpr int BE_WORDS = 8, BE_MAX_CAMS = 64 * BE_WORDS;
 __device__ inline void block_entry_item(const Arrays& A, const Prob& pr, int c1, int chunk, int lane, int& a, int& p, int& r0, int& r1,
-                                        unsigned long long& mask)
+                                        unsigned long long (&mask)[BE_WORDS])
 {
     const int s0 = A.cam_start[pr.camstart_off + c1], s1 = A.cam_start[pr.camstart_off + c1 + 1];
     const int k  = s0 + chunk * 64 + lane;
-    a = -1, p = 0, r0 = 0, r1 = 0, mask = 0ull;
+    a = -1, p = 0, r0 = 0, r1 = 0;
+#pragma unroll
+    for (int w = 0; w < BE_WORDS; ++w) mask[w] = 0ull;
     if (k >= s1) return;
     const int s  = A.cam_items[pr.citem_off + k];
     const int go = pr.obs_off + s;
@@ -3154,65 +3157,81 @@ __device__ inline void block_entry_item(const Arrays& A, const Prob& pr, int c1,
     for (int c = r0; c < r1; ++c)
     {
         const int cc = A.o_cam[pr.obs_off + c];
-        if (cc >= c1) mask |= 1ull << cc;
+        if (cc < c1) continue;
+        const unsigned long long bit = 1ull << (cc & 63);
+#pragma unroll
+        for (int w = 0; w < BE_WORDS; ++w)
+            if (w == (cc >> 6)) mask[w] |= bit;
     }
 }
 
 __global__ __launch_bounds__(64) void block_entries_count(Arrays A, int* __restrict__ cnt)
 {
     const Prob pr = A.prob[blockIdx.y];
-    const int w   = blockIdx.x;
-    if (pr.be_nch <= 0 || w >= pr.nfc * pr.be_nch) return;
-    const int c1 = w / pr.be_nch, chunk = w - c1 * pr.be_nch, lane = threadIdx.x;
+    const int w0  = blockIdx.x;
+    if (pr.be_nch <= 0 || w0 >= pr.nfc * pr.be_nch) return;
+    const int c1 = w0 / pr.be_nch, chunk = w0 - c1 * pr.be_nch, lane = threadIdx.x;
     int a, p, r0, r1;
-    unsigned long long mask;
+    unsigned long long mask[BE_WORDS];
     block_entry_item(A, pr, c1, chunk, lane, a, p, r0, r1, mask);
-    int mine = 0;
-    for (int c2 = c1; c2 < pr.nfc; ++c2)
+    int* out = cnt + pr.becnt_off + (size_t)(c1 * pr.be_nch + chunk) * pr.nfc;
+#pragma unroll
+    for (int w = 0; w < BE_WORDS; ++w)
     {
-        const unsigned long long m = __builtin_amdgcn_ballot_w64((mask >> c2) & 1ull);
-        if (lane == c2) mine = __popcll(m);
+        if (w * 64 >= pr.nfc) break;  // uniform
+        int mine = 0;
+        if (__builtin_amdgcn_ballot_w64(mask[w] != 0ull) != 0ull)  // uniform: most words of a big scene are empty
+            for (int b = 0; b < 64; ++b)
+            {
+                const unsigned long long m = __builtin_amdgcn_ballot_w64((mask[w] >> b) & 1ull);
+                if (lane == b) mine = __popcll(m);
+            }
+        if (w * 64 + lane < pr.nfc) out[w * 64 + lane] = mine;  // (cameras below c1 are in no mask: zeros)
     }
-    if (lane < pr.nfc) cnt[pr.becnt_off + (size_t)(c1 * pr.be_nch + chunk) * pr.nfc + lane] = mine;
 }
 
 // per problem: chunk counts -> chunk bases (in place), block totals -> blk_start (exclusive scan over the nfc * nfc blocks)
-__global__ __launch_bounds__(256) void block_entries_scan(Arrays A, int* __restrict__ cnt, int* __restrict__ blk_start)
+constexpr int BE_SCAN_THREADS = 1024;
+__global__ __launch_bounds__(BE_SCAN_THREADS) void block_entries_scan(Arrays A, int* __restrict__ cnt, int* __restrict__ blk_start)
 {
-    __shared__ int s_scan[256];
+    __shared__ int s_wave[BE_SCAN_THREADS / 64];
     __shared__ int s_run;
     const Prob pr = A.prob[blockIdx.x];
-    const int nb = pr.nfc * pr.nfc, tid = threadIdx.x;
+    const int nb = pr.nfc * pr.nfc, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_run = 0;
     __syncthreads();
-    for (int base = 0; base < nb; base += 256)
+    for (int base = 0; base < nb; base += BE_SCAN_THREADS)
     {
         const int blk = base + tid;
         int tot = 0;
         if (blk < nb && pr.be_nch > 0)
         {
             const int c1 = blk / pr.nfc, c2 = blk - c1 * pr.nfc;
-            for (int ch = 0; ch < pr.be_nch; ++ch)
-            {
-                int* q = cnt + pr.becnt_off + (size_t)(c1 * pr.be_nch + ch) * pr.nfc + c2;
-                const int v = *q;
-                *q = tot;
-                tot += v;
-            }
+            if (c2 >= c1)  // the lower blocks have no entries (and their counters were never written)
+                for (int ch = 0; ch < pr.be_nch; ++ch)
+                {
+                    int* q = cnt + pr.becnt_off + (size_t)(c1 * pr.be_nch + ch) * pr.nfc + c2;
+                    const int v = *q;
+                    *q = tot;
+                    tot += v;
+                }
         }
-        s_scan[tid] = tot;
-        __syncthreads();
-        for (int off = 1; off < 256; off <<= 1)  // inclusive scan
+        // inclusive scan: inside the wavefront by shuffles, then the wavefront totals
+        int incl = tot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1)
         {
-            const int v = tid >= off ? s_scan[tid - off] : 0;
-            __syncthreads();
-            s_scan[tid] += v;
-            __syncthreads();
+            const int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
         }
-        const int run = s_run;
-        if (blk < nb) blk_start[pr.blkstart_off + blk] = run + s_scan[tid] - tot;
+        if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
-        if (tid == 255) s_run = run + s_scan[255];
+        int before = 0;
+        for (int w = 0; w < wave; ++w) before += s_wave[w];
+        const int run = s_run;
+        if (blk < nb) blk_start[pr.blkstart_off + blk] = run + before + incl - tot;
+        __syncthreads();
+        if (tid == BE_SCAN_THREADS - 1) s_run = run + before + incl;
         __syncthreads();
     }
     if (tid == 0) blk_start[pr.blkstart_off + nb] = s_run;
@@ -3220,25 +3239,33 @@ __global__ __launch_bounds__(256) void block_entries_scan(Arrays A, int* __restr
 
 __global__ __launch_bounds__(64) void block_entries_fill(Arrays A, const int* __restrict__ cnt, int4* __restrict__ blk_ent)
 {
-    __shared__ unsigned long long s_ball[64];
-    __shared__ int s_base[64];
+    extern __shared__ __attribute__((aligned(16))) unsigned char be_smem[];
     const Prob pr = A.prob[blockIdx.y];
-    const int w   = blockIdx.x;
-    if (pr.be_nch <= 0 || w >= pr.nfc * pr.be_nch) return;
-    const int c1 = w / pr.be_nch, chunk = w - c1 * pr.be_nch, lane = threadIdx.x;
+    const int w0  = blockIdx.x;
+    if (pr.be_nch <= 0 || w0 >= pr.nfc * pr.be_nch) return;
+    unsigned long long* s_ball = reinterpret_cast<unsigned long long*>(be_smem);  // [words * 64] ballots per camera c2
+    const int nwords = (pr.nfc + 63) >> 6;
+    int* s_base = reinterpret_cast<int*>(s_ball + nwords * 64);                     // [words * 64] first entry of (c1, chunk, c2)
+    const int c1 = w0 / pr.be_nch, chunk = w0 - c1 * pr.be_nch, lane = threadIdx.x;
     int a, p, r0, r1;
-    unsigned long long mask;
+    unsigned long long mask[BE_WORDS];
     block_entry_item(A, pr, c1, chunk, lane, a, p, r0, r1, mask);
-    unsigned long long mine = 0ull;
-    for (int c2 = c1; c2 < pr.nfc; ++c2)
+    const int* cin = cnt + pr.becnt_off + (size_t)(c1 * pr.be_nch + chunk) * pr.nfc;
+#pragma unroll
+    for (int w = 0; w < BE_WORDS; ++w)
     {
-        const unsigned long long m = __builtin_amdgcn_ballot_w64((mask >> c2) & 1ull);
-        if (lane == c2) mine = m;
+        if (w * 64 >= pr.nfc) break;  // uniform
+        unsigned long long mine = 0ull;
+        if (__builtin_amdgcn_ballot_w64(mask[w] != 0ull) != 0ull)
+            for (int b = 0; b < 64; ++b)
+            {
+                const unsigned long long m = __builtin_amdgcn_ballot_w64((mask[w] >> b) & 1ull);
+                if (lane == b) mine = m;
+            }
+        const int c2 = w * 64 + lane;
+        s_ball[c2] = mine;
+        s_base[c2] = c2 >= c1 && c2 < pr.nfc ? A.blk_start[pr.blkstart_off + c1 * pr.nfc + c2] + cin[c2] : 0;
     }
-    s_ball[lane] = mine;
-    s_base[lane] = lane >= c1 && lane < pr.nfc ? A.blk_start[pr.blkstart_off + c1 * pr.nfc + lane] +
-                                                     cnt[pr.becnt_off + (size_t)(c1 * pr.be_nch + chunk) * pr.nfc + lane]
-                                               : 0;
     __syncthreads();
     if (a < 0) return;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -3435,7 +3462,6 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     probs.resize((size_t)count);
     auto &pose = LS.pose, &pt = LS.pt, &ouv2 = LS.ouv2, &odepth = LS.odepth, &oweight = LS.oweight;
     auto &ptc = LS.ptc, &optfree = LS.optfree;
-    auto& csobs    = LS.csobs;
     auto& setitems = LS.setitems;
     auto& setobs   = LS.setobs;
     auto& setpts   = LS.setpts;
@@ -3517,7 +3543,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     std::vector<long long> ent_bound((size_t)count, 0);
     int blkstart_total = 0, max_citems = 0;
     // camera-pair blocks on the host: co-observations of every ordered pair (dense block grid, empty blocks allowed).  The
-    // builder for scenes the device kernels do not take (more than 64 free cameras, one camera twice on a point), and their checker.
+    // builder for scenes the device kernels do not take (more than 512 free cameras, one camera twice on a point), and their checker.
     auto host_block_entries = [&](int b, pvec<int>& blkstart, pvec<int4>& blkent)
     {
         const snk_ba_problem& P = problems[b];
@@ -3646,18 +3672,24 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             int* q_img = oimg.data() + at, *q_cam = ocam.data() + at, *q_orig = oorig.data() + at, *q_pt = optidx.data() + at;
             unsigned char* q_free = optfree.data() + at;
             double *q_uv = ouv2.data() + 2 * at, *q_d = odepth.data() + at, *q_w = oweight.data() + at;
-            unsigned long long seen = 0ull;  // free cameras of the current point (device-built block entries: no camera twice)
-            int seen_pt             = -1;
+            unsigned long long seen[BE_WORDS] = {};  // free cameras of the current point (device-built block entries: no camera twice)
+            int seen_pt                       = -1;
+            const int seen_words              = nfc <= BE_MAX_CAMS ? (nfc + 63) >> 6 : 0;
             for (int s = 0; s < no; ++s)
             {
                 const int o = order[(size_t)s];
                 const int i = P.obs_img[o], p = P.obs_pt[o];
-                if (p != seen_pt) seen = 0ull, seen_pt = p;
-                if (cidx[(size_t)i] >= 0 && nfc <= 64)
+                if (p != seen_pt)
                 {
-                    const unsigned long long bit = 1ull << cidx[(size_t)i];
-                    if (seen & bit) dev_entries_ok = false;
-                    seen |= bit;
+                    for (int w = 0; w < seen_words; ++w) seen[w] = 0ull;
+                    seen_pt = p;
+                }
+                if (cidx[(size_t)i] >= 0 && nfc <= BE_MAX_CAMS)
+                {
+                    const unsigned long long bit = 1ull << (cidx[(size_t)i] & 63);
+                    unsigned long long& word     = seen[cidx[(size_t)i] >> 6];
+                    if (word & bit) dev_entries_ok = false;
+                    word |= bit;
                 }
                 q_img[s]  = i;
                 q_cam[s]  = cidx[(size_t)i];
@@ -3722,7 +3754,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             pr.be_nch = ceil_div(longest, 64);
             // (the same list as static records -- what cam_pass streams -- is gathered on the device: gather_cam_records)
         }
-        if (nfc > 64) dev_entries_ok = false;
+        if (nfc > BE_MAX_CAMS) dev_entries_ok = false;
         {
             // room for the block entries when the device builds them: every pair of a point's run is the most there can be
             long long bound = 0;
@@ -4266,11 +4298,12 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             hipLaunchKernelGGL(block_entries_count, dim3(max_be_waves, count), dim3(64), 0, st, A, h->d_becnt.as<int>());
             SNK_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL(block_entries_scan, dim3(count), dim3(256), 0, st, A, h->d_becnt.as<int>(), h->d_blkstart.as<int>());
+        hipLaunchKernelGGL(block_entries_scan, dim3(count), dim3(BE_SCAN_THREADS), 0, st, A, h->d_becnt.as<int>(), h->d_blkstart.as<int>());
         SNK_LAUNCH_CHECK();
         if (max_be_waves > 0)
         {
-            hipLaunchKernelGGL(block_entries_fill, dim3(max_be_waves, count), dim3(64), 0, st, A, h->d_becnt.as<int>(), h->d_blkent.as<int4>());
+            const size_t be_lds = (size_t)((max_nfc + 63) / 64) * 64 * 12;  // ballots (8 B) + bases (4 B) per camera
+            hipLaunchKernelGGL(block_entries_fill, dim3(max_be_waves, count), dim3(64), be_lds, st, A, h->d_becnt.as<int>(), h->d_blkent.as<int4>());
             SNK_LAUNCH_CHECK();
         }
     }

@@ -23,7 +23,7 @@ ROOT = Path(__file__).resolve().parent.parent
     {"SNK_BA_SCHUR_SET_MIN_ITEMS": "1", "SNK_BA_NO_SCHUR_FUSED": "1"},  # point_wave + schur_mfma (W through HBM)
     {"SNK_BA_SCHUR_SET_MIN_ITEMS": "1", "SNK_BA_NO_SCHUR_MFMA": "1"},   # point_wave + the vector-ALU schur_set          # explicitly built hipGraph already for the first solve of every scene
     {"SNK_BA_CHECK_LISTS": "1", "SNK_BA_NO_SCHUR_SET": "1"},            # every scene hand-over compares the device-built lists (camera records, block entries) with the host builder's
-    {"SNK_BA_HOST_ENTRIES": "1", "SNK_BA_NO_SCHUR_SET": "1"},           # block entries by the host builder (what scenes with > 64 free cameras use)
+    {"SNK_BA_HOST_ENTRIES": "1", "SNK_BA_NO_SCHUR_SET": "1"},           # block entries by the host builder (what scenes with > 512 free cameras use)
     {"SNK_BA_SCHUR_SET_MIN_ITEMS": "1", "SNK_BA_CAM_SUMS": "1"},       # schur_fused<3, true>'s per-item camera sums + cam_sum instead of cam_pass (measured slower: not the default)
     {"SNK_BA_PCG_LDS": "1"},                                            # S in LDS (pcg_solve<true>) instead of registers (pcg_small) for local-BA sized systems
     {"SNK_BA_LOCAL_SYNC": "1"},                                         # snk_ba_solve_local_scene decides about the extra iteration on the host (count read back)
@@ -43,7 +43,7 @@ def test_ba_parity_suite_with_forced_path(env):
 def test_equivalent_paths_give_bit_identical_solutions(pair):
     """Pairs of paths that run the same arithmetic in the same order, in two child processes, must agree bit for bit:
     * the camera records and camera-pair block entries are built by kernels (gather_cam_records, block_entries_*) when a scene has
-      <= 64 free cameras and no camera twice on a point.  With SNK_BA_CHECK_LISTS=1 snk_ba_set_problems compares them with the
+      <= 512 free cameras and no camera twice on a point.  With SNK_BA_CHECK_LISTS=1 snk_ba_set_problems compares them with the
       host builder element by element (and fails on a difference); SNK_BA_HOST_ENTRIES=1 uses the host builder's lists;
     * pcg_small keeps its quarter of S in registers, pcg_solve<true> reads it from LDS -- same summation order."""
     code = r"""
@@ -52,7 +52,8 @@ from snake_slam_amd import synth
 from snake_slam_amd.ba import BARec, lba_options
 rng = np.random.default_rng(5)
 scenes = []
-for seed, (kf, npt, opp) in enumerate([(20, 2000, 8), (3, 10, 2), (8, 300, 5), (64, 500, 12), (66, 400, 6), (5, 1, 5), (12, 700, 12)]):
+for seed, (kf, npt, opp) in enumerate([(20, 2000, 8), (3, 10, 2), (8, 300, 5), (64, 500, 12), (66, 400, 6), (5, 1, 5), (12, 700, 12), (131, 900, 9),
+                                       (520, 1600, 7)]):  # 130 free cameras: three mask words on the device; 519: the host builder
     sc, _ = synth.ba_scene(n_kf=kf, n_pt=npt, obs_per_pt=opp, seed=100 + seed, outlier_frac=0.02, n_fixed=1 + seed % 3)
     sc["pt_const"][: npt // 7] = 1
     sc["obs_img"] = sc["obs_img"].copy(); sc["obs_pt"] = sc["obs_pt"].copy()
