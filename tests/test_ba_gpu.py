@@ -329,14 +329,17 @@ def _local_scene_by_steps(ba, sc, problem, pre):
     return int(mark.sum()), ci[problem], cf[problem], pose, pt, flags
 
 
-@pytest.mark.parametrize("case", ["outliers", "clean", "preset", "invalid"])
+@pytest.mark.parametrize("case", ["outliers", "clean", "preset", "invalid", "multi_workgroup_pcg"])
 def test_solve_local_scene_equals_the_call_sequence(orc, case):
     """snk_ba_solve_local_scene == solve -> residuals -> host threshold -> set_outliers -> solve(1) -> get_state, bit for bit
     (same kernels in the same order; only the thresholding moved to the device)."""
     from snake_slam_amd import synth
     from snake_slam_amd.ba import BARec, lba_options
 
-    sc, _ = synth.ba_scene(n_kf=8, n_pt=300, obs_per_pt=5, seed=21, outlier_frac=0.0 if case == "clean" else 0.05,
+    # 30 keyframes: the reduced system (174 unknowns) exceeds one workgroup's LDS -> multi-workgroup PCG, whose launch sequence
+    # sizes itself on the host: the extra iteration is decided after reading the count back
+    n_kf, n_pt = (30, 900) if case == "multi_workgroup_pcg" else (8, 300)
+    sc, _ = synth.ba_scene(n_kf=n_kf, n_pt=n_pt, obs_per_pt=5, seed=21, outlier_frac=0.0 if case == "clean" else 0.05,
                            pixel_noise=0.05 if case == "clean" else 0.5)
     pre = None
     if case == "preset":
