@@ -87,13 +87,14 @@ struct Opt
     int max_pcg;
     int pcg_general;  // SNK_BA_PCG_GENERAL=1: the 256-thread PCG loop for every size (A/B against the replicated one)
     double pcg_tol, huber_mono, huber_stereo, lambda_init;
+    double chi2_mono, chi2_stereo;  // point_pass<3> (the chi-square pass of SolveLocalScene): thresholds of the squared residual
 };
 
 struct State  // per problem, device resident
 {
     double cost, cost_new, lambda, vfac, cost_initial;
     int accepted, iter, pcg_iters;
-    int marked;  // observations the chi-square pass after this solve marked (mark_outliers_kernel); begin_solve resets it
+    int marked;  // observations the chi-square pass after this solve marked (point_pass<3>); begin_solve resets it
     double first_cost_initial, first_cost;  // the costs at the time of that pass (a conditional extra iteration overwrites the others)
 };
 
@@ -273,7 +274,13 @@ __global__ __launch_bounds__(128) void point_pass(Arrays A, Opt O)
     const int pb  = blockIdx.y;
     const Prob pr = A.prob[pb];
     const int p   = blockIdx.x * 128 + threadIdx.x;
+    if (MODE == 3 && blockIdx.x == 0 && threadIdx.x == 0)  // the costs at the time of the chi-square pass (see State)
+    {
+        A.state[pb].first_cost_initial = A.state[pb].cost_initial;
+        A.state[pb].first_cost         = A.state[pb].cost;
+    }
     if (p >= pr.np) return;
+    int marked          = 0;
     const int gp        = pr.pt_off + p;
     const double* poses = (MODE == 1 ? A.pose_new : A.pose) + (size_t)pr.img_off * 7;
     const double* ptp   = (MODE == 1 ? A.pt_new : A.pt) + (size_t)gp * 3;
@@ -303,6 +310,17 @@ __global__ __launch_bounds__(128) void point_pass(Arrays A, Opt O)
         if (MODE == 2)
         {
             A.chi2[oo] = sq;
+            continue;
+        }
+        if (MODE == 3)
+        {
+            // SolveLocalScene's chi-square pass (LocalBundleAdjustment.cpp:368-397): a valid observation that is not an outlier
+            // yet (those were skipped above) becomes one when its squared residual exceeds the threshold of its kind
+            if (sq > (A.o_depth[go] > 0.0 ? O.chi2_stereo : O.chi2_mono))
+            {
+                const_cast<unsigned char*>(A.outlier)[oo] = 1;
+                ++marked;
+            }
             continue;
         }
         if (!dim) continue;
@@ -345,6 +363,11 @@ __global__ __launch_bounds__(128) void point_pass(Arrays A, Opt O)
         }
     }
     if (MODE == 2) return;
+    if (MODE == 3)
+    {
+        if (marked) atomicAdd(&A.state[pb].marked, marked);  // integer: order independent
+        return;
+    }
     if (MODE == 1)
     {
         A.cost_pt_new[gp] = cost;
@@ -3042,6 +3065,7 @@ struct BaLists
     pvec<int> camidx, ptstart, oimg, ocam, oorig, camstart, camitems, blkstart, optidx, wvpt, rpcnext, camrpcstart, camrpcitems, blkrpc;
     pvec<RpcMeta> rpcmeta;
     pvec<int4> blkent;
+    pvec<State> states;
     void clear()
     {
         probs.clear(), pose.clear(), pt.clear(), ouv2.clear(), odepth.clear(), oweight.clear(), ptc.clear(), optfree.clear();
@@ -3059,6 +3083,7 @@ struct snk_ba : HandleBase
     DevBuf d_becnt;   // per (camera, 64-item chunk, camera) counters of the device-built block entries
     DevBuf d_probcond;  // the problem table of a conditional extra iteration (select_marked)
     DevBuf d_campart, d_ccstart, d_ccitems;  // per (work item, free camera) sums of schur_fused<3, true> and the per-camera lists of them
+    bool state_fresh = false;                // the device state is the uploaded initial one (no solve since the hand-over)
     bool cam_sums_ok = false;                // every observation of a free camera belongs to a work item with pairs (no constant point seen by a free camera)
     snk_ba_options opt{};
     int count = 0;
@@ -3101,6 +3126,7 @@ Opt make_opt(const snk_ba_options& o)
     d.huber_mono   = o.huber_mono;
     d.huber_stereo = o.huber_stereo;
     d.lambda_init  = o.lambda_init > 0.0 ? o.lambda_init : 1e-4;
+    d.chi2_mono = d.chi2_stereo = 0.0;
     return d;
 }
 
@@ -3277,43 +3303,27 @@ __global__ __launch_bounds__(64) void block_entries_fill(Arrays A, const int* __
     }
 }
 
-// The chi-square pass of SolveLocalScene (reference Snake/Optimizer/LocalBundleAdjustment.cpp:368-397) on the device: every observation
-// that is not yet an outlier and whose squared residual (A.chi2, caller order, written by point_pass<2>) exceeds its threshold
-// becomes one; state[problem].marked = how many were marked (reset by begin_solve).  Integer atomics only (order independent).
-// A.chi2 is read for VALID observations only (point_pass<2> writes every one of them), so it needs no clearing first.
-__global__ __launch_bounds__(256) void mark_outliers_kernel(Arrays A, unsigned char* __restrict__ outlier_w, double chi2_mono,
-                                                            double chi2_stereo)
-{
-    const int pb  = blockIdx.y;
-    const Prob pr = A.prob[pb];
-    const int s   = blockIdx.x * 256 + threadIdx.x;
-    bool mark     = false;
-    if (s < pr.no)
-    {
-        const int orig = A.o_orig[pr.obs_off + s];
-        mark = !outlier_w[orig] && A.chi2[orig] > (A.o_depth[pr.obs_off + s] > 0.0 ? chi2_stereo : chi2_mono);
-        if (mark) outlier_w[orig] = 1;
-    }
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(mark);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&A.state[pb].marked, __popcll(m));
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-    {
-        A.state[pb].first_cost_initial = A.state[pb].cost_initial;
-        A.state[pb].first_cost         = A.state[pb].cost;
-    }
-}
-
 // The extra iteration of SolveLocalScene runs only for scenes whose chi-square pass marked something
 // (LocalBundleAdjustment.cpp:399).  Instead of reading the count back and deciding on the host, the iteration is enqueued
 // behind the pass with THIS table of problems: an unmarked problem appears with every size zero, so each kernel of the
 // iteration finds nothing to do for it (the same way an empty scene in a batch does); begin_solve and accept_pass, which touch
 // the per-problem state whatever the sizes, take the condition as an argument.
-__global__ __launch_bounds__(64) void select_marked(const Prob* __restrict__ prob, Prob* __restrict__ out, const State* __restrict__ st, int n)
+__global__ __launch_bounds__(64) void select_marked(const Prob* __restrict__ prob, Prob* __restrict__ out, State* __restrict__ st, int n,
+                                                    double lambda_init)
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     Prob p = prob[i];
-    if (st[i].marked == 0) p.ni = p.np = p.no = p.nfc = p.n6 = p.n_wv = p.n_rpc = p.n_set = p.be_nch = 0;
+    if (st[i].marked == 0)
+        p.ni = p.np = p.no = p.nfc = p.n6 = p.n_wv = p.n_rpc = p.n_set = p.be_nch = 0;
+    else  // what begin_solve does (but the count stays: the kernels of the iteration test it)
+    {
+        st[i].lambda    = lambda_init;
+        st[i].vfac      = 2.0;
+        st[i].iter      = 0;
+        st[i].pcg_iters = 0;
+        st[i].accepted  = 0;
+    }
     out[i] = p;
 }
 
@@ -3654,46 +3664,40 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         for (int p = 0; p < P.n_pt; ++p) pstart[(size_t)p + 1] += pstart[(size_t)p];
         const int no = pstart[(size_t)P.n_pt];
         pr.no        = no;
-        std::vector<int> order((size_t)no);
-        {
-            std::vector<int> fill(pstart.begin(), pstart.end() - 1);
-            for (int o = 0; o < P.n_obs; ++o)
-                if (valid[(size_t)o]) order[(size_t)fill[(size_t)P.obs_pt[o]]++] = o;
-        }
         pr.ptstart_off = (int)ptstart.size();
         ptstart.insert(ptstart.end(), pstart.begin(), pstart.end());
         mark(0);
-        std::vector<int> s_cam((size_t)no);
+        // the sorted observation arrays, written in ONE pass over the caller's order: position = next free slot of the point
+        // (sized once, written by index: nine push_backs per observation were a fifth of the hand-over's host time; a
+        // separate pass that built the sorted order first was another tenth)
+        const size_t obs_at = oimg.size();
+        oimg.resize(obs_at + (size_t)no), ocam.resize(obs_at + (size_t)no), optfree.resize(obs_at + (size_t)no), ouv2.resize(2 * (obs_at + (size_t)no));
+        odepth.resize(obs_at + (size_t)no), oweight.resize(obs_at + (size_t)no), oorig.resize(obs_at + (size_t)no), optidx.resize(obs_at + (size_t)no);
+        const int* const s_cam  = ocam.data() + obs_at;   // free-camera index of sorted observation s (stable until the next problem)
+        const int* const s_orig = oorig.data() + obs_at;  // its caller-order index + orig_off
         {
-            // sized once, written by index (nine push_backs per observation were a fifth of the hand-over's host time)
-            const size_t at = oimg.size();
-            oimg.resize(at + (size_t)no), ocam.resize(at + (size_t)no), optfree.resize(at + (size_t)no), ouv2.resize(2 * (at + (size_t)no));
-            odepth.resize(at + (size_t)no), oweight.resize(at + (size_t)no), oorig.resize(at + (size_t)no), optidx.resize(at + (size_t)no);
-            int* q_img = oimg.data() + at, *q_cam = ocam.data() + at, *q_orig = oorig.data() + at, *q_pt = optidx.data() + at;
-            unsigned char* q_free = optfree.data() + at;
-            double *q_uv = ouv2.data() + 2 * at, *q_d = odepth.data() + at, *q_w = oweight.data() + at;
-            unsigned long long seen[BE_WORDS] = {};  // free cameras of the current point (device-built block entries: no camera twice)
-            int seen_pt                       = -1;
-            const int seen_words              = nfc <= BE_MAX_CAMS ? (nfc + 63) >> 6 : 0;
-            for (int s = 0; s < no; ++s)
+            int* q_img = oimg.data() + obs_at, *q_cam = ocam.data() + obs_at, *q_orig = oorig.data() + obs_at, *q_pt = optidx.data() + obs_at;
+            unsigned char* q_free = optfree.data() + obs_at;
+            double *q_uv = ouv2.data() + 2 * obs_at, *q_d = odepth.data() + obs_at, *q_w = oweight.data() + obs_at;
+            // free cameras seen so far per point (device-built block entries: no camera twice on a point)
+            const int seen_words = nfc <= BE_MAX_CAMS ? (nfc + 63) >> 6 : 0;
+            std::vector<unsigned long long> seen((size_t)P.n_pt * (size_t)seen_words, 0ull);
+            std::vector<int> fill(pstart.begin(), pstart.end() - 1);
+            for (int o = 0; o < P.n_obs; ++o)
             {
-                const int o = order[(size_t)s];
+                if (!valid[(size_t)o]) continue;
                 const int i = P.obs_img[o], p = P.obs_pt[o];
-                if (p != seen_pt)
+                const int s = fill[(size_t)p]++;
+                const int c = cidx[(size_t)i];
+                if (c >= 0 && seen_words)
                 {
-                    for (int w = 0; w < seen_words; ++w) seen[w] = 0ull;
-                    seen_pt = p;
-                }
-                if (cidx[(size_t)i] >= 0 && nfc <= BE_MAX_CAMS)
-                {
-                    const unsigned long long bit = 1ull << (cidx[(size_t)i] & 63);
-                    unsigned long long& word     = seen[cidx[(size_t)i] >> 6];
+                    const unsigned long long bit = 1ull << (c & 63);
+                    unsigned long long& word     = seen[(size_t)p * (size_t)seen_words + (size_t)(c >> 6)];
                     if (word & bit) dev_entries_ok = false;
                     word |= bit;
                 }
                 q_img[s]  = i;
-                q_cam[s]  = cidx[(size_t)i];
-                s_cam[(size_t)s] = cidx[(size_t)i];
+                q_cam[s]  = c;
                 q_free[s] = P.pt_const[p] ? 0 : 1;
                 q_uv[2 * s]     = P.obs_uv[o][0];
                 q_uv[2 * s + 1] = P.obs_uv[o][1];
@@ -3921,7 +3925,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                             ipts.push_back(make_int2(pp, pstart[(size_t)pp]));
                             for (int a = 0; a < si.run; ++a)
                             {
-                                const int sidx = pstart[(size_t)pp] + a, o = order[(size_t)sidx];
+                                const int sidx = pstart[(size_t)pp] + a, o = s_orig[sidx] - orig_off;
                                 SetObs rec;
                                 rec.u = P.obs_uv[o][0]; rec.v = P.obs_uv[o][1];
                                 rec.depth = P.obs_depth[o]; rec.weight = P.obs_weight[o];
@@ -4209,7 +4213,18 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         return SNK_OK;
     };
     if ((rc = zero(h->d_outlier, (size_t)std::max(orig_off, 1))) != SNK_OK) return rc;
-    if ((rc = zero(h->d_state, (size_t)count * sizeof(State))) != SNK_OK) return rc;
+    {
+        // the state starts as begin_solve would leave it (the first solve of the scene then needs no launch for that)
+        auto& states = LS.states;
+        State s0{};
+        s0.lambda = make_opt(h->opt).lambda_init;
+        s0.vfac   = 2.0;
+        states.assign((size_t)count, s0);
+        SNK_REQUIRE(tab.n < COPY_TAB_MAX, "scene list too large for the upload table");
+        tab.src[tab.n] = states.data(), tab.dst[tab.n] = h->d_state.p, tab.bytes[tab.n] = (unsigned)(states.size() * sizeof(State));
+        ++tab.n;
+        h->state_fresh = true;
+    }
     if ((rc = zero(h->d_r, nobs * 4 * 8)) != SNK_OK) return rc;
     if ((rc = zero(h->d_x, (size_t)std::max(vec_off, 1) * 8)) != SNK_OK) return rc;
     // points without observations are in no work item of schur_fused: their cost, V^-1 and b_p are zero once and for all
@@ -4417,10 +4432,15 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L, bool only_marked =
     {
         int rc = h->d_probcond.reserve((size_t)B * sizeof(Prob));
         if (rc != SNK_OK) return rc;
-        LAUNCH(select_marked, dim3(ceil_div(B, 64)), dim3(64), 0, h->d_prob.as<Prob>(), h->d_probcond.as<Prob>(), h->d_state.as<State>(), B);
+        LAUNCH(select_marked, dim3(ceil_div(B, 64)), dim3(64), 0, h->d_prob.as<Prob>(), h->d_probcond.as<Prob>(), h->d_state.as<State>(), B,
+               O.lambda_init);
         A.prob = h->d_probcond.as<Prob>();
     }
-    LAUNCH(begin_solve, dim3(ceil_div(B, 64)), dim3(64), 0, h->d_state.as<State>(), B, O.lambda_init, cond);
+    else if (h->state_fresh && L.graph == nullptr)
+        ;  // the first solve after a hand-over: the uploaded state IS what begin_solve writes (one launch less on the keyframe path)
+    else
+        LAUNCH(begin_solve, dim3(ceil_div(B, 64)), dim3(64), 0, h->d_state.as<State>(), B, O.lambda_init, 0);
+    if (L.graph == nullptr) h->state_fresh = false;
     const dim3 gpt(std::max(1, ceil_div(h->max_np, 128)), B);
     size_t pcg_lds        = (size_t)h->max_n6 * 9 * 8 + (size_t)h->max_nfc * 36 * 8;
     const size_t s_bytes  = (size_t)h->max_n6 * h->max_n6 * 8;
@@ -4624,14 +4644,11 @@ int snk_ba_solve_local_scene(snk_ba* h, int problem, double chi2_mono, double ch
     SNK_HIP_CHECK(hipSetDevice(h->device));
     int rc = snk_ba_solve_async(h, h->opt.max_iterations);  // initAndSolve
     if (rc != SNK_OK) return rc;
-    const Opt O = make_opt(h->opt);
-    // chi-square pass at the solved state, marking on the device (the count and the costs of this moment stay in the state)
-    hipLaunchKernelGGL(point_pass<2>, dim3(std::max(1, ceil_div(h->max_np, 128)), h->count), dim3(128), 0, h->stream, h->arr, O);
-    SNK_LAUNCH_CHECK();
-    int max_no = 1;
-    for (const Prob& q : h->probs) max_no = q.no > max_no ? q.no : max_no;
-    hipLaunchKernelGGL(mark_outliers_kernel, dim3(ceil_div(max_no, 256), h->count), dim3(256), 0, h->stream, h->arr,
-                       h->d_outlier.as<unsigned char>(), chi2_mono, chi2_stereo);
+    Opt O         = make_opt(h->opt);
+    O.chi2_mono   = chi2_mono;
+    O.chi2_stereo = chi2_stereo;
+    // chi-square pass at the solved state, marking on the device in the same kernel (the count and the costs of this moment stay in the state)
+    hipLaunchKernelGGL(point_pass<3>, dim3(std::max(1, ceil_div(h->max_np, 128)), h->count), dim3(128), 0, h->stream, h->arr, O);
     SNK_LAUNCH_CHECK();
     // The extra iteration(s) (:399-410) run for the problems that had something marked.  Default: enqueued right behind the
     // pass, conditional on the device (select_marked) -- the whole call is ONE synchronisation.  SNK_BA_LOCAL_SYNC=1 (A/B), and
