@@ -4236,6 +4236,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         // enough workgroups per array to keep the bus busy: one per 64 KB of the largest list, 16 .. 256
         unsigned big = 0;
         for (int e = 0; e < tab.n; ++e) big = std::max(big, tab.bytes[e]);
+        // (more workgroups per array do not shorten it: 16.3 / 18.3 / 17.1 / 15.2 us with one per 64 / 16 / 4 / 1 KB, r03ag)
         const int gx = (int)std::min(256u, std::max(16u, big >> 16));
         hipLaunchKernelGGL(copy_table_kernel, dim3(gx, tab.n), dim3(256), 0, st, tab);
         SNK_LAUNCH_CHECK();
