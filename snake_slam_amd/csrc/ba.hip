@@ -38,6 +38,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <map>
+#include <unordered_map>
 #include <tuple>
 #include <utility>
 #include <vector>
@@ -3780,9 +3781,24 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         pr.n_set    = 0;
         {
             const size_t nb = (size_t)nfc * nfc;
-            std::map<std::vector<int>, int> gid;
+            // camera set -> group: a hash of the signature finds the candidate, the stored signature confirms it (a std::map keyed by
+            // the vectors themselves was 60 ns per point, a third of a batch hand-over's list time)
+            std::unordered_multimap<unsigned long long, int> gid;
             std::vector<std::vector<int>> gpts;
             std::vector<std::vector<int>> gsig;
+            auto find_group = [&](const std::vector<int>& key) -> int
+            {
+                unsigned long long hsh = 1469598103934665603ull;
+                for (int v : key) hsh = (hsh ^ (unsigned long long)(unsigned)v) * 1099511628211ull;
+                auto range = gid.equal_range(hsh);
+                for (auto it = range.first; it != range.second; ++it)
+                    if (gsig[(size_t)it->second] == key) return it->second;
+                gid.emplace(hsh, (int)gpts.size());
+                gpts.emplace_back();
+                gsig.push_back(key);
+                return (int)gpts.size() - 1;
+            };
+            std::vector<int> sig;
             // The point-major kernels (schur_fused / schur_mfma / update_cost) are only chosen when the launch has enough work
             // items (max_set_items * count >= SNK_BA_SCHUR_SET_MIN_ITEMS, default 256): for the reference's per-keyframe
             // call -- ONE window of a few thousand points -- their lists are never used, and building + uploading them
@@ -3792,19 +3808,12 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             bool ok = nfc > 0 && (count >= 8 || P.n_pt >= 8000 || sets_forced);
             // points that produce no Schur products (constant points, points seen by constant cameras only) still need their
             // linearisation (cost, V, b_p): they form groups of their own, keyed by their run length, with no pairs
+            std::vector<int> plain_key;
             auto plain_group = [&](int p, int run)
             {
-                const std::vector<int> key = {-1000, run};
-                auto f = gid.find(key);
-                if (f == gid.end())
-                {
-                    gid.emplace(key, (int)gpts.size());
-                    gpts.emplace_back();
-                    gsig.push_back(std::vector<int>((size_t)run, -1));
-                    gpts.back().push_back(p);
-                }
-                else
-                    gpts[(size_t)f->second].push_back(p);
+                // (a signature of `run` times -1 cannot be a set with free cameras: the plain group of that run length)
+                plain_key.assign((size_t)run, -1);
+                gpts[(size_t)find_group(plain_key)].push_back(p);
             };
             for (int p = 0; p < P.n_pt && ok; ++p)
             {
@@ -3818,7 +3827,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                     plain_group(p, a1 - a0);
                     continue;
                 }
-                std::vector<int> sig;
+                sig.clear();
                 int k = 0;
                 for (int a = a0; a < a1; ++a)
                 {
@@ -3835,16 +3844,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                     continue;
                 }
                 if (k > SET_MAX_K || a1 - a0 > SET_MAX_RUN) ok = false;
-                auto f = gid.find(sig);
-                if (f == gid.end())
-                {
-                    gid.emplace(sig, (int)gpts.size());
-                    gpts.emplace_back();
-                    gsig.push_back(sig);
-                    gpts.back().push_back(p);
-                }
-                else
-                    gpts[(size_t)f->second].push_back(p);
+                gpts[(size_t)find_group(sig)].push_back(p);
             }
             mark(8);
             std::vector<std::vector<int>> contrib(nb);
