@@ -322,18 +322,24 @@ inline Scene flatten(const SaigaScene& scene, std::vector<std::pair<int, int>>* 
         for (int k = 0; k < 3; ++k) s.points[j][(size_t)k] = scene.worldPoints[j].p(k);
         s.point_constant[j] = scene.worldPoints[j].constant ? 1 : 0;
     }
-    if (where) where->clear();
+    // sized once, written by index (seven push_backs per observation are a tenth of a millisecond for a 16 000-observation window)
+    size_t n_obs = 0;
+    for (size_t i = 0; i < scene.images.size(); ++i) n_obs += scene.images[i].stereoPoints.size();
+    s.obs_image.resize(n_obs), s.obs_point.resize(n_obs), s.obs_pixel.resize(n_obs), s.obs_depth.resize(n_obs);
+    s.obs_weight.resize(n_obs), s.obs_outlier.resize(n_obs);
+    if (where) where->resize(n_obs);
+    size_t at = 0;
     for (size_t i = 0; i < scene.images.size(); ++i)
-        for (size_t k = 0; k < scene.images[i].stereoPoints.size(); ++k)
+        for (size_t k = 0; k < scene.images[i].stereoPoints.size(); ++k, ++at)
         {
-            const auto& o = scene.images[i].stereoPoints[k];
-            s.obs_image.push_back((int32_t)i);
-            s.obs_point.push_back((int32_t)o.wp);
-            s.obs_pixel.push_back({(double)o.point(0), (double)o.point(1)});
-            s.obs_depth.push_back((double)o.depth);
-            s.obs_weight.push_back((double)o.weight);
-            s.obs_outlier.push_back(o.outlier ? 1 : 0);
-            if (where) where->emplace_back((int)i, (int)k);
+            const auto& o    = scene.images[i].stereoPoints[k];
+            s.obs_image[at]  = (int32_t)i;
+            s.obs_point[at]  = (int32_t)o.wp;
+            s.obs_pixel[at]  = {(double)o.point(0), (double)o.point(1)};
+            s.obs_depth[at]  = (double)o.depth;
+            s.obs_weight[at] = (double)o.weight;
+            s.obs_outlier[at] = o.outlier ? 1 : 0;
+            if (where) (*where)[at] = {(int)i, (int)k};
         }
     const auto& in = scene.intrinsics[0];
     s.K[0] = in.fx, s.K[1] = in.fy, s.K[2] = in.cx, s.K[3] = in.cy;
