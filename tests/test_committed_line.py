@@ -20,7 +20,7 @@ def test_latest_committed_default_line_is_complete_and_verified():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["identical_to_gpu"] is True and c["frames_checked"] >= 256
     assert c["ba"]["identical_to_gpu"] is True and len(c["ba"]["windows_checked"]) == 3
-    assert d["tracking"]["identical_to_gpu"] is True if "identical_to_gpu" in d["tracking"] else True
+    assert d["tracking"]["cpu_baseline"]["identical_to_gpu"] is True
     ba = d["ba"]
     assert ba["roofline"]["frac"] >= 0.35 and ba["value"] >= 4.95e5      # the round-2 review's bar for the BA leg
     assert d["value"] >= 1.0e4                                            # north_star: >= 10 000 frames/s
