@@ -3158,6 +3158,27 @@ __global__ __launch_bounds__(256) void gather_cam_records(Arrays A, CamObs* __re
     out[pr.citem_off + k] = rec;
 }
 
+// The static observation records in the order schur_fused / update_cost walk them (work item, point of the item, observation of
+// the point) are a gather as well: 48 bytes per observation that the host loop wrote one by one and the bus carried (786 KB per
+// benchmark window -- half of a batch's upload).  One workgroup per work item.
+__global__ __launch_bounds__(256) void gather_set_records(Arrays A, SetObs* __restrict__ out)
+{
+    const Prob pr = A.prob[blockIdx.y];
+    if ((int)blockIdx.x >= pr.n_set) return;
+    const SetItem si = A.set_items[pr.set_off + blockIdx.x];
+    const int n      = si.n_pts * si.run;
+    for (int idx = threadIdx.x; idx < n; idx += 256)
+    {
+        const int q = idx / si.run, a = idx - q * si.run;
+        const int go = pr.obs_off + A.set_pts[si.pts_off + q].y + a;
+        const double2 uv = A.o_uv[go];
+        SetObs rec;
+        rec.u = uv.x; rec.v = uv.y; rec.depth = A.o_depth[go]; rec.weight = A.o_weight[go];
+        rec.img = A.o_img[go]; rec.orig = A.o_orig[go]; rec.cam = A.o_cam[go]; rec.ptfree = A.o_ptfree[go];
+        out[(size_t)si.rec_off + idx] = rec;
+    }
+}
+
 // The camera-pair block entries of schur_pass -- for every upper block (c1, c2) the co-observations (observation of c1,
 // observation of c2, point) in ascending order -- built by three launches instead of a host loop over every pair of every
 // point (half of a scene hand-over's host time, and 1.1 MB over the bus for a 20 x 2000 x 8 window).  Requirements (checked
@@ -3474,11 +3495,11 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     auto &pose = LS.pose, &pt = LS.pt, &ouv2 = LS.ouv2, &odepth = LS.odepth, &oweight = LS.oweight;
     auto &ptc = LS.ptc, &optfree = LS.optfree;
     auto& setitems = LS.setitems;
-    auto& setobs   = LS.setobs;
     auto& setpts   = LS.setpts;
     auto &setpairs = LS.setpairs, &cblkstart = LS.cblkstart, &cblkitems = LS.cblkitems, &ccstart = LS.ccstart, &ccitems = LS.ccitems;
     int n_partials = 0, max_set_items = 0, max_set_pairs = 0, max_set_run = 0, max_set_k = 0;
     int n_cparts = 0;          // per (work item, free camera) partial sums of the camera pass
+    long long n_setrec = 0;    // static observation records of the work items
     bool cam_sums_ok = true;   // no constant point is seen by a free camera (its observations are in no work item with pairs)
     bool set_ok = true;  // every problem can run the point-major Schur pass
     auto &camidx = LS.camidx, &ptstart = LS.ptstart, &oimg = LS.oimg, &ocam = LS.ocam, &oorig = LS.oorig, &camstart = LS.camstart,
@@ -3515,7 +3536,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             sets_likely |= problems[b].n_pt >= 8000;
         }
         cblkstart.reserve(t_blk);
-        if (sets_likely) setobs.reserve(t_obs), setpts.reserve(t_pt), cblkitems.reserve(2 * t_obs), ccitems.reserve(t_obs);
+        if (sets_likely) setpts.reserve(t_pt), cblkitems.reserve(2 * t_obs), ccitems.reserve(t_obs);
     }
     h->orig_off.assign((size_t)count, 0);
     h->orig_n.assign((size_t)count, 0);
@@ -3675,7 +3696,6 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         oimg.resize(obs_at + (size_t)no), ocam.resize(obs_at + (size_t)no), optfree.resize(obs_at + (size_t)no), ouv2.resize(2 * (obs_at + (size_t)no));
         odepth.resize(obs_at + (size_t)no), oweight.resize(obs_at + (size_t)no), oorig.resize(obs_at + (size_t)no), optidx.resize(obs_at + (size_t)no);
         const int* const s_cam  = ocam.data() + obs_at;   // free-camera index of sorted observation s (stable until the next problem)
-        const int* const s_orig = oorig.data() + obs_at;  // its caller-order index + orig_off
         {
             int* q_img = oimg.data() + obs_at, *q_cam = ocam.data() + obs_at, *q_orig = oorig.data() + obs_at, *q_pt = optidx.data() + obs_at;
             unsigned char* q_free = optfree.data() + obs_at;
@@ -3850,6 +3870,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             std::vector<std::vector<int>> contrib(nb);
             std::vector<std::vector<int>> ccontrib((size_t)nfc);  // per free camera: its partial sums in cam_part
             int cparts = n_cparts;
+            long long recs = n_setrec;  // static observation records of the work items (gathered on the device: gather_set_records)
             std::vector<SetItem> items;
             std::vector<int2> ipts;
             std::vector<int> ipairs;
@@ -3914,7 +3935,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                         si.run      = (int)sig.size();
                         si.aux_off  = aux_off;
                         si.nfree    = 0;
-                        si.rec_off  = (int)setobs.size();
+                        si.rec_off  = (int)recs;
                         for (int v : sig) si.nfree += v >= 0 ? 1 : 0;
                         si.cpart_off = cparts;
                         for (int f = 0; f < si.nfree; ++f) ccontrib[(size_t)fcams[(size_t)f]].push_back(cparts + f);
@@ -3923,17 +3944,9 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                         {
                             const int pp = gpts[g][q0 + (size_t)q];
                             ipts.push_back(make_int2(pp, pstart[(size_t)pp]));
-                            for (int a = 0; a < si.run; ++a)
-                            {
-                                const int sidx = pstart[(size_t)pp] + a, o = s_orig[sidx] - orig_off;
-                                SetObs rec;
-                                rec.u = P.obs_uv[o][0]; rec.v = P.obs_uv[o][1];
-                                rec.depth = P.obs_depth[o]; rec.weight = P.obs_weight[o];
-                                rec.img = P.obs_img[o]; rec.orig = orig_off + o;
-                                rec.cam = s_cam[(size_t)sidx]; rec.ptfree = P.pt_const[pp] ? 0 : 1;
-                                setobs.push_back(rec);
-                            }
                         }
+                        recs += (long long)si.n_pts * si.run;
+                        if (recs >= (1ll << 31)) ok = false;  // (would not be addressable by rec_off: the block-major pass then)
                         for (int q = 0; q < npairs; ++q) contrib[(size_t)blocks[(size_t)q]].push_back(parts + q);
                         parts += npairs;
                         items.push_back(si);
@@ -3962,6 +3975,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                 pr.n_set   = (int)items.size();
                 n_partials = parts;
                 n_cparts   = cparts;
+                n_setrec   = recs;
                 setitems.insert(setitems.end(), items.begin(), items.end());
                 setpts.insert(setpts.end(), ipts.begin(), ipts.end());
                 setpairs.insert(setpairs.end(), ipairs.begin(), ipairs.end());
@@ -4123,7 +4137,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     UP(d_camitems, camitems);
     if ((rc = h->d_csobs.reserve(std::max<size_t>(camitems.size(), 1) * sizeof(CamObs))) != SNK_OK) return rc;  // gather_cam_records
     UP(d_setitems, setitems);
-    UP(d_setobs, setobs);
+    if ((rc = h->d_setobs.reserve((size_t)std::max<long long>(n_setrec, 1) * sizeof(SetObs))) != SNK_OK) return rc;  // gather_set_records
     UP(d_setpts, setpts);
     UP(d_setpairs, setpairs);
     UP(d_cblkstart, cblkstart);
@@ -4307,6 +4321,11 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         hipLaunchKernelGGL(gather_cam_records, dim3(ceil_div(max_citems, 256), count), dim3(256), 0, st, A, h->d_csobs.as<CamObs>());
         SNK_LAUNCH_CHECK();
     }
+    if (max_set_items > 0)
+    {
+        hipLaunchKernelGGL(gather_set_records, dim3(max_set_items, count), dim3(256), 0, st, A, h->d_setobs.as<SetObs>());
+        SNK_LAUNCH_CHECK();
+    }
     if (dev_entries)
     {
         if (max_be_waves > 0)
@@ -4345,6 +4364,32 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                                   r.pt == P.obs_pt[o] && r.orig == pr.orig_off + o && r.img == P.obs_img[o] &&
                                   r.ptfree == (P.pt_const[P.obs_pt[o]] ? 0 : 1);
                 SNK_REQUIRE(same, "SNK_BA_CHECK_LISTS: a device-gathered camera record differs from the caller's observation");
+            }
+        }
+        {
+            // the work items' observation records (gather_set_records) against the caller's arrays
+            std::vector<SetObs> d_sr((size_t)n_setrec);
+            if (!d_sr.empty()) SNK_HIP_CHECK(hipMemcpy(d_sr.data(), h->d_setobs.p, d_sr.size() * sizeof(SetObs), hipMemcpyDeviceToHost));
+            for (int b = 0; b < count; ++b)
+            {
+                const snk_ba_problem& P = problems[b];
+                const Prob& pr          = probs[(size_t)b];
+                for (int it = 0; it < pr.n_set; ++it)
+                {
+                    const SetItem& si = LS.setitems[(size_t)pr.set_off + (size_t)it];
+                    for (int q = 0; q < si.n_pts; ++q)
+                        for (int a = 0; a < si.run; ++a)
+                        {
+                            const int2 pp = LS.setpts[(size_t)si.pts_off + (size_t)q];
+                            const int s = pp.y + a, o = oorig[(size_t)pr.obs_off + (size_t)s] - pr.orig_off;
+                            const SetObs& r = d_sr[(size_t)si.rec_off + (size_t)q * si.run + (size_t)a];
+                            const bool same = r.u == P.obs_uv[o][0] && r.v == P.obs_uv[o][1] && r.depth == P.obs_depth[o] &&
+                                              r.weight == P.obs_weight[o] && r.img == P.obs_img[o] && r.orig == pr.orig_off + o &&
+                                              r.cam == ocam[(size_t)pr.obs_off + (size_t)s] && r.ptfree == (P.pt_const[pp.x] ? 0 : 1) &&
+                                              P.obs_pt[o] == pp.x;
+                            SNK_REQUIRE(same, "SNK_BA_CHECK_LISTS: a device-gathered work-item record differs from the caller's observation");
+                        }
+                }
             }
         }
         if (dev_entries)
