@@ -408,3 +408,28 @@ def test_solve_local_scene_in_a_batch(orc):
     assert ba._lib.snk_ba_solve_local_scene(ba._h, 0, 4.0, 5.0, 1, None, None, None, None, None, None) != 0        # n_marked is required
     assert ba._lib.snk_ba_solve_local_scene(ba._h, 0, 4.0, 5.0, 1, None, C.byref(n), None, None, None, None) == 0  # every output optional
     ba.close()
+
+
+def test_solve_local_scene_degenerate_scenes(orc):
+    """Nothing to optimise (every camera constant), nothing to observe (no observations), a single point: the call returns the
+    scene as it was handed over (or the step-by-step result) and marks nothing it should not."""
+    from snake_slam_amd import synth
+    from snake_slam_amd.ba import BARec, lba_options
+
+    base, _ = synth.ba_scene(n_kf=4, n_pt=40, obs_per_pt=3, seed=5)
+    allc = dict(base, img_const=np.ones_like(base["img_const"]), pt_const=np.ones_like(base["pt_const"]))
+    empty = dict(base, obs_img=base["obs_img"][:0], obs_pt=base["obs_pt"][:0], obs_uv=base["obs_uv"][:0], obs_depth=base["obs_depth"][:0],
+                 obs_weight=base["obs_weight"][:0])
+    one, _ = synth.ba_scene(n_kf=3, n_pt=1, obs_per_pt=3, seed=6)
+    for sc in (allc, empty, one):
+        a, b = BARec(lba_options()), BARec(lba_options())
+        a.create(sc)
+        b.create(sc)
+        want = _local_scene_by_steps(a, sc, 0, None)
+        got = b.solve_local_scene(2.1**2, 2.3**2)
+        assert got[0] == want[0]
+        assert np.array_equal(got[3], want[3]) and np.array_equal(got[4], want[4]) and np.array_equal(got[5], want[5])
+        if sc is allc or sc is empty:
+            assert np.array_equal(got[3], sc["pose"]) and np.array_equal(got[4], sc["pt"]) and got[0] == 0
+        a.close()
+        b.close()
