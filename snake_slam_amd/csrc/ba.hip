@@ -3058,9 +3058,7 @@ struct BaLists
     pvec<Prob> probs;
     pvec<double> pose, pt, ouv2, odepth, oweight;
     pvec<unsigned char> ptc, optfree;
-    pvec<CamObs> csobs;
     pvec<SetItem> setitems;
-    pvec<SetObs> setobs;
     pvec<int2> setpts;
     pvec<int> setpairs, cblkstart, cblkitems, ccstart, ccitems;
     pvec<int> camidx, ptstart, oimg, ocam, oorig, camstart, camitems, blkstart, optidx, wvpt, rpcnext, camrpcstart, camrpcitems, blkrpc;
@@ -3070,7 +3068,7 @@ struct BaLists
     void clear()
     {
         probs.clear(), pose.clear(), pt.clear(), ouv2.clear(), odepth.clear(), oweight.clear(), ptc.clear(), optfree.clear();
-        csobs.clear(), setitems.clear(), setobs.clear(), setpts.clear(), setpairs.clear(), cblkstart.clear(), cblkitems.clear();
+        setitems.clear(), setpts.clear(), setpairs.clear(), cblkstart.clear(), cblkitems.clear();
         camidx.clear(), ptstart.clear(), oimg.clear(), ocam.clear(), oorig.clear(), camstart.clear(), camitems.clear();
         blkstart.clear(), optidx.clear(), wvpt.clear(), rpcnext.clear(), camrpcstart.clear(), camrpcitems.clear(), blkrpc.clear();
         rpcmeta.clear(), blkent.clear(), ccstart.clear(), ccitems.clear();
