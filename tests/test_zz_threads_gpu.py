@@ -61,9 +61,16 @@ def test_seams_run_concurrently_on_their_own_handles(orc):
         pose, pt, it = ba.state(0)
         return ci.tobytes() + cf.tobytes() + chi.tobytes() + c1[1].tobytes() + c2[1].tobytes() + pose.tobytes() + pt.tobytes()
 
+    def run_ba_one_call(ba, k):
+        # the same call through snk_ba_solve_local_scene: device-built lists, the chi-square pass and the conditional extra
+        # iteration enqueued in one go, results through the handle's pinned buffer
+        ba.create(scenes[k % 3])
+        n, ci, cf, pose, pt, flags = ba.solve_local_scene(4.41, 5.29)
+        return bytes([n & 255]) + np.float64(ci).tobytes() + np.float64(cf).tobytes() + pose.tobytes() + pt.tobytes() + flags.tobytes()
+
     ext = ORBExtractor(300, 1.2, 3, 20, 7)
-    pre, bfm, trk, ba = Preprocess(), BruteForceMatcher(), SnakeORBMatcher(), BARec(lba_options())
-    seams = [(run_orb, ext), (run_pre, (pre, bfm)), (run_track, trk), (run_ba, ba)]
+    pre, bfm, trk, ba, ba2 = Preprocess(), BruteForceMatcher(), SnakeORBMatcher(), BARec(lba_options()), BARec(lba_options())
+    seams = [(run_orb, ext), (run_pre, (pre, bfm)), (run_track, trk), (run_ba, ba), (run_ba_one_call, ba2)]
     try:
         want = [[fn(h, k) for k in range(3)] for fn, h in seams]  # each call alone
         errors, got = [], [[None] * ROUNDS for _ in seams]
@@ -89,4 +96,4 @@ def test_seams_run_concurrently_on_their_own_handles(orc):
             for k in range(ROUNDS):
                 assert got[si][k] == want[si][k % 3], (si, k)
     finally:
-        ext.close(), pre.close(), bfm.close(), trk.close(), ba.close()
+        ext.close(), pre.close(), bfm.close(), trk.close(), ba.close(), ba2.close()
