@@ -433,3 +433,36 @@ def test_solve_local_scene_degenerate_scenes(orc):
             assert np.array_equal(got[3], sc["pose"]) and np.array_equal(got[4], sc["pt"]) and got[0] == 0
         a.close()
         b.close()
+
+
+def test_big_batch_of_unequal_scenes(orc):
+    """Batches of >= 256 problems cut their camera sets into work items of up to 128 points (two list registers in schur_fused /
+    update_cost): 300 scenes of different sizes -- sets of 1 .. ~190 points, runs of 2 .. 8 -- in one batch, a sample of them against
+    the oracle."""
+    from snake_slam_amd import synth
+    from snake_slam_amd.ba import BARec, lba_options
+
+    rng = np.random.default_rng(17)
+    scenes = []
+    for k in range(300):
+        n_kf = int(rng.integers(3, 9))
+        opp = int(rng.integers(2, n_kf + 1))
+        # well-posed scenes only (the fuzzer's rule: every camera sees >= ~8 points): with 4 points per keyframe the PCG stops at
+        # its iteration limit and GPU (either path) and oracle end 1e-6 .. 1e-5 apart in cost -- conditioning, not the path
+        n_min = max(24, -(-8 * n_kf // opp))
+        n_pt = int(rng.choice([n_min, max(n_min, 65 * n_kf // 2), max(n_min, 129 * n_kf // 3), int(rng.integers(n_min, n_min + 400))]))
+        sc, _ = synth.ba_scene(n_kf=n_kf, n_pt=n_pt, obs_per_pt=opp, seed=1000 + k, n_fixed=int(rng.integers(1, 3)), outlier_frac=0.02)
+        if k % 7 == 0:
+            sc["pt_const"] = (rng.random(n_pt) < 0.15).astype(np.uint8)
+        scenes.append(sc)
+    ba = BARec(lba_options())
+    ba.create(scenes)
+    ci, cf = ba.initAndSolve()
+    worst = 0.0
+    for k in list(range(0, 300, 13)) + [299]:
+        wpose, wpt, wci, wcf, _ = orc.ba_solve(scenes[k], orc.ba_options())
+        pose, pt, _ = ba.state(k)
+        assert abs(ci[k] - wci) <= 1e-9 * max(1.0, wci) and abs(cf[k] - wcf) <= 1e-7 * max(1.0, wcf), k
+        worst = max(worst, rmse(pt, wpt), rmse(pose, wpose))
+    assert worst <= TOL, worst
+    ba.close()

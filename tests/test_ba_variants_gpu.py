@@ -26,6 +26,7 @@ ROOT = Path(__file__).resolve().parent.parent
     {"SNK_BA_HOST_ENTRIES": "1", "SNK_BA_NO_SCHUR_SET": "1"},           # block entries by the host builder (what scenes with > 512 free cameras use)
     {"SNK_BA_SCHUR_SET_MIN_ITEMS": "1", "SNK_BA_CAM_SUMS": "1"},       # schur_fused<3, true>'s per-item camera sums + cam_sum instead of cam_pass (measured slower: not the default)
     {"SNK_BA_PCG_LDS": "1"},                                            # S in LDS (pcg_solve<true>) instead of registers (pcg_small) for local-BA sized systems
+    {"SNK_BA_NO_BIG_ITEMS": "1"},                                       # batches of >= 256 problems keep work items of <= 64 points
     {"SNK_BA_LOCAL_SYNC": "1"},                                         # snk_ba_solve_local_scene decides about the extra iteration on the host (count read back)
     {"SNK_BA_NO_SCHUR_WIDE": "1", "SNK_BA_NO_SCHUR_SET": "1"},          # block-major schur_pass with one wavefront per block also for single windows
 ])
