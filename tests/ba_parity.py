@@ -1,0 +1,70 @@
+"""The BA parity rule, in one place (tests/test_ba_gpu.py, tools/fuzz_ba_pose.py, tools/probes/diag_big_batch.py).
+
+Specification (BASELINE.json north_star): pose / point RMSE <= 1e-5 against the CPU restatement; the tests add the LM costs
+(initial to 1e-9, final to 1e-7 relative).  One class of scene cannot meet that for a reason that is not the kernel path: the
+reference's options stop the PCG after 30 iterations (LocalBundleAdjustment.cpp:47-64).  In a sparse, badly conditioned scene
+(few points per camera, 2-3 observations per point) the PCG does not converge in 30, the truncated iterate depends on the
+summation order of the dot products (it differs between any two correct implementations -- also between two GPU paths), and
+LM amplifies the difference: both sides end at equally good but different points.  Measured on the 300-scene batch of
+test_big_batch_of_unequal_scenes (profiles/r04/r04a_diag_big_batch.log): 3 of 300 scenes on the default path, 6 of 300 with
+SNK_BA_NO_SCHUR_SET=1, every one with the PCG at its limit in all three LM iterations on both sides (90 vs 90), every one
+agreeing to <= 1e-11 RMSE once both sides may iterate until the tolerance is met.
+
+The rule: a scene either meets the strict tolerances, or (a) both sides ran at least `max_pcg_iterations` PCG iterations (the
+necessary condition for a truncated solve) AND (b) solved again -- alone, both sides -- with max_pcg_iterations = 2000 it meets the
+strict tolerances.  (b) runs the same kernels (linearisation, Schur complement, PCG, update) on the same scene, so a defect in
+any of them still fails; only the order-dependence of a truncated Krylov iterate is excused.  The caller bounds how many
+scenes may take that route.
+"""
+import numpy as np
+
+TOL = 1e-5
+CONVERGED_PCG = 2000
+
+
+def rmse(a, b):
+    return float(np.sqrt(((np.asarray(a) - np.asarray(b)) ** 2).sum(axis=-1).mean())) if len(a) else 0.0
+
+
+def deltas(ci, cf, pose, pt, wci, wcf, wpose, wpt):
+    return (abs(ci - wci) / max(1.0, wci), abs(cf - wcf) / max(1.0, wcf), max(rmse(pose, wpose), rmse(pt, wpt)))
+
+
+def within(d, cost_tol=1e-7):
+    return d[0] <= 1e-9 and d[1] <= cost_tol and d[2] <= TOL
+
+
+def check_scene(orc, scene, got, kw=None, outlier=None, iterations=None, cost_tol_converged=1e-7):
+    """got = (cost_initial, cost_final, pose, pt, pcg_iterations) of the HIP path for `scene` solved with lba_options(**kw).
+    Returns (kind, text, rmse): kind "ok" | "truncated" (excused by the rule above) | "fail"."""
+    from snake_slam_amd.ba import BARec, lba_options
+
+    kw = dict(kw or {})
+    ci, cf, pose, pt, pcg = got
+    wpose, wpt, wci, wcf, wpcg = orc.ba_solve(scene, orc.ba_options(**kw), iterations=iterations, outlier=outlier)
+    d = deltas(ci, cf, pose, pt, wci, wcf, wpose, wpt)
+    if within(d):
+        return "ok", "", d[2]
+    text = (f"{len(scene['pose'])} kf ({int(np.asarray(scene['img_const']).sum())} const) x {len(scene['pt'])} pts x {len(scene['obs_img'])} obs, {kw}: "
+            f"ci rel {d[0]:.3g}, cf rel {d[1]:.3g} ({cf!r} vs {wcf!r}), rmse {d[2]:.3g}, PCG iterations {int(pcg)} vs {int(wpcg)}")
+    limit = lba_options(**kw).max_pcg_iterations
+    if d[0] > 1e-9:
+        return "fail", text + "; the INITIAL cost differs (no solve involved)", d[2]
+    if int(pcg) < limit or int(wpcg) < limit:
+        return "fail", text + f"; no PCG solve can have been truncated (limit {limit})", d[2]
+    kw2 = dict(kw, max_pcg_iterations=CONVERGED_PCG)
+    ba2 = BARec(lba_options(**kw2))
+    try:
+        ba2.create(scene)
+        if outlier is not None:
+            ba2.set_outliers(0, outlier)
+        ci2, cf2 = ba2.solve(iterations)
+        pose2, pt2, pcg2 = ba2.state(0)
+    finally:
+        ba2.close()
+    wpose2, wpt2, wci2, wcf2, wpcg2 = orc.ba_solve(scene, orc.ba_options(**kw2), iterations=iterations, outlier=outlier)
+    d2 = deltas(ci2[0], cf2[0], pose2, pt2, wci2, wcf2, wpose2, wpt2)
+    text += f"; with a PCG that may converge: cf rel {d2[1]:.3g}, rmse {d2[2]:.3g}, PCG iterations {int(pcg2)} vs {int(wpcg2)}"
+    if within(d2, cost_tol_converged):
+        return "truncated", text, d[2]
+    return "fail", text, d[2]

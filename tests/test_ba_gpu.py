@@ -235,7 +235,7 @@ def test_irregular_camera_sets_and_point_major_limits(orc):
     """Shapes around the limits of the point-major Schur pass (<= 10 free-camera observations out of <= 14 per point, a
     camera at most once per point): random camera subsets (hundreds of different camera sets, most of them with a
     single point), points with 12 observations, one camera twice on a point.  Whatever pass is chosen must agree
-    with the oracle (tests/test_ba_variants_gpu.py runs this file with each pass forced)."""
+    with the oracle (tests/test_zy_ba_variants_gpu.py runs this file with each pass forced)."""
     from snake_slam_amd import synth
 
     rng = np.random.default_rng(77)
@@ -437,8 +437,13 @@ def test_solve_local_scene_degenerate_scenes(orc):
 
 def test_big_batch_of_unequal_scenes(orc):
     """Batches of >= 256 problems cut their camera sets into work items of up to 128 points (two list registers in schur_fused /
-    update_cost): 300 scenes of different sizes -- sets of 1 .. ~190 points, runs of 2 .. 8 -- in one batch, a sample of them against
-    the oracle."""
+    update_cost): 300 scenes of different sizes -- sets of 1 .. ~190 points, runs of 2 .. 8 -- in one batch, EVERY scene against
+    the oracle under the parity rule of tests/ba_parity.py: strict tolerances, or -- for scenes whose PCG ran into the reference's
+    30-iteration limit on both sides -- strict tolerances once both sides may converge.  Round 3 ended red on this test: it sampled 24
+    scenes at strict tolerance, and under SNK_BA_NO_SCHUR_SET=1 sample 195 (8 keyframes x 344 points x 3 observations, PCG 90 vs 90)
+    was 1.3e-7 apart in cost; profiles/r04/r04a_diag_big_batch.log shows 3-6 such scenes of the 300 on EVERY path including the default
+    one, all of them at 1e-11 RMSE with a converged PCG -- truncation sensitivity, not a path defect."""
+    from ba_parity import check_scene
     from snake_slam_amd import synth
     from snake_slam_amd.ba import BARec, lba_options
 
@@ -447,8 +452,6 @@ def test_big_batch_of_unequal_scenes(orc):
     for k in range(300):
         n_kf = int(rng.integers(3, 9))
         opp = int(rng.integers(2, n_kf + 1))
-        # well-posed scenes only (the fuzzer's rule: every camera sees >= ~8 points): with 4 points per keyframe the PCG stops at
-        # its iteration limit and GPU (either path) and oracle end 1e-6 .. 1e-5 apart in cost -- conditioning, not the path
         n_min = max(24, -(-8 * n_kf // opp))
         n_pt = int(rng.choice([n_min, max(n_min, 65 * n_kf // 2), max(n_min, 129 * n_kf // 3), int(rng.integers(n_min, n_min + 400))]))
         sc, _ = synth.ba_scene(n_kf=n_kf, n_pt=n_pt, obs_per_pt=opp, seed=1000 + k, n_fixed=int(rng.integers(1, 3)), outlier_frac=0.02)
@@ -458,11 +461,13 @@ def test_big_batch_of_unequal_scenes(orc):
     ba = BARec(lba_options())
     ba.create(scenes)
     ci, cf = ba.initAndSolve()
-    worst = 0.0
-    for k in list(range(0, 300, 13)) + [299]:
-        wpose, wpt, wci, wcf, _ = orc.ba_solve(scenes[k], orc.ba_options())
-        pose, pt, _ = ba.state(k)
-        assert abs(ci[k] - wci) <= 1e-9 * max(1.0, wci) and abs(cf[k] - wcf) <= 1e-7 * max(1.0, wcf), k
-        worst = max(worst, rmse(pt, wpt), rmse(pose, wpose))
-    assert worst <= TOL, worst
+    states = [ba.state(k) for k in range(len(scenes))]
     ba.close()
+    truncated = []
+    for k, sc in enumerate(scenes):
+        pose, pt, pcg = states[k]
+        kind, text, _ = check_scene(orc, sc, (ci[k], cf[k], pose, pt, pcg))
+        assert kind != "fail", f"scene {k}: {text}"
+        if kind == "truncated":
+            truncated.append(k)
+    assert len(truncated) <= 12, truncated  # 3 .. 6 of 300 measured, depending on the path

@@ -1,6 +1,10 @@
 """GPU: the alternative kernel paths of the BA solver are selected by problem shape (or, for A/B measurements, by
 environment variables read once per process).  The parity suite of test_ba_gpu.py runs again in child processes with
-each path forced, so that small test scenes also go through the point-major Schur pass and the fallbacks."""
+each path forced, so that small test scenes also go through the point-major Schur pass and the fallbacks.
+
+The file sorts after every default-path parity file (test_zy_...): with `pytest -x` a red non-default switch must not hide the
+default-path tests of the other subsystems (round 3: it hid 169 of 192).  A failing child's report is forwarded whole: `-rf
+--tb=short`, last 6000 characters, so the record names the inner test, the scene and the assertion."""
 import os
 import subprocess
 import sys
@@ -31,9 +35,9 @@ ROOT = Path(__file__).resolve().parent.parent
     {"SNK_BA_NO_SCHUR_WIDE": "1", "SNK_BA_NO_SCHUR_SET": "1"},          # block-major schur_pass with one wavefront per block also for single windows
 ])
 def test_ba_parity_suite_with_forced_path(env):
-    r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_ba_gpu.py"), "-m", "gpu", "-x", "-q", "-p",
-                        "no:cacheprovider"], env=dict(os.environ, **env), capture_output=True, text=True, cwd=str(ROOT), timeout=600)
-    assert r.returncode == 0, (env, r.stdout[-2000:], r.stderr[-1000:])
+    r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_ba_gpu.py"), "-m", "gpu", "-x", "-q", "-rf", "--tb=short",
+                        "-p", "no:cacheprovider"], env=dict(os.environ, **env), capture_output=True, text=True, cwd=str(ROOT), timeout=600)
+    assert r.returncode == 0, f"{env}\n--- child stdout (tail) ---\n{r.stdout[-6000:]}\n--- child stderr (tail) ---\n{r.stderr[-1500:]}"
     assert " passed" in r.stdout
 
 
