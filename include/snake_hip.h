@@ -559,19 +559,32 @@ SNK_API int snk_pose_refine_matches_batch_dev(snk_matcher* m, const snk_frames_d
                                               int pts_cap, const float* level_scale, int n_levels, double* poses_dev,
                                               uint8_t* outlier_dev, int32_t* inliers_dev);
 
+/* The same refinement fed the way the reference feeds it: frame_pt_dev [batch][frames->cap] is `frame.mvpMapPoints` as indices
+ * into the frame's point table (pts_dev [batch][pts_cap] records of pts_stride bytes starting with the position; -1 = nullptr,
+ * entries >= n_pts_dev[b] are ignored) and the pairs enter in FEATURE order -- the loop `for (auto i : frame.featureRange())` of
+ * PoseRefinement.cpp:37-57.  outlier_dev [batch][frames->cap] is `frame.mvbOutlier` (flag of every feature with a point, 0
+ * elsewhere); frames->n is required.  Everything else as snk_pose_refine_matches_batch_dev. */
+SNK_API int snk_pose_refine_frame_batch_dev(snk_matcher* m, const snk_frames_dev* frames, const float* depth_dev,
+                                            const snk_camera* cam, const snk_pose_options* opt, const void* pts_dev,
+                                            int pts_stride, const int32_t* frame_pt_dev, const int32_t* n_pts_dev,
+                                            int pts_cap, const float* level_scale, int n_levels, double* poses_dev,
+                                            uint8_t* outlier_dev, int32_t* inliers_dev);
+
 /* Several sequences per GPU in lockstep (BASELINE.json config 5, "sequences batched"): the two glue steps that keep frame t of
  * every sequence on the device between the batched BF matcher and the batched pose refinement.
- * snk_track_bf_matches_batch_dev -- Tracking::TrackBruteForce, Snake/Tracking/TrackingCoarse.cpp:342-387: of the filtered matches
- * (pairs_dev [batch][cap][2] = (reference feature q, current feature t), n_pairs_dev [batch]: the output of
- * snk_bf_filter_batch_dev with the reference frame as query set) those whose reference feature has a map point
- * (prev_has_dev [batch][cap]) become match_idx_dev[b][q] = t, all other entries -1 -- the form
- * snk_pose_refine_matches_batch_dev consumes with the reference frame's points as the "local map".
+ * snk_track_bf_matches_batch_dev -- Tracking::TrackBruteForce, Snake/Tracking/TrackingCoarse.cpp:342-387: the reference matches
+ * `matchKnn2_omp(frame.descriptors, ref->frame->descriptors)` (:351) -- the CURRENT frame is the query set -- and sets
+ * `frame.mvpMapPoints[m.first] = ref->GetMapPoint(m.second)` for the filtered matches whose reference feature has a point
+ * (:373-377).  pairs_dev [batch][cap][2] = (current feature f, reference feature r), n_pairs_dev [batch]: the output of
+ * snk_bf_filter_batch_dev with the current frame as query set; ref_has_dev [batch][cap] = the reference feature has a map point;
+ * output frame_pt_dev[b][f] = r for those matches, -1 (nullptr) everywhere else -- mvpMapPoints as indices, the form
+ * snk_pose_refine_frame_batch_dev consumes with the reference frame's points as the point table.
  * snk_track_backproject_batch_dev -- the stereo points of every frame in the world, p_w = R^T (p_c - t) with
  * p_c = ((x - cx) / fx * z, (y - cy) / fy * z, z), z = depth (the inverse of `currentPose * wp`,
  * Snake/Tracking/SnakeORBMatcher.cpp:229): world_dev [batch][cap][3], has_dev [batch][cap] = depth > 0.  Both asynchronous on the
  * handle's stream. */
 SNK_API int snk_track_bf_matches_batch_dev(snk_matcher* m, const int32_t* pairs_dev, const int32_t* n_pairs_dev,
-                                           const uint8_t* prev_has_dev, int cap, int batch, int32_t* match_idx_dev);
+                                           const uint8_t* ref_has_dev, int cap, int batch, int32_t* frame_pt_dev);
 SNK_API int snk_track_backproject_batch_dev(snk_matcher* m, const snk_frames_dev* frames, const float* depth_dev,
                                             const snk_camera* cam, const double* poses_dev, double* world_dev, uint8_t* has_dev);
 

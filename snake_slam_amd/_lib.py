@@ -62,6 +62,7 @@ SIGNATURES = {
     "snk_match_project_keyframe": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, f32, i32, vp, C.POINTER(i32)]),
     "snk_pose_refine": (i32, [vp, vp, vp, vp, i32]),
     "snk_pose_refine_matches_batch_dev": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp]),
+    "snk_pose_refine_frame_batch_dev": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp]),
     "snk_match_fuse": (i32, [vp, vp, vp, vp, vp, vp, i32, f32, f32, i32, vp, i32, vp, C.POINTER(i32)]),
     "snk_match_triangulation_project": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, f32, i32, vp,
                                               C.POINTER(i32)]),

@@ -4078,7 +4078,17 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
 
     // block entries: on the device when every problem qualifies, by the host builder otherwise
     static const bool host_entries = getenv("SNK_BA_HOST_ENTRIES") != nullptr;  // A/B and tests
-    const bool dev_entries = dev_entries_ok && !host_entries;
+    bool dev_entries = dev_entries_ok && !host_entries;
+    if (dev_entries)
+    {
+        // The device builder counts into nfc x chunks x nfc ints per problem -- quadratic in the free cameras.  A global BA with
+        // ~500 free cameras and one long camera list needs hundreds of megabytes of counters the host builder never allocates:
+        // beyond a modest budget (64 MB; a batch of 1024 local windows needs 1.6 MB) the host builder takes over.
+        long long cnt = 0;
+        for (int b = 0; b < count; ++b) cnt += (long long)probs[(size_t)b].nfc * probs[(size_t)b].be_nch * probs[(size_t)b].nfc;
+        static const long long budget = getenv("SNK_BA_BECNT_BUDGET") ? atoll(getenv("SNK_BA_BECNT_BUDGET")) : (64ll << 20);  // bytes; tests force the fallback
+        if (cnt * (long long)sizeof(int) > budget) dev_entries = false;
+    }
     long long ent_total = 0, becnt_total = 0;
     int max_be_waves = 0;
     if (dev_entries)
@@ -4686,7 +4696,21 @@ int snk_ba_solve_local_scene(snk_ba* h, int problem, double chi2_mono, double ch
     SNK_REQUIRE(problem >= 0 && problem < h->count && n_marked != nullptr, "bad arguments");
     SNK_REQUIRE(chi2_mono > 0.0 && chi2_stereo > 0.0 && extra_iterations >= 0, "thresholds must be positive, extra_iterations >= 0");
     SNK_HIP_CHECK(hipSetDevice(h->device));
-    int rc = snk_ba_solve_async(h, h->opt.max_iterations);  // initAndSolve
+    int rc;
+    {
+        // The pinned staging buffer is sized for everything this call reads back BEFORE anything is enqueued: growing it frees the
+        // old allocation, which an earlier snk_ba_set_outliers may still be copying from (its H2D copy is asynchronous) -- so a
+        // growth waits for the stream first, and no reserve() below can reallocate behind an enqueued kernel or cost a second wait.
+        const Prob& pr0   = h->probs[(size_t)problem];
+        const size_t need = (size_t)pr0.ni * 56 + (size_t)pr0.np * 24 + (size_t)h->orig_n[(size_t)problem] +
+                            (size_t)h->count * sizeof(State) + 4 * (256 + 16) + 128;
+        if (need > h->h_stage.bytes)
+        {
+            SNK_HIP_CHECK(hipStreamSynchronize(h->stream));
+            if ((rc = h->h_stage.reserve(need)) != SNK_OK) return rc;
+        }
+    }
+    rc = snk_ba_solve_async(h, h->opt.max_iterations);  // initAndSolve
     if (rc != SNK_OK) return rc;
     Opt O         = make_opt(h->opt);
     O.chi2_mono   = chi2_mono;
@@ -4709,13 +4733,25 @@ int snk_ba_solve_local_scene(snk_ba* h, int problem, double chi2_mono, double ch
     }
     else if (extra_iterations > 0)
     {
-        if ((rc = h->h_stage.reserve(64 + sizeof(State))) != SNK_OK) return rc;
-        SNK_HIP_CHECK(hipMemcpyAsync(h->h_stage.p, h->d_state.as<State>() + problem, sizeof(State), hipMemcpyDeviceToHost, h->stream));
+        // Host-side decision (the multi-workgroup PCG, SNK_BA_LOCAL_SYNC): the SAME per-problem rule as the device path -- every
+        // problem of the batch that had something marked gets the extra iteration(s), the others are left as they are.  The states of
+        // all problems are read back; the iteration itself runs on select_marked's table like on the device path (a problem without
+        // marks appears with every size zero, and the multi-workgroup PCG's kernels skip a problem with n6 == 0).
+        const size_t sb = (size_t)h->count * sizeof(State);
+        if ((rc = h->h_stage.reserve(64 + sb)) != SNK_OK) return rc;  // no-op: sized at the top
+        SNK_HIP_CHECK(hipMemcpyAsync(h->h_stage.p, h->d_state.as<State>(), sb, hipMemcpyDeviceToHost, h->stream));
         SNK_HIP_CHECK(hipStreamSynchronize(h->stream));
-        memcpy(&st, h->h_stage.p, sizeof(State));
+        const State* all = h->h_stage.as<State>();
+        bool any = false;
+        for (int b = 0; b < h->count; ++b) any = any || all[b].marked > 0;
+        memcpy(&st, all + problem, sizeof(State));
         have_state = true;
-        // every problem of a batch is solved again when the one asked for has marks (the documented behaviour of this path)
-        if (st.marked > 0 && (rc = snk_ba_solve_async(h, extra_iterations)) != SNK_OK) return rc;
+        if (any)
+        {
+            Launcher direct;
+            direct.st = h->stream;
+            if ((rc = enqueue_lm(h, extra_iterations, direct, true)) != SNK_OK) return rc;
+        }
     }
     // One kernel writes the results into the pinned buffer (device visible) instead of one copy-engine transfer each; its
     // 16-byte loads want aligned sources: every piece is copied from the 16-byte boundary below it.

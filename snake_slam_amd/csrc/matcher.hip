@@ -662,7 +662,7 @@ __global__ __launch_bounds__(1024) void stereo_frame_kernel(const snk_kp64* __re
             syj[t]  = iround_d(kr.y, ls.iround_mode);
             soct[t] = kr.octave;
             sang[t] = kr.angle;
-            int r   = (int)floor(kr.y + 0.5) + ST_ROW_BIAS;  // the row of stereo_sort_kernel's index
+            int r   = syj[t] + ST_ROW_BIAS;  // the row of stereo_sort_kernel's index: the same rounding rule as syj and the left row
             row[u]  = r < 0 ? 0 : (r > 65535 ? 65535 : r);
             atomicMin(&s_row0, row[u]);
         }

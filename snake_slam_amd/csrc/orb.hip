@@ -2482,6 +2482,10 @@ static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long i
         // Front halves (VALU-bound: level passes, FAST) back to back on the handle's stream; the back half of part p (latency-bound:
         // distribution, descriptors) on the second stream beside the front half of part p + 1.  Parts are disjoint image ranges
         // with their own scratch, the only ordering is front(p) -> back(p).
+        // INVARIANT: parts p and p + MAX_PARTS share the chain slot p % MAX_PARTS, i.e. one distribute queue (d_queue) and one
+        // profiling event set.  Both are touched by the BACK half only (stages & 2 in run_part), and every back half is enqueued on
+        // the single stream `sb`, so two users of a slot never overlap.  Moving back halves onto more than one stream requires
+        // sizing dist_queue / part_ev by MAX_STAGGER and passing `p` as the part index.
         const int P = o->stagger;
         hipStream_t sf = o->stream, sb = o->extra[0];
         SNK_HIP_CHECK(hipEventRecord(o->ev_fork, sf));

@@ -511,10 +511,15 @@ __global__ __launch_bounds__(64 * WAVES) void pose_kernel(const PoseMeta* __rest
 // ---- device-resident form: the matches of a projection matcher -> (world point, observation) pairs per frame ----
 // One wavefront per frame walks the local-map points in order (ballot prefix: the pairs keep the points' order, which is the
 // order RefinePoseWithMatches gathers them, PoseRefinement.cpp:37-57) and writes the frame's PoseMeta.
+// BY_FEATURE: match_idx[b][f] = local-map point of frame feature f (`frame.mvpMapPoints[f]` as an index, -1 = nullptr) and the walk
+// is over the frame's features -- literally the loop of RefinePoseWithMatches (PoseRefinement.cpp:37-57); rows have `stride`
+// entries (the feature capacity), n_walk = features of the frame.  Otherwise match_idx[b][i] = feature of local-map point i
+// (a projection matcher's output), the walk is over the points, stride = pts_cap.
+template <bool BY_FEATURE>
 __global__ __launch_bounds__(256) void gather_matches_kernel(const snk_kp64* __restrict__ kps, const float* __restrict__ depth, int cap,
                                                             const unsigned char* __restrict__ pts, int pts_stride,
                                                             const int* __restrict__ match_idx, const int* __restrict__ n_pts,
-                                                            int pts_cap, const double* __restrict__ poses, float s0, float s1, float s2,
+                                                            const int* __restrict__ n_feat, int pts_cap, const double* __restrict__ poses, float s0, float s1, float s2,
                                                             float s3, float s4, float s5, float s6, float s7, int n_levels,
                                                             PoseMeta* __restrict__ meta, double* __restrict__ wps,
                                                             snk_pose_obs* __restrict__ obs, int* __restrict__ slot_of)
@@ -523,15 +528,19 @@ __global__ __launch_bounds__(256) void gather_matches_kernel(const snk_kp64* __r
     // (double-buffered by round parity: one barrier per round) -- the pairs keep the points' order
     __shared__ int s_wcnt[2][4];
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
-    const int m = min(n_pts[b], pts_cap);
+    const int n_p = min(n_pts[b], pts_cap);
+    const int stride = BY_FEATURE ? cap : pts_cap;
+    const int m = BY_FEATURE ? min(max(n_feat[b], 0), cap) : n_p;
     const float ls[8] = {s0, s1, s2, s3, s4, s5, s6, s7};
-    const size_t base = (size_t)b * pts_cap;
+    const size_t base = (size_t)b * stride;
     int count = 0;
     for (int i0 = 0, par = 0; i0 < m; i0 += 256, par ^= 1)
     {
         const int i = i0 + tid;
-        const int f = i < m ? match_idx[base + i] : -1;
-        const bool has = f >= 0 && f < cap;
+        const int v = i < m ? match_idx[base + i] : -1;
+        const int f = BY_FEATURE ? i : v;                 // the frame's feature
+        const int p = BY_FEATURE ? v : i;                 // the local-map point
+        const bool has = BY_FEATURE ? (v >= 0 && v < n_p) : (v >= 0 && v < cap);
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(has);
         if ((tid & 63) == 0) s_wcnt[par][wave] = __popcll(mask);
         __syncthreads();
@@ -546,7 +555,7 @@ __global__ __launch_bounds__(256) void gather_matches_kernel(const snk_kp64* __r
         if (has)
         {
             const int k = count + before + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-            const double* pp = reinterpret_cast<const double*>(pts + (base + i) * (size_t)pts_stride);
+            const double* pp = reinterpret_cast<const double*>(pts + ((size_t)b * pts_cap + p) * (size_t)pts_stride);
             double* w = wps + (base + k) * 3;
             w[0] = pp[0]; w[1] = pp[1]; w[2] = pp[2];
             const snk_kp64 kp = kps[(size_t)b * cap + f];
@@ -594,21 +603,24 @@ __global__ __launch_bounds__(64) void scatter_pose_kernel(const PoseMeta* __rest
 }
 // ---- sequences in lockstep (BASELINE.json config 5 with several sequences per GPU): the two glue steps between the batched BF
 // matcher and the batched pose refinement, so that a frame of every sequence is tracked without a host round trip ----
-// TrackBruteForce (Snake/Tracking/TrackingCoarse.cpp:342-387): the filtered matches whose reference feature has a map point become
-// (world point, observation) pairs.  Here the reference features' points are the previous frame's stereo points: pair (q, t) of
-// the filtered list (q = previous feature, t = current feature) is kept when prev_has[q]; match_idx[q] = t, everything else -1.
+// TrackBruteForce (Snake/Tracking/TrackingCoarse.cpp:342-387): `matchKnn2_omp(frame.descriptors, ref->frame->descriptors)` -- the
+// CURRENT frame is the query set, the reference keyframe the train set (:351) -- and for every filtered match m with a map point on
+// the reference feature, `frame.mvpMapPoints[m.first] = ref->GetMapPoint(m.second)` (:373-377).  Here the reference features'
+// points are the previous frame's stereo points: pair (f, r) of the filtered list (f = current feature, r = reference feature)
+// gives frame_pt[f] = r when ref_has[r], everything else -1 (= nullptr).  Several frame features may point at one reference
+// feature, never two reference features at one frame feature (one pair per query).
 __global__ __launch_bounds__(256) void bf_matches_kernel(const int2* __restrict__ pairs, const int* __restrict__ n_pairs,
-                                                         const u8* __restrict__ prev_has, int cap, int* __restrict__ match_idx)
+                                                         const u8* __restrict__ ref_has, int cap, int* __restrict__ frame_pt)
 {
     const int b = blockIdx.x, tid = threadIdx.x;
     const size_t base = (size_t)b * cap;
-    for (int i = tid; i < cap; i += 256) match_idx[base + i] = -1;
+    for (int i = tid; i < cap; i += 256) frame_pt[base + i] = -1;
     __syncthreads();  // the -1 fill and the scatter below touch the same words
     const int n = min(max(n_pairs[b], 0), cap);
     for (int j = tid; j < n; j += 256)
     {
         const int2 pr = pairs[base + j];  // queries are distinct (one pair per query at most): no two threads write one word
-        if (pr.x >= 0 && pr.x < cap && pr.y >= 0 && pr.y < cap && prev_has[base + pr.x]) match_idx[base + pr.x] = pr.y;
+        if (pr.x >= 0 && pr.x < cap && pr.y >= 0 && pr.y < cap && ref_has[base + pr.y]) frame_pt[base + pr.x] = pr.y;
     }
 }
 
@@ -649,15 +661,15 @@ __global__ __launch_bounds__(256) void backproject_kernel(const snk_kp64* __rest
 using namespace snk;
 
 extern "C" int snk_track_bf_matches_batch_dev(snk_matcher* m, const int32_t* pairs_dev, const int32_t* n_pairs_dev,
-                                              const uint8_t* prev_has_dev, int cap, int batch, int32_t* match_idx_dev)
+                                              const uint8_t* ref_has_dev, int cap, int batch, int32_t* frame_pt_dev)
 {
     SNK_REQUIRE(m != nullptr, "matcher is NULL");
     SNK_REQUIRE(batch >= 0 && cap >= 1, "bad sizes");
-    SNK_REQUIRE(pairs_dev && n_pairs_dev && prev_has_dev && match_idx_dev, "NULL device buffer");
+    SNK_REQUIRE(pairs_dev && n_pairs_dev && ref_has_dev && frame_pt_dev, "NULL device buffer");
     if (batch == 0) return SNK_OK;
     SNK_HIP_CHECK(hipSetDevice(m->device));
     hipLaunchKernelGGL(bf_matches_kernel, dim3(batch), dim3(256), 0, m->stream, reinterpret_cast<const int2*>(pairs_dev), n_pairs_dev,
-                       prev_has_dev, cap, match_idx_dev);
+                       ref_has_dev, cap, frame_pt_dev);
     SNK_LAUNCH_CHECK();
     return SNK_OK;
 }
@@ -757,15 +769,15 @@ extern "C" int snk_pose_refine(snk_matcher* m, const snk_camera* cam, const snk_
     return SNK_OK;
 }
 
-extern "C" int snk_pose_refine_matches_batch_dev(snk_matcher* m, const snk_frames_dev* frames, const float* depth_dev,
-                                                 const snk_camera* cam, const snk_pose_options* opt, const void* pts_dev,
-                                                 int pts_stride, const int32_t* match_idx_dev, const int32_t* n_pts_dev, int pts_cap,
-                                                 const float* level_scale, int n_levels, double* poses_dev, uint8_t* outlier_dev,
-                                                 int32_t* inliers_dev)
+static int refine_batch_impl(snk_matcher* m, const snk_frames_dev* frames, const float* depth_dev, const snk_camera* cam,
+                             const snk_pose_options* opt, const void* pts_dev, int pts_stride, const int32_t* match_idx_dev,
+                             const int32_t* n_pts_dev, int pts_cap, const float* level_scale, int n_levels, double* poses_dev,
+                             uint8_t* outlier_dev, int32_t* inliers_dev, bool by_feature)
 {
     SNK_REQUIRE(m != nullptr && frames != nullptr && cam != nullptr && opt != nullptr, "NULL argument");
     SNK_REQUIRE(frames->batch >= 0 && frames->cap >= 1 && frames->kps != nullptr, "bad frames");
     SNK_REQUIRE(depth_dev && pts_dev && match_idx_dev && n_pts_dev && poses_dev && outlier_dev && inliers_dev, "NULL device buffer");
+    SNK_REQUIRE(!by_feature || frames->n != nullptr, "frames->n (features per frame) is required");
     SNK_REQUIRE(pts_stride >= 24 && pts_stride % 8 == 0 && pts_cap >= 1, "pts_stride must be a multiple of 8, >= 24");
     SNK_REQUIRE(level_scale != nullptr && n_levels >= 1 && n_levels <= 8, "level_scale / n_levels (1..8)");
     SNK_REQUIRE(opt->outer_iterations >= 0 && opt->outer_iterations <= 64 && opt->inner_iterations >= 0 &&
@@ -775,7 +787,8 @@ extern "C" int snk_pose_refine_matches_batch_dev(snk_matcher* m, const snk_frame
     const int batch = frames->batch;
     if (batch == 0) return SNK_OK;
     SNK_HIP_CHECK(hipSetDevice(m->device));
-    const size_t total = (size_t)batch * pts_cap;
+    const int stride   = by_feature ? frames->cap : pts_cap;  // pairs per frame at most; row length of match_idx / outlier
+    const size_t total = (size_t)batch * stride;
     // q: meta | wps | obs | slot_of      out: outlier (pair order) | pose_out | inliers
     const size_t o_wps = ((size_t)batch * sizeof(PoseMeta) + 15) & ~(size_t)15, o_obs = o_wps + total * 24;
     const size_t o_slot = o_obs + total * sizeof(snk_pose_obs), in_b = o_slot + total * 4;
@@ -787,19 +800,23 @@ extern "C" int snk_pose_refine_matches_batch_dev(snk_matcher* m, const snk_frame
     char* o = m->out.as<char>();
     float ls[8];
     for (int i = 0; i < 8; ++i) ls[i] = level_scale[i < n_levels ? i : n_levels - 1];
-    hipLaunchKernelGGL(gather_matches_kernel, dim3(batch), dim3(256), 0, m->stream, frames->kps, depth_dev, frames->cap,
-                       reinterpret_cast<const unsigned char*>(pts_dev), pts_stride, match_idx_dev, n_pts_dev, pts_cap,
-                       (const double*)poses_dev, ls[0], ls[1], ls[2], ls[3], ls[4], ls[5], ls[6], ls[7], n_levels,
-                       reinterpret_cast<PoseMeta*>(d), reinterpret_cast<double*>(d + o_wps), reinterpret_cast<snk_pose_obs*>(d + o_obs),
-                       reinterpret_cast<int*>(d + o_slot));
+#define GATHER_LAUNCH(BF_)                                                                                                            \
+    hipLaunchKernelGGL(gather_matches_kernel<BF_>, dim3(batch), dim3(256), 0, m->stream, frames->kps, depth_dev, frames->cap,        \
+                       reinterpret_cast<const unsigned char*>(pts_dev), pts_stride, match_idx_dev, n_pts_dev, frames->n, pts_cap,    \
+                       (const double*)poses_dev, ls[0], ls[1], ls[2], ls[3], ls[4], ls[5], ls[6], ls[7], n_levels,                  \
+                       reinterpret_cast<PoseMeta*>(d), reinterpret_cast<double*>(d + o_wps),                                        \
+                       reinterpret_cast<snk_pose_obs*>(d + o_obs), reinterpret_cast<int*>(d + o_slot))
+    if (by_feature) GATHER_LAUNCH(true);
+    else GATHER_LAUNCH(false);
+#undef GATHER_LAUNCH
     CamD C{cam->fx, cam->fy, cam->cx, cam->cy, cam->bf};
     static const bool no_lds = getenv("SNK_POSE_NO_LDS") != nullptr;  // A/B: matches re-read from global memory in every step
     // matches of a frame kept in LDS (56 bytes each): the whole local map when few frames are in flight (one workgroup per CU
     // anyway), otherwise at most POSE_LDS_MATCHES so that three frames share a compute unit (a tracking pass matches about half
     // of its local map; SNK_POSE_LDS_MATCHES overrides, tests force the global-memory tail with a small value)
     static const int lds_env = getenv("SNK_POSE_LDS_MATCHES") ? atoi(getenv("SNK_POSE_LDS_MATCHES")) : 0;
-    int lds_matches = pts_cap;
-    if (lds_env > 0) lds_matches = lds_env < pts_cap ? lds_env : pts_cap;
+    int lds_matches = stride;
+    if (lds_env > 0) lds_matches = lds_env < stride ? lds_env : stride;
     else if (batch > 768 && lds_matches > 656) lds_matches = 656;  // four frames per CU (656 x 56 B + 3.8 KB static <= 40 KB): 1024 frames are ONE round of the 256 CUs
     else if (batch > 256 && lds_matches > 896) lds_matches = 896;  // three
     if ((size_t)lds_matches * 56 > 150 * 1024) lds_matches = 150 * 1024 / 56;
@@ -808,18 +825,38 @@ extern "C" int snk_pose_refine_matches_batch_dev(snk_matcher* m, const snk_frame
     hipLaunchKernelGGL((pose_kernel<W_, 0, L_>), dim3(batch), dim3(64 * W_), LDS_, m->stream, reinterpret_cast<const PoseMeta*>(d),  \
                        reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),                \
                        reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), inliers_dev, C, *opt, lds_matches)
-    if (pts_cap >= 256 && !no_lds)
+    if (stride >= 256 && !no_lds)
     {
         int rc = set_max_lds_once(reinterpret_cast<const void*>(pose_kernel<4, 0, true>), 152 * 1024);
         if (rc != SNK_OK) return rc;
         POSE_LAUNCH(4, true, match_lds);
     }
-    else if (pts_cap >= 256) POSE_LAUNCH(4, false, 0);
+    else if (stride >= 256) POSE_LAUNCH(4, false, 0);
     else POSE_LAUNCH(1, false, 0);
 #undef POSE_LAUNCH
     hipLaunchKernelGGL(scatter_pose_kernel, dim3(batch), dim3(64), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
                        reinterpret_cast<const double*>(o + o_pose), reinterpret_cast<const u8*>(o), reinterpret_cast<const int*>(d + o_slot),
-                       pts_cap, poses_dev, outlier_dev, inliers_dev);
+                       stride, poses_dev, outlier_dev, inliers_dev);
     SNK_LAUNCH_CHECK();
     return SNK_OK;
+}
+
+extern "C" int snk_pose_refine_matches_batch_dev(snk_matcher* m, const snk_frames_dev* frames, const float* depth_dev,
+                                                 const snk_camera* cam, const snk_pose_options* opt, const void* pts_dev,
+                                                 int pts_stride, const int32_t* match_idx_dev, const int32_t* n_pts_dev, int pts_cap,
+                                                 const float* level_scale, int n_levels, double* poses_dev, uint8_t* outlier_dev,
+                                                 int32_t* inliers_dev)
+{
+    return refine_batch_impl(m, frames, depth_dev, cam, opt, pts_dev, pts_stride, match_idx_dev, n_pts_dev, pts_cap, level_scale,
+                             n_levels, poses_dev, outlier_dev, inliers_dev, false);
+}
+
+extern "C" int snk_pose_refine_frame_batch_dev(snk_matcher* m, const snk_frames_dev* frames, const float* depth_dev,
+                                               const snk_camera* cam, const snk_pose_options* opt, const void* pts_dev,
+                                               int pts_stride, const int32_t* frame_pt_dev, const int32_t* n_pts_dev, int pts_cap,
+                                               const float* level_scale, int n_levels, double* poses_dev, uint8_t* outlier_dev,
+                                               int32_t* inliers_dev)
+{
+    return refine_batch_impl(m, frames, depth_dev, cam, opt, pts_dev, pts_stride, frame_pt_dev, n_pts_dev, pts_cap, level_scale,
+                             n_levels, poses_dev, outlier_dev, inliers_dev, true);
 }

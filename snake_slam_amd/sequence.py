@@ -110,13 +110,16 @@ class SequenceTracker:
         if self.prev is None:
             pose = np.array([0, 0, 0, 1.0, 0, 0, 0])
         else:
-            self.bf.matchKnn2(self.prev["desc"], gd)     # TrackBruteForce: previous (key)frame -> current frame
+            # TrackBruteForce (TrackingCoarse.cpp:351-352, 373-377): matchKnn2_omp(frame.descriptors, ref->frame->descriptors) -- the
+            # current frame is the QUERY set, m.first a frame feature, m.second a reference feature; pairs come in frame-feature
+            # order, which is also the order RefinePoseWithMatches walks frame.mvpMapPoints (PoseRefinement.cpp:37-57)
+            self.bf.matchKnn2(gd, self.prev["desc"])
             n_pairs = self.bf.filterMatches(60, 0.8)
             pairs = np.asarray(self.bf.matches, np.int64).reshape(-1, 2)
-            keep = self.prev["has_world"][pairs[:, 0]] if len(pairs) else np.zeros(0, bool)
-            q, t = pairs[keep, 0], pairs[keep, 1]
-            obs = pose_observations(g[t], depth[t], self.level_scale)
-            pose, _, inl = self.ref.RefinePoseWithMatches(self.cam, self.prev["pose"], self.prev["world"][q], obs)
+            keep = self.prev["has_world"][pairs[:, 1]] if len(pairs) else np.zeros(0, bool)
+            f, r = pairs[keep, 0], pairs[keep, 1]
+            obs = pose_observations(g[f], depth[f], self.level_scale)
+            pose, _, inl = self.ref.RefinePoseWithMatches(self.cam, self.prev["pose"], self.prev["world"][r], obs)
         # this frame's stereo points in the world: the "map" the next frame is tracked against
         has = depth > 0
         z = np.where(has, depth, 1.0).astype(np.float64)
@@ -137,7 +140,7 @@ class MultiSequenceTracker:
     """S sequences on ONE GPU in lockstep, device resident (BASELINE.json config 5, "sequences batched"): frame t of every
     sequence goes through the batched entry points as one batch -- Detect of the 2 S images, rectify, feature grid,
     StereoMatching, matchKnn2 + filterMatches against the previous frame's descriptors, the kept matches as (world point,
-    observation) pairs (`snk_track_bf_matches_batch_dev`), RefinePoseWithMatches (`snk_pose_refine_matches_batch_dev`, the previous
+    observation) pairs (`snk_track_bf_matches_batch_dev`), RefinePoseWithMatches (`snk_pose_refine_frame_batch_dev`, the previous
     frame's stereo points as the "map"), this frame's stereo points into the world (`snk_track_backproject_batch_dev`) -- on one
     stream, without a host round trip: what crosses PCIe per step is the 2 S images going in and, at the end of the run, the poses
     and four counters coming out.  Same chain and same arithmetic per sequence as `SequenceTracker` (which makes one synchronous
@@ -252,13 +255,14 @@ class MultiSequenceTracker:
                                      self.level_scale, True, self.right_points, self.depth, self.n_stereo)
             fd = self._frames_dev(self.bounds, self.nkp[:S], self.kp64_g, self.desc_g, self.right_points, self.taken, self.cell_start)
             if self.t > 0:
-                self.bf.knn2_batch_dev(self.prev_desc, self.prev_n, self.desc_g, self.nkp[:S], self.knn)
-                self.bf.filter_batch_dev(self.knn, self.prev_n, 60, 0.8, self.pairs, self.n_pairs)
+                # current frame = query, previous frame = train (TrackingCoarse.cpp:351); frame_pt = mvpMapPoints as indices
+                self.bf.knn2_batch_dev(self.desc_g, self.nkp[:S], self.prev_desc, self.prev_n, self.knn)
+                self.bf.filter_batch_dev(self.knn, self.nkp[:S], 60, 0.8, self.pairs, self.n_pairs)
                 lib.check(lib.load().snk_track_bf_matches_batch_dev(self.ref._h, self.pairs.data_ptr(), self.n_pairs.data_ptr(),
                                                                     self.prev_has.data_ptr(), cap, S, self.match_idx.data_ptr()),
                           "snk_track_bf_matches_batch_dev")
-                self.ref.refine_matches_batch_dev(fd, self.depth, self.cam, self.prev_world.view(torch.uint8).view(S, cap, 24), self.match_idx,
-                                                  self.prev_n, self.level_scale, self.poses, self.outlier, self.inliers)
+                self.ref.refine_frame_batch_dev(fd, self.depth, self.cam, self.prev_world.view(torch.uint8).view(S, cap, 24), self.match_idx,
+                                                self.prev_n, self.level_scale, self.poses, self.outlier, self.inliers)
                 self.counters[2] += self.n_pairs.sum()
                 self.counters[3] += self.inliers.sum()
             c = Camera(*self.cam)

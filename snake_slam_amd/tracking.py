@@ -391,6 +391,17 @@ class PoseRefinement(_Handle):
                                                                int(pts.shape[1]), _ptr(ls), len(ls), poses.data_ptr(), outlier.data_ptr(),
                                                                inliers.data_ptr()), "snk_pose_refine_matches_batch_dev")
 
+    def refine_frame_batch_dev(self, frames: FramesDev, depth, cam, pts, frame_pt, n_pts, level_scale, poses, outlier, inliers):
+        """RefinePoseWithMatches(Frame&) for a batch, fed like the reference (PoseRefinement.cpp:37-57): frame_pt [B, cap] int32 =
+        `frame.mvpMapPoints` as indices into pts [B, m_cap, stride] (-1 = nullptr), pairs in FEATURE order; outlier [B, cap] uint8 =
+        `frame.mvbOutlier`.  Everything else as refine_matches_batch_dev."""
+        ls = np.ascontiguousarray(level_scale, np.float32)
+        c = Camera(*cam)
+        _lib.check(self._lib.snk_pose_refine_frame_batch_dev(self._h, C.byref(frames), depth.data_ptr(), C.byref(c), C.byref(self.options),
+                                                             pts.data_ptr(), int(pts.shape[2]), frame_pt.data_ptr(), n_pts.data_ptr(),
+                                                             int(pts.shape[1]), _ptr(ls), len(ls), poses.data_ptr(), outlier.data_ptr(),
+                                                             inliers.data_ptr()), "snk_pose_refine_frame_batch_dev")
+
     def refinePose(self, cam, pose, wps, obs, prediction=None, prediction_weight_rotation=0.0,
                    prediction_weight_translation=0.0):
         """The optimiser call of ``refinePose`` (PoseRefinement.h:62-76): the smooth variant when

@@ -36,10 +36,12 @@ def oracle_sequence(orc, frames, width, height, orb=ORB, cam=CAM, threads=4):
         if prev is None:
             pose = np.array([0, 0, 0, 1.0, 0, 0, 0])
         else:
-            knn = orc.bf_knn2(prev["desc"], gd, threads=threads)
+            # TrackBruteForce (TrackingCoarse.cpp:351-352, 373-377): the current frame is the query set, pairs = (frame feature f,
+            # reference feature r) in frame-feature order; kept when the reference feature has a point
+            knn = orc.bf_knn2(gd, prev["desc"], threads=threads)
             pairs = np.asarray(orc.bf_filter(knn, 60, 0.8), np.int64).reshape(-1, 2)
-            keep = prev["has"][pairs[:, 0]] if len(pairs) else np.zeros(0, bool)
-            q, c = pairs[keep, 0], pairs[keep, 1]
+            keep = prev["has"][pairs[:, 1]] if len(pairs) else np.zeros(0, bool)
+            c, q = pairs[keep, 0], pairs[keep, 1]
             obs = np.zeros(len(c), orc.POSE_OBS)
             obs["x"], obs["y"], obs["depth"] = g["x"][c], g["y"][c], depth[c]
             obs["weight"] = np.sqrt(1.0 / (ls.astype(np.float64)[g["octave"][c]] ** 2))

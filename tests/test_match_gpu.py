@@ -259,3 +259,52 @@ def test_definition_switches_parity(bf, st, orc, definitions, key, value):
         assert len(pairs) < len(base_pairs)      # the strict operator drops the rows that sit exactly on the bound
     else:
         assert not np.array_equal(rp, base_rp)   # another rounding of the .5 rows moves the row bands
+
+
+@pytest.mark.parametrize("B", [4, 9])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_definition_switches_parity_batched_stereo(st, orc, definitions, B, mode):
+    """The batched StereoMatching entry point under the rounding definitions (stereo_frame_kernel -- the B >= 8 kernel
+    -- bucketed right keypoints with floor(y + 0.5) whatever "iround.mode" said, while the row it compared against followed the
+    mode).  Right rows exactly on .5, left rows on integers; mode 1 (half away from zero) only differs for negative rows, so that
+    case sits above the image.  B = 4: sort + 16-lane kernel; B = 9: one workgroup per frame."""
+    import torch
+    from oracle.oracle import KP64
+
+    rng = np.random.default_rng(SEED + 9100 + 10 * B + mode)
+    capl, capr = 400, 380
+    dev = torch.device("cuda:0")
+    L, R = np.zeros((B, capl), KP64), np.zeros((B, capr), KP64)
+    DL, DR = np.zeros((B, capl, 4), np.uint64), np.zeros((B, capr, 4), np.uint64)
+    nl = rng.integers(200, capl + 1, B).astype(np.int32)
+    nr = rng.integers(200, capr + 1, B).astype(np.int32)
+    for b in range(B):
+        l, dl, r, dr, bfv, ls = make_stereo_case(rng, int(nl[b]), int(nr[b]))
+        r["y"] = np.floor(r["y"]) + 0.5
+        l["y"] = np.floor(l["y"])
+        if mode == 1:
+            r["y"] -= 600.0
+            l["y"] -= 600.0
+        L[b, : nl[b]], DL[b, : nl[b]], R[b, : nr[b]], DR[b, : nr[b]] = l, dl, r, dr
+    ls = (np.float32(1.2) ** np.arange(4)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    Ld, Rd = t(L.view(np.uint8).reshape(B, capl, 24)), t(R.view(np.uint8).reshape(B, capr, 24))
+    DLd, DRd, nld, nrd = t(DL.view(np.int64)), t(DR.view(np.int64)), t(nl), t(nr)
+
+    def run():
+        rp = torch.full((B, capl), -1000.0, dtype=torch.float32, device=dev)
+        dp = torch.full((B, capl), -1000.0, dtype=torch.float32, device=dev)
+        nm = torch.full((B,), -1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        st.match_batch_dev(Ld, DLd, nld, Rd, DRd, nrd, 47.9, ls, True, rp, dp, nm)
+        st.sync()
+        rp_h, dp_h, nm_h = rp.cpu().numpy(), dp.cpu().numpy(), nm.cpu().numpy()
+        for b in range(B):
+            n2, rp2, dp2 = orc.stereo_match(L[b, : nl[b]], DL[b, : nl[b]], R[b, : nr[b]], DR[b, : nr[b]], 47.9, ls, True)
+            assert nm_h[b] == n2, f"batch {b}"
+            assert np.array_equal(rp_h[b, : nl[b]], rp2) and np.array_equal(dp_h[b, : nl[b]], dp2)
+        return rp_h
+
+    base = run()
+    definitions("iround.mode", mode)
+    assert not np.array_equal(run(), base)   # the rule decided something

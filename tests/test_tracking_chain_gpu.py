@@ -211,9 +211,9 @@ def test_lockstep_glue_kernels_against_numpy():
     ref.sync()
     want = np.full((B, cap), -1, np.int32)
     for b in range(B):
-        for q, t in pairs[b, : n_pairs[b]]:
-            if 0 <= q < cap and 0 <= t < cap and has[b, q]:
-                want[b, q] = t
+        for f, r in pairs[b, : n_pairs[b]]:  # (current feature, reference feature): frame.mvpMapPoints[f] = point of r
+            if 0 <= f < cap and 0 <= r < cap and has[b, r]:
+                want[b, f] = r
     assert np.array_equal(d_mi.cpu().numpy(), want) and (want >= 0).sum() > 100
 
     kps = np.zeros((B, cap), KP64_DTYPE)
@@ -248,3 +248,77 @@ def test_lockstep_glue_kernels_against_numpy():
         assert np.array_equal(got_h[b, :m], hb.astype(np.uint8)) and np.allclose(got_w[b, :m], w, rtol=0, atol=1e-12)
         assert not got_h[b, m:].any() and not got_w[b, m:].any()   # beyond the frame's features: no point
     ref.close()
+
+
+def test_refine_frame_batch_dev_walks_features_like_the_reference(orc):
+    """snk_pose_refine_frame_batch_dev: `frame.mvpMapPoints` as indices, pairs in FEATURE order (PoseRefinement.cpp:37-57) -- what
+    TrackBruteForce leaves behind (TrackingCoarse.cpp:373-377: several frame features may carry the point of one reference feature).
+    A ragged batch: an ordinary frame, one whose features share few points, an empty frame, a frame with two pairs (pose untouched),
+    indices beyond the frame's point count (ignored) -- against orc.pose_refine on the pairs gathered in feature order; mvbOutlier
+    per feature identical, pose within 1e-9."""
+    import torch
+
+    from snake_slam_amd.tracking import KP64_DTYPE, PoseRefinement, frames_dev, pose_observations
+
+    rng = np.random.default_rng(SEED + 4242)
+    B, cap, mcap = 5, 700, 500
+    dev = torch.device("cuda", 0)
+    cam = PH.CAM
+    ls = (np.float32(1.2) ** np.arange(4)).astype(np.float32)
+    nf = np.array([650, 400, 0, 300, 700], np.int32)
+    npts = np.array([500, 40, 10, 500, 480], np.int32)
+    kps = np.zeros((B, cap), KP64_DTYPE)
+    depth = np.full((B, cap), -1.0, np.float32)
+    pts = np.zeros((B, mcap, 3))
+    frame_pt = np.full((B, cap), -1, np.int32)
+    poses0 = np.zeros((B, 7))
+    for b in range(B):
+        pr = PH.make_problem(int(rng.integers(0, 1 << 30)), int(npts[b]), outlier_frac=0.2)
+        poses0[b] = pr["pose0"]
+        pts[b, : npts[b]] = pr["wps"]
+        n = int(nf[b])
+        if n == 0:
+            continue
+        # feature f observes point frame_pt[f]: a random subset of features, points drawn WITH replacement
+        obs_of = pr["obs"]
+        sel = rng.random(n) < (0.7 if b != 3 else 0.0)
+        if b == 3:
+            sel[[5, 200]] = True   # two pairs only: nothing to refine
+        which = rng.integers(0, npts[b], n)
+        frame_pt[b, :n] = np.where(sel, which, -1)
+        kps["x"][b, :n], kps["y"][b, :n] = obs_of["x"][which], obs_of["y"][which]
+        kps["octave"][b, :n] = rng.integers(0, 4, n)
+        depth[b, :n] = np.where(obs_of["depth"][which] > 0, obs_of["depth"][which], -1.0)
+        if b == 4:
+            frame_pt[b, 7] = npts[b] + 3    # beyond the frame's points: ignored
+            frame_pt[b, n - 1] = mcap + 50  # beyond the table: ignored
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_kps, d_depth, d_n = t(kps.view(np.uint8).reshape(B, cap, 24)), t(depth), t(nf)
+    d_desc = torch.zeros((B, cap, 4), dtype=torch.int64, device=dev)
+    d_rp, d_tk = torch.zeros((B, cap), dtype=torch.float32, device=dev), torch.zeros((B, cap), dtype=torch.uint8, device=dev)
+    d_cs = torch.zeros((B, 38 * 24 + 1), dtype=torch.int32, device=dev)
+    d_pts, d_fp, d_np, d_pose = t(pts.view(np.uint8).reshape(B, mcap, 24)), t(frame_pt), t(npts), t(poses0)
+    outl = torch.full((B, cap), 9, dtype=torch.uint8, device=dev)
+    inl = torch.full((B,), -7, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ref = PoseRefinement()
+    try:
+        fd = frames_dev((0.0, 0.0, 752.0, 480.0), d_n, d_kps, d_desc, d_rp, d_tk, d_cs)
+        ref.refine_frame_batch_dev(fd, d_depth, cam, d_pts, d_fp, d_np, ls, d_pose, outl, inl)
+        ref.sync()
+    finally:
+        ref.close()
+    got_pose, got_outl, got_inl = d_pose.cpu().numpy(), outl.cpu().numpy(), inl.cpu().numpy()
+    for b in range(B):
+        n = int(nf[b])
+        f = np.nonzero((frame_pt[b, :n] >= 0) & (frame_pt[b, :n] < npts[b]))[0]
+        want_outl = np.zeros(cap, np.uint8)
+        if len(f) < 3:
+            assert np.array_equal(got_pose[b], poses0[b]) and got_inl[b] == 0 and not got_outl[b].any(), b
+            continue
+        obs = pose_observations(kps[b, f], depth[b, f], ls)
+        wpose, woutl, winl = orc.pose_refine(poses0[b], orc.Camera(*cam), pts[b, frame_pt[b, f]], obs)
+        want_outl[f] = woutl
+        assert np.allclose(got_pose[b], wpose, rtol=0, atol=1e-9), b
+        assert got_inl[b] == winl and np.array_equal(got_outl[b], want_outl), b
+    assert len(set(frame_pt[0][frame_pt[0] >= 0].tolist())) < (frame_pt[0] >= 0).sum()  # the case did contain shared points

@@ -32,6 +32,7 @@ ROOT = Path(__file__).resolve().parent.parent
     {"SNK_BA_PCG_LDS": "1"},                                            # S in LDS (pcg_solve<true>) instead of registers (pcg_small) for local-BA sized systems
     {"SNK_BA_NO_BIG_ITEMS": "1"},                                       # batches of >= 256 problems keep work items of <= 64 points
     {"SNK_BA_LOCAL_SYNC": "1"},                                         # snk_ba_solve_local_scene decides about the extra iteration on the host (count read back)
+    {"SNK_BA_BECNT_BUDGET": "1", "SNK_BA_CHECK_LISTS": "1"},            # the counter-memory budget of the device-built block entries exceeded: host builder takes over
     {"SNK_BA_NO_SCHUR_WIDE": "1", "SNK_BA_NO_SCHUR_SET": "1"},          # block-major schur_pass with one wavefront per block also for single windows
 ])
 def test_ba_parity_suite_with_forced_path(env):
