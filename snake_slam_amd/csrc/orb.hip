@@ -2406,7 +2406,11 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
         static const int fast_stop = getenv("SNK_ORB_FAST_STOP") ? atoi(getenv("SNK_ORB_FAST_STOP")) : 0;  // timing experiments
         auto fk      = cpw > 1 ? (fq == 3 ? fast_kernel<3, true> : (fq == 4 ? fast_kernel<4, true> : fast_kernel<0, true>))
                                : (fq == 3 ? fast_kernel<3, false> : (fq == 4 ? fast_kernel<4, false> : fast_kernel<0, false>));
-        hipLaunchKernelGGL(fk, xcd_grid(gx, batch), dim3(256), (size_t)4 * L.f_lds_wave, st, L, images_dev, pitch,
+        // occupancy shaping (experiment, round 4): a workgroup that asks for at least SNK_ORB_FAST_LDS_WG bytes of LDS caps how many
+        // FAST workgroups a CU holds, so that back-half workgroups of another stream (staggered schedule) find room beside them
+        static const size_t lds_wg_env = getenv("SNK_ORB_FAST_LDS_WG") ? (size_t)atoll(getenv("SNK_ORB_FAST_LDS_WG")) : 0;
+        const size_t fast_lds = std::max((size_t)4 * L.f_lds_wave, std::min(lds_wg_env, (size_t)LDS_MAX_BYTES));
+        hipLaunchKernelGGL(fk, xcd_grid(gx, batch), dim3(256), fast_lds, st, L, images_dev, pitch,
                            image_stride, aligned0, o->params.ini_th_fast, o->params.min_th_fast, d_cand, d_cellcnt, gx, batch, fast_stop,
                            cpw);
         SNK_LAUNCH_CHECK();
