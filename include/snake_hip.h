@@ -282,6 +282,62 @@ SNK_API int snk_feature_grid_batch_dev(snk_matcher* m, const snk_grid_bounds* bo
                                        snk_kp64* kps_out_dev, uint64_t* desc_out_dev, int32_t* perm_dev,
                                        int32_t* cell_start_dev);
 
+/* ------------------------------------------------------------------------------------------
+ * One stereo frame through the front-end in one call
+ * ------------------------------------------------------------------------------------------ */
+
+/* What FeatureDetector + Preprocess are constructed with (Snake/Preprocess/FeatureDetector.cpp:31-41: the extractor arguments;
+ * Snake/System/SnakeGlobal.h:107-108,115: rect_left / rect_right, featureGridBounds; Snake/System/Settings.h:123: fd_relaxed_stereo). */
+typedef struct snk_frontend_params
+{
+    snk_orb_params orb;
+    snk_rectification rect_left, rect_right; /* undistortKeypoints uses rect_left, StereoMatching's Forward of the right keypoints rect_right */
+    snk_grid_bounds bounds;                  /* featureGridBounds */
+    double bf;                               /* rect_left.bf / stereo_cam.bf as StereoMatching reads it (Preprocess.cpp:137) */
+    int32_t relaxed_stereo;                  /* settings.fd_relaxed_stereo */
+    int32_t stereo;                          /* 1 = settings.inputType == Stereo (left + right image, StereoMatching); 0 = mono: left only */
+} snk_frontend_params;
+
+/* The members of Snake::Frame that FeatureDetector::Detect and Preprocess::Process fill (Snake/Map/Frame.h, Features.h), as
+ * caller-owned arrays of `capacity` entries each (any pointer may be NULL = not wanted).  After the call the left arrays are in
+ * FEATURE-GRID order (Preprocess::computeFeatureGrid scatters keypoints, descriptors, undistorted_keypoints and
+ * normalized_points, Preprocess.cpp:254-260), the right arrays in extractor order (Preprocess.cpp:41-49). */
+typedef struct snk_frontend_frame
+{
+    int32_t capacity;                 /* in: entries per array (snk_frontend_max_keypoints) */
+    int32_t n, n_right, n_stereo;     /* out: frame.N, keypoints_right.size(), the return value of StereoMatching */
+    int32_t cols, rows;               /* out: the grid's cell counts (cell id = cx * rows + cy) */
+    snk_keypoint* keypoints;          /* frame.keypoints (the reference widens them to KeyPoint<double>; same values) */
+    uint64_t (*descriptors)[4];       /* frame.descriptors */
+    snk_kp64* undistorted_keypoints;  /* frame.undistorted_keypoints (.point, .angle, .octave) */
+    double (*normalized_points)[2];   /* frame.normalized_points */
+    int32_t* permutation;             /* what frame.grid.create returned: new index of extractor feature i */
+    int32_t* cell_start;              /* cols * rows + 1 entries: first feature of every cell */
+    float* right_points;              /* frame.right_points (-1000 where unmatched, Frame.cpp:25) */
+    float* depth;                     /* frame.depth (-1000 where unmatched, Frame.cpp:26) */
+    snk_keypoint* keypoints_right;    /* frame.keypoints_right */
+    uint64_t (*descriptors_right)[4]; /* frame.descriptors_right */
+} snk_frontend_frame;
+
+typedef struct snk_frontend snk_frontend;
+
+/* One handle = the reference's FeatureDetector + Preprocess pair for one camera rig: its own stream, extractor and scratch. */
+SNK_API int snk_frontend_create(const snk_frontend_params* params, int device, snk_frontend** out);
+SNK_API int snk_frontend_destroy(snk_frontend* f);
+/* Capacity to provide for images of this size (configures the handle for it). */
+SNK_API int snk_frontend_max_keypoints(snk_frontend* f, int width, int height, int* out);
+SNK_API int snk_frontend_grid_dims(const snk_frontend* f, int* cols, int* rows);
+
+/* FeatureDetector::Detect (left, right: Snake/Preprocess/FeatureDetector.cpp:116-156) + Preprocess::Process (allocateTmp,
+ * undistortKeypoints, computeFeatureGrid, StereoMatching: Snake/Preprocess/Preprocess.cpp:35-53) for ONE frame in ONE synchronous
+ * call: one upload of the two images, the extractor as one two-image launch chain, rectification / grid / StereoMatching enqueued
+ * behind it, one download, one synchronisation; from the second frame of an image size on the launch sequence is replayed as
+ * a hipGraph.  Results are bit for bit those of snk_orb_detect x 2 + snk_rectify x 2 + snk_feature_grid + snk_stereo_match (the same
+ * kernels).  level_scale of StereoMatching = the extractor's own pyramid scales (scale[l] = scale[l - 1] * scale_factor in
+ * float).  right / pitch_right are ignored by a mono handle.  SNK_ERR_CAPACITY (n / n_right set) when capacity is too small. */
+SNK_API int snk_frontend_process(snk_frontend* f, const uint8_t* left, int pitch_left, const uint8_t* right, int pitch_right,
+                                 int width, int height, snk_frontend_frame* out);
+
 /* The per-frame data the tracking matchers read (Snake/Map/Features.h:18-41, Frame.h:44-46), in
  * feature-grid order.  taken[i] != 0 <=> frame.mvpMapPoints[i] != nullptr. */
 typedef struct snk_frame_view

@@ -69,6 +69,11 @@ SIGNATURES = {
     "snk_match_triangulation_bow": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, f32, i32, vp, C.POINTER(i32)]),
     "snk_match_triangulation_bf": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, C.POINTER(i32)]),
     "snk_match_relink": (i32, [vp, vp, vp, vp, vp, i32, f32, f64, i32, vp, vp, C.POINTER(i32)]),
+    "snk_frontend_create": (i32, [vp, i32, C.POINTER(vp)]),
+    "snk_frontend_destroy": (i32, [vp]),
+    "snk_frontend_max_keypoints": (i32, [vp, i32, i32, C.POINTER(i32)]),
+    "snk_frontend_grid_dims": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
+    "snk_frontend_process": (i32, [vp, vp, i32, vp, i32, i32, i32, vp]),
     "snk_orb_create": (i32, [vp, i32, vp, C.POINTER(vp)]),
     "snk_orb_destroy": (i32, [vp]),
     "snk_orb_sync": (i32, [vp]),

@@ -1,0 +1,183 @@
+"""GPU: one stereo frame through the front-end in ONE call (snk_frontend_process = FeatureDetector::Detect x 2 + Preprocess::Process,
+reference Snake/Preprocess/FeatureDetector.cpp:116-156, Snake/Preprocess/Preprocess.cpp:35-53) against (a) the oracle chain and (b) the
+call-by-call path through the host entry points -- bit for bit, on the first frame (plain launches), the second (recorded as a
+hipGraph) and later ones (replayed), across an image-size change and with the graph switched off."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+E_K, E_D = (458.654, 457.296, 367.215, 248.375), (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0, 0.0, 0.0, 0.0)
+E_K2, E_D2 = (457.587, 456.134, 379.999, 255.238), (-0.28368365, 0.07451284, -0.00010473, -3.55590700e-05, 0.0, 0.0, 0.0, 0.0)
+
+
+def oracle_frame(orc, orb, rl, rr, bounds, bf, ls, left, right):
+    p = orc.orb_params(*orb)
+    kl, dl = orc.orb_detect(p, left)
+    out = dict(N=len(kl))
+    ul, nl = orc.rectify(rl, kl)
+    perm, cell_start, cols, rows = orc.feature_grid(ul, bounds)
+    perm = np.asarray(perm)
+    g, gd, gk, gn = np.zeros_like(ul), np.zeros_like(dl), np.zeros_like(kl), np.zeros_like(nl)
+    g[perm], gd[perm], gk[perm], gn[perm] = ul, dl, kl, nl
+    out.update(keypoints=gk, descriptors=gd, undistorted_keypoints=g, normalized_points=gn, permutation=perm.astype(np.int32),
+               cell_start=np.asarray(cell_start, np.int32), cols=cols, rows=rows)
+    if right is not None:
+        kr, dr = orc.orb_detect(p, right)
+        ur, _ = orc.rectify(rr, kr)
+        n_st, rp, depth = orc.stereo_match(g, gd, ur, dr, bf, ls, True)
+        out.update(keypoints_right=kr, descriptors_right=dr, n_right=len(kr), n_stereo=int(n_st), right_points=rp, depth=depth)
+    return out
+
+
+def assert_same(got, want, what):
+    for k, w in want.items():
+        g = got[k]
+        if isinstance(w, np.ndarray) and w.dtype.names:
+            for f in w.dtype.names:
+                assert np.array_equal(g[f], w[f]), f"{what}: {k}.{f}"
+        else:
+            assert np.array_equal(np.asarray(g), np.asarray(w)), f"{what}: {k}"
+
+
+def test_one_call_frame_equals_oracle_and_call_by_call(orc):
+    from snake_slam_amd import synth
+    from snake_slam_amd.frontend import Frontend
+    from snake_slam_amd.matcher import Preprocess, Rectification
+    from snake_slam_amd.orb import ORBExtractor
+    from snake_slam_amd.tracking import FeatureGrid
+
+    orb = (1000, 1.2, 4, 20, 7)
+    bounds, bf = (-120.0, -60.0, 880.0, 540.0), 47.9
+    fe = Frontend(orb, Rectification.make(E_K, E_D), Rectification.make(E_K2, E_D2), bounds, bf)
+    ls = fe.level_scale
+    orl, orr = orc.rectification(E_K, E_D), orc.rectification(E_K2, E_D2)
+    ext, pre, grid = ORBExtractor(*orb), Preprocess(0), FeatureGrid(0)
+    try:
+        for t in range(4):  # frame 0 plain, frame 1 captured, frames 2-3 replayed
+            left, right = synth.stereo_frame(20 + t, 752, 480)
+            got = fe.Process(left, right)
+            want = oracle_frame(orc, orb, orl, orr, bounds, bf, ls, left, right)
+            assert got["N"] > 900 and got["n_stereo"] > 100
+            assert_same(got, want, f"frame {t} vs oracle")
+            # call by call through the host entry points (five synchronisations)
+            kl, dl = ext.Detect(left)
+            kr, dr = ext.Detect(right)
+            ul, nl = pre.rectify(Rectification.make(E_K, E_D), kl)
+            ur, _ = pre.rectify(Rectification.make(E_K2, E_D2), kr)
+            perm = np.asarray(grid.create(bounds, ul)[0])
+            g, gd = np.zeros_like(ul), np.zeros_like(dl)
+            g[perm], gd[perm] = ul, dl
+            n_st, rp, depth = pre.StereoMatching(g, gd, ur, dr, bf, ls, True)
+            assert n_st == got["n_stereo"] and np.array_equal(rp, got["right_points"]) and np.array_equal(depth, got["depth"])
+            assert np.array_equal(gd, got["descriptors"]) and np.array_equal(dr, got["descriptors_right"])
+        # another image size through the same handle (reconfigures, drops the graph), then back
+        for (w, h), seed in (((640, 400), 7), ((752, 480), 8), ((752, 480), 9)):
+            left, right = synth.stereo_frame(seed, w, h)
+            got = fe.Process(left, right)
+            assert_same(got, oracle_frame(orc, orb, orl, orr, bounds, bf, ls, left, right), f"size {w}x{h}")
+        # a featureless pair: no keypoints, nothing matched, nothing written beyond the counts
+        flat = np.full((480, 752), 90, np.uint8)
+        got = fe.Process(flat, flat)
+        assert got["N"] == 0 and got["n_right"] == 0 and got["n_stereo"] == 0 and not got["cell_start"].any()
+    finally:
+        for hnd in (fe, ext, pre, grid):
+            hnd.close()
+
+
+def test_mono_frame_and_kitti_size(orc):
+    """stereo = 0 (settings.inputType == Mono: left image only, no StereoMatching) and the KITTI configuration (1241x376, 2000
+    features, 7 levels; reference configs/kitti.ini:30-34)."""
+    from snake_slam_amd import synth
+    from snake_slam_amd.frontend import Frontend
+    from snake_slam_amd.matcher import Rectification
+
+    orb = (2000, 1.2, 7, 20, 7)
+    bounds = (0.0, 0.0, 1241.0, 376.0)
+    k = (718.856, 718.856, 607.1928, 185.2157)
+    for stereo in (False, True):
+        fe = Frontend(orb, Rectification.make(k), None, bounds, 386.1448, stereo=stereo)
+        try:
+            for t in range(3):
+                left, right = synth.stereo_frame(40 + t, 1241, 376)
+                got = fe.Process(left, right if stereo else None)
+                want = oracle_frame(orc, orb, orc.rectification(k), orc.rectification(k), bounds, 386.1448, fe.level_scale, left,
+                                    right if stereo else None)
+                assert got["N"] > 1500
+                assert_same(got, want, f"kitti stereo={stereo} frame {t}")
+                if not stereo:
+                    assert got["n_right"] == 0 and got["n_stereo"] == 0 and (got["right_points"] == -1000).all() and (got["depth"] == -1000).all()
+        finally:
+            fe.close()
+
+
+def test_without_graph_and_under_a_definition_change(orc, tmp_path):
+    """SNK_FRONTEND_NO_GRAPH=1 (plain launches for every frame) gives the same frames; and a change of the "iround.mode" definition
+    between frames -- a kernel argument the recorded graph holds -- is honoured (the graph is rebuilt)."""
+    code = r"""
+import numpy as np, sys
+from snake_slam_amd import synth, _lib
+from snake_slam_amd.frontend import Frontend
+fe = Frontend()
+out = []
+for t in range(4):
+    if t == 3:
+        _lib.set_definition("iround.mode", 2)
+    l, r = synth.stereo_frame(60 + t, 752, 480)
+    f = fe.Process(l, r)
+    out += [f["descriptors"], f["right_points"], f["depth"], f["permutation"], np.array([f["n_stereo"]])]
+fe.close()
+np.savez(sys.argv[1], *out)
+print("ok")
+"""
+    res = {}
+    for name, env in (("graph", {}), ("plain", {"SNK_FRONTEND_NO_GRAPH": "1"})):
+        f = str(tmp_path / (name + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, PYTHONPATH=str(ROOT), **env), capture_output=True, text=True,
+                           cwd=str(ROOT), timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (name, r.stdout[-1500:], r.stderr[-1500:])
+        res[name] = np.load(f)
+    for k in res["graph"].files:
+        assert np.array_equal(res["graph"][k], res["plain"][k]), k
+    # the last frame ran under iround.mode = 2: the oracle with that definition agrees with it
+    from snake_slam_amd import synth
+    from snake_slam_amd.frontend import Frontend  # noqa: F401  (level scales)
+
+    l, r = synth.stereo_frame(63, 752, 480)
+    ls = np.cumprod(np.array([1.0, 1.2, 1.2, 1.2], np.float32), dtype=np.float32)
+    rect = orc.rectification((1.0, 1.0, 0.0, 0.0))
+    orc.set_definition("iround.mode", 2)
+    try:
+        want = oracle_frame(orc, (1000, 1.2, 4, 20, 7), rect, rect, (0.0, 0.0, 752.0, 480.0), 47.9, ls, l, r)
+    finally:
+        orc.set_definition("iround.mode", 0)
+    files = res["graph"].files
+    assert np.array_equal(res["graph"][files[-4]], want["right_points"]) and int(res["graph"][files[-1]][0]) == want["n_stereo"]
+
+
+def test_invalid_arguments(orc):
+    import ctypes as C
+
+    from snake_slam_amd import _lib
+    from snake_slam_amd.frontend import Frontend, FrontendFrame
+
+    lib = _lib.load()
+    fe = Frontend()
+    fr = FrontendFrame()
+    img = np.zeros((480, 752), np.uint8)
+    assert lib.snk_frontend_process(fe._h, None, 752, img.ctypes.data, 752, 752, 480, C.byref(fr)) != 0        # no left image
+    assert lib.snk_frontend_process(fe._h, img.ctypes.data, 700, img.ctypes.data, 752, 752, 480, C.byref(fr)) != 0  # pitch < width
+    assert lib.snk_frontend_process(fe._h, img.ctypes.data, 752, None, 752, 752, 480, C.byref(fr)) != 0        # stereo handle, no right image
+    assert lib.snk_frontend_process(fe._h, img.ctypes.data, 752, img.ctypes.data, 752, 752, 480, None) != 0
+    from snake_slam_amd import synth
+
+    l, r = synth.stereo_frame(1, 752, 480)
+    fr.capacity = 10  # too small: SNK_ERR_CAPACITY with the counts set
+    assert lib.snk_frontend_process(fe._h, l.ctypes.data, 752, r.ctypes.data, 752, 752, 480, C.byref(fr)) == 4 and fr.n > 900
+    fe.close()
