@@ -143,6 +143,64 @@ class Preprocess
     snk_matcher* h_ = nullptr;
 };
 
+// FeatureDetector::Detect (left + right) and Preprocess::Process for one frame in ONE call and one synchronisation
+// (snk_frontend_process) -- Snake/Preprocess/FeatureDetector.cpp:116-156, Snake/Preprocess/Preprocess.cpp:35-53.  The result
+// vectors hold what those two modules leave in Snake::Frame: left arrays in feature-grid order, right arrays in extractor order.
+struct FrontendResult
+{
+    std::vector<KeyPointF> keypoints, keypoints_right;
+    std::vector<DescriptorORB> descriptors, descriptors_right;
+    std::vector<snk_kp64> undistorted_keypoints;
+    std::vector<std::array<double, 2>> normalized_points;
+    std::vector<int32_t> permutation, cell_start;
+    std::vector<float> right_points, depth;
+    int cols = 0, rows = 0, stereo_matches = 0;
+};
+class Frontend
+{
+   public:
+    Frontend(const snk_frontend_params& p, int device = 0) : p_(p) { check(snk_frontend_create(&p, device, &h_), "snk_frontend_create"); }
+    ~Frontend() { snk_frontend_destroy(h_); }
+    Frontend(const Frontend&)            = delete;
+    Frontend& operator=(const Frontend&) = delete;
+
+    // right may be null for a mono handle; returns the number of stereo matches
+    int Process(const uint8_t* left, int pitch_left, const uint8_t* right, int pitch_right, int width, int height, FrontendResult& r)
+    {
+        int cap = 0;
+        check(snk_frontend_max_keypoints(h_, width, height, &cap), "snk_frontend_max_keypoints");
+        check(snk_frontend_grid_dims(h_, &r.cols, &r.rows), "snk_frontend_grid_dims");
+        const size_t c = (size_t)cap;
+        r.keypoints.resize(c), r.keypoints_right.resize(c), r.descriptors.resize(c), r.descriptors_right.resize(c);
+        r.undistorted_keypoints.resize(c), r.normalized_points.resize(c), r.permutation.resize(c), r.right_points.resize(c), r.depth.resize(c);
+        r.cell_start.resize((size_t)r.cols * r.rows + 1);
+        snk_frontend_frame f{};
+        f.capacity              = cap;
+        f.keypoints             = r.keypoints.data();
+        f.descriptors           = reinterpret_cast<uint64_t(*)[4]>(r.descriptors.data());
+        f.undistorted_keypoints = r.undistorted_keypoints.data();
+        f.normalized_points     = reinterpret_cast<double(*)[2]>(r.normalized_points.data());
+        f.permutation           = r.permutation.data();
+        f.cell_start            = r.cell_start.data();
+        f.right_points          = r.right_points.data();
+        f.depth                 = r.depth.data();
+        f.keypoints_right       = r.keypoints_right.data();
+        f.descriptors_right     = reinterpret_cast<uint64_t(*)[4]>(r.descriptors_right.data());
+        check(snk_frontend_process(h_, left, pitch_left, right, pitch_right, width, height, &f), "snk_frontend_process");
+        const size_t n = (size_t)f.n, nr = (size_t)f.n_right;
+        r.keypoints.resize(n), r.descriptors.resize(n), r.undistorted_keypoints.resize(n), r.normalized_points.resize(n);
+        r.permutation.resize(n), r.right_points.resize(n), r.depth.resize(n);
+        r.keypoints_right.resize(nr), r.descriptors_right.resize(nr);
+        r.stereo_matches = f.n_stereo;
+        return f.n_stereo;
+    }
+    const snk_frontend_params& params() const { return p_; }
+
+   private:
+    snk_frontend* h_ = nullptr;
+    snk_frontend_params p_;
+};
+
 // Frame data the tracking matchers read, grid-ordered (Snake/Map/Features.h:18-41, Frame.h:44-46).
 struct FrameView
 {

@@ -20,6 +20,7 @@
 #pragma once
 #include <cstring>
 #include <tuple>
+#include <type_traits>
 
 #include "snake_hip.hpp"
 
@@ -176,6 +177,69 @@ class Preprocess
     snake_hip::Preprocess pre_;
     SnakeORBMatcher grid_;
     bool exact_ = true;
+};
+
+// FeatureDetector::Detect(Frame&) + Preprocess::Process(Frame&) for a stereo (or mono) frame in ONE call and one synchronisation
+// (snk_frontend_process): Snake/Preprocess/FeatureDetector.cpp:116-156 (extract left and right, keypoints cast to double, frame.N)
+// followed by Snake/Preprocess/Preprocess.cpp:35-53 (allocateTmp, undistortKeypoints, computeFeatureGrid, StereoMatching).  A Snake
+// build calls it where FeatureDetector::Detect runs the extractor (the "FeatureDetection" thread) and lets Preprocess::Process
+// pass the frame through -- one GPU round trip per frame instead of six.  The images are read through the members of
+// Saiga::ImageView<unsigned char> (`data`, `width`, `height`, `pitchBytes`), i.e. frame.image.getImageView() / frame.right_image.getImageView().
+class FrontEnd
+{
+   public:
+    FrontEnd(const Globals& g, const snk_orb_params& orb, int device = 0) : g_(g), fe_(make(g, orb), device) {}
+
+    template <class Frame, class ImageViewT>
+    int DetectAndProcess(Frame& frame, const ImageViewT& left, const ImageViewT* right)
+    {
+        const int n_stereo = fe_.Process(reinterpret_cast<const uint8_t*>(left.data), (int)left.pitchBytes,
+                                         right ? reinterpret_cast<const uint8_t*>(right->data) : nullptr, right ? (int)right->pitchBytes : 0,
+                                         (int)left.width, (int)left.height, r_);
+        using KP = typename std::decay<decltype(frame.keypoints[0])>::type;
+        auto widen = [](const KeyPointF& k)  // kp.cast<double>() (FeatureDetector.cpp:128-131)
+        {
+            KP o{};
+            o.point(0) = k.x, o.point(1) = k.y, o.size = k.size, o.angle = k.angle, o.response = k.response, o.octave = k.octave;
+            return o;
+        };
+        const size_t N = r_.keypoints.size(), NR = r_.keypoints_right.size();
+        frame.keypoints.clear(), frame.keypoints_right.clear();
+        for (size_t i = 0; i < N; ++i) frame.keypoints.push_back(widen(r_.keypoints[i]));
+        for (size_t i = 0; i < NR; ++i) frame.keypoints_right.push_back(widen(r_.keypoints_right[i]));
+        frame.descriptors.resize(N), frame.descriptors_right.resize(NR);
+        static_assert(sizeof(frame.descriptors[0]) == 32, "FeatureDescriptor must be the 256-bit Saiga::DescriptorORB");
+        if (N) std::memcpy(&frame.descriptors[0], r_.descriptors.data(), N * 32);
+        if (NR) std::memcpy(&frame.descriptors_right[0], r_.descriptors_right.data(), NR * 32);
+        frame.N = (int)N;      // FeatureDetector.cpp:169
+        frame.allocateTmp();   // Preprocess.cpp:40
+        frame.undistorted_keypoints.clear();
+        for (size_t i = 0; i < N; ++i)
+        {
+            frame.undistorted_keypoints.emplace_back(frame.keypoints[i]);                    // Preprocess.cpp:60
+            frame.undistorted_keypoints[i].point(0) = r_.undistorted_keypoints[i].x;         // :75
+            frame.undistorted_keypoints[i].point(1) = r_.undistorted_keypoints[i].y;
+            frame.normalized_points[i](0)           = r_.normalized_points[i][0];            // :73
+            frame.normalized_points[i](1)           = r_.normalized_points[i][1];
+            frame.right_points[i]                   = r_.right_points[i];                    // :235
+            frame.depth[i]                          = r_.depth[i];                           // :236
+        }
+        frame.grid.cell_start = r_.cell_start;  // frame.grid.create (:246)
+        frame.grid.cols = r_.cols, frame.grid.rows = r_.rows, frame.grid.bounds = g_.featureGridBounds;
+        return n_stereo;
+    }
+
+   private:
+    static snk_frontend_params make(const Globals& g, const snk_orb_params& orb)
+    {
+        snk_frontend_params p{};
+        p.orb = orb, p.rect_left = g.rect_left, p.rect_right = g.rect_right, p.bounds = g.featureGridBounds;
+        p.bf = g.rect_left.bf, p.relaxed_stereo = g.relaxed_stereo ? 1 : 0, p.stereo = g.mono ? 0 : 1;
+        return p;
+    }
+    const Globals& g_;
+    Frontend fe_;
+    FrontendResult r_;
 };
 
 // Snake::SnakeORBMatcher with the reference's signatures (Snake/Tracking/SnakeORBMatcher.h:21-30).  FeatureDistance is an int.

@@ -363,6 +363,53 @@ int main(int argc, char** argv)
             dump("out_tr_kf_mvp", mpk);
             wr("out_tr_kf_n", std::vector<int32_t>{n});
         }
+        // ---------------- FeatureDetector::Detect + Preprocess::Process of a stereo frame in ONE call (ref::FrontEnd)
+        {
+            struct ImageView  // the members of Saiga::ImageView<unsigned char> the shim reads
+            {
+                const unsigned char* data;
+                int width, height;
+                size_t pitchBytes;
+            };
+            ref::Globals G;
+            const auto r = rd<snk_rectification>("fe_rect");
+            G.rect_left = r[0], G.rect_right = r[1];
+            const auto b        = rd<double>("fe_bounds");
+            G.featureGridBounds = snk_grid_bounds{b[0], b[1], b[2], b[3]};
+            const auto dims     = rd<int32_t>("fe_dims");  // width, height, pitch
+            const auto left = rd<uint8_t>("fe_left"), right = rd<uint8_t>("fe_right");
+            ref::FrontEnd fe(G, snk_orb_params{1000, 1.2f, 4, 20, 7, 0});
+            const ImageView lv{left.data(), dims[0], dims[1], (size_t)dims[2]}, rv{right.data(), dims[0], dims[1], (size_t)dims[2]};
+            std::vector<int32_t> counts;
+            Snake::Frame frame;
+            for (int rep = 0; rep < 3; ++rep)  // plain launches, the recorded graph, its replay: the last frame is written out
+            {
+                frame = Snake::Frame();
+                const int n = fe.DetectAndProcess(frame, lv, &rv);
+                counts.insert(counts.end(), {frame.N, (int32_t)frame.keypoints_right.size(), n});
+            }
+            std::vector<double> kp, und, nrm, kpr;
+            std::vector<uint64_t> dl, dr;
+            for (int i = 0; i < frame.N; ++i)
+            {
+                const auto& k = frame.keypoints[(size_t)i];
+                const auto& u = frame.undistorted_keypoints[(size_t)i];
+                kp.insert(kp.end(), {k.point(0), k.point(1), k.size, k.angle, k.response, (double)k.octave});
+                und.insert(und.end(), {u.point(0), u.point(1), u.angle, (double)u.octave});
+                nrm.insert(nrm.end(), {frame.normalized_points[(size_t)i](0), frame.normalized_points[(size_t)i](1)});
+                dl.insert(dl.end(), frame.descriptors[(size_t)i].begin(), frame.descriptors[(size_t)i].end());
+            }
+            for (size_t i = 0; i < frame.keypoints_right.size(); ++i)
+            {
+                const auto& k = frame.keypoints_right[i];
+                kpr.insert(kpr.end(), {k.point(0), k.point(1), k.size, k.angle, k.response, (double)k.octave});
+                dr.insert(dr.end(), frame.descriptors_right[i].begin(), frame.descriptors_right[i].end());
+            }
+            wr("out_fe_counts", counts), wr("out_fe_kp", kp), wr("out_fe_und", und), wr("out_fe_norm", nrm), wr("out_fe_dl", dl);
+            wr("out_fe_kpr", kpr), wr("out_fe_dr", dr), wr("out_fe_rp", frame.right_points), wr("out_fe_dp", frame.depth);
+            wr("out_fe_cell_start", frame.grid.cell_start);
+            if ((int)frame.mvpMapPoints.size() != frame.N) throw std::runtime_error("allocateTmp was not applied");
+        }
         // ---------------- SolveLocalScene on a Saiga::Scene (LocalBundleAdjustment.cpp:353-413)
         {
             Saiga::Scene scene;

@@ -68,8 +68,48 @@ def test_reference_signatures_match_golden(tmp_path, orc):
         put(f"ba_{k}", np.asarray(b[f"in_{k}"], dt))
     put("ba_bf", np.array([float(b["in_bf"])], np.float64))
 
+    # --- the whole front-end of a stereo frame in one call: FeatureDetector::Detect + Preprocess::Process (ref::FrontEnd)
+    from snake_slam_amd import synth
+
+    fe_k1, fe_d1 = (458.654, 457.296, 367.215, 248.375), (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0, 0.0, 0.0, 0.0)
+    fe_k2, fe_d2 = (457.587, 456.134, 379.999, 255.238), (-0.28368365, 0.07451284, -0.00010473, -3.55590700e-05, 0.0, 0.0, 0.0, 0.0)
+    fe_bounds, fe_bf = (-120.0, -60.0, 880.0, 540.0), 47.9
+    fe_left, fe_right = synth.stereo_frame(77, 752, 480)
+    pitch = 768
+    for name, im in (("fe_left", fe_left), ("fe_right", fe_right)):
+        padded = np.full((480, pitch), 255, np.uint8)  # a row pitch larger than the width, padding that must not be read as image
+        padded[:, :752] = im
+        put(name, padded)
+    put("fe_dims", np.array([752, 480, pitch], np.int32)), put("fe_bounds", np.array(fe_bounds, np.float64))
+    (d / "fe_rect.bin").write_bytes(bytes(Rectification.make(fe_k1, fe_d1, bf=fe_bf)) + bytes(Rectification.make(fe_k2, fe_d2, bf=fe_bf)))
+
     r = subprocess.run([str(exe), str(d)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout, r.stderr)
+
+    # ref::FrontEnd::DetectAndProcess: every member FeatureDetector::Detect and Preprocess::Process fill, against the oracle chain
+    ls = np.cumprod(np.array([1.0, 1.2, 1.2, 1.2], np.float32), dtype=np.float32)
+    par = orc.orb_params(1000, 1.2, 4, 20, 7)
+    kl, dl = orc.orb_detect(par, fe_left)
+    kr, dr = orc.orb_detect(par, fe_right)
+    ul, nl = orc.rectify(orc.rectification(fe_k1, fe_d1), kl)
+    ur, _ = orc.rectify(orc.rectification(fe_k2, fe_d2), kr)
+    perm, cell_start, _, _ = orc.feature_grid(ul, fe_bounds)
+    gu, gd, gk, gn = np.zeros_like(ul), np.zeros_like(dl), np.zeros_like(kl), np.zeros_like(nl)
+    gu[perm], gd[perm], gk[perm], gn[perm] = ul, dl, kl, nl
+    n_st, rp, dp = orc.stereo_match(gu, gd, ur, dr, fe_bf, ls, True)
+    counts = get("fe_counts", np.int32).reshape(3, 3)
+    assert (counts == np.array([len(kl), len(kr), n_st])).all() and n_st > 100
+    kp = get("fe_kp", np.float64).reshape(-1, 6)
+    for c, f in enumerate(("x", "y", "size", "angle", "response", "octave")):
+        assert np.array_equal(kp[:, c], gk[f].astype(np.float64)), f
+        assert np.array_equal(get("fe_kpr", np.float64).reshape(-1, 6)[:, c], kr[f].astype(np.float64)), f
+    und = get("fe_und", np.float64).reshape(-1, 4)
+    assert np.array_equal(und[:, 0], gu["x"]) and np.array_equal(und[:, 1], gu["y"])
+    assert np.array_equal(und[:, 2].astype(np.float32), gu["angle"]) and np.array_equal(und[:, 3].astype(np.int32), gu["octave"])
+    assert np.array_equal(get("fe_norm", np.float64).reshape(-1, 2), gn)
+    assert np.array_equal(get("fe_dl", np.uint64).reshape(-1, 4), gd) and np.array_equal(get("fe_dr", np.uint64).reshape(-1, 4), dr)
+    assert np.array_equal(get("fe_rp", np.float32), rp) and np.array_equal(get("fe_dp", np.float32), dp)
+    assert np.array_equal(get("fe_cell_start", np.int32), cell_start)
 
     # undistortKeypoints: undistorted_keypoints[i] = keypoints[i] with the rectified point; normalized_points
     und = get("pp_undistorted", np.float64).reshape(-1, 4)

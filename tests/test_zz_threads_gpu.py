@@ -68,9 +68,22 @@ def test_seams_run_concurrently_on_their_own_handles(orc):
         n, ci, cf, pose, pt, flags = ba.solve_local_scene(4.41, 5.29)
         return bytes([n & 255]) + np.float64(ci).tobytes() + np.float64(cf).tobytes() + pose.tobytes() + pt.tobytes() + flags.tobytes()
 
+    def run_frontend(fe, k):
+        # snk_frontend_process: the sizes go A, B, A, A, B, A, ... -- every change reconfigures the handle (allocations, the graph
+        # dropped), every A after an A RECORDS the launch chain with a stream capture while the other seams' threads copy, allocate
+        # and launch on their own streams (a capture must not be invalidated by them: nothing in the library uses the legacy stream)
+        l, r = fe_pairs[k % 3]
+        f = fe.Process(l, r)
+        return b"".join(np.ascontiguousarray(f[key]).tobytes() for key in ("keypoints", "descriptors", "undistorted_keypoints", "permutation",
+                                                                           "right_points", "depth", "descriptors_right")) + bytes([f["n_stereo"] & 255])
+
+    from snake_slam_amd.frontend import Frontend
+
+    fe_pairs = [synth.stereo_frame(50, 320, 240, n_rects=90), synth.stereo_frame(51, 352, 256, n_rects=90), synth.stereo_frame(52, 320, 240, n_rects=90)]
+    fe = Frontend((300, 1.2, 3, 20, 7), bounds=(0.0, 0.0, 352.0, 256.0))
     ext = ORBExtractor(300, 1.2, 3, 20, 7)
     pre, bfm, trk, ba, ba2 = Preprocess(), BruteForceMatcher(), SnakeORBMatcher(), BARec(lba_options()), BARec(lba_options())
-    seams = [(run_orb, ext), (run_pre, (pre, bfm)), (run_track, trk), (run_ba, ba), (run_ba_one_call, ba2)]
+    seams = [(run_orb, ext), (run_pre, (pre, bfm)), (run_track, trk), (run_ba, ba), (run_ba_one_call, ba2), (run_frontend, fe)]
     try:
         want = [[fn(h, k) for k in range(3)] for fn, h in seams]  # each call alone
         errors, got = [], [[None] * ROUNDS for _ in seams]
@@ -96,4 +109,4 @@ def test_seams_run_concurrently_on_their_own_handles(orc):
             for k in range(ROUNDS):
                 assert got[si][k] == want[si][k % 3], (si, k)
     finally:
-        ext.close(), pre.close(), bfm.close(), trk.close(), ba.close(), ba2.close()
+        ext.close(), pre.close(), bfm.close(), trk.close(), ba.close(), ba2.close(), fe.close()
