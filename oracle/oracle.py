@@ -189,6 +189,15 @@ def descriptor(img: np.ndarray, x: int, y: int, angle: float) -> np.ndarray:
     return out
 
 
+def descriptor_on_plane(plane: np.ndarray, x: int, y: int, angle: float) -> np.ndarray:
+    """The 256 steered tests evaluated on the plane GIVEN (what orb_detect hands the blurred level): isolates steering, rounding and
+    bit order from the blur (tests/test_oracle_pin.py pins it against scikit-image's _orb_loop on an unblurred plane)."""
+    plane = np.ascontiguousarray(plane, np.uint8)
+    out = np.zeros(4, np.uint64)
+    lib().orc_descriptor_blurred(_p(plane), plane.shape[1], x, y, C.c_float(angle), _p(out))
+    return out
+
+
 def brief_pattern() -> np.ndarray:
     arr = (C.c_int8 * 1024).in_dll(lib(), "orc_brief_pattern")
     return np.frombuffer(arr, np.int8).copy()

@@ -44,6 +44,27 @@ def test_benchmark_scene_parity(orc):
     assert np.array_equal(pose[0], sc["pose"][0])
 
 
+def test_converged_optimum_matches_scipy(orc):
+    """The HIP solver run to convergence against an INDEPENDENT minimiser of the same robust cost (tests/ba_scipy.py:
+    scipy.optimize.least_squares with a complex-step Jacobian; the oracle is not involved): cost to 1e-12 relative, poses / points
+    to 1e-8.  The CPU suite holds the same pin for the oracle (tests/test_oracle_pin.py::test_ba_optimum_against_scipy)."""
+    import ba_scipy
+    from scipy.spatial.transform import Rotation
+    from snake_slam_amd import synth
+    from snake_slam_amd.ba import BARec, lba_options
+
+    sc, _ = synth.ba_scene(n_kf=6, n_pt=120, obs_per_pt=4, seed=61, outlier_frac=0.05)
+    R, t, pt, cost, _ = ba_scipy.optimum(sc)
+    ba = BARec(lba_options(max_iterations=60, max_pcg_iterations=2000, pcg_tol=1e-14))
+    ba.create(sc)
+    ci, cf = ba.initAndSolve()
+    pose, got_pt, _ = ba.state(0)
+    ba.close()
+    assert abs(cf[0] - cost) <= 1e-12 * cost, (cf[0], cost)
+    assert np.abs(Rotation.from_quat(pose[:, :4]).as_matrix() - R).max() <= 1e-8
+    assert np.abs(pose[:, 4:] - t).max() <= 1e-8 and np.abs(got_pt - pt).max() <= 2e-8
+
+
 def test_small_and_degenerate_scenes(orc):
     from snake_slam_amd import synth
 
