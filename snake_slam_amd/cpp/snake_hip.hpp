@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -731,6 +732,11 @@ static_assert(sizeof(KeyPointD) == 48, "KeyPoint<double> layout");
 inline void WriteFeatures(const std::string& file, const std::vector<KeyPointD>& keypoints,
                           const std::vector<DescriptorORB>& descriptors)
 {
+    // The layout is an unverified assumption (Saiga::BinaryFile is absent): a cache written here may be silently misread by a
+    // real Snake-SLAM build.  Refuse unless the caller acknowledges that (or has pinned the layout with tools/check_features_dir.py).
+    const char* ack = std::getenv("SNK_FEATURES_LAYOUT_ACK");
+    if (!ack || std::string(ack) != "1")
+        throw std::runtime_error("WriteFeatures: the .features layout is an unverified assumption; set SNK_FEATURES_LAYOUT_ACK=1 to write it anyway");
     FILE* f = std::fopen(file.c_str(), "wb");
     if (!f) throw std::runtime_error("cannot open " + file);
     const uint64_t nk = keypoints.size(), nd = descriptors.size();

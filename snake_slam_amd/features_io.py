@@ -34,7 +34,16 @@ def cast_double(kps) -> np.ndarray:
     return out
 
 
+LAYOUT_ACK_ENV = "SNK_FEATURES_LAYOUT_ACK"
+
+
 def write_features(path: str, keypoints, descriptors) -> None:
+    """Writes the ASSUMED layout (module docstring).  Until a file written by a real Snake-SLAM build has been probed
+    (tools/check_features_dir.py), a cache written here may be unreadable to -- or, worse, silently misread by -- the reference:
+    the writer refuses unless the caller acknowledges that with SNK_FEATURES_LAYOUT_ACK=1."""
+    if os.environ.get(LAYOUT_ACK_ENV) != "1":
+        raise PermissionError("write_features: the .features layout is an unverified assumption (Saiga::BinaryFile is absent); set "
+                              f"{LAYOUT_ACK_ENV}=1 to write it anyway, or pin the layout first with tools/check_features_dir.py")
     k = np.ascontiguousarray(keypoints, KEYPOINT_D_DTYPE)
     d = np.ascontiguousarray(descriptors, "<u8").reshape(-1, 4)
     with open(path, "wb") as f:

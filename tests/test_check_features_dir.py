@@ -15,6 +15,13 @@ sys.path.insert(0, str(ROOT / "tools"))
 import check_features_dir as T  # noqa: E402
 
 
+@pytest.fixture(autouse=True)
+def _layout_ack(monkeypatch):
+    """The writer of the assumed .features layout refuses to run without this acknowledgement (features_io.write_features)."""
+    monkeypatch.setenv("SNK_FEATURES_LAYOUT_ACK", "1")
+
+
+
 def _kps(n, rng):
     from snake_slam_amd.orb import KEYPOINT_DTYPE
 

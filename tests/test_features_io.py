@@ -10,6 +10,13 @@ from snake_slam_amd import features_io as FIO
 ROOT = Path(__file__).resolve().parent.parent
 
 
+@pytest.fixture(autouse=True)
+def _layout_ack(monkeypatch):
+    """The writer of the assumed .features layout refuses to run without this acknowledgement (features_io.write_features)."""
+    monkeypatch.setenv("SNK_FEATURES_LAYOUT_ACK", "1")
+
+
+
 def sample(n, seed=0):
     rng = np.random.default_rng(seed)
     k = np.zeros(n, FIO.KEYPOINT_D_DTYPE)
@@ -103,3 +110,15 @@ def test_cpp_adaptor_reads_and_writes_the_same_bytes(tmp_path):
     k2, d2 = FIO.read_features(b)
     k["response"] += 1.0
     assert np.array_equal(k2, k) and np.array_equal(d2, d)
+
+
+def test_writer_refuses_without_acknowledgement(tmp_path, monkeypatch):
+    """the guessed layout must not be written silently."""
+    from snake_slam_amd import features_io as FIO
+
+    monkeypatch.delenv("SNK_FEATURES_LAYOUT_ACK", raising=False)
+    k = np.zeros(3, FIO.KEYPOINT_D_DTYPE)
+    d = np.zeros((3, 4), np.uint64)
+    with pytest.raises(PermissionError):
+        FIO.write_features(str(tmp_path / "x.features"), k, d)
+    assert not (tmp_path / "x.features").exists()
