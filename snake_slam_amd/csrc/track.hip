@@ -529,14 +529,18 @@ __global__ __launch_bounds__(1024) void coarse_frame_kernel(FramesDev Fb, const 
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char frame_lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int b = blockIdx.y, i0 = (blockIdx.x * 16 + wave) * 64;
+    const int b = blockIdx.y;
     const int m = min(m_dev[b], m_cap);
     if (blockIdx.x * 1024 >= m) return;  // whole workgroup
-    const FrameDev F = stage_frame_lds(frame_of(Fb, b), frame_lds, 1024);
-    if (i0 >= m) return;
+    const FrameDev F = stage_frame_lds(frame_of(Fb, b), frame_lds, 1024);  // once per workgroup; the chunks of its share follow
     const CamDev C = cams[b];
-    coarse_wave64(F, C, S, pts + (size_t)b * m_cap, m, i0, 64, th, feature_error, direction, lane, best + (size_t)b * m_cap,
-                  bins + (size_t)b * m_cap);
+    for (int chunk = blockIdx.x; chunk * 1024 < m; chunk += gridDim.x)
+    {
+        const int i0 = (chunk * 16 + wave) * 64;
+        if (i0 >= m) break;
+        coarse_wave64(F, C, S, pts + (size_t)b * m_cap, m, i0, 64, th, feature_error, direction, lane, best + (size_t)b * m_cap,
+                      bins + (size_t)b * m_cap);
+    }
 }
 
 __global__ __launch_bounds__(1024) void fine_frame_kernel(FramesDev Fb, const CamDev* __restrict__ cams, ScalesDev S,
@@ -545,13 +549,20 @@ __global__ __launch_bounds__(1024) void fine_frame_kernel(FramesDev Fb, const Ca
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char frame_lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int b = blockIdx.y, i0 = (blockIdx.x * 16 + wave) * 64;
+    const int b = blockIdx.y;
     const int m = min(m_dev[b], m_cap);
     if (blockIdx.x * 1024 >= m) return;  // whole workgroup
+    // The frame (65 KB for 1000 features) is staged ONCE per workgroup and the workgroup walks the chunks blockIdx.x, + gridDim.x, ...
+    // of the frame's local map: with one chunk per workgroup the ten workgroups of a 10 000-point local map each staged the same
+    // frame -- 40 % of a workgroup's input bytes (round 4; grid.x is chosen by the launch, SNK_TRACK_FRAME_WGS).
     const FrameDev F = stage_frame_lds(frame_of(Fb, b), frame_lds, 1024);
-    if (i0 >= m) return;
     const CamDev C = cams[b];
-    fine_wave64(F, C, S, pts + (size_t)b * m_cap, m, i0, 64, th, ratio, lane, best + (size_t)b * m_cap, visible + (size_t)b * m_cap);
+    for (int chunk = blockIdx.x; chunk * 1024 < m; chunk += gridDim.x)
+    {
+        const int i0 = (chunk * 16 + wave) * 64;
+        if (i0 >= m) break;  // chunks ascend: nothing further for this wavefront (no barrier follows)
+        fine_wave64(F, C, S, pts + (size_t)b * m_cap, m, i0, 64, th, ratio, lane, best + (size_t)b * m_cap, visible + (size_t)b * m_cap);
+    }
 }
 
 // first claimant (lowest local-map index) of every feature wins; coarse additionally applies the
@@ -1157,6 +1168,18 @@ bool no_frame_lds()
     return v;
 }
 
+// Workgroups per frame of the frame-resident matchers: every workgroup stages the frame in LDS once and then walks its share of the
+// local map's 1024-point chunks, so as few as keep the chip's 512 workgroup slots (two 65 KB frames per CU) filled about twice.
+// Measured on the tracking leg of bench.py (1024 frames x 10 000 points, profiles/r04/r04g_track_wgs.log): 10 workgroups per frame
+// (one per chunk, the round-3 form) 537 k frames/s, 5: 582 k, 3: 595 k, 2: 610 k, 1: 611 k.  SNK_TRACK_FRAME_WGS forces a value.
+int frame_wgs(int chunks, int batch)
+{
+    static const int forced = getenv("SNK_TRACK_FRAME_WGS") ? atoi(getenv("SNK_TRACK_FRAME_WGS")) : 0;  // A/B, tests
+    int wgs = batch > 0 ? (1024 + batch - 1) / batch : chunks;
+    if (forced >= 1) wgs = forced;
+    return wgs < 1 ? 1 : (wgs > chunks ? chunks : wgs);
+}
+
 int points_per_wave(long long total_points)
 {
     static const int forced = getenv("SNK_TRACK_PPW") ? atoi(getenv("SNK_TRACK_PPW")) : 0;  // tests: force a value
@@ -1524,7 +1547,7 @@ int snk_match_project_coarse_batch_dev(snk_matcher* m, const snk_frames_dev* fra
     if (ppw == 64 && flds <= FRAME_LDS_MAX && !no_frame_lds())
     {
         if ((rc = set_max_lds_once(reinterpret_cast<const void*>(coarse_frame_kernel), FRAME_LDS_MAX)) != SNK_OK) return rc;
-        hipLaunchKernelGGL(coarse_frame_kernel, dim3(ceil_div(pts_cap, 1024), batch), dim3(1024), flds, m->stream, F, (const CamDev*)cams,
+        hipLaunchKernelGGL(coarse_frame_kernel, dim3(frame_wgs(ceil_div(pts_cap, 1024), batch), batch), dim3(1024), flds, m->stream, F, (const CamDev*)cams,
                            S, pts_dev, n_pts_dev, pts_cap, th, feature_error, direction, best, bins);
     }
     else
@@ -1561,7 +1584,8 @@ int snk_match_project_fine_batch_dev(snk_matcher* m, const snk_frames_dev* frame
     if (ppw == 64 && flds <= FRAME_LDS_MAX && !no_frame_lds())
     {
         if ((rc = set_max_lds_once(reinterpret_cast<const void*>(fine_frame_kernel), FRAME_LDS_MAX)) != SNK_OK) return rc;
-        hipLaunchKernelGGL(fine_frame_kernel, dim3(ceil_div(pts_cap, 1024), batch), dim3(1024), flds, m->stream, F, (const CamDev*)cams, S,
+        const int wgs = frame_wgs(ceil_div(pts_cap, 1024), batch);
+        hipLaunchKernelGGL(fine_frame_kernel, dim3(wgs, batch), dim3(1024), flds, m->stream, F, (const CamDev*)cams, S,
                            pts_dev, n_pts_dev, pts_cap, th, ratio, best, visible_dev);
     }
     else
