@@ -26,7 +26,7 @@ def kstats(src: Path, dst: Path):
             n = re.sub(r"\(anonymous namespace\)::", "", r["Name"])
             n = re.sub(r"^void ", "", n).split("(")[0]
             if n.startswith("snk::"):
-                f.write(f'{n},{r["Calls"]},{float(r["AverageNs"]) / 1e3:.1f},{float(r["MinNs"]) / 1e3:.1f},'
+                f.write(f'"{n}",{r["Calls"]},{float(r["AverageNs"]) / 1e3:.1f},{float(r["MinNs"]) / 1e3:.1f},'
                         f'{float(r["MaxNs"]) / 1e3:.1f},{float(r["TotalDurationNs"]) / 1e3:.0f},{r["Percentage"]}\n')
 
 

@@ -27,7 +27,8 @@ def main(d, out=None):
             continue
         n = max(len(v) for v in cs.values())
         rows.append([k, n] + [f"{sum(cs[c]) / len(cs[c]):.4g}" if c in cs else "" for c in counters])
-    text = "\n".join(",".join(map(str, r)) for r in rows)
+    # kernel names carry commas (pose_kernel<4, 0, true>): quoted, so that the columns stay aligned for csv readers
+    text = "\n".join(",".join(f'"{v}"' if isinstance(v, str) and "," in v else str(v) for v in r) for r in rows)
     print(text)
     if out:
         Path(out).write_text(text + "\n")

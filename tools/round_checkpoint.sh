@@ -1,0 +1,25 @@
+#!/bin/bash
+# One measurement checkpoint of a round on the GPU box: full GPU test suite, default bench line (+ KITTI), kernel stats and PMC
+# passes of the front-end, the tracking chain and the 1024-window BA, the per-frame latencies.   usage: tools/round_checkpoint.sh <tag> [notest]
+TAG=${1:-x}
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+cd $REPO
+mkdir -p gpurun_out/$TAG
+if [ "${2:-}" != "notest" ]; then
+  timeout 2400 python -m pytest tests -m gpu -x -q -rf --tb=short 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/pytest_gpu.log
+  tail -3 gpurun_out/$TAG/pytest_gpu.log
+fi
+timeout 600 python bench.py 2>&1 | grep '"metric"' > gpurun_out/$TAG/bench_default.json
+timeout 600 python bench.py --workload kitti --ba-windows 0 --gba-keyframes 0 --pose-frames 0 --track-frames 0 2>&1 | grep '"metric"' > gpurun_out/$TAG/bench_kitti.json
+tools/profile_gpu.sh $TAG > gpurun_out/$TAG/profile_gpu.log 2>&1
+python tools/collect_traffic.py gpurun_out/prof_$TAG 2048 > gpurun_out/$TAG/collect_traffic.log 2>&1 && cp profiles/fast_kernel_traffic.json gpurun_out/$TAG/fast_kernel_traffic.json
+tools/profile_track.sh $TAG pmc > gpurun_out/$TAG/profile_track.log 2>&1
+tools/profile_ba.sh $TAG pmc > gpurun_out/$TAG/profile_ba.log 2>&1
+(python tools/latency_frontend.py; python tools/latency.py; python tools/lba_call_latency_cpp.py) 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/latencies.log
+python -c "
+import json
+d=json.load(open('gpurun_out/$TAG/bench_default.json'))
+print('front-end', d['value'], d['ms_per_step'], d['roofline']['frac'], d.get('stage_ms_per_step'))
+print('ba', d['ba']['value'], 'tracking', d['tracking']['value'])
+"
+tail -5 gpurun_out/$TAG/latencies.log
