@@ -386,6 +386,21 @@ def spawn_ranks_if_needed(args):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
+def _pipeline_traffic(section, sources):
+    """profiles/pipeline_traffic.json[section] (tools/collect_pipeline_traffic.py) when it was collected on the current sources."""
+    import hashlib
+
+    tj = ROOT / "profiles" / "pipeline_traffic.json"
+    try:
+        t = json.loads(tj.read_text())[section]
+        h = hashlib.sha256()
+        for n in sources:
+            h.update((ROOT / "snake_slam_amd" / "csrc" / n).read_bytes())
+        return t if t.get("source_sha256") == h.hexdigest() else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -630,6 +645,20 @@ def main():
         ba_out["roofline"] = {"bound": "hbm", "algorithmic_bytes_per_lm_iteration": 5650000,
                               "achieved": round(5.65e6 * ba_out["value"] / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(5.65e6 * ba_out["value"] / 1e9 / HBM_PEAK_GBS, 5)}
+        # What the kernels actually move and compute, beside the model fraction above (its 5.65 MB contain 4.6 MB of W written and read
+        # back, which schur_fused keeps in LDS): HBM bytes per window and LM iteration from the FETCH_SIZE / WRITE_SIZE passes of
+        # tools/profile_ba.sh (profiles/pipeline_traffic.json, bound to ba.hip by hash), and the f64 rate on SURVEY.md section 8d's
+        # 46 MFLOP per LM iteration against the 78.6 TFLOP/s f64 peak (vector = matrix on this part).
+        ba_out["roofline"]["traffic"] = None
+        pt = _pipeline_traffic("ba", ["ba.hip"])
+        if pt is not None:
+            tb = pt["hbm_bytes_per_window_iteration"]
+            ba_out["roofline"]["traffic"] = int(tb)
+            ba_out["roofline"]["actual"] = {"hbm_bytes_per_lm_iteration": int(tb), "achieved": round(tb * ba_out["value"] / 1e9, 2), "unit": "GB/s",
+                                            "frac": round(tb * ba_out["value"] / 1e9 / HBM_PEAK_GBS, 5),
+                                            "source": "FETCH_SIZE x 2 + WRITE_SIZE of separate rocprofv3 --pmc passes (profiles/pipeline_traffic.json)"}
+        ba_out["roofline"]["flops"] = {"model_flop_per_lm_iteration": 46.0e6, "achieved": round(46.0e6 * ba_out["value"] / 1e12, 3), "peak": 78.6,
+                                       "unit": "TFLOP/s (f64)", "frac": round(46.0e6 * ba_out["value"] / 1e12 / 78.6, 5)}
         ba.close()
         ba1.close()
         # global BA (GlobalBundleAdjustment::FullBA(4), PCG <= 40): one big scene,
@@ -891,8 +920,14 @@ def main():
         a_frame = 2 * (3 * P + 56 * n_kp) + 2 * (2 * n_kp * 32 + n_kp * 16)
         out["pipeline_roofline"] = {"bound": "hbm", "algorithmic_bytes_per_frame": int(a_frame),
                                     "achieved": round(a_frame * value / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(a_frame * value / 1e9 / HBM_PEAK_GBS, 5),
+                                    "frac": round(a_frame * value / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
                                     "note": "extract (L+R) + stereo match + BF match, algorithmic bytes only"}
+        pt = _pipeline_traffic("frontend", ["orb.hip", "matcher.hip", "track.hip", "preprocess.hip"]) if args.workload == "euroc" else None
+        if pt is not None:
+            # counter bytes of every kernel of a step (FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes), per stereo frame
+            out["pipeline_roofline"]["traffic"] = int(pt["hbm_bytes_per_frame"])
+            out["pipeline_roofline"]["traffic_over_algorithmic"] = round(pt["hbm_bytes_per_frame"] / a_frame, 3)
+            out["pipeline_roofline"]["actual_GBs"] = round(pt["hbm_bytes_per_frame"] * value / 1e9, 2)
         if ba_out is not None:
             out["ba"] = ba_out
         if pose_out is not None:

@@ -44,6 +44,12 @@ def main(tag):
     t = G / tag / "fast_kernel_traffic.json"
     if t.exists():
         shutil.copy(t, ROOT / "profiles" / "fast_kernel_traffic.json")
+    t = G / tag / "pipeline_traffic.json"
+    if t.exists():
+        shutil.copy(t, ROOT / "profiles" / "pipeline_traffic.json")
+    for f in ("latencies.log",):
+        if (G / tag / f).exists():
+            shutil.copy(G / tag / f, P / f"{tag}_{f}")
     print("\n".join(sorted(p.name for p in P.glob(f"{tag}_*"))))
 
 
