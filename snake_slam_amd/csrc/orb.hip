@@ -726,8 +726,11 @@ static inline const void* fast_kernel_for(const Layout& L, bool loop)
 // 248-byte store per row.  Per row: neighbour dwords by lane shuffle, horizontal pass with
 // v_alignbyte + v_dot4_u32_u8 (exact 16-bit rows), vertical pass over the register window, one rounding.
 // ------------------------------------------------------------------------------------------------
-constexpr int SM_BH        = 64;         // output rows per band
-constexpr int SM_ROWS      = SM_BH + 6;  // rows streamed per band = 10 * 7 (the window index stays static)
+constexpr int SM_BH        = 64;         // output rows per band (big launches); BH + 6 rows are streamed per band, a multiple of 14
+                                          // so that the 7-row window index stays static.  Small launches (the per-frame calls: one or two
+                                          // images) use bands of 22 or 8 rows: a wavefront walks its band row by row behind a chain of
+                                          // load latencies, and a 752x480 level with 64-row bands is 32 wavefronts of 70 rows each --
+                                          // 22 us per level on an otherwise empty chip (profiles/r04/r04j_*); same arithmetic per pixel.
 constexpr int SM_LANES_OUT = 61;  // strip <= 244 columns: 8 loaded columns remain to the right for the down-scale taps
 
 // The same pass also produces level l+1 (make_next): whenever the stream holds source rows sy, sy+1
@@ -744,22 +747,24 @@ __device__ __forceinline__ u32 dot2(u32 pair, u32 w, u32 acc)
 
 // ALIGNED = false: level 0 of an input whose base / pitch is not a multiple of 4 (byte loads; its own instantiation so
 // that the usual one does not carry the byte-column registers).
-template <bool ALIGNED>
+template <bool ALIGNED, int BH>
 __global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* __restrict__ img0, int pitch0, long long stride0,
-                                                    int make_next, int gx, int batch)
+                                                    int make_next, int gx, int batch, int n_bands)
 {
+    constexpr int SM_ROWS = BH + 6;
+    static_assert(BH <= 64, "lane r of the wavefront keeps the row map of source row yb0 + r");
     __shared__ u32 rowbuf[4][64];  // one raw row per wavefront (down-scale taps)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int b, bxi;
     if (!xcd_image_map(gx, batch, b, bxi)) return;
     const LevelInfo& lv = L.lv[l];
     const int u    = bxi * 4 + wave;
-    if (u >= lv.n_strips * lv.n_bands) return;  // whole wavefront
+    if (u >= lv.n_strips * n_bands) return;  // whole wavefront
     const int band  = u / lv.n_strips, strip = u - band * lv.n_strips;
     const int sx0   = strip * lv.strip_stride;
     const int sx1   = min(sx0 + lv.strip_stride, lv.w);
     const int xl    = sx0 - 4 + 4 * lane;  // image column of this lane's dword
-    const int yb0   = band * SM_BH, yb1 = min(yb0 + SM_BH, lv.h);
+    const int yb0   = band * BH, yb1 = min(yb0 + BH, lv.h);
     const bool out_lane = lane >= 1 && lane <= SM_LANES_OUT && xl < sx1;
     const u8* src      = l == 0 ? img0 + (long long)b * stride0 : lv.base + (long long)b * lv.img_stride;
     // 32-bit offsets inside one image (pitch * h < 2^31), scalars pinned in SGPRs
@@ -2383,10 +2388,18 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
         }
         if (tiny(l)) continue;
         {
-            const int gx = ceil_div(lv.n_strips * lv.n_bands, 4);
-            auto lk = l == 0 && !aligned0 ? level_kernel<false> : level_kernel<true>;
+            // rows per band: 64 when the launch fills the chip's 8192 wavefront slots anyway, else 22, else 8 (per-frame calls)
+            static const int bh_env = getenv("SNK_ORB_LEVEL_BH") ? atoi(getenv("SNK_ORB_LEVEL_BH")) : 0;  // A/B, tests: 64 / 22 / 8
+            const long long strips = (long long)lv.n_strips * batch;
+            int bh = strips * ceil_div(lv.h, 64) >= 2048 ? 64 : (strips * ceil_div(lv.h, 22) >= 2048 ? 22 : 8);
+            if (bh_env == 64 || bh_env == 22 || bh_env == 8) bh = bh_env;
+            const int n_bands = ceil_div(lv.h, bh);
+            const int gx = ceil_div(lv.n_strips * n_bands, 4);
+            const bool al = !(l == 0 && !aligned0);
+            auto lk = bh == 64 ? (al ? level_kernel<true, 64> : level_kernel<false, 64>)
+                               : (bh == 22 ? (al ? level_kernel<true, 22> : level_kernel<false, 22>) : (al ? level_kernel<true, 8> : level_kernel<false, 8>));
             hipLaunchKernelGGL(lk, xcd_grid(gx, batch), dim3(256), 0, st, L, l, images_dev, pitch, image_stride,
-                               fused && l + 1 < L.n_levels && L.lv[l + 1].w > 0 && L.lv[l + 1].h > 0 ? 1 : 0, gx, batch);
+                               fused && l + 1 < L.n_levels && L.lv[l + 1].w > 0 && L.lv[l + 1].h > 0 ? 1 : 0, gx, batch, n_bands);
         }
         SNK_LAUNCH_CHECK();
     }

@@ -798,6 +798,86 @@ __global__ __launch_bounds__(256) void grid_kernel(const snk_kp64* __restrict__ 
     for (int q = last + 1 + tid; q <= ncell; q += 256) cell_start[q] = n;
 }
 
+// The same grid by counting instead of sorting: cell histogram (LDS atomics), exclusive scan = cell_start, members dropped into their
+// cell's segment in arrival order, final position of a feature = segment start + number of members with a smaller index (cells hold
+// one or two features on average).  Five barriers instead of the 55 compare-exchange stages of the bitonic network: 22 -> ~5 us for
+// the one frame of a per-frame call (the network's time is latency, not work).  Same perm / order / cell_start.  LDS: 2 (ncell + 1)
+// + 2 n ints (GRID_COUNT_LDS_MAX bounds it; larger grids keep the network).
+constexpr int GRID_COUNT_LDS_MAX = 96 * 1024;
+__global__ __launch_bounds__(256) void grid_count_kernel(const snk_kp64* __restrict__ kps, const int* __restrict__ n_dev, int n_host, int cap,
+                                                         double min_x, double min_y, int cols, int rows, int* __restrict__ perm,
+                                                         int* __restrict__ order, int* __restrict__ cell_start)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+    __shared__ int s_wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b   = blockIdx.x;
+    int n         = n_dev ? n_dev[b] : n_host;
+    n             = n < cap ? n : cap;
+    kps += (size_t)b * cap;
+    perm += (size_t)b * cap;
+    if (order) order += (size_t)b * cap;
+    const int ncell = cols * rows;
+    cell_start += (size_t)b * (ncell + 1);
+    int* start  = reinterpret_cast<int*>(gsm);  // [ncell + 1]: counts, then exclusive starts
+    int* fill   = start + ncell + 1;            // [ncell + 1]: next free slot of every cell
+    int* cellof = fill + ncell + 1;             // [n]
+    int* seg    = cellof + n;                   // [n]: members of every cell, arrival order
+    for (int c = tid; c <= ncell; c += 256) start[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256)
+    {
+        const snk_kp64 kp = kps[i];
+        const int cell    = cell_coord(kp.x, min_x, cols) * rows + cell_coord(kp.y, min_y, rows);
+        cellof[i]         = cell;
+        atomicAdd(&start[cell], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the ncell counts: a contiguous chunk per thread, the 256 chunk sums scanned by wavefront shuffles
+    {
+        const int chunk = (ncell + 256) / 256;  // covers index ncell too
+        const int c0 = tid * chunk, c1 = min(c0 + chunk, ncell + 1);
+        int sum = 0;
+        for (int c = c0; c < c1; ++c) sum += start[c];
+        int inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1)
+        {
+            const int v = __shfl_up(inc, off);
+            if (lane >= off) inc += v;
+        }
+        if (lane == 63) s_wsum[wave] = inc;
+        __syncthreads();
+        int base = inc - sum;
+        for (int w = 0; w < wave; ++w) base += s_wsum[w];
+        for (int c = c0; c < c1; ++c)
+        {
+            const int v = start[c];
+            start[c]    = base;
+            fill[c]     = base;
+            cell_start[c] = base;  // start[ncell] = n: the end marker
+            base += v;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) seg[atomicAdd(&fill[cellof[i]], 1)] = i;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256)
+    {
+        const int c = cellof[i], s0 = start[c], s1 = start[c + 1];
+        int r = s0;
+        for (int q = s0; q < s1; ++q) r += seg[q] < i ? 1 : 0;
+        perm[i] = r;
+        if (order) order[r] = i;
+    }
+}
+bool grid_count_fits(int n, int ncell) { return ((size_t)2 * (ncell + 1) + (size_t)2 * n) * 4 <= (size_t)GRID_COUNT_LDS_MAX; }
+bool grid_use_network()
+{
+    static const bool v = getenv("SNK_GRID_NETWORK") != nullptr;  // A/B, tests: the bitonic network also where the counting form fits
+    return v;
+}
+
 // out[p] = in[order[p]] for the rectified keypoints and the descriptors (Preprocess.cpp:254-260)
 __global__ __launch_bounds__(256) void reorder_kernel(const int* __restrict__ order, const int* __restrict__ n_dev, int cap,
                                                       const snk_kp64* __restrict__ kin, const uint4* __restrict__ din,
@@ -1329,9 +1409,19 @@ int snk_feature_grid(snk_matcher* m, const snk_kp64* undistorted, int n, const s
     int* d_perm = m->aux2.as<int>();
     int* d_cs   = d_perm + (n > 0 ? n : 1);
     if (n) SNK_HIP_CHECK(hipMemcpyAsync(m->aux.p, undistorted, (size_t)n * sizeof(snk_kp64), hipMemcpyHostToDevice, m->stream));
-    if ((rc = set_max_lds_once(reinterpret_cast<const void*>(grid_kernel), 16384 * 4)) != SNK_OK) return rc;
-    hipLaunchKernelGGL(grid_kernel, dim3(1), dim3(256), (size_t)n_pow2 * 4, m->stream, m->aux.as<snk_kp64>(), (const int*)nullptr,
-                       n, n > 0 ? n : 1, bounds->min_x, bounds->min_y, cols, rows, d_perm, (int*)nullptr, d_cs);
+    if (grid_count_fits(n, cols * rows) && !grid_use_network())
+    {
+        if ((rc = set_max_lds_once(reinterpret_cast<const void*>(grid_count_kernel), GRID_COUNT_LDS_MAX)) != SNK_OK) return rc;
+        hipLaunchKernelGGL(grid_count_kernel, dim3(1), dim3(256), ((size_t)2 * (cols * rows + 1) + (size_t)2 * n) * 4, m->stream,
+                           m->aux.as<snk_kp64>(), (const int*)nullptr, n, n > 0 ? n : 1, bounds->min_x, bounds->min_y, cols, rows, d_perm,
+                           (int*)nullptr, d_cs);
+    }
+    else
+    {
+        if ((rc = set_max_lds_once(reinterpret_cast<const void*>(grid_kernel), 16384 * 4)) != SNK_OK) return rc;
+        hipLaunchKernelGGL(grid_kernel, dim3(1), dim3(256), (size_t)n_pow2 * 4, m->stream, m->aux.as<snk_kp64>(), (const int*)nullptr,
+                           n, n > 0 ? n : 1, bounds->min_x, bounds->min_y, cols, rows, d_perm, (int*)nullptr, d_cs);
+    }
     SNK_LAUNCH_CHECK();
     if (n) SNK_HIP_CHECK(hipMemcpyAsync(perm, d_perm, (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
     SNK_HIP_CHECK(hipMemcpyAsync(cell_start, d_cs, nc * 4, hipMemcpyDeviceToHost, m->stream));
@@ -1355,9 +1445,18 @@ int snk_feature_grid_batch_dev(snk_matcher* m, const snk_grid_bounds* bounds, co
     if ((rc = m->aux2.reserve((size_t)batch * cap * 4)) != SNK_OK) return rc;
     int cap_pow2 = 2;
     while (cap_pow2 < cap) cap_pow2 <<= 1;
-    if ((rc = set_max_lds_once(reinterpret_cast<const void*>(grid_kernel), 16384 * 4)) != SNK_OK) return rc;
-    hipLaunchKernelGGL(grid_kernel, dim3(batch), dim3(256), (size_t)cap_pow2 * 4, m->stream, kps_dev, n_dev, 0, cap, bounds->min_x,
-                       bounds->min_y, cols, rows, perm_dev, m->aux2.as<int>(), cell_start_dev);
+    if (grid_count_fits(cap, cols * rows) && !grid_use_network())
+    {
+        if ((rc = set_max_lds_once(reinterpret_cast<const void*>(grid_count_kernel), GRID_COUNT_LDS_MAX)) != SNK_OK) return rc;
+        hipLaunchKernelGGL(grid_count_kernel, dim3(batch), dim3(256), ((size_t)2 * (cols * rows + 1) + (size_t)2 * cap) * 4, m->stream, kps_dev,
+                           n_dev, 0, cap, bounds->min_x, bounds->min_y, cols, rows, perm_dev, m->aux2.as<int>(), cell_start_dev);
+    }
+    else
+    {
+        if ((rc = set_max_lds_once(reinterpret_cast<const void*>(grid_kernel), 16384 * 4)) != SNK_OK) return rc;
+        hipLaunchKernelGGL(grid_kernel, dim3(batch), dim3(256), (size_t)cap_pow2 * 4, m->stream, kps_dev, n_dev, 0, cap, bounds->min_x,
+                           bounds->min_y, cols, rows, perm_dev, m->aux2.as<int>(), cell_start_dev);
+    }
     hipLaunchKernelGGL(reorder_kernel, dim3(ceil_div(cap, 256), batch), dim3(256), 0, m->stream, m->aux2.as<int>(), n_dev, cap,
                        kps_dev, reinterpret_cast<const uint4*>(desc_dev), kps_out_dev, reinterpret_cast<uint4*>(desc_out_dev));
     SNK_LAUNCH_CHECK();

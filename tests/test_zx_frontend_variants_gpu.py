@@ -1,0 +1,78 @@
+"""GPU: the front-end's alternative kernel forms, chosen by launch size in normal use, forced through their switches: the parity suites
+run again in child processes so that every form sees every test input (the pattern of test_zy_ba_variants_gpu.py; sorts after the
+default-path suites).
+* SNK_ORB_LEVEL_BH = 64 / 22 / 8: rows per band of level_kernel (64 for big batches, 22 / 8 for the per-frame calls);
+* SNK_GRID_NETWORK=1, SNK_STEREO_SORT_NETWORK=1: the bitonic networks instead of the counting forms of the feature grid / the stereo
+  row index;
+* SNK_TRACK_FRAME_WGS = 1 / 3: workgroups per frame of the frame-resident projection matchers."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.mark.parametrize("env,files", [
+    ({"SNK_ORB_LEVEL_BH": "64"}, ["test_orb_gpu.py"]),
+    ({"SNK_ORB_LEVEL_BH": "22"}, ["test_orb_gpu.py"]),
+    ({"SNK_ORB_LEVEL_BH": "8"}, ["test_orb_gpu.py"]),
+    ({"SNK_GRID_NETWORK": "1", "SNK_STEREO_SORT_NETWORK": "1"}, ["test_match_gpu.py", "test_track_gpu.py", "test_frontend_gpu.py"]),
+    ({"SNK_TRACK_FRAME_WGS": "1"}, ["test_track_gpu.py", "test_tracking_chain_gpu.py"]),
+    ({"SNK_TRACK_FRAME_WGS": "3"}, ["test_track_gpu.py", "test_tracking_chain_gpu.py"]),
+])
+def test_parity_suites_with_forced_form(env, files):
+    r = subprocess.run([sys.executable, "-m", "pytest"] + [str(ROOT / "tests" / f) for f in files] +
+                       ["-m", "gpu", "-x", "-q", "-rf", "--tb=short", "-p", "no:cacheprovider"], env=dict(os.environ, **env), capture_output=True,
+                       text=True, cwd=str(ROOT), timeout=900)
+    assert r.returncode == 0, f"{env}\n--- child stdout (tail) ---\n{r.stdout[-6000:]}\n--- child stderr (tail) ---\n{r.stderr[-1500:]}"
+    assert " passed" in r.stdout
+
+
+def test_stereo_index_of_rows_far_outside_the_image(orc):
+    """The counting form of the stereo row index holds 4096 rows; right keypoints that rectification pushed thousands of rows apart run
+    the network inside the same launch.  Host call and batched call (B = 3: the sort + 16-lane path), against the oracle."""
+    import torch
+
+    from helpers import SEED, make_stereo_case
+    from snake_slam_amd.matcher import Preprocess
+
+    rng = np.random.default_rng(SEED + 777)
+    left, dl, right, dr, bf, ls = make_stereo_case(rng, 400, 380)
+    # spread a third of the pairs far apart (the same shift on both sides keeps them matchable)
+    sh = np.where(np.arange(380) % 3 == 0, rng.integers(-3000, 3000, 380) * 1.0, 0.0)
+    right["y"] += sh
+    k = min(len(left), len(right))
+    left["y"][:k] += sh[:k]
+    pre = Preprocess(0)
+    try:
+        n, rp, dp = pre.StereoMatching(left, dl, right, dr, bf, ls, True)
+        wn, wrp, wdp = orc.stereo_match(left, dl, right, dr, bf, ls, True)
+        assert n == wn and np.array_equal(rp, wrp) and np.array_equal(dp, wdp)
+        B, capl, capr = 3, 420, 400
+        from oracle.oracle import KP64
+
+        L, R = np.zeros((B, capl), KP64), np.zeros((B, capr), KP64)
+        DL, DR = np.zeros((B, capl, 4), np.uint64), np.zeros((B, capr, 4), np.uint64)
+        for b in range(B):
+            L[b, :400], DL[b, :400], R[b, :380], DR[b, :380] = left, dl, right, dr
+        R["y"][1] -= 5000.0  # one frame entirely above the image
+        dev = torch.device("cuda:0")
+        t = lambda a: torch.from_numpy(a).to(dev)
+        nl, nr = t(np.full(B, 400, np.int32)), t(np.full(B, 380, np.int32))
+        rpd = torch.full((B, capl), -1000.0, dtype=torch.float32, device=dev)
+        dpd = torch.full((B, capl), -1000.0, dtype=torch.float32, device=dev)
+        nm = torch.zeros(B, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        pre.match_batch_dev(t(L.view(np.uint8).reshape(B, capl, 24)), t(DL.view(np.int64)), nl, t(R.view(np.uint8).reshape(B, capr, 24)),
+                            t(DR.view(np.int64)), nr, bf, ls, True, rpd, dpd, nm)
+        pre.sync()
+        for b in range(B):
+            wn, wrp, wdp = orc.stereo_match(L[b, :400], DL[b, :400], R[b, :380], DR[b, :380], bf, ls, True)
+            assert int(nm[b]) == wn and np.array_equal(rpd[b, :400].cpu().numpy(), wrp) and np.array_equal(dpd[b, :400].cpu().numpy(), wdp), b
+    finally:
+        pre.close()
