@@ -255,6 +255,31 @@ SNK_API int snk_rectify(snk_matcher* m, const snk_rectification* rect, const snk
 SNK_API int snk_rectify_batch_dev(snk_matcher* m, const snk_rectification* rect, const snk_keypoint* kps_dev,
                                   const int32_t* n_dev, int cap, int batch, snk_kp64* out_dev, double* normalized_dev);
 
+/* Replaces Snake::Preprocess::ComputeStereoFromRGBD(Frame&) -- Snake/Preprocess/Preprocess.cpp:79-120, the RGB-D branch of
+ * Preprocess::Process (:43-46).  The globals it reads (Snake/System/SnakeGlobal.h): K (fx fy cx cy of the undistorted image),
+ * rgbd_intrinsics.depthModel.dis (D_depth, rational radial-tangential order k1..k6 p1 p2), rgbd_intrinsics.depthModel.K (K_depth)
+ * and rgbd_intrinsics.bf. */
+typedef struct snk_rgbd_model
+{
+    double K[4];
+    double D_depth[8];
+    double K_depth[4];
+    double bf;
+} snk_rgbd_model;
+
+/* undistorted = frame.undistorted_keypoints (n), depth_image = frame.depth_image (float metres, row pitch in floats).  Per keypoint:
+ * unproject with K, distort with D_depth, project with K_depth, nearest pixel `(int)(v + 0.5)`; depth > 0: depth[i] = depth,
+ * right_points[i] = x - bf / depth; else both -1 (:106-114).  *n_matches = the function's return value.  Where the reference aborts
+ * (SAIGA_ASSERT: outside the depth image, depth < 0 or >= 20, :100-104) the call returns SNK_ERR_INVALID_ARG with
+ * *n_matches = -(index + 1) of the first such keypoint and leaves the outputs untouched.  The _batch_dev form never fails for data:
+ * status_dev[b] = 0x7FFFFFFF (fine) or index + 1 of the first offending keypoint (that frame's outputs are then partial). */
+SNK_API int snk_rgbd_stereo(snk_matcher* m, const snk_rgbd_model* model, const snk_kp64* undistorted, int n, const float* depth_image,
+                            int width, int height, int pitch_floats, float* right_points, float* depth, int* n_matches);
+SNK_API int snk_rgbd_stereo_batch_dev(snk_matcher* m, const snk_rgbd_model* model, const snk_kp64* undistorted_dev, const int32_t* n_dev,
+                                      int cap, int batch, const float* depth_images_dev, int width, int height, int pitch_floats,
+                                      size_t image_stride_floats, float* right_points_dev, float* depth_dev, int32_t* n_matches_dev,
+                                      int32_t* status_dev);
+
 /* ------------------------------------------------------------------------------------------
  * Feature grid and projection-guided tracking matchers
  * ------------------------------------------------------------------------------------------ */

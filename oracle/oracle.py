@@ -242,6 +242,22 @@ def rectify(rect: Rectification, kps):
     return out, norm
 
 
+def rgbd_stereo(und, K, D_depth, K_depth, bf, depth_image):
+    """Preprocess::ComputeStereoFromRGBD.  Returns (matches, right_points, depth); matches < 0: the reference would abort at keypoint
+    -matches - 1 (outside the depth image / depth not in [0, 20))."""
+    und = np.ascontiguousarray(und, KP64)
+    img = np.ascontiguousarray(depth_image, np.float32)
+    K = np.ascontiguousarray(K, np.float64)
+    Dd = np.zeros(8, np.float64)
+    Dd[: len(D_depth)] = D_depth
+    Kd = np.ascontiguousarray(K_depth, np.float64)
+    rp, dp = np.zeros(max(len(und), 1), np.float32), np.zeros(max(len(und), 1), np.float32)
+    lib().orc_rgbd_stereo.restype = C.c_int
+    n = lib().orc_rgbd_stereo(_p(und), C.c_int(len(und)), _p(K), _p(Dd), _p(Kd), C.c_double(bf), _p(img), C.c_int(img.shape[1]),
+                              C.c_int(img.shape[0]), C.c_int(img.shape[1]), _p(rp), _p(dp))
+    return n, rp[: len(und)], dp[: len(und)]
+
+
 # ------------------------------------------------------------------ BA -------------------------
 class BaOptions(C.Structure):
     _fields_ = [("max_iterations", C.c_int32), ("max_pcg_iterations", C.c_int32), ("pcg_tol", C.c_double),

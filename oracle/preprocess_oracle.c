@@ -80,3 +80,41 @@ void orc_rectify(const orc_rectification* R, const orc_keypoint* kps, int n, orc
         out[i].octave = kps[i].octave;
     }
 }
+
+/* Snake::Preprocess::ComputeStereoFromRGBD (reference Snake/Preprocess/Preprocess.cpp:79-120), the RGB-D branch of Preprocess::Process:
+ * per undistorted keypoint, K.unproject2 -> distortNormalizedPoint(depthModel.dis) -> depthModel.K.normalizedToImage (:93-95), the
+ * nearest depth pixel by `int x = reprojected.x() + 0.5` (:97-98: truncation towards zero of the double), and
+ *   depth > 0 : depth[i] = depth, right_points[i] = kpun.x - bf / depth (:106-109, float stores)      else: both -1 (:113-114).
+ * Returns the number of keypoints with depth, or the NEGATED (index + 1) of the first keypoint on which the reference would
+ * abort: outside the depth image (:100), depth < 0 or >= 20 (:103-104).  [DEFINED]: distortNormalizedPoint = the forward rational
+ * radial-tangential model of `distort` above (what undistortPointGN inverts). */
+int orc_rgbd_stereo(const orc_kp64* und, int n, const double* K, const double* D_depth, const double* K_depth, double bf,
+                    const float* depth_image, int w, int h, int pitch_floats, float* right_points, float* depth)
+{
+    int matches = 0;
+    for (int i = 0; i < n; ++i)
+    {
+        const double nx = (und[i].x - K[2]) / K[0], ny = (und[i].y - K[3]) / K[1];
+        double dx, dy, J[4];
+        distort(D_depth, nx, ny, &dx, &dy, J);
+        const double rx = K_depth[0] * dx + K_depth[2], ry = K_depth[1] * dy + K_depth[3];
+        const int ok_range = rx + 0.5 > -1.0 && ry + 0.5 > -1.0 && rx < 2.0e9 && ry < 2.0e9; /* (int) of anything else is undefined */
+        const int x = ok_range ? (int)(rx + 0.5) : -1, y = ok_range ? (int)(ry + 0.5) : -1;
+        if (!ok_range || x < 0 || y < 0 || x >= w || y >= h) return -(i + 1);
+        const float d = depth_image[(long long)y * pitch_floats + x];
+        if (!(d >= 0.0f) || !(d < 20.0f)) return -(i + 1);
+        if (d > 0.0f)
+        {
+            depth[i]               = d;
+            const double disparity = bf / (double)d;
+            right_points[i]        = (float)(und[i].x - disparity);
+            ++matches;
+        }
+        else
+        {
+            depth[i]        = -1.0f;
+            right_points[i] = -1.0f;
+        }
+    }
+    return matches;
+}

@@ -103,6 +103,8 @@ typedef struct orc_rectification
 } orc_rectification;
 void orc_undistort_gn(const double* D, double px, double py, double* ox, double* oy);
 void orc_rectify(const orc_rectification* R, const orc_keypoint* kps, int n, orc_kp64* out, double (*normalized)[2]);
+int orc_rgbd_stereo(const orc_kp64* und, int n, const double* K, const double* D_depth, const double* K_depth, double bf,
+                    const float* depth_image, int w, int h, int pitch_floats, float* right_points, float* depth);
 
 /* ---- ba_oracle.c ---- */
 typedef struct orc_ba_options

@@ -50,6 +50,8 @@ SIGNATURES = {
     "snk_stereo_match_batch_dev": (i32, [vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, f64, vp, i32, i32, vp, vp, vp]),
     "snk_rectify": (i32, [vp, vp, vp, i32, vp, vp]),
     "snk_rectify_batch_dev": (i32, [vp, vp, vp, vp, i32, i32, vp, vp]),
+    "snk_rgbd_stereo": (i32, [vp, vp, vp, i32, vp, i32, i32, i32, vp, vp, C.POINTER(i32)]),
+    "snk_rgbd_stereo_batch_dev": (i32, [vp, vp, vp, vp, i32, i32, vp, i32, i32, i32, C.c_size_t, vp, vp, vp, vp]),
     "snk_feature_grid": (i32, [vp, vp, i32, vp, vp, vp, C.POINTER(i32), C.POINTER(i32)]),
     "snk_feature_grid_batch_dev": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]),
     "snk_match_bind_frame": (i32, [vp, vp]),

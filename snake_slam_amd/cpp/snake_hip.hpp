@@ -122,6 +122,20 @@ class Preprocess
               "snk_rectify");
     }
 
+    // Preprocess::ComputeStereoFromRGBD (Preprocess.cpp:79-120): right_points / depth from the depth image; returns the match count.
+    // Throws where the reference aborts (a keypoint outside the depth image, a depth outside [0, 20)).
+    int ComputeStereoFromRGBD(const snk_rgbd_model& model, const std::vector<snk_kp64>& undistorted, const float* depth_image, int width,
+                              int height, int pitch_floats, std::vector<float>& right_points, std::vector<float>& depth)
+    {
+        right_points.resize(undistorted.size());
+        depth.resize(undistorted.size());
+        int n = 0;
+        check(snk_rgbd_stereo(h_, &model, undistorted.data(), (int)undistorted.size(), depth_image, width, height, pitch_floats,
+                              right_points.data(), depth.data(), &n),
+              "snk_rgbd_stereo");
+        return n;
+    }
+
     // returns the number of stereo matches; right_points / depth keep their -1000 fill where unmatched
     int StereoMatching(const std::vector<snk_kp64>& left_rectified, const std::vector<DescriptorORB>& desc_left,
                        const std::vector<snk_kp64>& right_rectified, const std::vector<DescriptorORB>& desc_right, double bf,

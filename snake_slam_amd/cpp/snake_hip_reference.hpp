@@ -168,6 +168,20 @@ class Preprocess
         for (size_t i = 0; i < rp.size(); ++i) frame.right_points[i] = rp[i], frame.depth[i] = dp[i];  // :235-236
         return n;
     }
+    // ComputeStereoFromRGBD(Frame&) -- Preprocess.cpp:79-120, the RGB-D branch of Preprocess::Process.  frame.depth_image is read
+    // through the members of Saiga::ImageView<float> (`data`, `width`, `height`, `pitchBytes`): frame.depth_image.getImageView().
+    template <class Frame, class DepthView>
+    int ComputeStereoFromRGBD(Frame& frame, const DepthView& depth_image, const snk_rgbd_model& model)
+    {
+        std::vector<snk_kp64> und;
+        und.reserve((size_t)frame.N);
+        for (int i = 0; i < frame.N; ++i) und.push_back(detail::kp64(frame.undistorted_keypoints[(size_t)i]));
+        std::vector<float> rp, dp;
+        const int n = pre_.ComputeStereoFromRGBD(model, und, reinterpret_cast<const float*>(depth_image.data), (int)depth_image.width,
+                                                 (int)depth_image.height, (int)(depth_image.pitchBytes / sizeof(float)), rp, dp);
+        for (int i = 0; i < frame.N; ++i) frame.right_points[(size_t)i] = rp[(size_t)i], frame.depth[(size_t)i] = dp[(size_t)i];  // :106-114
+        return n;
+    }
     // false after a StereoMatching whose keypoint coordinates were not exactly representable as float (the extractor's are:
     // kp.cast<double>() of KeyPoint<float>, FeatureDetector.cpp:128-131)
     bool exact() const { return exact_; }

@@ -71,6 +71,61 @@ __global__ __launch_bounds__(256) void rectify_kernel(RectDev rc, const snk_keyp
     out[(size_t)b * cap + i] = o;
 }
 
+// Snake::Preprocess::ComputeStereoFromRGBD (Preprocess.cpp:79-120): one thread per undistorted keypoint; the same fp64 operation
+// sequence as the oracle.  status[b]: 0, or (index + 1) of the LOWEST keypoint on which the reference would abort (atomicMin).
+struct RgbdDev
+{
+    double K[4], D[8], Kd[4], bf;
+};
+__global__ __launch_bounds__(256) void rgbd_stereo_kernel(RgbdDev rc, const snk_kp64* __restrict__ und, const int* __restrict__ n_dev, int cap,
+                                                          int n_host, const float* __restrict__ depth_image, int w, int h, int pitch_floats,
+                                                          long long image_stride, float* __restrict__ right_points, float* __restrict__ depth,
+                                                          int* __restrict__ n_matches, int* __restrict__ status)
+{
+    const int b = blockIdx.y;
+    int n       = n_dev ? n_dev[b] : n_host;
+    n           = n < cap ? n : cap;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool hit    = false;
+    if (i < n)
+    {
+        const snk_kp64 kp = und[(size_t)b * cap + i];
+        const double nx = (kp.x - rc.K[2]) / rc.K[0], ny = (kp.y - rc.K[3]) / rc.K[1];
+        double dx, dy, J[4];
+        distort(rc.D, nx, ny, dx, dy, J);
+        const double rx = rc.Kd[0] * dx + rc.Kd[2], ry = rc.Kd[1] * dy + rc.Kd[3];
+        const int x = (int)(rx + 0.5), y = (int)(ry + 0.5);
+        bool bad    = !(rx + 0.5 > -1.0 && ry + 0.5 > -1.0 && rx < 2.0e9 && ry < 2.0e9) || x < 0 || y < 0 || x >= w || y >= h;
+        float d     = 0.0f;
+        if (!bad)
+        {
+            d   = depth_image[(long long)b * image_stride + (long long)y * pitch_floats + x];
+            bad = !(d >= 0.0f) || !(d < 20.0f);
+        }
+        if (bad)
+            atomicMin(&status[b], i + 1);
+        else if (d > 0.0f)
+        {
+            depth[(size_t)b * cap + i]        = d;
+            const double disparity            = rc.bf / (double)d;
+            right_points[(size_t)b * cap + i] = (float)(kp.x - disparity);
+            hit                               = true;
+        }
+        else
+        {
+            depth[(size_t)b * cap + i]        = -1.0f;
+            right_points[(size_t)b * cap + i] = -1.0f;
+        }
+    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&n_matches[b], __popcll(m));
+}
+__global__ void rgbd_init_kernel(int* n_matches, int* status, int batch)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < batch) n_matches[b] = 0, status[b] = 0x7FFFFFFF;
+}
+
 int to_dev(const snk_rectification* r, RectDev* d)
 {
     SNK_REQUIRE(r != nullptr, "rectification is NULL");
@@ -127,6 +182,82 @@ int snk_rectify(snk_matcher* m, const snk_rectification* rect, const snk_keypoin
     SNK_HIP_CHECK(hipMemcpyAsync(out, ab + kin, kout, hipMemcpyDeviceToHost, m->stream));
     if (normalized) SNK_HIP_CHECK(hipMemcpyAsync(normalized, m->aux2.p, nb, hipMemcpyDeviceToHost, m->stream));
     SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return SNK_OK;
+}
+
+static int rgbd_params(const snk_rgbd_model* mdl, RgbdDev* rc)
+{
+    SNK_REQUIRE(mdl != nullptr, "rgbd model is NULL");
+    SNK_REQUIRE(mdl->K[0] != 0.0 && mdl->K[1] != 0.0, "K focal length is zero");
+    memcpy(rc->K, mdl->K, sizeof(rc->K));
+    memcpy(rc->D, mdl->D_depth, sizeof(rc->D));
+    memcpy(rc->Kd, mdl->K_depth, sizeof(rc->Kd));
+    rc->bf = mdl->bf;
+    return SNK_OK;
+}
+
+int snk_rgbd_stereo_batch_dev(snk_matcher* m, const snk_rgbd_model* model, const snk_kp64* undistorted_dev, const int32_t* n_dev, int cap,
+                              int batch, const float* depth_images_dev, int width, int height, int pitch_floats, size_t image_stride_floats,
+                              float* right_points_dev, float* depth_dev, int32_t* n_matches_dev, int32_t* status_dev)
+{
+    SNK_REQUIRE(m != nullptr, "matcher is NULL");
+    SNK_REQUIRE(batch >= 0 && cap >= 0 && width >= 1 && height >= 1 && pitch_floats >= width, "bad sizes");
+    SNK_REQUIRE(undistorted_dev && n_dev && depth_images_dev && right_points_dev && depth_dev && n_matches_dev && status_dev, "NULL device buffer");
+    RgbdDev rc;
+    int st = rgbd_params(model, &rc);
+    if (st != SNK_OK) return st;
+    if (batch == 0) return SNK_OK;
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    hipLaunchKernelGGL(rgbd_init_kernel, dim3(ceil_div(batch, 256)), dim3(256), 0, m->stream, n_matches_dev, status_dev, batch);
+    if (cap > 0)
+        hipLaunchKernelGGL(rgbd_stereo_kernel, dim3(ceil_div(cap, 256), batch), dim3(256), 0, m->stream, rc, undistorted_dev, n_dev, cap, 0,
+                           depth_images_dev, width, height, pitch_floats, (long long)image_stride_floats, right_points_dev, depth_dev,
+                           n_matches_dev, status_dev);
+    SNK_LAUNCH_CHECK();
+    return SNK_OK;
+}
+
+int snk_rgbd_stereo(snk_matcher* m, const snk_rgbd_model* model, const snk_kp64* undistorted, int n, const float* depth_image, int width,
+                    int height, int pitch_floats, float* right_points, float* depth, int* n_matches)
+{
+    SNK_REQUIRE(m != nullptr && n_matches != nullptr, "NULL argument");
+    *n_matches = 0;
+    SNK_REQUIRE(n >= 0 && width >= 1 && height >= 1 && pitch_floats >= width, "bad sizes");
+    RgbdDev rc;
+    int st = rgbd_params(model, &rc);
+    if (st != SNK_OK) return st;
+    if (n == 0) return SNK_OK;
+    SNK_REQUIRE(undistorted && depth_image && right_points && depth, "NULL buffer");
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    // aux: keypoints | right_points | depth | n_matches, status;   aux2: the depth image
+    const size_t kb = ((size_t)n * sizeof(snk_kp64) + 15) & ~(size_t)15, fb = ((size_t)n * 4 + 15) & ~(size_t)15;
+    const size_t ib = (size_t)width * height * 4;
+    if ((st = m->aux.reserve(kb + 2 * fb + 16)) != SNK_OK) return st;
+    if ((st = m->aux2.reserve(ib)) != SNK_OK) return st;
+    char* ab = m->aux.as<char>();
+    SNK_HIP_CHECK(hipMemcpyAsync(ab, undistorted, (size_t)n * sizeof(snk_kp64), hipMemcpyHostToDevice, m->stream));
+    SNK_HIP_CHECK(hipMemcpy2DAsync(m->aux2.p, (size_t)width * 4, depth_image, (size_t)pitch_floats * 4, (size_t)width * 4, (size_t)height,
+                                   hipMemcpyHostToDevice, m->stream));
+    int* d_cnt = reinterpret_cast<int*>(ab + kb + 2 * fb);
+    hipLaunchKernelGGL(rgbd_init_kernel, dim3(1), dim3(256), 0, m->stream, d_cnt, d_cnt + 1, 1);
+    hipLaunchKernelGGL(rgbd_stereo_kernel, dim3(ceil_div(n, 256), 1), dim3(256), 0, m->stream, rc, (const snk_kp64*)ab, (const int*)nullptr, n, n,
+                       m->aux2.as<float>(), width, height, width, (long long)0, reinterpret_cast<float*>(ab + kb),
+                       reinterpret_cast<float*>(ab + kb + fb), d_cnt, d_cnt + 1);
+    SNK_LAUNCH_CHECK();
+    int res[2] = {0, 0};
+    SNK_HIP_CHECK(hipMemcpyAsync(res, d_cnt, 8, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (res[1] != 0x7FFFFFFF)
+    {
+        // the reference aborts here (SAIGA_ASSERT, Preprocess.cpp:100,103-104); outputs untouched
+        set_error("ComputeStereoFromRGBD: keypoint %d reprojects outside the depth image or its depth is not in [0, 20)", res[1] - 1);
+        *n_matches = -res[1];
+        return SNK_ERR_INVALID_ARG;
+    }
+    SNK_HIP_CHECK(hipMemcpyAsync(right_points, ab + kb, (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(depth, ab + kb + fb, (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    *n_matches = res[0];
     return SNK_OK;
 }
 }

@@ -157,6 +157,21 @@ class Rectification(C.Structure):
         return r
 
 
+class RgbdModel(C.Structure):
+    """K, rgbd_intrinsics.depthModel.dis / .K and rgbd_intrinsics.bf as ComputeStereoFromRGBD reads them (Preprocess.cpp:93-95,108)."""
+    _fields_ = [("K", C.c_double * 4), ("D_depth", C.c_double * 8), ("K_depth", C.c_double * 4), ("bf", C.c_double)]
+
+    @classmethod
+    def make(cls, K, D_depth=None, K_depth=None, bf=40.0):
+        r = cls()
+        r.K[:] = list(K)
+        d = list(D_depth) if D_depth is not None else []
+        r.D_depth[:] = d + [0.0] * (8 - len(d))
+        r.K_depth[:] = list(K_depth) if K_depth is not None else list(K)
+        r.bf = bf
+        return r
+
+
 class Preprocess(StereoMatcher):
     """undistortKeypoints / Rectification::Forward + StereoMatching on one handle (the reference's
     "Preprocess" thread, Snake/Preprocess/Preprocess.cpp:35-53)."""
@@ -173,6 +188,26 @@ class Preprocess(StereoMatcher):
             "snk_rectify",
         )
         return out, norm
+
+    def ComputeStereoFromRGBD(self, model: "RgbdModel", undistorted, depth_image):
+        """Preprocess::ComputeStereoFromRGBD (Preprocess.cpp:79-120).  Returns (matches, right_points, depth); raises SnakeHipError where
+        the reference aborts (a keypoint outside the depth image, a depth outside [0, 20))."""
+        u = np.ascontiguousarray(undistorted, KP64_DTYPE)
+        img = np.ascontiguousarray(depth_image, np.float32)
+        rp, dp = np.zeros(max(len(u), 1), np.float32), np.zeros(max(len(u), 1), np.float32)
+        n = C.c_int(0)
+        _lib.check(self._lib.snk_rgbd_stereo(self._h, C.byref(model), _ptr(u), len(u), _ptr(img), img.shape[1], img.shape[0], img.shape[1],
+                                             _ptr(rp), _ptr(dp), C.byref(n)), "snk_rgbd_stereo")
+        return n.value, rp[: len(u)], dp[: len(u)]
+
+    def rgbd_batch_dev(self, model: "RgbdModel", undistorted, n, depth_images, right_points, depth, n_matches, status):
+        """undistorted [B, cap, 24] uint8 (snk_kp64), n [B] int32, depth_images [B, H, W] float32; outputs right_points / depth [B, cap]
+        float32, n_matches / status [B] int32 (status 0x7FFFFFFF = fine).  Asynchronous on the handle's stream."""
+        B, cap = undistorted.shape[0], undistorted.shape[1]
+        _lib.check(self._lib.snk_rgbd_stereo_batch_dev(self._h, C.byref(model), undistorted.data_ptr(), n.data_ptr(), cap, B, depth_images.data_ptr(),
+                                                       int(depth_images.shape[2]), int(depth_images.shape[1]), int(depth_images.stride(1)),
+                                                       int(depth_images.stride(0)), right_points.data_ptr(), depth.data_ptr(), n_matches.data_ptr(),
+                                                       status.data_ptr()), "snk_rgbd_stereo_batch_dev")
 
     def rectify_batch_dev(self, rect: Rectification, kps, n, out, normalized=None):
         B, cap = kps.shape[0], kps.shape[1]

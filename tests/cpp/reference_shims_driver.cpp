@@ -270,6 +270,20 @@ int main(int argc, char** argv)
             const int n = pre.StereoMatching(frame);
             if (!pre.exact()) throw std::runtime_error("StereoMatching: inputs were not float-representable");
             wr("out_st_rp", frame.right_points), wr("out_st_dp", frame.depth), wr("out_st_n", std::vector<int32_t>{n});
+            // ---------------- ComputeStereoFromRGBD(Frame&) (Preprocess.cpp:79-120) on the same frame: undistorted = the left keypoints
+            struct DepthView  // the members of Saiga::ImageView<float> the shim reads
+            {
+                const float* data;
+                int width, height;
+                size_t pitchBytes;
+            };
+            const auto dims = rd<int32_t>("rgbd_dims");  // width, height, pitch in floats
+            const auto dimg = rd<float>("rgbd_depth");
+            const auto mdl  = rd<snk_rgbd_model>("rgbd_model");
+            frame.undistorted_keypoints = frame.keypoints;
+            const DepthView dv{dimg.data(), dims[0], dims[1], (size_t)dims[2] * sizeof(float)};
+            const int nd = pre.ComputeStereoFromRGBD(frame, dv, mdl[0]);
+            wr("out_rgbd_rp", frame.right_points), wr("out_rgbd_dp", frame.depth), wr("out_rgbd_n", std::vector<int32_t>{nd});
         }
         // ---------------- the three SnakeORBMatcher searches with the reference's signatures
         {

@@ -54,6 +54,17 @@ def test_reference_signatures_match_golden(tmp_path, orc):
     ident = Rectification.make((1.0, 1.0, 0.0, 0.0), bf=float(m["bf"]))
     (d / "st_rect.bin").write_bytes(bytes(ident) + bytes(ident))
     want_st = orc.stereo_match(left, m["dl"], right, m["dr"], float(m["bf"]), m["ls"], True)
+    # --- ComputeStereoFromRGBD(Frame&): the same left keypoints as undistorted_keypoints, a depth image with a padded row pitch
+    from snake_slam_amd.matcher import RgbdModel
+
+    rg_K, rg_Kd, rg_D = (525.0, 525.0, 319.5, 239.5), (570.3, 570.3, 320.0, 240.0), (0.05, -0.1, 0.0, 0.0, 0.0, 0.0, 1e-3, -5e-4)
+    dw, dh, dpitch = 800, 520, 832
+    dimg = np.where(rng.random((dh, dw)) < 0.3, 0.0, rng.uniform(0.3, 19.9, (dh, dw))).astype(np.float32)
+    padded = np.full((dh, dpitch), 99.0, np.float32)
+    padded[:, :dw] = dimg
+    put("rgbd_depth", padded), put("rgbd_dims", np.array([dw, dh, dpitch], np.int32))
+    (d / "rgbd_model.bin").write_bytes(bytes(RgbdModel.make(rg_K, rg_D, rg_Kd, 40.0)))
+    want_rgbd = orc.rgbd_stereo(left, rg_K, rg_D, rg_Kd, 40.0, dimg)
     # --- tracking matchers
     t = np.load(G / "track_small.npz")
     put("tr_kps", t["f_kps"]), put("tr_desc", t["f_desc"]), put("tr_rp", t["f_right_points"]), put("tr_taken", t["f_taken"])
@@ -134,6 +145,9 @@ def test_reference_signatures_match_golden(tmp_path, orc):
     # StereoMatching(Frame&)
     assert int(get("st_n", np.int32)[0]) == want_st[0] > 10
     assert np.array_equal(get("st_rp", np.float32), want_st[1]) and np.array_equal(get("st_dp", np.float32), want_st[2])
+    # ComputeStereoFromRGBD(Frame&)
+    assert int(get("rgbd_n", np.int32)[0]) == want_rgbd[0] > 10
+    assert np.array_equal(get("rgbd_rp", np.float32), want_rgbd[1]) and np.array_equal(get("rgbd_dp", np.float32), want_rgbd[2])
 
     # the matchers: mvpMapPoints[idx] = lm.points[i].mp (-2 = a map point the frame already had, -1 = none)
     def check_mvp(name, idx, count, n_name):

@@ -1,4 +1,6 @@
 """CPU: pin the undistort / rectify oracle (PARITY UNPINNED vs saiga; see oracle/preprocess_oracle.c)."""
+import ctypes as C
+
 import numpy as np
 
 EUROC_K = (458.654, 457.296, 367.215, 248.375)
@@ -54,3 +56,36 @@ def test_rotation_and_new_intrinsics(orc):
     q = R @ p
     assert np.abs(norm[:, 0] - q[0] / q[2]).max() < 1e-14
     assert np.abs(out["y"] - (q[1] / q[2] * Kd[1] + Kd[3])).max() < 1e-10
+
+
+def test_rgbd_stereo_hand_checkable(orc):
+    """Preprocess::ComputeStereoFromRGBD (Preprocess.cpp:79-120) on cases one can do by hand: no distortion, K_depth = K, so the
+    depth pixel of a keypoint is (int)(x + 0.5), (int)(y + 0.5); depth 0 -> -1 / -1; outside the image or depth >= 20 -> the
+    reference's abort is reported with the index."""
+    from oracle.oracle import KP64
+
+    K = (500.0, 500.0, 320.0, 240.0)
+    img = np.zeros((480, 640), np.float32)
+    img[100, 200], img[101, 200], img[300, 50] = 2.0, 4.0, 0.0
+    und = np.zeros(4, KP64)
+    und["x"], und["y"] = [200.4, 200.49, 50.0, 199.5], [100.4, 100.5, 300.0, 99.6]
+    n, rp, dp = orc.rgbd_stereo(und, K, np.zeros(8), K, 40.0, img)
+    # (200, 100) -> 2 m; (200, 101) -> 4 m (100.5 + 0.5 = 101); (50, 300) -> no depth; (200, 100) again (199.5 + 0.5 = 200, 99.6 + 0.5 = 100.1)
+    assert n == 3
+    assert np.array_equal(dp, np.array([2.0, 4.0, -1.0, 2.0], np.float32))
+    assert np.array_equal(rp, np.array([np.float32(200.4 - 20.0), np.float32(200.49 - 10.0), -1.0, np.float32(199.5 - 20.0)], np.float32))
+    und["x"][2] = 700.0  # right of the image
+    assert orc.rgbd_stereo(und, K, np.zeros(8), K, 40.0, img)[0] == -3
+    und["x"][2] = 50.0
+    img[300, 50] = 25.0  # SAIGA_ASSERT(depth < 20)
+    assert orc.rgbd_stereo(und, K, np.zeros(8), K, 40.0, img)[0] == -3
+    # with distortion: the same forward model undistortPointGN inverts -- distort(undistort(p)) = p
+    D = np.array([-0.28, 0.07, 0.0, 0.0, 0.0, 0.0, 2e-4, 1e-5])
+    for px, py in ((0.31, -0.22), (-0.4, 0.3), (0.0, 0.0)):
+        ux, uy = C.c_double(), C.c_double()
+        orc.lib().orc_undistort_gn(D.ctypes.data_as(C.c_void_p), C.c_double(px), C.c_double(py), C.byref(ux), C.byref(uy))
+        one = np.zeros(1, KP64)
+        one["x"], one["y"] = ux.value * K[0] + K[2], uy.value * K[1] + K[3]
+        big = np.full((480, 640), 1.0, np.float32)
+        big[int(py * K[1] + K[3] + 0.5), int(px * K[0] + K[2] + 0.5)] = 7.0  # the distorted point's pixel, and only that one
+        assert orc.rgbd_stereo(one, K, D, K, 40.0, big)[2][0] == 7.0

@@ -24,3 +24,68 @@ def test_rectify_parity(orc):
             assert np.array_equal(got[f], want[f]), f
         assert np.array_equal(gn, wn)
     pp.close()
+
+
+def test_rgbd_stereo_parity(orc):
+    """Preprocess::ComputeStereoFromRGBD (Preprocess.cpp:79-120) on the device against the oracle, bit for bit (fp64 geometry, float
+    stores): host call and batched device form, with a distorted depth camera; and the reference's aborts reported, not executed."""
+    import torch
+
+    from oracle.oracle import KP64
+    from snake_slam_amd._lib import SnakeHipError
+    from snake_slam_amd.matcher import Preprocess, RgbdModel
+
+    rng = np.random.default_rng(2026)
+    w, h = 640, 480
+    K, Kd = (525.0, 525.0, 319.5, 239.5), (570.3, 570.3, 320.0, 240.0)
+    Dd = (0.05, -0.1, 0.0, 0.0, 0.0, 0.0, 1e-3, -5e-4)
+    model = RgbdModel.make(K, Dd, Kd, 40.0)
+    pre = Preprocess(0)
+    try:
+        for n in (0, 1, 777, 2000):
+            und = np.zeros(n, KP64)
+            und["x"], und["y"] = rng.uniform(40, w - 40, n), rng.uniform(40, h - 40, n)
+            img = np.where(rng.random((h, w)) < 0.3, 0.0, rng.uniform(0.3, 19.9, (h, w))).astype(np.float32)
+            got = pre.ComputeStereoFromRGBD(model, und, img)
+            want = orc.rgbd_stereo(und, K, Dd, Kd, 40.0, img)
+            assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+            if n > 100:
+                assert 0 < got[0] < n and (got[2] == -1).any()
+        # the reference aborts: outside the depth image / depth >= 20
+        und = np.zeros(5, KP64)
+        und["x"], und["y"] = [100, 200, 5000, 300, 9000], [100, 100, 100, 100, 100]
+        img = np.full((h, w), 1.0, np.float32)
+        assert orc.rgbd_stereo(und, K, Dd, Kd, 40.0, img)[0] == -3
+        with pytest.raises(SnakeHipError):
+            pre.ComputeStereoFromRGBD(model, und, img)
+        und["x"][2], und["x"][4] = 150, 160
+        img[:, :] = 20.0
+        assert orc.rgbd_stereo(und, K, Dd, Kd, 40.0, img)[0] == -1
+        with pytest.raises(SnakeHipError):
+            pre.ComputeStereoFromRGBD(model, und, img)
+        # batched, device resident: ragged counts, one frame with an offending keypoint
+        B, cap = 4, 900
+        dev = torch.device("cuda:0")
+        U = np.zeros((B, cap), KP64)
+        nn = np.array([900, 0, 333, 512], np.int32)
+        imgs = np.where(rng.random((B, h, w)) < 0.3, 0.0, rng.uniform(0.3, 19.9, (B, h, w))).astype(np.float32)
+        for b in range(B):
+            U["x"][b, : nn[b]], U["y"][b, : nn[b]] = rng.uniform(40, w - 40, nn[b]), rng.uniform(40, h - 40, nn[b])
+        U["x"][3, 17] = -500.0
+        t = lambda a: torch.from_numpy(a).to(dev)
+        rp = torch.full((B, cap), -1000.0, dtype=torch.float32, device=dev)
+        dp = torch.full((B, cap), -1000.0, dtype=torch.float32, device=dev)
+        nm, stt = torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        pre.rgbd_batch_dev(model, t(U.view(np.uint8).reshape(B, cap, 24)), t(nn), t(imgs), rp, dp, nm, stt)
+        pre.sync()
+        for b in range(B):
+            want = orc.rgbd_stereo(U[b, : nn[b]], K, Dd, Kd, 40.0, imgs[b])
+            if b == 3:
+                assert want[0] == -18 and int(stt[b]) == 18
+                continue
+            assert int(stt[b]) == 0x7FFFFFFF and int(nm[b]) == want[0]
+            assert np.array_equal(rp[b, : nn[b]].cpu().numpy(), want[1]) and np.array_equal(dp[b, : nn[b]].cpu().numpy(), want[2])
+            assert (rp[b, nn[b]:] == -1000).all()
+    finally:
+        pre.close()
