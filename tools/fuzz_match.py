@@ -35,11 +35,19 @@ def main():
     rng = np.random.default_rng(a.seed)
     bf, st, pm, mm, dm = BruteForceMatcher(0), StereoMatcher(0), SnakeORBMatcher(0), MappingORBMatcher(), DeferredMapper()
     t0, n = time.time(), {"bf": 0, "stereo": 0, "coarse": 0, "fine": 0, "keyframe": 0, "fuse": 0, "tri_project": 0, "tri_bow": 0,
-                          "tri_bf": 0, "relink": 0}
+                          "tri_bf": 0, "relink": 0, "grid": 0, "rgbd": 0, "frontend": 0}
+    from snake_slam_amd.matcher import Preprocess, Rectification, RgbdModel  # noqa: E402
+    from snake_slam_amd.tracking import FeatureGrid  # noqa: E402
+    from snake_slam_amd.frontend import Frontend  # noqa: E402
+    from snake_slam_amd import synth  # noqa: E402
+    from oracle.oracle import KP64  # noqa: E402
+
+    grid, pre = FeatureGrid(0), Preprocess(0)
+    fe_cache = {}
     from snake_slam_amd import _lib  # noqa: E402
 
     while time.time() - t0 < a.seconds:
-        kind = int(rng.integers(0, 10))
+        kind = int(rng.integers(0, 13))
         if kind <= 1:  # the [DEFINED] switches (snk_set_definition), the same random setting in the library and in the oracle
             for key, (lo, hi) in _lib.DEFINITIONS.items():
                 v = int(rng.integers(lo, hi + 1)) if rng.random() < 0.5 else 0
@@ -75,6 +83,62 @@ def main():
             ok = got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
             what = f"stereo {nl}x{nr} relaxed {relaxed}"
             n["stereo"] += 1
+        elif kind == 10:  # feature grid (counting form, or the network where the grid is too large for it): points in and out of the bounds, clusters
+            npt = sizes(rng, 3000)
+            w, h = float(rng.integers(40, 2600)), float(rng.integers(40, 1600))
+            bounds = (float(rng.integers(-200, 1)), float(rng.integers(-200, 1)), w, h)
+            k = np.zeros(npt, KP64)
+            k["x"], k["y"] = rng.uniform(bounds[0] - 50, w + 50, npt), rng.uniform(bounds[1] - 50, h + 50, npt)
+            if npt > 10 and rng.random() < 0.4:  # a crowded cell
+                k["x"][: npt // 2], k["y"][: npt // 2] = rng.uniform(100, 118, npt // 2), rng.uniform(60, 78, npt // 2)
+            got = grid.create(bounds, k)
+            want = orc.feature_grid(k, bounds)
+            ok = np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2:] == tuple(want[2:])
+            what = f"grid n {npt} bounds {bounds}"
+            n["grid"] += 1
+        elif kind == 11:  # Preprocess::ComputeStereoFromRGBD
+            npt = sizes(rng, 3000)
+            w, h = int(rng.integers(64, 1300)), int(rng.integers(64, 800))
+            K = (float(rng.uniform(300, 800)), float(rng.uniform(300, 800)), w / 2.0, h / 2.0)
+            Kd = (K[0] * float(rng.uniform(0.9, 1.1)), K[1] * float(rng.uniform(0.9, 1.1)), K[2] + float(rng.uniform(-3, 3)), K[3] + float(rng.uniform(-3, 3)))
+            Dd = tuple(float(v) for v in rng.uniform(-1, 1, 8) * np.array([0.1, 0.05, 0.01, 0.01, 0.01, 0.01, 1e-3, 1e-3])) if rng.random() < 0.7 else (0.0,) * 8
+            k = np.zeros(npt, KP64)
+            k["x"], k["y"] = rng.uniform(0.2 * w, 0.8 * w, npt), rng.uniform(0.2 * h, 0.8 * h, npt)
+            img = np.where(rng.random((h, w)) < 0.3, 0.0, rng.uniform(0.2, 19.9, (h, w))).astype(np.float32)
+            want = orc.rgbd_stereo(k, K, Dd, Kd, 40.0, img)
+            try:
+                got = pre.ComputeStereoFromRGBD(RgbdModel.make(K, Dd, Kd, 40.0), k, img)
+                ok = got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+            except Exception:
+                ok = want[0] < 0  # the reference's abort, reported as an error
+            what = f"rgbd n {npt} image {w}x{h}"
+            n["rgbd"] += 1
+        elif kind == 12:  # snk_frontend_process against the oracle chain (a handle per image size, so the graph path is exercised too)
+            w, h = int(rng.choice([96, 160, 320, 333])), int(rng.choice([96, 128, 240]))
+            orb = (int(rng.choice([100, 300])), 1.2, int(rng.integers(1, 4)), 20, 7)
+            key = (w, h, orb)
+            if key not in fe_cache:
+                if len(fe_cache) >= 6:
+                    fe_cache.pop(next(iter(fe_cache))).close()
+                fe_cache[key] = Frontend(orb, bounds=(0.0, 0.0, float(w), float(h)), bf=40.0)
+            fe = fe_cache[key]
+            l, r = synth.stereo_frame(int(rng.integers(0, 1 << 20)), w, h, n_rects=int(rng.integers(5, 90)))
+            got = fe.Process(l, r)
+            p_ = orc.orb_params(*orb)
+            kl, dl = orc.orb_detect(p_, l)
+            kr, dr = orc.orb_detect(p_, r)
+            rect = orc.rectification((1.0, 1.0, 0.0, 0.0))
+            ul, nl_ = orc.rectify(rect, kl)
+            ur, _ = orc.rectify(rect, kr)
+            perm = np.asarray(orc.feature_grid(ul, (0.0, 0.0, float(w), float(h)))[0])
+            g, gd = np.zeros_like(ul), np.zeros_like(dl)
+            g[perm], gd[perm] = ul, dl
+            wn, wrp, wdp = orc.stereo_match(g, gd, ur, dr, 40.0, fe.level_scale, True) if len(kl) and len(kr) else (0, np.full(len(kl), -1000, np.float32), np.full(len(kl), -1000, np.float32))
+            ok = got["N"] == len(kl) and got["n_right"] == len(kr) and got["n_stereo"] == wn and np.array_equal(got["descriptors"], gd) and \
+                np.array_equal(got["right_points"], wrp) and np.array_equal(got["depth"], wdp) and np.array_equal(got["descriptors_right"], dr) and \
+                np.array_equal(got["permutation"], perm)
+            what = f"frontend {w}x{h} orb {orb}"
+            n["frontend"] += 1
         elif kind >= 5:
             m_pts, clutter = max(30, sizes(rng, 2000)), sizes(rng, 1500)
             if kind == 5:
