@@ -421,6 +421,8 @@ def main():
                     "halves (level passes, FAST) back to back, the back half (distribution, descriptors) of part p on a second stream "
                     "beside the front half of part p + 1 (0 = off)")
     ap.add_argument("--gba-keyframes", type=int, default=300, help="keyframes of the global-BA leg (0 = skip; single GPU only)")
+    ap.add_argument("--frame-calls", type=int, default=100, help="calls of the per-frame leg (snk_frontend_process against the six host "
+                    "calls, one 752x480 stereo frame per call; 0 = skip; single GPU, euroc workload only)")
     ap.add_argument("--pose-frames", type=int, default=256, help="frames per pose-refinement call (0 = skip; single GPU only)")
     ap.add_argument("--track-frames", type=int, default=1024, help="frames of the tracking-matcher leg (device-resident coarse + fine "
                     "projection matchers on the frames the front-end left in HBM; 0 = skip)")
@@ -720,6 +722,58 @@ def main():
             pose_out["cpu_baseline"] = {"value": round(done / (time.perf_counter() - tc0), 1), "unit": "frames/s", "cores": 1,
                                         "kind": "port", "sample": f"{done} refinements of the same problems"}
 
+    # ---- the reference's per-frame call shape (FeatureDetector::Detect x 2 + Preprocess::Process, one stereo frame at a time): the
+    # one-call form snk_frontend_process (one upload, one launch chain / hipGraph replay, one download, ONE synchronisation) beside the
+    # same work as six synchronous host calls.  Host pointers in and out: PCIe inclusive.  Median over distinct frames; single GPU only.
+    frame_out = None
+    if world == 1 and args.workload == "euroc" and args.frame_calls > 0:
+        import ctypes as C
+
+        from snake_slam_amd import _lib as L_
+        from snake_slam_amd.frontend import Frontend
+        from snake_slam_amd.matcher import Preprocess, Rectification
+        from snake_slam_amd.tracking import FeatureGrid
+
+        pairs = [synth.stereo_frame(900 + k, W, H) for k in range(8)]
+        rect_ = Rectification.make((458.654, 457.296, 367.215, 248.375))
+        orb_t = (ORB["nfeatures"], ORB["scale_factor"], ORB["n_levels"], ORB["ini_th_fast"], ORB["min_th_fast"])
+        fe = Frontend(orb_t, rect_, rect_, (0.0, 0.0, float(W), float(H)), 47.9, device=local)
+        ext1, pre1, grid1 = ORBExtractor(**ORB, device=local), Preprocess(local), FeatureGrid(local)
+        fe.Process(*pairs[0])
+        lib_ = L_.load()
+
+        def one_call(l, r):
+            return lib_.snk_frontend_process(fe._h, l.ctypes.data, W, r.ctypes.data, W, W, H, C.byref(fe._frame))
+
+        def six_calls(l, r):
+            kl, dl = ext1.Detect(l)
+            kr, dr = ext1.Detect(r)
+            ul, _ = pre1.rectify(rect_, kl)
+            ur, _ = pre1.rectify(rect_, kr)
+            perm = np.asarray(grid1.create((0.0, 0.0, float(W), float(H)), ul)[0])
+            g_, gd_ = np.zeros_like(ul), np.zeros_like(dl)
+            g_[perm], gd_[perm] = ul, dl
+            return pre1.StereoMatching(g_, gd_, ur, dr, 47.9, fe.level_scale, True)[0]
+
+        med = {}
+        for name, fn in (("one_call", one_call), ("six_calls", six_calls)):
+            for k in range(6):
+                fn(*pairs[k % 8])
+            ts = []
+            for k in range(args.frame_calls):
+                t0 = time.perf_counter()
+                fn(*pairs[k % 8])
+                ts.append(time.perf_counter() - t0)
+            med[name] = float(np.median(ts)) * 1e3
+        n_st = int(fe._frame.n_stereo)
+        for hnd in (fe, ext1, pre1, grid1):
+            hnd.close()
+        frame_out = {"metric": f"ms per {W}x{H} stereo frame through the host API, one frame per call (PCIe inclusive, median of {args.frame_calls} calls)",
+                     "value": round(med["one_call"], 4), "unit": "ms", "higher_is_better": False,
+                     "entry_point": "snk_frontend_process: Detect L + R, undistortKeypoints, computeFeatureGrid, StereoMatching in one call, one synchronisation",
+                     "six_host_calls_ms": round(med["six_calls"], 4), "frames_per_s_one_call": round(1e3 / med["one_call"], 1),
+                     "stereo_matches_last_frame": n_st}
+
     # ---- tracking matchers on the frames the front-end left in HBM: SearchByProjectionFrameFrame2 with
     # M = 1500 points, `mvpMapPoints[idx] = mp` on the device, SearchByProjection2 with M = 10 000 points -- the 1-2 coarse + 1
     # fine call the Tracking thread makes per frame (TrackingCoarse.cpp:234, TrackingFine.cpp:149), for a batch of frames, device
@@ -932,6 +986,8 @@ def main():
             out["ba"] = ba_out
         if pose_out is not None:
             out["pose_refine"] = pose_out
+        if frame_out is not None:
+            out["frontend_frame"] = frame_out
         if track_out is not None:
             out["tracking"] = track_out
         if not args.no_cpu_baseline and world == 1:
