@@ -33,7 +33,14 @@ def per_kernel(d: Path, counter: str):
                     n = re.sub(r"^void ", "", n).split("(")[0]
                     if n.startswith("snk::"):
                         vals[n][row["Dispatch_Id"]] += float(row["Counter_Value"]) * 1024.0
-    return {k: (sum(v.values()) / len(v), len(v)) for k, v in vals.items()}
+    # only the batch-sized dispatches of a kernel (a run may also hold per-frame launches of the same kernel, orders of magnitude smaller)
+    out = {}
+    for k, v in vals.items():
+        d = list(v.values())
+        top = max(d)
+        big = [x for x in d if x >= 0.25 * top] if top > 0 else d
+        out[k] = (sum(big) / len(big), len(big))
+    return out
 
 
 def sha(*names):

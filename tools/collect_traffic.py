@@ -31,6 +31,11 @@ def mean_counter(d: Path, counter: str, prefix: str):
                     if name.startswith(prefix):
                         vals[row.get("Dispatch_Id", len(vals))].append(float(row["Counter_Value"]))
     per_dispatch = [sum(v) for v in vals.values()]  # a dispatch's rows (one per XCD / instance) add up
+    # only the batch-sized launches: a run may contain per-frame launches of the same kernel (bench.py's frontend_frame leg), orders of
+    # magnitude smaller -- they must not enter the mean of "one launch over 2048 images"
+    if per_dispatch:
+        top = max(per_dispatch)
+        per_dispatch = [v for v in per_dispatch if v >= 0.5 * top]
     return (sum(per_dispatch) / len(per_dispatch), len(per_dispatch)) if per_dispatch else (None, 0)
 
 
