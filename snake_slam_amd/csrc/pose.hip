@@ -224,8 +224,17 @@ __device__ int chol_solve6(const double* A, const double* b, double* x)
 // PPT > 0: the frame's matches are held in registers (at most PPT per thread, n <= PPT * 64 * WAVES), read once instead of in
 // each of the 40 steps; PPT = 0: any n, matches re-read per step.  One wavefront per frame is right for a few dozen matches;
 // with the ~770 - 1500 matches of a tracking pass, 16 wavefronts with two matches per thread are (0.43 -> 0.2x ms per 256 frames).
+#ifndef SNK_POSE_NO_UNROLL
+#define SNK_POSE_NO_UNROLL 0
+#endif
+#ifndef SNK_POSE_STUB_SOLVE
+#define SNK_POSE_STUB_SOLVE 0
+#endif
+#ifndef SNK_POSE_MIN_WAVES
+#define SNK_POSE_MIN_WAVES 1
+#endif
 template <int WAVES, int PPT, bool LDSM>
-__global__ __launch_bounds__(64 * WAVES) void pose_kernel(const PoseMeta* __restrict__ meta, const double* __restrict__ wps,
+__global__ __launch_bounds__(64 * WAVES, SNK_POSE_MIN_WAVES) void pose_kernel(const PoseMeta* __restrict__ meta, const double* __restrict__ wps,
                                                           const snk_pose_obs* __restrict__ obs, u8* __restrict__ outlier,
                                                           double* __restrict__ pose_out, int* __restrict__ inliers_out, CamD cam,
                                                           snk_pose_options opt, int lds_matches)
@@ -361,6 +370,9 @@ __global__ __launch_bounds__(64 * WAVES) void pose_kernel(const PoseMeta* __rest
                     if (have[k] && !bad[k]) add_match(pw[k], po[k]);
             }
             else
+#if SNK_POSE_NO_UNROLL
+#pragma unroll 1
+#endif
                 for (int i = lane; i < n; i += STRIDE)
                 {
                     if (out[i]) continue;
@@ -435,7 +447,14 @@ __global__ __launch_bounds__(64 * WAVES) void pose_kernel(const PoseMeta* __rest
             double nb[6], d[6];
 #pragma unroll
             for (int a = 0; a < 6; ++a) nb[a] = -b[a];
+#if SNK_POSE_STUB_SOLVE == 1
+            for (int a = 0; a < 6; ++a) d[a] = nb[a] / H[a * 6 + a];
+            se3_update(pose, d);
+#elif SNK_POSE_STUB_SOLVE == 2
+            for (int a = 0; a < 6; ++a) pose[a] += nb[a] / H[a * 6 + a];
+#else
             if (chol_solve6(H, nb, d) == 0) se3_update(pose, d);
+#endif
             }
             if (WAVES > 1)
             {
