@@ -39,7 +39,7 @@ def test_ba_parity_suite_with_forced_path(env):
     r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_ba_gpu.py"), "-m", "gpu", "-x", "-q", "-rf", "--tb=short",
                         "-p", "no:cacheprovider",
                         # 14 s of scipy on the CPU per run and independent of the path switches that only change launch shapes: default path only
-                        "--deselect", str(ROOT / "tests" / "test_ba_gpu.py") + "::test_converged_optimum_matches_scipy"], env=dict(os.environ, **env), capture_output=True, text=True, cwd=str(ROOT), timeout=600)
+                        "-k", "not matches_scipy"], env=dict(os.environ, **env), capture_output=True, text=True, cwd=str(ROOT), timeout=600)
     assert r.returncode == 0, f"{env}\n--- child stdout (tail) ---\n{r.stdout[-6000:]}\n--- child stderr (tail) ---\n{r.stderr[-1500:]}"
     assert " passed" in r.stdout
 
