@@ -2368,7 +2368,8 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
     // one streaming pass per level: blur of level l + down-scale to level l+1 (the chain makes the
     // passes sequential; every level is read once)
     const int aligned0 = (reinterpret_cast<uintptr_t>(images_dev) % 4 == 0 && pitch % 4 == 0 && image_stride % 4 == 0) ? 1 : 0;
-    const bool fused_ok = o->params.scale_factor <= 2.0f;  // the in-stream down-scale reaches 3 * scale + 1 columns right
+    static const bool unfused_env = getenv("SNK_ORB_UNFUSED") != nullptr;  // A/B: stand-alone resize_kernel + blur-only passes
+    const bool fused_ok = o->params.scale_factor <= 2.0f && !unfused_env;  // the in-stream down-scale reaches 3 * scale + 1 columns right
     // levels below 8 x 8 (deep levels of small images) cannot hold a feature and are outside the domain of
     // the streaming pass's reflect-101 halo: they are only down-scaled (stand-alone kernel), never blurred
     auto tiny = [&](int l) { return L.lv[l].w < 8 || L.lv[l].h < 8; };
