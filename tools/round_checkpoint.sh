@@ -16,7 +16,7 @@ python tools/collect_traffic.py gpurun_out/prof_$TAG 2048 > gpurun_out/$TAG/coll
 bash tools/profile_track.sh $TAG pmc > gpurun_out/$TAG/profile_track.log 2>&1
 bash tools/profile_ba.sh $TAG pmc > gpurun_out/$TAG/profile_ba.log 2>&1
 python tools/collect_pipeline_traffic.py gpurun_out/prof_$TAG gpurun_out/prof_ba_$TAG 1024 1024 > gpurun_out/$TAG/collect_pipeline_traffic.log 2>&1 && cp profiles/pipeline_traffic.json gpurun_out/$TAG/pipeline_traffic.json
-(python tools/latency_frontend.py; python tools/latency.py; python tools/lba_call_latency_cpp.py) 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/latencies.log
+(python tools/latency_frontend.py; python tools/frontend_latency_cpp.py; python tools/latency.py; python tools/lba_call_latency_cpp.py) 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/latencies.log
 python -c "
 import json
 d=json.load(open('gpurun_out/$TAG/bench_default.json'))
