@@ -747,8 +747,11 @@ __device__ __forceinline__ u32 dot2(u32 pair, u32 w, u32 acc)
 
 // ALIGNED = false: level 0 of an input whose base / pitch is not a multiple of 4 (byte loads; its own instantiation so
 // that the usual one does not carry the byte-column registers).
+#ifndef SNK_LEVEL_MIN_WAVES
+#define SNK_LEVEL_MIN_WAVES 1  // build-time A/B: wavefronts per SIMD the register allocator must leave room for in level_kernel
+#endif
 template <bool ALIGNED, int BH>
-__global__ __launch_bounds__(256) void level_kernel(Layout L, int l, const u8* __restrict__ img0, int pitch0, long long stride0,
+__global__ __launch_bounds__(256, SNK_LEVEL_MIN_WAVES) void level_kernel(Layout L, int l, const u8* __restrict__ img0, int pitch0, long long stride0,
                                                     int make_next, int gx, int batch, int n_bands)
 {
     constexpr int SM_ROWS = BH + 6;
