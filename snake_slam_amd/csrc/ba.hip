@@ -35,12 +35,14 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <chrono>
 #include <map>
 #include <unordered_map>
 #include <tuple>
 #include <utility>
+#include <thread>
 #include <vector>
 
 // This file is compiled with -ffp-contract=fast (snake_slam_amd/build.py): BA is specified by a tolerance, its kernels
@@ -3045,6 +3047,18 @@ struct PinnedAlloc
         return static_cast<T*>(p);
     }
     void deallocate(T* p, size_t) { (void)hipHostFree(p); }
+    // resize() default-initialises (no zero fill): every list is written in full right after it is sized, and zeroing hundreds of
+    // megabytes of pinned memory first was host time of a batch hand-over; resize(n, value) still fills
+    template <typename U>
+    void construct(U* p) noexcept
+    {
+        ::new (static_cast<void*>(p)) U;
+    }
+    template <typename U, typename... Args>
+    void construct(U* p, Args&&... args)
+    {
+        ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...);
+    }
     template <typename U>
     bool operator==(const PinnedAlloc<U>&) const { return true; }
     template <typename U>
@@ -3630,136 +3644,179 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         sec_us[k] += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(now - sec_t).count();
         sec_t = now;
     };
+    // ---- sizing pass + fill pass over the problems, on several host threads for batches (round 4) ----
+    // The values, the free-camera indices, the counting sort by point and the eight sorted observation arrays of a problem depend on nothing
+    // but that problem, and they were half of a batch hand-over's list time on ONE core (1024 windows: 117 of 227 ms).  Pass 1 counts
+    // (valid observations, free cameras) per problem, a prefix sum gives every problem its place in the shared lists, pass 2 writes the
+    // places directly -- disjoint ranges, no locks.  The per-problem loop below then only READS these lists.  Same contents as the serial
+    // builder (the loop's old code, run per problem): SNK_BA_CHECK_LISTS and the bit-identity tests of the variants suite cover it.
     for (int b = 0; b < count; ++b)
     {
         const snk_ba_problem& P = problems[b];
-        mark(7);
         SNK_REQUIRE(P.n_img >= 0 && P.n_pt >= 0 && P.n_obs >= 0, "negative problem size");
         SNK_REQUIRE(P.n_img == 0 || (P.pose && P.img_const), "NULL pose arrays");
         SNK_REQUIRE(P.n_pt == 0 || (P.pt && P.pt_const), "NULL point arrays");
         SNK_REQUIRE(P.n_obs == 0 || (P.obs_img && P.obs_pt && P.obs_uv && P.obs_depth && P.obs_weight), "NULL observation arrays");
         SNK_REQUIRE(P.n_rpc >= 0 && (P.n_rpc == 0 || P.rpc != nullptr), "bad relative pose constraints");
-        Prob& pr = probs[(size_t)b];
-        memset(&pr, 0, sizeof(pr));
-        pr.ni = P.n_img;
-        pr.np = P.n_pt;
-        for (int k = 0; k < 4; ++k) pr.K[k] = P.K[k];
-        pr.bf       = P.bf;
-        pr.img_off  = img_off;
-        pr.pt_off   = pt_off;
-        pr.obs_off  = obs_off;
-        pr.cam_off  = cam_off;
-        pr.orig_off = orig_off;
-        pr.vec_off  = vec_off;
-        pr.s_off    = s_off;
-        h->orig_off[(size_t)b] = orig_off;
-        h->orig_n[(size_t)b]   = P.n_obs;
-        // values
-        if (P.n_img) pose.insert(pose.end(), &P.pose[0][0], &P.pose[0][0] + (size_t)P.n_img * 7);
-        if (P.n_pt)
+    }
+    struct PreProb
+    {
+        int nfc, no;
+        size_t img_at, pt_at, ps_at, obs_at;
+        int orig_at;
+        char dup;  // one camera twice on a point (device-built block entries are then off)
+    };
+    std::vector<PreProb> pre((size_t)count);
+    static const int host_threads_env = getenv("SNK_BA_HOST_THREADS") ? atoi(getenv("SNK_BA_HOST_THREADS")) : 0;
+    int n_threads = 1;
+    if (count >= 16)
+    {
+        n_threads = host_threads_env > 0 ? host_threads_env : (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+        n_threads = std::min(n_threads, count / 8);
+    }
+    else if (host_threads_env > 0 && count >= 2)
+        n_threads = std::min(host_threads_env, count);  // tests force the threaded form on small batches
+    auto parallel_for = [&](auto&& body)
+    {
+        if (n_threads <= 1)
         {
-            pt.insert(pt.end(), &P.pt[0][0], &P.pt[0][0] + (size_t)P.n_pt * 3);
-            const size_t at = ptc.size();
-            ptc.resize(at + (size_t)P.n_pt);
-            for (int p = 0; p < P.n_pt; ++p) ptc[at + (size_t)p] = P.pt_const[p] ? 1 : 0;
+            for (int b = 0; b < count; ++b) body(b);
+            return;
         }
-        // free cameras
-        int nfc = 0;
-        std::vector<int> cidx((size_t)P.n_img);
-        for (int i = 0; i < P.n_img; ++i) cidx[(size_t)i] = P.img_const[i] ? -1 : nfc++;
-        camidx.insert(camidx.end(), cidx.begin(), cidx.end());
-        pr.nfc = nfc;
-        pr.n6  = 6 * nfc;
-        // valid observations, counting sort by point (stable: caller order inside a point)
-        std::vector<int> pstart((size_t)P.n_pt + 1, 0);
-        std::vector<char> valid((size_t)P.n_obs, 0);
+        std::atomic<int> next{0};
+        std::vector<std::thread> pool;
+        auto work = [&]()
+        {
+            for (;;)
+            {
+                const int b0 = next.fetch_add(8);
+                if (b0 >= count) return;
+                for (int b = b0; b < std::min(b0 + 8, count); ++b) body(b);
+            }
+        };
+        for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
+        work();
+        for (auto& t : pool) t.join();
+    };
+    parallel_for([&](int b)
+    {
+        const snk_ba_problem& P = problems[b];
+        PreProb& q = pre[(size_t)b];
+        q.nfc = 0;
+        for (int i = 0; i < P.n_img; ++i) q.nfc += P.img_const[i] ? 0 : 1;
+        int no = 0;
         for (int o = 0; o < P.n_obs; ++o)
         {
             const int i = P.obs_img[o], p = P.obs_pt[o];
             if (i < 0 || i >= P.n_img || p < 0 || p >= P.n_pt) continue;
             if (P.img_const[i] && P.pt_const[p]) continue;  // reference LocalBundleAdjustment.cpp:286
+            ++no;
+        }
+        q.no  = no;
+        q.dup = 0;
+    });
+    {
+        size_t a_img = 0, a_pt = 0, a_ps = 0, a_obs = 0;
+        long long a_orig = 0;
+        for (int b = 0; b < count; ++b)
+        {
+            PreProb& q = pre[(size_t)b];
+            q.img_at = a_img, q.pt_at = a_pt, q.ps_at = a_ps, q.obs_at = a_obs, q.orig_at = (int)a_orig;
+            a_img += (size_t)problems[b].n_img, a_pt += (size_t)problems[b].n_pt, a_ps += (size_t)problems[b].n_pt + 1, a_obs += (size_t)q.no;
+            a_orig += problems[b].n_obs;
+            SNK_REQUIRE(a_orig < (1ll << 31) && a_obs < ((size_t)1 << 31), "scene list too large (observations)");
+        }
+        pose.resize(7 * a_img), pt.resize(3 * a_pt), ptc.resize(a_pt), camidx.resize(a_img), ptstart.resize(a_ps);
+        oimg.resize(a_obs), ocam.resize(a_obs), optfree.resize(a_obs), ouv2.resize(2 * a_obs), odepth.resize(a_obs), oweight.resize(a_obs);
+        oorig.resize(a_obs), optidx.resize(a_obs);
+    }
+    parallel_for([&](int b)
+    {
+        const snk_ba_problem& P = problems[b];
+        PreProb& q = pre[(size_t)b];
+        // values
+        if (P.n_img) memcpy(pose.data() + 7 * q.img_at, &P.pose[0][0], (size_t)P.n_img * 7 * sizeof(double));
+        if (P.n_pt) memcpy(pt.data() + 3 * q.pt_at, &P.pt[0][0], (size_t)P.n_pt * 3 * sizeof(double));
+        for (int p = 0; p < P.n_pt; ++p) ptc[q.pt_at + (size_t)p] = P.pt_const[p] ? 1 : 0;
+        // free cameras
+        int* cidx = camidx.data() + q.img_at;
+        int nfc   = 0;
+        for (int i = 0; i < P.n_img; ++i) cidx[i] = P.img_const[i] ? -1 : nfc++;
+        // valid observations, counting sort by point (stable: caller order inside a point)
+        int* pstart = ptstart.data() + q.ps_at;
+        for (int p = 0; p <= P.n_pt; ++p) pstart[p] = 0;
+        std::vector<char> valid((size_t)P.n_obs, 0);
+        for (int o = 0; o < P.n_obs; ++o)
+        {
+            const int i = P.obs_img[o], p = P.obs_pt[o];
+            if (i < 0 || i >= P.n_img || p < 0 || p >= P.n_pt) continue;
+            if (P.img_const[i] && P.pt_const[p]) continue;
             valid[(size_t)o] = 1;
-            pstart[(size_t)p + 1]++;
+            pstart[p + 1]++;
         }
-        for (int p = 0; p < P.n_pt; ++p) pstart[(size_t)p + 1] += pstart[(size_t)p];
-        const int no = pstart[(size_t)P.n_pt];
-        pr.no        = no;
-        pr.ptstart_off = (int)ptstart.size();
-        ptstart.insert(ptstart.end(), pstart.begin(), pstart.end());
-        mark(0);
+        for (int p = 0; p < P.n_pt; ++p) pstart[p + 1] += pstart[p];
         // the sorted observation arrays, written in ONE pass over the caller's order: position = next free slot of the point
-        // (sized once, written by index: nine push_backs per observation were a fifth of the hand-over's host time; a
-        // separate pass that built the sorted order first was another tenth)
-        const size_t obs_at = oimg.size();
-        oimg.resize(obs_at + (size_t)no), ocam.resize(obs_at + (size_t)no), optfree.resize(obs_at + (size_t)no), ouv2.resize(2 * (obs_at + (size_t)no));
-        odepth.resize(obs_at + (size_t)no), oweight.resize(obs_at + (size_t)no), oorig.resize(obs_at + (size_t)no), optidx.resize(obs_at + (size_t)no);
-        const int* const s_cam  = ocam.data() + obs_at;   // free-camera index of sorted observation s (stable until the next problem)
+        const size_t obs_at = q.obs_at;
+        int* q_img = oimg.data() + obs_at, *q_cam = ocam.data() + obs_at, *q_orig = oorig.data() + obs_at, *q_pt = optidx.data() + obs_at;
+        unsigned char* q_free = optfree.data() + obs_at;
+        double *q_uv = ouv2.data() + 2 * obs_at, *q_d = odepth.data() + obs_at, *q_w = oweight.data() + obs_at;
+        // free cameras seen so far per point (device-built block entries: no camera twice on a point)
+        const int seen_words = nfc <= BE_MAX_CAMS ? (nfc + 63) >> 6 : 0;
+        std::vector<unsigned long long> seen((size_t)P.n_pt * (size_t)seen_words, 0ull);
+        std::vector<int> fill(pstart, pstart + P.n_pt);
+        for (int o = 0; o < P.n_obs; ++o)
         {
-            int* q_img = oimg.data() + obs_at, *q_cam = ocam.data() + obs_at, *q_orig = oorig.data() + obs_at, *q_pt = optidx.data() + obs_at;
-            unsigned char* q_free = optfree.data() + obs_at;
-            double *q_uv = ouv2.data() + 2 * obs_at, *q_d = odepth.data() + obs_at, *q_w = oweight.data() + obs_at;
-            // free cameras seen so far per point (device-built block entries: no camera twice on a point)
-            const int seen_words = nfc <= BE_MAX_CAMS ? (nfc + 63) >> 6 : 0;
-            std::vector<unsigned long long> seen((size_t)P.n_pt * (size_t)seen_words, 0ull);
-            std::vector<int> fill(pstart.begin(), pstart.end() - 1);
-            for (int o = 0; o < P.n_obs; ++o)
+            if (!valid[(size_t)o]) continue;
+            const int i = P.obs_img[o], p = P.obs_pt[o];
+            const int sl = fill[(size_t)p]++;
+            const int c  = cidx[i];
+            if (c >= 0 && seen_words)
             {
-                if (!valid[(size_t)o]) continue;
-                const int i = P.obs_img[o], p = P.obs_pt[o];
-                const int s = fill[(size_t)p]++;
-                const int c = cidx[(size_t)i];
-                if (c >= 0 && seen_words)
-                {
-                    const unsigned long long bit = 1ull << (c & 63);
-                    unsigned long long& word     = seen[(size_t)p * (size_t)seen_words + (size_t)(c >> 6)];
-                    if (word & bit) dev_entries_ok = false;
-                    word |= bit;
-                }
-                q_img[s]  = i;
-                q_cam[s]  = c;
-                q_free[s] = P.pt_const[p] ? 0 : 1;
-                q_uv[2 * s]     = P.obs_uv[o][0];
-                q_uv[2 * s + 1] = P.obs_uv[o][1];
-                q_d[s]    = P.obs_depth[o];
-                q_w[s]    = P.obs_weight[o];
-                q_orig[s] = orig_off + o;
-                q_pt[s]   = p;
+                const unsigned long long bit = 1ull << (c & 63);
+                unsigned long long& word     = seen[(size_t)p * (size_t)seen_words + (size_t)(c >> 6)];
+                if (word & bit) q.dup = 1;
+                word |= bit;
             }
+            q_img[sl]  = i;
+            q_cam[sl]  = c;
+            q_free[sl] = P.pt_const[p] ? 0 : 1;
+            q_uv[2 * sl]     = P.obs_uv[o][0];
+            q_uv[2 * sl + 1] = P.obs_uv[o][1];
+            q_d[sl]    = P.obs_depth[o];
+            q_w[sl]    = P.obs_weight[o];
+            q_orig[sl] = q.orig_at + o;
+            q_pt[sl]   = p;
         }
-        mark(1);
-        // point_wave work items: consecutive whole points with <= 64 observations in total
-        pr.wv_off = (int)wvpt.size();
-        pr.n_wv   = 0;
-        {
-            bool ok = true;
-            std::vector<int> wv;
-            int p = 0;
-            while (p < P.n_pt && ok)
-            {
-                wv.push_back(p);
-                int n = 0, q = p;
-                while (q < P.n_pt && q - p < 64 && n + (pstart[(size_t)q + 1] - pstart[(size_t)q]) <= 64)
-                {
-                    n += pstart[(size_t)q + 1] - pstart[(size_t)q];
-                    ++q;
-                }
-                if (q == p) ok = false;  // a point with more than 64 observations: point_pass handles the problem
-                p = q;
-            }
-            if (ok)
-            {
-                wv.push_back(P.n_pt);
-                pr.n_wv = (int)wv.size() - 1;
-                wvpt.insert(wvpt.end(), wv.begin(), wv.end());
-                max_wv = std::max(max_wv, pr.n_wv);
-            }
-            else
-                wave_ok = false;
-        }
-        mark(2);
+    });
+    mark(0);
+    mark(1);
+    // ---- pass 3: the camera lists and the point-major lists of every problem, built with PROBLEM-LOCAL offsets on the host threads; the
+    // per-problem loop below appends them to the shared lists and relocates the offsets (positions in setpts / setpairs / cblkitems / ccitems,
+    // partial-sum, camera-partial and record indices) by the running totals -- the same lists the serial builder wrote ----
+    struct Built
+    {
+        std::vector<int> camstart, camitems;
+        int be_nch          = 0;
+        long long ent_bound = 0;
+        bool ok = false, cam_sums_bad = false;
+        std::vector<SetItem> items;
+        std::vector<int2> ipts;
+        std::vector<int> ipairs;
+        int parts = 0, cparts = 0;
+        long long recs = 0;
+        int max_pairs = 0, max_run = 0, max_k = 0;
+        std::vector<int> cblkstart, cblkitems, ccstart, ccitems;
+    };
+    std::vector<Built> built((size_t)count);
+    parallel_for([&](int b)
+    {
+        const snk_ba_problem& P = problems[b];
+        const PreProb& pq       = pre[(size_t)b];
+        Built& B                = built[(size_t)b];
+        const int nfc = pq.nfc, no = pq.no;
+        const int* const pstart = ptstart.data() + pq.ps_at;
+        const int* const s_cam  = ocam.data() + pq.obs_at;
         // camera lists
-        pr.camstart_off = (int)camstart.size();
-        pr.citem_off    = (int)camitems.size();
         {
             std::vector<int> cs((size_t)nfc + 1, 0);
             for (int s = 0; s < no; ++s)
@@ -3769,15 +3826,14 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             std::vector<int> fill(cs.begin(), cs.end() - 1);
             for (int s = 0; s < no; ++s)
                 if (s_cam[(size_t)s] >= 0) items[(size_t)fill[(size_t)s_cam[(size_t)s]]++] = s;
-            camstart.insert(camstart.end(), cs.begin(), cs.end());
-            camitems.insert(camitems.end(), items.begin(), items.end());
-            max_citems = std::max(max_citems, (int)items.size());
+            B.camstart.assign(cs.begin(), cs.end());
+            B.camitems.swap(items);
+            
             int longest = 0;
             for (int c = 0; c < nfc; ++c) longest = std::max(longest, cs[(size_t)c + 1] - cs[(size_t)c]);
-            pr.be_nch = ceil_div(longest, 64);
+            B.be_nch = ceil_div(longest, 64);
             // (the same list as static records -- what cam_pass streams -- is gathered on the device: gather_cam_records)
         }
-        if (nfc > BE_MAX_CAMS) dev_entries_ok = false;
         {
             // room for the block entries when the device builds them: every pair of a point's run is the most there can be
             long long bound = 0;
@@ -3786,17 +3842,10 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                 const long long run = pstart[(size_t)p + 1] - pstart[(size_t)p];
                 bound += run * run;
             }
-            ent_bound[(size_t)b] = bound;
+            B.ent_bound = bound;
         }
-        pr.blkstart_off = blkstart_total;
-        blkstart_total += nfc * nfc + 1;
-        mark(3);
-        mark(4);
         // point-major Schur pass: points grouped by camera set, work items of <= SET_CHUNK points, per-block lists of
         // the partial sums they produce
-        pr.set_off  = (int)setitems.size();
-        pr.cblk_off = (int)cblkstart.size();
-        pr.n_set    = 0;
         {
             const size_t nb = (size_t)nfc * nfc;
             // camera set -> group: a hash of the signature finds the candidate, the stored signature confirms it (a std::map keyed by
@@ -3841,7 +3890,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                 if (P.pt_const[p])
                 {
                     for (int a = a0; a < a1; ++a)
-                        if (s_cam[(size_t)a] >= 0) cam_sums_ok = false;
+                        if (s_cam[(size_t)a] >= 0) B.cam_sums_bad = true;
                     plain_group(p, a1 - a0);
                     continue;
                 }
@@ -3864,22 +3913,21 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                 if (k > SET_MAX_K || a1 - a0 > SET_MAX_RUN) ok = false;
                 gpts[(size_t)find_group(sig)].push_back(p);
             }
-            mark(8);
             std::vector<std::vector<int>> contrib(nb);
             std::vector<std::vector<int>> ccontrib((size_t)nfc);  // per free camera: its partial sums in cam_part
-            int cparts = n_cparts;
-            long long recs = n_setrec;  // static observation records of the work items (gathered on the device: gather_set_records)
+            int cparts = 0;
+            long long recs = 0;  // static observation records of the work items (gathered on the device: gather_set_records)
             std::vector<SetItem> items;
             std::vector<int2> ipts;
             std::vector<int> ipairs;
-            int parts = n_partials;
+            int parts = 0;
             if (ok)
             {
                 // groups in order of their first point (std::map order would do as well: any fixed order)
                 for (size_t g = 0; g < gpts.size(); ++g)
                 {
                     const std::vector<int>& sig = gsig[g];
-                    const int pair_off = (int)(setpairs.size() + ipairs.size());
+                    const int pair_off = (int)((size_t)0 + ipairs.size());
                     std::vector<int> blocks;
                     for (size_t i = 0; i < sig.size(); ++i)
                         for (size_t j = i; j < sig.size(); ++j)
@@ -3893,7 +3941,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                     const int npairs = (int)blocks.size();
                     // matrix-core form (schur_mfma): the point's free rows ordered by camera index, so that every pair
                     // (ra, rb) -- camera(ra) < camera(rb) -- lies in the upper triangle of Y W^T, and the slot of each
-                    const int aux_off = (int)(setpairs.size() + ipairs.size());
+                    const int aux_off = (int)((size_t)0 + ipairs.size());
                     std::vector<int> fcams;  // the set's free cameras in ascending order (= the order of the k run positions)
                     {
                         std::vector<int> fpos;
@@ -3909,10 +3957,10 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                                 int slot = -1;
                                 if (i <= j)
                                     for (int q = 0; q < npairs; ++q)
-                                        if (ipairs[(size_t)(pair_off - (int)setpairs.size()) + (size_t)q] == (fpos[(size_t)i] | (fpos[(size_t)j] << 8))) slot = q;
+                                        if (ipairs[(size_t)(pair_off - (int)(size_t)0) + (size_t)q] == (fpos[(size_t)i] | (fpos[(size_t)j] << 8))) slot = q;
                                 ipairs.push_back(slot);
                             }
-                        max_set_k = std::max(max_set_k, kf);
+                        B.max_k = std::max(B.max_k, kf);
                     }
                     const size_t chunk    = big_items ? SET_CHUNK_BIG : SET_CHUNK;
                     const size_t n_in_set = gpts[g].size(), n_cuts = (n_in_set + chunk - 1) / chunk;
@@ -3925,7 +3973,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                     for (size_t q0 = 0; q0 < n_in_set; q0 += cut)
                     {
                         SetItem si;
-                        si.pts_off  = (int)(setpts.size() + ipts.size());
+                        si.pts_off  = (int)((size_t)0 + ipts.size());
                         si.n_pts    = (int)std::min<size_t>(cut, n_in_set - q0);
                         si.pair_off = pair_off;
                         si.npairs   = npairs;
@@ -3948,53 +3996,178 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                         for (int q = 0; q < npairs; ++q) contrib[(size_t)blocks[(size_t)q]].push_back(parts + q);
                         parts += npairs;
                         items.push_back(si);
-                        max_set_pairs = std::max(max_set_pairs, npairs);
-                        max_set_run   = std::max(max_set_run, si.run);
+                        B.max_pairs = std::max(B.max_pairs, npairs);
+                        B.max_run   = std::max(B.max_run, si.run);
                     }
                 }
             }
-            mark(9);
-            pr.ccam_off = (int)ccstart.size();
             {
-                int crun = (int)ccitems.size();
+                int crun = 0;
                 for (int c = 0; c < nfc; ++c)
                 {
-                    ccstart.push_back(crun);
+                    B.ccstart.push_back(crun);
                     if (ok)
                     {
-                        ccitems.insert(ccitems.end(), ccontrib[(size_t)c].begin(), ccontrib[(size_t)c].end());
+                        B.ccitems.insert(B.ccitems.end(), ccontrib[(size_t)c].begin(), ccontrib[(size_t)c].end());
                         crun += (int)ccontrib[(size_t)c].size();
                     }
                 }
-                ccstart.push_back(crun);
+                B.ccstart.push_back(crun);
             }
+            B.ok = ok;
             if (ok)
             {
-                pr.n_set   = (int)items.size();
-                n_partials = parts;
-                n_cparts   = cparts;
-                n_setrec   = recs;
-                setitems.insert(setitems.end(), items.begin(), items.end());
-                setpts.insert(setpts.end(), ipts.begin(), ipts.end());
-                setpairs.insert(setpairs.end(), ipairs.begin(), ipairs.end());
-                max_set_items = std::max(max_set_items, pr.n_set);
+                B.items.swap(items);
+                B.ipts.swap(ipts);
+                B.ipairs.swap(ipairs);
+                B.parts  = parts;
+                B.cparts = cparts;
+                B.recs   = recs;
             }
-            else
-                set_ok = false;
-            int run = (int)cblkitems.size();
-            const size_t cb_at = cblkstart.size();
-            cblkstart.resize(cb_at + nb + 1);
-            int* cb = cblkstart.data() + cb_at;
+            int run = 0;
+            B.cblkstart.resize(nb + 1);
+            int* cb = B.cblkstart.data();
             for (size_t k = 0; k < nb; ++k)
             {
                 cb[k] = run;
                 if (ok && !contrib[k].empty())
                 {
-                    cblkitems.insert(cblkitems.end(), contrib[k].begin(), contrib[k].end());
+                    B.cblkitems.insert(B.cblkitems.end(), contrib[k].begin(), contrib[k].end());
                     run += (int)contrib[k].size();
                 }
             }
             cb[nb] = run;
+        }
+    });
+    mark(3);
+    for (int b = 0; b < count; ++b)
+    {
+        const snk_ba_problem& P = problems[b];
+        mark(7);
+        SNK_REQUIRE(P.n_img >= 0 && P.n_pt >= 0 && P.n_obs >= 0, "negative problem size");
+        SNK_REQUIRE(P.n_img == 0 || (P.pose && P.img_const), "NULL pose arrays");
+        SNK_REQUIRE(P.n_pt == 0 || (P.pt && P.pt_const), "NULL point arrays");
+        SNK_REQUIRE(P.n_obs == 0 || (P.obs_img && P.obs_pt && P.obs_uv && P.obs_depth && P.obs_weight), "NULL observation arrays");
+        SNK_REQUIRE(P.n_rpc >= 0 && (P.n_rpc == 0 || P.rpc != nullptr), "bad relative pose constraints");
+        Prob& pr = probs[(size_t)b];
+        memset(&pr, 0, sizeof(pr));
+        pr.ni = P.n_img;
+        pr.np = P.n_pt;
+        for (int k = 0; k < 4; ++k) pr.K[k] = P.K[k];
+        pr.bf       = P.bf;
+        pr.img_off  = img_off;
+        pr.pt_off   = pt_off;
+        pr.obs_off  = obs_off;
+        pr.cam_off  = cam_off;
+        pr.orig_off = orig_off;
+        pr.vec_off  = vec_off;
+        pr.s_off    = s_off;
+        h->orig_off[(size_t)b] = orig_off;
+        h->orig_n[(size_t)b]   = P.n_obs;
+        // values, free-camera indices, counting sort and the sorted observation arrays: written by the fill pass above
+        const PreProb& pq = pre[(size_t)b];
+        const int nfc     = pq.nfc;
+        const int* const cidx = camidx.data() + pq.img_at;
+        pr.nfc = nfc;
+        pr.n6  = 6 * nfc;
+        const int* const pstart = ptstart.data() + pq.ps_at;
+        const int no = pq.no;
+        pr.no        = no;
+        pr.ptstart_off = (int)pq.ps_at;
+        const size_t obs_at = pq.obs_at;
+        const int* const s_cam = ocam.data() + obs_at;   // free-camera index of sorted observation s
+        if (pq.dup) dev_entries_ok = false;
+        // point_wave work items: consecutive whole points with <= 64 observations in total
+        pr.wv_off = (int)wvpt.size();
+        pr.n_wv   = 0;
+        {
+            bool ok = true;
+            std::vector<int> wv;
+            int p = 0;
+            while (p < P.n_pt && ok)
+            {
+                wv.push_back(p);
+                int n = 0, q = p;
+                while (q < P.n_pt && q - p < 64 && n + (pstart[(size_t)q + 1] - pstart[(size_t)q]) <= 64)
+                {
+                    n += pstart[(size_t)q + 1] - pstart[(size_t)q];
+                    ++q;
+                }
+                if (q == p) ok = false;  // a point with more than 64 observations: point_pass handles the problem
+                p = q;
+            }
+            if (ok)
+            {
+                wv.push_back(P.n_pt);
+                pr.n_wv = (int)wv.size() - 1;
+                wvpt.insert(wvpt.end(), wv.begin(), wv.end());
+                max_wv = std::max(max_wv, pr.n_wv);
+            }
+            else
+                wave_ok = false;
+        }
+        mark(2);
+        // camera lists (built in pass 3; positions and items are problem-local: appended as they are)
+        pr.camstart_off = (int)camstart.size();
+        pr.citem_off    = (int)camitems.size();
+        const Built& B  = built[(size_t)b];
+        camstart.insert(camstart.end(), B.camstart.begin(), B.camstart.end());
+        camitems.insert(camitems.end(), B.camitems.begin(), B.camitems.end());
+        max_citems = std::max(max_citems, (int)B.camitems.size());
+        pr.be_nch  = B.be_nch;
+        if (nfc > BE_MAX_CAMS) dev_entries_ok = false;
+        ent_bound[(size_t)b] = B.ent_bound;
+        pr.blkstart_off = blkstart_total;
+        blkstart_total += nfc * nfc + 1;
+        mark(3);
+        mark(4);
+        // point-major Schur pass (built in pass 3 with problem-local offsets): append, relocating by the running totals
+        pr.set_off  = (int)setitems.size();
+        pr.cblk_off = (int)cblkstart.size();
+        pr.n_set    = 0;
+        {
+            if (B.cam_sums_bad) cam_sums_ok = false;
+            max_set_k     = std::max(max_set_k, B.max_k);
+            max_set_pairs = std::max(max_set_pairs, B.max_pairs);
+            max_set_run   = std::max(max_set_run, B.max_run);
+            pr.ccam_off = (int)ccstart.size();
+            {
+                const int base_cc = (int)ccitems.size();
+                for (int v : B.ccstart) ccstart.push_back(v + base_cc);
+                for (int v : B.ccitems) ccitems.push_back(v + n_cparts);
+            }
+            if (B.ok)
+            {
+                SNK_REQUIRE(n_setrec + B.recs < (1ll << 31) && (long long)n_partials + B.parts < (1ll << 31), "scene list too large (work-item records)");
+                const int base_pts = (int)setpts.size(), base_pairs = (int)setpairs.size();
+                for (SetItem si : B.items)
+                {
+                    si.pts_off += base_pts;
+                    si.pair_off += base_pairs;
+                    si.aux_off += base_pairs;
+                    si.part_off += n_partials;
+                    si.cpart_off += n_cparts;
+                    si.rec_off += (int)n_setrec;
+                    setitems.push_back(si);
+                }
+                setpts.insert(setpts.end(), B.ipts.begin(), B.ipts.end());
+                setpairs.insert(setpairs.end(), B.ipairs.begin(), B.ipairs.end());
+                pr.n_set      = (int)B.items.size();
+                max_set_items = std::max(max_set_items, pr.n_set);
+            }
+            else
+                set_ok = false;
+            {
+                const int base_cb = (int)cblkitems.size();
+                for (int v : B.cblkstart) cblkstart.push_back(v + base_cb);
+                for (int v : B.cblkitems) cblkitems.push_back(v + n_partials);
+            }
+            if (B.ok)
+            {
+                n_partials += B.parts;
+                n_cparts += B.cparts;
+                n_setrec += B.recs;
+            }
         }
         mark(5);
         // relative pose constraints (IMU scenes): valid ones, per-camera incidence, per-block chains
