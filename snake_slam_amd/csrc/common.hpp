@@ -168,8 +168,14 @@ inline int ceil_div(int a, int b)
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov64(double v)
 {
+#if defined(SNK_DPP_OLD_INIT)  // A/B: the first form -- `old` = 0 without bound_ctrl costs a v_mov per half and step to initialise the destination
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+#else
+    // every lane of these controls (quad_perm, row_mirror, row_half_mirror) has a valid source lane: no `old` value is needed
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+#endif
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double readlane64(double v, int l)

@@ -4,10 +4,9 @@
 // the reference calls (Saiga::RobustPoseOptimization::optimizePoseRobust, absent submodule) is
 // [DEFINED] in DESIGN.md §3c and restated on the CPU in oracle/pose_oracle.c.
 //
-// One WAVEFRONT per frame (problem): a lane owns matches lane, lane + 64, ...; each damped
-// Gauss-Newton iteration accumulates the 21 + 6 entries of J^T W J / J^T W r per lane, sums them
-// over the wavefront in a fixed butterfly order (deterministic), and every lane solves the same 6x6
-// system.  No LDS, no workgroup barriers; problems of a batch run side by side.
+// One workgroup of one or four WAVEFRONTS per frame (problem): a thread owns matches t, t + threads, ...; each damped
+// Gauss-Newton iteration accumulates the 21 + 6 entries of J^T W J / J^T W r per thread, sums them in a fixed order
+// (deterministic), and one wavefront solves the 6x6 system.  Problems of a batch run side by side.
 #include <cmath>
 
 #include "matcher_handle.hpp"
@@ -17,6 +16,7 @@ namespace snk
 namespace
 {
 typedef unsigned char u8;
+typedef unsigned int u32;
 
 struct PoseMeta
 {
@@ -40,13 +40,62 @@ __device__ __forceinline__ void quat_to_R(const double* q, double* R)
     R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
 }
 
+// 1 / z and 1 / sqrt(s) from the hardware approximations plus two Newton steps each (5 / 8 instructions; the IEEE division and
+// square root the compiler expands to are 14 - 18 each and a match needs three of them per Gauss-Newton step).  Within an ulp or
+// two of the correctly rounded values for the magnitudes that occur (depths in metres, squared pixel errors); "snk-pose v1" is
+// specified by a tolerance on the refined pose, not bit for bit.
+__device__ __forceinline__ double rcp_nr(double z)
+{
+    double y = __builtin_amdgcn_rcp(z);
+    y        = fma(y, fma(-z, y, 1.0), y);
+    return fma(y, fma(-z, y, 1.0), y);
+}
+__device__ __forceinline__ double rsqrt_nr(double s)
+{
+    const double hs = 0.5 * s;
+    double y        = __builtin_amdgcn_rsq(s);
+    y               = fma(y, fma(-hs * y, y, 0.5), y);
+    return fma(y, fma(-hs * y, y, 0.5), y);
+}
+
+// sin and cos of a half angle |x| <= pi / 4 by their Taylor series (terms to x^17 / x^16: truncation below 1e-19 relative);
+// larger arguments -- a Gauss-Newton step that turns the camera by more than 90 degrees -- take the library's sincos.  The
+// library call alone was ~150 of the ~860 instructions the solver wavefront runs per step while the others wait.
+__device__ __forceinline__ void sincos_half(double x, double* s, double* c)
+{
+    if (fabs(x) > 0.78539816339744831)
+    {
+        sincos(x, s, c);
+        return;
+    }
+    const double z = x * x;
+    double ps = -1.0 / 355687428096000.0;  // -1/17!
+    ps        = fma(ps, z, 1.0 / 1307674368000.0);
+    ps        = fma(ps, z, -1.0 / 6227020800.0);
+    ps        = fma(ps, z, 1.0 / 39916800.0);
+    ps        = fma(ps, z, -1.0 / 362880.0);
+    ps        = fma(ps, z, 1.0 / 5040.0);
+    ps        = fma(ps, z, -1.0 / 120.0);
+    ps        = fma(ps, z, 1.0 / 6.0);
+    *s        = fma(-x * z, ps, x);
+    double pc = 1.0 / 20922789888000.0;  // 1/16!
+    pc        = fma(pc, z, -1.0 / 87178291200.0);
+    pc        = fma(pc, z, 1.0 / 479001600.0);
+    pc        = fma(pc, z, -1.0 / 3628800.0);
+    pc        = fma(pc, z, 1.0 / 40320.0);
+    pc        = fma(pc, z, -1.0 / 720.0);
+    pc        = fma(pc, z, 1.0 / 24.0);
+    pc        = fma(pc, z, -0.5);
+    *c        = fma(z, pc, 1.0);
+}
+
 // pose <- exp(delta) * pose, delta = (translation, rotation)
 __device__ void se3_update(double* pose, const double* d)
 {
     const double wx = d[3], wy = d[4], wz = d[5];
-    const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
+    const double th2 = wx * wx + wy * wy + wz * wz;
     double B, Cc, qd[4];
-    if (th < 1e-8)
+    if (th2 < 1e-16)
     {
         B  = 0.5 - th2 / 24.0;
         Cc = 1.0 / 6.0 - th2 / 120.0;
@@ -55,13 +104,16 @@ __device__ void se3_update(double* pose, const double* d)
     }
     else
     {
-        // one sincos of the half angle (the four libm calls of the textbook form were a fifth of a Gauss-Newton step)
+        // one sincos of the half angle (the four libm calls of the textbook form were a fifth of a Gauss-Newton step); 1 / th from
+        // the reciprocal square root instead of a square root and three divisions
+        const double ith = rsqrt_nr(th2), th = th2 * ith;
         double s2, c2;
-        sincos(0.5 * th, &s2, &c2);
+        sincos_half(0.5 * th, &s2, &c2);
         const double s = 2.0 * s2 * c2, c = 1.0 - 2.0 * s2 * s2;
-        B  = (1.0 - c) / th2;
-        Cc = (th - s) / (th2 * th);
-        const double sh = s2 / th;
+        const double ith2 = ith * ith;
+        B  = (1.0 - c) * ith2;
+        Cc = (th - s) * (ith2 * ith);
+        const double sh = s2 * ith;
         qd[0] = sh * wx; qd[1] = sh * wy; qd[2] = sh * wz; qd[3] = c2;
     }
     const double vx = d[0], vy = d[1], vz = d[2];
@@ -77,8 +129,8 @@ __device__ void se3_update(double* pose, const double* d)
     q[1] = aw * by - ax * bz + ay * bw + az * bx;
     q[2] = aw * bz + ax * by - ay * bx + az * bw;
     q[3] = aw * bw - ax * bx - ay * by - az * bz;
-    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    pose[0] = q[0] / n; pose[1] = q[1] / n; pose[2] = q[2] / n; pose[3] = q[3] / n;
+    const double rn = rsqrt_nr(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    pose[0] = q[0] * rn; pose[1] = q[1] * rn; pose[2] = q[2] * rn; pose[3] = q[3] * rn;
     pose[4] = Rd[0] * tx + Rd[1] * ty + Rd[2] * tz + tdx;
     pose[5] = Rd[3] * tx + Rd[4] * ty + Rd[5] * tz + tdy;
     pose[6] = Rd[6] * tx + Rd[7] * ty + Rd[8] * tz + tdz;
@@ -127,40 +179,40 @@ __device__ void se3_log_rel(const double* pose, const double* pred, double* e)
     e[3] = wx; e[4] = wy; e[5] = wz;
 }
 
-// residual (dim 2 / 3) and its 6 derivatives per row; 0 when the point is not in front of the camera
-__device__ __forceinline__ int linearize(const double* R, const double* t, const double* p, const CamD& cam,
-                                         const snk_pose_obs& o, double* r, double* J)
+// One match as the kernel walks it: world point, observation, od = x - bf / depth (the right-image column the stereo residual
+// compares with; NaN marks a monocular observation -- computed once per solve, not in each of the 40 steps) and the weight.
+struct Match
 {
-    const double X = R[0] * p[0] + R[1] * p[1] + R[2] * p[2] + t[0];
-    const double Y = R[3] * p[0] + R[4] * p[1] + R[5] * p[2] + t[1];
-    const double Z = R[6] * p[0] + R[7] * p[1] + R[8] * p[2] + t[2];
-    if (Z <= 0.0) return 0;
-    const double iz = 1.0 / Z, iz2 = iz * iz, w = o.weight;
-    const int dim = o.depth > 0.0 ? 3 : 2;
-    double P[9];
-    r[0] = w * (cam.fx * X * iz + cam.cx - o.x);
-    r[1] = w * (cam.fy * Y * iz + cam.cy - o.y);
-    P[0] = cam.fx * iz; P[1] = 0.0;         P[2] = -cam.fx * X * iz2;
-    P[3] = 0.0;         P[4] = cam.fy * iz; P[5] = -cam.fy * Y * iz2;
-    r[2] = 0.0;
-    P[6] = P[7] = P[8] = 0.0;
-    if (dim == 3)
-    {
-        r[2] = w * ((cam.fx * X * iz + cam.cx - cam.bf * iz) - (o.x - cam.bf / o.depth));
-        P[6] = cam.fx * iz; P[8] = -cam.fx * X * iz2 + cam.bf * iz2;
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-    {
-        const double a = w * P[3 * k], b = w * P[3 * k + 1], c = w * P[3 * k + 2];
-        J[6 * k + 0] = a;
-        J[6 * k + 1] = b;
-        J[6 * k + 2] = c;
-        J[6 * k + 3] = -b * Z + c * Y;
-        J[6 * k + 4] = a * Z - c * X;
-        J[6 * k + 5] = -a * Y + b * X;
-    }
-    return dim;
+    double px, py, pz, ox, oy, od, w;
+};
+__device__ __forceinline__ Match make_match(const double* p, const snk_pose_obs& o, const CamD& cam)
+{
+    return Match{p[0], p[1], p[2], o.x, o.y, o.depth > 0.0 ? o.x - cam.bf / o.depth : __builtin_nan(""), o.weight};
+}
+
+// The weighted residual (r[2] = 0 for a monocular observation) of a match under (R, t); false when the point is not in front of
+// the camera.  X, Y, Z = the point in the camera frame, iz = 1 / Z, pu = projected column.
+struct Proj
+{
+    double X, Y, Z, iz, xz, yz, r0, r1, r2;
+    bool stereo;
+};
+__device__ __forceinline__ bool project(const double* R, const double* t, const Match& m, const CamD& cam, Proj& q)
+{
+    q.X = R[0] * m.px + R[1] * m.py + R[2] * m.pz + t[0];
+    q.Y = R[3] * m.px + R[4] * m.py + R[5] * m.pz + t[1];
+    q.Z = R[6] * m.px + R[7] * m.py + R[8] * m.pz + t[2];
+    if (q.Z <= 0.0) return false;
+    q.iz     = rcp_nr(q.Z);
+    q.xz     = q.X * q.iz;
+    q.yz     = q.Y * q.iz;
+    q.stereo = m.od == m.od;
+    const double pu = cam.fx * q.xz + cam.cx;
+    q.r0     = m.w * (pu - m.ox);
+    q.r1     = m.w * (cam.fy * q.yz + cam.cy - m.oy);
+    const double r2 = m.w * ((pu - cam.bf * q.iz) - m.od);
+    q.r2     = q.stereo ? r2 : 0.0;
+    return true;
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -191,8 +243,8 @@ __device__ int chol_solve6(const double* A, const double* b, double* x)
             if (i == j)
             {
                 if (!(s > 0.0)) return -1;
-                L[i * 6 + i] = sqrt(s);
-                inv[i]       = 1.0 / L[i * 6 + i];  // one division per pivot; the 27 others of the textbook form become products
+                inv[i]       = rsqrt_nr(s);  // 1 / L_ii directly (8 instructions; sqrt + division are 34), L_ii = s / L_ii
+                L[i * 6 + i] = s * inv[i];
             }
             else
                 L[i * 6 + j] = s * inv[j];
@@ -221,29 +273,41 @@ __device__ int chol_solve6(const double* A, const double* b, double* x)
 // lanes with four DPP steps (no LDS, no read-back), the 4 * WAVES row sums of every quantity meet in LDS, 27 threads add them in
 // a fixed order and everybody reads the totals: two barriers per step.  (The first form ran a six-step __shfl_xor tree per
 // quantity -- 324 ds_bpermute round trips per wavefront and step -- and let every thread add all WAVES partials of all 27.)
-// PPT > 0: the frame's matches are held in registers (at most PPT per thread, n <= PPT * 64 * WAVES), read once instead of in
-// each of the 40 steps; PPT = 0: any n, matches re-read per step.  One wavefront per frame is right for a few dozen matches;
-// with the ~770 - 1500 matches of a tracking pass, 16 wavefronts with two matches per thread are (0.43 -> 0.2x ms per 256 frames).
-#ifndef SNK_POSE_NO_UNROLL
-#define SNK_POSE_NO_UNROLL 0
-#endif
+// Matches are re-read in every step (from the LDS copy where LDSM says so); which of a thread's matches are outliers lives in a
+// register (bit k = the thread's k-th match; from the 33rd on in the `outlier` array itself).  One wavefront per frame is right
+// for a few dozen matches; with the ~770 - 1500 matches of a tracking pass, four wavefronts are (0.43 -> 0.2x ms per 256 frames).
+//
+// Round 4 -- the normal equations from the structure of the Jacobian instead of row by row.  A row of the 3 x 6 Jacobian is
+// (a, b, c) [I | G] with G = -[p]x, p = the point in the camera frame, and (a, b, c) = a row of w P, P the 3 x 3 projection
+// Jacobian with the zero pattern (x 0 x; 0 x x; x 0 x).  So with A = wgt P^T P (five distinct non-zero entries) and g = wgt P^T r
+//   H += [A, A G; (A G)^T, G^T A G],   b += [g; G^T g]
+// costs 70 multiply-adds per match against the 117 of three rank-one updates (a fifth of those were products with the structural
+// zeros, which the compiler must keep without fast-math).
 #ifndef SNK_POSE_STUB_SOLVE
 #define SNK_POSE_STUB_SOLVE 0
 #endif
 #ifndef SNK_POSE_MIN_WAVES
-#define SNK_POSE_MIN_WAVES 1
+#define SNK_POSE_MIN_WAVES 2  // two wavefronts per SIMD (<= 256 registers incl. accumulation registers): without the bound the allocator has gone to 254 + 6 = one wavefront
 #endif
-template <int WAVES, int PPT, bool LDSM>
+#ifndef SNK_POSE_RED_STEPS  // DPP steps of the 27 sums before they meet in LDS: 4 = rows of 16 lanes, 2 = quads (see the kernel)
+#define SNK_POSE_RED_STEPS 2
+#endif
+constexpr int POSE_SLOTS_PER_WAVE = 64 >> SNK_POSE_RED_STEPS;
+template <int WAVES, bool LDSM>
 __global__ __launch_bounds__(64 * WAVES, SNK_POSE_MIN_WAVES) void pose_kernel(const PoseMeta* __restrict__ meta, const double* __restrict__ wps,
                                                           const snk_pose_obs* __restrict__ obs, u8* __restrict__ outlier,
                                                           double* __restrict__ pose_out, int* __restrict__ inliers_out, CamD cam,
                                                           snk_pose_options opt, int lds_matches)
 {
     constexpr int STRIDE = 64 * WAVES;
-    constexpr int NP     = PPT > 0 ? PPT : 1;
-    __shared__ double s_part[WAVES * 4][28];
+    constexpr int SLOTS = WAVES * POSE_SLOTS_PER_WAVE;
+    __shared__ double s_part[SLOTS][28];
     __shared__ double s_tot[28];
     const int lane    = threadIdx.x;  // thread of the frame's workgroup
+    // the first wavefront solves the 6 x 6 system of a step (see below; giving the job to a different wavefront in every other
+    // workgroup, so that the solves of two frames of a compute unit land on different SIMDs, measured nothing: r04w4)
+    const bool is_solver = lane < 64;
+    const int slane   = lane & 63;
     const PoseMeta& M = meta[blockIdx.x];
     const int n       = M.n;
     const double* W   = wps + 3 * (long long)M.off;
@@ -252,57 +316,34 @@ __global__ __launch_bounds__(64 * WAVES, SNK_POSE_MIN_WAVES) void pose_kernel(co
     double pose[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) pose[i] = M.pose[i];
-    // register-resident matches (PPT > 0)
-    double pw[NP][3];
-    snk_pose_obs po[NP];
-    bool have[NP], bad[NP];
-#pragma unroll
-    for (int k = 0; k < NP; ++k)
-    {
-        const int i = lane + k * STRIDE;
-        have[k]     = PPT > 0 && i < n;
-        bad[k]      = false;
-        pw[k][0] = pw[k][1] = pw[k][2] = 0.0;
-        po[k] = snk_pose_obs{0.0, 0.0, 0.0, 0.0};
-        if (have[k])
-        {
-            pw[k][0] = W[3 * i], pw[k][1] = W[3 * i + 1], pw[k][2] = W[3 * i + 2];
-            po[k] = O[i];
-        }
-    }
-    // LDSM: the frame's matches (world point + observation, 56 bytes each) are copied to LDS once; the 40 steps then read them
-    // with LDS latency instead of a global-memory round trip per match and step (one wavefront per SIMD hides nothing)
-    // The LDS carve holds the first `lds_matches` matches of the frame (the launch sizes it so that several frames share a compute
-    // unit: a frame's 40 steps are a chain of latencies, and with one workgroup per CU every SIMD holds ONE wavefront); matches
-    // beyond it -- a frame with more matches than the usual half of its local map -- are read from global memory, same values.
+    // LDSM: the frame's matches (56 bytes each, see Match) are copied to LDS once; the 40 steps then read them with LDS latency
+    // instead of a global-memory round trip per match and step (two wavefronts per SIMD hide nothing).  The LDS carve holds the
+    // first `lds_matches` matches of the frame (sized by the launch so that the frames a compute unit's registers admit also fit
+    // its LDS); matches beyond it -- a frame with more matches than usual -- are read from global memory, same values.
     extern __shared__ __attribute__((aligned(16))) double s_match[];
     const int nl = LDSM ? min(n, lds_matches) : 0;
-    double* s_w = s_match;           // [3 nl]
-    double* s_o = s_match + 3 * nl;  // [4 nl]
-    if (PPT == 0)
+    for (int i = lane; i < n; i += STRIDE) out[i] = 0;
+    if (LDSM)
     {
-        for (int i = lane; i < n; i += STRIDE) out[i] = 0;
-        if (LDSM)
+        for (int i = lane; i < nl; i += STRIDE)
         {
-            for (int i = lane; i < 3 * nl; i += STRIDE) s_w[i] = W[i];
-            const double* Od = reinterpret_cast<const double*>(O);
-            for (int i = lane; i < 4 * nl; i += STRIDE) s_o[i] = Od[i];
+            const Match mt = make_match(W + 3 * i, O[i], cam);
+            double* d      = s_match + 7 * i;
+            d[0] = mt.px, d[1] = mt.py, d[2] = mt.pz, d[3] = mt.ox, d[4] = mt.oy, d[5] = mt.od, d[6] = mt.w;
         }
-        if (WAVES > 1 || LDSM) __syncthreads();
     }
-    auto fetch = [&](int i, double* p, snk_pose_obs& o)
+    if (WAVES > 1 || LDSM) __syncthreads();
+    auto fetch = [&](int i) -> Match
     {
         if (LDSM && i < nl)
         {
-            p[0] = s_w[3 * i], p[1] = s_w[3 * i + 1], p[2] = s_w[3 * i + 2];
-            o.x = s_o[4 * i], o.y = s_o[4 * i + 1], o.depth = s_o[4 * i + 2], o.weight = s_o[4 * i + 3];
+            const double* d = s_match + 7 * i;
+            return Match{d[0], d[1], d[2], d[3], d[4], d[5], d[6]};
         }
-        else
-        {
-            p[0] = W[3 * i], p[1] = W[3 * i + 1], p[2] = W[3 * i + 2];
-            o = O[i];
-        }
+        return make_match(W + 3 * i, O[i], cam);
     };
+    u32 badbits = 0;  // bit k: this thread's k-th match (lane + k * STRIDE) is an outlier, k < 32
+    auto is_bad = [&](int i, int k) -> bool { return k < 32 ? ((badbits >> k) & 1u) != 0 : out[i] != 0; };
 
     // sums of acc[0..CNT) over the workgroup, left in acc for every thread (CNT is a compile-time constant: acc stays in registers)
     auto reduce = [&](double* acc, auto cnt_c)
@@ -337,71 +378,100 @@ __global__ __launch_bounds__(64 * WAVES, SNK_POSE_MIN_WAVES) void pose_kernel(co
             for (int i = 0; i < 27; ++i) acc[i] = 0.0;
             double R[9];
             quat_to_R(pose, R);
-            auto add_match = [&](const double* p, const snk_pose_obs& o)
+            int k = 0;
+            for (int i = lane; i < n; i += STRIDE, ++k)
             {
-                double r[3], J[18];
-                const int dim = linearize(R, pose + 4, p, cam, o, r, J);
-                if (!dim) return;
-                const double s = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];  // r[2] = 0 for mono
+                if (is_bad(i, k)) continue;
+                const Match mt = fetch(i);
+                Proj q;
+                if (!project(R, pose + 4, mt, cam, q)) continue;
+                const double s = q.r0 * q.r0 + q.r1 * q.r1 + q.r2 * q.r2;
                 double wgt     = 1.0;
                 if (robust)
                 {
-                    const double d = dim == 3 ? opt.th_stereo : opt.th_mono;
-                    if (s > d * d) wgt = d / sqrt(s);
+                    const double d = q.stereo ? opt.th_stereo : opt.th_mono;
+                    if (s > d * d) wgt = d * rsqrt_nr(s);
                 }
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                {
-                    int u = 0;
-#pragma unroll
-                    for (int a = 0; a < 6; ++a)
-                    {
-                        const double ja = wgt * J[6 * k + a];
-                        acc[21 + a] += ja * r[k];
-#pragma unroll
-                        for (int c = a; c < 6; ++c) acc[u++] += ja * J[6 * k + c];
-                    }
-                }
-            };
-            if (PPT > 0)
-            {
-#pragma unroll
-                for (int k = 0; k < NP; ++k)
-                    if (have[k] && !bad[k]) add_match(pw[k], po[k]);
+                // rows of w P: (u, 0, c0), (0, v, c1), (a2, 0, c2) -- the third only for a stereo observation
+                const double wi = mt.w * q.iz;
+                const double u = cam.fx * wi, v = cam.fy * wi;
+                const double c0 = -(u * q.xz), c1 = -(v * q.yz);
+                const double a2 = q.stereo ? u : 0.0;
+                const double c2 = q.stereo ? c0 + cam.bf * wi * q.iz : 0.0;
+                const double wu = wgt * u, wv = wgt * v, wa2 = wgt * a2, wc0 = wgt * c0, wc1 = wgt * c1, wc2 = wgt * c2;
+                const double A00 = wu * u + wa2 * a2, A02 = wu * c0 + wa2 * c2, A11 = wv * v, A12 = wv * c1;
+                const double A22 = wc0 * c0 + wc1 * c1 + wc2 * c2;
+                const double g0 = wu * q.r0 + wa2 * q.r2, g1 = wv * q.r1, g2 = wc0 * q.r0 + wc1 * q.r1 + wc2 * q.r2;
+                const double X = q.X, Y = q.Y, Z = q.Z;
+                // M = A G (A01 = 0)
+                const double M00 = Y * A02, M01 = Z * A00 - X * A02, M02 = -(Y * A00);
+                const double M10 = Y * A12 - Z * A11, M11 = -(X * A12), M12 = X * A11;
+                const double M20 = Y * A22 - Z * A12, M21 = Z * A02 - X * A22, M22 = X * A12 - Y * A02;
+                acc[0] += A00;  // (0,1) gets nothing
+                acc[2] += A02;
+                acc[3] += M00, acc[4] += M01, acc[5] += M02;
+                acc[6] += A11;
+                acc[7] += A12;
+                acc[8] += M10, acc[9] += M11, acc[10] += M12;
+                acc[11] += A22;
+                acc[12] += M20, acc[13] += M21, acc[14] += M22;
+                // G^T M, upper triangle
+                acc[15] += Y * M20 - Z * M10;
+                acc[16] += Y * M21 - Z * M11;
+                acc[17] += Y * M22 - Z * M12;
+                acc[18] += Z * M01 - X * M21;
+                acc[19] += Z * M02 - X * M22;
+                acc[20] += X * M12 - Y * M02;
+                acc[21] += g0, acc[22] += g1, acc[23] += g2;
+                acc[24] += Y * g2 - Z * g1;
+                acc[25] += Z * g0 - X * g2;
+                acc[26] += X * g1 - Y * g0;
             }
-            else
-#if SNK_POSE_NO_UNROLL
-#pragma unroll 1
-#endif
-                for (int i = lane; i < n; i += STRIDE)
-                {
-                    if (out[i]) continue;
-                    double p[3];
-                    snk_pose_obs o;
-                    fetch(i, p, o);
-                    add_match(p, o);
-                }
             if (WAVES > 1)
             {
-                // The 6 x 6 solve and the pose update are the same numbers for every thread: only the FIRST wavefront runs them
+                // The 6 x 6 solve and the pose update are the same numbers for every thread: only ONE wavefront runs them
                 // (the others wait at the barrier and leave their SIMDs to the other frames of the compute unit -- with several
                 // frames per CU the redundant Cholesky, 6 square roots and 6 divisions in fp64, was a third of the kernel's vector
-                // instructions) and hands the new pose over through LDS.  Same arithmetic, same order: bit-identical poses.
+                // instructions) and hands the new pose over through LDS.
+#if SNK_POSE_RED_STEPS == 4
 #pragma unroll
                 for (int i = 0; i < 27; ++i) acc[i] = row_sum64_dpp(acc[i]);
                 if ((lane & 15) == 0)
 #pragma unroll
                     for (int i = 0; i < 27; ++i) s_part[lane >> 4][i] = acc[i];
                 __syncthreads();
-                if (lane < 64)
+                if (is_solver)
                 {
-                    if (lane < 27)
+                    if (slane < 27)
                     {
-                        double v = s_part[0][lane];
+                        double v = s_part[0][slane];
 #pragma unroll
-                        for (int w = 1; w < WAVES * 4; ++w) v += s_part[w][lane];
-                        s_tot[lane] = v;
+                        for (int w = 1; w < SLOTS; ++w) v += s_part[w][slane];
+                        s_tot[slane] = v;
                     }
+#else
+                // Two DPP steps (sums over quads) instead of four: every wavefront saves 27 x 2 x 3 instructions per step; the
+                // solver wavefront then adds SLOTS = 16 * WAVES partial sums per quantity instead of 4 * WAVES, two lanes per
+                // quantity (a few dozen LDS reads issued back to back on the one wavefront everybody waits for anyway)
+#pragma unroll
+                for (int i = 0; i < 27; ++i) acc[i] += dpp_mov64<0xB1>(acc[i]);
+#pragma unroll
+                for (int i = 0; i < 27; ++i) acc[i] += dpp_mov64<0x4E>(acc[i]);
+                if ((lane & 3) == 0)
+#pragma unroll
+                    for (int i = 0; i < 27; ++i) s_part[lane >> 2][i] = acc[i];
+                __syncthreads();
+                if (is_solver)
+                {
+                    {
+                        const int qn = min(slane >> 1, 26), half = slane & 1;
+                        double v = s_part[half * (SLOTS / 2)][qn];
+#pragma unroll
+                        for (int w = 1; w < SLOTS / 2; ++w) v += s_part[half * (SLOTS / 2) + w][qn];
+                        v += dpp_mov64<0xB1>(v);
+                        if (slane < 54 && half == 0) s_tot[qn] = v;
+                    }
+#endif
                     __builtin_amdgcn_wave_barrier();  // one wavefront: the LDS serves it in program order
 #pragma unroll
                     for (int i = 0; i < 27; ++i) acc[i] = s_tot[i];
@@ -412,7 +482,7 @@ __global__ __launch_bounds__(64 * WAVES, SNK_POSE_MIN_WAVES) void pose_kernel(co
 #pragma unroll
                 for (int i = 0; i < 27; ++i) acc[i] = wave_sum64_dpp(acc[i]);
             }
-            if (WAVES == 1 || lane < 64)
+            if (WAVES == 1 || is_solver)
             {
             double H[36], b[6];
             {
@@ -447,63 +517,50 @@ __global__ __launch_bounds__(64 * WAVES, SNK_POSE_MIN_WAVES) void pose_kernel(co
             double nb[6], d[6];
 #pragma unroll
             for (int a = 0; a < 6; ++a) nb[a] = -b[a];
-#if SNK_POSE_STUB_SOLVE == 1
+#if SNK_POSE_STUB_SOLVE == 1  // timing experiments only
             for (int a = 0; a < 6; ++a) d[a] = nb[a] / H[a * 6 + a];
             se3_update(pose, d);
 #elif SNK_POSE_STUB_SOLVE == 2
-            for (int a = 0; a < 6; ++a) pose[a] += nb[a] / H[a * 6 + a];
+            for (int a = 0; a < 6; ++a) pose[a + 1] += 1e-12 * nb[a] / H[a * 6 + a];
 #else
             if (chol_solve6(H, nb, d) == 0) se3_update(pose, d);
 #endif
             }
             if (WAVES > 1)
             {
-                if (lane == 0)
+                if (is_solver && slane == 0)
 #pragma unroll
                     for (int i = 0; i < 7; ++i) s_tot[i] = pose[i];  // s_tot's sums have been consumed (by this wavefront, in order)
                 __syncthreads();
 #pragma unroll
                 for (int i = 0; i < 7; ++i) pose[i] = s_tot[i];
-                // no third barrier: the next write of s_tot (lane < 27 of the first wavefront) comes after the next step's
-                // barrier, which every thread reaches only after these reads
+                // no third barrier: the next write of s_tot (the solver wavefront) comes after the next step's barrier, which every
+                // thread reaches only after these reads
             }
         }
         // re-classify every match
         double R[9];
         quat_to_R(pose, R);
-        int cnt = 0;
-        auto classify = [&](const double* p, const snk_pose_obs& o) -> bool
+        int cnt = 0, k = 0;
+        for (int i = lane; i < n; i += STRIDE, ++k)
         {
-            double r[3], J[18];
-            const int dim  = linearize(R, pose + 4, p, cam, o, r, J);
-            const double s = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
-            const double d = dim == 3 ? opt.th_stereo : opt.th_mono;
-            return !dim || s > d * d;
-        };
-        if (PPT > 0)
-        {
-#pragma unroll
-            for (int k = 0; k < NP; ++k)
-                if (have[k])
-                {
-                    bad[k] = classify(pw[k], po[k]);
-                    cnt += bad[k] ? 0 : 1;
-                }
-        }
-        else
-            for (int i = lane; i < n; i += STRIDE)
+            const Match mt = fetch(i);
+            Proj q;
+            bool bd = true;
+            if (project(R, pose + 4, mt, cam, q))
             {
-                double p[3];
-                snk_pose_obs o;
-                fetch(i, p, o);
-                const bool bd        = classify(p, o);
-                out[i]               = bd ? 1 : 0;
-                cnt += bd ? 0 : 1;
+                const double s = q.r0 * q.r0 + q.r1 * q.r1 + q.r2 * q.r2;
+                const double d = q.stereo ? opt.th_stereo : opt.th_mono;
+                bd             = s > d * d;
             }
+            out[i] = bd ? 1 : 0;
+            if (k < 32) badbits = (badbits & ~(1u << k)) | ((bd ? 1u : 0u) << k);
+            cnt += bd ? 0 : 1;
+        }
         if (WAVES > 1)
         {
             double c1[1] = {(double)cnt};
-            reduce(c1, std::integral_constant<int, 1>{});  // its barriers also order this round's flags before the next round reads them (PPT = 0)
+            reduce(c1, std::integral_constant<int, 1>{});  // its barriers also order this round's flags before the next round reads them
             cnt = (int)c1[0];
         }
         else
@@ -512,12 +569,6 @@ __global__ __launch_bounds__(64 * WAVES, SNK_POSE_MIN_WAVES) void pose_kernel(co
             for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
         }
         inliers = cnt;
-    }
-    if (PPT > 0)
-    {
-#pragma unroll
-        for (int k = 0; k < NP; ++k)
-            if (have[k]) out[lane + k * STRIDE] = bad[k] ? 1 : 0;
     }
     if (lane == 0)
     {
@@ -765,11 +816,11 @@ extern "C" int snk_pose_refine(snk_matcher* m, const snk_camera* cam, const snk_
     SNK_HIP_CHECK(hipMemcpyAsync(d, stage.data(), in_b, hipMemcpyHostToDevice, m->stream));
     CamD C{cam->fx, cam->fy, cam->cx, cam->cy, cam->bf};
     if (total >= (size_t)n_problems * 192)  // ~200 matches per frame and more: four wavefronts per frame
-        hipLaunchKernelGGL((pose_kernel<4, 0, false>), dim3(n_problems), dim3(256), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
+        hipLaunchKernelGGL((pose_kernel<4, false>), dim3(n_problems), dim3(256), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
                            reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),
                            reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), reinterpret_cast<int*>(o + o_inl), C, *opt, 0);
     else
-        hipLaunchKernelGGL((pose_kernel<1, 0, false>), dim3(n_problems), dim3(64), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
+        hipLaunchKernelGGL((pose_kernel<1, false>), dim3(n_problems), dim3(64), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
                            reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),
                            reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), reinterpret_cast<int*>(o + o_inl), C, *opt, 0);
     SNK_LAUNCH_CHECK();
@@ -831,22 +882,27 @@ static int refine_batch_impl(snk_matcher* m, const snk_frames_dev* frames, const
     CamD C{cam->fx, cam->fy, cam->cx, cam->cy, cam->bf};
     static const bool no_lds = getenv("SNK_POSE_NO_LDS") != nullptr;  // A/B: matches re-read from global memory in every step
     // matches of a frame kept in LDS (56 bytes each): the whole local map when few frames are in flight (one workgroup per CU
-    // anyway), otherwise at most POSE_LDS_MATCHES so that three frames share a compute unit (a tracking pass matches about half
-    // of its local map; SNK_POSE_LDS_MATCHES overrides, tests force the global-memory tail with a small value)
+    // anyway), otherwise at most ~1300, so that TWO frames share a compute unit -- what the kernel's ~250 registers admit (two
+    // wavefronts per SIMD; until round 4 the carve was sized for four frames, 656 matches, and a frame with the usual ~770 read
+    // the rest from global memory in every step).  SNK_POSE_LDS_MATCHES overrides; tests force the global-memory tail with a small value.
     static const int lds_env = getenv("SNK_POSE_LDS_MATCHES") ? atoi(getenv("SNK_POSE_LDS_MATCHES")) : 0;
     int lds_matches = stride;
     if (lds_env > 0) lds_matches = lds_env < stride ? lds_env : stride;
-    else if (batch > 768 && lds_matches > 656) lds_matches = 656;  // four frames per CU (656 x 56 B + 3.8 KB static <= 40 KB): 1024 frames are ONE round of the 256 CUs
-    else if (batch > 256 && lds_matches > 896) lds_matches = 896;  // three
-    if ((size_t)lds_matches * 56 > 150 * 1024) lds_matches = 150 * 1024 / 56;
+    else
+    {
+        const int two_per_cu = (80 * 1024 - (4 * POSE_SLOTS_PER_WAVE * 28 + 28) * 8 - 256) / 56;  // carve + static LDS <= 80 KB
+        if (batch > 256 && lds_matches > two_per_cu) lds_matches = two_per_cu;
+    }
+    const int dyn_max = 160 * 1024 - (4 * POSE_SLOTS_PER_WAVE * 28 + 28) * 8 - 2048;  // what a workgroup can have beside the static part
+    if ((size_t)lds_matches * 56 > (size_t)dyn_max) lds_matches = dyn_max / 56;
     const size_t match_lds = (size_t)lds_matches * 7 * sizeof(double);
 #define POSE_LAUNCH(W_, L_, LDS_)                                                                                                    \
-    hipLaunchKernelGGL((pose_kernel<W_, 0, L_>), dim3(batch), dim3(64 * W_), LDS_, m->stream, reinterpret_cast<const PoseMeta*>(d),  \
+    hipLaunchKernelGGL((pose_kernel<W_, L_>), dim3(batch), dim3(64 * W_), LDS_, m->stream, reinterpret_cast<const PoseMeta*>(d),  \
                        reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),                \
                        reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), inliers_dev, C, *opt, lds_matches)
     if (stride >= 256 && !no_lds)
     {
-        int rc = set_max_lds_once(reinterpret_cast<const void*>(pose_kernel<4, 0, true>), 152 * 1024);
+        int rc = set_max_lds_once(reinterpret_cast<const void*>(pose_kernel<4, true>), dyn_max);
         if (rc != SNK_OK) return rc;
         POSE_LAUNCH(4, true, match_lds);
     }
