@@ -162,6 +162,25 @@ inline int ceil_div(int a, int b)
 }
 
 #if defined(__HIPCC__)
+// x / N for a small positive integer constant N with the bits of the IEEE division it replaces, in five instructions instead of the
+// ~14 of the expanded division (the projection matchers evaluate 20 such divisions per local-map point: the 16 terms of det_exp and
+// the four cell coordinates of a window).  y = RN(1 / N) is a compile-time constant, r = x - N q is exact in an FMA.
+// q1 = RN(q0 + r0 y): q0 + r0 y = x / N - (x / N - q0)(1 - N y) lies within 2^-105 (relative) of x / N, so q1 is a faithful rounding; then
+// Markstein's theorem (y the correctly rounded reciprocal, q faithful, N's significand not all ones) makes RN(q1 + r1 y) the
+// correctly rounded quotient.  (x = -0 gives +0: every use adds the quotient to 1.0 or takes its floor.)  Checked against the
+// division on the hardware over 4e9 random operands by tools/probes/div_const_probe.hip.
+template <int N>
+__device__ __forceinline__ double div_const(double x)
+{
+    constexpr double y = 1.0 / (double)N;
+    constexpr double n = (double)N;
+    double q = x * y;
+    double r = __builtin_fma(-n, q, x);
+    q        = __builtin_fma(r, y, q);
+    r        = __builtin_fma(-n, q, x);
+    return __builtin_fma(r, y, q);
+}
+
 // Sum over the 64 lanes of a double, returned to every lane, without the LDS: four DPP butterflies inside each row of 16 lanes
 // (two 32-bit moves per step), then the four row sums are read back with v_readlane and added in a fixed order.  The
 // __shfl_xor tree above is twelve dependent ds_bpermute round trips per sum.

@@ -64,24 +64,30 @@ __device__ __forceinline__ double det_log(double x)
     }
     const double z = (m - 1.0) / (m + 1.0), z2 = z * z;
     double s = 1.0 / 21.0;
-#pragma unroll 1
+#pragma unroll  // fully: 1 / k are then constants (the same values the division gives at run time)
     for (int k = 19; k >= 1; k -= 2) s = s * z2 + 1.0 / (double)k;
     return 2.0 * z * s + (double)e * 0.69314718055994530942;
 }
 
+template <int N>
+__device__ __forceinline__ double det_exp_terms(double s, double f)
+{
+    if constexpr (N >= 1)
+        return det_exp_terms<N - 1>(1.0 + div_const<N>(s * f), f);
+    else
+        return s;
+}
 __device__ __forceinline__ double det_exp(double y)
 {
     const double k = floor(y * 1.44269504088896340736 + 0.5);
     const double f = y - k * 0.69314718055994530942;
-    double s = 1.0;
-#pragma unroll 1
-    for (int n = 16; n >= 1; --n) s = 1.0 + s * f / (double)n;
-    return ldexp(s, (int)k);
+    // s = 1 + s f / n for n = 16 ... 1
+    return ldexp(det_exp_terms<16>(1.0, f), (int)k);
 }
 
 __device__ __forceinline__ int cell_coord(double p, double lo, int n)
 {
-    const int c = (int)floor((p - lo) / 20.0);
+    const int c = (int)floor(div_const<20>(p - lo));
     return c < 0 ? 0 : (c >= n ? n - 1 : c);
 }
 
