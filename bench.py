@@ -793,7 +793,7 @@ def main():
         d_pc = torch.from_numpy(np.stack([x[0] for x in lm]).view(np.uint8).reshape(TB, TRACK_M_COARSE, 88)).to(dev)
         pf_host = np.stack([x[1] for x in lm])
         d_pf0 = torch.from_numpy(pf_host.view(np.uint8).reshape(TB, TRACK_M_FINE, 96)).to(dev)
-        d_pf = d_pf0.clone()
+        d_pf = d_pf0
         d_mc = torch.full((TB,), TRACK_M_COARSE, dtype=torch.int32, device=dev)
         d_mf = torch.full((TB,), TRACK_M_FINE, dtype=torch.int32, device=dev)
         ident = np.zeros((TB, 7))
@@ -816,12 +816,12 @@ def main():
             trk.coarse_batch_dev(fd, TRACK_CAM, d_pose, d_pc, d_mc, 10.0, 75, 0, level_scale, mi_c, n_c)   # th 10: stereo, Tracking.h:184
             refp.refine_matches_batch_dev(fd, depth[:TB], TRACK_CAM, d_pc, mi_c, d_mc, level_scale, d_pose, outl_c, inl_c)  # TrackingCoarse.cpp:270
             trk.mark_taken_batch_dev(mi_c, d_mc, taken)
-            trk.fine_batch_dev(fd, TRACK_CAM, d_pose, d_pf, d_mf, 4.0, 0.8, level_scale, mi_f, vis, n_f)    # th 4: stereo, Tracking.h:189
+            trk.fine_batch_dev(fd, TRACK_CAM, d_pose, d_pf, d_mf, 4.0, 0.8, level_scale, mi_f, vis, n_f,    # th 4: stereo, Tracking.h:189
+                               write_valid=False)  # local-map records read-only (lmp.valid after the search = vis): nothing to restore
 
-        def restore_inputs():  # what a step consumes destructively: the local map's `valid` flags (the reference builds a fresh
-            taken.zero_()      # LocalMap per frame), the taken mask and the start poses -- input preparation, not the chain
+        def restore_inputs():  # what a step consumes: the taken mask and the start poses (16 KB + 56 B per frame) -- input preparation
+            taken.zero_()      # (until round 4 also the 983 MB of local-map records whose `valid` flags the fine matcher cleared in place)
             d_pose.copy_(d_pose0)
-            d_pf.copy_(d_pf0)
 
         ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
         ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -848,8 +848,8 @@ def main():
         track_out = {"metric": "frames/s of the tracking chain (coarse M=1500 th=10 -> RefinePoseWithMatches -> fine M=10000 th=4), device resident",
                      "value": round(fps, 1), "unit": "frames/s", "frames_per_step": TB, "ms_per_step": round(chain_s / args.steps * 1e3, 4),
                      "timing": "HIP events around the chain on its stream, summed over the steps (inputs resident); "
-                               "ms_per_step_with_input_restore is the host clock around the same steps including the restore of the "
-                               f"{TB} x {TRACK_M_FINE} local-map records ({TB * TRACK_M_FINE * 96 / 1e6:.0f} MB copy) that a step consumes",
+                               "ms_per_step_with_input_restore is the host clock around the same steps including the reset of the taken "
+                               "mask and of the start poses (the local-map records are read-only: snk_match_project_fine_batch_ro_dev)",
                      "ms_per_step_with_input_restore": round(wall_s / args.steps * 1e3, 4),
                      "coarse_matches_per_frame": round(float(n_c.float().mean().item()), 1),
                      "fine_matches_per_frame": round(float(n_f.float().mean().item()), 1),

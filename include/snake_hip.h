@@ -463,6 +463,15 @@ SNK_API int snk_match_project_fine_batch_dev(snk_matcher* m, const snk_frames_de
                                              int pts_cap, float th, float ratio, const float* level_scale, int n_levels,
                                              int32_t* match_idx_dev, uint8_t* visible_dev, int32_t* n_matches_dev);
 
+/* The same with the local-map records READ-ONLY: pts_dev[..].valid is read, never written.  The flag the reference leaves in lmp.valid
+ * (SnakeORBMatcher.cpp:397-428) is visible_dev[b][i]: a point keeps valid = 1 exactly when it passes every cull, which is where
+ * IncreaseVisible() is called (:431).  For callers that match a local map again (or share its records between frames) without restoring
+ * it, and 6 x fewer bytes written: the in-place flag is one byte into each 96-byte record. */
+SNK_API int snk_match_project_fine_batch_ro_dev(snk_matcher* m, const snk_frames_dev* frames, const snk_camera* cam,
+                                                const double* poses_dev, const snk_lm_fine* pts_dev, const int32_t* n_pts_dev,
+                                                int pts_cap, float th, float ratio, const float* level_scale, int n_levels,
+                                                int32_t* match_idx_dev, uint8_t* visible_dev, int32_t* n_matches_dev);
+
 /* taken_dev[b][match_idx_dev[b][i]] = 1 for every matched point: `CurrentFrame.mvpMapPoints[idx] = mp`
  * (SnakeORBMatcher.cpp:330, :522) applied on the device between two matcher calls on the same frames. */
 SNK_API int snk_match_mark_taken_batch_dev(snk_matcher* m, const int32_t* match_idx_dev, const int32_t* n_pts_dev, int pts_cap,

@@ -60,6 +60,7 @@ SIGNATURES = {
     "snk_match_project_fine": (i32, [vp, vp, vp, vp, vp, i32, f32, f32, vp, i32, vp, vp, C.POINTER(i32)]),
     "snk_match_project_coarse_batch_dev": (i32, [vp, vp, vp, vp, vp, vp, i32, f32, i32, i32, vp, i32, vp, vp]),
     "snk_match_project_fine_batch_dev": (i32, [vp, vp, vp, vp, vp, vp, i32, f32, f32, vp, i32, vp, vp, vp]),
+    "snk_match_project_fine_batch_ro_dev": (i32, [vp, vp, vp, vp, vp, vp, i32, f32, f32, vp, i32, vp, vp, vp]),
     "snk_match_mark_taken_batch_dev": (i32, [vp, vp, vp, i32, i32, vp, i32]),
     "snk_match_project_keyframe": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, f32, i32, vp, C.POINTER(i32)]),
     "snk_pose_refine": (i32, [vp, vp, vp, vp, i32]),

@@ -415,7 +415,11 @@ __global__ __launch_bounds__(256) void coarse_batch_kernel(FramesDev Fb, const C
                   bins + (size_t)b * m_cap);
 }
 
-// fine (SnakeORBMatcher.cpp:388-512): 64 points starting at i0; best[], visible[] and pts[].valid (in place)
+// fine (SnakeORBMatcher.cpp:388-512): 64 points starting at i0; best[], visible[] and pts[].valid (in place).
+// WRITE_VALID = false: the records stay untouched.  The flag the reference leaves in lmp.valid equals visible[]: a point keeps valid = 1
+// exactly when it passes every cull, which is where IncreaseVisible() is called (:431).  Written back, it is one byte into each 96-byte
+// record -- a 32-byte sector written per point, six times the bytes of the results proper.
+template <bool WRITE_VALID = true>
 __device__ __forceinline__ void fine_wave64(const FrameDev& F, const CamDev& C, const ScalesDev& S, snk_lm_fine* __restrict__ pts, int m,
                                             int i0, int ppw, float th, float ratio, int lane, int* __restrict__ best, u8* __restrict__ visible)
 {
@@ -501,7 +505,7 @@ __device__ __forceinline__ void fine_wave64(const FrameDev& F, const CamDev& C, 
     {
         best[i]      = my_res[lane];
         visible[i]   = vis;
-        pts[i].valid = valid;
+        if (WRITE_VALID) pts[i].valid = valid;
     }
 }
 
@@ -514,6 +518,7 @@ __global__ __launch_bounds__(256) void fine_kernel(FrameDev F, CamDev C, ScalesD
     fine_wave64(F, C, S, pts, m, i0, ppw, th, ratio, lane, best, visible);
 }
 
+template <bool WRITE_VALID>
 __global__ __launch_bounds__(256) void fine_batch_kernel(FramesDev Fb, const CamDev* __restrict__ cams, ScalesDev S,
                                                          snk_lm_fine* __restrict__ pts, const int* __restrict__ m_dev, int m_cap, int ppw,
                                                          float th, float ratio, int* __restrict__ best, u8* __restrict__ visible)
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(256) void fine_batch_kernel(FramesDev Fb, const Cam
     if (i0 >= m) return;
     const FrameDev F = frame_of(Fb, b);
     const CamDev C   = cams[b];
-    fine_wave64(F, C, S, pts + (size_t)b * m_cap, m, i0, ppw, th, ratio, lane, best + (size_t)b * m_cap, visible + (size_t)b * m_cap);
+    fine_wave64<WRITE_VALID>(F, C, S, pts + (size_t)b * m_cap, m, i0, ppw, th, ratio, lane, best + (size_t)b * m_cap, visible + (size_t)b * m_cap);
 }
 
 // Frame-resident forms of the two batched matchers: 1024 threads (16 wavefronts, 1024 points) per workgroup, the frame in LDS.
@@ -549,6 +554,7 @@ __global__ __launch_bounds__(1024) void coarse_frame_kernel(FramesDev Fb, const 
     }
 }
 
+template <bool WRITE_VALID>
 __global__ __launch_bounds__(1024) void fine_frame_kernel(FramesDev Fb, const CamDev* __restrict__ cams, ScalesDev S,
                                                           snk_lm_fine* __restrict__ pts, const int* __restrict__ m_dev, int m_cap, float th,
                                                           float ratio, int* __restrict__ best, u8* __restrict__ visible)
@@ -567,7 +573,7 @@ __global__ __launch_bounds__(1024) void fine_frame_kernel(FramesDev Fb, const Ca
     {
         const int i0 = (chunk * 16 + wave) * 64;
         if (i0 >= m) break;  // chunks ascend: nothing further for this wavefront (no barrier follows)
-        fine_wave64(F, C, S, pts + (size_t)b * m_cap, m, i0, 64, th, ratio, lane, best + (size_t)b * m_cap, visible + (size_t)b * m_cap);
+        fine_wave64<WRITE_VALID>(F, C, S, pts + (size_t)b * m_cap, m, i0, 64, th, ratio, lane, best + (size_t)b * m_cap, visible + (size_t)b * m_cap);
     }
 }
 
@@ -1664,10 +1670,11 @@ int snk_match_project_coarse_batch_dev(snk_matcher* m, const snk_frames_dev* fra
     return SNK_OK;
 }
 
-int snk_match_project_fine_batch_dev(snk_matcher* m, const snk_frames_dev* frames, const snk_camera* cam, const double* poses_dev,
-                                     snk_lm_fine* pts_dev, const int32_t* n_pts_dev, int pts_cap, float th, float ratio,
-                                     const float* level_scale, int n_levels, int32_t* match_idx_dev, uint8_t* visible_dev,
-                                     int32_t* n_matches_dev)
+}  // extern "C"
+static int fine_batch_impl(snk_matcher* m, const snk_frames_dev* frames, const snk_camera* cam, const double* poses_dev,
+                           snk_lm_fine* pts_dev, const int32_t* n_pts_dev, int pts_cap, float th, float ratio,
+                           const float* level_scale, int n_levels, int32_t* match_idx_dev, uint8_t* visible_dev,
+                           int32_t* n_matches_dev, bool write_valid)
 {
     SNK_REQUIRE(m != nullptr && cam != nullptr, "NULL argument");
     SNK_REQUIRE(poses_dev && pts_dev && n_pts_dev && match_idx_dev && visible_dev && n_matches_dev, "NULL device buffer");
@@ -1688,18 +1695,45 @@ int snk_match_project_fine_batch_dev(snk_matcher* m, const snk_frames_dev* frame
     const size_t flds = frame_lds_host(F.cap, F.cols * F.rows + 1);
     if (ppw == 64 && flds <= FRAME_LDS_MAX && !no_frame_lds())
     {
-        if ((rc = set_max_lds_once(reinterpret_cast<const void*>(fine_frame_kernel), FRAME_LDS_MAX)) != SNK_OK) return rc;
+        const void* fk = write_valid ? reinterpret_cast<const void*>(fine_frame_kernel<true>) : reinterpret_cast<const void*>(fine_frame_kernel<false>);
+        if ((rc = set_max_lds_once(fk, FRAME_LDS_MAX)) != SNK_OK) return rc;
         const int wgs = frame_wgs(ceil_div(pts_cap, 1024), batch);
-        hipLaunchKernelGGL(fine_frame_kernel, dim3(wgs, batch), dim3(1024), flds, m->stream, F, (const CamDev*)cams, S,
-                           pts_dev, n_pts_dev, pts_cap, th, ratio, best, visible_dev);
+        if (write_valid)
+            hipLaunchKernelGGL(fine_frame_kernel<true>, dim3(wgs, batch), dim3(1024), flds, m->stream, F, (const CamDev*)cams, S, pts_dev,
+                               n_pts_dev, pts_cap, th, ratio, best, visible_dev);
+        else
+            hipLaunchKernelGGL(fine_frame_kernel<false>, dim3(wgs, batch), dim3(1024), flds, m->stream, F, (const CamDev*)cams, S, pts_dev,
+                               n_pts_dev, pts_cap, th, ratio, best, visible_dev);
     }
+    else if (write_valid)
+        hipLaunchKernelGGL(fine_batch_kernel<true>, dim3(ceil_div(pts_cap, 4 * ppw), batch), dim3(256), 0, m->stream, F, (const CamDev*)cams,
+                           S, pts_dev, n_pts_dev, pts_cap, ppw, th, ratio, best, visible_dev);
     else
-        hipLaunchKernelGGL(fine_batch_kernel, dim3(ceil_div(pts_cap, 4 * ppw), batch), dim3(256), 0, m->stream, F, (const CamDev*)cams, S,
-                           pts_dev, n_pts_dev, pts_cap, ppw, th, ratio, best, visible_dev);
+        hipLaunchKernelGGL(fine_batch_kernel<false>, dim3(ceil_div(pts_cap, 4 * ppw), batch), dim3(256), 0, m->stream, F, (const CamDev*)cams,
+                           S, pts_dev, n_pts_dev, pts_cap, ppw, th, ratio, best, visible_dev);
     if ((rc = launch_resolve_batch(m, batch, frames->cap, (const int*)best, (const int*)nullptr, n_pts_dev, pts_cap, F, claim, 0,
                                    match_idx_dev, n_matches_dev)) != SNK_OK)
         return rc;
     return SNK_OK;
+}
+extern "C"
+{
+int snk_match_project_fine_batch_dev(snk_matcher* m, const snk_frames_dev* frames, const snk_camera* cam, const double* poses_dev,
+                                     snk_lm_fine* pts_dev, const int32_t* n_pts_dev, int pts_cap, float th, float ratio,
+                                     const float* level_scale, int n_levels, int32_t* match_idx_dev, uint8_t* visible_dev,
+                                     int32_t* n_matches_dev)
+{
+    return fine_batch_impl(m, frames, cam, poses_dev, pts_dev, n_pts_dev, pts_cap, th, ratio, level_scale, n_levels, match_idx_dev,
+                           visible_dev, n_matches_dev, true);
+}
+
+int snk_match_project_fine_batch_ro_dev(snk_matcher* m, const snk_frames_dev* frames, const snk_camera* cam, const double* poses_dev,
+                                        const snk_lm_fine* pts_dev, const int32_t* n_pts_dev, int pts_cap, float th, float ratio,
+                                        const float* level_scale, int n_levels, int32_t* match_idx_dev, uint8_t* visible_dev,
+                                        int32_t* n_matches_dev)
+{
+    return fine_batch_impl(m, frames, cam, poses_dev, const_cast<snk_lm_fine*>(pts_dev), n_pts_dev, pts_cap, th, ratio, level_scale,
+                           n_levels, match_idx_dev, visible_dev, n_matches_dev, false);
 }
 
 int snk_match_mark_taken_batch_dev(snk_matcher* m, const int32_t* match_idx_dev, const int32_t* n_pts_dev, int pts_cap, int batch,

@@ -144,14 +144,16 @@ class SnakeORBMatcher(_FrameBinding):
                                                                 int(direction), _ptr(ls), len(ls), match_idx.data_ptr(),
                                                                 n_matches.data_ptr()), "snk_match_project_coarse_batch_dev")
 
-    def fine_batch_dev(self, frames: FramesDev, cam, poses, pts, n_pts, th, ratio, level_scale, match_idx, visible, n_matches):
-        """pts [B, m_cap, 96] uint8 (snk_lm_fine, .valid updated in place); visible [B, m_cap] uint8."""
+    def fine_batch_dev(self, frames: FramesDev, cam, poses, pts, n_pts, th, ratio, level_scale, match_idx, visible, n_matches,
+                       write_valid: bool = True):
+        """pts [B, m_cap, 96] uint8 (snk_lm_fine, .valid updated in place); visible [B, m_cap] uint8.  write_valid=False: the records
+        are read-only (snk_match_project_fine_batch_ro_dev); the flag the reference leaves in .valid is `visible`."""
         ls = np.ascontiguousarray(level_scale, np.float32)
         c = Camera(*cam)
-        _lib.check(self._lib.snk_match_project_fine_batch_dev(self._h, C.byref(frames), C.byref(c), poses.data_ptr(), pts.data_ptr(),
-                                                              n_pts.data_ptr(), int(pts.shape[1]), float(th), float(ratio), _ptr(ls),
-                                                              len(ls), match_idx.data_ptr(), visible.data_ptr(), n_matches.data_ptr()),
-                   "snk_match_project_fine_batch_dev")
+        name = "snk_match_project_fine_batch_dev" if write_valid else "snk_match_project_fine_batch_ro_dev"
+        _lib.check(getattr(self._lib, name)(self._h, C.byref(frames), C.byref(c), poses.data_ptr(), pts.data_ptr(), n_pts.data_ptr(),
+                                            int(pts.shape[1]), float(th), float(ratio), _ptr(ls), len(ls), match_idx.data_ptr(),
+                                            visible.data_ptr(), n_matches.data_ptr()), name)
 
     def mark_taken_batch_dev(self, match_idx, n_pts, taken):
         """taken[b, match_idx[b, i]] = 1 for every matched point (the adaptor's mvpMapPoints[idx] = mp, on the device)."""

@@ -347,8 +347,16 @@ def test_coarse_then_fine_batch_dev_parity(orc, matcher):
     torch.cuda.synchronize()
     matcher.coarse_batch_dev(fd, cam, poses, d_pc, d_nc, 15.0, 75, 0, ls, mi_c, n_c)
     matcher.mark_taken_batch_dev(mi_c, d_nc, D["taken"])
+    # the read-only form first (snk_match_project_fine_batch_ro_dev): same matches, the records untouched
+    mi_r, vis_r, n_r = torch.full_like(mi_f, -7), torch.full_like(vis, 9), torch.zeros_like(n_f)
+    pf_before = d_pf.clone()
+    matcher.fine_batch_dev(fd, cam, poses, d_pf, d_nf, 5.0, 0.8, ls, mi_r, vis_r, n_r, write_valid=False)
+    matcher.sync()
+    assert torch.equal(d_pf, pf_before)
     matcher.fine_batch_dev(fd, cam, poses, d_pf, d_nf, 5.0, 0.8, ls, mi_f, vis, n_f)
     matcher.sync()
+    assert torch.equal(mi_r, mi_f) and torch.equal(vis_r, vis) and torch.equal(n_r, n_f)
+    assert not torch.equal(d_pf, pf_before)  # the in-place form did clear flags
     mi_c, mi_f, vis, n_c, n_f = mi_c.cpu().numpy(), mi_f.cpu().numpy(), vis.cpu().numpy(), n_c.cpu().numpy(), n_f.cpu().numpy()
     taken_after = D["taken"].cpu().numpy()
     pf_after = d_pf.cpu().numpy().view(LM_FINE_DTYPE).reshape(B, mf_cap)
@@ -364,6 +372,7 @@ def test_coarse_then_fine_batch_dev_parity(orc, matcher):
         wn, widx, wvis, wvalid = orc.match_fine(f2, cam, pose, fine[b], 5.0, 0.8, ls)
         assert n_f[b] == wn and np.array_equal(mi_f[b, : nf[b]], widx), b
         assert np.array_equal(vis[b, : nf[b]], wvis) and np.array_equal(pf_after[b, : nf[b]]["valid"], wvalid), b
+        assert np.array_equal(np.asarray(wvis) != 0, np.asarray(wvalid) != 0), b  # what the read-only form relies on: valid after = visible
         total += int(n_c[b]) + int(n_f[b])
     assert total > 500
 
