@@ -1730,8 +1730,10 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
 
     const u8* src      = l == 0 ? img0 + (long long)b * stride0 : lv.base + (long long)b * lv.img_stride;
     const int pitch    = l == 0 ? pitch0 : lv.pitch;
-    const u8* bsrc     = lv.blur + (long long)b * lv.img_stride;
-    const int bpitch   = lv.pitch;
+    // dbg_fake == 2 (SNK_ORB_DESC_FAKE=2, timing experiment only, results meaningless): the patch from the RAW level, i.e. the rows the
+    // moment window reads anyway -- the memory side of "blur inside describe_kernel" (one window per keypoint instead of two)
+    const u8* bsrc     = dbg_fake == 2 ? src : lv.blur + (long long)b * lv.img_stride;
+    const int bpitch   = dbg_fake == 2 ? pitch : lv.pitch;
     const bool aligned = l == 0 ? aligned0 != 0 : true;
 
     // per-lane geometry, shared by the keypoints: byte offsets of its moment / patch items relative to the window
@@ -1750,11 +1752,11 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
         vyv[k]         = row - 15;
         // dbg_fake (SNK_ORB_DESC_FAKE=1, timing experiment only, results meaningless): the window's bytes from ONE contiguous run
         // behind the keypoint instead of 31 / 37 rows -- what the kernel would cost with ~46 instead of ~111 sectors per keypoint
-        moff[k]        = dbg_fake ? 12 * it : (row - 15) * pitch + 12 * (it - row * 3);
+        moff[k]        = dbg_fake == 1 ? 12 * it : (row - 15) * pitch + 12 * (it - row * 3);
         bok[k]         = item < PATCH_QUADS;
         const int ib   = bok[k] ? item : PATCH_QUADS - 1;
         const int rb   = (ib * 171) >> 9;
-        boff[k]        = dbg_fake ? 16 * ib : (rb - PATCH_R) * bpitch + 16 * (ib - rb * 3);
+        boff[k]        = dbg_fake == 1 ? 16 * ib : (rb - PATCH_R) * bpitch + 16 * (ib - rb * 3);
     }
 
     // ---- issue every load of the wavefront; the copy of the moment table to LDS (and its barrier) comes after, so
@@ -2481,7 +2483,7 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
         const int nb = batch >= 16 ? 8 * ceil_div(batch, 8) : batch;
         hipLaunchKernelGGL(describe_kernel, dim3(gx * L.n_levels * nb), dim3(256), 0, st, L, images_dev, pitch, image_stride,
                            aligned0, d_sel, d_selscore, d_selcnt, kps_dev, (u64*)desc_dev, n_dev, out_cap, gx, batch,
-                           getenv("SNK_ORB_DESC_FAKE") ? 1 : 0);
+                           getenv("SNK_ORB_DESC_FAKE") ? atoi(getenv("SNK_ORB_DESC_FAKE")) : 0);
     }
     SNK_LAUNCH_CHECK();
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[5], st));
