@@ -78,8 +78,13 @@ def main():
         torch.cuda.synchronize()
         pm.coarse_batch_dev(fd, cam, poses, d_pc, d_nc, thc, fe, direction, ls, mi_c, n_c)
         pm.mark_taken_batch_dev(mi_c, d_nc, D["taken"])
-        pm.fine_batch_dev(fd, cam, poses, d_pf, d_nf, thf, ratio, ls, mi_f, vis, n_ff)
+        ro = bool(rng.integers(0, 2))  # every other batch through the read-only form (snk_match_project_fine_batch_ro_dev)
+        pf_in = d_pf.clone() if ro else None
+        pm.fine_batch_dev(fd, cam, poses, d_pf, d_nf, thf, ratio, ls, mi_f, vis, n_ff, write_valid=not ro)
         pm.sync()
+        if ro and not torch.equal(d_pf, pf_in):
+            print("FAIL: the read-only fine matcher wrote into the local-map records")
+            sys.exit(1)
         mi_c, mi_f, vis, n_c, n_ff = mi_c.cpu().numpy(), mi_f.cpu().numpy(), vis.cpu().numpy(), n_c.cpu().numpy(), n_ff.cpu().numpy()
         pf_after = d_pf.cpu().numpy().view(LM_FINE_DTYPE).reshape(B, mf_cap)
         for b, (frame, _, pose, _, _, _) in enumerate(cases):
@@ -90,7 +95,7 @@ def main():
             f2["taken"][widx[widx >= 0]] = 1
             wn, widx, wvis, wvalid = orc.match_fine(f2, cam, pose, fine[b], thf, ratio, ls)
             ok = ok and n_ff[b] == wn and np.array_equal(mi_f[b, : nf[b]], widx) and np.array_equal(vis[b, : nf[b]], wvis) and \
-                np.array_equal(pf_after[b, : nf[b]]["valid"], wvalid)
+                (ro or np.array_equal(pf_after[b, : nf[b]]["valid"], wvalid)) and np.array_equal(np.asarray(wvis) != 0, np.asarray(wvalid) != 0)
             if not ok:
                 print(f"MISMATCH batch {n_b} frame {b}: B {B} features {len(frame['kps'])} cap {cap} coarse {nc[b]} fine {nf[b]} "
                       f"th {thc}/{thf} fe {fe} dir {direction} ratio {ratio} levels {n_levels}")
