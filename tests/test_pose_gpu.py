@@ -40,6 +40,24 @@ def test_refine_matches_oracle(orc, seed, n):
         ref.close()
 
 
+def test_more_than_32_matches_per_thread(orc):
+    """The kernel keeps the outlier flags of a thread's first 32 matches in a register and reads the rest from the `outlier` array: 9000
+    matches through the four-wavefront kernel (36 per thread) and, in a batch whose average is small (one wavefront per problem),
+    a problem of 2300 matches."""
+    from snake_slam_amd.tracking import PoseRefinement
+
+    ref = PoseRefinement()
+    try:
+        big = PH.make_problem(31, 9000, outlier_frac=0.25)
+        compare(orc, ref.refinePose(PH.CAM, big["pose0"], big["wps"], big["obs"]), big, orc.pose_options())
+        prs = [PH.make_problem(40 + i, n, outlier_frac=0.2) for i, n in enumerate([2300] + [20] * 15)]  # 2600 matches / 16 problems < 192
+        res = ref.refine_batch(PH.CAM, [dict(pose=p["pose0"], wps=p["wps"], obs=p["obs"]) for p in prs])
+        for got, pr in zip(res, prs):
+            compare(orc, got, pr, orc.pose_options())
+    finally:
+        ref.close()
+
+
 def test_batch_of_frames_one_launch(orc):
     from snake_slam_amd.tracking import PoseRefinement
 
