@@ -203,6 +203,9 @@ struct Arrays
     double* chi2;  // caller order
 };
 
+#ifndef SNK_BA_IEEE_DIV
+#define SNK_BA_IEEE_DIV 0
+#endif
 __device__ __forceinline__ void quat_to_R(const double* q, double* R)
 {
     const double x = q[0], y = q[1], z = q[2], w = q[3];
@@ -220,12 +223,16 @@ __device__ __forceinline__ int obs_linearize(const double* pose, const double* R
     const double Y = R[3] * pt[0] + R[4] * pt[1] + R[5] * pt[2] + pose[5];
     const double Z = R[6] * pt[0] + R[7] * pt[1] + R[8] * pt[2] + pose[6];
     if (Z <= 0.0) return 0;
-    const double iz = 1.0 / Z, iz2 = iz * iz;
+    // round 4: reciprocals / reciprocal square roots by rcp_nr / rsqrt_nr (common.hpp: hardware approximation + two Newton steps, within
+    // an ulp or two) instead of the IEEE division / square root the compiler expands to 14 - 18 dependent instructions each -- an
+    // observation needs two divisions here and a division and two roots in huber_rho, in each of the three kernels that linearise it.
+    // "snk-ba v1" is specified by tolerances.  SNK_BA_IEEE_DIV=1 (build-time A/B) keeps the divisions.
+    const double iz = SNK_BA_IEEE_DIV ? 1.0 / Z : rcp_nr(Z), iz2 = iz * iz;
     const double fx = K[0], fy = K[1], cx = K[2], cy = K[3];
     const int dim = depth > 0.0 ? 3 : 2;
     r[0] = w * (fx * X * iz + cx - u);
     r[1] = w * (fy * Y * iz + cy - v);
-    r[2] = dim == 3 ? w * ((fx * X * iz + cx - bf * iz) - (u - bf / depth)) : 0.0;
+    r[2] = dim == 3 ? w * ((fx * X * iz + cx - bf * iz) - (u - (SNK_BA_IEEE_DIV ? bf / depth : bf * rcp_nr(depth)))) : 0.0;
     if (JAC)
     {
         double P[9];
@@ -259,8 +266,13 @@ __device__ __forceinline__ double huber_rho(double s, double d, double& sqrt_w)
         sqrt_w = 1.0;
         return s;
     }
+#if SNK_BA_IEEE_DIV
     const double rt = sqrt(s);
     sqrt_w = sqrt(d / rt);
+#else
+    const double irt = rsqrt_nr(s), rt = s * irt, q = d * irt;  // s > d^2 > 0
+    sqrt_w = q * rsqrt_nr(q);                                    // sqrt(d / sqrt(s))
+#endif
     return 2.0 * d * rt - d2;
 }
 
@@ -4074,8 +4086,6 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         const int no = pq.no;
         pr.no        = no;
         pr.ptstart_off = (int)pq.ps_at;
-        const size_t obs_at = pq.obs_at;
-        const int* const s_cam = ocam.data() + obs_at;   // free-camera index of sorted observation s
         if (pq.dup) dev_entries_ok = false;
         // point_wave work items: consecutive whole points with <= 64 observations in total
         pr.wv_off = (int)wvpt.size();

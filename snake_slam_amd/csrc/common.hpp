@@ -162,6 +162,24 @@ inline int ceil_div(int a, int b)
 }
 
 #if defined(__HIPCC__)
+// 1 / z and 1 / sqrt(s) from the hardware approximations plus two Newton steps each (5 / 8 instructions; the IEEE division and
+// square root the compiler expands to are 14 - 18 each and a match needs three of them per Gauss-Newton step).  Within an ulp or
+// two of the correctly rounded values for the magnitudes that occur (depths in metres, squared pixel errors); only for arithmetic
+// that is specified by a tolerance ("snk-pose v1", "snk-ba v1": DESIGN.md sections 3c, 4), never where results are compared bit for bit.
+__device__ __forceinline__ double rcp_nr(double z)
+{
+    double y = __builtin_amdgcn_rcp(z);
+    y        = fma(y, fma(-z, y, 1.0), y);
+    return fma(y, fma(-z, y, 1.0), y);
+}
+__device__ __forceinline__ double rsqrt_nr(double s)
+{
+    const double hs = 0.5 * s;
+    double y        = __builtin_amdgcn_rsq(s);
+    y               = fma(y, fma(-hs * y, y, 0.5), y);
+    return fma(y, fma(-hs * y, y, 0.5), y);
+}
+
 // x / N for a small positive integer constant N with the bits of the IEEE division it replaces, in five instructions instead of the
 // ~14 of the expanded division (the projection matchers evaluate 20 such divisions per local-map point: the 16 terms of det_exp and
 // the four cell coordinates of a window).  y = RN(1 / N) is a compile-time constant, r = x - N q is exact in an FMA.

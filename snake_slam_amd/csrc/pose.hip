@@ -40,24 +40,6 @@ __device__ __forceinline__ void quat_to_R(const double* q, double* R)
     R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
 }
 
-// 1 / z and 1 / sqrt(s) from the hardware approximations plus two Newton steps each (5 / 8 instructions; the IEEE division and
-// square root the compiler expands to are 14 - 18 each and a match needs three of them per Gauss-Newton step).  Within an ulp or
-// two of the correctly rounded values for the magnitudes that occur (depths in metres, squared pixel errors); "snk-pose v1" is
-// specified by a tolerance on the refined pose, not bit for bit.
-__device__ __forceinline__ double rcp_nr(double z)
-{
-    double y = __builtin_amdgcn_rcp(z);
-    y        = fma(y, fma(-z, y, 1.0), y);
-    return fma(y, fma(-z, y, 1.0), y);
-}
-__device__ __forceinline__ double rsqrt_nr(double s)
-{
-    const double hs = 0.5 * s;
-    double y        = __builtin_amdgcn_rsq(s);
-    y               = fma(y, fma(-hs * y, y, 0.5), y);
-    return fma(y, fma(-hs * y, y, 0.5), y);
-}
-
 // sin and cos of a half angle |x| <= pi / 4 by their Taylor series (terms to x^17 / x^16: truncation below 1e-19 relative);
 // larger arguments -- a Gauss-Newton step that turns the camera by more than 90 degrees -- take the library's sincos.  The
 // library call alone was ~150 of the ~860 instructions the solver wavefront runs per step while the others wait.
