@@ -3290,12 +3290,7 @@ __global__ __launch_bounds__(BE_SCAN_THREADS) void block_entries_scan(Arrays A, 
         }
         // inclusive scan: inside the wavefront by shuffles, then the wavefront totals
         int incl = tot;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1)
-        {
-            const int v = __shfl_up(incl, off);
-            if (lane >= off) incl += v;
-        }
+        incl = wave_scan_incl_dpp(incl);
         if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
         int before = 0;

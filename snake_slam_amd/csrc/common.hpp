@@ -199,6 +199,19 @@ __device__ __forceinline__ double div_const(double x)
     return __builtin_fma(r, y, q);
 }
 
+// Inclusive prefix sum of one int per lane over the wavefront with six DPP additions (shifts by 1, 2, 4, 8 inside each row of 16
+// lanes -- lanes without a source add `old` = 0 --, then lane 15 of rows 0 / 2 into rows 1 / 3 and lane 31 into rows 2 and 3) instead of
+// six __shfl_up = ds_bpermute round trips through the LDS crossbar.  Integer sums: the same values in any order.
+__device__ __forceinline__ int wave_scan_incl_dpp(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return x;
+}
 // Sum over the 64 lanes of a double, returned to every lane, without the LDS: four DPP butterflies inside each row of 16 lanes
 // (two 32-bit moves per step), then the four row sums are read back with v_readlane and added in a fixed order.  The
 // __shfl_xor tree above is twelve dependent ds_bpermute round trips per sum.

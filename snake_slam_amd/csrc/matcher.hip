@@ -415,12 +415,7 @@ __global__ __launch_bounds__(256) void stereo_count_kernel(const snk_kp64* __res
         int sum = 0;
         for (int c = c0; c < c1; ++c) sum += start[c];
         int inc = sum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1)
-        {
-            const int v = __shfl_up(inc, off);
-            if (lane >= off) inc += v;
-        }
+        inc = wave_scan_incl_dpp(inc);
         if (lane == 63) s_wsum[wave] = inc;
         __syncthreads();
         int base = inc - sum;
@@ -761,12 +756,7 @@ __global__ __launch_bounds__(1024) void stereo_frame_kernel(const snk_kp64* __re
         // exclusive scan of the ST_ROWS bucket counts, two per thread
         const int a = start[2 * tid], c = start[2 * tid + 1];
         int x       = a + c;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1)
-        {
-            const int y = __shfl_up(x, off);
-            if ((tid & 63) >= off) x += y;
-        }
+        x = wave_scan_incl_dpp(x);
         if ((tid & 63) == 63) s_wtot[tid >> 6] = x;
         __syncthreads();
         int base = 0;

@@ -1056,12 +1056,7 @@ __device__ int block_scan_incl(int v, int tid, int* wave_tot /* >= 8 */)
 {
     const int lane = tid & 63, wave = tid >> 6;
     int x = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1)
-    {
-        const int y = __shfl_up(x, off);
-        if (lane >= off) x += y;
-    }
+    x = wave_scan_incl_dpp(x);
     if (lane == 63) wave_tot[wave] = x;
     __syncthreads();
     int base = 0;

@@ -852,12 +852,7 @@ __global__ __launch_bounds__(256) void grid_count_kernel(const snk_kp64* __restr
         int sum = 0;
         for (int c = c0; c < c1; ++c) sum += start[c];
         int inc = sum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1)
-        {
-            const int v = __shfl_up(inc, off);
-            if (lane >= off) inc += v;
-        }
+        inc = wave_scan_incl_dpp(inc);
         if (lane == 63) s_wsum[wave] = inc;
         __syncthreads();
         int base = inc - sum;
