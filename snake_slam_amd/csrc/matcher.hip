@@ -861,6 +861,8 @@ int snk_matcher_create(int device, void* stream, snk_matcher** out)
     for (snk::DevBuf* b : {&m->q, &m->t, &m->out, &m->aux, &m->aux2, &m->view})
         if (rc == SNK_OK) rc = b->reserve(SCRATCH);
     if (rc == SNK_OK) rc = m->cnt.reserve(256);
+    if (rc == SNK_OK) rc = m->h_in.reserve(1u << 20);  // 10 000 local-map points of the fine matcher
+    if (rc == SNK_OK) rc = m->h_res.reserve(256u << 10);
     if (rc != SNK_OK)
     {
         snk_matcher_destroy(m);
@@ -881,6 +883,8 @@ int snk_matcher_destroy(snk_matcher* m)
     m->aux2.release();
     m->cnt.release();
     m->view.release();
+    m->h_in.release();
+    m->h_res.release();
     m->fini();
     delete m;
     return SNK_OK;

@@ -5,6 +5,10 @@
 struct snk_matcher : snk::HandleBase
 {
     snk::DevBuf q, t, out, aux, aux2, cnt;
+    // pinned staging of the per-frame (host pointer) projection matchers and of snk_pose_refine: the inputs of a call are copied here and
+    // go up with one DMA, the results come back as one block (copies from / to pageable memory are staged by the runtime chunk by
+    // chunk, and every one of them costs a submission: round 4, tools/latency_tracking.py)
+    snk::HostBuf h_in, h_res;
     // device copy of the frame the projection matchers were last called with (track.hip): 1-2 coarse calls and one
     // fine call per frame (TrackingCoarse.cpp:234, TrackingFine.cpp:149) look at the same frame, which is uploaded once
     snk::DevBuf view;

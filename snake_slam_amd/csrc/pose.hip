@@ -770,10 +770,13 @@ extern "C" int snk_pose_refine(snk_matcher* m, const snk_camera* cam, const snk_
     int rc;
     if ((rc = m->q.reserve(in_b + 64)) != SNK_OK) return rc;
     if ((rc = m->out.reserve(out_b + 64)) != SNK_OK) return rc;
-    // stage inputs contiguously on the host, one upload
-    std::string stage(in_b, '\0');
-    PoseMeta* meta = reinterpret_cast<PoseMeta*>(&stage[0]);
+    if ((rc = m->h_in.reserve(in_b)) != SNK_OK) return rc;
+    if ((rc = m->h_res.reserve(out_b)) != SNK_OK) return rc;
+    // stage inputs contiguously in pinned memory, one upload
+    char* stage    = m->h_in.as<char>();
+    PoseMeta* meta = reinterpret_cast<PoseMeta*>(stage);
     size_t off     = 0;
+    int n_max      = 0;
     for (int i = 0; i < n_problems; ++i)
     {
         const snk_pose_problem& P = problems[i];
@@ -792,22 +795,44 @@ extern "C" int snk_pose_refine(snk_matcher* m, const snk_camera* cam, const snk_
             memcpy(&stage[o_obs + off * sizeof(snk_pose_obs)], P.obs, (size_t)P.n * sizeof(snk_pose_obs));
         }
         off += (size_t)P.n;
+        n_max = P.n > n_max ? P.n : n_max;
     }
     char* d = m->q.as<char>();
     char* o = m->out.as<char>();
-    SNK_HIP_CHECK(hipMemcpyAsync(d, stage.data(), in_b, hipMemcpyHostToDevice, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(d, stage, in_b, hipMemcpyHostToDevice, m->stream));
     CamD C{cam->fx, cam->fy, cam->cx, cam->cy, cam->bf};
     if (total >= (size_t)n_problems * 192)  // ~200 matches per frame and more: four wavefronts per frame
-        hipLaunchKernelGGL((pose_kernel<4, false>), dim3(n_problems), dim3(256), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
-                           reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),
-                           reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), reinterpret_cast<int*>(o + o_inl), C, *opt, 0);
+    {
+        // the matches of a problem in LDS for its 40 steps (as in the device-resident form): one problem per call is a chain of
+        // latencies, and a global-memory round trip per match and step was most of it
+        static const bool no_lds = getenv("SNK_POSE_NO_LDS") != nullptr;
+        const int dyn_max = 160 * 1024 - (4 * POSE_SLOTS_PER_WAVE * 28 + 28) * 8 - 2048;
+        int lds_matches   = n_max;
+        if (n_problems > 256) lds_matches = std::min(lds_matches, (80 * 1024 - (4 * POSE_SLOTS_PER_WAVE * 28 + 28) * 8 - 256) / 56);  // two problems per CU
+        if ((size_t)lds_matches * 56 > (size_t)dyn_max) lds_matches = dyn_max / 56;
+        // (eight wavefronts per problem for calls with one or a few large problems -- the reference's call is ONE frame of ~900 matches,
+        // a chain of latencies on an empty chip -- measured nothing: 0.229 vs 0.224 ms per call, round 4; a step is bound by its serial
+        // part: reduction, 6 x 6 solve, pose hand-over)
+        if (!no_lds)
+        {
+            if ((rc = set_max_lds_once(reinterpret_cast<const void*>(pose_kernel<4, true>), dyn_max)) != SNK_OK) return rc;
+            hipLaunchKernelGGL((pose_kernel<4, true>), dim3(n_problems), dim3(256), (size_t)lds_matches * 56, m->stream,
+                               reinterpret_cast<const PoseMeta*>(d), reinterpret_cast<const double*>(d + o_wps),
+                               reinterpret_cast<const snk_pose_obs*>(d + o_obs), reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose),
+                               reinterpret_cast<int*>(o + o_inl), C, *opt, lds_matches);
+        }
+        else
+            hipLaunchKernelGGL((pose_kernel<4, false>), dim3(n_problems), dim3(256), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
+                               reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),
+                               reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), reinterpret_cast<int*>(o + o_inl), C, *opt, 0);
+    }
     else
         hipLaunchKernelGGL((pose_kernel<1, false>), dim3(n_problems), dim3(64), 0, m->stream, reinterpret_cast<const PoseMeta*>(d),
                            reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),
                            reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), reinterpret_cast<int*>(o + o_inl), C, *opt, 0);
     SNK_LAUNCH_CHECK();
-    std::string back(out_b, '\0');
-    SNK_HIP_CHECK(hipMemcpyAsync(&back[0], o, out_b, hipMemcpyDeviceToHost, m->stream));
+    char* back = m->h_res.as<char>();
+    SNK_HIP_CHECK(hipMemcpyAsync(back, o, out_b, hipMemcpyDeviceToHost, m->stream));
     SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
     off = 0;
     for (int i = 0; i < n_problems; ++i)

@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void fine_kernel(FrameDev F, CamDev C, ScalesD
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int i0 = (blockIdx.x * 4 + wave) * ppw;
     if (i0 >= m) return;
-    fine_wave64(F, C, S, pts, m, i0, ppw, th, ratio, lane, best, visible);
+    fine_wave64<false>(F, C, S, pts, m, i0, ppw, th, ratio, lane, best, visible);  // the host entry point sets pts[].valid from visible[]
 }
 
 template <bool WRITE_VALID>
@@ -1516,22 +1516,26 @@ int snk_match_project_coarse(snk_matcher* m, const snk_frame_view* frame, const 
     const size_t np = (size_t)n_pts;
     // q: points | out: best, bins, match | t: claim | cnt: count
     if ((rc = m->q.reserve(np * sizeof(snk_lm_coarse))) != SNK_OK) return rc;
-    if ((rc = m->out.reserve(np * 12)) != SNK_OK) return rc;
+    if ((rc = m->out.reserve(np * 12 + 64)) != SNK_OK) return rc;
     if ((rc = m->t.reserve((size_t)(F.n > 0 ? F.n : 1) * 4)) != SNK_OK) return rc;
     if ((rc = m->cnt.reserve(64)) != SNK_OK) return rc;
+    if ((rc = m->h_in.reserve(np * sizeof(snk_lm_coarse))) != SNK_OK) return rc;
+    if ((rc = m->h_res.reserve(np * 4 + 4)) != SNK_OK) return rc;
     int* d_best = m->out.as<int>();
     int* d_bins = d_best + np;
-    int* d_match = d_bins + np;
-    SNK_HIP_CHECK(hipMemcpyAsync(m->q.p, pts, np * sizeof(snk_lm_coarse), hipMemcpyHostToDevice, m->stream));
+    int* d_match = d_bins + np;  // match[np] | count: one block, one copy back
+    memcpy(m->h_in.p, pts, np * sizeof(snk_lm_coarse));
+    SNK_HIP_CHECK(hipMemcpyAsync(m->q.p, m->h_in.p, np * sizeof(snk_lm_coarse), hipMemcpyHostToDevice, m->stream));
     const int ppw = points_per_wave(n_pts);
     hipLaunchKernelGGL(coarse_kernel, dim3(ceil_div(n_pts, 4 * ppw)), dim3(256), 0, m->stream, F, C, S, m->q.as<snk_lm_coarse>(), n_pts, ppw,
                        th, feature_error, direction, d_best, d_bins);
     hipLaunchKernelGGL(resolve_kernel, dim3(1), dim3(256), 0, m->stream, d_best, d_bins, n_pts, F.taken, m->t.as<int>(), F.n, 1,
-                       d_match, m->cnt.as<int>());
+                       d_match, d_match + np);
     SNK_LAUNCH_CHECK();
-    SNK_HIP_CHECK(hipMemcpyAsync(match_idx, d_match, np * 4, hipMemcpyDeviceToHost, m->stream));
-    SNK_HIP_CHECK(hipMemcpyAsync(n_matches, m->cnt.p, 4, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(m->h_res.p, d_match, np * 4 + 4, hipMemcpyDeviceToHost, m->stream));
     SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    memcpy(match_idx, m->h_res.p, np * 4);
+    memcpy(n_matches, m->h_res.as<char>() + np * 4, 4);
     return SNK_OK;
 }
 
@@ -1553,24 +1557,33 @@ int snk_match_project_fine(snk_matcher* m, const snk_frame_view* frame, const sn
     if (n_pts == 0) return SNK_OK;
     const size_t np = (size_t)n_pts;
     if ((rc = m->q.reserve(np * sizeof(snk_lm_fine))) != SNK_OK) return rc;
-    if ((rc = m->out.reserve(np * 12 + np)) != SNK_OK) return rc;
+    const size_t res_b = np * 4 + 4 + np;  // match[np] | count | visible[np]: one block, one copy back
+    if ((rc = m->out.reserve(np * 4 + res_b + 64)) != SNK_OK) return rc;
     if ((rc = m->t.reserve((size_t)(F.n > 0 ? F.n : 1) * 4)) != SNK_OK) return rc;
     if ((rc = m->cnt.reserve(64)) != SNK_OK) return rc;
+    if ((rc = m->h_in.reserve(np * sizeof(snk_lm_fine))) != SNK_OK) return rc;
+    if ((rc = m->h_res.reserve(res_b)) != SNK_OK) return rc;
     int* d_best  = m->out.as<int>();
     int* d_match = d_best + np;
-    u8* d_vis    = reinterpret_cast<u8*>(d_match + np);
-    SNK_HIP_CHECK(hipMemcpyAsync(m->q.p, pts, np * sizeof(snk_lm_fine), hipMemcpyHostToDevice, m->stream));
+    int* d_cnt   = d_match + np;
+    u8* d_vis    = reinterpret_cast<u8*>(d_cnt + 1);
+    memcpy(m->h_in.p, pts, np * sizeof(snk_lm_fine));
+    SNK_HIP_CHECK(hipMemcpyAsync(m->q.p, m->h_in.p, np * sizeof(snk_lm_fine), hipMemcpyHostToDevice, m->stream));
     const int ppw = points_per_wave(n_pts);
     hipLaunchKernelGGL(fine_kernel, dim3(ceil_div(n_pts, 4 * ppw)), dim3(256), 0, m->stream, F, C, S, m->q.as<snk_lm_fine>(), n_pts, ppw, th,
                        ratio, d_best, d_vis);
     hipLaunchKernelGGL(resolve_kernel, dim3(1), dim3(256), 0, m->stream, d_best, (const int*)nullptr, n_pts, F.taken,
-                       m->t.as<int>(), F.n, 0, d_match, m->cnt.as<int>());
+                       m->t.as<int>(), F.n, 0, d_match, d_cnt);
     SNK_LAUNCH_CHECK();
-    SNK_HIP_CHECK(hipMemcpyAsync(match_idx, d_match, np * 4, hipMemcpyDeviceToHost, m->stream));
-    SNK_HIP_CHECK(hipMemcpyAsync(visible, d_vis, np, hipMemcpyDeviceToHost, m->stream));
-    SNK_HIP_CHECK(hipMemcpyAsync(pts, m->q.p, np * sizeof(snk_lm_fine), hipMemcpyDeviceToHost, m->stream));
-    SNK_HIP_CHECK(hipMemcpyAsync(n_matches, m->cnt.p, 4, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(m->h_res.p, d_match, res_b, hipMemcpyDeviceToHost, m->stream));
     SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    const char* hr = m->h_res.as<char>();
+    memcpy(match_idx, hr, np * 4);
+    memcpy(n_matches, hr + np * 4, 4);
+    memcpy(visible, hr + np * 4 + 4, np);
+    // lmp.valid after the search is `visible` (a point keeps valid = 1 exactly when it passes every cull, which is where
+    // IncreaseVisible() is called, SnakeORBMatcher.cpp:397-431): the 96-byte records are not copied back for one byte each
+    for (size_t i = 0; i < np; ++i) pts[i].valid = visible[i];
     return SNK_OK;
 }
 
