@@ -935,16 +935,21 @@ int snk_bf_knn2(snk_matcher* m, const uint64_t (*query)[4], int nq, const uint64
     SNK_REQUIRE(nt == 0 || train != nullptr, "NULL train buffer");
     SNK_HIP_CHECK(hipSetDevice(m->device));
     int rc;
-    if ((rc = m->q.reserve((size_t)nq * 32)) != SNK_OK) return rc;
-    if ((rc = m->t.reserve((size_t)(nt > 0 ? nt : 1) * 32)) != SNK_OK) return rc;
-    if ((rc = m->out.reserve((size_t)nq * sizeof(snk_knn2))) != SNK_OK) return rc;
-    SNK_HIP_CHECK(hipMemcpyAsync(m->q.p, query, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
-    if (nt > 0) SNK_HIP_CHECK(hipMemcpyAsync(m->t.p, train, (size_t)nt * 32, hipMemcpyHostToDevice, m->stream));
-    rc = launch_knn2(m, m->q.as<uint64_t>(), nullptr, nq, nq, m->t.as<uint64_t>(), nullptr, nt > 0 ? nt : 1, nt, 1,
-                     m->out.as<snk_knn2>());
+    // query | train in ONE device block, through the pinned staging buffer: one upload, one download (see matcher_handle.hpp)
+    const size_t qb = (size_t)nq * 32, tb = (size_t)(nt > 0 ? nt : 1) * 32, ob = (size_t)nq * sizeof(snk_knn2);
+    if ((rc = m->q.reserve(qb + tb)) != SNK_OK) return rc;
+    if ((rc = m->out.reserve(ob)) != SNK_OK) return rc;
+    if ((rc = m->h_in.reserve(qb + tb)) != SNK_OK) return rc;
+    if ((rc = m->h_res.reserve(ob)) != SNK_OK) return rc;
+    memcpy(m->h_in.p, query, qb);
+    if (nt > 0) memcpy(m->h_in.as<char>() + qb, train, (size_t)nt * 32);
+    SNK_HIP_CHECK(hipMemcpyAsync(m->q.p, m->h_in.p, qb + (nt > 0 ? (size_t)nt * 32 : 0), hipMemcpyHostToDevice, m->stream));
+    rc = launch_knn2(m, m->q.as<uint64_t>(), nullptr, nq, nq, reinterpret_cast<const uint64_t*>(m->q.as<char>() + qb), nullptr,
+                     nt > 0 ? nt : 1, nt, 1, m->out.as<snk_knn2>());
     if (rc != SNK_OK) return rc;
-    SNK_HIP_CHECK(hipMemcpyAsync(out, m->out.p, (size_t)nq * sizeof(snk_knn2), hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(m->h_res.p, m->out.p, ob, hipMemcpyDeviceToHost, m->stream));
     SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    memcpy(out, m->h_res.p, ob);
     return SNK_OK;
 }
 
@@ -970,18 +975,22 @@ int snk_bf_filter(snk_matcher* m, const snk_knn2* knn, int nq, int threshold, fl
     SNK_REQUIRE(knn != nullptr && pairs != nullptr, "NULL buffer");
     SNK_HIP_CHECK(hipSetDevice(m->device));
     int rc;
-    if ((rc = m->out.reserve((size_t)nq * sizeof(snk_knn2))) != SNK_OK) return rc;
-    if ((rc = m->aux.reserve((size_t)nq * 8)) != SNK_OK) return rc;
-    if ((rc = m->cnt.reserve(64)) != SNK_OK) return rc;
-    SNK_HIP_CHECK(hipMemcpyAsync(m->out.p, knn, (size_t)nq * sizeof(snk_knn2), hipMemcpyHostToDevice, m->stream));
+    // aux: count (16 bytes) | pairs: ONE copy back (the count first and the n pairs after it were two round trips)
+    const size_t kb = (size_t)nq * sizeof(snk_knn2), pb = 16 + (size_t)nq * 8;
+    if ((rc = m->out.reserve(kb)) != SNK_OK) return rc;
+    if ((rc = m->aux.reserve(pb)) != SNK_OK) return rc;
+    if ((rc = m->h_in.reserve(kb)) != SNK_OK) return rc;
+    if ((rc = m->h_res.reserve(pb)) != SNK_OK) return rc;
+    memcpy(m->h_in.p, knn, kb);
+    SNK_HIP_CHECK(hipMemcpyAsync(m->out.p, m->h_in.p, kb, hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(bf_filter_kernel, dim3(1), dim3(256), 0, m->stream, m->out.as<snk_knn2>(), (const int*)nullptr,
                        nq, nq, threshold, ratio, definition(DEF_BF_FILTER_THRESHOLD_STRICT), definition(DEF_BF_FILTER_RATIO_STRICT),
-                       m->aux.as<int2>(), m->cnt.as<int>());
+                       reinterpret_cast<int2*>(m->aux.as<char>() + 16), m->aux.as<int>());
     SNK_LAUNCH_CHECK();
-    int n = 0;
-    SNK_HIP_CHECK(hipMemcpyAsync(&n, m->cnt.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(m->h_res.p, m->aux.p, pb, hipMemcpyDeviceToHost, m->stream));
     SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
-    if (n > 0 && (rc = copy_sync(pairs, m->aux.p, (size_t)n * 8, hipMemcpyDeviceToHost, m->stream)) != SNK_OK) return rc;
+    const int n = *m->h_res.as<int>();
+    if (n > 0) memcpy(pairs, m->h_res.as<char>() + 16, (size_t)n * 8);
     *n_pairs = n;
     return SNK_OK;
 }
@@ -1026,22 +1035,30 @@ int snk_stereo_match(snk_matcher* m, const snk_kp64* left, const uint64_t (*desc
     SNK_REQUIRE(left && desc_left && right && desc_right && right_points && depth, "NULL buffer");
     SNK_HIP_CHECK(hipSetDevice(m->device));
     const size_t kl = (size_t)nl * sizeof(snk_kp64), kr = (size_t)nr * sizeof(snk_kp64);
-    // aux: left kps | right kps ; q/t: descriptors ; aux2: right_points | depth ; cnt: n_matches
-    if ((rc = m->aux.reserve(kl + kr)) != SNK_OK) return rc;
-    if ((rc = m->q.reserve((size_t)nl * 32)) != SNK_OK) return rc;
-    if ((rc = m->t.reserve((size_t)nr * 32)) != SNK_OK) return rc;
-    if ((rc = m->aux2.reserve((size_t)nl * 8)) != SNK_OK) return rc;
-    if ((rc = m->cnt.reserve(64)) != SNK_OK) return rc;
+    // ONE device block (aux): left kps | right kps | left descriptors | right descriptors | right_points | depth | count, filled through
+    // the pinned staging buffer with one copy; right_points | depth | count come back with one copy (nine copies from / to pageable
+    // memory before round 4)
+    auto al16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_kr = al16(kl), o_dl = al16(o_kr + kr), o_dr = al16(o_dl + (size_t)nl * 32), o_rp = al16(o_dr + (size_t)nr * 32);
+    const size_t o_dp = o_rp + (size_t)nl * 4, o_cnt = o_dp + (size_t)nl * 4, in_b = o_cnt + 4, res_b = in_b - o_rp;
+    if ((rc = m->aux.reserve(in_b)) != SNK_OK) return rc;
+    if ((rc = m->h_in.reserve(in_b)) != SNK_OK) return rc;
+    if ((rc = m->h_res.reserve(res_b)) != SNK_OK) return rc;
     char* ab   = m->aux.as<char>();
-    float* rp  = m->aux2.as<float>();
-    float* dp  = rp + nl;
-    SNK_HIP_CHECK(hipMemcpyAsync(ab, left, kl, hipMemcpyHostToDevice, m->stream));
-    SNK_HIP_CHECK(hipMemcpyAsync(ab + kl, right, kr, hipMemcpyHostToDevice, m->stream));
-    SNK_HIP_CHECK(hipMemcpyAsync(m->q.p, desc_left, (size_t)nl * 32, hipMemcpyHostToDevice, m->stream));
-    SNK_HIP_CHECK(hipMemcpyAsync(m->t.p, desc_right, (size_t)nr * 32, hipMemcpyHostToDevice, m->stream));
-    SNK_HIP_CHECK(hipMemcpyAsync(rp, right_points, (size_t)nl * 4, hipMemcpyHostToDevice, m->stream));
-    SNK_HIP_CHECK(hipMemcpyAsync(dp, depth, (size_t)nl * 4, hipMemcpyHostToDevice, m->stream));
-    SNK_HIP_CHECK(hipMemsetAsync(m->cnt.p, 0, sizeof(int), m->stream));
+    char* hb   = m->h_in.as<char>();
+    float* rp  = reinterpret_cast<float*>(ab + o_rp);
+    float* dp  = reinterpret_cast<float*>(ab + o_dp);
+    int* d_cnt = reinterpret_cast<int*>(ab + o_cnt);
+    const uint4* d_dl = reinterpret_cast<const uint4*>(ab + o_dl);
+    const uint4* d_dr = reinterpret_cast<const uint4*>(ab + o_dr);
+    memcpy(hb, left, kl);
+    memcpy(hb + o_kr, right, kr);
+    memcpy(hb + o_dl, desc_left, (size_t)nl * 32);
+    memcpy(hb + o_dr, desc_right, (size_t)nr * 32);
+    memcpy(hb + o_rp, right_points, (size_t)nl * 4);
+    memcpy(hb + o_dp, depth, (size_t)nl * 4);
+    memset(hb + o_cnt, 0, 4);
+    SNK_HIP_CHECK(hipMemcpyAsync(ab, hb, in_b, hipMemcpyHostToDevice, m->stream));
     const u32* srt = nullptr;
     if (nr <= ST_SORT_MAX)
     {
@@ -1057,27 +1074,28 @@ int snk_stereo_match(snk_matcher* m, const snk_kp64* left, const uint64_t (*desc
             const size_t lds = std::max(((size_t)2 * (ST_COUNT_ROWS + 1) + (size_t)2 * nrc) * 4, (size_t)np2 * 4);
             if ((rc = set_max_lds_once(reinterpret_cast<const void*>(stereo_count_kernel), (2 * (ST_COUNT_ROWS + 1) + 2 * ST_SORT_MAX) * 4)) != SNK_OK)
                 return rc;
-            hipLaunchKernelGGL(stereo_count_kernel, dim3(1), dim3(256), lds, m->stream, (const snk_kp64*)(ab + kl), (const int*)nullptr, nrc, nr,
+            hipLaunchKernelGGL(stereo_count_kernel, dim3(1), dim3(256), lds, m->stream, (const snk_kp64*)(ab + o_kr), (const int*)nullptr, nrc, nr,
                                ls.iround_mode, m->out.as<u32>());
         }
         else
-            hipLaunchKernelGGL(stereo_sort_kernel, dim3(1), dim3(256), (size_t)np2 * 4, m->stream, (const snk_kp64*)(ab + kl),
+            hipLaunchKernelGGL(stereo_sort_kernel, dim3(1), dim3(256), (size_t)np2 * 4, m->stream, (const snk_kp64*)(ab + o_kr),
                                (const int*)nullptr, nr, nr, ls.iround_mode, m->out.as<u32>());
         srt = m->out.as<u32>();
     }
     if (srt)
-        hipLaunchKernelGGL(stereo_kernel16, dim3(ceil_div(nl, 16), 1), dim3(256), (size_t)nr * 4, m->stream, (const snk_kp64*)ab,
-                           m->q.as<uint4>(), (const int*)nullptr, nl, nl, (const snk_kp64*)(ab + kl), m->t.as<uint4>(),
-                           (const int*)nullptr, nr, nr, bf, ls, relaxed, rp, dp, m->cnt.as<int>(), srt);
+        hipLaunchKernelGGL(stereo_kernel16, dim3(ceil_div(nl, 16), 1), dim3(256), (size_t)nr * 4, m->stream, (const snk_kp64*)ab, d_dl,
+                           (const int*)nullptr, nl, nl, (const snk_kp64*)(ab + o_kr), d_dr, (const int*)nullptr, nr, nr, bf, ls, relaxed, rp, dp,
+                           d_cnt, srt);
     else
-        hipLaunchKernelGGL(stereo_kernel, dim3(ceil_div(nl, 4), 1), dim3(256), 0, m->stream, (const snk_kp64*)ab,
-                           m->q.as<uint4>(), (const int*)nullptr, nl, nl, (const snk_kp64*)(ab + kl), m->t.as<uint4>(),
-                           (const int*)nullptr, nr, nr, bf, ls, relaxed, rp, dp, m->cnt.as<int>(), srt);
+        hipLaunchKernelGGL(stereo_kernel, dim3(ceil_div(nl, 4), 1), dim3(256), 0, m->stream, (const snk_kp64*)ab, d_dl, (const int*)nullptr,
+                           nl, nl, (const snk_kp64*)(ab + o_kr), d_dr, (const int*)nullptr, nr, nr, bf, ls, relaxed, rp, dp, d_cnt, srt);
     SNK_LAUNCH_CHECK();
-    SNK_HIP_CHECK(hipMemcpyAsync(right_points, rp, (size_t)nl * 4, hipMemcpyDeviceToHost, m->stream));
-    SNK_HIP_CHECK(hipMemcpyAsync(depth, dp, (size_t)nl * 4, hipMemcpyDeviceToHost, m->stream));
-    SNK_HIP_CHECK(hipMemcpyAsync(n_matches, m->cnt.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(m->h_res.p, ab + o_rp, res_b, hipMemcpyDeviceToHost, m->stream));
     SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    const char* hr = m->h_res.as<char>();
+    memcpy(right_points, hr, (size_t)nl * 4);
+    memcpy(depth, hr + (size_t)nl * 4, (size_t)nl * 4);
+    memcpy(n_matches, hr + (size_t)nl * 8, 4);
     return SNK_OK;
 }
 

@@ -171,17 +171,22 @@ int snk_rectify(snk_matcher* m, const snk_rectification* rect, const snk_keypoin
     if (n == 0) return SNK_OK;
     SNK_REQUIRE(kps && out, "NULL buffer");
     SNK_HIP_CHECK(hipSetDevice(m->device));
-    const size_t kin = (size_t)n * sizeof(snk_keypoint), kout = (size_t)n * sizeof(snk_kp64), nb = (size_t)n * 16;
-    if ((st = m->aux.reserve(kin + kout)) != SNK_OK) return st;
-    if ((st = m->aux2.reserve(nb)) != SNK_OK) return st;
+    // aux: keypoints in | undistorted out | normalized out (16-byte aligned pieces); through the pinned staging buffers, one copy each way
+    const size_t kin = ((size_t)n * sizeof(snk_keypoint) + 15) & ~(size_t)15, kout = (size_t)n * sizeof(snk_kp64), nb = (size_t)n * 16;
+    const size_t res_b = kout + (normalized ? nb : 0);
+    if ((st = m->aux.reserve(kin + kout + nb)) != SNK_OK) return st;
+    if ((st = m->h_in.reserve(kin)) != SNK_OK) return st;
+    if ((st = m->h_res.reserve(res_b)) != SNK_OK) return st;
     char* ab = m->aux.as<char>();
-    SNK_HIP_CHECK(hipMemcpyAsync(ab, kps, kin, hipMemcpyHostToDevice, m->stream));
+    memcpy(m->h_in.p, kps, (size_t)n * sizeof(snk_keypoint));
+    SNK_HIP_CHECK(hipMemcpyAsync(ab, m->h_in.p, (size_t)n * sizeof(snk_keypoint), hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(rectify_kernel, dim3(ceil_div(n, 256), 1), dim3(256), 0, m->stream, rc, (const snk_keypoint*)ab,
-                       (const int*)nullptr, n, n, (snk_kp64*)(ab + kin), normalized ? m->aux2.as<double2>() : nullptr);
+                       (const int*)nullptr, n, n, (snk_kp64*)(ab + kin), normalized ? reinterpret_cast<double2*>(ab + kin + kout) : nullptr);
     SNK_LAUNCH_CHECK();
-    SNK_HIP_CHECK(hipMemcpyAsync(out, ab + kin, kout, hipMemcpyDeviceToHost, m->stream));
-    if (normalized) SNK_HIP_CHECK(hipMemcpyAsync(normalized, m->aux2.p, nb, hipMemcpyDeviceToHost, m->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(m->h_res.p, ab + kin, res_b, hipMemcpyDeviceToHost, m->stream));
     SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    memcpy(out, m->h_res.p, kout);
+    if (normalized) memcpy(normalized, m->h_res.as<char>() + kout, nb);
     return SNK_OK;
 }
 

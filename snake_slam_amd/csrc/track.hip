@@ -1415,7 +1415,13 @@ int snk_feature_grid(snk_matcher* m, const snk_kp64* undistorted, int n, const s
     if (n_pow2 < 2) n_pow2 = 2;
     int* d_perm = m->aux2.as<int>();
     int* d_cs   = d_perm + (n > 0 ? n : 1);
-    if (n) SNK_HIP_CHECK(hipMemcpyAsync(m->aux.p, undistorted, (size_t)n * sizeof(snk_kp64), hipMemcpyHostToDevice, m->stream));
+    if ((rc = m->h_in.reserve((size_t)(n > 0 ? n : 1) * sizeof(snk_kp64))) != SNK_OK) return rc;
+    if ((rc = m->h_res.reserve((size_t)(n > 0 ? n : 1) * 4 + nc * 4)) != SNK_OK) return rc;
+    if (n)
+    {
+        memcpy(m->h_in.p, undistorted, (size_t)n * sizeof(snk_kp64));  // pinned staging: see matcher_handle.hpp
+        SNK_HIP_CHECK(hipMemcpyAsync(m->aux.p, m->h_in.p, (size_t)n * sizeof(snk_kp64), hipMemcpyHostToDevice, m->stream));
+    }
     if (grid_count_fits(n, cols * rows) && !grid_use_network())
     {
         if ((rc = set_max_lds_once(reinterpret_cast<const void*>(grid_count_kernel), GRID_COUNT_LDS_MAX)) != SNK_OK) return rc;
@@ -1430,9 +1436,12 @@ int snk_feature_grid(snk_matcher* m, const snk_kp64* undistorted, int n, const s
                            n, n > 0 ? n : 1, bounds->min_x, bounds->min_y, cols, rows, d_perm, (int*)nullptr, d_cs);
     }
     SNK_LAUNCH_CHECK();
-    if (n) SNK_HIP_CHECK(hipMemcpyAsync(perm, d_perm, (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
-    SNK_HIP_CHECK(hipMemcpyAsync(cell_start, d_cs, nc * 4, hipMemcpyDeviceToHost, m->stream));
+    // permutation | cell starts are adjacent in aux2: one copy back
+    const size_t np1 = (size_t)(n > 0 ? n : 1);
+    SNK_HIP_CHECK(hipMemcpyAsync(m->h_res.p, d_perm, (np1 + nc) * 4, hipMemcpyDeviceToHost, m->stream));
     SNK_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (n) memcpy(perm, m->h_res.p, (size_t)n * 4);
+    memcpy(cell_start, m->h_res.as<int>() + np1, nc * 4);
     return SNK_OK;
 }
 
