@@ -58,6 +58,11 @@ SNK_API int snk_device_count(void);        /* number of visible HIP devices (0 =
  *   "bf_filter.ratio_strict"      same call: 0 = keep d1 <= ratio * d2 (default), 1 = keep d1 < ratio * d2
  *   "iround.mode"                 Saiga::iRound as Preprocess::StereoMatching uses it (Snake/Preprocess/Preprocess.cpp:155,165):
  *                                 0 = floor(x + 0.5) (default), 1 = round half away from zero, 2 = round half to even
+ *   "orb.response"                the corner measure of Saiga::ORBExtractor::Detect (ctor call Snake/Preprocess/FeatureDetector.cpp:31-41;
+ *                                 the extractor itself is in saiga): 0 = the FAST-9 score (default; published ORB-SLAM2), 1 = the Harris
+ *                                 response of the FAST corners (7 x 7 block, k = 0.04: OpenCV's ORB HARRIS_SCORE form).  Under 1 the
+ *                                 FAST stage (corners, non-maximum suppression, thresholds, candidate budgets) is unchanged; the Harris
+ *                                 response picks the point a quadtree node keeps and is KeyPoint::response.
  * Unknown key / out-of-range value: SNK_ERR_INVALID_ARG, nothing changes.  The oracle mirrors every key (orc_set_definition). */
 SNK_API int snk_set_definition(const char* key, int value);
 SNK_API int snk_get_definition(const char* key, int* value);

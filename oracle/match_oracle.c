@@ -72,6 +72,7 @@ int orc_set_definition(const char* key, int value)
     if (key && strcmp(key, "bf_filter.threshold_strict") == 0 && (value == 0 || value == 1)) { g_def_th_strict = value; return 0; }
     if (key && strcmp(key, "bf_filter.ratio_strict") == 0 && (value == 0 || value == 1)) { g_def_ratio_strict = value; return 0; }
     if (key && strcmp(key, "iround.mode") == 0 && value >= 0 && value <= 2) { g_def_iround = value; return 0; }
+    if (key && strcmp(key, "orb.response") == 0) return orc_orb_set_response(value);
     return 1;
 }
 

@@ -149,6 +149,32 @@ def distribute(cands: np.ndarray, w: int, h: int, N: int) -> np.ndarray:
     return out[:n].copy()
 
 
+def distribute_ranked(cands: np.ndarray, rank: np.ndarray, w: int, h: int, N: int) -> np.ndarray:
+    cands = np.ascontiguousarray(cands, CAND)
+    rank = np.ascontiguousarray(rank, np.uint32)
+    out = np.zeros(lib().orc_orb_distribute_bound(w, h, N) + 8, np.int32)
+    lib().orc_orb_distribute_ranked.restype = C.c_int
+    n = lib().orc_orb_distribute_ranked(_p(cands), _p(rank), cands.shape[0], w, h, N, _p(out))
+    return out[:n].copy()
+
+
+def harris_abc(img: np.ndarray, x: int, y: int):
+    """The three integer sums of OpenCV's HarrisResponses over the 7 x 7 block around (x, y)."""
+    a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+    lib().orc_harris_abc(_p(img), img.shape[1], int(x), int(y), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+def harris_response(img: np.ndarray, x: int, y: int) -> np.float32:
+    lib().orc_harris_response.restype = C.c_float
+    return np.float32(lib().orc_harris_response(_p(img), img.shape[1], int(x), int(y)))
+
+
+def harris_rank(r) -> int:
+    lib().orc_harris_rank.restype = C.c_uint32
+    return lib().orc_harris_rank(C.c_float(float(r)))
+
+
 def point_key(x: int, y: int, W: int, H: int) -> int:
     lib().orc_point_key.restype = C.c_uint64
     return lib().orc_point_key(x, y, W, H)

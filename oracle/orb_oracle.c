@@ -488,6 +488,13 @@ int orc_orb_distribute_bound(int w, int h, int N)
  * output order (capacity orc_orb_distribute_bound); returns the number selected. */
 int orc_orb_distribute(const orc_cand* pts, int n, int w, int h, int N, int* out_idx)
 {
+    return orc_orb_distribute_ranked(pts, NULL, n, w, h, N, out_idx);
+}
+
+/* The same distribution with the kept point of a node chosen by `rank` (higher first, then smallest y, then smallest x)
+ * instead of the FAST score: "orb.response" = 1 ranks by the Harris response (orc_harris_rank).  rank == NULL: the score. */
+int orc_orb_distribute_ranked(const orc_cand* pts, const uint32_t* rank, int n, int w, int h, int N, int* out_idx)
+{
     if (n <= 0 || N <= 0) return 0;
     int W = w - 2 * MIN_BORDER, H = h - 2 * MIN_BORDER;
     int nIni = n_roots(W, H);
@@ -574,7 +581,8 @@ int orc_orb_distribute(const orc_cand* pts, int n, int w, int h, int N, int* out
         {
             int id = t.idx[nd->begin + k];
             const orc_cand *a = &pts[id], *b = &pts[best];
-            if (a->score > b->score || (a->score == b->score && (a->y < b->y || (a->y == b->y && a->x < b->x)))) best = id;
+            const uint32_t ra = rank ? rank[id] : a->score, rb = rank ? rank[best] : b->score;
+            if (ra > rb || (ra == rb && (a->y < b->y || (a->y == b->y && a->x < b->x)))) best = id;
         }
         sel[ns].id  = best;
         sel[ns].key = orc_point_key(pts[best].x - MIN_BORDER, pts[best].y - MIN_BORDER, W, H);
@@ -788,6 +796,68 @@ void orc_descriptor(const uint8_t* img, int w, int h, int pitch, int x, int y, f
 }
 
 /* ---------------------------------------------------------------------------------------------- */
+/* Harris response ("orb.response" = 1)                                                           */
+/* ---------------------------------------------------------------------------------------------- */
+/* north_star names the Harris score among the extractor's steps; published ORB-SLAM2 ranks by the FAST score, OpenCV's ORB
+ * (cv::ORB, HARRIS_SCORE: the default) by the Harris response of the FAST corners, and which of the two saiga's extractor
+ * uses cannot be read here (reference Snake/Preprocess/FeatureDetector.cpp:31-41 shows the constructor call only).  So it is a
+ * definition switch: "orb.response" 0 = FAST score (default, [ORB-SLAM2]), 1 = Harris.
+ * [OpenCV] HarrisResponses (modules/features2d/src/orb.cpp), restated from the published algorithm: over the 7 x 7 block
+ * around the corner, with the 3 x 3 Sobel derivatives
+ *     Ix = 2 (p[y][x+1] - p[y][x-1]) + (p[y-1][x+1] - p[y-1][x-1]) + (p[y+1][x+1] - p[y+1][x-1])      (Iy likewise)
+ * a = sum Ix^2, b = sum Iy^2, c = sum Ix Iy (exact integers, < 2^26) and, in float with every operation rounded in this order,
+ *     response = (fa * fb - fc * fc - 0.04f * (fa + fb) * (fa + fb)) * scale^4,   scale = 1 / (4 * 7 * 255)
+ * [DEFINED] what the response is used for: the FAST stage is unchanged (corners, non-maximum suppression, the two thresholds
+ * and the per-cell / per-level candidate budgets are all on the FAST score -- OpenCV likewise retains by FAST response before
+ * it computes Harris); the point kept in a quadtree node is the one with the highest Harris response (then smallest y, x), and
+ * KeyPoint::response is the Harris response. */
+void orc_harris_abc(const uint8_t* img, int pitch, int x, int y, int32_t* a, int32_t* b, int32_t* c)
+{
+    int32_t sa = 0, sb = 0, sc = 0;
+    for (int dy = -3; dy <= 3; ++dy)
+        for (int dx = -3; dx <= 3; ++dx)
+        {
+            const uint8_t* p = img + (size_t)(y + dy) * pitch + (x + dx);
+            int Ix = ((int)p[1] - (int)p[-1]) * 2 + ((int)p[-pitch + 1] - (int)p[-pitch - 1]) + ((int)p[pitch + 1] - (int)p[pitch - 1]);
+            int Iy = ((int)p[pitch] - (int)p[-pitch]) * 2 + ((int)p[pitch - 1] - (int)p[-pitch - 1]) + ((int)p[pitch + 1] - (int)p[-pitch + 1]);
+            sa += Ix * Ix;
+            sb += Iy * Iy;
+            sc += Ix * Iy;
+        }
+    *a = sa;
+    *b = sb;
+    *c = sc;
+}
+
+float orc_harris_response(const uint8_t* img, int pitch, int x, int y)
+{
+    int32_t a, b, c;
+    orc_harris_abc(img, pitch, x, y, &a, &b, &c);
+    const float fa = (float)a, fb = (float)b, fc = (float)c;
+    const float s4 = 0x1.bb9da2p-52f; /* ((1 / 7140) ^ 4 in float, multiplied left to right) */
+    const float det = fa * fb - fc * fc;
+    const float tr  = fa + fb;
+    const float kt  = 0.04f * tr * tr;
+    return (det - kt) * s4;
+}
+
+/* order-preserving map of a float onto uint32 (no NaN occurs: a, b, c are finite) */
+uint32_t orc_harris_rank(float r)
+{
+    uint32_t u;
+    memcpy(&u, &r, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+static int g_def_orb_response = 0;
+int orc_orb_set_response(int v)
+{
+    if (v != 0 && v != 1) return 1;
+    g_def_orb_response = v;
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
 /* whole extractor                                                                                */
 /* ---------------------------------------------------------------------------------------------- */
 int orc_orb_pyramid(const orc_orb_params* p, const uint8_t* img, int w, int h, int pitch, uint8_t** levels /* malloc'd */,
@@ -822,7 +892,19 @@ int orc_orb_detect(const orc_orb_params* p, const uint8_t* img, int w, int h, in
         orc_cand* cand = (orc_cand*)malloc(sizeof(orc_cand) * (size_t)level_cap);
         int nc         = orc_orb_candidates(levels[l], lw, lh, lw, p->ini_th, p->min_th, cand, level_cap);
         int* sel       = (int*)malloc(sizeof(int) * (size_t)(orc_orb_distribute_bound(lw, lh, L.nfeat[l]) + 8));
-        int ns         = orc_orb_distribute(cand, nc, lw, lh, L.nfeat[l], sel);
+        uint32_t* rank = NULL;
+        float* hres    = NULL;
+        if (g_def_orb_response == 1)
+        {
+            rank = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(nc + 1));
+            hres = (float*)malloc(sizeof(float) * (size_t)(nc + 1));
+            for (int i = 0; i < nc; ++i)
+            {
+                hres[i] = orc_harris_response(levels[l], lw, cand[i].x, cand[i].y);
+                rank[i] = orc_harris_rank(hres[i]);
+            }
+        }
+        int ns         = orc_orb_distribute_ranked(cand, rank, nc, lw, lh, L.nfeat[l], sel);
         uint8_t* blurred = (uint8_t*)malloc((size_t)lw * lh);
         orc_blur_image(levels[l], lw, lh, lw, blurred, lw);
         lk[l]          = (orc_keypoint*)malloc(sizeof(orc_keypoint) * (size_t)(ns + 1));
@@ -839,12 +921,14 @@ int orc_orb_detect(const orc_orb_params* p, const uint8_t* img, int w, int h, in
             lk[l][i].y        = (float)c->y * L.scale[l];
             lk[l][i].size     = (float)PATCH_SIZE * L.scale[l];
             lk[l][i].angle    = angle;
-            lk[l][i].response = (float)(c->score - 1);
+            lk[l][i].response = hres ? hres[sel[i]] : (float)(c->score - 1);
             lk[l][i].octave   = l;
         }
         free(cand);
         free(sel);
         free(blurred);
+        free(rank);
+        free(hres);
     }
     int n = 0, overflow = 0;
     for (int l = 0; l < L.n_levels; ++l)

@@ -79,6 +79,11 @@ int orc_orb_candidates(const uint8_t* img, int w, int h, int pitch, int ini_th, 
 uint64_t orc_point_key(int x, int y, int W, int H);
 int orc_orb_distribute_bound(int w, int h, int N); /* capacity of out_idx below */
 int orc_orb_distribute(const orc_cand* pts, int n, int w, int h, int N, int* out_idx);
+int orc_orb_distribute_ranked(const orc_cand* pts, const uint32_t* rank, int n, int w, int h, int N, int* out_idx);
+void orc_harris_abc(const uint8_t* img, int pitch, int x, int y, int32_t* a, int32_t* b, int32_t* c);
+float orc_harris_response(const uint8_t* img, int pitch, int x, int y);
+uint32_t orc_harris_rank(float r);
+int orc_orb_set_response(int v); /* "orb.response": 0 = FAST score, 1 = Harris (set through orc_set_definition) */
 void orc_umax(int* umax);
 void orc_ic_moments(const uint8_t* img, int pitch, int x, int y, int* m10, int* m01);
 float orc_fast_atan2(float y, float x);

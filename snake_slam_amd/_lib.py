@@ -150,7 +150,7 @@ def check(rc: int, what: str = "") -> None:
         raise SnakeHipError(f"{what} failed with status {rc}: {msg}")
 
 
-DEFINITIONS = {"bf_filter.threshold_strict": (0, 1), "bf_filter.ratio_strict": (0, 1), "iround.mode": (0, 2)}  # key -> (min, max); default 0
+DEFINITIONS = {"bf_filter.threshold_strict": (0, 1), "bf_filter.ratio_strict": (0, 1), "iround.mode": (0, 2), "orb.response": (0, 1)}  # key -> (min, max); default 0
 
 
 def set_definition(key: str, value: int) -> None:

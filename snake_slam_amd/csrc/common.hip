@@ -52,6 +52,7 @@ const DefInfo k_defs[DEF_COUNT] = {
     {"bf_filter.threshold_strict", 0, 1, 0},
     {"bf_filter.ratio_strict", 0, 1, 0},
     {"iround.mode", 0, 2, 0},
+    {"orb.response", 0, 1, 0},
 };
 std::atomic<int> g_defs[DEF_COUNT];
 std::once_flag g_defs_once;

@@ -143,6 +143,7 @@ enum DefKey
     DEF_BF_FILTER_THRESHOLD_STRICT = 0,  // filterMatches: 0 = keep d1 <= th (default), 1 = keep d1 < th
     DEF_BF_FILTER_RATIO_STRICT,          // filterMatches: 0 = keep d1 <= ratio * d2 (default), 1 = keep d1 < ratio * d2
     DEF_IROUND_MODE,                     // Saiga::iRound: 0 = floor(x + 0.5) (default), 1 = half away from zero, 2 = half to even
+    DEF_ORB_RESPONSE,                    // ORB extractor: 0 = FAST-9 score ranks / is the response (default, ORB-SLAM2), 1 = Harris response (OpenCV's ORB form)
     DEF_COUNT
 };
 int definition(DefKey k);

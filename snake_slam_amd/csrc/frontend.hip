@@ -48,14 +48,17 @@ struct snk_frontend
     size_t t_desc = 0, t_kp64 = 0;  // d_tmp: descriptors in extractor order (2 images) | rectified keypoints (2 images)
     hipGraphExec_t graph = nullptr;
     int graph_key        = -1;  // definition values the recorded launches depend on
+    int last_key         = -1;  // ... of the previous frame (a change runs one frame uncaptured: the extractor may size new scratch)
+    bool graph_failed    = false;  // a capture / instantiation failed for this configuration: plain launches from then on
     int frames_seen      = 0;   // of the current configuration
 };
 
 static void drop_graph(snk_frontend* f)
 {
     if (f->graph) (void)hipGraphExecDestroy(f->graph);
-    f->graph     = nullptr;
-    f->graph_key = -1;
+    f->graph        = nullptr;
+    f->graph_key    = -1;
+    f->graph_failed = false;
 }
 
 extern "C" int snk_frontend_create(const snk_frontend_params* params, int device, snk_frontend** out)
@@ -207,15 +210,20 @@ extern "C" int snk_frontend_process(snk_frontend* f, const uint8_t* left, int pi
     SNK_HIP_CHECK(hipMemcpyAsync(f->d_img.p, hi, plane * f->n_img, hipMemcpyHostToDevice, f->stream));
 
     static const bool no_graph = getenv("SNK_FRONTEND_NO_GRAPH") != nullptr;
-    const int key              = definition(DEF_IROUND_MODE);
-    if (f->graph && f->graph_key != key) drop_graph(f);
+    const int key              = definition(DEF_IROUND_MODE) | (definition(DEF_ORB_RESPONSE) << 4);
+    if (f->last_key != key)
+    {
+        drop_graph(f);
+        f->frames_seen = 0;
+        f->last_key    = key;
+    }
     bool launched = false;
     if (!no_graph && f->graph)
     {
         SNK_HIP_CHECK(hipGraphLaunch(f->graph, f->stream));
         launched = true;
     }
-    else if (!no_graph && f->frames_seen >= 1)
+    else if (!no_graph && !f->graph_failed && f->frames_seen >= 1)
     {
         // second frame of the configuration: record the chain (every scratch buffer has its size from the first frame)
         hipGraph_t g = nullptr;
@@ -231,6 +239,13 @@ extern "C" int snk_frontend_process(snk_frontend* f, const uint8_t* left, int pi
             }
             if (g) (void)hipGraphDestroy(g);
             (void)hipGetLastError();
+            if (!f->graph)
+            {
+                // not retried frame after frame (begin capture, the whole chain, end capture, instantiate -- each time); configure() and
+                // a changed definition key reset the flag through drop_graph
+                f->graph_failed = true;
+                if (getenv("SNK_DEBUG")) fprintf(stderr, "snake_hip: front-end graph capture failed (chain rc %d, %s); plain launches\n", rc, hipGetErrorString(e));
+            }
             if (f->graph)
             {
                 SNK_HIP_CHECK(hipGraphLaunch(f->graph, f->stream));
@@ -238,7 +253,10 @@ extern "C" int snk_frontend_process(snk_frontend* f, const uint8_t* left, int pi
             }
         }
         else
+        {
             (void)hipGetLastError();
+            f->graph_failed = true;
+        }
     }
     if (!launched && (rc = enqueue_chain(f)) != SNK_OK) return rc;
     ++f->frames_seen;

@@ -719,6 +719,106 @@ static inline const void* fast_kernel_for(const Layout& L, bool loop)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Harris response of the FAST candidates ("orb.response" = 1; include/snake_hip.h).  One wavefront per FAST
+// cell, one lane per candidate slot: the 9 x 9 pixels around the corner come from the level image (L2-hot: fast_kernel has just
+// read the cell) as three aligned dwords per row, the 3 x 3 Sobel derivatives over the 7 x 7 block are separable integer sums, the
+// response is OpenCV's float expression with every operation rounded in its written order (the file is compiled with
+// -ffp-contract=off).  Written as an order-preserving uint32 next to the candidate; distribute_kernel ranks with it.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 harris_rank(float r)
+{
+    const u32 u = __builtin_bit_cast(u32, r);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float harris_unrank(u32 k)
+{
+    return __builtin_bit_cast(float, (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+__global__ __launch_bounds__(256) void harris_kernel(Layout L, const u8* __restrict__ img0, int pitch0, long long stride0, int aligned0,
+                                                     const u32* __restrict__ cand, const u16* __restrict__ cell_cnt,
+                                                     u32* __restrict__ cand_h, int gx, int batch)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int b, bxi;
+    if (!xcd_image_map(gx, batch, b, bxi)) return;
+    const int cid = bxi * 4 + wave;
+    if (cid >= L.total_cells) return;
+    const long long cell_index = (long long)b * L.total_cells + cid;
+    const int cnt = min((int)cell_cnt[cell_index], CELL_SLOTS);
+    if (lane >= cnt) return;
+    const int4 ct = L.cell_tab[cid];
+    const int l   = ct.w;
+    const LevelInfo& lv = L.lv[l];
+    const u32 k   = cand[cell_index * CELL_SLOTS + lane];
+    const int x   = ct.x + 63 - (int)(k & 63u), y = ct.y + 63 - (int)((k >> 6) & 63u);
+    const u8* src      = l == 0 ? img0 + (long long)b * stride0 : lv.base + (long long)b * lv.img_stride;
+    const int pitch    = l == 0 ? pitch0 : lv.pitch;
+    const bool aligned = l == 0 ? aligned0 != 0 : true;
+    // rows y - 4 .. y + 4, columns x - 4 .. x + 4 (corners lie >= 19 px inside the level): rw[r][j] = bytes 4 j .. 4 j + 3 of the row
+    u32 rw[9][3];
+    const int xa = (x - 4) & ~3, sh = (x - 4) & 3;
+#pragma unroll
+    for (int r = 0; r < 9; ++r)
+    {
+        const u8* rp = src + (long long)(y - 4 + r) * pitch;
+        if (aligned)
+        {
+            const u32 d0 = *reinterpret_cast<const u32*>(rp + xa), d1 = *reinterpret_cast<const u32*>(rp + xa + 4),
+                      d2 = *reinterpret_cast<const u32*>(rp + xa + 8);
+            // the funnel shift takes its byte count from a register: sh is per lane
+            const u64 q01 = ((u64)d1 << 32) | d0, q12 = ((u64)d2 << 32) | d1;
+            rw[r][0] = (u32)(q01 >> (8 * sh));
+            rw[r][1] = (u32)(q12 >> (8 * sh));
+            rw[r][2] = d2 >> (8 * sh);
+        }
+        else
+        {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+            {
+                u32 v = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * j + e < 9) v |= (u32)rp[x - 4 + 4 * j + e] << (8 * e);
+                rw[r][j] = v;
+            }
+        }
+    }
+    auto px = [&](int r, int c) -> int { return (int)((rw[r][c >> 2] >> (8 * (c & 3))) & 0xFFu); };
+    // separable Sobel: dxr = p[c + 1] - p[c - 1], sxr = p[c - 1] + 2 p[c] + p[c + 1] per row; Ix = dxr(r - 1) + 2 dxr(r) + dxr(r + 1),
+    // Iy = sxr(r + 1) - sxr(r - 1) -- the integers of the written 3 x 3 form
+    int a = 0, bb = 0, c = 0;
+#pragma unroll
+    for (int cc = 1; cc <= 7; ++cc)
+    {
+        int dxr[9], sxr[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r)
+        {
+            const int p0 = px(r, cc - 1), p1 = px(r, cc), p2 = px(r, cc + 1);
+            dxr[r] = p2 - p0;
+            sxr[r] = p0 + 2 * p1 + p2;
+        }
+#pragma unroll
+        for (int r = 1; r <= 7; ++r)
+        {
+            const int Ix = dxr[r - 1] + 2 * dxr[r] + dxr[r + 1];
+            const int Iy = sxr[r + 1] - sxr[r - 1];
+            a += Ix * Ix;
+            bb += Iy * Iy;
+            c += Ix * Iy;
+        }
+    }
+    const float fa = (float)a, fb = (float)bb, fc = (float)c;
+    const float s4 = 0x1.bb9da2p-52f;  // (1 / (4 * 7 * 255))^4 in float, multiplied left to right
+    const float det = fa * fb - fc * fc;
+    const float tr  = fa + fb;
+    const float kt  = 0.04f * tr * tr;
+    cand_h[cell_index * CELL_SLOTS + lane] = harris_rank((det - kt) * s4);
+}
+
+// ------------------------------------------------------------------------------------------------
 // 7x7 Gaussian {18,33,49,56,49,33,18}/256 of every level (what the descriptors sample), streaming:
 // one WAVEFRONT walks down a column strip of 62 x 4 output pixels (lane = one aligned dword per row,
 // lanes 0 / 63 are the 3-pixel halo) through a band of 64 rows with the 7-row window held in
@@ -1142,7 +1242,10 @@ __device__ bool distribute_body(const Layout& L, int b, int l, int lds_cap, cons
                                 const u16* __restrict__ cell_cnt, u32* __restrict__ sel /* [B][total_slots] x|y<<16 */,
                                 u8* __restrict__ sel_score, int* __restrict__ sel_cnt,
                                 int* __restrict__ cand_total /* debug: [B][levels] */,
-                                unsigned long long* __restrict__ dbg_t = nullptr /* SNK_ORB_DIST_TIMING: [levels][16] cycle sums */)
+                                unsigned long long* __restrict__ dbg_t = nullptr /* SNK_ORB_DIST_TIMING: [levels][16] cycle sums */,
+                                const u32* __restrict__ cand_h = nullptr /* "orb.response" = 1: Harris rank per candidate slot */,
+                                u32* __restrict__ sel_resp = nullptr /* ... and the selected keypoints' ranks */,
+                                u32* __restrict__ h_global = nullptr /* ranks of this workgroup's candidates when the LDS carve has no room (full-budget launch) */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int cap     = lds_cap;      // LDS carve of this launch
@@ -1154,6 +1257,9 @@ __device__ bool distribute_body(const Layout& L, int b, int l, int lds_cap, cons
     u8* sc        = reinterpret_cast<u8*>(py + cap);
     signed char* lcp = reinterpret_cast<signed char*>(sc + cap);
     u8* fd        = reinterpret_cast<u8*>(lcp + cap + 16);
+    // Harris ranks of the gathered candidates: behind the carve (the launch adds 4 * cap bytes) or in global scratch
+    u32* hv       = cand_h ? (h_global ? h_global : reinterpret_cast<u32*>(smem + ((cap * 8 + cap / 2 * 8 + cap * 2 * 2 + cap + (cap + 16) + cap + 15) & ~15)))
+                           : nullptr;
     __shared__ int wave_tot[8];
     __shared__ int hist_lcp[20], hist_m[20];
     __shared__ int s_n, s_k, s_D, s_careful, s_size, s_nnodes, s_finish, s_jstar, s_out;
@@ -1174,6 +1280,7 @@ __device__ bool distribute_body(const Layout& L, int b, int l, int lds_cap, cons
     const int N     = lv.nfeat;
     const u16* cc   = cell_cnt + (long long)b * L.total_cells + lv.cell_off;
     const u32* cd   = cand + ((long long)b * L.total_cells + lv.cell_off) * CELL_SLOTS;
+    const u32* chd  = cand_h ? cand_h + ((long long)b * L.total_cells + lv.cell_off) * CELL_SLOTS : nullptr;
     int* out_cnt    = sel_cnt + b * MAX_LEVELS + l;
 
     // ---- 1. per-cell budget k: largest k <= CELL_SLOTS with sum(min(cnt, k)) <= cap -------------
@@ -1238,6 +1345,7 @@ __device__ bool distribute_body(const Layout& L, int b, int l, int lds_cap, cons
                                 px[o] = (u16)(x0 + 63 - (int)(k & 63u));
                                 py[o] = (u16)(y0 + 63 - (int)((k >> 6) & 63u));
                                 sc[o] = (u8)(k >> 12);
+                                if (hv) hv[o] = chd[(long long)c * CELL_SLOTS + i + 4 * v + u];
                             }
                     }
                 }
@@ -1542,7 +1650,7 @@ __device__ bool distribute_body(const Layout& L, int b, int l, int lds_cap, cons
         for (int i = tid; i < n; i += DIST_THREADS)
         {
             const int c = (int)(keys[i] & 0x1FFFu);
-            keys[i]     = ((u64)sc[c] << 32) | ((u64)(0xFFFFu - py[c]) << 16) | (u64)(0xFFFFu - px[c]);
+            keys[i]     = ((u64)(hv ? hv[c] : (u32)sc[c]) << 32) | ((u64)(0xFFFFu - py[c]) << 16) | (u64)(0xFFFFu - px[c]);
         }
         __syncthreads();
         unsigned long long* best = reinterpret_cast<unsigned long long*>(nodes);
@@ -1568,6 +1676,7 @@ __device__ bool distribute_body(const Layout& L, int b, int l, int lds_cap, cons
             const unsigned long long w = best[k];
             out[k]    = (0xFFFFu - (u32)(w & 0xFFFFu)) | ((0xFFFFu - (u32)((w >> 16) & 0xFFFFu)) << 16);
             out_sc[k] = (u8)(w >> 32);
+            if (sel_resp) sel_resp[(long long)b * L.total_slots + lv.slot_off + k] = (u32)(w >> 32);
         }
         if (tid == 0) *out_cnt = count;
     }
@@ -1581,10 +1690,11 @@ __global__ __launch_bounds__(DIST_THREADS, SNK_DIST_MIN_WAVES) void distribute_k
                                                                   const u16* __restrict__ cell_cnt, u32* __restrict__ sel,
                                                                   u8* __restrict__ sel_score, int* __restrict__ sel_cnt,
                                                                   int* __restrict__ cand_total, int* __restrict__ queue,
-                                                                  unsigned long long* __restrict__ dbg_t)
+                                                                  unsigned long long* __restrict__ dbg_t, const u32* __restrict__ cand_h,
+                                                                  u32* __restrict__ sel_resp)
 {
     const int l = blockIdx.x, b = blockIdx.y;
-    if (!distribute_body(L, b, l, lds_cap, cand, cell_cnt, sel, sel_score, sel_cnt, cand_total, dbg_t) && threadIdx.x == 0)
+    if (!distribute_body(L, b, l, lds_cap, cand, cell_cnt, sel, sel_score, sel_cnt, cand_total, dbg_t, cand_h, sel_resp) && threadIdx.x == 0)
         queue[1 + atomicAdd(&queue[0], 1)] = b * MAX_LEVELS + l;
 }
 
@@ -1593,13 +1703,15 @@ __global__ __launch_bounds__(DIST_THREADS) void distribute_large_kernel(Layout L
                                                                         const u16* __restrict__ cell_cnt,
                                                                         u32* __restrict__ sel, u8* __restrict__ sel_score,
                                                                         int* __restrict__ sel_cnt, int* __restrict__ cand_total,
-                                                                        const int* __restrict__ queue)
+                                                                        const int* __restrict__ queue, const u32* __restrict__ cand_h,
+                                                                        u32* __restrict__ sel_resp, u32* __restrict__ h_scratch)
 {
     const int count = queue[0];
     for (int i = blockIdx.x; i < count; i += gridDim.x)
     {
         const int item = queue[1 + i];
-        distribute_body(L, item / MAX_LEVELS, item % MAX_LEVELS, L.level_cap, cand, cell_cnt, sel, sel_score, sel_cnt, cand_total);
+        distribute_body(L, item / MAX_LEVELS, item % MAX_LEVELS, L.level_cap, cand, cell_cnt, sel, sel_score, sel_cnt, cand_total, nullptr,
+                        cand_h, sel_resp, cand_h ? h_scratch + (size_t)blockIdx.x * L.level_cap : nullptr);
         __syncthreads();
     }
 }
@@ -1684,7 +1796,8 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
                                                        long long stride0, int aligned0, const u32* __restrict__ sel,
                                                        const u8* __restrict__ sel_score, const int* __restrict__ sel_cnt,
                                                        snk_keypoint* __restrict__ kps, u64* __restrict__ desc,
-                                                       int* __restrict__ n_out, int out_cap, int gx, int batch, int dbg_fake)
+                                                       int* __restrict__ n_out, int out_cap, int gx, int batch, int dbg_fake,
+                                                       const u32* __restrict__ sel_resp /* "orb.response" = 1: Harris ranks, else NULL */)
 {
     __shared__ uint2 mtab[4 * MOM_PAD];
     __shared__ __attribute__((aligned(16))) u32 patch[4][PATCH_ITEMS + 16];
@@ -1781,7 +1894,7 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
         {
             const int slot = slot0 + s;
             const u32 xy   = sel[sbase + (valid[s] ? slot : slot0)];
-            scv[s]         = sel_score[sbase + (valid[s] ? slot : slot0)];
+            scv[s]         = sel_resp ? (int)sel_resp[sbase + (valid[s] ? slot : slot0)] : (int)sel_score[sbase + (valid[s] ? slot : slot0)];
             kxv[s]         = (int)(xy & 0xFFFFu);
             kyv[s]         = (int)(xy >> 16);
         }
@@ -1914,7 +2027,7 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
             kp.y        = (float)ky * lv.scale;
             kp.size     = 31.0f * lv.scale;
             kp.angle    = angle;
-            kp.response = (float)(scv[s] - 1);
+            kp.response = sel_resp ? harris_unrank((u32)scv[s]) : (float)(scv[s] - 1);
             kp.octave   = l;
             kps[(long long)b * out_cap + oi] = kp;
             u64* d = desc + ((long long)b * out_cap + oi) * 4;
@@ -1942,6 +2055,7 @@ struct snk_orb : HandleBase
     DevBuf cell_tab;         // FAST cell geometry
     DevBuf img0;             // level-0 staging for the host API
     DevBuf cand, cell_cnt, sel, sel_score, sel_cnt, cand_total, dist_queue;
+    DevBuf cand_h, sel_resp, dist_h;  // "orb.response" = 1 only (reserved by the first call that runs under it)
     DevBuf out_kps;          // host-API staging: [count | pad to 64 B][cap keypoints][cap descriptors], fetched with ONE copy
     HostBuf h_out, h_img;    // pinned mirrors of out_kps / img0
     int pitch0_host = 0;
@@ -2162,6 +2276,9 @@ int snk_orb_destroy(snk_orb* o)
     o->sel_cnt.release();
     o->cand_total.release();
     o->dist_queue.release();
+    o->cand_h.release();
+    o->sel_resp.release();
+    o->dist_h.release();
     o->out_kps.release();
     o->h_out.release();
     o->h_img.release();
@@ -2292,7 +2409,7 @@ int snk_orb_configure(snk_orb* o, int width, int height, int max_batch)
     // process-wide, once per kernel, to the largest carve any handle can ask for (never per-handle sizes: two extractors
     // with different image sizes / level_cap would overwrite each other's limit)
     SNK_REQUIRE(4 * L.f_lds_wave <= LDS_MAX_BYTES, "FAST cells too large for the LDS (image too small for its cell grid?)");
-    if ((rc = set_max_lds_once(reinterpret_cast<const void*>(distribute_kernel), (int)dist_lds_bytes(2048))) != SNK_OK) return rc;
+    if ((rc = set_max_lds_once(reinterpret_cast<const void*>(distribute_kernel), (int)dist_lds_bytes(2048) + 4 * 2048 + 16)) != SNK_OK) return rc;  // + the Harris ranks ("orb.response" = 1)
     if ((rc = set_max_lds_once(reinterpret_cast<const void*>(distribute_large_kernel), (int)dist_lds_bytes(8192))) != SNK_OK) return rc;
     if ((rc = set_max_lds_once(fast_kernel_for(L, false), LDS_MAX_BYTES)) != SNK_OK) return rc;
     if ((rc = set_max_lds_once(fast_kernel_for(L, true), LDS_MAX_BYTES)) != SNK_OK) return rc;
@@ -2347,6 +2464,25 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
     int* d_selcnt   = o->sel_cnt.as<int>() + (size_t)b0 * MAX_LEVELS;
     int* d_candtot  = o->cand_total.as<int>() + (size_t)b0 * MAX_LEVELS;
     int* d_queue    = o->dist_queue.as<int>() + (size_t)part * ((size_t)o->max_batch * MAX_LEVELS + 1);
+    // "orb.response" = 1 (snk_set_definition): Harris response of the FAST candidates ranks the points of a quadtree node and is the
+    // keypoints' response.  Its scratch is reserved by the first call that runs under it (a growing reserve synchronises the device).
+    const bool harris = definition(DEF_ORB_RESPONSE) == 1;
+    u32 *d_candh = nullptr, *d_selresp = nullptr, *d_disth = nullptr;
+    const int large_workers = L.n_levels * batch < 256 ? L.n_levels * batch : 256;
+    if (harris)
+    {
+        const size_t cells = (size_t)(L.total_cells > 0 ? L.total_cells : 1) * o->max_batch;
+        const size_t slots = (size_t)(L.total_slots > 0 ? L.total_slots : 1) * o->max_batch;
+        int rc;
+        if ((rc = o->cand_h.reserve(cells * CELL_SLOTS * sizeof(u32))) != SNK_OK) return rc;
+        if ((rc = o->sel_resp.reserve(slots * sizeof(u32))) != SNK_OK) return rc;
+        if (o->dist_small_cap < L.level_cap &&
+            (rc = o->dist_h.reserve((size_t)snk_orb::MAX_PARTS * 256 * L.level_cap * sizeof(u32))) != SNK_OK)
+            return rc;
+        d_candh   = o->cand_h.as<u32>() + (size_t)b0 * L.total_cells * CELL_SLOTS;
+        d_selresp = o->sel_resp.as<u32>() + (size_t)b0 * L.total_slots;
+        d_disth   = o->dist_h.as<u32>() ? o->dist_h.as<u32>() + (size_t)part * 256 * L.level_cap : nullptr;
+    }
     std::array<hipEvent_t, 7>* ev = nullptr;
     if (o->profiling)
     {
@@ -2444,9 +2580,17 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
         SNK_HIP_CHECK(hipMalloc(&d_dbg, MAX_LEVELS * 16 * sizeof(unsigned long long)));
         SNK_HIP_CHECK(hipMemsetAsync(d_dbg, 0, MAX_LEVELS * 16 * sizeof(unsigned long long), st));
     }
-    hipLaunchKernelGGL(distribute_kernel, dim3(L.n_levels, batch), dim3(DIST_THREADS), o->dist_lds_small, st, L,
+    if (harris && L.total_cells > 0)
+    {
+        const int gxh = ceil_div(L.total_cells, 4);
+        hipLaunchKernelGGL(harris_kernel, xcd_grid(gxh, batch), dim3(256), 0, st, L, images_dev, pitch, image_stride, aligned0, d_cand, d_cellcnt,
+                           d_candh, gxh, batch);
+        SNK_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(distribute_kernel, dim3(L.n_levels, batch), dim3(DIST_THREADS),
+                       o->dist_lds_small + (harris ? 4 * (size_t)o->dist_small_cap + 16 : 0), st, L,
                        o->dist_small_cap, d_cand, d_cellcnt, d_sel, d_selscore,
-                       d_selcnt, d_candtot, d_queue, d_dbg);
+                       d_selcnt, d_candtot, d_queue, d_dbg, d_candh, d_selresp);
     SNK_LAUNCH_CHECK();
     if (dist_timing)
     {
@@ -2464,10 +2608,9 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
     }
     if (o->dist_small_cap < L.level_cap)
     {
-        const int workers = L.n_levels * batch < 256 ? L.n_levels * batch : 256;
-        hipLaunchKernelGGL(distribute_large_kernel, dim3(workers), dim3(DIST_THREADS), o->dist_lds, st, L,
+        hipLaunchKernelGGL(distribute_large_kernel, dim3(large_workers), dim3(DIST_THREADS), o->dist_lds, st, L,
                            d_cand, d_cellcnt, d_sel, d_selscore,
-                           d_selcnt, d_candtot, d_queue);
+                           d_selcnt, d_candtot, d_queue, d_candh, d_selresp, d_disth);
         SNK_LAUNCH_CHECK();
     }
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[4], st));
@@ -2478,7 +2621,7 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
         const int nb = batch >= 16 ? 8 * ceil_div(batch, 8) : batch;
         hipLaunchKernelGGL(describe_kernel, dim3(gx * L.n_levels * nb), dim3(256), 0, st, L, images_dev, pitch, image_stride,
                            aligned0, d_sel, d_selscore, d_selcnt, kps_dev, (u64*)desc_dev, n_dev, out_cap, gx, batch,
-                           getenv("SNK_ORB_DESC_FAKE") ? atoi(getenv("SNK_ORB_DESC_FAKE")) : 0);
+                           getenv("SNK_ORB_DESC_FAKE") ? atoi(getenv("SNK_ORB_DESC_FAKE")) : 0, d_selresp);
     }
     SNK_LAUNCH_CHECK();
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[5], st));

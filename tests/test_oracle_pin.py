@@ -117,3 +117,26 @@ def test_brief_steering_against_skimage():
                 co = [c * pat[b, 0] - s * pat[b, 1], s * pat[b, 0] + c * pat[b, 1], c * pat[b, 2] - s * pat[b, 3], s * pat[b, 2] + c * pat[b, 3]]
                 assert min(abs(abs(v - np.floor(v)) - 0.5) for v in co) < 1e-3, (deg, k, b, co)
     assert n_all == 9 * len(g["xs"]) * 256 and n_diff <= n_all // 2000, (n_diff, n_all)
+
+
+def test_harris_response_against_skimage_derivatives(orc):
+    """Round 5 ("orb.response" = 1): the oracle's Harris response against tests/golden/skimage_pin3.npz -- the 7 x 7 box sums of
+    skimage's Sobel derivative products (exact integers) and det - 0.04 trace^2 on them in double (pin_against_skimage3.py).  The three
+    sums must be equal, the float response equal to float rounding, the rank map order-preserving; skimage's own corner_harris (a
+    Gaussian window) must rank the FAST corners among the points almost identically."""
+    P = np.load(G / "skimage_pin3.npz")
+    img = np.ascontiguousarray(PIN["img"])
+    resp = np.zeros(len(P["xs"]), np.float32)
+    for i, (x, y) in enumerate(zip(P["xs"], P["ys"])):
+        assert orc.harris_abc(img, x, y) == (int(P["a"][i]), int(P["b"][i]), int(P["c"][i])), (x, y)
+        resp[i] = orc.harris_response(img, x, y)
+    want = P["response"]
+    # float rounding of the three terms before their (cancelling) difference: 1e-6 of their magnitudes
+    A, B, Cc = (P[k].astype(np.float64) for k in "abc")
+    mag = (A * B + Cc * Cc + 0.04 * (A + B) ** 2) * (1.0 / 7140.0) ** 4
+    assert np.all(np.abs(resp - want) <= 1e-6 * mag)
+    assert (resp < 0).any() and (resp > 0).any()  # edges and corners
+    order = np.argsort(resp, kind="stable")
+    ranks = np.array([orc.harris_rank(r) for r in resp], np.uint64)
+    assert np.all(np.diff(ranks[order].astype(np.int64)) >= 0), "harris_rank must preserve the order of the float response"
+    assert float(P["spearman"]) > 0.8

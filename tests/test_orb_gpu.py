@@ -9,6 +9,26 @@ from helpers import SEED
 pytestmark = pytest.mark.gpu
 
 
+HARRIS = {"on": False}  # set by the `harris` fixture: stage_check then ranks the oracle's distribution like "orb.response" = 1
+
+
+@pytest.fixture
+def harris(orc):
+    """snk_set_definition("orb.response", 1) on both sides (the Harris response of the FAST corners ranks the points of a quadtree
+    node and is the keypoints' response), restored afterwards."""
+    from snake_slam_amd import _lib
+
+    _lib.set_definition("orb.response", 1)
+    orc.set_definition("orb.response", 1)
+    HARRIS["on"] = True
+    try:
+        yield
+    finally:
+        HARRIS["on"] = False
+        _lib.set_definition("orb.response", 0)
+        orc.set_definition("orb.response", 0)
+
+
 def stage_check(ext, orc, img, p):
     """Compare pyramid, per-cell candidates and per-level selections with the oracle."""
     from snake_slam_amd import orb as O
@@ -36,7 +56,11 @@ def stage_check(ext, orc, img, p):
                 k = int(k)
                 got.add((x0 + 63 - (k & 63), y0 + 63 - ((k >> 6) & 63), k >> 12))
             assert got == want.get(cell, set()), f"level {l} cell {cell}: candidates differ"
-        sel = orc.distribute(cand, w, h, L.nfeat[l])
+        if HARRIS["on"]:
+            rank = np.array([orc.harris_rank(orc.harris_response(levels[l], int(c["x"]), int(c["y"]))) for c in cand], np.uint32)
+            sel = orc.distribute_ranked(cand, rank, w, h, L.nfeat[l])
+        else:
+            sel = orc.distribute(cand, w, h, L.nfeat[l])
         n_sel = int(ext.debug_fetch(O.DEBUG_SELECTED_COUNT, 0, l, np.int32)[0])
         got_sel = ext.debug_fetch(O.DEBUG_SELECTED, 0, l, np.uint32)[:n_sel]
         want_sel = [(int(cand[i]["x"]) | (int(cand[i]["y"]) << 16)) for i in sel]
@@ -414,3 +438,112 @@ def test_levels_scaled_down_to_nothing(orc):
     for shape, levels, scale in [((40, 1300), 8, 2.5), ((60, 45), 8, 2.5), ((45, 70), 8, 2.0), ((800, 48), 7, 2.5)]:
         img = rng.integers(0, 256, shape, dtype=np.uint8)
         check_image(orc, img, 400, levels, scale, 20, 7, stages=False)
+
+
+def test_harris_response_parity(orc, harris):
+    """north_star's "Harris score" as the definition switch "orb.response" = 1: BASELINE configs 2 and 3 at full size, bit for bit
+    (keypoints, the float response, descriptors), stage by stage; and the switch changes the result (it is not a no-op)."""
+    from snake_slam_amd import _lib, synth
+    from snake_slam_amd.orb import ORBExtractor
+
+    left, right = synth.stereo_frame(0)
+    assert check_image(orc, left) >= 1000
+    assert check_image(orc, right) >= 1000
+    kitti, _ = synth.stereo_frame(1, 1241, 376, n_rects=600)
+    assert check_image(orc, kitti, 2000, 7) >= 1500
+    ext = ORBExtractor(1000, 1.2, 4, 20, 7)
+    try:
+        k1, _ = ext.Detect(left)
+        _lib.set_definition("orb.response", 0)
+        k0, _ = ext.Detect(left)
+        _lib.set_definition("orb.response", 1)
+    finally:
+        ext.close()
+    assert len(k0) == len(k1)
+    same = set(zip(k0["x"], k0["y"], k0["octave"])) & set(zip(k1["x"], k1["y"], k1["octave"]))
+    assert 0.3 * len(k0) < len(same) < len(k0), "Harris ranking must move some keypoints, not all"
+    assert np.all(k0["response"] == np.round(k0["response"])) and not np.all(k1["response"] == np.round(k1["response"]))
+
+
+@pytest.mark.parametrize("shape", [(480, 752), (200, 120), (97, 131), (40, 45)])
+def test_harris_on_noise_images(orc, harris, shape):
+    """Uniform noise under "orb.response" = 1: the 64-per-cell cap and the level budget (both on the FAST score) feed the Harris
+    ranking; negative responses (edges) occur and must order correctly."""
+    rng = np.random.default_rng(SEED + 5 * shape[0])
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    check_image(orc, img, 1000, 4)
+
+
+def test_harris_random_shapes_unaligned_and_large(orc, harris):
+    """Random shapes / parameters; a level-0 view whose rows are not 4-byte aligned (byte loads in harris_kernel); a 2000 x 1500
+    image whose levels exceed the 2048-candidate LDS carve (ranks of the full-budget launch live in global scratch)."""
+    from snake_slam_amd import synth
+
+    rng = np.random.default_rng(SEED + 123)
+    for k in range(8):
+        w, h = int(rng.integers(40, 420)), int(rng.integers(40, 320))
+        levels, scale = int(rng.integers(1, 9)), float(rng.choice([1.1, 1.2, 1.3, 1.5, 2.0]))
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8) if k % 2 else synth.stereo_frame(300 + k, w, h, n_rects=60)[0]
+        check_image(orc, img, int(rng.integers(50, 1500)), levels, scale, int(rng.integers(10, 40)), int(rng.integers(3, 10)), stages=(k < 3))
+    big, _ = synth.stereo_frame(77, 2000, 1500, n_rects=2500)
+    assert check_image(orc, big, 5000, 8, 1.2, 20, 7, stages=False) >= 5000
+    noise = rng.integers(0, 256, (700, 900), dtype=np.uint8)  # > 2048 candidates on level 0: distribute_large_kernel
+    check_image(orc, noise, 3000, 3, 1.2, 20, 7, stages=False)
+
+
+def test_harris_batch_dev_and_frontend(orc, harris):
+    """The device-resident batch entry point (XCD-mapped, >= 16 images) and the one-call front-end (hipGraph keyed by the
+    definition: flipping the switch between frames must rebuild it) under "orb.response" = 1."""
+    import torch
+    from snake_slam_amd import _lib, synth
+    from snake_slam_amd.orb import ORBExtractor, KEYPOINT_DTYPE
+
+    B, W, H = 18, 320, 240
+    imgs = [synth.stereo_frame(i, W, H, n_rects=150)[i % 2] for i in range(B)]
+    ext = ORBExtractor(300, 1.2, 3, 20, 7)
+    try:
+        cap = ext.configure(W, H, B)
+        dev = torch.device("cuda:0")
+        d_img = torch.from_numpy(np.stack(imgs)).to(dev)
+        d_kps = torch.zeros((B, cap, 24), dtype=torch.uint8, device=dev)
+        d_desc = torch.zeros((B, cap, 4), dtype=torch.int64, device=dev)
+        d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ext.detect_batch_dev(d_img, d_kps, d_desc, d_n)
+        ext.sync()
+        n = d_n.cpu().numpy()
+        kps = d_kps.cpu().numpy().view(KEYPOINT_DTYPE).reshape(B, cap)
+        desc = d_desc.cpu().numpy().view(np.uint64)
+        p = orc.orb_params(300, 1.2, 3, 20, 7)
+        for i in range(B):
+            wk, wd = orc.orb_detect(p, imgs[i])
+            assert n[i] == len(wk), f"image {i}"
+            assert np.array_equal(kps[i, : n[i]], wk.astype(KEYPOINT_DTYPE)) and np.array_equal(desc[i, : n[i]], wd), f"image {i}"
+    finally:
+        ext.close()
+
+    # the one-call front-end: frames 1-3 under Harris (uncaptured, captured, replayed), then the switch flips back and forth
+    from snake_slam_amd.frontend import Frontend
+    from snake_slam_amd.matcher import Rectification
+
+    left, right = synth.stereo_frame(3, 752, 480)
+    e_k, e_d = (458.654, 457.296, 367.215, 248.375), (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0, 0.0, 0.0, 0.0)
+    rect = Rectification.make(e_k, e_d)
+    fe = Frontend((1000, 1.2, 4, 20, 7), rect, rect, (-120.0, -60.0, 880.0, 540.0), 47.9)
+    p = orc.orb_params(1000, 1.2, 4, 20, 7)
+    try:
+        for mode in (1, 1, 1, 0, 0, 1, 1):
+            _lib.set_definition("orb.response", mode)
+            orc.set_definition("orb.response", mode)
+            fr = fe.Process(left, right)
+            wk, _ = orc.orb_detect(p, left)
+            wr, wdr = orc.orb_detect(p, right)
+            assert fr["N"] == len(wk) and fr["n_right"] == len(wr), mode
+            # the left keypoints come back in grid order: compare as multisets of (x, y, octave, response)
+            k = fr["keypoints"]
+            got = sorted(zip(k["x"], k["y"], k["octave"], k["response"]))
+            want = sorted(zip(wk["x"], wk["y"], wk["octave"], wk["response"]))
+            assert got == want, mode
+            assert np.array_equal(fr["keypoints_right"], wr.astype(KEYPOINT_DTYPE)) and np.array_equal(fr["descriptors_right"], wdr), mode
+    finally:
+        fe.close()

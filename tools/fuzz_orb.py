@@ -13,7 +13,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle as orc  # noqa: E402
-from snake_slam_amd import synth  # noqa: E402
+from snake_slam_amd import _lib, synth  # noqa: E402
 from snake_slam_amd.orb import ORBExtractor  # noqa: E402
 
 
@@ -50,6 +50,9 @@ def main():
         scale = float(rng.choice([1.05, 1.1, 1.2, 1.3, 1.5, 2.0, 2.5]))
         ini, mn = int(rng.integers(8, 40)), int(rng.integers(2, 9))
         img = np.ascontiguousarray(image(rng, w, h))
+        resp = int(rng.integers(0, 2))  # "orb.response": FAST score / Harris response, both sides
+        _lib.set_definition("orb.response", resp)
+        orc.set_definition("orb.response", resp)
         ext = ORBExtractor(nfeat, scale, levels, ini, mn)
         try:
             kps, desc = ext.Detect(img)
@@ -60,7 +63,7 @@ def main():
             and np.array_equal(desc, wd)
         if not ok:
             np.save("fuzz_orb_failure.npy", img)
-            print(f"MISMATCH case {n}: {w}x{h} nfeat {nfeat} levels {levels} scale {scale} th {ini}/{mn}: {len(kps)} vs {len(wk)} keypoints "
+            print(f"MISMATCH case {n}: {w}x{h} nfeat {nfeat} levels {levels} scale {scale} th {ini}/{mn} orb.response {resp}: {len(kps)} vs {len(wk)} keypoints "
                   "(image saved to fuzz_orb_failure.npy)")
             return 1
         n += 1
