@@ -783,6 +783,38 @@ SNK_API int snk_ba_solve_local_scene(snk_ba* h, int problem, double chi2_mono, d
                                      uint8_t* obs_outlier, int* n_marked, double* cost_initial, double* cost_final,
                                      double (*pose)[7], double (*pt)[3]);
 
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU result gather (BASELINE config 5: one sequence per GPU)
+ * ------------------------------------------------------------------------------------------
+ * The path shards over independent units -- one Snake-SLAM process and one sequence per GPU -- and exchanges nothing while it
+ * runs.  When a rank is done it holds what the reference writes per run: the TUM trajectory (Snake/System/System.cpp:552-563,
+ * "timestamp tx ty tz qx qy qz qw" per frame) and a few counters.  These entry points gather such fixed-size blocks across the
+ * ranks with ONE RCCL all-gather over xGMI, without torch.distributed or MPI in the process.  RCCL is opened at run time (dlopen
+ * by SONAME librccl.so.1; SNK_RCCL_LIB overrides): the library has no link-time dependency on it.
+ * Replaces: nothing in the reference (it is a single-GPU program); serves the "RCCL/xGMI only for result gather" of north_star.
+ * One handle per process / GPU; calls on a handle are serial. */
+typedef struct snk_dist snk_dist;
+#define SNK_DIST_ID_BYTES 128 /* = NCCL_UNIQUE_ID_BYTES */
+
+/* Rank 0 creates the 128-byte communicator id and hands it to the other ranks by any means (environment, file, socket). */
+SNK_API int snk_dist_get_unique_id(uint8_t id[SNK_DIST_ID_BYTES]);
+/* Collective over all `world` ranks (ncclCommInitRank): rank r runs on HIP device `device`.  Returns when every rank has called. */
+SNK_API int snk_dist_init(const uint8_t id[SNK_DIST_ID_BYTES], int rank, int world, int device, snk_dist** out);
+/* The same with the id passed through a file all ranks can see: rank 0 writes `path` (atomically), the others wait up to
+ * timeout_s seconds (<= 0: 60) for it.  A fresh path per job. */
+SNK_API int snk_dist_init_file(const char* path, int rank, int world, int device, double timeout_s, snk_dist** out);
+SNK_API int snk_dist_destroy(snk_dist* d);
+SNK_API int snk_dist_rank(const snk_dist* d, int* rank, int* world);
+/* recv[r * bytes .. (r + 1) * bytes) = rank r's `send` block, on every rank; every rank passes the same `bytes`.  Host memory
+ * (staged through one pinned buffer: upload, ncclAllGather on the handle's stream, download, one synchronisation). */
+SNK_API int snk_dist_all_gather(snk_dist* d, const void* send, size_t bytes, void* recv);
+/* Device memory, no staging; returns after the handle's stream has drained. */
+SNK_API int snk_dist_all_gather_dev(snk_dist* d, const void* send_dev, size_t bytes, void* recv_dev);
+/* Maximum of one value per rank on every rank (the longest trajectory: blocks are padded to it); doubles as a barrier. */
+SNK_API int snk_dist_max_i64(snk_dist* d, int64_t value, int64_t* out);
+/* ncclGetVersion of the RCCL this process resolved (SNK_ERR_NO_DEVICE when none can be opened). */
+SNK_API int snk_dist_rccl_version(int* version);
+
 #ifdef __cplusplus
 }
 #endif

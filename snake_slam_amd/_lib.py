@@ -105,6 +105,15 @@ SIGNATURES = {
     "snk_ba_get_state": (i32, [vp, i32, vp, vp, C.POINTER(i32)]),
     "snk_ba_residuals": (i32, [vp, i32, vp]),
     "snk_ba_solve_local_scene": (i32, [vp, i32, f64, f64, i32, vp, vp, vp, vp, vp, vp]),
+    "snk_dist_get_unique_id": (i32, [vp]),
+    "snk_dist_init": (i32, [vp, i32, i32, i32, C.POINTER(vp)]),
+    "snk_dist_init_file": (i32, [C.c_char_p, i32, i32, i32, f64, C.POINTER(vp)]),
+    "snk_dist_destroy": (i32, [vp]),
+    "snk_dist_rank": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
+    "snk_dist_all_gather": (i32, [vp, vp, C.c_size_t, vp]),
+    "snk_dist_all_gather_dev": (i32, [vp, vp, C.c_size_t, vp]),
+    "snk_dist_max_i64": (i32, [vp, C.c_int64, C.POINTER(C.c_int64)]),
+    "snk_dist_rccl_version": (i32, [C.POINTER(i32)]),
 }
 
 

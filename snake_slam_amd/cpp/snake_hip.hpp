@@ -13,6 +13,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -838,4 +839,79 @@ inline KeyPointD cast_double(const snk_keypoint& k)
 {
     return KeyPointD{(double)k.x, (double)k.y, (double)k.size, (double)k.angle, (double)k.response, k.octave, 0};
 }
+// ------------------------------------------------------------------------------------------------
+// One Snake-SLAM process per GPU (BASELINE config 5): gather every rank's results with RCCL over xGMI, no MPI / torch in the process.
+// A rank's block is what System::writeFrameTrajectory writes for its sequence (Snake/System/System.cpp:546-563): one
+// {timestamp, tx, ty, tz, qx, qy, qz, qw} row per frame with a valid pose.
+// ------------------------------------------------------------------------------------------------
+struct TumPose
+{
+    double t, tx, ty, tz, qx, qy, qz, qw;
+};
+
+class Dist
+{
+   public:
+    // rendezvous through a file all ranks see (snk_dist_init_file): a fresh path per job
+    Dist(const std::string& rendezvous_file, int rank, int world, int device, double timeout_s = 60.0)
+    {
+        check(snk_dist_init_file(rendezvous_file.c_str(), rank, world, device, timeout_s, &h_), "snk_dist_init_file");
+        rank_ = rank;
+        world_ = world;
+        if (rank == 0) file_ = rendezvous_file;
+    }
+    // the 128-byte id was handed around by the launcher
+    Dist(const uint8_t id[SNK_DIST_ID_BYTES], int rank, int world, int device)
+    {
+        check(snk_dist_init(id, rank, world, device, &h_), "snk_dist_init");
+        rank_ = rank;
+        world_ = world;
+    }
+    ~Dist()
+    {
+        snk_dist_destroy(h_);
+        if (!file_.empty()) std::remove(file_.c_str());
+    }
+    Dist(const Dist&)            = delete;
+    Dist& operator=(const Dist&) = delete;
+    int rank() const { return rank_; }
+    int world() const { return world_; }
+
+    // all ranks' trajectories on every rank: result[r] = rank r's rows.  Two collectives: the longest trajectory (blocks are padded to
+    // it), then ONE all-gather of {n, rows} blocks -- the exchange SURVEY.md section 8e describes (~236 KB per rank for MH_01).
+    std::vector<std::vector<TumPose>> GatherTrajectories(const std::vector<TumPose>& mine)
+    {
+        int64_t longest = 0;
+        check(snk_dist_max_i64(h_, (int64_t)mine.size(), &longest), "snk_dist_max_i64");
+        const size_t block = 8 + (size_t)longest * sizeof(TumPose);  // {int64 n, rows}
+        std::vector<uint8_t> send(block, 0), recv(block * (size_t)world_);
+        const int64_t n = (int64_t)mine.size();
+        std::memcpy(send.data(), &n, 8);
+        if (n) std::memcpy(send.data() + 8, mine.data(), (size_t)n * sizeof(TumPose));
+        check(snk_dist_all_gather(h_, send.data(), block, recv.data()), "snk_dist_all_gather");
+        std::vector<std::vector<TumPose>> all((size_t)world_);
+        for (int r = 0; r < world_; ++r)
+        {
+            int64_t nr = 0;
+            std::memcpy(&nr, recv.data() + (size_t)r * block, 8);
+            all[(size_t)r].resize((size_t)nr);
+            if (nr) std::memcpy(all[(size_t)r].data(), recv.data() + (size_t)r * block + 8, (size_t)nr * sizeof(TumPose));
+        }
+        return all;
+    }
+    // any fixed-size block per rank (counters: frames, frames/s, matches, BA costs)
+    template <typename T>
+    std::vector<T> GatherBlocks(const T& mine)
+    {
+        static_assert(std::is_trivially_copyable<T>::value, "plain data only");
+        std::vector<T> all((size_t)world_);
+        check(snk_dist_all_gather(h_, &mine, sizeof(T), all.data()), "snk_dist_all_gather");
+        return all;
+    }
+
+   private:
+    snk_dist* h_ = nullptr;
+    int rank_ = 0, world_ = 1;
+    std::string file_;
+};
 }  // namespace snake_hip

@@ -27,7 +27,17 @@ def init_distributed(device: torch.device | None = None, backend: str | None = N
     if world <= 1 and not os.environ.get("SNK_DIST_FORCE"):
         return 0, 1
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29531")
+    if "MASTER_PORT" not in os.environ:
+        # torchrun / the driver export MASTER_PORT for every multi-rank job.  Without a launcher only the one-rank rehearsal gets here:
+        # it takes a port the kernel hands out (a fixed default made two jobs on one node collide); ranks of a real job cannot agree
+        # on a port by themselves, so that is an error rather than a guess.
+        if world > 1:
+            raise RuntimeError("WORLD_SIZE > 1 but MASTER_PORT is not set: launch with torch.distributed.run (or export MASTER_ADDR / MASTER_PORT)")
+        import socket
+
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend is None:
         # SNK_DIST_BACKEND=gloo: rehearsal of the multi-rank code on a box with one GPU (every rank on the same device, see

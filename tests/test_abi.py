@@ -81,3 +81,25 @@ def test_definition_switches_abi():
         _lib.set_definition("no.such.key", 0)
     with pytest.raises(SnakeHipError):
         _lib.get_definition("no.such.key")
+
+
+def test_dist_entry_points_fail_loudly_without_a_device():
+    """snk_dist_* (RCCL result gather, include/snake_hip.h): argument checks need no device; creating a communicator without a GPU
+    returns a status and an error text instead of crashing (RCCL is only opened here, by dlopen -- the library itself must load on a
+    box without RCCL, which the export test above already proves for this container's CPU-only run)."""
+    import ctypes as C
+
+    import torch
+
+    from snake_slam_amd import _lib
+
+    lib = _lib.load()
+    h = C.c_void_p()
+    ident = (C.c_uint8 * 128)()
+    assert lib.snk_dist_init(ident, 2, 2, 0, C.byref(h)) != 0 and b"rank" in lib.snk_last_error()
+    assert lib.snk_dist_init(None, 0, 1, 0, C.byref(h)) != 0
+    assert lib.snk_dist_init_file(b"", 0, 1, 0, 1.0, C.byref(h)) != 0
+    assert lib.snk_dist_destroy(None) == 0
+    if not torch.cuda.is_available():
+        assert lib.snk_dist_get_unique_id(ident) != 0 or lib.snk_dist_init(ident, 0, 1, 0, C.byref(h)) != 0
+        assert len(lib.snk_last_error()) > 0
