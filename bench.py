@@ -353,6 +353,33 @@ def lockstep_sequence_mode(args, rank, world, local, dev, n_frames):
     trk.close()
 
 
+def kitti_leg(args):
+    """BASELINE.json configs[2] (KITTI seq 00 stereo 1241x376, 2000 features, 7 levels; reference configs/kitti.ini:30-34) as part of the
+    default line: this script once more with --workload kitti (front-end only, 512 stereo frames per step, outputs of the last step
+    checked bit for bit against the oracle on a few frames), its line cut down to the measured keys.  Runs after the EuRoC legs have
+    released the GPU's memory; a failure is reported in the line, it does not take the headline down."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "kitti", "--steps", str(args.kitti_steps), "--warmup", "2", "--batch", "512",
+           "--ba-windows", "0", "--gba-keyframes", "0", "--pose-frames", "0", "--track-frames", "0", "--frame-calls", "0", "--kitti-steps", "0",
+           "--cpu-seconds", "3", "--check-frames", "16", "--distinct", "64"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+        if r.returncode != 0 or not line:
+            return {"error": f"kitti leg failed (status {r.returncode}): {r.stderr[-300:]}"}
+        d = json.loads(line[-1])
+        keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "data", "config", "roofline", "pipeline_roofline", "stage_ms_per_step",
+                "keypoints_per_image", "stereo_matches_per_frame")
+        k = {key: d[key] for key in keep if key in d}
+        cb = d.get("cpu_baseline", {})
+        k["checked_against_oracle"] = {key: cb[key] for key in ("identical_to_gpu", "frames_checked") if key in cb}
+        k["cpu_baseline"] = {key: cb[key] for key in ("value", "unit", "cores", "kind", "sample") if key in cb}
+        return k
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"kitti leg: {e!r}"}
+
+
 def spawn_ranks_if_needed(args):
     """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset) starts its own N ranks: it re-executes this very command
     line under `torch.distributed.run --nproc-per-node N` on 127.0.0.1 (one process per GPU, rank r on GPU r) and exits with the
@@ -404,7 +431,7 @@ def _pipeline_traffic(section, sources):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="stereo frames per GPU per step (1024 = 2048 images = 0.74 GB of input resident in "
                     "HBM; every kernel of the chain ends in a tail of a few microseconds, measured 154 / 172 / 181 / 185 k frames/s at 128 / 256 / "
@@ -448,6 +475,9 @@ def main():
     ap.add_argument("--check-frames", type=int, default=256, help="frames of the last timed step whose outputs in HBM are compared "
                     "bit for bit with the oracle's (those the CPU baseline reaches in its time budget)")
     ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events")
+    ap.add_argument("--kitti-steps", type=int, default=20, help="steps of the KITTI leg of the default line (BASELINE.json configs[2]: 1241x376 stereo, 2000 "
+                    "features, 7 levels; this script re-run with --workload kitti on 512 frames per step once the EuRoC legs are done, its line "
+                    "embedded under \"kitti\"; 0 = skip; single GPU, euroc workload only)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
@@ -742,7 +772,12 @@ def main():
         fe.Process(*pairs[0])
         lib_ = L_.load()
 
+        # both sides at the same layer: the Python wrappers (each allocates / copies its result arrays); the bare C ABI call is timed
+        # beside them, and without Python by tools/cpp/frontend_latency.cpp
         def one_call(l, r):
+            return fe.Process(l, r)
+
+        def one_call_abi(l, r):
             return lib_.snk_frontend_process(fe._h, l.ctypes.data, W, r.ctypes.data, W, W, H, C.byref(fe._frame))
 
         def six_calls(l, r):
@@ -756,7 +791,7 @@ def main():
             return pre1.StereoMatching(g_, gd_, ur, dr, 47.9, fe.level_scale, True)[0]
 
         med = {}
-        for name, fn in (("one_call", one_call), ("six_calls", six_calls)):
+        for name, fn in (("one_call", one_call), ("one_call_abi", one_call_abi), ("six_calls", six_calls)):
             for k in range(6):
                 fn(*pairs[k % 8])
             ts = []
@@ -766,12 +801,45 @@ def main():
                 ts.append(time.perf_counter() - t0)
             med[name] = float(np.median(ts)) * 1e3
         n_st = int(fe._frame.n_stereo)
+        # the PIPELINED form (snk_frontend_submit / snk_frontend_collect: the reference's FeatureDetection -> Preprocess stage queue,
+        # Snake/Preprocess/FeatureDetector.h:39): still one frame per call, `depth` frames in flight; bare C ABI calls from one thread
+        want = [fe.Process(*pairs[k]) for k in range(8)]
+        depth_ = 3
+        fe.set_depth(depth_)
+        identical = True
+        for k in range(8 + depth_ - 1):  # checked pass through the wrappers (also takes every slot past its captured frame)
+            if k < 8:
+                fe.Submit(*pairs[k])
+            if k >= depth_ - 1:
+                g_ = fe.Collect()
+                w_ = want[k - depth_ + 1]
+                identical = identical and all(np.array_equal(g_[key], w_[key]) for key in w_)
+        for k in range(8):
+            fe.Submit(*pairs[k]), fe.Collect()
+        n_pipe = max(args.frame_calls * 5, 200)
+
+        def pipe_run(count):
+            for k in range(count + depth_ - 1):
+                if k < count:
+                    l_, r_ = pairs[k % 8]
+                    lib_.snk_frontend_submit(fe._h, l_.ctypes.data, W, r_.ctypes.data, W, W, H)
+                if k >= depth_ - 1:
+                    lib_.snk_frontend_collect(fe._h, C.byref(fe._frame), -1)
+
+        pipe_run(4 * depth_)
+        tq0 = time.perf_counter()
+        pipe_run(n_pipe)
+        pipe_fps = n_pipe / (time.perf_counter() - tq0)
         for hnd in (fe, ext1, pre1, grid1):
             hnd.close()
         frame_out = {"metric": f"ms per {W}x{H} stereo frame through the host API, one frame per call (PCIe inclusive, median of {args.frame_calls} calls)",
                      "value": round(med["one_call"], 4), "unit": "ms", "higher_is_better": False,
                      "entry_point": "snk_frontend_process: Detect L + R, undistortKeypoints, computeFeatureGrid, StereoMatching in one call, one synchronisation",
+                     "layer": "Python wrappers on both sides (Frontend.Process against ORBExtractor.Detect x 2, rectify x 2, FeatureGrid.create, StereoMatching)",
                      "six_host_calls_ms": round(med["six_calls"], 4), "frames_per_s_one_call": round(1e3 / med["one_call"], 1),
+                     "one_call_c_abi_ms": round(med["one_call_abi"], 4),
+                     "pipelined": {"entry_points": "snk_frontend_submit / snk_frontend_collect (bare C ABI calls, one thread, one frame per call)",
+                                   "depth": depth_, "frames": n_pipe, "frames_per_s": round(pipe_fps, 1), "identical_to_process": bool(identical)},
                      "stereo_matches_last_frame": n_st}
 
     # ---- tracking matchers on the frames the front-end left in HBM: SearchByProjectionFrameFrame2 with
@@ -994,6 +1062,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(frames, gpu_snapshot, seconds_budget=args.cpu_seconds)
             if ba_out is not None:
                 out["cpu_baseline"]["ba"] = cpu_baseline_ba(ba_check)
+        if world == 1 and args.workload == "euroc" and args.mode == "batch" and args.kitti_steps > 0 and "WORLD_SIZE" not in os.environ:
+            out["kitti"] = kitti_leg(args)
         print(json.dumps(out), flush=True)
 
     parallel.shutdown()

@@ -39,7 +39,8 @@ typedef enum snk_status
     SNK_ERR_NO_DEVICE     = 2, /* no HIP device / HIP runtime failure at create */
     SNK_ERR_HIP           = 3, /* a HIP call failed; see snk_last_error() */
     SNK_ERR_CAPACITY      = 4, /* caller-provided capacity too small */
-    SNK_ERR_NOT_CONFIGURED = 5
+    SNK_ERR_NOT_CONFIGURED = 5,
+    SNK_ERR_TIMEOUT       = 6  /* snk_frontend_collect: no frame arrived within the time given */
 } snk_status;
 
 /* "infinite" Hamming distance: the Snake side initialises its running minima with 256
@@ -367,6 +368,25 @@ SNK_API int snk_frontend_grid_dims(const snk_frontend* f, int* cols, int* rows);
  * float).  right / pitch_right are ignored by a mono handle.  SNK_ERR_CAPACITY (n / n_right set) when capacity is too small. */
 SNK_API int snk_frontend_process(snk_frontend* f, const uint8_t* left, int pitch_left, const uint8_t* right, int pitch_right,
                                  int width, int height, snk_frontend_frame* out);
+
+/* The same frame work PIPELINED, mirroring the reference's blocking single-slot stage queues (SynchronizedSlot<FramePtr>
+ * output_buffer: Snake/Preprocess/FeatureDetector.h:39 between FeatureDetection and Preprocess, Preprocess.h:36 between Preprocess and
+ * Tracking): the handle owns `depth` independent slots (stream, extractor, scratch, pinned staging, hipGraph, completion event; default 3,
+ * snk_frontend_set_depth 1..8 while nothing is in flight).
+ *   snk_frontend_submit   stages the images, enqueues upload -> launch chain -> download on the next slot's stream and RETURNS;
+ *                         blocks only while all `depth` slots hold uncollected frames (SynchronizedSlot::set).
+ *   snk_frontend_collect  waits for the OLDEST submitted frame and fills `out` exactly as snk_frontend_process would (frames
+ *                         come back in submission order; bit-identical results).  timeout_ms < 0: wait for a submission as
+ *                         long as it takes (SynchronizedSlot::get), 0: do not wait, > 0: that long; SNK_ERR_TIMEOUT when none came.
+ *                         SNK_ERR_CAPACITY consumes the frame.
+ * One thread may submit while another collects (the reference's FeatureDetection / Preprocess threads); at most one thread on
+ * each side.  snk_frontend_process must not be mixed with frames in flight (SNK_ERR_INVALID_ARG); all frames in flight have
+ * one image size. */
+SNK_API int snk_frontend_set_depth(snk_frontend* f, int depth);
+SNK_API int snk_frontend_submit(snk_frontend* f, const uint8_t* left, int pitch_left, const uint8_t* right, int pitch_right,
+                                int width, int height);
+SNK_API int snk_frontend_collect(snk_frontend* f, snk_frontend_frame* out, int timeout_ms);
+SNK_API int snk_frontend_in_flight(snk_frontend* f, int* n);
 
 /* The per-frame data the tracking matchers read (Snake/Map/Features.h:18-41, Frame.h:44-46), in
  * feature-grid order.  taken[i] != 0 <=> frame.mvpMapPoints[i] != nullptr. */

@@ -77,6 +77,10 @@ SIGNATURES = {
     "snk_frontend_max_keypoints": (i32, [vp, i32, i32, C.POINTER(i32)]),
     "snk_frontend_grid_dims": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
     "snk_frontend_process": (i32, [vp, vp, i32, vp, i32, i32, i32, vp]),
+    "snk_frontend_set_depth": (i32, [vp, i32]),
+    "snk_frontend_submit": (i32, [vp, vp, i32, vp, i32, i32, i32]),
+    "snk_frontend_collect": (i32, [vp, vp, i32]),
+    "snk_frontend_in_flight": (i32, [vp, C.POINTER(i32)]),
     "snk_orb_create": (i32, [vp, i32, vp, C.POINTER(vp)]),
     "snk_orb_destroy": (i32, [vp]),
     "snk_orb_sync": (i32, [vp]),

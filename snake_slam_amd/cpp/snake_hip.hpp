@@ -183,15 +183,50 @@ class Frontend
     // right may be null for a mono handle; returns the number of stereo matches
     int Process(const uint8_t* left, int pitch_left, const uint8_t* right, int pitch_right, int width, int height, FrontendResult& r)
     {
-        int cap = 0;
-        check(snk_frontend_max_keypoints(h_, width, height, &cap), "snk_frontend_max_keypoints");
-        check(snk_frontend_grid_dims(h_, &r.cols, &r.rows), "snk_frontend_grid_dims");
-        const size_t c = (size_t)cap;
+        snk_frontend_frame f = bind(width, height, r);
+        check(snk_frontend_process(h_, left, pitch_left, right, pitch_right, width, height, &f), "snk_frontend_process");
+        return finish(f, r);
+    }
+    // The pipelined form: Submit returns as soon as the frame is enqueued (it blocks only while `depth` frames are uncollected, like
+    // SynchronizedSlot::set of FeatureDetector::output_buffer, Snake/Preprocess/FeatureDetector.h:39); Collect hands out the oldest
+    // frame, bit for bit what Process returns (SynchronizedSlot::get).  One thread may Submit while another Collects.
+    void SetDepth(int depth) { check(snk_frontend_set_depth(h_, depth), "snk_frontend_set_depth"); }
+    void Submit(const uint8_t* left, int pitch_left, const uint8_t* right, int pitch_right, int width, int height)
+    {
+        check(snk_frontend_submit(h_, left, pitch_left, right, pitch_right, width, height), "snk_frontend_submit");
+        width_ = width, height_ = height;
+    }
+    int Collect(FrontendResult& r, int timeout_ms = -1)
+    {
+        snk_frontend_frame f = bind(width_, height_, r);
+        check(snk_frontend_collect(h_, &f, timeout_ms), "snk_frontend_collect");
+        return finish(f, r);
+    }
+    int InFlight()
+    {
+        int n = 0;
+        check(snk_frontend_in_flight(h_, &n), "snk_frontend_in_flight");
+        return n;
+    }
+    const snk_frontend_params& params() const { return p_; }
+
+   private:
+    // result vectors at capacity, pointers into them
+    snk_frontend_frame bind(int width, int height, FrontendResult& r)
+    {
+        if (cap_ == 0 || width != cap_w_ || height != cap_h_)
+        {
+            check(snk_frontend_max_keypoints(h_, width, height, &cap_), "snk_frontend_max_keypoints");
+            check(snk_frontend_grid_dims(h_, &cols_, &rows_), "snk_frontend_grid_dims");
+            cap_w_ = width, cap_h_ = height;
+        }
+        r.cols = cols_, r.rows = rows_;
+        const size_t c = (size_t)cap_;
         r.keypoints.resize(c), r.keypoints_right.resize(c), r.descriptors.resize(c), r.descriptors_right.resize(c);
         r.undistorted_keypoints.resize(c), r.normalized_points.resize(c), r.permutation.resize(c), r.right_points.resize(c), r.depth.resize(c);
         r.cell_start.resize((size_t)r.cols * r.rows + 1);
         snk_frontend_frame f{};
-        f.capacity              = cap;
+        f.capacity              = cap_;
         f.keypoints             = r.keypoints.data();
         f.descriptors           = reinterpret_cast<uint64_t(*)[4]>(r.descriptors.data());
         f.undistorted_keypoints = r.undistorted_keypoints.data();
@@ -202,7 +237,10 @@ class Frontend
         f.depth                 = r.depth.data();
         f.keypoints_right       = r.keypoints_right.data();
         f.descriptors_right     = reinterpret_cast<uint64_t(*)[4]>(r.descriptors_right.data());
-        check(snk_frontend_process(h_, left, pitch_left, right, pitch_right, width, height, &f), "snk_frontend_process");
+        return f;
+    }
+    static int finish(const snk_frontend_frame& f, FrontendResult& r)
+    {
         const size_t n = (size_t)f.n, nr = (size_t)f.n_right;
         r.keypoints.resize(n), r.descriptors.resize(n), r.undistorted_keypoints.resize(n), r.normalized_points.resize(n);
         r.permutation.resize(n), r.right_points.resize(n), r.depth.resize(n);
@@ -210,11 +248,9 @@ class Frontend
         r.stereo_matches = f.n_stereo;
         return f.n_stereo;
     }
-    const snk_frontend_params& params() const { return p_; }
-
-   private:
     snk_frontend* h_ = nullptr;
     snk_frontend_params p_;
+    int cap_ = 0, cap_w_ = 0, cap_h_ = 0, cols_ = 0, rows_ = 0, width_ = 0, height_ = 0;
 };
 
 // Frame data the tracking matchers read, grid-ordered (Snake/Map/Features.h:18-41, Frame.h:44-46).

@@ -18,7 +18,22 @@
 // The first frame of a configuration runs uncaptured (it sizes every scratch buffer: allocation is illegal inside a capture), the
 // second is captured, later ones replay.  SNK_FRONTEND_NO_GRAPH=1 keeps plain launches (A/B, tests).  The recorded launches depend on the
 // "iround.mode" definition (a kernel argument of StereoMatching): the graph is keyed by it and rebuilt when it changes.
+//
+// Pipelined form (round 5): snk_frontend_submit / snk_frontend_collect.  The reference overlaps its per-frame stages through blocking
+// single-slot queues (SynchronizedSlot<FramePtr> output_buffer, Snake/Preprocess/FeatureDetector.h:39, Preprocess.h:36): while
+// Preprocess works on frame k, FeatureDetection already extracts frame k + 1.  Here a handle owns `depth` SLOTS (default 3), each a
+// complete private context -- stream, extractor, matcher scratch, device blocks, pinned staging, hipGraph, completion event.  submit
+// stages the two images, enqueues upload -> chain -> download on the slot's stream, records the event and returns; collect waits for
+// the OLDEST frame's event and hands its results out (frames come back in submission order).  Frames in different slots share
+// nothing, so their uploads, kernels and downloads overlap on the device: one frame's 14 small launches leave most of the chip
+// idle.  submit blocks while all slots are occupied, collect while none is (the semantics of SynchronizedSlot::set / get); the two
+// may be called from different threads (one submitting thread, one collecting thread).  Results are bit for bit those of
+// snk_frontend_process: same kernels, same order inside a frame.
 #include <cmath>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <vector>
 
 #include "common.hpp"
 
@@ -32,33 +47,89 @@ static void grid_dims(const snk_grid_bounds* b, int* cols, int* rows)
     *rows = r < 1 ? 1 : r;
 }
 
-struct snk_frontend
+namespace
 {
-    int device         = 0;
+constexpr int MAX_DEPTH = 8;
+
+// everything one frame in flight needs; nothing is shared between slots
+struct Slot
+{
     hipStream_t stream = nullptr;
     snk_orb* orb       = nullptr;
     snk_matcher* mat   = nullptr;
+    int width = 0, height = 0;  // what this slot's extractor and blocks are sized for
+    DevBuf d_img, d_out, d_tmp;
+    HostBuf h_img, h_out;
+    hipGraphExec_t graph = nullptr;
+    int graph_key        = -1;     // definition values the recorded launches depend on
+    int last_key         = -1;     // ... of the previous frame (a change runs one frame uncaptured: the extractor may size new scratch)
+    bool graph_failed    = false;  // a capture / instantiation failed for this configuration: plain launches from then on
+    int frames_seen      = 0;      // of the current configuration
+    hipEvent_t done      = nullptr;  // recorded behind the download of a submitted frame
+};
+}  // namespace
+
+struct snk_frontend
+{
+    int device = 0;
     snk_frontend_params par{};
     int width = 0, height = 0, dpitch = 0, cap = 0, cols = 0, rows = 0, n_img = 2;
     float level_scale[8] = {};
-    // one device block for everything that goes back to the host, one pinned mirror
-    DevBuf d_img, d_out, d_tmp;
-    HostBuf h_img, h_out;
+    // layout of a slot's device block that goes back to the host (d_out / h_out) and of its scratch block (d_tmp)
     size_t o_n = 0, o_kps = 0, o_desc_r = 0, o_kp64_g = 0, o_desc_g = 0, o_norm = 0, o_perm = 0, o_cs = 0, o_rp = 0, o_dp = 0, out_len = 0;
     size_t t_desc = 0, t_kp64 = 0;  // d_tmp: descriptors in extractor order (2 images) | rectified keypoints (2 images)
-    hipGraphExec_t graph = nullptr;
-    int graph_key        = -1;  // definition values the recorded launches depend on
-    int last_key         = -1;  // ... of the previous frame (a change runs one frame uncaptured: the extractor may size new scratch)
-    bool graph_failed    = false;  // a capture / instantiation failed for this configuration: plain launches from then on
-    int frames_seen      = 0;   // of the current configuration
+    std::vector<Slot*> slots;       // slots[0] also serves snk_frontend_process
+    // the ring of submitted frames: frame number q lives in slot q % depth
+    std::mutex mu;
+    std::condition_variable cv;
+    int depth = 3;  // measured on MI355X (profiles/r05): 2 -> 9.2 k, 3 -> 12.5 k, 4 -> 11.3 k stereo frames/s through the C++ adaptor
+    unsigned long long submitted = 0, collected = 0;
 };
 
-static void drop_graph(snk_frontend* f)
+static void drop_graph(Slot* s)
 {
-    if (f->graph) (void)hipGraphExecDestroy(f->graph);
-    f->graph        = nullptr;
-    f->graph_key    = -1;
-    f->graph_failed = false;
+    if (s->graph) (void)hipGraphExecDestroy(s->graph);
+    s->graph        = nullptr;
+    s->graph_key    = -1;
+    s->graph_failed = false;
+}
+
+static void destroy_slot(Slot* s)
+{
+    if (!s) return;
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    drop_graph(s);
+    if (s->orb) (void)snk_orb_destroy(s->orb);
+    if (s->mat) (void)snk_matcher_destroy(s->mat);
+    s->d_img.release();
+    s->d_out.release();
+    s->d_tmp.release();
+    s->h_img.release();
+    s->h_out.release();
+    if (s->done) (void)hipEventDestroy(s->done);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+static int create_slot(snk_frontend* f, Slot** out)
+{
+    Slot* s = new Slot();
+    int rc  = SNK_OK;
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s->done, hipEventDisableTiming) != hipSuccess)
+    {
+        set_error("front-end slot: stream / event creation failed");
+        rc = SNK_ERR_HIP;
+    }
+    if (rc == SNK_OK) rc = snk_orb_create(&f->par.orb, f->device, s->stream, &s->orb);
+    if (rc == SNK_OK) rc = snk_matcher_create(f->device, s->stream, &s->mat);
+    if (rc != SNK_OK)
+    {
+        destroy_slot(s);
+        return rc;
+    }
+    *out = s;
+    return SNK_OK;
 }
 
 extern "C" int snk_frontend_create(const snk_frontend_params* params, int device, snk_frontend** out)
@@ -72,21 +143,14 @@ extern "C" int snk_frontend_create(const snk_frontend_params* params, int device
     f->device       = device;
     f->par          = *params;
     f->n_img        = params->stereo ? 2 : 1;
-    if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess)
-    {
-        set_error("hipStreamCreateWithFlags failed");
-        delete f;
-        return SNK_ERR_HIP;
-    }
-    int rc = snk_orb_create(&params->orb, device, f->stream, &f->orb);
-    if (rc == SNK_OK) rc = snk_matcher_create(device, f->stream, &f->mat);
+    Slot* s0        = nullptr;
+    const int rc    = create_slot(f, &s0);
     if (rc != SNK_OK)
     {
-        if (f->orb) (void)snk_orb_destroy(f->orb);
-        (void)hipStreamDestroy(f->stream);
         delete f;
         return rc;
     }
+    f->slots.push_back(s0);
     // ScalePyramid::Scale(l) as the extractor defines it: scale[l] = scale[l - 1] * factor in float
     f->level_scale[0] = 1.0f;
     for (int l = 1; l < 8; ++l) f->level_scale[l] = f->level_scale[l - 1] * params->orb.scale_factor;
@@ -99,29 +163,19 @@ extern "C" int snk_frontend_destroy(snk_frontend* f)
 {
     if (!f) return SNK_OK;
     (void)hipSetDevice(f->device);
-    (void)hipStreamSynchronize(f->stream);
-    drop_graph(f);
-    (void)snk_orb_destroy(f->orb);
-    (void)snk_matcher_destroy(f->mat);
-    f->d_img.release();
-    f->d_out.release();
-    f->d_tmp.release();
-    f->h_img.release();
-    f->h_out.release();
-    (void)hipStreamDestroy(f->stream);
+    for (Slot* s : f->slots) destroy_slot(s);
     delete f;
     return SNK_OK;
 }
 
 static size_t up64(size_t v) { return (v + 63) & ~(size_t)63; }
 
-static int configure(snk_frontend* f, int w, int h)
+// the block layout of an image size (the same for every slot)
+static int layout(snk_frontend* f, Slot* s, int w, int h)
 {
     int rc;
-    SNK_HIP_CHECK(hipStreamSynchronize(f->stream));
-    drop_graph(f);
-    if ((rc = snk_orb_configure(f->orb, w, h, 2)) != SNK_OK) return rc;
-    if ((rc = snk_orb_max_keypoints(f->orb, &f->cap)) != SNK_OK) return rc;
+    if ((rc = snk_orb_configure(s->orb, w, h, 2)) != SNK_OK) return rc;
+    if ((rc = snk_orb_max_keypoints(s->orb, &f->cap)) != SNK_OK) return rc;
     const size_t cap = (size_t)f->cap, ni = (size_t)f->n_img;
     f->width = w; f->height = h; f->dpitch = (w + 63) & ~63;
     size_t at = 0;
@@ -139,48 +193,62 @@ static int configure(snk_frontend* f, int w, int h)
     f->out_len  = at;
     f->t_desc   = 0;
     f->t_kp64   = up64(ni * cap * 32);
-    if ((rc = f->d_out.reserve(f->out_len + 64)) != SNK_OK) return rc;
-    if ((rc = f->h_out.reserve(f->out_len + 64)) != SNK_OK) return rc;
-    if ((rc = f->d_tmp.reserve(f->t_kp64 + ni * cap * sizeof(snk_kp64) + 64)) != SNK_OK) return rc;
-    if ((rc = f->d_img.reserve(ni * (size_t)f->dpitch * h + 64)) != SNK_OK) return rc;
-    if ((rc = f->h_img.reserve(ni * (size_t)f->dpitch * h + 64)) != SNK_OK) return rc;
-    f->frames_seen = 0;
     return SNK_OK;
 }
 
-// everything between the upload and the download, on the handle's stream
-static int enqueue_chain(snk_frontend* f)
+// size slot s for w x h images (its own extractor, blocks and staging)
+static int configure_slot(snk_frontend* f, Slot* s, int w, int h)
+{
+    int rc;
+    SNK_HIP_CHECK(hipStreamSynchronize(s->stream));
+    drop_graph(s);
+    if ((rc = layout(f, s, w, h)) != SNK_OK) return rc;
+    const size_t cap = (size_t)f->cap, ni = (size_t)f->n_img;
+    if ((rc = s->d_out.reserve(f->out_len + 64)) != SNK_OK) return rc;
+    if ((rc = s->h_out.reserve(f->out_len + 64)) != SNK_OK) return rc;
+    if ((rc = s->d_tmp.reserve(f->t_kp64 + ni * cap * sizeof(snk_kp64) + 64)) != SNK_OK) return rc;
+    if ((rc = s->d_img.reserve(ni * (size_t)f->dpitch * h + 64)) != SNK_OK) return rc;
+    if ((rc = s->h_img.reserve(ni * (size_t)f->dpitch * h + 64)) != SNK_OK) return rc;
+    s->width       = w;
+    s->height      = h;
+    s->frames_seen = 0;
+    s->last_key    = -1;
+    return SNK_OK;
+}
+
+// everything between the upload and the download, on the slot's stream
+static int enqueue_chain(snk_frontend* f, Slot* s)
 {
     const size_t cap = (size_t)f->cap;
-    char* o  = f->d_out.as<char>();
-    char* t  = f->d_tmp.as<char>();
+    char* o  = s->d_out.as<char>();
+    char* t  = s->d_tmp.as<char>();
     int* d_n = reinterpret_cast<int*>(o + f->o_n);
     auto* d_kps  = reinterpret_cast<snk_keypoint*>(o + f->o_kps);
     auto* d_desc = reinterpret_cast<uint64_t*>(t + f->t_desc);
     auto* d_kp64 = reinterpret_cast<snk_kp64*>(t + f->t_kp64);
     int rc;
     // FeatureDetector::Detect, left then right (FeatureDetector.cpp:116-156): one two-image launch chain
-    if ((rc = snk_orb_detect_batch_dev(f->orb, f->d_img.as<uint8_t>(), f->dpitch, (size_t)f->dpitch * f->height, f->n_img, d_kps, d_desc, d_n,
+    if ((rc = snk_orb_detect_batch_dev(s->orb, s->d_img.as<uint8_t>(), f->dpitch, (size_t)f->dpitch * f->height, f->n_img, d_kps, d_desc, d_n,
                                        f->cap)) != SNK_OK)
         return rc;
     // Frame::allocateTmp (Snake/Map/Frame.cpp:25-26): right_points and depth start at -1000
-    SNK_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(o + f->o_rp), 0xC47A0000u /* -1000.0f */, (f->o_dp - f->o_rp) / 4 + cap, f->stream));
+    SNK_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(o + f->o_rp), 0xC47A0000u /* -1000.0f */, (f->o_dp - f->o_rp) / 4 + cap, s->stream));
     // undistortKeypoints (Preprocess.cpp:55-77) with rect_left; Rectification::Forward of the right keypoints (:140-150) with rect_right
-    if ((rc = snk_rectify_batch_dev(f->mat, &f->par.rect_left, d_kps, d_n, f->cap, 1, d_kp64, reinterpret_cast<double*>(o + f->o_norm))) != SNK_OK) return rc;
+    if ((rc = snk_rectify_batch_dev(s->mat, &f->par.rect_left, d_kps, d_n, f->cap, 1, d_kp64, reinterpret_cast<double*>(o + f->o_norm))) != SNK_OK) return rc;
     if (f->n_img == 2 &&
-        (rc = snk_rectify_batch_dev(f->mat, &f->par.rect_right, d_kps + cap, d_n + 1, f->cap, 1, d_kp64 + cap, nullptr)) != SNK_OK)
+        (rc = snk_rectify_batch_dev(s->mat, &f->par.rect_right, d_kps + cap, d_n + 1, f->cap, 1, d_kp64 + cap, nullptr)) != SNK_OK)
         return rc;
     // computeFeatureGrid (Preprocess.cpp:244-266): permutation, cell starts, undistorted keypoints and descriptors in grid order
-    if ((rc = snk_feature_grid_batch_dev(f->mat, &f->par.bounds, d_kp64, d_desc, d_n, f->cap, 1, reinterpret_cast<snk_kp64*>(o + f->o_kp64_g),
+    if ((rc = snk_feature_grid_batch_dev(s->mat, &f->par.bounds, d_kp64, d_desc, d_n, f->cap, 1, reinterpret_cast<snk_kp64*>(o + f->o_kp64_g),
                                          reinterpret_cast<uint64_t*>(o + f->o_desc_g), reinterpret_cast<int32_t*>(o + f->o_perm),
                                          reinterpret_cast<int32_t*>(o + f->o_cs))) != SNK_OK)
         return rc;
     if (f->n_img == 2)
     {
         // the right descriptors go back in extractor order (frame.descriptors_right)
-        SNK_HIP_CHECK(hipMemcpyAsync(o + f->o_desc_r, d_desc + cap * 4, cap * 32, hipMemcpyDeviceToDevice, f->stream));
+        SNK_HIP_CHECK(hipMemcpyAsync(o + f->o_desc_r, d_desc + cap * 4, cap * 32, hipMemcpyDeviceToDevice, s->stream));
         // StereoMatching (Preprocess.cpp:122-242): left in grid order, right in extractor order (:41-49)
-        if ((rc = snk_stereo_match_batch_dev(f->mat, reinterpret_cast<const snk_kp64*>(o + f->o_kp64_g), reinterpret_cast<const uint64_t*>(o + f->o_desc_g),
+        if ((rc = snk_stereo_match_batch_dev(s->mat, reinterpret_cast<const snk_kp64*>(o + f->o_kp64_g), reinterpret_cast<const uint64_t*>(o + f->o_desc_g),
                                              d_n, f->cap, d_kp64 + cap, d_desc + cap * 4, d_n + 1, f->cap, 1, f->par.bf, f->level_scale,
                                              f->par.orb.n_levels, f->par.relaxed_stereo, reinterpret_cast<float*>(o + f->o_rp),
                                              reinterpret_cast<float*>(o + f->o_dp), d_n + 2)) != SNK_OK)
@@ -189,82 +257,114 @@ static int enqueue_chain(snk_frontend* f)
     return SNK_OK;
 }
 
-extern "C" int snk_frontend_process(snk_frontend* f, const uint8_t* left, int pitch_left, const uint8_t* right, int pitch_right, int width,
-                                    int height, snk_frontend_frame* out)
+// stage the images, upload, chain (hipGraph from the slot's second frame on), download -- all enqueued on the slot's stream, no wait
+static int enqueue_frame(snk_frontend* f, Slot* s, const uint8_t* left, int pitch_left, const uint8_t* right, int pitch_right, int width, int height)
 {
-    SNK_REQUIRE(f != nullptr && out != nullptr, "NULL argument");
-    out->n = out->n_right = out->n_stereo = 0;
-    SNK_REQUIRE(left != nullptr && width >= 1 && height >= 1 && pitch_left >= width, "bad left image");
-    SNK_REQUIRE(f->n_img == 1 || (right != nullptr && pitch_right >= width), "bad right image");
-    SNK_REQUIRE(out->capacity >= 0, "capacity");
-    SNK_HIP_CHECK(hipSetDevice(f->device));
     int rc;
-    if (f->width != width || f->height != height)
-        if ((rc = configure(f, width, height)) != SNK_OK) return rc;
+    if (s->width != width || s->height != height)
+    {
+        if ((rc = configure_slot(f, s, width, height)) != SNK_OK) return rc;
+    }
+    else if (f->width != width || f->height != height)
+        if ((rc = layout(f, s, width, height)) != SNK_OK) return rc;  // the handle last served another size through another slot
+    // SNK_FRONTEND_TIMING=1 (diagnostic): mean host microseconds per part of this function, printed every 256 frames
+    static const bool timing = getenv("SNK_FRONTEND_TIMING") != nullptr;
+    static double t_acc[5]  = {0, 0, 0, 0, 0};
+    static int t_n          = 0;
+    auto now                = [] { return std::chrono::steady_clock::now(); };
+    auto t_prev             = now();
+    auto lap                = [&](int i)
+    {
+        if (!timing) return;
+        const auto t = now();
+        t_acc[i] += std::chrono::duration<double, std::micro>(t - t_prev).count();
+        t_prev = t;
+    };
     // the two images into the pinned staging buffer, ONE upload
     const size_t plane = (size_t)f->dpitch * height;
-    uint8_t* hi        = f->h_img.as<uint8_t>();
-    for (int r = 0; r < height; ++r) memcpy(hi + (size_t)r * f->dpitch, left + (size_t)r * pitch_left, (size_t)width);
+    uint8_t* hi        = s->h_img.as<uint8_t>();
+    if (pitch_left == f->dpitch)
+        memcpy(hi, left, plane - (size_t)(f->dpitch - width));
+    else
+        for (int r = 0; r < height; ++r) memcpy(hi + (size_t)r * f->dpitch, left + (size_t)r * pitch_left, (size_t)width);
     if (f->n_img == 2)
-        for (int r = 0; r < height; ++r) memcpy(hi + plane + (size_t)r * f->dpitch, right + (size_t)r * pitch_right, (size_t)width);
-    SNK_HIP_CHECK(hipMemcpyAsync(f->d_img.p, hi, plane * f->n_img, hipMemcpyHostToDevice, f->stream));
+    {
+        if (pitch_right == f->dpitch)
+            memcpy(hi + plane, right, plane - (size_t)(f->dpitch - width));
+        else
+            for (int r = 0; r < height; ++r) memcpy(hi + plane + (size_t)r * f->dpitch, right + (size_t)r * pitch_right, (size_t)width);
+    }
+    lap(0);
+    SNK_HIP_CHECK(hipMemcpyAsync(s->d_img.p, hi, plane * f->n_img, hipMemcpyHostToDevice, s->stream));
+    lap(1);
 
     static const bool no_graph = getenv("SNK_FRONTEND_NO_GRAPH") != nullptr;
     const int key              = definition(DEF_IROUND_MODE) | (definition(DEF_ORB_RESPONSE) << 4);
-    if (f->last_key != key)
+    if (s->last_key != key)
     {
-        drop_graph(f);
-        f->frames_seen = 0;
-        f->last_key    = key;
+        drop_graph(s);
+        s->frames_seen = 0;
+        s->last_key    = key;
     }
     bool launched = false;
-    if (!no_graph && f->graph)
+    if (!no_graph && s->graph)
     {
-        SNK_HIP_CHECK(hipGraphLaunch(f->graph, f->stream));
+        SNK_HIP_CHECK(hipGraphLaunch(s->graph, s->stream));
         launched = true;
     }
-    else if (!no_graph && !f->graph_failed && f->frames_seen >= 1)
+    else if (!no_graph && !s->graph_failed && s->frames_seen >= 1)
     {
         // second frame of the configuration: record the chain (every scratch buffer has its size from the first frame)
         hipGraph_t g = nullptr;
-        if (hipStreamBeginCapture(f->stream, hipStreamCaptureModeRelaxed) == hipSuccess)
+        if (hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed) == hipSuccess)
         {
-            rc                = enqueue_chain(f);
-            const hipError_t e = hipStreamEndCapture(f->stream, &g);
+            rc                = enqueue_chain(f, s);
+            const hipError_t e = hipStreamEndCapture(s->stream, &g);
             hipGraphExec_t ex = nullptr;
             if (rc == SNK_OK && e == hipSuccess && g != nullptr && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess && ex != nullptr)
             {
-                f->graph     = ex;
-                f->graph_key = key;
+                s->graph     = ex;
+                s->graph_key = key;
             }
             if (g) (void)hipGraphDestroy(g);
             (void)hipGetLastError();
-            if (!f->graph)
+            if (!s->graph)
             {
-                // not retried frame after frame (begin capture, the whole chain, end capture, instantiate -- each time); configure() and
+                // not retried frame after frame (begin capture, the whole chain, end capture, instantiate -- each time); configure_slot and
                 // a changed definition key reset the flag through drop_graph
-                f->graph_failed = true;
+                s->graph_failed = true;
                 if (getenv("SNK_DEBUG")) fprintf(stderr, "snake_hip: front-end graph capture failed (chain rc %d, %s); plain launches\n", rc, hipGetErrorString(e));
             }
-            if (f->graph)
+            if (s->graph)
             {
-                SNK_HIP_CHECK(hipGraphLaunch(f->graph, f->stream));
+                SNK_HIP_CHECK(hipGraphLaunch(s->graph, s->stream));
                 launched = true;
             }
         }
         else
         {
             (void)hipGetLastError();
-            f->graph_failed = true;
+            s->graph_failed = true;
         }
     }
-    if (!launched && (rc = enqueue_chain(f)) != SNK_OK) return rc;
-    ++f->frames_seen;
-    // ONE download, ONE synchronisation
-    SNK_HIP_CHECK(hipMemcpyAsync(f->h_out.p, f->d_out.p, f->out_len, hipMemcpyDeviceToHost, f->stream));
-    SNK_HIP_CHECK(hipStreamSynchronize(f->stream));
+    if (!launched && (rc = enqueue_chain(f, s)) != SNK_OK) return rc;
+    ++s->frames_seen;
+    lap(2);
+    SNK_HIP_CHECK(hipMemcpyAsync(s->h_out.p, s->d_out.p, f->out_len, hipMemcpyDeviceToHost, s->stream));
+    lap(3);
+    if (timing && ++t_n % 256 == 0)
+    {
+        fprintf(stderr, "[frontend timing] per frame, us: stage %.1f | upload enqueue %.1f | chain / graph launch %.1f | download enqueue %.1f\n", t_acc[0] / 256,
+                t_acc[1] / 256, t_acc[2] / 256, t_acc[3] / 256);
+        t_acc[0] = t_acc[1] = t_acc[2] = t_acc[3] = 0;
+    }
+    return SNK_OK;
+}
 
-    const char* h  = f->h_out.as<char>();
+// a finished frame's pinned block -> the caller's arrays
+static int unpack(snk_frontend* f, Slot* s, snk_frontend_frame* out)
+{
+    const char* h  = s->h_out.as<char>();
     const int* hn  = reinterpret_cast<const int*>(h + f->o_n);
     const int n    = hn[0], nr = f->n_img == 2 ? hn[1] : 0;
     out->n         = n;
@@ -299,13 +399,136 @@ extern "C" int snk_frontend_process(snk_frontend* f, const uint8_t* left, int pi
     return SNK_OK;
 }
 
+extern "C" int snk_frontend_process(snk_frontend* f, const uint8_t* left, int pitch_left, const uint8_t* right, int pitch_right, int width,
+                                    int height, snk_frontend_frame* out)
+{
+    SNK_REQUIRE(f != nullptr && out != nullptr, "NULL argument");
+    out->n = out->n_right = out->n_stereo = 0;
+    SNK_REQUIRE(left != nullptr && width >= 1 && height >= 1 && pitch_left >= width, "bad left image");
+    SNK_REQUIRE(f->n_img == 1 || (right != nullptr && pitch_right >= width), "bad right image");
+    SNK_REQUIRE(out->capacity >= 0, "capacity");
+    {
+        std::lock_guard<std::mutex> lock(f->mu);
+        SNK_REQUIRE(f->submitted == f->collected, "frames submitted with snk_frontend_submit are still in flight: collect them first");
+    }
+    SNK_HIP_CHECK(hipSetDevice(f->device));
+    Slot* s = f->slots[0];
+    int rc;
+    if ((rc = enqueue_frame(f, s, left, pitch_left, right, pitch_right, width, height)) != SNK_OK) return rc;
+    SNK_HIP_CHECK(hipStreamSynchronize(s->stream));  // ONE synchronisation
+    return unpack(f, s, out);
+}
+
+extern "C" int snk_frontend_set_depth(snk_frontend* f, int depth)
+{
+    SNK_REQUIRE(f != nullptr, "frontend is NULL");
+    SNK_REQUIRE(depth >= 1 && depth <= MAX_DEPTH, "depth must be 1..8");
+    std::lock_guard<std::mutex> lock(f->mu);
+    SNK_REQUIRE(f->submitted == f->collected, "frames are in flight");
+    f->depth     = depth;
+    f->submitted = f->collected = 0;  // frame q lives in slot q % depth: restart the numbering with the new modulus
+    return SNK_OK;
+}
+
+extern "C" int snk_frontend_submit(snk_frontend* f, const uint8_t* left, int pitch_left, const uint8_t* right, int pitch_right, int width,
+                                   int height)
+{
+    SNK_REQUIRE(f != nullptr, "frontend is NULL");
+    SNK_REQUIRE(left != nullptr && width >= 1 && height >= 1 && pitch_left >= width, "bad left image");
+    SNK_REQUIRE(f->n_img == 1 || (right != nullptr && pitch_right >= width), "bad right image");
+    SNK_HIP_CHECK(hipSetDevice(f->device));
+    int si;
+    {
+        // SynchronizedSlot::set: wait for a free slot (the collector frees the oldest)
+        std::unique_lock<std::mutex> lock(f->mu);
+        // the block layout belongs to the handle: frames of one image size at a time
+        SNK_REQUIRE(f->submitted == f->collected || (f->width == width && f->height == height),
+                    "image size changed while frames are in flight: collect them first");
+        f->cv.wait(lock, [&] { return f->submitted - f->collected < (unsigned long long)f->depth; });
+        si = (int)(f->submitted % (unsigned long long)f->depth);
+        while ((int)f->slots.size() <= si)
+        {
+            Slot* s = nullptr;
+            const int rc = create_slot(f, &s);
+            if (rc != SNK_OK) return rc;
+            f->slots.push_back(s);
+        }
+    }
+    // the slot is this thread's until `submitted` moves: the collector only touches slots of frames < submitted
+    Slot* s = f->slots[(size_t)si];
+    int rc;
+    if ((rc = enqueue_frame(f, s, left, pitch_left, right, pitch_right, width, height)) != SNK_OK)
+    {
+        (void)hipStreamSynchronize(s->stream);  // whatever was enqueued must not run into the slot's next use
+        return rc;
+    }
+    SNK_HIP_CHECK(hipEventRecord(s->done, s->stream));
+    {
+        std::lock_guard<std::mutex> lock(f->mu);
+        ++f->submitted;
+    }
+    f->cv.notify_all();
+    return SNK_OK;
+}
+
+extern "C" int snk_frontend_collect(snk_frontend* f, snk_frontend_frame* out, int timeout_ms)
+{
+    SNK_REQUIRE(f != nullptr && out != nullptr, "NULL argument");
+    out->n = out->n_right = out->n_stereo = 0;
+    SNK_REQUIRE(out->capacity >= 0, "capacity");
+    SNK_HIP_CHECK(hipSetDevice(f->device));
+    Slot* s;
+    {
+        // SynchronizedSlot::get: wait for a submitted frame (timeout_ms < 0: for as long as it takes, 0: do not wait)
+        std::unique_lock<std::mutex> lock(f->mu);
+        auto ready = [&] { return f->collected < f->submitted; };
+        if (timeout_ms < 0)
+            f->cv.wait(lock, ready);
+        else if (!f->cv.wait_for(lock, std::chrono::milliseconds(timeout_ms), ready))
+        {
+            set_error("snk_frontend_collect: no frame was submitted within %d ms", timeout_ms);
+            return SNK_ERR_TIMEOUT;
+        }
+        s = f->slots[(size_t)(f->collected % (unsigned long long)f->depth)];
+    }
+    const hipError_t e = hipEventSynchronize(s->done);  // the frame's download is behind it on the slot's stream
+    int rc             = SNK_OK;
+    if (e != hipSuccess)
+    {
+        set_error("hipEventSynchronize failed: %s", hipGetErrorString(e));
+        rc = SNK_ERR_HIP;
+    }
+    else
+        rc = unpack(f, s, out);
+    {
+        std::lock_guard<std::mutex> lock(f->mu);
+        ++f->collected;  // the frame is consumed whatever the outcome: its slot is free again
+    }
+    f->cv.notify_all();
+    return rc;
+}
+
+extern "C" int snk_frontend_in_flight(snk_frontend* f, int* n)
+{
+    SNK_REQUIRE(f != nullptr && n != nullptr, "NULL argument");
+    std::lock_guard<std::mutex> lock(f->mu);
+    *n = (int)(f->submitted - f->collected);
+    return SNK_OK;
+}
+
 extern "C" int snk_frontend_max_keypoints(snk_frontend* f, int width, int height, int* out)
 {
     SNK_REQUIRE(f != nullptr && out != nullptr && width >= 1 && height >= 1, "bad arguments");
     SNK_HIP_CHECK(hipSetDevice(f->device));
     int rc;
     if (f->width != width || f->height != height)
-        if ((rc = configure(f, width, height)) != SNK_OK) return rc;
+    {
+        {
+            std::lock_guard<std::mutex> lock(f->mu);
+            SNK_REQUIRE(f->submitted == f->collected, "frames of another image size are in flight");
+        }
+        if ((rc = configure_slot(f, f->slots[0], width, height)) != SNK_OK) return rc;
+    }
     *out = f->cap;
     return SNK_OK;
 }

@@ -2211,6 +2211,19 @@ static void resize_tables(int src, int dst, int* ofs, int* w1)
     }
 }
 
+// extra streams + fork / join events of the multi-chain schedules (best effort: without them every batch runs as one chain)
+static bool ensure_extra_streams(snk_orb* o)
+{
+    if (o->stream2) return true;
+    bool ok = hipEventCreateWithFlags(&o->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < snk_orb::MAX_PARTS - 1; ++i)
+        ok = hipStreamCreateWithFlags(&o->extra[i], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&o->ev_join_n[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    o->stream2 = ok ? o->extra[0] : nullptr;
+    return ok;
+}
+
 extern "C" {
 
 int snk_orb_create(const snk_orb_params* params, int device, void* stream, snk_orb** out)
@@ -2237,25 +2250,21 @@ int snk_orb_create(const snk_orb_params* params, int device, void* stream, snk_o
         delete o;
         return rc;
     }
-    // extra streams + fork / join events (best effort: without them every batch runs as one chain)
+    // The extra streams / events of the multi-chain schedules are created when one is first asked for (ensure_extra_streams):
+    // HIP spreads streams over a handful of hardware queues in creation order, and an extractor that never splits its batches
+    // (the default, and every per-frame caller) should not take four of them -- the slots of a pipelined front-end would otherwise
+    // land on the same hardware queue and run one behind the other.
+    if (const char* e = getenv("SNK_ORB_PARTS"))
     {
-        bool ok = hipEventCreateWithFlags(&o->ev_fork, hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; ok && i < snk_orb::MAX_PARTS - 1; ++i)
-            ok = hipStreamCreateWithFlags(&o->extra[i], hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&o->ev_join_n[i], hipEventDisableTiming) == hipSuccess;
-        if (!ok) (void)hipGetLastError();
-        o->stream2 = ok ? o->extra[0] : nullptr;
-        if (const char* e = getenv("SNK_ORB_PARTS"))
-        {
-            const int v = atoi(e);
-            o->parts    = v < 1 ? 1 : (v > snk_orb::MAX_PARTS ? snk_orb::MAX_PARTS : v);
-        }
-        if (const char* e = getenv("SNK_ORB_STAGGER"))
-        {
-            const int v = atoi(e);
-            o->stagger  = ok && v >= 2 ? (v > snk_orb::MAX_STAGGER ? snk_orb::MAX_STAGGER : v) : 0;
-        }
+        const int v = atoi(e);
+        o->parts    = v < 1 ? 1 : (v > snk_orb::MAX_PARTS ? snk_orb::MAX_PARTS : v);
     }
+    if (const char* e = getenv("SNK_ORB_STAGGER"))
+    {
+        const int v = atoi(e);
+        o->stagger  = v >= 2 ? (v > snk_orb::MAX_STAGGER ? snk_orb::MAX_STAGGER : v) : 0;
+    }
+    if ((o->parts > 1 || o->stagger >= 2) && !ensure_extra_streams(o)) o->parts = 1, o->stagger = 0;
     *out = o;
     return SNK_OK;
 }
@@ -2765,7 +2774,8 @@ int snk_orb_set_chains(snk_orb* o, int chains)
 {
     SNK_REQUIRE(o != nullptr, "orb is NULL");
     SNK_REQUIRE(chains >= 1 && chains <= snk_orb::MAX_PARTS, "chains must be 1..4");
-    if (chains > 1 && o->stream2 == nullptr)
+    SNK_HIP_CHECK(hipSetDevice(o->device));
+    if (chains > 1 && !ensure_extra_streams(o))
     {
         set_error("the extra streams could not be created");
         return SNK_ERR_HIP;
@@ -2780,7 +2790,8 @@ int snk_orb_set_stagger(snk_orb* o, int parts)
 {
     SNK_REQUIRE(o != nullptr, "orb is NULL");
     SNK_REQUIRE(parts == 0 || (parts >= 2 && parts <= snk_orb::MAX_STAGGER), "parts must be 0 (off) or 2..16");
-    if (parts > 1 && o->stream2 == nullptr)
+    SNK_HIP_CHECK(hipSetDevice(o->device));
+    if (parts > 1 && !ensure_extra_streams(o))
     {
         set_error("the extra streams could not be created");
         return SNK_ERR_HIP;

@@ -72,6 +72,40 @@ class Frontend:
             setattr(fr, k, v.ctypes.data)
         self._arrays, self._frame, self._size = a, fr, (w, h)
 
+    def set_depth(self, depth: int) -> None:
+        """Frames that may be in flight between Submit and Collect (1..8, default 3)."""
+        _lib.check(self._lib.snk_frontend_set_depth(self._h, int(depth)), "snk_frontend_set_depth")
+
+    def Submit(self, left: np.ndarray, right: np.ndarray | None = None) -> None:
+        """snk_frontend_submit: enqueue one frame and return (blocks only while `depth` frames are uncollected) -- the producer side
+        of the reference's FeatureDetection -> Preprocess slot (Snake/Preprocess/FeatureDetector.h:39)."""
+        left = np.ascontiguousarray(left, np.uint8)
+        h, w = left.shape
+        if right is not None:
+            right = np.ascontiguousarray(right, np.uint8)
+            assert right.shape == left.shape
+        if self._arrays is None or self._size != (w, h):
+            self._alloc(w, h)
+        _lib.check(self._lib.snk_frontend_submit(self._h, left.ctypes.data, w, right.ctypes.data if right is not None else None, w, w, h),
+                   "snk_frontend_submit")
+
+    def Collect(self, timeout_ms: int = -1) -> dict:
+        """snk_frontend_collect: the oldest submitted frame, as Process returns it."""
+        fr, a = self._frame, self._arrays
+        _lib.check(self._lib.snk_frontend_collect(self._h, C.byref(fr), int(timeout_ms)), "snk_frontend_collect")
+        return self._result(fr, a)
+
+    def in_flight(self) -> int:
+        n = C.c_int(0)
+        _lib.check(self._lib.snk_frontend_in_flight(self._h, C.byref(n)), "snk_frontend_in_flight")
+        return n.value
+
+    def _result(self, fr, a) -> dict:
+        n, nr = fr.n, fr.n_right
+        out = {k: (v[:nr] if k.endswith("_right") else (v if k == "cell_start" else v[:n])).copy() for k, v in a.items()}
+        out.update(N=n, n_right=nr, n_stereo=fr.n_stereo, cols=fr.cols, rows=fr.rows)
+        return out
+
     def Process(self, left: np.ndarray, right: np.ndarray | None = None) -> dict:
         left = np.ascontiguousarray(left, np.uint8)
         h, w = left.shape
@@ -83,7 +117,4 @@ class Frontend:
         fr, a = self._frame, self._arrays
         _lib.check(self._lib.snk_frontend_process(self._h, left.ctypes.data, w, right.ctypes.data if right is not None else None, w, w, h,
                                                   C.byref(fr)), "snk_frontend_process")
-        n, nr = fr.n, fr.n_right
-        out = {k: (v[:nr] if k.endswith("_right") else (v if k == "cell_start" else v[:n])).copy() for k, v in a.items()}
-        out.update(N=n, n_right=nr, n_stereo=fr.n_stereo, cols=fr.cols, rows=fr.rows)
-        return out
+        return self._result(fr, a)

@@ -14,8 +14,8 @@ REQUIRED = {"metric": str, "value": float, "unit": str, "n_gpus": int, "steps": 
 
 
 def test_bench_prints_one_json_line():
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "16",
-                        "--ba-windows", "8", "--pose-frames", "8", "--gba-keyframes", "0", "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--kitti-steps", "2", "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "16",
+                        "--ba-windows", "8", "--pose-frames", "8", "--gba-keyframes", "0", "--no-cpu-baseline", "--frame-calls", "10"],
                        capture_output=True, text=True, cwd=str(ROOT), timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -29,13 +29,21 @@ def test_bench_prints_one_json_line():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["kernel"] == "fast_kernel"
     assert d["value"] > 0 and d["ba"]["value"] > 0 and d["pose_refine"]["value"] > 0
+    # BASELINE.json configs[2] rides in the default line: KITTI shape, checked against the oracle, with its own roofline
+    k = d["kitti"]
+    assert "error" not in k, k
+    assert "1241x376" in k["config"]["workload"] and k["value"] > 0 and k["roofline"]["frac"] > 0
+    assert k["checked_against_oracle"]["identical_to_gpu"] is True and k["checked_against_oracle"]["frames_checked"] >= 1, k
+    # the pipelined per-frame front-end: same results as the synchronous call
+    pf = d["frontend_frame"]["pipelined"]
+    assert pf["identical_to_process"] is True and pf["frames_per_s"] > 0 and pf["depth"] == 3
 
 
 def test_line_carries_verified_cpu_baseline():
     """The default line's `cpu_baseline` is not only a timing: the oracle's results for the frames it processed are compared
     bit for bit with what the last timed steps left in HBM (both extractor output sets of the two-stream pipeline, the
     stereo / kNN-2 / filter outputs), and three BA windows with the oracle's solve.  Small batch, short CPU budget."""
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "24",
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--kitti-steps", "0", "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "24",
                         "--distinct", "6", "--ba-windows", "8", "--pose-frames", "0", "--gba-keyframes", "0", "--track-frames", "0",
                         "--cpu-seconds", "1.0"], capture_output=True, text=True, cwd=str(ROOT), timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -56,7 +64,7 @@ def test_gpus_flag_without_a_launcher_on_a_one_gpu_box():
     if torch.cuda.device_count() >= 2:
         pytest.skip("box has two GPUs: the refusal cannot be provoked")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SNK_BENCH_DEVICE")}
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--batch", "16"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--kitti-steps", "0", "--gpus", "2", "--batch", "16"], capture_output=True, text=True,
                        cwd=str(ROOT), timeout=300, env=env)
     assert r.returncode != 0 and "--gpus 2" in r.stderr and "GPU(s)" in r.stderr, (r.returncode, r.stderr[-500:])
     assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
@@ -69,7 +77,7 @@ def test_gpus_flag_spawns_its_own_ranks():
 
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(SNK_DIST_BACKEND="gloo", SNK_BENCH_DEVICE="0")
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16",
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--kitti-steps", "0", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16",
                         "--ba-windows", "8", "--no-cpu-baseline"], capture_output=True, text=True, cwd=str(ROOT), timeout=900, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
@@ -87,7 +95,7 @@ def test_two_ranks_rehearsal_on_one_gpu(mode):
 
     env = dict(os.environ, SNK_DIST_BACKEND="gloo", SNK_BENCH_DEVICE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29577", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--mode",
+           "--master-port", "29577", str(ROOT / "bench.py"), "--kitti-steps", "0", "--gpus", "2", "--steps", "2", "--warmup", "1", "--mode",
            "sequence" if mode == "lockstep" else mode]
     if mode == "lockstep":
         cmd += ["--seqs-per-gpu", "3"]
@@ -120,7 +128,7 @@ def test_one_rank_process_group_on_rccl():
     env = {k: v for k, v in os.environ.items() if k not in ("SNK_DIST_BACKEND", "SNK_BENCH_DEVICE")}
     env.update(SNK_DIST_FORCE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29578")
     for extra in (["--batch", "16", "--ba-windows", "8", "--track-frames", "0"], ["--mode", "sequence"], ["--mode", "sequence", "--host-api"]):
-        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--kitti-steps", "0", "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                             "--gba-keyframes", "0", "--pose-frames", "0"] + extra, capture_output=True, text=True, cwd=str(ROOT), timeout=900, env=env)
         assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
         d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][0])
@@ -130,7 +138,7 @@ def test_one_rank_process_group_on_rccl():
 def test_lockstep_sequence_mode_line():
     """`--mode sequence --seqs-per-gpu S`: S sequences per GPU in lockstep (device-resident chain); the line reports S x steps
     frames per rank and every sequence's recovered motion (the rig moves 0.05 baselines per frame)."""
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--mode", "sequence", "--seqs-per-gpu", "4", "--steps", "5",
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--kitti-steps", "0", "--gpus", "1", "--mode", "sequence", "--seqs-per-gpu", "4", "--steps", "5",
                         "--warmup", "1"], capture_output=True, text=True, cwd=str(ROOT), timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][0])

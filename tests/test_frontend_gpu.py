@@ -181,3 +181,87 @@ def test_invalid_arguments(orc):
     fr.capacity = 10  # too small: SNK_ERR_CAPACITY with the counts set
     assert lib.snk_frontend_process(fe._h, l.ctypes.data, 752, r.ctypes.data, 752, 752, 480, C.byref(fr)) == 4 and fr.n > 900
     fe.close()
+
+
+def test_pipelined_submit_collect_is_bit_identical(orc):
+    """snk_frontend_submit / snk_frontend_collect (the reference's FeatureDetection -> Preprocess stage queue,
+    Snake/Preprocess/FeatureDetector.h:39, Preprocess.h:36): frames come back in submission order and every array is bit for bit what
+    snk_frontend_process returns for that frame -- depths 1..4, through each slot's uncaptured, captured and replayed frames, and with
+    `depth` frames in flight at once."""
+    from snake_slam_amd import SnakeHipError, synth
+    from snake_slam_amd.frontend import Frontend
+    from snake_slam_amd.matcher import Rectification
+
+    orb = (1000, 1.2, 4, 20, 7)
+    bounds, bf = (-120.0, -60.0, 880.0, 540.0), 47.9
+    fe = Frontend(orb, Rectification.make(E_K, E_D), Rectification.make(E_K2, E_D2), bounds, bf)
+    pairs = [synth.stereo_frame(40 + k, 752, 480) for k in range(6)]
+    pairs[4] = (np.full((480, 752), 9, np.uint8), pairs[4][1])  # an empty left image in the stream
+    try:
+        want = [fe.Process(l, r) for l, r in pairs]
+        for depth in (1, 2, 3, 4):
+            fe.set_depth(depth)
+            n_frames = 4 * depth + 3
+            got = []
+            for k in range(n_frames + depth - 1):
+                if k < n_frames:
+                    fe.Submit(*pairs[k % len(pairs)])
+                    assert fe.in_flight() == min(k + 1, depth)
+                if k >= depth - 1:
+                    got.append(fe.Collect())
+            assert fe.in_flight() == 0 and len(got) == n_frames
+            for k, g in enumerate(got):
+                assert_same(g, want[k % len(pairs)], f"depth {depth} frame {k}")
+        # the synchronous call refuses to run under frames in flight; a collect with nothing submitted times out
+        fe.Submit(*pairs[0])
+        with pytest.raises(SnakeHipError, match="in flight"):
+            fe.Process(*pairs[1])
+        small = synth.stereo_frame(1, 320, 240, n_rects=60)
+        with pytest.raises(SnakeHipError, match="in flight"):
+            fe.Submit(*small)
+        assert_same(fe.Collect(), want[0], "after the refused calls")
+        with pytest.raises(SnakeHipError, match="no frame was submitted"):
+            fe.Collect(timeout_ms=20)
+        # another image size once the pipeline is empty, then back
+        w_small = fe.Process(*small)
+        fe.Submit(*small), fe.Submit(*small)
+        assert_same(fe.Collect(), w_small, "small 0"), assert_same(fe.Collect(), w_small, "small 1")
+        fe.Submit(*pairs[2])
+        assert_same(fe.Collect(), want[2], "back to 752x480")
+    finally:
+        fe.close()
+
+
+def test_submit_and_collect_on_different_threads(orc):
+    """One thread submits, another collects (the reference's FeatureDetection and Preprocess threads): 60 frames through a depth-3
+    pipeline, every frame identical to the synchronous call's result, in order."""
+    import threading
+
+    from snake_slam_amd import synth
+    from snake_slam_amd.frontend import Frontend
+    from snake_slam_amd.matcher import Rectification
+
+    fe = Frontend((1000, 1.2, 4, 20, 7), Rectification.make(E_K, E_D), Rectification.make(E_K2, E_D2), (-120.0, -60.0, 880.0, 540.0), 47.9)
+    pairs = [synth.stereo_frame(70 + k, 752, 480) for k in range(5)]
+    try:
+        want = [fe.Process(l, r) for l, r in pairs]
+        fe.set_depth(3)
+        N, errors, got = 60, [], []
+
+        def producer():
+            try:
+                for k in range(N):
+                    fe.Submit(*pairs[k % len(pairs)])
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
+        t = threading.Thread(target=producer)
+        t.start()
+        for k in range(N):
+            got.append(fe.Collect(timeout_ms=20000))
+        t.join()
+        assert not errors, errors
+        for k, g in enumerate(got):
+            assert_same(g, want[k % len(pairs)], f"frame {k}")
+    finally:
+        fe.close()

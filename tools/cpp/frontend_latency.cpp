@@ -3,12 +3,17 @@
 // Preprocess::Process; Snake/Preprocess/FeatureDetector.cpp:116-156, Snake/Preprocess/Preprocess.cpp:35-53) and, for comparison, the
 // same work as the six calls of the per-seam adaptor classes (ORBExtractor::Detect x 2, Preprocess::Rectify x 2, the feature grid,
 // Preprocess::StereoMatching).  Images come as raw u8 arrays from tools/frontend_latency_cpp.py: <dir>/pair<k>_{left,right}.bin
+// Round 5: the PIPELINED form (Frontend::Submit / Collect, the reference's stage queues: FeatureDetector.h:39, Preprocess.h:36) -- still one
+// frame per call: (a) one thread, frame k + 1 submitted before frame k is collected; (b) two threads like the reference's FeatureDetection
+// and Preprocess threads, one submitting, one collecting; for depths 2, 3, 4.  Every collected frame's stereo-match count is compared with
+// the synchronous call's.
 // usage: frontend_latency <dir> <n_pairs> <width> <height> [calls]
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <fstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "snake_hip.hpp"
@@ -86,10 +91,65 @@ int main(int argc, char** argv)
             }
             med[which] = median(ts);
         }
+        // ---- pipelined: frames/s with one frame per call ----
+        std::vector<int> want((size_t)n);
+        const int n_one_last = n_one;
+        for (int k = 0; k < n; ++k) one_call(k), want[(size_t)k] = n_one;
+        n_one = n_one_last;
+        double submit_us[3] = {0, 0, 0};  // mean time inside Submit, two-thread runs, per depth
+        const int frames = calls * 5;
+        bool same        = true;
+        std::string pipe = "{";
+        for (int depth = 2; depth <= 4; ++depth)
+        {
+            fe.SetDepth(depth);
+            double fps[2];
+            for (int threads = 1; threads <= 2; ++threads)
+            {
+                auto run = [&](int count) -> double
+                {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    if (threads == 1)
+                    {
+                        FrontendResult r;
+                        for (int k = 0; k < count + depth - 1; ++k)
+                        {
+                            if (k < count) fe.Submit(L[(size_t)(k % n)].data(), w, R[(size_t)(k % n)].data(), w, w, h);
+                            if (k >= depth - 1) { const int got = fe.Collect(r); same = same && got == want[(size_t)((k - depth + 1) % n)]; }
+                        }
+                    }
+                    else
+                    {
+                        std::thread producer([&]
+                        {
+                            double in_submit = 0;
+                            for (int k = 0; k < count; ++k)
+                            {
+                                const auto s0 = std::chrono::steady_clock::now();
+                                fe.Submit(L[(size_t)(k % n)].data(), w, R[(size_t)(k % n)].data(), w, w, h);
+                                in_submit += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - s0).count();
+                            }
+                            submit_us[depth - 2] = in_submit / count;
+                        });
+                        FrontendResult r;
+                        for (int k = 0; k < count; ++k) { const int got = fe.Collect(r); same = same && got == want[(size_t)(k % n)]; }
+                        producer.join();
+                    }
+                    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                };
+                run(4 * depth);  // every slot past its captured frame
+                fps[threads - 1] = (double)frames / run(frames);
+            }
+            char buf[240];
+            std::snprintf(buf, sizeof(buf), "%s\"depth%d\": {\"one_thread_fps\": %.0f, \"two_threads_fps\": %.0f, \"mean_us_in_submit\": %.1f}", depth > 2 ? ", " : "", depth, fps[0], fps[1], submit_us[depth - 2]);
+            pipe += buf;
+        }
+        pipe += "}";
         std::printf("{\"tool\": \"frontend_latency.cpp\", \"image\": \"%dx%d stereo\", \"calls\": %d, \"one_call_ms\": %.4f, \"six_calls_ms\": %.4f, "
-                    "\"stereo_matches_last_frame\": {\"one_call\": %d, \"six_calls\": %d}}\n",
-                    w, h, calls, med[0], med[1], n_one, n_six);
-        return n_one == n_six ? 0 : 3;
+                    "\"stereo_matches_last_frame\": {\"one_call\": %d, \"six_calls\": %d}, \"pipelined_frames\": %d, \"pipelined\": %s, "
+                    "\"pipelined_identical_match_counts\": %s}\n",
+                    w, h, calls, med[0], med[1], n_one, n_six, frames, pipe.c_str(), same ? "true" : "false");
+        return n_one == n_six && same ? 0 : 3;
     }
     catch (const std::exception& e)
     {

@@ -21,7 +21,7 @@ def main():
     with tempfile.TemporaryDirectory() as d:
         exe = os.path.join(d, "frontend_latency")
         cmd = ["g++", "-std=c++17", "-O2", "-Wall", f"-I{ROOT}/include", f"-I{ROOT}/snake_slam_amd/cpp", f"{ROOT}/tools/cpp/frontend_latency.cpp",
-               f"-L{lib}", "-lsnake_hip", "-L/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+               f"-L{lib}", "-lsnake_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lpthread", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
         subprocess.run(cmd, check=True)
         for k in range(n):
             l, r = synth.stereo_frame(300 + k, w, h)
