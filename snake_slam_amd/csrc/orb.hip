@@ -684,8 +684,27 @@ __global__ __launch_bounds__(256, SNK_FAST_MIN_WAVES) void fast_kernel(Layout L,
     const bool ini = nini > 0;
     const u32 thr  = ((u32)(ini ? ini_th : min_th) << 12) | 0xFFFu;  // key > thr  <=>  score > threshold
     const int n    = ini ? nini : nl;
-    // rank the survivors of the effective threshold by strength; keep the CELL_SLOTS strongest
     u32* out = cand + cell_index * CELL_SLOTS;
+    if (n <= CELL_SLOTS)
+    {
+        // The usual cell: every candidate of the effective threshold has a slot, so the slots need no order -- the order only matters
+        // when somebody has to CUT a cell to its k strongest, i.e. when the level holds more candidates than its budget; distribute_kernel
+        // ranks such cells itself (rank_cut_cells, noise-like images only).  Compaction by ballot prefix instead of the all-pairs rank
+        // (~70 of the ~570 vector instructions of a cell).
+        int at = 0;
+        for (int i0 = 0; i0 < nl; i0 += 64)  // nl may exceed 64 when the ini threshold applies (the list holds everything above min_th)
+        {
+            const int i    = i0 + lane;
+            const u32 k    = list[min(i, nl - 1)];
+            const bool put = i < nl && k > thr;
+            const u64 m    = __builtin_amdgcn_ballot_w64(put);
+            if (put) out[at + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u))] = k;
+            at += __popcll(m);
+        }
+    }
+    else
+    {
+    // more candidates than slots: rank them by strength, keep the CELL_SLOTS strongest (in that order)
     for (int i = lane; i < nl; i += 64)
     {
         const u32 k = list[i];
@@ -699,6 +718,7 @@ __global__ __launch_bounds__(256, SNK_FAST_MIN_WAVES) void fast_kernel(Layout L,
         }
         for (; j < nl; ++j) r += list[j] > k ? 1 : 0;
         if (r < CELL_SLOTS) out[r] = k;
+    }
     }
     if (lane == 0) cell_cnt[cell_index] = (u16)(n > 65535 ? 65535 : n);
     }
@@ -1238,12 +1258,12 @@ __device__ void bucket_rank_sort(u64* keys, int n, int cap, int nroots, unsigned
 //   fd    u8[cap]       final node depth of every sorted point
 // Returns false (nothing written) when the level holds more candidates than this launch's LDS
 // carve (lds_cap) can sort; the caller then queues the (image, level) for the large-LDS launch.
-__device__ bool distribute_body(const Layout& L, int b, int l, int lds_cap, const u32* __restrict__ cand,
+__device__ bool distribute_body(const Layout& L, int b, int l, int lds_cap, u32* cand /* slots of cut cells are re-ordered in place */,
                                 const u16* __restrict__ cell_cnt, u32* __restrict__ sel /* [B][total_slots] x|y<<16 */,
                                 u8* __restrict__ sel_score, int* __restrict__ sel_cnt,
                                 int* __restrict__ cand_total /* debug: [B][levels] */,
                                 unsigned long long* __restrict__ dbg_t = nullptr /* SNK_ORB_DIST_TIMING: [levels][16] cycle sums */,
-                                const u32* __restrict__ cand_h = nullptr /* "orb.response" = 1: Harris rank per candidate slot */,
+                                u32* cand_h = nullptr /* "orb.response" = 1: Harris rank per candidate slot (moves with its slot) */,
                                 u32* __restrict__ sel_resp = nullptr /* ... and the selected keypoints' ranks */,
                                 u32* __restrict__ h_global = nullptr /* ranks of this workgroup's candidates when the LDS carve has no room (full-budget launch) */)
 {
@@ -1279,8 +1299,8 @@ __device__ bool distribute_body(const Layout& L, int b, int l, int lds_cap, cons
     const int ncell = lv.ncols * lv.nrows;
     const int N     = lv.nfeat;
     const u16* cc   = cell_cnt + (long long)b * L.total_cells + lv.cell_off;
-    const u32* cd   = cand + ((long long)b * L.total_cells + lv.cell_off) * CELL_SLOTS;
-    const u32* chd  = cand_h ? cand_h + ((long long)b * L.total_cells + lv.cell_off) * CELL_SLOTS : nullptr;
+    u32* cd         = cand + ((long long)b * L.total_cells + lv.cell_off) * CELL_SLOTS;
+    u32* chd        = cand_h ? cand_h + ((long long)b * L.total_cells + lv.cell_off) * CELL_SLOTS : nullptr;
     int* out_cnt    = sel_cnt + b * MAX_LEVELS + l;
 
     // ---- 1. per-cell budget k: largest k <= CELL_SLOTS with sum(min(cnt, k)) <= cap -------------
@@ -1302,6 +1322,32 @@ __device__ bool distribute_body(const Layout& L, int b, int l, int lds_cap, cons
     const int n     = s_n;
     mark(0);
     if (n > cap) return false;
+    // fast_kernel leaves the slots of a cell with <= CELL_SLOTS candidates in no particular order (cells with more hold their
+    // CELL_SLOTS strongest, strongest first).  When the level budget cuts cells (kcell < CELL_SLOTS: more candidates on the level than
+    // its budget -- noise, dense texture), a cell with kcell < count <= CELL_SLOTS is ranked here, in place, one wavefront per cell with a
+    // lane per slot; keys are distinct, so the ranks are a permutation.  The Harris ranks ("orb.response" = 1) move with their slots.
+    if (kcell < CELL_SLOTS)  // workgroup-uniform
+    {
+        u32* cdw = cd;
+        u32* chw = chd;
+        const int lane = tid & 63;
+        for (int c = tid >> 6; c < ncell; c += DIST_THREADS / 64)  // wave-uniform
+        {
+            const int cnt = (int)cc[c];
+            if (cnt <= kcell || cnt > CELL_SLOTS) continue;
+            const u32 k = lane < cnt ? cdw[(long long)c * CELL_SLOTS + lane] : 0u;
+            const u32 h = chw && lane < cnt ? chw[(long long)c * CELL_SLOTS + lane] : 0u;
+            int r       = 0;
+            for (int j = 0; j < cnt; ++j) r += (u32)__builtin_amdgcn_readlane((int)k, __builtin_amdgcn_readfirstlane(j)) > k ? 1 : 0;
+            __builtin_amdgcn_wave_barrier();  // every lane holds its key before any slot is overwritten
+            if (lane < cnt)
+            {
+                cdw[(long long)c * CELL_SLOTS + r] = k;
+                if (chw) chw[(long long)c * CELL_SLOTS + r] = h;
+            }
+        }
+        __syncthreads();  // the gather below reads the slots this workgroup has just rewritten (same CU, workgroup-scope ordering)
+    }
     if (tid == 0 && cand_total) cand_total[b * MAX_LEVELS + l] = n;
     if (n == 0 || N <= 0)
     {
@@ -1686,11 +1732,11 @@ __device__ bool distribute_body(const Layout& L, int b, int l, int lds_cap, cons
 }
 
 // small-LDS launch over every (level, image); levels that do not fit are queued
-__global__ __launch_bounds__(DIST_THREADS, SNK_DIST_MIN_WAVES) void distribute_kernel(Layout L, int lds_cap, const u32* __restrict__ cand,
+__global__ __launch_bounds__(DIST_THREADS, SNK_DIST_MIN_WAVES) void distribute_kernel(Layout L, int lds_cap, u32* cand,
                                                                   const u16* __restrict__ cell_cnt, u32* __restrict__ sel,
                                                                   u8* __restrict__ sel_score, int* __restrict__ sel_cnt,
                                                                   int* __restrict__ cand_total, int* __restrict__ queue,
-                                                                  unsigned long long* __restrict__ dbg_t, const u32* __restrict__ cand_h,
+                                                                  unsigned long long* __restrict__ dbg_t, u32* cand_h,
                                                                   u32* __restrict__ sel_resp)
 {
     const int l = blockIdx.x, b = blockIdx.y;
@@ -1699,11 +1745,11 @@ __global__ __launch_bounds__(DIST_THREADS, SNK_DIST_MIN_WAVES) void distribute_k
 }
 
 // full-budget launch: a fixed set of workgroups drains the queue (normally empty)
-__global__ __launch_bounds__(DIST_THREADS) void distribute_large_kernel(Layout L, const u32* __restrict__ cand,
+__global__ __launch_bounds__(DIST_THREADS) void distribute_large_kernel(Layout L, u32* cand,
                                                                         const u16* __restrict__ cell_cnt,
                                                                         u32* __restrict__ sel, u8* __restrict__ sel_score,
                                                                         int* __restrict__ sel_cnt, int* __restrict__ cand_total,
-                                                                        const int* __restrict__ queue, const u32* __restrict__ cand_h,
+                                                                        const int* __restrict__ queue, u32* cand_h,
                                                                         u32* __restrict__ sel_resp, u32* __restrict__ h_scratch)
 {
     const int count = queue[0];
