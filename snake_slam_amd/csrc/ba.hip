@@ -2647,7 +2647,20 @@ struct PcgLarge
     double* ppap;  // [B][G]    partial p.Ap
     double* scal;  // [B][4]    stop2, done, -, -
     int G, parts, tot_vec, B;
+    // the one-launch form (pcgl_persist, one problem): p double-buffered, per-workgroup partial sums, the grid barrier's counter
+    double* p2;       // [tot_vec]  the other direction buffer
+    double* wrr;      // [2][PERSIST_WGS]  partial r.r  (by iteration parity)
+    double* wrz;      // [2][PERSIST_WGS]  partial r.z
+    double* wpap;     // [PERSIST_WGS]     partial p.Ap
+    unsigned* bar;    // [PERSIST_WGS_MAX] the grid barrier's per-workgroup phase flags (zeroed by pcgl_init)
+    int persist_wgs;  // workgroups of the launch (all resident: cooperative launch)
 };
+constexpr int PERSIST_WGS_MAX = 1024;
+static inline int snk_env_int(const char* name, int dflt)
+{
+    const char* e = getenv(name);
+    return e && atoi(e) > 0 ? atoi(e) : dflt;
+}
 
 __device__ __forceinline__ double wave_sum64(double v)
 {
@@ -2695,6 +2708,8 @@ __global__ __launch_bounds__(64) void pcgl_init(Arrays A, Opt O, PcgLarge W)
     }
     rr = wave_sum64(rr);
     rz = wave_sum64(rz);
+    if (pb == 0 && blockIdx.x == 0 && W.bar)
+        for (int i = threadIdx.x; i < PERSIST_WGS_MAX; i += 64) W.bar[i] = 0u;  // the grid barrier's flags of pcgl_persist
     if (threadIdx.x == 0)
     {
         W.prr[(size_t)pb * W.G + blockIdx.x] = rr;  // buffer 0
@@ -2703,6 +2718,7 @@ __global__ __launch_bounds__(64) void pcgl_init(Arrays A, Opt O, PcgLarge W)
         {
             W.scal[pb * 4 + 1] = 0.0;  // done
             W.scal[pb * 4 + 0] = -1.0;  // stop2 not known yet (needs all partials): derived in pcgl_matvec of iteration 0
+
         }
     }
 }
@@ -2848,6 +2864,172 @@ __global__ void pcgl_latch(Arrays A, Opt O, PcgLarge W, int k)
         W.scal[pb * 4 + 1] = 1.0;
     else
         A.state[pb].pcg_iters += 1;
+}
+
+// ---- the same PCG as ONE launch (round 5; one problem -- a global scene is one problem) ----
+// The multi-launch form above pays five launches per PCG iteration and ran `pcgl_combine` on ceil(cameras / 64) wavefronts: FullBA(4) on
+// 300 keyframes was 160 iterations x 85 us = 13.5 of its 14.4 ms (profiles/r05/r05i_gba_kernel_stats.csv), none of it bandwidth.  Here
+// all workgroups stay resident (cooperative launch) and the phases of an iteration are separated by a grid barrier:
+//   1 matvec   (A p)[q] for the workgroup's rows q: S is symmetric, so row q is contiguous and one wavefront streams it against the
+//              direction p = z + beta p_prev held in LDS; partial p.Ap per workgroup                                -- barrier
+//   2 update   x += alpha p, r -= alpha Ap, z = Minv r (a thread per element, cameras never straddle workgroups),
+//              partial r.r / r.z of the next parity                                                                 -- barrier
+// Scalars (r.r, r.z, p.Ap, alpha, beta, the stopping test) are re-derived by every workgroup from the partial sums in a fixed
+// order: deterministic, no floating-point atomics.  The barrier is an arrival counter in HBM: __syncthreads, one agent-scope
+// release increment per workgroup, a spin on an agent-scope acquire load, __syncthreads.
+__device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned n_wgs, unsigned& phase)
+{
+    // One flag per workgroup, no read-modify-write: an arrival counter costs one device-scope atomic per workgroup on ONE address, and
+    // those are served one after the other at the memory side (the XCDs' L2s are not coherent with each other): 512 arrivals took
+    // ~45 us per barrier (profiles/r05/r05j_gba_persist_counter_barrier.txt).  Here a workgroup publishes its phase with a plain
+    // device-scope store and its first wavefront polls everybody's flags (n_wgs / 64 coalesced loads per round).
+    __syncthreads();
+    ++phase;
+    if (threadIdx.x < 64)
+    {
+        if (threadIdx.x == 0) __hip_atomic_store(bar + blockIdx.x, phase, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;)
+        {
+            bool ok = true;
+            for (unsigned i = threadIdx.x; i < n_wgs; i += 64) ok = ok && __hip_atomic_load(bar + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= phase;
+            if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);  // agent scope by default: the other workgroups' stores before their flags are visible
+    }
+    __syncthreads();
+}
+
+// sum of n partials in a fixed order by one wavefront-sized group of threads: lane l adds entries l, l + 64, ... then a butterfly
+__device__ __forceinline__ double sum_partials_wave(const double* a, int n, int lane)
+{
+    double t = 0.0;
+    for (int i = lane; i < n; i += 64) t += a[i];
+    return wave_sum64(t);
+}
+
+constexpr int PERSIST_THREADS = 256;
+constexpr int PERSIST_CAMS    = PERSIST_THREADS / 6;  // 42 cameras (252 elements) per workgroup in the update phase
+
+__global__ __launch_bounds__(PERSIST_THREADS) void pcgl_persist(Arrays A, Opt O, PcgLarge W)
+{
+    extern __shared__ __attribute__((aligned(16))) double sh_p[];  // the direction p of this iteration, all n6 entries
+    __shared__ double sh_r[PERSIST_THREADS], sh_red[2][PERSIST_THREADS / 64];
+    const Prob pr  = A.prob[0];
+    const int n6   = pr.n6, nfc = pr.nfc;
+    if (n6 == 0) return;  // every workgroup
+    const int tid  = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NW   = gridDim.x;
+    const int wg   = blockIdx.x;
+    const double* S = A.S + pr.s_off;
+    const int rpw   = (n6 + NW - 1) / NW;                            // rows of S (= entries of A p) per workgroup
+    const int q0    = min(wg * rpw, n6), q1 = min(q0 + rpw, n6);
+    const int n_upd = (nfc + PERSIST_CAMS - 1) / PERSIST_CAMS;       // workgroups of the update phase (= partial r.r / r.z entries)
+    unsigned phase = 0;
+    double stop2   = 0.0;
+    // parity 0 partials of r.r / r.z come from pcgl_init (camera groups of 64): G entries
+    int n_prev = (nfc + 63) / 64;
+    const double* prr_prev = W.prr;  // [B = 1][G], buffer 0
+    const double* prz_prev = W.prz;
+    double rz_prev = 0.0, rz_cur = 0.0;
+    int iters = 0;
+    for (int k = 0; k < O.max_pcg; ++k)
+    {
+        const double* p_prev = (k & 1) ? W.p2 : W.p;  // the direction of iteration k - 1 (k = 0: z, written by pcgl_init into p)
+        double* p_cur        = (k & 1) ? W.p : W.p2;
+        // ---- scalars of this iteration: |r|^2, r.z (every thread computes the same values) ----
+        const double rn2 = sum_partials_wave(prr_prev, n_prev, lane);
+        rz_cur           = sum_partials_wave(prz_prev, n_prev, lane);
+        if (k == 0) stop2 = O.pcg_tol * O.pcg_tol * rn2;
+        if (rn2 <= stop2) break;  // grid-uniform
+        const double beta = k == 0 ? 0.0 : rz_cur / rz_prev;
+        // ---- 1. A p for the workgroup's rows.  S is symmetric: row q is contiguous, a wavefront streams it (16 bytes per lane) against
+        // the direction in LDS, formed on the fly as z + beta p_prev; the rows' p entries are stored for the update / the next iteration ----
+        for (int u = tid; u < n6; u += PERSIST_THREADS) sh_p[u] = W.z[u] + beta * p_prev[u];
+        __syncthreads();
+        {
+            double pap = 0.0;
+            const int n2 = n6 >> 1;  // n6 = 6 * cameras: even, rows start 16-byte aligned (one problem: s_off = 0)
+            const double2* sp2 = reinterpret_cast<const double2*>(sh_p);
+            for (int q = q0 + wave; q < q1; q += PERSIST_THREADS / 64)
+            {
+                const double2* row = reinterpret_cast<const double2*>(S + (size_t)q * n6);
+                double acc = 0.0;
+                int u = lane;
+                for (; u + 192 < n2; u += 256)  // four loads in flight
+                {
+                    const double2 s0 = row[u], s1 = row[u + 64], s2 = row[u + 128], s3 = row[u + 192];
+                    const double2 p0 = sp2[u], p1 = sp2[u + 64], p2 = sp2[u + 128], p3 = sp2[u + 192];
+                    acc += s0.x * p0.x; acc += s0.y * p0.y;
+                    acc += s1.x * p1.x; acc += s1.y * p1.y;
+                    acc += s2.x * p2.x; acc += s2.y * p2.y;
+                    acc += s3.x * p3.x; acc += s3.y * p3.y;
+                }
+                for (; u < n2; u += 64)
+                {
+                    const double2 s0 = row[u], p0 = sp2[u];
+                    acc += s0.x * p0.x; acc += s0.y * p0.y;
+                }
+                acc = wave_sum64(acc);
+                if (lane == 0)
+                {
+                    const double pq = sh_p[q];
+                    W.Ap[q]  = acc;
+                    p_cur[q] = pq;
+                    pap += pq * acc;
+                }
+            }
+            if (lane == 0) sh_red[0][wave] = pap;
+            __syncthreads();
+            if (tid == 0) W.wpap[wg] = (sh_red[0][0] + sh_red[0][1]) + (sh_red[0][2] + sh_red[0][3]);
+        }
+        grid_barrier(W.bar, NW, phase);
+        // ---- 2. update ----
+        const double pAp = sum_partials_wave(W.wpap, NW, lane);
+        if (pAp <= 0.0) break;  // grid-uniform (the reference's break: the step of this iteration is not applied)
+        const double alpha = rz_cur / pAp;
+        double* wrr = W.wrr + (size_t)((k + 1) & 1) * PERSIST_WGS_MAX;
+        double* wrz = W.wrz + (size_t)((k + 1) & 1) * PERSIST_WGS_MAX;
+        for (int g = wg; g < n_upd; g += NW)  // normally one pass
+        {
+            const int cl = tid / 6, a = tid - cl * 6;  // camera inside the group, row
+            const int c  = g * PERSIST_CAMS + cl;
+            const bool on = cl < PERSIST_CAMS && c < nfc;
+            const int q  = c * 6 + a;
+            double rv    = 0.0;
+            if (on)
+            {
+                A.x[q] += alpha * p_cur[q];
+                rv     = W.r[q] - alpha * W.Ap[q];
+                W.r[q] = rv;
+            }
+            sh_r[tid] = rv;
+            __syncthreads();
+            double zz = 0.0;
+            if (on)
+            {
+                const double* Mi = W.Minv + (size_t)(pr.cam_off + c) * 36 + a * 6;
+                for (int b = 0; b < 6; ++b) zz += Mi[b] * sh_r[cl * 6 + b];
+                W.z[q] = zz;
+            }
+            const double rr = wave_sum64(rv * rv), rzn = wave_sum64(rv * zz);
+            if (lane == 0) sh_red[0][wave] = rr, sh_red[1][wave] = rzn;
+            __syncthreads();
+            if (tid == 0)
+            {
+                wrr[g] = (sh_red[0][0] + sh_red[0][1]) + (sh_red[0][2] + sh_red[0][3]);
+                wrz[g] = (sh_red[1][0] + sh_red[1][1]) + (sh_red[1][2] + sh_red[1][3]);
+            }
+            __syncthreads();
+        }
+        grid_barrier(W.bar, NW, phase);
+        prr_prev = wrr;
+        prz_prev = wrz;
+        n_prev   = n_upd;
+        rz_prev  = rz_cur;
+        ++iters;
+    }
+    if (wg == 0 && tid == 0) A.state[0].pcg_iters += iters;
 }
 
 // pose <- exp(delta) * pose
@@ -3416,6 +3598,7 @@ struct Launcher
     hipGraphNode_t last = nullptr;
     hipError_t err      = hipSuccess;
     int line            = 0;
+    bool cooperative    = false;  // the next launch is a cooperative one (all workgroups resident: grid barriers inside); plain launches only
     template <typename... P, typename... A>
     void operator()(int at, void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, A&&... a)
     {
@@ -3424,7 +3607,12 @@ struct Launcher
         std::tuple<P...> args{static_cast<P>(a)...};
         void* ptrs[sizeof...(P)];
         fill(ptrs, args, std::index_sequence_for<P...>{});
-        if (!graph)
+        if (cooperative)
+        {
+            cooperative = false;
+            err         = graph ? hipErrorNotSupported : hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kernel), grid, block, ptrs, (unsigned)lds, st);
+        }
+        else if (!graph)
             err = hipLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, ptrs, lds, st);
         else
         {
@@ -4387,7 +4575,8 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         const int rowchunks = std::max(1, ceil_div(max_n6, 256));
         W.parts             = std::min(64, std::max(1, ceil_div(1024, rowchunks * count)));
         const size_t nv = (size_t)std::max(vec_off, 1), ng = (size_t)count * W.G;
-        const size_t doubles = 4 * nv + (size_t)std::max(cam_off, 1) * 36 + (size_t)W.parts * nv + 5 * ng + (size_t)count * 4;
+        const size_t doubles = 4 * nv + (size_t)std::max(cam_off, 1) * 36 + (size_t)std::max(W.parts, PERSIST_WGS_MAX / rowchunks + 1) * nv + 5 * ng + (size_t)count * 4 +
+                               nv + 6 * (size_t)PERSIST_WGS_MAX + 8;
         RS(d_pcgw, doubles * 8);
         double* w = h->d_pcgw.as<double>();
         W.r = w;            w += nv;
@@ -4395,11 +4584,37 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         W.p = w;            w += nv;
         W.Ap = w;           w += nv;
         W.Minv = w;         w += (size_t)std::max(cam_off, 1) * 36;
-        W.ps = w;           w += (size_t)W.parts * nv;
+        W.ps = w;           w += (size_t)std::max(W.parts, PERSIST_WGS_MAX / rowchunks + 1) * nv;
         W.prr = w;          w += 2 * ng;
         W.prz = w;          w += 2 * ng;
         W.ppap = w;         w += ng;
-        W.scal = w;
+        W.scal = w;         w += (size_t)count * 4;
+        W.p2 = w;           w += nv;
+        W.wrr = w;          w += 2 * (size_t)PERSIST_WGS_MAX;
+        W.wrz = w;          w += 2 * (size_t)PERSIST_WGS_MAX;
+        W.wpap = w;         w += (size_t)PERSIST_WGS_MAX;
+        W.bar = reinterpret_cast<unsigned*>(w);
+        // one problem, a cooperative launch the device can hold: two workgroups per compute unit (SNK_BA_PCGL_LAUNCHES=1: the
+        // multi-launch form, A/B and the fallback for batches of large problems)
+        W.persist_wgs = 0;
+        static const bool launches_env = getenv("SNK_BA_PCGL_LAUNCHES") != nullptr;
+        if (count == 1 && !launches_env)
+        {
+            hipDeviceProp_t prop;
+            int coop = 0, per_cu = 0;
+            if (hipGetDeviceProperties(&prop, h->device) == hipSuccess &&
+                hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, h->device) == hipSuccess && coop &&
+                (per_cu = 1) >= 1)
+            {
+                // one workgroup per compute unit: the barrier's cost grows with the participants (measured 7.0 ms per FullBA(4) with 256, 10.4 with 512)
+                // workgroups: a dozen rows of S each, at most one per compute unit -- the barrier's cost grows with the participants (FullBA(4) on 300
+                // keyframes, n6 = 1794: 5.0 / 4.6 / 5.9 / 5.0 ms with 256 / 128 / 64 / 32 workgroups, 10.4 with 512 in the three-barrier form)
+                const int wgs = std::min(PERSIST_WGS_MAX, snk_env_int("SNK_BA_PERSIST_WGS", std::min(prop.multiProcessorCount, std::max(16, ceil_div(max_n6, 12)))));
+                const bool fits = (size_t)max_n6 * 8 <= 150 * 1024 && ceil_div(max_nfc, PERSIST_CAMS) <= PERSIST_WGS_MAX;  // p in LDS; partial-sum slots
+                if (wgs >= 1 && fits && set_max_lds_once(reinterpret_cast<const void*>(pcgl_persist), 150 * 1024) == SNK_OK) W.persist_wgs = wgs;
+            }
+            (void)hipGetLastError();
+        }
     }
 #undef RS
 #undef UP
@@ -4768,6 +4983,12 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L, bool only_marked =
                 const dim3 gcam(W.G, B);
                 const dim3 gmv(ceil_div(h->max_n6, 256) * W.parts, B);
                 LAUNCH(pcgl_init, gcam, dim3(64), 0, A, O, W);
+                if (W.persist_wgs > 0 && B == 1 && L.graph == nullptr)
+                {
+                    L.cooperative = true;
+                    LAUNCH(pcgl_persist, dim3(W.persist_wgs), dim3(PERSIST_THREADS), (size_t)h->max_n6 * 8, A, O, W);
+                }
+                else
                 for (int k = 0; k < O.max_pcg; ++k)
                 {
                     LAUNCH(pcgl_matvec, gmv, dim3(256), 0, A, O, W, k);
@@ -4823,7 +5044,9 @@ int snk_ba_solve_async(snk_ba* h, int iterations)
     static const bool graph_first = getenv("SNK_BA_GRAPH_FIRST") != nullptr;
     Launcher direct;
     direct.st = h->stream;
-    if (no_graph || iterations == 0) return enqueue_lm(h, iterations, direct);
+    // a cooperative launch is not a graph node: scenes solved by the one-launch PCG (global BA) always take plain launches -- seven per
+    // LM iteration there, against milliseconds of work
+    if (no_graph || iterations == 0 || (h->pcg_large && h->pcgw.persist_wgs > 0 && h->count == 1)) return enqueue_lm(h, iterations, direct);
     auto it = h->graphs.find(iterations);
     if (it == h->graphs.end())
     {

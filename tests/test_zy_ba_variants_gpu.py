@@ -36,6 +36,7 @@ ROOT = Path(__file__).resolve().parent.parent
     {"SNK_BA_HOST_THREADS": "4", "SNK_BA_CHECK_LISTS": "1", "SNK_BA_SCHUR_SET_MIN_ITEMS": "1"},  # the threaded list builder of a batch hand-over forced on every batch of >= 2 scenes, its lists checked
     {"SNK_BA_HOST_THREADS": "3", "SNK_BA_NO_SCHUR_SET": "1"},
     {"SNK_BA_NO_SCHUR_WIDE": "1", "SNK_BA_NO_SCHUR_SET": "1"},          # block-major schur_pass with one wavefront per block also for single windows
+    {"SNK_BA_PCGL_LAUNCHES": "1"},                                      # global scenes: the multi-launch PCG (pcgl_matvec / combine / update / direction / latch) instead of the one cooperative launch (pcgl_persist)
 ])
 def test_ba_parity_suite_with_forced_path(env):
     r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_ba_gpu.py"), "-m", "gpu", "-x", "-q", "-rf", "--tb=short",

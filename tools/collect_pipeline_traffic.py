@@ -22,6 +22,21 @@ ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "snake_slam_amd" / "csrc"
 
 
+def per_kernel_total(d: Path, counter: str):
+    """kernel -> (bytes summed over ALL dispatches of the run, dispatches).  Round 5: the front-end section is total / steps -- the round-4
+    form (mean over the "big" dispatches x count) dropped level_kernel's smallest level from the mean and over-counted it by 1.2."""
+    vals = defaultdict(lambda: defaultdict(float))
+    for f in (d / f"pmc_{counter}").rglob("*counter_collection.csv"):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row["Counter_Name"] == counter:
+                    n = re.sub(r"\(anonymous namespace\)::", "", row["Kernel_Name"])
+                    n = re.sub(r"^void ", "", n).split("(")[0]
+                    if n.startswith("snk::"):
+                        vals[n][row["Dispatch_Id"]] += float(row["Counter_Value"]) * 1024.0
+    return {k: (sum(v.values()), len(v)) for k, v in vals.items()}
+
+
 def per_kernel(d: Path, counter: str):
     """kernel -> (mean bytes per dispatch, dispatches per run)"""
     vals = defaultdict(lambda: defaultdict(float))
@@ -53,9 +68,10 @@ def sha(*names):
 def main():
     dfe, dba, frames, windows = Path(sys.argv[1]), Path(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     out = {}
-    f, w = per_kernel(dfe, "FETCH_SIZE"), per_kernel(dfe, "WRITE_SIZE")
+    f, w = per_kernel_total(dfe, "FETCH_SIZE"), per_kernel_total(dfe, "WRITE_SIZE")
     if f:
-        # tools/profile_gpu.sh runs bench.py --steps 3 --warmup 1: 4 steps; a kernel launched k times per step shows 4 k dispatches
+        # tools/profile_gpu.sh runs bench.py --steps 3 --warmup 1 (no per-frame leg, no KITTI leg): 4 steps; every front-end dispatch of the run
+        # belongs to one of them
         steps = 4
         ks = {}
         fe_kernels = ("level_kernel", "fast_kernel", "distribute", "describe_kernel", "rectify_kernel", "grid_kernel", "reorder_kernel",
@@ -66,11 +82,10 @@ def main():
                 continue
             fb, nd = f.get(k, (0.0, 0))
             wb, _ = w.get(k, (0.0, 0))
-            per_step = nd / steps
-            ks[k] = {"launches_per_step": round(per_step, 2), "fetch_bytes_per_step": int(fb * per_step), "write_bytes_per_step": int(wb * per_step)}
-            tot_raw += fb * per_step
-            tot_x2 += 2 * fb * per_step
-            tot_w += wb * per_step
+            ks[k] = {"launches_per_step": round(nd / steps, 2), "fetch_bytes_per_step": int(fb / steps), "write_bytes_per_step": int(wb / steps)}
+            tot_raw += fb / steps
+            tot_x2 += 2 * fb / steps
+            tot_w += wb / steps
         out["frontend"] = {"frames_per_step": frames, "kernels": ks, "fetch_bytes_per_frame_raw": int(tot_raw / frames),
                            "fetch_bytes_per_frame_x2": int(tot_x2 / frames), "write_bytes_per_frame": int(tot_w / frames),
                            "hbm_bytes_per_frame": int((tot_x2 + tot_w) / frames), "run": dfe.name,
@@ -92,6 +107,17 @@ def main():
         out["ba"] = {"windows_per_launch": windows, "kernels": ks, "fetch_bytes_per_window_iteration_raw": int(tot_raw / windows),
                      "fetch_bytes_per_window_iteration_x2": int(2 * tot_raw / windows), "write_bytes_per_window_iteration": int(tot_w / windows),
                      "hbm_bytes_per_window_iteration": int((2 * tot_raw + tot_w) / windows), "run": dba.name, "source_sha256": sha("ba.hip")}
+    # global BA (tools/profile_gba.sh <tag> pmc): counter bytes of one FullBA(4) = everything the run's solves moved / solves
+    dg = dfe.parent / dfe.name.replace("prof_", "prof_gba_")
+    if (dg / "pmc_FETCH_SIZE").exists():
+        f, w = per_kernel_total(dg, "FETCH_SIZE"), per_kernel_total(dg, "WRITE_SIZE")
+        solves = 4  # tools/gba_trace.py: the first solve + three timed ones
+        ks = {k: {"dispatches": f.get(k, (0, 0))[1], "fetch_bytes_per_solve": int(f.get(k, (0.0, 0))[0] / solves), "write_bytes_per_solve": int(w.get(k, (0.0, 0))[0] / solves)}
+              for k in sorted(set(f) | set(w))}
+        tf, tw = sum(v[0] for v in f.values()) / solves, sum(v[0] for v in w.values()) / solves
+        out["gba"] = {"scene": "300 keyframes x 15 000 points x 10 observations, FullBA(4)", "kernels": ks, "fetch_bytes_per_solve_raw": int(tf),
+                      "fetch_bytes_per_solve_x2": int(2 * tf), "write_bytes_per_solve": int(tw), "hbm_bytes_per_solve": int(2 * tf + tw), "run": dg.name,
+                      "source_sha256": sha("ba.hip")}
     out["note"] = ("MI355X_MICROARCH.md section HBM: FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads; an upper estimate "
                    "for narrow gathers), WRITE_SIZE as reported; separate --pmc passes per counter")
     (ROOT / "profiles" / "pipeline_traffic.json").write_text(json.dumps(out, indent=1) + "\n")

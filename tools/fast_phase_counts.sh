@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 for s in 1 2 3 4 0; do
-  SNK_ORB_FAST_STOP=$s rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/fastphase/s$s -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --ba-windows 0 --pose-frames 0 --track-frames 0 > /dev/null 2>&1
+  SNK_ORB_FAST_STOP=$s rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/fastphase/s$s -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --ba-windows 0 --pose-frames 0 --track-frames 0 --gba-keyframes 0 --frame-calls 0 --kitti-steps 0 > /dev/null 2>&1
 done
 python - <<PY
 import csv,glob,os
