@@ -3871,6 +3871,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     }
     else if (host_threads_env > 0 && count >= 2)
         n_threads = std::min(host_threads_env, count);  // tests force the threaded form on small batches
+    std::atomic<bool> worker_failed{false};
     auto parallel_for = [&](auto&& body)
     {
         if (n_threads <= 1)
@@ -3880,16 +3881,32 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         }
         std::atomic<int> next{0};
         std::vector<std::thread> pool;
+        // an exception in a worker (the vectors it grows: std::bad_alloc) must not reach std::terminate: it is caught, the remaining
+        // work is abandoned and the caller turns worker_failed into an error code after the join
         auto work = [&]()
         {
-            for (;;)
+            try
             {
-                const int b0 = next.fetch_add(8);
-                if (b0 >= count) return;
-                for (int b = b0; b < std::min(b0 + 8, count); ++b) body(b);
+                for (;;)
+                {
+                    const int b0 = next.fetch_add(8);
+                    if (b0 >= count || worker_failed.load(std::memory_order_relaxed)) return;
+                    for (int b = b0; b < std::min(b0 + 8, count); ++b) body(b);
+                }
+            }
+            catch (...)
+            {
+                worker_failed.store(true);
             }
         };
-        for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
+        try
+        {
+            for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
+        }
+        catch (...)
+        {
+            worker_failed.store(true);  // thread creation failed: the threads that exist finish, this thread does the rest
+        }
         work();
         for (auto& t : pool) t.join();
     };
@@ -3910,6 +3927,11 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         q.no  = no;
         q.dup = 0;
     });
+    if (worker_failed.load())
+    {
+        set_error("snk_ba_set_problems: a list-building thread failed (out of host memory?)");
+        return SNK_ERR_HIP;
+    }
     {
         size_t a_img = 0, a_pt = 0, a_ps = 0, a_obs = 0;
         long long a_orig = 0;
@@ -3983,6 +4005,11 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             q_pt[sl]   = p;
         }
     });
+    if (worker_failed.load())
+    {
+        set_error("snk_ba_set_problems: a list-building thread failed (out of host memory?)");
+        return SNK_ERR_HIP;
+    }
     mark(0);
     mark(1);
     // ---- pass 3: the camera lists and the point-major lists of every problem, built with PROBLEM-LOCAL offsets on the host threads; the
@@ -4234,6 +4261,11 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             cb[nb] = run;
         }
     });
+    if (worker_failed.load())
+    {
+        set_error("snk_ba_set_problems: a list-building thread failed (out of host memory?)");
+        return SNK_ERR_HIP;
+    }
     mark(3);
     for (int b = 0; b < count; ++b)
     {
@@ -4329,9 +4361,11 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                 for (int v : B.ccstart) ccstart.push_back(v + base_cc);
                 for (int v : B.ccitems) ccitems.push_back(v + n_cparts);
             }
-            if (B.ok)
+            // the batch's record / partial-sum counters are 32-bit on the device: a batch that would overflow them keeps the block-major pass
+            // (what the serial builder of round 3 did), it is not an error
+            const bool set_fits = n_setrec + B.recs < (1ll << 31) && (long long)n_partials + B.parts < (1ll << 31);
+            if (B.ok && set_fits)
             {
-                SNK_REQUIRE(n_setrec + B.recs < (1ll << 31) && (long long)n_partials + B.parts < (1ll << 31), "scene list too large (work-item records)");
                 const int base_pts = (int)setpts.size(), base_pairs = (int)setpairs.size();
                 for (SetItem si : B.items)
                 {
@@ -4355,7 +4389,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                 for (int v : B.cblkstart) cblkstart.push_back(v + base_cb);
                 for (int v : B.cblkitems) cblkitems.push_back(v + n_partials);
             }
-            if (B.ok)
+            if (B.ok && set_fits)
             {
                 n_partials += B.parts;
                 n_cparts += B.cparts;
