@@ -7,7 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_track_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-overlap --distinct 16 --ba-windows 0 --pose-frames 0 --frame-calls 0"
+CMD="python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-overlap --distinct 16 --ba-windows 0 --pose-frames 0 --frame-calls 0 --gba-keyframes 0 --kitti-steps 0"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
 if [ "${2:-}" = "pmc" ]; then
   timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq -o p -- $CMD > $OUT/pmc_sq.log 2>&1

@@ -10,11 +10,12 @@ if [ "${2:-}" != "notest" ]; then
   tail -3 gpurun_out/$TAG/pytest_gpu.log
 fi
 timeout 600 python bench.py 2>&1 | grep '"metric"' > gpurun_out/$TAG/bench_default.json
-timeout 600 python bench.py --workload kitti --ba-windows 0 --gba-keyframes 0 --pose-frames 0 --track-frames 0 2>&1 | grep '"metric"' > gpurun_out/$TAG/bench_kitti.json
+timeout 600 python bench.py --workload kitti --ba-windows 0 --gba-keyframes 0 --pose-frames 0 --track-frames 0 --kitti-steps 0 2>&1 | grep '"metric"' > gpurun_out/$TAG/bench_kitti.json
 bash tools/profile_gpu.sh $TAG > gpurun_out/$TAG/profile_gpu.log 2>&1
 python tools/collect_traffic.py gpurun_out/prof_$TAG 2048 > gpurun_out/$TAG/collect_traffic.log 2>&1 && cp profiles/fast_kernel_traffic.json gpurun_out/$TAG/fast_kernel_traffic.json
 bash tools/profile_track.sh $TAG pmc > gpurun_out/$TAG/profile_track.log 2>&1
 bash tools/profile_ba.sh $TAG pmc > gpurun_out/$TAG/profile_ba.log 2>&1
+bash tools/profile_gba.sh $TAG pmc > gpurun_out/$TAG/profile_gba.log 2>&1
 python tools/collect_pipeline_traffic.py gpurun_out/prof_$TAG gpurun_out/prof_ba_$TAG 1024 1024 > gpurun_out/$TAG/collect_pipeline_traffic.log 2>&1 && cp profiles/pipeline_traffic.json gpurun_out/$TAG/pipeline_traffic.json
 (python tools/latency_frontend.py; python tools/frontend_latency_cpp.py; python tools/latency.py; python tools/lba_call_latency_cpp.py) 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/latencies.log
 python -c "
