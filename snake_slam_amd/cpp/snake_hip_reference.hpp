@@ -35,7 +35,7 @@ struct Globals
     snk_grid_bounds featureGridBounds{};  // featureGridBounds
     std::vector<float> level_scale;       // scalePyramid.Scale(l), l = 0 .. levels - 1
     bool mono           = false;          // settings.inputType == InputType::Mono
-    bool rgbd           = false;          // settings.inputType == InputType::RGBD: Preprocess::Process calls ComputeStereoFromRGBD, not StereoMatching
+    bool rgbd           = false;          // settings.inputType == InputType::RGBD: Preprocess::Process calls ComputeStereoFromRGBD, not StereoMatching (FrontEnd then needs mono = true)
     bool relaxed_stereo = true;           // settings.fd_relaxed_stereo (Settings.h:123)
     snk_rectification rect_left{}, rect_right{};
 };
@@ -250,9 +250,10 @@ class FrontEnd
         // Preprocess::Process has three branches (Preprocess.cpp:43-49): RGBD -> ComputeStereoFromRGBD, Stereo -> StereoMatching, Mono -> neither.
         // snk_frontend_process serves the stereo and the mono branch.  An RGBD build would silently run as "stereo without a right image"
         // (an error) or as mono (depth / right_points left at -1000): refuse it here and name the call that serves it.
-        if (g.rgbd)
-            throw std::invalid_argument("snake_hip_reference::FrontEnd serves InputType::Stereo and InputType::Mono; for InputType::RGBD extract with "
-                                        "ORBExtractor::Detect and call Preprocess::ComputeStereoFromRGBD (snk_rgbd_stereo) -- Snake/Preprocess/Preprocess.cpp:43-46,79-120");
+        if (g.rgbd && !g.mono)
+            throw std::invalid_argument("snake_hip_reference::FrontEnd serves the stereo and the mono branch of Preprocess::Process; an InputType::RGBD build "
+                                        "constructs it with Globals::mono = true (left image: extraction, undistortion, grid) and then calls "
+                                        "Preprocess::ComputeStereoFromRGBD (snk_rgbd_stereo) -- Snake/Preprocess/Preprocess.cpp:43-46,79-120");
         snk_frontend_params p{};
         p.orb = orb, p.rect_left = g.rect_left, p.rect_right = g.rect_right, p.bounds = g.featureGridBounds;
         p.bf = g.rect_left.bf, p.relaxed_stereo = g.relaxed_stereo ? 1 : 0, p.stereo = g.mono ? 0 : 1;

@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "matcher_handle.hpp"
 
 using namespace snk;
 
@@ -76,7 +77,7 @@ struct snk_frontend
     int width = 0, height = 0, dpitch = 0, cap = 0, cols = 0, rows = 0, n_img = 2;
     float level_scale[8] = {};
     // layout of a slot's device block that goes back to the host (d_out / h_out) and of its scratch block (d_tmp)
-    size_t o_n = 0, o_kps = 0, o_desc_r = 0, o_kp64_g = 0, o_desc_g = 0, o_norm = 0, o_perm = 0, o_cs = 0, o_rp = 0, o_dp = 0, out_len = 0;
+    size_t o_n = 0, o_kps = 0, o_desc_x = 0, o_desc_r = 0, o_kp64_g = 0, o_desc_g = 0, o_norm = 0, o_perm = 0, o_cs = 0, o_rp = 0, o_dp = 0, out_len = 0;
     size_t t_desc = 0, t_kp64 = 0;  // d_tmp: descriptors in extractor order (2 images) | rectified keypoints (2 images)
     std::vector<Slot*> slots;       // slots[0] also serves snk_frontend_process
     // the ring of submitted frames: frame number q lives in slot q % depth
@@ -182,7 +183,8 @@ static int layout(snk_frontend* f, Slot* s, int w, int h)
     auto take = [&](size_t bytes) { const size_t o = at; at = up64(at + bytes); return o; };
     f->o_n      = take(16 * sizeof(int));                 // n[2], n_stereo
     f->o_kps    = take(ni * cap * sizeof(snk_keypoint));  // both images, extractor order
-    f->o_desc_r = take(cap * 32);                         // right descriptors, extractor order
+    f->o_desc_x = take(2 * cap * 32);                     // descriptors in extractor order, image-major as the extractor writes them: the left half is
+    f->o_desc_r = f->o_desc_x + cap * 32;                 // scratch that rides along in the download, the right half IS frame.descriptors_right
     f->o_kp64_g = take(cap * sizeof(snk_kp64));           // undistorted_keypoints, grid order
     f->o_desc_g = take(cap * 32);                         // left descriptors, grid order
     f->o_norm   = take(cap * 16);                         // normalized_points, extractor order (the host applies the permutation)
@@ -224,15 +226,19 @@ static int enqueue_chain(snk_frontend* f, Slot* s)
     char* t  = s->d_tmp.as<char>();
     int* d_n = reinterpret_cast<int*>(o + f->o_n);
     auto* d_kps  = reinterpret_cast<snk_keypoint*>(o + f->o_kps);
-    auto* d_desc = reinterpret_cast<uint64_t*>(t + f->t_desc);
+    // descriptors of both images in extractor order, image-major with stride cap * 4 words: a stereo handle keeps them inside the output
+    // block (o_desc_x, its second half = o_desc_r), so that no device-to-device copy stands between the extractor and the download
+    auto* d_desc = f->n_img == 2 ? reinterpret_cast<uint64_t*>(o + f->o_desc_x) : reinterpret_cast<uint64_t*>(t + f->t_desc);
     auto* d_kp64 = reinterpret_cast<snk_kp64*>(t + f->t_kp64);
     int rc;
     // FeatureDetector::Detect, left then right (FeatureDetector.cpp:116-156): one two-image launch chain
     if ((rc = snk_orb_detect_batch_dev(s->orb, s->d_img.as<uint8_t>(), f->dpitch, (size_t)f->dpitch * f->height, f->n_img, d_kps, d_desc, d_n,
                                        f->cap)) != SNK_OK)
         return rc;
-    // Frame::allocateTmp (Snake/Map/Frame.cpp:25-26): right_points and depth start at -1000
-    SNK_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(o + f->o_rp), 0xC47A0000u /* -1000.0f */, (f->o_dp - f->o_rp) / 4 + cap, s->stream));
+    // Frame::allocateTmp (Snake/Map/Frame.cpp:25-26): right_points and depth start at -1000 -- a stereo handle leaves that to its
+    // StereoMatching call below (whose first kernel does it: one launch less in a chain of short launches), a mono handle fills here
+    if (f->n_img != 2)
+        SNK_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(o + f->o_rp), 0xC47A0000u /* -1000.0f */, (f->o_dp - f->o_rp) / 4 + cap, s->stream));
     // undistortKeypoints (Preprocess.cpp:55-77) with rect_left; Rectification::Forward of the right keypoints (:140-150) with rect_right
     if ((rc = snk_rectify_batch_dev(s->mat, &f->par.rect_left, d_kps, d_n, f->cap, 1, d_kp64, reinterpret_cast<double*>(o + f->o_norm))) != SNK_OK) return rc;
     if (f->n_img == 2 &&
@@ -245,13 +251,13 @@ static int enqueue_chain(snk_frontend* f, Slot* s)
         return rc;
     if (f->n_img == 2)
     {
-        // the right descriptors go back in extractor order (frame.descriptors_right)
-        SNK_HIP_CHECK(hipMemcpyAsync(o + f->o_desc_r, d_desc + cap * 4, cap * 32, hipMemcpyDeviceToDevice, s->stream));
+        // the right descriptors go back in extractor order (frame.descriptors_right): the extractor wrote them where the download takes
+        // them from (d_desc's second half IS o_desc_r, see layout())
         // StereoMatching (Preprocess.cpp:122-242): left in grid order, right in extractor order (:41-49)
-        if ((rc = snk_stereo_match_batch_dev(s->mat, reinterpret_cast<const snk_kp64*>(o + f->o_kp64_g), reinterpret_cast<const uint64_t*>(o + f->o_desc_g),
+        if ((rc = stereo_match_batch_dev_impl(s->mat, reinterpret_cast<const snk_kp64*>(o + f->o_kp64_g), reinterpret_cast<const uint64_t*>(o + f->o_desc_g),
                                              d_n, f->cap, d_kp64 + cap, d_desc + cap * 4, d_n + 1, f->cap, 1, f->par.bf, f->level_scale,
                                              f->par.orb.n_levels, f->par.relaxed_stereo, reinterpret_cast<float*>(o + f->o_rp),
-                                             reinterpret_cast<float*>(o + f->o_dp), d_n + 2)) != SNK_OK)
+                                             reinterpret_cast<float*>(o + f->o_dp), d_n + 2, /*prefill=*/true)) != SNK_OK)
             return rc;
     }
     return SNK_OK;

@@ -372,10 +372,22 @@ __global__ __launch_bounds__(256) void stereo_sort_kernel(const snk_kp64* __rest
 // the one frame of a per-frame call).  Identical output: keys ascending = (row, then index).  A frame whose rows span more than
 // ST_COUNT_ROWS (rectification pushed keypoints far outside the image) runs the network inside the same launch.
 constexpr int ST_COUNT_ROWS = 4096;
+// n_matches / prefill_rp / prefill_dp (may be NULL): the frame's match counter is reset here and -- for the one-call front-end --
+// right_points / depth get Frame::allocateTmp's -1000 (Snake/Map/Frame.cpp:25-26) here, instead of one fill launch each in front of
+// a chain of a dozen short launches (a fill is a 4.5 us kernel of its own: profiles/r05/r05e_pipeline_trace_after.txt).
 __global__ __launch_bounds__(256) void stereo_count_kernel(const snk_kp64* __restrict__ right, const int* __restrict__ nr_dev, int nr_cap,
-                                                           int nr_host, int iround_mode, u32* __restrict__ row_sorted)
+                                                           int nr_host, int iround_mode, u32* __restrict__ row_sorted,
+                                                           int* __restrict__ n_matches, float* __restrict__ prefill_rp,
+                                                           float* __restrict__ prefill_dp, int prefill_n)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ssm[];
+    if (n_matches && threadIdx.x == 0) n_matches[blockIdx.x] = 0;
+    if (prefill_rp)
+        for (int i = threadIdx.x; i < prefill_n; i += 256)
+        {
+            prefill_rp[(size_t)blockIdx.x * prefill_n + i] = -1000.0f;
+            prefill_dp[(size_t)blockIdx.x * prefill_n + i] = -1000.0f;
+        }
     __shared__ int s_min, s_max, s_wsum[4];
     int* start   = reinterpret_cast<int*>(ssm);      // [ST_COUNT_ROWS + 1]
     int* fill    = start + ST_COUNT_ROWS + 1;        // [ST_COUNT_ROWS + 1]
@@ -1075,7 +1087,7 @@ int snk_stereo_match(snk_matcher* m, const snk_kp64* left, const uint64_t (*desc
             if ((rc = set_max_lds_once(reinterpret_cast<const void*>(stereo_count_kernel), (2 * (ST_COUNT_ROWS + 1) + 2 * ST_SORT_MAX) * 4)) != SNK_OK)
                 return rc;
             hipLaunchKernelGGL(stereo_count_kernel, dim3(1), dim3(256), lds, m->stream, (const snk_kp64*)(ab + o_kr), (const int*)nullptr, nrc, nr,
-                               ls.iround_mode, m->out.as<u32>());
+                               ls.iround_mode, m->out.as<u32>(), (int*)nullptr, (float*)nullptr, (float*)nullptr, 0);
         }
         else
             hipLaunchKernelGGL(stereo_sort_kernel, dim3(1), dim3(256), (size_t)np2 * 4, m->stream, (const snk_kp64*)(ab + o_kr),
@@ -1105,6 +1117,18 @@ int snk_stereo_match_batch_dev(snk_matcher* m, const snk_kp64* left_dev, const u
                                const float* level_scale_host, int n_levels, int relaxed, float* right_points_dev,
                                float* depth_dev, int32_t* n_matches_dev)
 {
+    return snk::stereo_match_batch_dev_impl(m, left_dev, desc_left_dev, nl_dev, nl_cap, right_dev, desc_right_dev, nr_dev, nr_cap, batch, bf, level_scale_host,
+                                            n_levels, relaxed, right_points_dev, depth_dev, n_matches_dev, false);
+}
+}  // extern "C"
+
+// prefill: right_points / depth (nl_cap entries per frame) are set to -1000 by the call itself (Frame::allocateTmp) -- the one-call
+// front-end's form; the public entry point leaves them to the caller (in / out arrays, include/snake_hip.h)
+int snk::stereo_match_batch_dev_impl(snk_matcher* m, const snk_kp64* left_dev, const uint64_t* desc_left_dev, const int32_t* nl_dev, int nl_cap,
+                                     const snk_kp64* right_dev, const uint64_t* desc_right_dev, const int32_t* nr_dev, int nr_cap, int batch, double bf,
+                                     const float* level_scale_host, int n_levels, int relaxed, float* right_points_dev, float* depth_dev,
+                                     int32_t* n_matches_dev, bool prefill)
+{
     SNK_REQUIRE(m != nullptr, "matcher is NULL");
     SNK_REQUIRE(batch >= 0 && nl_cap >= 0 && nr_cap >= 1 && nr_cap < (1 << 24), "bad sizes");
     SNK_REQUIRE(left_dev && desc_left_dev && nl_dev && right_dev && desc_right_dev && nr_dev && right_points_dev &&
@@ -1115,10 +1139,22 @@ int snk_stereo_match_batch_dev(snk_matcher* m, const snk_kp64* left_dev, const u
     if (rc != SNK_OK) return rc;
     if (batch == 0 || nl_cap == 0) return SNK_OK;
     SNK_HIP_CHECK(hipSetDevice(m->device));
-    SNK_HIP_CHECK(hipMemsetAsync(n_matches_dev, 0, (size_t)batch * sizeof(int), m->stream));
     const u32* srt = nullptr;
     static const bool no_frame_kernel = getenv("SNK_STEREO_NO_FRAME_KERNEL") != nullptr;  // A/B measurements
-    if (!no_frame_kernel && nr_cap <= ST_FRAME_MAX && batch >= 8)
+    static const bool sort_network    = getenv("SNK_STEREO_SORT_NETWORK") != nullptr;     // A/B, tests: the bitonic network
+    const bool frame_kernel = !no_frame_kernel && nr_cap <= ST_FRAME_MAX && batch >= 8;
+    // the counting kernel of the small-batch path resets the counter and does the prefill itself; every other path pays the fills
+    const bool count_path = !frame_kernel && nr_cap <= ST_SORT_MAX && !sort_network;
+    if (!count_path)
+    {
+        SNK_HIP_CHECK(hipMemsetAsync(n_matches_dev, 0, (size_t)batch * sizeof(int), m->stream));
+        if (prefill)
+        {
+            SNK_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(right_points_dev), 0xC47A0000u /* -1000.0f */, (size_t)batch * nl_cap, m->stream));
+            SNK_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(depth_dev), 0xC47A0000u, (size_t)batch * nl_cap, m->stream));
+        }
+    }
+    if (frame_kernel)
     {
         // enough frames to give every CU its own: one workgroup per frame, the right side resident in LDS
         if ((rc = set_max_lds_once(reinterpret_cast<const void*>(stereo_frame_kernel), (int)stereo_frame_lds(ST_FRAME_MAX))) != SNK_OK) return rc;
@@ -1135,14 +1171,13 @@ int snk_stereo_match_batch_dev(snk_matcher* m, const snk_kp64* left_dev, const u
         while (np2 < nr_cap) np2 <<= 1;
         if ((rc = set_max_lds_once(reinterpret_cast<const void*>(stereo_sort_kernel), ST_SORT_MAX * 4)) != SNK_OK) return rc;
         if ((rc = set_max_lds_once(reinterpret_cast<const void*>(stereo_kernel16), ST_SORT_MAX * 4)) != SNK_OK) return rc;
-        static const bool sort_network = getenv("SNK_STEREO_SORT_NETWORK") != nullptr;  // A/B, tests: the bitonic network
         if (!sort_network)
         {
             const size_t lds = std::max(((size_t)2 * (ST_COUNT_ROWS + 1) + (size_t)2 * nr_cap) * 4, (size_t)np2 * 4);
             if ((rc = set_max_lds_once(reinterpret_cast<const void*>(stereo_count_kernel), (2 * (ST_COUNT_ROWS + 1) + 2 * ST_SORT_MAX) * 4)) != SNK_OK)
                 return rc;
             hipLaunchKernelGGL(stereo_count_kernel, dim3(batch), dim3(256), lds, m->stream, right_dev, nr_dev, nr_cap, 0, ls.iround_mode,
-                               m->out.as<u32>());
+                               m->out.as<u32>(), n_matches_dev, prefill ? right_points_dev : (float*)nullptr, prefill ? depth_dev : (float*)nullptr, nl_cap);
         }
         else
             hipLaunchKernelGGL(stereo_sort_kernel, dim3(batch), dim3(256), (size_t)np2 * 4, m->stream, right_dev, nr_dev, nr_cap, 0,
@@ -1159,5 +1194,4 @@ int snk_stereo_match_batch_dev(snk_matcher* m, const snk_kp64* left_dev, const u
                            nr_cap, 0, bf, ls, relaxed, right_points_dev, depth_dev, n_matches_dev, srt);
     SNK_LAUNCH_CHECK();
     return SNK_OK;
-}
 }

@@ -16,3 +16,12 @@ struct snk_matcher : snk::HandleBase
     int view_n = 0, view_cols = 0, view_rows = 0;
     double view_bounds[4] = {0, 0, 0, 0};
 };
+
+namespace snk
+{
+// snk_stereo_match_batch_dev with the option of doing Frame::allocateTmp's -1000 prefill of right_points / depth itself (the one-call front-end)
+int stereo_match_batch_dev_impl(snk_matcher* m, const snk_kp64* left_dev, const uint64_t* desc_left_dev, const int32_t* nl_dev, int nl_cap,
+                                const snk_kp64* right_dev, const uint64_t* desc_right_dev, const int32_t* nr_dev, int nr_cap, int batch, double bf,
+                                const float* level_scale_host, int n_levels, int relaxed, float* right_points_dev, float* depth_dev,
+                                int32_t* n_matches_dev, bool prefill);
+}  // namespace snk

@@ -428,10 +428,12 @@ static inline dim3 xcd_grid(int gx, int batch) { return batch >= 16 ? dim3(8 * g
 template <int NQ, bool LOOP>
 __global__ __launch_bounds__(256, SNK_FAST_MIN_WAVES) void fast_kernel(Layout L, const u8* __restrict__ img0, int pitch0, long long stride0,
                                                    int aligned0, int ini_th, int min_th, u32* __restrict__ cand,
-                                                   u16* __restrict__ cell_cnt, int gx, int batch, int dbg_stop, int cpw)
+                                                   u16* __restrict__ cell_cnt, int gx, int batch, int dbg_stop, int cpw,
+                                                   int* __restrict__ queue_reset /* NULL or the distribute queue's counter: zeroed here instead of by a fill launch */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (queue_reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *queue_reset = 0;
     int b, bxi;
     if (!xcd_image_map(gx, batch, b, bxi)) return;
     // cpw cells per wavefront, one after the other (cells bxi * 4 * cpw + wave + 4 k): a cell is ~7 us of work, and with one cell per
@@ -2617,7 +2619,7 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
         const size_t fast_lds = std::max((size_t)4 * L.f_lds_wave, std::min(lds_wg_env, (size_t)LDS_MAX_BYTES));
         hipLaunchKernelGGL(fk, xcd_grid(gx, batch), dim3(256), fast_lds, st, L, images_dev, pitch,
                            image_stride, aligned0, o->params.ini_th_fast, o->params.min_th_fast, d_cand, d_cellcnt, gx, batch, fast_stop,
-                           cpw);
+                           cpw, stages == 3 ? d_queue : (int*)nullptr);
         SNK_LAUNCH_CHECK();
     }
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[3], st));
@@ -2626,7 +2628,9 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[6], st));
     {
     const int aligned0 = (reinterpret_cast<uintptr_t>(images_dev) % 4 == 0 && pitch % 4 == 0 && image_stride % 4 == 0) ? 1 : 0;
-    SNK_HIP_CHECK(hipMemsetAsync(d_queue, 0, sizeof(int), st));
+    // the queue's counter: reset by fast_kernel when this call enqueues the whole chain on one stream (the usual case: one launch less
+    // per frame); the split schedules (front and back halves on different streams, chain slots shared by parts) keep the fill
+    if (stages != 3 || L.total_cells <= 0) SNK_HIP_CHECK(hipMemsetAsync(d_queue, 0, sizeof(int), st));
     // SNK_ORB_DIST_TIMING=1 (diagnostic): cycle sums per phase and level, printed after a synchronisation
     static const bool dist_timing = getenv("SNK_ORB_DIST_TIMING") != nullptr;
     unsigned long long* d_dbg = nullptr;
