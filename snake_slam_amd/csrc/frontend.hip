@@ -240,9 +240,12 @@ static int enqueue_chain(snk_frontend* f, Slot* s)
     if (f->n_img != 2)
         SNK_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(o + f->o_rp), 0xC47A0000u /* -1000.0f */, (f->o_dp - f->o_rp) / 4 + cap, s->stream));
     // undistortKeypoints (Preprocess.cpp:55-77) with rect_left; Rectification::Forward of the right keypoints (:140-150) with rect_right
-    if ((rc = snk_rectify_batch_dev(s->mat, &f->par.rect_left, d_kps, d_n, f->cap, 1, d_kp64, reinterpret_cast<double*>(o + f->o_norm))) != SNK_OK) return rc;
-    if (f->n_img == 2 &&
-        (rc = snk_rectify_batch_dev(s->mat, &f->par.rect_right, d_kps + cap, d_n + 1, f->cap, 1, d_kp64 + cap, nullptr)) != SNK_OK)
+    if (f->n_img == 2)
+    {
+        if ((rc = rectify_pair_dev(s->mat, &f->par.rect_left, &f->par.rect_right, d_kps, d_n, f->cap, d_kp64, reinterpret_cast<double*>(o + f->o_norm))) != SNK_OK)
+            return rc;
+    }
+    else if ((rc = snk_rectify_batch_dev(s->mat, &f->par.rect_left, d_kps, d_n, f->cap, 1, d_kp64, reinterpret_cast<double*>(o + f->o_norm))) != SNK_OK)
         return rc;
     // computeFeatureGrid (Preprocess.cpp:244-266): permutation, cell starts, undistorted keypoints and descriptors in grid order
     if ((rc = snk_feature_grid_batch_dev(s->mat, &f->par.bounds, d_kp64, d_desc, d_n, f->cap, 1, reinterpret_cast<snk_kp64*>(o + f->o_kp64_g),

@@ -24,4 +24,8 @@ int stereo_match_batch_dev_impl(snk_matcher* m, const snk_kp64* left_dev, const 
                                 const snk_kp64* right_dev, const uint64_t* desc_right_dev, const int32_t* nr_dev, int nr_cap, int batch, double bf,
                                 const float* level_scale_host, int n_levels, int relaxed, float* right_points_dev, float* depth_dev,
                                 int32_t* n_matches_dev, bool prefill);
+// both rectifications of a stereo frame in one launch: image 0 of the pair (kps_dev[0 .. cap)) with rect_left (+ normalized points), image 1
+// (kps_dev[cap .. 2 cap)) with rect_right; n_dev[2], out_dev[2][cap]
+int rectify_pair_dev(snk_matcher* m, const snk_rectification* rect_left, const snk_rectification* rect_right, const snk_keypoint* kps_dev,
+                     const int32_t* n_dev, int cap, snk_kp64* out_dev, double* normalized_left_dev);
 }  // namespace snk

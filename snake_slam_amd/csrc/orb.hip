@@ -2466,7 +2466,8 @@ int snk_orb_configure(snk_orb* o, int width, int height, int max_batch)
     // process-wide, once per kernel, to the largest carve any handle can ask for (never per-handle sizes: two extractors
     // with different image sizes / level_cap would overwrite each other's limit)
     SNK_REQUIRE(4 * L.f_lds_wave <= LDS_MAX_BYTES, "FAST cells too large for the LDS (image too small for its cell grid?)");
-    if ((rc = set_max_lds_once(reinterpret_cast<const void*>(distribute_kernel), (int)dist_lds_bytes(2048) + 4 * 2048 + 16)) != SNK_OK) return rc;  // + the Harris ranks ("orb.response" = 1)
+    // the largest of: the 2048-candidate carve + the Harris ranks ("orb.response" = 1), the full-budget carve (small launches take it directly)
+    if ((rc = set_max_lds_once(reinterpret_cast<const void*>(distribute_kernel), (int)std::max(dist_lds_bytes(2048) + 4 * 2048 + 16, dist_lds_bytes(8192)))) != SNK_OK) return rc;
     if ((rc = set_max_lds_once(reinterpret_cast<const void*>(distribute_large_kernel), (int)dist_lds_bytes(8192))) != SNK_OK) return rc;
     if ((rc = set_max_lds_once(fast_kernel_for(L, false), LDS_MAX_BYTES)) != SNK_OK) return rc;
     if ((rc = set_max_lds_once(fast_kernel_for(L, true), LDS_MAX_BYTES)) != SNK_OK) return rc;
@@ -2646,9 +2647,13 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
                            d_candh, gxh, batch);
         SNK_LAUNCH_CHECK();
     }
+    // A launch of a few (image, level) workgroups (the per-frame calls) gives every workgroup the full-budget carve at once: nothing can
+    // be queued, the drain launch is skipped (one launch less in the per-frame chain; the carve only limits workgroups per CU, and these
+    // launches do not fill the chip).  Not under "orb.response" = 1: the Harris ranks do not fit beside the full carve.
+    const bool one_dist_launch = !harris && o->dist_small_cap < L.level_cap && (long long)L.n_levels * batch <= 128;
     hipLaunchKernelGGL(distribute_kernel, dim3(L.n_levels, batch), dim3(DIST_THREADS),
-                       o->dist_lds_small + (harris ? 4 * (size_t)o->dist_small_cap + 16 : 0), st, L,
-                       o->dist_small_cap, d_cand, d_cellcnt, d_sel, d_selscore,
+                       one_dist_launch ? o->dist_lds : o->dist_lds_small + (harris ? 4 * (size_t)o->dist_small_cap + 16 : 0), st, L,
+                       one_dist_launch ? L.level_cap : o->dist_small_cap, d_cand, d_cellcnt, d_sel, d_selscore,
                        d_selcnt, d_candtot, d_queue, d_dbg, d_candh, d_selresp);
     SNK_LAUNCH_CHECK();
     if (dist_timing)
@@ -2665,7 +2670,7 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
             fprintf(stderr, "\n");
         }
     }
-    if (o->dist_small_cap < L.level_cap)
+    if (o->dist_small_cap < L.level_cap && !one_dist_launch)
     {
         hipLaunchKernelGGL(distribute_large_kernel, dim3(large_workers), dim3(DIST_THREADS), o->dist_lds, st, L,
                            d_cand, d_cellcnt, d_sel, d_selscore,

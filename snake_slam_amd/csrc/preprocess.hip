@@ -33,11 +33,9 @@ __device__ __forceinline__ void distort(const double* D, double x, double y, dou
     J[3] = rad + y * drad * 2.0 * y + p1 * (2.0 * y + 4.0 * y) + 2.0 * p2 * x;
 }
 
-__global__ __launch_bounds__(256) void rectify_kernel(RectDev rc, const snk_keypoint* __restrict__ kps,
-                                                      const int* __restrict__ n_dev, int cap, int n_host,
-                                                      snk_kp64* __restrict__ out, double2* __restrict__ normalized)
+__device__ __forceinline__ void rectify_body(const RectDev& rc, const snk_keypoint* __restrict__ kps, const int* __restrict__ n_dev, int cap, int n_host,
+                                             snk_kp64* __restrict__ out, double2* __restrict__ normalized, int b)
 {
-    const int b = blockIdx.y;
     int n       = n_dev ? n_dev[b] : n_host;
     n           = n < cap ? n : cap;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -69,6 +67,26 @@ __global__ __launch_bounds__(256) void rectify_kernel(RectDev rc, const snk_keyp
     o.angle  = kp.angle;
     o.octave = kp.octave;
     out[(size_t)b * cap + i] = o;
+}
+
+__global__ __launch_bounds__(256) void rectify_kernel(RectDev rc, const snk_keypoint* __restrict__ kps,
+                                                      const int* __restrict__ n_dev, int cap, int n_host,
+                                                      snk_kp64* __restrict__ out, double2* __restrict__ normalized)
+{
+    rectify_body(rc, kps, n_dev, cap, n_host, out, normalized, blockIdx.y);
+}
+
+// The two rectifications of a stereo frame in ONE launch (the one-call front-end): image blockIdx.y of the pair with its own
+// rectification -- undistortKeypoints with rect_left (normalized points kept), Rectification::Forward of the right keypoints with
+// rect_right (Preprocess.cpp:55-77,140-150).  Same arithmetic per keypoint as two rectify_kernel launches.
+__global__ __launch_bounds__(256) void rectify_pair_kernel(RectDev rc_left, RectDev rc_right, const snk_keypoint* __restrict__ kps,
+                                                           const int* __restrict__ n_dev, int cap, snk_kp64* __restrict__ out,
+                                                           double2* __restrict__ normalized_left)
+{
+    if (blockIdx.y == 0)
+        rectify_body(rc_left, kps, n_dev, cap, 0, out, normalized_left, 0);
+    else
+        rectify_body(rc_right, kps, n_dev, cap, 0, out, nullptr, 1);
 }
 
 // Snake::Preprocess::ComputeStereoFromRGBD (Preprocess.cpp:79-120): one thread per undistorted keypoint; the same fp64 operation
@@ -159,6 +177,26 @@ int snk_rectify_batch_dev(snk_matcher* m, const snk_rectification* rect, const s
     SNK_LAUNCH_CHECK();
     return SNK_OK;
 }
+
+}  // extern "C"
+
+int snk::rectify_pair_dev(snk_matcher* m, const snk_rectification* rect_left, const snk_rectification* rect_right, const snk_keypoint* kps_dev,
+                          const int32_t* n_dev, int cap, snk_kp64* out_dev, double* normalized_left_dev)
+{
+    SNK_REQUIRE(m != nullptr && kps_dev && n_dev && out_dev, "NULL argument");
+    RectDev rl, rr;
+    int st = to_dev(rect_left, &rl);
+    if (st == SNK_OK) st = to_dev(rect_right, &rr);
+    if (st != SNK_OK) return st;
+    if (cap == 0) return SNK_OK;
+    SNK_HIP_CHECK(hipSetDevice(m->device));
+    hipLaunchKernelGGL(rectify_pair_kernel, dim3(ceil_div(cap, 256), 2), dim3(256), 0, m->stream, rl, rr, kps_dev, n_dev, cap, out_dev,
+                       (double2*)normalized_left_dev);
+    SNK_LAUNCH_CHECK();
+    return SNK_OK;
+}
+
+extern "C" {
 
 int snk_rectify(snk_matcher* m, const snk_rectification* rect, const snk_keypoint* kps, int n, snk_kp64* out,
                 double (*normalized)[2])
