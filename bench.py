@@ -442,8 +442,9 @@ def main():
     ap.add_argument("--workload", choices=["euroc", "kitti"], default="euroc",
                     help="euroc = BASELINE.json's metric config (752x480, 1000 features, 4 levels); kitti = configs[2] "
                          "(1241x376, 2000 features, 7 levels), an extra measured case")
-    ap.add_argument("--orb-chains", type=int, default=1, help="launch chains per ORB batch (2 = two half batches on two streams, +3 %%; "
-                    "per-kernel timings then overlap)")
+    ap.add_argument("--orb-chains", type=int, default=1, help="launch chains per ORB batch (1 = the library's default: the stages of a step do not overlap, "
+                    "their HIP-event times add up to the step; 2 = two half batches on two streams, +1 to +3 %% from overlapped launch tails, per-kernel "
+                    "timings then overlap)")
     ap.add_argument("--orb-stagger", type=int, default=0, help="staggered schedule of the extractor: the batch in this many parts, front "
                     "halves (level passes, FAST) back to back, the back half (distribution, descriptors) of part p on a second stream "
                     "beside the front half of part p + 1 (0 = off)")
@@ -1081,8 +1082,10 @@ def main():
                                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(fast_ms, 4),
                                "images_per_launch": images_per_launch, "launches_per_step": n_calls // args.steps,
                                "limited_by": "valu" if valu else None, "valu": valu}
-            # summed over the launch chains of a step (with --orb-chains 2 the chains overlap and the sum exceeds the step time)
+            # summed over the launch chains of a step (with --orb-chains 2 the chains overlap on the device and the sum exceeds the step time)
             out["stage_ms_per_step"] = {k: round(v / args.steps, 4) for k, v in zip(["pyramid", "blur", "fast", "distribute", "describe"], stage_ms)}
+            out["stage_ms_per_step"]["launch_chains"] = n_calls // args.steps
+            out["stage_ms_per_step"]["chains_overlap"] = bool(n_calls // args.steps > 1)
         # whole front-end against the HBM roofline: A_orb = 3 P + 56 N bytes per mono image,
         # BF / stereo matching (N1 + N2) * 32 + N1 * 16 bytes each
         n_kp = float(blocks[0][1].item()) / (2 * B)

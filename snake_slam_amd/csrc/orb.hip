@@ -2700,7 +2700,14 @@ static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long i
                         snk_keypoint* kps_dev, uint64_t* desc_dev, int32_t* n_dev, int out_cap)
 {
     static const bool one_stream = getenv("SNK_ORB_ONE_STREAM") != nullptr;
-    if (one_stream || o->stream2 == nullptr || batch < o->split_min_batch)
+    // Launch chains: one by default.  Two half-batch chains on two streams (snk_orb_set_chains) overlap the tails of one chain's launches
+    // with the other's kernels: 186.0 / 192.1 / 192.9 / 188.4 k frames/s with 1 / 2 / 3 / 4 chains in one run, 187.6 k with 2 in the next
+    // (profiles/r05/r05o_chains.txt, r05p_bench_two_chains_by_default.txt) -- the chains start together and mostly run the same stage at
+    // the same time, so the gain is the tails only and a kernel's duration is then measured under a concurrent copy of itself.  Tried as
+    // the default for big batches in round 5 and taken back.  Per-frame launches never split (and never create the extra streams).
+    const int want_parts = o->parts;
+    const bool want_split = !one_stream && batch >= o->split_min_batch && (want_parts > 1 || (o->stagger >= 2 && batch >= 2 * o->stagger));
+    if (!want_split || !ensure_extra_streams(o))
         return run_part(o, o->stream, 0, 0, images_dev, pitch, image_stride, batch, kps_dev, desc_dev, n_dev, out_cap);
     if (o->stagger >= 2 && batch >= 2 * o->stagger)
     {
@@ -2732,7 +2739,7 @@ static int run_pipeline(snk_orb* o, const u8* images_dev, int pitch, long long i
         SNK_HIP_CHECK(hipStreamWaitEvent(o->stream, o->ev_join_n[0], 0));
         return SNK_OK;
     }
-    const int parts = o->parts < batch ? o->parts : batch;
+    const int parts = want_parts < batch ? want_parts : batch;
     if (parts <= 1) return run_part(o, o->stream, 0, 0, images_dev, pitch, image_stride, batch, kps_dev, desc_dev, n_dev, out_cap);
     SNK_HIP_CHECK(hipEventRecord(o->ev_fork, o->stream));
     int b0 = 0;

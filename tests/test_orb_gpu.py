@@ -547,3 +547,4 @@ def test_harris_batch_dev_and_frontend(orc, harris):
             assert np.array_equal(fr["keypoints_right"], wr.astype(KEYPOINT_DTYPE)) and np.array_equal(fr["descriptors_right"], wdr), mode
     finally:
         fe.close()
+
