@@ -77,13 +77,35 @@ def test_seams_run_concurrently_on_their_own_handles(orc):
         return b"".join(np.ascontiguousarray(f[key]).tobytes() for key in ("keypoints", "descriptors", "undistorted_keypoints", "permutation",
                                                                            "right_points", "depth", "descriptors_right")) + bytes([f["n_stereo"] & 255])
 
+    def run_frontend_pipelined(fe2, k):
+        # snk_frontend_submit / collect on a handle of its own: two frames in flight, the older one collected (round 5) -- the slots'
+        # stream captures and cooperative scheduling beside every other seam's thread
+        key = ("keypoints", "descriptors", "undistorted_keypoints", "permutation", "right_points", "depth", "descriptors_right")
+        fe2.Submit(*fe_pairs[0])
+        fe2.Submit(*fe_pairs[2])
+        a, b = fe2.Collect(), fe2.Collect()
+        return b"".join(np.ascontiguousarray(f[x]).tobytes() for f in (a, b) for x in key) + bytes([a["n_stereo"] & 255, b["n_stereo"] & 255])
+
+    def run_gba(gba, k):
+        # a global scene: the PCG of every LM iteration is ONE cooperative launch (pcgl_persist, grid barriers inside) while the other
+        # seams' kernels come and go on the same device
+        gba.reset()
+        ci, cf = gba.initAndSolve()
+        pose, pt, it = gba.state(0)
+        return ci.tobytes() + cf.tobytes() + pose.tobytes() + pt.tobytes() + bytes([it & 255])
+
     from snake_slam_amd.frontend import Frontend
 
     fe_pairs = [synth.stereo_frame(50, 320, 240, n_rects=90), synth.stereo_frame(51, 352, 256, n_rects=90), synth.stereo_frame(52, 320, 240, n_rects=90)]
     fe = Frontend((300, 1.2, 3, 20, 7), bounds=(0.0, 0.0, 352.0, 256.0))
+    fe2 = Frontend((300, 1.2, 3, 20, 7), bounds=(0.0, 0.0, 352.0, 256.0))
+    gba = BARec(lba_options(max_iterations=2, max_pcg_iterations=25))
+    gba.create(synth.ba_scene(n_kf=60, n_pt=900, obs_per_pt=6, seed=77, n_fixed=1)[0])  # 354 x 354 reduced system: beyond one workgroup's LDS
+    gba.initAndSolve()
     ext = ORBExtractor(300, 1.2, 3, 20, 7)
     pre, bfm, trk, ba, ba2 = Preprocess(), BruteForceMatcher(), SnakeORBMatcher(), BARec(lba_options()), BARec(lba_options())
-    seams = [(run_orb, ext), (run_pre, (pre, bfm)), (run_track, trk), (run_ba, ba), (run_ba_one_call, ba2), (run_frontend, fe)]
+    seams = [(run_orb, ext), (run_pre, (pre, bfm)), (run_track, trk), (run_ba, ba), (run_ba_one_call, ba2), (run_frontend, fe),
+             (run_frontend_pipelined, fe2), (run_gba, gba)]
     try:
         want = [[fn(h, k) for k in range(3)] for fn, h in seams]  # each call alone
         errors, got = [], [[None] * ROUNDS for _ in seams]
@@ -109,4 +131,4 @@ def test_seams_run_concurrently_on_their_own_handles(orc):
             for k in range(ROUNDS):
                 assert got[si][k] == want[si][k % 3], (si, k)
     finally:
-        ext.close(), pre.close(), bfm.close(), trk.close(), ba.close(), ba2.close(), fe.close()
+        ext.close(), pre.close(), bfm.close(), trk.close(), ba.close(), ba2.close(), fe.close(), fe2.close(), gba.close()
