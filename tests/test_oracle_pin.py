@@ -140,3 +140,34 @@ def test_harris_response_against_skimage_derivatives(orc):
     ranks = np.array([orc.harris_rank(r) for r in resp], np.uint64)
     assert np.all(np.diff(ranks[order].astype(np.int64)) >= 0), "harris_rank must preserve the order of the float response"
     assert float(P["spearman"]) > 0.8
+
+
+def test_blur_and_pyramid_against_scipy_ndimage(orc):
+    """Two more [DEFINED] steps of "snk-orb v1" against library code that shares nothing with the oracle (scipy.ndimage, installed
+    here -- no fixture needed):
+    * the 7 x 7 blur = the separable integer kernel {18, 33, 49, 56, 49, 33, 18} applied to rows then columns in exact integers, ONE
+      rounding (acc + 2^15) >> 16, reflect-101 borders = scipy.ndimage.correlate1d(mode='mirror') on int64 -- every pixel equal;
+    * the pyramid down-scale = bilinear at source coordinate (d + 0.5) * (src / dst) - 0.5: scipy.ndimage.map_coordinates(order=1,
+      mode='nearest') evaluates the same interpolant in double; the oracle rounds the weights to 11 bits and the result once, so it
+      must lie within 0.5 (the rounding) + 0.25 (the weights) of the double value everywhere."""
+    import scipy.ndimage as ndi
+
+    rng = np.random.default_rng(77)
+    w = np.array([18, 33, 49, 56, 49, 33, 18], np.int64)
+    for img in (PIN["img"], rng.integers(0, 256, (61, 83), dtype=np.uint8), rng.integers(0, 256, (9, 12), dtype=np.uint8)):
+        img = np.ascontiguousarray(img)
+        h1 = ndi.correlate1d(img.astype(np.int64), w, axis=1, mode="mirror")
+        v1 = ndi.correlate1d(h1, w, axis=0, mode="mirror")
+        want = ((v1 + (1 << 15)) >> 16).astype(np.uint8)
+        assert np.array_equal(orc.blur_image(img), want)
+    src = np.ascontiguousarray(PIN["img"])
+    sh, sw = src.shape
+    for dw, dh in ((int(round(sw / 1.2)), int(round(sh / 1.2))), (sw // 2, sh // 2), (sw - 1, sh - 3)):
+        got = orc.resize(src, dw, dh).astype(np.int32)
+        ys = np.clip((np.arange(dh) + 0.5) * (sh / dh) - 0.5, 0, sh - 1)
+        xs = np.clip((np.arange(dw) + 0.5) * (sw / dw) - 0.5, 0, sw - 1)
+        yy, xx = np.meshgrid(ys, xs, indexing="ij")
+        ref = ndi.map_coordinates(src.astype(np.float64), [yy, xx], order=1, mode="nearest")
+        # one rounding of the result (<= 0.5) + the 11-bit weights (two taps x two axes: <= 255 * 4 * 2^-12 = 0.25)
+        err = np.abs(got - ref)
+        assert err.max() <= 0.5 + 0.25 and (err <= 0.5 + 1e-9).mean() > 0.9, (dw, dh, float(err.max()))
