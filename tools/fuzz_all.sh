@@ -4,7 +4,7 @@ S=${1:-90}
 SEED=${2:-7}
 cd "$(dirname "$0")/.."
 rc=0
-for f in fuzz_orb fuzz_orb_batch fuzz_match fuzz_match_batch fuzz_track_batch fuzz_ba_pose; do
+for f in fuzz_orb fuzz_orb_batch fuzz_match fuzz_match_batch fuzz_track_batch fuzz_ba_pose fuzz_frontend; do
   timeout $((S * 4 + 200)) python tools/$f.py --seconds "$S" --seed "$SEED" 2>&1 | grep -v amdgpu.ids | tail -2 || rc=1
 done
 SNK_ORB_LEVEL_BH=22 timeout $((S * 4 + 200)) python tools/fuzz_orb.py --seconds $((S / 2)) --seed $((SEED + 1)) 2>&1 | grep -v amdgpu.ids | tail -1
