@@ -124,6 +124,15 @@ static int create_slot(snk_frontend* f, Slot** out)
     }
     if (rc == SNK_OK) rc = snk_orb_create(&f->par.orb, f->device, s->stream, &s->orb);
     if (rc == SNK_OK) rc = snk_matcher_create(f->device, s->stream, &s->mat);
+    // HIP binds a stream to one of its few hardware queues when the stream is first USED, taking the least loaded one: slots that are
+    // created and touched back to back get different queues.  Left to their first frame, the slots were bound after every other handle of
+    // the process had taken a queue, and two slots could share one -- their frames then run one behind the other (9.8 k instead of 14.4 k
+    // frames/s on the same code, profiles/r05/r05s_latencies.log).  One recorded event is enough to bind the queue.
+    if (rc == SNK_OK && (hipEventRecord(s->done, s->stream) != hipSuccess || hipEventSynchronize(s->done) != hipSuccess))
+    {
+        set_error("front-end slot: the stream could not be started");
+        rc = SNK_ERR_HIP;
+    }
     if (rc != SNK_OK)
     {
         destroy_slot(s);
@@ -144,14 +153,20 @@ extern "C" int snk_frontend_create(const snk_frontend_params* params, int device
     f->device       = device;
     f->par          = *params;
     f->n_img        = params->stereo ? 2 : 1;
-    Slot* s0        = nullptr;
-    const int rc    = create_slot(f, &s0);
-    if (rc != SNK_OK)
+    // every slot of the default depth now (see create_slot: consecutive creation = different hardware queues); a larger depth set later
+    // adds its slots then
+    for (int i = 0; i < f->depth; ++i)
     {
-        delete f;
-        return rc;
+        Slot* s      = nullptr;
+        const int rc = create_slot(f, &s);
+        if (rc != SNK_OK)
+        {
+            for (Slot* q : f->slots) destroy_slot(q);
+            delete f;
+            return rc;
+        }
+        f->slots.push_back(s);
     }
-    f->slots.push_back(s0);
     // ScalePyramid::Scale(l) as the extractor defines it: scale[l] = scale[l - 1] * factor in float
     f->level_scale[0] = 1.0f;
     for (int l = 1; l < 8; ++l) f->level_scale[l] = f->level_scale[l - 1] * params->orb.scale_factor;
@@ -434,6 +449,14 @@ extern "C" int snk_frontend_set_depth(snk_frontend* f, int depth)
     SNK_REQUIRE(depth >= 1 && depth <= MAX_DEPTH, "depth must be 1..8");
     std::lock_guard<std::mutex> lock(f->mu);
     SNK_REQUIRE(f->submitted == f->collected, "frames are in flight");
+    SNK_HIP_CHECK(hipSetDevice(f->device));
+    while ((int)f->slots.size() < depth)
+    {
+        Slot* s      = nullptr;
+        const int rc = create_slot(f, &s);
+        if (rc != SNK_OK) return rc;
+        f->slots.push_back(s);
+    }
     f->depth     = depth;
     f->submitted = f->collected = 0;  // frame q lives in slot q % depth: restart the numbering with the new modulus
     return SNK_OK;
