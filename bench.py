@@ -1066,7 +1066,7 @@ def main():
                         if t.get("valu_insts_per_launch"):
                             # The kernel is instruction-bound, not HBM-bound (traffic ~ algorithmic bytes, nothing re-read): its
                             # vector-instruction roofline.  Peak: 256 CUs x 4 SIMDs, one wave64 integer / packed-16 VALU instruction per
-                            # 4 cycles (SIMD16 issue; measured on level_kernel) at the 2.4 GHz maximum clock.
+                            # 4 cycles (SIMD16 issue; measured on level_kernel, profiles/NOTES.md) at the 2.4 GHz maximum clock.
                             n_valu = t["valu_insts_per_launch"] * scale
                             peak = 1024 * VALU_CLOCK_HZ / 4.0
                             valu = {"instr_per_launch": int(n_valu), "issue_peak": peak, "unit": "wave64 VALU instructions/s",

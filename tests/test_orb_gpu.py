@@ -414,7 +414,7 @@ def test_fast_survivor_list_spill_path_on_ordinary_images():
 
 @pytest.mark.skipif(__import__("os").environ.get("SNK_ORB_NO_RECURSE") == "1", reason="child run")
 def test_fast_kernel_loop_form_on_ordinary_images():
-    """Big launches run fast_kernel with several cells per wavefront (the loop form); the parity file runs again
+    """Big launches run fast_kernel with several cells per wavefront (the loop form; measurements in profiles/NOTES.md); the parity file runs again
     in a child process with THREE cells per wavefront forced for every launch size (SNK_ORB_FAST_CPW; 3 does not divide the cell
     counts, so the last wavefronts of an image run out of cells mid-loop)."""
     import os
