@@ -103,3 +103,18 @@ def test_dist_entry_points_fail_loudly_without_a_device():
     if not torch.cuda.is_available():
         assert lib.snk_dist_get_unique_id(ident) != 0 or lib.snk_dist_init(ident, 0, 1, 0, C.byref(h)) != 0
         assert len(lib.snk_last_error()) > 0
+
+
+def test_header_is_plain_c99(tmp_path):
+    """The drop-in boundary is a C ABI: include/snake_hip.h must compile as C99 with no extensions (a cgo / JNI / Rust-bindgen binding
+    reads it as C), and its constants must be usable in constant expressions."""
+    import subprocess
+
+    src = tmp_path / "abi.c"
+    src.write_text('#include "snake_hip.h"\n'
+                   "typedef char id_is_128[SNK_DIST_ID_BYTES == 128 ? 1 : -1];\n"
+                   "int main(void) { snk_frontend_frame f; f.capacity = 0; return (int)sizeof(snk_keypoint) == 24 && SNK_ERR_TIMEOUT == 6 && f.capacity == 0 ? 0 : 1; }\n")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{ROOT / 'include'}", str(src), "-o", str(tmp_path / "abi")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert subprocess.run([str(tmp_path / "abi")]).returncode == 0
