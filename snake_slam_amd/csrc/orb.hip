@@ -874,7 +874,8 @@ __device__ __forceinline__ u32 dot2(u32 pair, u32 w, u32 acc)
 #endif
 template <bool ALIGNED, int BH>
 __global__ __launch_bounds__(256, SNK_LEVEL_MIN_WAVES) void level_kernel(Layout L, int l, const u8* __restrict__ img0, int pitch0, long long stride0,
-                                                    int make_next, int gx, int batch, int n_bands)
+                                                    int make_next, int gx, int batch, int n_bands,
+                                                    int no_blur_store /* SNK_ORB_BLUR_IN_DESCRIBE=1 (experiment): the blurred level is not written */)
 {
     constexpr int SM_ROWS = BH + 6;
     static_assert(BH <= 64, "lane r of the wavefront keeps the row map of source row yb0 + r");
@@ -1059,7 +1060,7 @@ __global__ __launch_bounds__(256, SNK_LEVEL_MIN_WAVES) void level_kernel(Layout 
                         t     = dot2(pr[(kk + 4) % 7][c], 49u | (56u << 16), t);
                         a[c]  = dot2(pr[(kk + 2) % 7][c], 18u | (33u << 16), t);
                     }
-                    if (out_lane)
+                    if (out_lane && !no_blur_store)
                     {
                         const u32 lo = __builtin_amdgcn_perm(a[1], a[0], 0x0c0c0602u);
                         const u32 hi = __builtin_amdgcn_perm(a[3], a[2], 0x06020c0cu);
@@ -1840,6 +1841,13 @@ constexpr int PATCH_ITEMS = (2 * PATCH_R + 1) * PATCH_DW;
 constexpr int MOM_TRIPLES = 31 * 3;                             // a moment-window row (9 dwords) is 3 lanes x 12 bytes -> 2 loads per lane
 typedef u32 u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
 
+// BLUR_IN = true (SNK_ORB_BLUR_IN_DESCRIBE=1; the round-4 review's item 1c, an EXPERIMENT: results are right in the interior of a level and
+// wrong within 21 pixels of its border, where the level-wide blur reflects and this one reads what is there): no blurred level at all --
+// the descriptor wavefront loads the RAW 43 x 48-byte window of a keypoint (129 sixteen-byte items, three loads per lane), blurs it in LDS
+// (horizontal pass: 430 (row, dword) items, 3 LDS reads + 6 v_alignbyte + 8 v_dot4 + 2 LDS writes each; vertical pass: 370 items, 14 LDS
+// reads + 12 v_perm + 12 v_dot2 + 4 v_mad + packing + 1 LDS write each) and runs the steered tests on the result; level_kernel then skips
+// the store of the blurred level.  Measured in profiles/r05/r05v_blur_in_describe.txt.
+template <bool BLUR_IN>
 __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __restrict__ img0, int pitch0,
                                                        long long stride0, int aligned0, const u32* __restrict__ sel,
                                                        const u8* __restrict__ sel_score, const int* __restrict__ sel_cnt,
@@ -1847,8 +1855,12 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
                                                        int* __restrict__ n_out, int out_cap, int gx, int batch, int dbg_fake,
                                                        const u32* __restrict__ sel_resp /* "orb.response" = 1: Harris ranks, else NULL */)
 {
+    constexpr int PR     = BLUR_IN ? PATCH_R + 3 : PATCH_R;     // rows above / below the keypoint in the loaded window
+    constexpr int PQUADS = (2 * PR + 1) * 3;                      // sixteen-byte items of the window
+    constexpr int NB     = (PQUADS + 63) / 64;                    // loads per lane
     __shared__ uint2 mtab[4 * MOM_PAD];
-    __shared__ __attribute__((aligned(16))) u32 patch[4][PATCH_ITEMS + 16];
+    __shared__ __attribute__((aligned(16))) u32 patch[4][(2 * PR + 1) * PATCH_DW + 16];
+    __shared__ u32 hbuf[BLUR_IN ? 4 : 1][BLUR_IN ? (2 * PR + 1) * 20 : 1];  // horizontally blurred rows, 40 pixels x 16 bit
     const int tid  = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     // XCD-aware 1-D grid (workgroup L runs on XCD L % 8, a speed matter only): every workgroup of an image
@@ -1888,16 +1900,25 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
     const int pitch    = l == 0 ? pitch0 : lv.pitch;
     // dbg_fake == 2 (SNK_ORB_DESC_FAKE=2, timing experiment only, results meaningless): the patch from the RAW level, i.e. the rows the
     // moment window reads anyway -- the memory side of "blur inside describe_kernel" (one window per keypoint instead of two)
-    const u8* bsrc     = dbg_fake == 2 ? src : lv.blur + (long long)b * lv.img_stride;
-    const int bpitch   = dbg_fake == 2 ? pitch : lv.pitch;
+    const u8* bsrc     = (dbg_fake == 2 || BLUR_IN) ? src : lv.blur + (long long)b * lv.img_stride;
+    const int bpitch   = (dbg_fake == 2 || BLUR_IN) ? pitch : lv.pitch;
     const bool aligned = l == 0 ? aligned0 != 0 : true;
 
     // per-lane geometry, shared by the keypoints: byte offsets of its moment / patch items relative to the window
     // origins.  A lane moves 12 (moment window) or 16 (patch) bytes per load: the texture-address unit works through a
     // wavefront load 4 lanes per cycle however few bytes a lane asks for, and with one dword per lane the 44 loads of a
     // wavefront (11 per keypoint) kept it busy for ~700 cycles; now 16 loads carry the same rows.
-    int moff[2], vyv[2], boff[2];
-    bool mok[2], bok[2];
+    int moff[2], vyv[2], boff[NB];
+    bool mok[2], bok[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+    {
+        const int item = lane + 64 * k;
+        bok[k]         = item < PQUADS;
+        const int ib   = bok[k] ? item : PQUADS - 1;
+        const int rb   = (ib * 171) >> 9;
+        boff[k]        = dbg_fake == 1 ? 16 * ib : (rb - PR) * bpitch + 16 * (ib - rb * 3);
+    }
 #pragma unroll
     for (int k = 0; k < 2; ++k)
     {
@@ -1909,10 +1930,6 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
         // dbg_fake (SNK_ORB_DESC_FAKE=1, timing experiment only, results meaningless): the window's bytes from ONE contiguous run
         // behind the keypoint instead of 31 / 37 rows -- what the kernel would cost with ~46 instead of ~111 sectors per keypoint
         moff[k]        = dbg_fake == 1 ? 12 * it : (row - 15) * pitch + 12 * (it - row * 3);
-        bok[k]         = item < PATCH_QUADS;
-        const int ib   = bok[k] ? item : PATCH_QUADS - 1;
-        const int rb   = (ib * 171) >> 9;
-        boff[k]        = dbg_fake == 1 ? 16 * ib : (rb - PATCH_R) * bpitch + 16 * (ib - rb * 3);
     }
 
     // ---- issue every load of the wavefront; the copy of the moment table to LDS (and its barrier) comes after, so
@@ -1920,7 +1937,7 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
     bool valid[DESC_KPW];
     int kxv[DESC_KPW], kyv[DESC_KPW], scv[DESC_KPW];
     u32x3_a4 dwv[DESC_KPW][2];
-    u32x4_a4 bpv[DESC_KPW][2];
+    u32x4_a4 bpv[DESC_KPW][NB];
     const long long sbase = (long long)b * L.total_slots + lv.slot_off;
 #pragma unroll
     for (int s = 0; s < DESC_KPW; ++s)
@@ -1929,11 +1946,9 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
         valid[s]       = work && slot < cnt_l && offset + slot < out_cap;
         kxv[s] = kyv[s] = scv[s] = 0;
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-        {
-            dwv[s][k] = u32x3_a4{0u, 0u, 0u};
-            bpv[s][k] = u32x4_a4{0u, 0u, 0u, 0u};
-        }
+        for (int k = 0; k < 2; ++k) dwv[s][k] = u32x3_a4{0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < NB; ++k) bpv[s][k] = u32x4_a4{0u, 0u, 0u, 0u};
     }
     if (work)
     {
@@ -1949,16 +1964,18 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
 #pragma unroll
         for (int s = 0; s < DESC_KPW; ++s)
         {
-            const int xa = (kxv[s] - 15) & ~3, xb = (kxv[s] - PATCH_R) & ~3;
+            const int xa = (kxv[s] - 15) & ~3, xb = (kxv[s] - PR) & ~3;
             const u8* mo = src + ((long long)kyv[s] * pitch + xa);
-            const u8* bo = bsrc + ((long long)kyv[s] * bpitch + xb);
+            // (BLUR_IN: the window may reach 2 rows / columns outside the level; the row is kept inside the plane, what is read there is
+            // not what the level-wide blur reflects -- see the kernel's header)
+            const u8* bo = bsrc + ((long long)(BLUR_IN ? min(max(kyv[s], PR), lv.h - 1 - PR) : kyv[s]) * bpitch + (BLUR_IN ? max(xb, 0) : xb));
             // lanes past the last item repeat it (no divergent branch around a load); their moment weights are zeroed
             // below and their patch quads are not stored
 #pragma unroll
             for (int k = 0; k < 2; ++k)
                 if (aligned) dwv[s][k] = *reinterpret_cast<const u32x3_a4*>(mo + moff[k]);
 #pragma unroll
-            for (int k = 0; k < 2; ++k) bpv[s][k] = *reinterpret_cast<const u32x4_a4*>(bo + boff[k]);
+            for (int k = 0; k < NB; ++k) bpv[s][k] = *reinterpret_cast<const u32x4_a4*>(bo + boff[k]);
         }
     }
     {
@@ -2044,8 +2061,60 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
         const int kx = kxv[s], ky = kyv[s];
         // blurred patch -> LDS (in-order per wavefront: the previous keypoint's reads are done)
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < NB; ++k)
             if (bok[k]) reinterpret_cast<u32x4_a16*>(patch[wave])[lane + 64 * k] = bpv[s][k];
+        if constexpr (BLUR_IN)
+        {
+            // 7 x 7 blur of the raw window in LDS: {18, 33, 49, 56, 49, 33, 18} / 256 per axis, exact 16-bit rows, one rounding -- the
+            // arithmetic of level_kernel on a keypoint's own window.  Blurred dword j of a row = raw dword j + d0 (the raw window starts
+            // 3 columns further left and is aligned separately).
+            __builtin_amdgcn_wave_barrier();
+            const u32 W0123 = 18u | (33u << 8) | (49u << 16) | (56u << 24), W456 = 49u | (33u << 8) | (18u << 16);
+            const int d0    = (((kx - PATCH_R) & ~3) - ((kx - PR) & ~3)) >> 2;
+            const u32* raw  = patch[wave];
+            u32* hb         = hbuf[wave];
+            for (int i = lane; i < (2 * PR + 1) * 10; i += 64)  // horizontal pass
+            {
+                const int row = (i * 205) >> 11, j = i - row * 10;  // i / 10
+                const int at  = row * PATCH_DW + j + d0;
+                const u32 dl = raw[max(at - 1, 0)], d = raw[at], dr = raw[at + 1];
+                const u32 q0 = __builtin_amdgcn_alignbyte(d, dl, 1), q1 = __builtin_amdgcn_alignbyte(d, dl, 2), q2 = __builtin_amdgcn_alignbyte(d, dl, 3);
+                const u32 r0 = __builtin_amdgcn_alignbyte(dr, d, 1), r1 = __builtin_amdgcn_alignbyte(dr, d, 2), r2 = __builtin_amdgcn_alignbyte(dr, d, 3);
+                const u32 h0 = __builtin_amdgcn_udot4(q0, W0123, __builtin_amdgcn_udot4(r0, W456, 0u, false), false);
+                const u32 h1 = __builtin_amdgcn_udot4(q1, W0123, __builtin_amdgcn_udot4(r1, W456, 0u, false), false);
+                const u32 h2 = __builtin_amdgcn_udot4(q2, W0123, __builtin_amdgcn_udot4(r2, W456, 0u, false), false);
+                const u32 h3 = __builtin_amdgcn_udot4(d, W0123, __builtin_amdgcn_udot4(dr, W456, 0u, false), false);
+                hb[row * 20 + 2 * j]     = h0 | (h1 << 16);
+                hb[row * 20 + 2 * j + 1] = h2 | (h3 << 16);
+            }
+            __builtin_amdgcn_wave_barrier();
+            u32* outp = patch[wave];
+            for (int i = lane; i < (2 * PATCH_R + 1) * 10; i += 64)  // vertical pass: blurred row r from horizontal rows r .. r + 6
+            {
+                const int row = (i * 205) >> 11, j = i - row * 10;
+                u32 a[7][2];
+#pragma unroll
+                for (int t = 0; t < 7; ++t) a[t][0] = hb[(row + t) * 20 + 2 * j], a[t][1] = hb[(row + t) * 20 + 2 * j + 1];
+                u32 px4[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                {
+                    // pixel c of the dword: half (c & 1) of word (c >> 1); rows paired by v_perm for v_dot2
+                    const u32 sel = (c & 1) ? 0x07060302u : 0x05040100u;
+                    const u32 p01 = __builtin_amdgcn_perm(a[1][c >> 1], a[0][c >> 1], sel), p23 = __builtin_amdgcn_perm(a[3][c >> 1], a[2][c >> 1], sel),
+                              p45 = __builtin_amdgcn_perm(a[5][c >> 1], a[4][c >> 1], sel);
+                    const u32 h6  = (c & 1) ? a[6][c >> 1] >> 16 : a[6][c >> 1] & 0xFFFFu;
+                    u32 t = __umul24(h6, 18u) + 32768u;
+                    t     = dot2(p01, 18u | (33u << 16), t);
+                    t     = dot2(p23, 49u | (56u << 16), t);
+                    px4[c] = dot2(p45, 49u | (33u << 16), t);
+                }
+                const u32 lo = __builtin_amdgcn_perm(px4[1], px4[0], 0x0c0c0602u), hi = __builtin_amdgcn_perm(px4[3], px4[2], 0x06020c0cu);
+                __builtin_amdgcn_wave_barrier();  // (the write below lands in the raw window: all lanes of this round have read)
+                outp[row * PATCH_DW + j] = lo | hi;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
         const float angle = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, angle_l), 16 * s));
         const float sn    = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sn_l), 16 * s));
         const float cs    = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cs_l), 16 * s));
@@ -2594,7 +2663,8 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
             auto lk = bh == 64 ? (al ? level_kernel<true, 64> : level_kernel<false, 64>)
                                : (bh == 22 ? (al ? level_kernel<true, 22> : level_kernel<false, 22>) : (al ? level_kernel<true, 8> : level_kernel<false, 8>));
             hipLaunchKernelGGL(lk, xcd_grid(gx, batch), dim3(256), 0, st, L, l, images_dev, pitch, image_stride,
-                               fused && l + 1 < L.n_levels && L.lv[l + 1].w > 0 && L.lv[l + 1].h > 0 ? 1 : 0, gx, batch, n_bands);
+                               fused && l + 1 < L.n_levels && L.lv[l + 1].w > 0 && L.lv[l + 1].h > 0 ? 1 : 0, gx, batch, n_bands,
+                               getenv("SNK_ORB_BLUR_IN_DESCRIBE") ? 1 : 0);
         }
         SNK_LAUNCH_CHECK();
     }
@@ -2683,8 +2753,9 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
     {
         const int gx = ceil_div(max_slot, 4 * DESC_KPW);
         const int nb = batch >= 16 ? 8 * ceil_div(batch, 8) : batch;
-        hipLaunchKernelGGL(describe_kernel, dim3(gx * L.n_levels * nb), dim3(256), 0, st, L, images_dev, pitch, image_stride,
-                           aligned0, d_sel, d_selscore, d_selcnt, kps_dev, (u64*)desc_dev, n_dev, out_cap, gx, batch,
+        static const bool blur_in = getenv("SNK_ORB_BLUR_IN_DESCRIBE") != nullptr;  // experiment (round 5), see describe_kernel<true>
+        hipLaunchKernelGGL(blur_in ? describe_kernel<true> : describe_kernel<false>, dim3(gx * L.n_levels * nb), dim3(256), 0, st, L, images_dev, pitch,
+                           image_stride, aligned0, d_sel, d_selscore, d_selcnt, kps_dev, (u64*)desc_dev, n_dev, out_cap, gx, batch,
                            getenv("SNK_ORB_DESC_FAKE") ? atoi(getenv("SNK_ORB_DESC_FAKE")) : 0, d_selresp);
     }
     SNK_LAUNCH_CHECK();

@@ -76,3 +76,46 @@ def test_stereo_index_of_rows_far_outside_the_image(orc):
             assert int(nm[b]) == wn and np.array_equal(rpd[b, :400].cpu().numpy(), wrp) and np.array_equal(dpd[b, :400].cpu().numpy(), wdp), b
     finally:
         pre.close()
+
+
+def test_blur_in_describe_experiment_is_exact_in_the_interior(orc):
+    """SNK_ORB_BLUR_IN_DESCRIBE=1 (round 5, the review's item 1c as an experiment switch: no blurred level in HBM, the descriptor wavefront
+    blurs each keypoint's raw 43 x 48 window in LDS).  Its claim: the same keypoints, and bit-identical descriptors for every keypoint at
+    least 21 pixels inside its level (the level-wide blur reflects at the border, the window blur does not).  Child process: the switch is
+    read once; compared with the ORACLE's descriptors."""
+    import json
+
+    code = r"""
+import json, sys
+import numpy as np
+from snake_slam_amd import synth
+from snake_slam_amd.orb import ORBExtractor
+out = []
+for seed, (w, h, nf, nl) in enumerate([(752, 480, 1000, 4), (1241, 376, 2000, 7), (320, 240, 300, 3)]):
+    img, _ = synth.stereo_frame(20 + seed, w, h)
+    ext = ORBExtractor(nf, 1.2, nl, 20, 7)
+    k, d = ext.Detect(img)
+    ext.close()
+    np.save(sys.argv[1] + f"_{seed}.npy", np.concatenate([k["x"][:, None].astype(np.float64), k["y"][:, None], k["octave"][:, None], k["angle"][:, None],
+                                                          d.view(np.uint8).reshape(len(k), 32)], 1))
+"""
+    import tempfile
+
+    from snake_slam_amd import synth
+
+    with tempfile.TemporaryDirectory() as td:
+        r = subprocess.run([sys.executable, "-c", code, os.path.join(td, "bid")], env=dict(os.environ, SNK_ORB_BLUR_IN_DESCRIBE="1"), capture_output=True,
+                           text=True, cwd=str(ROOT), timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        for seed, (w, h, nf, nl) in enumerate([(752, 480, 1000, 4), (1241, 376, 2000, 7), (320, 240, 300, 3)]):
+            got = np.load(os.path.join(td, f"bid_{seed}.npy"))
+            img, _ = synth.stereo_frame(20 + seed, w, h)
+            wk, wd = orc.orb_detect(orc.orb_params(nf, 1.2, nl, 20, 7), img)
+            assert len(got) == len(wk) and np.array_equal(got[:, 0], wk["x"].astype(np.float64)) and np.array_equal(got[:, 1], wk["y"].astype(np.float64))
+            assert np.array_equal(got[:, 3], wk["angle"].astype(np.float64))
+            scale = np.float32(1.2) ** wk["octave"].astype(np.float32)
+            lw, lh = np.rint(w / scale), np.rint(h / scale)
+            x, y = np.rint(wk["x"] / scale), np.rint(wk["y"] / scale)
+            interior = (x >= 21) & (y >= 21) & (x <= lw - 22) & (y <= lh - 22)
+            same = (got[:, 4:].astype(np.uint8) == wd.view(np.uint8).reshape(len(wk), 32)).all(1)
+            assert interior.sum() > 0.8 * len(wk) and same[interior].all(), (seed, int(interior.sum()), int(same[interior].sum()))
