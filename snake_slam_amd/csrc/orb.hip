@@ -888,7 +888,7 @@ __global__ __launch_bounds__(256, SNK_LEVEL_MIN_WAVES) void level_kernel(Layout 
     if (u >= lv.n_strips * n_bands) return;  // whole wavefront
     const int band  = u / lv.n_strips, strip = u - band * lv.n_strips;
     const int sx0   = strip * lv.strip_stride;
-    const int sx1   = min(sx0 + lv.strip_stride, lv.w);
+    const int sx1   = strip == lv.n_strips - 1 ? lv.w : sx0 + lv.strip_stride;  // the last strip takes the rest of the row (<= 244 columns)
     const int xl    = sx0 - 4 + 4 * lane;  // image column of this lane's dword
     const int yb0   = band * BH, yb1 = min(yb0 + BH, lv.h);
     const bool out_lane = lane >= 1 && lane <= SM_LANES_OUT && xl < sx1;
@@ -2254,8 +2254,21 @@ static int compute_layout(snk_orb* o, int w, int h)
         // streaming blur: balanced strips of <= 62 dwords, bands of 64 rows
         if (lv.w > 0 && lv.h > 0)
         {
-            lv.n_strips     = ceil_div(lv.w, 4 * SM_LANES_OUT);
-            lv.strip_stride = ((ceil_div(lv.w, lv.n_strips) + 3) / 4) * 4;
+            // Strips START on 64-byte boundaries of the row (stride 192 columns; the last strip takes what is left, up to the 244 columns a
+            // wavefront can produce): a wavefront's row store then never shares a 64-byte sector with its neighbour strip's.  Round 5,
+            // tools/probes/hbm_write_shapes.sh: rows written as 4 x 188-byte strips (the balanced layout of a 752-px level) reach 3.3 TB/s,
+            // as 4 x 192-byte strips 5.1 TB/s.  SNK_ORB_BALANCED_STRIPS=1: the round-1..4 layout (equal strips of a multiple of 4 columns).
+            static const bool balanced = getenv("SNK_ORB_BALANCED_STRIPS") != nullptr;
+            if (balanced || lv.w <= 4 * SM_LANES_OUT)
+            {
+                lv.n_strips     = ceil_div(lv.w, 4 * SM_LANES_OUT);
+                lv.strip_stride = ((ceil_div(lv.w, lv.n_strips) + 3) / 4) * 4;
+            }
+            else
+            {
+                lv.strip_stride = 192;
+                lv.n_strips     = 1 + ceil_div(lv.w - 4 * SM_LANES_OUT, 192);
+            }
             lv.n_bands      = ceil_div(lv.h, SM_BH);
         }
         else  // a level scaled down to nothing (small image, many levels, large scale factor): no strips, no work

@@ -72,6 +72,14 @@ int main()
     {
         hipLaunchKernelGGL((write_dword<3, 64, 256>), dim3((bands * 3 + 3) / 4), dim3(256), 0, 0, buf, bands * 3);
         hipLaunchKernelGGL((write_dword<4, 47, 188>), dim3((bands * 4 + 3) / 4), dim3(256), 0, 0, buf, bands * 4);
+        // round 5: the same 752 bytes of a row as strips that start on 64-byte / 32-byte boundaries, and the strip widths of levels 1-3
+        hipLaunchKernelGGL((write_dword<4, 48, 192>), dim3((bands * 4 + 3) / 4), dim3(256), 0, 0, buf, bands * 4);
+        hipLaunchKernelGGL((write_dword<3, 56, 224>), dim3((bands * 3 + 3) / 4), dim3(256), 0, 0, buf, bands * 3);
+        hipLaunchKernelGGL((write_dword<3, 53, 212>), dim3((bands * 3 + 3) / 4), dim3(256), 0, 0, buf, bands * 3);
+        hipLaunchKernelGGL((write_dword<3, 44, 176>), dim3((bands * 3 + 3) / 4), dim3(256), 0, 0, buf, bands * 3);
+        hipLaunchKernelGGL((write_dword<2, 55, 220>), dim3((bands * 2 + 3) / 4), dim3(256), 0, 0, buf, bands * 2);
+        hipLaunchKernelGGL((write_dword<2, 61, 244>), dim3((bands * 2 + 3) / 4), dim3(256), 0, 0, buf, bands * 2);
+        hipLaunchKernelGGL((write_dword<2, 60, 240>), dim3((bands * 2 + 3) / 4), dim3(256), 0, 0, buf, bands * 2);
         hipLaunchKernelGGL(write_quad, dim3((unsigned)((bytes / 16 + 255) / 256)), dim3(256), 0, 0, reinterpret_cast<uint4*>(buf), bytes / 16);
         hipLaunchKernelGGL(read_dword, dim3((bands * 3 + 3) / 4), dim3(256), 0, 0, buf, bands * 3, out);
         hipLaunchKernelGGL(read_quad, dim3((unsigned)((bytes / 16 + 255) / 256)), dim3(256), 0, 0, reinterpret_cast<const uint4*>(buf), bytes / 16, out);
