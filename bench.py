@@ -472,6 +472,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="post-extraction stage on the extractor's stream (no overlap of batch i's "
                     "stage with batch i + 1's extraction)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-track-inputs", default="", help="tools: write the first 16 frames of the tracking leg's inputs (grid-ordered features, "
+                    "cell starts, local maps) to this .npz (tools/track_scan_stats.py reads it)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline of the front-end")
     ap.add_argument("--check-frames", type=int, default=256, help="frames of the last timed step whose outputs in HBM are compared "
                     "bit for bit with the oracle's (those the CPU baseline reaches in its time budget)")
@@ -906,6 +908,11 @@ def main():
         rng = np.random.default_rng(synth.SEED + 4711)
         lm = [tracking_points(h_kps[b], h_desc[b], int(h_n[b]), h_depth[b], rng, TRACK_M_COARSE, TRACK_M_FINE, level_scale)
               for b in range(TB)]
+        if args.dump_track_inputs:
+            nd = min(TB, 16)
+            np.savez_compressed(args.dump_track_inputs, kps=h_kps[:nd], n=h_n[:nd], cell_start=cell_start[:nd].cpu().numpy(),
+                                coarse=np.stack([x[0] for x in lm[:nd]]), fine=np.stack([x[1] for x in lm[:nd]]),
+                                level_scale=np.asarray(level_scale), bounds=np.asarray(GRID_BOUNDS, np.float64), cam=np.asarray(TRACK_CAM))
         d_pc = torch.from_numpy(np.stack([x[0] for x in lm]).view(np.uint8).reshape(TB, TRACK_M_COARSE, 88)).to(dev)
         pf_host = np.stack([x[1] for x in lm])
         d_pf0 = torch.from_numpy(pf_host.view(np.uint8).reshape(TB, TRACK_M_FINE, 96)).to(dev)

@@ -303,7 +303,7 @@ __device__ __forceinline__ uint4 bcast_u4(const uint4& v, int src)
 // coarse (SnakeORBMatcher.cpp:221-318): 64 points starting at i0; results to best[] / bins[] (indexed like pts)
 __device__ __forceinline__ void coarse_wave64(const FrameDev& F, const CamDev& C, const ScalesDev& S, const snk_lm_coarse* __restrict__ pts,
                                               int m, int i0, int ppw, float th, int feature_error, int direction, int lane,
-                                              int* __restrict__ best, int* __restrict__ bins)
+                                              int* __restrict__ best, int* __restrict__ bins, int* claim = nullptr)
 {
     const int i   = i0 + lane;
     const bool in = lane < ppw && i < m;  // ppw points per wavefront: 64 for large batches, fewer when the points are few
@@ -383,8 +383,10 @@ __device__ __forceinline__ void coarse_wave64(const FrameDev& F, const CamDev& C
     __builtin_amdgcn_wave_barrier();
     if (in)
     {
-        best[i] = my_res[lane];
+        const int res = my_res[lane];
+        best[i] = res;
         bins[i] = my_bin[lane];
+        if (claim != nullptr && res >= 0 && !F.taken[res]) atomicMin(&claim[res], i);  // the fused resolution (coarse_frame_kernel)
     }
 }
 
@@ -421,7 +423,8 @@ __global__ __launch_bounds__(256) void coarse_batch_kernel(FramesDev Fb, const C
 // record -- a 32-byte sector written per point, six times the bytes of the results proper.
 template <bool WRITE_VALID = true>
 __device__ __forceinline__ void fine_wave64(const FrameDev& F, const CamDev& C, const ScalesDev& S, snk_lm_fine* __restrict__ pts, int m,
-                                            int i0, int ppw, float th, float ratio, int lane, int* __restrict__ best, u8* __restrict__ visible)
+                                            int i0, int ppw, float th, float ratio, int lane, int* __restrict__ best, u8* __restrict__ visible,
+                                            int* claim = nullptr)
 {
     const int i   = i0 + lane;
     const bool in = lane < ppw && i < m;
@@ -503,9 +506,11 @@ __device__ __forceinline__ void fine_wave64(const FrameDev& F, const CamDev& C, 
     __builtin_amdgcn_wave_barrier();
     if (in)
     {
-        best[i]      = my_res[lane];
-        visible[i]   = vis;
+        const int res = my_res[lane];
+        best[i]       = res;
+        visible[i]    = vis;
         if (WRITE_VALID) pts[i].valid = valid;
+        if (claim != nullptr && res >= 0 && !F.taken[res]) atomicMin(&claim[res], i);  // the fused resolution (fine_frame_kernel)
     }
 }
 
@@ -532,59 +537,15 @@ __global__ __launch_bounds__(256) void fine_batch_kernel(FramesDev Fb, const Cam
     fine_wave64<WRITE_VALID>(F, C, S, pts + (size_t)b * m_cap, m, i0, ppw, th, ratio, lane, best + (size_t)b * m_cap, visible + (size_t)b * m_cap);
 }
 
-// Frame-resident forms of the two batched matchers: 1024 threads (16 wavefronts, 1024 points) per workgroup, the frame in LDS.
-__global__ __launch_bounds__(1024) void coarse_frame_kernel(FramesDev Fb, const CamDev* __restrict__ cams, ScalesDev S,
-                                                            const snk_lm_coarse* __restrict__ pts, const int* __restrict__ m_dev,
-                                                            int m_cap, float th, int feature_error, int direction,
-                                                            int* __restrict__ best, int* __restrict__ bins)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char frame_lds[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int b = blockIdx.y;
-    const int m = min(m_dev[b], m_cap);
-    if (blockIdx.x * 1024 >= m) return;  // whole workgroup
-    const FrameDev F = stage_frame_lds(frame_of(Fb, b), frame_lds, 1024);  // once per workgroup; the chunks of its share follow
-    const CamDev C = cams[b];
-    for (int chunk = blockIdx.x; chunk * 1024 < m; chunk += gridDim.x)
-    {
-        const int i0 = (chunk * 16 + wave) * 64;
-        if (i0 >= m) break;
-        coarse_wave64(F, C, S, pts + (size_t)b * m_cap, m, i0, 64, th, feature_error, direction, lane, best + (size_t)b * m_cap,
-                      bins + (size_t)b * m_cap);
-    }
-}
-
-template <bool WRITE_VALID>
-__global__ __launch_bounds__(1024) void fine_frame_kernel(FramesDev Fb, const CamDev* __restrict__ cams, ScalesDev S,
-                                                          snk_lm_fine* __restrict__ pts, const int* __restrict__ m_dev, int m_cap, float th,
-                                                          float ratio, int* __restrict__ best, u8* __restrict__ visible)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char frame_lds[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int b = blockIdx.y;
-    const int m = min(m_dev[b], m_cap);
-    if (blockIdx.x * 1024 >= m) return;  // whole workgroup
-    // The frame (65 KB for 1000 features) is staged ONCE per workgroup and the workgroup walks the chunks blockIdx.x, + gridDim.x, ...
-    // of the frame's local map: with one chunk per workgroup the ten workgroups of a 10 000-point local map each staged the same
-    // frame -- 40 % of a workgroup's input bytes (round 4; grid.x is chosen by the launch, SNK_TRACK_FRAME_WGS).
-    const FrameDev F = stage_frame_lds(frame_of(Fb, b), frame_lds, 1024);
-    const CamDev C = cams[b];
-    for (int chunk = blockIdx.x; chunk * 1024 < m; chunk += gridDim.x)
-    {
-        const int i0 = (chunk * 16 + wave) * 64;
-        if (i0 >= m) break;  // chunks ascend: nothing further for this wavefront (no barrier follows)
-        fine_wave64<WRITE_VALID>(F, C, S, pts + (size_t)b * m_cap, m, i0, 64, th, ratio, lane, best + (size_t)b * m_cap, visible + (size_t)b * m_cap);
-    }
-}
-
 // first claimant (lowest local-map index) of every feature wins; coarse additionally applies the
 // rotation-histogram filter.  One workgroup per frame.
 // CLAIM: int* in global memory (any number of features) or in LDS (the batched kernel: the claims of a frame's features fit, and
 // an LDS atomic per local-map point instead of a global one is most of the kernel's time)
+// Second half of the resolution: the claims are in (claim[f] = lowest local-map index that wants feature f); every thread of the
+// workgroup calls it.  Starts with a barrier, so it may follow the claiming pass directly.
 template <typename CLAIM>
-__device__ __forceinline__ void resolve_body(const int* __restrict__ best, const int* __restrict__ bins, int m,
-                                             const u8* __restrict__ taken, CLAIM claim, int n_feat,
-                                             int with_rotation, int* __restrict__ match_idx, int* __restrict__ n_out)
+__device__ __forceinline__ void resolve_finish(const int* __restrict__ best, const int* __restrict__ bins, int m, const u8* taken, CLAIM claim,
+                                               int with_rotation, int* __restrict__ match_idx, int* __restrict__ n_out)
 {
     __shared__ int hist[30];
     __shared__ int keep[3];
@@ -592,13 +553,6 @@ __device__ __forceinline__ void resolve_body(const int* __restrict__ best, const
     const int tid = threadIdx.x, nthr = blockDim.x;
     if (tid < 30) hist[tid] = 0;
     if (tid == 0) count = 0;
-    for (int f = tid; f < n_feat; f += nthr) claim[f] = 0x7FFFFFFF;
-    __syncthreads();
-    for (int i = tid; i < m; i += nthr)
-    {
-        const int b = best[i];
-        if (b >= 0 && !taken[b]) atomicMin(&claim[b], i);
-    }
     __syncthreads();
     for (int i = tid; i < m; i += nthr)
     {
@@ -648,6 +602,21 @@ __device__ __forceinline__ void resolve_body(const int* __restrict__ best, const
     __syncthreads();
     if (tid == 0) *n_out = count;
 }
+template <typename CLAIM>
+__device__ __forceinline__ void resolve_body(const int* __restrict__ best, const int* __restrict__ bins, int m,
+                                             const u8* __restrict__ taken, CLAIM claim, int n_feat,
+                                             int with_rotation, int* __restrict__ match_idx, int* __restrict__ n_out)
+{
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    for (int f = tid; f < n_feat; f += nthr) claim[f] = 0x7FFFFFFF;
+    __syncthreads();
+    for (int i = tid; i < m; i += nthr)
+    {
+        const int b = best[i];
+        if (b >= 0 && !taken[b]) atomicMin(&claim[b], i);
+    }
+    resolve_finish(best, bins, m, taken, claim, with_rotation, match_idx, n_out);
+}
 
 __global__ __launch_bounds__(256) void resolve_kernel(const int* __restrict__ best, const int* __restrict__ bins, int m,
                                                       const u8* __restrict__ taken, int* __restrict__ claim, int n_feat,
@@ -675,6 +644,85 @@ __global__ __launch_bounds__(1024) void resolve_batch_kernel(const int* __restri
                      claim + (size_t)b * Fb.cap, min(Fb.n[b], Fb.cap), with_rotation, match_idx + (size_t)b * m_cap, n_out + b);
     // entries past the frame's point count read as "no match"
     for (int i = m + threadIdx.x; i < m_cap; i += blockDim.x) match_idx[(size_t)b * m_cap + i] = -1;
+}
+
+// Frame-resident forms of the two batched matchers: 1024 threads (16 wavefronts, 1024 points) per workgroup, the frame in LDS.
+// Eight wavefronts per SIMD (<= 64 VGPRs, three dwords spilled outside the scan): TWO workgroups per CU.  At the 68 / 69 VGPRs the
+// kernels take unbounded only one workgroup fits a CU -- four wavefronts per SIMD against a window scan that is a chain of dependent
+// LDS reads.  Round 5, tracking leg of bench.py (1024 frames): 853 k -> 911 k frames/s (profiles/r05/r05z_track_experiments.json).
+#ifndef SNK_TRACK_FRAME_WAVES_PER_EU
+#define SNK_TRACK_FRAME_WAVES_PER_EU 8
+#endif
+// FUSED resolution (claim_off >= 0, only with ONE workgroup per frame, which is what large batches get): the claims of the frame's
+// features live in LDS behind the frame (claim_off bytes into the carve), every wavefront claims as it produces a point's best feature, and
+// after the last chunk the workgroup finishes like resolve_batch_kernel does (first claimant wins, coarse: rotation histogram) -- the
+// separate launch, its three passes over best[] from HBM and its barriers are gone.  A thread resolves the points it matched itself
+// (point i is thread i mod 1024 in both halves).  Round 5: resolve_batch_kernel was 26 + 52 us of the 1.13 ms chain per 1024 frames.
+__global__ __launch_bounds__(1024, SNK_TRACK_FRAME_WAVES_PER_EU) void coarse_frame_kernel(FramesDev Fb, const CamDev* __restrict__ cams, ScalesDev S,
+                                                            const snk_lm_coarse* __restrict__ pts, const int* __restrict__ m_dev,
+                                                            int m_cap, float th, int feature_error, int direction,
+                                                            int* __restrict__ best, int* __restrict__ bins, int claim_off,
+                                                            int* __restrict__ match_idx, int* __restrict__ n_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char frame_lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int b = blockIdx.y;
+    const int m = min(m_dev[b], m_cap);
+    const bool fused = claim_off >= 0;
+    if (!fused && blockIdx.x * 1024 >= m) return;  // whole workgroup
+    int* claim = fused ? reinterpret_cast<int*>(frame_lds + claim_off) : nullptr;
+    const FrameDev G = frame_of(Fb, b);
+    if (fused)
+        for (int f = threadIdx.x; f < G.n; f += 1024) claim[f] = 0x7FFFFFFF;  // the barrier at the end of the staging covers it
+    const FrameDev F = stage_frame_lds(G, frame_lds, 1024);  // once per workgroup; the chunks of its share follow
+    const CamDev C = cams[b];
+    for (int chunk = blockIdx.x; chunk * 1024 < m; chunk += gridDim.x)
+    {
+        const int i0 = (chunk * 16 + wave) * 64;
+        if (i0 >= m) break;
+        coarse_wave64(F, C, S, pts + (size_t)b * m_cap, m, i0, 64, th, feature_error, direction, lane, best + (size_t)b * m_cap,
+                      bins + (size_t)b * m_cap, claim);
+    }
+    if (fused)
+    {
+        resolve_finish(best + (size_t)b * m_cap, bins + (size_t)b * m_cap, m, F.taken, claim, 1, match_idx + (size_t)b * m_cap, n_out + b);
+        for (int i = m + threadIdx.x; i < m_cap; i += 1024) match_idx[(size_t)b * m_cap + i] = -1;
+    }
+}
+
+template <bool WRITE_VALID>
+__global__ __launch_bounds__(1024, SNK_TRACK_FRAME_WAVES_PER_EU) void fine_frame_kernel(FramesDev Fb, const CamDev* __restrict__ cams, ScalesDev S,
+                                                          snk_lm_fine* __restrict__ pts, const int* __restrict__ m_dev, int m_cap, float th,
+                                                          float ratio, int* __restrict__ best, u8* __restrict__ visible, int claim_off,
+                                                          int* __restrict__ match_idx, int* __restrict__ n_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char frame_lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int b = blockIdx.y;
+    const int m = min(m_dev[b], m_cap);
+    const bool fused = claim_off >= 0;
+    if (!fused && blockIdx.x * 1024 >= m) return;  // whole workgroup
+    // The frame (65 KB for 1000 features) is staged ONCE per workgroup and the workgroup walks the chunks blockIdx.x, + gridDim.x, ...
+    // of the frame's local map: with one chunk per workgroup the ten workgroups of a 10 000-point local map each staged the same
+    // frame -- 40 % of a workgroup's input bytes (round 4; grid.x is chosen by the launch, SNK_TRACK_FRAME_WGS).
+    int* claim = fused ? reinterpret_cast<int*>(frame_lds + claim_off) : nullptr;
+    const FrameDev G = frame_of(Fb, b);
+    if (fused)
+        for (int f = threadIdx.x; f < G.n; f += 1024) claim[f] = 0x7FFFFFFF;
+    const FrameDev F = stage_frame_lds(G, frame_lds, 1024);
+    const CamDev C = cams[b];
+    for (int chunk = blockIdx.x; chunk * 1024 < m; chunk += gridDim.x)
+    {
+        const int i0 = (chunk * 16 + wave) * 64;
+        if (i0 >= m) break;  // chunks ascend: nothing further for this wavefront (the barriers of the fused resolution come after the loop)
+        fine_wave64<WRITE_VALID>(F, C, S, pts + (size_t)b * m_cap, m, i0, 64, th, ratio, lane, best + (size_t)b * m_cap, visible + (size_t)b * m_cap,
+                                 claim);
+    }
+    if (fused)
+    {
+        resolve_finish(best + (size_t)b * m_cap, (const int*)nullptr, m, F.taken, claim, 0, match_idx + (size_t)b * m_cap, n_out + b);
+        for (int i = m + threadIdx.x; i < m_cap; i += 1024) match_idx[(size_t)b * m_cap + i] = -1;
+    }
 }
 
 // CamDev of every frame of a batch from its pose (same operations, in the same order, as make_cam on the host)
@@ -1267,6 +1315,15 @@ int frame_wgs(int chunks, int batch)
     return wgs < 1 ? 1 : (wgs > chunks ? chunks : wgs);
 }
 
+// Byte offset of the claims inside the LDS carve of a frame-resident matcher that resolves its matches itself, -1 = separate resolution
+// (several workgroups per frame, or the claims do not fit behind the frame).  SNK_TRACK_NO_FUSED_RESOLVE=1: always separate (A/B, tests).
+int fused_claim_offset(int wgs, size_t flds, int cap)
+{
+    static const bool off = getenv("SNK_TRACK_NO_FUSED_RESOLVE") != nullptr;
+    const size_t at = (flds + 15) & ~(size_t)15;
+    return (off || wgs != 1 || at + (size_t)cap * 4 > (size_t)FRAME_LDS_MAX) ? -1 : (int)at;
+}
+
 int points_per_wave(long long total_points)
 {
     static const int forced = getenv("SNK_TRACK_PPW") ? atoi(getenv("SNK_TRACK_PPW")) : 0;  // tests: force a value
@@ -1675,8 +1732,13 @@ int snk_match_project_coarse_batch_dev(snk_matcher* m, const snk_frames_dev* fra
     if (ppw == 64 && flds <= FRAME_LDS_MAX && !no_frame_lds())
     {
         if ((rc = set_max_lds_once(reinterpret_cast<const void*>(coarse_frame_kernel), FRAME_LDS_MAX)) != SNK_OK) return rc;
-        hipLaunchKernelGGL(coarse_frame_kernel, dim3(frame_wgs(ceil_div(pts_cap, 1024), batch), batch), dim3(1024), flds, m->stream, F, (const CamDev*)cams,
-                           S, pts_dev, n_pts_dev, pts_cap, th, feature_error, direction, best, bins);
+        const int wgs       = frame_wgs(ceil_div(pts_cap, 1024), batch);
+        const int claim_off = fused_claim_offset(wgs, flds, F.cap);
+        hipLaunchKernelGGL(coarse_frame_kernel, dim3(wgs, batch), dim3(1024), claim_off >= 0 ? (size_t)claim_off + (size_t)F.cap * 4 : flds, m->stream, F,
+                           (const CamDev*)cams, S, pts_dev, n_pts_dev, pts_cap, th, feature_error, direction, best, bins, claim_off, match_idx_dev,
+                           n_matches_dev);
+        SNK_LAUNCH_CHECK();
+        if (claim_off >= 0) return SNK_OK;  // resolved in the kernel
     }
     else
         hipLaunchKernelGGL(coarse_batch_kernel, dim3(ceil_div(pts_cap, 4 * ppw), batch), dim3(256), 0, m->stream, F, (const CamDev*)cams, S,
@@ -1715,12 +1777,19 @@ static int fine_batch_impl(snk_matcher* m, const snk_frames_dev* frames, const s
         const void* fk = write_valid ? reinterpret_cast<const void*>(fine_frame_kernel<true>) : reinterpret_cast<const void*>(fine_frame_kernel<false>);
         if ((rc = set_max_lds_once(fk, FRAME_LDS_MAX)) != SNK_OK) return rc;
         const int wgs = frame_wgs(ceil_div(pts_cap, 1024), batch);
+        const int claim_off = fused_claim_offset(wgs, flds, F.cap);
+        const size_t lds    = claim_off >= 0 ? (size_t)claim_off + (size_t)F.cap * 4 : flds;
         if (write_valid)
-            hipLaunchKernelGGL(fine_frame_kernel<true>, dim3(wgs, batch), dim3(1024), flds, m->stream, F, (const CamDev*)cams, S, pts_dev,
-                               n_pts_dev, pts_cap, th, ratio, best, visible_dev);
+            hipLaunchKernelGGL(fine_frame_kernel<true>, dim3(wgs, batch), dim3(1024), lds, m->stream, F, (const CamDev*)cams, S, pts_dev,
+                               n_pts_dev, pts_cap, th, ratio, best, visible_dev, claim_off, match_idx_dev, n_matches_dev);
         else
-            hipLaunchKernelGGL(fine_frame_kernel<false>, dim3(wgs, batch), dim3(1024), flds, m->stream, F, (const CamDev*)cams, S, pts_dev,
-                               n_pts_dev, pts_cap, th, ratio, best, visible_dev);
+            hipLaunchKernelGGL(fine_frame_kernel<false>, dim3(wgs, batch), dim3(1024), lds, m->stream, F, (const CamDev*)cams, S, pts_dev,
+                               n_pts_dev, pts_cap, th, ratio, best, visible_dev, claim_off, match_idx_dev, n_matches_dev);
+        if (claim_off >= 0)
+        {
+            SNK_LAUNCH_CHECK();
+            return SNK_OK;  // resolved in the kernel
+        }
     }
     else if (write_valid)
         hipLaunchKernelGGL(fine_batch_kernel<true>, dim3(ceil_div(pts_cap, 4 * ppw), batch), dim3(256), 0, m->stream, F, (const CamDev*)cams,
