@@ -907,7 +907,30 @@ static int refine_batch_impl(snk_matcher* m, const snk_frames_dev* frames, const
     hipLaunchKernelGGL((pose_kernel<W_, L_>), dim3(batch), dim3(64 * W_), LDS_, m->stream, reinterpret_cast<const PoseMeta*>(d),  \
                        reinterpret_cast<const double*>(d + o_wps), reinterpret_cast<const snk_pose_obs*>(d + o_obs),                \
                        reinterpret_cast<u8*>(o), reinterpret_cast<double*>(o + o_pose), inliers_dev, C, *opt, lds_matches)
-    if (stride >= 256 && !no_lds)
+    // Wavefronts per frame.  Four: the shortest step (a thread walks a quarter of the matches), right while the chip holds every frame at
+    // once -- two per CU at the kernel's ~250 registers.  More frames than that would run in rounds of 2 x #CU; with TWO wavefronts per frame
+    // four frames share a CU (same wavefronts per SIMD), the steps are longer and the frames all run together: tracking leg of bench.py,
+    // 1024 frames, pose_kernel 467 -> ~365 us, the chain 1.100 -> 1.000 ms (profiles/r05/r05z_track_experiments.json).  The LDS carve
+    // then holds ~590 matches of a frame (the rest from global memory in every step: 200 / 400 / 500 / 590 in LDS = 1.052 / 1.016 / 1.006 /
+    // 0.995 ms, 640 = three frames per CU = 1.148 ms).  SNK_POSE_WAVES=2|4 forces a form.
+    static const int waves_env = getenv("SNK_POSE_WAVES") ? atoi(getenv("SNK_POSE_WAVES")) : 0;
+    static const int n_cu = []
+    {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256;
+        return v > 0 ? v : 256;
+    }();
+    const bool two_waves = waves_env == 2 || (waves_env != 4 && batch > 2 * n_cu);
+    if (stride >= 256 && !no_lds && two_waves)
+    {
+        int rc = set_max_lds_once(reinterpret_cast<const void*>(pose_kernel<2, true>), dyn_max);
+        if (rc != SNK_OK) return rc;
+        int lm = (160 * 1024 / 4 - (2 * POSE_SLOTS_PER_WAVE * 28 + 28) * 8 - 512) / 56;  // four frames per CU
+        if (lds_env > 0) lm = lds_env;
+        lds_matches = lm < stride ? lm : stride;
+        POSE_LAUNCH(2, true, (size_t)lds_matches * 56);
+    }
+    else if (stride >= 256 && !no_lds)
     {
         int rc = set_max_lds_once(reinterpret_cast<const void*>(pose_kernel<4, true>), dyn_max);
         if (rc != SNK_OK) return rc;

@@ -161,10 +161,14 @@ def test_device_resident_chain_coarse_refine_fine(orc):
 
 
 @pytest.mark.skipif(__import__("os").environ.get("SNK_POSE_NO_RECURSE") == "1", reason="child run")
-def test_device_resident_chain_with_a_small_pose_lds_carve():
-    """pose_kernel keeps the first `lds_matches` matches of a frame in LDS (sized so that several frames share a compute unit) and
-    reads the rest from global memory; the device-resident chain runs again in a child process with the carve forced down to 100
-    matches (SNK_POSE_LDS_MATCHES), so that most matches of every frame take the global-memory tail -- same poses."""
+@pytest.mark.parametrize("switches", [{"SNK_POSE_LDS_MATCHES": "100"}, {"SNK_POSE_WAVES": "2"}, {"SNK_POSE_WAVES": "2", "SNK_POSE_LDS_MATCHES": "100"}],
+                         ids=["small_carve", "two_waves", "two_waves_small_carve"])
+def test_device_resident_chain_under_the_forms_large_batches_take(switches):
+    """The chain's kernels pick their form by the batch: pose_kernel keeps the first `lds_matches` matches of a frame in LDS (sized so that
+    several frames share a compute unit), reads the rest from global memory and runs two wavefronts per frame instead of four when there are
+    more frames than two per CU.  The device-resident chain runs again in a child process with each of these forced on the small test batch
+    (a carve of 100 matches, so that most matches of every frame take the global-memory tail; SNK_POSE_WAVES=2) -- same poses.  (The forms
+    of the frame-resident matchers: test_zx_frontend_variants_gpu.py.)"""
     import os
     import subprocess
     import sys
@@ -173,7 +177,7 @@ def test_device_resident_chain_with_a_small_pose_lds_carve():
     root = Path(__file__).resolve().parent.parent
     r = subprocess.run([sys.executable, "-m", "pytest", str(Path(__file__).resolve()), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
                         "-k", "device_resident_chain_coarse_refine_fine"],
-                       env=dict(os.environ, SNK_POSE_LDS_MATCHES="100", SNK_POSE_NO_RECURSE="1"), capture_output=True, text=True,
+                       env=dict(os.environ, SNK_POSE_NO_RECURSE="1", **switches), capture_output=True, text=True,
                        cwd=str(root), timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-1000:])
     assert "1 passed" in r.stdout

@@ -4,7 +4,10 @@ default-path suites).
 * SNK_ORB_LEVEL_BH = 64 / 22 / 8: rows per band of level_kernel (64 for big batches, 22 / 8 for the per-frame calls);
 * SNK_GRID_NETWORK=1, SNK_STEREO_SORT_NETWORK=1: the bitonic networks instead of the counting forms of the feature grid / the stereo
   row index;
-* SNK_TRACK_FRAME_WGS = 1 / 3: workgroups per frame of the frame-resident projection matchers."""
+* SNK_TRACK_FRAME_WGS = 1 / 3: workgroups per frame of the frame-resident projection matchers;
+* SNK_TRACK_PPW=64 (every batched matcher call takes the frame-resident kernels) with one workgroup per frame -- the matcher resolves its
+  matches itself -- and with SNK_TRACK_NO_FUSED_RESOLVE=1 (separate resolve_batch_kernel);
+* SNK_POSE_WAVES=2: two wavefronts per frame in pose_kernel (what batches of more than two frames per CU take)."""
 import os
 import subprocess
 import sys
@@ -24,6 +27,9 @@ ROOT = Path(__file__).resolve().parent.parent
     ({"SNK_GRID_NETWORK": "1", "SNK_STEREO_SORT_NETWORK": "1"}, ["test_match_gpu.py", "test_track_gpu.py", "test_frontend_gpu.py"]),
     ({"SNK_TRACK_FRAME_WGS": "1"}, ["test_track_gpu.py", "test_tracking_chain_gpu.py"]),
     ({"SNK_TRACK_FRAME_WGS": "3"}, ["test_track_gpu.py", "test_tracking_chain_gpu.py"]),
+    ({"SNK_TRACK_PPW": "64", "SNK_TRACK_FRAME_WGS": "1", "SNK_TRACK_NO_RECURSE": "1", "SNK_POSE_NO_RECURSE": "1"}, ["test_track_gpu.py", "test_tracking_chain_gpu.py"]),
+    ({"SNK_TRACK_PPW": "64", "SNK_TRACK_FRAME_WGS": "1", "SNK_TRACK_NO_FUSED_RESOLVE": "1", "SNK_TRACK_NO_RECURSE": "1", "SNK_POSE_NO_RECURSE": "1"}, ["test_track_gpu.py", "test_tracking_chain_gpu.py"]),
+    ({"SNK_POSE_WAVES": "2", "SNK_TRACK_NO_RECURSE": "1", "SNK_POSE_NO_RECURSE": "1"}, ["test_pose_gpu.py", "test_tracking_chain_gpu.py"]),
 ])
 def test_parity_suites_with_forced_form(env, files):
     r = subprocess.run([sys.executable, "-m", "pytest"] + [str(ROOT / "tests" / f) for f in files] +
