@@ -955,12 +955,27 @@ __device__ inline void cam_finish(const Arrays& A, const Prob& pr, int pb, int c
 // linearising three observations: with many windows per launch ONE wavefront per camera (12 observations per thread for the
 // benchmark window) is fastest -- 143 us (4 wavefronts) -> 102 (2) -> 86 (1) per 256 windows; a single window keeps 4 for latency.
 template <int CAM_THREADS>
-__global__ __launch_bounds__(CAM_THREADS, SNK_BA_CAM_WAVES) void cam_pass(Arrays A, Opt O)
+__global__ __launch_bounds__(CAM_THREADS, SNK_BA_CAM_WAVES) void cam_pass(Arrays A, Opt O, int nbx, int B)
 {
     __shared__ double part[CAM_THREADS / 64][33];
-    const int pb  = blockIdx.y;
+    // nbx > 0 (batched windows): 1-D grid, all cameras of a window on ONE XCD like the other passes of the iteration (workgroup L runs on
+    // XCD L % 8).  Every observation gathers 48 bytes of its point (position | V^-1 b_p, 96 KB per benchmark window, written by
+    // schur_fused on that XCD); with the cameras of a window dealt over the eight XCDs each L2 fetched the window's points for itself:
+    // counter bytes 1.64 MB per window and launch, half of them those gathers (round 5).
+    int pb, c;
+    if (nbx > 0)
+    {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        pb = (slot / nbx) * 8 + xcd;
+        c  = slot - (slot / nbx) * nbx;
+        if (pb >= B) return;
+    }
+    else
+    {
+        pb = blockIdx.y;
+        c  = blockIdx.x;
+    }
     const Prob pr = A.prob[pb];
-    const int c   = blockIdx.x;
     if (c >= pr.nfc) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int s0 = A.cam_start[pr.camstart_off + c], s1 = A.cam_start[pr.camstart_off + c + 1];
@@ -4969,9 +4984,13 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L, bool only_marked =
             if (cam_sums)
                 LAUNCH(cam_sum, dim3(h->max_nfc, B), dim3(64), 0, A);
             else if (B >= 16)
-                LAUNCH(cam_pass<64>, dim3(h->max_nfc, B), dim3(64), 0, A, O);
+            {
+                static const bool cam_2d = getenv("SNK_BA_CAM_GRID_2D") != nullptr;  // A/B: the round-1..4 grid (cameras of a window over all XCDs)
+                if (cam_2d) LAUNCH(cam_pass<64>, dim3(h->max_nfc, B), dim3(64), 0, A, O, 0, B);
+                else LAUNCH(cam_pass<64>, dim3(8 * h->max_nfc * ceil_div(B, 8)), dim3(64), 0, A, O, h->max_nfc, B);
+            }
             else
-                LAUNCH(cam_pass<256>, dim3(h->max_nfc, B), dim3(256), 0, A, O);
+                LAUNCH(cam_pass<256>, dim3(h->max_nfc, B), dim3(256), 0, A, O, 0, B);
             {
                 const int nbx = ceil_div(h->max_nfc * h->max_nfc, 4);
                 if (use_set)
