@@ -111,6 +111,7 @@ struct LevelInfo
     u8* base;              // level buffer (levels >= 1); level 0 comes from the caller
     u8* blur;              // blurred level (all levels), same pitch / stride as the level buffers
     int strip_stride, n_strips, n_bands, unit_off;  // streaming pass: column strips x row bands of this level
+    int store_end;         // the last strip writes the blurred row up to this column (>= w: into the row padding, whole 64-byte sectors)
     const int* ymap;      // [h] destination row of level l+1 whose upper source row is this row, or -1
     const int* strip_dx;  // [n_strips + 1] first destination dword (4 px) of level l+1 owned by each strip
     int ncols, nrows, wcell, hcell;
@@ -891,7 +892,7 @@ __global__ __launch_bounds__(256, SNK_LEVEL_MIN_WAVES) void level_kernel(Layout 
     const int sx1   = strip == lv.n_strips - 1 ? lv.w : sx0 + lv.strip_stride;  // the last strip takes the rest of the row (<= 244 columns)
     const int xl    = sx0 - 4 + 4 * lane;  // image column of this lane's dword
     const int yb0   = band * BH, yb1 = min(yb0 + BH, lv.h);
-    const bool out_lane = lane >= 1 && lane <= SM_LANES_OUT && xl < sx1;
+    const bool out_lane = lane >= 1 && lane <= SM_LANES_OUT && xl < (strip == lv.n_strips - 1 ? lv.store_end : sx1);
     const u8* src      = l == 0 ? img0 + (long long)b * stride0 : lv.base + (long long)b * lv.img_stride;
     // 32-bit offsets inside one image (pitch * h < 2^31), scalars pinned in SGPRs
     const int pitch    = __builtin_amdgcn_readfirstlane(l == 0 ? pitch0 : lv.pitch);
@@ -2269,6 +2270,12 @@ static int compute_layout(snk_orb* o, int w, int h)
                 lv.strip_stride = 192;
                 lv.n_strips     = 1 + ceil_div(lv.w - 4 * SM_LANES_OUT, 192);
             }
+            // The last strip's blurred store runs on to the end of the row pitch when its 61 lanes reach it (EuRoC levels 0 and 2: 576 + 192 =
+            // 768, 384 + 192 = 576): whole 64-byte sectors instead of a ragged end; the padding columns hold reflected-border blur values
+            // nobody reads.  +0.4 % end to end; one more 192-column strip wherever the rest exceeds 192 columns instead: -1.5 %
+            // (profiles/r05/r05z_strip_store_end.json).
+            lv.store_end = lv.w;
+            if (!balanced && lv.w > 4 * SM_LANES_OUT && lv.pitch - (lv.n_strips - 1) * lv.strip_stride <= 4 * SM_LANES_OUT) lv.store_end = lv.pitch;
             lv.n_bands      = ceil_div(lv.h, SM_BH);
         }
         else  // a level scaled down to nothing (small image, many levels, large scale factor): no strips, no work
