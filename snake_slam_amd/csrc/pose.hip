@@ -946,6 +946,7 @@ static int refine_batch_impl(snk_matcher* m, const snk_frames_dev* frames, const
         int lm = (160 * 1024 / 4 - (2 * POSE_SLOTS_PER_WAVE * 28 + 28) * 8 - 512) / 56;  // four frames per CU
         if (lds_env > 0) lm = lds_env;
         lds_matches = lm < stride ? lm : stride;
+        if ((size_t)lds_matches * 56 > (size_t)dyn_max) lds_matches = dyn_max / 56;
         POSE_LAUNCH(2, true, (size_t)lds_matches * 56);
     }
     else if (stride >= 256 && !no_lds)
