@@ -258,6 +258,87 @@ __device__ __forceinline__ int obs_linearize(const double* pose, const double* R
     return dim;
 }
 
+// ---- the observation Jacobians by their structure (round 5; the batch kernels schur_fused, cam_pass, update_cost) ----
+// With Xc = R p + t and the rows m_k = w * d proj_k / d Xc (k < dim; obs_linearize's P scaled by the weight)
+//     J_c,k = [ m_k | Xc x m_k ]   (translation | rotation part of obs_linearize's Jc),      J_p,k = m_k^T R,
+// and m_0 = (a0, 0, c0), m_1 = (0, b1, c1), m_2 = (a0, 0, c2) (stereo only).  Every product the solver takes of them is a function
+// of the symmetric M = sum_k m_k m_k^T (M01 = 0), h = sum_k m_k r_k, Xc and R:
+//     W = J_c^T J_p = [ N ; Xc x N ] with N = M R (cross product column by column),     V = J_p^T J_p = R^T N,      b_p = -R^T h,
+//     U = J_c^T J_c = [ M, T ; T^T, Xc x T ] with T[i] = Xc x M[:, i],                   b_c = -[ h ; Xc x h ],
+//     J_c^T J_p v = [ f ; Xc x f ] with f = M (R v),                                      J_p^T (J_c dc) = R^T M (dt + dr x Xc).
+// ~80 instead of ~150 fp64 operations per observation in schur_fused, ~125 instead of ~210 in cam_pass, ~35 instead of ~110 in the
+// back-substitution half of update_cost, and 5 + 3 + 3 live values instead of J_c (18) and J_p (9).  Algebraically identical; the
+// rounding differs in the last bits (bundle adjustment is specified by a tolerance).  The residual -- and with
+// it every cost -- is computed by the same expressions as obs_linearize.
+struct ObsCore
+{
+    double X, Y, Z;             // the point in the camera frame
+    double a0, c0, b1, c1, c2;  // the rows of w * d proj / d Xc (c2 = 0 for a monocular observation)
+    int dim;
+};
+
+__device__ __forceinline__ int obs_core(const double* pose, const double* R, const double* pt, const double* K, double bf, double u,
+                                        double v, double depth, double w, double* r, ObsCore& o)
+{
+    const double X = R[0] * pt[0] + R[1] * pt[1] + R[2] * pt[2] + pose[4];
+    const double Y = R[3] * pt[0] + R[4] * pt[1] + R[5] * pt[2] + pose[5];
+    const double Z = R[6] * pt[0] + R[7] * pt[1] + R[8] * pt[2] + pose[6];
+    if (Z <= 0.0) return 0;
+    const double iz = SNK_BA_IEEE_DIV ? 1.0 / Z : rcp_nr(Z), iz2 = iz * iz;
+    const double fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+    const int dim = depth > 0.0 ? 3 : 2;
+    r[0] = w * (fx * X * iz + cx - u);
+    r[1] = w * (fy * Y * iz + cy - v);
+    r[2] = dim == 3 ? w * ((fx * X * iz + cx - bf * iz) - (u - (SNK_BA_IEEE_DIV ? bf / depth : bf * rcp_nr(depth)))) : 0.0;
+    o.X = X; o.Y = Y; o.Z = Z;
+    o.a0 = w * (fx * iz);
+    o.c0 = w * (-fx * X * iz2);
+    o.b1 = w * (fy * iz);
+    o.c1 = w * (-fy * Y * iz2);
+    o.c2 = dim == 3 ? w * (-fx * X * iz2 + bf * iz2) : 0.0;
+    o.dim = dim;
+    return dim;
+}
+
+struct ObsMoments
+{
+    double M00, M02, M11, M12, M22;  // s2 * sum_k m_k m_k^T (M01 = 0)
+    double h0, h1, h2;               // s2 * sum_k m_k r_k
+};
+
+// s2 = the squared IRLS scale (J_c, J_p and r each carry one factor of it)
+__device__ __forceinline__ void obs_moments(const ObsCore& o, const double* r, double s2, ObsMoments& m)
+{
+    const double a2 = o.dim == 3 ? o.a0 : 0.0;
+    m.M00 = s2 * (o.a0 * o.a0 + a2 * a2);
+    m.M02 = s2 * (o.a0 * o.c0 + a2 * o.c2);
+    m.M11 = s2 * (o.b1 * o.b1);
+    m.M12 = s2 * (o.b1 * o.c1);
+    m.M22 = s2 * (o.c0 * o.c0 + o.c1 * o.c1 + o.c2 * o.c2);
+    m.h0  = s2 * (o.a0 * r[0] + a2 * r[2]);
+    m.h1  = s2 * (o.b1 * r[1]);
+    m.h2  = s2 * (o.c0 * r[0] + o.c1 * r[1] + o.c2 * r[2]);
+}
+
+// obs_linearize's J_c scaled by sw, from the core (only the camera-sum variant of schur_fused still wants the matrix itself)
+__device__ __forceinline__ void core_to_Jc(const ObsCore& o, double sw, double* Jc)
+{
+    const double ma[3] = {sw * o.a0, 0.0, o.dim == 3 ? sw * o.a0 : 0.0};
+    const double mb[3] = {0.0, sw * o.b1, 0.0};
+    const double mc[3] = {sw * o.c0, sw * o.c1, sw * o.c2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+    {
+        const double a = ma[k], b = mb[k], c = mc[k];
+        Jc[6 * k + 0] = a;
+        Jc[6 * k + 1] = b;
+        Jc[6 * k + 2] = c;
+        Jc[6 * k + 3] = -b * o.Z + c * o.Y;
+        Jc[6 * k + 4] = a * o.Z - c * o.X;
+        Jc[6 * k + 5] = -a * o.Y + b * o.X;
+    }
+}
+
 __device__ __forceinline__ double huber_rho(double s, double d, double& sqrt_w)
 {
     const double d2 = d * d;
@@ -1015,35 +1096,62 @@ __global__ __launch_bounds__(CAM_THREADS, SNK_BA_CAM_WAVES) void cam_pass(Arrays
         const double vb[3] = {pv_n[3], pv_n[4], pv_n[5]};
         if (s + CAM_THREADS < s1) fetch(s + CAM_THREADS);
         if (skip) continue;
-        double r[3], J[18], Jp[9];
-        const int dim = obs_linearize<true>(pose, R, pt, pr.K, pr.bf, ob.u, ob.v, ob.depth, ob.weight, r, J, Jp);
+        double r[3];
+        ObsCore oc;
+        const int dim = obs_core(pose, R, pt, pr.K, pr.bf, ob.u, ob.v, ob.depth, ob.weight, r, oc);
         if (!dim) continue;
+        ObsMoments mo;
         {
             const double sq = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
             double sw;
             (void)huber_rho(sq, dim == 3 ? O.huber_stereo : O.huber_mono, sw);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) r[k] *= sw;
-#pragma unroll
-            for (int k = 0; k < 18; ++k) J[k] *= sw;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) Jp[k] *= sw;
+            obs_moments(oc, r, sw * sw, mo);
         }
-        int q = 0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b = a; b < 6; ++b) acc[q++] += J[a] * J[b] + J[6 + a] * J[6 + b] + J[12 + a] * J[12 + b];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) acc[21 + a] -= J[a] * r[0] + J[6 + a] * r[1] + J[12 + a] * r[2];
+        const double X = oc.X, Y = oc.Y, Z = oc.Z;
+        // U = J_c^T J_c = [ M, T ; T^T, Xc x T ], T[i] = Xc x M[:, i] (obs_core); upper triangle row by row, acc[1] (U01) stays 0
+        const double T00 = Y * mo.M02, T01 = Z * mo.M00 - X * mo.M02, T02 = -Y * mo.M00;
+        const double T10 = Y * mo.M12 - Z * mo.M11, T11 = -X * mo.M12, T12 = X * mo.M11;
+        const double T20 = Y * mo.M22 - Z * mo.M12, T21 = Z * mo.M02 - X * mo.M22, T22 = X * mo.M12 - Y * mo.M02;
+        acc[0] += mo.M00;
+        acc[2] += mo.M02;
+        acc[3] += T00;
+        acc[4] += T01;
+        acc[5] += T02;
+        acc[6] += mo.M11;
+        acc[7] += mo.M12;
+        acc[8] += T10;
+        acc[9] += T11;
+        acc[10] += T12;
+        acc[11] += mo.M22;
+        acc[12] += T20;
+        acc[13] += T21;
+        acc[14] += T22;
+        acc[15] += Y * T20 - Z * T10;  // B = Xc x (the columns of T)
+        acc[16] += Y * T21 - Z * T11;
+        acc[17] += Y * T22 - Z * T12;
+        acc[18] += Z * T01 - X * T21;
+        acc[19] += Z * T02 - X * T22;
+        acc[20] += X * T12 - Y * T02;
+        // b_c = -J_c^T r = -[ h ; Xc x h ]
+        acc[21] -= mo.h0;
+        acc[22] -= mo.h1;
+        acc[23] -= mo.h2;
+        acc[24] -= Y * mo.h2 - Z * mo.h1;
+        acc[25] -= Z * mo.h0 - X * mo.h2;
+        acc[26] -= X * mo.h1 - Y * mo.h0;
         if (ob.ptfree)
         {
-            // Y b_p = W V^-1 b_p = J_c^T (J_p (V^-1 b_p))
-            const double t0 = Jp[0] * vb[0] + Jp[1] * vb[1] + Jp[2] * vb[2];
-            const double t1 = Jp[3] * vb[0] + Jp[4] * vb[1] + Jp[5] * vb[2];
-            const double t2 = Jp[6] * vb[0] + Jp[7] * vb[1] + Jp[8] * vb[2];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) acc[27 + a] += J[a] * t0 + J[6 + a] * t1 + J[12 + a] * t2;
+            // Y b_p = W V^-1 b_p = J_c^T (J_p (V^-1 b_p)) = [ f ; Xc x f ], f = M (R v)
+            const double e0 = R[0] * vb[0] + R[1] * vb[1] + R[2] * vb[2];
+            const double e1 = R[3] * vb[0] + R[4] * vb[1] + R[5] * vb[2];
+            const double e2 = R[6] * vb[0] + R[7] * vb[1] + R[8] * vb[2];
+            const double f0 = mo.M00 * e0 + mo.M02 * e2, f1 = mo.M11 * e1 + mo.M12 * e2, f2 = mo.M02 * e0 + mo.M12 * e1 + mo.M22 * e2;
+            acc[27] += f0;
+            acc[28] += f1;
+            acc[29] += f2;
+            acc[30] += Y * f2 - Z * f1;
+            acc[31] += Z * f0 - X * f2;
+            acc[32] += X * f1 - Y * f0;
         }
     }
     // fixed-order reduction: xor butterfly inside each wavefront, then the 4 wavefronts in order
@@ -1561,41 +1669,48 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
 #pragma unroll
             for (int k = 0; k < SF_NC; ++k) con[k] = 0.0;
             bool cpl = false;  // the observation couples a free camera with a free point: it has a row of W
-            double Jc[18], Jp[9];
             double r[3] = {0.0, 0.0, 0.0};
             bool lin = false;  // the observation is active in this iteration (what cam_pass sums)
+            ObsCore oc{};      // kept for the camera-sum variant, which rebuilds J_c from it (cam_term)
+            double sw_obs = 0.0;
+            double N[9];       // N = M R; W = [N ; Xc x N] (see obs_core)
+            double Xc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-            for (int k = 0; k < 18; ++k) Jc[k] = 0.0;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) Jp[k] = 0.0;
+            for (int k = 0; k < 9; ++k) N[k] = 0.0;
             if (ob.act && !gt.is_out)
             {
                 double R[9];
                 quat_to_R(gt.pose, R);
-                const int dim = obs_linearize<true>(gt.pose, R, ob.pt, pr.K, pr.bf, ob.rec.u, ob.rec.v, ob.rec.depth, ob.rec.weight, r, Jc, Jp);
+                const int dim = obs_core(gt.pose, R, ob.pt, pr.K, pr.bf, ob.rec.u, ob.rec.v, ob.rec.depth, ob.rec.weight, r, oc);
                 lin           = dim != 0;
                 if (dim)
                 {
                     const double sq = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
                     double sw;
                     con[9] = huber_rho(sq, dim == 3 ? O.huber_stereo : O.huber_mono, sw);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) r[k] *= sw;
-#pragma unroll
-                    for (int k = 0; k < 18; ++k) Jc[k] *= sw;
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) Jp[k] *= sw;
+                    ObsMoments mo;
+                    obs_moments(oc, r, sw * sw, mo);
+                    sw_obs = sw;
                     if (ob.rec.ptfree)
                     {
-                        con[0] = Jp[0] * Jp[0] + Jp[3] * Jp[3] + Jp[6] * Jp[6];
-                        con[1] = Jp[0] * Jp[1] + Jp[3] * Jp[4] + Jp[6] * Jp[7];
-                        con[2] = Jp[0] * Jp[2] + Jp[3] * Jp[5] + Jp[6] * Jp[8];
-                        con[3] = Jp[1] * Jp[1] + Jp[4] * Jp[4] + Jp[7] * Jp[7];
-                        con[4] = Jp[1] * Jp[2] + Jp[4] * Jp[5] + Jp[7] * Jp[8];
-                        con[5] = Jp[2] * Jp[2] + Jp[5] * Jp[5] + Jp[8] * Jp[8];
 #pragma unroll
-                        for (int b = 0; b < 3; ++b) con[6 + b] = -(Jp[b] * r[0] + Jp[3 + b] * r[1] + Jp[6 + b] * r[2]);
-                        cpl = ob.rec.cam >= 0;
+                        for (int j = 0; j < 3; ++j)
+                        {
+                            N[j]     = mo.M00 * R[j] + mo.M02 * R[6 + j];
+                            N[3 + j] = mo.M11 * R[3 + j] + mo.M12 * R[6 + j];
+                            N[6 + j] = mo.M02 * R[j] + mo.M12 * R[3 + j] + mo.M22 * R[6 + j];
+                        }
+                        // V = J_p^T J_p = R^T N (upper triangle), b_p = -R^T h
+                        con[0] = R[0] * N[0] + R[3] * N[3] + R[6] * N[6];
+                        con[1] = R[0] * N[1] + R[3] * N[4] + R[6] * N[7];
+                        con[2] = R[0] * N[2] + R[3] * N[5] + R[6] * N[8];
+                        con[3] = R[1] * N[1] + R[4] * N[4] + R[7] * N[7];
+                        con[4] = R[1] * N[2] + R[4] * N[5] + R[7] * N[8];
+                        con[5] = R[2] * N[2] + R[5] * N[5] + R[8] * N[8];
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) con[6 + b] = -(R[b] * mo.h0 + R[3 + b] * mo.h1 + R[6 + b] * mo.h2);
+                        cpl   = ob.rec.cam >= 0;
+                        Xc[0] = oc.X; Xc[1] = oc.Y; Xc[2] = oc.Z;
                     }
                 }
             }
@@ -1603,11 +1718,18 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
             for (int k = 0; k < SF_NC; ++k) s_con[lane * SF_NC + k] = con[k];
             if (si.nfree != 0)
             {
+                // the observation's row of W = J_c^T J_p: rows 0-2 = N, rows 3-5 = Xc x (the columns of N); zero unless it couples
 #pragma unroll
-                for (int a = 0; a < 6; ++a)
-#pragma unroll
-                    for (int b = 0; b < 3; ++b)
-                        s_w[lane * 18 + a * 3 + b] = cpl ? Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b] + Jc[12 + a] * Jp[6 + b] : 0.0;
+                for (int b = 0; b < 3; ++b)
+                {
+                    const double n0 = cpl ? N[b] : 0.0, n1 = cpl ? N[3 + b] : 0.0, n2 = cpl ? N[6 + b] : 0.0;
+                    s_w[lane * 18 + 0 * 3 + b] = n0;
+                    s_w[lane * 18 + 1 * 3 + b] = n1;
+                    s_w[lane * 18 + 2 * 3 + b] = n2;
+                    s_w[lane * 18 + 3 * 3 + b] = Xc[1] * n2 - Xc[2] * n1;
+                    s_w[lane * 18 + 4 * 3 + b] = Xc[2] * n0 - Xc[0] * n2;
+                    s_w[lane * 18 + 5 * 3 + b] = Xc[0] * n1 - Xc[1] * n0;
+                }
             }
             __builtin_amdgcn_wave_barrier();
 
@@ -1622,15 +1744,22 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
             }
             __builtin_amdgcn_wave_barrier();
             // ---- camera sums, the 27 terms of J_c and r (the contribution buffer is free again; J_c dies here) ----
-            if (CS && si.nfree != 0)
+            if constexpr (CS)
             {
-#pragma unroll
-                for (int pass = 0; pass < 4; ++pass)
+                if (si.nfree != 0)
                 {
-                    double term[8];
+                    double Jc[18];
+                    core_to_Jc(oc, sw_obs, Jc);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) term[k] = pass * 8 + k < 27 && lin ? cam_term(pass * 8 + k, Jc, r) : 0.0;
-                    cs_pass(pass, term, gc);
+                    for (int k = 0; k < 3; ++k) r[k] *= sw_obs;
+#pragma unroll
+                    for (int pass = 0; pass < 4; ++pass)
+                    {
+                        double term[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) term[k] = pass * 8 + k < 27 && lin ? cam_term(pass * 8 + k, Jc, r) : 0.0;
+                        cs_pass(pass, term, gc);
+                    }
                 }
             }
         }
@@ -1877,22 +2006,25 @@ __global__ __launch_bounds__(256, SNK_BA_UC_WAVES) void update_cost(Arrays A, Op
         double t[3] = {0, 0, 0};
         if (ob.act && !(is_out || ob.rec.cam < 0 || !ob.rec.ptfree))
         {
-            double R[9], r[3], Jc[18], Jp[9];
+            double R[9], r[3];
             quat_to_R(pose, R);
-            const int dim = obs_linearize<true>(pose, R, ob.pt, pr.K, pr.bf, ob.rec.u, ob.rec.v, ob.rec.depth, ob.rec.weight, r, Jc, Jp);
+            ObsCore oc;
+            const int dim = obs_core(pose, R, ob.pt, pr.K, pr.bf, ob.rec.u, ob.rec.v, ob.rec.depth, ob.rec.weight, r, oc);
             if (dim)
             {
                 const double sq = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
                 double sw;
                 (void)huber_rho(sq, dim == 3 ? O.huber_stereo : O.huber_mono, sw);
                 const double s2 = sw * sw;  // J_c and J_p each carry the IRLS scale
-                double u[3];
+                // J_p^T (J_c dc) = R^T M d with d = dt + dr x Xc (obs_core): u_k = m_k . d, g = sum_k m_k u_k
+                const double d0 = xv[0] + (xv[4] * oc.Z - xv[5] * oc.Y);
+                const double d1 = xv[1] + (xv[5] * oc.X - xv[3] * oc.Z);
+                const double d2 = xv[2] + (xv[3] * oc.Y - xv[4] * oc.X);
+                const double a2 = dim == 3 ? oc.a0 : 0.0;
+                const double u0 = s2 * (oc.a0 * d0 + oc.c0 * d2), u1 = s2 * (oc.b1 * d1 + oc.c1 * d2), u2 = s2 * (a2 * d0 + oc.c2 * d2);
+                const double g0 = oc.a0 * u0 + a2 * u2, g1 = oc.b1 * u1, g2 = oc.c0 * u0 + oc.c1 * u1 + oc.c2 * u2;
 #pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    u[k] = s2 * (Jc[6 * k] * xv[0] + Jc[6 * k + 1] * xv[1] + Jc[6 * k + 2] * xv[2] + Jc[6 * k + 3] * xv[3] + Jc[6 * k + 4] * xv[4] +
-                                 Jc[6 * k + 5] * xv[5]);
-#pragma unroll
-                for (int b = 0; b < 3; ++b) t[b] = Jp[b] * u[0] + Jp[3 + b] * u[1] + Jp[6 + b] * u[2];
+                for (int b = 0; b < 3; ++b) t[b] = R[b] * g0 + R[3 + b] * g1 + R[6 + b] * g2;
             }
         }
         s_t[lane * 3] = t[0];
