@@ -53,6 +53,9 @@
 #ifndef SNK_BA_CAM_WAVES
 #define SNK_BA_CAM_WAVES 1
 #endif
+#ifndef SNK_BA_CAM_BUTTERFLY
+#define SNK_BA_CAM_BUTTERFLY 0
+#endif
 #ifndef SNK_BA_UC_WAVES
 #define SNK_BA_UC_WAVES 1
 #endif
@@ -1032,6 +1035,52 @@ __device__ inline void cam_finish(const Arrays& A, const Prob& pr, int pb, int c
     for (int a = 0; a < 6; ++a) A.rhs[pr.vec_off + c * 6 + a] = tot[21 + a] - tot[27 + a];
 }
 
+// Column sums of 33 values per lane over the 64 lanes of a wavefront, "transpose and add": every step pairs the lanes, each lane keeps
+// one half of its values and hands the other half to its partner, so the number of live sums halves with the number of lanes that
+// share them -- 17 + 9 + 5 + 3 + 2 + 1 = 37 additions instead of the 33 x 6 of a butterfly that carries every sum through all six
+// steps.  Steps 1 and 2 are gfx950's v_permlane32_swap / v_permlane16_swap (two registers exchange halves / alternate rows: one
+// instruction per 32-bit half, no select), steps 3-6 DPP moves inside a row of 16 (row_ror:8, row_half_mirror, quad_perm).  On return
+// lane l holds the total of value idx = 17 b5 + 9 b4 + 5 b3 + 3 b2 + 2 b1 + b0 (the bits of l) when `ok` (the other lanes hold the
+// zero padding of the odd splits).  The order of the additions is fixed (a tree over the lanes), like the butterfly's.
+__device__ __forceinline__ double swap_add32(double a, double b)  // lanes < 32: a(l) + a(l + 32); lanes >= 32: b(l - 32) + b(l)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double swap_add16(double a, double b)  // even rows of 16: a(l) + a(l + 16); odd rows: b(l - 16) + b(l)
+{
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ double xchg_add(double lo, double hi, bool bit)  // bit = 0: lo(l) + lo(partner); bit = 1: hi(l) + hi(partner)
+{
+    const double keep = bit ? hi : lo, send = bit ? lo : hi;
+    return keep + dpp_mov64<CTRL>(send);
+}
+__device__ __forceinline__ double wave_reduce33(const double (&acc)[33], int lane, int& idx, bool& ok)
+{
+    double a[17], b[9], c[5], d[3], e[2];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) a[i] = swap_add32(acc[i], i + 17 < 33 ? acc[i + 17] : 0.0);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) b[i] = swap_add16(a[i], i + 9 < 17 ? a[i + 9] : 0.0);
+    const int b5 = (lane >> 5) & 1, b4 = (lane >> 4) & 1, b3 = (lane >> 3) & 1, b2 = (lane >> 2) & 1, b1 = (lane >> 1) & 1, b0 = lane & 1;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) c[i] = xchg_add<0x128>(b[i], i + 5 < 9 ? b[i + 5] : 0.0, b3 != 0);  // row_ror:8
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d[i] = xchg_add<0x141>(c[i], i + 3 < 5 ? c[i + 3] : 0.0, b2 != 0);  // row_half_mirror: l <-> 7 - l
+#pragma unroll
+    for (int i = 0; i < 2; ++i) e[i] = xchg_add<0x4E>(d[i], i + 2 < 3 ? d[i + 2] : 0.0, b1 != 0);   // quad_perm [2,3,0,1]
+    const double f = xchg_add<0xB1>(e[0], e[1], b0 != 0);                                            // quad_perm [1,0,3,2]
+    const int i3 = 2 * b1 + b0, i5 = 3 * b2 + i3, i9 = 5 * b3 + i5, i17 = 9 * b4 + i9;
+    idx = 17 * b5 + i17;
+    ok  = i3 < 3 && i5 < 5 && i9 < 9 && i17 < 17 && idx < 33;
+    return f;
+}
+
 // CAM_THREADS threads per camera.  The 33 sums of a wavefront are reduced with a 6-step butterfly (~600 instructions), as much as
 // linearising three observations: with many windows per launch ONE wavefront per camera (12 observations per thread for the
 // benchmark window) is fastest -- 143 us (4 wavefronts) -> 102 (2) -> 86 (1) per 256 windows; a single window keeps 4 for latency.
@@ -1154,7 +1203,8 @@ __global__ __launch_bounds__(CAM_THREADS, SNK_BA_CAM_WAVES) void cam_pass(Arrays
             acc[32] += X * f1 - Y * f0;
         }
     }
-    // fixed-order reduction: xor butterfly inside each wavefront, then the 4 wavefronts in order
+    // fixed-order reduction: inside each wavefront (wave_reduce33), then the wavefronts in order
+#if SNK_BA_CAM_BUTTERFLY  // build-time A/B: the xor butterfly of rounds 1-4, every sum through all six steps (~600 instructions)
 #pragma unroll
     for (int k = 0; k < 33; ++k)
     {
@@ -1166,6 +1216,14 @@ __global__ __launch_bounds__(CAM_THREADS, SNK_BA_CAM_WAVES) void cam_pass(Arrays
     if (lane == 0)
 #pragma unroll
         for (int k = 0; k < 33; ++k) part[wave][k] = acc[k];
+#else
+    {
+        int idx;
+        bool ok;
+        const double v = wave_reduce33(acc, lane, idx, ok);
+        if (ok) part[wave][idx] = v;
+    }
+#endif
     __syncthreads();
     if (tid == 0)
     {
