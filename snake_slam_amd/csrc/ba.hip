@@ -1603,7 +1603,7 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
     static_assert(!CS || T == 3, "camera sums: at most 8 free cameras per set (lane = (camera, term of eight))");
     // per wavefront: the W rows of the group (64 x 18 doubles) | the observations' contributions (64 x 10) | the sums of
     // the group's points | their V^-1 | V^-1 b_p.  16.8 KB: two workgroups per CU, which is also what the registers allow.
-    __shared__ __attribute__((aligned(16))) double s_buf[4][64 * 18 + 64 * SF_NC + SF_GMAX * (SF_NC + 6) + 4 + SF_GMAX * 3];
+    __shared__ __attribute__((aligned(16))) double s_buf[4][64 * 18 + 64 * SF_NC + SF_GMAX * (SF_NC + 9) + 4 + SF_GMAX * 3 + SF_GMAX * 4];
     int pb, bx;
     if (B >= 16)  // batched windows: one XCD per window
     {
@@ -1634,8 +1634,9 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
     double* s_con  = s_w + 64 * 18;
     double* s_sum  = s_con + 64 * SF_NC;
     double* s_vi   = s_sum + SF_GMAX * SF_NC;
-    double* s_zero = s_vi + SF_GMAX * 6;  // 4 zeros: what the operand lanes outside the matrix read
+    double* s_zero = s_vi + SF_GMAX * 9;  // 4 zeros: what the operand lanes outside the matrix read
     double* s_vb   = s_zero + 4;          // V^-1 b_p of the group's points (camera sums)
+    double* s_pp   = s_vb + SF_GMAX * 3;  // position | "is an unknown" of the group's points, left by the first observation lane of each point
     const int run  = si.run, G = min(64 / run, SF_GMAX);  // run <= SET_MAX_RUN = 14: at least 4 points per group
     const int lg   = lane / run;                           // point of the group (its observation is lane - lg * run)
     const double* poses = A.pose + (size_t)pr.img_off * 7;
@@ -1645,21 +1646,26 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
     const int nrows = si.nfree * 6;
     const int kk = lane >> 4, mr = lane & 15;
     // Operand addressing of the matrix products without selects: lane (row 16 t + mr, inner index kk) reads its row of W at
-    // wrow[t] + point * wstep[t]; lanes outside the matrix (row >= 6k, or kk == 3) have their pointer parked on four zeros
-    // with a zero step, so they read zeros and need no masking.
+    // wrow[t] + point * wstep[t]; lanes outside the matrix (row >= 6k) have their pointer parked on four zeros with a zero step,
+    // so they read zeros and need no masking.
+    // The inner dimension of a product is FOUR wide and a point has three coordinates: four points share three products (round 5;
+    // one point per product left a quarter of every v_mfma_f64_16x16x4 multiplying zeros).  Inner index 4 s + kk of product s of a
+    // block of four points is (point gl[s], coordinate cs[s]) = ((4 s + kk) / 3, (4 s + kk) % 3); V^-1 is kept as the full 3 x 3
+    // matrix per point, so that the lane's column is at 3 * (4 s + kk) doubles from the block's start -- a per-lane base and
+    // compile-time offsets.
     const double* wrow0[T];
     int wstep[T];
 #pragma unroll
     for (int t = 0; t < T; ++t)
     {
         const int m = 16 * t + mr, i = (m * 43) >> 8, r = m - 6 * i;
-        const bool ok = m < nrows && kk < 3;
-        const int pos = m < nrows ? A.set_pairs[si.aux_off + i] : 0;
+        const bool ok = m < nrows;
+        const int pos = ok ? A.set_pairs[si.aux_off + i] : 0;
         wrow0[t]    = ok ? s_w + pos * 18 + r * 3 : s_zero;
         wstep[t]    = ok ? run * 18 : 0;
     }
-    const int vsel0 = kk == 0 ? 0 : (kk == 1 ? 1 : 2), vsel1 = kk == 0 ? 1 : (kk == 1 ? 3 : 4), vsel2 = kk == 0 ? 2 : (kk == 1 ? 4 : 5);
-    const int ksel  = kk < 3 ? kk : 0;
+    const int gl[3] = {kk == 3 ? 1 : 0, kk >= 2 ? 2 : 1, kk >= 1 ? 3 : 2};
+    const int cs[3] = {kk == 3 ? 0 : kk, kk == 2 ? 0 : (kk == 3 ? 1 : kk + 1), kk == 0 ? 2 : kk - 1};
     double4_t acc[T * (T + 1) / 2];
 #pragma unroll
     for (int q = 0; q < T * (T + 1) / 2; ++q) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
@@ -1774,6 +1780,15 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
             }
 #pragma unroll
             for (int k = 0; k < SF_NC; ++k) s_con[lane * SF_NC + k] = con[k];
+            // phase 2b wants the point's position and constancy per POINT: the point's first observation lane has both in registers
+            // (round 5: they used to be two dependent global loads in front of phase 2b, one memory round trip per group)
+            if (ob.act && lane == lg * run)
+            {
+                s_pp[lg * 4 + 0] = ob.pt[0];
+                s_pp[lg * 4 + 1] = ob.pt[1];
+                s_pp[lg * 4 + 2] = ob.pt[2];
+                s_pp[lg * 4 + 3] = ob.rec.ptfree ? 1.0 : 0.0;
+            }
             if (si.nfree != 0)
             {
                 // the observation's row of W = J_c^T J_p: rows 0-2 = N, rows 3-5 = Xc x (the columns of N); zero unless it couples
@@ -1827,7 +1842,7 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
         if (lane < gc)
         {
             const int gp2 = pr.pt_off + p2;
-            const bool pfree = !A.pt_const[gp2];
+            const bool pfree = s_pp[lane * 4 + 3] != 0.0;
             const double* sm = s_sum + lane * SF_NC;
             double V[6] = {sm[0], sm[1], sm[2], sm[3], sm[4], sm[5]};
             const double bp[3] = {sm[6], sm[7], sm[8]};
@@ -1858,8 +1873,12 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
                 vb[1] = Vi[1] * bp[0] + Vi[3] * bp[1] + Vi[4] * bp[2];
                 vb[2] = Vi[2] * bp[0] + Vi[4] * bp[1] + Vi[5] * bp[2];
             }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) s_vi[lane * 6 + k] = Vi[k];
+            {
+                double* vo = s_vi + lane * 9;  // the full symmetric matrix: column c = row c = three consecutive doubles
+                vo[0] = Vi[0]; vo[1] = Vi[1]; vo[2] = Vi[2];
+                vo[3] = Vi[1]; vo[4] = Vi[3]; vo[5] = Vi[4];
+                vo[6] = Vi[2]; vo[7] = Vi[4]; vo[8] = Vi[5];
+            }
             if (CS)
             {
                 s_vb[lane * 3 + 0] = vb[0];
@@ -1867,8 +1886,7 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
                 s_vb[lane * 3 + 2] = vb[2];
             }
             {
-                const double* ptp = A.pt + (size_t)gp2 * 3;
-                const double px = ptp[0], py = ptp[1], pz = ptp[2];
+                const double px = s_pp[lane * 4], py = s_pp[lane * 4 + 1], pz = s_pp[lane * 4 + 2];
                 double* pv        = A.ptv + (size_t)gp2 * 6;
                 pv[0] = px; pv[1] = py; pv[2] = pz;
                 pv[3] = vb[0]; pv[4] = vb[1]; pv[5] = vb[2];
@@ -1893,17 +1911,45 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
             const double* wr[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) wr[t] = wrow0[t];
-            const double* vv = s_vi;
-            for (int g = 0; g < gc; ++g, vv += 6)
+            const double* vq = s_vi + 3 * kk;
+            int g = 0;
+            for (; g + 4 <= gc; g += 4, vq += 36)  // four points, three products per tile pair
             {
-                const double vc0 = vv[vsel0], vc1 = vv[vsel1], vc2 = vv[vsel2];  // column kk of the symmetric V^-1
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+                {
+                    const double vc0 = vq[12 * s], vc1 = vq[12 * s + 1], vc2 = vq[12 * s + 2];  // column cs[s] of the symmetric V^-1 of point gl[s]
+                    double ya[T], wb[T];
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+                    {
+                        const double* w = wr[t] + gl[s] * wstep[t];
+                        ya[t] = w[0] * vc0 + w[1] * vc1 + w[2] * vc2;  // (W V^-1)[row][coordinate]
+                        wb[t] = w[cs[s]];                               // W[row][coordinate]
+                    }
+                    int q = 0;
+#pragma unroll
+                    for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+                        for (int tj = ti; tj < T; ++tj, ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[ti], wb[tj], acc[q], 0, 0, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < T; ++t) wr[t] += 4 * wstep[t];
+            }
+            // what is left of a group whose points are no multiple of four: one point per product, the fourth inner index reads zeros
+            const bool on   = kk < 3;
+            const int ksel  = on ? kk : 0;
+            for (; g < gc; ++g, vq += 9)
+            {
+                const double* vt = on ? vq : s_zero;
+                const double vc0 = vt[0], vc1 = vt[1], vc2 = vt[2];
                 double ya[T], wb[T];
 #pragma unroll
                 for (int t = 0; t < T; ++t)
                 {
-                    const double* w = wr[t];
-                    ya[t] = w[0] * vc0 + w[1] * vc1 + w[2] * vc2;  // (W V^-1)[row][kk]
-                    wb[t] = w[ksel];                               // W[row][kk]
+                    const double* w = on ? wr[t] : s_zero;
+                    ya[t] = w[0] * vc0 + w[1] * vc1 + w[2] * vc2;
+                    wb[t] = w[ksel];
                     wr[t] += wstep[t];
                 }
                 int q = 0;
