@@ -53,6 +53,9 @@
 #ifndef SNK_BA_CAM_WAVES
 #define SNK_BA_CAM_WAVES 1
 #endif
+#ifndef SNK_SF_SKIP
+#define SNK_SF_SKIP 0  // timing experiments only (results are then meaningless): schur_fused without 1 = its matrix products, 2 = phase 2b, 4 = the linearisation, 8 = phase 2a
+#endif
 #ifndef SNK_BA_CAM_BUTTERFLY
 #define SNK_BA_CAM_BUTTERFLY 0
 #endif
@@ -1741,7 +1744,7 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
             double Xc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
             for (int k = 0; k < 9; ++k) N[k] = 0.0;
-            if (ob.act && !gt.is_out)
+            if (ob.act && !gt.is_out && !(SNK_SF_SKIP & 4))
             {
                 double R[9];
                 quat_to_R(gt.pose, R);
@@ -1807,7 +1810,7 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
             __builtin_amdgcn_wave_barrier();
 
             // ---- phase 2a: lane = (point of the group, term): the point's sums in observation order ----
-            for (int idx = lane; idx < gc * SF_NC; idx += 64)
+            for (int idx = lane; idx < (SNK_SF_SKIP & 8 ? 0 : gc * SF_NC); idx += 64)
             {
                 const int g = (idx * 205) >> 11, comp = idx - g * SF_NC;  // idx / 10 (idx < 160)
                 const double* q = s_con + g * run * SF_NC + comp;
@@ -1839,7 +1842,7 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
         if (more) load2(obn, gtn);
         // ---- phase 2b: lane = point of the group: damping, V^-1, the per-point outputs of point_wave ----
         const int p2 = pt_at(min(n0 + lane, si.n_pts - 1));  // outside the branch
-        if (lane < gc)
+        if (lane < gc && !(SNK_SF_SKIP & 2))
         {
             const int gp2 = pr.pt_off + p2;
             const bool pfree = s_pp[lane * 4 + 3] != 0.0;
@@ -1906,7 +1909,7 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
         }
 
         // ---- phase 3: (W V^-1) W^T of every point of the group on the matrix cores ----
-        if (si.nfree != 0)  // wave-uniform; a work item without pairs is linearisation only
+        if (si.nfree != 0 && !(SNK_SF_SKIP & 1))  // wave-uniform; a work item without pairs is linearisation only
         {
             const double* wr[T];
 #pragma unroll
