@@ -1810,13 +1810,37 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
             __builtin_amdgcn_wave_barrier();
 
             // ---- phase 2a: lane = (point of the group, term): the point's sums in observation order ----
-            for (int idx = lane; idx < (SNK_SF_SKIP & 8 ? 0 : gc * SF_NC); idx += 64)
+            // (a lane's items lane, lane + 64, lane + 128 of the gc * 10 <= 160 are summed side by side: the sums are chains of dependent
+            // LDS reads and additions, and the second / third pass over 16 lanes used to cost as much as the first over 64)
+            if (!(SNK_SF_SKIP & 8))
             {
-                const int g = (idx * 205) >> 11, comp = idx - g * SF_NC;  // idx / 10 (idx < 160)
-                const double* q = s_con + g * run * SF_NC + comp;
-                double sum = 0.0;
-                for (int a = 0; a < run; ++a) sum += q[a * SF_NC];
-                s_sum[idx] = sum;
+                const int n_items = gc * SF_NC;
+                const double* q[3];
+                bool has[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                {
+                    const int idx = min(lane + 64 * u, n_items - 1);
+                    const int g = (idx * 205) >> 11, comp = idx - g * SF_NC;  // idx / 10 (idx < 160)
+                    q[u]   = s_con + g * run * SF_NC + comp;
+                    has[u] = lane + 64 * u < n_items;
+                }
+                double sum[3] = {0.0, 0.0, 0.0};
+                if (n_items > 128)  // wave-uniform (more than 12 points per group: runs of <= 5)
+                    for (int a = 0; a < run; ++a)
+                    {
+#pragma unroll
+                        for (int u = 0; u < 3; ++u) sum[u] += q[u][a * SF_NC];
+                    }
+                else
+                    for (int a = 0; a < run; ++a)
+                    {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) sum[u] += q[u][a * SF_NC];
+                    }
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    if (has[u]) s_sum[lane + 64 * u] = sum[u];
             }
             __builtin_amdgcn_wave_barrier();
             // ---- camera sums, the 27 terms of J_c and r (the contribution buffer is free again; J_c dies here) ----
@@ -1983,7 +2007,17 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
         if (cs_k < 3) cp[24 + cs_k] = cs_acc[3];
         if (cs_k < 6) cp[27 + cs_k] = cs_acc[4];
     }
+    // The slot of every camera pair of the set, staged in LDS first (the contribution buffer is free): looked up in global memory
+    // element by element, each of the up to 24 + 8 stores below waited for its own dependent load -- and, the counter being shared, for
+    // the store before it -- a chain of ~28 memory round trips at the end of every wavefront (round 5: a quarter of a wavefront's life).
     const int* tab = A.set_pairs + si.aux_off + si.nfree;
+    int* s_tab     = reinterpret_cast<int*>(s_con);
+    {
+        const int n2 = si.nfree * si.nfree;  // nfree <= 10 (SET_MAX_K): at most two entries per lane
+        if (lane < n2) s_tab[lane] = tab[lane];
+        if (lane + 64 < n2) s_tab[lane + 64] = tab[lane + 64];
+    }
+    __builtin_amdgcn_wave_barrier();
     double* part   = A.s_part + (size_t)si.part_off * 36;
     int q = 0;
 #pragma unroll
@@ -1997,7 +2031,7 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
                 if (m >= nrows || n >= nrows) continue;
                 const int ia = (m * 43) >> 8, r = m - 6 * ia, ib = (n * 43) >> 8, c = n - 6 * ib;
                 if (ia > ib) continue;
-                const int slot = tab[ia * si.nfree + ib];
+                const int slot = s_tab[ia * si.nfree + ib];
                 const double v = acc[q][j];
                 part[(size_t)slot * 36 + r * 6 + c] = v;
                 if (ia == ib && ti != tj) part[(size_t)slot * 36 + c * 6 + r] = v;
