@@ -1038,6 +1038,17 @@ __device__ inline void cam_finish(const Arrays& A, const Prob& pr, int pb, int c
     for (int a = 0; a < 6; ++a) A.rhs[pr.vec_off + c * 6 + a] = tot[21 + a] - tot[27 + a];
 }
 
+// a wave-uniform double into scalar registers
+// (inline assembly: the builtin lets the compiler move the read in front of the arithmetic that produced the value and redo that
+// arithmetic -- there is no scalar fp64 unit -- in vector registers)
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    int lo, hi;
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(lo) : "v"(__double2loint(v)));
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(hi) : "v"(__double2hiint(v)));
+    return __hiloint2double(hi, lo);
+}
+
 // Column sums of 33 values per lane over the 64 lanes of a wavefront, "transpose and add": every step pairs the lanes, each lane keeps
 // one half of its values and hands the other half to its partner, so the number of live sums halves with the number of lanes that
 // share them -- 17 + 9 + 5 + 3 + 2 + 1 = 37 additions instead of the 33 x 6 of a butterfly that carries every sum through all six
@@ -1119,13 +1130,21 @@ __global__ __launch_bounds__(CAM_THREADS, SNK_BA_CAM_WAVES) void cam_pass(Arrays
     // of this camera and one 48-byte gather per observation (point position of the linearisation | V^-1 b_p) with the
     // same code that point_wave ran -- instead of being written there per observation (224 bytes) and gathered back
     // here in camera order, which made this pass and point_wave bound by HBM / texture-address traffic.
+    // The camera is the same for every lane: its rotation matrix and translation are kept in SCALAR registers (v_readfirstlane of the
+    // wave-uniform values; 24 of them) -- as vector registers they were 24 of the kernel's 182, which kept it at two wavefronts per SIMD.
     double R[9];
-    const double* pose = nullptr;
+    double pose[7] = {0, 0, 0, 1, 0, 0, 0};
     if (s1 > s0)
     {
-        pose = A.pose + (size_t)(pr.img_off + A.cs_obs[pr.citem_off + s0].img) * 7;
-        quat_to_R(pose, R);
+        const double* pg = A.pose + (size_t)(pr.img_off + A.cs_obs[pr.citem_off + s0].img) * 7;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) pose[k] = pg[k];
     }
+    quat_to_R(pose, R);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = uniform_f64(R[k]);
+#pragma unroll
+    for (int k = 4; k < 7; ++k) pose[k] = uniform_f64(pose[k]);
     // a thread runs ~3 observations: the record, the outlier flag and the 48-byte gather of the NEXT one are in flight
     // while the current one is linearised (record -> gather is a dependent pair of memory round trips)
     CamObs ob_n{};
