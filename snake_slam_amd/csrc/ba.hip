@@ -3455,13 +3455,22 @@ __global__ __launch_bounds__(ACC_THREADS) void accept_pass(Arrays A, int only_ma
     // fixed-order sums: contiguous chunk per thread, then the tree
     const int chunk = (pr.np + ACC_THREADS - 1) / ACC_THREADS;
     double c0 = 0.0, c1 = 0.0;
-    for (int k = 0; k < chunk; ++k)
+    for (int k0 = 0; k0 < chunk; k0 += 4)  // four loads of each array in flight, added in index order (one at a time: `chunk` dependent round trips)
     {
-        const int p = tid * chunk + k;
-        if (p < pr.np)
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
         {
-            c0 += A.cost_pt[pr.pt_off + p];
-            c1 += A.cost_pt_new[pr.pt_off + p];
+            const int p   = tid * chunk + k0 + u;
+            const bool ok = k0 + u < chunk && p < pr.np;
+            a[u]          = ok ? A.cost_pt[pr.pt_off + p] : 0.0;
+            b[u]          = ok ? A.cost_pt_new[pr.pt_off + p] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+        {
+            c0 += a[u];
+            c1 += b[u];
         }
     }
     double cost     = block_sum<ACC_THREADS>(c0, red, tid);
