@@ -2244,6 +2244,10 @@ __global__ __launch_bounds__(256, SNK_BA_UC_WAVES) void update_cost(Arrays A, Op
 }
 
 // S(c1, c2) = U(c1) [c1 == c2] - sum of the block's partial sums (fixed order) - relative-pose cross terms; lane = element.
+// A wavefront takes SUM_NB consecutive blocks of the window and walks their lists side by side (round 5: one block per wavefront was a
+// chain of three dependent memory round trips -- list bounds, list, partial sums -- for a handful of additions, 370 000 wavefronts per
+// launch of 1024 windows, half of them lower-triangle blocks that left at once).  The additions of a block keep the order of its list.
+constexpr int SUM_NB = 4;  // measured per 1024 windows: 1 block per wavefront 118 us, 4: 90 us, 8: 151 us (profiles/r05/r05Q_, r05R_)
 __global__ __launch_bounds__(256) void schur_sum(Arrays A, int nbx, int B)
 {
     int pb, bx;
@@ -2261,59 +2265,86 @@ __global__ __launch_bounds__(256) void schur_sum(Arrays A, int nbx, int B)
     if (pb >= B) return;
     const Prob pr  = A.prob[pb];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int blk  = bx * 4 + wave;
-    if (blk >= pr.nfc * pr.nfc) return;
-    const int c1 = blk / pr.nfc, c2 = blk - c1 * pr.nfc;
-    if (c2 < c1) return;
-    const int e0 = A.cblk_start[pr.cblk_off + blk], e1 = A.cblk_start[pr.cblk_off + blk + 1];
+    const int blk0 = (bx * 4 + wave) * SUM_NB;
+    const int nb   = pr.nfc * pr.nfc;
+    if (blk0 >= nb) return;
     const int el = lane < 36 ? lane : 0, r = el / 6, c = el - 6 * r;
-    // the list (one entry per lane) and then four partial sums at a time are in flight; the order of the adds is the list's
-    const int my_item = e0 + lane < e1 ? A.cblk_items[e0 + lane] : 0;
-    double acc = 0.0;
-    for (int k0 = 0; k0 < e1 - e0; k0 += 64)
+    int c1[SUM_NB], c2[SUM_NB], e0[SUM_NB], n[SUM_NB];
+    bool on[SUM_NB];
+    int nmax = 0;
+#pragma unroll
+    for (int i = 0; i < SUM_NB; ++i)
     {
-        const int chunk = min(64, e1 - e0 - k0);
-        const int items = k0 == 0 ? my_item : (e0 + k0 + lane < e1 ? A.cblk_items[e0 + k0 + lane] : 0);
-        for (int k = 0; k < chunk; k += 4)
+        const int blk = blk0 + i;
+        c1[i]         = blk / pr.nfc;
+        c2[i]         = blk - c1[i] * pr.nfc;
+        on[i]         = blk < nb && c2[i] >= c1[i];  // wave-uniform
+        const int bq  = on[i] ? blk : 0;
+        e0[i]         = A.cblk_start[pr.cblk_off + bq];
+        n[i]          = on[i] ? A.cblk_start[pr.cblk_off + bq + 1] - e0[i] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < SUM_NB; ++i) nmax = max(nmax, n[i]);
+    double acc[SUM_NB];
+#pragma unroll
+    for (int i = 0; i < SUM_NB; ++i) acc[i] = 0.0;
+    // the lists (one entry per lane) and then four partial sums per block at a time are in flight; the order of the adds is the list's
+    for (int k0 = 0; k0 < nmax; k0 += 64)
+    {
+        int items[SUM_NB];
+#pragma unroll
+        for (int i = 0; i < SUM_NB; ++i) items[i] = k0 + lane < n[i] ? A.cblk_items[e0[i] + k0 + lane] : 0;
+        const int cmax = min(64, nmax - k0);
+        for (int k = 0; k < cmax; k += 4)
         {
-            double v[4];
+            double v[SUM_NB][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-            {
-                const int idx = __builtin_amdgcn_readlane(items, min(k + u, chunk - 1));
-                v[u]          = A.s_part[(size_t)idx * 36 + el];
-            }
+            for (int i = 0; i < SUM_NB; ++i)
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (k + u < chunk) acc += v[u];
+                for (int u = 0; u < 4; ++u)
+                {
+                    const int idx = __builtin_amdgcn_readlane(items[i], min(k + u, 63));
+                    v[i][u]       = k0 + k + u < n[i] ? A.s_part[(size_t)idx * 36 + el] : 0.0;
+                }
+#pragma unroll
+            for (int i = 0; i < SUM_NB; ++i)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (k0 + k + u < n[i]) acc[i] += v[i][u];
         }
     }
-    double* S  = A.S + pr.s_off + (size_t)(c1 * 6) * pr.n6 + c2 * 6;
-    double* St = A.S + pr.s_off + (size_t)(c2 * 6) * pr.n6 + c1 * 6;
-    if (c1 == c2)
+#pragma unroll
+    for (int i = 0; i < SUM_NB; ++i)
     {
-        // symmetrise the diagonal block (Y W^T of one camera is symmetric up to rounding)
-        const double at = __shfl(acc, c * 6 + r);
-        const double v  = A.U[(size_t)(pr.cam_off + c1) * 36 + (r <= c ? r * 6 + c : c * 6 + r)] - 0.5 * (acc + at);
-        if (lane < 36) S[(size_t)r * pr.n6 + c] = v;
-    }
-    else
-    {
-        if (pr.n_rpc > 0)  // camera-camera terms J(c1)^T J(c2) of the relative pose constraints of this pair
+        if (!on[i]) continue;
+        double* S  = A.S + pr.s_off + (size_t)(c1[i] * 6) * pr.n6 + c2[i] * 6;
+        double* St = A.S + pr.s_off + (size_t)(c2[i] * 6) * pr.n6 + c1[i] * 6;
+        if (c1[i] == c2[i])
         {
-            int code = A.blk_rpc[pr.blkstart_off - pb + blk];
-            while (code != 0)
-            {
-                const int k = (code - 1) >> 1, tr = (code - 1) & 1;
-                const double* H = A.rpc_out + (size_t)(pr.rpc_off + k) * RPC_STRIDE + 35;
-                acc -= tr ? H[c * 6 + r] : H[r * 6 + c];
-                code = A.rpc_next[pr.rpc_off + k];
-            }
+            // symmetrise the diagonal block (Y W^T of one camera is symmetric up to rounding)
+            const double at = __shfl(acc[i], c * 6 + r);
+            const double v  = A.U[(size_t)(pr.cam_off + c1[i]) * 36 + (r <= c ? r * 6 + c : c * 6 + r)] - 0.5 * (acc[i] + at);
+            if (lane < 36) S[(size_t)r * pr.n6 + c] = v;
         }
-        if (lane < 36)
+        else
         {
-            S[(size_t)r * pr.n6 + c]  = -acc;
-            St[(size_t)c * pr.n6 + r] = -acc;
+            double a = acc[i];
+            if (pr.n_rpc > 0)  // camera-camera terms J(c1)^T J(c2) of the relative pose constraints of this pair
+            {
+                int code = A.blk_rpc[pr.blkstart_off - pb + blk0 + i];
+                while (code != 0)
+                {
+                    const int k = (code - 1) >> 1, tr = (code - 1) & 1;
+                    const double* H = A.rpc_out + (size_t)(pr.rpc_off + k) * RPC_STRIDE + 35;
+                    a -= tr ? H[c * 6 + r] : H[r * 6 + c];
+                    code = A.rpc_next[pr.rpc_off + k];
+                }
+            }
+            if (lane < 36)
+            {
+                S[(size_t)r * pr.n6 + c]  = -a;
+                St[(size_t)c * pr.n6 + r] = -a;
+            }
         }
     }
 }
@@ -5293,7 +5324,8 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L, bool only_marked =
             else
                 LAUNCH(cam_pass<256>, dim3(h->max_nfc, B), dim3(256), 0, A, O, 0, B);
             {
-                const int nbx = ceil_div(h->max_nfc * h->max_nfc, 4);
+                const int nbx = ceil_div(h->max_nfc * h->max_nfc, 4);  // schur_pass: a block per wavefront
+                const int nbs = ceil_div(h->max_nfc * h->max_nfc, 4 * SUM_NB);  // schur_sum: SUM_NB blocks per wavefront
                 if (use_set)
                 {
                     const bool q2 = h->set_run_max * 9 + 3 <= 2 * 64;
@@ -5310,7 +5342,7 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L, bool only_marked =
                         LAUNCH((schur_set<4, 2>), dim3(nsx * 8 * ceil_div(B, 8)), dim3(256), 0, A, nsx, B);
                     else
                         LAUNCH((schur_set<6, 3>), dim3(nsx * 8 * ceil_div(B, 8)), dim3(256), 0, A, nsx, B);
-                    LAUNCH(schur_sum, dim3(nbx * 8 * ceil_div(B, 8)), dim3(256), 0, A, nbx, B);
+                    LAUNCH(schur_sum, dim3(nbs * 8 * ceil_div(B, 8)), dim3(256), 0, A, nbs, B);
                 }
                 else
                 {
