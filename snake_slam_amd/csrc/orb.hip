@@ -126,6 +126,17 @@ struct LevelInfo
     const int* yw1;
 };
 
+// what fast_kernel reads of a level: the head of LevelInfo, taken with one 32-byte load
+struct LevelHead
+{
+    int w, h, pitch, pad_;
+    long long img_stride;
+    u8* base;
+};
+static_assert(sizeof(LevelHead) == 32 && offsetof(LevelInfo, w) == 0 && offsetof(LevelInfo, h) == 4 && offsetof(LevelInfo, pitch) == 8 &&
+                  offsetof(LevelInfo, img_stride) == 16 && offsetof(LevelInfo, base) == 24,
+              "LevelHead mirrors the first 32 bytes of LevelInfo");
+
 struct Layout
 {
     int n_levels;
@@ -454,9 +465,16 @@ __global__ __launch_bounds__(256, SNK_FAST_MIN_WAVES) void fast_kernel(Layout L,
     u32* list         = reinterpret_cast<u32*>(slice + L.f_off_list);
     const int TPD = NQ ? NQ * 4 : L.f_tile_pitch_dw, TP = TPD * 4, SP = NQ == 3 ? 40 : (NQ == 4 ? 64 : L.f_s_pitch);
 
-    const int4 ct = L.cell_tab[cid];
+    // The cell's entry by a SCALAR load (the index is wave-uniform; as a vector load it was an L2 round trip per cell in front of
+    // everything else), and the five fields of the level the cell needs -- w, h, pitch, img_stride, base: the first 32 bytes of
+    // LevelInfo -- by ONE scalar load (read field by field they were four dependent scalar-load round trips per cell).
+    int4 ct;
+    {
+        const int4* cp = L.cell_tab + cid;
+        asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ct) : "s"(cp) : "memory");
+    }
     const int l   = ct.w;
-    const LevelInfo& lv = L.lv[l];
+    const LevelHead lv = *reinterpret_cast<const LevelHead*>(&L.lv[l]);
     const int x0 = ct.x, y0 = ct.y;
     const int cw = (int)(short)(ct.z & 0xFFFF), ch = (int)(short)((unsigned)ct.z >> 16);
     const long long cell_index = (long long)b * L.total_cells + cid;
@@ -770,9 +788,16 @@ __global__ __launch_bounds__(256) void harris_kernel(Layout L, const u8* __restr
     const long long cell_index = (long long)b * L.total_cells + cid;
     const int cnt = min((int)cell_cnt[cell_index], CELL_SLOTS);
     if (lane >= cnt) return;
-    const int4 ct = L.cell_tab[cid];
+    // The cell's entry by a SCALAR load (the index is wave-uniform; as a vector load it was an L2 round trip per cell in front of
+    // everything else), and the five fields of the level the cell needs -- w, h, pitch, img_stride, base: the first 32 bytes of
+    // LevelInfo -- by ONE scalar load (read field by field they were four dependent scalar-load round trips per cell).
+    int4 ct;
+    {
+        const int4* cp = L.cell_tab + cid;
+        asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ct) : "s"(cp) : "memory");
+    }
     const int l   = ct.w;
-    const LevelInfo& lv = L.lv[l];
+    const LevelHead lv = *reinterpret_cast<const LevelHead*>(&L.lv[l]);
     const u32 k   = cand[cell_index * CELL_SLOTS + lane];
     const int x   = ct.x + 63 - (int)(k & 63u), y = ct.y + 63 - (int)((k >> 6) & 63u);
     const u8* src      = l == 0 ? img0 + (long long)b * stride0 : lv.base + (long long)b * lv.img_stride;
