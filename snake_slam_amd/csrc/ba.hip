@@ -117,11 +117,14 @@ struct RpcMeta
 constexpr int RPC_STRIDE = 72;
 
 // What cam_pass needs of an observation that never changes during a solve, stored in the order of the camera lists
-// so that a camera's workgroup streams it (48 bytes).
+// so that a camera's workgroup streams it: 40 bytes (round 5; 48 before: cam_pass and update_cost run at the speed their records
+// stream at, so the index fields are packed -- the point index and "the point is an unknown" share a word, the image is the
+// camera's and is looked up once per camera).
 struct CamObs
 {
     double u, v, depth, weight;
-    int pt, orig, img, ptfree;
+    int ptw;   // point index | "the point is an unknown" << 31
+    int orig;  // caller-order index (global)
 };
 
 // One wavefront's share of the point-major Schur pass: <= SET_CHUNK points that are all observed by the same cameras
@@ -145,11 +148,24 @@ constexpr int CS_TERMS = 33, CS_PASSES = 5;
 
 // Static part of an observation in the order schur_fused walks it (item, point of the item, observation of the point): a lane's
 // record is at rec_off + group * run + lane, so the first round of loads of a group is three coalesced 16-byte loads.
+// In memory 40 bytes (round 5; 48 before): image, free-camera index and the "unknown" flag share a word.  SET_MAX_IMG bounds the images of a
+// problem for which the packed form exists (snk_ba_set_problems refuses more).
+constexpr int SET_MAX_IMG = 32767;
 struct SetObs
 {
     double u, v, depth, weight;
-    int img, orig, cam, ptfree;  // image inside the problem, caller-order index (global), free-camera index or -1, point is an unknown
+    int orig;  // caller-order index (global)
+    int pk;    // image inside the problem (15 bits) | point is an unknown << 15 | (free-camera index + 1) << 16
 };
+struct SetRec  // the same in a lane's registers (the index word stays packed: two registers fewer per record set than four ints)
+{
+    double u, v, depth, weight;
+    int orig, pk;
+    __device__ __forceinline__ int img() const { return pk & 0x7FFF; }           // image inside the problem
+    __device__ __forceinline__ int cam() const { return (int)((unsigned)pk >> 16) - 1; }  // free-camera index or -1
+    __device__ __forceinline__ bool ptfree() const { return (pk & 0x8000) != 0; }  // the point is an unknown
+};
+__host__ __device__ inline int set_pack(int img, int cam, int ptfree) { return img | (ptfree ? 1 << 15 : 0) | ((cam + 1) << 16); }
 
 struct Arrays
 {
@@ -1136,7 +1152,8 @@ __global__ __launch_bounds__(CAM_THREADS, SNK_BA_CAM_WAVES) void cam_pass(Arrays
     double pose[7] = {0, 0, 0, 1, 0, 0, 0};
     if (s1 > s0)
     {
-        const double* pg = A.pose + (size_t)(pr.img_off + A.cs_obs[pr.citem_off + s0].img) * 7;
+        // the camera's image: that of its first observation (the packed records do not carry it)
+        const double* pg = A.pose + (size_t)(pr.img_off + A.o_img[pr.obs_off + A.cam_items[pr.citem_off + s0]]) * 7;
 #pragma unroll
         for (int k = 0; k < 7; ++k) pose[k] = pg[k];
     }
@@ -1154,7 +1171,7 @@ __global__ __launch_bounds__(CAM_THREADS, SNK_BA_CAM_WAVES) void cam_pass(Arrays
     {
         ob_n  = A.cs_obs[pr.citem_off + s];
         out_n = A.outlier[ob_n.orig];
-        const double2* pv = reinterpret_cast<const double2*>(A.ptv + (size_t)(pr.pt_off + ob_n.pt) * 6);
+        const double2* pv = reinterpret_cast<const double2*>(A.ptv + (size_t)(pr.pt_off + (ob_n.ptw & 0x7FFFFFFF)) * 6);
         const double2 a = pv[0], b = pv[1], c = pv[2];
         pv_n[0] = a.x; pv_n[1] = a.y; pv_n[2] = b.x; pv_n[3] = b.y; pv_n[4] = c.x; pv_n[5] = c.y;
     };
@@ -1210,7 +1227,7 @@ __global__ __launch_bounds__(CAM_THREADS, SNK_BA_CAM_WAVES) void cam_pass(Arrays
         acc[24] -= Y * mo.h2 - Z * mo.h1;
         acc[25] -= Z * mo.h0 - X * mo.h2;
         acc[26] -= X * mo.h1 - Y * mo.h0;
-        if (ob.ptfree)
+        if (ob.ptw < 0)  // the point is an unknown
         {
             // Y b_p = W V^-1 b_p = J_c^T (J_p (V^-1 b_p)) = [ f ; Xc x f ], f = M (R v)
             const double e0 = R[0] * vb[0] + R[1] * vb[1] + R[2] * vb[2];
@@ -1592,9 +1609,11 @@ __global__ __launch_bounds__(256) void schur_mfma(Arrays A, int nbx, int B)
 // come as work items without pairs.  Observation inputs are read once (48 bytes + cached point / pose gathers).
 constexpr int SF_GMAX = 16;  // points linearised at a time (64 / run, at most this many: bounds the per-point LDS arrays)
 constexpr int SF_NC   = 10;  // per-observation contributions summed per point: V (6), b_p (3), cost
+typedef unsigned int u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+typedef unsigned int u32x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 struct SfObs  // first round of loads of a lane: its static observation record and its point (both known without a lookup)
 {
-    SetObs rec;
+    SetRec rec;
     double pt[3];
     bool act;
 };
@@ -1725,8 +1744,9 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
         o.act        = lg < gc;
         // 32-bit offsets from uniform bases: one address instruction per load
         const unsigned ri = min((unsigned)(n0 * run + lane), n_rec - 1u);
-        const uint4* rp   = reinterpret_cast<const uint4*>(rec_base + ri * 48u);
-        const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+        const char* rp = rec_base + ri * 40u;  // 40-byte records: 8-byte aligned
+        const u32x4_a8 r0 = *reinterpret_cast<const u32x4_a8*>(rp), r1 = *reinterpret_cast<const u32x4_a8*>(rp + 16);
+        const u32x2_a8 r2 = *reinterpret_cast<const u32x2_a8*>(rp + 32);
         const int px   = pt_at(n0 + (o.act ? lg : 0));
         const double* ptp = reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.pt) + (unsigned)(pr.pt_off + px) * 24u);
         o.pt[0] = ptp[0]; o.pt[1] = ptp[1]; o.pt[2] = ptp[2];
@@ -1734,11 +1754,11 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
         o.rec.v      = __hiloint2double((int)r0.w, (int)r0.z);
         o.rec.depth  = __hiloint2double((int)r1.y, (int)r1.x);
         o.rec.weight = __hiloint2double((int)r1.w, (int)r1.z);
-        o.rec.img = (int)r2.x; o.rec.orig = (int)r2.y; o.rec.cam = (int)r2.z; o.rec.ptfree = (int)r2.w;
+        o.rec.orig = (int)r2.x; o.rec.pk = (int)r2.y;
     };
     auto load2 = [&](const SfObs& o, SfGather& g)
     {
-        const double* posep = reinterpret_cast<const double*>(reinterpret_cast<const char*>(poses) + (unsigned)o.rec.img * 56u);
+        const double* posep = reinterpret_cast<const double*>(reinterpret_cast<const char*>(poses) + (unsigned)o.rec.img() * 56u);
 #pragma unroll
         for (int k = 0; k < 7; ++k) g.pose[k] = posep[k];
         g.is_out = A.outlier[(unsigned)o.rec.orig] != 0;
@@ -1777,7 +1797,7 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
                     ObsMoments mo;
                     obs_moments(oc, r, sw * sw, mo);
                     sw_obs = sw;
-                    if (ob.rec.ptfree)
+                    if (ob.rec.ptfree())
                     {
 #pragma unroll
                         for (int j = 0; j < 3; ++j)
@@ -1795,7 +1815,7 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
                         con[5] = R[2] * N[2] + R[5] * N[5] + R[8] * N[8];
 #pragma unroll
                         for (int b = 0; b < 3; ++b) con[6 + b] = -(R[b] * mo.h0 + R[3 + b] * mo.h1 + R[6 + b] * mo.h2);
-                        cpl   = ob.rec.cam >= 0;
+                        cpl   = ob.rec.cam() >= 0;
                         Xc[0] = oc.X; Xc[1] = oc.Y; Xc[2] = oc.Z;
                     }
                 }
@@ -1809,7 +1829,7 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
                 s_pp[lg * 4 + 0] = ob.pt[0];
                 s_pp[lg * 4 + 1] = ob.pt[1];
                 s_pp[lg * 4 + 2] = ob.pt[2];
-                s_pp[lg * 4 + 3] = ob.rec.ptfree ? 1.0 : 0.0;
+                s_pp[lg * 4 + 3] = ob.rec.ptfree() ? 1.0 : 0.0;
             }
             if (si.nfree != 0)
             {
@@ -2109,8 +2129,9 @@ __global__ __launch_bounds__(256, SNK_BA_UC_WAVES) void update_cost(Arrays A, Op
         const int gc = min(G, si.n_pts - n0);
         o.act        = lg < gc;
         const unsigned ri = min((unsigned)(n0 * run + lane), n_rec - 1u);
-        const uint4* rp   = reinterpret_cast<const uint4*>(rec_base + ri * 48u);
-        const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+        const char* rp = rec_base + ri * 40u;  // 40-byte records: 8-byte aligned
+        const u32x4_a8 r0 = *reinterpret_cast<const u32x4_a8*>(rp), r1 = *reinterpret_cast<const u32x4_a8*>(rp + 16);
+        const u32x2_a8 r2 = *reinterpret_cast<const u32x2_a8*>(rp + 32);
         const int px   = pt_at(n0 + (o.act ? lg : 0));
         const double* ptp = reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.pt) + (unsigned)(pr.pt_off + px) * 24u);
         o.pt[0] = ptp[0]; o.pt[1] = ptp[1]; o.pt[2] = ptp[2];
@@ -2118,7 +2139,7 @@ __global__ __launch_bounds__(256, SNK_BA_UC_WAVES) void update_cost(Arrays A, Op
         o.rec.v      = __hiloint2double((int)r0.w, (int)r0.z);
         o.rec.depth  = __hiloint2double((int)r1.y, (int)r1.x);
         o.rec.weight = __hiloint2double((int)r1.w, (int)r1.z);
-        o.rec.img = (int)r2.x; o.rec.orig = (int)r2.y; o.rec.cam = (int)r2.z; o.rec.ptfree = (int)r2.w;
+        o.rec.orig = (int)r2.x; o.rec.pk = (int)r2.y;
     };
     SfObs ob;
     load1(0, ob);
@@ -2130,13 +2151,13 @@ __global__ __launch_bounds__(256, SNK_BA_UC_WAVES) void update_cost(Arrays A, Op
         // first round for the next one
         double pose[7], posen[7], xv[6];
         {
-            const double* posep = reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.pose) + (unsigned)(pr.img_off + ob.rec.img) * 56u);
-            const double* posnp = reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.pose_new) + (unsigned)(pr.img_off + ob.rec.img) * 56u);
+            const double* posep = reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.pose) + (unsigned)(pr.img_off + ob.rec.img()) * 56u);
+            const double* posnp = reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.pose_new) + (unsigned)(pr.img_off + ob.rec.img()) * 56u);
 #pragma unroll
             for (int k = 0; k < 7; ++k) pose[k] = posep[k];
 #pragma unroll
             for (int k = 0; k < 7; ++k) posen[k] = posnp[k];
-            const double* xc = x + (ob.rec.cam < 0 ? 0 : ob.rec.cam) * 6;
+            const double* xc = x + (ob.rec.cam() < 0 ? 0 : ob.rec.cam()) * 6;
 #pragma unroll
             for (int a = 0; a < 6; ++a) xv[a] = xc[a];
         }
@@ -2164,7 +2185,7 @@ __global__ __launch_bounds__(256, SNK_BA_UC_WAVES) void update_cost(Arrays A, Op
 
         // ---- lane = observation: t = J_p^T (J_c dc) (update_wave) ----
         double t[3] = {0, 0, 0};
-        if (ob.act && !(is_out || ob.rec.cam < 0 || !ob.rec.ptfree))
+        if (ob.act && !(is_out || ob.rec.cam() < 0 || !ob.rec.ptfree()))
         {
             double R[9], r[3];
             quat_to_R(pose, R);
@@ -3707,7 +3728,7 @@ __global__ __launch_bounds__(256) void gather_cam_records(Arrays A, CamObs* __re
     const double2 uv = A.o_uv[go];
     CamObs rec;
     rec.u = uv.x; rec.v = uv.y; rec.depth = A.o_depth[go]; rec.weight = A.o_weight[go];
-    rec.pt = A.o_pt[go]; rec.orig = A.o_orig[go]; rec.img = A.o_img[go]; rec.ptfree = A.o_ptfree[go];
+    rec.ptw = A.o_pt[go] | (A.o_ptfree[go] ? (int)0x80000000u : 0); rec.orig = A.o_orig[go];
     out[pr.citem_off + k] = rec;
 }
 
@@ -3727,7 +3748,7 @@ __global__ __launch_bounds__(256) void gather_set_records(Arrays A, SetObs* __re
         const double2 uv = A.o_uv[go];
         SetObs rec;
         rec.u = uv.x; rec.v = uv.y; rec.depth = A.o_depth[go]; rec.weight = A.o_weight[go];
-        rec.img = A.o_img[go]; rec.orig = A.o_orig[go]; rec.cam = A.o_cam[go]; rec.ptfree = A.o_ptfree[go];
+        rec.orig = A.o_orig[go]; rec.pk = set_pack(A.o_img[go], A.o_cam[go], A.o_ptfree[go]);
         out[(size_t)si.rec_off + idx] = rec;
     }
 }
@@ -4037,6 +4058,8 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
 {
     SNK_REQUIRE(h != nullptr, "ba is NULL");
     SNK_REQUIRE(count >= 1 && count <= 65535 && problems != nullptr, "count must be 1..65535");
+    for (int b = 0; b < count; ++b)  // the packed observation records hold the image index in 15 bits (SetObs)
+        SNK_REQUIRE(problems[b].n_img <= SET_MAX_IMG, "a problem has more than 32767 images");
     SNK_HIP_CHECK(hipSetDevice(h->device));
     SNK_HIP_CHECK(hipStreamSynchronize(h->stream));
     h->drop_graphs();
@@ -5143,8 +5166,8 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                 const int s = camitems[(size_t)pr.citem_off + (size_t)k], o = oorig[(size_t)pr.obs_off + (size_t)s] - pr.orig_off;
                 const CamObs& r = d_rec[(size_t)pr.citem_off + (size_t)k];
                 const bool same = r.u == P.obs_uv[o][0] && r.v == P.obs_uv[o][1] && r.depth == P.obs_depth[o] && r.weight == P.obs_weight[o] &&
-                                  r.pt == P.obs_pt[o] && r.orig == pr.orig_off + o && r.img == P.obs_img[o] &&
-                                  r.ptfree == (P.pt_const[P.obs_pt[o]] ? 0 : 1);
+                                  (r.ptw & 0x7FFFFFFF) == P.obs_pt[o] && r.orig == pr.orig_off + o &&
+                                  (r.ptw < 0 ? 1 : 0) == (P.pt_const[P.obs_pt[o]] ? 0 : 1);
                 SNK_REQUIRE(same, "SNK_BA_CHECK_LISTS: a device-gathered camera record differs from the caller's observation");
             }
         }
@@ -5166,8 +5189,8 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                             const int s = pp.y + a, o = oorig[(size_t)pr.obs_off + (size_t)s] - pr.orig_off;
                             const SetObs& r = d_sr[(size_t)si.rec_off + (size_t)q * si.run + (size_t)a];
                             const bool same = r.u == P.obs_uv[o][0] && r.v == P.obs_uv[o][1] && r.depth == P.obs_depth[o] &&
-                                              r.weight == P.obs_weight[o] && r.img == P.obs_img[o] && r.orig == pr.orig_off + o &&
-                                              r.cam == ocam[(size_t)pr.obs_off + (size_t)s] && r.ptfree == (P.pt_const[pp.x] ? 0 : 1) &&
+                                              r.weight == P.obs_weight[o] && r.orig == pr.orig_off + o &&
+                                              r.pk == set_pack(P.obs_img[o], ocam[(size_t)pr.obs_off + (size_t)s], P.pt_const[pp.x] ? 0 : 1) &&
                                               P.obs_pt[o] == pp.x;
                             SNK_REQUIRE(same, "SNK_BA_CHECK_LISTS: a device-gathered work-item record differs from the caller's observation");
                         }
