@@ -766,7 +766,8 @@ SNK_API int snk_ba_sync(snk_ba* h);
 
 /* Replaces BARecRel::create(scene) — LocalBundleAdjustment.cpp:359: analyse the structure, copy
  * the problem to the device.  set_problems loads `count` independent windows that are solved side
- * by side (one launch sequence for all).  The arrays are copied; they need not stay alive. */
+ * by side (one launch sequence for all).  The arrays are copied; they need not stay alive.
+ * Limits: count <= 65535; n_img <= 32767 per problem (SNK_ERR_INVALID_ARG beyond). */
 SNK_API int snk_ba_set_problem(snk_ba* h, const snk_ba_problem* problem);
 SNK_API int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count);
 
