@@ -1617,9 +1617,8 @@ struct SfObs  // first round of loads of a lane: its static observation record a
     double pt[3];
     bool act;
 };
-struct SfGather  // second round: through the record's indices
+struct SfGather  // second round: through the record's indices (the camera of a lane is loop-invariant, see schur_fused)
 {
-    double pose[7];
     bool is_out;
 };
 // CS (camera sums, T == 3 only): the wavefront also emits what cam_pass computes -- per free camera b_c = -sum J_c^T r,
@@ -1756,13 +1755,22 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
         o.rec.weight = __hiloint2double((int)r1.w, (int)r1.z);
         o.rec.orig = (int)r2.x; o.rec.pk = (int)r2.y;
     };
-    auto load2 = [&](const SfObs& o, SfGather& g)
+    // Second round (through the record's indices): the outlier flag of every observation -- and the camera.  All points of a work item
+    // see the same FREE cameras in the same run positions and lane -> (point of the group, position) is the same in every group, so a
+    // lane's camera is loop-invariant unless its position holds a constant camera that differs from point to point: its rotation matrix
+    // and translation are formed ONCE in front of the loop (camR) and again only by the lanes whose image changes (a dependent round
+    // trip then, at the end of a group) -- instead of seven gathered loads and a quaternion -> matrix conversion per observation and group.
+    double camR[9], camT[7] = {0, 0, 0, 1, 0, 0, 0};  // camT[4..6] = the translation (obs_core reads pose[4..6])
+    auto load_cam = [&](int img)
     {
-        const double* posep = reinterpret_cast<const double*>(reinterpret_cast<const char*>(poses) + (unsigned)o.rec.img() * 56u);
+        const double* posep = reinterpret_cast<const double*>(reinterpret_cast<const char*>(poses) + (unsigned)img * 56u);
+        double q[7];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) g.pose[k] = posep[k];
-        g.is_out = A.outlier[(unsigned)o.rec.orig] != 0;
+        for (int k = 0; k < 7; ++k) q[k] = posep[k];
+        quat_to_R(q, camR);
+        camT[4] = q[4]; camT[5] = q[5]; camT[6] = q[6];
     };
+    auto load2 = [&](const SfObs& o, SfGather& g) { g.is_out = A.outlier[(unsigned)o.rec.orig] != 0; };
     // one group: `ob` / `gt` are its inputs (already loaded), `obn` / `gtn` receive the next group's
     auto process = [&](int n0, const SfObs& ob, const SfGather& gt, SfObs& obn, SfGather& gtn)
     {
@@ -1785,9 +1793,8 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
             for (int k = 0; k < 9; ++k) N[k] = 0.0;
             if (ob.act && !gt.is_out && !(SNK_SF_SKIP & 4))
             {
-                double R[9];
-                quat_to_R(gt.pose, R);
-                const int dim = obs_core(gt.pose, R, ob.pt, pr.K, pr.bf, ob.rec.u, ob.rec.v, ob.rec.depth, ob.rec.weight, r, oc);
+                const double* R = camR;
+                const int dim = obs_core(camT, R, ob.pt, pr.K, pr.bf, ob.rec.u, ob.rec.v, ob.rec.depth, ob.rec.weight, r, oc);
                 lin           = dim != 0;
                 if (dim)
                 {
@@ -2026,11 +2033,14 @@ __global__ __launch_bounds__(256) void schur_fused(Arrays A, Opt O, int nbx, int
             }
         }
         __builtin_amdgcn_wave_barrier();
+        // a lane whose position holds another image in the next group (constant cameras only) forms that camera's matrix now
+        if (more && obn.act && obn.rec.img() != ob.rec.img()) load_cam(obn.rec.img());  // (lanes active in a group were active in every group before it)
     };
     // two register sets, used alternately: no copies between the groups
     SfObs oa, obb;
     SfGather ga, gb;
     load1(0, oa);
+    load_cam(oa.rec.img());
     load2(oa, ga);
     for (int n0 = 0; n0 < si.n_pts; n0 += 2 * G)
     {
