@@ -387,6 +387,21 @@ SNK_API int snk_frontend_submit(snk_frontend* f, const uint8_t* left, int pitch_
                                 int width, int height);
 SNK_API int snk_frontend_collect(snk_frontend* f, snk_frontend_frame* out, int timeout_ms);
 SNK_API int snk_frontend_in_flight(snk_frontend* f, int* n);
+/* Waits (like snk_frontend_collect: timeout_ms < 0 / 0 / > 0, SNK_ERR_TIMEOUT) until a submitted frame EXISTS -- not until it is
+ * finished -- and reports the image size it was submitted with and the capacity its arrays need; the frame stays queued.  This is
+ * how a collecting thread sizes its arrays without looking at what the submitting thread is doing (any pointer may be NULL). */
+SNK_API int snk_frontend_peek(snk_frontend* f, int timeout_ms, int* width, int* height, int* capacity);
+/* snk_frontend_submit without the host-side staging copy (about half of a submit's host time): the upload reads the CALLER's
+ * buffers, which must be page-locked (snk_pinned_alloc, hipHostMalloc, hipHostRegister) for the copy to be asynchronous and must
+ * stay valid and unmodified until the frame has been collected -- the reference's Input thread owns its image buffers the same
+ * way (Snake/Preprocess/Input.h:48, FeatureDetector.h:39).  Rows keep the caller's pitch on the device when pitch_left is a
+ * multiple of 4, equals pitch_right and does not exceed the width rounded up to 64 (one copy when right == left + pitch * height,
+ * two otherwise); other pitches go through a 2-D copy per image.  Results are bit for bit those of snk_frontend_submit. */
+SNK_API int snk_frontend_submit_pinned(snk_frontend* f, const uint8_t* left, int pitch_left, const uint8_t* right, int pitch_right,
+                                       int width, int height);
+/* Page-locked host memory for the images of snk_frontend_submit_pinned (hipHostMalloc / hipHostFree), for callers that do not link HIP. */
+SNK_API int snk_pinned_alloc(size_t bytes, void** out);
+SNK_API int snk_pinned_free(void* p);
 
 /* The per-frame data the tracking matchers read (Snake/Map/Features.h:18-41, Frame.h:44-46), in
  * feature-grid order.  taken[i] != 0 <=> frame.mvpMapPoints[i] != nullptr. */
@@ -821,8 +836,10 @@ typedef struct snk_dist snk_dist;
 SNK_API int snk_dist_get_unique_id(uint8_t id[SNK_DIST_ID_BYTES]);
 /* Collective over all `world` ranks (ncclCommInitRank): rank r runs on HIP device `device`.  Returns when every rank has called. */
 SNK_API int snk_dist_init(const uint8_t id[SNK_DIST_ID_BYTES], int rank, int world, int device, snk_dist** out);
-/* The same with the id passed through a file all ranks can see: rank 0 writes `path` (atomically), the others wait up to
- * timeout_s seconds (<= 0: 60) for it.  A fresh path per job. */
+/* The same with the id passed through a file all ranks can see: rank 0 removes whatever an earlier job left at `path`, writes
+ * the id (atomically: `path`.tmp + rename), the others wait up to timeout_s seconds (<= 0: 60) for it.  Rank 0 removes the file
+ * again in snk_dist_destroy and when its init fails.  Use a fresh path per job, or start rank 0 first: a rank that reads a
+ * stale file before rank 0 has removed it joins a dead communicator. */
 SNK_API int snk_dist_init_file(const char* path, int rank, int world, int device, double timeout_s, snk_dist** out);
 SNK_API int snk_dist_destroy(snk_dist* d);
 SNK_API int snk_dist_rank(const snk_dist* d, int* rank, int* world);

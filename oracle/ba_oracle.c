@@ -294,6 +294,54 @@ static double clampd(double v)
 }
 
 /* Runs `iterations` LM iterations in place on P->pose / P->pt.  Returns 0, fills costs. */
+/* ---- the summation-order control (round 6; tests/test_oracle_ba.py, tools/ba_truncation_control.py) ------------------------------
+ * The BA parity rule (tests/ba_parity.py) excuses scenes whose PCG stops at the reference's iteration limit
+ * (LocalBundleAdjustment.cpp:47-64, maxIterativeIterations = 30) on the ground that a truncated Krylov iterate depends on the order
+ * of the floating-point sums.  This switch lets the ORACLE be run against a re-ordered copy of ITSELF: the same algorithm, the same
+ * operations, only the order in which sums are accumulated changes --
+ *   0  the order of the restatement (default; what every parity test uses)
+ *   1  reversed: observations visited last to first (U, V, right-hand sides), points last to first in the Schur complement, every
+ *      dot product and matrix-vector row of the PCG accumulated from the last element to the first
+ *   2  pairwise: dot products and matrix-vector rows of the PCG by recursive halving (the order of a parallel tree reduction), the
+ *      Schur complement over even points then odd points
+ * Not thread-safe (one process-wide switch): test infrastructure. */
+static int g_sum_order = 0;
+void orc_ba_set_sum_order(int mode) { g_sum_order = mode; }
+
+static double dot_pairwise(const double* a, const double* b, int n)
+{
+    if (n <= 4)
+    {
+        double s = 0;
+        for (int k = 0; k < n; ++k) s += a[k] * b[k];
+        return s;
+    }
+    const int h = n / 2;
+    return dot_pairwise(a, b, h) + dot_pairwise(a + h, b + h, n - h);
+}
+static double dot_ord(const double* a, const double* b, int n)
+{
+    double s = 0;
+    if (g_sum_order == 1)
+        for (int k = n - 1; k >= 0; --k) s += a[k] * b[k];
+    else if (g_sum_order == 2)
+        return dot_pairwise(a, b, n);
+    else
+        for (int k = 0; k < n; ++k) s += a[k] * b[k];
+    return s;
+}
+/* visit order of n items: position k -> item */
+static int visit(int k, int n)
+{
+    if (g_sum_order == 1) return n - 1 - k;
+    if (g_sum_order == 2)
+    {
+        const int ne = (n + 1) / 2; /* even items first, then the odd ones */
+        return k < ne ? 2 * k : 2 * (k - ne) + 1;
+    }
+    return k;
+}
+
 int orc_ba_solve(orc_ba_problem* P, const orc_ba_options* O, int iterations, double* cost_initial, double* cost_final,
                  int* pcg_iterations_total)
 {
@@ -334,8 +382,9 @@ int orc_ba_solve(orc_ba_problem* P, const orc_ba_options* O, int iterations, dou
         memset(bp, 0, sizeof(double) * (size_t)np * 3);
         memset(used, 0, (size_t)no);
         /* 1. linearise */
-        for (int o = 0; o < no; ++o)
+        for (int ov = 0; ov < no; ++ov)
         {
+            const int o = g_sum_order == 1 ? no - 1 - ov : ov; /* control: the order U, V, bc, bp are accumulated in */
             const int i = P->obs_img[o], p = P->obs_pt[o];
             if (i < 0 || p < 0 || i >= P->n_img || p >= P->n_pt) continue;
             if (P->obs_outlier && P->obs_outlier[o]) continue;
@@ -470,8 +519,9 @@ int orc_ba_solve(orc_ba_problem* P, const orc_ba_options* O, int iterations, dou
             memcpy(fill, start, sizeof(int) * (size_t)(np + 1));
             for (int o = 0; o < no; ++o)
                 if (used[o]) items[fill[P->obs_pt[o]]++] = o;
-            for (int p = 0; p < np; ++p)
+            for (int pv = 0; pv < np; ++pv)
             {
+                const int p = visit(pv, np); /* control: the order the points' terms are subtracted from S and rhs in */
                 const double* vi = Vi + p * 9;
                 for (int a1 = start[p]; a1 < start[p + 1]; ++a1)
                 {
@@ -513,6 +563,7 @@ int orc_ba_solve(orc_ba_problem* P, const orc_ba_options* O, int iterations, dou
                 rr[k] = rhs[k];
                 bnorm2 += rhs[k] * rhs[k];
             }
+            if (g_sum_order) bnorm2 = dot_ord(rhs, rhs, n6);
             double rz = 0;
             for (int c = 0; c < nfc; ++c)
                 for (int a = 0; a < 6; ++a)
@@ -523,20 +574,28 @@ int orc_ba_solve(orc_ba_problem* P, const orc_ba_options* O, int iterations, dou
                     pp[c * 6 + a] = s2;
                     rz += rr[c * 6 + a] * s2;
                 }
+            if (g_sum_order) rz = dot_ord(rr, zz, n6);
             const double stop2 = O->pcg_tol * O->pcg_tol * bnorm2;
             for (int k = 0; k < O->max_pcg_iterations && n6 > 0; ++k)
             {
                 double rn2 = 0;
-                for (int q = 0; q < n6; ++q) rn2 += rr[q] * rr[q];
+                if (g_sum_order)
+                    rn2 = dot_ord(rr, rr, n6);
+                else
+                    for (int q = 0; q < n6; ++q) rn2 += rr[q] * rr[q];
                 if (rn2 <= stop2) break;
                 double pAp = 0;
                 for (int q = 0; q < n6; ++q)
                 {
                     double s2 = 0;
-                    for (int t = 0; t < n6; ++t) s2 += S[(size_t)q * n6 + t] * pp[t];
+                    if (g_sum_order)
+                        s2 = dot_ord(S + (size_t)q * n6, pp, n6);
+                    else
+                        for (int t = 0; t < n6; ++t) s2 += S[(size_t)q * n6 + t] * pp[t];
                     Ap[q] = s2;
                     pAp += pp[q] * s2;
                 }
+                if (g_sum_order) pAp = dot_ord(pp, Ap, n6);
                 if (pAp <= 0.0) break;
                 const double alpha = rz / pAp;
                 for (int q = 0; q < n6; ++q)
@@ -553,6 +612,7 @@ int orc_ba_solve(orc_ba_problem* P, const orc_ba_options* O, int iterations, dou
                         zz[c * 6 + a] = s2;
                         rz_new += rr[c * 6 + a] * s2;
                     }
+                if (g_sum_order) rz_new = dot_ord(rr, zz, n6);
                 const double beta = rz_new / rz;
                 rz = rz_new;
                 for (int q = 0; q < n6; ++q) pp[q] = zz[q] + beta * pp[q];

@@ -352,13 +352,19 @@ def ba_chi2(scene, outlier=None) -> np.ndarray:
     return out
 
 
-def ba_solve(scene, options: BaOptions = None, iterations=None, outlier=None):
-    """Returns (pose, pt, cost_initial, cost_final, pcg_iterations)."""
+def ba_solve(scene, options: BaOptions = None, iterations=None, outlier=None, sum_order: int = 0):
+    """Returns (pose, pt, cost_initial, cost_final, pcg_iterations).  sum_order != 0: the oracle with its floating-point sums
+    accumulated in another order (1 reversed, 2 pairwise; ba_oracle.c orc_ba_set_sum_order) -- the control of the truncated-PCG
+    rule in tests/ba_parity.py, never used by a parity comparison."""
     options = options or ba_options()
     P, a = _ba_pack(scene, outlier)
     ci, cf, it = C.c_double(), C.c_double(), C.c_int()
-    lib().orc_ba_solve(C.byref(P), C.byref(options), C.c_int(options.max_iterations if iterations is None else iterations),
-                       C.byref(ci), C.byref(cf), C.byref(it))
+    lib().orc_ba_set_sum_order(C.c_int(int(sum_order)))
+    try:
+        lib().orc_ba_solve(C.byref(P), C.byref(options), C.c_int(options.max_iterations if iterations is None else iterations),
+                           C.byref(ci), C.byref(cf), C.byref(it))
+    finally:
+        lib().orc_ba_set_sum_order(C.c_int(0))
     return a["pose"], a["pt"], ci.value, cf.value, it.value
 
 

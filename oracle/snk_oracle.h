@@ -151,6 +151,9 @@ typedef struct orc_ba_problem
 void orc_se3_update(const double* pose, const double* d, double* out);
 int orc_ba_rpc_linearize(const double* pose1, const double* pose2, const orc_ba_rpc* c, double* r, double* J1);
 void orc_ba_chi2(const orc_ba_problem* P, double* chi2);
+/* 0 = the restatement's summation order (default), 1 = reversed, 2 = pairwise: the oracle against a re-ordered copy of itself
+ * (the control behind the truncated-PCG rule of tests/ba_parity.py); process-wide, test infrastructure */
+void orc_ba_set_sum_order(int mode);
 int orc_ba_solve(orc_ba_problem* P, const orc_ba_options* O, int iterations, double* cost_initial, double* cost_final,
                  int* pcg_iterations_total);
 

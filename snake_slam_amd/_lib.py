@@ -81,6 +81,10 @@ SIGNATURES = {
     "snk_frontend_submit": (i32, [vp, vp, i32, vp, i32, i32, i32]),
     "snk_frontend_collect": (i32, [vp, vp, i32]),
     "snk_frontend_in_flight": (i32, [vp, C.POINTER(i32)]),
+    "snk_frontend_peek": (i32, [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+    "snk_frontend_submit_pinned": (i32, [vp, vp, i32, vp, i32, i32, i32]),
+    "snk_pinned_alloc": (i32, [C.c_size_t, C.POINTER(vp)]),
+    "snk_pinned_free": (i32, [vp]),
     "snk_orb_create": (i32, [vp, i32, vp, C.POINTER(vp)]),
     "snk_orb_destroy": (i32, [vp]),
     "snk_orb_sync": (i32, [vp]),

@@ -175,7 +175,11 @@ struct FrontendResult
 class Frontend
 {
    public:
-    Frontend(const snk_frontend_params& p, int device = 0) : p_(p) { check(snk_frontend_create(&p, device, &h_), "snk_frontend_create"); }
+    Frontend(const snk_frontend_params& p, int device = 0) : p_(p)
+    {
+        check(snk_frontend_create(&p, device, &h_), "snk_frontend_create");
+        check(snk_frontend_grid_dims(h_, &cols_, &rows_), "snk_frontend_grid_dims");  // constants of the handle (the bounds / 20 px)
+    }
     ~Frontend() { snk_frontend_destroy(h_); }
     Frontend(const Frontend&)            = delete;
     Frontend& operator=(const Frontend&) = delete;
@@ -189,16 +193,24 @@ class Frontend
     }
     // The pipelined form: Submit returns as soon as the frame is enqueued (it blocks only while `depth` frames are uncollected, like
     // SynchronizedSlot::set of FeatureDetector::output_buffer, Snake/Preprocess/FeatureDetector.h:39); Collect hands out the oldest
-    // frame, bit for bit what Process returns (SynchronizedSlot::get).  One thread may Submit while another Collects.
+    // frame, bit for bit what Process returns (SynchronizedSlot::get).  One thread may Submit while another Collects: the two share
+    // nothing in this object (Collect sizes its arrays from what the C layer reports for the frame it is about to receive).
     void SetDepth(int depth) { check(snk_frontend_set_depth(h_, depth), "snk_frontend_set_depth"); }
     void Submit(const uint8_t* left, int pitch_left, const uint8_t* right, int pitch_right, int width, int height)
     {
         check(snk_frontend_submit(h_, left, pitch_left, right, pitch_right, width, height), "snk_frontend_submit");
-        width_ = width, height_ = height;
+    }
+    // the images are page-locked memory of the caller (PinnedImage below) that stays untouched until the frame has been collected:
+    // no staging copy (Snake/Preprocess/Input.h:48 -- the Input thread owns its image buffers)
+    void SubmitPinned(const uint8_t* left, int pitch_left, const uint8_t* right, int pitch_right, int width, int height)
+    {
+        check(snk_frontend_submit_pinned(h_, left, pitch_left, right, pitch_right, width, height), "snk_frontend_submit_pinned");
     }
     int Collect(FrontendResult& r, int timeout_ms = -1)
     {
-        snk_frontend_frame f = bind(width_, height_, r);
+        int cap = 0;
+        check(snk_frontend_peek(h_, timeout_ms, nullptr, nullptr, &cap), "snk_frontend_peek");  // blocks until a frame has been submitted
+        snk_frontend_frame f = bind_capacity(cap, r);
         check(snk_frontend_collect(h_, &f, timeout_ms), "snk_frontend_collect");
         return finish(f, r);
     }
@@ -211,22 +223,25 @@ class Frontend
     const snk_frontend_params& params() const { return p_; }
 
    private:
-    // result vectors at capacity, pointers into them
+    // result vectors at capacity, pointers into them (Process: the calling thread is the only user of the handle)
     snk_frontend_frame bind(int width, int height, FrontendResult& r)
     {
         if (cap_ == 0 || width != cap_w_ || height != cap_h_)
         {
             check(snk_frontend_max_keypoints(h_, width, height, &cap_), "snk_frontend_max_keypoints");
-            check(snk_frontend_grid_dims(h_, &cols_, &rows_), "snk_frontend_grid_dims");
             cap_w_ = width, cap_h_ = height;
         }
+        return bind_capacity(cap_, r);
+    }
+    snk_frontend_frame bind_capacity(int cap, FrontendResult& r) const
+    {
         r.cols = cols_, r.rows = rows_;
-        const size_t c = (size_t)cap_;
+        const size_t c = (size_t)cap;
         r.keypoints.resize(c), r.keypoints_right.resize(c), r.descriptors.resize(c), r.descriptors_right.resize(c);
         r.undistorted_keypoints.resize(c), r.normalized_points.resize(c), r.permutation.resize(c), r.right_points.resize(c), r.depth.resize(c);
         r.cell_start.resize((size_t)r.cols * r.rows + 1);
         snk_frontend_frame f{};
-        f.capacity              = cap_;
+        f.capacity              = cap;
         f.keypoints             = r.keypoints.data();
         f.descriptors           = reinterpret_cast<uint64_t(*)[4]>(r.descriptors.data());
         f.undistorted_keypoints = r.undistorted_keypoints.data();
@@ -250,7 +265,28 @@ class Frontend
     }
     snk_frontend* h_ = nullptr;
     snk_frontend_params p_;
-    int cap_ = 0, cap_w_ = 0, cap_h_ = 0, cols_ = 0, rows_ = 0, width_ = 0, height_ = 0;
+    int cap_ = 0, cap_w_ = 0, cap_h_ = 0, cols_ = 0, rows_ = 0;  // cap_*: Process only; cols_ / rows_: set once in the constructor
+};
+
+// Page-locked image memory for Frontend::SubmitPinned (snk_pinned_alloc): what Snake's Input thread would allocate its image buffers from.
+class PinnedImage
+{
+   public:
+    PinnedImage(int pitch, int height, int count = 1) : pitch_(pitch), height_(height)
+    {
+        void* p = nullptr;
+        check(snk_pinned_alloc((size_t)pitch * height * count, &p), "snk_pinned_alloc");
+        p_ = static_cast<uint8_t*>(p);
+    }
+    ~PinnedImage() { snk_pinned_free(p_); }
+    PinnedImage(const PinnedImage&)            = delete;
+    PinnedImage& operator=(const PinnedImage&) = delete;
+    uint8_t* data(int image = 0) { return p_ + (size_t)image * pitch_ * height_; }
+    int pitch() const { return pitch_; }
+
+   private:
+    uint8_t* p_ = nullptr;
+    int pitch_ = 0, height_ = 0;
 };
 
 // Frame data the tracking matchers read, grid-ordered (Snake/Map/Features.h:18-41, Frame.h:44-46).

@@ -5025,7 +5025,16 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                 // keyframes, n6 = 1794: 5.0 / 4.6 / 5.9 / 5.0 ms with 256 / 128 / 64 / 32 workgroups, 10.4 with 512 in the three-barrier form)
                 const int wgs = std::min(PERSIST_WGS_MAX, snk_env_int("SNK_BA_PERSIST_WGS", std::min(prop.multiProcessorCount, std::max(16, ceil_div(max_n6, 12)))));
                 const bool fits = (size_t)max_n6 * 8 <= 150 * 1024 && ceil_div(max_nfc, PERSIST_CAMS) <= PERSIST_WGS_MAX;  // p in LDS; partial-sum slots
-                if (wgs >= 1 && fits && set_max_lds_once(reinterpret_cast<const void*>(pcgl_persist), 150 * 1024) == SNK_OK) W.persist_wgs = wgs;
+                if (wgs >= 1 && fits && set_max_lds_once(reinterpret_cast<const void*>(pcgl_persist), 150 * 1024) == SNK_OK)
+                {
+                    // all workgroups must be resident at once (grid barriers inside): ask the runtime what this kernel's registers and THIS
+                    // problem's LDS allow per compute unit instead of assuming one (round-5 advisor) -- other CU / LDS configurations,
+                    // partitioned devices
+                    int resident = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, reinterpret_cast<const void*>(pcgl_persist), PERSIST_THREADS, (size_t)max_n6 * 8) == hipSuccess &&
+                        resident >= 1)
+                        W.persist_wgs = std::min(wgs, resident * prop.multiProcessorCount);
+                }
             }
             (void)hipGetLastError();
         }
@@ -5402,12 +5411,28 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L, bool only_marked =
                 const dim3 gcam(W.G, B);
                 const dim3 gmv(ceil_div(h->max_n6, 256) * W.parts, B);
                 LAUNCH(pcgl_init, gcam, dim3(64), 0, A, O, W);
-                if (W.persist_wgs > 0 && B == 1 && L.graph == nullptr)
+                bool persisted = false;
+                if (W.persist_wgs > 0 && B == 1 && L.graph == nullptr && L.err == hipSuccess)
                 {
+                    static const bool fail_hook = getenv("SNK_BA_PERSIST_FAIL") != nullptr;  // tests: the runtime refuses the cooperative launch
                     L.cooperative = true;
-                    LAUNCH(pcgl_persist, dim3(W.persist_wgs), dim3(PERSIST_THREADS), (size_t)h->max_n6 * 8, A, O, W);
+                    if (fail_hook)
+                        L.cooperative = false, L.err = hipErrorCooperativeLaunchTooLarge;
+                    else
+                        LAUNCH(pcgl_persist, dim3(W.persist_wgs), dim3(PERSIST_THREADS), (size_t)h->max_n6 * 8, A, O, W);
+                    persisted = L.err == hipSuccess;
+                    if (!persisted)
+                    {
+                        // the runtime refused the cooperative launch (co-residency under another CU / LDS configuration, a partitioned device, a
+                        // driver without cooperative queues): nothing ran, pcgl_init's state is what the launch sequence below starts from too --
+                        // this handle uses that sequence from now on
+                        if (getenv("SNK_DEBUG")) fprintf(stderr, "snake_hip: cooperative PCG launch refused (%s); multi-launch PCG\n", hipGetErrorString(L.err));
+                        (void)hipGetLastError();
+                        L.err               = hipSuccess;
+                        h->pcgw.persist_wgs = 0;
+                    }
                 }
-                else
+                if (!persisted)
                 for (int k = 0; k < O.max_pcg; ++k)
                 {
                     LAUNCH(pcgl_matvec, gmv, dim3(256), 0, A, O, W, k);

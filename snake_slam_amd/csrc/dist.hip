@@ -57,7 +57,10 @@ int rccl_open()
 {
     std::lock_guard<std::mutex> lock(g_rccl_mu);
     if (g_rccl.so) return SNK_OK;
-    const char* names[] = {getenv("SNK_RCCL_LIB"), "librccl.so.1", "librccl.so"};
+    // SNK_RCCL_LIB names the library to use; with SNK_RCCL_STRICT set nothing else is tried (a deployment that pins its RCCL build
+    // wants an error, not another copy)
+    const bool strict   = getenv("SNK_RCCL_STRICT") != nullptr && getenv("SNK_RCCL_LIB") != nullptr;
+    const char* names[] = {getenv("SNK_RCCL_LIB"), strict ? nullptr : "librccl.so.1", strict ? nullptr : "librccl.so"};
     void* so            = nullptr;
     std::string tried;
     for (const char* n : names)
@@ -65,7 +68,8 @@ int rccl_open()
         if (!n || !*n) continue;
         so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (so) break;
-        tried += std::string(n) + ": " + (dlerror() ? dlerror() : "?") + "; ";
+        const char* e = dlerror();  // one call: dlerror() clears the message it returns
+        tried += std::string(n) + ": " + (e ? e : "?") + "; ";
     }
     if (!so)
     {
@@ -112,6 +116,7 @@ struct snk_dist : HandleBase
     int rank = 0, world = 1;
     DevBuf d_send, d_recv;
     HostBuf h_buf;  // [send | recv]
+    std::string rendezvous;  // rank 0 of snk_dist_init_file: the file it wrote, removed in snk_dist_destroy
 };
 
 extern "C" {
@@ -170,12 +175,24 @@ int snk_dist_init_file(const char* path, int rank, int world, int device, double
     uint8_t id[SNK_DIST_ID_BYTES];
     if (rank == 0)
     {
+        // a file left behind by an earlier job (a crashed rank 0, a C caller that never destroyed its handle) would hand the other
+        // ranks a dead id and hang them in ncclCommInitRank: remove it before the new id exists.  Ranks that read the stale file in
+        // the window before this line is a launcher problem (start rank 0 first or use a per-job path); the header says so.
+        (void)unlink(path);
         int rc = snk_dist_get_unique_id(id);
         if (rc != SNK_OK) return rc;
         const std::string tmp = std::string(path) + ".tmp";
         FILE* f               = fopen(tmp.c_str(), "wb");
-        if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id) || fclose(f) != 0 || rename(tmp.c_str(), path) != 0)
+        bool ok               = f != nullptr;
+        if (f)
         {
+            ok = fwrite(id, 1, sizeof(id), f) == sizeof(id);
+            ok = (fclose(f) == 0) && ok;  // closed on every path
+        }
+        if (ok) ok = rename(tmp.c_str(), path) == 0;
+        if (!ok)
+        {
+            (void)unlink(tmp.c_str());
             set_error("snk_dist_init_file: cannot write %s", path);
             return SNK_ERR_INVALID_ARG;
         }
@@ -201,7 +218,15 @@ int snk_dist_init_file(const char* path, int rank, int world, int device, double
             std::this_thread::sleep_for(std::chrono::milliseconds(5));
         }
     }
-    return snk_dist_init(id, rank, world, device, out);
+    const int rc = snk_dist_init(id, rank, world, device, out);
+    if (rank == 0)
+    {
+        if (rc == SNK_OK)
+            (*out)->rendezvous = path;
+        else
+            (void)unlink(path);  // a failed init leaves nothing behind
+    }
+    return rc;
 }
 
 int snk_dist_destroy(snk_dist* d)
@@ -210,6 +235,7 @@ int snk_dist_destroy(snk_dist* d)
     (void)hipSetDevice(d->device);
     (void)hipStreamSynchronize(d->stream);
     if (d->comm) (void)g_rccl.CommDestroy(d->comm);
+    if (!d->rendezvous.empty()) (void)unlink(d->rendezvous.c_str());  // every rank has joined the communicator: the id is spent
     d->d_send.release();
     d->d_recv.release();
     d->h_buf.release();

@@ -52,13 +52,25 @@ namespace
 {
 constexpr int MAX_DEPTH = 8;
 
+// Layout of a slot's device block that goes back to the host (d_out / h_out) and of its scratch block (d_tmp) for one image size.
+// Every slot keeps ITS OWN copy (written by the submitting thread before the frame is published, read by the collecting thread after):
+// the handle's copy is only the size the submitter last configured, read and written under the handle's mutex.
+struct FLayout
+{
+    int width = 0, height = 0, dpitch = 0, cap = 0;
+    size_t o_n = 0, o_kps = 0, o_desc_x = 0, o_desc_r = 0, o_kp64_g = 0, o_desc_g = 0, o_norm = 0, o_perm = 0, o_cs = 0, o_rp = 0, o_dp = 0, out_len = 0;
+    size_t t_desc = 0, t_kp64 = 0;  // d_tmp: descriptors in extractor order (2 images) | rectified keypoints (2 images)
+};
+
 // everything one frame in flight needs; nothing is shared between slots
 struct Slot
 {
     hipStream_t stream = nullptr;
     snk_orb* orb       = nullptr;
     snk_matcher* mat   = nullptr;
-    int width = 0, height = 0;  // what this slot's extractor and blocks are sized for
+    FLayout lay;                // what this slot's extractor and blocks are sized for (lay.width == 0: nothing yet)
+    int img_pitch = 0;          // row pitch of the images in d_img for the frame being enqueued (dpitch, or the caller's for a direct upload)
+    int graph_pitch = 0;        // ... of the recorded launches
     DevBuf d_img, d_out, d_tmp;
     HostBuf h_img, h_out;
     hipGraphExec_t graph = nullptr;
@@ -74,12 +86,10 @@ struct snk_frontend
 {
     int device = 0;
     snk_frontend_params par{};
-    int width = 0, height = 0, dpitch = 0, cap = 0, cols = 0, rows = 0, n_img = 2;
+    int cols = 0, rows = 0, n_img = 2;  // constants of the handle
     float level_scale[8] = {};
-    // layout of a slot's device block that goes back to the host (d_out / h_out) and of its scratch block (d_tmp)
-    size_t o_n = 0, o_kps = 0, o_desc_x = 0, o_desc_r = 0, o_kp64_g = 0, o_desc_g = 0, o_norm = 0, o_perm = 0, o_cs = 0, o_rp = 0, o_dp = 0, out_len = 0;
-    size_t t_desc = 0, t_kp64 = 0;  // d_tmp: descriptors in extractor order (2 images) | rectified keypoints (2 images)
-    std::vector<Slot*> slots;       // slots[0] also serves snk_frontend_process
+    FLayout lay;               // the image size last configured (guarded by mu)
+    std::vector<Slot*> slots;  // slots[0] also serves snk_frontend_process
     // the ring of submitted frames: frame number q lives in slot q % depth
     std::mutex mu;
     std::condition_variable cv;
@@ -186,30 +196,32 @@ extern "C" int snk_frontend_destroy(snk_frontend* f)
 
 static size_t up64(size_t v) { return (v + 63) & ~(size_t)63; }
 
-// the block layout of an image size (the same for every slot)
+// the block layout of an image size (the same for every slot), into the slot's own copy
 static int layout(snk_frontend* f, Slot* s, int w, int h)
 {
     int rc;
+    FLayout y;
     if ((rc = snk_orb_configure(s->orb, w, h, 2)) != SNK_OK) return rc;
-    if ((rc = snk_orb_max_keypoints(s->orb, &f->cap)) != SNK_OK) return rc;
-    const size_t cap = (size_t)f->cap, ni = (size_t)f->n_img;
-    f->width = w; f->height = h; f->dpitch = (w + 63) & ~63;
+    if ((rc = snk_orb_max_keypoints(s->orb, &y.cap)) != SNK_OK) return rc;
+    const size_t cap = (size_t)y.cap, ni = (size_t)f->n_img;
+    y.width = w; y.height = h; y.dpitch = (w + 63) & ~63;
     size_t at = 0;
     auto take = [&](size_t bytes) { const size_t o = at; at = up64(at + bytes); return o; };
-    f->o_n      = take(16 * sizeof(int));                 // n[2], n_stereo
-    f->o_kps    = take(ni * cap * sizeof(snk_keypoint));  // both images, extractor order
-    f->o_desc_x = take(2 * cap * 32);                     // descriptors in extractor order, image-major as the extractor writes them: the left half is
-    f->o_desc_r = f->o_desc_x + cap * 32;                 // scratch that rides along in the download, the right half IS frame.descriptors_right
-    f->o_kp64_g = take(cap * sizeof(snk_kp64));           // undistorted_keypoints, grid order
-    f->o_desc_g = take(cap * 32);                         // left descriptors, grid order
-    f->o_norm   = take(cap * 16);                         // normalized_points, extractor order (the host applies the permutation)
-    f->o_perm   = take(cap * 4);
-    f->o_cs     = take(((size_t)f->cols * f->rows + 1) * 4);
-    f->o_rp     = take(cap * 4);
-    f->o_dp     = take(cap * 4);                          // directly behind right_points: one fill for both
-    f->out_len  = at;
-    f->t_desc   = 0;
-    f->t_kp64   = up64(ni * cap * 32);
+    y.o_n      = take(16 * sizeof(int));                 // n[2], n_stereo
+    y.o_kps    = take(ni * cap * sizeof(snk_keypoint));  // both images, extractor order
+    y.o_desc_x = take(2 * cap * 32);                     // descriptors in extractor order, image-major as the extractor writes them: the left half is
+    y.o_desc_r = y.o_desc_x + cap * 32;                  // scratch that rides along in the download, the right half IS frame.descriptors_right
+    y.o_kp64_g = take(cap * sizeof(snk_kp64));           // undistorted_keypoints, grid order
+    y.o_desc_g = take(cap * 32);                         // left descriptors, grid order
+    y.o_norm   = take(cap * 16);                         // normalized_points, extractor order (the host applies the permutation)
+    y.o_perm   = take(cap * 4);
+    y.o_cs     = take(((size_t)f->cols * f->rows + 1) * 4);
+    y.o_rp     = take(cap * 4);
+    y.o_dp     = take(cap * 4);                          // directly behind right_points: one fill for both
+    y.out_len  = at;
+    y.t_desc   = 0;
+    y.t_kp64   = up64(ni * cap * 32);
+    s->lay     = y;
     return SNK_OK;
 }
 
@@ -219,15 +231,17 @@ static int configure_slot(snk_frontend* f, Slot* s, int w, int h)
     int rc;
     SNK_HIP_CHECK(hipStreamSynchronize(s->stream));
     drop_graph(s);
+    s->lay.width = 0;  // not configured until everything below has succeeded
     if ((rc = layout(f, s, w, h)) != SNK_OK) return rc;
-    const size_t cap = (size_t)f->cap, ni = (size_t)f->n_img;
-    if ((rc = s->d_out.reserve(f->out_len + 64)) != SNK_OK) return rc;
-    if ((rc = s->h_out.reserve(f->out_len + 64)) != SNK_OK) return rc;
-    if ((rc = s->d_tmp.reserve(f->t_kp64 + ni * cap * sizeof(snk_kp64) + 64)) != SNK_OK) return rc;
-    if ((rc = s->d_img.reserve(ni * (size_t)f->dpitch * h + 64)) != SNK_OK) return rc;
-    if ((rc = s->h_img.reserve(ni * (size_t)f->dpitch * h + 64)) != SNK_OK) return rc;
-    s->width       = w;
-    s->height      = h;
+    const FLayout y  = s->lay;
+    s->lay.width     = 0;
+    const size_t cap = (size_t)y.cap, ni = (size_t)f->n_img;
+    if ((rc = s->d_out.reserve(y.out_len + 64)) != SNK_OK) return rc;
+    if ((rc = s->h_out.reserve(y.out_len + 64)) != SNK_OK) return rc;
+    if ((rc = s->d_tmp.reserve(y.t_kp64 + ni * cap * sizeof(snk_kp64) + 64)) != SNK_OK) return rc;
+    if ((rc = s->d_img.reserve(ni * (size_t)y.dpitch * h + 64)) != SNK_OK) return rc;
+    if ((rc = s->h_img.reserve(ni * (size_t)y.dpitch * h + 64)) != SNK_OK) return rc;
+    s->lay         = y;
     s->frames_seen = 0;
     s->last_key    = -1;
     return SNK_OK;
@@ -236,61 +250,64 @@ static int configure_slot(snk_frontend* f, Slot* s, int w, int h)
 // everything between the upload and the download, on the slot's stream
 static int enqueue_chain(snk_frontend* f, Slot* s)
 {
-    const size_t cap = (size_t)f->cap;
+    const FLayout& y = s->lay;
+    const size_t cap = (size_t)y.cap;
     char* o  = s->d_out.as<char>();
     char* t  = s->d_tmp.as<char>();
-    int* d_n = reinterpret_cast<int*>(o + f->o_n);
-    auto* d_kps  = reinterpret_cast<snk_keypoint*>(o + f->o_kps);
+    int* d_n = reinterpret_cast<int*>(o + y.o_n);
+    auto* d_kps  = reinterpret_cast<snk_keypoint*>(o + y.o_kps);
     // descriptors of both images in extractor order, image-major with stride cap * 4 words: a stereo handle keeps them inside the output
     // block (o_desc_x, its second half = o_desc_r), so that no device-to-device copy stands between the extractor and the download
-    auto* d_desc = f->n_img == 2 ? reinterpret_cast<uint64_t*>(o + f->o_desc_x) : reinterpret_cast<uint64_t*>(t + f->t_desc);
-    auto* d_kp64 = reinterpret_cast<snk_kp64*>(t + f->t_kp64);
+    auto* d_desc = f->n_img == 2 ? reinterpret_cast<uint64_t*>(o + y.o_desc_x) : reinterpret_cast<uint64_t*>(t + y.t_desc);
+    auto* d_kp64 = reinterpret_cast<snk_kp64*>(t + y.t_kp64);
     int rc;
     // FeatureDetector::Detect, left then right (FeatureDetector.cpp:116-156): one two-image launch chain
-    if ((rc = snk_orb_detect_batch_dev(s->orb, s->d_img.as<uint8_t>(), f->dpitch, (size_t)f->dpitch * f->height, f->n_img, d_kps, d_desc, d_n,
-                                       f->cap)) != SNK_OK)
+    if ((rc = snk_orb_detect_batch_dev(s->orb, s->d_img.as<uint8_t>(), s->img_pitch, (size_t)s->img_pitch * y.height, f->n_img, d_kps, d_desc, d_n,
+                                       y.cap)) != SNK_OK)
         return rc;
     // Frame::allocateTmp (Snake/Map/Frame.cpp:25-26): right_points and depth start at -1000 -- a stereo handle leaves that to its
     // StereoMatching call below (whose first kernel does it: one launch less in a chain of short launches), a mono handle fills here
     if (f->n_img != 2)
-        SNK_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(o + f->o_rp), 0xC47A0000u /* -1000.0f */, (f->o_dp - f->o_rp) / 4 + cap, s->stream));
+        SNK_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(o + y.o_rp), 0xC47A0000u /* -1000.0f */, (y.o_dp - y.o_rp) / 4 + cap, s->stream));
     // undistortKeypoints (Preprocess.cpp:55-77) with rect_left; Rectification::Forward of the right keypoints (:140-150) with rect_right
     if (f->n_img == 2)
     {
-        if ((rc = rectify_pair_dev(s->mat, &f->par.rect_left, &f->par.rect_right, d_kps, d_n, f->cap, d_kp64, reinterpret_cast<double*>(o + f->o_norm))) != SNK_OK)
+        if ((rc = rectify_pair_dev(s->mat, &f->par.rect_left, &f->par.rect_right, d_kps, d_n, y.cap, d_kp64, reinterpret_cast<double*>(o + y.o_norm))) != SNK_OK)
             return rc;
     }
-    else if ((rc = snk_rectify_batch_dev(s->mat, &f->par.rect_left, d_kps, d_n, f->cap, 1, d_kp64, reinterpret_cast<double*>(o + f->o_norm))) != SNK_OK)
+    else if ((rc = snk_rectify_batch_dev(s->mat, &f->par.rect_left, d_kps, d_n, y.cap, 1, d_kp64, reinterpret_cast<double*>(o + y.o_norm))) != SNK_OK)
         return rc;
     // computeFeatureGrid (Preprocess.cpp:244-266): permutation, cell starts, undistorted keypoints and descriptors in grid order
-    if ((rc = snk_feature_grid_batch_dev(s->mat, &f->par.bounds, d_kp64, d_desc, d_n, f->cap, 1, reinterpret_cast<snk_kp64*>(o + f->o_kp64_g),
-                                         reinterpret_cast<uint64_t*>(o + f->o_desc_g), reinterpret_cast<int32_t*>(o + f->o_perm),
-                                         reinterpret_cast<int32_t*>(o + f->o_cs))) != SNK_OK)
+    if ((rc = snk_feature_grid_batch_dev(s->mat, &f->par.bounds, d_kp64, d_desc, d_n, y.cap, 1, reinterpret_cast<snk_kp64*>(o + y.o_kp64_g),
+                                         reinterpret_cast<uint64_t*>(o + y.o_desc_g), reinterpret_cast<int32_t*>(o + y.o_perm),
+                                         reinterpret_cast<int32_t*>(o + y.o_cs))) != SNK_OK)
         return rc;
     if (f->n_img == 2)
     {
         // the right descriptors go back in extractor order (frame.descriptors_right): the extractor wrote them where the download takes
         // them from (d_desc's second half IS o_desc_r, see layout())
         // StereoMatching (Preprocess.cpp:122-242): left in grid order, right in extractor order (:41-49)
-        if ((rc = stereo_match_batch_dev_impl(s->mat, reinterpret_cast<const snk_kp64*>(o + f->o_kp64_g), reinterpret_cast<const uint64_t*>(o + f->o_desc_g),
-                                             d_n, f->cap, d_kp64 + cap, d_desc + cap * 4, d_n + 1, f->cap, 1, f->par.bf, f->level_scale,
-                                             f->par.orb.n_levels, f->par.relaxed_stereo, reinterpret_cast<float*>(o + f->o_rp),
-                                             reinterpret_cast<float*>(o + f->o_dp), d_n + 2, /*prefill=*/true)) != SNK_OK)
+        if ((rc = stereo_match_batch_dev_impl(s->mat, reinterpret_cast<const snk_kp64*>(o + y.o_kp64_g), reinterpret_cast<const uint64_t*>(o + y.o_desc_g),
+                                             d_n, y.cap, d_kp64 + cap, d_desc + cap * 4, d_n + 1, y.cap, 1, f->par.bf, f->level_scale,
+                                             f->par.orb.n_levels, f->par.relaxed_stereo, reinterpret_cast<float*>(o + y.o_rp),
+                                             reinterpret_cast<float*>(o + y.o_dp), d_n + 2, /*prefill=*/true)) != SNK_OK)
             return rc;
     }
     return SNK_OK;
 }
 
-// stage the images, upload, chain (hipGraph from the slot's second frame on), download -- all enqueued on the slot's stream, no wait
-static int enqueue_frame(snk_frontend* f, Slot* s, const uint8_t* left, int pitch_left, const uint8_t* right, int pitch_right, int width, int height)
+// The images onto the device, the chain (hipGraph from the slot's second frame on), the download -- all enqueued on the slot's
+// stream, no wait.  direct = false: the two images are staged into the slot's pinned buffer (row pitch dpitch) and go up with ONE
+// copy; the caller's memory is free again when this returns.  direct = true (snk_frontend_submit_pinned): the caller's buffers are
+// the source of the upload (one copy when the right image follows the left one in memory, two otherwise), no staging copy on the
+// host -- for callers whose image buffers are pinned and stay untouched until the frame has been collected.
+static int enqueue_frame(snk_frontend* f, Slot* s, const uint8_t* left, int pitch_left, const uint8_t* right, int pitch_right, int width, int height,
+                         bool direct)
 {
     int rc;
-    if (s->width != width || s->height != height)
-    {
+    if (s->lay.width != width || s->lay.height != height)
         if ((rc = configure_slot(f, s, width, height)) != SNK_OK) return rc;
-    }
-    else if (f->width != width || f->height != height)
-        if ((rc = layout(f, s, width, height)) != SNK_OK) return rc;  // the handle last served another size through another slot
+    const FLayout& y = s->lay;
     // SNK_FRONTEND_TIMING=1 (diagnostic): mean host microseconds per part of this function, printed every 256 frames
     static const bool timing = getenv("SNK_FRONTEND_TIMING") != nullptr;
     static double t_acc[5]  = {0, 0, 0, 0, 0};
@@ -304,22 +321,53 @@ static int enqueue_frame(snk_frontend* f, Slot* s, const uint8_t* left, int pitc
         t_acc[i] += std::chrono::duration<double, std::micro>(t - t_prev).count();
         t_prev = t;
     };
-    // the two images into the pinned staging buffer, ONE upload
-    const size_t plane = (size_t)f->dpitch * height;
-    uint8_t* hi        = s->h_img.as<uint8_t>();
-    if (pitch_left == f->dpitch)
-        memcpy(hi, left, plane - (size_t)(f->dpitch - width));
-    else
-        for (int r = 0; r < height; ++r) memcpy(hi + (size_t)r * f->dpitch, left + (size_t)r * pitch_left, (size_t)width);
-    if (f->n_img == 2)
+    uint8_t* di = s->d_img.as<uint8_t>();
+    if (direct && pitch_left % 4 == 0 && pitch_left <= y.dpitch && (f->n_img == 1 || pitch_right == pitch_left))
     {
-        if (pitch_right == f->dpitch)
-            memcpy(hi + plane, right, plane - (size_t)(f->dpitch - width));
+        // rows keep the caller's pitch on the device (the extractor takes any pitch; a multiple of four keeps its aligned loads):
+        // plain 1-D copies straight out of the caller's memory
+        const size_t plane = (size_t)pitch_left * height;
+        s->img_pitch       = pitch_left;
+        lap(0);
+        if (f->n_img == 2 && right == left + plane)
+            SNK_HIP_CHECK(hipMemcpyAsync(di, left, 2 * plane, hipMemcpyHostToDevice, s->stream));
         else
-            for (int r = 0; r < height; ++r) memcpy(hi + plane + (size_t)r * f->dpitch, right + (size_t)r * pitch_right, (size_t)width);
+        {
+            SNK_HIP_CHECK(hipMemcpyAsync(di, left, plane - (size_t)(pitch_left - width), hipMemcpyHostToDevice, s->stream));
+            if (f->n_img == 2)
+                SNK_HIP_CHECK(hipMemcpyAsync(di + plane, right, plane - (size_t)(pitch_left - width), hipMemcpyHostToDevice, s->stream));
+        }
     }
-    lap(0);
-    SNK_HIP_CHECK(hipMemcpyAsync(s->d_img.p, hi, plane * f->n_img, hipMemcpyHostToDevice, s->stream));
+    else if (direct)
+    {
+        // odd pitches: a 2-D copy per image into the dpitch layout, still without a host-side copy
+        const size_t plane = (size_t)y.dpitch * height;
+        s->img_pitch       = y.dpitch;
+        lap(0);
+        SNK_HIP_CHECK(hipMemcpy2DAsync(di, (size_t)y.dpitch, left, (size_t)pitch_left, (size_t)width, (size_t)height, hipMemcpyHostToDevice, s->stream));
+        if (f->n_img == 2)
+            SNK_HIP_CHECK(hipMemcpy2DAsync(di + plane, (size_t)y.dpitch, right, (size_t)pitch_right, (size_t)width, (size_t)height, hipMemcpyHostToDevice, s->stream));
+    }
+    else
+    {
+        // the two images into the pinned staging buffer, ONE upload
+        const size_t plane = (size_t)y.dpitch * height;
+        uint8_t* hi        = s->h_img.as<uint8_t>();
+        s->img_pitch       = y.dpitch;
+        if (pitch_left == y.dpitch)
+            memcpy(hi, left, plane - (size_t)(y.dpitch - width));
+        else
+            for (int r = 0; r < height; ++r) memcpy(hi + (size_t)r * y.dpitch, left + (size_t)r * pitch_left, (size_t)width);
+        if (f->n_img == 2)
+        {
+            if (pitch_right == y.dpitch)
+                memcpy(hi + plane, right, plane - (size_t)(y.dpitch - width));
+            else
+                for (int r = 0; r < height; ++r) memcpy(hi + plane + (size_t)r * y.dpitch, right + (size_t)r * pitch_right, (size_t)width);
+        }
+        lap(0);
+        SNK_HIP_CHECK(hipMemcpyAsync(di, hi, plane * f->n_img, hipMemcpyHostToDevice, s->stream));
+    }
     lap(1);
 
     static const bool no_graph = getenv("SNK_FRONTEND_NO_GRAPH") != nullptr;
@@ -330,6 +378,7 @@ static int enqueue_frame(snk_frontend* f, Slot* s, const uint8_t* left, int pitc
         s->frames_seen = 0;
         s->last_key    = key;
     }
+    if (s->graph && s->graph_pitch != s->img_pitch) drop_graph(s);  // the row pitch is an argument of the recorded launches
     bool launched = false;
     if (!no_graph && s->graph)
     {
@@ -347,8 +396,9 @@ static int enqueue_frame(snk_frontend* f, Slot* s, const uint8_t* left, int pitc
             hipGraphExec_t ex = nullptr;
             if (rc == SNK_OK && e == hipSuccess && g != nullptr && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess && ex != nullptr)
             {
-                s->graph     = ex;
-                s->graph_key = key;
+                s->graph       = ex;
+                s->graph_key   = key;
+                s->graph_pitch = s->img_pitch;
             }
             if (g) (void)hipGraphDestroy(g);
             (void)hipGetLastError();
@@ -374,7 +424,7 @@ static int enqueue_frame(snk_frontend* f, Slot* s, const uint8_t* left, int pitc
     if (!launched && (rc = enqueue_chain(f, s)) != SNK_OK) return rc;
     ++s->frames_seen;
     lap(2);
-    SNK_HIP_CHECK(hipMemcpyAsync(s->h_out.p, s->d_out.p, f->out_len, hipMemcpyDeviceToHost, s->stream));
+    SNK_HIP_CHECK(hipMemcpyAsync(s->h_out.p, s->d_out.p, y.out_len, hipMemcpyDeviceToHost, s->stream));
     lap(3);
     if (timing && ++t_n % 256 == 0)
     {
@@ -385,11 +435,12 @@ static int enqueue_frame(snk_frontend* f, Slot* s, const uint8_t* left, int pitc
     return SNK_OK;
 }
 
-// a finished frame's pinned block -> the caller's arrays
+// a finished frame's pinned block -> the caller's arrays (the slot's own layout: nothing of the handle that another thread may write)
 static int unpack(snk_frontend* f, Slot* s, snk_frontend_frame* out)
 {
+    const FLayout& y = s->lay;
     const char* h  = s->h_out.as<char>();
-    const int* hn  = reinterpret_cast<const int*>(h + f->o_n);
+    const int* hn  = reinterpret_cast<const int*>(h + y.o_n);
     const int n    = hn[0], nr = f->n_img == 2 ? hn[1] : 0;
     out->n         = n;
     out->n_right   = nr;
@@ -401,25 +452,25 @@ static int unpack(snk_frontend* f, Slot* s, snk_frontend_frame* out)
         set_error("capacity %d too small for %d / %d keypoints (see snk_frontend_max_keypoints)", out->capacity, n, nr);
         return SNK_ERR_CAPACITY;
     }
-    const size_t cap = (size_t)f->cap;
-    const auto* kps  = reinterpret_cast<const snk_keypoint*>(h + f->o_kps);
-    const int* perm  = reinterpret_cast<const int*>(h + f->o_perm);
+    const size_t cap = (size_t)y.cap;
+    const auto* kps  = reinterpret_cast<const snk_keypoint*>(h + y.o_kps);
+    const int* perm  = reinterpret_cast<const int*>(h + y.o_perm);
     // computeFeatureGrid's scatter of the arrays that stayed in extractor order (Preprocess.cpp:254-260)
     if (out->keypoints)
         for (int i = 0; i < n; ++i) out->keypoints[perm[i]] = kps[i];
     if (out->normalized_points)
     {
-        const double* nm = reinterpret_cast<const double*>(h + f->o_norm);
+        const double* nm = reinterpret_cast<const double*>(h + y.o_norm);
         for (int i = 0; i < n; ++i) out->normalized_points[perm[i]][0] = nm[2 * i], out->normalized_points[perm[i]][1] = nm[2 * i + 1];
     }
-    if (out->descriptors && n) memcpy(out->descriptors, h + f->o_desc_g, (size_t)n * 32);
-    if (out->undistorted_keypoints && n) memcpy(out->undistorted_keypoints, h + f->o_kp64_g, (size_t)n * sizeof(snk_kp64));
+    if (out->descriptors && n) memcpy(out->descriptors, h + y.o_desc_g, (size_t)n * 32);
+    if (out->undistorted_keypoints && n) memcpy(out->undistorted_keypoints, h + y.o_kp64_g, (size_t)n * sizeof(snk_kp64));
     if (out->permutation && n) memcpy(out->permutation, perm, (size_t)n * 4);
-    if (out->cell_start) memcpy(out->cell_start, h + f->o_cs, ((size_t)f->cols * f->rows + 1) * 4);
-    if (out->right_points && n) memcpy(out->right_points, h + f->o_rp, (size_t)n * 4);
-    if (out->depth && n) memcpy(out->depth, h + f->o_dp, (size_t)n * 4);
+    if (out->cell_start) memcpy(out->cell_start, h + y.o_cs, ((size_t)f->cols * f->rows + 1) * 4);
+    if (out->right_points && n) memcpy(out->right_points, h + y.o_rp, (size_t)n * 4);
+    if (out->depth && n) memcpy(out->depth, h + y.o_dp, (size_t)n * 4);
     if (out->keypoints_right && nr) memcpy(out->keypoints_right, kps + cap, (size_t)nr * sizeof(snk_keypoint));
-    if (out->descriptors_right && nr) memcpy(out->descriptors_right, h + f->o_desc_r, (size_t)nr * 32);
+    if (out->descriptors_right && nr) memcpy(out->descriptors_right, h + y.o_desc_r, (size_t)nr * 32);
     return SNK_OK;
 }
 
@@ -438,7 +489,11 @@ extern "C" int snk_frontend_process(snk_frontend* f, const uint8_t* left, int pi
     SNK_HIP_CHECK(hipSetDevice(f->device));
     Slot* s = f->slots[0];
     int rc;
-    if ((rc = enqueue_frame(f, s, left, pitch_left, right, pitch_right, width, height)) != SNK_OK) return rc;
+    if ((rc = enqueue_frame(f, s, left, pitch_left, right, pitch_right, width, height, false)) != SNK_OK) return rc;
+    {
+        std::lock_guard<std::mutex> lock(f->mu);
+        f->lay = s->lay;
+    }
     SNK_HIP_CHECK(hipStreamSynchronize(s->stream));  // ONE synchronisation
     return unpack(f, s, out);
 }
@@ -462,8 +517,7 @@ extern "C" int snk_frontend_set_depth(snk_frontend* f, int depth)
     return SNK_OK;
 }
 
-extern "C" int snk_frontend_submit(snk_frontend* f, const uint8_t* left, int pitch_left, const uint8_t* right, int pitch_right, int width,
-                                   int height)
+static int submit_impl(snk_frontend* f, const uint8_t* left, int pitch_left, const uint8_t* right, int pitch_right, int width, int height, bool direct)
 {
     SNK_REQUIRE(f != nullptr, "frontend is NULL");
     SNK_REQUIRE(left != nullptr && width >= 1 && height >= 1 && pitch_left >= width, "bad left image");
@@ -473,10 +527,10 @@ extern "C" int snk_frontend_submit(snk_frontend* f, const uint8_t* left, int pit
     {
         // SynchronizedSlot::set: wait for a free slot (the collector frees the oldest)
         std::unique_lock<std::mutex> lock(f->mu);
-        // the block layout belongs to the handle: frames of one image size at a time
-        SNK_REQUIRE(f->submitted == f->collected || (f->width == width && f->height == height),
-                    "image size changed while frames are in flight: collect them first");
         f->cv.wait(lock, [&] { return f->submitted - f->collected < (unsigned long long)f->depth; });
+        // frames of one image size at a time (checked behind the wait: what is in flight NOW decides)
+        SNK_REQUIRE(f->submitted == f->collected || (f->lay.width == width && f->lay.height == height),
+                    "image size changed while frames are in flight: collect them first");
         si = (int)(f->submitted % (unsigned long long)f->depth);
         while ((int)f->slots.size() <= si)
         {
@@ -489,7 +543,7 @@ extern "C" int snk_frontend_submit(snk_frontend* f, const uint8_t* left, int pit
     // the slot is this thread's until `submitted` moves: the collector only touches slots of frames < submitted
     Slot* s = f->slots[(size_t)si];
     int rc;
-    if ((rc = enqueue_frame(f, s, left, pitch_left, right, pitch_right, width, height)) != SNK_OK)
+    if ((rc = enqueue_frame(f, s, left, pitch_left, right, pitch_right, width, height, direct)) != SNK_OK)
     {
         (void)hipStreamSynchronize(s->stream);  // whatever was enqueued must not run into the slot's next use
         return rc;
@@ -497,9 +551,58 @@ extern "C" int snk_frontend_submit(snk_frontend* f, const uint8_t* left, int pit
     SNK_HIP_CHECK(hipEventRecord(s->done, s->stream));
     {
         std::lock_guard<std::mutex> lock(f->mu);
+        f->lay = s->lay;
         ++f->submitted;
     }
     f->cv.notify_all();
+    return SNK_OK;
+}
+
+extern "C" int snk_frontend_submit(snk_frontend* f, const uint8_t* left, int pitch_left, const uint8_t* right, int pitch_right, int width,
+                                   int height)
+{
+    return submit_impl(f, left, pitch_left, right, pitch_right, width, height, false);
+}
+
+extern "C" int snk_frontend_submit_pinned(snk_frontend* f, const uint8_t* left, int pitch_left, const uint8_t* right, int pitch_right, int width,
+                                          int height)
+{
+    return submit_impl(f, left, pitch_left, right, pitch_right, width, height, true);
+}
+
+// caller-owned image memory the upload engine reads directly (Snake/Preprocess/Input.h:48: the Input thread owns its image buffers)
+extern "C" int snk_pinned_alloc(size_t bytes, void** out)
+{
+    SNK_REQUIRE(out != nullptr && bytes > 0, "bad arguments");
+    *out = nullptr;
+    SNK_HIP_CHECK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return SNK_OK;
+}
+
+extern "C" int snk_pinned_free(void* p)
+{
+    if (p) SNK_HIP_CHECK(hipHostFree(p));
+    return SNK_OK;
+}
+
+// wait for the oldest submitted frame to EXIST (not to finish) and report what its arrays need: the collecting thread sizes its
+// buffers from this, never from what the submitting thread is doing
+extern "C" int snk_frontend_peek(snk_frontend* f, int timeout_ms, int* width, int* height, int* capacity)
+{
+    SNK_REQUIRE(f != nullptr, "frontend is NULL");
+    std::unique_lock<std::mutex> lock(f->mu);
+    auto ready = [&] { return f->collected < f->submitted; };
+    if (timeout_ms < 0)
+        f->cv.wait(lock, ready);
+    else if (!f->cv.wait_for(lock, std::chrono::milliseconds(timeout_ms), ready))
+    {
+        set_error("snk_frontend_peek: no frame was submitted within %d ms", timeout_ms);
+        return SNK_ERR_TIMEOUT;
+    }
+    const Slot* s = f->slots[(size_t)(f->collected % (unsigned long long)f->depth)];
+    if (width) *width = s->lay.width;
+    if (height) *height = s->lay.height;
+    if (capacity) *capacity = s->lay.cap;
     return SNK_OK;
 }
 
@@ -552,16 +655,16 @@ extern "C" int snk_frontend_max_keypoints(snk_frontend* f, int width, int height
 {
     SNK_REQUIRE(f != nullptr && out != nullptr && width >= 1 && height >= 1, "bad arguments");
     SNK_HIP_CHECK(hipSetDevice(f->device));
-    int rc;
-    if (f->width != width || f->height != height)
+    std::lock_guard<std::mutex> lock(f->mu);
+    if (f->lay.width != width || f->lay.height != height)
     {
-        {
-            std::lock_guard<std::mutex> lock(f->mu);
-            SNK_REQUIRE(f->submitted == f->collected, "frames of another image size are in flight");
-        }
+        // another size than the one last configured: slot 0 is re-sized for it, which needs the handle idle
+        SNK_REQUIRE(f->submitted == f->collected, "frames of another image size are in flight");
+        int rc;
         if ((rc = configure_slot(f, f->slots[0], width, height)) != SNK_OK) return rc;
+        f->lay = f->slots[0]->lay;
     }
-    *out = f->cap;
+    *out = f->lay.cap;
     return SNK_OK;
 }
 

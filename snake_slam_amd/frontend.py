@@ -49,6 +49,9 @@ class Frontend:
         if getattr(self, "_h", None):
             self._lib.snk_frontend_destroy(self._h)
             self._h = None
+            for p in getattr(self, "_pinned", []):
+                self._lib.snk_pinned_free(p)
+            self._pinned = []
 
     def __del__(self):
         try:
@@ -89,20 +92,44 @@ class Frontend:
         _lib.check(self._lib.snk_frontend_submit(self._h, left.ctypes.data, w, right.ctypes.data if right is not None else None, w, w, h),
                    "snk_frontend_submit")
 
-    def Collect(self, timeout_ms: int = -1) -> dict:
-        """snk_frontend_collect: the oldest submitted frame, as Process returns it."""
+    def pinned_images(self, width: int, height: int, count: int = 2, pitch: int | None = None) -> np.ndarray:
+        """`count` images of page-locked host memory (snk_pinned_alloc) as one (count, height, pitch) uint8 array -- what Snake's Input
+        thread would allocate its image buffers from (Snake/Preprocess/Input.h:48).  Freed when the Frontend is closed."""
+        pitch = int(pitch or width)
+        p = C.c_void_p()
+        _lib.check(self._lib.snk_pinned_alloc(count * height * pitch, C.byref(p)), "snk_pinned_alloc")
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p)
+        buf = (C.c_uint8 * (count * height * pitch)).from_address(p.value)
+        return np.frombuffer(buf, np.uint8).reshape(count, height, pitch)
+
+    def SubmitPinned(self, left: np.ndarray, right: np.ndarray | None = None) -> None:
+        """snk_frontend_submit_pinned: like Submit, but the upload reads the caller's (page-locked) arrays directly -- they must stay
+        untouched until the frame has been collected.  `left` / `right`: 2-D uint8 views with contiguous rows (pitch = strides[0])."""
+        h, w = left.shape
+        assert left.dtype == np.uint8 and left.strides[1] == 1 and (right is None or (right.shape == left.shape and right.strides[1] == 1))
+        if self._arrays is None or self._size != (w, h):
+            self._alloc(w, h)
+        _lib.check(self._lib.snk_frontend_submit_pinned(self._h, left.ctypes.data, left.strides[0], right.ctypes.data if right is not None else None,
+                                                        right.strides[0] if right is not None else 0, w, h), "snk_frontend_submit_pinned")
+
+    def Collect(self, timeout_ms: int = -1, copy: bool = True) -> dict:
+        """snk_frontend_collect: the oldest submitted frame, as Process returns it.  copy=False hands out views of the handle's own
+        arrays (valid until the next Collect / Process): what a consumer that reads the frame before asking for the next one needs."""
         fr, a = self._frame, self._arrays
         _lib.check(self._lib.snk_frontend_collect(self._h, C.byref(fr), int(timeout_ms)), "snk_frontend_collect")
-        return self._result(fr, a)
+        return self._result(fr, a, copy)
 
     def in_flight(self) -> int:
         n = C.c_int(0)
         _lib.check(self._lib.snk_frontend_in_flight(self._h, C.byref(n)), "snk_frontend_in_flight")
         return n.value
 
-    def _result(self, fr, a) -> dict:
+    def _result(self, fr, a, copy: bool = True) -> dict:
         n, nr = fr.n, fr.n_right
-        out = {k: (v[:nr] if k.endswith("_right") else (v if k == "cell_start" else v[:n])).copy() for k, v in a.items()}
+        out = {k: (v[:nr] if k.endswith("_right") else (v if k == "cell_start" else v[:n])) for k, v in a.items()}
+        if copy:
+            out = {k: v.copy() for k, v in out.items()}
         out.update(N=n, n_right=nr, n_stereo=fr.n_stereo, cols=fr.cols, rows=fr.rows)
         return out
 

@@ -15,6 +15,12 @@ necessary condition for a truncated solve) AND (b) solved again -- alone, both s
 strict tolerances.  (b) runs the same kernels (linearisation, Schur complement, PCG, update) on the same scene, so a defect in
 any of them still fails; only the order-dependence of a truncated Krylov iterate is excused.  The caller bounds how many
 scenes may take that route.
+
+The premise is not only asserted (round 6): tests/test_oracle_ba.py::test_truncated_pcg_depends_on_summation_order_in_the_oracle_itself
+solves such scenes with the ORACLE against a copy of itself whose sums run in another order (reversed / pairwise; no kernel
+involved) -- they differ by up to ~0.5 RMSE at the iteration limit and agree to 1e-8 once the PCG may converge -- and
+tools/ba_truncation_control.py records, over the fuzzers' scene distribution, oracle-vs-re-ordered-oracle beside HIP-vs-oracle on the
+same scenes (profiles/r06/r06_ba_truncation_control*.json).
 """
 import numpy as np
 

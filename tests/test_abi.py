@@ -1,5 +1,6 @@
 """CPU: the C-ABI library exists, loads, and exports every symbol include/snake_hip.h declares."""
 import ctypes
+import os
 import re
 
 import pytest
@@ -103,6 +104,34 @@ def test_dist_entry_points_fail_loudly_without_a_device():
     if not torch.cuda.is_available():
         assert lib.snk_dist_get_unique_id(ident) != 0 or lib.snk_dist_init(ident, 0, 1, 0, C.byref(h)) != 0
         assert len(lib.snk_last_error()) > 0
+
+
+def test_rccl_that_cannot_be_opened_is_an_error_code_not_a_crash(tmp_path):
+    """rccl_open() on a box without a loadable RCCL (round-5 advisor: `dlerror() ? dlerror() : "?"` read the message twice, got NULL
+    the second time and built a std::string from it -- every snk_dist_* entry point died with SIGSEGV).  SNK_RCCL_LIB names a file
+    that is not a shared object and SNK_RCCL_STRICT forbids the fall-back to the system's copy: the header's SNK_ERR_NO_DEVICE comes
+    back, with both the path and the loader's message in the error text.  In a child process: the library caches an opened RCCL."""
+    import subprocess
+    import sys
+
+    bogus = tmp_path / "librccl_bogus.so.1"
+    bogus.write_bytes(b"not an ELF file")
+    code = (
+        "import ctypes as C\n"
+        "from snake_slam_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "v = C.c_int(0)\n"
+        "rc = lib.snk_dist_rccl_version(C.byref(v))\n"
+        "ident = (C.c_uint8 * 128)()\n"
+        "rc2 = lib.snk_dist_get_unique_id(ident)\n"
+        "print(rc, rc2, lib.snk_last_error().decode())\n"
+    )
+    env = dict(os.environ, SNK_RCCL_LIB=str(bogus), SNK_RCCL_STRICT="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=str(ROOT), timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])  # -11 before the fix
+    rc, rc2, text = r.stdout.strip().split(" ", 2)
+    assert int(rc) == 2 and int(rc2) == 2, r.stdout  # SNK_ERR_NO_DEVICE
+    assert "RCCL not found" in text and "librccl_bogus" in text and "?" not in text.split("librccl_bogus.so.1:")[1][:3], text
 
 
 def test_header_is_plain_c99(tmp_path):

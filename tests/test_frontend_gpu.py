@@ -265,3 +265,64 @@ def test_submit_and_collect_on_different_threads(orc):
             assert_same(g, want[k % len(pairs)], f"frame {k}")
     finally:
         fe.close()
+
+
+def test_submit_pinned_and_peek(orc):
+    """snk_frontend_submit_pinned (round 6: caller-owned page-locked images, no staging copy; Snake/Preprocess/Input.h:48) and
+    snk_frontend_peek (what the collecting thread sizes its arrays from): every array bit for bit what snk_frontend_process returns,
+    with the caller's pitch kept on the device (752: a multiple of four), with a padded pitch (768), with an odd pitch (755: the 2-D
+    copy), with left and right adjacent in memory (one upload) and apart (two), alternating with the staged submit on the same
+    slots (the recorded launch sequence is keyed by the row pitch), and for a mono handle."""
+    import ctypes as C
+
+    from snake_slam_amd import SnakeHipError, synth
+    from snake_slam_amd.frontend import Frontend
+    from snake_slam_amd.matcher import Rectification
+
+    orb = (1000, 1.2, 4, 20, 7)
+    bounds, bf = (-120.0, -60.0, 880.0, 540.0), 47.9
+    fe = Frontend(orb, Rectification.make(E_K, E_D), Rectification.make(E_K2, E_D2), bounds, bf)
+    pairs = [synth.stereo_frame(90 + k, 752, 480) for k in range(4)]
+    try:
+        want = [fe.Process(l, r) for l, r in pairs]
+        lib = fe._lib
+        w_, h_, cap = C.c_int(0), C.c_int(0), C.c_int(0)
+        assert lib.snk_frontend_peek(fe._h, 10, C.byref(w_), C.byref(h_), C.byref(cap)) == 6  # SNK_ERR_TIMEOUT: nothing submitted
+        for pitch in (752, 768, 755):
+            bufs = [fe.pinned_images(752, 480, 2, pitch) for _ in range(4)]    # adjacent: right = left + pitch * height
+            lone = [fe.pinned_images(752, 480, 1, pitch) for _ in range(4)]    # a right image somewhere else
+            for k, (l, r) in enumerate(pairs):
+                bufs[k][0, :, :752], bufs[k][1, :, :752] = l, r
+                lone[k][0, :, :752] = r
+            got = []
+            for rnd in range(3):  # uncaptured, captured, replayed on every slot
+                for k in range(4):
+                    right = bufs[k][1, :, :752] if (k + rnd) % 2 == 0 else lone[k][0, :, :752]
+                    fe.SubmitPinned(bufs[k][0, :, :752], right)
+                    if k == 1:
+                        assert lib.snk_frontend_peek(fe._h, -1, C.byref(w_), C.byref(h_), C.byref(cap)) == 0
+                        assert (w_.value, h_.value) == (752, 480) and cap.value == fe._frame.capacity
+                    if fe.in_flight() == 3:
+                        got.append(fe.Collect())
+                while fe.in_flight():
+                    got.append(fe.Collect())
+            assert len(got) == 12
+            for k, g in enumerate(got):
+                assert_same(g, want[k % 4], f"pitch {pitch} frame {k}")
+            # the staged submit in between (its rows have pitch 768 on the device), then pinned again
+            fe.Submit(*pairs[1]), fe.SubmitPinned(bufs[2][0, :, :752], bufs[2][1, :, :752]), fe.Submit(*pairs[3])
+            assert_same(fe.Collect(), want[1], "staged"), assert_same(fe.Collect(copy=False), want[2], "pinned"), assert_same(fe.Collect(), want[3], "staged")
+        rc = lib.snk_frontend_submit_pinned(fe._h, None, 752, None, 752, 752, 480)
+        assert rc == 1 and b"bad left image" in lib.snk_last_error()  # SNK_ERR_INVALID_ARG
+    finally:
+        fe.close()
+    mono = Frontend(orb, Rectification.make(E_K, E_D), None, bounds, bf, stereo=False)
+    try:
+        l = pairs[0][0]
+        want_m = mono.Process(l)
+        buf = mono.pinned_images(752, 480, 1)
+        buf[0] = l
+        mono.SubmitPinned(buf[0]), mono.SubmitPinned(buf[0])
+        assert_same(mono.Collect(), want_m, "mono 0"), assert_same(mono.Collect(), want_m, "mono 1")
+    finally:
+        mono.close()

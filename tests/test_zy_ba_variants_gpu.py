@@ -37,6 +37,7 @@ ROOT = Path(__file__).resolve().parent.parent
     {"SNK_BA_HOST_THREADS": "3", "SNK_BA_NO_SCHUR_SET": "1"},
     {"SNK_BA_NO_SCHUR_WIDE": "1", "SNK_BA_NO_SCHUR_SET": "1"},          # block-major schur_pass with one wavefront per block also for single windows
     {"SNK_BA_PCGL_LAUNCHES": "1"},                                      # global scenes: the multi-launch PCG (pcgl_matvec / combine / update / direction / latch) instead of the one cooperative launch (pcgl_persist)
+    {"SNK_BA_PERSIST_FAIL": "1"},                                       # global scenes: the runtime refuses the cooperative launch -> the handle falls back to the multi-launch PCG inside the same solve (round-5 advisor)
 ])
 def test_ba_parity_suite_with_forced_path(env):
     r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_ba_gpu.py"), "-m", "gpu", "-x", "-q", "-rf", "--tb=short",

@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstring>
+#include <memory>
 #include <fstream>
 #include <string>
 #include <thread>
@@ -99,6 +101,24 @@ int main(int argc, char** argv)
         double submit_us[3] = {0, 0, 0};  // mean time inside Submit, two-thread runs, per depth
         const int frames = calls * 5;
         bool same        = true;
+        // round 6: the same frames from caller-owned page-locked buffers (Frontend::SubmitPinned: no staging copy in Submit)
+        std::vector<std::unique_ptr<PinnedImage>> P;
+        for (int k = 0; k < n; ++k)
+        {
+            P.emplace_back(new PinnedImage(w, h, 2));
+            std::memcpy(P.back()->data(0), L[(size_t)k].data(), (size_t)w * h);
+            std::memcpy(P.back()->data(1), R[(size_t)k].data(), (size_t)w * h);
+        }
+        std::string pipes[2];
+        for (int pinned = 0; pinned < 2; ++pinned)
+        {
+        auto submit = [&](int k)
+        {
+            if (pinned)
+                fe.SubmitPinned(P[(size_t)k]->data(0), w, P[(size_t)k]->data(1), w, w, h);
+            else
+                fe.Submit(L[(size_t)k].data(), w, R[(size_t)k].data(), w, w, h);
+        };
         std::string pipe = "{";
         for (int depth = 2; depth <= 4; ++depth)
         {
@@ -114,7 +134,7 @@ int main(int argc, char** argv)
                         FrontendResult r;
                         for (int k = 0; k < count + depth - 1; ++k)
                         {
-                            if (k < count) fe.Submit(L[(size_t)(k % n)].data(), w, R[(size_t)(k % n)].data(), w, w, h);
+                            if (k < count) submit(k % n);
                             if (k >= depth - 1) { const int got = fe.Collect(r); same = same && got == want[(size_t)((k - depth + 1) % n)]; }
                         }
                     }
@@ -126,7 +146,7 @@ int main(int argc, char** argv)
                             for (int k = 0; k < count; ++k)
                             {
                                 const auto s0 = std::chrono::steady_clock::now();
-                                fe.Submit(L[(size_t)(k % n)].data(), w, R[(size_t)(k % n)].data(), w, w, h);
+                                submit(k % n);
                                 in_submit += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - s0).count();
                             }
                             submit_us[depth - 2] = in_submit / count;
@@ -145,10 +165,12 @@ int main(int argc, char** argv)
             pipe += buf;
         }
         pipe += "}";
+        pipes[pinned] = pipe;
+        }
         std::printf("{\"tool\": \"frontend_latency.cpp\", \"image\": \"%dx%d stereo\", \"calls\": %d, \"one_call_ms\": %.4f, \"six_calls_ms\": %.4f, "
                     "\"stereo_matches_last_frame\": {\"one_call\": %d, \"six_calls\": %d}, \"pipelined_frames\": %d, \"pipelined\": %s, "
-                    "\"pipelined_identical_match_counts\": %s}\n",
-                    w, h, calls, med[0], med[1], n_one, n_six, frames, pipe.c_str(), same ? "true" : "false");
+                    "\"pipelined_pinned\": %s, \"pipelined_identical_match_counts\": %s}\n",
+                    w, h, calls, med[0], med[1], n_one, n_six, frames, pipes[0].c_str(), pipes[1].c_str(), same ? "true" : "false");
         return n_one == n_six && same ? 0 : 3;
     }
     catch (const std::exception& e)
