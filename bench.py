@@ -353,6 +353,58 @@ def lockstep_sequence_mode(args, rank, world, local, dev, n_frames):
     trk.close()
 
 
+def harris_leg(args, step, stream, out_sets, step_no, n_sets, B):
+    """The headline batch once more with the Harris response as the corner measure (`"orb.response"` = 1: harris_kernel + the ranked
+    distribution): frames/s of the same step.  Returns the line's "harris" object and host copies of the
+    first frames' keypoints / descriptors of the last step (for cpu_baseline_harris).  Runs last: it overwrites the extractor's output sets."""
+    import torch
+
+    from snake_slam_amd import _lib as L_
+    from snake_slam_amd.orb import KEYPOINT_DTYPE
+
+    L_.set_definition("orb.response", 1)
+    try:
+        with torch.cuda.stream(stream):
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.harris_steps):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+        kps, desc, nkp = out_sets[(step_no[0] - 1) % n_sets]
+        out = {"metric": "stereo frames/s, the headline step with the Harris response as corner measure (orb.response = 1)",
+               "value": round(B * args.harris_steps / (t1 - t0), 1), "unit": "frames/s", "ms_per_step": round((t1 - t0) / args.harris_steps * 1e3, 4),
+               "steps": args.harris_steps}
+        hn, snap = nkp.cpu().numpy(), []
+        for b in range(min(4, B)):
+            for side in (0, 1):
+                row = b + side * B
+                n = int(hn[row])
+                snap.append((b, side, kps[row, :n].cpu().numpy().view(KEYPOINT_DTYPE).reshape(n), desc[row, :n].cpu().numpy().view(np.uint64)))
+        return out, snap
+    finally:
+        L_.set_definition("orb.response", 0)
+
+
+def cpu_baseline_harris(frames, n_dpairs, snap):
+    """The oracle under the same definition on the images `harris_leg` kept: bit for bit."""
+    from oracle import oracle as orc
+
+    orc.build()
+    orc.set_definition("orb.response", 1)
+    try:
+        p = orc.orb_params(ORB["nfeatures"], ORB["scale_factor"], ORB["n_levels"], ORB["ini_th_fast"], ORB["min_th_fast"])
+        same = True
+        for b, side, gk, gd in snap:
+            wk, wd = orc.orb_detect(p, frames[b % n_dpairs][side], threads=2)
+            same = same and len(gk) == len(wk) and all(np.array_equal(gk[f], wk[f]) for f in ("x", "y", "angle", "response", "octave")) and np.array_equal(gd, wd)
+        return {"identical_to_oracle": bool(same), "images_checked": len(snap)}
+    finally:
+        orc.set_definition("orb.response", 0)
+
+
 def kitti_leg(args):
     """BASELINE.json configs[2] (KITTI seq 00 stereo 1241x376, 2000 features, 7 levels; reference configs/kitti.ini:30-34) as part of the
     default line: this script once more with --workload kitti (front-end only, 512 stereo frames per step, outputs of the last step
@@ -361,7 +413,7 @@ def kitti_leg(args):
     import subprocess
 
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", "kitti", "--steps", str(args.kitti_steps), "--warmup", "2", "--batch", "512",
-           "--ba-windows", "0", "--gba-keyframes", "0", "--pose-frames", "0", "--track-frames", "0", "--frame-calls", "0", "--kitti-steps", "0",
+           "--ba-windows", "0", "--gba-keyframes", "0", "--pose-frames", "0", "--track-frames", "0", "--frame-calls", "0", "--kitti-steps", "0", "--harris-steps", "0",
            "--cpu-seconds", "3", "--check-frames", "16", "--distinct", "64"]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
@@ -411,6 +463,27 @@ def spawn_ranks_if_needed(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def measured_copy_bandwidth(dev, gib=1.0, reps=5):
+    """the achievable copy bandwidth of THIS device beside the 8 TB/s data-sheet peak -- a device-to-device copy of
+    `gib` GiB (torch's copy kernel), read + write bytes over the best of `reps` timings with HIP events."""
+    import torch
+
+    n = int(gib * (1 << 30))
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty(n, dtype=torch.uint8, device=dev)
+    a.zero_(), b.zero_()
+    best = 0.0
+    for _ in range(reps + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        best = max(best, 2.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    return {"value": round(best, 1), "unit": "GB/s", "how": f"device-to-device copy of {gib:g} GiB (read + write bytes), best of {reps}, HIP events, this run"}
 
 
 def _pipeline_traffic(section, sources):
@@ -478,6 +551,8 @@ def main():
     ap.add_argument("--check-frames", type=int, default=256, help="frames of the last timed step whose outputs in HBM are compared "
                     "bit for bit with the oracle's (those the CPU baseline reaches in its time budget)")
     ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events")
+    ap.add_argument("--harris-steps", type=int, default=20, help="steps of the Harris leg (the same batch under snk_set_definition(\"orb.response\", 1): "
+                    "north_star lists the Harris score among the hot-path kernels; 0 = skip; single GPU only)")
     ap.add_argument("--kitti-steps", type=int, default=20, help="steps of the KITTI leg of the default line (BASELINE.json configs[2]: 1241x376 stereo, 2000 "
                     "features, 7 levels; this script re-run with --workload kitti on 512 frames per step once the EuRoC legs are done, its line "
                     "embedded under \"kitti\"; 0 = skip; single GPU, euroc workload only)")
@@ -652,6 +727,25 @@ def main():
             torch.cuda.synchronize()
             barrier()
             tb1 = time.perf_counter()
+        # The same windows WITH their hand-over on the clock (round-5 review: `value` is a resident-data number; the reference pays
+        # `create(scene)` in every solve, LocalBundleAdjustment.cpp:357-365, and so does the CPU baseline beside it): snk_ba_set_problems
+        # (host list building on up to 16 threads + upload of the lists) followed by the three LM iterations, warm handle, median of 3.
+        ho_ms, ho_total_ms = [], []
+        with torch.cuda.stream(stream):
+            for _ in range(3):
+                torch.cuda.synchronize()
+                tw0 = time.perf_counter()
+                ba.create([distinct[k % n_dscenes] for k in range(NW)])
+                ba.sync()
+                tw1 = time.perf_counter()
+                ba.solve_async(LM_IT)
+                torch.cuda.synchronize()
+                tw2 = time.perf_counter()
+                # without what the Python binding spends turning numpy arrays into snk_ba_problem structs (a C++ host holds them already)
+                ho_ms.append((tw1 - tw0) * 1e3 - ba.last_pack_ms)
+                ho_total_ms.append((tw2 - tw0) * 1e3 - ba.last_pack_ms)
+        ho_warm = sorted(ho_ms)[1]
+        ho_total = parallel.max_over_ranks(sorted(ho_total_ms)[1] * 1e-3, dev)
         ci, cf = ba.solve(0)
         ba_check = None
         if verify:  # state of three windows after the LAST timed solve (reset + 3 LM iterations), compared with the oracle below
@@ -674,6 +768,11 @@ def main():
                   "windows_per_gpu_per_step": NW, "ms_per_step": round(float(tba.item()) / args.steps * 1e3, 4),
                   "single_window_ms_per_solve": round((tl1 - tl0) / 10 * 1e3, 4),
                   "ms_batch_hand_over_first": round((th1 - th0) * 1e3, 1),  # not part of `value`: windows are resident when the timed region starts
+                  "ms_batch_hand_over_warm": round(ho_warm, 1),
+                  # hand-over (snk_ba_set_problems: host-built lists + upload, every step) + solve on the clock -- the figure to set beside
+                  # cpu_baseline, whose oracle pays its set-up inside every solve too
+                  "value_with_hand_over": round(world * NW * LM_IT / ho_total, 1),
+                  "ms_per_step_with_hand_over": round(ho_total * 1e3, 2),
                   "cost_initial": round(float(ci[0]), 3), "cost_final": round(float(cf[0]), 3), "dtype": "f64",
                   "data": f"synthetic: {n_dscenes} distinct seeded scenes per rank over {NW} windows"}
         # ~5.65 MB algorithmic per LM iteration of the 20 x 2000 x 8 window
@@ -862,6 +961,34 @@ def main():
             tq0 = time.perf_counter()
             pipe_run(n_pipe)
             pipe_fps = max(pipe_fps, n_pipe / (time.perf_counter() - tq0))
+        # round 6: the same loop with caller-owned page-locked images (snk_frontend_submit_pinned: no staging copy inside submit)
+        pin_ = [fe.pinned_images(W, H, 2) for _ in range(8)]
+        for k in range(8):
+            pin_[k][0], pin_[k][1] = pairs[k]
+        pin_adr = [(int(q[0].ctypes.data), int(q[1].ctypes.data)) for q in pin_]
+
+        def pipe_run_pinned(count):
+            for k in range(count + depth_ - 1):
+                if k < count:
+                    a_l, a_r = pin_adr[k % 8]
+                    lib_.snk_frontend_submit_pinned(fe._h, a_l, W, a_r, W, W, H)
+                if k >= depth_ - 1:
+                    lib_.snk_frontend_collect(fe._h, C.byref(fe._frame), -1)
+
+        identical_pinned = True
+        for k in range(8 + depth_ - 1):
+            if k < 8:
+                fe.SubmitPinned(pin_[k][0], pin_[k][1])
+            if k >= depth_ - 1:
+                g_ = fe.Collect()
+                w_ = want[k - depth_ + 1]
+                identical_pinned = identical_pinned and all(np.array_equal(g_[key], w_[key]) for key in w_)
+        pipe_run_pinned(4 * depth_)
+        pipe_fps_pinned = 0.0
+        for _ in range(3):
+            tq0 = time.perf_counter()
+            pipe_run_pinned(n_pipe)
+            pipe_fps_pinned = max(pipe_fps_pinned, n_pipe / (time.perf_counter() - tq0))
         for hnd in (fe, ext1, pre1, grid1):
             hnd.close()
         # the same measurement without Python in the timed region: tools/cpp/frontend_latency.cpp through the C++ adaptor (built here with g++,
@@ -878,6 +1005,7 @@ def main():
                 cpp_ = {"tool": "tools/cpp/frontend_latency.cpp (snake_hip::Frontend, no Python in the timed region)",
                         "one_call_ms": cj["one_call_ms"], "six_calls_ms": cj["six_calls_ms"],
                         "pipelined_frames_per_s": {k: v for k, v in cj["pipelined"].items()},
+                        "pipelined_pinned_frames_per_s": {k: v for k, v in cj.get("pipelined_pinned", {}).items()},
                         "identical_match_counts": cj["pipelined_identical_match_counts"]}
         except Exception as e:  # noqa: BLE001
             cpp_ = {"error": repr(e)[:200]}
@@ -888,7 +1016,11 @@ def main():
                      "six_host_calls_ms": round(med["six_calls"], 4), "frames_per_s_one_call": round(1e3 / med["one_call"], 1),
                      "one_call_c_abi_ms": round(med["one_call_abi"], 4),
                      "pipelined": {"entry_points": "snk_frontend_submit / snk_frontend_collect (bare C ABI calls, one thread, one frame per call)",
-                                   "depth": depth_, "frames": n_pipe, "frames_per_s": round(pipe_fps, 1), "identical_to_process": bool(identical)},
+                                   "depth": depth_, "frames": n_pipe, "frames_per_s": round(pipe_fps, 1), "identical_to_process": bool(identical),
+                                   "pinned": {"entry_points": "snk_frontend_submit_pinned / snk_frontend_collect (caller-owned page-locked images: no staging copy)",
+                                              "frames_per_s": round(pipe_fps_pinned, 1), "identical_to_process": bool(identical_pinned)},
+                                   "supported_host": "the C++ adaptor (cpp_adaptor below) is the host layer a Snake-SLAM build uses; this Python loop pays two "
+                                                     "interpreter-level ctypes calls per frame"},
                      "cpp_adaptor": cpp_,
                      "stereo_matches_last_frame": n_st}
 
@@ -1058,7 +1190,9 @@ def main():
             achieved = alg_bytes / (fast_ms * 1e-3) / 1e9
             traffic = None
             valu = None
-            tj = ROOT / "profiles" / "fast_kernel_traffic.json"
+            # the counters of THIS workload (a KITTI image has 1.55 x the pixels of a EuRoC one, 7 levels, other FAST cells: the EuRoC pass
+            # scaled by the image count is not a KITTI measurement -- round-5 review; without its own pass the KITTI leg reports null)
+            tj = ROOT / "profiles" / ("fast_kernel_traffic.json" if args.workload == "euroc" else f"fast_kernel_traffic_{args.workload}.json")
             if tj.exists():
                 # PMC bytes of a separate rocprofv3 --pmc run (tools/profile_gpu.sh + tools/collect_traffic.py); only valid for the
                 # kernel source it was collected on: a file whose recorded source hash is not the current one is refused
@@ -1067,7 +1201,7 @@ def main():
 
                     t = json.loads(tj.read_text())
                     cur = hashlib.sha256((ROOT / t.get("source", "snake_slam_amd/csrc/orb.hip")).read_bytes()).hexdigest()
-                    if t.get("source_sha256") == cur and t.get("images_per_launch"):
+                    if t.get("source_sha256") == cur and t.get("images_per_launch") and t.get("workload", "euroc") == args.workload:
                         scale = images_per_launch / t.get("images_per_launch")
                         traffic = int(t.get("hbm_bytes_per_launch") * scale)
                         if t.get("valu_insts_per_launch"):
@@ -1079,12 +1213,18 @@ def main():
                             valu = {"instr_per_launch": int(n_valu), "issue_peak": peak, "unit": "wave64 VALU instructions/s",
                                     "achieved": round(n_valu / (fast_ms * 1e-3), 1), "frac": round(n_valu / (fast_ms * 1e-3) / peak, 4),
                                     "instr_per_wave": round(t["valu_insts_per_launch"] / max(1, t.get("waves_per_launch") or 1), 1),
-                                    "source": "SQ_INSTS_VALU of a separate rocprofv3 --pmc pass (profiles/fast_kernel_traffic.json)"}
+                                    "source": f"SQ_INSTS_VALU of a separate rocprofv3 --pmc pass (profiles/{tj.name})"}
                             if t.get("busy_cycles_per_launch"):  # the clock the chip actually held during the profiled launch
                                 valu["frac_at_profiled_clock"] = round(t["valu_insts_per_launch"] * 4.0 / (1024 * t["busy_cycles_per_launch"]), 4)
                 except Exception:
                     traffic, valu = None, None
-            out["roofline"] = {"bound": "hbm", "kernel": "fast_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            peak_meas = None
+            if world == 1:
+                try:
+                    peak_meas = measured_copy_bandwidth(dev)
+                except Exception as e:  # noqa: BLE001
+                    peak_meas = {"error": repr(e)[:120]}
+            out["roofline"] = {"bound": "hbm", "kernel": "fast_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "peak_measured": peak_meas,
                                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(fast_ms, 4),
                                "images_per_launch": images_per_launch, "launches_per_step": n_calls // args.steps,
@@ -1115,8 +1255,13 @@ def main():
             out["frontend_frame"] = frame_out
         if track_out is not None:
             out["tracking"] = track_out
+        harris_snap = None
+        if world == 1 and args.harris_steps > 0 and args.mode == "batch":
+            out["harris"], harris_snap = harris_leg(args, step, stream, out_sets, step_no, n_sets, B)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames, gpu_snapshot, seconds_budget=args.cpu_seconds)
+            if harris_snap:
+                out["harris"].update(cpu_baseline_harris(frames, n_dpairs, harris_snap))
             if ba_out is not None:
                 out["cpu_baseline"]["ba"] = cpu_baseline_ba(ba_check)
         if world == 1 and args.workload == "euroc" and args.mode == "batch" and args.kitti_steps > 0 and "WORLD_SIZE" not in os.environ:

@@ -82,10 +82,17 @@ class BARec:
             pass
 
     def create(self, scene_or_scenes) -> None:
+        import time
+
         scenes = scene_or_scenes if isinstance(scene_or_scenes, (list, tuple)) else [scene_or_scenes]
+        t0 = time.perf_counter()
         packed = [_pack(s) for s in scenes]
         arr = (BaProblem * len(packed))(*[p for p, _ in packed])
+        t1 = time.perf_counter()
         _lib.check(self._lib.snk_ba_set_problems(self._h, arr, len(packed)), "snk_ba_set_problems")
+        # what this binding adds (numpy -> snk_ba_problem structs) and what the C call took (bench.py reports them apart: a C++ host pays
+        # only the second); the call returns with the uploads enqueued, snk_ba_sync waits for them
+        self.last_pack_ms, self.last_set_problems_ms = (t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3
         self._scenes = scenes
 
     def _solve(self, iterations):

@@ -3021,7 +3021,9 @@ struct PcgLarge
     double* wrr;      // [2][PERSIST_WGS]  partial r.r  (by iteration parity)
     double* wrz;      // [2][PERSIST_WGS]  partial r.z
     double* wpap;     // [PERSIST_WGS]     partial p.Ap
-    unsigned* bar;    // [PERSIST_WGS_MAX] the grid barrier's per-workgroup phase flags (zeroed by pcgl_init)
+    unsigned* bar;    // [BAR_WORDS] the grid barrier's phase flags: per workgroup, per group of eight, per group generation (zeroed by pcgl_init)
+    int bar_flat;     // SNK_BA_FLAT_BARRIER=1: every workgroup polls every flag (the round-5 barrier)
+    int persist_one;  // pcgl_persist1 (one grid barrier per PCG iteration; r, z, p private in LDS) instead of pcgl_persist
     int persist_wgs;  // workgroups of the launch (all resident: cooperative launch)
 };
 constexpr int PERSIST_WGS_MAX = 1024;
@@ -3078,7 +3080,7 @@ __global__ __launch_bounds__(64) void pcgl_init(Arrays A, Opt O, PcgLarge W)
     rr = wave_sum64(rr);
     rz = wave_sum64(rz);
     if (pb == 0 && blockIdx.x == 0 && W.bar)
-        for (int i = threadIdx.x; i < PERSIST_WGS_MAX; i += 64) W.bar[i] = 0u;  // the grid barrier's flags of pcgl_persist
+        for (int i = threadIdx.x; i < PERSIST_WGS_MAX + 32 + 8 * 32 /* BAR_WORDS */; i += 64) W.bar[i] = 0u;  // the grid barrier's flags of pcgl_persist
     if (threadIdx.x == 0)
     {
         W.prr[(size_t)pb * W.G + blockIdx.x] = rr;  // buffer 0
@@ -3246,7 +3248,13 @@ __global__ void pcgl_latch(Arrays A, Opt O, PcgLarge W, int k)
 // Scalars (r.r, r.z, p.Ap, alpha, beta, the stopping test) are re-derived by every workgroup from the partial sums in a fixed
 // order: deterministic, no floating-point atomics.  The barrier is an arrival counter in HBM: __syncthreads, one agent-scope
 // release increment per workgroup, a spin on an agent-scope acquire load, __syncthreads.
-__device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned n_wgs, unsigned& phase)
+constexpr int BAR_PER_XCD = PERSIST_WGS_MAX / 8;      // arrival flags of group x at bar[x * BAR_PER_XCD + (workgroup >> 3)]
+constexpr int BAR_XFLAG   = PERSIST_WGS_MAX;          // the eight group flags, one 32-byte run
+constexpr int BAR_GEN     = PERSIST_WGS_MAX + 32;     // the groups' generation words, 128 bytes apart
+constexpr int BAR_WORDS   = BAR_GEN + 8 * 32;
+static_assert(BAR_WORDS <= 2 * (PERSIST_WGS_MAX + 8), "the barrier's words live in the (PERSIST_WGS_MAX + 8) doubles behind wpap");
+
+__device__ __forceinline__ void grid_barrier_flat(unsigned* bar, unsigned n_wgs, unsigned& phase)
 {
     // One flag per workgroup, no read-modify-write: an arrival counter costs one device-scope atomic per workgroup on ONE address, and
     // those are served one after the other at the memory side (the XCDs' L2s are not coherent with each other): 512 arrivals took
@@ -3267,6 +3275,65 @@ __device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned n_wgs, unsi
         __atomic_thread_fence(__ATOMIC_ACQUIRE);  // agent scope by default: the other workgroups' stores before their flags are visible
     }
     __syncthreads();
+}
+
+// The same barrier as a two-level tree (round 6; the round-5 review measured the flat form at ~8 us against the 4-6 us
+// MI355X_MICROARCH.md gives for an XCD-hierarchical barrier): in the flat form every workgroup polls every flag, i.e. n_wgs pollers
+// hammer the same few lines at the memory side, where same-line requests are served one after the other.  Here workgroup w belongs
+// to group w % 8 (the XCD it runs on under the round-robin dispatch -- a speed matter only, any grouping is correct); its members
+// publish their phase to the group's flag run, the group's leader (w < 8) waits for them, publishes the GROUP's flag, waits for the
+// eight group flags and releases its members through the group's generation word.  Pollers per line: the leader on its members' run,
+// eight leaders on the group flags, a group's members on their own generation word.  Still no read-modify-write anywhere.
+__device__ __forceinline__ void grid_barrier_xcd(unsigned* bar, unsigned n_wgs, unsigned& phase)
+{
+    __syncthreads();
+    ++phase;
+    if (threadIdx.x < 64)
+    {
+        const unsigned lane = threadIdx.x, x = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        const unsigned n_x = (n_wgs + 7u - x) >> 3;  // members of group x (workgroups x, x + 8, ...)
+        const unsigned groups = n_wgs < 8u ? n_wgs : 8u;
+        unsigned* flags = bar + x * BAR_PER_XCD;
+        unsigned* gen   = bar + BAR_GEN + 32u * x;
+        if (j != 0)
+        {
+            if (lane == 0)
+            {
+                __hip_atomic_store(flags + j, phase, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase) __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        else
+        {
+            for (;;)  // the members of this group
+            {
+                bool ok = true;
+                for (unsigned i = 1u + lane; i < n_x; i += 64) ok = ok && __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= phase;
+                if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            // (the members' data was written back by THEIR release stores before their flags became visible; this release covers the
+            // leader's own)
+            if (lane == 0) __hip_atomic_store(bar + BAR_XFLAG + x, phase, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            for (;;)  // the eight groups
+            {
+                const bool ok = lane >= groups || __hip_atomic_load(bar + BAR_XFLAG + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= phase;
+                if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0 && n_x > 1u) __hip_atomic_store(gen, phase, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);  // agent scope: every workgroup's stores before its arrival are visible
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned n_wgs, unsigned& phase, int flat)
+{
+    if (flat)  // grid-uniform (SNK_BA_FLAT_BARRIER=1: A/B against the round-5 form)
+        grid_barrier_flat(bar, n_wgs, phase);
+    else
+        grid_barrier_xcd(bar, n_wgs, phase);
 }
 
 // sum of n partials in a fixed order by one wavefront-sized group of threads: lane l adds entries l, l + 64, ... then a butterfly
@@ -3352,7 +3419,7 @@ __global__ __launch_bounds__(PERSIST_THREADS) void pcgl_persist(Arrays A, Opt O,
             __syncthreads();
             if (tid == 0) W.wpap[wg] = (sh_red[0][0] + sh_red[0][1]) + (sh_red[0][2] + sh_red[0][3]);
         }
-        grid_barrier(W.bar, NW, phase);
+        grid_barrier(W.bar, NW, phase, W.bar_flat);
         // ---- 2. update ----
         const double pAp = sum_partials_wave(W.wpap, NW, lane);
         if (pAp <= 0.0) break;  // grid-uniform (the reference's break: the step of this iteration is not applied)
@@ -3391,11 +3458,135 @@ __global__ __launch_bounds__(PERSIST_THREADS) void pcgl_persist(Arrays A, Opt O,
             }
             __syncthreads();
         }
-        grid_barrier(W.bar, NW, phase);
+        grid_barrier(W.bar, NW, phase, W.bar_flat);
         prr_prev = wrr;
         prz_prev = wrz;
         n_prev   = n_upd;
         rz_prev  = rz_cur;
+        ++iters;
+    }
+    if (wg == 0 && tid == 0) A.state[0].pcg_iters += iters;
+}
+
+// The same PCG with ONE grid barrier per iteration (round 6).  Of the two reductions of an iteration only p.Ap needs every workgroup's
+// rows; r.r and r.z of the next iteration are functions of r - alpha A p, which every workgroup can form for ALL n6 entries itself once
+// A p is known: 6 x 6 blocks against 299 cameras are ~11 k multiply-adds, a microsecond, against the ~6 us of a barrier.  So every
+// workgroup keeps private copies of r, z and p in LDS (identical in all workgroups: same inputs, same instruction sequence -- the
+// grid-uniform decisions stay grid-uniform), multiplies its rows of S, publishes A p and its share of p.Ap, waits at the ONE barrier,
+// and then updates r, z, r.r, r.z for the whole vector redundantly.  A p and the p.Ap partials alternate between two buffers: a
+// workgroup that is one iteration ahead (it cannot be two: the barrier) writes the other parity.  Same arithmetic per element as the
+// two-barrier form; the sums r.r / r.z run in this kernel's own fixed order (256 strided partials, four wavefronts).
+// LDS: 3 n6 doubles (n6 <= 6400: ~1060 free cameras; beyond that pcgl_persist).
+__global__ __launch_bounds__(PERSIST_THREADS) void pcgl_persist1(Arrays A, Opt O, PcgLarge W)
+{
+    extern __shared__ __attribute__((aligned(16))) double sh_all[];
+    __shared__ double sh_red[2][PERSIST_THREADS / 64];
+    const Prob pr  = A.prob[0];
+    const int n6   = pr.n6;
+    if (n6 == 0) return;  // every workgroup
+    double* sh_p = sh_all;             // the direction
+    double* sh_r = sh_all + n6;        // the residual
+    double* sh_z = sh_all + 2 * n6;    // the preconditioned residual
+    const int tid  = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NW   = gridDim.x;
+    const int wg   = blockIdx.x;
+    const double* S = A.S + pr.s_off;
+    const int rpw   = (n6 + NW - 1) / NW;
+    const int q0    = min(wg * rpw, n6), q1 = min(q0 + rpw, n6);
+    unsigned phase = 0;
+    // block-wide sums of two values per thread, every thread gets both (fixed order: wavefront butterflies, then the four wavefronts)
+    auto block_sum2 = [&](double a, double b, double& sa, double& sb)
+    {
+        a = wave_sum64(a);
+        b = wave_sum64(b);
+        __syncthreads();  // the previous round's readers are done
+        if (lane == 0) sh_red[0][wave] = a, sh_red[1][wave] = b;
+        __syncthreads();
+        sa = (sh_red[0][0] + sh_red[0][1]) + (sh_red[0][2] + sh_red[0][3]);
+        sb = (sh_red[1][0] + sh_red[1][1]) + (sh_red[1][2] + sh_red[1][3]);
+    };
+    // r, z from pcgl_init; |r|^2 and r.z in this kernel's order
+    double rn2, rz_cur;
+    {
+        double a = 0.0, b = 0.0;
+        for (int u = tid; u < n6; u += PERSIST_THREADS)
+        {
+            const double rv = W.r[u], zv = W.z[u];
+            sh_r[u] = rv;
+            sh_z[u] = zv;
+            sh_p[u] = 0.0;
+            a += rv * rv;
+            b += rv * zv;
+        }
+        block_sum2(a, b, rn2, rz_cur);
+    }
+    const double stop2 = O.pcg_tol * O.pcg_tol * rn2;
+    double rz_prev = 0.0;
+    int iters = 0;
+    for (int k = 0; k < O.max_pcg; ++k)
+    {
+        if (rn2 <= stop2) break;  // grid-uniform
+        const double beta = k == 0 ? 0.0 : rz_cur / rz_prev;
+        double* Ap   = (k & 1) ? W.p2 : W.Ap;                                   // the two A p buffers (p2 is free in this form)
+        double* wpap = W.wrr + (size_t)(k & 1) * PERSIST_WGS_MAX;               // ... and the two partial-sum buffers
+        for (int u = tid; u < n6; u += PERSIST_THREADS) sh_p[u] = sh_z[u] + beta * sh_p[u];
+        __syncthreads();
+        {
+            double pap = 0.0;
+            const int n2 = n6 >> 1;
+            const double2* sp2 = reinterpret_cast<const double2*>(sh_p);
+            for (int q = q0 + wave; q < q1; q += PERSIST_THREADS / 64)
+            {
+                const double2* row = reinterpret_cast<const double2*>(S + (size_t)q * n6);
+                double acc = 0.0;
+                int u = lane;
+                for (; u + 192 < n2; u += 256)  // four loads in flight
+                {
+                    const double2 s0 = row[u], s1 = row[u + 64], s2 = row[u + 128], s3 = row[u + 192];
+                    const double2 p0 = sp2[u], p1 = sp2[u + 64], p2 = sp2[u + 128], p3 = sp2[u + 192];
+                    acc += s0.x * p0.x; acc += s0.y * p0.y;
+                    acc += s1.x * p1.x; acc += s1.y * p1.y;
+                    acc += s2.x * p2.x; acc += s2.y * p2.y;
+                    acc += s3.x * p3.x; acc += s3.y * p3.y;
+                }
+                for (; u < n2; u += 64)
+                {
+                    const double2 s0 = row[u], p0 = sp2[u];
+                    acc += s0.x * p0.x; acc += s0.y * p0.y;
+                }
+                acc = wave_sum64(acc);
+                if (lane == 0)
+                {
+                    Ap[q] = acc;
+                    pap += sh_p[q] * acc;
+                }
+            }
+            if (lane == 0) sh_red[0][wave] = pap;
+            __syncthreads();
+            if (tid == 0) wpap[wg] = (sh_red[0][0] + sh_red[0][1]) + (sh_red[0][2] + sh_red[0][3]);
+        }
+        grid_barrier(W.bar, NW, phase, W.bar_flat);
+        const double pAp = sum_partials_wave(wpap, NW, lane);
+        if (pAp <= 0.0) break;  // grid-uniform (the reference's break: the step of this iteration is not applied)
+        const double alpha = rz_cur / pAp;
+        for (int u = tid; u < n6; u += PERSIST_THREADS) sh_r[u] -= alpha * Ap[u];
+        for (int q = q0 + tid; q < q1; q += PERSIST_THREADS) A.x[q] += alpha * sh_p[q];  // the rows' owner keeps the solution
+        __syncthreads();
+        double a = 0.0, b = 0.0;
+        for (int u = tid; u < n6; u += PERSIST_THREADS)
+        {
+            const int c = u / 6, ar = u - c * 6;
+            const double* Mi = W.Minv + (size_t)(pr.cam_off + c) * 36 + ar * 6;
+            const double* rc = sh_r + c * 6;
+            double zz = 0.0;
+            for (int bq = 0; bq < 6; ++bq) zz += Mi[bq] * rc[bq];
+            sh_z[u] = zz;
+            const double rv = sh_r[u];
+            a += rv * rv;
+            b += rv * zz;
+        }
+        rz_prev = rz_cur;
+        block_sum2(a, b, rn2, rz_cur);
         ++iters;
     }
     if (wg == 0 && tid == 0) A.state[0].pcg_iters += iters;
@@ -5007,7 +5198,8 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         W.wrr = w;          w += 2 * (size_t)PERSIST_WGS_MAX;
         W.wrz = w;          w += 2 * (size_t)PERSIST_WGS_MAX;
         W.wpap = w;         w += (size_t)PERSIST_WGS_MAX;
-        W.bar = reinterpret_cast<unsigned*>(w);
+        W.bar = reinterpret_cast<unsigned*>(w);  // (PERSIST_WGS_MAX + 8) doubles = 2064 words >= BAR_WORDS
+        W.bar_flat = getenv("SNK_BA_FLAT_BARRIER") != nullptr ? 1 : 0;
         // one problem, a cooperative launch the device can hold: two workgroups per compute unit (SNK_BA_PCGL_LAUNCHES=1: the
         // multi-launch form, A/B and the fallback for batches of large problems)
         W.persist_wgs = 0;
@@ -5034,6 +5226,13 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, reinterpret_cast<const void*>(pcgl_persist), PERSIST_THREADS, (size_t)max_n6 * 8) == hipSuccess &&
                         resident >= 1)
                         W.persist_wgs = std::min(wgs, resident * prop.multiProcessorCount);
+                    // the one-barrier form needs 3 n6 doubles of LDS (SNK_BA_PERSIST_TWO_BARRIERS=1: A/B, the round-5 form)
+                    W.persist_one = 0;
+                    if (W.persist_wgs > 0 && (size_t)max_n6 * 24 <= 150 * 1024 && getenv("SNK_BA_PERSIST_TWO_BARRIERS") == nullptr &&
+                        set_max_lds_once(reinterpret_cast<const void*>(pcgl_persist1), 150 * 1024) == SNK_OK &&
+                        hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, reinterpret_cast<const void*>(pcgl_persist1), PERSIST_THREADS, (size_t)max_n6 * 24) == hipSuccess &&
+                        resident >= 1 && resident * prop.multiProcessorCount >= W.persist_wgs)
+                        W.persist_one = 1;
                 }
             }
             (void)hipGetLastError();
@@ -5419,7 +5618,12 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L, bool only_marked =
                     if (fail_hook)
                         L.cooperative = false, L.err = hipErrorCooperativeLaunchTooLarge;
                     else
-                        LAUNCH(pcgl_persist, dim3(W.persist_wgs), dim3(PERSIST_THREADS), (size_t)h->max_n6 * 8, A, O, W);
+                    {
+                        if (W.persist_one)
+                            LAUNCH(pcgl_persist1, dim3(W.persist_wgs), dim3(PERSIST_THREADS), (size_t)h->max_n6 * 24, A, O, W);
+                        else
+                            LAUNCH(pcgl_persist, dim3(W.persist_wgs), dim3(PERSIST_THREADS), (size_t)h->max_n6 * 8, A, O, W);
+                    }
                     persisted = L.err == hipSuccess;
                     if (!persisted)
                     {

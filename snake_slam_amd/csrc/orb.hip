@@ -1873,7 +1873,16 @@ typedef u32 u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
 // (horizontal pass: 430 (row, dword) items, 3 LDS reads + 6 v_alignbyte + 8 v_dot4 + 2 LDS writes each; vertical pass: 370 items, 14 LDS
 // reads + 12 v_perm + 12 v_dot2 + 4 v_mad + packing + 1 LDS write each) and runs the steered tests on the result; level_kernel then skips
 // the store of the blurred level.  Measured in profiles/r05/r05v_blur_in_describe.txt.
-template <bool BLUR_IN>
+// DMA = true (round 6; the round-5 review's item 1b, SNK_ORB_DESC_DMA=1): the blurred patch goes from global memory straight into the
+// wavefront's LDS slice with gfx950's LDS-DMA loads (global_load_lds_dwordx4: a lane names a global address, the 64 x 16 bytes of the
+// instruction land side by side at the LDS address in M0) -- no patch registers (32 of the 94), no ds_write of the patch.  Two patch
+// buffers per wavefront: the patches of keypoints 0 and 1 are requested up front with everything else, the patch of keypoint s + 2 is
+// requested into the buffer keypoint s has just been tested from; counted s_waitcnt vmcnt keep the younger request in flight while a
+// keypoint is tested, which is why the kernel's global STORES all come at its end (loads return in order among themselves, stores do not
+// with respect to them).  Same bytes in the same LDS layout as the register path: identical results.
+// (Sixteen wavefronts per workgroup -- the 10 KB moment table shared by more wavefronts: 8 instead of 6 per SIMD at the DMA form's 60
+// registers -- was measured and is much slower, 2.0 against 1.37 ms: profiles/r06/r06d_ab_describe_16_wave_workgroups_negative.txt.)
+template <bool BLUR_IN, bool DMA = false>
 __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __restrict__ img0, int pitch0,
                                                        long long stride0, int aligned0, const u32* __restrict__ sel,
                                                        const u8* __restrict__ sel_score, const int* __restrict__ sel_cnt,
@@ -1884,8 +1893,11 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
     constexpr int PR     = BLUR_IN ? PATCH_R + 3 : PATCH_R;     // rows above / below the keypoint in the loaded window
     constexpr int PQUADS = (2 * PR + 1) * 3;                      // sixteen-byte items of the window
     constexpr int NB     = (PQUADS + 63) / 64;                    // loads per lane
+    static_assert(!(BLUR_IN && DMA), "the LDS-DMA form reads the blurred level");
+    constexpr int PBUF   = 64 * NB * 4;                           // dwords of one LDS-DMA patch buffer: NB instructions x 64 lanes x 16 bytes
     __shared__ uint2 mtab[4 * MOM_PAD];
-    __shared__ __attribute__((aligned(16))) u32 patch[4][(2 * PR + 1) * PATCH_DW + 16];
+    constexpr int WPB = 4;  // wavefronts per workgroup
+    __shared__ __attribute__((aligned(16))) u32 patch[WPB][DMA ? 2 * PBUF : (2 * PR + 1) * PATCH_DW + 16];
     __shared__ u32 hbuf[BLUR_IN ? 4 : 1][BLUR_IN ? (2 * PR + 1) * 20 : 1];  // horizontally blurred rows, 40 pixels x 16 bit
     const int tid  = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -1918,8 +1930,8 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
     if (bx == 0 && l == 0 && tid == 0) n_out[b] = total < out_cap ? total : out_cap;
     const LevelInfo& lv = L.lv[l];
     const int cnt_l     = cnts[l];
-    if (bx * 4 * DESC_KPW >= cnt_l) return;  // whole workgroup (the grid is sized for the largest level)
-    const int slot0     = (bx * 4 + wave) * DESC_KPW;
+    if (bx * WPB * DESC_KPW >= cnt_l) return;  // whole workgroup (the grid is sized for the largest level)
+    const int slot0     = (bx * WPB + wave) * DESC_KPW;
     const bool work     = slot0 < cnt_l && offset + slot0 < out_cap;  // whole wavefront
 
     const u8* src      = l == 0 ? img0 + (long long)b * stride0 : lv.base + (long long)b * lv.img_stride;
@@ -1963,8 +1975,23 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
     bool valid[DESC_KPW];
     int kxv[DESC_KPW], kyv[DESC_KPW], scv[DESC_KPW];
     u32x3_a4 dwv[DESC_KPW][2];
-    u32x4_a4 bpv[DESC_KPW][NB];
+    u32x4_a4 bpv[DMA ? 1 : DESC_KPW][NB];
     const long long sbase = (long long)b * L.total_slots + lv.slot_off;
+    // LDS-DMA request of keypoint s's blurred patch into buffer s & 1 of this wavefront (lanes past the last item are switched off)
+    auto dma_patch = [&](int s)
+    {
+        if constexpr (DMA)
+        {
+            const int xb = (kxv[s] - PR) & ~3;
+            const u8* bo = bsrc + ((long long)kyv[s] * bpitch + xb);
+            u32* dst     = &patch[wave][PBUF * (s & 1)];
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+                if (bok[k])
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bo + boff[k]),
+                                                     (__attribute__((address_space(3))) void*)(dst + 256 * k), 16, 0, 0);
+        }
+    };
 #pragma unroll
     for (int s = 0; s < DESC_KPW; ++s)
     {
@@ -1973,8 +2000,11 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
         kxv[s] = kyv[s] = scv[s] = 0;
 #pragma unroll
         for (int k = 0; k < 2; ++k) dwv[s][k] = u32x3_a4{0u, 0u, 0u};
+        if constexpr (!DMA)
+        {
 #pragma unroll
-        for (int k = 0; k < NB; ++k) bpv[s][k] = u32x4_a4{0u, 0u, 0u, 0u};
+            for (int k = 0; k < NB; ++k) bpv[s][k] = u32x4_a4{0u, 0u, 0u, 0u};
+        }
     }
     if (work)
     {
@@ -2000,13 +2030,22 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
 #pragma unroll
             for (int k = 0; k < 2; ++k)
                 if (aligned) dwv[s][k] = *reinterpret_cast<const u32x3_a4*>(mo + moff[k]);
+            if constexpr (!DMA)
+            {
 #pragma unroll
-            for (int k = 0; k < NB; ++k) bpv[s][k] = *reinterpret_cast<const u32x4_a4*>(bo + boff[k]);
+                for (int k = 0; k < NB; ++k) bpv[s][k] = *reinterpret_cast<const u32x4_a4*>(bo + boff[k]);
+            }
+        }
+        if constexpr (DMA)
+        {
+            // behind the moment-window loads (the moments are needed first): the first two patches
+            if (valid[0]) dma_patch(0);
+            if (valid[1]) dma_patch(1);
         }
     }
     {
         const uint2* g = reinterpret_cast<const uint2*>(&c_moment.v[0][0][0]);
-        for (int i = tid; i < 4 * MOM_PAD; i += 256) mtab[i] = g[i];
+        for (int i = tid; i < 4 * MOM_PAD; i += 64 * WPB) mtab[i] = g[i];
     }
     __syncthreads();
     if (!work) return;
@@ -2079,16 +2118,29 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
         sincos_deg(angle_l, sn_l, cs_l);
     }
 
-    const u8* pb = reinterpret_cast<const u8*>(patch[wave]);
+    u64 wordv[DMA ? DESC_KPW : 1][4];  // DMA: the descriptors wait for the stores at the end (wave-uniform: scalar registers)
 #pragma unroll
     for (int s = 0; s < DESC_KPW; ++s)
     {
         if (!valid[s]) break;  // wave-uniform
         const int kx = kxv[s], ky = kyv[s];
-        // blurred patch -> LDS (in-order per wavefront: the previous keypoint's reads are done)
+        const u8* pb = reinterpret_cast<const u8*>(DMA ? &patch[wave][PBUF * (s & 1)] : &patch[wave][0]);
+        if constexpr (DMA)
+        {
+            // the patch of keypoint s has landed when at most the younger request (keypoint s + 1's: NB instructions) is outstanding
+            if (s + 1 < DESC_KPW && valid[s + 1])
+                __builtin_amdgcn_s_waitcnt(0x0F70 | NB);  // vmcnt(NB), expcnt / lgkmcnt untouched
+            else
+                __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
+            __builtin_amdgcn_wave_barrier();
+        }
+        else
+        {
+            // blurred patch -> LDS (in-order per wavefront: the previous keypoint's reads are done)
 #pragma unroll
-        for (int k = 0; k < NB; ++k)
-            if (bok[k]) reinterpret_cast<u32x4_a16*>(patch[wave])[lane + 64 * k] = bpv[s][k];
+            for (int k = 0; k < NB; ++k)
+                if (bok[k]) reinterpret_cast<u32x4_a16*>(patch[wave])[lane + 64 * k] = bpv[s][k];
+        }
         if constexpr (BLUR_IN)
         {
             // 7 x 7 blur of the raw window in LDS: {18, 33, 49, 56, 49, 33, 18} / 256 per axis, exact 16-bit rows, one rounding -- the
@@ -2141,13 +2193,40 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
             }
             __builtin_amdgcn_wave_barrier();
         }
-        const float angle = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, angle_l), 16 * s));
         const float sn    = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sn_l), 16 * s));
         const float cs    = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cs_l), 16 * s));
 
         // 256 steered tests on the blurred patch; lane computes bits lane, lane+64, lane+128, lane+192
         const int pc = PATCH_R * (4 * PATCH_DW) + PATCH_R + ((kx - PATCH_R) & 3);  // patch byte of the keypoint
         u64 word[4];
+        if constexpr (DMA)
+        {
+            // The eight test bytes of a lane by ds_read_u8 in ONE assembly block with its own lgkmcnt wait: behind an LDS-DMA request the
+            // compiler guards every LDS read it knows of with s_waitcnt vmcnt(0) (it cannot tell the two patch buffers apart), which would
+            // also wait for the NEXT keypoint's patch just requested -- the counted vmcnt above is the only wait these reads need.
+            u32 adr[8], tb[8];
+            const u32 lds0 = (u32)(size_t)(const __attribute__((address_space(3))) u8*)pb + (u32)pc;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                {
+                    const float pxf = pt[k][2 * e], pyf = pt[k][2 * e + 1];
+                    const int ry    = __float2int_rn(pxf * sn + pyf * cs);
+                    const int rx    = __float2int_rn(pxf * cs - pyf * sn);
+                    adr[2 * k + e]  = lds0 + (u32)(ry * (4 * PATCH_DW) + rx);
+                }
+            asm volatile("ds_read_u8 %0, %8\n\tds_read_u8 %1, %9\n\tds_read_u8 %2, %10\n\tds_read_u8 %3, %11\n\t"
+                         "ds_read_u8 %4, %12\n\tds_read_u8 %5, %13\n\tds_read_u8 %6, %14\n\tds_read_u8 %7, %15\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(tb[0]), "=&v"(tb[1]), "=&v"(tb[2]), "=&v"(tb[3]), "=&v"(tb[4]), "=&v"(tb[5]), "=&v"(tb[6]), "=&v"(tb[7])
+                         : "v"(adr[0]), "v"(adr[1]), "v"(adr[2]), "v"(adr[3]), "v"(adr[4]), "v"(adr[5]), "v"(adr[6]), "v"(adr[7])
+                         : "memory");
+#pragma unroll
+            for (int k = 0; k < 4; ++k) word[k] = __ballot(tb[2 * k] < tb[2 * k + 1]);
+        }
+        else
+        {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
         {
@@ -2162,23 +2241,44 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
             }
             word[k] = __ballot(t[0] < t[1]);
         }
-        if (lane == 0)
-        {
-            const int oi = offset + slot0 + s;
-            snk_keypoint kp;
-            kp.x        = (float)kx * lv.scale;
-            kp.y        = (float)ky * lv.scale;
-            kp.size     = 31.0f * lv.scale;
-            kp.angle    = angle;
-            kp.response = sel_resp ? harris_unrank((u32)scv[s]) : (float)(scv[s] - 1);
-            kp.octave   = l;
-            kps[(long long)b * out_cap + oi] = kp;
-            u64* d = desc + ((long long)b * out_cap + oi) * 4;
-            d[0] = word[0];
-            d[1] = word[1];
-            d[2] = word[2];
-            d[3] = word[3];
         }
+        auto store_keypoint = [&](int s_, const u64 (&w)[4])
+        {
+            const float angle = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, angle_l), 16 * s_));
+            if (lane == 0)
+            {
+                const int oi = offset + slot0 + s_;
+                snk_keypoint kp;
+                kp.x        = (float)kxv[s_] * lv.scale;
+                kp.y        = (float)kyv[s_] * lv.scale;
+                kp.size     = 31.0f * lv.scale;
+                kp.angle    = angle;
+                kp.response = sel_resp ? harris_unrank((u32)scv[s_]) : (float)(scv[s_] - 1);
+                kp.octave   = l;
+                kps[(long long)b * out_cap + oi] = kp;
+                u64* d = desc + ((long long)b * out_cap + oi) * 4;
+                d[0] = w[0];
+                d[1] = w[1];
+                d[2] = w[2];
+                d[3] = w[3];
+            }
+        };
+        if constexpr (DMA)
+        {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wordv[s][k] = word[k];
+            // every test byte of this buffer has been consumed by the ballots above: the patch of keypoint s + 2 may overwrite it
+            if (s + 2 < DESC_KPW && valid[s + 2]) dma_patch(s + 2);
+            if (s == DESC_KPW - 1 || !valid[s + 1 < DESC_KPW ? s + 1 : s])  // (the second operand is only read for s < DESC_KPW - 1)
+            {
+                // the last keypoint of the wavefront: all stores now
+#pragma unroll
+                for (int s2 = 0; s2 <= s; ++s2) store_keypoint(s2, wordv[s2]);
+            }
+        }
+        else
+            store_keypoint(s, word);
+        (void)ky;
     }
 }
 }  // namespace
@@ -2796,12 +2896,18 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
     int max_slot = 1;
     for (int l = 0; l < L.n_levels; ++l) max_slot = L.lv[l].slot_cap > max_slot ? L.lv[l].slot_cap : max_slot;
     {
-        const int gx = ceil_div(max_slot, 4 * DESC_KPW);
         const int nb = batch >= 16 ? 8 * ceil_div(batch, 8) : batch;
         static const bool blur_in = getenv("SNK_ORB_BLUR_IN_DESCRIBE") != nullptr;  // experiment (round 5), see describe_kernel<true>
-        hipLaunchKernelGGL(blur_in ? describe_kernel<true> : describe_kernel<false>, dim3(gx * L.n_levels * nb), dim3(256), 0, st, L, images_dev, pitch,
-                           image_stride, aligned0, d_sel, d_selscore, d_selcnt, kps_dev, (u64*)desc_dev, n_dev, out_cap, gx, batch,
-                           getenv("SNK_ORB_DESC_FAKE") ? atoi(getenv("SNK_ORB_DESC_FAKE")) : 0, d_selresp);
+        // round 6: the blurred patch by LDS-DMA (describe_kernel<false, true>; same-box A/B 1.457 -> 1.398 ms per 2048 images,
+        // profiles/r06/r06c_ab_describe_lds_dma.txt).  SNK_ORB_DESC_NO_DMA=1: the register path
+        static const bool dma = getenv("SNK_ORB_DESC_NO_DMA") == nullptr;
+        const int dfake       = getenv("SNK_ORB_DESC_FAKE") ? atoi(getenv("SNK_ORB_DESC_FAKE")) : 0;
+        const int gx          = ceil_div(max_slot, 4 * DESC_KPW);
+        auto dk = describe_kernel<false, false>;
+        if (blur_in) dk = describe_kernel<true, false>;
+        else if (dma) dk = describe_kernel<false, true>;
+        hipLaunchKernelGGL(dk, dim3(gx * L.n_levels * nb), dim3(256), 0, st, L, images_dev, pitch, image_stride, aligned0, d_sel, d_selscore, d_selcnt,
+                           kps_dev, (u64*)desc_dev, n_dev, out_cap, gx, batch, dfake, d_selresp);
     }
     SNK_LAUNCH_CHECK();
     if (ev) SNK_HIP_CHECK(hipEventRecord((*ev)[5], st));

@@ -251,25 +251,33 @@ __device__ __forceinline__ FrameDev stage_frame_lds(const FrameDev& G, unsigned 
     unsigned char* p_tk   = p_rp + (((size_t)n * 4 + 15) & ~(size_t)15);
     unsigned char* p_cs   = p_tk + (((size_t)n + 15) & ~(size_t)15);
     const int tid = threadIdx.x;
+    // (unroll pragmas below: left alone the compiler unrolls these copies eight-fold -- the byte and float copies are one or two
+    // iterations per thread anyway -- and their addresses and loads in flight push two or three values of the callers, which hold 64
+    // registers for two workgroups per CU, into scratch)
     {
         const u32* src = reinterpret_cast<const u32*>(G.kps);
         u32* dst       = reinterpret_cast<u32*>(p_kps);
+#pragma unroll 2
         for (int i = tid; i < n * 6; i += nthreads) dst[i] = src[i];
     }
     {
         const uint4* src = G.desc;
         uint4* dst       = reinterpret_cast<uint4*>(p_desc);
+#pragma unroll 2
         for (int i = tid; i < n * 2; i += nthreads) dst[i] = src[i];
     }
     {
         const float* src = G.right_points;
         float* dst       = reinterpret_cast<float*>(p_rp);
+#pragma unroll 1
         for (int i = tid; i < n; i += nthreads) dst[i] = src[i];
         u8* dt = p_tk;
+#pragma unroll 1
         for (int i = tid; i < n; i += nthreads) dt[i] = G.taken[i];
     }
     {
         int* dst = reinterpret_cast<int*>(p_cs);
+#pragma unroll 1
         for (int i = tid; i < ncell1; i += nthreads) dst[i] = G.cell_start[i];
     }
     FrameDev F     = G;
@@ -674,8 +682,13 @@ __global__ __launch_bounds__(1024, SNK_TRACK_FRAME_WAVES_PER_EU) void coarse_fra
     const FrameDev G = frame_of(Fb, b);
     if (fused)
         for (int f = threadIdx.x; f < G.n; f += 1024) claim[f] = 0x7FFFFFFF;  // the barrier at the end of the staging covers it
-    const FrameDev F = stage_frame_lds(G, frame_lds, 1024);  // once per workgroup; the chunks of its share follow
-    const CamDev C = cams[b];
+    // The frame's camera (20 doubles) in LDS, not in scalar registers: as a by-value copy it took 40 of the ~100 scalar registers, the
+    // allocator parked scalars in lanes of vector registers and vector registers in scratch (12 bytes per lane, round-5 review);
+    // the projection reads it once per point as broadcast LDS reads.
+    __shared__ CamDev s_cam;
+    if (threadIdx.x < sizeof(CamDev) / 8) reinterpret_cast<double*>(&s_cam)[threadIdx.x] = reinterpret_cast<const double*>(cams + b)[threadIdx.x];
+    const FrameDev F = stage_frame_lds(G, frame_lds, 1024);  // once per workgroup; the chunks of its share follow (its closing barrier covers s_cam)
+    const CamDev& C = s_cam;
     for (int chunk = blockIdx.x; chunk * 1024 < m; chunk += gridDim.x)
     {
         const int i0 = (chunk * 16 + wave) * 64;
@@ -709,13 +722,20 @@ __global__ __launch_bounds__(1024, SNK_TRACK_FRAME_WAVES_PER_EU) void fine_frame
     const FrameDev G = frame_of(Fb, b);
     if (fused)
         for (int f = threadIdx.x; f < G.n; f += 1024) claim[f] = 0x7FFFFFFF;
+    // see coarse_frame_kernel: the camera in LDS instead of 40 scalar registers -- and here the pyramid scales too (37 more: the fine
+    // matcher indexes them per lane and reads log_f / s_last per point); 44 bytes of scratch per lane before
+    __shared__ CamDev s_cam;
+    __shared__ ScalesDev s_scales;
+    if (threadIdx.x < sizeof(CamDev) / 8) reinterpret_cast<double*>(&s_cam)[threadIdx.x] = reinterpret_cast<const double*>(cams + b)[threadIdx.x];
+    if (threadIdx.x == 64) s_scales = S;
     const FrameDev F = stage_frame_lds(G, frame_lds, 1024);
-    const CamDev C = cams[b];
+    const CamDev& C = s_cam;
+    const ScalesDev& SL = s_scales;
     for (int chunk = blockIdx.x; chunk * 1024 < m; chunk += gridDim.x)
     {
         const int i0 = (chunk * 16 + wave) * 64;
         if (i0 >= m) break;  // chunks ascend: nothing further for this wavefront (the barriers of the fused resolution come after the loop)
-        fine_wave64<WRITE_VALID>(F, C, S, pts + (size_t)b * m_cap, m, i0, 64, th, ratio, lane, best + (size_t)b * m_cap, visible + (size_t)b * m_cap,
+        fine_wave64<WRITE_VALID>(F, C, SL, pts + (size_t)b * m_cap, m, i0, 64, th, ratio, lane, best + (size_t)b * m_cap, visible + (size_t)b * m_cap,
                                  claim);
     }
     if (fused)

@@ -2,7 +2,11 @@
 """Turns the FETCH_SIZE / WRITE_SIZE passes of tools/profile_gpu.sh into profiles/fast_kernel_traffic.json, the file
 bench.py reads for `roofline.traffic`.
 
-usage: collect_traffic.py <gpurun_out/prof_TAG> <images_per_launch> [kernel name prefix, default snk::fast_kernel]
+usage: collect_traffic.py <gpurun_out/prof_TAG> <images_per_launch> [kernel name prefix, default snk::fast_kernel] [workload, default euroc]
+
+workload = kitti (a pass of tools/profile_gpu.sh run with `--workload kitti --batch 512`) writes profiles/fast_kernel_traffic_kitti.json:
+the KITTI leg of bench.py reads ITS OWN counters (a KITTI image has 1.55 x the pixels, 7 levels, other cell shapes); it no longer
+scales the EuRoC pass by the image count (round-5 review).
 
 Corrections (MI355X_MICROARCH.md, section HBM): on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide
 coalesced read (16 B per lane) -- fast_kernel's tile loader is `global_load_dwordx4`, so FETCH_SIZE is doubled;
@@ -42,6 +46,7 @@ def mean_counter(d: Path, counter: str, prefix: str):
 def main():
     d, images = Path(sys.argv[1]), int(sys.argv[2])
     prefix = sys.argv[3] if len(sys.argv) > 3 else "snk::fast_kernel"
+    workload = sys.argv[4] if len(sys.argv) > 4 else "euroc"
     fetch_kb, nf = mean_counter(d / "pmc_FETCH_SIZE", "FETCH_SIZE", prefix)
     write_kb, nw = mean_counter(d / "pmc_WRITE_SIZE", "WRITE_SIZE", prefix)
     if fetch_kb is None or write_kb is None:
@@ -54,7 +59,7 @@ def main():
     salu, _ = mean_counter(d / "pmc_sq", "SQ_INSTS_SALU", prefix)
     waves, _ = mean_counter(d / "pmc_sq", "SQ_WAVES", prefix)
     gui, _ = mean_counter(d / "pmc_sq2", "GRBM_GUI_ACTIVE", prefix)
-    out = {"kernel": "fast_kernel", "images_per_launch": images, "hbm_bytes_per_launch": hbm,
+    out = {"kernel": "fast_kernel", "workload": workload, "images_per_launch": images, "hbm_bytes_per_launch": hbm,
            "valu_insts_per_launch": None if valu is None else int(valu), "salu_insts_per_launch": None if salu is None else int(salu),
            "waves_per_launch": None if waves is None else int(waves), "busy_cycles_per_launch": None if gui is None else int(gui / 8),
            "raw": {"FETCH_SIZE_KB": round(fetch_kb, 1), "WRITE_SIZE_KB": round(write_kb, 1), "dispatches": [nf, nw], "run": d.name},
@@ -62,7 +67,7 @@ def main():
            "note": "MI355X_MICROARCH.md section HBM: gfx950 FETCH_SIZE = 1/2 of the bytes of a 16-B-per-lane coalesced read "
                    "(fast_kernel's tile loader is global_load_dwordx4) -> x2; WRITE_SIZE as reported; separate --pmc passes",
            "source": str(SOURCE.relative_to(ROOT)), "source_sha256": hashlib.sha256(SOURCE.read_bytes()).hexdigest()}
-    (ROOT / "profiles" / "fast_kernel_traffic.json").write_text(json.dumps(out, indent=1) + "\n")
+    (ROOT / "profiles" / ("fast_kernel_traffic.json" if workload == "euroc" else f"fast_kernel_traffic_{workload}.json")).write_text(json.dumps(out, indent=1) + "\n")
     print(json.dumps(out))
 
 

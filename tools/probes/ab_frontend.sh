@@ -5,7 +5,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 N=${1:-3}
 cd $REPO
 run() {
-  timeout 300 python bench.py --steps 40 --ba-windows 0 --gba-keyframes 0 --pose-frames 0 --track-frames 0 --frame-calls 0 --kitti-steps 0 --no-cpu-baseline 2>&1 | grep '"metric"' | python -c "
+  timeout 300 python bench.py --steps 40 --ba-windows 0 --gba-keyframes 0 --pose-frames 0 --track-frames 0 --frame-calls 0 --kitti-steps 0 --harris-steps 0 --no-cpu-baseline 2>&1 | grep '"metric"' | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); s=d['stage_ms_per_step']
 print('$1', round(d['value']), s['pyramid'], s['fast'], s['distribute'], s['describe'])"

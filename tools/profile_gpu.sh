@@ -7,7 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-overlap --distinct 16 --ba-windows 0 --frame-calls 0 --gba-keyframes 0 --kitti-steps 0 $*"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-overlap --distinct 16 --ba-windows 0 --frame-calls 0 --gba-keyframes 0 --kitti-steps 0 --harris-steps 0 $*"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $REPO/bench.py $ARGS > $OUT/trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o p -- python $REPO/bench.py $ARGS > $OUT/pmc_$C.log 2>&1
