@@ -893,12 +893,12 @@ def main():
         from snake_slam_amd.matcher import Preprocess, Rectification
         from snake_slam_amd.tracking import FeatureGrid
 
-        pairs = [synth.stereo_frame(900 + k, W, H) for k in range(8)]
+        fpairs = [synth.stereo_frame(900 + k, W, H) for k in range(8)]
         rect_ = Rectification.make((458.654, 457.296, 367.215, 248.375))
         orb_t = (ORB["nfeatures"], ORB["scale_factor"], ORB["n_levels"], ORB["ini_th_fast"], ORB["min_th_fast"])
         fe = Frontend(orb_t, rect_, rect_, (0.0, 0.0, float(W), float(H)), 47.9, device=local)
         ext1, pre1, grid1 = ORBExtractor(**ORB, device=local), Preprocess(local), FeatureGrid(local)
-        fe.Process(*pairs[0])
+        fe.Process(*fpairs[0])
         lib_ = L_.load()
 
         # both sides at the same layer: the Python wrappers (each allocates / copies its result arrays); the bare C ABI call is timed
@@ -922,35 +922,35 @@ def main():
         med = {}
         for name, fn in (("one_call", one_call), ("one_call_abi", one_call_abi), ("six_calls", six_calls)):
             for k in range(6):
-                fn(*pairs[k % 8])
+                fn(*fpairs[k % 8])
             ts = []
             for k in range(args.frame_calls):
                 t0 = time.perf_counter()
-                fn(*pairs[k % 8])
+                fn(*fpairs[k % 8])
                 ts.append(time.perf_counter() - t0)
             med[name] = float(np.median(ts)) * 1e3
         n_st = int(fe._frame.n_stereo)
         # the PIPELINED form (snk_frontend_submit / snk_frontend_collect: the reference's FeatureDetection -> Preprocess stage queue,
         # Snake/Preprocess/FeatureDetector.h:39): still one frame per call, `depth` frames in flight; bare C ABI calls from one thread
-        want = [fe.Process(*pairs[k]) for k in range(8)]
+        want = [fe.Process(*fpairs[k]) for k in range(8)]
         depth_ = 3
         fe.set_depth(depth_)
         identical = True
         for k in range(8 + depth_ - 1):  # checked pass through the wrappers (also takes every slot past its captured frame)
             if k < 8:
-                fe.Submit(*pairs[k])
+                fe.Submit(*fpairs[k])
             if k >= depth_ - 1:
                 g_ = fe.Collect()
                 w_ = want[k - depth_ + 1]
                 identical = identical and all(np.array_equal(g_[key], w_[key]) for key in w_)
         for k in range(8):
-            fe.Submit(*pairs[k]), fe.Collect()
+            fe.Submit(*fpairs[k]), fe.Collect()
         n_pipe = max(args.frame_calls * 5, 200)
 
         def pipe_run(count):
             for k in range(count + depth_ - 1):
                 if k < count:
-                    l_, r_ = pairs[k % 8]
+                    l_, r_ = fpairs[k % 8]
                     lib_.snk_frontend_submit(fe._h, l_.ctypes.data, W, r_.ctypes.data, W, W, H)
                 if k >= depth_ - 1:
                     lib_.snk_frontend_collect(fe._h, C.byref(fe._frame), -1)
@@ -964,7 +964,7 @@ def main():
         # round 6: the same loop with caller-owned page-locked images (snk_frontend_submit_pinned: no staging copy inside submit)
         pin_ = [fe.pinned_images(W, H, 2) for _ in range(8)]
         for k in range(8):
-            pin_[k][0], pin_[k][1] = pairs[k]
+            pin_[k][0], pin_[k][1] = fpairs[k]
         pin_adr = [(int(q[0].ctypes.data), int(q[1].ctypes.data)) for q in pin_]
 
         def pipe_run_pinned(count):

@@ -947,6 +947,7 @@ class Dist
     Dist(const Dist&)            = delete;
     Dist& operator=(const Dist&) = delete;
     int rank() const { return rank_; }
+    snk_dist* handle() const { return h_; }  // for snk_dist_rank (what the communicator itself reports)
     int world() const { return world_; }
 
     // all ranks' trajectories on every rank: result[r] = rank r's rows.  Two collectives: the longest trajectory (blocks are padded to

@@ -49,6 +49,8 @@ struct Rccl
     int (*AllReduce)(const void*, void*, size_t, int, int, rccl_comm, hipStream_t)        = nullptr;
     const char* (*GetErrorString)(int)                                                    = nullptr;
     int (*GetVersion)(int*)                                                               = nullptr;
+    int (*CommCount)(rccl_comm, int*)                                                     = nullptr;  // optional: what RCCL itself says
+    int (*CommUserRank)(rccl_comm, int*)                                                  = nullptr;  // optional
 };
 Rccl g_rccl;
 std::mutex g_rccl_mu;
@@ -94,6 +96,8 @@ int rccl_open()
     SNK_SYM(GetErrorString, "ncclGetErrorString")
     SNK_SYM(GetVersion, "ncclGetVersion")
 #undef SNK_SYM
+    *reinterpret_cast<void**>(&r.CommCount)    = dlsym(so, "ncclCommCount");
+    *reinterpret_cast<void**>(&r.CommUserRank) = dlsym(so, "ncclCommUserRank");
     g_rccl = r;
     return SNK_OK;
 }
@@ -247,8 +251,21 @@ int snk_dist_destroy(snk_dist* d)
 int snk_dist_rank(const snk_dist* d, int* rank, int* world)
 {
     SNK_REQUIRE(d != nullptr, "dist is NULL");
-    if (rank) *rank = d->rank;
-    if (world) *world = d->world;
+    int r = d->rank, w = d->world;
+    // what the COMMUNICATOR says (ncclCommCount / ncclCommUserRank), not what the caller passed in: a launcher check that all `world`
+    // ranks really joined one RCCL communicator (tools/run_all_gpus.py, tests/cpp/dist_driver.cpp)
+    if (d->comm && g_rccl.CommCount && g_rccl.CommUserRank)
+    {
+        SNK_RCCL_CHECK(g_rccl.CommCount(d->comm, &w));
+        SNK_RCCL_CHECK(g_rccl.CommUserRank(d->comm, &r));
+        if (w != d->world || r != d->rank)
+        {
+            set_error("snk_dist_rank: the communicator reports rank %d of %d, the handle was created as rank %d of %d", r, w, d->rank, d->world);
+            return SNK_ERR_HIP;
+        }
+    }
+    if (rank) *rank = r;
+    if (world) *world = w;
     return SNK_OK;
 }
 

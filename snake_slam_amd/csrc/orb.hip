@@ -571,6 +571,75 @@ __global__ __launch_bounds__(256, SNK_FAST_MIN_WAVES) void fast_kernel(Layout L,
         spilled = true;
     };
     const int lpy = lane >> 5, lpx = lane & 31;
+#ifdef SNK_FAST_PHASE_A_DWORDS
+    if constexpr (NQ != 0)
+    {
+        // Round 6 (the round-5 review's item 1a), built and MEASURED SLOWER -- an experiment build (-DSNK_FAST_PHASE_A_DWORDS), not the
+        // default: same-box A/B FAST 1.80 (byte form below) against 1.96 ms (this form), step 192.2 against 187.0 k frames/s
+        // (profiles/r06/r06g_ab_fast_phase_a_dwords_negative.txt); bit-exact in the extractor fuzzers (2 836 + 383 cases).  It removes 65
+        // of a cell's ~160 LDS instructions and adds ten v_perm plus two more ballot / prefix / branch groups per step: the kernel is
+        // bound by vector issue, not by the LDS pipe.  (Also: a step can add up to R x cw survivors, so it needs f_surv_cap >= that --
+        // true for the layout's own choice, not for the test's forced 128.)
+        // The quick test on whole tile DWORDS.  The byte form below read every operand with
+        // ds_read_u8 -- ten LDS instructions per 128 pixels, ~80 of a cell's ~160, in a kernel whose LDS pipe is as busy as its vector
+        // ALU (one LDS instruction per three vector ones, SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS 0.48).  Here a lane owns one aligned
+        // dword of a tile row = four pixels: it reads that dword with its two neighbours and the dwords three rows up and down (five
+        // dword reads, the compiler pairs them into ds_read2_b32: three LDS instructions per ~250 pixels), unpacks to the packed 16-bit
+        // form with v_perm_b32 (ten, what the byte reads did for free) and evaluates the same bound
+        //   ub = max(min(max(r0, r8), max(r4, r12)) - c, c - max(min(r0, r8), min(r4, r12)))
+        // on two register pairs.  Lanes = ncol dword columns x R rows (ncol = the dwords the cell's columns touch, 8..10 for 30-pixel
+        // cells; R = 64 / ncol rows per step).  Same survivors (as a set: the order of the list does not matter downstream).
+        const int c0   = (3 + sh) >> 2;
+        const int ncol = ((3 + sh + cw - 1) >> 2) - c0 + 1;                      // wave-uniform
+        const int R    = 64 / ncol;                                              // rows per step (ncol <= 16 for cells up to 52 pixels)
+        const int lr   = (lane * ((65536 + ncol - 1) / ncol)) >> 16;             // lane / ncol (exact for lane < 64, ncol <= 16)
+        const int lc   = lane - lr * ncol;
+        const int px0  = 4 * (c0 + lc) - 3 - sh;                                 // cell column of the dword's first pixel (may be < 0)
+        const bool lane_on = lr < R;
+        const u32* trow = tile_dw + 3 * TPD + (c0 + lc);                         // the dword of cell row 0
+        const int step_max = R * cw;                                             // survivors one step can add
+        bool okx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) okx[j] = lane_on && px0 + j >= 0 && px0 + j < cw;
+        for (int y0 = 0; y0 < ch; y0 += R)
+        {
+            if (ns + step_max > surv_cap) flush();  // wave-uniform
+            const int py     = y0 + lr;
+            const bool rowok = py < ch;
+            const u32* q     = trow + min(py, ch - 1) * TPD;                    // rows past the cell are clamped (their results are masked)
+            const u32 up = q[-3 * TPD], dn = q[3 * TPD], dm = q[-1], d = q[0], dp = q[1];
+            u32 ubw[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+            {
+                // pixels 2 hh, 2 hh + 1 of the dword in the 16-bit halves
+                const u32 sel  = hh ? 0x0c030c02u : 0x0c010c00u;
+                const u32 c    = __builtin_amdgcn_perm(0u, d, sel);
+                const u32 r0   = __builtin_amdgcn_perm(0u, dn, sel);
+                const u32 r8   = __builtin_amdgcn_perm(0u, up, sel);
+                const u32 r4   = __builtin_amdgcn_perm(dp, d, hh ? 0x0c060c05u : 0x0c040c03u);   // bytes j + 3 of {dp : d}
+                const u32 r12  = __builtin_amdgcn_perm(d, dm, hh ? 0x0c040c03u : 0x0c020c01u);   // bytes j + 1 of {d : dm}
+                const u32 hi   = pku_min(pku_max(r0, r8), pku_max(r4, r12));
+                const u32 lo   = pku_max(pku_min(r0, r8), pku_min(r4, r12));
+                ubw[hh]        = __builtin_bit_cast(u32, pk_max(pk_sub(hi, c), pk_sub(c, lo)));
+            }
+            const u32 code0 = ((u32)py << 6) + (u32)px0;  // (py << 6) | px of pixel 0 when it is valid; pixel j: + j
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                const u32 w   = ubw[j >> 1];
+                const bool sv = (j & 1) ? (int)w > ((min_th << 16) | 0xFFFF) : (int)(short)(w & 0xFFFFu) > min_th;
+                const bool on = sv && okx[j] && rowok;
+                const u64 m   = __builtin_amdgcn_ballot_w64(on);
+                if (on) surv[ns + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u))] = (u16)(code0 + (u32)j);
+                ns += __popcll(m);
+            }
+        }
+        (void)lpy;
+        (void)lpx;
+    }
+    else
+#endif
     if constexpr (NQ != 0)
     {
         // Compile-time pitch: FOUR rows of 32 pixels per step, two pixels per lane in the 16-bit halves of a register (rows

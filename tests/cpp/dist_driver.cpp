@@ -34,7 +34,10 @@ int main(int argc, char** argv)
         const auto stats = dist.GatherBlocks(Stats{(double)(37 + 11 * rank), 1000.0 + rank, 250.0 * rank, 0.5});
         FILE* f = fopen(argv[5], "w");
         if (!f) return 3;
-        fprintf(f, "rccl %d world %d\n", version, dist.world());
+        int c_rank = -1, c_world = -1;
+        snake_hip::check(snk_dist_rank(dist.handle(), &c_rank, &c_world), "snk_dist_rank");  // ncclCommUserRank / ncclCommCount of the communicator
+        if (c_rank != rank || c_world != world) return 4;
+        fprintf(f, "rccl %d world %d\n", version, c_world);
         for (int r = 0; r < world; ++r)
         {
             const auto want = trajectory_of(r);

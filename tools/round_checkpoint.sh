@@ -13,6 +13,9 @@ timeout 600 python bench.py 2>&1 | grep '"metric"' > gpurun_out/$TAG/bench_defau
 timeout 600 python bench.py --workload kitti --ba-windows 0 --gba-keyframes 0 --pose-frames 0 --track-frames 0 --kitti-steps 0 2>&1 | grep '"metric"' > gpurun_out/$TAG/bench_kitti.json
 bash tools/profile_gpu.sh $TAG > gpurun_out/$TAG/profile_gpu.log 2>&1
 python tools/collect_traffic.py gpurun_out/prof_$TAG 2048 > gpurun_out/$TAG/collect_traffic.log 2>&1 && cp profiles/fast_kernel_traffic.json gpurun_out/$TAG/fast_kernel_traffic.json
+# the KITTI leg's own counters (round 6: no longer the EuRoC pass scaled by the image count): 512 stereo frames = 1024 images per launch
+bash tools/profile_gpu.sh ${TAG}_kitti --workload kitti --batch 512 --pose-frames 0 --track-frames 0 > gpurun_out/$TAG/profile_gpu_kitti.log 2>&1
+python tools/collect_traffic.py gpurun_out/prof_${TAG}_kitti 1024 snk::fast_kernel kitti > gpurun_out/$TAG/collect_traffic_kitti.log 2>&1 && cp profiles/fast_kernel_traffic_kitti.json gpurun_out/$TAG/fast_kernel_traffic_kitti.json
 bash tools/profile_track.sh $TAG pmc > gpurun_out/$TAG/profile_track.log 2>&1
 bash tools/profile_ba.sh $TAG pmc > gpurun_out/$TAG/profile_ba.log 2>&1
 bash tools/profile_gba.sh $TAG pmc > gpurun_out/$TAG/profile_gba.log 2>&1
@@ -25,3 +28,5 @@ print('front-end', d['value'], d['ms_per_step'], d['roofline']['frac'], d.get('s
 print('ba', d['ba']['value'], 'tracking', d['tracking']['value'])
 "
 tail -5 gpurun_out/$TAG/latencies.log
+# BASELINE config 5 on every GPU of this node (one here): native RCCL gather + bench.py --gpus N --mode sequence
+timeout 900 python tools/run_all_gpus.py --out gpurun_out/$TAG/all_gpus --skip-batch > gpurun_out/$TAG/all_gpus.log 2>&1; tail -1 gpurun_out/$TAG/all_gpus.log
