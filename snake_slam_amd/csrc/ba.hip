@@ -4325,29 +4325,13 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     // work items of up to 128 points: see SET_CHUNK_BIG.  Needs the default point-major kernels (the A/B switches that select
     // the others are read here as well) and at most 8 free observations per point in EVERY problem (else the batch runs
     // point_wave + schur_mfma<4>), which is known only after a look at all of them.
+    // (decided behind the sizing pass below, which counts the free observations per point on the host threads: as a serial loop over
+    // every observation of the batch in front of everything else it was ~20 of a 1024-window hand-over's 53 ms of list time, round 6)
     bool big_items = false;
-    {
-        static const bool alt_paths = getenv("SNK_BA_NO_SCHUR_FUSED") || getenv("SNK_BA_NO_SCHUR_MFMA") || getenv("SNK_BA_NO_UPDATE_COST") ||
-                                      getenv("SNK_BA_FUSED_K10") || getenv("SNK_BA_NO_SCHUR_SET") || getenv("SNK_BA_NO_POINT_WAVE") ||
-                                      getenv("SNK_BA_NO_BIG_ITEMS");
-        if (count >= 256 && !alt_paths)
-        {
-            big_items = true;
-            std::vector<unsigned char> kfree;
-            for (int b = 0; b < count && big_items; ++b)
-            {
-                const snk_ba_problem& P = problems[b];
-                if (P.n_pt <= 0 || P.n_obs <= 0 || !P.obs_img || !P.obs_pt || !P.img_const) continue;
-                kfree.assign((size_t)P.n_pt, 0);
-                for (int o = 0; o < P.n_obs; ++o)
-                {
-                    const int i = P.obs_img[o], p = P.obs_pt[o];
-                    if (i < 0 || i >= P.n_img || p < 0 || p >= P.n_pt || P.img_const[i]) continue;
-                    if (++kfree[(size_t)p] > 8) big_items = false;
-                }
-            }
-        }
-    }
+    static const bool alt_paths = getenv("SNK_BA_NO_SCHUR_FUSED") || getenv("SNK_BA_NO_SCHUR_MFMA") || getenv("SNK_BA_NO_UPDATE_COST") ||
+                                  getenv("SNK_BA_FUSED_K10") || getenv("SNK_BA_NO_SCHUR_SET") || getenv("SNK_BA_NO_POINT_WAVE") ||
+                                  getenv("SNK_BA_NO_BIG_ITEMS");
+    const bool want_big_items = count >= 256 && !alt_paths;
     size_t blkrpc_logical = 0;   // entries of blk_rpc up to the current problem (materialised only for problems with constraints)
     bool dev_entries_ok = true;  // every problem can have its block entries built on the device
     std::vector<long long> ent_bound((size_t)count, 0);
@@ -4431,13 +4415,16 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         size_t img_at, pt_at, ps_at, obs_at;
         int orig_at;
         char dup;  // one camera twice on a point (device-built block entries are then off)
+        char k_over8;  // a point with more than eight free observations (work items of up to 128 points are then off)
     };
     std::vector<PreProb> pre((size_t)count);
     static const int host_threads_env = getenv("SNK_BA_HOST_THREADS") ? atoi(getenv("SNK_BA_HOST_THREADS")) : 0;
     int n_threads = 1;
     if (count >= 16)
     {
-        n_threads = host_threads_env > 0 ? host_threads_env : (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+        // up to 32 threads (round 6; 16 before): on the 256-thread hosts of the MI355X boxes a 1024-window hand-over builds its lists in 35
+        // instead of 53 ms with 32, no faster with 64 (profiles/r06/r06i_ba_handover_threads_before.txt)
+        n_threads = host_threads_env > 0 ? host_threads_env : (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
         n_threads = std::min(n_threads, count / 8);
     }
     else if (host_threads_env > 0 && count >= 2)
@@ -4497,7 +4484,24 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         }
         q.no  = no;
         q.dup = 0;
+        q.k_over8 = 0;
+        if (want_big_items && P.n_pt > 0 && P.n_obs > 0)
+        {
+            // work items of up to 128 points need at most 8 free observations per point in EVERY problem
+            std::vector<unsigned char> kfree((size_t)P.n_pt, 0);
+            for (int o = 0; o < P.n_obs; ++o)
+            {
+                const int i = P.obs_img[o], p = P.obs_pt[o];
+                if (i < 0 || i >= P.n_img || p < 0 || p >= P.n_pt || P.img_const[i]) continue;
+                if (++kfree[(size_t)p] > 8) q.k_over8 = 1;
+            }
+        }
     });
+    if (want_big_items)
+    {
+        big_items = true;
+        for (int b = 0; b < count; ++b) big_items = big_items && !pre[(size_t)b].k_over8;
+    }
     if (worker_failed.load())
     {
         set_error("snk_ba_set_problems: a list-building thread failed (out of host memory?)");
@@ -4583,6 +4587,39 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     }
     mark(0);
     mark(1);
+    // ---- batches: the observation arrays (0.85 of a batch's 1.1 GB) go over the bus NOW, while pass 3 and the merge below build the rest on
+    // the host (round 6: the upload of a 1024-window batch is ~20 ms of PCIe time that used to start when the last list was done).
+    // Everything in this table is final: pass 2 wrote it in place.  The kernel reads the handle's pinned vectors; nothing below touches them.
+    const bool early_upload = count >= 16;
+    if (early_upload)
+    {
+        CopyTab tabE;
+        tabE.n = 0;
+        int rcE;
+#define UPE(buf, vec) if ((rcE = upload(h->buf, vec, tabE)) != SNK_OK) return rcE
+        UPE(d_pose, pose);
+        UPE(d_pt, pt);
+        UPE(d_ptc, ptc);
+        UPE(d_camidx, camidx);
+        UPE(d_ptstart, ptstart);
+        UPE(d_oimg, oimg);
+        UPE(d_ocam, ocam);
+        UPE(d_optfree, optfree);
+        UPE(d_ouv, ouv2);
+        UPE(d_odepth, odepth);
+        UPE(d_oweight, oweight);
+        UPE(d_oorig, oorig);
+        UPE(d_optidx, optidx);
+#undef UPE
+        if (tabE.n > 0)
+        {
+            unsigned big = 0;
+            for (int e = 0; e < tabE.n; ++e) big = std::max(big, tabE.bytes[e]);
+            const int gxe = (int)std::min(256u, std::max(16u, big >> 16));
+            hipLaunchKernelGGL(copy_table_kernel, dim3(gxe, tabE.n), dim3(256), 0, h->stream, tabE);
+            SNK_LAUNCH_CHECK();
+        }
+    }
     // ---- pass 3: the camera lists and the point-major lists of every problem, built with PROBLEM-LOCAL offsets on the host threads; the
     // per-problem loop below appends them to the shared lists and relocates the offsets (positions in setpts / setpairs / cblkitems / ccitems,
     // partial-sum, camera-partial and record indices) by the running totals -- the same lists the serial builder wrote ----
@@ -5098,20 +5135,40 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     tab.n = 0;
 #define UP(buf, vec) if ((rc = upload(h->buf, vec, tab)) != SNK_OK) return rc
     UP(d_prob, probs);
-    UP(d_pose, pose);
-    UP(d_pose0, pose);
-    UP(d_pt, pt);
-    UP(d_pt0, pt);
-    UP(d_ptc, ptc);
-    UP(d_camidx, camidx);
-    UP(d_ptstart, ptstart);
-    UP(d_oimg, oimg);
-    UP(d_ocam, ocam);
-    UP(d_optfree, optfree);
-    UP(d_ouv, ouv2);
-    UP(d_odepth, odepth);
-    UP(d_oweight, oweight);
-    UP(d_oorig, oorig);
+    // batches: the second and third copies of the poses / points (the reset state, the trial points) are device-to-device copies behind
+    // the upload instead of two more trips over the bus (round 6: 100 MB of a 1024-window hand-over's 1.1 GB); a single window keeps the
+    // one launch
+    const bool dup_on_device = count >= 16;
+    CopyTab tab2;
+    tab2.n = 0;
+    auto dup = [&](DevBuf& dst, const DevBuf& src, size_t bytes) -> int
+    {
+        int rc2 = dst.reserve(std::max<size_t>(bytes, 1));
+        if (rc2 != SNK_OK || bytes == 0) return rc2;
+        SNK_REQUIRE(tab2.n < COPY_TAB_MAX && bytes < (1ull << 32), "scene list too large for the upload table");
+        tab2.src[tab2.n] = src.p, tab2.dst[tab2.n] = dst.p, tab2.bytes[tab2.n] = (unsigned)bytes;
+        ++tab2.n;
+        return SNK_OK;
+    };
+    if (!early_upload) { UP(d_pose, pose); }
+    if (!dup_on_device) { UP(d_pose0, pose); }
+    else if ((rc = dup(h->d_pose0, h->d_pose, pose.size() * sizeof(double))) != SNK_OK) return rc;
+    if (!early_upload) { UP(d_pt, pt); }
+    if (!dup_on_device) { UP(d_pt0, pt); }
+    else if ((rc = dup(h->d_pt0, h->d_pt, pt.size() * sizeof(double))) != SNK_OK) return rc;
+    if (!early_upload)
+    {
+        UP(d_ptc, ptc);
+        UP(d_camidx, camidx);
+        UP(d_ptstart, ptstart);
+        UP(d_oimg, oimg);
+        UP(d_ocam, ocam);
+        UP(d_optfree, optfree);
+        UP(d_ouv, ouv2);
+        UP(d_odepth, odepth);
+        UP(d_oweight, oweight);
+        UP(d_oorig, oorig);
+    }
     UP(d_camstart, camstart);
     UP(d_camitems, camitems);
     if ((rc = h->d_csobs.reserve(std::max<size_t>(camitems.size(), 1) * sizeof(CamObs))) != SNK_OK) return rc;  // gather_cam_records
@@ -5134,14 +5191,15 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         UP(d_blkstart, blkstart);
         UP(d_blkent, blkent);
     }
-    UP(d_optidx, optidx);
+    if (!early_upload) { UP(d_optidx, optidx); }
     UP(d_wvpt, wvpt);
     UP(d_rpcmeta, rpcmeta);
     UP(d_rpcnext, rpcnext);
     UP(d_camrpcstart, camrpcstart);
     UP(d_camrpcitems, camrpcitems);
     UP(d_blkrpc, blkrpc);
-    UP(d_pt_new, pt);  // points without observations stay put
+    if (!dup_on_device) { UP(d_pt_new, pt); }  // points without observations stay put
+    else if ((rc = dup(h->d_pt_new, h->d_pt, pt.size() * sizeof(double))) != SNK_OK) return rc;
     const auto t_up = std::chrono::steady_clock::now();
     const size_t nobs = (size_t)std::max(obs_off, 1), npt = (size_t)std::max(pt_off, 1);
 #define RS(buf, bytes) if ((rc = h->buf.reserve(bytes)) != SNK_OK) return rc
@@ -5277,6 +5335,11 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         const int gx = (int)std::min(256u, std::max(16u, big >> 16));
         hipLaunchKernelGGL(copy_table_kernel, dim3(gx, tab.n), dim3(256), 0, st, tab);
         SNK_LAUNCH_CHECK();
+        if (tab2.n > 0)
+        {
+            hipLaunchKernelGGL(copy_table_kernel, dim3(gx, tab2.n), dim3(256), 0, st, tab2);  // stream-ordered behind the upload
+            SNK_LAUNCH_CHECK();
+        }
     }
     if (!h->pcg_large)
     {
