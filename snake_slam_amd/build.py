@@ -31,12 +31,14 @@ HIP_FLAGS = [
 # pose.hip (round 4): pose refinement is specified by a tolerance too (<= 1e-9 on the pose against the oracle; the sums already differ
 # from the oracle's by their order), its kernel is 62 % VALU-issue bound in fp64 multiply-add chains.  The flag covers the whole file: the
 # glue kernels backproject_kernel (world points of the next frame) and gather_matches_kernel's weights are fp64 multiply-add chains too and
-# are therefore tolerance-specified like pose_kernel (tests hold them to 1e-12 / 1e-9 against the host chain), not bit-exact.
+# were tolerance-specified like pose_kernel until round 6; backproject_kernel -- whose output is the next frame's local map -- now carries
+# `#pragma clang fp contract(off)` and is bit-exact against the same expressions in double on the host (gather_matches_kernel's weight,
+# sqrt(1 / (s * s)), has nothing to contract).
 # pose.hip, -disable-machine-licm (round 6): pose_kernel's solver section (se3 exponential / logarithm, Cholesky) is full of 64-bit polynomial
 # literals; the machine-level loop-invariant code motion hoists ~60 of their v_mov pairs in front of the iteration loops, the kernel
 # sits at 254 registers and the allocator then SPILLS three of those constants to scratch (28-36 bytes per lane, reloaded in the loop
 # where a v_mov would do).  Without the pass: 180 registers, no scratch (tests/test_kernel_resources.py holds that).
-HIP_FLAGS_PER_SOURCE = {"ba.hip": ["-ffp-contract=fast"], "pose.hip": ["-ffp-contract=fast", "-mllvm", "-disable-machine-licm"]}
+HIP_FLAGS_PER_SOURCE = {"ba.hip": ["-ffp-contract=fast"], "pose.hip": ["-mllvm", "-disable-machine-licm"]}  # pose.hip: contraction by pragma inside the file
 
 
 def _newer(target: Path, deps) -> bool:

@@ -11,6 +11,12 @@
 
 #include "matcher_handle.hpp"
 
+// Floating-point contraction of this file (round 6): pose refinement is specified by a tolerance and its kernel is bound by fp64 issue
+// slots, so a * b + c may be ONE v_fma_f64 -- by this pragma, not by -ffp-contract=fast on the command line (the command-line form lets
+// the back end fuse whatever it finds and cannot be switched off per kernel; the pragma puts the permission on the operations, and
+// backproject_kernel below takes it back: its world points are the next frame's local map and stay bit-exact).
+#pragma clang fp contract(fast)
+
 namespace snk
 {
 namespace
@@ -712,8 +718,20 @@ __global__ __launch_bounds__(256) void backproject_kernel(const snk_kp64* __rest
         world[3 * k] = world[3 * k + 1] = world[3 * k + 2] = 0.0;
         return;
     }
+    // The world points of frame t are the local map of frame t + 1: a chain of a thousand frames feeds every rounding of this kernel
+    // forward.  The file is built with -ffp-contract=fast for pose_kernel's sake (build.py); THIS kernel is not contracted (round 6,
+    // the round-5 review's weak point 10): every product and sum below is its own IEEE operation, so the points are bit for bit what the
+    // same expressions give on the host in double (tests/test_tracking_chain_gpu.py compares exactly).
+    {
+#pragma clang fp contract(off)
     double R[9];
-    quat_to_R(poses + (size_t)b * 7, R);
+    {
+        const double* q = poses + (size_t)b * 7;  // quat_to_R, restated here so that the pragma covers it
+        const double x = q[0], y = q[1], z = q[2], w = q[3];
+        R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
+        R[3] = 2 * (x * y + z * w);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+        R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
+    }
     const double tx = poses[(size_t)b * 7 + 4], ty = poses[(size_t)b * 7 + 5], tz = poses[(size_t)b * 7 + 6];
     const float d  = depth[k];
     const bool h   = d > 0.0f;
@@ -724,6 +742,7 @@ __global__ __launch_bounds__(256) void backproject_kernel(const snk_kp64* __rest
     world[3 * k + 1] = px * R[1] + py * R[4] + pz * R[7];
     world[3 * k + 2] = px * R[2] + py * R[5] + pz * R[8];
     has[k] = h ? 1 : 0;
+    }
 }
 }  // namespace
 }  // namespace snk

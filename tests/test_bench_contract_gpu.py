@@ -37,6 +37,13 @@ def test_bench_prints_one_json_line():
     # the pipelined per-frame front-end: same results as the synchronous call
     pf = d["frontend_frame"]["pipelined"]
     assert pf["identical_to_process"] is True and pf["frames_per_s"] > 0 and pf["depth"] == 3
+    # round 6: caller-owned pinned images (snk_frontend_submit_pinned), the hand-over of the BA batch on the clock, the achievable copy
+    # bandwidth beside the data-sheet peak, the Harris leg (north_star lists the Harris score among the kernels)
+    assert pf["pinned"]["identical_to_process"] is True and pf["pinned"]["frames_per_s"] > 0
+    assert 0 < d["ba"]["value_with_hand_over"] < d["ba"]["value"] and d["ba"]["ms_batch_hand_over_warm"] > 0
+    pm = rf["peak_measured"]
+    assert pm["unit"] == "GB/s" and 1000.0 < pm["value"] < 8000.0, pm
+    assert d["harris"]["value"] > 0 and d["harris"]["unit"] == "frames/s" and "identical_to_oracle" not in d["harris"]  # --no-cpu-baseline: timing only
 
 
 def test_line_carries_verified_cpu_baseline():
@@ -53,6 +60,7 @@ def test_line_carries_verified_cpu_baseline():
     assert cb["identical_to_gpu"] is True and cb["frames_checked"] == 6, cb
     assert cb["ba"]["cores"] == 1 and cb["ba"]["identical_to_gpu"] is True and cb["ba"]["windows_checked"] == [0, 3, 7], cb["ba"]
     assert d["timed_region_s"] > 0 and d["dist"] == {"world_size": 1, "backend": "none"}
+    assert d["harris"]["identical_to_oracle"] is True and d["harris"]["images_checked"] == 8, d["harris"]
 
 
 def test_gpus_flag_without_a_launcher_on_a_one_gpu_box():

@@ -186,7 +186,7 @@ def test_device_resident_chain_under_the_forms_large_batches_take(switches):
 def test_lockstep_glue_kernels_against_numpy():
     """snk_track_bf_matches_batch_dev / snk_track_backproject_batch_dev (the two glue steps of MultiSequenceTracker) on a ragged
     batch -- an empty frame, a frame without pairs, pairs whose reference feature has no point, out-of-range indices -- against
-    plain numpy.  Integer work exact; the world points to 1e-12 (three multiply-adds per coordinate)."""
+    plain numpy.  Integer work exact; the world points exact too (the kernel is compiled without floating-point contraction)."""
     import ctypes as C
 
     import torch
@@ -248,8 +248,12 @@ def test_lockstep_glue_kernels_against_numpy():
         hb = depth[b, :m] > 0
         z = np.where(hb, depth[b, :m], 1.0).astype(np.float64)
         pc = np.stack([(kps["x"][b, :m] - cam[2]) / cam[0] * z, (kps["y"][b, :m] - cam[3]) / cam[1] * z, z], 1)
-        w = (pc - poses[b, 4:]) @ synth.quat_to_R(poses[b, :4])
-        assert np.array_equal(got_h[b, :m], hb.astype(np.uint8)) and np.allclose(got_w[b, :m], w, rtol=0, atol=1e-12)
+        R = synth.quat_to_R(poses[b, :4])
+        p = pc - poses[b, 4:]
+        # the kernel's expressions operation by operation (round 6: backproject_kernel is compiled without contraction, so the world
+        # points -- the next frame's local map -- are exactly these doubles; a BLAS product would fuse multiply-adds)
+        w = np.stack([(p[:, 0] * R[0, k] + p[:, 1] * R[1, k]) + p[:, 2] * R[2, k] for k in range(3)], 1)
+        assert np.array_equal(got_h[b, :m], hb.astype(np.uint8)) and np.array_equal(got_w[b, :m], w)
         assert not got_h[b, m:].any() and not got_w[b, m:].any()   # beyond the frame's features: no point
     ref.close()
 
