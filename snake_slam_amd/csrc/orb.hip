@@ -2024,7 +2024,7 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
         bok[k]         = item < PQUADS;
         const int ib   = bok[k] ? item : PQUADS - 1;
         const int rb   = (ib * 171) >> 9;
-        boff[k]        = dbg_fake == 1 ? 16 * ib : (rb - PR) * bpitch + 16 * (ib - rb * 3);
+        boff[k]        = (dbg_fake == 1 || dbg_fake == 4) ? 16 * ib : (rb - PR) * bpitch + 16 * (ib - rb * 3);  // 4: only the PATCH from one contiguous run (timing experiment)
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k)
