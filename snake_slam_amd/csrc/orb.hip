@@ -124,7 +124,14 @@ struct LevelInfo
     const int* xw1;
     const int* yofs;
     const int* yw1;
+    long long blur_stride;  // bytes between consecutive images of the BLURRED level: pitch x (h rounded up to 4) -- room for the tiled layout
 };
+
+// Tiled layout of the blurred planes (round 6, an EXPERIMENT -- see orb_blur_mode): a 128-byte line holds 32 pixels x 4 rows, so the
+// 37 x 40-pixel patch describe_kernel reads per keypoint touches ~23 lines instead of ~51 (measured upper bound with contiguous
+// patches: 1.39 -> 1.135 ms, profiles/r06/r06o_*).  Byte of pixel (x, y): (y >> 2) * 4 * pitch + (x >> 5) * 128 + (y & 3) * 32 + (x & 31).
+__device__ __forceinline__ u32 blur_tiled_x(int x) { return (u32)(((x >> 5) << 7) + (x & 31)); }
+__device__ __forceinline__ u32 blur_tiled_y(int y, int pitch) { return (u32)((y >> 2) * 4 * pitch + ((y & 3) << 5)); }
 
 // what fast_kernel reads of a level: the head of LevelInfo, taken with one 32-byte load
 struct LevelHead
@@ -970,7 +977,8 @@ __device__ __forceinline__ u32 dot2(u32 pair, u32 w, u32 acc)
 template <bool ALIGNED, int BH>
 __global__ __launch_bounds__(256, SNK_LEVEL_MIN_WAVES) void level_kernel(Layout L, int l, const u8* __restrict__ img0, int pitch0, long long stride0,
                                                     int make_next, int gx, int batch, int n_bands,
-                                                    int no_blur_store /* SNK_ORB_BLUR_IN_DESCRIBE=1 (experiment): the blurred level is not written */)
+                                                    int blur_mode /* 0: the blurred level row-major, 2: tiled 32 x 4 (describe_kernel's LDS-DMA form reads that),
+                                                                     1: not written at all (SNK_ORB_BLUR_IN_DESCRIBE=1, experiment) */)
 {
     constexpr int SM_ROWS = BH + 6;
     static_assert(BH <= 64, "lane r of the wavefront keeps the row map of source row yb0 + r");
@@ -1016,7 +1024,9 @@ __global__ __launch_bounds__(256, SNK_LEVEL_MIN_WAVES) void level_kernel(Layout 
                    ((u32)((l2 == la ? 0 : 4) + (xr2 & 3)) << 16) | ((u32)((l3 == la ? 0 : 4) + (xr3 & 3)) << 24);
     }
     const bool border_strip = aligned && __any(!col_ok);  // wave-uniform
-    u8* blur = lv.blur + (long long)b * lv.img_stride;
+    u8* blur = lv.blur + (long long)b * lv.blur_stride;
+    const bool no_blur_store = blur_mode == 1, blur_tiled = blur_mode == 2;
+    const u32 xl_store       = blur_tiled ? blur_tiled_x(max(xl, 0)) : (u32)xl;  // the lane's column part of its store address (loop-invariant)
     const u32 W0123 = 18u | (33u << 8) | (49u << 16) | (56u << 24);
     const u32 W456  = 49u | (33u << 8) | (18u << 16);
 
@@ -1159,7 +1169,7 @@ __global__ __launch_bounds__(256, SNK_LEVEL_MIN_WAVES) void level_kernel(Layout 
                     {
                         const u32 lo = __builtin_amdgcn_perm(a[1], a[0], 0x0c0c0602u);
                         const u32 hi = __builtin_amdgcn_perm(a[3], a[2], 0x06020c0cu);
-                        *reinterpret_cast<u32*>(blur + (u32)(yo * bpitch) + (u32)xl) = lo | hi;
+                        *reinterpret_cast<u32*>(blur + (blur_tiled ? blur_tiled_y(yo, bpitch) : (u32)(yo * bpitch)) + xl_store) = lo | hi;
                     }
                 }
 #pragma unroll
@@ -1951,7 +1961,10 @@ typedef u32 u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
 // with respect to them).  Same bytes in the same LDS layout as the register path: identical results.
 // (Sixteen wavefronts per workgroup -- the 10 KB moment table shared by more wavefronts: 8 instead of 6 per SIMD at the DMA form's 60
 // registers -- was measured and is much slower, 2.0 against 1.37 ms: profiles/r06/r06d_ab_describe_16_wave_workgroups_negative.txt.)
-template <bool BLUR_IN, bool DMA = false>
+// TILED = true (with DMA): the blurred plane is in the 32 x 4 tiled layout (blur_tiled_x / _y): the patch is 37 rows of FOUR 16-byte
+// chunks at 16-pixel-aligned columns (no chunk straddles a tile; 40 needed pixels at any alignment fit 64), 148 items = three LDS-DMA
+// instructions, 64-byte patch rows in LDS.
+template <bool BLUR_IN, bool DMA = false, bool TILED = false>
 __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __restrict__ img0, int pitch0,
                                                        long long stride0, int aligned0, const u32* __restrict__ sel,
                                                        const u8* __restrict__ sel_score, const int* __restrict__ sel_cnt,
@@ -1963,7 +1976,11 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
     constexpr int PQUADS = (2 * PR + 1) * 3;                      // sixteen-byte items of the window
     constexpr int NB     = (PQUADS + 63) / 64;                    // loads per lane
     static_assert(!(BLUR_IN && DMA), "the LDS-DMA form reads the blurred level");
-    constexpr int PBUF   = 64 * NB * 4;                           // dwords of one LDS-DMA patch buffer: NB instructions x 64 lanes x 16 bytes
+    static_assert(!TILED || DMA, "the tiled blurred plane is read by the LDS-DMA form only");
+    constexpr int PROW   = TILED ? 16 : PATCH_DW;                 // dwords of a patch row in LDS
+    constexpr int TITEMS = (2 * PATCH_R + 1) * 4;                 // TILED: 148 sixteen-byte items
+    constexpr int NBT    = TILED ? (TITEMS + 63) / 64 : NB;       // LDS-DMA instructions per patch
+    constexpr int PBUF   = TILED ? TITEMS * 4 : 64 * NB * 4;      // dwords of one LDS-DMA patch buffer (TILED: lanes past the last item are switched off)
     __shared__ uint2 mtab[4 * MOM_PAD];
     constexpr int WPB = 4;  // wavefronts per workgroup
     __shared__ __attribute__((aligned(16))) u32 patch[WPB][DMA ? 2 * PBUF : (2 * PR + 1) * PATCH_DW + 16];
@@ -2007,7 +2024,7 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
     const int pitch    = l == 0 ? pitch0 : lv.pitch;
     // dbg_fake == 2 (SNK_ORB_DESC_FAKE=2, timing experiment only, results meaningless): the patch from the RAW level, i.e. the rows the
     // moment window reads anyway -- the memory side of "blur inside describe_kernel" (one window per keypoint instead of two)
-    const u8* bsrc     = (dbg_fake == 2 || BLUR_IN) ? src : lv.blur + (long long)b * lv.img_stride;
+    const u8* bsrc     = (dbg_fake == 2 || BLUR_IN) ? src : lv.blur + (long long)b * lv.blur_stride;
     const int bpitch   = (dbg_fake == 2 || BLUR_IN) ? pitch : lv.pitch;
     const bool aligned = l == 0 ? aligned0 != 0 : true;
 
@@ -2049,7 +2066,26 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
     // LDS-DMA request of keypoint s's blurred patch into buffer s & 1 of this wavefront (lanes past the last item are switched off)
     auto dma_patch = [&](int s)
     {
-        if constexpr (DMA)
+        if constexpr (DMA && TILED)
+        {
+            // item = (row r, chunk c): 16 bytes at column xb + 16 c (a multiple of 16: inside one 32-pixel tile) of row ky - 18 + r
+            const int xb = (kxv[s] - PATCH_R) & ~15, y0 = kyv[s] - PATCH_R;
+            u32* dst     = &patch[wave][PBUF * (s & 1)];
+#pragma unroll
+            for (int k = 0; k < NBT; ++k)
+            {
+                const int it = lane + 64 * k;
+                if (it < TITEMS)
+                {
+                    const int r = it >> 2, c = it & 3;
+                    const int x = min(xb + 16 * c, bpitch - 16);  // the fourth chunk may lie right of the plane: any bytes will do, inside the plane
+                    const u8* g = bsrc + (size_t)(blur_tiled_y(y0 + r, bpitch) + blur_tiled_x(x));
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                     (__attribute__((address_space(3))) void*)(dst + 256 * k), 16, 0, 0);
+                }
+            }
+        }
+        else if constexpr (DMA)
         {
             const int xb = (kxv[s] - PR) & ~3;
             const u8* bo = bsrc + ((long long)kyv[s] * bpitch + xb);
@@ -2198,7 +2234,7 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
         {
             // the patch of keypoint s has landed when at most the younger request (keypoint s + 1's: NB instructions) is outstanding
             if (s + 1 < DESC_KPW && valid[s + 1])
-                __builtin_amdgcn_s_waitcnt(0x0F70 | NB);  // vmcnt(NB), expcnt / lgkmcnt untouched
+                __builtin_amdgcn_s_waitcnt(0x0F70 | NBT);  // vmcnt(NBT), expcnt / lgkmcnt untouched
             else
                 __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
             __builtin_amdgcn_wave_barrier();
@@ -2266,7 +2302,8 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
         const float cs    = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cs_l), 16 * s));
 
         // 256 steered tests on the blurred patch; lane computes bits lane, lane+64, lane+128, lane+192
-        const int pc = PATCH_R * (4 * PATCH_DW) + PATCH_R + ((kx - PATCH_R) & 3);  // patch byte of the keypoint
+        const int pc = TILED ? PATCH_R * (4 * PROW) + PATCH_R + ((kx - PATCH_R) & 15)       // patch byte of the keypoint
+                             : PATCH_R * (4 * PATCH_DW) + PATCH_R + ((kx - PATCH_R) & 3);
         u64 word[4];
         if constexpr (DMA)
         {
@@ -2283,7 +2320,7 @@ __global__ __launch_bounds__(256) void describe_kernel(Layout L, const u8* __res
                     const float pxf = pt[k][2 * e], pyf = pt[k][2 * e + 1];
                     const int ry    = __float2int_rn(pxf * sn + pyf * cs);
                     const int rx    = __float2int_rn(pxf * cs - pyf * sn);
-                    adr[2 * k + e]  = lds0 + (u32)(ry * (4 * PATCH_DW) + rx);
+                    adr[2 * k + e]  = lds0 + (u32)(ry * (4 * PROW) + rx);
                 }
             asm volatile("ds_read_u8 %0, %8\n\tds_read_u8 %1, %9\n\tds_read_u8 %2, %10\n\tds_read_u8 %3, %11\n\t"
                          "ds_read_u8 %4, %12\n\tds_read_u8 %5, %13\n\tds_read_u8 %6, %14\n\tds_read_u8 %7, %15\n\t"
@@ -2446,6 +2483,7 @@ static int compute_layout(snk_orb* o, int w, int h)
         slot_off += lv.slot_cap;
         lv.pitch      = (lv.w + 63) & ~63;
         lv.img_stride = (long long)lv.pitch * lv.h;
+        lv.blur_stride = (long long)lv.pitch * ((lv.h + 3) & ~3);
         // streaming blur: balanced strips of <= 62 dwords, bands of 64 rows
         if (lv.w > 0 && lv.h > 0)
         {
@@ -2707,7 +2745,7 @@ int snk_orb_configure(snk_orb* o, int width, int height, int max_batch)
     }
     for (int l = 0; l < L.n_levels; ++l)
     {
-        if ((rc = o->blur[l].reserve((size_t)L.lv[l].img_stride * max_batch + 64)) != SNK_OK) return rc;
+        if ((rc = o->blur[l].reserve((size_t)L.lv[l].blur_stride * max_batch + 256)) != SNK_OK) return rc;
         L.lv[l].blur = o->blur[l].as<u8>();
     }
     {
@@ -2785,6 +2823,17 @@ int snk_orb_max_keypoints(const snk_orb* o, int* out)
 // One launch chain over images [b0, b0 + batch) of a call on stream `st`: every per-image buffer is indexed
 // relative to the chain's first image, so the bases are simply advanced by b0 images.
 // stages: 1 = the front half (pyramid / blur passes + FAST cells), 2 = the back half (distribution + descriptors), 3 = both
+// Layout of the blurred planes for this process (level_kernel writes it, describe_kernel reads it -- both ask here): 0 = row-major (the
+// default), 2 = tiled 32 x 4 (SNK_ORB_BLUR_TILED=1, an experiment of round 6: built, bit-exact, MEASURED SLOWER -- describe_kernel
+// 1.39 -> 1.32 ms, but level_kernel's stores, 16-byte pieces of 47 lines per row instead of two whole lines, cost 1.50 -> 1.74 ms:
+// 191.6 -> 187.9 k frames/s, profiles/r06/r06p_ab_blur_tiled_negative.txt), 1 = no blurred plane (SNK_ORB_BLUR_IN_DESCRIBE=1).
+static int orb_blur_mode()
+{
+    static const int mode = getenv("SNK_ORB_BLUR_IN_DESCRIBE") ? 1
+                            : (getenv("SNK_ORB_BLUR_TILED") && !getenv("SNK_ORB_DESC_NO_DMA") && !getenv("SNK_ORB_DESC_FAKE")) ? 2 : 0;
+    return mode;
+}
+
 static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* images_dev, int pitch, long long image_stride,
                     int batch, snk_keypoint* kps_dev, uint64_t* desc_dev, int32_t* n_dev, int out_cap, int stages = 3)
 {
@@ -2792,7 +2841,7 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
     for (int l = 0; l < L.n_levels; ++l)
     {
         if (L.lv[l].base) L.lv[l].base += (long long)b0 * L.lv[l].img_stride;
-        if (L.lv[l].blur) L.lv[l].blur += (long long)b0 * L.lv[l].img_stride;
+        if (L.lv[l].blur) L.lv[l].blur += (long long)b0 * L.lv[l].blur_stride;
     }
     images_dev += (long long)b0 * image_stride;
     kps_dev += (long long)b0 * out_cap;
@@ -2878,7 +2927,7 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
                                : (bh == 22 ? (al ? level_kernel<true, 22> : level_kernel<false, 22>) : (al ? level_kernel<true, 8> : level_kernel<false, 8>));
             hipLaunchKernelGGL(lk, xcd_grid(gx, batch), dim3(256), 0, st, L, l, images_dev, pitch, image_stride,
                                fused && l + 1 < L.n_levels && L.lv[l + 1].w > 0 && L.lv[l + 1].h > 0 ? 1 : 0, gx, batch, n_bands,
-                               getenv("SNK_ORB_BLUR_IN_DESCRIBE") ? 1 : 0);
+                               orb_blur_mode());
         }
         SNK_LAUNCH_CHECK();
     }
@@ -2972,9 +3021,10 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
         static const bool dma = getenv("SNK_ORB_DESC_NO_DMA") == nullptr;
         const int dfake       = getenv("SNK_ORB_DESC_FAKE") ? atoi(getenv("SNK_ORB_DESC_FAKE")) : 0;
         const int gx          = ceil_div(max_slot, 4 * DESC_KPW);
-        auto dk = describe_kernel<false, false>;
-        if (blur_in) dk = describe_kernel<true, false>;
-        else if (dma) dk = describe_kernel<false, true>;
+        auto dk = describe_kernel<false, false, false>;
+        if (blur_in) dk = describe_kernel<true, false, false>;
+        else if (dma && orb_blur_mode() == 2) dk = describe_kernel<false, true, true>;
+        else if (dma) dk = describe_kernel<false, true, false>;
         hipLaunchKernelGGL(dk, dim3(gx * L.n_levels * nb), dim3(256), 0, st, L, images_dev, pitch, image_stride, aligned0, d_sel, d_selscore, d_selcnt,
                            kps_dev, (u64*)desc_dev, n_dev, out_cap, gx, batch, dfake, d_selresp);
     }
