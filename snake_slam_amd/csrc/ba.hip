@@ -3919,6 +3919,47 @@ struct CopyTab
 // ---- scene lists built on the device -------------------------------------------------------------------------------------------
 // The static per-camera observation records (what cam_pass streams) are a gather of the sorted observation arrays through the
 // camera lists: 40 bytes per observation that neither the host loop nor the bus has to touch.
+// Batches (round 6): three of the sorted observation arrays and the camera lists are functions of arrays that are on the device anyway --
+// 13 of the 53 bytes per observation a hand-over used to carry over the bus (210 MB of a 1024-window batch's 1.07 GB).
+//   o_pt[s]     = the point whose run [pt_start[p], pt_start[p + 1]) holds s (binary search),
+//   o_cam[s]    = cam_idx[o_img[s]],   o_ptfree[s] = !pt_const[o_pt[s]]
+__global__ __launch_bounds__(256) void derive_obs_fields(Arrays A, int* __restrict__ o_pt, int* __restrict__ o_cam, unsigned char* __restrict__ o_ptfree)
+{
+    const Prob pr = A.prob[blockIdx.y];
+    const int s   = blockIdx.x * 256 + threadIdx.x;
+    if (s >= pr.no) return;
+    const int* ps = A.pt_start + pr.ptstart_off;
+    int lo = 0, hi = pr.np;  // ps[lo] <= s < ps[hi]
+    while (hi - lo > 1)
+    {
+        const int mid = (lo + hi) >> 1;
+        if (ps[mid] <= s) lo = mid;
+        else hi = mid;
+    }
+    const int go  = pr.obs_off + s;
+    o_pt[go]      = lo;
+    o_cam[go]     = A.cam_idx[pr.img_off + A.o_img[go]];
+    o_ptfree[go]  = A.pt_const[pr.pt_off + lo] ? 0 : 1;
+}
+// cam_items of camera c = the observations s with o_cam[s] == c in ascending s (the host builder's order): one wavefront per (camera,
+// problem) walks the observations 64 at a time and compacts by ballot.  cam_start comes from the host (nfc + 1 ints per problem).
+__global__ __launch_bounds__(64) void derive_cam_items(Arrays A, const int* __restrict__ o_cam, int* __restrict__ cam_items)
+{
+    const Prob pr = A.prob[blockIdx.y];
+    const int c   = blockIdx.x;
+    if (c >= pr.nfc) return;
+    const int lane = threadIdx.x;
+    int at = pr.citem_off + A.cam_start[pr.camstart_off + c];
+    for (int s0 = 0; s0 < pr.no; s0 += 64)
+    {
+        const int s    = s0 + lane;
+        const bool hit = s < pr.no && o_cam[pr.obs_off + s] == c;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+        if (hit) cam_items[at + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = s;
+        at += __popcll(m);
+    }
+}
+
 __global__ __launch_bounds__(256) void gather_cam_records(Arrays A, CamObs* __restrict__ out)
 {
     const Prob pr = A.prob[blockIdx.y];
@@ -4231,6 +4272,7 @@ int snk_ba_destroy(snk_ba* h)
 {
     if (!h) return SNK_OK;
     (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);  // an upload of a hand-over (it reads the handle's pinned lists) or a solve may still be in flight
     // every device buffer of the handle (the struct's DevBuf members)
     DevBuf* all[] = {&h->d_setitems, &h->d_setpts, &h->d_setpairs, &h->d_setobs, &h->d_cblkstart, &h->d_cblkitems, &h->d_spart,
                      &h->d_prob, &h->d_state, &h->d_pose, &h->d_pose_new, &h->d_pose0, &h->d_pt, &h->d_pt_new,
@@ -4430,14 +4472,16 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     else if (host_threads_env > 0 && count >= 2)
         n_threads = std::min(host_threads_env, count);  // tests force the threaded form on small batches
     std::atomic<bool> worker_failed{false};
+    int pf_lo = 0, pf_hi = count;  // the problems a parallel_for covers (the fill pass of a batch runs in chunks, see below)
     auto parallel_for = [&](auto&& body)
     {
+        const int lo = pf_lo, hi = pf_hi;
         if (n_threads <= 1)
         {
-            for (int b = 0; b < count; ++b) body(b);
+            for (int b = lo; b < hi; ++b) body(b);
             return;
         }
-        std::atomic<int> next{0};
+        std::atomic<int> next{lo};
         std::vector<std::thread> pool;
         // an exception in a worker (the vectors it grows: std::bad_alloc) must not reach std::terminate: it is caught, the remaining
         // work is abandoned and the caller turns worker_failed into an error code after the join
@@ -4448,8 +4492,8 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                 for (;;)
                 {
                     const int b0 = next.fetch_add(8);
-                    if (b0 >= count || worker_failed.load(std::memory_order_relaxed)) return;
-                    for (int b = b0; b < std::min(b0 + 8, count); ++b) body(b);
+                    if (b0 >= hi || worker_failed.load(std::memory_order_relaxed)) return;
+                    for (int b = b0; b < std::min(b0 + 8, hi); ++b) body(b);
                 }
             }
             catch (...)
@@ -4522,7 +4566,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         oimg.resize(a_obs), ocam.resize(a_obs), optfree.resize(a_obs), ouv2.resize(2 * a_obs), odepth.resize(a_obs), oweight.resize(a_obs);
         oorig.resize(a_obs), optidx.resize(a_obs);
     }
-    parallel_for([&](int b)
+    auto fill_pass = [&](int b)
     {
         const snk_ba_problem& P = problems[b];
         PreProb& q = pre[(size_t)b];
@@ -4579,38 +4623,63 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             q_orig[sl] = q.orig_at + o;
             q_pt[sl]   = p;
         }
-    });
-    if (worker_failed.load())
-    {
-        set_error("snk_ba_set_problems: a list-building thread failed (out of host memory?)");
-        return SNK_ERR_HIP;
-    }
-    mark(0);
-    mark(1);
-    // ---- batches: the observation arrays (0.85 of a batch's 1.1 GB) go over the bus NOW, while pass 3 and the merge below build the rest on
-    // the host (round 6: the upload of a 1024-window batch is ~20 ms of PCIe time that used to start when the last list was done).
-    // Everything in this table is final: pass 2 wrote it in place.  The kernel reads the handle's pinned vectors; nothing below touches them.
+    };
+    // ---- batches: the observation arrays (0.65 of a batch's GB) go over the bus WHILE the lists are built (round 6): the fill pass runs in
+    // four chunks of problems, every chunk's ranges of the arrays are sent as soon as they are written (the upload of a 1024-window batch is
+    // ~15 ms of PCIe time that used to start when the last list was done), and pass 3 and the merge below build the rest meanwhile.
+    // Everything sent here is final: the fill pass writes it in place and nothing below touches it.  o_cam, o_ptfree, o_pt and cam_items
+    // are derived on the device (derive_obs_fields, derive_cam_items): reserved, not sent.
     const bool early_upload = count >= 16;
+    const int n_chunks      = early_upload && count >= 64 ? 4 : 1;
     if (early_upload)
     {
+        int rcE;
+#define RSE(buf, vec, T) if ((rcE = h->buf.reserve(std::max<size_t>((vec).size(), 1) * sizeof(T))) != SNK_OK) return rcE
+        RSE(d_pose, pose, double); RSE(d_pt, pt, double); RSE(d_ptc, ptc, unsigned char); RSE(d_camidx, camidx, int); RSE(d_ptstart, ptstart, int);
+        RSE(d_oimg, oimg, int); RSE(d_ouv, ouv2, double); RSE(d_odepth, odepth, double); RSE(d_oweight, oweight, double); RSE(d_oorig, oorig, int);
+        RSE(d_ocam, ocam, int); RSE(d_optfree, optfree, unsigned char); RSE(d_optidx, optidx, int);
+#undef RSE
+    }
+    for (int ck = 0; ck < n_chunks; ++ck)
+    {
+        const int b0 = (int)((long long)count * ck / n_chunks), b1 = (int)((long long)count * (ck + 1) / n_chunks);
+        pf_lo = b0, pf_hi = b1;
+        parallel_for(fill_pass);
+        pf_lo = 0, pf_hi = count;
+        if (worker_failed.load())
+        {
+            set_error("snk_ba_set_problems: a list-building thread failed (out of host memory?)");
+            return SNK_ERR_HIP;
+        }
+        if (!early_upload) continue;
+        // this chunk's ranges of the arrays.  Range ends are rounded outwards to 16 bytes (the copy kernel moves 16-byte words): the few
+        // bytes of a neighbouring chunk that go along are either final already or sent again, later on the same stream, by their own chunk
         CopyTab tabE;
         tabE.n = 0;
-        int rcE;
-#define UPE(buf, vec) if ((rcE = upload(h->buf, vec, tabE)) != SNK_OK) return rcE
-        UPE(d_pose, pose);
-        UPE(d_pt, pt);
-        UPE(d_ptc, ptc);
-        UPE(d_camidx, camidx);
-        UPE(d_ptstart, ptstart);
-        UPE(d_oimg, oimg);
-        UPE(d_ocam, ocam);
-        UPE(d_optfree, optfree);
-        UPE(d_ouv, ouv2);
-        UPE(d_odepth, odepth);
-        UPE(d_oweight, oweight);
-        UPE(d_oorig, oorig);
-        UPE(d_optidx, optidx);
-#undef UPE
+        auto part = [&](DevBuf& buf, const void* host, size_t elem, size_t e0, size_t e1, size_t total)
+        {
+            const size_t x0 = (e0 * elem) & ~(size_t)15, x1 = e1 >= total ? total * elem : std::min(total * elem, (e1 * elem + 15) & ~(size_t)15);
+            if (x1 <= x0 || tabE.n >= COPY_TAB_MAX) return;
+            tabE.src[tabE.n]   = static_cast<const char*>(host) + x0;
+            tabE.dst[tabE.n]   = static_cast<char*>(buf.p) + x0;
+            tabE.bytes[tabE.n] = (unsigned)(x1 - x0);
+            ++tabE.n;
+        };
+        const size_t i0 = pre[(size_t)b0].img_at, p0 = pre[(size_t)b0].pt_at, s0 = pre[(size_t)b0].ps_at, o0 = pre[(size_t)b0].obs_at;
+        const bool last = b1 >= count;
+        const size_t i1 = last ? camidx.size() : pre[(size_t)b1].img_at, p1 = last ? ptc.size() : pre[(size_t)b1].pt_at,
+                     s1 = last ? ptstart.size() : pre[(size_t)b1].ps_at, o1 = last ? oimg.size() : pre[(size_t)b1].obs_at;
+        SNK_REQUIRE((o1 - o0) * 16 < (1ull << 32), "scene list too large for the upload table");
+        part(h->d_pose, pose.data(), 56, i0, i1, camidx.size());
+        part(h->d_camidx, camidx.data(), 4, i0, i1, camidx.size());
+        part(h->d_pt, pt.data(), 24, p0, p1, ptc.size());
+        part(h->d_ptc, ptc.data(), 1, p0, p1, ptc.size());
+        part(h->d_ptstart, ptstart.data(), 4, s0, s1, ptstart.size());
+        part(h->d_oimg, oimg.data(), 4, o0, o1, oimg.size());
+        part(h->d_ouv, ouv2.data(), 16, o0, o1, oimg.size());
+        part(h->d_odepth, odepth.data(), 8, o0, o1, oimg.size());
+        part(h->d_oweight, oweight.data(), 8, o0, o1, oimg.size());
+        part(h->d_oorig, oorig.data(), 4, o0, o1, oimg.size());
         if (tabE.n > 0)
         {
             unsigned big = 0;
@@ -4620,6 +4689,8 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             SNK_LAUNCH_CHECK();
         }
     }
+    mark(0);
+    mark(1);
     // ---- pass 3: the camera lists and the point-major lists of every problem, built with PROBLEM-LOCAL offsets on the host threads; the
     // per-problem loop below appends them to the shared lists and relocates the offsets (positions in setpts / setpairs / cblkitems / ccitems,
     // partial-sum, camera-partial and record indices) by the running totals -- the same lists the serial builder wrote ----
@@ -4636,7 +4707,22 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         long long recs = 0;
         int max_pairs = 0, max_run = 0, max_k = 0;
         std::vector<int> cblkstart, cblkitems, ccstart, ccitems;
+        std::vector<int> wv;  // point_wave work items (first point of each, then n_pt); empty: a point has more than 64 observations
+        bool wv_ok = false;
     };
+    // where the per-problem loop below puts a problem's lists in the shared ones: the loop only takes the decisions and does the
+    // arithmetic of the running totals; the element copies (with their relocations) run on the host threads afterwards (round 6: the
+    // loop's push_back relocations were ~6 of a 1024-window hand-over's 23 ms of list time)
+    struct MergeAt
+    {
+        size_t wvpt, camstart, camitems, ccstart, ccitems, setitems, setpts, setpairs, cblkstart, cblkitems;
+        int base_parts, base_cparts;
+        long long base_rec;
+        bool set;
+    };
+    std::vector<MergeAt> at((size_t)count);
+    size_t n_wvpt = 0, n_camstart = 0, n_camitems = 0, n_ccstart = 0, n_ccitems = 0, n_setitems = 0, n_setpts = 0, n_setpairs = 0, n_cblkstart = 0,
+           n_cblkitems = 0;
     std::vector<Built> built((size_t)count);
     parallel_for([&](int b)
     {
@@ -4673,6 +4759,27 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                 bound += run * run;
             }
             B.ent_bound = bound;
+        }
+        // point_wave work items: consecutive whole points with <= 64 observations in total
+        {
+            bool ok = true;
+            std::vector<int>& wv = B.wv;
+            int p = 0;
+            while (p < P.n_pt && ok)
+            {
+                wv.push_back(p);
+                int n = 0, q = p;
+                while (q < P.n_pt && q - p < 64 && n + (pstart[(size_t)q + 1] - pstart[(size_t)q]) <= 64)
+                {
+                    n += pstart[(size_t)q + 1] - pstart[(size_t)q];
+                    ++q;
+                }
+                if (q == p) ok = false;  // a point with more than 64 observations: point_pass handles the problem
+                p = q;
+            }
+            if (ok) wv.push_back(P.n_pt);
+            else wv.clear();
+            B.wv_ok = ok;
         }
         // point-major Schur pass: points grouped by camera set, work items of <= SET_CHUNK points, per-block lists of
         // the partial sums they produce
@@ -4905,47 +5012,31 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         const int* const cidx = camidx.data() + pq.img_at;
         pr.nfc = nfc;
         pr.n6  = 6 * nfc;
-        const int* const pstart = ptstart.data() + pq.ps_at;
         const int no = pq.no;
         pr.no        = no;
         pr.ptstart_off = (int)pq.ps_at;
         if (pq.dup) dev_entries_ok = false;
-        // point_wave work items: consecutive whole points with <= 64 observations in total
-        pr.wv_off = (int)wvpt.size();
+        const Built& B = built[(size_t)b];
+        MergeAt& M     = at[(size_t)b];
+        // point_wave work items (built in pass 3)
+        pr.wv_off = (int)n_wvpt;
         pr.n_wv   = 0;
+        M.wvpt    = n_wvpt;
+        if (B.wv_ok)
         {
-            bool ok = true;
-            std::vector<int> wv;
-            int p = 0;
-            while (p < P.n_pt && ok)
-            {
-                wv.push_back(p);
-                int n = 0, q = p;
-                while (q < P.n_pt && q - p < 64 && n + (pstart[(size_t)q + 1] - pstart[(size_t)q]) <= 64)
-                {
-                    n += pstart[(size_t)q + 1] - pstart[(size_t)q];
-                    ++q;
-                }
-                if (q == p) ok = false;  // a point with more than 64 observations: point_pass handles the problem
-                p = q;
-            }
-            if (ok)
-            {
-                wv.push_back(P.n_pt);
-                pr.n_wv = (int)wv.size() - 1;
-                wvpt.insert(wvpt.end(), wv.begin(), wv.end());
-                max_wv = std::max(max_wv, pr.n_wv);
-            }
-            else
-                wave_ok = false;
+            pr.n_wv = (int)B.wv.size() - 1;
+            n_wvpt += B.wv.size();
+            max_wv = std::max(max_wv, pr.n_wv);
         }
+        else
+            wave_ok = false;
         mark(2);
         // camera lists (built in pass 3; positions and items are problem-local: appended as they are)
-        pr.camstart_off = (int)camstart.size();
-        pr.citem_off    = (int)camitems.size();
-        const Built& B  = built[(size_t)b];
-        camstart.insert(camstart.end(), B.camstart.begin(), B.camstart.end());
-        camitems.insert(camitems.end(), B.camitems.begin(), B.camitems.end());
+        pr.camstart_off = (int)n_camstart;
+        pr.citem_off    = (int)n_camitems;
+        M.camstart = n_camstart, M.camitems = n_camitems;
+        n_camstart += B.camstart.size();
+        n_camitems += B.camitems.size();
         max_citems = std::max(max_citems, (int)B.camitems.size());
         pr.be_nch  = B.be_nch;
         if (nfc > BE_MAX_CAMS) dev_entries_ok = false;
@@ -4955,49 +5046,38 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         mark(3);
         mark(4);
         // point-major Schur pass (built in pass 3 with problem-local offsets): append, relocating by the running totals
-        pr.set_off  = (int)setitems.size();
-        pr.cblk_off = (int)cblkstart.size();
+        pr.set_off  = (int)n_setitems;
+        pr.cblk_off = (int)n_cblkstart;
         pr.n_set    = 0;
         {
             if (B.cam_sums_bad) cam_sums_ok = false;
             max_set_k     = std::max(max_set_k, B.max_k);
             max_set_pairs = std::max(max_set_pairs, B.max_pairs);
             max_set_run   = std::max(max_set_run, B.max_run);
-            pr.ccam_off = (int)ccstart.size();
-            {
-                const int base_cc = (int)ccitems.size();
-                for (int v : B.ccstart) ccstart.push_back(v + base_cc);
-                for (int v : B.ccitems) ccitems.push_back(v + n_cparts);
-            }
+            pr.ccam_off = (int)n_ccstart;
+            M.ccstart = n_ccstart, M.ccitems = n_ccitems;  // ccstart entries + base_cc (= M.ccitems), ccitems entries + base_cparts
+            n_ccstart += B.ccstart.size();
+            n_ccitems += B.ccitems.size();
+            M.base_parts = n_partials, M.base_cparts = n_cparts, M.base_rec = n_setrec;
             // the batch's record / partial-sum counters are 32-bit on the device: a batch that would overflow them keeps the block-major pass
             // (what the serial builder of round 3 did), it is not an error
             const bool set_fits = n_setrec + B.recs < (1ll << 31) && (long long)n_partials + B.parts < (1ll << 31);
-            if (B.ok && set_fits)
+            M.set = B.ok && set_fits;
+            M.setitems = n_setitems, M.setpts = n_setpts, M.setpairs = n_setpairs;
+            if (M.set)
             {
-                const int base_pts = (int)setpts.size(), base_pairs = (int)setpairs.size();
-                for (SetItem si : B.items)
-                {
-                    si.pts_off += base_pts;
-                    si.pair_off += base_pairs;
-                    si.aux_off += base_pairs;
-                    si.part_off += n_partials;
-                    si.cpart_off += n_cparts;
-                    si.rec_off += (int)n_setrec;
-                    setitems.push_back(si);
-                }
-                setpts.insert(setpts.end(), B.ipts.begin(), B.ipts.end());
-                setpairs.insert(setpairs.end(), B.ipairs.begin(), B.ipairs.end());
+                n_setitems += B.items.size();
+                n_setpts += B.ipts.size();
+                n_setpairs += B.ipairs.size();
                 pr.n_set      = (int)B.items.size();
                 max_set_items = std::max(max_set_items, pr.n_set);
             }
             else
                 set_ok = false;
-            {
-                const int base_cb = (int)cblkitems.size();
-                for (int v : B.cblkstart) cblkstart.push_back(v + base_cb);
-                for (int v : B.cblkitems) cblkitems.push_back(v + n_partials);
-            }
-            if (B.ok && set_fits)
+            M.cblkstart = n_cblkstart, M.cblkitems = n_cblkitems;  // cblkstart entries + base_cb (= M.cblkitems), cblkitems entries + base_parts
+            n_cblkstart += B.cblkstart.size();
+            n_cblkitems += B.cblkitems.size();
+            if (M.set)
             {
                 n_partials += B.parts;
                 n_cparts += B.cparts;
@@ -5070,6 +5150,54 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         max_ni  = std::max(max_ni, P.n_img);
         max_nfc = std::max(max_nfc, nfc);
         max_n6  = std::max(max_n6, pr.n6);
+    }
+    // ---- the element copies the loop above left out: every problem's lists into its ranges of the shared lists, relocated, on the host
+    // threads (disjoint ranges, no locks) ----
+    wvpt.resize(n_wvpt), camstart.resize(n_camstart), camitems.resize(n_camitems), ccstart.resize(n_ccstart), ccitems.resize(n_ccitems);
+    setitems.resize(n_setitems), setpts.resize(n_setpts), setpairs.resize(n_setpairs), cblkstart.resize(n_cblkstart), cblkitems.resize(n_cblkitems);
+    parallel_for([&](int b)
+    {
+        const Built& B   = built[(size_t)b];
+        const MergeAt& M = at[(size_t)b];
+        auto put = [](auto& dst, size_t pos, const auto& src)
+        {
+            if (!src.empty()) memcpy(dst.data() + pos, src.data(), src.size() * sizeof(src[0]));
+        };
+        if (B.wv_ok) put(wvpt, M.wvpt, B.wv);
+        put(camstart, M.camstart, B.camstart);
+        put(camitems, M.camitems, B.camitems);
+        {
+            int* d = ccstart.data() + M.ccstart;
+            for (size_t k = 0; k < B.ccstart.size(); ++k) d[k] = B.ccstart[k] + (int)M.ccitems;
+            d = ccitems.data() + M.ccitems;
+            for (size_t k = 0; k < B.ccitems.size(); ++k) d[k] = B.ccitems[k] + M.base_cparts;
+            d = cblkstart.data() + M.cblkstart;
+            for (size_t k = 0; k < B.cblkstart.size(); ++k) d[k] = B.cblkstart[k] + (int)M.cblkitems;
+            d = cblkitems.data() + M.cblkitems;
+            for (size_t k = 0; k < B.cblkitems.size(); ++k) d[k] = B.cblkitems[k] + M.base_parts;
+        }
+        if (M.set)
+        {
+            SetItem* d = setitems.data() + M.setitems;
+            for (size_t k = 0; k < B.items.size(); ++k)
+            {
+                SetItem si = B.items[k];
+                si.pts_off += (int)M.setpts;
+                si.pair_off += (int)M.setpairs;
+                si.aux_off += (int)M.setpairs;
+                si.part_off += M.base_parts;
+                si.cpart_off += M.base_cparts;
+                si.rec_off += (int)M.base_rec;
+                d[k] = si;
+            }
+            put(setpts, M.setpts, B.ipts);
+            put(setpairs, M.setpairs, B.ipairs);
+        }
+    });
+    if (worker_failed.load())
+    {
+        set_error("snk_ba_set_problems: a list-building thread failed (out of host memory?)");
+        return SNK_ERR_HIP;
     }
     const size_t pcg_lds = (size_t)max_n6 * 9 * 8 + (size_t)max_nfc * 36 * 8;
     // S (and the vectors) of the largest problem fit one workgroup's LDS -> one workgroup per problem;
@@ -5170,7 +5298,8 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         UP(d_oorig, oorig);
     }
     UP(d_camstart, camstart);
-    UP(d_camitems, camitems);
+    if (!early_upload) { UP(d_camitems, camitems); }
+    else if ((rc = h->d_camitems.reserve(std::max<size_t>(camitems.size(), 1) * sizeof(int))) != SNK_OK) return rc;
     if ((rc = h->d_csobs.reserve(std::max<size_t>(camitems.size(), 1) * sizeof(CamObs))) != SNK_OK) return rc;  // gather_cam_records
     UP(d_setitems, setitems);
     if ((rc = h->d_setobs.reserve((size_t)std::max<long long>(n_setrec, 1) * sizeof(SetObs))) != SNK_OK) return rc;  // gather_set_records
@@ -5402,6 +5531,22 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     A.x         = h->d_x.as<double>();
     A.chi2      = h->d_chi2.as<double>();
     // the lists the device builds from the uploaded ones (stream ordered behind copy_table_kernel)
+    if (early_upload)
+    {
+        if (obs_off > 0)
+        {
+            int max_no = 0;
+            for (int b = 0; b < count; ++b) max_no = std::max(max_no, probs[(size_t)b].no);
+            hipLaunchKernelGGL(derive_obs_fields, dim3(ceil_div(std::max(max_no, 1), 256), count), dim3(256), 0, st, A, h->d_optidx.as<int>(), h->d_ocam.as<int>(),
+                               h->d_optfree.as<unsigned char>());
+            SNK_LAUNCH_CHECK();
+        }
+        if (max_nfc > 0 && max_citems > 0)
+        {
+            hipLaunchKernelGGL(derive_cam_items, dim3(max_nfc, count), dim3(64), 0, st, A, (const int*)h->d_ocam.as<int>(), h->d_camitems.as<int>());
+            SNK_LAUNCH_CHECK();
+        }
+    }
     if (max_citems > 0)
     {
         hipLaunchKernelGGL(gather_cam_records, dim3(ceil_div(max_citems, 256), count), dim3(256), 0, st, A, h->d_csobs.as<CamObs>());
