@@ -4669,7 +4669,8 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         const bool last = b1 >= count;
         const size_t i1 = last ? camidx.size() : pre[(size_t)b1].img_at, p1 = last ? ptc.size() : pre[(size_t)b1].pt_at,
                      s1 = last ? ptstart.size() : pre[(size_t)b1].ps_at, o1 = last ? oimg.size() : pre[(size_t)b1].obs_at;
-        SNK_REQUIRE((o1 - o0) * 16 < (1ull << 32), "scene list too large for the upload table");
+        SNK_REQUIRE((o1 - o0 + 1) * 16 < (1ull << 32) && (p1 - p0 + 1) * 24 < (1ull << 32) && (i1 - i0 + 1) * 56 < (1ull << 32),
+                    "scene list too large for the upload table");
         part(h->d_pose, pose.data(), 56, i0, i1, camidx.size());
         part(h->d_camidx, camidx.data(), 4, i0, i1, camidx.size());
         part(h->d_pt, pt.data(), 24, p0, p1, ptc.size());
