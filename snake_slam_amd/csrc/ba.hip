@@ -3535,30 +3535,66 @@ __global__ __launch_bounds__(PERSIST_THREADS) void pcgl_persist1(Arrays A, Opt O
             double pap = 0.0;
             const int n2 = n6 >> 1;
             const double2* sp2 = reinterpret_cast<const double2*>(sh_p);
-            for (int q = q0 + wave; q < q1; q += PERSIST_THREADS / 64)
+            // Two rows of the wavefront at a time, eight 16-byte loads per row in flight (sixteen per lane): the workgroup is alone on its CU
+            // (one wavefront per SIMD), S comes out of the Infinity Cache at ~1 us per round trip, and with four loads in flight a
+            // wavefront's three rows were a dozen dependent round trips of a 16 us iteration.  Every row is accumulated in the same order
+            // as before (ascending u in steps of 64 per lane): bit-identical sums.
+            constexpr int WV = PERSIST_THREADS / 64;
+            auto row_dot = [&](const double2* __restrict__ ra, const double2* __restrict__ rb, double& acc_a, double& acc_b)
             {
-                const double2* row = reinterpret_cast<const double2*>(S + (size_t)q * n6);
-                double acc = 0.0;
                 int u = lane;
-                for (; u + 192 < n2; u += 256)  // four loads in flight
+                for (; u + 448 < n2; u += 512)
                 {
-                    const double2 s0 = row[u], s1 = row[u + 64], s2 = row[u + 128], s3 = row[u + 192];
-                    const double2 p0 = sp2[u], p1 = sp2[u + 64], p2 = sp2[u + 128], p3 = sp2[u + 192];
-                    acc += s0.x * p0.x; acc += s0.y * p0.y;
-                    acc += s1.x * p1.x; acc += s1.y * p1.y;
-                    acc += s2.x * p2.x; acc += s2.y * p2.y;
-                    acc += s3.x * p3.x; acc += s3.y * p3.y;
+                    double2 sa[8], sb[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) sa[k] = ra[u + 64 * k], sb[k] = rb[u + 64 * k];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                    {
+                        const double2 pv = sp2[u + 64 * k];
+                        acc_a += sa[k].x * pv.x; acc_a += sa[k].y * pv.y;
+                        acc_b += sb[k].x * pv.x; acc_b += sb[k].y * pv.y;
+                    }
+                }
+                for (; u + 192 < n2; u += 256)
+                {
+                    double2 sa[4], sb[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sa[k] = ra[u + 64 * k], sb[k] = rb[u + 64 * k];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                    {
+                        const double2 pv = sp2[u + 64 * k];
+                        acc_a += sa[k].x * pv.x; acc_a += sa[k].y * pv.y;
+                        acc_b += sb[k].x * pv.x; acc_b += sb[k].y * pv.y;
+                    }
                 }
                 for (; u < n2; u += 64)
                 {
-                    const double2 s0 = row[u], p0 = sp2[u];
-                    acc += s0.x * p0.x; acc += s0.y * p0.y;
+                    const double2 s0 = ra[u], s1 = rb[u], pv = sp2[u];
+                    acc_a += s0.x * pv.x; acc_a += s0.y * pv.y;
+                    acc_b += s1.x * pv.x; acc_b += s1.y * pv.y;
                 }
-                acc = wave_sum64(acc);
+            };
+            for (int q = q0 + wave; q < q1; q += 2 * WV)
+            {
+                const int qb    = q + WV;
+                const bool two  = qb < q1;  // wave-uniform
+                const double2* ra = reinterpret_cast<const double2*>(S + (size_t)q * n6);
+                const double2* rb = reinterpret_cast<const double2*>(S + (size_t)(two ? qb : q) * n6);
+                double acc_a = 0.0, acc_b = 0.0;
+                row_dot(ra, rb, acc_a, acc_b);
+                acc_a = wave_sum64(acc_a);
+                acc_b = wave_sum64(acc_b);
                 if (lane == 0)
                 {
-                    Ap[q] = acc;
-                    pap += sh_p[q] * acc;
+                    Ap[q] = acc_a;
+                    pap += sh_p[q] * acc_a;
+                    if (two)
+                    {
+                        Ap[qb] = acc_b;
+                        pap += sh_p[qb] * acc_b;
+                    }
                 }
             }
             if (lane == 0) sh_red[0][wave] = pap;
