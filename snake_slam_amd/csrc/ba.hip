@@ -5736,25 +5736,43 @@ int snk_ba_reset(snk_ba* h)
     return SNK_OK;
 }
 
+constexpr int BA_GRAPH_CHAINS = 1;  // chains a recorded batch sequence is split into by default (measured: see enqueue_lm)
 static int enqueue_lm(snk_ba* h, int iterations, Launcher& L, bool only_marked = false)
 {
     const Opt O = make_opt(h->opt);
-    const int B = h->count;
-    Arrays A    = h->arr;
+    const int B_all = h->count;
+    Arrays A_all    = h->arr;
     const int cond = only_marked ? 1 : 0;
     if (only_marked)
     {
-        int rc = h->d_probcond.reserve((size_t)B * sizeof(Prob));
+        int rc = h->d_probcond.reserve((size_t)B_all * sizeof(Prob));
         if (rc != SNK_OK) return rc;
-        LAUNCH(select_marked, dim3(ceil_div(B, 64)), dim3(64), 0, h->d_prob.as<Prob>(), h->d_probcond.as<Prob>(), h->d_state.as<State>(), B,
+        LAUNCH(select_marked, dim3(ceil_div(B_all, 64)), dim3(64), 0, h->d_prob.as<Prob>(), h->d_probcond.as<Prob>(), h->d_state.as<State>(), B_all,
                O.lambda_init);
-        A.prob = h->d_probcond.as<Prob>();
+        A_all.prob = h->d_probcond.as<Prob>();
     }
     else if (h->state_fresh && L.graph == nullptr)
         ;  // the first solve after a hand-over: the uploaded state IS what begin_solve writes (one launch less on the keyframe path)
     else
-        LAUNCH(begin_solve, dim3(ceil_div(B, 64)), dim3(64), 0, h->d_state.as<State>(), B, O.lambda_init, 0);
+        LAUNCH(begin_solve, dim3(ceil_div(B_all, 64)), dim3(64), 0, h->d_state.as<State>(), B_all, O.lambda_init, 0);
     if (L.graph == nullptr) h->state_fresh = false;
+    // A recorded sequence of a big batch is recorded as SEVERAL chains over disjoint ranges of the windows (windows are independent; a
+    // kernel finds its window through A.prob / A.state only, so a range is those two pointers moved): the graph's branches run side by
+    // side, and the latency-bound kernels of one range (pcg_small: one workgroup per window walking its PCG iterations; schur_sum; accept_pass)
+    // fill the issue slots the bandwidth-bound ones of another leave.  Same kernels, same arithmetic per window.  SNK_BA_GRAPH_CHAINS=n.
+    static const int chains_env = getenv("SNK_BA_GRAPH_CHAINS") ? atoi(getenv("SNK_BA_GRAPH_CHAINS")) : 0;
+    int n_chain = 1;
+    if (L.graph != nullptr && !h->pcg_large && B_all >= 128) n_chain = chains_env > 0 ? std::min(chains_env, B_all / 64) : BA_GRAPH_CHAINS;
+    hipGraphNode_t const root = L.last;
+    for (int chain = 0; chain < n_chain; ++chain)
+    {
+    const int b_lo = chain == 0 ? 0 : ((int)((long long)B_all * chain / n_chain) & ~7);
+    const int b_hi = chain == n_chain - 1 ? B_all : ((int)((long long)B_all * (chain + 1) / n_chain) & ~7);
+    const int B    = b_hi - b_lo;
+    Arrays A       = A_all;
+    A.prob += b_lo;
+    A.state += b_lo;
+    L.last = root;
     const dim3 gpt(std::max(1, ceil_div(h->max_np, 128)), B);
     size_t pcg_lds        = (size_t)h->max_n6 * 9 * 8 + (size_t)h->max_nfc * 36 * 8;
     const size_t s_bytes  = (size_t)h->max_n6 * h->max_n6 * 8;
@@ -5913,6 +5931,7 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L, bool only_marked =
         if (h->max_rpc > 0 && h->max_nfc > 0) LAUNCH(rpc_pass, dim3(ceil_div(h->max_rpc, 64), B), dim3(64), 0, A, 1);
         LAUNCH(accept_pass, dim3(B), dim3(ACC_THREADS), 0, A, cond);
     }
+    }  // chain
     if (L.err != hipSuccess)
     {
         set_error("bundle adjustment launch failed: %s (%s:%d)", hipGetErrorString(L.err), __FILE__, L.line);

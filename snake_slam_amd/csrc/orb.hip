@@ -942,6 +942,125 @@ __global__ __launch_bounds__(256) void harris_kernel(Layout L, const u8* __restr
     cand_h[cell_index * CELL_SLOTS + lane] = harris_rank((det - kt) * s4);
 }
 
+// The same response with the candidates of HARRIS_NC consecutive cells packed densely into the lanes (round 6).  A FAST cell of the
+// benchmark images holds ~6 candidates (3 700 per image over ~650 cells): one wavefront per cell with one lane per slot ran its ~630
+// vector instructions for a tenth of its lanes, and 27 scattered dword loads per lane -- 3.2 ms per 2048 images, the longest kernel of
+// a batch under "orb.response" = 1.  Here a wavefront takes 16 cells: the counts of the cells are scanned across lanes 0..15, lane i
+// of a round finds (cell, slot) of the group's i-th candidate in the scan, the level of its cell by a select over the levels (the
+// cells of a group may lie on two levels), and reads each of the 9 rows with ONE 12-byte load.  Same integers, same float expression.
+constexpr int HARRIS_NC = 16;
+typedef u32 u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+__global__ __launch_bounds__(256) void harris_dense_kernel(Layout L, const u8* __restrict__ img0, int pitch0, long long stride0, int aligned0,
+                                                           const u32* __restrict__ cand, const u16* __restrict__ cell_cnt,
+                                                           u32* __restrict__ cand_h, int gx, int batch)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int b, bxi;
+    if (!xcd_image_map(gx, batch, b, bxi)) return;
+    const int cid0 = (bxi * 4 + wave) * HARRIS_NC;
+    if (cid0 >= L.total_cells) return;
+    const int ncell         = min(HARRIS_NC, L.total_cells - cid0);
+    const long long cell0   = (long long)b * L.total_cells + cid0;
+    const int cnt           = lane < ncell ? min((int)cell_cnt[cell0 + lane], CELL_SLOTS) : 0;
+    int inc = cnt;  // inclusive scan over lanes 0 .. 15 (the other lanes hold 0 and are not read)
+#pragma unroll
+    for (int d = 1; d < HARRIS_NC; d <<= 1)
+    {
+        const int t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
+    const int total = __builtin_amdgcn_readlane(inc, HARRIS_NC - 1);
+    const int exc   = inc - cnt;
+    for (int base = 0; base < total; base += 64)  // wave-uniform rounds
+    {
+        const int i    = base + lane;
+        const bool act = i < total;
+        const int ii   = act ? i : total - 1;
+        int j = 0;  // the candidate's cell: how many cells end at or before it
+#pragma unroll
+        for (int t = 0; t < HARRIS_NC - 1; ++t) j += __builtin_amdgcn_readlane(inc, t) <= ii ? 1 : 0;
+        const int slot = ii - __shfl(exc, j);
+        const int4 ct  = L.cell_tab[cid0 + j];
+        const int l    = ct.w;
+        const long long cell_index = cell0 + j;
+        const u32 k   = cand[cell_index * CELL_SLOTS + slot];
+        const int x   = ct.x + 63 - (int)(k & 63u), y = ct.y + 63 - (int)((k >> 6) & 63u);
+        const u8* src = img0 + (long long)b * stride0;
+        int pitch     = pitch0;
+        for (int q = 1; q < L.n_levels; ++q)  // wave-uniform loop, per-lane select
+        {
+            const LevelHead lv = *reinterpret_cast<const LevelHead*>(&L.lv[q]);
+            if (l == q)
+            {
+                src   = lv.base + (long long)b * lv.img_stride;
+                pitch = lv.pitch;
+            }
+        }
+        const bool aligned = l == 0 ? aligned0 != 0 : true;
+        // rows y - 4 .. y + 4, columns x - 4 .. x + 4 (corners lie >= 19 px inside the level): rw[r][j] = bytes 4 j .. 4 j + 3 of the row
+        u32 rw[9][3];
+        const int xa = (x - 4) & ~3, sh = (x - 4) & 3;
+        const u8* rp0 = src + (long long)(y - 4) * pitch;
+        if (__builtin_amdgcn_ballot_w64(!aligned) == 0)
+        {
+            u32x3_a4 d[9];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) d[r] = *reinterpret_cast<const u32x3_a4*>(rp0 + r * pitch + xa);
+#pragma unroll
+            for (int r = 0; r < 9; ++r)
+            {
+                const u64 q01 = ((u64)d[r].y << 32) | d[r].x, q12 = ((u64)d[r].z << 32) | d[r].y;
+                rw[r][0] = (u32)(q01 >> (8 * sh));
+                rw[r][1] = (u32)(q12 >> (8 * sh));
+                rw[r][2] = d[r].z >> (8 * sh);
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int r = 0; r < 9; ++r)
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj)
+                {
+                    u32 v = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (4 * jj + e < 9) v |= (u32)rp0[r * pitch + x - 4 + 4 * jj + e] << (8 * e);
+                    rw[r][jj] = v;
+                }
+        }
+        auto px = [&](int r, int c) -> int { return (int)((rw[r][c >> 2] >> (8 * (c & 3))) & 0xFFu); };
+        int a = 0, bb = 0, c = 0;
+#pragma unroll
+        for (int cc = 1; cc <= 7; ++cc)
+        {
+            int dxr[9], sxr[9];
+#pragma unroll
+            for (int r = 0; r < 9; ++r)
+            {
+                const int p0 = px(r, cc - 1), p1 = px(r, cc), p2 = px(r, cc + 1);
+                dxr[r] = p2 - p0;
+                sxr[r] = p0 + 2 * p1 + p2;
+            }
+#pragma unroll
+            for (int r = 1; r <= 7; ++r)
+            {
+                const int Ix = dxr[r - 1] + 2 * dxr[r] + dxr[r + 1];
+                const int Iy = sxr[r + 1] - sxr[r - 1];
+                a += Ix * Ix;
+                bb += Iy * Iy;
+                c += Ix * Iy;
+            }
+        }
+        const float fa = (float)a, fb = (float)bb, fc = (float)c;
+        const float s4 = 0x1.bb9da2p-52f;  // (1 / (4 * 7 * 255))^4 in float, multiplied left to right
+        const float det = fa * fb - fc * fc;
+        const float tr  = fa + fb;
+        const float kt  = 0.04f * tr * tr;
+        if (act) cand_h[cell_index * CELL_SLOTS + slot] = harris_rank((det - kt) * s4);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 7x7 Gaussian {18,33,49,56,49,33,18}/256 of every level (what the descriptors sample), streaming:
 // one WAVEFRONT walks down a column strip of 62 x 4 output pixels (lane = one aligned dword per row,
@@ -2975,9 +3094,19 @@ static int run_part(snk_orb* o, hipStream_t st, int part, int b0, const u8* imag
     }
     if (harris && L.total_cells > 0)
     {
-        const int gxh = ceil_div(L.total_cells, 4);
-        hipLaunchKernelGGL(harris_kernel, xcd_grid(gxh, batch), dim3(256), 0, st, L, images_dev, pitch, image_stride, aligned0, d_cand, d_cellcnt,
-                           d_candh, gxh, batch);
+        static const bool per_cell = getenv("SNK_ORB_HARRIS_PER_CELL") != nullptr;  // A/B: one wavefront per cell, one lane per slot (round 5)
+        if (per_cell)
+        {
+            const int gxh = ceil_div(L.total_cells, 4);
+            hipLaunchKernelGGL(harris_kernel, xcd_grid(gxh, batch), dim3(256), 0, st, L, images_dev, pitch, image_stride, aligned0, d_cand, d_cellcnt,
+                               d_candh, gxh, batch);
+        }
+        else
+        {
+            const int gxh = ceil_div(ceil_div(L.total_cells, HARRIS_NC), 4);
+            hipLaunchKernelGGL(harris_dense_kernel, xcd_grid(gxh, batch), dim3(256), 0, st, L, images_dev, pitch, image_stride, aligned0, d_cand,
+                               d_cellcnt, d_candh, gxh, batch);
+        }
         SNK_LAUNCH_CHECK();
     }
     // A launch of a few (image, level) workgroups (the per-frame calls) gives every workgroup the full-budget carve at once: nothing can

@@ -9,7 +9,9 @@ default-path suites).
   matches itself -- and with SNK_TRACK_NO_FUSED_RESOLVE=1 (separate resolve_batch_kernel);
 * SNK_POSE_WAVES=2: two wavefronts per frame in pose_kernel (what batches of more than two frames per CU take);
 * SNK_ORB_DESC_NO_DMA=1: describe_kernel's register path for the blurred patch (round 6 made the LDS-DMA form the default);
-* SNK_ORB_BLUR_TILED=1: the blurred planes in 32 x 4 pixel tiles (round 6 experiment, measured slower end to end: not the default)."""
+* SNK_ORB_BLUR_TILED=1: the blurred planes in 32 x 4 pixel tiles (round 6 experiment, measured slower end to end: not the default);
+* SNK_ORB_HARRIS_PER_CELL=1: the Harris response with one wavefront per FAST cell (round 5) instead of the candidates of 16 cells packed
+  into the lanes (round 6 default)."""
 import os
 import subprocess
 import sys
@@ -28,6 +30,7 @@ ROOT = Path(__file__).resolve().parent.parent
     ({"SNK_ORB_LEVEL_BH": "8"}, ["test_orb_gpu.py"]),
     ({"SNK_ORB_DESC_NO_DMA": "1"}, ["test_orb_gpu.py"]),
     ({"SNK_ORB_BLUR_TILED": "1"}, ["test_orb_gpu.py"]),
+    ({"SNK_ORB_HARRIS_PER_CELL": "1"}, ["test_orb_gpu.py"]),
     ({"SNK_GRID_NETWORK": "1", "SNK_STEREO_SORT_NETWORK": "1"}, ["test_match_gpu.py", "test_track_gpu.py", "test_frontend_gpu.py"]),
     ({"SNK_TRACK_FRAME_WGS": "1"}, ["test_track_gpu.py", "test_tracking_chain_gpu.py"]),
     ({"SNK_TRACK_FRAME_WGS": "3"}, ["test_track_gpu.py", "test_tracking_chain_gpu.py"]),

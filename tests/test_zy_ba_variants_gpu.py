@@ -39,6 +39,7 @@ ROOT = Path(__file__).resolve().parent.parent
     {"SNK_BA_PCGL_LAUNCHES": "1"},                                      # global scenes: the multi-launch PCG (pcgl_matvec / combine / update / direction / latch) instead of the one cooperative launch (pcgl_persist)
     {"SNK_BA_PERSIST_TWO_BARRIERS": "1"},                               # global scenes: the two-barrier persistent PCG of round 5 (pcgl_persist) instead of the one-barrier form (pcgl_persist1)
     {"SNK_BA_FLAT_BARRIER": "1"},                                       # global scenes: the flat grid barrier of round 5 (every workgroup polls every flag) instead of the two-level one
+    {"SNK_BA_GRAPH_CHAINS": "2", "SNK_BA_GRAPH_FIRST": "1"},            # batches of >= 128 windows recorded as two graph branches over disjoint window ranges (measured +1 % with 2, -6 % with 4: not the default)
     {"SNK_BA_PERSIST_FAIL": "1"},                                       # global scenes: the runtime refuses the cooperative launch -> the handle falls back to the multi-launch PCG inside the same solve (round-5 advisor)
 ])
 def test_ba_parity_suite_with_forced_path(env):
