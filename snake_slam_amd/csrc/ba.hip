@@ -3025,6 +3025,8 @@ struct PcgLarge
     int bar_flat;     // SNK_BA_FLAT_BARRIER=1: every workgroup polls every flag (the round-5 barrier)
     int persist_one;  // pcgl_persist1 (one grid barrier per PCG iteration; r, z, p private in LDS) instead of pcgl_persist
     int persist_wgs;  // workgroups of the launch (all resident: cooperative launch)
+    int persist_rows;  // pcgl_persist_reg: rows of S per workgroup (8 or 16)
+    int timing;       // SNK_BA_PCG_TIMING=1 (diagnostic): workgroup 0 of pcgl_persist_reg adds its cycles per phase to ps[0..5]
 };
 constexpr int PERSIST_WGS_MAX = 1024;
 static inline int snk_env_int(const char* name, int dflt)
@@ -3626,6 +3628,241 @@ __global__ __launch_bounds__(PERSIST_THREADS) void pcgl_persist1(Arrays A, Opt O
         ++iters;
     }
     if (wg == 0 && tid == 0) A.state[0].pcg_iters += iters;
+}
+
+// sum over the 64 lanes on the vector ALU only (permlane swaps + DPP moves; every lane gets the same bits): the __shfl_xor butterfly goes
+// through the LDS crossbar, ~100 cycles per dependent step
+__device__ __forceinline__ double wave_sum64_valu(double v)
+{
+    v = swap_add32(v, v);
+    v = swap_add16(v, v);
+    v += dpp_mov64<0x128>(v);  // row_ror:8
+    v += dpp_mov64<0x141>(v);  // row_half_mirror
+    v += dpp_mov64<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov64<0xB1>(v);   // quad_perm [1,0,3,2]
+    return v;
+}
+// The one-barrier PCG with the workgroup's rows of S held in REGISTERS for the whole launch (round 6, late).  A launch runs up to
+// max_pcg (40) iterations on the same S: pcgl_persist1 streamed its dozen rows per workgroup out of the Infinity Cache in every one of
+// them (~2.7 us of a 15 us iteration, 25.9 MB per iteration for 300 keyframes).  A workgroup is alone on its compute unit (one
+// wavefront per SIMD: 512 registers per lane, arch + acc), so R rows x 8 columns per thread (column u = tid + 256 k) fit the register
+// file for n6 <= 2048 (~340 free cameras) with R = 8 (128 registers) or 16 (256: half of them parked in the acc half, a move per use);
+// S is then read ONCE per launch.  A thread owns the entries u = tid + 256 j of r, z and p -- registers too, with the six
+// preconditioner values of each (42 L2 loads per thread and iteration before) -- so it multiplies its columns against the entries of
+// p it has just formed itself: no LDS read, no barrier in front of the product.  The R row sums are reduced by a transpose-and-add
+// over the wavefront (vector ALU only) and a four-way sum through LDS; LDS otherwise holds the copies of p and r other threads read.
+// Same algorithm, same grid barrier and buffers as pcgl_persist1; the sums run in this kernel's own fixed order.  16 rows per
+// workgroup above 1024 unknowns: barrier and exchange grow with the workgroups (113 instead of 225 for 300 keyframes: 5.2 instead of
+// 7.8 us of an iteration).  Bigger systems keep pcgl_persist1 (SNK_BA_PERSIST_STREAM=1: always).
+// Measured per iteration, 300 keyframes (SNK_BA_PCG_TIMING=1): product + row sums 1.2, barrier 3.4, A p exchange 1.8, preconditioner +
+// r.r / r.z 0.7 us = 7.1 (pcgl_persist1: 15.3).  Also built and dropped: no barrier at all, exchange buffers whose entries validate
+// themselves (a NaN pattern = "not written yet", three buffers in turn) -- every workgroup then polls 15 KB at the memory side and
+// the wait costs what barrier + exchange cost (profiles/NOTES.md).
+constexpr int PREG_MAX_N6 = 2048;
+template <int R>
+__global__ __launch_bounds__(PERSIST_THREADS) void pcgl_persist_reg(Arrays A, Opt O, PcgLarge W)
+{
+    constexpr int NT = PERSIST_THREADS, KC = PREG_MAX_N6 / NT, NWV = NT / 64;  // columns (and own entries) per thread, wavefronts
+    static_assert(R == 8 || R == 16, "rows per workgroup");
+    extern __shared__ __attribute__((aligned(16))) double sh_all[];
+    __shared__ double sh_red[2][NWV], sh_acc[NWV][R];
+    const Prob pr  = A.prob[0];
+    const int n6   = pr.n6;
+    if (n6 == 0) return;  // every workgroup
+    double* sh_p = sh_all;             // the direction (read by the owners of other rows: p.Ap, x)
+    double* sh_r = sh_all + n6;        // the residual (read by the six threads of a camera: z = Minv r)
+    const int tid  = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NW   = gridDim.x;
+    const int wg   = blockIdx.x;
+    const int q0   = min(wg * R, n6), nrow = min(R, n6 - q0);
+    unsigned phase = 0;
+    const bool timing = W.timing != 0 && wg == 0 && tid == 0;
+    unsigned long long tc[5] = {0, 0, 0, 0, 0}, t_at = timing ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    auto stamp = [&](int slot)
+    {
+        if (!timing) return;
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        tc[slot] += now - t_at;
+        t_at = now;
+    };
+    double s[R][KC];
+    {
+        const double* S = A.S + pr.s_off;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+            {
+                const int u = tid + NT * k;
+                s[r][k]     = r < nrow && u < n6 ? S[(size_t)(q0 + r) * n6 + u] : 0.0;
+            }
+    }
+    // ... and so do the preconditioner rows of the thread's own entries (6 doubles each; 42 L2 loads per thread and iteration before)
+    double mrow[KC][6];
+#pragma unroll
+    for (int j = 0; j < KC; ++j)
+    {
+        const int u = tid + NT * j;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) mrow[j][b] = u < n6 ? W.Minv[(size_t)pr.cam_off * 36 + (size_t)u * 6 + b] : 0.0;  // 36 c + 6 a + b = 6 u + b
+    }
+    // block-wide sums of two values per thread, every thread gets both (fixed order: wavefront trees, then the four wavefronts)
+    auto block_sum2 = [&](double a, double b, double& sa, double& sb)
+    {
+        a = wave_sum64_valu(a);
+        b = wave_sum64_valu(b);
+        __syncthreads();  // the previous round's readers are done
+        if (lane == 0) sh_red[0][wave] = a, sh_red[1][wave] = b;
+        __syncthreads();
+        sa = sh_red[0][0], sb = sh_red[1][0];
+#pragma unroll
+        for (int w = 1; w < NWV; ++w) sa += sh_red[0][w], sb += sh_red[1][w];
+    };
+    // The thread's own entries u = tid + 256 j of r, z and p stay in registers from iteration to iteration (it is the only writer of
+    // them and the only reader of z); LDS holds the copies other threads need.  All loads of a phase are issued before its stores:
+    // reads and writes of the one LDS array in the same loop body would be kept in program order by the compiler, entry by entry.
+    double rv[KC], zv[KC], pv[KC];
+    double rn2, rz_cur;
+    {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int j = 0; j < KC; ++j)
+        {
+            const int u = tid + NT * j;
+            rv[j] = u < n6 ? W.r[u] : 0.0;
+            zv[j] = u < n6 ? W.z[u] : 0.0;
+            pv[j] = 0.0;
+            a += rv[j] * rv[j];
+            b += rv[j] * zv[j];
+        }
+        block_sum2(a, b, rn2, rz_cur);
+    }
+    const double stop2 = O.pcg_tol * O.pcg_tol * rn2;
+    double rz_prev = 0.0;
+    int iters = 0;
+    stamp(0);  // set-up: S into registers, the preconditioner into LDS, r / z
+    for (int k = 0; k < O.max_pcg; ++k)
+    {
+        if (rn2 <= stop2) break;  // grid-uniform
+        const double beta = k == 0 ? 0.0 : rz_cur / rz_prev;
+        double* Ap   = (k & 1) ? W.p2 : W.Ap;                                   // the two A p buffers (p2 is free in this form)
+        double* wpap = W.wrr + (size_t)(k & 1) * PERSIST_WGS_MAX;               // ... and the two partial-sum buffers
+#pragma unroll
+        for (int j = 0; j < KC; ++j)
+        {
+            const int u = tid + NT * j;
+            pv[j]       = zv[j] + beta * pv[j];
+            if (u < n6) sh_p[u] = pv[j];
+        }
+        double acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+        {
+            double t = 0.0;
+#pragma unroll
+            for (int j = 0; j < KC; ++j) t += s[r][j] * pv[j];
+            acc[r] = t;
+        }
+        // The row sums over the wavefront as a reduce-scatter (cam_pass's "transpose and add"): halve the rows a lane carries while
+        // doubling the lanes a value covers (permlane32_swap, permlane16_swap, row_ror:8, ...), then DPP steps on the one row left --
+        // 10 vector-ALU exchanges for 8 rows instead of the 48 LDS-crossbar round trips of eight butterflies (~100 cycles each,
+        // dependent: 2 of an iteration's 13 us, SNK_BA_PCG_TIMING).  Row r ends up in the lanes whose upper bits are r.
+        if constexpr (R == 8)
+        {
+            double w4[4], w2[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w4[i] = swap_add32(acc[i], acc[i + 4]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) w2[i] = swap_add16(w4[i], w4[i + 2]);
+            double w1 = xchg_add<0x128>(w2[0], w2[1], (lane & 8) != 0);  // row_ror:8
+            w1 += dpp_mov64<0x141>(w1);  // row_half_mirror
+            w1 += dpp_mov64<0x4E>(w1);   // quad_perm [2,3,0,1]
+            w1 += dpp_mov64<0xB1>(w1);   // quad_perm [1,0,3,2]
+            if ((lane & 7) == 0) sh_acc[wave][lane >> 3] = w1;
+        }
+        else
+        {
+            double w8[8], w4[4], w2[2];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w8[i] = swap_add32(acc[i], acc[i + 8]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w4[i] = swap_add16(w8[i], w8[i + 4]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) w2[i] = xchg_add<0x128>(w4[i], w4[i + 2], (lane & 8) != 0);  // row_ror:8
+            double w1 = xchg_add<0x141>(w2[0], w2[1], (lane & 4) != 0);                           // row_half_mirror: l <-> 7 - l
+            w1 += dpp_mov64<0x4E>(w1);   // quad_perm [2,3,0,1]
+            w1 += dpp_mov64<0xB1>(w1);   // quad_perm [1,0,3,2]
+            if ((lane & 3) == 0) sh_acc[wave][lane >> 2] = w1;  // row r = bits 5..2 of the lane
+        }
+        __syncthreads();
+        if (wave == 0)
+        {
+            double pap = 0.0, v = 0.0;
+            if (lane < nrow)
+            {
+                v = sh_acc[0][lane];
+#pragma unroll
+                for (int w = 1; w < NWV; ++w) v += sh_acc[w][lane];
+                pap = sh_p[q0 + lane] * v;
+            }
+            pap = wave_sum64_valu(pap);
+            if (lane < nrow) Ap[q0 + lane] = v;
+            if (lane == 0) wpap[wg] = pap;
+        }
+        stamp(1);  // direction, product, row sums
+        double apv[KC];
+        double pAp = 0.0;
+        grid_barrier(W.bar, NW, phase, W.bar_flat);
+        stamp(2);  // barrier
+        // A p of the other workgroups comes from the memory side (~2 us): requested BEFORE p.Ap is summed, whose own loads and the
+        // break below would otherwise stand in front of it as a second round trip
+#pragma unroll
+        for (int j = 0; j < KC; ++j)
+        {
+            const int u = tid + NT * j;
+            apv[j]      = u < n6 ? Ap[u] : 0.0;
+        }
+        for (int i = lane; i < NW; i += 64) pAp += wpap[i];
+        pAp = wave_sum64_valu(pAp);
+        if (pAp <= 0.0) break;  // grid-uniform (the reference's break: the step of this iteration is not applied)
+        const double alpha = rz_cur / pAp;
+        if (tid < nrow) A.x[q0 + tid] += alpha * sh_p[q0 + tid];  // the rows' owner keeps the solution
+#pragma unroll
+        for (int j = 0; j < KC; ++j)
+        {
+            const int u = tid + NT * j;
+            rv[j] -= alpha * apv[j];
+            if (u < n6) sh_r[u] = rv[j];
+        }
+        __syncthreads();
+        stamp(3);  // p.Ap from the partial sums, r -= alpha A p (A p from the other workgroups)
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int j = 0; j < KC; ++j)
+        {
+            const int u = min(tid + NT * j, n6 - 1);
+            const double2* rc = reinterpret_cast<const double2*>(sh_r + (u / 6) * 6);  // the camera's six entries: 48 bytes, 16-byte aligned
+            const double2 r01 = rc[0], r23 = rc[1], r45 = rc[2];
+            zv[j] = ((mrow[j][0] * r01.x + mrow[j][1] * r01.y) + (mrow[j][2] * r23.x + mrow[j][3] * r23.y)) + (mrow[j][4] * r45.x + mrow[j][5] * r45.y);
+            a += rv[j] * rv[j];
+            b += rv[j] * zv[j];
+        }
+        rz_prev = rz_cur;
+        block_sum2(a, b, rn2, rz_cur);
+        stamp(4);  // z = Minv r, r.r, r.z
+        ++iters;
+    }
+    if (timing)
+    {
+        for (int i = 0; i < 5; ++i) W.ps[i] += (double)tc[i];
+        W.ps[5] += (double)iters;
+    }
+    if (wg == 0 && tid == 0) A.state[0].pcg_iters += iters;
+}
+
+static inline const void* persist_reg_kernel(int rows)
+{
+    return rows == 16 ? reinterpret_cast<const void*>(pcgl_persist_reg<16>) : reinterpret_cast<const void*>(pcgl_persist_reg<8>);
 }
 
 // pose <- exp(delta) * pose
@@ -5424,6 +5661,7 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         W.wpap = w;         w += (size_t)PERSIST_WGS_MAX;
         W.bar = reinterpret_cast<unsigned*>(w);  // (PERSIST_WGS_MAX + 8) doubles = 2064 words >= BAR_WORDS
         W.bar_flat = getenv("SNK_BA_FLAT_BARRIER") != nullptr ? 1 : 0;
+        W.timing   = getenv("SNK_BA_PCG_TIMING") != nullptr ? 1 : 0;
         // one problem, a cooperative launch the device can hold: two workgroups per compute unit (SNK_BA_PCGL_LAUNCHES=1: the
         // multi-launch form, A/B and the fallback for batches of large problems)
         W.persist_wgs = 0;
@@ -5457,6 +5695,22 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                         hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, reinterpret_cast<const void*>(pcgl_persist1), PERSIST_THREADS, (size_t)max_n6 * 24) == hipSuccess &&
                         resident >= 1 && resident * prop.multiProcessorCount >= W.persist_wgs)
                         W.persist_one = 1;
+                    // ... and with S in registers when the system is small enough (8 rows x 2048 columns per workgroup, one workgroup per 8 rows)
+                    // 16 rows per workgroup above 1024 unknowns (the barrier and the exchange of A p grow with the workgroups: 225 against 113
+                    // for 300 keyframes), 8 below; SNK_BA_PERSIST_REG_ROWS / _THREADS: A/B
+                    static const int rows_env = snk_env_int("SNK_BA_PERSIST_REG_ROWS", 0);
+                    const int reg_rows     = rows_env == 8 || rows_env == 16 ? rows_env : (max_n6 > 1024 ? 16 : 8);
+                    const void* reg_kernel = persist_reg_kernel(reg_rows);
+                    const int wgs_reg = ceil_div(std::max(max_n6, 1), reg_rows);
+                    if (W.persist_one == 1 && max_n6 <= PREG_MAX_N6 && getenv("SNK_BA_PERSIST_STREAM") == nullptr && getenv("SNK_BA_PERSIST_WGS") == nullptr &&
+                        set_max_lds_once(reg_kernel, 150 * 1024) == SNK_OK &&
+                        hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, reg_kernel, PERSIST_THREADS, (size_t)max_n6 * 16) == hipSuccess &&
+                        resident >= 1 && resident * prop.multiProcessorCount >= wgs_reg && wgs_reg <= PERSIST_WGS_MAX)
+                    {
+                        W.persist_rows = reg_rows;
+                        W.persist_one = 2;
+                        W.persist_wgs = wgs_reg;
+                    }
                 }
             }
             (void)hipGetLastError();
@@ -5882,7 +6136,11 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L, bool only_marked =
                         L.cooperative = false, L.err = hipErrorCooperativeLaunchTooLarge;
                     else
                     {
-                        if (W.persist_one)
+                        if (W.persist_one == 2 && W.persist_rows == 16)
+                            LAUNCH(pcgl_persist_reg<16>, dim3(W.persist_wgs), dim3(PERSIST_THREADS), (size_t)h->max_n6 * 16, A, O, W);
+                        else if (W.persist_one == 2)
+                            LAUNCH(pcgl_persist_reg<8>, dim3(W.persist_wgs), dim3(PERSIST_THREADS), (size_t)h->max_n6 * 16, A, O, W);
+                        else if (W.persist_one)
                             LAUNCH(pcgl_persist1, dim3(W.persist_wgs), dim3(PERSIST_THREADS), (size_t)h->max_n6 * 24, A, O, W);
                         else
                             LAUNCH(pcgl_persist, dim3(W.persist_wgs), dim3(PERSIST_THREADS), (size_t)h->max_n6 * 8, A, O, W);
@@ -5989,11 +6247,21 @@ int snk_ba_solve_async(snk_ba* h, int iterations)
 
 int snk_ba_solve(snk_ba* h, int iterations, double* cost_initial, double* cost_final)
 {
+    const bool pcg_timing = h->pcg_large && h->pcgw.timing && h->pcgw.persist_one == 2;  // SNK_BA_PCG_TIMING=1 (diagnostic)
+    if (pcg_timing) SNK_HIP_CHECK(hipMemsetAsync(h->pcgw.ps, 0, 6 * sizeof(double), h->stream));
     int rc = snk_ba_solve_async(h, iterations);
     if (rc != SNK_OK) return rc;
     std::vector<State> st((size_t)h->count);
     SNK_HIP_CHECK(hipMemcpyAsync(st.data(), h->d_state.p, st.size() * sizeof(State), hipMemcpyDeviceToHost, h->stream));
     SNK_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (pcg_timing)
+    {
+        double t[6];
+        SNK_HIP_CHECK(hipMemcpy(t, h->pcgw.ps, sizeof(t), hipMemcpyDeviceToHost));
+        const double it = std::max(t[5], 1.0);  // 100 MHz ticks of workgroup 0, summed over the launches of this solve
+        fprintf(stderr, "[pcgl_persist_reg] %d PCG iterations; set-up %.1f us per launch-sum; per iteration: product %.2f, barrier %.2f, A p exchange %.2f, "
+                        "preconditioner + sums %.2f us\n", (int)t[5], t[0] * 0.01, t[1] * 0.01 / it, t[2] * 0.01 / it, t[3] * 0.01 / it, t[4] * 0.01 / it);
+    }
     for (int b = 0; b < h->count; ++b)
     {
         if (cost_initial) cost_initial[b] = st[(size_t)b].cost_initial;
