@@ -826,7 +826,7 @@ def main():
             g_roof = {"bound": "hbm", "algorithmic_bytes_per_solve": int(g_bytes), "pcg_iterations": int(g_pcg),
                       "achieved": round(g_bytes / (ms_solve * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": round(g_bytes / (ms_solve * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
-                      "note": "S (n6 x n6 doubles = %.1f MB) fits the 256 MB Infinity Cache: its re-reads never reach HBM; the solve is bound by the grid barrier of a PCG iteration (one since round 6) and the latency of its matrix-vector product, not by bandwidth" % (8 * n6_ * n6_ / 1e6)}
+                      "note": "S (n6 x n6 doubles = %.1f MB) fits the 256 MB Infinity Cache: and, up to 2048 unknowns, the registers of the persistent PCG kernel, which reads it once per LM iteration (the figure above counts one read per PCG iteration, as the algorithm is written); the solve is bound by the grid barrier of a PCG iteration and the exchange of A p between XCDs, not by bandwidth" % (8 * n6_ * n6_ / 1e6)}
             gt_ = _pipeline_traffic("gba", ["ba.hip"]) if args.gba_keyframes == 300 else None
             if gt_ is not None:
                 g_roof["traffic"] = int(gt_["hbm_bytes_per_solve"])
@@ -844,7 +844,7 @@ def main():
                          "identical_to_gpu": bool(rm(g_pose, o_pose) <= 1e-5 and rm(g_pt, o_pt) <= 1e-5), "tolerance": 1e-5}
             ba_out["global_ba"] = {"metric": "FullBA(4) wall time, host call to result", "keyframes": args.gba_keyframes,
                                    "points": 50 * args.gba_keyframes, "observations": 500 * args.gba_keyframes,
-                                   "ms_per_solve": round(ms_solve, 3), "pcg": "one cooperative launch per LM iteration (pcgl_persist1: one grid barrier per PCG iteration)",
+                                   "ms_per_solve": round(ms_solve, 3), "pcg": "one cooperative launch per LM iteration (pcgl_persist_reg up to 2048 unknowns: the rows of S in registers for the launch, one grid barrier per PCG iteration; pcgl_persist1 above)",
                                    "roofline": g_roof, "cpu_baseline": g_cpu,
                                    "ms_scene_hand_over": {"first": round((tc1 - tc0) * 1e3, 3), "same_handle_again": round((tc3 - tc2) * 1e3, 3)},
                                    "cost_initial": round(float(gci[0]), 3),
