@@ -3981,7 +3981,28 @@ __global__ __launch_bounds__(ACC_THREADS) void accept_pass(Arrays A, int only_ma
     // fixed-order sums: contiguous chunk per thread, then the tree
     const int chunk = (pr.np + ACC_THREADS - 1) / ACC_THREADS;
     double c0 = 0.0, c1 = 0.0;
-    for (int k0 = 0; k0 < chunk; k0 += 4)  // four loads of each array in flight, added in index order (one at a time: `chunk` dependent round trips)
+    int k_from = 0;
+    // big problems (a global scene: 15 000 points, 59 per thread): sixteen loads of each array in flight -- with four, the sums were 15
+    // dependent round trips of this kernel's 42 us on ONE workgroup, 5 % of a FullBA(4).  Same additions in the same order.
+    for (; k_from + 16 <= chunk; k_from += 16)
+    {
+        double a[16], b[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+        {
+            const int p   = tid * chunk + k_from + u;
+            const bool ok = p < pr.np;
+            a[u]          = ok ? A.cost_pt[pr.pt_off + p] : 0.0;
+            b[u]          = ok ? A.cost_pt_new[pr.pt_off + p] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+        {
+            c0 += a[u];
+            c1 += b[u];
+        }
+    }
+    for (int k0 = k_from; k0 < chunk; k0 += 4)  // four loads of each array in flight, added in index order (one at a time: `chunk` dependent round trips)
     {
         double a[4], b[4];
 #pragma unroll
@@ -4036,7 +4057,16 @@ __global__ __launch_bounds__(ACC_THREADS) void accept_pass(Arrays A, int only_ma
         const double* src = A.pt_new + (size_t)pr.pt_off * 3;
         double* dst       = A.pt + (size_t)pr.pt_off * 3;
         const int n       = pr.np * 3;
-        for (int k0 = tid; k0 < n; k0 += 8 * ACC_THREADS)
+        int k_lo          = tid;
+        for (; k_lo + 31 * ACC_THREADS < n; k_lo += 32 * ACC_THREADS)  // big problems: 32 loads in flight (45 000 doubles: 6 rounds instead of 22)
+        {
+            double v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = src[k_lo + u * ACC_THREADS];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) dst[k_lo + u * ACC_THREADS] = v[u];
+        }
+        for (int k0 = k_lo; k0 < n; k0 += 8 * ACC_THREADS)
         {
             double v[8];
 #pragma unroll
