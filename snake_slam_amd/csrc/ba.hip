@@ -42,6 +42,9 @@
 #include <unordered_map>
 #include <tuple>
 #include <utility>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -4155,9 +4158,82 @@ struct BaLists
     }
 };
 
+// The host threads of a batch hand-over, kept by the handle (round 6, late).  snk_ba_set_problems runs seven threaded passes over the
+// problems of a batch; with std::thread created and joined per pass that was 7 x 31 creations (~20 us each, issued one after the
+// other) inside a 22 ms hand-over.  Workers park on a condition variable between passes and end with the handle.
+struct HostPool
+{
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv, cv_done;
+    const std::function<void()>* job = nullptr;
+    unsigned gen = 0;
+    int n_run = 0, n_left = 0;
+    bool stop = false;
+    void worker(int idx)
+    {
+        unsigned seen = 0;
+        for (;;)
+        {
+            const std::function<void()>* j = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen;
+                if (idx < n_run) j = job;
+            }
+            if (j)
+            {
+                (*j)();  // the passes catch their own exceptions
+                std::lock_guard<std::mutex> lk(m);
+                if (--n_left == 0) cv_done.notify_one();
+            }
+        }
+    }
+    // runs `work` on up to `helpers` pool threads and on the caller; returns when all of them are done
+    void run(int helpers, const std::function<void()>& work)
+    {
+        try
+        {
+            while ((int)th.size() < helpers) th.emplace_back(&HostPool::worker, this, (int)th.size());
+        }
+        catch (...)
+        {
+        }  // thread creation failed: the threads that exist (and the caller) do the work
+        const int n = std::min(helpers, (int)th.size());
+        if (n > 0)
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job    = &work;
+            n_run  = n;
+            n_left = n;
+            ++gen;
+        }
+        if (n > 0) cv.notify_all();
+        work();
+        if (n > 0)
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv_done.wait(lk, [&] { return n_left == 0; });
+            job = nullptr;
+        }
+    }
+    ~HostPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+};
+
 struct snk_ba : HandleBase
 {
     BaLists lists;
+    HostPool pool;    // host threads of the batch hand-over
     HostBuf h_stage;  // pinned staging of the small per-call transfers (outlier masks)
     DevBuf d_becnt;   // per (camera, 64-item chunk, camera) counters of the device-built block entries
     DevBuf d_probcond;  // the problem table of a conditional extra iteration (select_marked)
@@ -4785,10 +4861,9 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
             return;
         }
         std::atomic<int> next{lo};
-        std::vector<std::thread> pool;
         // an exception in a worker (the vectors it grows: std::bad_alloc) must not reach std::terminate: it is caught, the remaining
-        // work is abandoned and the caller turns worker_failed into an error code after the join
-        auto work = [&]()
+        // work is abandoned and the caller turns worker_failed into an error code after the pass
+        const std::function<void()> work = [&]()
         {
             try
             {
@@ -4804,6 +4879,13 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                 worker_failed.store(true);
             }
         };
+        static const bool no_pool = getenv("SNK_BA_NO_HOST_POOL") != nullptr;  // A/B: threads created and joined per pass (rounds 4-6)
+        if (!no_pool)
+        {
+            h->pool.run(n_threads - 1, work);
+            return;
+        }
+        std::vector<std::thread> pool;
         try
         {
             for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
