@@ -34,6 +34,7 @@ ROOT = Path(__file__).resolve().parent.parent
     {"SNK_BA_LOCAL_SYNC": "1"},                                         # snk_ba_solve_local_scene decides about the extra iteration on the host (count read back)
     {"SNK_BA_BECNT_BUDGET": "1", "SNK_BA_CHECK_LISTS": "1"},            # the counter-memory budget of the device-built block entries exceeded: host builder takes over
     {"SNK_BA_HOST_THREADS": "4", "SNK_BA_CHECK_LISTS": "1", "SNK_BA_SCHUR_SET_MIN_ITEMS": "1"},  # the threaded list builder of a batch hand-over forced on every batch of >= 2 scenes, its lists checked
+    {"SNK_BA_HOST_THREADS": "4", "SNK_BA_NO_HOST_POOL": "1", "SNK_BA_CHECK_LISTS": "1"},  # ... with threads created and joined per pass (rounds 4-6) instead of the handle's parked pool
     {"SNK_BA_HOST_THREADS": "3", "SNK_BA_NO_SCHUR_SET": "1"},
     {"SNK_BA_NO_SCHUR_WIDE": "1", "SNK_BA_NO_SCHUR_SET": "1"},          # block-major schur_pass with one wavefront per block also for single windows
     {"SNK_BA_PCGL_LAUNCHES": "1"},                                      # global scenes: the multi-launch PCG (pcgl_matvec / combine / update / direction / latch) instead of the one cooperative launch (pcgl_persist)
