@@ -4239,6 +4239,7 @@ struct snk_ba : HandleBase
     DevBuf d_probcond;  // the problem table of a conditional extra iteration (select_marked)
     DevBuf d_campart, d_ccstart, d_ccitems;  // per (work item, free camera) sums of schur_fused<3, true> and the per-camera lists of them
     bool state_fresh = false;                // the device state is the uploaded initial one (no solve since the hand-over)
+    bool blk_built = true;                   // the camera-pair block entries of the current problem set exist on the device (see ba_sets_will_run)
     bool cam_sums_ok = false;                // every observation of a free camera belongs to a work item with pairs (no constant point seen by a free camera)
     snk_ba_options opt{};
     int count = 0;
@@ -4625,6 +4626,18 @@ struct Launcher
     }
 };
 #define LAUNCH(...) L(__LINE__, __VA_ARGS__)
+
+// Will the LM sequence of this problem set run the point-major kernels (schur_fused / schur_mfma + update_cost over the camera-set work
+// items)?  Decided by the hand-over's results and by switches that are read once per process: the hand-over asks too, because the
+// camera-pair block entries are only read by the block-major pass (schur_pass) -- building them for a 1024-window batch that never
+// runs it was 1.4 ms of device time behind every hand-over (block_entries_count 0.40 + block_entries_fill 1.03 ms, round 6 trace).
+static bool ba_sets_will_run(const snk_ba* h)
+{
+    static const bool no_wave       = getenv("SNK_BA_NO_POINT_WAVE") != nullptr;
+    static const bool no_set        = getenv("SNK_BA_NO_SCHUR_SET") != nullptr;
+    static const long long set_min  = getenv("SNK_BA_SCHUR_SET_MIN_ITEMS") ? atoll(getenv("SNK_BA_SCHUR_SET_MIN_ITEMS")) : 256;
+    return h->max_nfc > 0 && h->point_wave_ok && !no_wave && h->set_ok && !no_set && (long long)h->max_set_items * h->count >= set_min;
+}
 
 extern "C" {
 
@@ -5960,7 +5973,11 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
         hipLaunchKernelGGL(gather_set_records, dim3(max_set_items, count), dim3(256), 0, st, A, h->d_setobs.as<SetObs>());
         SNK_LAUNCH_CHECK();
     }
-    if (dev_entries)
+    // batches that will run the point-major kernels never read the block entries (SNK_BA_CHECK_LISTS=1 builds and checks them anyway)
+    static const bool check_lists_be = getenv("SNK_BA_CHECK_LISTS") != nullptr;
+    const bool skip_entries = dev_entries && count >= 16 && ba_sets_will_run(h) && !check_lists_be;
+    h->blk_built = !skip_entries;
+    if (dev_entries && !skip_entries)
     {
         if (max_be_waves > 0)
         {
@@ -6148,12 +6165,17 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L, bool only_marked =
     for (int it = 0; it < iterations; ++it)
     {
         static const bool no_wave = getenv("SNK_BA_NO_POINT_WAVE") != nullptr;
-        static const bool no_set = getenv("SNK_BA_NO_SCHUR_SET") != nullptr;  // A/B measurements
-        // a single small window has too few work items to fill the chip: the block-major pass is quicker there
-        static const long long set_min = getenv("SNK_BA_SCHUR_SET_MIN_ITEMS") ? atoll(getenv("SNK_BA_SCHUR_SET_MIN_ITEMS")) : 256;  // tests: 1
+        // (SNK_BA_NO_SCHUR_SET, SNK_BA_SCHUR_SET_MIN_ITEMS: ba_sets_will_run -- a single small window has too few work items to fill the
+        // chip, the block-major pass is quicker there)
         static const bool no_mfma  = getenv("SNK_BA_NO_SCHUR_MFMA") != nullptr;   // A/B: the vector-ALU form (schur_set)
         static const bool no_fused = getenv("SNK_BA_NO_SCHUR_FUSED") != nullptr;  // A/B: point_wave + schur_mfma through W in HBM
-        const bool use_set = h->max_nfc > 0 && h->point_wave_ok && !no_wave && h->set_ok && !no_set && (long long)h->max_set_items * B >= set_min;
+        // (the whole batch decides, not the range of a chain: the hand-over left out the block entries on the same answer)
+        const bool use_set = ba_sets_will_run(h);
+        if (!use_set && !h->blk_built)
+        {
+            set_error("bundle adjustment: the block-major pass was chosen but the hand-over did not build its lists (internal)");
+            return SNK_ERR_HIP;
+        }
         // points with 9 or 10 free observations need a fourth tile row: 260 registers, one wavefront per SIMD -- there the
         // linearisation stays in point_wave and schur_mfma<4> reads W (measured on the 300-keyframe global BA: 14.7 vs 15.5 ms);
         // SNK_BA_FUSED_K10=1 forces the fused form (tests)
