@@ -3973,7 +3973,7 @@ __global__ __launch_bounds__(128) void update_pass(Arrays A, int images_only)
 }
 
 constexpr int ACC_THREADS = 256;
-__global__ __launch_bounds__(ACC_THREADS) void accept_pass(Arrays A, int only_marked)
+__global__ __launch_bounds__(ACC_THREADS) void accept_pass(Arrays A, int only_marked, int no_copy)
 {
     __shared__ double red[ACC_THREADS];
     __shared__ int s_acc;
@@ -4054,7 +4054,7 @@ __global__ __launch_bounds__(ACC_THREADS) void accept_pass(Arrays A, int only_ma
         s_acc = acc;
     }
     __syncthreads();
-    if (!s_acc) return;
+    if (!s_acc || no_copy) return;  // no_copy: accept_copy follows (big single problems: the copy on many workgroups)
     {
         // eight loads in flight per thread (one at a time the 6000 doubles of a window's points were 24 dependent round trips)
         const double* src = A.pt_new + (size_t)pr.pt_off * 3;
@@ -4080,6 +4080,24 @@ __global__ __launch_bounds__(ACC_THREADS) void accept_pass(Arrays A, int only_ma
         }
     }
     for (int k = tid; k < pr.ni * 7; k += ACC_THREADS) A.pose[(size_t)pr.img_off * 7 + k] = A.pose_new[(size_t)pr.img_off * 7 + k];
+}
+
+// The accepted state of a BIG problem copied by many workgroups (a global scene: 15 000 points + 300 poses = 377 KB read and written;
+// on accept_pass's one workgroup that was most of its 41 us -- one compute unit's worth of memory requests in flight).
+__global__ __launch_bounds__(256) void accept_copy(Arrays A, int only_marked)
+{
+    const int pb = blockIdx.y;
+    if (only_marked && A.state[pb].marked == 0) return;
+    if (!A.state[pb].accepted) return;
+    const Prob pr = A.prob[pb];
+    const int n_pt = pr.np * 3, n = n_pt + pr.ni * 7;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256)
+    {
+        if (k < n_pt)
+            A.pt[(size_t)pr.pt_off * 3 + k] = A.pt_new[(size_t)pr.pt_off * 3 + k];
+        else
+            A.pose[(size_t)pr.img_off * 7 + (k - n_pt)] = A.pose_new[(size_t)pr.img_off * 7 + (k - n_pt)];
+    }
 }
 
 __global__ void begin_solve(State* st, int n, double lambda_init, int only_marked)
@@ -6321,7 +6339,10 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L, bool only_marked =
             LAUNCH(point_pass<1>, gpt, dim3(128), 0, A, O);
         }
         if (h->max_rpc > 0 && h->max_nfc > 0) LAUNCH(rpc_pass, dim3(ceil_div(h->max_rpc, 64), B), dim3(64), 0, A, 1);
-        LAUNCH(accept_pass, dim3(B), dim3(ACC_THREADS), 0, A, cond);
+        // big problems in small numbers: the copy of the accepted state on its own workgroups (one workgroup per problem otherwise)
+        const bool split_copy = B <= 4 && h->max_np >= 4096;
+        LAUNCH(accept_pass, dim3(B), dim3(ACC_THREADS), 0, A, cond, split_copy ? 1 : 0);
+        if (split_copy) LAUNCH(accept_copy, dim3(std::min(128, ceil_div(h->max_np * 3 + h->max_ni * 7, 512)), B), dim3(256), 0, A, cond);
     }
     }  // chain
     if (L.err != hipSuccess)
