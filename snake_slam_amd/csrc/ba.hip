@@ -4179,6 +4179,7 @@ struct BaLists
 // The host threads of a batch hand-over, kept by the handle (round 6, late).  snk_ba_set_problems runs seven threaded passes over the
 // problems of a batch; with std::thread created and joined per pass that was 7 x 31 creations (~20 us each, issued one after the
 // other) inside a 22 ms hand-over.  Workers park on a condition variable between passes and end with the handle.
+constexpr int BA_FILL_CHUNKS = 4;   // chunks of problems the fill pass of a batch hand-over runs (and uploads) in
 struct HostPool
 {
     std::vector<std::thread> th;
@@ -5046,7 +5047,8 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
     // Everything sent here is final: the fill pass writes it in place and nothing below touches it.  o_cam, o_ptfree, o_pt and cam_items
     // are derived on the device (derive_obs_fields, derive_cam_items): reserved, not sent.
     const bool early_upload = count >= 16;
-    const int n_chunks      = early_upload && count >= 64 ? 4 : 1;
+    static const int chunks_env = getenv("SNK_BA_FILL_CHUNKS") ? atoi(getenv("SNK_BA_FILL_CHUNKS")) : 0;  // A/B
+    const int n_chunks      = early_upload && count >= 64 ? (chunks_env > 0 ? std::min(chunks_env, count / 16) : BA_FILL_CHUNKS) : 1;
     if (early_upload)
     {
         int rcE;
