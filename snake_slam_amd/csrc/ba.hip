@@ -3973,7 +3973,8 @@ __global__ __launch_bounds__(128) void update_pass(Arrays A, int images_only)
 }
 
 constexpr int ACC_THREADS = 256;
-__global__ __launch_bounds__(ACC_THREADS) void accept_pass(Arrays A, int only_marked, int no_copy)
+constexpr int ACC_TILE    = ACC_THREADS * 14;  // entries of each cost array per LDS tile of accept_pass's tiled sums (2 x 28 KB: under the 64 KB a launch gets without asking)
+__global__ __launch_bounds__(ACC_THREADS) void accept_pass(Arrays A, int only_marked, int no_copy, int tiled /* launched with 2 * ACC_TILE doubles of LDS */)
 {
     __shared__ double red[ACC_THREADS];
     __shared__ int s_acc;
@@ -3985,25 +3986,41 @@ __global__ __launch_bounds__(ACC_THREADS) void accept_pass(Arrays A, int only_ma
     const int chunk = (pr.np + ACC_THREADS - 1) / ACC_THREADS;
     double c0 = 0.0, c1 = 0.0;
     int k_from = 0;
-    // big problems (a global scene: 15 000 points, 59 per thread): sixteen loads of each array in flight -- with four, the sums were 15
-    // dependent round trips of this kernel's 42 us on ONE workgroup, 5 % of a FullBA(4).  Same additions in the same order.
-    for (; k_from + 16 <= chunk; k_from += 16)
+    if (tiled)
     {
-        double a[16], b[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
+        // Big problems (a global scene: 15 000 points, 59 per thread).  A thread's chunk is contiguous, so the direct loads below are
+        // strided across the lanes -- 64 cache lines per load instruction, and all of it on ONE compute unit: 28 us of sums.  Here the
+        // workgroup loads both arrays tile by tile, coalesced (the next tile's loads in flight meanwhile), and every thread adds the
+        // entries of its chunk that lie in the tile out of LDS -- the same additions in the same order.
+        extern __shared__ __attribute__((aligned(16))) double acc_tile[];
+        double* ta = acc_tile, *tb = acc_tile + ACC_TILE;
+        const int lo = tid * chunk, hi = min(lo + chunk, pr.np);
+        double va[ACC_TILE / ACC_THREADS], vb[ACC_TILE / ACC_THREADS];
+        auto fetch = [&](int t0)
         {
-            const int p   = tid * chunk + k_from + u;
-            const bool ok = p < pr.np;
-            a[u]          = ok ? A.cost_pt[pr.pt_off + p] : 0.0;
-            b[u]          = ok ? A.cost_pt_new[pr.pt_off + p] : 0.0;
-        }
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
+            for (int u = 0; u < ACC_TILE / ACC_THREADS; ++u)
+            {
+                const int p = t0 + u * ACC_THREADS + tid;
+                va[u]       = p < pr.np ? A.cost_pt[pr.pt_off + p] : 0.0;
+                vb[u]       = p < pr.np ? A.cost_pt_new[pr.pt_off + p] : 0.0;
+            }
+        };
+        fetch(0);
+        for (int t0 = 0; t0 < pr.np; t0 += ACC_TILE)
         {
-            c0 += a[u];
-            c1 += b[u];
+            __syncthreads();  // the previous tile's readers are done
+#pragma unroll
+            for (int u = 0; u < ACC_TILE / ACC_THREADS; ++u) ta[u * ACC_THREADS + tid] = va[u], tb[u * ACC_THREADS + tid] = vb[u];
+            __syncthreads();
+            if (t0 + ACC_TILE < pr.np) fetch(t0 + ACC_TILE);
+            for (int p = max(lo, t0); p < min(hi, t0 + ACC_TILE); ++p)
+            {
+                c0 += ta[p - t0];
+                c1 += tb[p - t0];
+            }
         }
+        k_from = chunk;  // nothing left for the direct loop
     }
     for (int k0 = k_from; k0 < chunk; k0 += 4)  // four loads of each array in flight, added in index order (one at a time: `chunk` dependent round trips)
     {
@@ -6343,7 +6360,7 @@ static int enqueue_lm(snk_ba* h, int iterations, Launcher& L, bool only_marked =
         if (h->max_rpc > 0 && h->max_nfc > 0) LAUNCH(rpc_pass, dim3(ceil_div(h->max_rpc, 64), B), dim3(64), 0, A, 1);
         // big problems in small numbers: the copy of the accepted state on its own workgroups (one workgroup per problem otherwise)
         const bool split_copy = B <= 4 && h->max_np >= 4096;
-        LAUNCH(accept_pass, dim3(B), dim3(ACC_THREADS), 0, A, cond, split_copy ? 1 : 0);
+        LAUNCH(accept_pass, dim3(B), dim3(ACC_THREADS), split_copy ? 2 * ACC_TILE * sizeof(double) : 0, A, cond, split_copy ? 1 : 0, split_copy ? 1 : 0);
         if (split_copy) LAUNCH(accept_copy, dim3(std::min(128, ceil_div(h->max_np * 3 + h->max_ni * 7, 512)), B), dim3(256), 0, A, cond);
     }
     }  // chain
