@@ -3655,7 +3655,7 @@ __device__ __forceinline__ double wave_sum64_valu(double v)
 // p it has just formed itself: no LDS read, no barrier in front of the product.  The R row sums are reduced by a transpose-and-add
 // over the wavefront (vector ALU only) and a four-way sum through LDS; LDS otherwise holds the copies of p and r other threads read.
 // Same algorithm, same grid barrier and buffers as pcgl_persist1; the sums run in this kernel's own fixed order.  16 rows per
-// workgroup above 1024 unknowns: barrier and exchange grow with the workgroups (113 instead of 225 for 300 keyframes: 5.2 instead of
+// workgroup above 512 unknowns: barrier and exchange grow with the workgroups (113 instead of 225 for 300 keyframes: 5.2 instead of
 // 7.8 us of an iteration).  Bigger systems keep pcgl_persist1 (SNK_BA_PERSIST_STREAM=1: always).
 // Measured per iteration, 300 keyframes (SNK_BA_PCG_TIMING=1): product + row sums 1.2, barrier 3.4, A p exchange 1.8, preconditioner +
 // r.r / r.z 0.7 us = 7.1 (pcgl_persist1: 15.3).  Also built and dropped: no barrier at all, exchange buffers whose entries validate
@@ -5858,10 +5858,10 @@ int snk_ba_set_problems(snk_ba* h, const snk_ba_problem* problems, int count)
                         resident >= 1 && resident * prop.multiProcessorCount >= W.persist_wgs)
                         W.persist_one = 1;
                     // ... and with S in registers when the system is small enough (8 rows x 2048 columns per workgroup, one workgroup per 8 rows)
-                    // 16 rows per workgroup above 1024 unknowns (the barrier and the exchange of A p grow with the workgroups: 225 against 113
-                    // for 300 keyframes), 8 below; SNK_BA_PERSIST_REG_ROWS / _THREADS: A/B
+                    // 16 rows per workgroup above 512 unknowns (the barrier and the exchange of A p grow with the workgroups: 225 against 113
+                    // for 300 keyframes: 9.4 -> 7.1 us per PCG iteration; 90 against 45 for 120 keyframes: 6.45 -> 5.7), 8 below; SNK_BA_PERSIST_REG_ROWS / _THREADS: A/B
                     static const int rows_env = snk_env_int("SNK_BA_PERSIST_REG_ROWS", 0);
-                    const int reg_rows     = rows_env == 8 || rows_env == 16 ? rows_env : (max_n6 > 1024 ? 16 : 8);
+                    const int reg_rows     = rows_env == 8 || rows_env == 16 ? rows_env : (max_n6 > 512 ? 16 : 8);
                     const void* reg_kernel = persist_reg_kernel(reg_rows);
                     const int wgs_reg = ceil_div(std::max(max_n6, 1), reg_rows);
                     if (W.persist_one == 1 && max_n6 <= PREG_MAX_N6 && getenv("SNK_BA_PERSIST_STREAM") == nullptr && getenv("SNK_BA_PERSIST_WGS") == nullptr &&

@@ -176,11 +176,11 @@ def test_global_ba_scale_and_pose_only(orc):
     assert np.array_equal(pt, sc2["pt"]) and cf < ci
 
 
-@pytest.mark.parametrize("n_kf", [26, 150, 172, 173, 342, 343])
+@pytest.mark.parametrize("n_kf", [26, 86, 87, 150, 172, 173, 342, 343])
 def test_global_ba_register_pcg_boundary_sizes(orc, n_kf):
     """The one-launch PCG with the rows of S in registers (pcgl_persist_reg) at the sizes where its form changes:
-    just above one workgroup's PCG (25 free cameras, 19 workgroups of 8 rows), n6 = 894 (8 rows), 1026 (the first size with 16 rows
-    per workgroup; 1032 has a full last workgroup), 2046 (the largest system it takes, last workgroup 14 rows) and 2052 (back to the
+    just above one workgroup's PCG (25 free cameras, 19 workgroups of 8 rows), n6 = 510 / 516 (the last size with 8 and the first with 16
+    rows per workgroup), 894, 1026, 1032, 2046 (the largest system it takes, last workgroup 14 rows) and 2052 (back to the
     streaming pcgl_persist1).  Same tolerance against the oracle as every global scene.  Match: GlobalBundleAdjustment.cpp:32-43."""
     from snake_slam_amd import synth
 

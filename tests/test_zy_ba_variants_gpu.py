@@ -39,7 +39,7 @@ ROOT = Path(__file__).resolve().parent.parent
     {"SNK_BA_NO_SCHUR_WIDE": "1", "SNK_BA_NO_SCHUR_SET": "1"},          # block-major schur_pass with one wavefront per block also for single windows
     {"SNK_BA_PCGL_LAUNCHES": "1"},                                      # global scenes: the multi-launch PCG (pcgl_matvec / combine / update / direction / latch) instead of the one cooperative launch (pcgl_persist)
     {"SNK_BA_PERSIST_STREAM": "1"},                                     # global scenes: the one-barrier PCG streaming its rows of S in every iteration (pcgl_persist1) instead of holding them in registers (pcgl_persist_reg)
-    {"SNK_BA_PERSIST_REG_ROWS": "16"},                                  # global scenes: 16 rows of S per workgroup in pcgl_persist_reg also below 1024 unknowns (default there: 8)
+    {"SNK_BA_PERSIST_REG_ROWS": "16"},                                  # global scenes: 16 rows of S per workgroup in pcgl_persist_reg also below 512 unknowns (default there: 8)
     {"SNK_BA_PERSIST_TWO_BARRIERS": "1"},                               # global scenes: the two-barrier persistent PCG of round 5 (pcgl_persist) instead of the one-barrier form (pcgl_persist1)
     {"SNK_BA_FLAT_BARRIER": "1"},                                       # global scenes: the flat grid barrier of round 5 (every workgroup polls every flag) instead of the two-level one
     {"SNK_BA_GRAPH_CHAINS": "2", "SNK_BA_GRAPH_FIRST": "1"},            # batches of >= 128 windows recorded as two graph branches over disjoint window ranges (measured +1 % with 2, -6 % with 4: not the default)
