@@ -538,3 +538,37 @@ def test_big_batch_of_unequal_scenes(orc):
         if kind == "truncated":
             truncated.append(k)
     assert len(truncated) <= 12, truncated  # 3 .. 6 of 300 measured, depending on the path
+
+
+def test_hand_over_threads_end_with_the_handle(orc):
+    """The host threads that build the lists of a batch hand-over are parked in the handle between hand-overs (HostPool in
+    csrc/ba.hip) -- they must not outlive it, and repeated hand-overs must not add more.  Linux: /proc/self/status."""
+    from snake_slam_amd import synth
+    from snake_slam_amd.ba import BARec, lba_options
+
+    def n_threads():
+        for line in open("/proc/self/status"):
+            if line.startswith("Threads:"):
+                return int(line.split()[1])
+        return -1
+
+    scenes = [synth.ba_scene(n_kf=5 + k % 3, n_pt=90 + 11 * k, obs_per_pt=4, seed=300 + k)[0] for k in range(32)]
+    warm = BARec(lba_options(max_iterations=1, max_pcg_iterations=10))  # runtime threads of the first use of the device
+    warm.create(scenes[:1])
+    warm.initAndSolve()
+    warm.close()
+    before = n_threads()
+    ba = BARec(lba_options(max_iterations=2, max_pcg_iterations=30))
+    ba.create(scenes)
+    during = n_threads()
+    for _ in range(3):
+        ba.create(scenes)
+    assert n_threads() == during
+    ci, cf = ba.initAndSolve()
+    k = 17
+    wpose, wpt, wci, wcf, _ = orc.ba_solve(scenes[k], orc.ba_options(2, 30))
+    pose, pt, _ = ba.state(k)
+    assert rmse(pose, wpose) <= TOL and rmse(pt, wpt) <= TOL
+    ba.close()
+    assert during > before, "a batch of 32 scenes is expected to use the threaded list builder"
+    assert n_threads() <= before
