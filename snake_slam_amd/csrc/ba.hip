@@ -3473,6 +3473,19 @@ __global__ __launch_bounds__(PERSIST_THREADS) void pcgl_persist(Arrays A, Opt O,
     if (wg == 0 && tid == 0) A.state[0].pcg_iters += iters;
 }
 
+// sum over the 64 lanes on the vector ALU only (permlane swaps + DPP moves; every lane gets the same bits): the __shfl_xor butterfly goes
+// through the LDS crossbar, ~100 cycles per dependent step
+__device__ __forceinline__ double wave_sum64_valu(double v)
+{
+    v = swap_add32(v, v);
+    v = swap_add16(v, v);
+    v += dpp_mov64<0x128>(v);  // row_ror:8
+    v += dpp_mov64<0x141>(v);  // row_half_mirror
+    v += dpp_mov64<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov64<0xB1>(v);   // quad_perm [1,0,3,2]
+    return v;
+}
+
 // The same PCG with ONE grid barrier per iteration (round 6).  Of the two reductions of an iteration only p.Ap needs every workgroup's
 // rows; r.r and r.z of the next iteration are functions of r - alpha A p, which every workgroup can form for ALL n6 entries itself once
 // A p is known: 6 x 6 blocks against 299 cameras are ~11 k multiply-adds, a microsecond, against the ~6 us of a barrier.  So every
@@ -3499,11 +3512,24 @@ __global__ __launch_bounds__(PERSIST_THREADS) void pcgl_persist1(Arrays A, Opt O
     const int rpw   = (n6 + NW - 1) / NW;
     const int q0    = min(wg * rpw, n6), q1 = min(q0 + rpw, n6);
     unsigned phase = 0;
-    // block-wide sums of two values per thread, every thread gets both (fixed order: wavefront butterflies, then the four wavefronts)
+    // The six preconditioner values of the thread's own entries u = tid + 256 j in registers for the launch (up to 4096 unknowns; round 6,
+    // late: 42-84 L2 loads per thread and iteration before, beside a workgroup that is alone on its compute unit and has 512 registers
+    // per lane); bigger systems read them from memory as before.
+    constexpr int MK = 16;
+    const bool m_regs = n6 <= MK * PERSIST_THREADS;  // grid-uniform
+    double mrow[MK][6];
+#pragma unroll
+    for (int j = 0; j < MK; ++j)
+    {
+        const int u = tid + PERSIST_THREADS * j;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) mrow[j][b] = m_regs && u < n6 ? W.Minv[(size_t)pr.cam_off * 36 + (size_t)u * 6 + b] : 0.0;
+    }
+    // block-wide sums of two values per thread, every thread gets both (fixed order: wavefront trees, then the four wavefronts)
     auto block_sum2 = [&](double a, double b, double& sa, double& sb)
     {
-        a = wave_sum64(a);
-        b = wave_sum64(b);
+        a = wave_sum64_valu(a);
+        b = wave_sum64_valu(b);
         __syncthreads();  // the previous round's readers are done
         if (lane == 0) sh_red[0][wave] = a, sh_red[1][wave] = b;
         __syncthreads();
@@ -3589,8 +3615,8 @@ __global__ __launch_bounds__(PERSIST_THREADS) void pcgl_persist1(Arrays A, Opt O
                 const double2* rb = reinterpret_cast<const double2*>(S + (size_t)(two ? qb : q) * n6);
                 double acc_a = 0.0, acc_b = 0.0;
                 row_dot(ra, rb, acc_a, acc_b);
-                acc_a = wave_sum64(acc_a);
-                acc_b = wave_sum64(acc_b);
+                acc_a = wave_sum64_valu(acc_a);
+                acc_b = wave_sum64_valu(acc_b);
                 if (lane == 0)
                 {
                     Ap[q] = acc_a;
@@ -3607,13 +3633,60 @@ __global__ __launch_bounds__(PERSIST_THREADS) void pcgl_persist1(Arrays A, Opt O
             if (tid == 0) wpap[wg] = (sh_red[0][0] + sh_red[0][1]) + (sh_red[0][2] + sh_red[0][3]);
         }
         grid_barrier(W.bar, NW, phase, W.bar_flat);
-        const double pAp = sum_partials_wave(wpap, NW, lane);
+        // A p of the other workgroups comes from the memory side (~2 us): the first 16 entries per thread are requested BEFORE p.Ap is
+        // summed, whose own loads and the break below would otherwise stand in front of them as a second round trip
+        double apv[MK];
+#pragma unroll
+        for (int j = 0; j < MK; ++j)
+        {
+            const int u = tid + PERSIST_THREADS * j;
+            apv[j]      = u < n6 ? Ap[u] : 0.0;
+        }
+        double pAp = 0.0;
+        for (int i = lane; i < NW; i += 64) pAp += wpap[i];
+        pAp = wave_sum64_valu(pAp);
         if (pAp <= 0.0) break;  // grid-uniform (the reference's break: the step of this iteration is not applied)
         const double alpha = rz_cur / pAp;
-        for (int u = tid; u < n6; u += PERSIST_THREADS) sh_r[u] -= alpha * Ap[u];
+#pragma unroll
+        for (int j = 0; j < MK; ++j)
+        {
+            const int u = tid + PERSIST_THREADS * j;
+            if (u < n6) sh_r[u] -= alpha * apv[j];
+        }
+        for (int u = tid + MK * PERSIST_THREADS; u < n6; u += PERSIST_THREADS) sh_r[u] -= alpha * Ap[u];
         for (int q = q0 + tid; q < q1; q += PERSIST_THREADS) A.x[q] += alpha * sh_p[q];  // the rows' owner keeps the solution
         __syncthreads();
         double a = 0.0, b = 0.0;
+        if (m_regs)
+        {
+            // all reads of r in front of the stores of z (one LDS array: the compiler keeps their order entry by entry otherwise); the
+            // same six products in the same order as the loop below
+            double zz[MK];
+#pragma unroll
+            for (int j = 0; j < MK; ++j)
+            {
+                const int u = min(tid + PERSIST_THREADS * j, n6 - 1);
+                const double2* rc = reinterpret_cast<const double2*>(sh_r + (u / 6) * 6);  // the camera's six entries: 48 bytes, 16-byte aligned
+                const double2 r01 = rc[0], r23 = rc[1], r45 = rc[2];
+                double t = 0.0;
+                t += mrow[j][0] * r01.x; t += mrow[j][1] * r01.y; t += mrow[j][2] * r23.x;
+                t += mrow[j][3] * r23.y; t += mrow[j][4] * r45.x; t += mrow[j][5] * r45.y;
+                zz[j] = t;
+            }
+#pragma unroll
+            for (int j = 0; j < MK; ++j)
+            {
+                const int u = tid + PERSIST_THREADS * j;
+                if (u < n6)
+                {
+                    const double rv = sh_r[u];
+                    sh_z[u] = zz[j];
+                    a += rv * rv;
+                    b += rv * zz[j];
+                }
+            }
+        }
+        else
         for (int u = tid; u < n6; u += PERSIST_THREADS)
         {
             const int c = u / 6, ar = u - c * 6;
@@ -3633,18 +3706,6 @@ __global__ __launch_bounds__(PERSIST_THREADS) void pcgl_persist1(Arrays A, Opt O
     if (wg == 0 && tid == 0) A.state[0].pcg_iters += iters;
 }
 
-// sum over the 64 lanes on the vector ALU only (permlane swaps + DPP moves; every lane gets the same bits): the __shfl_xor butterfly goes
-// through the LDS crossbar, ~100 cycles per dependent step
-__device__ __forceinline__ double wave_sum64_valu(double v)
-{
-    v = swap_add32(v, v);
-    v = swap_add16(v, v);
-    v += dpp_mov64<0x128>(v);  // row_ror:8
-    v += dpp_mov64<0x141>(v);  // row_half_mirror
-    v += dpp_mov64<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp_mov64<0xB1>(v);   // quad_perm [1,0,3,2]
-    return v;
-}
 // The one-barrier PCG with the workgroup's rows of S held in REGISTERS for the whole launch (round 6, late).  A launch runs up to
 // max_pcg (40) iterations on the same S: pcgl_persist1 streamed its dozen rows per workgroup out of the Infinity Cache in every one of
 // them (~2.7 us of a 15 us iteration, 25.9 MB per iteration for 300 keyframes).  A workgroup is alone on its compute unit (one
