@@ -1,6 +1,8 @@
 """GPU: HIP local BA vs the CPU oracle through the C ABI.  Tolerance (north_star): pose / point
 RMSE <= 1e-5 against the CPU restatement (fp64 on both sides; only summation orders differ)."""
 import numpy as np
+import os
+
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -570,5 +572,6 @@ def test_hand_over_threads_end_with_the_handle(orc):
     pose, pt, _ = ba.state(k)
     assert rmse(pose, wpose) <= TOL and rmse(pt, wpt) <= TOL
     ba.close()
-    assert during > before, "a batch of 32 scenes is expected to use the threaded list builder"
+    if "SNK_BA_NO_HOST_POOL" not in os.environ:  # (the variants matrix runs this file with threads created and joined per pass as well)
+        assert during > before, "a batch of 32 scenes is expected to use the threaded list builder"
     assert n_threads() <= before
